@@ -1,0 +1,232 @@
+"""Stage-by-stage float64 restatement of the Hensman GP block and its hand-derived
+reverse pass, cut exactly where the HIP kernels are cut (svgp-vae_amd/csrc).
+
+TEST INFRASTRUCTURE ONLY (see oracle/svgpvae_oracle.py header; parity unpinned).
+Each stage names the HIP entry point it checks.  The backward formulas are validated
+against torch.autograd of `svgpvae_oracle.gp_block_efficient` in tests/test_oracle_kat.py.
+
+Math: SURVEY.md Appendix A / I; reference lines SVGPVAE_model.py:220-343 (GP block),
+:427-476 (kernel), :880-902 (assembly), utils.py:483-504 (cross entropy).
+"""
+import math
+
+import torch
+
+from .svgpvae_oracle import DT, LOG_2PI, reciprocal_no_nan
+
+
+# ------------------------------------------------------------------ kernel matrices
+def kernel_matrix_fwd(aux, ip, ov, ls, amp, normalize=False):
+    """svgp_kernel_matrix_fwd: K_mm (m,m), K_nm (b,m), k_nn (b).  aux (b,2+M) batch rows
+    [id, angle, pca...]; ip (m,2+M) inducing rows; ov (n_obj,M) GPLVM table or None."""
+    th_n, th_m = aux[:, 1], ip[:, 1]
+    o_m = ip[:, 2:]
+    o_n = aux[:, 2:] if ov is None else ov[aux[:, 0].long()]
+    if normalize:
+        o_mh = o_m / torch.linalg.norm(o_m, dim=1, keepdim=True)
+        o_nh = o_n / torch.linalg.norm(o_n, dim=1, keepdim=True)
+    else:
+        o_mh, o_nh = o_m, o_n
+
+    def view(d):
+        s = torch.sin(0.5 * d)
+        return amp ** 2 * torch.exp(-2.0 * s * s / ls ** 2)
+
+    K = view(th_m[:, None] - th_m[None, :]) * (o_mh @ o_mh.T)
+    Kn = view(th_n[:, None] - th_m[None, :]) * (o_nh @ o_mh.T)
+    knn = amp ** 2 * torch.sum(o_nh * o_nh, dim=1)
+    return K, Kn, knn
+
+
+def kernel_matrix_bwd(aux, ip, ov, ls, amp, gK, gKn, gknn, normalize=False):
+    """svgp_kernel_matrix_bwd: VJP of kernel_matrix_fwd.  gK (m,m) is used as-is (not
+    symmetrised).  Returns d_ip (m,2+M) (id column zero), d_ls, d_amp, d_ov (n_obj,M) or None."""
+    m = ip.shape[0]
+    th_n, th_m = aux[:, 1], ip[:, 1]
+    o_m = ip[:, 2:]
+    ids = aux[:, 0].long()
+    o_n = aux[:, 2:] if ov is None else ov[ids]
+    nm = torch.linalg.norm(o_m, dim=1, keepdim=True)
+    nn_ = torch.linalg.norm(o_n, dim=1, keepdim=True)
+    o_mh, o_nh = (o_m / nm, o_n / nn_) if normalize else (o_m, o_n)
+    a2, l2 = amp ** 2, ls ** 2
+
+    def parts(d, oa, ob):
+        s = torch.sin(0.5 * d)
+        V = a2 * torch.exp(-2.0 * s * s / l2)     # view kernel
+        D = oa @ ob.T                             # object kernel
+        return V, D, torch.sin(d), s * s
+
+    # ---- K_mm (both arguments are inducing rows)
+    V, D, sd, s2h = parts(th_m[:, None] - th_m[None, :], o_mh, o_mh)
+    Kmat = V * D
+    GK = gK * Kmat
+    d_amp = 2.0 * GK.sum() / amp
+    d_ls = (GK * 4.0 * s2h).sum() / ls ** 3
+    T = GK * sd / l2
+    d_th = -T.sum(1) + T.sum(0)
+    GV = gK * V
+    dD_a = GV @ o_mh          # d/d(o_mh row i) from first argument
+    dD_b = GV.T @ o_mh        # second argument
+    d_omh = dD_a + dD_b
+    # ---- K_nm
+    Vn, Dn, sdn, s2hn = parts(th_n[:, None] - th_m[None, :], o_nh, o_mh)
+    Knm = Vn * Dn
+    GKn = gKn * Knm
+    d_amp = d_amp + 2.0 * GKn.sum() / amp
+    d_ls = d_ls + (GKn * 4.0 * s2hn).sum() / ls ** 3
+    d_th = d_th + (GKn * sdn / l2).sum(0)
+    GVn = gKn * Vn
+    d_omh = d_omh + GVn.T @ o_nh
+    d_onh = GVn @ o_mh
+    # ---- k_nn = a^2 |o_nh|^2
+    knn = a2 * torch.sum(o_nh * o_nh, dim=1)
+    d_amp = d_amp + 2.0 * (gknn * knn).sum() / amp
+    d_onh = d_onh + 2.0 * a2 * gknn[:, None] * o_nh
+    if normalize:  # o_h = o/|o|: d_o = (d_oh - <d_oh,o_h> o_h)/|o|
+        d_om = (d_omh - (d_omh * o_mh).sum(1, keepdim=True) * o_mh) / nm
+        d_on = (d_onh - (d_onh * o_nh).sum(1, keepdim=True) * o_nh) / nn_
+    else:
+        d_om, d_on = d_omh, d_onh
+    d_ip = torch.zeros_like(ip)
+    d_ip[:, 1] = d_th
+    d_ip[:, 2:] = d_om
+    d_ov = None
+    if ov is not None:
+        d_ov = torch.zeros_like(ov)
+        d_ov.index_add_(0, ids, d_on)
+    return d_ip, d_ls, d_amp, d_ov
+
+
+# ------------------------------------------------------------------ weighted statistics
+def gp_stats(Kn, w, a, bvec=None):
+    """svgp_gp_stats: S[l] = Kn^T diag(w[:,l]) Kn (L,m,m); v1[l] = Kn^T a[:,l]; v2[l] = Kn^T b[:,l].
+    Forward: w = p, a = p*y.  Backward: w = g_pv, a = mv_bar, b = c*g_pm.  These are the only
+    cross-row reductions of the block, i.e. the tensors all-reduced under data parallelism."""
+    S = torch.einsum('nl,ni,nj->lij', w, Kn, Kn)
+    v1 = torch.einsum('nl,ni->li', a, Kn)
+    v2 = None if bvec is None else torch.einsum('nl,ni->li', bvec, Kn)
+    return S, v1, v2
+
+
+# ------------------------------------------------------------------ m x m factor stage
+def gp_factor_fwd(K, S, v, jitter, c):
+    """svgp_gp_factor_fwd: shared Ki, ldK and per-channel Si, t, mu_hat, A_hat, G, Aji, u, KL."""
+    m = K.shape[0]
+    eye = torch.eye(m, dtype=DT)
+    Kj = K + jitter * eye
+    Ki = torch.linalg.inv(Kj)
+    ldK = 2 * torch.log(torch.diagonal(torch.linalg.cholesky(Kj))).sum()
+    Si = torch.linalg.inv(K[None] + c * S + jitter * eye[None])
+    t = torch.einsum('lij,lj->li', Si, v)
+    G = Si @ K[None]
+    A = K[None] @ G
+    mu = c * (t @ K.T)
+    u = mu @ Ki.T
+    Aj = A + jitter * eye[None]
+    Aji = torch.linalg.inv(Aj)
+    ldA = 2 * torch.log(torch.diagonal(torch.linalg.cholesky(Aj), dim1=-2, dim2=-1)).sum(-1)
+    KL = 0.5 * (ldK - ldA - m + torch.einsum('ij,lji->l', Ki, A) + (mu * u).sum(1))
+    return dict(Ki=Ki, ldK=ldK, Si=Si, t=t, G=G, A=A, mu=mu, u=u, Aji=Aji, ldA=ldA, KL=KL)
+
+
+# ------------------------------------------------------------------ per-sample stage
+def gp_posterior_fwd(Kn, knn, y, s2, eps, f, c):
+    """svgp_gp_posterior_hensman_fwd: per (n,l) posterior moments, L3/CE integrands, sample z."""
+    p = reciprocal_no_nan(s2)
+    W = Kn @ f['Ki']
+    q = (W * Kn).sum(1)
+    p_m = c * (Kn @ f['t'].T)
+    r = torch.einsum('ni,lij,nj->nl', Kn, f['Si'], Kn)
+    p_v = (knn - q)[:, None] + r
+    mv = Kn @ f['u'].T
+    s = torch.einsum('ni,lij,nj->nl', W, f['A'], W)
+    e = y - mv
+    d = (knn - q)[:, None] + s + e * e                       # L3 integrand (times p)
+    L3 = -0.5 * ((p * d).sum(0) + torch.log(s2).sum(0) + Kn.shape[0] * LOG_2PI)
+    ce = -0.5 * (LOG_2PI + torch.log(s2) + (p_v + (p_m - y) ** 2) * p)
+    z = p_m + eps * torch.sqrt(p_v)
+    return dict(p=p, W=W, q=q, p_m=p_m, p_v=p_v, mv=mv, e=e, d=d, L3=L3, CE=ce.sum(), z=z)
+
+
+# ------------------------------------------------------------------ backward stages
+def gp_posterior_bwd_weights(y, s2, eps, ps, zbar, gT, c):
+    """First half of svgp_gp_posterior_hensman_bwd (element-wise): upstream gradients of
+    p_m, p_v and the weights of the backward statistics.  gT = d loss / d KL_term."""
+    p = ps['p']
+    g3 = gT
+    g_pv = 0.5 * gT * p + zbar * eps / (2.0 * torch.sqrt(ps['p_v']))
+    g_pm = gT * p * (ps['p_m'] - y) + zbar
+    mvbar = g3 * p * ps['e']
+    return g_pv, g_pm, mvbar
+
+
+def gp_factor_bwd(K, S, v, f, A2, ud, td, gT, c, N_train, b_global):
+    """svgp_gp_factor_bwd: all m x m reverse algebra (identical on every rank once S, v, A2, ud, td
+    are the global sums).  Returns K_bar (m,m), and per channel P = 2 Si, Q = Ssym - g3 Ki A Ki,
+    v_bar, Ssym (for the per-sample stage)."""
+    L, m = v.shape
+    g3 = gT
+    gK = -gT * (b_global / N_train)
+    Ki, Si, A, G, Aji, mu, u, t = (f[k] for k in ('Ki', 'Si', 'A', 'G', 'Aji', 'mu', 'u', 't'))
+    KiSKi = Ki[None] @ S @ Ki[None]
+    Abar = -0.5 * g3 * KiSKi + 0.5 * gK * (Ki[None] - Aji)
+    ubar = ud + 0.5 * gK * mu
+    mubar = 0.5 * gK * u + ubar @ Ki.T
+    Kibar = 0.5 * gK * A.sum(0) + torch.einsum('li,lj->ij', ubar, mu)
+    Gbar = K[None] @ Abar
+    Kbar = (Abar @ G.transpose(1, 2)).sum(0) + (Si @ Gbar).sum(0)
+    Sibar = Gbar @ K[None] + A2
+    Kbar = Kbar + c * torch.einsum('li,lj->ij', mubar, t)
+    tbar = td + c * (mubar @ K.T)
+    Sibar = Sibar + torch.einsum('li,lj->lij', tbar, v)
+    vbar = torch.einsum('lij,lj->li', Si, tbar)
+    Sgbar = -(Si @ Sibar @ Si)
+    Kbar = Kbar + Sgbar.sum(0)
+    Sbar = c * Sgbar
+    Ssym = Sbar + Sbar.transpose(1, 2)
+    # Kn^T Wbar written through the all-reduced statistics
+    KnTWbar = (-g3) * (S @ Ki[None] @ A).sum(0) + (0.5 * g3 * S - A2).sum(0)
+    Kibar = Kibar + KnTWbar
+    Kbar = Kbar - Ki @ Kibar @ Ki + (0.5 * gK * L) * Ki
+    P = 2.0 * Si
+    Q = Ssym - g3 * (Ki[None] @ A @ Ki[None])
+    return dict(Kbar=Kbar, P=P, Q=Q, vbar=vbar, Ssym=Ssym)
+
+
+def gp_posterior_bwd_rows(Kn, knn, y, s2, ps, f, fb, g_pv, g_pm, mvbar, gT, c):
+    """Second half of svgp_gp_posterior_hensman_bwd: row-local gradients
+    Kn_bar (b,m), knn_bar (b), y_bar (b,L), s2_bar (b,L)."""
+    p = ps['p']
+    g3 = gT
+    qbar = (0.5 * g3 * p - g_pv).sum(1)
+    knnbar = -qbar
+    Mk = torch.einsum('nl,lij,nj->ni', g_pv, fb['P'], Kn) + torch.einsum('nl,lij,nj->ni', p, fb['Q'], Kn)
+    Knbar = (Mk + mvbar @ f['u'] + c * (g_pm @ f['t']) + (p * y) @ fb['vbar']
+             + 2.0 * qbar[:, None] * ps['W'])
+    kv = Kn @ fb['vbar'].T                                     # (b,L)
+    kSk = 0.5 * torch.einsum('ni,lij,nj->nl', Kn, fb['Ssym'], Kn)
+    pbar = -0.5 * g3 * ps['d'] + kSk + y * kv
+    ce_y = -gT * p * (ps['p_m'] - y)
+    ce_s2 = 0.5 * gT * (p - (ps['p_v'] + (ps['p_m'] - y) ** 2) * p * p)
+    ybar = ce_y - g3 * p * ps['e'] + p * kv
+    s2bar = ce_s2 - 0.5 * g3 * p - pbar * p * p
+    return Knbar, knnbar, ybar, s2bar
+
+
+def gp_block_manual(K, Kn, knn, y, s2, eps, zbar, gT, jitter, N_train, b_global=None):
+    """Whole block forward + hand-derived backward (single rank).  Returns forward dicts and
+    (K_bar, Kn_bar, knn_bar, y_bar, s2_bar)."""
+    b = Kn.shape[0]
+    bg = float(b if b_global is None else b_global)
+    c = N_train / bg
+    p = reciprocal_no_nan(s2)
+    S, v, _ = gp_stats(Kn, p, p * y)
+    f = gp_factor_fwd(K, S, v, jitter, c)
+    ps = gp_posterior_fwd(Kn, knn, y, s2, eps, f, c)
+    g_pv, g_pm, mvbar = gp_posterior_bwd_weights(y, s2, eps, ps, zbar, gT, c)
+    A2, ud, td = gp_stats(Kn, g_pv, mvbar, c * g_pm)
+    fb = gp_factor_bwd(K, S, v, f, A2, ud, td, gT, c, N_train, bg)
+    Knbar, knnbar, ybar, s2bar = gp_posterior_bwd_rows(Kn, knn, y, s2, ps, f, fb, g_pv, g_pm,
+                                                       mvbar, gT, c)
+    return f, ps, fb, (fb['Kbar'], Knbar, knnbar, ybar, s2bar)

@@ -236,7 +236,7 @@ def _conv2d_nhwc(x, w, bias, stride, padding):
         ph = max((math.ceil(H / stride) - 1) * stride + kh - H, 0)
         pw = max((math.ceil(Wd / stride) - 1) * stride + kw - Wd, 0)
         xin = F.pad(xin, (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2))
-    out = F.conv2d(xin, w.permute(3, 2, 0, 1), bias, stride=stride)
+    out = F.conv2d(xin.contiguous(), w.permute(3, 2, 0, 1).contiguous(), bias, stride=stride)
     return out.permute(0, 2, 3, 1)
 
 

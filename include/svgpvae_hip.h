@@ -1,0 +1,213 @@
+/*
+ * svgpvae_hip.h - C ABI of libsvgpvae_hip.so, the MI355X (gfx950) implementation of the
+ * SVGPVAE_Hensman training step of ratschlab/SVGP-VAE (rotated-MNIST path).
+ *
+ * The reference has no native/FFI layer (it is TensorFlow-1.15 graph code), so each entry point
+ * below cites the reference Python it replaces (file:line into the reference checkout) instead of
+ * a reference FFI declaration.  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions
+ *   - every function returns int: 0 = ok, <0 = svgp_status; svgp_last_error() gives a
+ *     thread-local message.  No C++ exception crosses the boundary.
+ *   - all tensor pointers are CALLER-OWNED DEVICE pointers (row-major, contiguous, float64);
+ *     nothing is retained after return.  Scratch lives in the caller-provided workspace whose
+ *     layout svgp_mnist_ws_layout() describes (offsets in float64 elements).
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it,
+ *     no hidden synchronisation, no allocation -> every call is hipGraph-capturable.
+ *   - per-step scalars (GECO state, Adam step, lr, beta, alpha) live in a small DEVICE state
+ *     vector (svgp_state_slot) so that a captured graph can be replayed unchanged.
+ *   - no global mutable state: re-entrant, usable from several threads on different streams.
+ */
+#ifndef SVGPVAE_HIP_H
+#define SVGPVAE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVGP_VERSION_MAJOR 0
+#define SVGP_VERSION_MINOR 1
+
+typedef enum {
+    SVGP_OK = 0,
+    SVGP_ERR_INVALID = -1,     /* bad argument / null pointer / inconsistent shapes            */
+    SVGP_ERR_UNSUPPORTED = -2, /* shape outside what this build implements (e.g. m > 64)       */
+    SVGP_ERR_HIP = -3          /* a HIP runtime call failed (message has hipGetErrorString)    */
+} svgp_status;
+
+/* Shapes + constants of one rank's share of a rotated-MNIST SVGPVAE step.
+ * Mirrors the constructor arguments of mnistSVGP (SVGPVAE_model.py:383-384), mnistVAE
+ * (VAE_utils.py:103) and the flags consumed by forward_pass_SVGPVAE (SVGPVAE_model.py:823-825). */
+typedef struct {
+    int32_t b;             /* rows of THIS rank's batch                                         */
+    int32_t b_global;      /* rows of the global batch (= b on one GPU); N_train/b_global is c  */
+    int32_t m;             /* number of inducing points (rows of inducing_index_points)         */
+    int32_t L;             /* latent channels (mnistVAE L)                                      */
+    int32_t M;             /* GPLVM / object-vector dimension (--M)                             */
+    int32_t n_obj;         /* rows of the object_vectors table; 0 = no table (aux cols 2: used) */
+    int32_t normalize_obj; /* K_obj_normalize (SVGPVAE_model.py:465-474)                        */
+    int32_t clip_qs;       /* clipping_qs: clip qnet_var to [1e-3, 10] (SVGPVAE_model.py:858)   */
+    int32_t geco;          /* GECO objective (SVGPVAE_model.py:908-915) else beta-ELBO (:917)   */
+    int32_t train_ip;      /* 1: inducing points trainable (--ip_joint)                         */
+    int32_t train_gp;      /* 1: l_GP, amplitude trainable (--GP_joint)                         */
+    int32_t train_ov;      /* 1: object_vectors trainable (--ov_joint)                          */
+    double  N_train;       /* mainSVGP.N_train                                                  */
+    double  jitter;        /* mainSVGP.jitter                                                   */
+    double  kappa_squared; /* GECO kappa^2                                                      */
+    double  alpha;         /* GECO moving-average alpha used from the 2nd step on               */
+    double  rep_weight;    /* weight of rank-replicated gradient terms: 1 on rank 0, else 0     */
+} svgp_mnist_cfg;
+
+/* Flat parameter vector theta (float64).  Offsets in elements.  Order = the reference's
+ * trainable-variable creation order: VAE encoder, decoder (VAE_utils.py:114-141), inducing points
+ * (SVGPVAE_model.py:203), l_GP, amplitude (:412-413), object_vectors (:421).  TF layouts:
+ * conv kernels (kh,kw,cin,cout), dense (in,out), NHWC flatten.                                  */
+typedef struct {
+    int64_t enc_c1_w, enc_c1_b, enc_c2_w, enc_c2_b, enc_c3_w, enc_c3_b, enc_d_w, enc_d_b;
+    int64_t dec_d_w, dec_d_b, dec_c1_w, dec_c1_b, dec_c2_w, dec_c2_b, dec_c3_w, dec_c3_b;
+    int64_t ip, l_GP, amplitude, ov;
+    int64_t n_enc;   /* number of encoder parameters (prefix of theta)       */
+    int64_t n_vae;   /* encoder + decoder                                     */
+    int64_t n_total; /* everything                                            */
+} svgp_mnist_param_layout;
+
+/* Workspace (float64) offsets of every intermediate of the step.  All are inspectable for tests. */
+typedef struct {
+    /* encoder (VAE_utils.py:114-126,143-152) */
+    int64_t enc_a1, enc_a2, enc_a3;       /* post-ELU activations (b,13,13,8) (b,6,6,8) (b,32)    */
+    int64_t qnet_mu, qnet_var_raw, qnet_var; /* (b,L) each; var = clip(exp(.))                    */
+    /* kernel matrices (SVGPVAE_model.py:427-476) */
+    int64_t K, Kn, knn;                   /* (m,m) (b,m) (b)                                      */
+    /* forward statistics: ONE contiguous all-reduce block [S | v] */
+    int64_t statA, statA_len, S, v;       /* S (L,m,m), v (L,m)                                   */
+    /* m x m factor stage (SVGPVAE_model.py:239,270-279,319-341) */
+    int64_t Ki, ldK, Si, t, G, A, Aji, mu_hat, u, M2, KL, q; /* M2 = Ki A Ki (L,m,m); q (b)       */
+    /* per-sample stage (:264-299,332-337, 888-902; utils.py:498-504) */
+    int64_t p_m, p_v, e, d, eps, z;       /* (b,L) each                                           */
+    /* decoder (VAE_utils.py:128-141,154-162) */
+    int64_t dec_h0, dec_a1, dec_a2, recon; /* (b,128) (b,8,8,8) (b,14,14,8) (b,28,28,1)           */
+    /* backward */
+    int64_t zbar, g_pv, g_pm, mvbar;      /* (b,L) each                                           */
+    int64_t statB, statB_len, A2, ud, td; /* ONE contiguous all-reduce block [A2 | ud | td]       */
+    int64_t Kbar, fb_part, Qm, vbar, Ssym; /* (m,m) (2,L,m,m) scratch (L,m,m) (L,m) (L,m,m)        */
+    int64_t Knbar_part;                   /* (L,b,m) per-channel row gradients before the sum     */
+    int64_t Knbar, knnbar, ybar, s2bar;   /* (b,m) (b) (b,L) (b,L)                                */
+    int64_t d_on;                         /* (b,M) gradient of gathered object rows               */
+    /* partial sums */
+    int64_t part_dec, part_enc, n_part;   /* (n_part, n_dec) / (n_part, n_enc) weight-grad partials */
+    int64_t part_gp;                      /* (m + n_rowblk, 2) amplitude / length-scale partials  */
+    int64_t part_sums, n_post;            /* (n_part,4) [.,.,recon sq,.] then (n_post,2) [L3 data, CE] */
+    /* final all-reduce block: [grad (n_total) | sums (8)] */
+    int64_t gradC, gradC_len, grad, sums;
+    int64_t total;                        /* workspace size in float64 elements                   */
+} svgp_mnist_ws_layout;
+
+/* Device state vector (float64[SVGP_STATE_LEN]); the host initialises slots 0..5, kernels keep
+ * them up to date (MNIST_experiment.py:313-355 host state machine moved on device).            */
+typedef enum {
+    SVGP_ST_C_MA = 0,        /* GECO moving average C_ma  (init 0.0, MNIST_experiment.py:314)    */
+    SVGP_ST_LAGRANGE = 1,    /* GECO lagrange multiplier  (init 1.0, :315)                       */
+    SVGP_ST_ALPHA = 2,       /* alpha used by the NEXT step (init 0.0 = first_step, :330-333)    */
+    SVGP_ST_ADAM_T = 3,      /* number of Adam updates done so far (global_step)                 */
+    SVGP_ST_LR = 4,          /* learning rate                                                    */
+    SVGP_ST_BETA = 5,        /* beta of the beta-ELBO                                            */
+    SVGP_ST_ELBO = 6,        /* outputs of the last step (the scalar members of the 16-tuple)    */
+    SVGP_ST_RECON_LOSS = 7,
+    SVGP_ST_KL_TERM = 8,
+    SVGP_ST_INSIDE_ELBO = 9,
+    SVGP_ST_CE_TERM = 10,
+    SVGP_ST_INSIDE_RECON = 11,
+    SVGP_ST_INSIDE_KL = 12,
+    SVGP_ST_RNG_CTR = 13,    /* counter of the on-device N(0,1) generator (bit pattern of u64)   */
+    SVGP_STATE_LEN = 16
+} svgp_state_slot;
+
+int         svgp_version(void);
+const char* svgp_last_error(void);
+
+int svgp_mnist_param_layout_get(const svgp_mnist_cfg* cfg, svgp_mnist_param_layout* out);
+int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* cfg, svgp_mnist_ws_layout* out);
+
+/* ---- stage entry points (each enqueues 1-2 kernels on `stream`) ----------------------------
+ * theta: flat parameters; ws: workspace; images (b,28,28,1); aux (b,2+M); state: device state.   */
+
+/* mnistVAE.encode + clip  (VAE_utils.py:143-152, SVGPVAE_model.py:854-859) */
+int svgp_mnist_encoder_fwd(const svgp_mnist_cfg*, const double* theta, const double* images,
+                           double* ws, void* stream);
+/* mnistSVGP.kernel_matrix x3: K_mm, K_nm, diag K_nn (SVGPVAE_model.py:427-476) */
+int svgp_kernel_matrix_fwd(const svgp_mnist_cfg*, const double* theta, const double* aux,
+                           double* ws, void* stream);
+/* S_l = K_mn diag(1/var_l) K_nm, v_l = K_mn (y_l/var_l)  (SVGPVAE_model.py:328-334) and, in the
+ * same launch, K_mm_inv / logdet (:239,270,273).  Output block statA is what DP all-reduces.     */
+int svgp_gp_stats_fwd(const svgp_mnist_cfg*, double* ws, void* stream);
+/* Sigma_l^-1, mu_hat, A_hat, KL_l (SVGPVAE_model.py:331-341, 270-279) */
+int svgp_gp_factor_fwd(const svgp_mnist_cfg*, double* ws, void* stream);
+/* posterior mean/var at the batch points, L3 / cross-entropy integrands, z = p_m + eps sqrt(p_v)
+ * (SVGPVAE_model.py:264-265,284-299,332-337,895-902).  eps (b,L) may be NULL: then N(0,1) numbers
+ * are drawn on device (Philox) as tf.random.normal does at :901.                                  */
+int svgp_gp_posterior_fwd(const svgp_mnist_cfg*, const double* eps, double* ws, double* state,
+                          void* stream);
+/* mnistVAE.decode + squared reconstruction error (VAE_utils.py:154-162, SVGPVAE_model.py:905-918) */
+int svgp_mnist_decoder_fwd(const svgp_mnist_cfg*, const double* theta, const double* images,
+                           double* ws, void* stream);
+/* reverse of the decoder; writes zbar and decoder weight-gradient partials */
+int svgp_mnist_decoder_bwd(const svgp_mnist_cfg*, const double* theta, const double* images,
+                           double* ws, const double* state, void* stream);
+/* upstream gradients of p_m, p_v + backward statistics block statB (DP all-reduces it) */
+int svgp_gp_stats_bwd(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+/* all m x m reverse algebra -> Kbar and the per-channel matrices of the row stage */
+int svgp_gp_factor_bwd(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+/* row-local gradients: Knbar, knnbar, ybar, s2bar */
+int svgp_gp_posterior_bwd(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+/* VJP of kernel_matrix: gradients of inducing points, l_GP, amplitude, object_vectors into grad */
+int svgp_kernel_matrix_bwd(const svgp_mnist_cfg*, const double* theta, const double* aux,
+                           double* ws, void* stream);
+/* reverse of the encoder (through exp and the clip mask); encoder weight-gradient partials */
+int svgp_mnist_encoder_bwd(const svgp_mnist_cfg*, const double* theta, const double* images,
+                           double* ws, void* stream);
+/* fixed-order reduction of all partials into the final block [grad | sums] (DP all-reduces it) */
+int svgp_mnist_grad_reduce(const svgp_mnist_cfg*, double* ws, void* stream);
+/* tf.train.AdamOptimizer.apply_gradients, TF1 formula (MNIST_experiment.py:200,207-208) */
+int svgp_adam_tf1_step(int64_t n, double* theta, const double* grad, double* adam_m, double* adam_v,
+                       const double* state, double beta1, double beta2, double epsilon, void* stream);
+/* scalar members of the 16-tuple + GECO state update + global_step (SVGPVAE_model.py:880-925,
+ * MNIST_experiment.py:334-355) */
+int svgp_elbo_finalize(const svgp_mnist_cfg*, double* ws, double* state, void* stream);
+/* same, but global_step is not advanced (forward/backward only, no optimiser update) */
+int svgp_elbo_finalize_noadam(const svgp_mnist_cfg*, double* ws, double* state, void* stream);
+
+/* ---- phases: the stages above grouped between the data-parallel exchange points -------------
+ * phase 0: encoder_fwd, kernel_matrix_fwd, gp_stats_fwd            -> all-reduce ws[statA]
+ * phase 1: gp_factor_fwd, gp_posterior_fwd, decoder_fwd, decoder_bwd, gp_stats_bwd
+ *                                                                   -> all-reduce ws[statB]
+ * phase 2: gp_factor_bwd, gp_posterior_bwd, kernel_matrix_bwd, encoder_bwd, grad_reduce
+ *                                                                   -> all-reduce ws[gradC]
+ * phase 3: adam_tf1_step (skipped when adam_m == NULL), elbo_finalize
+ * svgp_mnist_train_step runs phases 0..3 back to back (single GPU).                            */
+int svgp_mnist_step_phase(const svgp_mnist_cfg*, int phase, double* theta, const double* images,
+                          const double* aux, const double* eps, double* ws, double* state,
+                          double* adam_m, double* adam_v, void* stream);
+int svgp_mnist_train_step(const svgp_mnist_cfg*, double* theta, const double* images,
+                          const double* aux, const double* eps, double* ws, double* state,
+                          double* adam_m, double* adam_v, void* stream);
+
+/* ---- runtime helpers: HIP graphs and events without going through torch ---------------------*/
+int svgp_stream_create(void** stream_out);
+int svgp_stream_destroy(void* stream);
+int svgp_stream_sync(void* stream);
+int svgp_graph_begin(void* stream);                       /* hipStreamBeginCapture               */
+int svgp_graph_end(void* stream, void** graph_exec_out);  /* EndCapture + Instantiate            */
+int svgp_graph_launch(void* graph_exec, void* stream);
+int svgp_graph_destroy(void* graph_exec);
+int svgp_event_create(void** event_out);
+int svgp_event_record(void* event, void* stream);
+int svgp_event_elapsed_ms(void* start, void* stop, float* ms_out); /* synchronises on `stop`      */
+int svgp_event_destroy(void* event);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVGPVAE_HIP_H */

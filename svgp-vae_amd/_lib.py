@@ -1,0 +1,129 @@
+"""ctypes binding of libsvgpvae_hip.so (include/svgpvae_hip.h).
+
+There is NO CPU fallback: if the shared object is missing or does not export a symbol the
+header declares, loading fails loudly.  PyTorch only supplies device memory / streams."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsvgpvae_hip.so")
+
+
+class SvgpError(RuntimeError):
+    pass
+
+
+class MnistCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("b", "b_global", "m", "L", "M", "n_obj", "normalize_obj", "clip_qs",
+                                         "geco", "train_ip", "train_gp", "train_ov")] + \
+               [(n, C.c_double) for n in ("N_train", "jitter", "kappa_squared", "alpha", "rep_weight")]
+
+
+PARAM_FIELDS = ("enc_c1_w", "enc_c1_b", "enc_c2_w", "enc_c2_b", "enc_c3_w", "enc_c3_b", "enc_d_w", "enc_d_b",
+                "dec_d_w", "dec_d_b", "dec_c1_w", "dec_c1_b", "dec_c2_w", "dec_c2_b", "dec_c3_w", "dec_c3_b",
+                "ip", "l_GP", "amplitude", "ov", "n_enc", "n_vae", "n_total")
+
+
+class ParamLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in PARAM_FIELDS]
+
+
+WS_FIELDS = ("enc_a1", "enc_a2", "enc_a3", "qnet_mu", "qnet_var_raw", "qnet_var", "K", "Kn", "knn",
+             "statA", "statA_len", "S", "v",
+             "Ki", "ldK", "Si", "t", "G", "A", "Aji", "mu_hat", "u", "M2", "KL", "q",
+             "p_m", "p_v", "e", "d", "eps", "z",
+             "dec_h0", "dec_a1", "dec_a2", "recon",
+             "zbar", "g_pv", "g_pm", "mvbar",
+             "statB", "statB_len", "A2", "ud", "td",
+             "Kbar", "fb_part", "Qm", "vbar", "Ssym", "Knbar_part",
+             "Knbar", "knnbar", "ybar", "s2bar", "d_on",
+             "part_dec", "part_enc", "n_part", "part_gp", "part_sums", "n_post",
+             "gradC", "gradC_len", "grad", "sums", "total")
+
+
+class WsLayout(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in WS_FIELDS]
+
+
+STATE = dict(C_MA=0, LAGRANGE=1, ALPHA=2, ADAM_T=3, LR=4, BETA=5, ELBO=6, RECON_LOSS=7, KL_TERM=8,
+             INSIDE_ELBO=9, CE_TERM=10, INSIDE_RECON=11, INSIDE_KL=12, RNG_CTR=13)
+STATE_LEN = 16
+
+_P = C.c_void_p
+_CFG = C.POINTER(MnistCfg)
+
+# name -> argtypes ; every function returns int (status) except the two noted below
+SIGNATURES = {
+    "svgp_mnist_param_layout_get": [_CFG, C.POINTER(ParamLayout)],
+    "svgp_mnist_ws_layout_get": [_CFG, C.POINTER(WsLayout)],
+    "svgp_mnist_encoder_fwd": [_CFG, _P, _P, _P, _P],
+    "svgp_kernel_matrix_fwd": [_CFG, _P, _P, _P, _P],
+    "svgp_gp_stats_fwd": [_CFG, _P, _P],
+    "svgp_gp_factor_fwd": [_CFG, _P, _P],
+    "svgp_gp_posterior_fwd": [_CFG, _P, _P, _P, _P],
+    "svgp_mnist_decoder_fwd": [_CFG, _P, _P, _P, _P],
+    "svgp_mnist_decoder_bwd": [_CFG, _P, _P, _P, _P, _P],
+    "svgp_gp_stats_bwd": [_CFG, _P, _P, _P],
+    "svgp_gp_factor_bwd": [_CFG, _P, _P, _P],
+    "svgp_gp_posterior_bwd": [_CFG, _P, _P, _P],
+    "svgp_kernel_matrix_bwd": [_CFG, _P, _P, _P, _P],
+    "svgp_mnist_encoder_bwd": [_CFG, _P, _P, _P, _P],
+    "svgp_mnist_grad_reduce": [_CFG, _P, _P],
+    "svgp_adam_tf1_step": [C.c_int64, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P],
+    "svgp_elbo_finalize": [_CFG, _P, _P, _P],
+    "svgp_elbo_finalize_noadam": [_CFG, _P, _P, _P],
+    "svgp_mnist_step_phase": [_CFG, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "svgp_mnist_train_step": [_CFG, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "svgp_stream_create": [C.POINTER(_P)],
+    "svgp_stream_destroy": [_P],
+    "svgp_stream_sync": [_P],
+    "svgp_graph_begin": [_P],
+    "svgp_graph_end": [_P, C.POINTER(_P)],
+    "svgp_graph_launch": [_P, _P],
+    "svgp_graph_destroy": [_P],
+    "svgp_event_create": [C.POINTER(_P)],
+    "svgp_event_record": [_P, _P],
+    "svgp_event_elapsed_ms": [_P, _P, C.POINTER(C.c_float)],
+    "svgp_event_destroy": [_P],
+}
+NON_STATUS = {"svgp_version": ([], C.c_int), "svgp_last_error": ([], C.c_char_p)}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Loads the HIP library once and checks every declared symbol.  Raises SvgpError when the
+    shared object is absent (build it with `python -c "import __graft_entry__ as g; g.build()"`
+    or `make -C svgp-vae_amd/csrc`)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise SvgpError(f"{p} not found: the HIP extension is not built; there is no CPU fallback")
+    lib = C.CDLL(p)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise SvgpError(f"{p} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    for name, (argtypes, restype) in NON_STATUS.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc, lib=None):
+    if rc != 0:
+        lib = lib or load_library()
+        raise SvgpError(f"libsvgpvae_hip status {rc}: {lib.svgp_last_error().decode()}")
+
+
+def call(name, *args):
+    lib = load_library()
+    check(getattr(lib, name)(*args), lib)

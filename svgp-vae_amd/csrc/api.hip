@@ -1,0 +1,211 @@
+// C-ABI glue: error strings, layouts, phase orchestration, HIP graph / event helpers.
+#include <cstdarg>
+
+#include "common.hpp"
+
+static thread_local char g_err[512] = "";
+
+void svgp_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* svgp_last_error(void) { return g_err; }
+extern "C" int svgp_version(void) { return SVGP_VERSION_MAJOR * 100 + SVGP_VERSION_MINOR; }
+
+int svgp_check_cfg(const svgp_mnist_cfg* c) {
+    SVGP_REQUIRE(c != nullptr, SVGP_ERR_INVALID, "cfg is NULL");
+    SVGP_REQUIRE(c->b >= 1 && c->b_global >= c->b, SVGP_ERR_INVALID, "need 1 <= b <= b_global (b=%d b_global=%d)",
+                 c->b, c->b_global);
+    SVGP_REQUIRE(c->m >= 1 && c->L >= 1 && c->M >= 1 && c->n_obj >= 0, SVGP_ERR_INVALID,
+                 "bad shape m=%d L=%d M=%d n_obj=%d", c->m, c->L, c->M, c->n_obj);
+    SVGP_REQUIRE(c->m <= SVGP_M_MAX, SVGP_ERR_UNSUPPORTED,
+                 "m=%d inducing points: this build keeps the m x m stages LDS-resident and supports m <= %d",
+                 c->m, SVGP_M_MAX);
+    SVGP_REQUIRE(c->M <= 32, SVGP_ERR_UNSUPPORTED, "M=%d: object-vector dimension > 32 not supported", c->M);
+    SVGP_REQUIRE(c->L <= 64, SVGP_ERR_UNSUPPORTED, "L=%d: more than 64 latent channels not supported", c->L);
+    SVGP_REQUIRE(c->N_train > 0 && c->jitter >= 0, SVGP_ERR_INVALID, "bad N_train / jitter");
+    return SVGP_OK;
+}
+
+extern "C" int svgp_mnist_param_layout_get(const svgp_mnist_cfg* c, svgp_mnist_param_layout* o) {
+    int rc = svgp_check_cfg(c);
+    if (rc) return rc;
+    SVGP_REQUIRE(o != nullptr, SVGP_ERR_INVALID, "out is NULL");
+    int64_t p = 0;
+    auto take = [&](int64_t n) { int64_t r = p; p += n; return r; };
+    o->enc_c1_w = take(3 * 3 * 1 * 8);  o->enc_c1_b = take(8);
+    o->enc_c2_w = take(3 * 3 * 8 * 8);  o->enc_c2_b = take(8);
+    o->enc_c3_w = take(3 * 3 * 8 * 8);  o->enc_c3_b = take(8);
+    o->enc_d_w = take(32 * 2 * c->L);   o->enc_d_b = take(2 * c->L);
+    o->n_enc = p;
+    o->dec_d_w = take((int64_t)c->L * 128); o->dec_d_b = take(128);
+    o->dec_c1_w = take(3 * 3 * 8 * 8);  o->dec_c1_b = take(8);
+    o->dec_c2_w = take(3 * 3 * 8 * 8);  o->dec_c2_b = take(8);
+    o->dec_c3_w = take(3 * 3 * 8 * 1);  o->dec_c3_b = take(1);
+    o->n_vae = p;
+    o->ip = take((int64_t)c->m * (2 + c->M));
+    o->l_GP = take(1);
+    o->amplitude = take(1);
+    o->ov = take((int64_t)c->n_obj * c->M);
+    o->n_total = p;
+    return SVGP_OK;
+}
+
+extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_layout* o) {
+    svgp_mnist_param_layout pl;
+    int rc = svgp_mnist_param_layout_get(c, &pl);
+    if (rc) return rc;
+    SVGP_REQUIRE(o != nullptr, SVGP_ERR_INVALID, "out is NULL");
+    const int64_t b = c->b, m = c->m, L = c->L, M = c->M;
+    int64_t p = 0;
+    // every field starts on a 16-element (128-byte) boundary
+    auto take = [&](int64_t n) { int64_t r = p; p += (n + 15) / 16 * 16; return r; };
+    o->enc_a1 = take(b * 13 * 13 * 8); o->enc_a2 = take(b * 6 * 6 * 8); o->enc_a3 = take(b * 32);
+    o->qnet_mu = take(b * L); o->qnet_var_raw = take(b * L); o->qnet_var = take(b * L);
+    o->K = take(m * m); o->Kn = take(b * m); o->knn = take(b);
+    o->statA = p; o->S = p; p += L * m * m; o->v = p; p += L * m; o->statA_len = p - o->statA; take(0);
+    o->Ki = take(m * m); o->ldK = take(1);
+    o->Si = take(L * m * m); o->t = take(L * m); o->G = take(L * m * m); o->A = take(L * m * m);
+    o->Aji = take(L * m * m); o->mu_hat = take(L * m); o->u = take(L * m); o->M2 = take(L * m * m);
+    o->KL = take(L); o->q = take(b);
+    o->p_m = take(b * L); o->p_v = take(b * L); o->e = take(b * L); o->d = take(b * L);
+    o->eps = take(b * L); o->z = take(b * L);
+    o->dec_h0 = take(b * 128); o->dec_a1 = take(b * 512); o->dec_a2 = take(b * 1568); o->recon = take(b * 784);
+    o->zbar = take(b * L); o->g_pv = take(b * L); o->g_pm = take(b * L); o->mvbar = take(b * L);
+    o->statB = p; o->A2 = p; p += L * m * m; o->ud = p; p += L * m; o->td = p; p += L * m;
+    o->statB_len = p - o->statB; take(0);
+    o->Kbar = take(m * m); o->fb_part = take(2 * L * m * m); o->Qm = take(L * m * m); o->vbar = take(L * m);
+    o->Ssym = take(L * m * m); o->Knbar_part = take(L * b * m);
+    o->Knbar = take(b * m); o->knnbar = take(b); o->ybar = take(b * L); o->s2bar = take(b * L);
+    o->d_on = take(b * M);
+    o->n_part = svgp_n_part(c);
+    o->part_dec = take(o->n_part * (pl.n_vae - pl.n_enc));
+    o->part_enc = take(o->n_part * pl.n_enc);
+    o->part_gp = take((m + svgp_n_rowblk(c)) * 2);
+    o->n_post = (int64_t)L * svgp_n_postblk(c);
+    o->part_sums = take(o->n_part * 4 + o->n_post * 2);
+    o->gradC = p; o->grad = p; p += pl.n_total; o->sums = p; p += 8; o->gradC_len = p - o->gradC; take(0);
+    o->total = p;
+    return SVGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// phases
+// ---------------------------------------------------------------------------------------------
+extern "C" int svgp_mnist_step_phase(const svgp_mnist_cfg* c, int phase, double* theta, const double* images,
+                                     const double* aux, const double* eps, double* ws, double* state,
+                                     double* adam_m, double* adam_v, void* stream) {
+    int rc = svgp_check_cfg(c);
+    if (rc) return rc;
+    SVGP_REQUIRE(theta && images && aux && ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+#define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
+    switch (phase) {
+    case 0:
+        RUN(svgp_mnist_encoder_fwd(c, theta, images, ws, stream));
+        RUN(svgp_kernel_matrix_fwd(c, theta, aux, ws, stream));
+        RUN(svgp_gp_stats_fwd(c, ws, stream));
+        break;
+    case 1:
+        RUN(svgp_gp_factor_fwd(c, ws, stream));
+        RUN(svgp_gp_posterior_fwd(c, eps, ws, state, stream));
+        RUN(svgp_mnist_decoder_fwd(c, theta, images, ws, stream));
+        RUN(svgp_mnist_decoder_bwd(c, theta, images, ws, state, stream));
+        RUN(svgp_gp_stats_bwd(c, ws, state, stream));
+        break;
+    case 2:
+        RUN(svgp_gp_factor_bwd(c, ws, state, stream));
+        RUN(svgp_gp_posterior_bwd(c, ws, state, stream));
+        RUN(svgp_kernel_matrix_bwd(c, theta, aux, ws, stream));
+        RUN(svgp_mnist_encoder_bwd(c, theta, images, ws, stream));
+        RUN(svgp_mnist_grad_reduce(c, ws, stream));
+        break;
+    case 3: {
+        svgp_mnist_param_layout pl;
+        svgp_mnist_ws_layout wl;
+        RUN(svgp_mnist_param_layout_get(c, &pl));
+        RUN(svgp_mnist_ws_layout_get(c, &wl));
+        if (adam_m != nullptr) {
+            SVGP_REQUIRE(adam_v != nullptr, SVGP_ERR_INVALID, "adam_v is NULL");
+            RUN(svgp_adam_tf1_step(pl.n_total, theta, ws + wl.grad, adam_m, adam_v, state, 0.9, 0.999, 1e-8,
+                                   stream));
+            RUN(svgp_elbo_finalize(c, ws, state, stream));
+        } else {
+            RUN(svgp_elbo_finalize_noadam(c, ws, state, stream));
+        }
+        break;
+    }
+    default:
+        SVGP_REQUIRE(false, SVGP_ERR_INVALID, "phase %d out of range 0..3", phase);
+    }
+#undef RUN
+    return SVGP_OK;
+}
+
+extern "C" int svgp_mnist_train_step(const svgp_mnist_cfg* c, double* theta, const double* images,
+                                     const double* aux, const double* eps, double* ws, double* state,
+                                     double* adam_m, double* adam_v, void* stream) {
+    SVGP_REQUIRE(c && c->b == c->b_global, SVGP_ERR_INVALID,
+                 "svgp_mnist_train_step is the single-GPU form (b == b_global); use svgp_mnist_step_phase "
+                 "with all-reduces between phases for data parallelism");
+    for (int ph = 0; ph < 4; ++ph) {
+        int rc = svgp_mnist_step_phase(c, ph, theta, images, aux, eps, ws, state, adam_m, adam_v, stream);
+        if (rc) return rc;
+    }
+    return SVGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// runtime helpers
+// ---------------------------------------------------------------------------------------------
+extern "C" int svgp_stream_create(void** out) {
+    SVGP_REQUIRE(out, SVGP_ERR_INVALID, "out is NULL");
+    hipStream_t s;
+    SVGP_CHECK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *out = (void*)s;
+    return SVGP_OK;
+}
+extern "C" int svgp_stream_destroy(void* s) { SVGP_CHECK_HIP(hipStreamDestroy((hipStream_t)s)); return SVGP_OK; }
+extern "C" int svgp_stream_sync(void* s) { SVGP_CHECK_HIP(hipStreamSynchronize((hipStream_t)s)); return SVGP_OK; }
+
+extern "C" int svgp_graph_begin(void* s) {
+    SVGP_CHECK_HIP(hipStreamBeginCapture((hipStream_t)s, hipStreamCaptureModeThreadLocal));
+    return SVGP_OK;
+}
+extern "C" int svgp_graph_end(void* s, void** exec_out) {
+    SVGP_REQUIRE(exec_out, SVGP_ERR_INVALID, "exec_out is NULL");
+    hipGraph_t g = nullptr;
+    SVGP_CHECK_HIP(hipStreamEndCapture((hipStream_t)s, &g));
+    hipGraphExec_t e = nullptr;
+    hipError_t err = hipGraphInstantiate(&e, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    SVGP_CHECK_HIP(err);
+    *exec_out = (void*)e;
+    return SVGP_OK;
+}
+extern "C" int svgp_graph_launch(void* e, void* s) {
+    SVGP_CHECK_HIP(hipGraphLaunch((hipGraphExec_t)e, (hipStream_t)s));
+    return SVGP_OK;
+}
+extern "C" int svgp_graph_destroy(void* e) { SVGP_CHECK_HIP(hipGraphExecDestroy((hipGraphExec_t)e)); return SVGP_OK; }
+
+extern "C" int svgp_event_create(void** out) {
+    SVGP_REQUIRE(out, SVGP_ERR_INVALID, "out is NULL");
+    hipEvent_t ev;
+    SVGP_CHECK_HIP(hipEventCreate(&ev));
+    *out = (void*)ev;
+    return SVGP_OK;
+}
+extern "C" int svgp_event_record(void* ev, void* s) {
+    SVGP_CHECK_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)s));
+    return SVGP_OK;
+}
+extern "C" int svgp_event_elapsed_ms(void* a, void* b, float* ms) {
+    SVGP_REQUIRE(ms, SVGP_ERR_INVALID, "ms is NULL");
+    SVGP_CHECK_HIP(hipEventSynchronize((hipEvent_t)b));
+    SVGP_CHECK_HIP(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return SVGP_OK;
+}
+extern "C" int svgp_event_destroy(void* ev) { SVGP_CHECK_HIP(hipEventDestroy((hipEvent_t)ev)); return SVGP_OK; }

@@ -1,0 +1,80 @@
+// Shared declarations for libsvgpvae_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/svgpvae_hip.h"
+
+typedef double real;
+
+#define SVGP_BLOCK 256
+#define SVGP_MAX_PART 256      // max workgroups that write weight-gradient partials (= CUs)
+#define SVGP_M_MAX 64          // LDS-resident m x m stages (this build)
+#define SVGP_LOG_2PI 1.8378770664093453
+
+void svgp_set_error(const char* fmt, ...);
+
+#define SVGP_CHECK_HIP(expr)                                                              \
+    do {                                                                                  \
+        hipError_t _e = (expr);                                                           \
+        if (_e != hipSuccess) {                                                           \
+            svgp_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, \
+                           __LINE__);                                                     \
+            return SVGP_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+#define SVGP_REQUIRE(cond, code, ...)   \
+    do {                                \
+        if (!(cond)) {                  \
+            svgp_set_error(__VA_ARGS__); \
+            return (code);              \
+        }                               \
+    } while (0)
+
+#define SVGP_LAUNCH_CHECK() SVGP_CHECK_HIP(hipGetLastError())
+
+int svgp_check_cfg(const svgp_mnist_cfg* c);
+
+static inline int svgp_n_part(const svgp_mnist_cfg* c) {
+    return c->b < SVGP_MAX_PART ? c->b : SVGP_MAX_PART;
+}
+static inline int svgp_n_rowblk(const svgp_mnist_cfg* c) { return (c->b + 63) / 64; }
+// per-sample kernels: thread (row, i) with SVGP_BLOCK / m rows per workgroup
+static inline int svgp_rows_per_block(const svgp_mnist_cfg* c) { return SVGP_BLOCK / c->m; }
+static inline int svgp_n_postblk(const svgp_mnist_cfg* c) {
+    const int rb = svgp_rows_per_block(c);
+    return (c->b + rb - 1) / rb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ real wave_sum(real x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    return x;  // valid in lane 0
+}
+
+// Sum over the workgroup (blockDim.x multiple of 64, <= 1024); result valid in thread 0.
+// `red` is an LDS scratch of >= 16 reals.  Fixed order -> deterministic.
+__device__ __forceinline__ real block_sum(real x, real* red) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    x = wave_sum(x);
+    __syncthreads();
+    if (lane == 0) red[w] = x;
+    __syncthreads();
+    real s = 0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+
+__device__ __forceinline__ real elu_f(real x) { return x > 0 ? x : expm1(x); }
+// derivative of ELU expressed through its OUTPUT: out > 0 -> 1, else exp(pre) = out + 1
+__device__ __forceinline__ real elu_grad_from_out(real out) { return out > 0 ? real(1) : out + real(1); }
+
+__device__ __forceinline__ real recip_no_nan(real x) { return x == real(0) ? real(0) : real(1) / x; }

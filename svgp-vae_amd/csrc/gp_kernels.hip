@@ -1,0 +1,1033 @@
+// Sparse-GP (Hensman) block of the SVGPVAE step for gfx950: kernel matrices, weighted
+// statistics, m x m factor stage, per-sample stage - forward and hand-derived reverse.
+//
+// Reference semantics: SVGPVAE_model.py:220-343 (mainSVGP.variational_loss Hensman branch,
+// approximate_posterior_params), :427-476 (mnistSVGP.kernel_matrix), :880-902 (assembly),
+// utils.py:483-504 (gauss_cross_entropy).  Math and the reverse formulas: DESIGN.md section 4,
+// checked stage by stage against oracle/staged_gp.py.
+//
+// The reference materialises a (b,m,m) tensor and several b x b products per channel
+// (SVGPVAE_model.py:284-294,336-337); here everything is O(L b m^2 + L m^3) and the only
+// cross-row reductions are the statistics blocks statA / statB (what data parallelism all-reduces).
+#include "common.hpp"
+
+namespace {
+
+// =============================================================================================
+// LDS matrix helpers.  LDS matrices are m x m with leading dimension ld = m + 1 (odd-ish pad:
+// column walks hit distinct banks with 8-byte elements).  All helpers are workgroup-cooperative
+// and do NOT end with a barrier unless stated.
+// =============================================================================================
+__device__ __forceinline__ void mat_load(real* R, int ld, const real* __restrict__ g, int m) {
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) R[(o / m) * ld + (o % m)] = g[o];
+}
+__device__ __forceinline__ void mat_store(real* __restrict__ g, const real* R, int ld, int m) {
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) g[o] = R[(o / m) * ld + (o % m)];
+}
+// C = alpha * op(A) * op(B)   (all LDS, C must not alias A or B)
+template <bool TA, bool TB>
+__device__ __forceinline__ void mat_gemm(real* C, const real* A, const real* B, int ld, int m, real alpha) {
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
+        const int i = o / m, j = o % m;
+        real acc = 0;
+        for (int k = 0; k < m; ++k) {
+            const real a = TA ? A[k * ld + i] : A[i * ld + k];
+            const real b = TB ? B[j * ld + k] : B[k * ld + j];
+            acc += a * b;
+        }
+        C[i * ld + j] = alpha * acc;
+    }
+}
+// Cg (global, ld = m) = alpha * op(A) * op(B) + beta * Cg
+template <bool TA, bool TB>
+__device__ __forceinline__ void mat_gemm_g(real* __restrict__ Cg, const real* A, const real* B, int ld, int m,
+                                           real alpha, real beta) {
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
+        const int i = o / m, j = o % m;
+        real acc = 0;
+        for (int k = 0; k < m; ++k) {
+            const real a = TA ? A[k * ld + i] : A[i * ld + k];
+            const real b = TB ? B[j * ld + k] : B[k * ld + j];
+            acc += a * b;
+        }
+        Cg[o] = alpha * acc + (beta != real(0) ? beta * Cg[o] : real(0));
+    }
+}
+// y = alpha * A x (+ y0), threads < m; x, y in LDS (y must not alias x)
+__device__ __forceinline__ void mat_vec(real* y, const real* A, int ld, const real* x, int m, real alpha) {
+    if (threadIdx.x < m) {
+        real acc = 0;
+        for (int j = 0; j < m; ++j) acc += A[threadIdx.x * ld + j] * x[j];
+        y[threadIdx.x] = alpha * acc;
+    }
+}
+
+// A (SPD, LDS) <- A^{-1} via Cholesky; W is an m x m LDS scratch.  Returns log det A (all
+// threads).  Begins and ends with a barrier.
+__device__ real chol_inv(real* A, real* W, int ld, int m) {
+    real logdet = 0;
+    // 1. right-looking Cholesky, lower factor in the lower triangle of A
+    for (int k = 0; k < m; ++k) {
+        __syncthreads();
+        const real lkk = sqrt(A[k * ld + k]);
+        const real inv = real(1) / lkk;
+        logdet += real(2) * log(lkk);
+        for (int i = k + 1 + threadIdx.x; i < m; i += blockDim.x) A[i * ld + k] *= inv;
+        __syncthreads();
+        if (threadIdx.x == 0) A[k * ld + k] = lkk;
+        const int n = m - k - 1;
+        for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
+            const int i = k + 1 + idx / n, j = k + 1 + idx % n;
+            if (j <= i) A[i * ld + j] -= A[i * ld + k] * A[j * ld + k];
+        }
+    }
+    __syncthreads();
+    // 2. X = L^{-1} (lower) into W, one thread per column
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) W[(o / m) * ld + (o % m)] = 0;
+    __syncthreads();
+    if (threadIdx.x < m) {
+        const int j = threadIdx.x;
+        W[j * ld + j] = real(1) / A[j * ld + j];
+        for (int i = j + 1; i < m; ++i) {
+            real acc = 0;
+            for (int k = j; k < i; ++k) acc += A[i * ld + k] * W[k * ld + j];
+            W[i * ld + j] = -acc / A[i * ld + i];
+        }
+    }
+    __syncthreads();
+    // 3. A^{-1} = X^T X
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
+        const int i = o / m, j = o % m;
+        real acc = 0;
+        for (int k = (i > j ? i : j); k < m; ++k) acc += W[k * ld + i] * W[k * ld + j];
+        A[i * ld + j] = acc;
+    }
+    __syncthreads();
+    return logdet;
+}
+
+// =============================================================================================
+// kernel matrices  (SVGPVAE_model.py:427-476; TFP ExpSinSquared x Linear)
+// =============================================================================================
+struct KernArgs {
+    int b, m, M, n_obj, normalize;
+    const real* aux;   // (b, 2+M)
+    const real* ip;    // (m, 2+M)
+    const real* ov;    // (n_obj, M) or unused
+    const real* ls;    // scalar
+    const real* amp;   // scalar
+};
+
+__device__ __forceinline__ const real* obj_row(const KernArgs& a, int n) {
+    return a.n_obj > 0 ? a.ov + (size_t)((long long)a.aux[(size_t)n * (2 + a.M)]) * a.M
+                       : a.aux + (size_t)n * (2 + a.M) + 2;
+}
+__device__ __forceinline__ real view_k(real d, real a2, real inv_l2) {
+    const real s = sin(real(0.5) * d);
+    return a2 * exp(real(-2) * s * s * inv_l2);
+}
+__device__ __forceinline__ real dotM(const real* x, const real* y, int M) {
+    real s = 0;
+    for (int k = 0; k < M; ++k) s += x[k] * y[k];
+    return s;
+}
+
+__global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_fwd(KernArgs a, real* __restrict__ K,
+                                                                  real* __restrict__ Kn, real* __restrict__ knn) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nbm = (long long)a.b * a.m, nmm = (long long)a.m * a.m;
+    const int st = 2 + a.M;
+    const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
+    if (idx < nbm) {
+        const int n = (int)(idx / a.m), j = (int)(idx % a.m);
+        const real* on = obj_row(a, n);
+        const real* oj = a.ip + (size_t)j * st + 2;
+        real D = dotM(on, oj, a.M);
+        if (a.normalize) D /= sqrt(dotM(on, on, a.M)) * sqrt(dotM(oj, oj, a.M));
+        Kn[idx] = view_k(a.aux[(size_t)n * st + 1] - a.ip[(size_t)j * st + 1], a2, inv_l2) * D;
+    } else if (idx < nbm + nmm) {
+        const long long o = idx - nbm;
+        const int i = (int)(o / a.m), j = (int)(o % a.m);
+        const real* oi = a.ip + (size_t)i * st + 2;
+        const real* oj = a.ip + (size_t)j * st + 2;
+        real D = dotM(oi, oj, a.M);
+        if (a.normalize) D /= sqrt(dotM(oi, oi, a.M)) * sqrt(dotM(oj, oj, a.M));
+        K[o] = view_k(a.ip[(size_t)i * st + 1] - a.ip[(size_t)j * st + 1], a2, inv_l2) * D;
+    } else if (idx < nbm + nmm + a.b) {
+        const int n = (int)(idx - nbm - nmm);
+        const real* on = obj_row(a, n);
+        knn[n] = a.normalize ? a2 : a2 * dotM(on, on, a.M);
+    }
+}
+
+// VJP, inducing side: one workgroup per inducing point j.
+// d_ip[j] = [0, d_theta_j, d_o_j], partial amplitude / length-scale sums -> part_gp[j].
+#define KM_MAXM 32
+__global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_cols(KernArgs a, real rep_weight, int train_ip,
+                                                                       const real* __restrict__ K,
+                                                                       const real* __restrict__ Kn,
+                                                                       const real* __restrict__ Kbar,
+                                                                       const real* __restrict__ Knbar,
+                                                                       real* __restrict__ d_ip,
+                                                                       real* __restrict__ part_gp) {
+    __shared__ real red[16];
+    __shared__ real res[KM_MAXM + 4];
+    const int j = blockIdx.x, st = 2 + a.M, M = a.M;
+    const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
+    const real* oj = a.ip + (size_t)j * st + 2;
+    const real thj = a.ip[(size_t)j * st + 1];
+    const real nj = a.normalize ? sqrt(dotM(oj, oj, M)) : real(1);
+    real acc_amp = 0, acc_ls = 0, acc_th = 0, acc_o[KM_MAXM];
+#pragma unroll
+    for (int k = 0; k < KM_MAXM; ++k) acc_o[k] = 0;
+    // ---- K_nm column j
+    for (int n = threadIdx.x; n < a.b; n += blockDim.x) {
+        const real gk = Knbar[(size_t)n * a.m + j];
+        const real d = a.aux[(size_t)n * st + 1] - thj;
+        const real V = view_k(d, a2, inv_l2);
+        const real G = gk * Kn[(size_t)n * a.m + j];
+        const real sh = sin(real(0.5) * d);
+        acc_amp += G;
+        acc_ls += G * sh * sh;
+        acc_th += G * sin(d);
+        const real* on = obj_row(a, n);
+        const real c = gk * V / (a.normalize ? sqrt(dotM(on, on, M)) : real(1));
+#pragma unroll
+        for (int k = 0; k < KM_MAXM; ++k)
+            if (k < M) acc_o[k] += c * on[k];
+    }
+    // ---- K_mm: row j (first argument) and column j (second argument), replicated across ranks
+    for (int i = threadIdx.x; i < a.m; i += blockDim.x) {
+        const real* oi = a.ip + (size_t)i * st + 2;
+        const real ni = a.normalize ? sqrt(dotM(oi, oi, M)) : real(1);
+        const real d = thj - a.ip[(size_t)i * st + 1];          // theta_j - theta_i  (entry (j,i))
+        const real V = view_k(d, a2, inv_l2);                   // even in d
+        const real sh = sin(real(0.5) * d);
+        const real g_ji = rep_weight * Kbar[(size_t)j * a.m + i], g_ij = rep_weight * Kbar[(size_t)i * a.m + j];
+        const real G_ji = g_ji * K[(size_t)j * a.m + i], G_ij = g_ij * K[(size_t)i * a.m + j];
+        acc_amp += G_ji;
+        acc_ls += G_ji * sh * sh;
+        // entry (j,i): dK/dtheta_j = -K sin(d);  entry (i,j): dK/dtheta_j = +K sin(theta_i - theta_j) = -K sin(d)
+        acc_th += -(G_ji + G_ij) * sin(d);
+        const real c = (g_ji + g_ij) * V / ni;
+#pragma unroll
+        for (int k = 0; k < KM_MAXM; ++k)
+            if (k < M) acc_o[k] += c * oi[k];
+    }
+    real t;
+    t = block_sum(acc_amp, red); if (threadIdx.x == 0) res[KM_MAXM] = t;
+    t = block_sum(acc_ls, red);  if (threadIdx.x == 0) res[KM_MAXM + 1] = t;
+    t = block_sum(acc_th, red);  if (threadIdx.x == 0) res[KM_MAXM + 2] = t;
+#pragma unroll
+    for (int k = 0; k < KM_MAXM; ++k) {
+        if (k < M) {                                 // M is workgroup-uniform
+            t = block_sum(acc_o[k], red);
+            if (threadIdx.x == 0) res[k] = t;
+        }
+    }
+    if (threadIdx.x == 0) {
+        part_gp[j * 2 + 0] = real(2) * res[KM_MAXM] / amp;                         // d amplitude
+        part_gp[j * 2 + 1] = real(4) * res[KM_MAXM + 1] / (ls * ls * ls);          // d length scale
+        real* out = d_ip + (size_t)j * st;
+        out[0] = 0;
+        out[1] = train_ip ? res[KM_MAXM + 2] * inv_l2 : real(0);
+        // res[k] is the gradient w.r.t. the (normalised) o_j direction: d_oh; chain through o/|o|
+        real proj = 0;
+        if (a.normalize)
+            for (int k = 0; k < M; ++k) proj += res[k] * oj[k] / nj;
+        for (int k = 0; k < M; ++k) {
+            real g = res[k];
+            if (a.normalize) g = (g - proj * oj[k] / nj) / nj;
+            out[2 + k] = train_ip ? g : real(0);
+        }
+    }
+}
+
+// VJP, batch-row side: one thread per batch row -> d_on (b,M) (gradient of the gathered object
+// row) and the k_nn part of the amplitude gradient (partials per 64-row block).
+__global__ __launch_bounds__(64) void k_kernel_matrix_bwd_rows(KernArgs a, const real* __restrict__ Knbar,
+                                                               const real* __restrict__ knnbar,
+                                                               const real* __restrict__ knn,
+                                                               real* __restrict__ d_on, real* __restrict__ part_gp) {
+    const int n = blockIdx.x * 64 + threadIdx.x, st = 2 + a.M, M = a.M;
+    const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
+    real acc_amp = 0;
+    if (n < a.b) {
+        const real* on = obj_row(a, n);
+        const real nn = a.normalize ? sqrt(dotM(on, on, M)) : real(1);
+        const real thn = a.aux[(size_t)n * st + 1];
+        real g[KM_MAXM];
+#pragma unroll
+        for (int k = 0; k < KM_MAXM; ++k) g[k] = 0;
+        for (int j = 0; j < a.m; ++j) {
+            const real* oj = a.ip + (size_t)j * st + 2;
+            const real nj = a.normalize ? sqrt(dotM(oj, oj, M)) : real(1);
+            const real c = Knbar[(size_t)n * a.m + j] * view_k(thn - a.ip[(size_t)j * st + 1], a2, inv_l2) / nj;
+#pragma unroll
+            for (int k = 0; k < KM_MAXM; ++k)
+                if (k < M) g[k] += c * oj[k];
+        }
+        const real gk = knnbar[n];
+        acc_amp = real(2) * gk * knn[n] / amp;
+        // k_nn = a^2 |o_hat|^2 ; d/d o_hat = 2 a^2 o_hat
+        real proj = 0;
+        for (int k = 0; k < M; ++k) {
+            g[k] += real(2) * a2 * gk * on[k] / nn;
+            proj += g[k] * on[k] / nn;
+        }
+        for (int k = 0; k < M; ++k) {
+            real v = g[k];
+            if (a.normalize) v = (v - proj * on[k] / nn) / nn;
+            d_on[(size_t)n * M + k] = v;
+        }
+    }
+    acc_amp = wave_sum(acc_amp);
+    if (threadIdx.x == 0) {
+        part_gp[(a.m + blockIdx.x) * 2 + 0] = acc_amp;
+        part_gp[(a.m + blockIdx.x) * 2 + 1] = 0;
+    }
+}
+
+// Deterministic scatter-add of d_on into the object table gradient (duplicate ids sum in row
+// order) + final amplitude / length-scale sums.  Last block does the scalars.
+__global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernArgs a, int n_gp_part, int train_gp,
+                                                                          int train_ov,
+                                                                          const real* __restrict__ d_on,
+                                                                          const real* __restrict__ part_gp,
+                                                                          real* __restrict__ d_ov,
+                                                                          real* __restrict__ d_ls,
+                                                                          real* __restrict__ d_amp) {
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ real red[16];
+        real sa = 0, sl = 0;
+        for (int i = threadIdx.x; i < n_gp_part; i += blockDim.x) { sa += part_gp[i * 2]; sl += part_gp[i * 2 + 1]; }
+        sa = block_sum(sa, red);
+        sl = block_sum(sl, red);
+        if (threadIdx.x == 0) { *d_amp = train_gp ? sa : real(0); *d_ls = train_gp ? sl : real(0); }
+        return;
+    }
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= a.n_obj * a.M) return;
+    const int r = o / a.M, k = o % a.M, st = 2 + a.M;
+    real acc = 0;
+    if (train_ov)
+        for (int n = 0; n < a.b; ++n)
+            if ((long long)a.aux[(size_t)n * st] == r) acc += d_on[(size_t)n * a.M + k];
+    d_ov[o] = acc;
+}
+
+// =============================================================================================
+// weighted statistics  S_l = Kn^T diag(w_l) Kn,  v1_l = Kn^T a_l,  v2_l = Kn^T b_l
+// grid (T, L [+1]): blockIdx.y = channel, blockIdx.x = tile of 256 outputs of the m x m matrix.
+// mode 0 (forward):  w = 1/var, a = y/var                      (SVGPVAE_model.py:328-334)
+// mode 1 (backward): computes g_pv, g_pm, mvbar (stored) and uses w = g_pv, a = mvbar, b = c g_pm
+// In forward mode the extra block blockIdx.y == L inverts K_mm + jitter I (:239,270,273).
+// =============================================================================================
+#define STAT_RC 64   // rows staged per pass
+struct StatArgs {
+    int b, m, L, mode;
+    real c, jitter, beta_over_L_unused;
+    int geco;
+    const real* Kn;      // (b,m)
+    const real* y;       // qnet_mu (b,L)
+    const real* s2;      // qnet_var (b,L)
+    // backward-only inputs
+    const real* p_m; const real* p_v; const real* e; const real* eps; const real* zbar; const real* state;
+    real* g_pv; real* g_pm; real* mvbar;
+    // outputs
+    real* S; real* v1; real* v2;
+    // forward-only: K -> Ki, ldK
+    const real* K; real* Ki; real* ldK;
+};
+
+__device__ __forceinline__ real grad_KL_term(int geco, int L, const real* state) {
+    // d(minimised objective)/d(KL_term): GECO -1 (SVGPVAE_model.py:913), beta-ELBO -beta/L (:925)
+    return geco ? real(-1) : -state[SVGP_ST_BETA] / (real)L;
+}
+
+__global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
+    extern __shared__ __align__(16) real smem[];
+    const int m = a.m, l = blockIdx.y;
+    if (l == a.L) {   // ---- K_mm inverse block (forward mode only, blockIdx.x == 0)
+        if (blockIdx.x != 0) return;
+        const int ld = m + 1;
+        real* A = smem;
+        real* W = A + m * ld;
+        mat_load(A, ld, a.K, m);
+        __syncthreads();
+        if (threadIdx.x < m) A[threadIdx.x * ld + threadIdx.x] += a.jitter;
+        const real logdet = chol_inv(A, W, ld, m);
+        mat_store(a.Ki, A, ld, m);
+        if (threadIdx.x == 0) *a.ldK = logdet;
+        return;
+    }
+    real* kt = smem;                   // STAT_RC x m tile of Kn
+    real* w = kt + STAT_RC * m;        // STAT_RC
+    real* va = w + STAT_RC;            // STAT_RC
+    real* vb = va + STAT_RC;           // STAT_RC
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;      // output element of the m x m matrix
+    const bool act = o < m * m;
+    const int i = act ? o / m : 0, j = act ? o % m : 0;
+    const bool vec = (blockIdx.x == 0) && (threadIdx.x < m);  // also accumulates v1/v2 element
+    real accS = 0, acc1 = 0, acc2 = 0;
+    const real gT = a.mode ? grad_KL_term(a.geco, a.L, a.state) : real(0);
+    for (int r0 = 0; r0 < a.b; r0 += STAT_RC) {
+        const int rows = min(STAT_RC, a.b - r0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < rows * m; t += blockDim.x) kt[t] = a.Kn[(size_t)r0 * m + t];
+        if (threadIdx.x < rows) {
+            const size_t e = (size_t)(r0 + threadIdx.x) * a.L + l;
+            const real p = recip_no_nan(a.s2[e]);
+            if (a.mode == 0) {
+                w[threadIdx.x] = p;
+                va[threadIdx.x] = p * a.y[e];
+                vb[threadIdx.x] = 0;
+            } else {
+                const real zb = a.zbar[e];
+                const real gpv = real(0.5) * gT * p + zb * a.eps[e] / (real(2) * sqrt(a.p_v[e]));
+                const real gpm = gT * p * (a.p_m[e] - a.y[e]) + zb;
+                const real mvb = gT * p * a.e[e];
+                w[threadIdx.x] = gpv;
+                va[threadIdx.x] = mvb;
+                vb[threadIdx.x] = a.c * gpm;
+                if (blockIdx.x == 0) { a.g_pv[e] = gpv; a.g_pm[e] = gpm; a.mvbar[e] = mvb; }
+            }
+        }
+        __syncthreads();
+        if (act)
+            for (int r = 0; r < rows; ++r) accS += w[r] * kt[r * m + i] * kt[r * m + j];
+        if (vec)
+            for (int r = 0; r < rows; ++r) {
+                const real k = kt[r * m + threadIdx.x];
+                acc1 += va[r] * k;
+                acc2 += vb[r] * k;
+            }
+    }
+    if (act) a.S[(size_t)l * m * m + o] = accS;
+    if (vec) {
+        a.v1[(size_t)l * m + threadIdx.x] = acc1;
+        if (a.v2) a.v2[(size_t)l * m + threadIdx.x] = acc2;
+    }
+}
+
+// =============================================================================================
+// m x m factor stage, forward.  blockIdx.x < L: channel l.  blockIdx.x >= L: q_n = k_n^T Ki k_n
+// for a block of rows (shared by all channels).
+// =============================================================================================
+struct FactArgs {
+    int b, m, L;
+    real c, jitter;
+    const real* K; const real* Ki; const real* ldK; const real* S; const real* v; const real* Kn;
+    real* Si; real* t; real* G; real* A; real* Aji; real* mu; real* u; real* M2; real* KL; real* q;
+};
+
+__global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
+    extern __shared__ __align__(16) real smem[];
+    const int m = a.m, ld = m + 1, mm = m * ld;
+    real* R0 = smem;
+    real* R1 = R0 + mm;
+    real* R2 = R1 + mm;
+    real* R3 = R2 + mm;
+    real* vx = R3 + mm;       // m
+    real* vy = vx + m;        // m
+    real* vz = vy + m;        // m
+    real* red = vz + m;       // 16 (+ row scratch 256 for the q blocks)
+    if ((int)blockIdx.x >= a.L) {
+        // ---- q rows: thread (n_local, i); rows per block RB = blockDim / m
+        const int RB = blockDim.x / m, rb = blockIdx.x - a.L;
+        const int nl = threadIdx.x / m, i = threadIdx.x % m, n = rb * RB + nl;
+        const bool act = nl < RB && n < a.b;
+        mat_load(R0, ld, a.Ki, m);
+        real* kr = R1;          // RB x m rows of Kn
+        if (act) kr[nl * m + i] = a.Kn[(size_t)n * m + i];
+        __syncthreads();
+        real acc = 0;
+        if (act) {
+            for (int j = 0; j < m; ++j) acc += R0[j * ld + i] * kr[nl * m + j];   // Ki symmetric
+            acc *= kr[nl * m + i];
+        }
+        real* sc = red + 16;
+        sc[threadIdx.x] = act ? acc : real(0);
+        __syncthreads();
+        if (act && i == 0) {
+            real s = 0;
+            for (int k = 0; k < m; ++k) s += sc[nl * m + k];
+            a.q[n] = s;
+        }
+        return;
+    }
+    const int l = blockIdx.x;
+    const size_t om = (size_t)l * m * m, ov = (size_t)l * m;
+    // R0 = K ; R1 = K + c S_l + jitter I
+    mat_load(R0, ld, a.K, m);
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
+        const int i = o / m, j = o % m;
+        R1[i * ld + j] = a.K[o] + a.c * a.S[om + o] + (i == j ? a.jitter : real(0));
+    }
+    if (threadIdx.x < m) vx[threadIdx.x] = a.v[ov + threadIdx.x];
+    chol_inv(R1, R2, ld, m);                       // R1 = Sigma_l^{-1}
+    mat_store(a.Si + om, R1, ld, m);
+    mat_vec(vy, R1, ld, vx, m, real(1));           // t = Si v
+    mat_gemm<false, false>(R2, R1, R0, ld, m, real(1));   // G = Si K
+    __syncthreads();
+    if (threadIdx.x < m) a.t[ov + threadIdx.x] = vy[threadIdx.x];
+    mat_store(a.G + om, R2, ld, m);
+    mat_gemm<false, false>(R3, R0, R2, ld, m, real(1));   // A = K G
+    mat_vec(vz, R0, ld, vy, m, a.c);               // mu_hat = c K t
+    __syncthreads();
+    mat_store(a.A + om, R3, ld, m);
+    if (threadIdx.x < m) a.mu[ov + threadIdx.x] = vz[threadIdx.x];
+    mat_load(R1, ld, a.Ki, m);                     // R1 = Ki   (Si, G no longer needed in LDS)
+    __syncthreads();
+    mat_vec(vx, R1, ld, vz, m, real(1));           // u = Ki mu_hat
+    // tr(Ki A) = sum_ij Ki_ij A_ji
+    real tr = 0;
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) tr += R1[(o / m) * ld + (o % m)] * R3[(o % m) * ld + (o / m)];
+    mat_gemm<false, false>(R2, R3, R1, ld, m, real(1));   // T = A Ki
+    __syncthreads();
+    tr = block_sum(tr, red);
+    real muu = 0;
+    if (threadIdx.x < m) {
+        a.u[ov + threadIdx.x] = vx[threadIdx.x];
+        muu = vz[threadIdx.x] * vx[threadIdx.x];
+    }
+    muu = block_sum(muu, red);
+    mat_gemm<false, false>(R0, R1, R2, ld, m, real(1));   // M2 = Ki A Ki   (K no longer needed)
+    __syncthreads();
+    mat_store(a.M2 + om, R0, ld, m);
+    if (threadIdx.x < m) R3[threadIdx.x * ld + threadIdx.x] += a.jitter;     // A + jitter I
+    const real ldA = chol_inv(R3, R2, ld, m);
+    mat_store(a.Aji + om, R3, ld, m);
+    if (threadIdx.x == 0) a.KL[l] = real(0.5) * (*a.ldK - ldA - (real)m + tr + muu);
+}
+
+// =============================================================================================
+// per-sample stage, forward.  grid (ceil(b/RB), L); thread (n_local, i), RB = 256 / m rows.
+// =============================================================================================
+struct PostArgs {
+    int b, m, L, n_rowblk_unused;
+    real c;
+    int use_rng;
+    const real* Kn; const real* knn; const real* q; const real* y; const real* s2;
+    const real* Si; const real* M2; const real* t; const real* u;
+    const real* eps_in; const real* state;
+    real* eps; real* p_m; real* p_v; real* e; real* d; real* z;
+    real* part;     // (L * gridDim.x, 2) partial [L3 data term, CE]
+};
+
+// Philox4x32-10 -> one N(0,1) double (Box-Muller on two 53-bit uniforms... 2 x 32-bit + 2 x 32-bit)
+__device__ __forceinline__ real philox_normal(unsigned long long ctr, unsigned long long idx) {
+    unsigned int c0 = (unsigned int)idx, c1 = (unsigned int)(idx >> 32), c2 = (unsigned int)ctr,
+                 c3 = (unsigned int)(ctr >> 32);
+    unsigned int k0 = 0x5356u, k1 = 0x47505641u;   // fixed key
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned int)p1;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned int)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const real u1 = ((real)(((unsigned long long)c0 << 21) ^ (unsigned long long)(c1 >> 11)) + real(0.5)) *
+                    (real(1) / real(9007199254740992.0));   // (0,1), 53 bits
+    const real u2 = ((real)(((unsigned long long)c2 << 21) ^ (unsigned long long)(c3 >> 11)) + real(0.5)) *
+                    (real(1) / real(9007199254740992.0));
+    return sqrt(real(-2) * log(u1)) * cos(real(6.283185307179586) * u2);
+}
+
+__global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_fwd(PostArgs a) {
+    extern __shared__ __align__(16) real smem[];
+    const int m = a.m, ld = m + 1, mm = m * ld, l = blockIdx.y;
+    real* R0 = smem;            // Si_l
+    real* R1 = R0 + mm;         // M2_l
+    real* tv = R1 + mm;         // t_l
+    real* uv = tv + m;          // u_l
+    real* kr = uv + m;          // RB x m
+    real* sc = kr + SVGP_BLOCK; // 4 x 256 partial products
+    real* red = sc + 4 * SVGP_BLOCK;
+    const int RB = blockDim.x / m;
+    const int nl = threadIdx.x / m, i = threadIdx.x % m, n = blockIdx.x * RB + nl;
+    const bool act = nl < RB && n < a.b;
+    const size_t om = (size_t)l * m * m;
+    mat_load(R0, ld, a.Si + om, m);
+    mat_load(R1, ld, a.M2 + om, m);
+    if (threadIdx.x < m) { tv[threadIdx.x] = a.t[(size_t)l * m + threadIdx.x]; uv[threadIdx.x] = a.u[(size_t)l * m + threadIdx.x]; }
+    if (act) kr[nl * m + i] = a.Kn[(size_t)n * m + i];
+    __syncthreads();
+    real r = 0, s = 0, pm = 0, mv = 0;
+    if (act) {
+        const real ki = kr[nl * m + i];
+        for (int j = 0; j < m; ++j) {
+            const real kj = kr[nl * m + j];
+            r += R0[j * ld + i] * kj;       // symmetric matrices: column walk = row walk
+            s += R1[j * ld + i] * kj;
+        }
+        r *= ki; s *= ki; pm = tv[i] * ki; mv = uv[i] * ki;
+    }
+    sc[threadIdx.x] = r; sc[SVGP_BLOCK + threadIdx.x] = s; sc[2 * SVGP_BLOCK + threadIdx.x] = pm;
+    sc[3 * SVGP_BLOCK + threadIdx.x] = mv;
+    __syncthreads();
+    real l3 = 0, ce = 0;
+    if (act && i == 0) {
+        real rs = 0, ss = 0, pms = 0, mvs = 0;
+        for (int k = 0; k < m; ++k) {
+            rs += sc[nl * m + k]; ss += sc[SVGP_BLOCK + nl * m + k];
+            pms += sc[2 * SVGP_BLOCK + nl * m + k]; mvs += sc[3 * SVGP_BLOCK + nl * m + k];
+        }
+        const size_t e = (size_t)n * a.L + l;
+        const real y = a.y[e], s2 = a.s2[e], p = recip_no_nan(s2);
+        const real kq = a.knn[n] - a.q[n];
+        const real p_m = a.c * pms, p_v = kq + rs, ee = y - mvs, dd = kq + ss + ee * ee;
+        real ep;
+        if (a.use_rng) ep = philox_normal((unsigned long long)a.state[SVGP_ST_RNG_CTR], (unsigned long long)e);
+        else ep = a.eps_in[e];
+        a.eps[e] = ep;
+        a.p_m[e] = p_m; a.p_v[e] = p_v; a.e[e] = ee; a.d[e] = dd;
+        a.z[e] = p_m + ep * sqrt(p_v);
+        const real ls2 = log(s2);
+        l3 = real(-0.5) * (p * dd + ls2);
+        const real dm = p_m - y;
+        ce = real(-0.5) * (real(SVGP_LOG_2PI) + ls2 + (p_v + dm * dm) * p);
+    }
+    l3 = block_sum(l3, red);
+    ce = block_sum(ce, red);
+    if (threadIdx.x == 0) {
+        const size_t pi = ((size_t)l * gridDim.x + blockIdx.x) * 2;
+        a.part[pi] = l3; a.part[pi + 1] = ce;
+    }
+}
+
+// =============================================================================================
+// m x m factor stage, reverse (per channel) + final K_bar assembly.
+// =============================================================================================
+struct FactBwdArgs {
+    int b_global, m, L, geco;
+    real c, N_train;
+    const real* state;
+    const real* K; const real* Ki; const real* S; const real* v; const real* Si; const real* t; const real* G;
+    const real* A; const real* Aji; const real* mu; const real* u; const real* M2;
+    const real* A2; const real* ud; const real* td;
+    real* Kbar_part; real* Kibar_part;     // (L,m,m) each
+    real* vbar; real* Ssym; real* Qm;
+    real* Kbar;                             // final (m,m)
+};
+
+__global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
+    extern __shared__ __align__(16) real smem[];
+    const int m = a.m, ld = m + 1, mm = m * ld, l = blockIdx.x;
+    real* R0 = smem;
+    real* R1 = R0 + mm;
+    real* R2 = R1 + mm;
+    real* R3 = R2 + mm;
+    real* ubar = R3 + mm;      // m
+    real* mubar = ubar + m;    // m
+    real* tbar = mubar + m;    // m
+    real* tv = tbar + m;       // m  (t_l)
+    real* vv = tv + m;         // m  (v_l)
+    real* muv = vv + m;        // m  (mu_hat_l)
+    const size_t om = (size_t)l * m * m, ov = (size_t)l * m;
+    const real gT = grad_KL_term(a.geco, a.L, a.state);
+    const real g3 = gT, gK = -gT * ((real)a.b_global / a.N_train);
+    real* Kb = a.Kbar_part + om;
+    real* Kib = a.Kibar_part + om;
+
+    mat_load(R0, ld, a.Ki, m);
+    mat_load(R1, ld, a.S + om, m);
+    if (threadIdx.x < m) {
+        muv[threadIdx.x] = a.mu[ov + threadIdx.x];
+        ubar[threadIdx.x] = a.ud[ov + threadIdx.x] + real(0.5) * gK * muv[threadIdx.x];
+        tv[threadIdx.x] = a.t[ov + threadIdx.x];
+        vv[threadIdx.x] = a.v[ov + threadIdx.x];
+    }
+    __syncthreads();
+    mat_vec(mubar, R0, ld, ubar, m, real(1));                       // Ki ubar
+    mat_gemm<false, false>(R2, R1, R0, ld, m, real(1));             // T1 = S Ki
+    __syncthreads();
+    if (threadIdx.x < m) mubar[threadIdx.x] += real(0.5) * gK * a.u[ov + threadIdx.x];
+    mat_gemm<false, false>(R3, R0, R2, ld, m, real(1));             // Ki S Ki
+    __syncthreads();
+    mat_load(R1, ld, a.Aji + om, m);
+    __syncthreads();
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {         // Abar
+        const int idx = (o / m) * ld + (o % m);
+        R3[idx] = real(-0.5) * g3 * R3[idx] + real(0.5) * gK * (R0[idx] - R1[idx]);
+    }
+    __syncthreads();
+    mat_load(R1, ld, a.A + om, m);
+    __syncthreads();
+    mat_gemm<false, false>(R0, R2, R1, ld, m, real(1));             // T1 A = S Ki A   (Ki dropped)
+    __syncthreads();
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {         // Kibar_l
+        const int i = o / m, j = o % m, idx = i * ld + j;
+        Kib[o] = -g3 * R0[idx] + real(0.5) * gK * R1[idx] + ubar[i] * muv[j] + real(0.5) * g3 * a.S[om + o] -
+                 a.A2[om + o];
+    }
+    __syncthreads();
+    mat_load(R0, ld, a.K, m);
+    __syncthreads();
+    mat_gemm<false, false>(R1, R0, R3, ld, m, real(1));             // Gbar = K Abar
+    mat_load(R2, ld, a.G + om, m);
+    __syncthreads();
+    mat_gemm_g<false, true>(Kb, R3, R2, ld, m, real(1), real(0));   // Kbar_l = Abar G^T
+    // tbar = td + c K mubar
+    if (threadIdx.x < m) {
+        real acc = 0;
+        for (int j = 0; j < m; ++j) acc += R0[threadIdx.x * ld + j] * mubar[j];
+        tbar[threadIdx.x] = a.td[ov + threadIdx.x] + a.c * acc;
+    }
+    __syncthreads();
+    mat_load(R2, ld, a.Si + om, m);
+    __syncthreads();
+    mat_gemm_g<false, false>(Kb, R2, R1, ld, m, real(1), real(1));  // += Si Gbar
+    mat_gemm<false, false>(R3, R1, R0, ld, m, real(1));             // Gbar K
+    __syncthreads();
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
+        const int i = o / m, j = o % m;
+        R3[i * ld + j] += a.A2[om + o] + tbar[i] * vv[j];           // Sibar
+        Kb[o] += a.c * mubar[i] * tv[j];
+    }
+    if (threadIdx.x < m) {                                          // vbar = Si tbar
+        real acc = 0;
+        for (int j = 0; j < m; ++j) acc += R2[threadIdx.x * ld + j] * tbar[j];
+        a.vbar[ov + threadIdx.x] = acc;
+    }
+    __syncthreads();
+    mat_gemm<false, false>(R1, R2, R3, ld, m, real(1));             // Si Sibar
+    __syncthreads();
+    mat_gemm<false, false>(R0, R1, R2, ld, m, real(-1));            // Sgbar = -Si Sibar Si
+    __syncthreads();
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
+        const int i = o / m, j = o % m;
+        Kb[o] += R0[i * ld + j];
+        const real ss = a.c * (R0[i * ld + j] + R0[j * ld + i]);
+        a.Ssym[om + o] = ss;
+        a.Qm[om + o] = ss - g3 * a.M2[om + o];
+    }
+}
+
+__global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd_final(FactBwdArgs a) {
+    extern __shared__ __align__(16) real smem[];
+    const int m = a.m, ld = m + 1, mm = m * ld;
+    real* R0 = smem;
+    real* R1 = R0 + mm;
+    real* R2 = R1 + mm;
+    real* R3 = R2 + mm;
+    const real gT = grad_KL_term(a.geco, a.L, a.state);
+    const real gK = -gT * ((real)a.b_global / a.N_train);
+    mat_load(R0, ld, a.Ki, m);
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
+        real s = 0;
+        for (int l = 0; l < a.L; ++l) s += a.Kibar_part[(size_t)l * m * m + o];
+        R1[(o / m) * ld + (o % m)] = s;
+    }
+    __syncthreads();
+    mat_gemm<false, false>(R2, R0, R1, ld, m, real(1));
+    __syncthreads();
+    mat_gemm<false, false>(R3, R2, R0, ld, m, real(1));     // Ki Kibar Ki
+    __syncthreads();
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
+        real s = 0;
+        for (int l = 0; l < a.L; ++l) s += a.Kbar_part[(size_t)l * m * m + o];
+        const int idx = (o / m) * ld + (o % m);
+        a.Kbar[o] = s - R3[idx] + real(0.5) * gK * (real)a.L * R0[idx];
+    }
+}
+
+// =============================================================================================
+// per-sample stage, reverse.  Pass 1 grid (ceil(b/RB), L): per-channel row terms.
+// Pass 2 grid ceil(b/RB): sum over channels + the Ki term.
+// =============================================================================================
+struct PostBwdArgs {
+    int b, m, L, geco;
+    real c;
+    const real* state;
+    const real* Kn; const real* y; const real* s2; const real* p_m; const real* p_v; const real* e; const real* d;
+    const real* g_pv; const real* g_pm; const real* mvbar;
+    const real* Si; const real* Qm; const real* Ssym; const real* u; const real* t; const real* vbar; const real* Ki;
+    real* Knbar_part;   // (L, b, m)
+    real* Knbar; real* knnbar; real* ybar; real* s2bar;
+};
+
+__global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_l(PostBwdArgs a) {
+    extern __shared__ __align__(16) real smem[];
+    const int m = a.m, ld = m + 1, mm = m * ld, l = blockIdx.y;
+    real* R0 = smem;            // Si_l
+    real* R1 = R0 + mm;         // Q_l
+    real* R2 = R1 + mm;         // Ssym_l
+    real* uv = R2 + mm;         // u_l
+    real* tv = uv + m;          // t_l
+    real* vb = tv + m;          // vbar_l
+    real* kr = vb + m;          // RB x m
+    real* sc = kr + SVGP_BLOCK; // 2 x 256
+    const int RB = blockDim.x / m;
+    const int nl = threadIdx.x / m, i = threadIdx.x % m, n = blockIdx.x * RB + nl;
+    const bool act = nl < RB && n < a.b;
+    const size_t om = (size_t)l * m * m, ov = (size_t)l * m;
+    mat_load(R0, ld, a.Si + om, m);
+    mat_load(R1, ld, a.Qm + om, m);
+    mat_load(R2, ld, a.Ssym + om, m);
+    if (threadIdx.x < m) { uv[threadIdx.x] = a.u[ov + threadIdx.x]; tv[threadIdx.x] = a.t[ov + threadIdx.x]; vb[threadIdx.x] = a.vbar[ov + threadIdx.x]; }
+    if (act) kr[nl * m + i] = a.Kn[(size_t)n * m + i];
+    __syncthreads();
+    const real gT = grad_KL_term(a.geco, a.L, a.state);
+    const real g3 = gT;
+    real ksk = 0, kv = 0;
+    if (act) {
+        const size_t e = (size_t)n * a.L + l;
+        const real p = recip_no_nan(a.s2[e]), gpv = a.g_pv[e];
+        real sik = 0, qk = 0, ssk = 0;
+        for (int j = 0; j < m; ++j) {
+            const real kj = kr[nl * m + j];
+            sik += R0[j * ld + i] * kj;
+            qk += R1[j * ld + i] * kj;
+            ssk += R2[j * ld + i] * kj;
+        }
+        const real ki = kr[nl * m + i];
+        a.Knbar_part[((size_t)l * a.b + n) * m + i] = real(2) * gpv * sik + p * qk + a.mvbar[e] * uv[i] +
+                                                      a.c * a.g_pm[e] * tv[i] + p * a.y[e] * vb[i];
+        ksk = real(0.5) * ssk * ki;
+        kv = vb[i] * ki;
+    }
+    sc[threadIdx.x] = ksk; sc[SVGP_BLOCK + threadIdx.x] = kv;
+    __syncthreads();
+    if (act && i == 0) {
+        real kS = 0, kV = 0;
+        for (int k = 0; k < m; ++k) { kS += sc[nl * m + k]; kV += sc[SVGP_BLOCK + nl * m + k]; }
+        const size_t e = (size_t)n * a.L + l;
+        const real y = a.y[e], s2 = a.s2[e], p = recip_no_nan(s2);
+        const real dm = a.p_m[e] - y;
+        const real pbar = real(-0.5) * g3 * a.d[e] + kS + y * kV;
+        const real ce_y = -gT * p * dm;
+        const real ce_s2 = real(0.5) * gT * (p - (a.p_v[e] + dm * dm) * p * p);
+        a.ybar[e] = ce_y - g3 * p * a.e[e] + p * kV;
+        a.s2bar[e] = ce_s2 - real(0.5) * g3 * p - pbar * p * p;
+    }
+}
+
+__global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_sum(PostBwdArgs a) {
+    extern __shared__ __align__(16) real smem[];
+    const int m = a.m, ld = m + 1, mm = m * ld;
+    real* R0 = smem;            // Ki
+    real* kr = R0 + mm;         // RB x m
+    real* qb = kr + SVGP_BLOCK; // RB
+    const int RB = blockDim.x / m;
+    const int nl = threadIdx.x / m, i = threadIdx.x % m, n = blockIdx.x * RB + nl;
+    const bool act = nl < RB && n < a.b;
+    mat_load(R0, ld, a.Ki, m);
+    if (act) kr[nl * m + i] = a.Kn[(size_t)n * m + i];
+    const real gT = grad_KL_term(a.geco, a.L, a.state);
+    if (act && i == 0) {
+        real qbar = 0;
+        for (int l = 0; l < a.L; ++l) {
+            const size_t e = (size_t)n * a.L + l;
+            qbar += real(0.5) * gT * recip_no_nan(a.s2[e]) - a.g_pv[e];
+        }
+        qb[nl] = qbar;
+        a.knnbar[n] = -qbar;
+    }
+    __syncthreads();
+    if (act) {
+        real acc = 0;
+        for (int l = 0; l < a.L; ++l) acc += a.Knbar_part[((size_t)l * a.b + n) * m + i];
+        real w = 0;
+        for (int j = 0; j < m; ++j) w += R0[j * ld + i] * kr[nl * m + j];
+        a.Knbar[(size_t)n * m + i] = acc + real(2) * qb[nl] * w;
+    }
+}
+
+template <typename F>
+int set_dyn_lds(F kernel, size_t bytes) {
+    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return SVGP_OK;
+}
+
+KernArgs make_kern_args(const svgp_mnist_cfg* c, const svgp_mnist_param_layout& pl, const double* theta,
+                        const double* aux) {
+    KernArgs a;
+    a.b = c->b; a.m = c->m; a.M = c->M; a.n_obj = c->n_obj; a.normalize = c->normalize_obj;
+    a.aux = aux; a.ip = theta + pl.ip; a.ov = theta + pl.ov; a.ls = theta + pl.l_GP; a.amp = theta + pl.amplitude;
+    return a;
+}
+
+}  // namespace
+
+#define GET_LAYOUTS()                                          \
+    svgp_mnist_param_layout pl;                                \
+    svgp_mnist_ws_layout wl;                                   \
+    {                                                          \
+        int rc_ = svgp_mnist_param_layout_get(c, &pl);         \
+        if (rc_) return rc_;                                   \
+        rc_ = svgp_mnist_ws_layout_get(c, &wl);                \
+        if (rc_) return rc_;                                   \
+    }
+
+static inline size_t mat_lds(int m, int nmat) { return (size_t)nmat * m * (m + 1) * sizeof(real); }
+
+extern "C" int svgp_kernel_matrix_fwd(const svgp_mnist_cfg* c, const double* theta, const double* aux, double* ws,
+                                      void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(theta && aux && ws, SVGP_ERR_INVALID, "NULL device pointer");
+    KernArgs a = make_kern_args(c, pl, theta, aux);
+    const long long total = (long long)c->b * c->m + (long long)c->m * c->m + c->b;
+    hipLaunchKernelGGL(k_kernel_matrix_fwd, dim3((unsigned)((total + SVGP_BLOCK - 1) / SVGP_BLOCK)), dim3(SVGP_BLOCK), 0,
+                       (hipStream_t)stream, a, ws + wl.K, ws + wl.Kn, ws + wl.knn);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+extern "C" int svgp_kernel_matrix_bwd(const svgp_mnist_cfg* c, const double* theta, const double* aux, double* ws,
+                                      void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(theta && aux && ws, SVGP_ERR_INVALID, "NULL device pointer");
+    KernArgs a = make_kern_args(c, pl, theta, aux);
+    real* grad = ws + wl.grad;
+    hipLaunchKernelGGL(k_kernel_matrix_bwd_cols, dim3(c->m), dim3(SVGP_BLOCK), 0, (hipStream_t)stream, a,
+                       c->rep_weight, c->train_ip, ws + wl.K, ws + wl.Kn, ws + wl.Kbar, ws + wl.Knbar, grad + pl.ip,
+                       ws + wl.part_gp);
+    SVGP_LAUNCH_CHECK();
+    const int nrb = svgp_n_rowblk(c);
+    hipLaunchKernelGGL(k_kernel_matrix_bwd_rows, dim3(nrb), dim3(64), 0, (hipStream_t)stream, a, ws + wl.Knbar,
+                       ws + wl.knnbar, ws + wl.knn, ws + wl.d_on, ws + wl.part_gp);
+    SVGP_LAUNCH_CHECK();
+    const int n_ov = c->n_obj * c->M;
+    hipLaunchKernelGGL(k_kernel_matrix_bwd_scatter, dim3((n_ov + SVGP_BLOCK - 1) / SVGP_BLOCK + 1), dim3(SVGP_BLOCK), 0,
+                       (hipStream_t)stream, a, c->m + nrb, c->train_gp, c->train_ov, ws + wl.d_on, ws + wl.part_gp,
+                       grad + pl.ov, grad + pl.l_GP, grad + pl.amplitude);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
+                        int mode, void* stream) {
+    StatArgs a;
+    memset(&a, 0, sizeof(a));
+    a.b = c->b; a.m = c->m; a.L = c->L; a.mode = mode; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;
+    a.geco = c->geco;
+    a.Kn = ws + wl.Kn; a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var;
+    a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v; a.e = ws + wl.e; a.eps = ws + wl.eps; a.zbar = ws + wl.zbar;
+    a.state = state;
+    a.g_pv = ws + wl.g_pv; a.g_pm = ws + wl.g_pm; a.mvbar = ws + wl.mvbar;
+    if (mode == 0) { a.S = ws + wl.S; a.v1 = ws + wl.v; a.v2 = nullptr; }
+    else { a.S = ws + wl.A2; a.v1 = ws + wl.ud; a.v2 = ws + wl.td; }
+    a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.ldK = ws + wl.ldK;
+    const int m = c->m;
+    size_t lds = (size_t)(STAT_RC * m + 3 * STAT_RC) * sizeof(real);
+    const size_t lds_inv = mat_lds(m, 2);
+    if (mode == 0 && lds_inv > lds) lds = lds_inv;
+    int rc = set_dyn_lds(k_gp_stats, lds);
+    if (rc) return rc;
+    const int T = (m * m + SVGP_BLOCK - 1) / SVGP_BLOCK;
+    hipLaunchKernelGGL(k_gp_stats, dim3(T, c->L + (mode == 0 ? 1 : 0)), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+extern "C" int svgp_gp_stats_fwd(const svgp_mnist_cfg* c, double* ws, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
+    return launch_stats(c, wl, ws, nullptr, 0, stream);
+}
+
+extern "C" int svgp_gp_stats_bwd(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    return launch_stats(c, wl, ws, state, 1, stream);
+}
+
+static inline int rows_per_block(int m) { return SVGP_BLOCK / m; }
+
+extern "C" int svgp_gp_factor_fwd(const svgp_mnist_cfg* c, double* ws, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
+    FactArgs a;
+    a.b = c->b; a.m = c->m; a.L = c->L; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;
+    a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.ldK = ws + wl.ldK; a.S = ws + wl.S; a.v = ws + wl.v; a.Kn = ws + wl.Kn;
+    a.Si = ws + wl.Si; a.t = ws + wl.t; a.G = ws + wl.G; a.A = ws + wl.A; a.Aji = ws + wl.Aji; a.mu = ws + wl.mu_hat;
+    a.u = ws + wl.u; a.M2 = ws + wl.M2; a.KL = ws + wl.KL; a.q = ws + wl.q;
+    const int m = c->m, RB = rows_per_block(m);
+    const size_t lds = mat_lds(m, 4) + (size_t)(3 * m + 16 + SVGP_BLOCK) * sizeof(real);
+    int rc = set_dyn_lds(k_gp_factor_fwd, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gp_factor_fwd, dim3(c->L + (c->b + RB - 1) / RB), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+extern "C" int svgp_gp_posterior_fwd(const svgp_mnist_cfg* c, const double* eps, double* ws, double* state,
+                                     void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    PostArgs a;
+    a.b = c->b; a.m = c->m; a.L = c->L; a.n_rowblk_unused = 0; a.c = c->N_train / (double)c->b_global;
+    a.use_rng = eps == nullptr;
+    a.Kn = ws + wl.Kn; a.knn = ws + wl.knn; a.q = ws + wl.q; a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var;
+    a.Si = ws + wl.Si; a.M2 = ws + wl.M2; a.t = ws + wl.t; a.u = ws + wl.u; a.eps_in = eps; a.state = state;
+    a.eps = ws + wl.eps; a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v; a.e = ws + wl.e; a.d = ws + wl.d; a.z = ws + wl.z;
+    a.part = ws + wl.part_sums + (size_t)svgp_n_part(c) * 4;
+    const int m = c->m, RB = rows_per_block(m), nb = (c->b + RB - 1) / RB;
+    SVGP_REQUIRE((int64_t)c->L * nb == wl.n_post, SVGP_ERR_INVALID, "partial-sum layout mismatch");
+    const size_t lds = mat_lds(m, 2) + (size_t)(2 * m + SVGP_BLOCK + 4 * SVGP_BLOCK + 16) * sizeof(real);
+    int rc = set_dyn_lds(k_gp_posterior_fwd, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gp_posterior_fwd, dim3(nb, c->L), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+static FactBwdArgs make_fb(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state) {
+    FactBwdArgs a;
+    a.b_global = c->b_global; a.m = c->m; a.L = c->L; a.geco = c->geco; a.c = c->N_train / (double)c->b_global;
+    a.N_train = c->N_train; a.state = state;
+    a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.S = ws + wl.S; a.v = ws + wl.v; a.Si = ws + wl.Si; a.t = ws + wl.t;
+    a.G = ws + wl.G; a.A = ws + wl.A; a.Aji = ws + wl.Aji; a.mu = ws + wl.mu_hat; a.u = ws + wl.u; a.M2 = ws + wl.M2;
+    a.A2 = ws + wl.A2; a.ud = ws + wl.ud; a.td = ws + wl.td;
+    a.Kbar_part = ws + wl.fb_part;            // scratch (L,m,m)
+    a.Kibar_part = ws + wl.fb_part + (size_t)c->L * c->m * c->m;
+    a.vbar = ws + wl.vbar; a.Ssym = ws + wl.Ssym; a.Qm = ws + wl.Qm; a.Kbar = ws + wl.Kbar;
+    return a;
+}
+
+extern "C" int svgp_gp_factor_bwd(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    FactBwdArgs a = make_fb(c, wl, ws, state);
+    const int m = c->m;
+    const size_t lds = mat_lds(m, 4) + (size_t)(6 * m) * sizeof(real);
+    int rc = set_dyn_lds(k_gp_factor_bwd, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gp_factor_bwd, dim3(c->L), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    SVGP_LAUNCH_CHECK();
+    const size_t lds2 = mat_lds(m, 4);
+    rc = set_dyn_lds(k_gp_factor_bwd_final, lds2);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gp_factor_bwd_final, dim3(1), dim3(SVGP_BLOCK), lds2, (hipStream_t)stream, a);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+extern "C" int svgp_gp_posterior_bwd(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    PostBwdArgs a;
+    a.b = c->b; a.m = c->m; a.L = c->L; a.geco = c->geco; a.c = c->N_train / (double)c->b_global; a.state = state;
+    a.Kn = ws + wl.Kn; a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var; a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v;
+    a.e = ws + wl.e; a.d = ws + wl.d; a.g_pv = ws + wl.g_pv; a.g_pm = ws + wl.g_pm; a.mvbar = ws + wl.mvbar;
+    a.Si = ws + wl.Si; a.Qm = ws + wl.Qm; a.Ssym = ws + wl.Ssym; a.u = ws + wl.u; a.t = ws + wl.t; a.vbar = ws + wl.vbar;
+    a.Ki = ws + wl.Ki;
+    a.Knbar_part = ws + wl.Knbar_part;
+    a.Knbar = ws + wl.Knbar; a.knnbar = ws + wl.knnbar; a.ybar = ws + wl.ybar; a.s2bar = ws + wl.s2bar;
+    const int m = c->m, RB = rows_per_block(m), nb = (c->b + RB - 1) / RB;
+    const size_t lds = mat_lds(m, 3) + (size_t)(3 * m + SVGP_BLOCK + 2 * SVGP_BLOCK) * sizeof(real);
+    int rc = set_dyn_lds(k_gp_posterior_bwd_l, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gp_posterior_bwd_l, dim3(nb, c->L), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    SVGP_LAUNCH_CHECK();
+    const size_t lds2 = mat_lds(m, 1) + (size_t)(SVGP_BLOCK + SVGP_BLOCK) * sizeof(real);
+    rc = set_dyn_lds(k_gp_posterior_bwd_sum, lds2);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_gp_posterior_bwd_sum, dim3(nb), dim3(SVGP_BLOCK), lds2, (hipStream_t)stream, a);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}

@@ -1,0 +1,519 @@
+// mnistVAE encoder / decoder, forward and reverse, for gfx950.
+//
+// Reference semantics: VAE_utils.py:99-162 (Keras NHWC, 3x3 kernels (kh,kw,cin,cout), ELU after
+// every conv incl. the last decoder conv, 'valid' encoder convs with stride 2, decoder
+// UpSampling2D(2) nearest + conv 'same'/'valid'/'same').
+//
+// Design: one workgroup (256 threads = 4 waves) owns one image at a time; all activations of an
+// image (13.5 k values) and all weights stay in LDS, so HBM traffic is exactly: image in,
+// activations out once (kept for the reverse pass), weight-gradient partials out once per
+// workgroup.  UpSampling2D is never materialised (index >> 1 on the LDS read).  Weight gradients
+// are accumulated in LDS over the images a workgroup walks and written as per-workgroup partials;
+// svgp_mnist_grad_reduce sums them in a fixed order (bitwise reproducible, no float atomics).
+#include "common.hpp"
+
+namespace {
+
+// 3x3 convolution on an LDS-resident NHWC tile.  Stored input is HS x HS x CIN; the effective
+// input is its nearest-neighbour upsampling by UPS (HE = HS*UPS) zero-padded by PAD.
+template <int HS, int UPS, int PAD, int STRIDE, int CIN, int COUT, int HOUT>
+struct Conv3 {
+    static constexpr int HE = HS * UPS;
+    static constexpr int NW = 9 * CIN * COUT;
+    static constexpr int NOUT = HOUT * HOUT * COUT;
+    static constexpr int NIN = HS * HS * CIN;
+    static constexpr int NPIX = HOUT * HOUT;
+
+    // out = elu(conv(in) + bias)
+    static __device__ void fwd(const real* in, const real* w, const real* bias, real* out) {
+        for (int o = threadIdx.x; o < NOUT; o += blockDim.x) {
+            const int co = o % COUT, x = (o / COUT) % HOUT, y = o / (COUT * HOUT);
+            real acc = bias[co];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = y * STRIDE + ky - PAD;
+                if ((unsigned)iy >= (unsigned)HE) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = x * STRIDE + kx - PAD;
+                    if ((unsigned)ix >= (unsigned)HE) continue;
+                    const real* src = in + ((iy / UPS) * HS + ix / UPS) * CIN;
+                    const real* wk = w + ((ky * 3 + kx) * CIN) * COUT + co;
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) acc += src[ci] * wk[ci * COUT];
+                }
+            }
+            out[o] = elu_f(acc);
+        }
+    }
+
+    // din (stored coordinates, HS x HS x CIN) = conv^T(dpre) summed over the UPS x UPS replicas
+    static __device__ void bwd_data(const real* dpre, const real* w, real* din) {
+        for (int i = threadIdx.x; i < NIN; i += blockDim.x) {
+            const int ci = i % CIN, xs = (i / CIN) % HS, ys = i / (CIN * HS);
+            real acc = 0;
+#pragma unroll
+            for (int dy = 0; dy < UPS; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < UPS; ++dx) {
+                    const int ye = ys * UPS + dy, xe = xs * UPS + dx;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const int ty = ye + PAD - ky;
+                        if (ty < 0 || (ty % STRIDE) != 0) continue;
+                        const int y = ty / STRIDE;
+                        if (y >= HOUT) continue;
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const int tx = xe + PAD - kx;
+                            if (tx < 0 || (tx % STRIDE) != 0) continue;
+                            const int x = tx / STRIDE;
+                            if (x >= HOUT) continue;
+                            const real* dp = dpre + (y * HOUT + x) * COUT;
+                            const real* wk = w + ((ky * 3 + kx) * CIN + ci) * COUT;
+#pragma unroll
+                            for (int co = 0; co < COUT; ++co) acc += dp[co] * wk[co];
+                        }
+                    }
+                }
+            din[i] = acc;
+        }
+    }
+
+    // gw[(ky,kx,ci,co)] += sum_pixels in * dpre ;  gb[co] += sum_pixels dpre.
+    // scratch: >= 256 reals of LDS.  Ends with a barrier.
+    static __device__ void bwd_weight(const real* in, const real* dpre, real* gw, real* gb, real* scratch) {
+        constexpr int NCH = (NW >= SVGP_BLOCK) ? 1 : (SVGP_BLOCK / NW);   // pixel chunks per weight
+        if (NCH == 1) {
+            for (int widx = threadIdx.x; widx < NW; widx += blockDim.x) gw[widx] += wsum(in, dpre, widx, 0, 1);
+        } else {
+            const int chunk = threadIdx.x / NW, widx = threadIdx.x % NW;
+            if (chunk < NCH) scratch[chunk * NW + widx] = wsum(in, dpre, widx, chunk, NCH);
+            __syncthreads();
+            if (threadIdx.x < NW) {
+                real s = 0;
+                for (int c = 0; c < NCH; ++c) s += scratch[c * NW + threadIdx.x];
+                gw[threadIdx.x] += s;
+            }
+        }
+        __syncthreads();
+        // bias: thread t -> (co = t % COUT, pixel chunk t / COUT)
+        constexpr int BCH = SVGP_BLOCK / COUT;
+        {
+            const int co = threadIdx.x % COUT, chunk = threadIdx.x / COUT;
+            real s = 0;
+            if (chunk < BCH)
+                for (int p = chunk; p < NPIX; p += BCH) s += dpre[p * COUT + co];
+            scratch[threadIdx.x] = (chunk < BCH) ? s : real(0);
+            __syncthreads();
+            if (threadIdx.x < COUT) {
+                real t = 0;
+                for (int c = 0; c < BCH; ++c) t += scratch[c * COUT + threadIdx.x];
+                gb[threadIdx.x] += t;
+            }
+        }
+        __syncthreads();
+    }
+
+    static __device__ __forceinline__ real wsum(const real* in, const real* dpre, int widx, int p0, int pstep) {
+        const int co = widx % COUT, ci = (widx / COUT) % CIN, kx = (widx / (COUT * CIN)) % 3,
+                  ky = widx / (COUT * CIN * 3);
+        real acc = 0;
+        for (int p = p0; p < NPIX; p += pstep) {
+            const int y = p / HOUT, x = p % HOUT;
+            const int iy = y * STRIDE + ky - PAD, ix = x * STRIDE + kx - PAD;
+            if ((unsigned)iy >= (unsigned)HE || (unsigned)ix >= (unsigned)HE) continue;
+            acc += in[((iy / UPS) * HS + ix / UPS) * CIN + ci] * dpre[p * COUT + co];
+        }
+        return acc;
+    }
+};
+
+using EncC1 = Conv3<28, 1, 0, 2, 1, 8, 13>;
+using EncC2 = Conv3<13, 1, 0, 2, 8, 8, 6>;
+using EncC3 = Conv3<6, 1, 0, 2, 8, 8, 2>;
+using DecC1 = Conv3<4, 2, 1, 1, 8, 8, 8>;
+using DecC2 = Conv3<8, 2, 0, 1, 8, 8, 14>;
+using DecC3 = Conv3<14, 2, 1, 1, 8, 1, 28>;
+
+__device__ __forceinline__ void lds_copy_in(real* dst, const real* __restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+__device__ __forceinline__ void lds_copy_out(real* __restrict__ dst, const real* src, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+__device__ __forceinline__ void lds_zero(real* dst, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = 0;
+}
+
+struct EncOff { int c1w, c1b, c2w, c2b, c3w, c3b, dw, db, n; };
+struct DecOff { int dw, db, c1w, c1b, c2w, c2b, c3w, c3b, n; };
+
+__device__ __host__ inline EncOff enc_off(int L) {
+    EncOff o; int p = 0;
+    o.c1w = p; p += 72; o.c1b = p; p += 8; o.c2w = p; p += 576; o.c2b = p; p += 8;
+    o.c3w = p; p += 576; o.c3b = p; p += 8; o.dw = p; p += 32 * 2 * L; o.db = p; p += 2 * L; o.n = p;
+    return o;
+}
+__device__ __host__ inline DecOff dec_off(int L) {
+    DecOff o; int p = 0;
+    o.dw = p; p += L * 128; o.db = p; p += 128; o.c1w = p; p += 576; o.c1b = p; p += 8;
+    o.c2w = p; p += 576; o.c2b = p; p += 8; o.c3w = p; p += 72; o.c3b = p; p += 1; o.n = p;
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------
+// encoder forward: images -> a1,a2,a3 (saved), qnet_mu, qnet_var_raw = exp(.), qnet_var = clip
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SVGP_BLOCK) void k_encoder_fwd(int b, int L, int clip, const real* __restrict__ th_enc,
+                                                            const real* __restrict__ images, real* __restrict__ a1g,
+                                                            real* __restrict__ a2g, real* __restrict__ a3g,
+                                                            real* __restrict__ mu, real* __restrict__ var_raw,
+                                                            real* __restrict__ var) {
+    extern __shared__ __align__(16) real smem[];
+    const EncOff eo = enc_off(L);
+    real* w = smem;                 // eo.n
+    real* img = w + eo.n;           // 784
+    real* a1 = img + 784;           // 1352
+    real* a2 = a1 + 1352;           // 288
+    real* a3 = a2 + 288;            // 32
+    lds_copy_in(w, th_enc, eo.n);
+    for (int n = blockIdx.x; n < b; n += gridDim.x) {
+        __syncthreads();
+        lds_copy_in(img, images + (size_t)n * 784, 784);
+        __syncthreads();
+        EncC1::fwd(img, w + eo.c1w, w + eo.c1b, a1);
+        __syncthreads();
+        EncC2::fwd(a1, w + eo.c2w, w + eo.c2b, a2);
+        __syncthreads();
+        EncC3::fwd(a2, w + eo.c3w, w + eo.c3b, a3);
+        __syncthreads();
+        lds_copy_out(a1g + (size_t)n * 1352, a1, 1352);
+        lds_copy_out(a2g + (size_t)n * 288, a2, 288);
+        lds_copy_out(a3g + (size_t)n * 32, a3, 32);
+        const int twoL = 2 * L;
+        for (int j = threadIdx.x; j < twoL; j += blockDim.x) {
+            real acc = w[eo.db + j];
+            for (int i = 0; i < 32; ++i) acc += a3[i] * w[eo.dw + i * twoL + j];
+            if (j < L) {
+                mu[(size_t)n * L + j] = acc;
+            } else {
+                const real vr = exp(acc);
+                var_raw[(size_t)n * L + j - L] = vr;
+                var[(size_t)n * L + j - L] = clip ? fmin(fmax(vr, 1e-3), 10.0) : vr;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// encoder reverse: (ybar, s2bar) -> encoder weight-gradient partials
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SVGP_BLOCK) void k_encoder_bwd(int b, int L, int clip, const real* __restrict__ th_enc,
+                                                            const real* __restrict__ images,
+                                                            const real* __restrict__ a1g, const real* __restrict__ a2g,
+                                                            const real* __restrict__ a3g,
+                                                            const real* __restrict__ var_raw,
+                                                            const real* __restrict__ ybar,
+                                                            const real* __restrict__ s2bar, real* __restrict__ part) {
+    extern __shared__ __align__(16) real smem[];
+    const EncOff eo = enc_off(L);
+    real* w = smem;                  // eo.n
+    real* g = w + eo.n;              // eo.n   gradient accumulators
+    real* img = g + eo.n;            // 784
+    real* a1 = img + 784;            // 1352
+    real* a2 = a1 + 1352;            // 288
+    real* a3 = a2 + 288;             // 32
+    real* d1 = a3 + 32;              // 1352
+    real* d2 = d1 + 1352;            // 288
+    real* d3 = d2 + 288;             // 32
+    real* dout = d3 + 32;            // 2L (<=128)
+    real* scratch = dout + 128;      // 256
+    lds_copy_in(w, th_enc, eo.n);
+    lds_zero(g, eo.n);
+    const int twoL = 2 * L;
+    for (int n = blockIdx.x; n < b; n += gridDim.x) {
+        __syncthreads();
+        lds_copy_in(img, images + (size_t)n * 784, 784);
+        lds_copy_in(a1, a1g + (size_t)n * 1352, 1352);
+        lds_copy_in(a2, a2g + (size_t)n * 288, 288);
+        lds_copy_in(a3, a3g + (size_t)n * 32, 32);
+        for (int j = threadIdx.x; j < twoL; j += blockDim.x) {
+            real dj;
+            if (j < L) {
+                dj = ybar[(size_t)n * L + j];
+            } else {
+                const real vr = var_raw[(size_t)n * L + j - L];
+                const bool pass = !clip || (vr >= 1e-3 && vr <= 10.0);
+                dj = pass ? s2bar[(size_t)n * L + j - L] * vr : real(0);
+            }
+            dout[j] = dj;
+        }
+        __syncthreads();
+        // dense: weight / bias gradients and da3
+        for (int o = threadIdx.x; o < 32 * twoL; o += blockDim.x) g[eo.dw + o] += a3[o / twoL] * dout[o % twoL];
+        for (int j = threadIdx.x; j < twoL; j += blockDim.x) g[eo.db + j] += dout[j];
+        if (threadIdx.x < 32) {
+            real acc = 0;
+            for (int j = 0; j < twoL; ++j) acc += dout[j] * w[eo.dw + threadIdx.x * twoL + j];
+            d3[threadIdx.x] = acc * elu_grad_from_out(a3[threadIdx.x]);
+        }
+        __syncthreads();
+        EncC3::bwd_weight(a2, d3, g + eo.c3w, g + eo.c3b, scratch);
+        EncC3::bwd_data(d3, w + eo.c3w, d2);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 288; i += blockDim.x) d2[i] *= elu_grad_from_out(a2[i]);
+        __syncthreads();
+        EncC2::bwd_weight(a1, d2, g + eo.c2w, g + eo.c2b, scratch);
+        EncC2::bwd_data(d2, w + eo.c2w, d1);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1352; i += blockDim.x) d1[i] *= elu_grad_from_out(a1[i]);
+        __syncthreads();
+        EncC1::bwd_weight(img, d1, g + eo.c1w, g + eo.c1b, scratch);
+    }
+    __syncthreads();
+    lds_copy_out(part + (size_t)blockIdx.x * eo.n, g, eo.n);
+}
+
+// ------------------------------------------------------------------------------------------
+// decoder forward: z -> h0, a1, a2 (saved), recon, per-workgroup sum of squared errors
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SVGP_BLOCK) void k_decoder_fwd(int b, int L, const real* __restrict__ th_dec,
+                                                            const real* __restrict__ images,
+                                                            const real* __restrict__ zg, real* __restrict__ h0g,
+                                                            real* __restrict__ a1g, real* __restrict__ a2g,
+                                                            real* __restrict__ recon, real* __restrict__ part_sums) {
+    extern __shared__ __align__(16) real smem[];
+    const DecOff od = dec_off(L);
+    real* w = smem;                  // od.n
+    real* z = w + od.n;              // 64
+    real* h0 = z + 64;               // 128
+    real* a1 = h0 + 128;             // 512
+    real* a2 = a1 + 512;             // 1568
+    real* out = a2 + 1568;           // 784
+    real* red = out + 784;           // 16
+    lds_copy_in(w, th_dec, od.n);
+    real sq = 0;
+    for (int n = blockIdx.x; n < b; n += gridDim.x) {
+        __syncthreads();
+        lds_copy_in(z, zg + (size_t)n * L, L);
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            real acc = w[od.db + threadIdx.x];
+            for (int i = 0; i < L; ++i) acc += z[i] * w[od.dw + i * 128 + threadIdx.x];
+            h0[threadIdx.x] = acc;
+        }
+        __syncthreads();
+        DecC1::fwd(h0, w + od.c1w, w + od.c1b, a1);
+        __syncthreads();
+        DecC2::fwd(a1, w + od.c2w, w + od.c2b, a2);
+        __syncthreads();
+        DecC3::fwd(a2, w + od.c3w, w + od.c3b, out);
+        __syncthreads();
+        lds_copy_out(h0g + (size_t)n * 128, h0, 128);
+        lds_copy_out(a1g + (size_t)n * 512, a1, 512);
+        lds_copy_out(a2g + (size_t)n * 1568, a2, 1568);
+        for (int i = threadIdx.x; i < 784; i += blockDim.x) {
+            const real o = out[i];
+            recon[(size_t)n * 784 + i] = o;
+            const real df = images[(size_t)n * 784 + i] - o;
+            sq += df * df;
+        }
+    }
+    const real tot = block_sum(sq, red);
+    if (threadIdx.x == 0) part_sums[blockIdx.x * 4 + 2] = tot;
+}
+
+// ------------------------------------------------------------------------------------------
+// decoder reverse: d loss / d recon -> zbar, decoder weight-gradient partials
+// gscale = d loss / d (sum of squared errors): beta-ELBO 1/784; GECO lagrange_mult/(b_global*784)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SVGP_BLOCK) void k_decoder_bwd(int b, int L, int geco, real inv_bglobal,
+                                                            const real* __restrict__ state,
+                                                            const real* __restrict__ th_dec,
+                                                            const real* __restrict__ images,
+                                                            const real* __restrict__ zg, const real* __restrict__ h0g,
+                                                            const real* __restrict__ a1g, const real* __restrict__ a2g,
+                                                            const real* __restrict__ recon, real* __restrict__ zbar,
+                                                            real* __restrict__ part) {
+    extern __shared__ __align__(16) real smem[];
+    const DecOff od = dec_off(L);
+    real* w = smem;                  // od.n
+    real* g = w + od.n;              // od.n
+    real* z = g + od.n;              // 64
+    real* h0 = z + 64;               // 128
+    real* a1 = h0 + 128;             // 512
+    real* a2 = a1 + 512;             // 1568
+    real* d3 = a2 + 1568;            // 784
+    real* d2 = d3 + 784;             // 1568
+    real* d1 = d2 + 1568;            // 512
+    real* dh0 = d1 + 512;            // 128
+    real* scratch = dh0 + 128;       // 256
+    lds_copy_in(w, th_dec, od.n);
+    lds_zero(g, od.n);
+    const real gscale = (geco ? state[SVGP_ST_LAGRANGE] * inv_bglobal : real(1)) / real(784);
+    for (int n = blockIdx.x; n < b; n += gridDim.x) {
+        __syncthreads();
+        lds_copy_in(z, zg + (size_t)n * L, L);
+        lds_copy_in(h0, h0g + (size_t)n * 128, 128);
+        lds_copy_in(a1, a1g + (size_t)n * 512, 512);
+        lds_copy_in(a2, a2g + (size_t)n * 1568, 1568);
+        for (int i = threadIdx.x; i < 784; i += blockDim.x) {
+            const real o = recon[(size_t)n * 784 + i];
+            d3[i] = real(2) * gscale * (o - images[(size_t)n * 784 + i]) * elu_grad_from_out(o);
+        }
+        __syncthreads();
+        DecC3::bwd_weight(a2, d3, g + od.c3w, g + od.c3b, scratch);
+        DecC3::bwd_data(d3, w + od.c3w, d2);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1568; i += blockDim.x) d2[i] *= elu_grad_from_out(a2[i]);
+        __syncthreads();
+        DecC2::bwd_weight(a1, d2, g + od.c2w, g + od.c2b, scratch);
+        DecC2::bwd_data(d2, w + od.c2w, d1);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) d1[i] *= elu_grad_from_out(a1[i]);
+        __syncthreads();
+        DecC1::bwd_weight(h0, d1, g + od.c1w, g + od.c1b, scratch);
+        DecC1::bwd_data(d1, w + od.c1w, dh0);
+        __syncthreads();
+        // dense (no activation): weight / bias gradients and zbar
+        for (int o = threadIdx.x; o < L * 128; o += blockDim.x) g[od.dw + o] += z[o / 128] * dh0[o % 128];
+        if (threadIdx.x < 128) g[od.db + threadIdx.x] += dh0[threadIdx.x];
+        // zbar[i] = sum_j dh0[j] w[i][j] : 4 lanes per i would be nicer; L <= 64 threads, 128 terms
+        if (threadIdx.x < L) {
+            real acc = 0;
+            for (int j = 0; j < 128; ++j) acc += dh0[j] * w[od.dw + threadIdx.x * 128 + j];
+            zbar[(size_t)n * L + threadIdx.x] = acc;
+        }
+    }
+    __syncthreads();
+    lds_copy_out(part + (size_t)blockIdx.x * od.n, g, od.n);
+}
+
+// ------------------------------------------------------------------------------------------
+// fixed-order reduction of per-workgroup partials: out[i] = sum_w part[w][i]
+// thread (i_local = tid % 64, chunk = tid / 64) -> 4 chunks over w, then LDS combine
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SVGP_BLOCK) void k_reduce_partials(int n_part, int n, const real* __restrict__ part,
+                                                                real* __restrict__ out) {
+    __shared__ real s[4][64];
+    const int il = threadIdx.x & 63, ch = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + il;
+    real acc = 0;
+    if (i < n)
+        for (int wq = ch; wq < n_part; wq += 4) acc += part[(size_t)wq * n + i];
+    s[ch][il] = acc;
+    __syncthreads();
+    if (ch == 0 && i < n) out[i] = (s[0][il] + s[1][il]) + (s[2][il] + s[3][il]);
+}
+
+// sums block: [0] L3 data term, [1] CE, [2] sum of squared recon errors, [3] local rows
+__global__ void k_reduce_sums(int n_part, int n_post, int b, const real* __restrict__ part_sums,
+                              real* __restrict__ sums) {
+    __shared__ real red[16];
+    real l3 = 0, ce = 0, sq = 0;
+    for (int i = threadIdx.x; i < n_part; i += blockDim.x) sq += part_sums[i * 4 + 2];
+    const real* pp = part_sums + (size_t)n_part * 4;
+    for (int i = threadIdx.x; i < n_post; i += blockDim.x) { l3 += pp[i * 2]; ce += pp[i * 2 + 1]; }
+    l3 = block_sum(l3, red);
+    ce = block_sum(ce, red);
+    sq = block_sum(sq, red);
+    if (threadIdx.x == 0) {
+        sums[0] = l3; sums[1] = ce; sums[2] = sq; sums[3] = (real)b;
+        sums[4] = 0; sums[5] = 0; sums[6] = 0; sums[7] = 0;
+    }
+}
+
+template <typename F>
+int set_dyn_lds(F kernel, size_t bytes) {
+    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return SVGP_OK;
+}
+
+}  // namespace
+
+#define GET_LAYOUTS()                                          \
+    svgp_mnist_param_layout pl;                                \
+    svgp_mnist_ws_layout wl;                                   \
+    {                                                          \
+        int rc_ = svgp_mnist_param_layout_get(c, &pl);         \
+        if (rc_) return rc_;                                   \
+        rc_ = svgp_mnist_ws_layout_get(c, &wl);                \
+        if (rc_) return rc_;                                   \
+    }
+
+extern "C" int svgp_mnist_encoder_fwd(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
+                                      void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(theta && images && ws, SVGP_ERR_INVALID, "NULL device pointer");
+    const size_t lds = (size_t)(pl.n_enc + 784 + 1352 + 288 + 32) * sizeof(real);
+    int rc = set_dyn_lds(k_encoder_fwd, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_encoder_fwd, dim3(svgp_n_part(c)), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, c->b, c->L,
+                       c->clip_qs, theta, images, ws + wl.enc_a1, ws + wl.enc_a2, ws + wl.enc_a3, ws + wl.qnet_mu,
+                       ws + wl.qnet_var_raw, ws + wl.qnet_var);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+extern "C" int svgp_mnist_encoder_bwd(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
+                                      void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(theta && images && ws, SVGP_ERR_INVALID, "NULL device pointer");
+    const size_t lds = (size_t)(2 * pl.n_enc + 784 + 1352 + 288 + 32 + 1352 + 288 + 32 + 128 + 256) * sizeof(real);
+    int rc = set_dyn_lds(k_encoder_bwd, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_encoder_bwd, dim3(svgp_n_part(c)), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, c->b, c->L,
+                       c->clip_qs, theta, images, ws + wl.enc_a1, ws + wl.enc_a2, ws + wl.enc_a3,
+                       ws + wl.qnet_var_raw, ws + wl.ybar, ws + wl.s2bar, ws + wl.part_enc);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+extern "C" int svgp_mnist_decoder_fwd(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
+                                      void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(theta && images && ws, SVGP_ERR_INVALID, "NULL device pointer");
+    const int64_t n_dec = pl.n_vae - pl.n_enc;
+    const size_t lds = (size_t)(n_dec + 64 + 128 + 512 + 1568 + 784 + 16) * sizeof(real);
+    int rc = set_dyn_lds(k_decoder_fwd, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_decoder_fwd, dim3(svgp_n_part(c)), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, c->b, c->L,
+                       theta + pl.n_enc, images, ws + wl.z, ws + wl.dec_h0, ws + wl.dec_a1, ws + wl.dec_a2,
+                       ws + wl.recon, ws + wl.part_sums);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+extern "C" int svgp_mnist_decoder_bwd(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
+                                      const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(theta && images && ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    const int64_t n_dec = pl.n_vae - pl.n_enc;
+    const size_t lds = (size_t)(2 * n_dec + 64 + 128 + 512 + 1568 + 784 + 1568 + 512 + 128 + 256) * sizeof(real);
+    int rc = set_dyn_lds(k_decoder_bwd, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_decoder_bwd, dim3(svgp_n_part(c)), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, c->b, c->L,
+                       c->geco, 1.0 / (double)c->b_global, state, theta + pl.n_enc, images, ws + wl.z, ws + wl.dec_h0,
+                       ws + wl.dec_a1, ws + wl.dec_a2, ws + wl.recon, ws + wl.zbar, ws + wl.part_dec);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+extern "C" int svgp_mnist_grad_reduce(const svgp_mnist_cfg* c, double* ws, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
+    const int n_part = svgp_n_part(c);
+    const int n_enc = (int)pl.n_enc, n_dec = (int)(pl.n_vae - pl.n_enc);
+    hipLaunchKernelGGL(k_reduce_partials, dim3((n_enc + 63) / 64), dim3(SVGP_BLOCK), 0, (hipStream_t)stream, n_part,
+                       n_enc, ws + wl.part_enc, ws + wl.grad);
+    SVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_reduce_partials, dim3((n_dec + 63) / 64), dim3(SVGP_BLOCK), 0, (hipStream_t)stream, n_part,
+                       n_dec, ws + wl.part_dec, ws + wl.grad + pl.n_enc);
+    SVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_reduce_sums, dim3(1), dim3(SVGP_BLOCK), 0, (hipStream_t)stream, n_part,
+                       (int)wl.n_post, c->b, ws + wl.part_sums, ws + wl.sums);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}

@@ -1,0 +1,243 @@
+"""Host side of the SVGPVAE_Hensman step: owns the flat parameter / optimiser / workspace buffers
+in HBM, enqueues the HIP phases (include/svgpvae_hip.h) on one stream, replays them as a hipGraph,
+and inserts the three data-parallel all-reduces between phases.
+
+Counterpart of the reference's graph construction + `sess.run([optim_step, ...])` loop body
+(MNIST_experiment.py:111-134, 197-208, 327-355).  PyTorch is used for device memory, streams and
+torch.distributed only; every kernel is in libsvgpvae_hip.so.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import STATE, STATE_LEN, MnistCfg, ParamLayout, WsLayout, call
+
+VAE_PARAM_NAMES = ("enc_c1_w", "enc_c1_b", "enc_c2_w", "enc_c2_b", "enc_c3_w", "enc_c3_b", "enc_d_w", "enc_d_b",
+                   "dec_d_w", "dec_d_b", "dec_c1_w", "dec_c1_b", "dec_c2_w", "dec_c2_b", "dec_c3_w", "dec_c3_b")
+
+
+def param_shapes(m, L, M, n_obj):
+    """name -> shape, in flat-vector order (TF layouts; reference variable creation order)."""
+    shp = {
+        "enc_c1_w": (3, 3, 1, 8), "enc_c1_b": (8,), "enc_c2_w": (3, 3, 8, 8), "enc_c2_b": (8,),
+        "enc_c3_w": (3, 3, 8, 8), "enc_c3_b": (8,), "enc_d_w": (32, 2 * L), "enc_d_b": (2 * L,),
+        "dec_d_w": (L, 128), "dec_d_b": (128,), "dec_c1_w": (3, 3, 8, 8), "dec_c1_b": (8,),
+        "dec_c2_w": (3, 3, 8, 8), "dec_c2_b": (8,), "dec_c3_w": (3, 3, 8, 1), "dec_c3_b": (1,),
+        "inducing_index_points": (m, 2 + M), "l_GP": (), "amplitude": (),
+    }
+    if n_obj > 0:
+        shp["object_vectors"] = (n_obj, M)
+    return shp
+
+
+_LAYOUT_NAME = {"inducing_index_points": "ip", "object_vectors": "ov"}
+
+
+def shard_rows(b_global, world_size, rank):
+    """Row partition of the global batch: rank r gets rows [lo, hi).  Remainder rows go to the
+    lowest ranks (ragged last batch 210 = 27+27+26*6 on 8 ranks)."""
+    base, rem = divmod(b_global, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class DataParallelStep:
+    """The exchange schedule of one step, independent of what executes the phases.
+
+    backend: object with `.phase(k)` for k in 0..3 and `.block(name)` returning the flat tensors
+    'statA' (forward statistics S|v), 'statB' (backward statistics A2|ud|td), 'gradC' (gradients|sums).
+    With world_size 1 no collective is issued."""
+
+    def __init__(self, backend, group=None):
+        self.backend = backend
+        self.group = group
+        import torch.distributed as dist
+        self.dist = dist
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _allreduce(self, name):
+        if self.world > 1:
+            self.dist.all_reduce(self.backend.block(name), op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def step(self):
+        be = self.backend
+        be.phase(0)
+        self._allreduce("statA")
+        be.phase(1)
+        self._allreduce("statB")
+        be.phase(2)
+        self._allreduce("gradC")
+        be.phase(3)
+
+
+class MnistStepEngine:
+    """One rank's HIP execution state for the rotated-MNIST SVGPVAE_Hensman step."""
+
+    def __init__(self, m, L=16, M=8, n_obj=400, *, N_train=4050.0, jitter=1e-6, clip_qs=True, geco=False,
+                 K_obj_normalize=False, kappa_squared=0.020, alpha=0.99, beta=0.001, lr=1e-3,
+                 train_ip=True, train_gp=True, train_ov=True, b_max=256, device="cuda:0",
+                 rank=0, world_size=1):
+        self.lib = _lib.load_library()          # raises if the HIP extension is missing
+        if not torch.cuda.is_available():
+            raise _lib.SvgpError("MnistStepEngine needs a HIP device (torch.cuda.is_available() is False); "
+                                 "there is no CPU execution path")
+        self.device = torch.device(device)
+        self.rank, self.world_size = rank, world_size
+        self.base = dict(m=m, L=L, M=M, n_obj=n_obj, normalize_obj=int(K_obj_normalize), clip_qs=int(clip_qs),
+                         geco=int(geco), train_ip=int(train_ip), train_gp=int(train_gp), train_ov=int(train_ov),
+                         N_train=float(N_train), jitter=float(jitter), kappa_squared=float(kappa_squared),
+                         alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0)
+        self.b_max = b_max
+        self.cfg = None
+        self.pl = ParamLayout()
+        call("svgp_mnist_param_layout_get", C.byref(self._make_cfg(b_max, b_max)), C.byref(self.pl))
+        n = self.pl.n_total
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.theta = torch.zeros(n, **f64)
+        self.adam_m = torch.zeros(n, **f64)
+        self.adam_v = torch.zeros(n, **f64)
+        self.state = torch.zeros(STATE_LEN, **f64)
+        wl = WsLayout()
+        call("svgp_mnist_ws_layout_get", C.byref(self._make_cfg(b_max, b_max)), C.byref(wl))
+        self.ws = torch.zeros(wl.total, **f64)
+        self.shapes = param_shapes(m, L, M, n_obj)
+        self.params = {k: self._pview(self.theta, k) for k in self.shapes}
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.reset_state(beta=beta, lr=lr)
+        self._graphs = {}
+        self._bound = None
+        self.set_batch_size(b_max, b_max * world_size)
+
+    # ------------------------------------------------------------------ configuration
+    def _make_cfg(self, b, b_global):
+        return MnistCfg(b=b, b_global=b_global, **self.base)
+
+    def set_batch_size(self, b, b_global=None):
+        """Local rows b of a global batch b_global (ragged last batch: MNIST_experiment.py:327,
+        utils.py:846-848 `.batch()` without drop_remainder)."""
+        if b > self.b_max:
+            raise ValueError(f"b={b} exceeds b_max={self.b_max}")
+        b_global = b if b_global is None else b_global
+        self.cfg = self._make_cfg(b, b_global)
+        self.wl = WsLayout()
+        call("svgp_mnist_ws_layout_get", C.byref(self.cfg), C.byref(self.wl))
+        assert self.wl.total <= self.ws.numel()
+
+    def reset_state(self, beta=None, lr=None):
+        """MNIST_experiment.py:313-315: first_step=True (alpha 0), C_ma_=0, lagrange_mult_=1."""
+        st = torch.zeros(STATE_LEN, dtype=torch.float64)
+        st[STATE["LAGRANGE"]] = 1.0
+        st[STATE["ALPHA"]] = 0.0 if self.base["geco"] else self.base["alpha"]
+        st[STATE["LR"]] = float(self.state[STATE["LR"]]) if lr is None else lr
+        st[STATE["BETA"]] = float(self.state[STATE["BETA"]]) if beta is None else beta
+        self.state.copy_(st)
+
+    def set_scalars(self, **kw):
+        """Host writes into the device state vector (names of _lib.STATE, lower-case accepted)."""
+        st = self.state.cpu()
+        for k, v in kw.items():
+            st[STATE[k.upper()]] = float(v)
+        self.state.copy_(st)
+
+    def scalars(self):
+        st = self.state.cpu()
+        return {k.lower(): float(st[i]) for k, i in STATE.items()}
+
+    # ------------------------------------------------------------------ views
+    def _pview(self, flat, name):
+        off = getattr(self.pl, _LAYOUT_NAME.get(name, name))
+        shp = self.shapes[name]
+        return flat[off:off + int(np.prod(shp, dtype=np.int64))].view(shp)
+
+    def load_params(self, params):
+        """params: dict name -> array-like (numpy / torch, any device)."""
+        for k, v in params.items():
+            if k not in self.params:
+                raise KeyError(k)
+            self.params[k].copy_(torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v,
+                                                 dtype=torch.float64).reshape(self.shapes[k]))
+
+    def ws_view(self, name, shape=None):
+        off = getattr(self.wl, name)
+        if shape is None:
+            length = getattr(self.wl, name + "_len")
+            return self.ws[off:off + length]
+        return self.ws[off:off + int(np.prod(shape, dtype=np.int64))].view(shape)
+
+    def grads(self):
+        g = self.ws[self.wl.grad:self.wl.grad + self.pl.n_total]
+        return {k: self._pview(g, k) for k in self.shapes}
+
+    def block(self, name):
+        return self.ws_view(name)
+
+    # ------------------------------------------------------------------ execution
+    def bind(self, images, aux, eps=None):
+        """Device tensors of the current batch (float64, contiguous).  eps=None -> on-device N(0,1)."""
+        b = images.shape[0]
+        assert images.dtype == torch.float64 and images.is_contiguous() and images.shape[1:] == (28, 28, 1)
+        assert aux.dtype == torch.float64 and aux.is_contiguous() and aux.shape == (b, 2 + self.base["M"])
+        assert eps is None or (eps.dtype == torch.float64 and eps.is_contiguous() and eps.shape == (b, self.base["L"]))
+        if b != self.cfg.b:
+            raise ValueError(f"batch rows {b} != configured {self.cfg.b}; call set_batch_size first")
+        self._bound = (images, aux, eps)
+
+    def phase(self, k, adam=True):
+        images, aux, eps = self._bound
+        call("svgp_mnist_step_phase", C.byref(self.cfg), k, self.theta.data_ptr(), images.data_ptr(),
+             aux.data_ptr(), eps.data_ptr() if eps is not None else None, self.ws.data_ptr(),
+             self.state.data_ptr(), self.adam_m.data_ptr() if adam else None,
+             self.adam_v.data_ptr() if adam else None, self.stream.cuda_stream)
+
+    def run(self, adam=True, group=None):
+        """All four phases on self.stream, with all-reduces when world_size > 1."""
+        with torch.cuda.stream(self.stream):
+            if self.world_size == 1:
+                for k in range(4):
+                    self.phase(k, adam)
+            else:
+                be = _PhaseAdapter(self, adam)
+                DataParallelStep(be, group).step()
+
+    # hipGraph capture / replay through the library (not torch.cuda.graphs)
+    def capture(self, key, adam=True):
+        """Captures the 4 phases (single GPU) into a hipGraph stored under `key`."""
+        assert self.world_size == 1, "graph capture of the full step is the single-GPU form"
+        s = self.stream.cuda_stream
+        self.stream.synchronize()
+        call("svgp_graph_begin", s)
+        try:
+            for k in range(4):
+                self.phase(k, adam)
+        finally:
+            exe = C.c_void_p()
+            call("svgp_graph_end", s, C.byref(exe))
+        self._graphs[key] = exe
+        return exe
+
+    def replay(self, key):
+        call("svgp_graph_launch", self._graphs[key], self.stream.cuda_stream)
+
+    def synchronize(self):
+        self.stream.synchronize()
+
+    def __del__(self):
+        try:
+            for exe in self._graphs.values():
+                self.lib.svgp_graph_destroy(exe)
+        except Exception:
+            pass
+
+
+class _PhaseAdapter:
+    def __init__(self, eng, adam):
+        self.eng, self.adam = eng, adam
+
+    def phase(self, k):
+        self.eng.phase(k, self.adam)
+
+    def block(self, name):
+        return self.eng.block(name)

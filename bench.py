@@ -1,0 +1,251 @@
+"""SVGPVAE_Hensman train steps/sec on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one full training step (encoder, kernel matrices, sparse-GP block, decoder, reverse
+pass, TF1 Adam, GECO state update) on one 256-row rotated-MNIST-shaped batch per GPU (BASELINE
+config 2: m=32 inducing points, L=16, GPLVM dim 8, N_train=4050, float64 like the reference).
+Weak scaling: every rank keeps 256 rows, the global batch is 256*N rows coupled through the
+sufficient-statistics all-reduces; `value` = N * steps / time = 256-row batches trained per second.
+Inputs are synthetic, generated once and resident in HBM before the timed region.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B, M_IND, L, MDIM, N_OBJ, N_TRAIN = 256, 32, 16, 8, 400, 4050.0
+F64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (AMD datasheet; = 1/2 of the 157.3 TF f32 rate
+                           # listed in MI355X_MICROARCH.md, which has no f64 row)
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_problem(rank, seed=0):
+    """SURVEY 8d config 2 synthetic inputs; parameters identical on all ranks, data differs per rank."""
+    from svgp_vae_amd.VAE_utils import glorot_uniform_params
+    rs = np.random.RandomState(seed)
+    params = dict(glorot_uniform_params(L, seed))
+    angles16 = np.linspace(0, 2 * np.pi, 17)[:-1]
+    ip = np.concatenate([np.repeat(angles16, 2)[:, None], rs.normal(0, 1.5, (M_IND, MDIM))], 1)
+    params["inducing_index_points"] = np.concatenate([np.arange(M_IND)[:, None].astype(float), ip], 1)
+    params["l_GP"] = np.array(1.0)
+    params["amplitude"] = np.array(1.0)
+    params["object_vectors"] = rs.normal(0, 1.5, (N_OBJ, MDIM))
+    rd = np.random.RandomState(1000 + rank)
+    train_angles = np.delete(angles16, 7)
+    ids = rd.randint(0, N_OBJ, B).astype(float)
+    aux = np.concatenate([ids[:, None], rd.choice(train_angles, B)[:, None],
+                          params["object_vectors"][ids.astype(int)]], 1)
+    images = np.clip(rd.normal(0.142, 0.316, (B, 28, 28, 1)), -0.2, 1.2)
+    eps = rd.randn(B, L)
+    return params, images, aux, eps
+
+
+def stage_table(eng):
+    """(name, C symbol, args builder, algorithmic flops, algorithmic bytes) per stage, config 2 per GPU.
+    Flop/byte models: DESIGN.md section 5."""
+    from svgp_vae_amd import _lib
+    cfg, th, ws, st = C.byref(eng.cfg), eng.theta.data_ptr(), eng.ws.data_ptr(), eng.state.data_ptr()
+    img, aux, eps = (t.data_ptr() if t is not None else None for t in eng._bound)
+    s = eng.stream.cuda_stream
+    b, m, Lc = B, M_IND, L
+    enc_mac, dec_mac = 35_592, 207_872            # MACs per image (SURVEY App. B shapes)
+    act_enc, act_dec = 1352 + 288 + 32, 128 + 512 + 1568
+    n_enc, n_dec = eng.pl.n_enc, eng.pl.n_vae - eng.pl.n_enc
+    f8 = 8.0
+    return [
+        ("encoder_fwd", "svgp_mnist_encoder_fwd", (cfg, th, img, ws, s), 2 * enc_mac * b, f8 * b * (784 + act_enc + 3 * Lc)),
+        ("kernel_matrix_fwd", "svgp_kernel_matrix_fwd", (cfg, th, aux, ws, s), (b * m + m * m) * (2 * 9 + 12), f8 * (b * m + m * m + b + b * 10)),
+        ("gp_stats_fwd", "svgp_gp_stats_fwd", (cfg, ws, s), 3 * Lc * b * m * m + 2 * m ** 3, f8 * (b * m + 2 * b * Lc + Lc * m * (m + 1))),
+        ("gp_factor_fwd", "svgp_gp_factor_fwd", (cfg, ws, s), Lc * (2 * (m ** 3 / 3 + 2 * m ** 3 / 3) + 4 * 2 * m ** 3) + 2 * b * m * m, f8 * Lc * 7 * m * m),
+        ("gp_posterior_fwd", "svgp_gp_posterior_fwd", (cfg, eps, ws, st, s), 4 * Lc * b * m * m, f8 * (Lc * 2 * m * m + b * m + 8 * b * Lc)),
+        ("decoder_fwd", "svgp_mnist_decoder_fwd", (cfg, th, img, ws, s), 2 * dec_mac * b, f8 * b * (Lc + act_dec + 2 * 784)),
+        ("decoder_bwd", "svgp_mnist_decoder_bwd", (cfg, th, img, ws, st, s), 4 * dec_mac * b, f8 * (b * (Lc + act_dec + 2 * 784 + Lc) + eng.wl.n_part * n_dec)),
+        ("gp_stats_bwd", "svgp_gp_stats_bwd", (cfg, ws, st, s), 3 * Lc * b * m * m, f8 * (b * m + 9 * b * Lc + Lc * m * (m + 2))),
+        ("gp_factor_bwd", "svgp_gp_factor_bwd", (cfg, ws, st, s), Lc * 9 * 2 * m ** 3, f8 * Lc * 14 * m * m),
+        ("gp_posterior_bwd", "svgp_gp_posterior_bwd", (cfg, ws, st, s), 6 * Lc * b * m * m, f8 * (Lc * 3 * m * m + 2 * Lc * b * m + 12 * b * Lc)),
+        ("kernel_matrix_bwd", "svgp_kernel_matrix_bwd", (cfg, th, aux, ws, s), (2 * b * m + 2 * m * m) * (2 * 9 + 20), f8 * (2 * b * m + 2 * m * m + b * 10 + N_OBJ * 8)),
+        ("encoder_bwd", "svgp_mnist_encoder_bwd", (cfg, th, img, ws, s), 4 * enc_mac * b, f8 * (b * (784 + act_enc + 3 * Lc) + eng.wl.n_part * n_enc)),
+        ("grad_reduce", "svgp_mnist_grad_reduce", (cfg, ws, s), eng.wl.n_part * (n_enc + n_dec), f8 * eng.wl.n_part * (n_enc + n_dec)),
+    ]
+
+
+def time_stages(eng, reps=50):
+    """HIP events on the engine's own stream around `reps` back-to-back launches of each stage
+    (inputs of every stage are valid after one full step).  Returns list of dicts sorted by time."""
+    from svgp_vae_amd import _lib
+    lib = _lib.load_library()
+    s = eng.stream.cuda_stream
+    e0, e1 = C.c_void_p(), C.c_void_p()
+    _lib.call("svgp_event_create", C.byref(e0)); _lib.call("svgp_event_create", C.byref(e1))
+    rows = []
+    for name, sym, args, flops, nbytes in stage_table(eng):
+        fn = getattr(lib, sym)
+        for _ in range(3):
+            _lib.check(fn(*args))
+        _lib.call("svgp_event_record", e0, s)
+        for _ in range(reps):
+            _lib.check(fn(*args))
+        _lib.call("svgp_event_record", e1, s)
+        ms = C.c_float()
+        _lib.call("svgp_event_elapsed_ms", e0, e1, C.byref(ms))
+        rows.append(dict(stage=name, us=ms.value * 1e3 / reps, flops=float(flops), bytes=float(nbytes)))
+    _lib.call("svgp_event_destroy", e0); _lib.call("svgp_event_destroy", e1)
+    return sorted(rows, key=lambda r: -r["us"])
+
+
+def cpu_baseline(params, images, aux, eps, gpu_elbo, budget_s=15.0):
+    """The oracle's LITERAL formulation (same op sequence as the reference incl. the (b,m,m) tensor,
+    explicit inverses, autograd + TF1 Adam) timed on this host's cores.  kind = "port".
+    Also the parity gate of the run: the GPU's ELBO of the explicit-eps step vs the oracle's."""
+    from oracle import svgpvae_oracle as O
+    p = {k: torch.tensor(np.asarray(v), dtype=O.DT) for k, v in params.items()}
+    ti, ta, te = (torch.tensor(x, dtype=O.DT) for x in (images, aux, eps))
+    out, _ = O.loss_and_grads(p, ti, ta, te, beta=0.001, C_ma=torch.zeros((), dtype=O.DT),
+                              lagrange_mult=torch.ones((), dtype=O.DT), alpha=0.0, kappa=math.sqrt(0.020),
+                              clipping_qs=True, GECO=True, jitter=1e-6, N_train=N_TRAIN, L=L,
+                              formulation="efficient")
+    elbo_rel = abs(gpu_elbo - float(out[0])) / abs(float(out[0]))
+    assert elbo_rel < 1e-3, f"ELBO parity failed: GPU {gpu_elbo} oracle {float(out[0])}"
+    ms = {k: torch.zeros_like(v) for k, v in p.items()}
+    vs = {k: torch.zeros_like(v) for k, v in p.items()}
+    kw = dict(beta=0.001, C_ma=torch.zeros((), dtype=O.DT), lagrange_mult=torch.ones((), dtype=O.DT), alpha=0.0,
+              kappa=math.sqrt(0.020), clipping_qs=True, GECO=True, jitter=1e-6, N_train=N_TRAIN, L=L,
+              formulation="literal")
+
+    def one(t):
+        _, g = O.loss_and_grads(p, ti, ta, te, **kw)
+        O.adam_tf1_step(p, g, ms, vs, t, 1e-3)
+
+    for t in range(1, 3):
+        one(t)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one(3 + n)
+        n += 1
+        el = time.perf_counter() - t0
+        if (el > budget_s and n >= 5) or n >= 400:
+            break
+    return dict(value=n / el, unit="steps/s", cores=torch.get_num_threads(), kind="port",
+                elbo_rel_err_gpu_vs_oracle=elbo_rel,
+                sample=f"{n} literal-formulation float64 steps (torch-CPU autograd + TF1 Adam) of the same "
+                       f"config-2 batch, {el:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    from svgp_vae_amd.engine import MnistStepEngine
+    params, images, aux, eps = synthetic_problem(rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    eng = MnistStepEngine(M_IND, L, MDIM, N_OBJ, N_train=N_TRAIN, jitter=1e-6, clip_qs=True, geco=True,
+                          kappa_squared=0.020, alpha=0.99, beta=0.001, lr=1e-3, b_max=B, device=str(dev),
+                          rank=rank, world_size=world)
+    eng.load_params(params)
+    d_img, d_aux, d_eps = (torch.tensor(x, dtype=torch.float64, device=dev).contiguous() for x in (images, aux, eps))
+
+    # ---- one explicit-eps step whose ELBO the cpu_baseline leg checks against the oracle
+    gpu_elbo = None
+    if world == 1:
+        eng.bind(d_img, d_aux, d_eps)
+        eng.run(adam=False)
+        eng.synchronize()
+        gpu_elbo = eng.scalars()["elbo"]
+        eng.reset_state()
+
+    # ---- timed region: eps drawn on device every step (tf.random.normal, SVGPVAE_model.py:901)
+    eng.bind(d_img, d_aux, None)
+    use_graph = world == 1 and not args.no_graph
+    if use_graph:
+        eng.capture("step", adam=True)
+        step = lambda: eng.replay("step")
+    else:
+        step = lambda: eng.run(adam=True)
+    for _ in range(args.warmup):
+        step()
+    eng.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    sc = eng.scalars()
+    assert math.isfinite(sc["elbo"]) and sc["adam_t"] >= args.steps, sc
+
+    if rank == 0:
+        line = {
+            "metric": "SVGPVAE train steps/sec, rotated MNIST (N=4050, M=32, L=16)",
+            "value": world * args.steps / el, "unit": "steps/s (256-row batches, whole job)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: rotated-MNIST SVGPVAE_Hensman, m=32 inducing, L=16, "
+                                   "GPLVM dim 8, batch 256 per GPU, N_train=4050, GECO + clip_qs, float64",
+                       "global_batch": B * world, "rows_per_gpu": B,
+                       "launch": "hipGraph replay" if use_graph else "eager phases + RCCL all-reduce x3",
+                       "parallelism": f"dp{world}"},
+        }
+        if world == 1:
+            rows = time_stages(eng)
+            top = rows[0]
+            ai = top["flops"] / top["bytes"]
+            if ai >= F64_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+                ach = top["flops"] / (top["us"] * 1e-6) / 1e12
+                roof = {"bound": "mfma", "achieved": ach, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": ach / F64_PEAK_TFLOPS}
+            else:
+                ach = top["bytes"] / (top["us"] * 1e-6) / 1e9
+                roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS}
+            roof.update(traffic=None, kernel=top["stage"], launch_us=top["us"],
+                        note="latency-bound config: see DESIGN.md section 5")
+            line["roofline"] = roof
+            line["stages_us"] = {r["stage"]: round(r["us"], 2) for r in rows}
+            line["step_flops"] = sum(r["flops"] for r in rows)
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(params, images, aux, eps, gpu_elbo)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

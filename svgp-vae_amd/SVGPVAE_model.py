@@ -1,0 +1,268 @@
+"""The reference's `SVGPVAE_model.py` call surface for the rotated-MNIST Hensman path, executed by
+libsvgpvae_hip.so on MI355X.  Eager float64 CUDA tensors replace TF graph tensors; the N(0,1)
+draw `epsilon` and all weights are injectable so results can be compared on identical inputs.
+
+Mirrored names (reference file:line):
+  mnistSVGP(titsias, fixed_inducing_points, initial_inducing_points, fixed_gp_params,
+            object_vectors_init, name, jitter, N_train, L, K_obj_normalize)      SVGPVAE_model.py:383-384
+    .kernel_matrix(x, y, x_inducing=True, y_inducing=True, diag_only=False)      :427
+    .approximate_posterior_params(index_points_test, index_points_train, y, noise) -> (mean, B, mu_hat, A_hat)  :303
+    .variational_loss(x, y, mu_hat, A_hat, noise) -> (L3 sum term, KL term)       :220
+    .variable_summary()                                                           :478
+  forward_pass_SVGPVAE(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha, kappa,
+                       clipping_qs=False, GECO=False, ...) -> 16-tuple            :823-936
+  batching_encode_SVGPVAE(data_batch, vae, clipping_qs=False, ...)                :939-968
+Additional (no reference counterpart - TF's tf.gradients + AdamOptimizer live in the driver):
+  gradients_SVGPVAE(...) and train_step_SVGPVAE(...).
+
+Not implemented in this build (raise NotImplementedError): the Titsias branch (titsias=True), test
+points different from train points in approximate_posterior_params (conditional generation), SPRITES.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .engine import MnistStepEngine
+
+_F64 = torch.float64
+
+
+class mnistSVGP:
+    def __init__(self, titsias, fixed_inducing_points, initial_inducing_points, fixed_gp_params,
+                 object_vectors_init, name, jitter, N_train, L, K_obj_normalize=False, device="cuda:0"):
+        if titsias:
+            raise NotImplementedError("SVGPVAE_Titsias branch (SVGPVAE_model.py:246-259) is not built yet")
+        self.dtype = _F64
+        self.titsias = titsias
+        self.jitter = float(jitter)
+        self.N_train = float(N_train)
+        self.L = L
+        self.K_obj_normalize = bool(K_obj_normalize)
+        self.fixed_inducing_points = bool(fixed_inducing_points)
+        self.fixed_gp_params = bool(fixed_gp_params)
+        self.name = name
+        self.device = device
+        ip = torch.as_tensor(np.asarray(initial_inducing_points), dtype=_F64)
+        self.nr_inducing = ip.shape[0]
+        self.inducing_index_points = ip.clone()
+        self.l_GP = torch.tensor(1.0, dtype=_F64)          # SVGPVAE_model.py:409-413
+        self.amplitude = torch.tensor(1.0, dtype=_F64)
+        self.object_vectors = None if object_vectors_init is None else \
+            torch.as_tensor(np.asarray(object_vectors_init), dtype=_F64).clone()
+        self._rt = None
+
+    # -- parameters as a dict in the engine's naming
+    def _params(self):
+        p = {"inducing_index_points": self.inducing_index_points, "l_GP": self.l_GP, "amplitude": self.amplitude}
+        if self.object_vectors is not None:
+            p["object_vectors"] = self.object_vectors
+        return p
+
+    def _gp_engine(self, b, L):
+        """A private engine for the stand-alone GP methods (per-channel API, L = 1)."""
+        M = self.inducing_index_points.shape[1] - 2
+        n_obj = 0 if self.object_vectors is None else self.object_vectors.shape[0]
+        eng = MnistStepEngine(self.nr_inducing, L, M, n_obj, N_train=self.N_train, jitter=self.jitter,
+                              clip_qs=False, geco=False, K_obj_normalize=self.K_obj_normalize,
+                              b_max=b, device=self.device)
+        eng.load_params({k: v for k, v in self._params().items()})
+        return eng
+
+    def kernel_matrix(self, x, y, x_inducing=True, y_inducing=True, diag_only=False):
+        """K(x, y) for the three argument patterns the Hensman path uses (SVGPVAE_model.py:238-243,
+        318-325): (inducing, inducing) -> (m,m); (batch, inducing) -> (b,m); (batch, batch, diag_only) -> (b)."""
+        import ctypes as C
+        from ._lib import call
+        ip = self.inducing_index_points
+        if x_inducing and y_inducing and not diag_only:
+            aux = torch.zeros(1, ip.shape[1], dtype=_F64)
+            which = "K"
+        elif (not x_inducing) and y_inducing and not diag_only:
+            aux, which = x, "Kn"
+        elif (not x_inducing) and (not y_inducing) and diag_only and (x is y or torch.equal(x, y)):
+            aux, which = x, "knn"
+        else:
+            raise NotImplementedError("kernel_matrix: argument pattern not used by the SVGPVAE_Hensman path")
+        b = aux.shape[0]
+        eng = self._gp_engine(b, 1)
+        d_aux = aux.to(eng.device, _F64).contiguous()
+        with torch.cuda.stream(eng.stream):
+            eng.stream.wait_stream(torch.cuda.current_stream(eng.device))
+            call("svgp_kernel_matrix_fwd", C.byref(eng.cfg), eng.theta.data_ptr(), d_aux.data_ptr(),
+                 eng.ws.data_ptr(), eng.stream.cuda_stream)
+        eng.synchronize()
+        m = self.nr_inducing
+        shape = {"K": (m, m), "Kn": (b, m), "knn": (b,)}[which]
+        return eng.ws_view(which, shape).clone()
+
+    def _channel(self, index_points_train, y, noise):
+        import ctypes as C
+        from ._lib import call
+        b = index_points_train.shape[0]
+        eng = self._gp_engine(b, 1)
+        dev = eng.device
+        d_aux = index_points_train.to(dev, _F64).contiguous()
+        eng.ws_view("qnet_mu", (b, 1)).copy_(y.to(dev, _F64).reshape(b, 1))
+        eng.ws_view("qnet_var", (b, 1)).copy_(noise.to(dev, _F64).reshape(b, 1))
+        zeros = torch.zeros(b, 1, dtype=_F64, device=dev)
+        cfg, th, ws, st, s = C.byref(eng.cfg), eng.theta.data_ptr(), eng.ws.data_ptr(), eng.state.data_ptr(), \
+            eng.stream.cuda_stream
+        with torch.cuda.stream(eng.stream):
+            eng.stream.wait_stream(torch.cuda.current_stream(dev))
+            call("svgp_kernel_matrix_fwd", cfg, th, d_aux.data_ptr(), ws, s)
+            call("svgp_gp_stats_fwd", cfg, ws, s)
+            call("svgp_gp_factor_fwd", cfg, ws, s)
+            call("svgp_gp_posterior_fwd", cfg, zeros.data_ptr(), ws, st, s)
+        eng.synchronize()
+        return eng, b
+
+    def approximate_posterior_params(self, index_points_test, index_points_train=None, y=None, noise=None):
+        """(mean_vector, B, mu_hat, A_hat) of q_S for one latent channel (SVGPVAE_model.py:303-343);
+        test points must be the train points (the training-step use, :869)."""
+        if index_points_train is None:
+            index_points_train = index_points_test
+        if not (index_points_test is index_points_train or torch.equal(index_points_test, index_points_train)):
+            raise NotImplementedError("test points != train points (conditional generation) is a next-round row")
+        eng, b = self._channel(index_points_train, y, noise)
+        m = self.nr_inducing
+        return (eng.ws_view("p_m", (b,)).clone(), eng.ws_view("p_v", (b,)).clone(),
+                eng.ws_view("mu_hat", (m,)).clone(), eng.ws_view("A", (m, m)).clone())
+
+    def variational_loss(self, x, y, mu_hat, A_hat, noise=None):
+        """(L_3 sum term, KL term) of one channel (SVGPVAE_model.py:261-301).  mu_hat / A_hat must be the
+        ones approximate_posterior_params returns for the same (x, y, noise) - the only use in the
+        reference (:869-873); they are recomputed on device."""
+        eng, b = self._channel(x, y, noise)
+        p = 1.0 / eng.ws_view("qnet_var", (b,))
+        l3 = -0.5 * (torch.sum(p * eng.ws_view("d", (b,))) + torch.sum(torch.log(eng.ws_view("qnet_var", (b,))))
+                     + b * 1.8378770664093453)
+        return l3, eng.ws_view("KL", (1,))[0].clone()
+
+    def variable_summary(self):
+        """SVGPVAE_model.py:478-485: (l_GP, amplitude, object_vectors, inducing_index_points)."""
+        return self.l_GP, self.amplitude, self.object_vectors, self.inducing_index_points
+
+
+# ---------------------------------------------------------------------------------------------
+class _Runtime:
+    """Binds a (vae, svgp) pair to one MnistStepEngine: copies their parameters into the flat vector
+    and re-points the objects' attributes at views of it, so optimiser updates are visible to both."""
+
+    def __init__(self, vae, svgp, clipping_qs, GECO, kappa, alpha_flag=0.99, b_max=256, lr=1e-3, beta=0.001,
+                 rank=0, world_size=1):
+        M = svgp.inducing_index_points.shape[1] - 2
+        n_obj = 0 if svgp.object_vectors is None else svgp.object_vectors.shape[0]
+        self.key = (bool(clipping_qs), bool(GECO), float(kappa))
+        self.eng = MnistStepEngine(svgp.nr_inducing, vae.L, M, n_obj, N_train=svgp.N_train, jitter=svgp.jitter,
+                                   clip_qs=clipping_qs, geco=GECO, K_obj_normalize=svgp.K_obj_normalize,
+                                   kappa_squared=float(kappa) ** 2, alpha=alpha_flag, beta=beta, lr=lr,
+                                   train_ip=not svgp.fixed_inducing_points, train_gp=not svgp.fixed_gp_params,
+                                   train_ov=svgp.object_vectors is not None, b_max=b_max, device=svgp.device,
+                                   rank=rank, world_size=world_size)
+        params = dict(vae.params)
+        params.update(svgp._params())
+        self.eng.load_params(params)
+        vae.params = {k: self.eng.params[k] for k in vae.params}
+        vae._engine = self.eng
+        svgp.inducing_index_points = self.eng.params["inducing_index_points"]
+        svgp.l_GP = self.eng.params["l_GP"]
+        svgp.amplitude = self.eng.params["amplitude"]
+        if svgp.object_vectors is not None:
+            svgp.object_vectors = self.eng.params["object_vectors"]
+        svgp._rt = self
+
+
+def _runtime(vae, svgp, clipping_qs, GECO, kappa, b, **kw):
+    rt = svgp._rt
+    if rt is None or rt.key != (bool(clipping_qs), bool(GECO), float(kappa)) or rt.eng.b_max < b:
+        if rt is not None:   # carry the current parameter values into the new engine
+            vae.params = {k: v.detach().cpu().clone() for k, v in vae.params.items()}
+            vae._engine = None
+            for k in ("inducing_index_points", "l_GP", "amplitude", "object_vectors"):
+                v = getattr(svgp, k)
+                if v is not None:
+                    setattr(svgp, k, v.detach().cpu().clone())
+        rt = _Runtime(vae, svgp, clipping_qs, GECO, kappa, b_max=max(b, 256), **kw)
+    return rt
+
+
+def _prepare(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha, kappa, clipping_qs, GECO, epsilon,
+             b_global=None, **kw):
+    images, aux_data = data_batch
+    b = images.shape[0]
+    rt = _runtime(vae, svgp, clipping_qs, GECO, kappa, b, **kw)
+    eng = rt.eng
+    eng.set_batch_size(b, b_global)
+    eng.set_scalars(beta=float(beta), c_ma=float(C_ma), lagrange=float(lagrange_mult), alpha=float(alpha))
+    dev = eng.device
+    eng.bind(images.to(dev, _F64).contiguous(), aux_data.to(dev, _F64).contiguous(),
+             None if epsilon is None else epsilon.to(dev, _F64).contiguous())
+    return eng, b
+
+
+def _tuple16(eng, b):
+    L = eng.base["L"]
+    sc = eng.scalars()
+    t = lambda v: torch.tensor(v, dtype=_F64, device=eng.device)
+    w = lambda n, s: eng.ws_view(n, s).clone()
+    return (t(sc["elbo"]), t(sc["recon_loss"]), t(sc["kl_term"]), t(sc["inside_elbo"]), t(sc["ce_term"]),
+            w("p_m", (b, L)), w("p_v", (b, L)), w("qnet_mu", (b, L)), w("qnet_var", (b, L)),
+            w("recon", (b, 28, 28, 1)), t(sc["inside_recon"]), t(sc["inside_kl"]), w("z", (b, L)),
+            t(sc["c_ma"]), t(sc["lagrange"]), t(1.0))
+
+
+def forward_pass_SVGPVAE(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha, kappa,
+                         clipping_qs=False, GECO=False, repr_NN=None, segment_ids=None, repeats=None,
+                         bias_analysis=False, epsilon=None):
+    """SVGPVAE_model.py:823-936.  Returns (elbo, recon_loss, KL_term, inside_elbo, ce_term, p_m, p_v, qnet_mu,
+    qnet_var, recon_images, inside_elbo_recon, inside_elbo_kl, latent_samples, C_ma, lagrange_mult,
+    mean_vectors).  With GECO the `elbo` slot holds the GECO loss and recon_loss is kappa^2-shifted, as in
+    the reference (:909-913).  epsilon (b,L): the N(0,1) draw of :901; None -> drawn on device."""
+    if repr_NN is not None or bias_analysis:
+        raise NotImplementedError("SPRITES representation network / bias analysis are not part of this build")
+    eng, b = _prepare(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha, kappa, clipping_qs, GECO, epsilon)
+    with torch.cuda.stream(eng.stream):
+        eng.phase(0)
+        eng.phase(1)
+        eng.phase(2)                 # gradients come with the forward at negligible cost
+        eng.phase(3, adam=False)
+    eng.synchronize()
+    return _tuple16(eng, b)
+
+
+def gradients_SVGPVAE(vae, svgp):
+    """d(minimised objective)/d(parameters) of the last forward_pass_SVGPVAE / train_step_SVGPVAE
+    (tf.gradients of MNIST_experiment.py:202-205: GECO -> `elbo` slot, else -elbo)."""
+    return {k: v.clone() for k, v in svgp._rt.eng.grads().items()}
+
+
+def train_step_SVGPVAE(data_batch, beta, vae, svgp, alpha, kappa, lr, clipping_qs=False, GECO=False,
+                       epsilon=None, reset=False):
+    """One optimiser step = the reference's `sess.run([optim_step, ...])` (MNIST_experiment.py:334-340):
+    forward, reverse, TF1 Adam, and the GECO state carry (C_ma, lagrange_mult, first-step alpha=0) kept on
+    device between calls.  Returns the 16-tuple of the step."""
+    images = data_batch[0]
+    rt = _runtime(vae, svgp, clipping_qs, GECO, kappa, images.shape[0], alpha_flag=alpha)
+    eng = rt.eng
+    if reset:
+        eng.reset_state()
+    eng.set_batch_size(images.shape[0])
+    eng.set_scalars(beta=float(beta), lr=float(lr))
+    dev = eng.device
+    eng.bind(images.to(dev, _F64).contiguous(), data_batch[1].to(dev, _F64).contiguous(),
+             None if epsilon is None else epsilon.to(dev, _F64).contiguous())
+    eng.run(adam=True)
+    eng.synchronize()
+    return _tuple16(eng, images.shape[0])
+
+
+def batching_encode_SVGPVAE(data_batch, vae, clipping_qs=False, repr_nn=None, segment_ids=None, repeats=None):
+    """SVGPVAE_model.py:939-968: (qnet_mu, qnet_var, aux_data)."""
+    if repr_nn is not None:
+        raise NotImplementedError("SPRITES representation network is not part of this build")
+    images, aux_data = data_batch
+    mu, var = vae.encode(images)
+    if clipping_qs:
+        var = torch.clamp(var, 1e-3, 10.0)
+    return mu, var, aux_data

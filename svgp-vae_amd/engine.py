@@ -133,14 +133,19 @@ class MnistStepEngine:
         st[STATE["ALPHA"]] = 0.0 if self.base["geco"] else self.base["alpha"]
         st[STATE["LR"]] = float(self.state[STATE["LR"]]) if lr is None else lr
         st[STATE["BETA"]] = float(self.state[STATE["BETA"]]) if beta is None else beta
-        self.state.copy_(st)
+        with torch.cuda.stream(self.stream):
+            self.state.copy_(st)
+        self.stream.synchronize()
 
     def set_scalars(self, **kw):
         """Host writes into the device state vector (names of _lib.STATE, lower-case accepted)."""
+        self.stream.synchronize()
         st = self.state.cpu()
         for k, v in kw.items():
             st[STATE[k.upper()]] = float(v)
-        self.state.copy_(st)
+        with torch.cuda.stream(self.stream):
+            self.state.copy_(st)
+        self.stream.synchronize()
 
     def scalars(self):
         st = self.state.cpu()
@@ -154,11 +159,13 @@ class MnistStepEngine:
 
     def load_params(self, params):
         """params: dict name -> array-like (numpy / torch, any device)."""
-        for k, v in params.items():
-            if k not in self.params:
-                raise KeyError(k)
-            self.params[k].copy_(torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v,
-                                                 dtype=torch.float64).reshape(self.shapes[k]))
+        with torch.cuda.stream(self.stream):
+            for k, v in params.items():
+                if k not in self.params:
+                    raise KeyError(k)
+                self.params[k].copy_(torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v,
+                                                     dtype=torch.float64).reshape(self.shapes[k]))
+        self.stream.synchronize()
 
     def ws_view(self, name, shape=None):
         off = getattr(self.wl, name)
@@ -183,6 +190,8 @@ class MnistStepEngine:
         assert eps is None or (eps.dtype == torch.float64 and eps.is_contiguous() and eps.shape == (b, self.base["L"]))
         if b != self.cfg.b:
             raise ValueError(f"batch rows {b} != configured {self.cfg.b}; call set_batch_size first")
+        # the batch may have been produced on torch's current stream; kernels run on self.stream
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         self._bound = (images, aux, eps)
 
     def phase(self, k, adam=True):

@@ -1,0 +1,88 @@
+"""CPU-side checks of the drop-in boundary: the built library loads, exports every symbol
+include/svgpvae_hip.h declares, the ctypes binding covers them all, layouts are consistent, and
+the product path fails loudly without a GPU / without the extension (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import svgp_vae_amd
+from svgp_vae_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "svgpvae_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(svgp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(svgp_vae_amd.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = C.CDLL(svgp_vae_amd.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/svgpvae_hip.h but not exported"
+    bound = set(_lib.SIGNATURES) | set(_lib.NON_STATUS)
+    assert bound == set(names), (sorted(bound - set(names)), sorted(set(names) - bound))
+
+
+def test_layouts_match_reference_parameter_count_and_are_disjoint():
+    lib = svgp_vae_amd.load_library()
+    assert lib.svgp_version() == 1
+    cfg = _lib.MnistCfg(b=256, b_global=256, m=32, L=16, M=8, n_obj=400, N_train=4050.0, jitter=1e-6)
+    pl, wl = _lib.ParamLayout(), _lib.WsLayout()
+    _lib.call("svgp_mnist_param_layout_get", C.byref(cfg), C.byref(pl))
+    _lib.call("svgp_mnist_ws_layout_get", C.byref(cfg), C.byref(wl))
+    # 5721 VAE + 32x10 inducing + l, amp + 400x8 object vectors = 9243 trainables
+    assert (pl.n_enc, pl.n_vae, pl.n_total) == (2304, 5721, 9243)
+    offs = sorted(getattr(wl, f) for f in _lib.WS_FIELDS
+                  if f not in ("statA_len", "statB_len", "gradC_len", "n_part", "n_post", "total",
+                               "statA", "statB", "gradC"))
+    assert all(o >= 0 for o in offs) and offs[-1] < wl.total
+    assert wl.statA == wl.S and wl.v == wl.S + 16 * 32 * 32 and wl.statA_len == 16 * 32 * 33
+    assert wl.statB_len == 16 * 32 * 34 and wl.gradC_len == 9243 + 8 and wl.sums == wl.grad + 9243
+
+
+def test_bad_shapes_are_rejected_with_a_message():
+    cfg = _lib.MnistCfg(b=256, b_global=256, m=256, L=16, M=8, n_obj=400, N_train=4050.0, jitter=1e-6)
+    with pytest.raises(svgp_vae_amd.SvgpError, match="m <= 64"):
+        _lib.call("svgp_mnist_ws_layout_get", C.byref(cfg), C.byref(_lib.WsLayout()))
+    cfg = _lib.MnistCfg(b=0, b_global=0, m=8, L=1, M=1, n_obj=0, N_train=1.0)
+    with pytest.raises(svgp_vae_amd.SvgpError, match="b_global"):
+        _lib.call("svgp_mnist_param_layout_get", C.byref(cfg), C.byref(_lib.ParamLayout()))
+
+
+def test_null_pointers_are_rejected_before_any_launch():
+    cfg = _lib.MnistCfg(b=4, b_global=4, m=8, L=2, M=2, n_obj=0, N_train=10.0, jitter=1e-6)
+    with pytest.raises(svgp_vae_amd.SvgpError, match="NULL"):
+        _lib.call("svgp_mnist_encoder_fwd", C.byref(cfg), None, None, None, None)
+    with pytest.raises(svgp_vae_amd.SvgpError, match="phase"):
+        _lib.call("svgp_mnist_step_phase", C.byref(cfg), 7, 1, 1, 1, None, 1, 1, None, None, None)
+
+
+def test_missing_extension_fails_loudly(tmp_path):
+    with pytest.raises(svgp_vae_amd.SvgpError, match="no CPU fallback"):
+        svgp_vae_amd.load_library(str(tmp_path / "nope.so"))
+
+
+def test_engine_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from svgp_vae_amd.engine import MnistStepEngine
+    with pytest.raises(svgp_vae_amd.SvgpError, match="no CPU execution path"):
+        MnistStepEngine(32)
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "svgp-vae_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn

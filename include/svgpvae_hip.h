@@ -98,7 +98,7 @@ typedef struct {
     int64_t d_on;                         /* (b,M) gradient of gathered object rows               */
     /* partial sums */
     int64_t part_dec, part_enc, n_part;   /* (n_part, n_dec) / (n_part, n_enc) weight-grad partials */
-    int64_t part_gp;                      /* (m + n_rowblk, 2) amplitude / length-scale partials  */
+    int64_t part_gp;                      /* (m + n_postblk, 2) amplitude / length-scale partials */
     int64_t part_sums, n_post;            /* (n_part,4) [.,.,recon sq,.] then (n_post,2) [L3 data, CE] */
     /* final all-reduce block: [grad (n_total) | sums (8)] */
     int64_t gradC, gradC_len, grad, sums;

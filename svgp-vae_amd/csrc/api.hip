@@ -84,7 +84,7 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->n_part = svgp_n_part(c);
     o->part_dec = take(o->n_part * (pl.n_vae - pl.n_enc));
     o->part_enc = take(o->n_part * pl.n_enc);
-    o->part_gp = take((m + svgp_n_rowblk(c)) * 2);
+    o->part_gp = take((m + svgp_n_postblk(c)) * 2);
     o->n_post = (int64_t)L * svgp_n_postblk(c);
     o->part_sums = take(o->n_part * 4 + o->n_post * 2);
     o->gradC = p; o->grad = p; p += pl.n_total; o->sums = p; p += 8; o->gradC_len = p - o->gradC; take(0);

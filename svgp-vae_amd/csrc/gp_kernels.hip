@@ -24,86 +24,126 @@ __device__ __forceinline__ void mat_load(real* R, int ld, const real* __restrict
 __device__ __forceinline__ void mat_store(real* __restrict__ g, const real* R, int ld, int m) {
     for (int o = threadIdx.x; o < m * m; o += blockDim.x) g[o] = R[(o / m) * ld + (o % m)];
 }
-// C = alpha * op(A) * op(B)   (all LDS, C must not alias A or B)
+// ---- float64 MFMA GEMMs on LDS matrices -------------------------------------------------------
+// The factor kernels keep their matrices PADDED: mp = m rounded up to 16, leading dimension
+// ld = mp + 2 (conflict-free 16-row x 4-k operand fetch with 8-byte elements), pad region zero.
+// One wave computes one 16x16 output tile with v_mfma_f64_16x16x4_f64 (A[i=lane&15][k=lane>>4],
+// B[k=lane>>4][j=lane&15], D: col = lane&15, row = (lane>>4) + 4*reg), k-steps of 4 over mp.
+// Zero pads contribute nothing and pad outputs are written as zeros, so padding is preserved.
+typedef double d4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int pad16(int m) { return (m + 15) & ~15; }
+
+template <bool TA, bool TB>
+__device__ __forceinline__ d4_t mfma_tile(const real* A, const real* B, int ld, int mp, int ti, int tj) {
+    const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    d4_t acc = {0, 0, 0, 0};
+    const real* ap = TA ? A + q * ld + ti * 16 + r : A + (ti * 16 + r) * ld + q;
+    const real* bp = TB ? B + (tj * 16 + r) * ld + q : B + q * ld + tj * 16 + r;
+    const int as = TA ? 4 * ld : 4, bs = TB ? 4 : 4 * ld;
+    for (int k0 = 0; k0 < mp; k0 += 4) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(*ap, *bp, acc, 0, 0, 0);
+        ap += as;
+        bp += bs;
+    }
+    return acc;
+}
+// C = alpha * op(A) * op(B)   (all LDS padded, C must not alias A or B)
 template <bool TA, bool TB>
 __device__ __forceinline__ void mat_gemm(real* C, const real* A, const real* B, int ld, int m, real alpha) {
-    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
-        const int i = o / m, j = o % m;
-        real acc = 0;
-        for (int k = 0; k < m; ++k) {
-            const real a = TA ? A[k * ld + i] : A[i * ld + k];
-            const real b = TB ? B[j * ld + k] : B[k * ld + j];
-            acc += a * b;
-        }
-        C[i * ld + j] = alpha * acc;
+    const int mp = pad16(m), nt = mp >> 4, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    for (int t = threadIdx.x >> 6; t < nt * nt; t += (blockDim.x >> 6)) {
+        const int ti = t / nt, tj = t % nt;
+        const d4_t acc = mfma_tile<TA, TB>(A, B, ld, mp, ti, tj);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) C[(ti * 16 + q + 4 * g) * ld + tj * 16 + r] = alpha * acc[g];
     }
 }
-// Cg (global, ld = m) = alpha * op(A) * op(B) + beta * Cg
+// Cg (global, m x m, ld = m) = alpha * op(A) * op(B) + beta * Cg
 template <bool TA, bool TB>
 __device__ __forceinline__ void mat_gemm_g(real* __restrict__ Cg, const real* A, const real* B, int ld, int m,
                                            real alpha, real beta) {
-    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
-        const int i = o / m, j = o % m;
-        real acc = 0;
-        for (int k = 0; k < m; ++k) {
-            const real a = TA ? A[k * ld + i] : A[i * ld + k];
-            const real b = TB ? B[j * ld + k] : B[k * ld + j];
-            acc += a * b;
+    const int mp = pad16(m), nt = mp >> 4, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    for (int t = threadIdx.x >> 6; t < nt * nt; t += (blockDim.x >> 6)) {
+        const int ti = t / nt, tj = t % nt;
+        const d4_t acc = mfma_tile<TA, TB>(A, B, ld, mp, ti, tj);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int i = ti * 16 + q + 4 * g, j = tj * 16 + r;
+            if (i < m && j < m) {
+                const size_t o = (size_t)i * m + j;
+                Cg[o] = alpha * acc[g] + (beta != real(0) ? beta * Cg[o] : real(0));
+            }
         }
-        Cg[o] = alpha * acc + (beta != real(0) ? beta * Cg[o] : real(0));
     }
 }
 // y = alpha * A x (+ y0), threads < m; x, y in LDS (y must not alias x)
 __device__ __forceinline__ void mat_vec(real* y, const real* A, int ld, const real* x, int m, real alpha) {
     if (threadIdx.x < m) {
         real acc = 0;
+#pragma unroll 8
         for (int j = 0; j < m; ++j) acc += A[threadIdx.x * ld + j] * x[j];
         y[threadIdx.x] = alpha * acc;
     }
 }
 
-// A (SPD, LDS) <- A^{-1} via Cholesky; W is an m x m LDS scratch.  Returns log det A (all
-// threads).  Begins and ends with a barrier.
-__device__ real chol_inv(real* A, real* W, int ld, int m) {
+// A (SPD, LDS) <- A^{-1}; returns log det A (all threads).  Gauss-Jordan elimination without
+// pivoting (safe for the jittered SPD matrices of this path; pivots = the LDL^T diagonal, so
+// log det = sum log pivot).  Every thread keeps its EPT elements of A in REGISTERS for all m
+// steps; only the pivot row / column travel through a ping-pong LDS buffer (W, >= 5m reals), so
+// a step costs one barrier.  Begins and ends with a barrier.
+template <int EPT>
+__device__ __forceinline__ real spd_inv_t(real* A, real* W, int ld, int m) {
+    real a[EPT];
+    int ii[EPT], jj[EPT];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < EPT; ++t) {
+        const int o = threadIdx.x + t * blockDim.x;
+        if (o < m * m) { ii[t] = o / m; jj[t] = o % m; a[t] = A[ii[t] * ld + jj[t]]; }
+        else { ii[t] = -1; jj[t] = -1; a[t] = 0; }
+    }
     real logdet = 0;
-    // 1. right-looking Cholesky, lower factor in the lower triangle of A
     for (int k = 0; k < m; ++k) {
+        real* rowk = W + (k & 1) * 2 * m;
+        real* colk = rowk + m;
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) {
+            if (ii[t] == k) rowk[jj[t]] = a[t];
+            if (jj[t] == k) colk[ii[t]] = a[t];
+        }
         __syncthreads();
-        const real lkk = sqrt(A[k * ld + k]);
-        const real inv = real(1) / lkk;
-        logdet += real(2) * log(lkk);
-        for (int i = k + 1 + threadIdx.x; i < m; i += blockDim.x) A[i * ld + k] *= inv;
-        __syncthreads();
-        if (threadIdx.x == 0) A[k * ld + k] = lkk;
-        const int n = m - k - 1;
-        for (int idx = threadIdx.x; idx < n * n; idx += blockDim.x) {
-            const int i = k + 1 + idx / n, j = k + 1 + idx % n;
-            if (j <= i) A[i * ld + j] -= A[i * ld + k] * A[j * ld + k];
+        const real piv = rowk[k];
+        const real ipiv = real(1) / piv;
+        if (threadIdx.x == 0) W[4 * m + k] = piv;       // logs are taken in parallel after the sweep
+#pragma unroll
+        for (int t = 0; t < EPT; ++t) {
+            if (ii[t] >= 0) {
+                const int i = ii[t], j = jj[t];
+                const real rkj = (j == k) ? ipiv : rowk[j] * ipiv;
+                if (i == k) a[t] = rkj;
+                else a[t] = ((j == k) ? real(0) : a[t]) - colk[i] * rkj;
+            }
         }
     }
+#pragma unroll
+    for (int t = 0; t < EPT; ++t)
+        if (ii[t] >= 0) A[ii[t] * ld + jj[t]] = a[t];
     __syncthreads();
-    // 2. X = L^{-1} (lower) into W, one thread per column
-    for (int o = threadIdx.x; o < m * m; o += blockDim.x) W[(o / m) * ld + (o % m)] = 0;
-    __syncthreads();
-    if (threadIdx.x < m) {
-        const int j = threadIdx.x;
-        W[j * ld + j] = real(1) / A[j * ld + j];
-        for (int i = j + 1; i < m; ++i) {
-            real acc = 0;
-            for (int k = j; k < i; ++k) acc += A[i * ld + k] * W[k * ld + j];
-            W[i * ld + j] = -acc / A[i * ld + i];
-        }
+    // log det = sum_k log(pivot_k): one log per lane of wave 0, fixed-order combine, broadcast via LDS
+    if (threadIdx.x < 64) {
+        real lg = 0;
+        for (int k = threadIdx.x; k < m; k += 64) lg += log(W[4 * m + k]);
+        lg = wave_sum(lg);
+        if (threadIdx.x == 0) W[0] = lg;
     }
     __syncthreads();
-    // 3. A^{-1} = X^T X
-    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
-        const int i = o / m, j = o % m;
-        real acc = 0;
-        for (int k = (i > j ? i : j); k < m; ++k) acc += W[k * ld + i] * W[k * ld + j];
-        A[i * ld + j] = acc;
-    }
+    logdet = W[0];
     __syncthreads();
     return logdet;
+}
+__device__ __forceinline__ real chol_inv(real* A, real* W, int ld, int m) {
+    // SVGP_BLOCK threads: m <= 32 -> 4 elements per thread, m <= 64 -> 16
+    return (m * m <= 4 * SVGP_BLOCK) ? spd_inv_t<4>(A, W, ld, m) : spd_inv_t<16>(A, W, ld, m);
 }
 
 // =============================================================================================
@@ -243,53 +283,75 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_cols(KernArgs 
     }
 }
 
-// VJP, batch-row side: one thread per batch row -> d_on (b,M) (gradient of the gathered object
-// row) and the k_nn part of the amplitude gradient (partials per 64-row block).
-__global__ __launch_bounds__(64) void k_kernel_matrix_bwd_rows(KernArgs a, const real* __restrict__ Knbar,
-                                                               const real* __restrict__ knnbar,
-                                                               const real* __restrict__ knn,
-                                                               real* __restrict__ d_on, real* __restrict__ part_gp) {
-    const int n = blockIdx.x * 64 + threadIdx.x, st = 2 + a.M, M = a.M;
+// VJP, batch-row side.  grid ceil(b/RB), RB = 256/m rows per workgroup.  Phase 1: thread (row, j)
+// computes c = Knbar * view(theta_n - theta_j) / |o_j|; phase 2: thread (row, k) reduces over j ->
+// d_on (b,M), the gradient of the gathered object row.  Also the k_nn part of the amplitude gradient.
+__global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_rows(KernArgs a, const real* __restrict__ Knbar,
+                                                                       const real* __restrict__ knnbar,
+                                                                       const real* __restrict__ knn,
+                                                                       real* __restrict__ d_on,
+                                                                       real* __restrict__ part_gp) {
+    extern __shared__ __align__(16) real smem[];
+    __shared__ real red[16];
+    const int m = a.m, M = a.M, st = 2 + M, RB = blockDim.x / m;
+    real* O = smem;                 // m x M inducing object vectors, divided by their norm when normalising
+    real* cbuf = O + m * M;         // RB x m
+    real* gbuf = cbuf + SVGP_BLOCK; // RB x M (<= 256*32/m ... bounded by RB*M <= 8192/m*... see host check)
     const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
-    real acc_amp = 0;
-    if (n < a.b) {
-        const real* on = obj_row(a, n);
-        const real nn = a.normalize ? sqrt(dotM(on, on, M)) : real(1);
-        const real thn = a.aux[(size_t)n * st + 1];
-        real g[KM_MAXM];
-#pragma unroll
-        for (int k = 0; k < KM_MAXM; ++k) g[k] = 0;
-        for (int j = 0; j < a.m; ++j) {
-            const real* oj = a.ip + (size_t)j * st + 2;
-            const real nj = a.normalize ? sqrt(dotM(oj, oj, M)) : real(1);
-            const real c = Knbar[(size_t)n * a.m + j] * view_k(thn - a.ip[(size_t)j * st + 1], a2, inv_l2) / nj;
-#pragma unroll
-            for (int k = 0; k < KM_MAXM; ++k)
-                if (k < M) g[k] += c * oj[k];
+    for (int o = threadIdx.x; o < m * M; o += blockDim.x) {
+        const int j = o / M;
+        const real* oj = a.ip + (size_t)j * st + 2;
+        const real nj = a.normalize ? sqrt(dotM(oj, oj, M)) : real(1);
+        O[o] = oj[o % M] / nj;
+    }
+    {
+        const int nl = threadIdx.x / m, j = threadIdx.x % m, n = blockIdx.x * RB + nl;
+        real c = 0;
+        if (nl < RB && n < a.b)
+            c = Knbar[(size_t)n * m + j] * view_k(a.aux[(size_t)n * st + 1] - a.ip[(size_t)j * st + 1], a2, inv_l2);
+        if (nl < RB) cbuf[nl * m + j] = c;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < RB * M; it += blockDim.x) {
+        const int nl = it / M, k = it % M, n = blockIdx.x * RB + nl;
+        real g = 0;
+        if (n < a.b) {
+            for (int j = 0; j < m; ++j) g += cbuf[nl * m + j] * O[j * M + k];
+            const real* on = obj_row(a, n);
+            const real nn = a.normalize ? sqrt(dotM(on, on, M)) : real(1);
+            g += real(2) * a2 * knnbar[n] * on[k] / nn;      // k_nn = a^2 |o_hat|^2
         }
-        const real gk = knnbar[n];
-        acc_amp = real(2) * gk * knn[n] / amp;
-        // k_nn = a^2 |o_hat|^2 ; d/d o_hat = 2 a^2 o_hat
-        real proj = 0;
-        for (int k = 0; k < M; ++k) {
-            g[k] += real(2) * a2 * gk * on[k] / nn;
-            proj += g[k] * on[k] / nn;
-        }
-        for (int k = 0; k < M; ++k) {
-            real v = g[k];
-            if (a.normalize) v = (v - proj * on[k] / nn) / nn;
+        gbuf[it] = g;
+    }
+    __syncthreads();
+    for (int it = threadIdx.x; it < RB * M; it += blockDim.x) {
+        const int nl = it / M, k = it % M, n = blockIdx.x * RB + nl;
+        if (n < a.b) {
+            real v = gbuf[it];
+            if (a.normalize) {       // o_hat = o/|o| : d_o = (d_oh - <d_oh,o_hat> o_hat)/|o|
+                const real* on = obj_row(a, n);
+                const real nn = sqrt(dotM(on, on, M));
+                real proj = 0;
+                for (int kk = 0; kk < M; ++kk) proj += gbuf[nl * M + kk] * on[kk] / nn;
+                v = (v - proj * on[k] / nn) / nn;
+            }
             d_on[(size_t)n * M + k] = v;
         }
     }
-    acc_amp = wave_sum(acc_amp);
+    real acc_amp = 0;
+    {
+        const int n = blockIdx.x * RB + threadIdx.x;
+        if (threadIdx.x < RB && n < a.b) acc_amp = real(2) * knnbar[n] * knn[n] / amp;
+    }
+    acc_amp = block_sum(acc_amp, red);
     if (threadIdx.x == 0) {
-        part_gp[(a.m + blockIdx.x) * 2 + 0] = acc_amp;
-        part_gp[(a.m + blockIdx.x) * 2 + 1] = 0;
+        part_gp[(m + blockIdx.x) * 2 + 0] = acc_amp;
+        part_gp[(m + blockIdx.x) * 2 + 1] = 0;
     }
 }
 
 // Deterministic scatter-add of d_on into the object table gradient (duplicate ids sum in row
-// order) + final amplitude / length-scale sums.  Last block does the scalars.
+// order; ids staged through LDS) + final amplitude / length-scale sums.  Last block does the scalars.
 __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernArgs a, int n_gp_part, int train_gp,
                                                                           int train_ov,
                                                                           const real* __restrict__ d_on,
@@ -297,8 +359,9 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernAr
                                                                           real* __restrict__ d_ov,
                                                                           real* __restrict__ d_ls,
                                                                           real* __restrict__ d_amp) {
+    __shared__ int ids[1024];
+    __shared__ real red[16];
     if (blockIdx.x == gridDim.x - 1) {
-        __shared__ real red[16];
         real sa = 0, sl = 0;
         for (int i = threadIdx.x; i < n_gp_part; i += blockDim.x) { sa += part_gp[i * 2]; sl += part_gp[i * 2 + 1]; }
         sa = block_sum(sa, red);
@@ -307,13 +370,19 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernAr
         return;
     }
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= a.n_obj * a.M) return;
-    const int r = o / a.M, k = o % a.M, st = 2 + a.M;
+    const bool act = o < a.n_obj * a.M;
+    const int r = act ? o / a.M : -1, k = act ? o % a.M : 0, st = 2 + a.M;
     real acc = 0;
-    if (train_ov)
-        for (int n = 0; n < a.b; ++n)
-            if ((long long)a.aux[(size_t)n * st] == r) acc += d_on[(size_t)n * a.M + k];
-    d_ov[o] = acc;
+    for (int n0 = 0; n0 < a.b; n0 += 1024) {
+        const int cnt = min(1024, a.b - n0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt; t += blockDim.x) ids[t] = (int)a.aux[(size_t)(n0 + t) * st];
+        __syncthreads();
+        if (train_ov && act)
+            for (int t = 0; t < cnt; ++t)
+                if (ids[t] == r) acc += d_on[(size_t)(n0 + t) * a.M + k];
+    }
+    if (act) d_ov[o] = acc;
 }
 
 // =============================================================================================
@@ -323,9 +392,8 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernAr
 // mode 1 (backward): computes g_pv, g_pm, mvbar (stored) and uses w = g_pv, a = mvbar, b = c g_pm
 // In forward mode the extra block blockIdx.y == L inverts K_mm + jitter I (:239,270,273).
 // =============================================================================================
-#define STAT_RC 64   // rows staged per pass
 struct StatArgs {
-    int b, m, L, mode;
+    int b, m, L, mode, rc_rows;   // rc_rows: rows of K_nm staged per pass
     real c, jitter, beta_over_L_unused;
     int geco;
     const real* Kn;      // (b,m)
@@ -361,6 +429,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
         if (threadIdx.x == 0) *a.ldK = logdet;
         return;
     }
+    const int STAT_RC = a.rc_rows;
     real* kt = smem;                   // STAT_RC x m tile of Kn
     real* w = kt + STAT_RC * m;        // STAT_RC
     real* va = w + STAT_RC;            // STAT_RC
@@ -375,27 +444,29 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
         const int rows = min(STAT_RC, a.b - r0);
         __syncthreads();
         for (int t = threadIdx.x; t < rows * m; t += blockDim.x) kt[t] = a.Kn[(size_t)r0 * m + t];
-        if (threadIdx.x < rows) {
-            const size_t e = (size_t)(r0 + threadIdx.x) * a.L + l;
+        for (int rr = threadIdx.x; rr < rows; rr += blockDim.x) {
+            const size_t e = (size_t)(r0 + rr) * a.L + l;
             const real p = recip_no_nan(a.s2[e]);
             if (a.mode == 0) {
-                w[threadIdx.x] = p;
-                va[threadIdx.x] = p * a.y[e];
-                vb[threadIdx.x] = 0;
+                w[rr] = p;
+                va[rr] = p * a.y[e];
+                vb[rr] = 0;
             } else {
                 const real zb = a.zbar[e];
                 const real gpv = real(0.5) * gT * p + zb * a.eps[e] / (real(2) * sqrt(a.p_v[e]));
                 const real gpm = gT * p * (a.p_m[e] - a.y[e]) + zb;
                 const real mvb = gT * p * a.e[e];
-                w[threadIdx.x] = gpv;
-                va[threadIdx.x] = mvb;
-                vb[threadIdx.x] = a.c * gpm;
+                w[rr] = gpv;
+                va[rr] = mvb;
+                vb[rr] = a.c * gpm;
                 if (blockIdx.x == 0) { a.g_pv[e] = gpv; a.g_pm[e] = gpm; a.mvbar[e] = mvb; }
             }
         }
         __syncthreads();
-        if (act)
+        if (act) {
+#pragma unroll 4
             for (int r = 0; r < rows; ++r) accS += w[r] * kt[r * m + i] * kt[r * m + j];
+        }
         if (vec)
             for (int r = 0; r < rows; ++r) {
                 const real k = kt[r * m + threadIdx.x];
@@ -423,11 +494,13 @@ struct FactArgs {
 
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
     extern __shared__ __align__(16) real smem[];
-    const int m = a.m, ld = m + 1, mm = m * ld;
+    const int m = a.m, mp = pad16(m), ld = mp + 2, mm = mp * ld;
     real* R0 = smem;
     real* R1 = R0 + mm;
     real* R2 = R1 + mm;
     real* R3 = R2 + mm;
+    for (int o = threadIdx.x; o < 4 * mm; o += blockDim.x) smem[o] = 0;   // zero pads (MFMA tiles read them)
+    __syncthreads();
     real* vx = R3 + mm;       // m
     real* vy = vx + m;        // m
     real* vz = vy + m;        // m
@@ -615,11 +688,13 @@ struct FactBwdArgs {
 
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     extern __shared__ __align__(16) real smem[];
-    const int m = a.m, ld = m + 1, mm = m * ld, l = blockIdx.x;
+    const int m = a.m, mp = pad16(m), ld = mp + 2, mm = mp * ld, l = blockIdx.x;
     real* R0 = smem;
     real* R1 = R0 + mm;
     real* R2 = R1 + mm;
     real* R3 = R2 + mm;
+    for (int o = threadIdx.x; o < 4 * mm; o += blockDim.x) smem[o] = 0;   // zero pads (MFMA tiles read them)
+    __syncthreads();
     real* ubar = R3 + mm;      // m
     real* mubar = ubar + m;    // m
     real* tbar = mubar + m;    // m
@@ -704,34 +779,27 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
         a.Ssym[om + o] = ss;
         a.Qm[om + o] = ss - g3 * a.M2[om + o];
     }
+    // Kbar_l -= Ki Kibar_l Ki  (the inverse's VJP is linear, so it is applied per channel here and
+    // the final kernel only sums channels).  Kib was written by this workgroup above.
+    __syncthreads();
+    mat_load(R1, ld, a.Ki, m);
+    mat_load(R2, ld, Kib, m);
+    __syncthreads();
+    mat_gemm<false, false>(R3, R1, R2, ld, m, real(1));
+    __syncthreads();
+    mat_gemm_g<false, false>(Kb, R3, R1, ld, m, real(-1), real(1));
 }
 
+// Kbar = sum_l Kbar_l + (L gK / 2) Ki ; one thread per element, channel loads batched.
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd_final(FactBwdArgs a) {
-    extern __shared__ __align__(16) real smem[];
-    const int m = a.m, ld = m + 1, mm = m * ld;
-    real* R0 = smem;
-    real* R1 = R0 + mm;
-    real* R2 = R1 + mm;
-    real* R3 = R2 + mm;
+    const int m = a.m, o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= m * m) return;
     const real gT = grad_KL_term(a.geco, a.L, a.state);
     const real gK = -gT * ((real)a.b_global / a.N_train);
-    mat_load(R0, ld, a.Ki, m);
-    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
-        real s = 0;
-        for (int l = 0; l < a.L; ++l) s += a.Kibar_part[(size_t)l * m * m + o];
-        R1[(o / m) * ld + (o % m)] = s;
-    }
-    __syncthreads();
-    mat_gemm<false, false>(R2, R0, R1, ld, m, real(1));
-    __syncthreads();
-    mat_gemm<false, false>(R3, R2, R0, ld, m, real(1));     // Ki Kibar Ki
-    __syncthreads();
-    for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
-        real s = 0;
-        for (int l = 0; l < a.L; ++l) s += a.Kbar_part[(size_t)l * m * m + o];
-        const int idx = (o / m) * ld + (o % m);
-        a.Kbar[o] = s - R3[idx] + real(0.5) * gK * (real)a.L * R0[idx];
-    }
+    real s = 0;
+#pragma unroll 8
+    for (int l = 0; l < a.L; ++l) s += a.Kbar_part[(size_t)l * m * m + o];
+    a.Kbar[o] = s + real(0.5) * gK * (real)a.L * a.Ki[o];
 }
 
 // =============================================================================================
@@ -864,6 +932,10 @@ KernArgs make_kern_args(const svgp_mnist_cfg* c, const svgp_mnist_param_layout& 
     }
 
 static inline size_t mat_lds(int m, int nmat) { return (size_t)nmat * m * (m + 1) * sizeof(real); }
+static inline size_t mat_lds_pad(int m, int nmat) {
+    const int mp = (m + 15) & ~15;
+    return (size_t)nmat * mp * (mp + 2) * sizeof(real);
+}
 
 extern "C" int svgp_kernel_matrix_fwd(const svgp_mnist_cfg* c, const double* theta, const double* aux, double* ws,
                                       void* stream) {
@@ -887,9 +959,14 @@ extern "C" int svgp_kernel_matrix_bwd(const svgp_mnist_cfg* c, const double* the
                        c->rep_weight, c->train_ip, ws + wl.K, ws + wl.Kn, ws + wl.Kbar, ws + wl.Knbar, grad + pl.ip,
                        ws + wl.part_gp);
     SVGP_LAUNCH_CHECK();
-    const int nrb = svgp_n_rowblk(c);
-    hipLaunchKernelGGL(k_kernel_matrix_bwd_rows, dim3(nrb), dim3(64), 0, (hipStream_t)stream, a, ws + wl.Knbar,
-                       ws + wl.knnbar, ws + wl.knn, ws + wl.d_on, ws + wl.part_gp);
+    const int RBk = SVGP_BLOCK / c->m, nrb = (c->b + RBk - 1) / RBk;
+    const size_t lds_rows = (size_t)(c->m * c->M + SVGP_BLOCK + RBk * c->M) * sizeof(real);
+    {
+        int rc_ = set_dyn_lds(k_kernel_matrix_bwd_rows, lds_rows);
+        if (rc_) return rc_;
+    }
+    hipLaunchKernelGGL(k_kernel_matrix_bwd_rows, dim3(nrb), dim3(SVGP_BLOCK), lds_rows, (hipStream_t)stream, a,
+                       ws + wl.Knbar, ws + wl.knnbar, ws + wl.knn, ws + wl.d_on, ws + wl.part_gp);
     SVGP_LAUNCH_CHECK();
     const int n_ov = c->n_obj * c->M;
     hipLaunchKernelGGL(k_kernel_matrix_bwd_scatter, dim3((n_ov + SVGP_BLOCK - 1) / SVGP_BLOCK + 1), dim3(SVGP_BLOCK), 0,
@@ -913,8 +990,10 @@ static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     else { a.S = ws + wl.A2; a.v1 = ws + wl.ud; a.v2 = ws + wl.td; }
     a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.ldK = ws + wl.ldK;
     const int m = c->m;
-    size_t lds = (size_t)(STAT_RC * m + 3 * STAT_RC) * sizeof(real);
-    const size_t lds_inv = mat_lds(m, 2);
+    a.rc_rows = 8192 / m;                       // 64 KB tile of K_nm rows per pass
+    if (a.rc_rows > c->b) a.rc_rows = c->b;
+    size_t lds = (size_t)(a.rc_rows * m + 3 * a.rc_rows) * sizeof(real);
+    const size_t lds_inv = mat_lds(m, 1) + (size_t)(5 * m + 16) * sizeof(real);
     if (mode == 0 && lds_inv > lds) lds = lds_inv;
     int rc = set_dyn_lds(k_gp_stats, lds);
     if (rc) return rc;
@@ -947,7 +1026,7 @@ extern "C" int svgp_gp_factor_fwd(const svgp_mnist_cfg* c, double* ws, void* str
     a.Si = ws + wl.Si; a.t = ws + wl.t; a.G = ws + wl.G; a.A = ws + wl.A; a.Aji = ws + wl.Aji; a.mu = ws + wl.mu_hat;
     a.u = ws + wl.u; a.M2 = ws + wl.M2; a.KL = ws + wl.KL; a.q = ws + wl.q;
     const int m = c->m, RB = rows_per_block(m);
-    const size_t lds = mat_lds(m, 4) + (size_t)(3 * m + 16 + SVGP_BLOCK) * sizeof(real);
+    const size_t lds = mat_lds_pad(m, 4) + (size_t)(3 * m + 16 + SVGP_BLOCK) * sizeof(real);
     int rc = set_dyn_lds(k_gp_factor_fwd, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gp_factor_fwd, dim3(c->L + (c->b + RB - 1) / RB), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
@@ -994,15 +1073,13 @@ extern "C" int svgp_gp_factor_bwd(const svgp_mnist_cfg* c, double* ws, const dou
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     FactBwdArgs a = make_fb(c, wl, ws, state);
     const int m = c->m;
-    const size_t lds = mat_lds(m, 4) + (size_t)(6 * m) * sizeof(real);
+    const size_t lds = mat_lds_pad(m, 4) + (size_t)(6 * m) * sizeof(real);
     int rc = set_dyn_lds(k_gp_factor_bwd, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(k_gp_factor_bwd, dim3(c->L), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
     SVGP_LAUNCH_CHECK();
-    const size_t lds2 = mat_lds(m, 4);
-    rc = set_dyn_lds(k_gp_factor_bwd_final, lds2);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_gp_factor_bwd_final, dim3(1), dim3(SVGP_BLOCK), lds2, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_gp_factor_bwd_final, dim3((m * m + SVGP_BLOCK - 1) / SVGP_BLOCK), dim3(SVGP_BLOCK), 0,
+                       (hipStream_t)stream, a);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

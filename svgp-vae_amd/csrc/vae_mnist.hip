@@ -14,8 +14,13 @@
 
 namespace {
 
+#define VAE_NT 512          // threads per workgroup of the VAE kernels (8 waves: 2 per SIMD)
+#define VAE_SCRATCH 4096    // reals of LDS scratch for the weight-gradient chunk reduction
+
 // 3x3 convolution on an LDS-resident NHWC tile.  Stored input is HS x HS x CIN; the effective
 // input is its nearest-neighbour upsampling by UPS (HE = HS*UPS) zero-padded by PAD.
+// All loops are branch-free inside (clamped address + select), so the unrolled bodies expose many
+// independent LDS reads per thread; each thread produces a small register tile.
 template <int HS, int UPS, int PAD, int STRIDE, int CIN, int COUT, int HOUT>
 struct Conv3 {
     static constexpr int HE = HS * UPS;
@@ -23,109 +28,134 @@ struct Conv3 {
     static constexpr int NOUT = HOUT * HOUT * COUT;
     static constexpr int NIN = HS * HS * CIN;
     static constexpr int NPIX = HOUT * HOUT;
+    static constexpr int COG = (COUT % 2 == 0) ? 2 : 1;   // outputs per forward item
+    static constexpr int NCG = COUT / COG;
+    static constexpr int CIG = (CIN % 2 == 0) ? 2 : 1;    // inputs per bwd-data item
+    static constexpr int NIG = CIN / CIG;
 
-    // out = elu(conv(in) + bias)
+    // out = elu(conv(in) + bias); item = (pixel, group of COG output channels)
     static __device__ void fwd(const real* in, const real* w, const real* bias, real* out) {
-        for (int o = threadIdx.x; o < NOUT; o += blockDim.x) {
-            const int co = o % COUT, x = (o / COUT) % HOUT, y = o / (COUT * HOUT);
-            real acc = bias[co];
+        for (int it = threadIdx.x; it < NPIX * NCG; it += VAE_NT) {
+            const int cg = it % NCG, p = it / NCG, x = p % HOUT, y = p / HOUT;
+            real acc[COG];
 #pragma unroll
+            for (int g = 0; g < COG; ++g) acc[g] = bias[cg * COG + g];
+#pragma unroll 1
             for (int ky = 0; ky < 3; ++ky) {
                 const int iy = y * STRIDE + ky - PAD;
-                if ((unsigned)iy >= (unsigned)HE) continue;
+                const bool vy = (unsigned)iy < (unsigned)HE;
+                const int cy = vy ? iy / UPS : 0;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int ix = x * STRIDE + kx - PAD;
-                    if ((unsigned)ix >= (unsigned)HE) continue;
-                    const real* src = in + ((iy / UPS) * HS + ix / UPS) * CIN;
-                    const real* wk = w + ((ky * 3 + kx) * CIN) * COUT + co;
+                    const bool valid = vy && ((unsigned)ix < (unsigned)HE);
+                    const int cx = valid ? ix / UPS : 0;
+                    const real* src = in + (cy * HS + cx) * CIN;
+                    const real* wk = w + ((ky * 3 + kx) * CIN) * COUT + cg * COG;
 #pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) acc += src[ci] * wk[ci * COUT];
+                    for (int ci = 0; ci < CIN; ++ci) {
+                        const real a = valid ? src[ci] : real(0);
+#pragma unroll
+                        for (int g = 0; g < COG; ++g) acc[g] += a * wk[ci * COUT + g];
+                    }
                 }
             }
-            out[o] = elu_f(acc);
+#pragma unroll
+            for (int g = 0; g < COG; ++g) out[p * COUT + cg * COG + g] = elu_f(acc[g]);
         }
     }
 
-    // din (stored coordinates, HS x HS x CIN) = conv^T(dpre) summed over the UPS x UPS replicas
+    // din (stored coordinates) = conv^T(dpre) summed over the UPS x UPS replicas;
+    // item = (stored pixel, group of CIG input channels)
     static __device__ void bwd_data(const real* dpre, const real* w, real* din) {
-        for (int i = threadIdx.x; i < NIN; i += blockDim.x) {
-            const int ci = i % CIN, xs = (i / CIN) % HS, ys = i / (CIN * HS);
-            real acc = 0;
+        for (int it = threadIdx.x; it < HS * HS * NIG; it += VAE_NT) {
+            const int ig = it % NIG, ps = it / NIG, xs = ps % HS, ys = ps / HS;
+            real acc[CIG];
 #pragma unroll
+            for (int g = 0; g < CIG; ++g) acc[g] = 0;
+#pragma unroll 1
             for (int dy = 0; dy < UPS; ++dy)
-#pragma unroll
+#pragma unroll 1
                 for (int dx = 0; dx < UPS; ++dx) {
                     const int ye = ys * UPS + dy, xe = xs * UPS + dx;
-#pragma unroll
+#pragma unroll 1
                     for (int ky = 0; ky < 3; ++ky) {
                         const int ty = ye + PAD - ky;
-                        if (ty < 0 || (ty % STRIDE) != 0) continue;
-                        const int y = ty / STRIDE;
-                        if (y >= HOUT) continue;
+                        const bool vy = ty >= 0 && (ty % STRIDE) == 0 && (ty / STRIDE) < HOUT;
+                        const int y = vy ? ty / STRIDE : 0;
 #pragma unroll
                         for (int kx = 0; kx < 3; ++kx) {
                             const int tx = xe + PAD - kx;
-                            if (tx < 0 || (tx % STRIDE) != 0) continue;
-                            const int x = tx / STRIDE;
-                            if (x >= HOUT) continue;
+                            const bool valid = vy && tx >= 0 && (tx % STRIDE) == 0 && (tx / STRIDE) < HOUT;
+                            const int x = valid ? tx / STRIDE : 0;
                             const real* dp = dpre + (y * HOUT + x) * COUT;
-                            const real* wk = w + ((ky * 3 + kx) * CIN + ci) * COUT;
+                            const real* wk = w + ((ky * 3 + kx) * CIN + ig * CIG) * COUT;
 #pragma unroll
-                            for (int co = 0; co < COUT; ++co) acc += dp[co] * wk[co];
+                            for (int co = 0; co < COUT; ++co) {
+                                const real d = valid ? dp[co] : real(0);
+#pragma unroll
+                                for (int g = 0; g < CIG; ++g) acc[g] += d * wk[g * COUT + co];
+                            }
                         }
                     }
                 }
-            din[i] = acc;
+#pragma unroll
+            for (int g = 0; g < CIG; ++g) din[ps * CIN + ig * CIG + g] = acc[g];
         }
     }
 
     // gw[(ky,kx,ci,co)] += sum_pixels in * dpre ;  gb[co] += sum_pixels dpre.
-    // scratch: >= 256 reals of LDS.  Ends with a barrier.
+    // item = (tap, ci, pixel chunk) producing all COUT outputs; chunks are combined through
+    // `scratch` (>= VAE_SCRATCH reals) in a fixed order.  Ends with a barrier.
     static __device__ void bwd_weight(const real* in, const real* dpre, real* gw, real* gb, real* scratch) {
-        constexpr int NCH = (NW >= SVGP_BLOCK) ? 1 : (SVGP_BLOCK / NW);   // pixel chunks per weight
-        if (NCH == 1) {
-            for (int widx = threadIdx.x; widx < NW; widx += blockDim.x) gw[widx] += wsum(in, dpre, widx, 0, 1);
-        } else {
-            const int chunk = threadIdx.x / NW, widx = threadIdx.x % NW;
-            if (chunk < NCH) scratch[chunk * NW + widx] = wsum(in, dpre, widx, chunk, NCH);
-            __syncthreads();
-            if (threadIdx.x < NW) {
-                real s = 0;
-                for (int c = 0; c < NCH; ++c) s += scratch[c * NW + threadIdx.x];
-                gw[threadIdx.x] += s;
+        constexpr int NTC = 9 * CIN;
+        constexpr int NCH0 = VAE_NT / NTC;
+        constexpr int NCH1 = VAE_SCRATCH / NW;
+        constexpr int NCH = NCH0 < NCH1 ? (NCH0 < 1 ? 1 : NCH0) : NCH1;
+        const int tc = threadIdx.x % NTC, chunk = threadIdx.x / NTC;
+        if (chunk < NCH) {
+            const int ci = tc % CIN, kx = (tc / CIN) % 3, ky = tc / (CIN * 3);
+            real acc[COUT];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[co] = 0;
+#pragma unroll 2
+            for (int p = chunk; p < NPIX; p += NCH) {
+                const int y = p / HOUT, x = p % HOUT;
+                const int iy = y * STRIDE + ky - PAD, ix = x * STRIDE + kx - PAD;
+                const bool valid = ((unsigned)iy < (unsigned)HE) && ((unsigned)ix < (unsigned)HE);
+                const int cy = valid ? iy / UPS : 0, cx = valid ? ix / UPS : 0;
+                const real a = valid ? in[(cy * HS + cx) * CIN + ci] : real(0);
+                const real* dp = dpre + p * COUT;
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] += a * dp[co];
             }
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) scratch[chunk * NW + tc * COUT + co] = acc[co];
         }
         __syncthreads();
-        // bias: thread t -> (co = t % COUT, pixel chunk t / COUT)
-        constexpr int BCH = SVGP_BLOCK / COUT;
-        {
-            const int co = threadIdx.x % COUT, chunk = threadIdx.x / COUT;
+        for (int widx = threadIdx.x; widx < NW; widx += VAE_NT) {
             real s = 0;
-            if (chunk < BCH)
-                for (int p = chunk; p < NPIX; p += BCH) s += dpre[p * COUT + co];
-            scratch[threadIdx.x] = (chunk < BCH) ? s : real(0);
-            __syncthreads();
-            if (threadIdx.x < COUT) {
-                real t = 0;
-                for (int c = 0; c < BCH; ++c) t += scratch[c * COUT + threadIdx.x];
-                gb[threadIdx.x] += t;
-            }
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) s += scratch[c * NW + widx];
+            gw[widx] += s;
         }
         __syncthreads();
-    }
-
-    static __device__ __forceinline__ real wsum(const real* in, const real* dpre, int widx, int p0, int pstep) {
-        const int co = widx % COUT, ci = (widx / COUT) % CIN, kx = (widx / (COUT * CIN)) % 3,
-                  ky = widx / (COUT * CIN * 3);
-        real acc = 0;
-        for (int p = p0; p < NPIX; p += pstep) {
-            const int y = p / HOUT, x = p % HOUT;
-            const int iy = y * STRIDE + ky - PAD, ix = x * STRIDE + kx - PAD;
-            if ((unsigned)iy >= (unsigned)HE || (unsigned)ix >= (unsigned)HE) continue;
-            acc += in[((iy / UPS) * HS + ix / UPS) * CIN + ci] * dpre[p * COUT + co];
+        // bias: item (co, pixel chunk), 32 chunks
+        constexpr int BCH = 32;
+        if (threadIdx.x < BCH * COUT) {
+            const int co = threadIdx.x % COUT, chunk2 = threadIdx.x / COUT;
+            real s = 0;
+            for (int p = chunk2; p < NPIX; p += BCH) s += dpre[p * COUT + co];
+            scratch[threadIdx.x] = s;
         }
-        return acc;
+        __syncthreads();
+        if (threadIdx.x < COUT) {
+            real t = 0;
+#pragma unroll
+            for (int c = 0; c < BCH; ++c) t += scratch[c * COUT + threadIdx.x];
+            gb[threadIdx.x] += t;
+        }
+        __syncthreads();
     }
 };
 
@@ -165,7 +195,7 @@ __device__ __host__ inline DecOff dec_off(int L) {
 // ------------------------------------------------------------------------------------------
 // encoder forward: images -> a1,a2,a3 (saved), qnet_mu, qnet_var_raw = exp(.), qnet_var = clip
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SVGP_BLOCK) void k_encoder_fwd(int b, int L, int clip, const real* __restrict__ th_enc,
+__global__ __launch_bounds__(VAE_NT) void k_encoder_fwd(int b, int L, int clip, const real* __restrict__ th_enc,
                                                             const real* __restrict__ images, real* __restrict__ a1g,
                                                             real* __restrict__ a2g, real* __restrict__ a3g,
                                                             real* __restrict__ mu, real* __restrict__ var_raw,
@@ -209,7 +239,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_encoder_fwd(int b, int L, int cl
 // ------------------------------------------------------------------------------------------
 // encoder reverse: (ybar, s2bar) -> encoder weight-gradient partials
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SVGP_BLOCK) void k_encoder_bwd(int b, int L, int clip, const real* __restrict__ th_enc,
+__global__ __launch_bounds__(VAE_NT) void k_encoder_bwd(int b, int L, int clip, const real* __restrict__ th_enc,
                                                             const real* __restrict__ images,
                                                             const real* __restrict__ a1g, const real* __restrict__ a2g,
                                                             const real* __restrict__ a3g,
@@ -228,7 +258,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_encoder_bwd(int b, int L, int cl
     real* d2 = d1 + 1352;            // 288
     real* d3 = d2 + 288;             // 32
     real* dout = d3 + 32;            // 2L (<=128)
-    real* scratch = dout + 128;      // 256
+    real* scratch = dout + 128;      // VAE_SCRATCH
     lds_copy_in(w, th_enc, eo.n);
     lds_zero(g, eo.n);
     const int twoL = 2 * L;
@@ -278,7 +308,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_encoder_bwd(int b, int L, int cl
 // ------------------------------------------------------------------------------------------
 // decoder forward: z -> h0, a1, a2 (saved), recon, per-workgroup sum of squared errors
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SVGP_BLOCK) void k_decoder_fwd(int b, int L, const real* __restrict__ th_dec,
+__global__ __launch_bounds__(VAE_NT) void k_decoder_fwd(int b, int L, const real* __restrict__ th_dec,
                                                             const real* __restrict__ images,
                                                             const real* __restrict__ zg, real* __restrict__ h0g,
                                                             real* __restrict__ a1g, real* __restrict__ a2g,
@@ -328,7 +358,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_decoder_fwd(int b, int L, const 
 // decoder reverse: d loss / d recon -> zbar, decoder weight-gradient partials
 // gscale = d loss / d (sum of squared errors): beta-ELBO 1/784; GECO lagrange_mult/(b_global*784)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SVGP_BLOCK) void k_decoder_bwd(int b, int L, int geco, real inv_bglobal,
+__global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int b, int L, int geco, real inv_bglobal,
                                                             const real* __restrict__ state,
                                                             const real* __restrict__ th_dec,
                                                             const real* __restrict__ images,
@@ -348,7 +378,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_decoder_bwd(int b, int L, int ge
     real* d2 = d3 + 784;             // 1568
     real* d1 = d2 + 1568;            // 512
     real* dh0 = d1 + 512;            // 128
-    real* scratch = dh0 + 128;       // 256
+    real* scratch = dh0 + 128;       // VAE_SCRATCH
     lds_copy_in(w, th_dec, od.n);
     lds_zero(g, od.n);
     const real gscale = (geco ? state[SVGP_ST_LAGRANGE] * inv_bglobal : real(1)) / real(784);
@@ -379,11 +409,16 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_decoder_bwd(int b, int L, int ge
         // dense (no activation): weight / bias gradients and zbar
         for (int o = threadIdx.x; o < L * 128; o += blockDim.x) g[od.dw + o] += z[o / 128] * dh0[o % 128];
         if (threadIdx.x < 128) g[od.db + threadIdx.x] += dh0[threadIdx.x];
-        // zbar[i] = sum_j dh0[j] w[i][j] : 4 lanes per i would be nicer; L <= 64 threads, 128 terms
-        if (threadIdx.x < L) {
+        // zbar[i] = sum_j dh0[j] w[i][j]: 8 lanes per latent channel, xor-shuffle combine
+        {
+            const int i = threadIdx.x >> 3, part8 = threadIdx.x & 7;
             real acc = 0;
-            for (int j = 0; j < 128; ++j) acc += dh0[j] * w[od.dw + threadIdx.x * 128 + j];
-            zbar[(size_t)n * L + threadIdx.x] = acc;
+            if (i < L)
+                for (int j = part8; j < 128; j += 8) acc += dh0[j] * w[od.dw + i * 128 + j];
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            if (i < L && part8 == 0) zbar[(size_t)n * L + i] = acc;
         }
     }
     __syncthreads();
@@ -391,36 +426,49 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_decoder_bwd(int b, int L, int ge
 }
 
 // ------------------------------------------------------------------------------------------
-// fixed-order reduction of per-workgroup partials: out[i] = sum_w part[w][i]
-// thread (i_local = tid % 64, chunk = tid / 64) -> 4 chunks over w, then LDS combine
+// fixed-order reduction of the per-workgroup partials into [grad | sums] in ONE launch.
+// blocks [0, nb_enc): encoder weights, [nb_enc, nb_enc+nb_dec): decoder weights, last block: scalars.
+// thread (i_local = tid % 16, chunk = tid / 16): 16 chunks over the partial rows, LDS combine.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(SVGP_BLOCK) void k_reduce_partials(int n_part, int n, const real* __restrict__ part,
-                                                                real* __restrict__ out) {
-    __shared__ real s[4][64];
-    const int il = threadIdx.x & 63, ch = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + il;
+__global__ __launch_bounds__(SVGP_BLOCK) void k_grad_reduce(int n_part, int n_enc, int n_dec, int nb_enc, int nb_dec,
+                                                            int n_post, int b, const real* __restrict__ part_enc,
+                                                            const real* __restrict__ part_dec,
+                                                            const real* __restrict__ part_sums,
+                                                            real* __restrict__ grad, real* __restrict__ sums) {
+    __shared__ real s[16][17];
+    __shared__ real red[16];
+    if ((int)blockIdx.x == nb_enc + nb_dec) {
+        real l3 = 0, ce = 0, sq = 0;
+        for (int i = threadIdx.x; i < n_part; i += blockDim.x) sq += part_sums[i * 4 + 2];
+        const real* pp = part_sums + (size_t)n_part * 4;
+        for (int i = threadIdx.x; i < n_post; i += blockDim.x) { l3 += pp[i * 2]; ce += pp[i * 2 + 1]; }
+        l3 = block_sum(l3, red);
+        ce = block_sum(ce, red);
+        sq = block_sum(sq, red);
+        if (threadIdx.x == 0) {
+            sums[0] = l3; sums[1] = ce; sums[2] = sq; sums[3] = (real)b;
+            sums[4] = 0; sums[5] = 0; sums[6] = 0; sums[7] = 0;
+        }
+        return;
+    }
+    const bool enc = (int)blockIdx.x < nb_enc;
+    const int n = enc ? n_enc : n_dec, blk = enc ? blockIdx.x : blockIdx.x - nb_enc;
+    const real* part = enc ? part_enc : part_dec;
+    real* out = enc ? grad : grad + n_enc;
+    const int il = threadIdx.x & 15, ch = threadIdx.x >> 4;
+    const int i = blk * 16 + il;
     real acc = 0;
-    if (i < n)
-        for (int wq = ch; wq < n_part; wq += 4) acc += part[(size_t)wq * n + i];
+    if (i < n) {
+#pragma unroll 4
+        for (int wq = ch; wq < n_part; wq += 16) acc += part[(size_t)wq * n + i];
+    }
     s[ch][il] = acc;
     __syncthreads();
-    if (ch == 0 && i < n) out[i] = (s[0][il] + s[1][il]) + (s[2][il] + s[3][il]);
-}
-
-// sums block: [0] L3 data term, [1] CE, [2] sum of squared recon errors, [3] local rows
-__global__ void k_reduce_sums(int n_part, int n_post, int b, const real* __restrict__ part_sums,
-                              real* __restrict__ sums) {
-    __shared__ real red[16];
-    real l3 = 0, ce = 0, sq = 0;
-    for (int i = threadIdx.x; i < n_part; i += blockDim.x) sq += part_sums[i * 4 + 2];
-    const real* pp = part_sums + (size_t)n_part * 4;
-    for (int i = threadIdx.x; i < n_post; i += blockDim.x) { l3 += pp[i * 2]; ce += pp[i * 2 + 1]; }
-    l3 = block_sum(l3, red);
-    ce = block_sum(ce, red);
-    sq = block_sum(sq, red);
-    if (threadIdx.x == 0) {
-        sums[0] = l3; sums[1] = ce; sums[2] = sq; sums[3] = (real)b;
-        sums[4] = 0; sums[5] = 0; sums[6] = 0; sums[7] = 0;
+    if (ch == 0 && i < n) {
+        real t = 0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) t += s[c][il];
+        out[i] = t;
     }
 }
 
@@ -450,7 +498,7 @@ extern "C" int svgp_mnist_encoder_fwd(const svgp_mnist_cfg* c, const double* the
     const size_t lds = (size_t)(pl.n_enc + 784 + 1352 + 288 + 32) * sizeof(real);
     int rc = set_dyn_lds(k_encoder_fwd, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_encoder_fwd, dim3(svgp_n_part(c)), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, c->b, c->L,
+    hipLaunchKernelGGL(k_encoder_fwd, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
                        c->clip_qs, theta, images, ws + wl.enc_a1, ws + wl.enc_a2, ws + wl.enc_a3, ws + wl.qnet_mu,
                        ws + wl.qnet_var_raw, ws + wl.qnet_var);
     SVGP_LAUNCH_CHECK();
@@ -461,10 +509,10 @@ extern "C" int svgp_mnist_encoder_bwd(const svgp_mnist_cfg* c, const double* the
                                       void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(theta && images && ws, SVGP_ERR_INVALID, "NULL device pointer");
-    const size_t lds = (size_t)(2 * pl.n_enc + 784 + 1352 + 288 + 32 + 1352 + 288 + 32 + 128 + 256) * sizeof(real);
+    const size_t lds = (size_t)(2 * pl.n_enc + 784 + 1352 + 288 + 32 + 1352 + 288 + 32 + 128 + VAE_SCRATCH) * sizeof(real);
     int rc = set_dyn_lds(k_encoder_bwd, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_encoder_bwd, dim3(svgp_n_part(c)), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, c->b, c->L,
+    hipLaunchKernelGGL(k_encoder_bwd, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
                        c->clip_qs, theta, images, ws + wl.enc_a1, ws + wl.enc_a2, ws + wl.enc_a3,
                        ws + wl.qnet_var_raw, ws + wl.ybar, ws + wl.s2bar, ws + wl.part_enc);
     SVGP_LAUNCH_CHECK();
@@ -479,7 +527,7 @@ extern "C" int svgp_mnist_decoder_fwd(const svgp_mnist_cfg* c, const double* the
     const size_t lds = (size_t)(n_dec + 64 + 128 + 512 + 1568 + 784 + 16) * sizeof(real);
     int rc = set_dyn_lds(k_decoder_fwd, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_decoder_fwd, dim3(svgp_n_part(c)), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, c->b, c->L,
+    hipLaunchKernelGGL(k_decoder_fwd, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
                        theta + pl.n_enc, images, ws + wl.z, ws + wl.dec_h0, ws + wl.dec_a1, ws + wl.dec_a2,
                        ws + wl.recon, ws + wl.part_sums);
     SVGP_LAUNCH_CHECK();
@@ -491,10 +539,10 @@ extern "C" int svgp_mnist_decoder_bwd(const svgp_mnist_cfg* c, const double* the
     GET_LAYOUTS();
     SVGP_REQUIRE(theta && images && ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     const int64_t n_dec = pl.n_vae - pl.n_enc;
-    const size_t lds = (size_t)(2 * n_dec + 64 + 128 + 512 + 1568 + 784 + 1568 + 512 + 128 + 256) * sizeof(real);
+    const size_t lds = (size_t)(2 * n_dec + 64 + 128 + 512 + 1568 + 784 + 1568 + 512 + 128 + VAE_SCRATCH) * sizeof(real);
     int rc = set_dyn_lds(k_decoder_bwd, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_decoder_bwd, dim3(svgp_n_part(c)), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, c->b, c->L,
+    hipLaunchKernelGGL(k_decoder_bwd, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
                        c->geco, 1.0 / (double)c->b_global, state, theta + pl.n_enc, images, ws + wl.z, ws + wl.dec_h0,
                        ws + wl.dec_a1, ws + wl.dec_a2, ws + wl.recon, ws + wl.zbar, ws + wl.part_dec);
     SVGP_LAUNCH_CHECK();
@@ -506,14 +554,10 @@ extern "C" int svgp_mnist_grad_reduce(const svgp_mnist_cfg* c, double* ws, void*
     SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
     const int n_part = svgp_n_part(c);
     const int n_enc = (int)pl.n_enc, n_dec = (int)(pl.n_vae - pl.n_enc);
-    hipLaunchKernelGGL(k_reduce_partials, dim3((n_enc + 63) / 64), dim3(SVGP_BLOCK), 0, (hipStream_t)stream, n_part,
-                       n_enc, ws + wl.part_enc, ws + wl.grad);
-    SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_reduce_partials, dim3((n_dec + 63) / 64), dim3(SVGP_BLOCK), 0, (hipStream_t)stream, n_part,
-                       n_dec, ws + wl.part_dec, ws + wl.grad + pl.n_enc);
-    SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_reduce_sums, dim3(1), dim3(SVGP_BLOCK), 0, (hipStream_t)stream, n_part,
-                       (int)wl.n_post, c->b, ws + wl.part_sums, ws + wl.sums);
+    const int nb_enc = (n_enc + 15) / 16, nb_dec = (n_dec + 15) / 16;
+    hipLaunchKernelGGL(k_grad_reduce, dim3(nb_enc + nb_dec + 1), dim3(SVGP_BLOCK), 0, (hipStream_t)stream, n_part, n_enc,
+                       n_dec, nb_enc, nb_dec, (int)wl.n_post, c->b, ws + wl.part_enc, ws + wl.part_dec,
+                       ws + wl.part_sums, ws + wl.grad, ws + wl.sums);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

@@ -9,6 +9,8 @@
 // The reference materialises a (b,m,m) tensor and several b x b products per channel
 // (SVGPVAE_model.py:284-294,336-337); here everything is O(L b m^2 + L m^3) and the only
 // cross-row reductions are the statistics blocks statA / statB (what data parallelism all-reduces).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -141,9 +143,78 @@ __device__ __forceinline__ real spd_inv_t(real* A, real* W, int ld, int m) {
     __syncthreads();
     return logdet;
 }
+// Single-wave variant for m <= MP (MP = 16 or 32): wave 0 holds the whole matrix in registers as an
+// 8 x 8 grid of lanes, each owning a BS x BS block (BS = MP/8).  The k loop is fully unrolled so every
+// register index is static; per step a lane needs only the BS pivot-row and BS pivot-column values of
+// its block, fetched with cross-lane shuffles (ds_bpermute: register to register, no LDS memory, no
+// barrier, and - unlike an LDS exchange - not subject to single-thread store/load reordering).
+// Rows/columns >= m are an identity pad (pivot 1, log 0).  W: >= 1 real.  Other waves wait at the end.
+__device__ __forceinline__ real fast_rcp(real x) {
+    real r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, real(1)), r, r);
+    r = fma(fma(-x, r, real(1)), r, r);
+    return r;
+}
+template <int MP>
+__device__ __forceinline__ real spd_inv_wave(real* A, real* W, int ld, int m) {
+    constexpr int BS = MP / 8;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x, bi = lane >> 3, bj = lane & 7;
+        real a[BS][BS];
+#pragma unroll
+        for (int r = 0; r < BS; ++r)
+#pragma unroll
+            for (int c = 0; c < BS; ++c) {
+                const int i = bi * BS + r, j = bj * BS + c;
+                a[r][c] = (i < m && j < m) ? A[i * ld + j] : (i == j ? real(1) : real(0));
+            }
+        real mypiv = 1;
+#pragma unroll
+        for (int k = 0; k < MP; ++k) {
+            if (k < m) {                                   // wave-uniform
+                const int kb = k / BS, kr = k % BS;        // static after unrolling
+                real rowk[BS], colk[BS];
+#pragma unroll
+                for (int c = 0; c < BS; ++c) rowk[c] = __shfl(a[kr][c], kb * 8 + bj, 64);
+#pragma unroll
+                for (int r = 0; r < BS; ++r) colk[r] = __shfl(a[r][kr], bi * 8 + kb, 64);
+                const real piv = __shfl(a[kr][kr], kb * 8 + kb, 64);
+                const real ipiv = fast_rcp(piv);
+                if (lane == k) mypiv = piv;
+                real rkj[BS];
+#pragma unroll
+                for (int c = 0; c < BS; ++c) rkj[c] = (bj * BS + c == k) ? ipiv : rowk[c] * ipiv;
+#pragma unroll
+                for (int r = 0; r < BS; ++r)
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) {
+                        const bool ik = (bi * BS + r == k), jk = (bj * BS + c == k);
+                        a[r][c] = ik ? rkj[c] : ((jk ? real(0) : a[r][c]) - colk[r] * rkj[c]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < BS; ++r)
+#pragma unroll
+            for (int c = 0; c < BS; ++c) {
+                const int i = bi * BS + r, j = bj * BS + c;
+                if (i < m && j < m) A[i * ld + j] = a[r][c];
+            }
+        const real lg = wave_sum(log(mypiv));
+        if (lane == 0) W[0] = lg;
+    }
+    __syncthreads();
+    const real logdet = W[0];
+    __syncthreads();
+    return logdet;
+}
+
+// W must hold >= max(5 m, 65) reals.
 __device__ __forceinline__ real chol_inv(real* A, real* W, int ld, int m) {
-    // SVGP_BLOCK threads: m <= 32 -> 4 elements per thread, m <= 64 -> 16
-    return (m * m <= 4 * SVGP_BLOCK) ? spd_inv_t<4>(A, W, ld, m) : spd_inv_t<16>(A, W, ld, m);
+    if (m <= 16) return spd_inv_wave<16>(A, W, ld, m);
+    if (m <= 32) return spd_inv_wave<32>(A, W, ld, m);
+    return spd_inv_t<16>(A, W, ld, m);       // SVGP_BLOCK threads, m <= 64 -> 16 elements per thread
 }
 
 // =============================================================================================
@@ -486,7 +557,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
 // for a block of rows (shared by all channels).
 // =============================================================================================
 struct FactArgs {
-    int b, m, L;
+    int b, m, L, dbg_stop;   // dbg_stop: timing ablation only (env SVGP_DBG_STOP), 0 in production
     real c, jitter;
     const real* K; const real* Ki; const real* ldK; const real* S; const real* v; const real* Kn;
     real* Si; real* t; real* G; real* A; real* Aji; real* mu; real* u; real* M2; real* KL; real* q;
@@ -538,7 +609,9 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
         R1[i * ld + j] = a.K[o] + a.c * a.S[om + o] + (i == j ? a.jitter : real(0));
     }
     if (threadIdx.x < m) vx[threadIdx.x] = a.v[ov + threadIdx.x];
+    if (a.dbg_stop == 1) return;
     chol_inv(R1, R2, ld, m);                       // R1 = Sigma_l^{-1}
+    if (a.dbg_stop == 2) return;
     mat_store(a.Si + om, R1, ld, m);
     mat_vec(vy, R1, ld, vx, m, real(1));           // t = Si v
     mat_gemm<false, false>(R2, R1, R0, ld, m, real(1));   // G = Si K
@@ -549,6 +622,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
     mat_vec(vz, R0, ld, vy, m, a.c);               // mu_hat = c K t
     __syncthreads();
     mat_store(a.A + om, R3, ld, m);
+    if (a.dbg_stop == 3) return;
     if (threadIdx.x < m) a.mu[ov + threadIdx.x] = vz[threadIdx.x];
     mat_load(R1, ld, a.Ki, m);                     // R1 = Ki   (Si, G no longer needed in LDS)
     __syncthreads();
@@ -568,6 +642,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
     mat_gemm<false, false>(R0, R1, R2, ld, m, real(1));   // M2 = Ki A Ki   (K no longer needed)
     __syncthreads();
     mat_store(a.M2 + om, R0, ld, m);
+    if (a.dbg_stop == 4) return;
     if (threadIdx.x < m) R3[threadIdx.x * ld + threadIdx.x] += a.jitter;     // A + jitter I
     const real ldA = chol_inv(R3, R2, ld, m);
     mat_store(a.Aji + om, R3, ld, m);
@@ -993,7 +1068,7 @@ static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     a.rc_rows = 8192 / m;                       // 64 KB tile of K_nm rows per pass
     if (a.rc_rows > c->b) a.rc_rows = c->b;
     size_t lds = (size_t)(a.rc_rows * m + 3 * a.rc_rows) * sizeof(real);
-    const size_t lds_inv = mat_lds(m, 1) + (size_t)(5 * m + 16) * sizeof(real);
+    const size_t lds_inv = mat_lds(m, 1) + (size_t)(5 * m + 80) * sizeof(real);
     if (mode == 0 && lds_inv > lds) lds = lds_inv;
     int rc = set_dyn_lds(k_gp_stats, lds);
     if (rc) return rc;
@@ -1022,6 +1097,7 @@ extern "C" int svgp_gp_factor_fwd(const svgp_mnist_cfg* c, double* ws, void* str
     SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
     FactArgs a;
     a.b = c->b; a.m = c->m; a.L = c->L; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;
+    { const char* e_ = getenv("SVGP_DBG_STOP"); a.dbg_stop = e_ ? atoi(e_) : 0; }
     a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.ldK = ws + wl.ldK; a.S = ws + wl.S; a.v = ws + wl.v; a.Kn = ws + wl.Kn;
     a.Si = ws + wl.Si; a.t = ws + wl.t; a.G = ws + wl.G; a.A = ws + wl.A; a.Aji = ws + wl.Aji; a.mu = ws + wl.mu_hat;
     a.u = ws + wl.u; a.M2 = ws + wl.M2; a.KL = ws + wl.KL; a.q = ws + wl.q;

@@ -500,22 +500,31 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
         if (threadIdx.x == 0) *a.ldK = logdet;
         return;
     }
-    const int STAT_RC = a.rc_rows;
-    real* kt = smem;                   // STAT_RC x m tile of Kn
-    real* w = kt + STAT_RC * m;        // STAT_RC
+    // ---- statistics of channel l: S = Kn^T diag(w) Kn on the f64 MFMA (A[i][k=n] = w_n Kn[n][i],
+    // B[k=n][j] = Kn[n][j], k-steps of 4 rows), vectors on the VALU.  One wave per 16x16 tile.
+    const int STAT_RC = a.rc_rows;            // multiple of 4
+    const int mp = pad16(m), ldk = mp + 2, nt = mp >> 4;
+    real* kt = smem;                   // STAT_RC x ldk tile of Kn, zero padded
+    real* w = kt + STAT_RC * ldk;      // STAT_RC
     real* va = w + STAT_RC;            // STAT_RC
     real* vb = va + STAT_RC;           // STAT_RC
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;      // output element of the m x m matrix
-    const bool act = o < m * m;
-    const int i = act ? o / m : 0, j = act ? o % m : 0;
-    const bool vec = (blockIdx.x == 0) && (threadIdx.x < m);  // also accumulates v1/v2 element
-    real accS = 0, acc1 = 0, acc2 = 0;
+    real* scr = vb + STAT_RC;          // 2 x SVGP_BLOCK
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int vi = threadIdx.x % mp, vpart = threadIdx.x / mp, nparts = blockDim.x / mp;
+    d4_t acc[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) acc[tt] = d4_t{0, 0, 0, 0};
+    real acc1 = 0, acc2 = 0;
     const real gT = a.mode ? grad_KL_term(a.geco, a.L, a.state) : real(0);
     for (int r0 = 0; r0 < a.b; r0 += STAT_RC) {
-        const int rows = min(STAT_RC, a.b - r0);
+        const int rows = min(STAT_RC, a.b - r0), rows4 = (rows + 3) & ~3;
         __syncthreads();
-        for (int t = threadIdx.x; t < rows * m; t += blockDim.x) kt[t] = a.Kn[(size_t)r0 * m + t];
-        for (int rr = threadIdx.x; rr < rows; rr += blockDim.x) {
+        for (int t = threadIdx.x; t < rows4 * mp; t += blockDim.x) {
+            const int rr = t / mp, cc = t % mp;
+            kt[rr * ldk + cc] = (rr < rows && cc < m) ? a.Kn[(size_t)(r0 + rr) * m + cc] : real(0);
+        }
+        for (int rr = threadIdx.x; rr < rows4; rr += blockDim.x) {
+            if (rr >= rows) { w[rr] = 0; va[rr] = 0; vb[rr] = 0; continue; }
             const size_t e = (size_t)(r0 + rr) * a.L + l;
             const real p = recip_no_nan(a.s2[e]);
             if (a.mode == 0) {
@@ -530,25 +539,53 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
                 w[rr] = gpv;
                 va[rr] = mvb;
                 vb[rr] = a.c * gpm;
-                if (blockIdx.x == 0) { a.g_pv[e] = gpv; a.g_pm[e] = gpm; a.mvbar[e] = mvb; }
+                a.g_pv[e] = gpv; a.g_pm[e] = gpm; a.mvbar[e] = mvb;
             }
         }
         __syncthreads();
-        if (act) {
-#pragma unroll 4
-            for (int r = 0; r < rows; ++r) accS += w[r] * kt[r * m + i] * kt[r * m + j];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int t = wave + 4 * tt;
+            if (t < nt * nt) {
+                const int ti = t / nt, tj = t % nt;
+                const real* ap = kt + q * ldk + ti * 16 + r16;
+                const real* bp = kt + q * ldk + tj * 16 + r16;
+                for (int k0 = 0; k0 < rows4; k0 += 4) {
+                    acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0] * w[k0 + q], bp[0], acc[tt], 0, 0, 0);
+                    ap += 4 * ldk;
+                    bp += 4 * ldk;
+                }
+            }
         }
-        if (vec)
-            for (int r = 0; r < rows; ++r) {
-                const real k = kt[r * m + threadIdx.x];
+        if (vpart < nparts && vi < m) {
+            for (int r = vpart; r < rows; r += nparts) {
+                const real k = kt[r * ldk + vi];
                 acc1 += va[r] * k;
                 acc2 += vb[r] * k;
             }
+        }
     }
-    if (act) a.S[(size_t)l * m * m + o] = accS;
-    if (vec) {
-        a.v1[(size_t)l * m + threadIdx.x] = acc1;
-        if (a.v2) a.v2[(size_t)l * m + threadIdx.x] = acc2;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        const int t = wave + 4 * tt;
+        if (t < nt * nt) {
+            const int ti = t / nt, tj = t % nt;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int i = ti * 16 + q + 4 * g, j = tj * 16 + r16;
+                if (i < m && j < m) a.S[(size_t)l * m * m + (size_t)i * m + j] = acc[tt][g];
+            }
+        }
+    }
+    __syncthreads();
+    scr[threadIdx.x] = acc1;
+    scr[SVGP_BLOCK + threadIdx.x] = acc2;
+    __syncthreads();
+    if (threadIdx.x < m) {
+        real s1 = 0, s2 = 0;
+        for (int pp = 0; pp < nparts; ++pp) { s1 += scr[pp * mp + threadIdx.x]; s2 += scr[SVGP_BLOCK + pp * mp + threadIdx.x]; }
+        a.v1[(size_t)l * m + threadIdx.x] = s1;
+        if (a.v2) a.v2[(size_t)l * m + threadIdx.x] = s2;
     }
 }
 
@@ -1065,15 +1102,15 @@ static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     else { a.S = ws + wl.A2; a.v1 = ws + wl.ud; a.v2 = ws + wl.td; }
     a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.ldK = ws + wl.ldK;
     const int m = c->m;
-    a.rc_rows = 8192 / m;                       // 64 KB tile of K_nm rows per pass
-    if (a.rc_rows > c->b) a.rc_rows = c->b;
-    size_t lds = (size_t)(a.rc_rows * m + 3 * a.rc_rows) * sizeof(real);
+    const int mp_ = (m + 15) & ~15;
+    a.rc_rows = (8192 / (mp_ + 2)) & ~3;        // <= 64 KB tile of K_nm rows per pass, multiple of 4
+    if (a.rc_rows > ((c->b + 3) & ~3)) a.rc_rows = (c->b + 3) & ~3;
+    size_t lds = (size_t)(a.rc_rows * (mp_ + 2) + 3 * a.rc_rows + 2 * SVGP_BLOCK) * sizeof(real);
     const size_t lds_inv = mat_lds(m, 1) + (size_t)(5 * m + 80) * sizeof(real);
     if (mode == 0 && lds_inv > lds) lds = lds_inv;
     int rc = set_dyn_lds(k_gp_stats, lds);
     if (rc) return rc;
-    const int T = (m * m + SVGP_BLOCK - 1) / SVGP_BLOCK;
-    hipLaunchKernelGGL(k_gp_stats, dim3(T, c->L + (mode == 0 ? 1 : 0)), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_gp_stats, dim3(1, c->L + (mode == 0 ? 1 : 0)), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

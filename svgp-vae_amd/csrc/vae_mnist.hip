@@ -10,6 +10,8 @@
 // workgroup.  UpSampling2D is never materialised (index >> 1 on the LDS read).  Weight gradients
 // are accumulated in LDS over the images a workgroup walks and written as per-workgroup partials;
 // svgp_mnist_grad_reduce sums them in a fixed order (bitwise reproducible, no float atomics).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace {
@@ -159,12 +161,182 @@ struct Conv3 {
     }
 };
 
+// ---------------------------------------------------------------------------------------------
+// UpSampling2D(2) + 3x3 convolution (stride 1, PAD 0|1) as FOUR parity-specific 2x2 convolutions on
+// the low-resolution stored input (HS x HS x CIN): for output row y, base = y - PAD, parity
+// pi = base & 1, Y = base >> 1, the three taps ky read source rows Y + T(pi,ky) with
+// T(pi,k) = (k + pi >= 2), so taps sharing a source row are pre-summed into effective weights
+//   We[pi_y][pi_x][ty][tx][ci][co] = sum_{ky: T(pi_y,ky)=ty} sum_{kx: T(pi_x,kx)=tx} w[ky][kx][ci][co].
+// 4 taps instead of 9 in the forward, 16 instead of 36 in the data gradient, and the weight gradient
+// is accumulated on We (folded back to w once per workgroup).  Mathematically identical to the
+// reference's UpSampling2D + Conv2D (VAE_utils.py:132-140); summation order differs (1e-16 level).
+// ---------------------------------------------------------------------------------------------
+template <int HS, int PAD, int CIN, int COUT>
+struct UpConv3 {
+    static constexpr int HOUT = 2 * HS - 2 + 2 * PAD;
+    static constexpr int NPIX = HOUT * HOUT;
+    static constexpr int NWE = 16 * CIN * COUT;          // effective weights
+    static constexpr int NW = 9 * CIN * COUT;            // raw weights
+    static constexpr int COG = (COUT % 2 == 0) ? 2 : 1;
+    static constexpr int NCG = COUT / COG;
+    static constexpr int CIG = (CIN % 2 == 0) ? 2 : 1;
+    static constexpr int NIG = CIN / CIG;
+    static __device__ __forceinline__ int T(int pi, int k) { return (k + pi >= 2) ? 1 : 0; }
+
+    // We (LDS) from raw w (global or LDS)
+    static __device__ void build_weff(const real* w, real* We) {
+        for (int e = threadIdx.x; e < NWE; e += VAE_NT) {
+            const int co = e % COUT, ci = (e / COUT) % CIN, tap = (e / (COUT * CIN)) % 4, cls = e / (COUT * CIN * 4);
+            const int ty = tap >> 1, tx = tap & 1, py = cls >> 1, px = cls & 1;
+            real s = 0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+                    if (T(py, ky) == ty && T(px, kx) == tx) s += w[((ky * 3 + kx) * CIN + ci) * COUT + co];
+            We[e] = s;
+        }
+    }
+    // raw-weight gradient from the effective-weight gradient: gw[ky][kx] = sum_classes gWe[cls][T,T]
+    static __device__ void fold_grad(const real* gWe, real* gw) {
+        for (int e = threadIdx.x; e < NW; e += VAE_NT) {
+            const int co = e % COUT, ci = (e / COUT) % CIN, kx = (e / (COUT * CIN)) % 3, ky = e / (COUT * CIN * 3);
+            real s = 0;
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+                    s += gWe[(((py * 2 + px) * 4 + T(py, ky) * 2 + T(px, kx)) * CIN + ci) * COUT + co];
+            gw[e] = s;
+        }
+    }
+
+    // out = elu(conv(up(in)) + bias); item = (output pixel, group of COG channels)
+    static __device__ void fwd(const real* in, const real* We, const real* bias, real* out) {
+        for (int it = threadIdx.x; it < NPIX * NCG; it += VAE_NT) {
+            const int cg = it % NCG, p = it / NCG, x = p % HOUT, y = p / HOUT;
+            const int by = y - PAD, bx = x - PAD, py = by & 1, px = bx & 1, Y = by >> 1, X = bx >> 1;
+            real acc[COG];
+#pragma unroll
+            for (int g = 0; g < COG; ++g) acc[g] = bias[cg * COG + g];
+            const real* wc = We + ((py * 2 + px) * 4) * CIN * COUT + cg * COG;
+#pragma unroll
+            for (int ty = 0; ty < 2; ++ty) {
+                const int sy = Y + ty;
+                const bool vy = (unsigned)sy < (unsigned)HS;
+#pragma unroll
+                for (int tx = 0; tx < 2; ++tx) {
+                    const int sx = X + tx;
+                    const bool valid = vy && ((unsigned)sx < (unsigned)HS);
+                    const real* src = in + (valid ? (sy * HS + sx) * CIN : 0);
+                    const real* wk = wc + (ty * 2 + tx) * CIN * COUT;
+#pragma unroll
+                    for (int ci = 0; ci < CIN; ++ci) {
+                        const real a = valid ? src[ci] : real(0);
+#pragma unroll
+                        for (int g = 0; g < COG; ++g) acc[g] += a * wk[ci * COUT + g];
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < COG; ++g) out[p * COUT + cg * COG + g] = elu_f(acc[g]);
+        }
+    }
+
+    // din (HS x HS x CIN) from dpre (HOUT x HOUT x COUT); item = (stored pixel, group of CIG channels)
+    static __device__ void bwd_data(const real* dpre, const real* We, real* din) {
+        for (int it = threadIdx.x; it < HS * HS * NIG; it += VAE_NT) {
+            const int ig = it % NIG, ps = it / NIG, Xs = ps % HS, Ys = ps / HS;
+            real acc[CIG];
+#pragma unroll
+            for (int g = 0; g < CIG; ++g) acc[g] = 0;
+#pragma unroll 1
+            for (int cy = 0; cy < 4; ++cy) {            // (pi_y, ty)
+                const int py = cy >> 1, ty = cy & 1;
+                const int y = 2 * (Ys - ty) + py + PAD;
+                const bool vy = (unsigned)y < (unsigned)HOUT;
+#pragma unroll
+                for (int cx = 0; cx < 4; ++cx) {        // (pi_x, tx)
+                    const int px = cx >> 1, tx = cx & 1;
+                    const int x = 2 * (Xs - tx) + px + PAD;
+                    const bool valid = vy && ((unsigned)x < (unsigned)HOUT);
+                    const real* dp = dpre + (valid ? (y * HOUT + x) * COUT : 0);
+                    const real* wk = We + (((py * 2 + px) * 4 + ty * 2 + tx) * CIN + ig * CIG) * COUT;
+#pragma unroll
+                    for (int co = 0; co < COUT; ++co) {
+                        const real d = valid ? dp[co] : real(0);
+#pragma unroll
+                        for (int g = 0; g < CIG; ++g) acc[g] += d * wk[g * COUT + co];
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < CIG; ++g) din[ps * CIN + ig * CIG + g] = acc[g];
+        }
+    }
+
+    // gWe += sum_pixels in * dpre ; gb += sum_pixels dpre.  item = (class, tap, ci, pixel chunk) -> COUT
+    // outputs; chunks combined through `scratch` (>= VAE_SCRATCH reals) in fixed order.  Ends with a barrier.
+    static __device__ void bwd_weight(const real* in, const real* dpre, real* gWe, real* gb, real* scratch) {
+        constexpr int NTC = 16 * CIN;
+        constexpr int NCH0 = VAE_NT / NTC, NCH1 = VAE_SCRATCH / NWE;
+        constexpr int NCH = NCH0 < NCH1 ? (NCH0 < 1 ? 1 : NCH0) : NCH1;
+        constexpr int NG = HS + 1;                      // candidate Y (and X) values: -1 .. HS-1
+        const int tc = threadIdx.x % NTC, chunk = threadIdx.x / NTC;
+        if (chunk < NCH) {
+            const int ci = tc % CIN, tap = (tc / CIN) % 4, cls = tc / (CIN * 4);
+            const int ty = tap >> 1, tx = tap & 1, py = cls >> 1, px = cls & 1;
+            real acc[COUT];
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) acc[co] = 0;
+#pragma unroll 2
+            for (int idx = chunk; idx < NG * NG; idx += NCH) {
+                const int Y = idx / NG - 1, X = idx % NG - 1;
+                const int y = 2 * Y + py + PAD, x = 2 * X + px + PAD, sy = Y + ty, sx = X + tx;
+                const bool valid = ((unsigned)y < (unsigned)HOUT) && ((unsigned)x < (unsigned)HOUT) &&
+                                   ((unsigned)sy < (unsigned)HS) && ((unsigned)sx < (unsigned)HS);
+                const real a = valid ? in[(sy * HS + sx) * CIN + ci] : real(0);
+                const real* dp = dpre + (valid ? (y * HOUT + x) * COUT : 0);
+#pragma unroll
+                for (int co = 0; co < COUT; ++co) acc[co] += a * dp[co];
+            }
+#pragma unroll
+            for (int co = 0; co < COUT; ++co) scratch[chunk * NWE + tc * COUT + co] = acc[co];
+        }
+        __syncthreads();
+        for (int widx = threadIdx.x; widx < NWE; widx += VAE_NT) {
+            real s = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) s += scratch[c * NWE + widx];
+            gWe[widx] += s;
+        }
+        __syncthreads();
+        constexpr int BCH = 32;
+        if (threadIdx.x < BCH * COUT) {
+            const int co = threadIdx.x % COUT, chunk2 = threadIdx.x / COUT;
+            real s = 0;
+            for (int p = chunk2; p < NPIX; p += BCH) s += dpre[p * COUT + co];
+            scratch[threadIdx.x] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < COUT) {
+            real t = 0;
+#pragma unroll
+            for (int c = 0; c < BCH; ++c) t += scratch[c * COUT + threadIdx.x];
+            gb[threadIdx.x] += t;
+        }
+        __syncthreads();
+    }
+};
+
+using UpC1 = UpConv3<4, 1, 8, 8>;     // (4,4,8)  -> up 8x8   -> same  -> (8,8,8)
+using UpC2 = UpConv3<8, 0, 8, 8>;     // (8,8,8)  -> up 16x16 -> valid -> (14,14,8)
+using UpC3 = UpConv3<14, 1, 8, 1>;    // (14,14,8)-> up 28x28 -> same  -> (28,28,1)
+#define DEC_NWE (UpC1::NWE + UpC2::NWE + UpC3::NWE)   // 1024 + 1024 + 128
+
 using EncC1 = Conv3<28, 1, 0, 2, 1, 8, 13>;
 using EncC2 = Conv3<13, 1, 0, 2, 8, 8, 6>;
 using EncC3 = Conv3<6, 1, 0, 2, 8, 8, 2>;
-using DecC1 = Conv3<4, 2, 1, 1, 8, 8, 8>;
-using DecC2 = Conv3<8, 2, 0, 1, 8, 8, 14>;
-using DecC3 = Conv3<14, 2, 1, 1, 8, 1, 28>;
 
 __device__ __forceinline__ void lds_copy_in(real* dst, const real* __restrict__ src, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
@@ -322,7 +494,13 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_fwd(int b, int L, const real
     real* a2 = a1 + 512;             // 1568
     real* out = a2 + 1568;           // 784
     real* red = out + 784;           // 16
+    real* We1 = red + 16;            // effective weights of the three up-convolutions
+    real* We2 = We1 + UpC1::NWE;
+    real* We3 = We2 + UpC2::NWE;
     lds_copy_in(w, th_dec, od.n);
+    UpC1::build_weff(th_dec + od.c1w, We1);
+    UpC2::build_weff(th_dec + od.c2w, We2);
+    UpC3::build_weff(th_dec + od.c3w, We3);
     real sq = 0;
     for (int n = blockIdx.x; n < b; n += gridDim.x) {
         __syncthreads();
@@ -334,11 +512,11 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_fwd(int b, int L, const real
             h0[threadIdx.x] = acc;
         }
         __syncthreads();
-        DecC1::fwd(h0, w + od.c1w, w + od.c1b, a1);
+        UpC1::fwd(h0, We1, w + od.c1b, a1);
         __syncthreads();
-        DecC2::fwd(a1, w + od.c2w, w + od.c2b, a2);
+        UpC2::fwd(a1, We2, w + od.c2b, a2);
         __syncthreads();
-        DecC3::fwd(a2, w + od.c3w, w + od.c3b, out);
+        UpC3::fwd(a2, We3, w + od.c3b, out);
         __syncthreads();
         lds_copy_out(h0g + (size_t)n * 128, h0, 128);
         lds_copy_out(a1g + (size_t)n * 512, a1, 512);
@@ -358,7 +536,7 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_fwd(int b, int L, const real
 // decoder reverse: d loss / d recon -> zbar, decoder weight-gradient partials
 // gscale = d loss / d (sum of squared errors): beta-ELBO 1/784; GECO lagrange_mult/(b_global*784)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int b, int L, int geco, real inv_bglobal,
+__global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int dbg_stop, int b, int L, int geco, real inv_bglobal,
                                                             const real* __restrict__ state,
                                                             const real* __restrict__ th_dec,
                                                             const real* __restrict__ images,
@@ -368,9 +546,15 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int b, int L, int geco, 
                                                             real* __restrict__ part) {
     extern __shared__ __align__(16) real smem[];
     const DecOff od = dec_off(L);
-    real* w = smem;                  // od.n
-    real* g = w + od.n;              // od.n
-    real* z = g + od.n;              // 64
+    real* w = smem;                  // dense weights only: L*128
+    real* g = w + L * 128;           // od.n   gradient in the raw-parameter layout
+    real* We1 = g + od.n;            // effective weights / their gradients
+    real* We2 = We1 + UpC1::NWE;
+    real* We3 = We2 + UpC2::NWE;
+    real* gWe1 = We3 + UpC3::NWE;
+    real* gWe2 = gWe1 + UpC1::NWE;
+    real* gWe3 = gWe2 + UpC2::NWE;
+    real* z = gWe3 + UpC3::NWE;      // 64
     real* h0 = z + 64;               // 128
     real* a1 = h0 + 128;             // 512
     real* a2 = a1 + 512;             // 1568
@@ -379,8 +563,12 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int b, int L, int geco, 
     real* d1 = d2 + 1568;            // 512
     real* dh0 = d1 + 512;            // 128
     real* scratch = dh0 + 128;       // VAE_SCRATCH
-    lds_copy_in(w, th_dec, od.n);
+    lds_copy_in(w, th_dec + od.dw, L * 128);
     lds_zero(g, od.n);
+    lds_zero(gWe1, DEC_NWE);
+    UpC1::build_weff(th_dec + od.c1w, We1);
+    UpC2::build_weff(th_dec + od.c2w, We2);
+    UpC3::build_weff(th_dec + od.c3w, We3);
     const real gscale = (geco ? state[SVGP_ST_LAGRANGE] * inv_bglobal : real(1)) / real(784);
     for (int n = blockIdx.x; n < b; n += gridDim.x) {
         __syncthreads();
@@ -393,18 +581,25 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int b, int L, int geco, 
             d3[i] = real(2) * gscale * (o - images[(size_t)n * 784 + i]) * elu_grad_from_out(o);
         }
         __syncthreads();
-        DecC3::bwd_weight(a2, d3, g + od.c3w, g + od.c3b, scratch);
-        DecC3::bwd_data(d3, w + od.c3w, d2);
+        if (dbg_stop == 1) continue;
+        UpC3::bwd_weight(a2, d3, gWe3, g + od.c3b, scratch);
+        if (dbg_stop == 2) continue;
+        UpC3::bwd_data(d3, We3, d2);
+        if (dbg_stop == 3) continue;
         __syncthreads();
         for (int i = threadIdx.x; i < 1568; i += blockDim.x) d2[i] *= elu_grad_from_out(a2[i]);
         __syncthreads();
-        DecC2::bwd_weight(a1, d2, g + od.c2w, g + od.c2b, scratch);
-        DecC2::bwd_data(d2, w + od.c2w, d1);
+        UpC2::bwd_weight(a1, d2, gWe2, g + od.c2b, scratch);
+        if (dbg_stop == 4) continue;
+        UpC2::bwd_data(d2, We2, d1);
+        if (dbg_stop == 5) continue;
         __syncthreads();
         for (int i = threadIdx.x; i < 512; i += blockDim.x) d1[i] *= elu_grad_from_out(a1[i]);
         __syncthreads();
-        DecC1::bwd_weight(h0, d1, g + od.c1w, g + od.c1b, scratch);
-        DecC1::bwd_data(d1, w + od.c1w, dh0);
+        UpC1::bwd_weight(h0, d1, gWe1, g + od.c1b, scratch);
+        if (dbg_stop == 6) continue;
+        UpC1::bwd_data(d1, We1, dh0);
+        if (dbg_stop == 7) continue;
         __syncthreads();
         // dense (no activation): weight / bias gradients and zbar
         for (int o = threadIdx.x; o < L * 128; o += blockDim.x) g[od.dw + o] += z[o / 128] * dh0[o % 128];
@@ -414,13 +609,17 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int b, int L, int geco, 
             const int i = threadIdx.x >> 3, part8 = threadIdx.x & 7;
             real acc = 0;
             if (i < L)
-                for (int j = part8; j < 128; j += 8) acc += dh0[j] * w[od.dw + i * 128 + j];
+                for (int j = part8; j < 128; j += 8) acc += dh0[j] * w[i * 128 + j];
             acc += __shfl_xor(acc, 1, 64);
             acc += __shfl_xor(acc, 2, 64);
             acc += __shfl_xor(acc, 4, 64);
             if (i < L && part8 == 0) zbar[(size_t)n * L + i] = acc;
         }
     }
+    __syncthreads();
+    UpC1::fold_grad(gWe1, g + od.c1w);
+    UpC2::fold_grad(gWe2, g + od.c2w);
+    UpC3::fold_grad(gWe3, g + od.c3w);
     __syncthreads();
     lds_copy_out(part + (size_t)blockIdx.x * od.n, g, od.n);
 }
@@ -524,7 +723,7 @@ extern "C" int svgp_mnist_decoder_fwd(const svgp_mnist_cfg* c, const double* the
     GET_LAYOUTS();
     SVGP_REQUIRE(theta && images && ws, SVGP_ERR_INVALID, "NULL device pointer");
     const int64_t n_dec = pl.n_vae - pl.n_enc;
-    const size_t lds = (size_t)(n_dec + 64 + 128 + 512 + 1568 + 784 + 16) * sizeof(real);
+    const size_t lds = (size_t)(n_dec + 64 + 128 + 512 + 1568 + 784 + 16 + DEC_NWE) * sizeof(real);
     int rc = set_dyn_lds(k_decoder_fwd, lds);
     if (rc) return rc;
     hipLaunchKernelGGL(k_decoder_fwd, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
@@ -539,10 +738,11 @@ extern "C" int svgp_mnist_decoder_bwd(const svgp_mnist_cfg* c, const double* the
     GET_LAYOUTS();
     SVGP_REQUIRE(theta && images && ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     const int64_t n_dec = pl.n_vae - pl.n_enc;
-    const size_t lds = (size_t)(2 * n_dec + 64 + 128 + 512 + 1568 + 784 + 1568 + 512 + 128 + VAE_SCRATCH) * sizeof(real);
+    const size_t lds = (size_t)(c->L * 128 + n_dec + 2 * DEC_NWE + 64 + 128 + 512 + 1568 + 784 + 1568 + 512 + 128 + VAE_SCRATCH) * sizeof(real);
     int rc = set_dyn_lds(k_decoder_bwd, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_decoder_bwd, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
+    const char* e_ = getenv("SVGP_DBG_STOP");
+    hipLaunchKernelGGL(k_decoder_bwd, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, e_ ? atoi(e_) : 0, c->b, c->L,
                        c->geco, 1.0 / (double)c->b_global, state, theta + pl.n_enc, images, ws + wl.z, ws + wl.dec_h0,
                        ws + wl.dec_a1, ws + wl.dec_a2, ws + wl.recon, ws + wl.zbar, ws + wl.part_dec);
     SVGP_LAUNCH_CHECK();

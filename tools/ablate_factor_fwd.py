@@ -8,8 +8,8 @@ eng = MnistStepEngine(32, 16, 8, 400, geco=True, b_max=256)
 eng.load_params(params)
 t = lambda x: torch.tensor(x, dtype=torch.float64, device=dev).contiguous()
 eng.bind(t(images), t(aux), t(eps)); eng.run(adam=False); eng.synchronize()
-for stop in (1, 2, 3, 4, 0):
+for stop in (1, 2, 3, 4, 5, 6, 7, 0):
     os.environ["SVGP_DBG_STOP"] = str(stop)
     rows = {r["stage"]: r["us"] for r in bench.time_stages(eng, reps=100)}
-    print("stop", stop, "gp_factor_fwd us", round(rows["gp_factor_fwd"], 2), flush=True)
+    print("stop", stop, {k: round(rows[k], 1) for k in ("gp_factor_fwd", "decoder_bwd")}, flush=True)
 os.environ["SVGP_DBG_STOP"] = "0"

@@ -54,6 +54,8 @@ typedef struct {
     int32_t train_ip;      /* 1: inducing points trainable (--ip_joint)                         */
     int32_t train_gp;      /* 1: l_GP, amplitude trainable (--GP_joint)                         */
     int32_t train_ov;      /* 1: object_vectors trainable (--ov_joint)                          */
+    int32_t b_cap;         /* row capacity the workspace LAYOUT is computed for (0 = b); keeps    */
+                           /* offsets fixed across ragged batches / train-vs-test row counts      */
     double  N_train;       /* mainSVGP.N_train                                                  */
     double  jitter;        /* mainSVGP.jitter                                                   */
     double  kappa_squared; /* GECO kappa^2                                                      */

@@ -456,3 +456,37 @@ def train_trajectory(params, batches, epsilons, *, beta, lr, alpha_flag, kappa, 
         log.append(dict(elbo=float(out[0]), recon_loss=float(out[1]), KL_term=float(out[2]),
                         C_ma=float(out[13]), lagrange_mult=float(out[14])))
     return log, params, m_state, v_state
+
+
+# --------------------------------------------------------------------------------------
+# Conditional generation / test path (SVGPVAE_model.py:939-968, 1026-1083; MNIST_experiment.py:457-486)
+# --------------------------------------------------------------------------------------
+def batching_encode_SVGPVAE(data_batch, vae, clipping_qs=False):
+    """SVGPVAE_model.py:939-968."""
+    images, aux_data = data_batch
+    qnet_mu, qnet_var = vae.encode(images)
+    if clipping_qs:
+        qnet_var = clip_by_value(qnet_var, 1e-3, 10.0)
+    return qnet_mu, qnet_var, aux_data
+
+
+def bacthing_predict_SVGPVAE_rotated_mnist(test_data_batch, vae, svgp, qnet_mu, qnet_var, aux_data_train,
+                                           epsilon=None):
+    """SVGPVAE_model.py:1026-1083 (sic spelling).  GP posterior at the test aux data given the encodings
+    of the whole train set, sample, decode, per-pixel squared error.  Returns (recon_images, recon_loss)."""
+    images_test_batch, aux_data_test_batch = test_data_batch
+    _, w, h, _ = images_test_batch.shape
+    p_m, p_v = [], []
+    for l in range(qnet_mu.shape[1]):
+        p_m_l, p_v_l, _, _ = svgp.approximate_posterior_params(aux_data_test_batch, aux_data_train,
+                                                               qnet_mu[:, l], qnet_var[:, l])
+        p_m.append(p_m_l)
+        p_v.append(p_v_l)
+    p_m = torch.stack(p_m, dim=1)
+    p_v = torch.stack(p_v, dim=1)
+    if epsilon is None:
+        epsilon = torch.randn(p_m.shape, dtype=DT)
+    latent_samples = p_m + epsilon * torch.sqrt(p_v)
+    recon = vae.decode(latent_samples)
+    recon_loss = torch.sum((images_test_batch - recon) ** 2) / float(w * h)
+    return recon, recon_loss

@@ -266,3 +266,52 @@ def batching_encode_SVGPVAE(data_batch, vae, clipping_qs=False, repr_nn=None, se
     if clipping_qs:
         var = torch.clamp(var, 1e-3, 10.0)
     return mu, var, aux_data
+
+
+def bacthing_predict_SVGPVAE_rotated_mnist(test_data_batch, vae, svgp, qnet_mu, qnet_var, aux_data_train,
+                                           epsilon=None):
+    """SVGPVAE_model.py:1026-1083 (sic spelling): conditional generation for a test batch given the
+    encodings (qnet_mu, qnet_var) (N,L) and aux data (N,2+M) of the whole train set.  Returns
+    (recon_images_test, recon_loss) with recon_loss = sum (x - x_hat)^2 / (w*h)  (:1076-1080).
+
+    Device schedule: kernel matrices + statistics + factor stage over the N train rows (b = N, so
+    N_train/b is the reference's `self.N_train / b`, :316,328), then kernel matrices, per-sample stage and
+    decoder over the test rows with the same channel factors (the capacity-based workspace layout keeps
+    S, Sigma_l^-1, t at fixed offsets).  epsilon (b_test, L): the N(0,1) draw of :1057; None -> on device."""
+    import ctypes as C
+    from ._lib import call
+    images_test, aux_test = test_data_batch
+    N, bt, L = aux_data_train.shape[0], aux_test.shape[0], vae.L
+    rt = svgp._rt
+    if rt is None or rt.eng.b_max < max(N, bt):
+        rt = _runtime(vae, svgp, True if rt is None else rt.key[0], False if rt is None else rt.key[1],
+                      math.sqrt(0.020) if rt is None else rt.key[2], max(N, bt))
+    eng = rt.eng
+    dev = eng.device
+    saved = (eng.cfg.b, eng.cfg.b_global)
+    th, ws, st, s = eng.theta.data_ptr(), eng.ws.data_ptr(), eng.state.data_ptr(), eng.stream.cuda_stream
+    d_aux_tr = aux_data_train.to(dev, _F64).contiguous()
+    d_aux_te = aux_test.to(dev, _F64).contiguous()
+    d_img_te = images_test.to(dev, _F64).contiguous()
+    d_eps = None if epsilon is None else epsilon.to(dev, _F64).contiguous()
+    # ---- train rows: statistics and channel factors
+    eng.set_batch_size(N, N)
+    eng.ws_view("qnet_mu", (N, L)).copy_(qnet_mu.to(dev, _F64))
+    eng.ws_view("qnet_var", (N, L)).copy_(qnet_var.to(dev, _F64))
+    with torch.cuda.stream(eng.stream):
+        eng.stream.wait_stream(torch.cuda.current_stream(dev))
+        cfg = C.byref(eng.cfg)
+        call("svgp_kernel_matrix_fwd", cfg, th, d_aux_tr.data_ptr(), ws, s)
+        call("svgp_gp_stats_fwd", cfg, ws, s)
+        # ---- test rows: same global row count (c = N_train / N), different local rows
+        eng.set_batch_size(bt, N)
+        cfg = C.byref(eng.cfg)
+        call("svgp_kernel_matrix_fwd", cfg, th, d_aux_te.data_ptr(), ws, s)
+        call("svgp_gp_factor_fwd", cfg, ws, s)            # channel factors + q for the test rows
+        call("svgp_gp_posterior_fwd", cfg, None if d_eps is None else d_eps.data_ptr(), ws, st, s)
+        call("svgp_mnist_decoder_fwd", cfg, th, d_img_te.data_ptr(), ws, s)
+    eng.synchronize()
+    recon = eng.ws_view("recon", (bt, 28, 28, 1)).clone()
+    eng.set_batch_size(*saved)
+    recon_loss = torch.sum((d_img_te - recon) ** 2) / 784.0
+    return recon, recon_loss

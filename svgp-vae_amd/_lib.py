@@ -15,7 +15,7 @@ class SvgpError(RuntimeError):
 
 class MnistCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("b", "b_global", "m", "L", "M", "n_obj", "normalize_obj", "clip_qs",
-                                         "geco", "train_ip", "train_gp", "train_ov")] + \
+                                         "geco", "train_ip", "train_gp", "train_ov", "b_cap")] + \
                [(n, C.c_double) for n in ("N_train", "jitter", "kappa_squared", "alpha", "rep_weight")]
 
 

@@ -59,7 +59,10 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     int rc = svgp_mnist_param_layout_get(c, &pl);
     if (rc) return rc;
     SVGP_REQUIRE(o != nullptr, SVGP_ERR_INVALID, "out is NULL");
-    const int64_t b = c->b, m = c->m, L = c->L, M = c->M;
+    SVGP_REQUIRE(c->b_cap == 0 || c->b_cap >= c->b, SVGP_ERR_INVALID, "b_cap=%d < b=%d", c->b_cap, c->b);
+    svgp_mnist_cfg cc = *c;              // layout is a function of the capacity, not of the current rows
+    cc.b = c->b_cap > 0 ? c->b_cap : c->b;
+    const int64_t b = cc.b, m = c->m, L = c->L, M = c->M;
     int64_t p = 0;
     // every field starts on a 16-element (128-byte) boundary
     auto take = [&](int64_t n) { int64_t r = p; p += (n + 15) / 16 * 16; return r; };
@@ -81,11 +84,11 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->Ssym = take(L * m * m); o->Knbar_part = take(L * b * m);
     o->Knbar = take(b * m); o->knnbar = take(b); o->ybar = take(b * L); o->s2bar = take(b * L);
     o->d_on = take(b * M);
-    o->n_part = svgp_n_part(c);
+    o->n_part = svgp_n_part(&cc);
     o->part_dec = take(o->n_part * (pl.n_vae - pl.n_enc));
     o->part_enc = take(o->n_part * pl.n_enc);
-    o->part_gp = take((m + svgp_n_postblk(c)) * 2);
-    o->n_post = (int64_t)L * svgp_n_postblk(c);
+    o->part_gp = take((m + svgp_n_postblk(&cc)) * 2);
+    o->n_post = (int64_t)L * svgp_n_postblk(&cc);
     o->part_sums = take(o->n_part * 4 + o->n_post * 2);
     o->gradC = p; o->grad = p; p += pl.n_total; o->sums = p; p += 8; o->gradC_len = p - o->gradC; take(0);
     o->total = p;

@@ -1159,7 +1159,7 @@ extern "C" int svgp_gp_posterior_fwd(const svgp_mnist_cfg* c, const double* eps,
     a.eps = ws + wl.eps; a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v; a.e = ws + wl.e; a.d = ws + wl.d; a.z = ws + wl.z;
     a.part = ws + wl.part_sums + (size_t)svgp_n_part(c) * 4;
     const int m = c->m, RB = rows_per_block(m), nb = (c->b + RB - 1) / RB;
-    SVGP_REQUIRE((int64_t)c->L * nb == wl.n_post, SVGP_ERR_INVALID, "partial-sum layout mismatch");
+    SVGP_REQUIRE((int64_t)c->L * nb <= wl.n_post, SVGP_ERR_INVALID, "partial-sum layout mismatch");
     const size_t lds = mat_lds(m, 2) + (size_t)(2 * m + SVGP_BLOCK + 4 * SVGP_BLOCK + 16) * sizeof(real);
     int rc = set_dyn_lds(k_gp_posterior_fwd, lds);
     if (rc) return rc;

@@ -113,7 +113,7 @@ class MnistStepEngine:
 
     # ------------------------------------------------------------------ configuration
     def _make_cfg(self, b, b_global):
-        return MnistCfg(b=b, b_global=b_global, **self.base)
+        return MnistCfg(b=b, b_global=b_global, b_cap=self.b_max, **self.base)
 
     def set_batch_size(self, b, b_global=None):
         """Local rows b of a global batch b_global (ragged last batch: MNIST_experiment.py:327,
@@ -230,6 +230,28 @@ class MnistStepEngine:
     def replay(self, key):
         call("svgp_graph_launch", self._graphs[key], self.stream.cuda_stream)
 
+    def capture_phases(self, key, adam=True):
+        """Four hipGraphs, one per phase; data parallelism replays them with the RCCL all-reduces in
+        between (collectives themselves are not captured)."""
+        s = self.stream.cuda_stream
+        self.stream.synchronize()
+        execs = []
+        for k in range(4):
+            call("svgp_graph_begin", s)
+            try:
+                self.phase(k, adam)
+            finally:
+                exe = C.c_void_p()
+                call("svgp_graph_end", s, C.byref(exe))
+            execs.append(exe)
+            self._graphs[(key, k)] = exe
+        return execs
+
+    def run_phase_graphs(self, key, group=None):
+        """One step from the per-phase graphs (+ all-reduces when world_size > 1)."""
+        with torch.cuda.stream(self.stream):
+            DataParallelStep(_GraphAdapter(self, key), group).step()
+
     def synchronize(self):
         self.stream.synchronize()
 
@@ -239,6 +261,17 @@ class MnistStepEngine:
                 self.lib.svgp_graph_destroy(exe)
         except Exception:
             pass
+
+
+class _GraphAdapter:
+    def __init__(self, eng, key):
+        self.eng, self.key = eng, key
+
+    def phase(self, k):
+        self.eng.replay((self.key, k))
+
+    def block(self, name):
+        return self.eng.block(name)
 
 
 class _PhaseAdapter:

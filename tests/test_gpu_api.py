@@ -110,3 +110,32 @@ def test_not_yet_built_branches_say_so():
     from svgp_vae_amd.SVGPVAE_model import mnistSVGP
     with pytest.raises(NotImplementedError, match="Titsias"):
         mnistSVGP(True, False, np.zeros((4, 10)), False, None, 'main', 1e-6, 100, 16, False)
+
+
+def test_bacthing_predict_conditional_generation(golden):
+    """Test-MSE path (SVGPVAE_model.py:1026-1083, MNIST_experiment.py:457-486): encode a 'train' set in
+    batches, predict held-out rows from the GP posterior, compare with the oracle's literal restatement."""
+    from svgp_vae_amd.SVGPVAE_model import bacthing_predict_SVGPVAE_rotated_mnist, batching_encode_SVGPVAE
+    gin, _ = golden
+    params, _, _, _, VAE, SVGP_ = _models(golden)
+    SVGP_.N_train = 512.0
+    ovae, osv = O.make_models(params, False, 1e-6, 512.0, 16)
+    img = torch.tensor(gin["images"], dtype=DT)
+    aux = torch.tensor(gin["aux"], dtype=DT)
+    eps = torch.tensor(gin["epsilon"][512:640], dtype=DT)
+    means, vars_ = [], []
+    for lo in (0, 256):                                   # batches of 256 like the reference's loop
+        mu, var, _ = batching_encode_SVGPVAE((img[lo:lo + 256], aux[lo:lo + 256]), VAE, clipping_qs=True)
+        means.append(mu); vars_.append(var)
+    means, vars_ = torch.cat(means), torch.cat(vars_)
+    omu, ovar, _ = O.batching_encode_SVGPVAE((img[:512], aux[:512]), ovae, clipping_qs=True)
+    assert H.relerr(means, omu) < 1e-12 and H.relerr(vars_, ovar) < 1e-12
+    recon, loss = bacthing_predict_SVGPVAE_rotated_mnist((img[512:640], aux[512:640]), VAE, SVGP_, means, vars_,
+                                                         aux[:512], epsilon=eps)
+    orecon, oloss = O.bacthing_predict_SVGPVAE_rotated_mnist((img[512:640], aux[512:640]), ovae, osv, omu, ovar,
+                                                             aux[:512], epsilon=eps)
+    assert recon.shape == (128, 28, 28, 1)
+    assert H.relerr(recon, orecon) < 1e-8
+    assert abs(float(loss) - float(oloss)) < 1e-8 * float(oloss)
+    # MSE_cgen as the driver computes it: sum of batch losses / N_test
+    assert float(loss) / 128 > 0

@@ -1,0 +1,198 @@
+"""Rotated-MNIST experiment driver with the reference's CLI (MNIST_experiment.py:1115-1174 flags and
+defaults) for `--elbo SVGPVAE_Hensman`, running every step on the HIP library.
+
+    python -m svgp_vae_amd.MNIST_experiment --elbo SVGPVAE_Hensman --ip_joint --GP_joint --ov_joint \
+        --clip_qs --GECO --PCA --mnist_data_path "MNIST data/"
+
+Mirrors run_experiment_rotated_mnist_SVGPVAE (MNIST_experiment.py:30-541): model construction with the
+inverted `fixed_*` flags (:96-98), the un-shuffled epoch loop with ragged last batch (:319-355), GECO state
+carry / first-step alpha=0 (kept on device), and every 10 epochs: eval-set reconstruction MSE, conditional
+generation MSE on the test set (:457-486) and `pics/test_metrics.txt` lines `epoch,recon MSE,cgen MSE`
+(:509-510).  Plotting / pandas logging of the reference are not reproduced.
+Other --elbo values (VAE, CVAE, SVGPVAE_Titsias, GPVAE_Casale*, SVIGP_Hensman) are baselines outside this build.
+"""
+import argparse
+import json
+import os
+import pickle
+import time
+
+import numpy as np
+import torch
+
+from .SVGPVAE_model import _runtime, bacthing_predict_SVGPVAE_rotated_mnist, batching_encode_SVGPVAE, mnistSVGP
+from .utils import batches, generate_init_inducing_points, import_rotated_mnist, parse_opt_regime
+from .VAE_utils import mnistVAE
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Rotated MNIST experiment (MI355X SVGPVAE_Hensman path).")
+    p.add_argument('--expid', type=str, default="debug_MNIST")
+    p.add_argument('--base_dir', type=str, default=os.getcwd())
+    p.add_argument('--elbo', type=str, default="VAE",
+                   choices=['VAE', 'CVAE', 'SVGPVAE_Hensman', 'SVGPVAE_Titsias', 'GPVAE_Casale', 'GPVAE_Casale_batch',
+                            'SVIGP_Hensman'])
+    p.add_argument('--mnist_data_path', type=str, default='MNIST data/')
+    p.add_argument('--batch_size', type=int, default=256)
+    p.add_argument('--nr_epochs', type=int, default=1000)
+    p.add_argument('--beta', type=float, default=0.001)
+    p.add_argument('--nr_inducing_points', type=float, default=2)
+    p.add_argument('--save', action="store_true")
+    p.add_argument('--GP_joint', action="store_true")
+    p.add_argument('--ip_joint', action="store_true")
+    p.add_argument('--ov_joint', action="store_true")
+    p.add_argument('--lr', type=float, default=0.001)
+    p.add_argument('--save_model_weights', action="store_true")
+    p.add_argument('--dataset', type=str, choices=['3', '36', '13679'], default='3')
+    p.add_argument('--show_pics', action="store_true")
+    p.add_argument('--opt_regime', type=str, default=['joint-1000'], nargs="+")
+    p.add_argument('--L', type=int, default=16)
+    p.add_argument('--clip_qs', action="store_true")
+    p.add_argument('--ram', type=float, default=1.0)
+    p.add_argument('--test_set_metrics', action='store_true')
+    p.add_argument('--GECO', action='store_true')
+    p.add_argument('--alpha', type=float, default=0.99)
+    p.add_argument('--kappa_squared', type=float, default=0.020)
+    p.add_argument('--object_kernel_normalize', action='store_true')
+    p.add_argument('--save_latents', action='store_true')
+    p.add_argument('--jitter', type=float, default=0.000001)
+    p.add_argument('--PCA', action="store_true")
+    p.add_argument('--bias_analysis', action='store_true')
+    p.add_argument('--M', type=int, default=8)
+    # additions of this build
+    p.add_argument('--train_file', type=str, default=None,
+                   help="pickle used as the train set instead of train_data<dataset>.p (absent from the reference checkout)")
+    p.add_argument('--eval_every', type=int, default=10, help="reference: every 10 epochs")
+    p.add_argument('--seed', type=int, default=0, help="seed of the Keras-style weight init and numpy")
+    return p
+
+
+def run_experiment_rotated_mnist_SVGPVAE(args, args_dict=None):
+    """MNIST_experiment.py:30-541 for elbo == SVGPVAE_Hensman.  Returns a dict of the logged series."""
+    if args.elbo != "SVGPVAE_Hensman":
+        raise NotImplementedError(f"--elbo {args.elbo}: only SVGPVAE_Hensman is built (see DESIGN.md section 9)")
+    np.random.seed(args.seed)
+    n = len(args.dataset)
+    ending = args.dataset + ".p"
+    train, ev, te, train_batches = import_rotated_mnist(args.mnist_data_path, ending, args.batch_size,
+                                                        train_file=args.train_file)
+    N_train = len(train["images"]) if args.train_file else n * 4050
+    N_eval, N_test = len(ev["images"]), len(te["images"])
+
+    chkpnt_dir = None
+    if args.save:
+        stamp = time.strftime("%d_%m_%Y__at__%H_%M_%S")
+        chkpnt_dir = os.path.join(args.base_dir, args.expid, f"{args.elbo}_{args.beta}__on__{stamp}") + "/"
+        os.makedirs(chkpnt_dir + "pics/", exist_ok=True)
+        json.dump(args_dict or vars(args), open(chkpnt_dir + "args.json", "wt"))
+
+    # ---- model (MNIST_experiment.py:82-115)
+    VAE = mnistVAE(L=args.L, seed=args.seed)
+    inducing_points_init = generate_init_inducing_points(None, n=args.nr_inducing_points, remove_test_angle=None,
+                                                         PCA=args.PCA, M=args.M, aux_data=train["aux_data"])
+    ip_joint, GP_joint = not args.ip_joint, not args.GP_joint          # sic: passed as fixed_* (:96-98)
+    if args.ov_joint:
+        if args.PCA:
+            object_vectors_init = pickle.load(open(args.mnist_data_path + f'pca_ov_init{args.dataset}.p', 'rb'))
+        else:
+            object_vectors_init = np.random.normal(0, 1.5, n * 400 * args.M).reshape(n * 400, args.M)
+    else:
+        object_vectors_init = None
+    SVGP_ = mnistSVGP(titsias=False, fixed_inducing_points=ip_joint, initial_inducing_points=inducing_points_init,
+                      fixed_gp_params=GP_joint, object_vectors_init=object_vectors_init, name='main',
+                      jitter=args.jitter, N_train=N_train, L=args.L, K_obj_normalize=args.object_kernel_normalize)
+    kappa = float(np.sqrt(args.kappa_squared))
+    b_cap = max(args.batch_size, N_train)        # the cgen path runs the statistics over all train rows
+    rt = _runtime(VAE, SVGP_, args.clip_qs, args.GECO, kappa, b_cap, alpha_flag=args.alpha, lr=args.lr,
+                  beta=args.beta)
+    eng = rt.eng
+    dev = eng.device
+    print(f"Number of train params: {eng.pl.n_total}")
+
+    # ---- data resident in HBM; batches are copied device-to-device into fixed staging buffers so that
+    #      one captured hipGraph per batch size serves every batch
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    d_train_img, d_train_aux = t64(train["images"]), t64(train["aux_data"])
+    d_eval_img, d_eval_aux = t64(ev["images"]), t64(ev["aux_data"])
+    d_test_img, d_test_aux = t64(te["images"]), t64(te["aux_data"])
+    stage_img = torch.zeros(args.batch_size, 28, 28, 1, dtype=torch.float64, device=dev)
+    stage_aux = torch.zeros(args.batch_size, 2 + args.M, dtype=torch.float64, device=dev)
+    graphs = {}
+
+    def train_batch(lo, hi):
+        b = hi - lo
+        with torch.cuda.stream(eng.stream):
+            stage_img[:b].copy_(d_train_img[lo:hi])
+            stage_aux[:b].copy_(d_train_aux[lo:hi])
+        if b not in graphs:
+            eng.set_batch_size(b)
+            eng.bind(stage_img[:b], stage_aux[:b], None)       # eps drawn on device (tf.random.normal, :901)
+            eng.capture(("train", b), adam=True)
+            graphs[b] = True
+        eng.replay(("train", b))
+
+    nr_epochs, training_regime = parse_opt_regime(args.opt_regime)
+    log = dict(epoch=[], elbo=[], recon_loss=[], eval_mse=[], cgen_mse=[], epoch_time=[])
+    start = time.time()
+    for epoch in range(nr_epochs):
+        t0 = time.time()
+        elbos, losses = [], []
+        for lo, hi in train_batches:
+            train_batch(lo, hi)
+            # the reference fetches elbo / recon_loss every step (:334-340); one 128-byte read-back
+            eng.synchronize()
+            sc = eng.scalars()
+            elbos.append(sc["elbo"]); losses.append(sc["recon_loss"])
+        mse = np.sum(losses) / N_train
+        log["epoch"].append(epoch); log["elbo"].append(float(np.sum(elbos))); log["recon_loss"].append(float(mse))
+        log["epoch_time"].append(time.time() - t0)
+        print(f"Epoch {epoch}: ELBO sum {np.sum(elbos):.4f}  train MSE/px {mse:.6f}  "
+              f"{log['epoch_time'][-1]:.2f}s  (C_ma {sc['c_ma']:.5f}, lagrange {sc['lagrange']:.4f})", flush=True)
+
+        if (epoch + 1) % args.eval_every == 0 or epoch + 1 == nr_epochs:
+            # eval-set reconstruction through the posterior (forward only, no optimiser step)
+            ev_losses = []
+            for lo, hi in batches(N_eval, args.batch_size):
+                eng.set_batch_size(hi - lo)
+                eng.bind(d_eval_img[lo:hi].contiguous(), d_eval_aux[lo:hi].contiguous(), None)
+                with torch.cuda.stream(eng.stream):
+                    eng.phase(0); eng.phase(1)
+                eng.synchronize()
+                rec = eng.ws_view("recon", (hi - lo, 28, 28, 1))
+                ev_losses.append(float(torch.sum((d_eval_img[lo:hi] - rec) ** 2)) / 784.0)
+            eval_mse = float(np.sum(ev_losses) / N_eval)
+            # conditional generation on the test set (:457-486)
+            means, vars_ = [], []
+            for lo, hi in train_batches:
+                mu, var, _ = batching_encode_SVGPVAE((d_train_img[lo:hi], d_train_aux[lo:hi]), VAE,
+                                                     clipping_qs=args.clip_qs)
+                means.append(mu); vars_.append(var)
+            means, vars_ = torch.cat(means), torch.cat(vars_)
+            cg = []
+            for lo, hi in batches(N_test, args.batch_size):
+                _, loss_ = bacthing_predict_SVGPVAE_rotated_mnist((d_test_img[lo:hi], d_test_aux[lo:hi]), VAE, SVGP_,
+                                                                  means, vars_, d_train_aux)
+                cg.append(float(loss_))
+            cgen_mse = float(np.sum(cg) / N_test)
+            log["eval_mse"].append((epoch, eval_mse)); log["cgen_mse"].append((epoch, cgen_mse))
+            print(f"  eval recon MSE/px {eval_mse:.6f}   cgen test MSE/px {cgen_mse:.6f}   "
+                  f"l_GP {float(SVGP_.l_GP):.4f} amplitude {float(SVGP_.amplitude):.4f}", flush=True)
+            if chkpnt_dir:
+                with open(chkpnt_dir + "pics/test_metrics.txt", "a") as f:
+                    f.write(f"{epoch},{eval_mse},{cgen_mse}\n")
+                if args.save_model_weights:
+                    torch.save({"theta": eng.theta.cpu(), "adam_m": eng.adam_m.cpu(), "adam_v": eng.adam_v.cpu(),
+                                "state": eng.state.cpu()}, chkpnt_dir + f"model_{epoch}.pt")
+    log["total_time"] = time.time() - start
+    return log
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    if args.elbo in ("SVGPVAE_Hensman",):
+        return run_experiment_rotated_mnist_SVGPVAE(args, vars(args))
+    raise NotImplementedError(f"--elbo {args.elbo}: only SVGPVAE_Hensman is built (see DESIGN.md section 9)")
+
+
+if __name__ == "__main__":
+    main()

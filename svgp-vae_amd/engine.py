@@ -224,6 +224,9 @@ class MnistStepEngine:
         finally:
             exe = C.c_void_p()
             call("svgp_graph_end", s, C.byref(exe))
+        old = self._graphs.get(key)
+        if old is not None:
+            self.lib.svgp_graph_destroy(old)
         self._graphs[key] = exe
         return exe
 

@@ -188,6 +188,10 @@ def main():
     if use_graph:
         eng.capture("step", adam=True)
         step = lambda: eng.replay("step")
+    elif not args.no_graph:
+        # N > 1: one hipGraph per phase, RCCL all-reduces (not captured) in between
+        eng.capture_phases("step", adam=True)
+        step = lambda: eng.run_phase_graphs("step")
     else:
         step = lambda: eng.run(adam=True)
     for _ in range(args.warmup):
@@ -220,7 +224,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: rotated-MNIST SVGPVAE_Hensman, m=32 inducing, L=16, "
                                    "GPLVM dim 8, batch 256 per GPU, N_train=4050, GECO + clip_qs, float64",
                        "global_batch": B * world, "rows_per_gpu": B,
-                       "launch": "hipGraph replay" if use_graph else "eager phases + RCCL all-reduce x3",
+                       "launch": "hipGraph replay" if use_graph else ("eager phases" if args.no_graph else "per-phase hipGraphs") + " + RCCL all-reduce x3",
                        "parallelism": f"dp{world}"},
         }
         if world == 1:

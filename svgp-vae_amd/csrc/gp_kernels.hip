@@ -325,16 +325,23 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_cols(KernArgs 
         for (int k = 0; k < KM_MAXM; ++k)
             if (k < M) acc_o[k] += c * oi[k];
     }
-    real t;
-    t = block_sum(acc_amp, red); if (threadIdx.x == 0) res[KM_MAXM] = t;
-    t = block_sum(acc_ls, red);  if (threadIdx.x == 0) res[KM_MAXM + 1] = t;
-    t = block_sum(acc_th, red);  if (threadIdx.x == 0) res[KM_MAXM + 2] = t;
+    // one combined reduction: wave sums -> LDS [wave][3+M] -> thread v sums the waves (fixed order)
+    __shared__ real wred[SVGP_BLOCK / 64][KM_MAXM + 4];
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        real t = wave_sum(acc_amp); if (lane == 0) wred[wv][KM_MAXM] = t;
+        t = wave_sum(acc_ls);       if (lane == 0) wred[wv][KM_MAXM + 1] = t;
+        t = wave_sum(acc_th);       if (lane == 0) wred[wv][KM_MAXM + 2] = t;
 #pragma unroll
-    for (int k = 0; k < KM_MAXM; ++k) {
-        if (k < M) {                                 // M is workgroup-uniform
-            t = block_sum(acc_o[k], red);
-            if (threadIdx.x == 0) res[k] = t;
+        for (int k = 0; k < KM_MAXM; ++k)
+            if (k < M) { t = wave_sum(acc_o[k]); if (lane == 0) wred[wv][k] = t; }
+        __syncthreads();
+        if (threadIdx.x < KM_MAXM + 3 && (threadIdx.x < M || threadIdx.x >= KM_MAXM)) {
+            real sres = 0;
+            for (int wq = 0; wq < (int)(blockDim.x >> 6); ++wq) sres += wred[wq][threadIdx.x];
+            res[threadIdx.x] = sres;
         }
+        __syncthreads();
     }
     if (threadIdx.x == 0) {
         part_gp[j * 2 + 0] = real(2) * res[KM_MAXM] / amp;                         // d amplitude
@@ -422,7 +429,8 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_rows(KernArgs 
 }
 
 // Deterministic scatter-add of d_on into the object table gradient (duplicate ids sum in row
-// order; ids staged through LDS) + final amplitude / length-scale sums.  Last block does the scalars.
+// order).  Rows are processed in chunks of 256 with ids AND the d_on rows staged in LDS, so the scan
+// touches no global memory.  The last block does the final amplitude / length-scale sums.
 __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernArgs a, int n_gp_part, int train_gp,
                                                                           int train_ov,
                                                                           const real* __restrict__ d_on,
@@ -430,7 +438,8 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernAr
                                                                           real* __restrict__ d_ov,
                                                                           real* __restrict__ d_ls,
                                                                           real* __restrict__ d_amp) {
-    __shared__ int ids[1024];
+    extern __shared__ __align__(16) real smem[];
+    __shared__ int ids[256];
     __shared__ real red[16];
     if (blockIdx.x == gridDim.x - 1) {
         real sa = 0, sl = 0;
@@ -440,18 +449,21 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernAr
         if (threadIdx.x == 0) { *d_amp = train_gp ? sa : real(0); *d_ls = train_gp ? sl : real(0); }
         return;
     }
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool act = o < a.n_obj * a.M;
-    const int r = act ? o / a.M : -1, k = act ? o % a.M : 0, st = 2 + a.M;
+    real* dbuf = smem;      // 256 x M
+    const int o = blockIdx.x * blockDim.x + threadIdx.x, M = a.M;
+    const bool act = o < a.n_obj * M;
+    const int r = act ? o / M : -1, k = act ? o % M : 0, st = 2 + M;
     real acc = 0;
-    for (int n0 = 0; n0 < a.b; n0 += 1024) {
-        const int cnt = min(1024, a.b - n0);
+    for (int n0 = 0; n0 < a.b; n0 += 256) {
+        const int cnt = min(256, a.b - n0);
         __syncthreads();
-        for (int t = threadIdx.x; t < cnt; t += blockDim.x) ids[t] = (int)a.aux[(size_t)(n0 + t) * st];
+        if (threadIdx.x < cnt) ids[threadIdx.x] = (int)a.aux[(size_t)(n0 + threadIdx.x) * st];
+        for (int t = threadIdx.x; t < cnt * M; t += blockDim.x) dbuf[t] = d_on[(size_t)n0 * M + t];
         __syncthreads();
-        if (train_ov && act)
-            for (int t = 0; t < cnt; ++t)
-                if (ids[t] == r) acc += d_on[(size_t)(n0 + t) * a.M + k];
+        if (train_ov && act) {
+#pragma unroll 4
+            for (int t = 0; t < cnt; ++t) acc += (ids[t] == r) ? dbuf[t * M + k] : real(0);
+        }
     }
     if (act) d_ov[o] = acc;
 }
@@ -519,9 +531,10 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
     for (int r0 = 0; r0 < a.b; r0 += STAT_RC) {
         const int rows = min(STAT_RC, a.b - r0), rows4 = (rows + 3) & ~3;
         __syncthreads();
-        for (int t = threadIdx.x; t < rows4 * mp; t += blockDim.x) {
-            const int rr = t / mp, cc = t % mp;
-            kt[rr * ldk + cc] = (rr < rows && cc < m) ? a.Kn[(size_t)(r0 + rr) * m + cc] : real(0);
+        if (vpart < nparts) {          // thread = (column vi, row lane vpart): no division in the loop
+#pragma unroll 4
+            for (int rr = vpart; rr < rows4; rr += nparts)
+                kt[rr * ldk + vi] = (rr < rows && vi < m) ? a.Kn[(size_t)(r0 + rr) * m + vi] : real(0);
         }
         for (int rr = threadIdx.x; rr < rows4; rr += blockDim.x) {
             if (rr >= rows) { w[rr] = 0; va[rr] = 0; vb[rr] = 0; continue; }
@@ -1081,8 +1094,8 @@ extern "C" int svgp_kernel_matrix_bwd(const svgp_mnist_cfg* c, const double* the
                        ws + wl.Knbar, ws + wl.knnbar, ws + wl.knn, ws + wl.d_on, ws + wl.part_gp);
     SVGP_LAUNCH_CHECK();
     const int n_ov = c->n_obj * c->M;
-    hipLaunchKernelGGL(k_kernel_matrix_bwd_scatter, dim3((n_ov + SVGP_BLOCK - 1) / SVGP_BLOCK + 1), dim3(SVGP_BLOCK), 0,
-                       (hipStream_t)stream, a, c->m + nrb, c->train_gp, c->train_ov, ws + wl.d_on, ws + wl.part_gp,
+    hipLaunchKernelGGL(k_kernel_matrix_bwd_scatter, dim3((n_ov + SVGP_BLOCK - 1) / SVGP_BLOCK + 1), dim3(SVGP_BLOCK),
+                       (size_t)256 * c->M * sizeof(real), (hipStream_t)stream, a, c->m + nrb, c->train_gp, c->train_ov, ws + wl.d_on, ws + wl.part_gp,
                        grad + pl.ov, grad + pl.l_GP, grad + pl.amplitude);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;

@@ -42,10 +42,16 @@ __device__ __forceinline__ d4_t mfma_tile(const real* A, const real* B, int ld, 
     const real* ap = TA ? A + q * ld + ti * 16 + r : A + (ti * 16 + r) * ld + q;
     const real* bp = TB ? B + (tj * 16 + r) * ld + q : B + q * ld + tj * 16 + r;
     const int as = TA ? 4 * ld : 4, bs = TB ? 4 : 4 * ld;
-    for (int k0 = 0; k0 < mp; k0 += 4) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(*ap, *bp, acc, 0, 0, 0);
-        ap += as;
-        bp += bs;
+    // mp is a multiple of 16: four k-steps per trip, operands of the trip fetched together
+    for (int k0 = 0; k0 < mp; k0 += 16) {
+        const real a0 = ap[0], a1 = ap[as], a2 = ap[2 * as], a3 = ap[3 * as];
+        const real b0 = bp[0], b1 = bp[bs], b2 = bp[2 * bs], b3 = bp[3 * bs];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b2, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b3, acc, 0, 0, 0);
+        ap += 4 * as;
+        bp += 4 * bs;
     }
     return acc;
 }
@@ -281,7 +287,6 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_cols(KernArgs 
                                                                        const real* __restrict__ Knbar,
                                                                        real* __restrict__ d_ip,
                                                                        real* __restrict__ part_gp) {
-    __shared__ real red[16];
     __shared__ real res[KM_MAXM + 4];
     const int j = blockIdx.x, st = 2 + a.M, M = a.M;
     const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernAr
                                                                           real* __restrict__ d_ls,
                                                                           real* __restrict__ d_amp) {
     extern __shared__ __align__(16) real smem[];
-    __shared__ int ids[256];
+    __shared__ __align__(16) int ids[256];
     __shared__ real red[16];
     if (blockIdx.x == gridDim.x - 1) {
         real sa = 0, sl = 0;
@@ -457,12 +462,20 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernAr
     for (int n0 = 0; n0 < a.b; n0 += 256) {
         const int cnt = min(256, a.b - n0);
         __syncthreads();
-        if (threadIdx.x < cnt) ids[threadIdx.x] = (int)a.aux[(size_t)(n0 + threadIdx.x) * st];
+        if (threadIdx.x < 256) ids[threadIdx.x] = threadIdx.x < cnt ? (int)a.aux[(size_t)(n0 + threadIdx.x) * st] : -2;
         for (int t = threadIdx.x; t < cnt * M; t += blockDim.x) dbuf[t] = d_on[(size_t)n0 * M + t];
         __syncthreads();
         if (train_ov && act) {
-#pragma unroll 4
-            for (int t = 0; t < cnt; ++t) acc += (ids[t] == r) ? dbuf[t * M + k] : real(0);
+            // 16 ids per iteration through four 16-byte LDS reads issued together; matches are rare
+            const int4* idv = reinterpret_cast<const int4*>(ids);
+            for (int t = 0; t < cnt; t += 16) {
+                const int4 q0 = idv[(t >> 2)], q1 = idv[(t >> 2) + 1], q2 = idv[(t >> 2) + 2], q3 = idv[(t >> 2) + 3];
+                const int qq[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                                    q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (qq[u] == r) acc += dbuf[(t + u) * M + k];
+            }
         }
     }
     if (act) d_ov[o] = acc;
@@ -563,7 +576,19 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
                 const int ti = t / nt, tj = t % nt;
                 const real* ap = kt + q * ldk + ti * 16 + r16;
                 const real* bp = kt + q * ldk + tj * 16 + r16;
-                for (int k0 = 0; k0 < rows4; k0 += 4) {
+                int k0 = 0;
+                for (; k0 + 16 <= rows4; k0 += 16) {          // four k-steps per trip, loads issued together
+                    const real a0 = ap[0], a1 = ap[4 * ldk], a2 = ap[8 * ldk], a3 = ap[12 * ldk];
+                    const real b0 = bp[0], b1 = bp[4 * ldk], b2 = bp[8 * ldk], b3 = bp[12 * ldk];
+                    const real w0 = w[k0 + q], w1 = w[k0 + 4 + q], w2 = w[k0 + 8 + q], w3 = w[k0 + 12 + q];
+                    acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0 * w0, b0, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1 * w1, b1, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2 * w2, b2, acc[tt], 0, 0, 0);
+                    acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3 * w3, b3, acc[tt], 0, 0, 0);
+                    ap += 16 * ldk;
+                    bp += 16 * ldk;
+                }
+                for (; k0 < rows4; k0 += 4) {
                     acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[0] * w[k0 + q], bp[0], acc[tt], 0, 0, 0);
                     ap += 4 * ldk;
                     bp += 4 * ldk;
@@ -571,6 +596,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
             }
         }
         if (vpart < nparts && vi < m) {
+#pragma unroll 8
             for (int r = vpart; r < rows; r += nparts) {
                 const real k = kt[r * ldk + vi];
                 acc1 += va[r] * k;
@@ -637,6 +663,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
         __syncthreads();
         real acc = 0;
         if (act) {
+#pragma unroll 8
             for (int j = 0; j < m; ++j) acc += R0[j * ld + i] * kr[nl * m + j];   // Ki symmetric
             acc *= kr[nl * m + i];
         }
@@ -756,6 +783,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_fwd(PostArgs a) {
     real r = 0, s = 0, pm = 0, mv = 0;
     if (act) {
         const real ki = kr[nl * m + i];
+#pragma unroll 8
         for (int j = 0; j < m; ++j) {
             const real kj = kr[nl * m + j];
             r += R0[j * ld + i] * kj;       // symmetric matrices: column walk = row walk
@@ -769,6 +797,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_fwd(PostArgs a) {
     real l3 = 0, ce = 0;
     if (act && i == 0) {
         real rs = 0, ss = 0, pms = 0, mvs = 0;
+#pragma unroll 8
         for (int k = 0; k < m; ++k) {
             rs += sc[nl * m + k]; ss += sc[SVGP_BLOCK + nl * m + k];
             pms += sc[2 * SVGP_BLOCK + nl * m + k]; mvs += sc[3 * SVGP_BLOCK + nl * m + k];
@@ -970,6 +999,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_l(PostBwdArgs a
         const size_t e = (size_t)n * a.L + l;
         const real p = recip_no_nan(a.s2[e]), gpv = a.g_pv[e];
         real sik = 0, qk = 0, ssk = 0;
+#pragma unroll 8
         for (int j = 0; j < m; ++j) {
             const real kj = kr[nl * m + j];
             sik += R0[j * ld + i] * kj;
@@ -1022,8 +1052,10 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_sum(PostBwdArgs
     __syncthreads();
     if (act) {
         real acc = 0;
+#pragma unroll 8
         for (int l = 0; l < a.L; ++l) acc += a.Knbar_part[((size_t)l * a.b + n) * m + i];
         real w = 0;
+#pragma unroll 8
         for (int j = 0; j < m; ++j) w += R0[j * ld + i] * kr[nl * m + j];
         a.Knbar[(size_t)n * m + i] = acc + real(2) * qb[nl] * w;
     }
@@ -1094,9 +1126,11 @@ extern "C" int svgp_kernel_matrix_bwd(const svgp_mnist_cfg* c, const double* the
                        ws + wl.Knbar, ws + wl.knnbar, ws + wl.knn, ws + wl.d_on, ws + wl.part_gp);
     SVGP_LAUNCH_CHECK();
     const int n_ov = c->n_obj * c->M;
-    hipLaunchKernelGGL(k_kernel_matrix_bwd_scatter, dim3((n_ov + SVGP_BLOCK - 1) / SVGP_BLOCK + 1), dim3(SVGP_BLOCK),
-                       (size_t)256 * c->M * sizeof(real), (hipStream_t)stream, a, c->m + nrb, c->train_gp, c->train_ov, ws + wl.d_on, ws + wl.part_gp,
-                       grad + pl.ov, grad + pl.l_GP, grad + pl.amplitude);
+    {
+        hipLaunchKernelGGL(k_kernel_matrix_bwd_scatter, dim3((n_ov + SVGP_BLOCK - 1) / SVGP_BLOCK + 1), dim3(SVGP_BLOCK),
+                           (size_t)256 * c->M * sizeof(real), (hipStream_t)stream, a, c->m + nrb, c->train_gp, c->train_ov, ws + wl.d_on, ws + wl.part_gp,
+                           grad + pl.ov, grad + pl.l_GP, grad + pl.amplitude);
+    }
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

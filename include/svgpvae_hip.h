@@ -196,6 +196,18 @@ int svgp_mnist_train_step(const svgp_mnist_cfg*, double* theta, const double* im
                           const double* aux, const double* eps, double* ws, double* state,
                           double* adam_m, double* adam_v, void* stream);
 
+/* ---- batched float64 linear algebra on device matrices (large-m path; also usable on their own) ---
+ * replace tf.matmul / tf.linalg.inv / tf.linalg.cholesky+log(diag) (SVGPVAE_model.py:239,270-274,319,328-341)
+ * svgp_dgemm_batched: C[l] = alpha op(A[l]) op(B[l]) + beta C[l]; C is M x N, contraction K; ta/tb = 1 means
+ *   the operand is stored transposed (A as K x M, B as N x K); strides in elements, 0 = shared operand.
+ * svgp_spd_inverse_batched: A (batch, m, m) contiguous SPD -> A^-1 in place (blocked Gauss-Jordan, no
+ *   pivoting) and logdet[l] = log det A[l]; work holds svgp_spd_inverse_workspace_elems(m, batch) doubles. */
+int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
+                       long long strideA, const double* B, int ldb, long long strideB, double beta, double* C,
+                       int ldc, long long strideC, int batch, void* stream);
+size_t svgp_spd_inverse_workspace_elems(int m, int batch);
+int svgp_spd_inverse_batched(int m, int batch, double* A, double* logdet, double* work, void* stream);
+
 /* ---- runtime helpers: HIP graphs and events without going through torch ---------------------*/
 int svgp_stream_create(void** stream_out);
 int svgp_stream_destroy(void* stream);

@@ -74,6 +74,9 @@ SIGNATURES = {
     "svgp_elbo_finalize_noadam": [_CFG, _P, _P, _P],
     "svgp_mnist_step_phase": [_CFG, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "svgp_mnist_train_step": [_CFG, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "svgp_dgemm_batched": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.c_int, C.c_longlong, _P,
+                           C.c_int, C.c_longlong, C.c_double, _P, C.c_int, C.c_longlong, C.c_int, _P],
+    "svgp_spd_inverse_batched": [C.c_int, C.c_int, _P, _P, _P, _P],
     "svgp_stream_create": [C.POINTER(_P)],
     "svgp_stream_destroy": [_P],
     "svgp_stream_sync": [_P],
@@ -86,7 +89,8 @@ SIGNATURES = {
     "svgp_event_elapsed_ms": [_P, _P, C.POINTER(C.c_float)],
     "svgp_event_destroy": [_P],
 }
-NON_STATUS = {"svgp_version": ([], C.c_int), "svgp_last_error": ([], C.c_char_p)}
+NON_STATUS = {"svgp_version": ([], C.c_int), "svgp_last_error": ([], C.c_char_p),
+              "svgp_spd_inverse_workspace_elems": ([C.c_int, C.c_int], C.c_size_t)}
 
 _lib = None
 

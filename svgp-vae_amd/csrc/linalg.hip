@@ -1,0 +1,300 @@
+// Batched float64 linear algebra on global-memory matrices for the large-m (m > 64) GP path:
+//   svgp_dgemm_batched        C[l] = alpha op(A[l]) op(B[l]) + beta C[l]     (f64 MFMA, 64x64 tiles)
+//   svgp_spd_inverse_batched  A[l] <- A[l]^-1, logdet[l]                      (blocked Gauss-Jordan)
+// They replace tf.matmul / tf.linalg.inv / tf.linalg.cholesky+log(diag) of the reference
+// (SVGPVAE_model.py:239,270-274,319,328-341) when the m x m matrices no longer fit in LDS.
+#include "common.hpp"
+
+namespace {
+
+typedef double d4_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// GEMM.  Workgroup = 256 threads = 4 waves; output tile 64 x 64; wave w owns the 32 x 32 quadrant
+// (w>>1, w&1) = 2 x 2 MFMA 16x16 tiles; k-panels of 16 staged in LDS as As[k][i], Bs[k][j] (k-major:
+// the MFMA operand fetch A[i=lane&15][k=lane>>4] walks 16 consecutive i -> conflict-free).
+// ---------------------------------------------------------------------------------------------
+#define GT 64
+#define GK 16
+#define GLD (GT + 2)
+
+struct GemmArgs {
+    int M, N, K;            // C is M x N, contraction K
+    int ta, tb;             // op(A) = A^T if ta (A stored K x M), op(B) = B^T if tb (B stored N x K)
+    int lda, ldb, ldc;
+    long long sa, sb, sc;   // batch strides in elements (0 = shared)
+    real alpha, beta;
+    const real* A; const real* B; real* C;
+};
+
+__global__ __launch_bounds__(256) void k_dgemm_batched(GemmArgs g) {
+    __shared__ real As[GK][GLD];
+    __shared__ real Bs[GK][GLD];
+    const int l = blockIdx.z, i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+    const real* A = g.A + (size_t)l * g.sa;
+    const real* B = g.B + (size_t)l * g.sb;
+    real* C = g.C + (size_t)l * g.sc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    d4_t acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4_t{0, 0, 0, 0};
+    for (int k0 = 0; k0 < g.K; k0 += GK) {
+        __syncthreads();
+        // stage A panel: As[k][i] = op(A)[i0+i][k0+k]
+        if (g.ta) {          // A stored [k][i]: consecutive i
+            for (int t = tid; t < GK * GT; t += 256) {
+                const int k = t / GT, i = t % GT, gi = i0 + i, gk = k0 + k;
+                As[k][i] = (gi < g.M && gk < g.K) ? A[(size_t)gk * g.lda + gi] : real(0);
+            }
+        } else {             // A stored [i][k]: consecutive k
+            for (int t = tid; t < GK * GT; t += 256) {
+                const int i = t / GK, k = t % GK, gi = i0 + i, gk = k0 + k;
+                As[k][i] = (gi < g.M && gk < g.K) ? A[(size_t)gi * g.lda + gk] : real(0);
+            }
+        }
+        if (g.tb) {          // B stored [j][k]
+            for (int t = tid; t < GK * GT; t += 256) {
+                const int j = t / GK, k = t % GK, gj = j0 + j, gk = k0 + k;
+                Bs[k][j] = (gj < g.N && gk < g.K) ? B[(size_t)gj * g.ldb + gk] : real(0);
+            }
+        } else {             // B stored [k][j]
+            for (int t = tid; t < GK * GT; t += 256) {
+                const int k = t / GT, j = t % GT, gj = j0 + j, gk = k0 + k;
+                Bs[k][j] = (gj < g.N && gk < g.K) ? B[(size_t)gk * g.ldb + gj] : real(0);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GK; kk += 4) {
+            const real a0 = As[kk + q][wi + r], a1 = As[kk + q][wi + 16 + r];
+            const real b0 = Bs[kk + q][wj + r], b1 = Bs[kk + q][wj + 16 + r];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int gi = i0 + wi + a * 16 + q + 4 * e, gj = j0 + wj + b * 16 + r;
+                if (gi < g.M && gj < g.N) {
+                    const size_t o = (size_t)gi * g.ldc + gj;
+                    C[o] = g.alpha * acc[a][b][e] + (g.beta != real(0) ? g.beta * C[o] : real(0));
+                }
+            }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Blocked Gauss-Jordan inverse (no pivoting; SPD inputs), block size 32.  Per block step kb:
+//   k_bgj_pivot : P^-1 of the (updated) diagonal block via the single-wave register sweep, log det
+//                 accumulation, and a copy of the OLD block column kb (needed by every trailing update);
+//   k_bgj_row   : row panel  A[kb][j] <- P^-1 A[kb][j]  (j != kb),  A[kb][kb] <- P^-1;
+//   k_bgj_trail : A[i][j] <- A[i][j] - Cold[i] A[kb][j]  (i != kb, j != kb);  A[i][kb] <- -Cold[i] P^-1.
+// Rows / columns >= m of the last block behave as an identity pad.
+// ---------------------------------------------------------------------------------------------
+#define NB 32
+
+__device__ __forceinline__ real fast_rcp_la(real x) {
+    real r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, real(1)), r, r);
+    r = fma(fma(-x, r, real(1)), r, r);
+    return r;
+}
+__device__ __forceinline__ real wave_sum_la(real x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    return x;
+}
+
+struct BgjArgs {
+    int m, kb;
+    long long sA;          // batch stride of A (m*m)
+    real* A;               // (batch, m, m)
+    real* Pinv;            // (batch, 32, 32)
+    real* Cold;            // (batch, m, 32)
+    real* logdet;          // (batch)
+};
+
+// element (i,j) of the 32x32 block (bi,bj) of A with the identity pad
+__device__ __forceinline__ real blk_get(const real* A, int m, int bi, int bj, int i, int j) {
+    const int gi = bi * NB + i, gj = bj * NB + j;
+    return (gi < m && gj < m) ? A[(size_t)gi * m + gj] : (gi == gj ? real(1) : real(0));
+}
+
+__global__ __launch_bounds__(256) void k_bgj_pivot(BgjArgs g) {
+    __shared__ real P[NB][NB + 1];
+    const int l = blockIdx.x, m = g.m, kb = g.kb;
+    real* A = g.A + (size_t)l * g.sA;
+    for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) P[t / NB][t % NB] = blk_get(A, m, kb, kb, t / NB, t % NB);
+    // copy the old block column kb (all rows)
+    real* Cold = g.Cold + (size_t)l * m * NB;
+    for (int t = threadIdx.x; t < m * NB; t += blockDim.x) {
+        const int i = t / NB, j = t % NB, gj = kb * NB + j;
+        Cold[t] = (gj < m) ? A[(size_t)i * m + gj] : real(0);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {      // single-wave Gauss-Jordan on an 8 x 8 lane grid of 4 x 4 blocks
+        const int lane = threadIdx.x, bi = lane >> 3, bj = lane & 7;
+        real a[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[r][c] = P[bi * 4 + r][bj * 4 + c];
+        real mypiv = 1;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int kq = k / 4, kr = k % 4;
+            real rowk[4], colk[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rowk[c] = __shfl(a[kr][c], kq * 8 + bj, 64);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) colk[r] = __shfl(a[r][kr], bi * 8 + kq, 64);
+            const real piv = __shfl(a[kr][kr], kq * 8 + kq, 64);
+            const real ipiv = fast_rcp_la(piv);
+            if (lane == k) mypiv = piv;
+            real rkj[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rkj[c] = (bj * 4 + c == k) ? ipiv : rowk[c] * ipiv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool ik = (bi * 4 + r == k), jk = (bj * 4 + c == k);
+                    a[r][c] = ik ? rkj[c] : ((jk ? real(0) : a[r][c]) - colk[r] * rkj[c]);
+                }
+        }
+        real* Pinv = g.Pinv + (size_t)l * NB * NB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Pinv[(bi * 4 + r) * NB + bj * 4 + c] = a[r][c];
+        const real lg = wave_sum_la(log(mypiv));
+        if (lane == 0) g.logdet[l] = (kb == 0 ? real(0) : g.logdet[l]) + lg;
+    }
+}
+
+// C (32x32, registers -> out) = X (32x32, LDS) * Y (32x32, LDS) on one workgroup of 256 threads:
+// thread (i = tid/8, 4 consecutive columns j0 = (tid%8)*4)
+__device__ __forceinline__ void mm32(const real (*X)[NB + 1], const real (*Y)[NB + 1], real out[4]) {
+    const int i = threadIdx.x >> 3, j0 = (threadIdx.x & 7) * 4;
+    out[0] = out[1] = out[2] = out[3] = 0;
+#pragma unroll 8
+    for (int k = 0; k < NB; ++k) {
+        const real x = X[i][k];
+        out[0] += x * Y[k][j0]; out[1] += x * Y[k][j0 + 1]; out[2] += x * Y[k][j0 + 2]; out[3] += x * Y[k][j0 + 3];
+    }
+}
+
+// grid (nb, batch): block column j of the pivot row
+__global__ __launch_bounds__(256) void k_bgj_row(BgjArgs g) {
+    __shared__ real X[NB][NB + 1];
+    __shared__ real Y[NB][NB + 1];
+    const int j = blockIdx.x, l = blockIdx.y, m = g.m, kb = g.kb;
+    real* A = g.A + (size_t)l * g.sA;
+    const real* Pinv = g.Pinv + (size_t)l * NB * NB;
+    const int i = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+    if (j == kb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int gi = kb * NB + i, gj = kb * NB + c0 + e;
+            if (gi < m && gj < m) A[(size_t)gi * m + gj] = Pinv[i * NB + c0 + e];
+        }
+        return;
+    }
+    for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) {
+        X[t / NB][t % NB] = Pinv[t];
+        Y[t / NB][t % NB] = blk_get(A, m, kb, j, t / NB, t % NB);
+    }
+    __syncthreads();
+    // off-diagonal pad entries of blk_get are 0 except where gi == gj, impossible for kb != j
+    real out[4];
+    mm32(X, Y, out);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int gi = kb * NB + i, gj = j * NB + c0 + e;
+        if (gi < m && gj < m) A[(size_t)gi * m + gj] = out[e];
+    }
+}
+
+// grid (nb, nb, batch): block (i, j), i != kb
+__global__ __launch_bounds__(256) void k_bgj_trail(BgjArgs g) {
+    __shared__ real X[NB][NB + 1];
+    __shared__ real Y[NB][NB + 1];
+    const int bj = blockIdx.x, bi = blockIdx.y, l = blockIdx.z, m = g.m, kb = g.kb;
+    if (bi == kb) return;
+    real* A = g.A + (size_t)l * g.sA;
+    const real* Cold = g.Cold + (size_t)l * m * NB;
+    const real* Pinv = g.Pinv + (size_t)l * NB * NB;
+    for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) {
+        const int r = t / NB, cidx = t % NB, gi = bi * NB + r;
+        X[r][cidx] = (gi < m) ? Cold[(size_t)gi * NB + cidx] : real(0);          // old A[i][kb]
+        if (bj == kb) Y[r][cidx] = Pinv[t];
+        else {
+            const int gk = kb * NB + r, gj = bj * NB + cidx;                        // new row panel A[kb][j]
+            Y[r][cidx] = (gk < m && gj < m) ? A[(size_t)gk * m + gj] : real(0);
+        }
+    }
+    __syncthreads();
+    real out[4];
+    mm32(X, Y, out);
+    const int i = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int gi = bi * NB + i, gj = bj * NB + c0 + e;
+        if (gi < m && gj < m) {
+            const size_t o = (size_t)gi * m + gj;
+            A[o] = (bj == kb) ? -out[e] : A[o] - out[e];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
+                                  long long strideA, const double* B, int ldb, long long strideB, double beta,
+                                  double* C, int ldc, long long strideC, int batch, void* stream) {
+    SVGP_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, SVGP_ERR_INVALID, "negative dimension");
+    if (M == 0 || N == 0 || batch == 0) return SVGP_OK;
+    SVGP_REQUIRE(A && B && C, SVGP_ERR_INVALID, "NULL device pointer");
+    GemmArgs g;
+    g.M = M; g.N = N; g.K = K; g.ta = ta; g.tb = tb; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.sa = strideA; g.sb = strideB; g.sc = strideC; g.alpha = alpha; g.beta = beta; g.A = A; g.B = B; g.C = C;
+    hipLaunchKernelGGL(k_dgemm_batched, dim3((N + GT - 1) / GT, (M + GT - 1) / GT, batch), dim3(256), 0,
+                       (hipStream_t)stream, g);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+extern "C" size_t svgp_spd_inverse_workspace_elems(int m, int batch) {
+    return (size_t)batch * (NB * NB + (size_t)m * NB);
+}
+
+// A (batch, m, m) SPD, contiguous -> inverse in place; logdet (batch).  work: svgp_spd_inverse_workspace_elems.
+extern "C" int svgp_spd_inverse_batched(int m, int batch, double* A, double* logdet, double* work, void* stream) {
+    SVGP_REQUIRE(m >= 1 && batch >= 0, SVGP_ERR_INVALID, "bad m / batch");
+    if (batch == 0) return SVGP_OK;
+    SVGP_REQUIRE(A && logdet && work, SVGP_ERR_INVALID, "NULL device pointer");
+    BgjArgs g;
+    g.m = m; g.sA = (long long)m * m; g.A = A; g.Pinv = work; g.Cold = work + (size_t)batch * NB * NB;
+    g.logdet = logdet;
+    const int nb = (m + NB - 1) / NB;
+    for (int kb = 0; kb < nb; ++kb) {
+        g.kb = kb;
+        hipLaunchKernelGGL(k_bgj_pivot, dim3(batch), dim3(256), 0, (hipStream_t)stream, g);
+        SVGP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_bgj_row, dim3(nb, batch), dim3(256), 0, (hipStream_t)stream, g);
+        SVGP_LAUNCH_CHECK();
+        if (nb > 1) {
+            hipLaunchKernelGGL(k_bgj_trail, dim3(nb, nb, batch), dim3(256), 0, (hipStream_t)stream, g);
+            SVGP_LAUNCH_CHECK();
+        }
+    }
+    return SVGP_OK;
+}

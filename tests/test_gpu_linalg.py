@@ -1,0 +1,56 @@
+"""Batched float64 GEMM (MFMA) and blocked Gauss-Jordan SPD inverse against torch on the same inputs."""
+import ctypes as C
+
+import pytest
+import torch
+
+from svgp_vae_amd import _lib
+
+pytestmark = pytest.mark.gpu
+DT = torch.float64
+
+
+def _gemm(ta, tb, M, N, K, alpha, A, B, beta, Cm, batch, sa, sb):
+    s = torch.cuda.current_stream().cuda_stream
+    _lib.call("svgp_dgemm_batched", ta, tb, M, N, K, alpha, A.data_ptr(), A.shape[-1], sa, B.data_ptr(), B.shape[-1], sb,
+              beta, Cm.data_ptr(), Cm.shape[-1], M * N, batch, s)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K,batch", [(64, 64, 64, 1), (100, 37, 250, 3), (256, 256, 1024, 2), (5, 1, 7, 4), (130, 200, 3, 1)])
+def test_dgemm_batched(ta, tb, M, N, K, batch):
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
+    A = torch.randn((batch, K, M) if ta else (batch, M, K), dtype=DT, device="cuda", generator=g)
+    B = torch.randn((batch, N, K) if tb else (batch, K, N), dtype=DT, device="cuda", generator=g)
+    C0 = torch.randn(batch, M, N, dtype=DT, device="cuda", generator=g)
+    Cm = C0.clone()
+    _gemm(ta, tb, M, N, K, 0.7, A, B, -0.3, Cm, batch, A[0].numel(), B[0].numel())
+    opA = A.transpose(1, 2) if ta else A
+    opB = B.transpose(1, 2) if tb else B
+    want = 0.7 * opA @ opB - 0.3 * C0
+    assert float((Cm - want).abs().max()) <= 1e-12 * K * float(want.abs().max() + 1)
+    # shared B operand (stride 0) and beta = 0 must not read C
+    Cn = torch.full((batch, M, N), float("nan"), dtype=DT, device="cuda")
+    _gemm(ta, tb, M, N, K, 1.0, A, B[0].contiguous(), 0.0, Cn, batch, A[0].numel(), 0)
+    want = opA @ (opB[0])
+    assert float((Cn - want).abs().max()) <= 1e-12 * K * float(want.abs().max() + 1)
+
+
+@pytest.mark.parametrize("m,batch", [(32, 1), (64, 3), (72, 2), (100, 1), (256, 17), (513, 2)])
+def test_spd_inverse_batched(m, batch):
+    g = torch.Generator(device="cuda").manual_seed(m)
+    X = torch.randn(batch, m, m + 8, dtype=DT, device="cuda", generator=g)
+    A = X @ X.transpose(1, 2) / m + 0.05 * torch.eye(m, dtype=DT, device="cuda")
+    inv = A.clone()
+    logdet = torch.zeros(batch, dtype=DT, device="cuda")
+    lib = _lib.load_library()
+    work = torch.zeros(lib.svgp_spd_inverse_workspace_elems(m, batch), dtype=DT, device="cuda")
+    _lib.call("svgp_spd_inverse_batched", m, batch, inv.data_ptr(), logdet.data_ptr(), work.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    want = torch.linalg.inv(A)
+    assert float((inv - want).abs().max() / want.abs().max()) < 1e-9
+    assert float((logdet - torch.linalg.slogdet(A)[1]).abs().max()) < 1e-9 * m
+    eye = torch.eye(m, dtype=DT, device="cuda")
+    assert float((inv @ A - eye).abs().max()) < 1e-8

@@ -34,7 +34,7 @@ extern "C" {
 typedef enum {
     SVGP_OK = 0,
     SVGP_ERR_INVALID = -1,     /* bad argument / null pointer / inconsistent shapes            */
-    SVGP_ERR_UNSUPPORTED = -2, /* shape outside what this build implements (e.g. m > 64)       */
+    SVGP_ERR_UNSUPPORTED = -2, /* shape outside what this build implements (e.g. m > 2048)     */
     SVGP_ERR_HIP = -3          /* a HIP runtime call failed (message has hipGetErrorString)    */
 } svgp_status;
 
@@ -96,6 +96,7 @@ typedef struct {
     int64_t statB, statB_len, A2, ud, td; /* ONE contiguous all-reduce block [A2 | ud | td]       */
     int64_t Kbar, fb_part, Qm, vbar, Ssym; /* (m,m) (2,L,m,m) scratch (L,m,m) (L,m) (L,m,m)        */
     int64_t Knbar_part;                   /* (L,b,m) per-channel row gradients before the sum     */
+    int64_t scr_bm, scr_mm, scr_vec, scr_inv, scr_bl; /* scratch of the large-m (m > 64) path     */
     int64_t Knbar, knnbar, ybar, s2bar;   /* (b,m) (b) (b,L) (b,L)                                */
     int64_t d_on;                         /* (b,M) gradient of gathered object rows               */
     /* partial sums */

@@ -21,9 +21,8 @@ int svgp_check_cfg(const svgp_mnist_cfg* c) {
                  c->b, c->b_global);
     SVGP_REQUIRE(c->m >= 1 && c->L >= 1 && c->M >= 1 && c->n_obj >= 0, SVGP_ERR_INVALID,
                  "bad shape m=%d L=%d M=%d n_obj=%d", c->m, c->L, c->M, c->n_obj);
-    SVGP_REQUIRE(c->m <= SVGP_M_MAX, SVGP_ERR_UNSUPPORTED,
-                 "m=%d inducing points: this build keeps the m x m stages LDS-resident and supports m <= %d",
-                 c->m, SVGP_M_MAX);
+    SVGP_REQUIRE(c->m <= SVGP_M_LIMIT, SVGP_ERR_UNSUPPORTED,
+                 "m=%d inducing points: this build supports m <= %d", c->m, SVGP_M_LIMIT);
     SVGP_REQUIRE(c->M <= 32, SVGP_ERR_UNSUPPORTED, "M=%d: object-vector dimension > 32 not supported", c->M);
     SVGP_REQUIRE(c->L <= 64, SVGP_ERR_UNSUPPORTED, "L=%d: more than 64 latent channels not supported", c->L);
     SVGP_REQUIRE(c->N_train > 0 && c->jitter >= 0, SVGP_ERR_INVALID, "bad N_train / jitter");
@@ -82,6 +81,9 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->statB_len = p - o->statB; take(0);
     o->Kbar = take(m * m); o->fb_part = take(2 * L * m * m); o->Qm = take(L * m * m); o->vbar = take(L * m);
     o->Ssym = take(L * m * m); o->Knbar_part = take(L * b * m);
+    // scratch of the large-m path (gp_large.hip)
+    o->scr_bm = take(L * b * m); o->scr_mm = take(4 * L * m * m); o->scr_vec = take(3 * L * m + 3 * L);
+    o->scr_inv = take(L * (1024 + 32 * m)); o->scr_bl = take(2 * b * L);
     o->Knbar = take(b * m); o->knnbar = take(b); o->ybar = take(b * L); o->s2bar = take(b * L);
     o->d_on = take(b * M);
     o->n_part = svgp_n_part(&cc);

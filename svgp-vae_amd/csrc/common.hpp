@@ -12,7 +12,8 @@ typedef double real;
 
 #define SVGP_BLOCK 256
 #define SVGP_MAX_PART 256      // max workgroups that write weight-gradient partials (= CUs)
-#define SVGP_M_MAX 64          // LDS-resident m x m stages (this build)
+#define SVGP_M_MAX 64          // up to here the m x m stages stay LDS-resident (gp_kernels.hip)
+#define SVGP_M_LIMIT 2048      // beyond SVGP_M_MAX: global-memory matrices + batched MFMA GEMMs (gp_large.hip)
 #define SVGP_LOG_2PI 1.8378770664093453
 
 void svgp_set_error(const char* fmt, ...);
@@ -44,11 +45,27 @@ static inline int svgp_n_part(const svgp_mnist_cfg* c) {
 }
 static inline int svgp_n_rowblk(const svgp_mnist_cfg* c) { return (c->b + 63) / 64; }
 // per-sample kernels: thread (row, i) with SVGP_BLOCK / m rows per workgroup
-static inline int svgp_rows_per_block(const svgp_mnist_cfg* c) { return SVGP_BLOCK / c->m; }
+static inline int svgp_rows_per_block(const svgp_mnist_cfg* c) { return c->m >= SVGP_BLOCK ? 1 : SVGP_BLOCK / c->m; }
 static inline int svgp_n_postblk(const svgp_mnist_cfg* c) {
     const int rb = svgp_rows_per_block(c);
     return (c->b + rb - 1) / rb;
 }
+
+// number of (L3, CE) partial pairs the per-sample forward writes for this configuration
+static inline int svgp_n_post_actual(const svgp_mnist_cfg* c) {
+    return c->m > SVGP_M_MAX ? (c->b * c->L + SVGP_BLOCK - 1) / SVGP_BLOCK : c->L * svgp_n_postblk(c);
+}
+
+// large-m implementations (gp_large.hip)
+int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state, int mode,
+                   void* stream);
+int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, void* stream);
+int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, const double* eps, double* ws,
+                           double* state, void* stream);
+int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
+                        void* stream);
+int svgp_big_posterior_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
+                           void* stream);
 
 // ---------------------------------------------------------------------------------------------
 // device helpers

@@ -376,10 +376,10 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_rows(KernArgs 
                                                                        real* __restrict__ part_gp) {
     extern __shared__ __align__(16) real smem[];
     __shared__ real red[16];
-    const int m = a.m, M = a.M, st = 2 + M, RB = blockDim.x / m;
+    const int m = a.m, M = a.M, st = 2 + M, RB = m >= (int)blockDim.x ? 1 : blockDim.x / m;
     real* O = smem;                 // m x M inducing object vectors, divided by their norm when normalising
     real* cbuf = O + m * M;         // RB x m
-    real* gbuf = cbuf + SVGP_BLOCK; // RB x M (<= 256*32/m ... bounded by RB*M <= 8192/m*... see host check)
+    real* gbuf = cbuf + RB * m;     // RB x M (<= 256*32/m ... bounded by RB*M <= 8192/m*... see host check)
     const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
     for (int o = threadIdx.x; o < m * M; o += blockDim.x) {
         const int j = o / M;
@@ -387,12 +387,12 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_rows(KernArgs 
         const real nj = a.normalize ? sqrt(dotM(oj, oj, M)) : real(1);
         O[o] = oj[o % M] / nj;
     }
-    {
-        const int nl = threadIdx.x / m, j = threadIdx.x % m, n = blockIdx.x * RB + nl;
+    for (int it = threadIdx.x; it < RB * m; it += blockDim.x) {
+        const int nl = it / m, j = it % m, n = blockIdx.x * RB + nl;
         real c = 0;
-        if (nl < RB && n < a.b)
+        if (n < a.b)
             c = Knbar[(size_t)n * m + j] * view_k(a.aux[(size_t)n * st + 1] - a.ip[(size_t)j * st + 1], a2, inv_l2);
-        if (nl < RB) cbuf[nl * m + j] = c;
+        cbuf[it] = c;
     }
     __syncthreads();
     for (int it = threadIdx.x; it < RB * M; it += blockDim.x) {
@@ -1116,8 +1116,8 @@ extern "C" int svgp_kernel_matrix_bwd(const svgp_mnist_cfg* c, const double* the
                        c->rep_weight, c->train_ip, ws + wl.K, ws + wl.Kn, ws + wl.Kbar, ws + wl.Knbar, grad + pl.ip,
                        ws + wl.part_gp);
     SVGP_LAUNCH_CHECK();
-    const int RBk = SVGP_BLOCK / c->m, nrb = (c->b + RBk - 1) / RBk;
-    const size_t lds_rows = (size_t)(c->m * c->M + SVGP_BLOCK + RBk * c->M) * sizeof(real);
+    const int RBk = svgp_rows_per_block(c), nrb = (c->b + RBk - 1) / RBk;
+    const size_t lds_rows = (size_t)(c->m * c->M + RBk * c->m + RBk * c->M) * sizeof(real);
     {
         int rc_ = set_dyn_lds(k_kernel_matrix_bwd_rows, lds_rows);
         if (rc_) return rc_;
@@ -1165,12 +1165,14 @@ static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
 extern "C" int svgp_gp_stats_fwd(const svgp_mnist_cfg* c, double* ws, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
+    if (c->m > SVGP_M_MAX) return svgp_big_stats(c, wl, ws, nullptr, 0, stream);
     return launch_stats(c, wl, ws, nullptr, 0, stream);
 }
 
 extern "C" int svgp_gp_stats_bwd(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    if (c->m > SVGP_M_MAX) return svgp_big_stats(c, wl, ws, state, 1, stream);
     return launch_stats(c, wl, ws, state, 1, stream);
 }
 
@@ -1179,6 +1181,7 @@ static inline int rows_per_block(int m) { return SVGP_BLOCK / m; }
 extern "C" int svgp_gp_factor_fwd(const svgp_mnist_cfg* c, double* ws, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
+    if (c->m > SVGP_M_MAX) return svgp_big_factor_fwd(c, wl, ws, stream);
     FactArgs a;
     a.b = c->b; a.m = c->m; a.L = c->L; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;
     { const char* e_ = getenv("SVGP_DBG_STOP"); a.dbg_stop = e_ ? atoi(e_) : 0; }
@@ -1198,6 +1201,7 @@ extern "C" int svgp_gp_posterior_fwd(const svgp_mnist_cfg* c, const double* eps,
                                      void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    if (c->m > SVGP_M_MAX) return svgp_big_posterior_fwd(c, wl, eps, ws, state, stream);
     PostArgs a;
     a.b = c->b; a.m = c->m; a.L = c->L; a.n_rowblk_unused = 0; a.c = c->N_train / (double)c->b_global;
     a.use_rng = eps == nullptr;
@@ -1231,6 +1235,7 @@ static FactBwdArgs make_fb(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
 extern "C" int svgp_gp_factor_bwd(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    if (c->m > SVGP_M_MAX) return svgp_big_factor_bwd(c, wl, ws, state, stream);
     FactBwdArgs a = make_fb(c, wl, ws, state);
     const int m = c->m;
     const size_t lds = mat_lds_pad(m, 4) + (size_t)(6 * m) * sizeof(real);
@@ -1247,6 +1252,7 @@ extern "C" int svgp_gp_factor_bwd(const svgp_mnist_cfg* c, double* ws, const dou
 extern "C" int svgp_gp_posterior_bwd(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    if (c->m > SVGP_M_MAX) return svgp_big_posterior_bwd(c, wl, ws, state, stream);
     PostBwdArgs a;
     a.b = c->b; a.m = c->m; a.L = c->L; a.geco = c->geco; a.c = c->N_train / (double)c->b_global; a.state = state;
     a.Kn = ws + wl.Kn; a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var; a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v;

@@ -1,0 +1,467 @@
+// Large-m (m > SVGP_M_MAX) implementation of the GP stages: the m x m matrices live in the workspace
+// (HBM / Infinity-Cache resident) and every contraction is a batched float64 MFMA GEMM
+// (linalg.hip); inverses are blocked Gauss-Jordan.  Same mathematics, same workspace fields and the
+// same exchange blocks (statA / statB) as the LDS-resident path in gp_kernels.hip, so the phases,
+// data parallelism and parity tests are unchanged.  Reference lines: SVGPVAE_model.py:220-343.
+#include "common.hpp"
+
+extern "C" int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
+                                  long long strideA, const double* B, int ldb, long long strideB, double beta,
+                                  double* C, int ldc, long long strideC, int batch, void* stream);
+extern "C" int svgp_spd_inverse_batched(int m, int batch, double* A, double* logdet, double* work, void* stream);
+
+namespace {
+
+__device__ __forceinline__ real gradKL(int geco, int L, const real* state) {
+    return geco ? real(-1) : -state[SVGP_ST_BETA] / (real)L;
+}
+
+// ---- element-wise / reduction kernels ---------------------------------------------------------
+// weights of the statistics.  mode 0: w = 1/s2, a = y/s2.  mode 1: g_pv, g_pm, mvbar (stored), b = c g_pm.
+__global__ void k_big_weights(int n_el, int L, int mode, int geco, real c, const real* __restrict__ state,
+                              const real* __restrict__ y, const real* __restrict__ s2,
+                              const real* __restrict__ p_m, const real* __restrict__ p_v,
+                              const real* __restrict__ e, const real* __restrict__ eps,
+                              const real* __restrict__ zbar, real* __restrict__ w, real* __restrict__ a,
+                              real* __restrict__ bv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_el) return;
+    const real p = recip_no_nan(s2[i]);
+    if (mode == 0) {
+        w[i] = p; a[i] = p * y[i];
+    } else {
+        const real gT = gradKL(geco, L, state), zb = zbar[i];
+        const real gpv = real(0.5) * gT * p + zb * eps[i] / (real(2) * sqrt(p_v[i]));
+        const real gpm = gT * p * (p_m[i] - y[i]) + zb;
+        w[i] = gpv; bv[i] = gpm; a[i] = gT * p * e[i];       // g_pv, g_pm, mvbar buffers
+    }
+}
+// W[l][n][j] = wt[n][l] * scale * Kn[n][j]
+__global__ void k_big_scale_rows(int b, int m, int L, real scale, const real* __restrict__ Kn,
+                                 const real* __restrict__ wt, real* __restrict__ W) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long tot = (long long)L * b * m;
+    if (i >= tot) return;
+    const int j = (int)(i % m), n = (int)((i / m) % b), l = (int)(i / ((long long)m * b));
+    W[i] = scale * wt[(size_t)n * L + l] * Kn[(size_t)n * m + j];
+}
+// out[l] = in (m x m, shared) + c * S[l] + jitter * I     (S may be NULL -> in + jitter I, batch 1)
+__global__ void k_big_add_diag(int m, int L, real c, real jitter, const real* __restrict__ in,
+                               const real* __restrict__ S, long long s_in, real* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long mm = (long long)m * m;
+    if (i >= mm * L) return;
+    const long long o = i % mm, l = i / mm;
+    const int r = (int)(o / m), cidx = (int)(o % m);
+    out[i] = in[l * s_in + o] + (S ? c * S[i] : real(0)) + (r == cidx ? jitter : real(0));
+}
+// out[n][l] (+)= scale * sum_j X[l][n][j] * Kn[n][j]; one wave per (n,l)
+__global__ __launch_bounds__(256) void k_big_rowdot(int b, int m, int L, real scale, const real* __restrict__ X,
+                                                    long long sX, const real* __restrict__ Kn,
+                                                    real* __restrict__ out, int ld_out, int col0) {
+    const long long wid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wid >= (long long)b * L) return;
+    const int n = (int)(wid / L), l = (int)(wid % L);
+    const real* x = X + (size_t)l * sX + (size_t)n * m;
+    const real* k = Kn + (size_t)n * m;
+    real s = 0;
+    for (int j = lane; j < m; j += 64) s += x[j] * k[j];
+    s = wave_sum(s);
+    if (lane == 0) out[(size_t)n * ld_out + col0 + l] = scale * s;
+}
+// tr(Ki A_l) and mu_l . u_l  -> trm (L,2)
+__global__ __launch_bounds__(256) void k_big_kl_terms(int m, const real* __restrict__ Ki, const real* __restrict__ A,
+                                                      const real* __restrict__ mu, const real* __restrict__ u,
+                                                      real* __restrict__ trm) {
+    __shared__ real red[16];
+    const int l = blockIdx.x;
+    const real* Al = A + (size_t)l * m * m;
+    real tr = 0, muu = 0;
+    for (int o = threadIdx.x; o < m * m; o += blockDim.x) tr += Ki[o] * Al[(size_t)(o % m) * m + o / m];
+    for (int i = threadIdx.x; i < m; i += blockDim.x) muu += mu[(size_t)l * m + i] * u[(size_t)l * m + i];
+    tr = block_sum(tr, red);
+    muu = block_sum(muu, red);
+    if (threadIdx.x == 0) { trm[l * 2] = tr; trm[l * 2 + 1] = muu; }
+}
+__global__ void k_big_kl(int m, int L, const real* __restrict__ ldK, const real* __restrict__ ldA,
+                         const real* __restrict__ trm, real* __restrict__ KL) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l < L) KL[l] = real(0.5) * (*ldK - ldA[l] - (real)m + trm[l * 2] + trm[l * 2 + 1]);
+}
+// final element-wise part of the per-sample forward + partial sums
+struct PostFinArgs {
+    int b, L, use_rng;
+    const real* knn; const real* q; const real* y; const real* s2; const real* eps_in; const real* state;
+    real* p_m; real* p_v; real* e; real* d; real* eps; real* z; real* part;
+};
+__device__ __forceinline__ real philox_normal_big(unsigned long long ctr, unsigned long long idx) {
+    unsigned int c0 = (unsigned int)idx, c1 = (unsigned int)(idx >> 32), c2 = (unsigned int)ctr,
+                 c3 = (unsigned int)(ctr >> 32);
+    unsigned int k0 = 0x5356u, k1 = 0x47505641u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned int)p1;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned int)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const real u1 = ((real)(((unsigned long long)c0 << 21) ^ (unsigned long long)(c1 >> 11)) + real(0.5)) *
+                    (real(1) / real(9007199254740992.0));
+    const real u2 = ((real)(((unsigned long long)c2 << 21) ^ (unsigned long long)(c3 >> 11)) + real(0.5)) *
+                    (real(1) / real(9007199254740992.0));
+    return sqrt(real(-2) * log(u1)) * cos(real(6.283185307179586) * u2);
+}
+// in: p_m = c k.t (done), p_v = r, e = mv, d = s  -> out: final values
+__global__ __launch_bounds__(256) void k_big_post_final(PostFinArgs a) {
+    __shared__ real red[16];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    real l3 = 0, ce = 0;
+    if (i < a.b * a.L) {
+        const int n = i / a.L;
+        const real y = a.y[i], s2 = a.s2[i], p = recip_no_nan(s2), kq = a.knn[n] - a.q[n];
+        const real p_m = a.p_m[i], p_v = kq + a.p_v[i], ee = y - a.e[i], dd = kq + a.d[i] + ee * ee;
+        const real ep = a.use_rng ? philox_normal_big((unsigned long long)a.state[SVGP_ST_RNG_CTR], (unsigned long long)i)
+                                  : a.eps_in[i];
+        a.eps[i] = ep; a.p_v[i] = p_v; a.e[i] = ee; a.d[i] = dd;
+        a.z[i] = p_m + ep * sqrt(p_v);
+        const real ls2 = log(s2), dm = p_m - y;
+        l3 = real(-0.5) * (p * dd + ls2);
+        ce = real(-0.5) * (real(SVGP_LOG_2PI) + ls2 + (p_v + dm * dm) * p);
+    }
+    l3 = block_sum(l3, red);
+    ce = block_sum(ce, red);
+    if (threadIdx.x == 0) { a.part[blockIdx.x * 2] = l3; a.part[blockIdx.x * 2 + 1] = ce; }
+}
+
+// ---- factor backward element-wise pieces (device scalars g3 = gT, gK) ----------------------------
+struct FbArgs {
+    int m, L, geco, b_global;
+    real c, N_train;
+    const real* state;
+    const real* Ki; const real* Aji; const real* A; const real* S; const real* A2; const real* M2;
+    const real* mu; const real* u; const real* ud; const real* td; const real* t; const real* v;
+    real* X1;   // in: Ki S Ki  -> out: Abar
+    real* T1A;  // S Ki A
+    real* Kib;  // out
+    real* ubar; real* mubar; real* tbar;   // (L,m) each; mubar/tbar come in holding Ki ubar / K mubar
+    real* Sibar; real* Kb; real* Sg; real* Ssym; real* Qm;
+};
+__device__ __forceinline__ void fb_scalars(const FbArgs& a, real& g3, real& gK) {
+    const real gT = gradKL(a.geco, a.L, a.state);
+    g3 = gT; gK = -gT * ((real)a.b_global / a.N_train);
+}
+__global__ void k_big_fb_abar(FbArgs a) {     // Abar, ubar
+    real g3, gK; fb_scalars(a, g3, gK);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)a.m * a.m;
+    if (i < mm * a.L) {
+        const long long o = i % mm;
+        a.X1[i] = real(-0.5) * g3 * a.X1[i] + real(0.5) * gK * (a.Ki[o] - a.Aji[i]);
+    }
+    if (i < (long long)a.L * a.m) a.ubar[i] = a.ud[i] + real(0.5) * gK * a.mu[i];
+}
+__global__ void k_big_fb_mubar(FbArgs a) {    // mubar = Ki ubar (in place) + gK/2 u
+    real g3, gK; fb_scalars(a, g3, gK);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.L * a.m) a.mubar[i] += real(0.5) * gK * a.u[i];
+}
+__global__ void k_big_fb_kibar(FbArgs a) {
+    real g3, gK; fb_scalars(a, g3, gK);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)a.m * a.m;
+    if (i >= mm * a.L) return;
+    const long long o = i % mm, l = i / mm;
+    const int r = (int)(o / a.m), cidx = (int)(o % a.m);
+    a.Kib[i] = -g3 * a.T1A[i] + real(0.5) * gK * a.A[i] + a.ubar[l * a.m + r] * a.mu[l * a.m + cidx] +
+               real(0.5) * g3 * a.S[i] - a.A2[i];
+}
+__global__ void k_big_fb_tbar(FbArgs a) {     // tbar = td + c (K mubar)  (tbar holds K mubar)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.L * a.m) a.tbar[i] = a.td[i] + a.c * a.tbar[i];
+}
+__global__ void k_big_fb_sibar(FbArgs a) {    // Sibar += A2 + tbar v^T ; Kb += c mubar t^T
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)a.m * a.m;
+    if (i >= mm * a.L) return;
+    const long long o = i % mm, l = i / mm;
+    const int r = (int)(o / a.m), cidx = (int)(o % a.m);
+    a.Sibar[i] += a.A2[i] + a.tbar[l * a.m + r] * a.v[l * a.m + cidx];
+    a.Kb[i] += a.c * a.mubar[l * a.m + r] * a.t[l * a.m + cidx];
+}
+__global__ void k_big_fb_ssym(FbArgs a) {     // Kb += Sg ; Ssym = c (Sg + Sg^T) ; Q = Ssym - g3 M2
+    real g3, gK; fb_scalars(a, g3, gK);
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)a.m * a.m;
+    if (i >= mm * a.L) return;
+    const long long o = i % mm, l = i / mm;
+    const int r = (int)(o / a.m), cidx = (int)(o % a.m);
+    const real sg = a.Sg[i], sgt = a.Sg[l * mm + (long long)cidx * a.m + r];
+    a.Kb[i] += sg;
+    const real ss = a.c * (sg + sgt);
+    a.Ssym[i] = ss;
+    a.Qm[i] = ss - g3 * a.M2[i];
+}
+__global__ void k_big_fb_final(int m, int L, int geco, int b_global, real N_train, const real* __restrict__ state,
+                               const real* __restrict__ Kb, const real* __restrict__ Ki, real* __restrict__ Kbar) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= m * m) return;
+    const real gT = gradKL(geco, L, state), gK = -gT * ((real)b_global / N_train);
+    real s = 0;
+    for (int l = 0; l < L; ++l) s += Kb[(size_t)l * m * m + o];
+    Kbar[o] = s + real(0.5) * gK * (real)L * Ki[o];
+}
+
+// ---- per-sample backward element-wise pieces ----------------------------------------------------
+struct PbArgs {
+    int b, m, L, geco;
+    real c;
+    const real* state;
+    const real* y; const real* s2; const real* p_m; const real* p_v; const real* e; const real* d;
+    const real* g_pv; const real* g_pm; const real* mvbar;
+    const real* u; const real* t; const real* vbar;
+    const real* R;      // (L,b,m) product with Kn rows (meaning depends on the pass)
+    const real* kSk; const real* kv;   // (b,L)
+    const real* KnKi;   // (b,m)
+    real* part;         // Knbar_part (L,b,m)
+    real* Knbar; real* knnbar; real* ybar; real* s2bar;
+};
+__global__ void k_big_pb_part1(PbArgs a) {    // part = 2 g_pv (Kn Si)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, bm = (long long)a.b * a.m;
+    if (i >= bm * a.L) return;
+    const int n = (int)((i % bm) / a.m), l = (int)(i / bm);
+    a.part[i] = real(2) * a.g_pv[(size_t)n * a.L + l] * a.R[i];
+}
+__global__ void k_big_pb_part2(PbArgs a) {    // part += p (Kn Q) + mvbar u + c g_pm t + p y vbar
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, bm = (long long)a.b * a.m;
+    if (i >= bm * a.L) return;
+    const int j = (int)(i % a.m), n = (int)((i % bm) / a.m), l = (int)(i / bm);
+    const size_t e = (size_t)n * a.L + l, vi = (size_t)l * a.m + j;
+    const real p = recip_no_nan(a.s2[e]);
+    a.part[i] += p * a.R[i] + a.mvbar[e] * a.u[vi] + a.c * a.g_pm[e] * a.t[vi] + p * a.y[e] * a.vbar[vi];
+}
+__global__ void k_big_pb_elem(PbArgs a) {     // ybar, s2bar
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.b * a.L) return;
+    const real gT = gradKL(a.geco, a.L, a.state), g3 = gT;
+    const real y = a.y[i], s2 = a.s2[i], p = recip_no_nan(s2), dm = a.p_m[i] - y, kV = a.kv[i];
+    const real pbar = real(-0.5) * g3 * a.d[i] + a.kSk[i] + y * kV;
+    a.ybar[i] = -gT * p * dm - g3 * p * a.e[i] + p * kV;
+    a.s2bar[i] = real(0.5) * gT * (p - (a.p_v[i] + dm * dm) * p * p) - real(0.5) * g3 * p - pbar * p * p;
+}
+__global__ void k_big_pb_sum(PbArgs a) {      // Knbar = sum_l part + 2 qbar (Kn Ki); knnbar = -qbar
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, bm = (long long)a.b * a.m;
+    if (i >= bm) return;
+    const int n = (int)(i / a.m);
+    const real gT = gradKL(a.geco, a.L, a.state);
+    real qbar = 0, acc = 0;
+    for (int l = 0; l < a.L; ++l) {
+        const size_t e = (size_t)n * a.L + l;
+        qbar += real(0.5) * gT * recip_no_nan(a.s2[e]) - a.g_pv[e];
+        acc += a.part[(size_t)l * bm + i];
+    }
+    a.Knbar[i] = acc + real(2) * qbar * a.KnKi[i];
+    if (i % a.m == 0) a.knnbar[n] = -qbar;
+}
+
+inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+#define RUNC(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
+#define GEMM(...) RUNC(svgp_dgemm_batched(__VA_ARGS__, stream))
+
+// scratch carving (layout fields scr_bm / scr_mm / scr_vec / scr_inv / scr_bl are allocated by api.hip)
+struct BigScr {
+    real *bm, *bm2, *mm0, *mm1, *mm2, *mm3, *vec0, *vec1, *vec2, *trm, *ldtmp, *inv, *bl0, *bl1;
+};
+static BigScr big_scr(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws) {
+    const size_t Lmm = (size_t)c->L * c->m * c->m, Lm = (size_t)c->L * c->m, bL = (size_t)c->b * c->L;
+    BigScr s;
+    s.bm = ws + wl.scr_bm; s.bm2 = ws + wl.Knbar_part;
+    s.mm0 = ws + wl.scr_mm; s.mm1 = s.mm0 + Lmm; s.mm2 = s.mm1 + Lmm; s.mm3 = s.mm2 + Lmm;
+    s.vec0 = ws + wl.scr_vec; s.vec1 = s.vec0 + Lm; s.vec2 = s.vec1 + Lm; s.trm = s.vec2 + Lm; s.ldtmp = s.trm + 2 * c->L;
+    s.inv = ws + wl.scr_inv;
+    s.bl0 = ws + wl.scr_bl; s.bl1 = s.bl0 + bL;
+    return s;
+}
+
+int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state, int mode,
+                   void* stream) {
+    const int b = c->b, m = c->m, L = c->L;
+    const real cc = c->N_train / (double)c->b_global;
+    const BigScr s = big_scr(c, wl, ws);
+    hipStream_t st = (hipStream_t)stream;
+    real* Kn = ws + wl.Kn;
+    // weights: forward uses (g_pv, g_pm) as temporaries for (p, p*y); backward fills g_pv, mvbar, g_pm
+    real* wbuf = ws + wl.g_pv;
+    real* abuf = mode == 0 ? ws + wl.g_pm : ws + wl.mvbar;
+    real* bbuf = ws + wl.g_pm;
+    hipLaunchKernelGGL(k_big_weights, dim3(nblk((long long)b * L)), dim3(256), 0, st, b * L, L, mode, c->geco, cc, state,
+                       ws + wl.qnet_mu, ws + wl.qnet_var, ws + wl.p_m, ws + wl.p_v, ws + wl.e, ws + wl.eps,
+                       ws + wl.zbar, wbuf, abuf, bbuf);
+    SVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_big_scale_rows, dim3(nblk((long long)L * b * m)), dim3(256), 0, st, b, m, L, real(1), Kn, wbuf,
+                       s.bm);
+    SVGP_LAUNCH_CHECK();
+    real* S = mode == 0 ? ws + wl.S : ws + wl.A2;
+    real* v1 = mode == 0 ? ws + wl.v : ws + wl.ud;
+    // S_l = Kn^T (w_l o Kn)
+    GEMM(1, 0, m, m, b, 1.0, Kn, m, 0, s.bm, m, (long long)b * m, 0.0, S, m, (long long)m * m, L);
+    // v1 (L x m) = a^T Kn
+    GEMM(1, 0, L, m, b, 1.0, abuf, L, 0, Kn, m, 0, 0.0, v1, m, 0, 1);
+    if (mode == 1) GEMM(1, 0, L, m, b, cc, bbuf, L, 0, Kn, m, 0, 0.0, ws + wl.td, m, 0, 1);
+    if (mode == 0) {   // K_mm inverse + log det (SVGPVAE_model.py:239,270,273)
+        hipLaunchKernelGGL(k_big_add_diag, dim3(nblk((long long)m * m)), dim3(256), 0, st, m, 1, real(0), c->jitter,
+                           ws + wl.K, (const real*)nullptr, 0LL, ws + wl.Ki);
+        SVGP_LAUNCH_CHECK();
+        RUNC(svgp_spd_inverse_batched(m, 1, ws + wl.Ki, ws + wl.ldK, s.inv, stream));
+    }
+    return SVGP_OK;
+}
+
+int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, void* stream) {
+    const int b = c->b, m = c->m, L = c->L;
+    const long long mm = (long long)m * m;
+    const real cc = c->N_train / (double)c->b_global;
+    const BigScr s = big_scr(c, wl, ws);
+    hipStream_t st = (hipStream_t)stream;
+    real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si, *G = ws + wl.G, *A = ws + wl.A, *Aji = ws + wl.Aji;
+    real *t = ws + wl.t, *mu = ws + wl.mu_hat, *u = ws + wl.u, *v = ws + wl.v, *M2 = ws + wl.M2, *Kn = ws + wl.Kn;
+    hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, cc, c->jitter, K, ws + wl.S, 0LL, Si);
+    SVGP_LAUNCH_CHECK();
+    RUNC(svgp_spd_inverse_batched(m, L, Si, s.ldtmp, s.inv, stream));
+    GEMM(0, 0, m, 1, m, 1.0, Si, m, mm, v, 1, (long long)m, 0.0, t, 1, (long long)m, L);          // t = Si v
+    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, K, m, 0, 0.0, G, m, mm, L);                              // G = Si K
+    GEMM(0, 0, m, m, m, 1.0, K, m, 0, G, m, mm, 0.0, A, m, mm, L);                               // A = K G
+    GEMM(0, 0, m, 1, m, cc, K, m, 0, t, 1, (long long)m, 0.0, mu, 1, (long long)m, L);            // mu = c K t
+    GEMM(0, 0, m, 1, m, 1.0, Ki, m, 0, mu, 1, (long long)m, 0.0, u, 1, (long long)m, L);          // u = Ki mu
+    GEMM(0, 0, m, m, m, 1.0, A, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);                          // T = A Ki
+    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, M2, m, mm, L);                         // M2 = Ki A Ki
+    hipLaunchKernelGGL(k_big_kl_terms, dim3(L), dim3(256), 0, st, m, Ki, A, mu, u, s.trm);
+    SVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, real(0), c->jitter, A,
+                       (const real*)nullptr, mm, Aji);
+    SVGP_LAUNCH_CHECK();
+    RUNC(svgp_spd_inverse_batched(m, L, Aji, s.ldtmp, s.inv, stream));
+    hipLaunchKernelGGL(k_big_kl, dim3(nblk(L)), dim3(256), 0, st, m, L, ws + wl.ldK, s.ldtmp, s.trm, ws + wl.KL);
+    SVGP_LAUNCH_CHECK();
+    // q_n = k_n^T Ki k_n
+    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, Ki, m, 0, 0.0, s.bm, m, 0, 1);
+    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * 64)), dim3(256), 0, st, b, m, 1, real(1), s.bm, 0LL, Kn,
+                       ws + wl.q, 1, 0);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, const double* eps, double* ws,
+                           double* state, void* stream) {
+    const int b = c->b, m = c->m, L = c->L;
+    const long long mm = (long long)m * m, bm = (long long)b * m;
+    const real cc = c->N_train / (double)c->b_global;
+    const BigScr s = big_scr(c, wl, ws);
+    hipStream_t st = (hipStream_t)stream;
+    real* Kn = ws + wl.Kn;
+    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, ws + wl.Si, m, mm, 0.0, s.bm, m, bm, L);                  // Kn Si_l
+    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.bm, bm, Kn,
+                       ws + wl.p_v, L, 0);                                                      // r -> p_v slot
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, ws + wl.M2, m, mm, 0.0, s.bm, m, bm, L);                  // Kn M2_l
+    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.bm, bm, Kn,
+                       ws + wl.d, L, 0);                                                        // s -> d slot
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 1, b, L, m, cc, Kn, m, 0, ws + wl.t, m, 0, 0.0, ws + wl.p_m, L, 0, 1);               // p_m = c Kn t^T
+    GEMM(0, 1, b, L, m, 1.0, Kn, m, 0, ws + wl.u, m, 0, 0.0, ws + wl.e, L, 0, 1);                // mv -> e slot
+    PostFinArgs a;
+    a.b = b; a.L = L; a.use_rng = eps == nullptr;
+    a.knn = ws + wl.knn; a.q = ws + wl.q; a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var; a.eps_in = eps; a.state = state;
+    a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v; a.e = ws + wl.e; a.d = ws + wl.d; a.eps = ws + wl.eps; a.z = ws + wl.z;
+    a.part = ws + wl.part_sums + (size_t)svgp_n_part(c) * 4;
+    const unsigned nb = nblk((long long)b * L);
+    SVGP_REQUIRE((long long)nb <= wl.n_post, SVGP_ERR_INVALID, "partial-sum layout too small");
+    hipLaunchKernelGGL(k_big_post_final, dim3(nb), dim3(256), 0, st, a);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
+                        void* stream) {
+    const int m = c->m, L = c->L;
+    const long long mm = (long long)m * m, lm = (long long)m;
+    const real cc = c->N_train / (double)c->b_global;
+    const BigScr s = big_scr(c, wl, ws);
+    hipStream_t st = (hipStream_t)stream;
+    real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si, *G = ws + wl.G, *A = ws + wl.A, *S = ws + wl.S;
+    real* Kb = ws + wl.fb_part;
+    real* Kib = Kb + (size_t)L * mm;
+    FbArgs a;
+    a.m = m; a.L = L; a.geco = c->geco; a.b_global = c->b_global; a.c = cc; a.N_train = c->N_train; a.state = state;
+    a.Ki = Ki; a.Aji = ws + wl.Aji; a.A = A; a.S = S; a.A2 = ws + wl.A2; a.M2 = ws + wl.M2; a.mu = ws + wl.mu_hat;
+    a.u = ws + wl.u; a.ud = ws + wl.ud; a.td = ws + wl.td; a.t = ws + wl.t; a.v = ws + wl.v;
+    a.X1 = s.mm1; a.T1A = s.mm2; a.Kib = Kib; a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2;
+    a.Sibar = s.mm3; a.Kb = Kb; a.Sg = s.mm1; a.Ssym = ws + wl.Ssym; a.Qm = ws + wl.Qm;
+    const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m);
+    GEMM(0, 0, m, m, m, 1.0, S, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);            // T1 = S Ki
+    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, s.mm1, m, mm, L);        // Ki S Ki
+    hipLaunchKernelGGL(k_big_fb_abar, dim3(gmm), dim3(256), 0, st, a);             // Abar (mm1), ubar
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 0, m, 1, m, 1.0, Ki, m, 0, s.vec0, 1, lm, 0.0, s.vec1, 1, lm, L);      // Ki ubar
+    hipLaunchKernelGGL(k_big_fb_mubar, dim3(gv), dim3(256), 0, st, a);
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 0, m, m, m, 1.0, s.mm0, m, mm, A, m, mm, 0.0, s.mm2, m, mm, L);        // T1 A
+    hipLaunchKernelGGL(k_big_fb_kibar, dim3(gmm), dim3(256), 0, st, a);            // Kib
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 0, m, m, m, 1.0, K, m, 0, s.mm1, m, mm, 0.0, s.mm2, m, mm, L);         // Gbar = K Abar   (mm2)
+    GEMM(0, 1, m, m, m, 1.0, s.mm1, m, mm, G, m, mm, 0.0, Kb, m, mm, L);           // Kb = Abar G^T
+    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm2, m, mm, 1.0, Kb, m, mm, L);          // Kb += Si Gbar
+    GEMM(0, 0, m, 1, m, 1.0, K, m, 0, s.vec1, 1, lm, 0.0, s.vec2, 1, lm, L);       // K mubar
+    hipLaunchKernelGGL(k_big_fb_tbar, dim3(gv), dim3(256), 0, st, a);
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 0, m, m, m, 1.0, s.mm2, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);         // Gbar K  (mm3)
+    hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);            // Sibar, Kb += c mubar t^T
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 0, m, 1, m, 1.0, Si, m, mm, s.vec2, 1, lm, 0.0, ws + wl.vbar, 1, lm, L);   // vbar = Si tbar
+    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm3, m, mm, 0.0, s.mm0, m, mm, L);       // Si Sibar (mm0)
+    GEMM(0, 0, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);      // Sg = -Si Sibar Si (mm1)
+    hipLaunchKernelGGL(k_big_fb_ssym, dim3(gmm), dim3(256), 0, st, a);
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, Kib, m, mm, 0.0, s.mm0, m, mm, L);          // Ki Kib
+    GEMM(0, 0, m, m, m, -1.0, s.mm0, m, mm, Ki, m, 0, 1.0, Kb, m, mm, L);          // Kb -= Ki Kib Ki
+    hipLaunchKernelGGL(k_big_fb_final, dim3(nblk(mm)), dim3(256), 0, st, m, L, c->geco, c->b_global, c->N_train, state, Kb,
+                       Ki, ws + wl.Kbar);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+int svgp_big_posterior_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
+                           void* stream) {
+    const int b = c->b, m = c->m, L = c->L;
+    const long long mm = (long long)m * m, bm = (long long)b * m;
+    const real cc = c->N_train / (double)c->b_global;
+    const BigScr s = big_scr(c, wl, ws);
+    hipStream_t st = (hipStream_t)stream;
+    real* Kn = ws + wl.Kn;
+    PbArgs a;
+    a.b = b; a.m = m; a.L = L; a.geco = c->geco; a.c = cc; a.state = state;
+    a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var; a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v; a.e = ws + wl.e;
+    a.d = ws + wl.d; a.g_pv = ws + wl.g_pv; a.g_pm = ws + wl.g_pm; a.mvbar = ws + wl.mvbar;
+    a.u = ws + wl.u; a.t = ws + wl.t; a.vbar = ws + wl.vbar; a.R = s.bm; a.kSk = s.bl0; a.kv = s.bl1; a.KnKi = s.bm;
+    a.part = ws + wl.Knbar_part; a.Knbar = ws + wl.Knbar; a.knnbar = ws + wl.knnbar; a.ybar = ws + wl.ybar;
+    a.s2bar = ws + wl.s2bar;
+    const unsigned gbm = nblk(bm * L);
+    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, ws + wl.Si, m, mm, 0.0, s.bm, m, bm, L);
+    hipLaunchKernelGGL(k_big_pb_part1, dim3(gbm), dim3(256), 0, st, a);
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, ws + wl.Qm, m, mm, 0.0, s.bm, m, bm, L);
+    hipLaunchKernelGGL(k_big_pb_part2, dim3(gbm), dim3(256), 0, st, a);
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, ws + wl.Ssym, m, mm, 0.0, s.bm, m, bm, L);
+    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(0.5), s.bm, bm, Kn,
+                       s.bl0, L, 0);
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 1, b, L, m, 1.0, Kn, m, 0, ws + wl.vbar, m, 0, 0.0, s.bl1, L, 0, 1);   // kv = Kn vbar^T
+    hipLaunchKernelGGL(k_big_pb_elem, dim3(nblk((long long)b * L)), dim3(256), 0, st, a);
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, ws + wl.Ki, m, 0, 0.0, s.bm, m, 0, 1);       // Kn Ki
+    hipLaunchKernelGGL(k_big_pb_sum, dim3(nblk(bm)), dim3(256), 0, st, a);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}

@@ -756,7 +756,7 @@ extern "C" int svgp_mnist_grad_reduce(const svgp_mnist_cfg* c, double* ws, void*
     const int n_enc = (int)pl.n_enc, n_dec = (int)(pl.n_vae - pl.n_enc);
     const int nb_enc = (n_enc + 15) / 16, nb_dec = (n_dec + 15) / 16;
     hipLaunchKernelGGL(k_grad_reduce, dim3(nb_enc + nb_dec + 1), dim3(SVGP_BLOCK), 0, (hipStream_t)stream, n_part, n_enc,
-                       n_dec, nb_enc, nb_dec, c->L * svgp_n_postblk(c), c->b, ws + wl.part_enc, ws + wl.part_dec,
+                       n_dec, nb_enc, nb_dec, svgp_n_post_actual(c), c->b, ws + wl.part_enc, ws + wl.part_dec,
                        ws + wl.part_sums, ws + wl.grad, ws + wl.sums);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;

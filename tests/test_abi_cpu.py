@@ -50,8 +50,8 @@ def test_layouts_match_reference_parameter_count_and_are_disjoint():
 
 
 def test_bad_shapes_are_rejected_with_a_message():
-    cfg = _lib.MnistCfg(b=256, b_global=256, m=256, L=16, M=8, n_obj=400, N_train=4050.0, jitter=1e-6)
-    with pytest.raises(svgp_vae_amd.SvgpError, match="m <= 64"):
+    cfg = _lib.MnistCfg(b=256, b_global=256, m=4096, L=16, M=8, n_obj=400, N_train=4050.0, jitter=1e-6)
+    with pytest.raises(svgp_vae_amd.SvgpError, match="m <= 2048"):
         _lib.call("svgp_mnist_ws_layout_get", C.byref(cfg), C.byref(_lib.WsLayout()))
     cfg = _lib.MnistCfg(b=0, b_global=0, m=8, L=1, M=1, n_obj=0, N_train=1.0)
     with pytest.raises(svgp_vae_amd.SvgpError, match="b_global"):

@@ -15,8 +15,10 @@ Mirrored names (reference file:line):
 Additional (no reference counterpart - TF's tf.gradients + AdamOptimizer live in the driver):
   gradients_SVGPVAE(...) and train_step_SVGPVAE(...).
 
-Not implemented in this build (raise NotImplementedError): the Titsias branch (titsias=True), test
-points different from train points in approximate_posterior_params (conditional generation), SPRITES.
+  bacthing_predict_SVGPVAE_rotated_mnist(test_data_batch, vae, svgp, qnet_mu, qnet_var, aux_data_train)  :1026-1083
+Not implemented in this build (raise NotImplementedError): the Titsias branch (titsias=True), the
+single-channel approximate_posterior_params with test != train points (the batched conditional-generation
+function above covers that use), SPRITES.
 """
 import math
 

@@ -209,6 +209,33 @@ int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double alpha, const 
 size_t svgp_spd_inverse_workspace_elems(int m, int batch);
 int svgp_spd_inverse_batched(int m, int batch, double* A, double* logdet, double* work, void* stream);
 
+/* ---- generic NHWC float64 convolution as a tap-table gather-GEMM on the f64 MFMA (conv_taps.hip) ---------
+ * out[n][y*osy+ooy][x*osx+oox][co] = act(bias[co] + sum_t sum_ci in[n][y*sy+oy_t][x*sx+ox_t][ci] W_t[ci][co]),
+ * (y,x) in Hs x Ws, reads outside the input are zero; W_t = w + woff[t] is a (Ci x Co) row-major matrix.
+ * One descriptor = one class; classes of a launch share n, Hs, Ws.  With suitable tables: Keras Conv2D
+ * 3x3/2x2, stride 1/2, same/valid; UpSampling2D(2)+Conv2D as four parity classes on effective weights; all
+ * data gradients.  Replaces the Keras layers of spritesVAE / sprites_representation_network
+ * (VAE_utils.py:294-338,375-391).  act: 0 none, 1 bias + ELU, 2 bias only.                             */
+typedef struct {
+    int32_t n, Hi, Wi, Ci;      /* input tensor (n,Hi,Wi,Ci)                                  */
+    int32_t Ho, Wo, Co;         /* output tensor (n,Ho,Wo,Co)                                 */
+    int32_t Hs, Ws;             /* iteration space of this class                              */
+    int32_t sy, sx;             /* input stride per iteration step                            */
+    int32_t osy, osx, ooy, oox; /* output placement                                           */
+    int32_t nt, act;            /* taps (1..16), activation                                   */
+    int32_t oy[16], ox[16], woff[16];
+} svgp_conv_desc;
+int svgp_conv_taps_fwd(const svgp_conv_desc* d, int ncls, const double* in, const double* w, const double* bias,
+                       double* out, void* stream);
+/* dW_t[ci][co] = sum_{n,y,x} in[...] * dout[...] for the same tap tables; part: (ncls*nwg, part_stride) scratch;
+ * dw (part_stride values, laid out by woff) = fixed-order sum (accumulate != 0 adds to dw).               */
+int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const double* in, const double* dout, double* part,
+                         int nwg, int part_stride, double* dw, int accumulate, void* stream);
+/* dpre = dout * elu'(out) in place on dout (out == NULL: no activation) and db[c] = sum over pixels of dpre;
+ * part: (256, C) scratch.                                                                                   */
+int svgp_elu_bwd_bias(long long npix, int C, const double* out, double* dout, double* part, double* db,
+                      void* stream);
+
 /* ---- runtime helpers: HIP graphs and events without going through torch ---------------------*/
 int svgp_stream_create(void** stream_out);
 int svgp_stream_destroy(void* stream);

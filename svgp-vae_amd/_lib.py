@@ -46,6 +46,12 @@ class WsLayout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in WS_FIELDS]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n", "Hi", "Wi", "Ci", "Ho", "Wo", "Co", "Hs", "Ws", "sy", "sx", "osy", "osx",
+                                         "ooy", "oox", "nt", "act")] + \
+               [("oy", C.c_int32 * 16), ("ox", C.c_int32 * 16), ("woff", C.c_int32 * 16)]
+
+
 STATE = dict(C_MA=0, LAGRANGE=1, ALPHA=2, ADAM_T=3, LR=4, BETA=5, ELBO=6, RECON_LOSS=7, KL_TERM=8,
              INSIDE_ELBO=9, CE_TERM=10, INSIDE_RECON=11, INSIDE_KL=12, RNG_CTR=13)
 STATE_LEN = 16
@@ -78,6 +84,9 @@ SIGNATURES = {
     "svgp_dgemm_batched": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.c_int, C.c_longlong, _P,
                            C.c_int, C.c_longlong, C.c_double, _P, C.c_int, C.c_longlong, C.c_int, _P],
     "svgp_spd_inverse_batched": [C.c_int, C.c_int, _P, _P, _P, _P],
+    "svgp_conv_taps_fwd": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P],
+    "svgp_conv_taps_wgrad": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P],
+    "svgp_elu_bwd_bias": [C.c_longlong, C.c_int, _P, _P, _P, _P, _P],
     "svgp_stream_create": [C.POINTER(_P)],
     "svgp_stream_destroy": [_P],
     "svgp_stream_sync": [_P],

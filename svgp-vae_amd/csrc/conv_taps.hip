@@ -1,0 +1,304 @@
+// Generic NHWC float64 convolution as a "tap-table" gather-GEMM on the f64 MFMA (gfx950):
+//
+//   out[n][y*osy+ooy][x*osx+oox][co] = act( bias[co] + sum_t sum_ci in[n][y*sy+oy_t][x*sx+ox_t][ci] * W_t[ci][co] )
+//
+// for (y,x) in an Hs x Ws iteration space; reads outside the input are zero.  One descriptor = one
+// "class"; up to 4 classes per launch (blockIdx.z = image * ncls + class).  With suitable tap tables this
+// one kernel is: Conv2D 3x3 / 2x2, stride 1 / 2, 'same' / 'valid' (Keras padding) forward; UpSampling2D(2)+
+// Conv2D as four parity classes with pre-summed effective weights (2.25x fewer MACs); and every data
+// gradient (transposed weights; parity classes for stride 2).  `svgp_conv_taps_wgrad` is the matching weight
+// gradient: dW_t[ci][co] = sum_{n,y,x} in[...][ci] * dout[...][co].
+// Reference layers: spritesVAE / sprites_representation_network (VAE_utils.py:275-391).
+//
+// Mapping: a wave owns one 16-pixel row segment; A[i=pixel][k=ci] from an LDS halo tile (pixel stride
+// Ci4+2 doubles -> conflict-free 16-pixel fetch), B[k=ci][j=co] from LDS weights, one
+// v_mfma_f64_16x16x4 per (tap, 4 input channels).  Workgroup = 4 waves = 16 x 8 output pixels.
+#include "common.hpp"
+
+typedef double d4c_t __attribute__((ext_vector_type(4)));
+
+#define CT_TW 16      // tile width  (pixels per MFMA row segment)
+#define CT_TH 8       // tile height (2 rows per wave)
+#define CT_MAXT 16
+
+struct ConvLaunch {
+    int ncls;
+    svgp_conv_desc d[4];
+};
+
+namespace {
+
+__device__ __forceinline__ void tap_range(const svgp_conv_desc& d, int& omin_y, int& omax_y, int& omin_x, int& omax_x) {
+    omin_y = omax_y = d.oy[0]; omin_x = omax_x = d.ox[0];
+    for (int t = 1; t < d.nt; ++t) {
+        omin_y = min(omin_y, d.oy[t]); omax_y = max(omax_y, d.oy[t]);
+        omin_x = min(omin_x, d.ox[t]); omax_x = max(omax_x, d.ox[t]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_conv_taps_fwd(ConvLaunch L, const real* __restrict__ in,
+                                                       const real* __restrict__ w, const real* __restrict__ bias,
+                                                       real* __restrict__ out) {
+    extern __shared__ __align__(16) real smem[];
+    const int cls = blockIdx.z % L.ncls, n = blockIdx.z / L.ncls;
+    const svgp_conv_desc& d = L.d[cls];
+    const int tiles_x = (d.Ws + CT_TW - 1) / CT_TW;
+    const int x0 = (blockIdx.x % tiles_x) * CT_TW, y0 = (blockIdx.x / tiles_x) * CT_TH;
+    if (y0 >= d.Hs) return;
+    const int Ci4 = (d.Ci + 3) & ~3, ps = Ci4 + 2;         // channels padded to 4, pixel stride
+    int oy0, oy1, ox0, ox1;
+    tap_range(d, oy0, oy1, ox0, ox1);
+    const int hy0 = y0 * d.sy + oy0, hx0 = x0 * d.sx + ox0;
+    const int hh = (CT_TH - 1) * d.sy + (oy1 - oy0) + 1, hw = (CT_TW - 1) * d.sx + (ox1 - ox0) + 1;
+    real* tile = smem;                                     // hh x hw x ps
+    real* wl = tile + hh * hw * ps;                        // nt x Ci4 x 16 (co padded to 16)
+    const real* inn = in + (size_t)n * d.Hi * d.Wi * d.Ci;
+    for (int t = threadIdx.x; t < hh * hw * Ci4; t += blockDim.x) {
+        const int c = t % Ci4, px = (t / Ci4) % hw, py = t / (Ci4 * hw);
+        const int gy = hy0 + py, gx = hx0 + px;
+        real v = 0;
+        if (c < d.Ci && (unsigned)gy < (unsigned)d.Hi && (unsigned)gx < (unsigned)d.Wi)
+            v = inn[((size_t)gy * d.Wi + gx) * d.Ci + c];
+        tile[(py * hw + px) * ps + c] = v;
+    }
+    for (int t = threadIdx.x; t < d.nt * Ci4 * 16; t += blockDim.x) {
+        const int co = t & 15, c = (t >> 4) % Ci4, tp = t / (16 * Ci4);
+        wl[t] = (c < d.Ci && co < d.Co) ? w[d.woff[tp] + c * d.Co + co] : real(0);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+#pragma unroll 1
+    for (int rr = 0; rr < 2; ++rr) {
+        const int ly = wave * 2 + rr, y = y0 + ly;
+        if (y >= d.Hs) continue;
+        d4c_t acc = {0, 0, 0, 0};
+        for (int tp = 0; tp < d.nt; ++tp) {
+            const real* ap = tile + ((ly * d.sy + d.oy[tp] - oy0) * hw + (r * d.sx + d.ox[tp] - ox0)) * ps + q;
+            const real* bp = wl + (tp * Ci4 + q) * 16 + r;
+            for (int c0 = 0; c0 < Ci4; c0 += 4)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[c0], bp[c0 * 16], acc, 0, 0, 0);
+        }
+        // D: column (co) = lane & 15, row (pixel) = q + 4 g
+        const int gy = y * d.osy + d.ooy;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int x = x0 + q + 4 * g;
+            if (x < d.Ws && r < d.Co) {
+                real v = acc[g];
+                if (d.act) v += bias[r];
+                if (d.act == 1) v = v > 0 ? v : exp(v) - real(1);
+                out[(((size_t)n * d.Ho + gy) * d.Wo + (x * d.osx + d.oox)) * d.Co + r] = v;
+            }
+        }
+    }
+}
+
+// Weight gradient.  grid (nwg, ncls): workgroup g of a class walks tiles g, g+nwg, ... of ALL images and
+// keeps dW_t (Ci4 x 16 per tap) in MFMA accumulators: A[i=ci][k=pixel] = in, B[k=pixel][j=co] = dout,
+// k-steps of 4 consecutive pixels of a row segment.  Partials: part[(cls*nwg + g)][t][ci][co] (Ci x Co).
+__global__ __launch_bounds__(256) void k_conv_taps_wgrad(ConvLaunch L, int nwg, const real* __restrict__ in,
+                                                         const real* __restrict__ dout, real* __restrict__ part,
+                                                         int part_stride) {
+    extern __shared__ __align__(16) real smem[];
+    const int cls = blockIdx.y;
+    const svgp_conv_desc& d = L.d[cls];
+    const int tiles_x = (d.Ws + CT_TW - 1) / CT_TW, tiles_y = (d.Hs + CT_TH - 1) / CT_TH;
+    const int ntile = tiles_x * tiles_y * d.n;
+    const int Ci4 = (d.Ci + 3) & ~3, ps = Ci4 + 2;
+    int oy0, oy1, ox0, ox1;
+    tap_range(d, oy0, oy1, ox0, ox1);
+    const int hh = (CT_TH - 1) * d.sy + (oy1 - oy0) + 1, hw = (CT_TW - 1) * d.sx + (ox1 - ox0) + 1;
+    real* tile = smem;                          // hh x hw x ps      (input halo)
+    real* dt = tile + hh * hw * ps;             // CT_TH x CT_TW x 18 (dout tile, co padded to 16)
+    real* red = dt + CT_TH * CT_TW * 18;        // 4 waves x 64 lanes x 4  (cross-wave combine)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    // accumulators: per tap one 16x16 tile (rows ci, cols co); Ci4 <= 16.  Taps are split over the 4 waves.
+    d4c_t acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) acc[a] = d4c_t{0, 0, 0, 0};
+    for (int tl = blockIdx.x; tl < ntile; tl += nwg) {
+        const int n = tl / (tiles_x * tiles_y), tt = tl % (tiles_x * tiles_y);
+        const int x0 = (tt % tiles_x) * CT_TW, y0 = (tt / tiles_x) * CT_TH;
+        const int hy0 = y0 * d.sy + oy0, hx0 = x0 * d.sx + ox0;
+        const real* inn = in + (size_t)n * d.Hi * d.Wi * d.Ci;
+        __syncthreads();
+        for (int t = threadIdx.x; t < hh * hw * Ci4; t += blockDim.x) {
+            const int c = t % Ci4, px = (t / Ci4) % hw, py = t / (Ci4 * hw);
+            const int gy = hy0 + py, gx = hx0 + px;
+            real v = 0;
+            if (c < d.Ci && (unsigned)gy < (unsigned)d.Hi && (unsigned)gx < (unsigned)d.Wi)
+                v = inn[((size_t)gy * d.Wi + gx) * d.Ci + c];
+            tile[(py * hw + px) * ps + c] = v;
+        }
+        for (int t = threadIdx.x; t < CT_TH * CT_TW * 16; t += blockDim.x) {
+            const int co = t & 15, px = (t >> 4) % CT_TW, py = t / (16 * CT_TW);
+            const int y = y0 + py, x = x0 + px;
+            real v = 0;
+            if (co < d.Co && y < d.Hs && x < d.Ws)
+                v = dout[(((size_t)n * d.Ho + (y * d.osy + d.ooy)) * d.Wo + (x * d.osx + d.oox)) * d.Co + co];
+            dt[(py * CT_TW + px) * 18 + co] = v;
+        }
+        __syncthreads();
+        // wave w handles taps w, w+4, w+8, w+12 (acc[a] <-> tap w + 4a)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int tp = wave + 4 * a;
+            if (tp < d.nt) {
+                for (int py = 0; py < CT_TH; ++py) {
+                    const real* ap = tile + ((py * d.sy + d.oy[tp] - oy0) * hw + (d.ox[tp] - ox0)) * ps + r;  // ci = r
+                    const real* bp = dt + (py * CT_TW) * 18 + r;                                              // co = r
+#pragma unroll
+                    for (int px0 = 0; px0 < CT_TW; px0 += 4) {
+                        const real av = (r < Ci4) ? ap[((px0 + q) * d.sx) * ps] : real(0);
+                        const real bv = bp[(px0 + q) * 18];
+                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[a], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    (void)red;
+    // D: col (co) = r, row (ci) = q + 4 g
+    real* po = part + ((size_t)cls * nwg + blockIdx.x) * part_stride;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int tp = wave + 4 * a;
+        if (tp < d.nt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ci = q + 4 * g;
+                if (ci < d.Ci && r < d.Co) po[d.woff[tp] + ci * d.Co + r] = acc[a][g];
+            }
+        }
+    }
+}
+
+// out[i] (+)= sum_g part[g][i]   (fixed order)
+__global__ void k_sum_partials(int ng, int len, int stride, const real* __restrict__ part, real* __restrict__ out,
+                               int accumulate) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    real s = accumulate ? out[i] : real(0);
+#pragma unroll 4
+    for (int g = 0; g < ng; ++g) s += part[(size_t)g * stride + i];
+    out[i] = s;
+}
+
+// dpre = dout * elu'(out) in place on dout; also per-block column sums for the bias gradient
+__global__ __launch_bounds__(256) void k_elu_bwd_colsum(long long npix, int C, const real* __restrict__ outv,
+                                                        real* __restrict__ dout, real* __restrict__ part) {
+    __shared__ real sh[256];
+    // thread t handles channel t % C of pixels t / C + k * (256 / C)   (C <= 16 divides into 256 evenly enough)
+    const int c = threadIdx.x % C, lp = threadIdx.x / C, ppb = blockDim.x / C;
+    real s = 0;
+    if (lp < ppb) {
+        for (long long p = (long long)blockIdx.x * ppb + lp; p < npix; p += (long long)gridDim.x * ppb) {
+            const size_t o = (size_t)p * C + c;
+            real dv = dout[o];
+            if (outv) { const real ov = outv[o]; dv *= (ov > 0 ? real(1) : ov + real(1)); dout[o] = dv; }
+            s += dv;
+        }
+    }
+    sh[threadIdx.x] = (lp < ppb) ? s : real(0);
+    __syncthreads();
+    if (threadIdx.x < C) {
+        real t = 0;
+        for (int k = 0; k < ppb; ++k) t += sh[k * C + threadIdx.x];
+        part[blockIdx.x * C + threadIdx.x] = t;
+    }
+}
+
+size_t fwd_lds(const svgp_conv_desc& d) {
+    int oy0 = d.oy[0], oy1 = d.oy[0], ox0 = d.ox[0], ox1 = d.ox[0];
+    for (int t = 1; t < d.nt; ++t) {
+        oy0 = oy0 < d.oy[t] ? oy0 : d.oy[t]; oy1 = oy1 > d.oy[t] ? oy1 : d.oy[t];
+        ox0 = ox0 < d.ox[t] ? ox0 : d.ox[t]; ox1 = ox1 > d.ox[t] ? ox1 : d.ox[t];
+    }
+    const int Ci4 = (d.Ci + 3) & ~3, ps = Ci4 + 2;
+    const int hh = (CT_TH - 1) * d.sy + (oy1 - oy0) + 1, hw = (CT_TW - 1) * d.sx + (ox1 - ox0) + 1;
+    return (size_t)hh * hw * ps;
+}
+
+int check_desc(const svgp_conv_desc* d, int ncls) {
+    SVGP_REQUIRE(d && ncls >= 1 && ncls <= 4, SVGP_ERR_INVALID, "need 1..4 conv classes");
+    for (int c = 0; c < ncls; ++c) {
+        SVGP_REQUIRE(d[c].nt >= 1 && d[c].nt <= CT_MAXT, SVGP_ERR_INVALID, "taps must be 1..16");
+        SVGP_REQUIRE(d[c].Ci >= 1 && d[c].Ci <= 16 && d[c].Co >= 1 && d[c].Co <= 16, SVGP_ERR_UNSUPPORTED,
+                     "conv_taps supports 1..16 input and output channels (got %d, %d)", d[c].Ci, d[c].Co);
+        SVGP_REQUIRE(d[c].n >= 1 && d[c].Hs >= 1 && d[c].Ws >= 1 && d[c].sy >= 1 && d[c].sx >= 1, SVGP_ERR_INVALID,
+                     "bad conv descriptor");
+        SVGP_REQUIRE(d[c].n == d[0].n && d[c].Hs == d[0].Hs && d[c].Ws == d[0].Ws, SVGP_ERR_INVALID,
+                     "classes of one launch must share n and the iteration space");
+    }
+    return SVGP_OK;
+}
+
+}  // namespace
+
+extern "C" int svgp_conv_taps_fwd(const svgp_conv_desc* d, int ncls, const double* in, const double* w,
+                                  const double* bias, double* out, void* stream) {
+    int rc = check_desc(d, ncls);
+    if (rc) return rc;
+    SVGP_REQUIRE(in && w && out, SVGP_ERR_INVALID, "NULL device pointer");
+    ConvLaunch L;
+    L.ncls = ncls;
+    size_t lds = 0;
+    for (int c = 0; c < ncls; ++c) {
+        L.d[c] = d[c];
+        SVGP_REQUIRE(!d[c].act || bias, SVGP_ERR_INVALID, "bias is NULL but act != 0");
+        const size_t e = fwd_lds(d[c]) + (size_t)d[c].nt * ((d[c].Ci + 3) & ~3) * 16;
+        lds = e > lds ? e : lds;
+    }
+    lds *= sizeof(real);
+    SVGP_REQUIRE(lds <= 160 * 1024, SVGP_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
+    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_taps_fwd),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int tiles = ((d[0].Ws + CT_TW - 1) / CT_TW) * ((d[0].Hs + CT_TH - 1) / CT_TH);
+    hipLaunchKernelGGL(k_conv_taps_fwd, dim3(tiles, 1, d[0].n * ncls), dim3(256), lds, (hipStream_t)stream, L, in, w,
+                       bias, out);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+// part: (ncls * nwg, part_stride) scratch; dw (part_stride values, the layer's weight layout via woff) receives
+// the fixed-order sum over workgroups and classes (accumulate != 0 adds to dw).
+extern "C" int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const double* in, const double* dout,
+                                    double* part, int nwg, int part_stride, double* dw, int accumulate,
+                                    void* stream) {
+    int rc = check_desc(d, ncls);
+    if (rc) return rc;
+    SVGP_REQUIRE(in && dout && part && dw && nwg >= 1 && part_stride >= 1, SVGP_ERR_INVALID, "bad argument");
+    ConvLaunch L;
+    L.ncls = ncls;
+    size_t lds = 0;
+    for (int c = 0; c < ncls; ++c) {
+        L.d[c] = d[c];
+        const size_t e = fwd_lds(d[c]) + (size_t)CT_TH * CT_TW * 18 + 1024;
+        lds = e > lds ? e : lds;
+    }
+    lds *= sizeof(real);
+    SVGP_REQUIRE(lds <= 160 * 1024, SVGP_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
+    SVGP_CHECK_HIP(hipMemsetAsync(part, 0, (size_t)ncls * nwg * part_stride * sizeof(real), (hipStream_t)stream));
+    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_taps_wgrad),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_conv_taps_wgrad, dim3(nwg, ncls), dim3(256), lds, (hipStream_t)stream, L, nwg, in, dout, part,
+                       part_stride);
+    SVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sum_partials, dim3((part_stride + 255) / 256), dim3(256), 0, (hipStream_t)stream, ncls * nwg,
+                       part_stride, part_stride, part, dw, accumulate);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+// dpre = dout * elu'(out) (in place on dout; out == NULL skips the activation) and db[c] = sum dpre[.., c].
+// part: (nblk, C) scratch with nblk = svgp_elu_bwd_blocks().
+extern "C" int svgp_elu_bwd_bias(long long npix, int C, const double* out, double* dout, double* part, double* db,
+                                 void* stream) {
+    SVGP_REQUIRE(npix >= 1 && C >= 1 && C <= 16 && dout && part && db, SVGP_ERR_INVALID, "bad argument");
+    const int nblk = 256;
+    hipLaunchKernelGGL(k_elu_bwd_colsum, dim3(nblk), dim3(256), 0, (hipStream_t)stream, npix, C, out, dout, part);
+    SVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, nblk, C, C, part, db, 0);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}

@@ -1,0 +1,67 @@
+"""Generic tap-table MFMA convolution (csrc/conv_taps.hip via svgp_vae_amd.conv.ConvLayer) against the oracle's
+Keras-semantics convolutions (F.conv2d on CPU, float64): forward, data gradient, weight and bias gradients."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import svgpvae_oracle as O
+
+pytestmark = pytest.mark.gpu
+DT = torch.float64
+
+CASES = [
+    # (Hi, Ci, Co, k, stride, padding, up, elu)   -- the spritesVAE / repr-net / mnistVAE layer types
+    (64, 3, 16, 3, 1, "same", False, True),
+    (64, 16, 16, 3, 2, "same", False, True),
+    (16, 16, 16, 3, 1, "same", False, True),
+    (8, 16, 16, 3, 1, "same", True, True),
+    (32, 16, 16, 3, 1, "same", True, True),
+    (64, 16, 3, 3, 1, "same", False, True),
+    (64, 3, 16, 2, 2, "same", False, True),
+    (32, 16, 16, 2, 2, "same", False, True),
+    (28, 1, 8, 3, 2, "valid", False, True),
+    (8, 8, 8, 3, 1, "valid", True, True),
+    (14, 8, 1, 3, 1, "same", True, False),
+    (20, 5, 7, 3, 1, "same", False, False),
+]
+
+
+def _oracle(x, w, b, k, stride, padding, up, elu):
+    h = O._upsample2_nhwc(x) if up else x
+    y = O._conv2d_nhwc(h, w, b, stride, padding)
+    return F.elu(y) if elu else y
+
+
+@pytest.mark.parametrize("Hi,Ci,Co,k,stride,padding,up,elu", CASES)
+def test_conv_layer_forward_and_gradients(Hi, Ci, Co, k, stride, padding, up, elu):
+    from svgp_vae_amd.conv import ConvLayer
+    g = torch.Generator().manual_seed(Hi * 31 + Ci * 7 + Co + k)
+    n = 3
+    x = torch.randn(n, Hi, Hi, Ci, dtype=DT, generator=g)
+    w = torch.randn(k, k, Ci, Co, dtype=DT, generator=g) * 0.3
+    b = torch.randn(Co, dtype=DT, generator=g) * 0.1
+    xr, wr, br = (t.clone().requires_grad_() for t in (x, w, b))
+    want = _oracle(xr, wr, br, k, stride, padding, up, elu)
+    gout = torch.randn(*want.shape, dtype=DT, generator=g)
+    gx, gw, gb = torch.autograd.grad((want * gout).sum(), (xr, wr, br))
+
+    lay = ConvLayer(Hi, Ci, Co, k=k, stride=stride, padding=padding, up=up, elu=elu)
+    assert lay.Ho == want.shape[1]
+    dev = "cuda"
+    s = torch.cuda.current_stream().cuda_stream
+    dx_, dw_, db_ = x.to(dev), w.to(dev), b.to(dev)
+    out = torch.full((n, lay.Ho, lay.Ho, Co), float("nan"), dtype=DT, device=dev)
+    lay.forward(dx_, dw_, db_, out, s)
+    torch.cuda.synchronize()
+    rel = lambda a, c: float((a.cpu() - c).abs().max() / (c.abs().max() + 1e-300))
+    assert rel(out, want.detach()) < 1e-12
+
+    dout = gout.to(dev).clone()
+    ggw = torch.zeros(k, k, Ci, Co, dtype=DT, device=dev)
+    ggb = torch.zeros(Co, dtype=DT, device=dev)
+    scratch = torch.zeros(lay.scratch_elems(64), dtype=DT, device=dev)
+    gdx = lay.backward(dx_, dw_, out, dout, ggw, ggb, scratch, s, nwg=64)
+    torch.cuda.synchronize()
+    assert rel(ggb, gb) < 1e-11
+    assert rel(ggw, gw) < 1e-11
+    assert rel(gdx, gx) < 1e-11

@@ -56,6 +56,9 @@ typedef struct {
     int32_t train_ov;      /* 1: object_vectors trainable (--ov_joint)                          */
     int32_t b_cap;         /* row capacity the workspace LAYOUT is computed for (0 = b); keeps    */
                            /* offsets fixed across ragged batches / train-vs-test row counts      */
+    int32_t clip_pv;       /* 1: clip the posterior variance p_v to [1e-4, 100] (SPRITES,          */
+                           /* SVGPVAE_model.py:891-892); the clip mask enters the reverse pass     */
+    int32_t n_pix;         /* pixels per image in the reconstruction loss (0 = 784 = MNIST)        */
     double  N_train;       /* mainSVGP.N_train                                                  */
     double  jitter;        /* mainSVGP.jitter                                                   */
     double  kappa_squared; /* GECO kappa^2                                                      */
@@ -235,6 +238,45 @@ int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const double* in, co
  * part: (256, C) scratch.                                                                                   */
 int svgp_elu_bwd_bias(long long npix, int C, const double* out, double* dout, double* part, double* db,
                       void* stream);
+
+/* ---- SPRITES pieces (gp_sprites.hip) ----------------------------------------------------------------------
+ * spritesSVGP.kernel_matrix (SVGPVAE_model.py:550-600): K = k_action * k_character, each Linear (optionally
+ * cosine-normalised) or ExponentiatedQuadratic (k_se; se = [l_action, sigma_action, l_character, sigma_character]).
+ * aux (b, 1+Lc) = [action id, character vector]; ip (m, La+Lc); table = GPLVM action vectors (n_act, La).        */
+typedef struct {
+    int32_t b, m, La, Lc, n_act, normalize, k_se;
+    double rep_weight;          /* weight of the rank-replicated K_mm gradient terms (1 on rank 0)             */
+} svgp_sprites_kcfg;
+int svgp_sprites_kernel_matrix_fwd(const svgp_sprites_kcfg*, const double* aux, const double* ip, const double* table,
+                                   const double* se, double* K, double* Kn, double* knn, void* stream);
+/* VJP: d_ip (m,La+Lc), d_table (n_act,La), d_char (b,Lc) (gradient of the batch character vectors), d_se (4).
+ * scratch: b*La + (m+b)*4 doubles.                                                                              */
+int svgp_sprites_kernel_matrix_bwd(const svgp_sprites_kcfg*, const double* aux, const double* ip, const double* table,
+                                   const double* se, const double* Kbar, const double* Knbar, const double* knnbar,
+                                   double* d_ip, double* d_table, double* d_char, double* d_se, double* scratch,
+                                   void* stream);
+/* aux_data_SVGPVAE_sprites (SVGPVAE_model.py:1086-1115): segment_mean over seg_len consecutive frames, repeat,
+ * prepend the action id; and its reverse.                                                                        */
+int svgp_sprites_aux_fwd(int b, int seg_len, int Lc, const double* repr, const double* action_ids, double* aux,
+                         void* stream);
+int svgp_sprites_aux_bwd(int b, int seg_len, int Lc, const double* d_char, double* d_repr, void* stream);
+/* AveragePooling2D over the whole (HW) map of an (n,HW,C) tensor (VAE_utils.py:388) and its reverse */
+int svgp_avgpool_fwd(int n, int HW, int C, const double* x, double* y, void* stream);
+int svgp_avgpool_bwd(int n, int HW, int C, const double* dy, double* dx, void* stream);
+/* encoder head: enc (b,2L) += bias; mu = enc[:, :L], var_raw = exp(enc[:, L:]), var = clip (VAE_utils.py:347-348,
+ * SVGPVAE_model.py:858-859); reverse through exp and the clip mask                                             */
+int svgp_enc_head_fwd(int b, int L, int clip, const double* bias, double* enc, double* mu, double* var_raw,
+                      double* var, void* stream);
+int svgp_enc_head_bwd(int b, int L, int clip, const double* var_raw, const double* ybar, const double* s2bar,
+                      double* d_enc, void* stream);
+int svgp_bias_add(long long rows, int C, const double* bias, double* x, void* stream);
+/* sum (x - xhat)^2 partials into the workspace's partial-sum area (block g writes part_sums[4g+2]) and
+ * d loss / d xhat (beta-ELBO: 2(xhat-x)/n_pix; GECO: lagrange_mult/(b_global n_pix) times that)              */
+int svgp_sqerr_fwd(long long tot, int n_part, const double* x, const double* xhat, double* part_sums, void* stream);
+int svgp_sqerr_bwd(long long tot, int geco, int b_global, int n_pix, const double* state, const double* x,
+                   const double* xhat, double* dxhat, void* stream);
+/* tf.clip_by_value(grad, -thr, thr) (SPRITES_experiment.py:234-235) */
+int svgp_clip_by_value(long long tot, double thr, double* g, void* stream);
 
 /* ---- runtime helpers: HIP graphs and events without going through torch ---------------------*/
 int svgp_stream_create(void** stream_out);

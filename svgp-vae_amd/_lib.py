@@ -15,7 +15,7 @@ class SvgpError(RuntimeError):
 
 class MnistCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("b", "b_global", "m", "L", "M", "n_obj", "normalize_obj", "clip_qs",
-                                         "geco", "train_ip", "train_gp", "train_ov", "b_cap")] + \
+                                         "geco", "train_ip", "train_gp", "train_ov", "b_cap", "clip_pv", "n_pix")] + \
                [(n, C.c_double) for n in ("N_train", "jitter", "kappa_squared", "alpha", "rep_weight")]
 
 
@@ -44,6 +44,10 @@ WS_FIELDS = ("enc_a1", "enc_a2", "enc_a3", "qnet_mu", "qnet_var_raw", "qnet_var"
 
 class WsLayout(C.Structure):
     _fields_ = [(n, C.c_int64) for n in WS_FIELDS]
+
+
+class SpritesKcfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("b", "m", "La", "Lc", "n_act", "normalize", "k_se")] + [("rep_weight", C.c_double)]
 
 
 class ConvDesc(C.Structure):
@@ -87,6 +91,18 @@ SIGNATURES = {
     "svgp_conv_taps_fwd": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P],
     "svgp_conv_taps_wgrad": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P],
     "svgp_elu_bwd_bias": [C.c_longlong, C.c_int, _P, _P, _P, _P, _P],
+    "svgp_sprites_kernel_matrix_fwd": [C.POINTER(SpritesKcfg), _P, _P, _P, _P, _P, _P, _P, _P],
+    "svgp_sprites_kernel_matrix_bwd": [C.POINTER(SpritesKcfg)] + [_P] * 13,
+    "svgp_sprites_aux_fwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P],
+    "svgp_sprites_aux_bwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P],
+    "svgp_avgpool_fwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P],
+    "svgp_avgpool_bwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P],
+    "svgp_enc_head_fwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P],
+    "svgp_enc_head_bwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
+    "svgp_bias_add": [C.c_longlong, C.c_int, _P, _P, _P],
+    "svgp_sqerr_fwd": [C.c_longlong, C.c_int, _P, _P, _P, _P],
+    "svgp_sqerr_bwd": [C.c_longlong, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
+    "svgp_clip_by_value": [C.c_longlong, C.c_double, _P, _P],
     "svgp_stream_create": [C.POINTER(_P)],
     "svgp_stream_destroy": [_P],
     "svgp_stream_sync": [_P],

@@ -489,7 +489,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernAr
 // In forward mode the extra block blockIdx.y == L inverts K_mm + jitter I (:239,270,273).
 // =============================================================================================
 struct StatArgs {
-    int b, m, L, mode, rc_rows;   // rc_rows: rows of K_nm staged per pass
+    int b, m, L, mode, rc_rows, clip_pv;   // rc_rows: rows of K_nm staged per pass
     real c, jitter, beta_over_L_unused;
     int geco;
     const real* Kn;      // (b,m)
@@ -559,7 +559,9 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
                 vb[rr] = 0;
             } else {
                 const real zb = a.zbar[e];
-                const real gpv = real(0.5) * gT * p + zb * a.eps[e] / (real(2) * sqrt(a.p_v[e]));
+                const real pv = a.p_v[e];
+                real gpv = real(0.5) * gT * p + zb * a.eps[e] / (real(2) * sqrt(pv));
+                if (a.clip_pv && !(pv > 1e-4 && pv < 100.0)) gpv = 0;      // tf.clip_by_value mask (:891-892)
                 const real gpm = gT * p * (a.p_m[e] - a.y[e]) + zb;
                 const real mvb = gT * p * a.e[e];
                 w[rr] = gpv;
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
 // per-sample stage, forward.  grid (ceil(b/RB), L); thread (n_local, i), RB = 256 / m rows.
 // =============================================================================================
 struct PostArgs {
-    int b, m, L, n_rowblk_unused;
+    int b, m, L, clip_pv;
     real c;
     int use_rng;
     const real* Kn; const real* knn; const real* q; const real* y; const real* s2;
@@ -805,7 +807,9 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_fwd(PostArgs a) {
         const size_t e = (size_t)n * a.L + l;
         const real y = a.y[e], s2 = a.s2[e], p = recip_no_nan(s2);
         const real kq = a.knn[n] - a.q[n];
-        const real p_m = a.c * pms, p_v = kq + rs, ee = y - mvs, dd = kq + ss + ee * ee;
+        const real p_m = a.c * pms, ee = y - mvs, dd = kq + ss + ee * ee;
+        real p_v = kq + rs;
+        if (a.clip_pv) p_v = fmin(fmax(p_v, 1e-4), 100.0);
         real ep;
         if (a.use_rng) ep = philox_normal((unsigned long long)a.state[SVGP_ST_RNG_CTR], (unsigned long long)e);
         else ep = a.eps_in[e];
@@ -1140,7 +1144,7 @@ static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     StatArgs a;
     memset(&a, 0, sizeof(a));
     a.b = c->b; a.m = c->m; a.L = c->L; a.mode = mode; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;
-    a.geco = c->geco;
+    a.geco = c->geco; a.clip_pv = c->clip_pv;
     a.Kn = ws + wl.Kn; a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var;
     a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v; a.e = ws + wl.e; a.eps = ws + wl.eps; a.zbar = ws + wl.zbar;
     a.state = state;
@@ -1203,7 +1207,7 @@ extern "C" int svgp_gp_posterior_fwd(const svgp_mnist_cfg* c, const double* eps,
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     if (c->m > SVGP_M_MAX) return svgp_big_posterior_fwd(c, wl, eps, ws, state, stream);
     PostArgs a;
-    a.b = c->b; a.m = c->m; a.L = c->L; a.n_rowblk_unused = 0; a.c = c->N_train / (double)c->b_global;
+    a.b = c->b; a.m = c->m; a.L = c->L; a.clip_pv = c->clip_pv; a.c = c->N_train / (double)c->b_global;
     a.use_rng = eps == nullptr;
     a.Kn = ws + wl.Kn; a.knn = ws + wl.knn; a.q = ws + wl.q; a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var;
     a.Si = ws + wl.Si; a.M2 = ws + wl.M2; a.t = ws + wl.t; a.u = ws + wl.u; a.eps_in = eps; a.state = state;

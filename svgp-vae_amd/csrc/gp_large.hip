@@ -18,7 +18,7 @@ __device__ __forceinline__ real gradKL(int geco, int L, const real* state) {
 
 // ---- element-wise / reduction kernels ---------------------------------------------------------
 // weights of the statistics.  mode 0: w = 1/s2, a = y/s2.  mode 1: g_pv, g_pm, mvbar (stored), b = c g_pm.
-__global__ void k_big_weights(int n_el, int L, int mode, int geco, real c, const real* __restrict__ state,
+__global__ void k_big_weights(int n_el, int L, int mode, int geco, int clip_pv, real c, const real* __restrict__ state,
                               const real* __restrict__ y, const real* __restrict__ s2,
                               const real* __restrict__ p_m, const real* __restrict__ p_v,
                               const real* __restrict__ e, const real* __restrict__ eps,
@@ -31,7 +31,9 @@ __global__ void k_big_weights(int n_el, int L, int mode, int geco, real c, const
         w[i] = p; a[i] = p * y[i];
     } else {
         const real gT = gradKL(geco, L, state), zb = zbar[i];
-        const real gpv = real(0.5) * gT * p + zb * eps[i] / (real(2) * sqrt(p_v[i]));
+        const real pv = p_v[i];
+        real gpv = real(0.5) * gT * p + zb * eps[i] / (real(2) * sqrt(pv));
+        if (clip_pv && !(pv > 1e-4 && pv < 100.0)) gpv = 0;
         const real gpm = gT * p * (p_m[i] - y[i]) + zb;
         w[i] = gpv; bv[i] = gpm; a[i] = gT * p * e[i];       // g_pv, g_pm, mvbar buffers
     }
@@ -91,7 +93,7 @@ __global__ void k_big_kl(int m, int L, const real* __restrict__ ldK, const real*
 }
 // final element-wise part of the per-sample forward + partial sums
 struct PostFinArgs {
-    int b, L, use_rng;
+    int b, L, use_rng, clip_pv;
     const real* knn; const real* q; const real* y; const real* s2; const real* eps_in; const real* state;
     real* p_m; real* p_v; real* e; real* d; real* eps; real* z; real* part;
 };
@@ -122,7 +124,9 @@ __global__ __launch_bounds__(256) void k_big_post_final(PostFinArgs a) {
     if (i < a.b * a.L) {
         const int n = i / a.L;
         const real y = a.y[i], s2 = a.s2[i], p = recip_no_nan(s2), kq = a.knn[n] - a.q[n];
-        const real p_m = a.p_m[i], p_v = kq + a.p_v[i], ee = y - a.e[i], dd = kq + a.d[i] + ee * ee;
+        const real p_m = a.p_m[i], ee = y - a.e[i], dd = kq + a.d[i] + ee * ee;
+        real p_v = kq + a.p_v[i];
+        if (a.clip_pv) p_v = fmin(fmax(p_v, 1e-4), 100.0);
         const real ep = a.use_rng ? philox_normal_big((unsigned long long)a.state[SVGP_ST_RNG_CTR], (unsigned long long)i)
                                   : a.eps_in[i];
         a.eps[i] = ep; a.p_v[i] = p_v; a.e[i] = ee; a.d[i] = dd;
@@ -295,7 +299,7 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
     real* wbuf = ws + wl.g_pv;
     real* abuf = mode == 0 ? ws + wl.g_pm : ws + wl.mvbar;
     real* bbuf = ws + wl.g_pm;
-    hipLaunchKernelGGL(k_big_weights, dim3(nblk((long long)b * L)), dim3(256), 0, st, b * L, L, mode, c->geco, cc, state,
+    hipLaunchKernelGGL(k_big_weights, dim3(nblk((long long)b * L)), dim3(256), 0, st, b * L, L, mode, c->geco, c->clip_pv, cc, state,
                        ws + wl.qnet_mu, ws + wl.qnet_var, ws + wl.p_m, ws + wl.p_v, ws + wl.e, ws + wl.eps,
                        ws + wl.zbar, wbuf, abuf, bbuf);
     SVGP_LAUNCH_CHECK();
@@ -371,7 +375,7 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     GEMM(0, 1, b, L, m, cc, Kn, m, 0, ws + wl.t, m, 0, 0.0, ws + wl.p_m, L, 0, 1);               // p_m = c Kn t^T
     GEMM(0, 1, b, L, m, 1.0, Kn, m, 0, ws + wl.u, m, 0, 0.0, ws + wl.e, L, 0, 1);                // mv -> e slot
     PostFinArgs a;
-    a.b = b; a.L = L; a.use_rng = eps == nullptr;
+    a.b = b; a.L = L; a.use_rng = eps == nullptr; a.clip_pv = c->clip_pv;
     a.knn = ws + wl.knn; a.q = ws + wl.q; a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var; a.eps_in = eps; a.state = state;
     a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v; a.e = ws + wl.e; a.d = ws + wl.d; a.eps = ws + wl.eps; a.z = ws + wl.z;
     a.part = ws + wl.part_sums + (size_t)svgp_n_part(c) * 4;

@@ -1,0 +1,421 @@
+// SPRITES pieces of the SVGPVAE path (SURVEY 8a rows a2, a8 glue):
+//   spritesSVGP.kernel_matrix (SVGPVAE_model.py:550-600): K = k_action * k_character, each Linear
+//   (optionally cosine-normalised, :576-598) or ExponentiatedQuadratic (K_SE, :530-544); batch rows gather
+//   their action vector from the GPLVM table by id (:565) and carry the character vector in aux[:,1:].
+//   Forward + hand-derived VJP (inducing points, GPLVM table, SE hyper-parameters, batch character vectors).
+//   aux_data_SVGPVAE_sprites (:1086-1115): segment_mean over each character's frames, repeat, prepend id.
+//   Small element-wise helpers of the SPRITES step (encoder head, pooling, squared error, clipping).
+#include "common.hpp"
+
+namespace {
+
+#define SP_MAXD 32
+
+struct SpK {
+    int b, m, La, Lc, n_act, kind;   // kind: 0 linear, 1 normalised linear, 2 SE
+    real rep_weight;
+    const real* aux;    // (b, 1+Lc)
+    const real* ip;     // (m, La+Lc)
+    const real* table;  // (n_act, La)
+    const real* se;     // l_action, sigma_action, l_character, sigma_character
+};
+
+__device__ __forceinline__ real dotd(const real* x, const real* y, int D) {
+    real s = 0;
+    for (int k = 0; k < D; ++k) s += x[k] * y[k];
+    return s;
+}
+// group kernel value and the coefficients of d k / d y = ca * x + cb * y   (symmetric in x <-> y)
+__device__ __forceinline__ real grp_k(int kind, const real* x, const real* y, int D, real ell, real sig, real& ca,
+                                      real& cb, real& d2) {
+    d2 = 0;
+    if (kind == 2) {
+        for (int k = 0; k < D; ++k) { const real t = x[k] - y[k]; d2 += t * t; }
+        const real kv = sig * sig * exp(-d2 / (real(2) * ell * ell));
+        ca = kv / (ell * ell); cb = -ca;
+        return kv;
+    }
+    const real xy = dotd(x, y, D);
+    if (kind == 0) { ca = 1; cb = 0; return xy; }
+    const real nx = sqrt(dotd(x, x, D)), ny = sqrt(dotd(y, y, D));
+    const real kv = xy / (nx * ny);
+    ca = real(1) / (nx * ny); cb = -kv / (ny * ny);
+    return kv;
+}
+__device__ __forceinline__ const real* act_row(const SpK& a, int n) {
+    return a.table + (size_t)((long long)a.aux[(size_t)n * (1 + a.Lc)]) * a.La;
+}
+
+__global__ __launch_bounds__(256) void k_sprites_kernel_fwd(SpK a, real* __restrict__ K, real* __restrict__ Kn,
+                                                            real* __restrict__ knn) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long nbm = (long long)a.b * a.m, nmm = (long long)a.m * a.m;
+    const int D = a.La + a.Lc;
+    const real la = a.se[0], sa = a.se[1], lc = a.se[2], sc = a.se[3];
+    real ca, cb, d2;
+    if (idx < nbm) {
+        const int n = (int)(idx / a.m), j = (int)(idx % a.m);
+        const real* z = a.ip + (size_t)j * D;
+        Kn[idx] = grp_k(a.kind, act_row(a, n), z, a.La, la, sa, ca, cb, d2) *
+                  grp_k(a.kind, a.aux + (size_t)n * (1 + a.Lc) + 1, z + a.La, a.Lc, lc, sc, ca, cb, d2);
+    } else if (idx < nbm + nmm) {
+        const long long o = idx - nbm;
+        const real* zi = a.ip + (size_t)(o / a.m) * D;
+        const real* zj = a.ip + (size_t)(o % a.m) * D;
+        K[o] = grp_k(a.kind, zi, zj, a.La, la, sa, ca, cb, d2) * grp_k(a.kind, zi + a.La, zj + a.La, a.Lc, lc, sc, ca, cb, d2);
+    } else if (idx < nbm + nmm + a.b) {
+        const int n = (int)(idx - nbm - nmm);
+        const real* xa = act_row(a, n);
+        const real* xc = a.aux + (size_t)n * (1 + a.Lc) + 1;
+        knn[n] = grp_k(a.kind, xa, xa, a.La, la, sa, ca, cb, d2) * grp_k(a.kind, xc, xc, a.Lc, lc, sc, ca, cb, d2);
+    }
+}
+
+// VJP, inducing side: workgroup j.  d_ip[j] (La+Lc) and SE-parameter partials part_se[j][4].
+__global__ __launch_bounds__(256) void k_sprites_kernel_bwd_cols(SpK a, const real* __restrict__ Kbar,
+                                                                 const real* __restrict__ Knbar,
+                                                                 real* __restrict__ d_ip, real* __restrict__ part_se) {
+    __shared__ real wred[4][2 * SP_MAXD + 4];
+    const int j = blockIdx.x, La = a.La, Lc = a.Lc, D = La + Lc;
+    const real la = a.se[0], sa = a.se[1], lc = a.se[2], sc = a.se[3];
+    const real* zj = a.ip + (size_t)j * D;
+    real acc[2 * SP_MAXD + 4];
+#pragma unroll
+    for (int k = 0; k < 2 * SP_MAXD + 4; ++k) acc[k] = 0;
+    auto add = [&](const real* xa, const real* xc, real c_vec, real c_par) {
+        real caA, cbA, d2A, caC, cbC, d2C;
+        const real kA = grp_k(a.kind, xa, zj, La, la, sa, caA, cbA, d2A);
+        const real kC = grp_k(a.kind, xc, zj + La, Lc, lc, sc, caC, cbC, d2C);
+        const real cA = c_vec * kC, cC = c_vec * kA;
+#pragma unroll
+        for (int k = 0; k < SP_MAXD; ++k) {
+            if (k < La) acc[k] += cA * (caA * xa[k] + cbA * zj[k]);
+            if (k < Lc) acc[SP_MAXD + k] += cC * (caC * xc[k] + cbC * zj[La + k]);
+        }
+        if (a.kind == 2) {
+            const real kk = c_par * kA * kC;
+            acc[2 * SP_MAXD + 0] += kk * d2A / (la * la * la);
+            acc[2 * SP_MAXD + 1] += kk * real(2) / sa;
+            acc[2 * SP_MAXD + 2] += kk * d2C / (lc * lc * lc);
+            acc[2 * SP_MAXD + 3] += kk * real(2) / sc;
+        }
+    };
+    for (int n = threadIdx.x; n < a.b; n += blockDim.x) {
+        const real c = Knbar[(size_t)n * a.m + j];
+        add(act_row(a, n), a.aux + (size_t)n * (1 + Lc) + 1, c, c);
+    }
+    for (int i = threadIdx.x; i < a.m; i += blockDim.x) {
+        const real* zi = a.ip + (size_t)i * D;
+        const real g_ji = a.rep_weight * Kbar[(size_t)j * a.m + i], g_ij = a.rep_weight * Kbar[(size_t)i * a.m + j];
+        add(zi, zi + La, g_ji + g_ij, g_ji);       // hyper-parameters: each entry (j,i) once
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 2 * SP_MAXD + 4; ++k) {
+        const bool used = (k < La) || (k >= SP_MAXD && k < SP_MAXD + Lc) || (k >= 2 * SP_MAXD);
+        if (used) { const real t = wave_sum(acc[k]); if (lane == 0) wred[wv][k] = t; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * SP_MAXD + 4) {
+        const int k = threadIdx.x;
+        const real s = wred[0][k] + wred[1][k] + wred[2][k] + wred[3][k];
+        if (k < La) d_ip[(size_t)j * D + k] = s;
+        else if (k >= SP_MAXD && k < SP_MAXD + Lc) d_ip[(size_t)j * D + La + (k - SP_MAXD)] = s;
+        else if (k >= 2 * SP_MAXD) part_se[j * 4 + (k - 2 * SP_MAXD)] = s;
+    }
+}
+
+// VJP, batch-row side: one wave per row.  d_xa (b,La) [for the table scatter], d_char (b,Lc), SE partials per row.
+__global__ __launch_bounds__(64) void k_sprites_kernel_bwd_rows(SpK a, const real* __restrict__ Knbar,
+                                                                const real* __restrict__ knnbar,
+                                                                real* __restrict__ d_xa, real* __restrict__ d_char,
+                                                                real* __restrict__ part_se) {
+    const int n = blockIdx.x, lane = threadIdx.x, La = a.La, Lc = a.Lc, D = La + Lc;
+    const real la = a.se[0], sa = a.se[1], lc = a.se[2], sc = a.se[3];
+    const real* xa = act_row(a, n);
+    const real* xc = a.aux + (size_t)n * (1 + Lc) + 1;
+    real acc[2 * SP_MAXD + 4];
+#pragma unroll
+    for (int k = 0; k < 2 * SP_MAXD + 4; ++k) acc[k] = 0;
+    for (int j = lane; j < a.m; j += 64) {
+        const real* zj = a.ip + (size_t)j * D;
+        real caA, cbA, d2A, caC, cbC, d2C;
+        const real kA = grp_k(a.kind, zj, xa, La, la, sa, caA, cbA, d2A);          // d/d(second arg) = ca*first + cb*second
+        const real kC = grp_k(a.kind, zj + La, xc, Lc, lc, sc, caC, cbC, d2C);
+        const real c = Knbar[(size_t)n * a.m + j], cA = c * kC, cC = c * kA;
+#pragma unroll
+        for (int k = 0; k < SP_MAXD; ++k) {
+            if (k < La) acc[k] += cA * (caA * zj[k] + cbA * xa[k]);
+            if (k < Lc) acc[SP_MAXD + k] += cC * (caC * zj[La + k] + cbC * xc[k]);
+        }
+    }
+    // k_nn = kA(xa,xa) kC(xc,xc)
+    const real g = knnbar[n];
+    real separt[4] = {0, 0, 0, 0};
+    if (lane == 0) {
+        if (a.kind == 0) {
+            const real na2 = dotd(xa, xa, La), nc2 = dotd(xc, xc, Lc);
+            for (int k = 0; k < La; ++k) acc[k] += g * real(2) * nc2 * xa[k];
+            for (int k = 0; k < Lc; ++k) acc[SP_MAXD + k] += g * real(2) * na2 * xc[k];
+        } else if (a.kind == 2) {
+            const real knn = sa * sa * sc * sc;
+            separt[1] = g * real(2) * knn / sa;
+            separt[3] = g * real(2) * knn / sc;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SP_MAXD; ++k) {
+        if (k < La) { const real t = wave_sum(acc[k]); if (lane == 0) d_xa[(size_t)n * La + k] = t; }
+        if (k < Lc) { const real t = wave_sum(acc[SP_MAXD + k]); if (lane == 0) d_char[(size_t)n * Lc + k] = t; }
+    }
+    if (lane == 0)
+        for (int k = 0; k < 4; ++k) part_se[(size_t)(a.m + n) * 4 + k] = separt[k];
+}
+
+// table scatter (deterministic scan) + final SE-parameter sums (last block)
+__global__ __launch_bounds__(256) void k_sprites_kernel_bwd_scatter(SpK a, const real* __restrict__ d_xa,
+                                                                    const real* __restrict__ part_se,
+                                                                    real* __restrict__ d_table, real* __restrict__ d_se) {
+    __shared__ int ids[256];
+    __shared__ real red[16];
+    if (blockIdx.x == gridDim.x - 1) {
+        for (int k = 0; k < 4; ++k) {
+            real s = 0;
+            for (int i = threadIdx.x; i < a.m + a.b; i += blockDim.x) s += part_se[(size_t)i * 4 + k];
+            s = block_sum(s, red);
+            if (threadIdx.x == 0) d_se[k] = s;
+            __syncthreads();
+        }
+        return;
+    }
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool act = o < a.n_act * a.La;
+    const int r = act ? o / a.La : -1, k = act ? o % a.La : 0;
+    real acc = 0;
+    for (int n0 = 0; n0 < a.b; n0 += 256) {
+        const int cnt = min(256, a.b - n0);
+        __syncthreads();
+        if (threadIdx.x < cnt) ids[threadIdx.x] = (int)a.aux[(size_t)(n0 + threadIdx.x) * (1 + a.Lc)];
+        __syncthreads();
+        if (act)
+            for (int t = 0; t < cnt; ++t)
+                if (ids[t] == r) acc += d_xa[(size_t)(n0 + t) * a.La + k];
+    }
+    if (act) d_table[o] = acc;
+}
+
+// ---- aux data: segment mean over seg_len consecutive rows, repeat, prepend the action id --------------
+__global__ void k_sprites_aux_fwd(int b, int seg_len, int Lc, const real* __restrict__ repr,
+                                  const real* __restrict__ action_ids, real* __restrict__ aux) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b * (1 + Lc)) return;
+    const int n = i / (1 + Lc), c = i % (1 + Lc);
+    if (c == 0) { aux[i] = action_ids[n]; return; }
+    const int g0 = (n / seg_len) * seg_len;
+    real s = 0;
+    for (int t = 0; t < seg_len; ++t) s += repr[(size_t)(g0 + t) * Lc + c - 1];
+    aux[i] = s / (real)seg_len;
+}
+__global__ void k_sprites_aux_bwd(int b, int seg_len, int Lc, const real* __restrict__ d_char, real* __restrict__ d_repr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b * Lc) return;
+    const int n = i / Lc, c = i % Lc, g0 = (n / seg_len) * seg_len;
+    real s = 0;
+    for (int t = 0; t < seg_len; ++t) s += d_char[(size_t)(g0 + t) * Lc + c];
+    d_repr[i] = s / (real)seg_len;
+}
+// ---- average pooling over all HW positions of an (n, HW, C) map and its reverse ---------------------------
+__global__ void k_avgpool_fwd(int n, int HW, int Cc, const real* __restrict__ x, real* __restrict__ y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * Cc) return;
+    const int im = i / Cc, c = i % Cc;
+    real s = 0;
+    for (int p = 0; p < HW; ++p) s += x[((size_t)im * HW + p) * Cc + c];
+    y[i] = s / (real)HW;
+}
+__global__ void k_avgpool_bwd(long long tot, int HW, int Cc, const real* __restrict__ dy, real* __restrict__ dx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tot) return;
+    const int c = (int)(i % Cc);
+    const long long im = i / ((long long)HW * Cc);
+    dx[i] = dy[im * Cc + c] / (real)HW;
+}
+// ---- encoder head: enc (b,2L) (+bias) -> mu, var_raw = exp, var = clip; and its reverse -----------------
+__global__ void k_enc_head_fwd(int b, int L, int clip, const real* __restrict__ bias, real* __restrict__ enc,
+                               real* __restrict__ mu, real* __restrict__ var_raw, real* __restrict__ var) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b * 2 * L) return;
+    const int n = i / (2 * L), j = i % (2 * L);
+    const real v = enc[i] + bias[j];
+    enc[i] = v;
+    if (j < L) mu[(size_t)n * L + j] = v;
+    else {
+        const real vr = exp(v);
+        var_raw[(size_t)n * L + j - L] = vr;
+        var[(size_t)n * L + j - L] = clip ? fmin(fmax(vr, 1e-3), 10.0) : vr;
+    }
+}
+__global__ void k_enc_head_bwd(int b, int L, int clip, const real* __restrict__ var_raw, const real* __restrict__ ybar,
+                               const real* __restrict__ s2bar, real* __restrict__ d_enc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b * 2 * L) return;
+    const int n = i / (2 * L), j = i % (2 * L);
+    if (j < L) d_enc[i] = ybar[(size_t)n * L + j];
+    else {
+        const real vr = var_raw[(size_t)n * L + j - L];
+        const bool pass = !clip || (vr >= 1e-3 && vr <= 10.0);
+        d_enc[i] = pass ? s2bar[(size_t)n * L + j - L] * vr : real(0);
+    }
+}
+__global__ void k_bias_add(long long tot, int Cc, const real* __restrict__ bias, real* __restrict__ x) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < tot) x[i] += bias[i % Cc];
+}
+// ---- squared reconstruction error: per-block partial sums (n_part blocks) and its gradient -----------------
+__global__ __launch_bounds__(256) void k_sqerr_fwd(long long tot, const real* __restrict__ x, const real* __restrict__ xh,
+                                                   real* __restrict__ part_sums) {
+    __shared__ real red[16];
+    real s = 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+        const real d = x[i] - xh[i];
+        s += d * d;
+    }
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) part_sums[blockIdx.x * 4 + 2] = s;
+}
+__global__ void k_sqerr_bwd(long long tot, int geco, real inv_bglobal, real inv_npix, const real* __restrict__ state,
+                            const real* __restrict__ x, const real* __restrict__ xh, real* __restrict__ dxh) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tot) return;
+    const real gscale = (geco ? state[SVGP_ST_LAGRANGE] * inv_bglobal : real(1)) * inv_npix;
+    dxh[i] = real(2) * gscale * (xh[i] - x[i]);
+}
+__global__ void k_clip(long long tot, real thr, real* __restrict__ g) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < tot) g[i] = fmin(fmax(g[i], -thr), thr);
+}
+
+inline unsigned nb256(long long n) { return (unsigned)((n + 255) / 256); }
+
+int make_spk(const svgp_sprites_kcfg* c, const double* aux, const double* ip, const double* table, const double* se,
+             SpK& a) {
+    SVGP_REQUIRE(c && aux && ip && table && se, SVGP_ERR_INVALID, "NULL pointer");
+    SVGP_REQUIRE(c->b >= 1 && c->m >= 1 && c->La >= 1 && c->Lc >= 1 && c->La <= SP_MAXD && c->Lc <= SP_MAXD &&
+                 c->n_act >= 1, SVGP_ERR_UNSUPPORTED, "sprites kernel: need 1 <= L_action, L_character <= %d", SP_MAXD);
+    a.b = c->b; a.m = c->m; a.La = c->La; a.Lc = c->Lc; a.n_act = c->n_act;
+    a.kind = c->k_se ? 2 : (c->normalize ? 1 : 0);
+    a.rep_weight = c->rep_weight; a.aux = aux; a.ip = ip; a.table = table; a.se = se;
+    return SVGP_OK;
+}
+
+}  // namespace
+
+extern "C" int svgp_sprites_kernel_matrix_fwd(const svgp_sprites_kcfg* c, const double* aux, const double* ip,
+                                              const double* table, const double* se, double* K, double* Kn, double* knn,
+                                              void* stream) {
+    SpK a;
+    int rc = make_spk(c, aux, ip, table, se, a);
+    if (rc) return rc;
+    SVGP_REQUIRE(K && Kn && knn, SVGP_ERR_INVALID, "NULL pointer");
+    const long long tot = (long long)a.b * a.m + (long long)a.m * a.m + a.b;
+    hipLaunchKernelGGL(k_sprites_kernel_fwd, dim3(nb256(tot)), dim3(256), 0, (hipStream_t)stream, a, K, Kn, knn);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+// scratch: (b*La + (m+b)*4) doubles.  Outputs: d_ip (m,La+Lc), d_table (n_act,La), d_char (b,Lc), d_se (4).
+extern "C" int svgp_sprites_kernel_matrix_bwd(const svgp_sprites_kcfg* c, const double* aux, const double* ip,
+                                              const double* table, const double* se, const double* Kbar,
+                                              const double* Knbar, const double* knnbar, double* d_ip, double* d_table,
+                                              double* d_char, double* d_se, double* scratch, void* stream) {
+    SpK a;
+    int rc = make_spk(c, aux, ip, table, se, a);
+    if (rc) return rc;
+    SVGP_REQUIRE(Kbar && Knbar && knnbar && d_ip && d_table && d_char && d_se && scratch, SVGP_ERR_INVALID, "NULL pointer");
+    real* d_xa = scratch;
+    real* part_se = scratch + (size_t)a.b * a.La;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sprites_kernel_bwd_cols, dim3(a.m), dim3(256), 0, st, a, Kbar, Knbar, d_ip, part_se);
+    SVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sprites_kernel_bwd_rows, dim3(a.b), dim3(64), 0, st, a, Knbar, knnbar, d_xa, d_char, part_se);
+    SVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sprites_kernel_bwd_scatter, dim3(nb256((long long)a.n_act * a.La) + 1), dim3(256), 0, st, a, d_xa,
+                       part_se, d_table, d_se);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+extern "C" int svgp_sprites_aux_fwd(int b, int seg_len, int Lc, const double* repr, const double* action_ids, double* aux,
+                                    void* stream) {
+    SVGP_REQUIRE(b >= 1 && seg_len >= 1 && b % seg_len == 0 && repr && action_ids && aux, SVGP_ERR_INVALID,
+                 "batch must be a multiple of the frames-per-character count (SPRITES_experiment.py:40-41)");
+    hipLaunchKernelGGL(k_sprites_aux_fwd, dim3(nb256((long long)b * (1 + Lc))), dim3(256), 0, (hipStream_t)stream, b, seg_len,
+                       Lc, repr, action_ids, aux);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_sprites_aux_bwd(int b, int seg_len, int Lc, const double* d_char, double* d_repr, void* stream) {
+    SVGP_REQUIRE(b >= 1 && seg_len >= 1 && b % seg_len == 0 && d_char && d_repr, SVGP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_sprites_aux_bwd, dim3(nb256((long long)b * Lc)), dim3(256), 0, (hipStream_t)stream, b, seg_len, Lc,
+                       d_char, d_repr);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_avgpool_fwd(int n, int HW, int Cc, const double* x, double* y, void* stream) {
+    SVGP_REQUIRE(n >= 1 && HW >= 1 && Cc >= 1 && x && y, SVGP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_avgpool_fwd, dim3(nb256((long long)n * Cc)), dim3(256), 0, (hipStream_t)stream, n, HW, Cc, x, y);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_avgpool_bwd(int n, int HW, int Cc, const double* dy, double* dx, void* stream) {
+    SVGP_REQUIRE(n >= 1 && HW >= 1 && Cc >= 1 && dy && dx, SVGP_ERR_INVALID, "bad argument");
+    const long long tot = (long long)n * HW * Cc;
+    hipLaunchKernelGGL(k_avgpool_bwd, dim3(nb256(tot)), dim3(256), 0, (hipStream_t)stream, tot, HW, Cc, dy, dx);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_enc_head_fwd(int b, int L, int clip, const double* bias, double* enc, double* mu, double* var_raw,
+                                 double* var, void* stream) {
+    SVGP_REQUIRE(b >= 1 && L >= 1 && bias && enc && mu && var_raw && var, SVGP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_enc_head_fwd, dim3(nb256((long long)b * 2 * L)), dim3(256), 0, (hipStream_t)stream, b, L, clip, bias,
+                       enc, mu, var_raw, var);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_enc_head_bwd(int b, int L, int clip, const double* var_raw, const double* ybar, const double* s2bar,
+                                 double* d_enc, void* stream) {
+    SVGP_REQUIRE(b >= 1 && L >= 1 && var_raw && ybar && s2bar && d_enc, SVGP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_enc_head_bwd, dim3(nb256((long long)b * 2 * L)), dim3(256), 0, (hipStream_t)stream, b, L, clip,
+                       var_raw, ybar, s2bar, d_enc);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_bias_add(long long rows, int Cc, const double* bias, double* x, void* stream) {
+    SVGP_REQUIRE(rows >= 1 && Cc >= 1 && bias && x, SVGP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_bias_add, dim3(nb256(rows * Cc)), dim3(256), 0, (hipStream_t)stream, rows * Cc, Cc, bias, x);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+// part_sums: the workspace's partial-sum area; n_part blocks write [blk*4+2]
+extern "C" int svgp_sqerr_fwd(long long tot, int n_part, const double* x, const double* xhat, double* part_sums,
+                              void* stream) {
+    SVGP_REQUIRE(tot >= 1 && n_part >= 1 && x && xhat && part_sums, SVGP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_sqerr_fwd, dim3(n_part), dim3(256), 0, (hipStream_t)stream, tot, x, xhat, part_sums);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_sqerr_bwd(long long tot, int geco, int b_global, int n_pix, const double* state, const double* x,
+                              const double* xhat, double* dxhat, void* stream) {
+    SVGP_REQUIRE(tot >= 1 && b_global >= 1 && n_pix >= 1 && state && x && xhat && dxhat, SVGP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_sqerr_bwd, dim3(nb256(tot)), dim3(256), 0, (hipStream_t)stream, tot, geco, 1.0 / b_global,
+                       1.0 / n_pix, state, x, xhat, dxhat);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_clip_by_value(long long tot, double thr, double* g, void* stream) {
+    SVGP_REQUIRE(tot >= 0 && thr > 0 && (g || tot == 0), SVGP_ERR_INVALID, "bad argument");
+    if (tot == 0) return SVGP_OK;
+    hipLaunchKernelGGL(k_clip, dim3(nb256(tot)), dim3(256), 0, (hipStream_t)stream, tot, thr, g);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}

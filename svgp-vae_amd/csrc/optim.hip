@@ -23,7 +23,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_adam_tf1(long long n, real* __re
 }
 
 struct FinArgs {
-    int b_global, L, geco, did_adam;
+    int b_global, L, geco, did_adam, n_pix;
     real N_train, kappa_squared, alpha_next;
     const real* sums;   // [L3 data term, CE, recon sq, rows] summed over ranks
     const real* KL;     // (L)
@@ -44,14 +44,14 @@ __global__ void k_elbo_finalize(FinArgs a) {
     const real sq = a.sums[2];
     real elbo, recon_loss;
     if (a.geco) {
-        recon_loss = sq / real(784) - bg * a.kappa_squared;
+        recon_loss = sq / (real)a.n_pix - bg * a.kappa_squared;
         const real alpha = st[SVGP_ST_ALPHA], lam = st[SVGP_ST_LAGRANGE];
         const real C_ma = alpha * st[SVGP_ST_C_MA] + (real(1) - alpha) * recon_loss / bg;
         elbo = -KL_term + lam * (recon_loss / bg + (C_ma - recon_loss / bg));
         st[SVGP_ST_C_MA] = C_ma;
         st[SVGP_ST_LAGRANGE] = lam * exp(C_ma);
     } else {
-        recon_loss = sq / real(784);
+        recon_loss = sq / (real)a.n_pix;
         elbo = -recon_loss + (st[SVGP_ST_BETA] / Lr) * KL_term;
     }
     st[SVGP_ST_ELBO] = elbo;
@@ -85,6 +85,7 @@ static int finalize_impl(const svgp_mnist_cfg* c, double* ws, double* state, int
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     FinArgs a;
     a.b_global = c->b_global; a.L = c->L; a.geco = c->geco; a.did_adam = did_adam;
+    a.n_pix = c->n_pix > 0 ? c->n_pix : 784;
     a.N_train = c->N_train; a.kappa_squared = c->kappa_squared; a.alpha_next = c->alpha;
     a.sums = ws + wl.sums; a.KL = ws + wl.KL; a.state = state;
     hipLaunchKernelGGL(k_elbo_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, a);

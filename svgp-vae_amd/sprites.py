@@ -1,0 +1,347 @@
+"""SPRITES SVGPVAE_Hensman step on the HIP library (BASELINE config 4 shape).
+
+Reference call surface mirrored here (eager float64 CUDA tensors instead of TF graph tensors):
+  spritesVAE(L, im_width=64, im_height=64, n_channels=3)                          VAE_utils.py:275-360
+  sprites_representation_network(L, ...)                                           VAE_utils.py:363-391
+  spritesSVGP(titsias, fixed_inducing_points, initial_inducing_points, name, jitter, N_train, L_action,
+              initial_GPLVM_action, L_character, L, fixed_GP_params, fixed_GPLVM, K_obj_normalize, K_SE)
+                                                                                   SVGPVAE_model.py:489-548
+  aux_data_sprites_utils(batch_size, N, repeats)                                   SPRITES_utils.py:317-332
+  forward_pass_SVGPVAE(..., repr_NN=..., segment_ids=..., repeats=...) -> 16-tuple SVGPVAE_model.py:823-936
+and `SpritesStepEngine.train_step` = the reference's `sess.run([optim_step_joint, ...])`
+(SPRITES_experiment.py:386-407) incl. optional element-wise gradient clipping (:234-235).
+
+Every per-pixel / per-row / per-matrix operation is a HIP kernel: tap-table MFMA convolutions
+(conv_taps.hip), batched MFMA GEMMs for the dense layers (linalg.hip), the product-kernel matrices and
+their VJP (gp_sprites.hip), the sparse-GP stages (gp_kernels.hip / gp_large.hip for m > 64), TF1 Adam.
+The reference runs SPRITES in float32; this build computes in float64 (a superset precision).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import STATE, STATE_LEN, MnistCfg, SpritesKcfg, WsLayout, call
+from .conv import ConvLayer
+
+_F64 = torch.float64
+ENC_STRIDES = (1, 2, 1, 2, 1, 2)
+DEC_UP = (True, False, True, False, True, False, False)
+
+
+def aux_data_sprites_utils(batch_size, N, repeats):
+    """SPRITES_utils.py:317-332."""
+    n_char = int(batch_size / N)
+    return np.array([[i] * N for i in range(n_char)]).reshape(-1), [repeats for _ in range(n_char)]
+
+
+def sprites_param_shapes(L, L_character=16):
+    """name -> shape in flat-vector order: spritesVAE encoder, decoder (VAE_utils.py:294-338), repr net (:375-391)."""
+    shp = []
+    for i in range(1, 7):
+        shp += [(f"enc_c{i}_w", (3, 3, 3 if i == 1 else 16, 16)), (f"enc_c{i}_b", (16,))]
+    shp += [("enc_d_w", (1024, 2 * L)), ("enc_d_b", (2 * L,)), ("dec_d_w", (L, 1024)), ("dec_d_b", (1024,))]
+    for i in range(1, 8):
+        co = 16 if i < 7 else 3
+        shp += [(f"dec_c{i}_w", (3, 3, 16, co)), (f"dec_c{i}_b", (co,))]
+    for i, cin in ((1, 3), (2, L_character), (3, L_character)):
+        shp += [(f"repr_c{i}_w", (2, 2, cin, L_character)), (f"repr_c{i}_b", (L_character,))]
+    return shp
+
+
+def glorot_uniform_params(L, L_character=16, seed=0):
+    rng = np.random.RandomState(seed)
+    out = {}
+    for name, shp in sprites_param_shapes(L, L_character):
+        if name.endswith("_b"):
+            out[name] = np.zeros(shp)
+            continue
+        rf = shp[0] * shp[1] if len(shp) == 4 else 1
+        fi, fo = (rf * shp[2], rf * shp[3]) if len(shp) == 4 else shp
+        lim = math.sqrt(6.0 / (fi + fo))
+        out[name] = rng.uniform(-lim, lim, size=shp)
+    return out
+
+
+class spritesVAE:
+    dtype = torch.float64
+
+    def __init__(self, L, im_width=64, im_height=64, n_channels=3, seed=0):
+        if (im_width, im_height, n_channels) != (64, 64, 3):
+            raise NotImplementedError("spritesVAE is specialised to 64x64x3 frames")
+        self.L = L
+        self.seed = seed
+
+
+class sprites_representation_network:
+    dtype = torch.float64
+
+    def __init__(self, L, im_width=64, im_height=64, n_channels=3):
+        self.L = L            # L_character
+
+
+class spritesSVGP:
+    def __init__(self, titsias, fixed_inducing_points, initial_inducing_points, name, jitter, N_train, L_action,
+                 initial_GPLVM_action, L_character, L, fixed_GP_params=False, fixed_GPLVM=False,
+                 K_obj_normalize=False, K_SE=False):
+        if titsias:
+            raise NotImplementedError("SVGPVAE_Titsias branch is not built")
+        self.titsias, self.jitter, self.N_train, self.L = titsias, float(jitter), float(N_train), L
+        self.L_action, self.L_character = L_action, L_character
+        self.fixed_inducing_points, self.fixed_GP_params, self.fixed_GPLVM = \
+            bool(fixed_inducing_points), bool(fixed_GP_params), bool(fixed_GPLVM)
+        self.K_obj_normalize, self.K_SE = bool(K_obj_normalize), bool(K_SE)
+        self.inducing_index_points = torch.as_tensor(np.asarray(initial_inducing_points), dtype=_F64).clone()
+        self.GPLVM_action = torch.as_tensor(np.asarray(initial_GPLVM_action), dtype=_F64).clone()
+        self.nr_inducing = self.inducing_index_points.shape[0]
+        # SVGPVAE_model.py:531-540
+        self.se = torch.tensor([1.0, 0.1, 1.0, 0.1], dtype=_F64)   # l_action, sigma_action, l_character, sigma_character
+
+    def variable_summary(self):
+        return self.GPLVM_action, self.inducing_index_points
+
+
+class SpritesStepEngine:
+    """Buffers + kernel schedule of one rank's SPRITES step."""
+
+    def __init__(self, vae, repr_nn, svgp, *, b_max, seg_len=50, clip_qs=False, geco=False, kappa_squared=0.0075,
+                 alpha=0.99, beta=0.001, lr=1e-3, clip_grad=None, device="cuda:0", params=None):
+        self.lib = _lib.load_library()
+        if not torch.cuda.is_available():
+            raise _lib.SvgpError("SpritesStepEngine needs a HIP device; there is no CPU execution path")
+        self.dev = torch.device(device)
+        self.L, self.La, self.Lc, self.m = vae.L, svgp.L_action, svgp.L_character, svgp.nr_inducing
+        self.n_act = svgp.GPLVM_action.shape[0]
+        self.seg_len, self.clip_grad, self.geco, self.clip_qs = seg_len, clip_grad, bool(geco), bool(clip_qs)
+        self.svgp, self.b_max = svgp, b_max
+        self.stream = torch.cuda.Stream(device=self.dev)
+        f64 = dict(dtype=_F64, device=self.dev)
+        # ---- flat parameter vector: networks, inducing points, GPLVM table, SE hyper-parameters
+        self.shapes = dict(sprites_param_shapes(self.L, self.Lc))
+        self.shapes.update(inducing_index_points=(self.m, self.La + self.Lc), GPLVM_action=(self.n_act, self.La), se=(4,))
+        n_tot = sum(int(np.prod(s)) for s in self.shapes.values())
+        self.theta, self.grad = torch.zeros(n_tot, **f64), torch.zeros(n_tot, **f64)
+        self.adam_m, self.adam_v = torch.zeros(n_tot, **f64), torch.zeros(n_tot, **f64)
+        self.params, self.grads, off = {}, {}, 0
+        for k, s in self.shapes.items():
+            n = int(np.prod(s))
+            self.params[k] = self.theta[off:off + n].view(s)
+            self.grads[k] = self.grad[off:off + n].view(s)
+            off += n
+        init = glorot_uniform_params(self.L, self.Lc, vae.seed) if params is None else params
+        init = dict(init)
+        init.setdefault("inducing_index_points", svgp.inducing_index_points)
+        init.setdefault("GPLVM_action", svgp.GPLVM_action)
+        init.setdefault("se", svgp.se)
+        with torch.cuda.stream(self.stream):
+            for k, v in init.items():
+                self.params[k].copy_(torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v, dtype=_F64)
+                                     .reshape(self.shapes[k]))
+        svgp.inducing_index_points, svgp.GPLVM_action, svgp.se = \
+            self.params["inducing_index_points"], self.params["GPLVM_action"], self.params["se"]
+        # ---- GP workspace (shared stage kernels of the MNIST path; model-agnostic fields only)
+        self.base = dict(m=self.m, L=self.L, M=1, n_obj=0, normalize_obj=0, clip_qs=int(clip_qs), geco=int(geco),
+                         train_ip=1, train_gp=1, train_ov=0, b_cap=b_max, clip_pv=1, n_pix=64 * 64 * 3,
+                         N_train=svgp.N_train, jitter=svgp.jitter, kappa_squared=float(kappa_squared),
+                         alpha=float(alpha), rep_weight=1.0)
+        self.cfg = MnistCfg(b=b_max, b_global=b_max, **self.base)
+        self.wl = WsLayout()
+        call("svgp_mnist_ws_layout_get", C.byref(self.cfg), C.byref(self.wl))
+        self.ws = torch.zeros(self.wl.total, **f64)
+        self.state = torch.zeros(STATE_LEN, **f64)
+        st = torch.zeros(STATE_LEN, dtype=_F64)
+        st[STATE["LAGRANGE"]], st[STATE["ALPHA"]] = 1.0, (0.0 if geco else alpha)
+        st[STATE["LR"]], st[STATE["BETA"]] = lr, beta
+        with torch.cuda.stream(self.stream):
+            self.state.copy_(st)
+        # ---- layers
+        self.enc = [ConvLayer(h, ci, 16, 3, s, "same") for h, ci, s in
+                    zip((64, 64, 32, 32, 16, 16), (3, 16, 16, 16, 16, 16), ENC_STRIDES)]
+        dec_h = (8, 16, 16, 32, 32, 64, 64)
+        self.dec = [ConvLayer(h, 16, 16 if i < 6 else 3, 3, 1, "same", up=u) for i, (h, u) in enumerate(zip(dec_h, DEC_UP))]
+        self.rep = [ConvLayer(h, ci, self.Lc, 2, 2, "same") for h, ci in zip((64, 32, 16), (3, self.Lc, self.Lc))]
+        self.nwg = 256
+        self.scratch = torch.zeros(max(l.scratch_elems(self.nwg) for l in self.enc + self.dec + self.rep), **f64)
+        self.kscratch = torch.zeros(b_max * self.La + (self.m + b_max) * 4 + 16, **f64)
+        self.stream.synchronize()
+        self.act = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _v(self, name, shape):
+        off = getattr(self.wl, name)
+        return self.ws[off:off + int(np.prod(shape))].view(shape)
+
+    def _gemm(self, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, Cm, ldc):
+        call("svgp_dgemm_batched", ta, tb, M, N, K, float(alpha), A.data_ptr(), lda, 0, B.data_ptr(), ldb, 0, float(beta),
+             Cm.data_ptr(), ldc, 0, 1, self.stream.cuda_stream)
+
+    def scalars(self):
+        self.stream.synchronize()
+        st = self.state.cpu()
+        return {k.lower(): float(st[i]) for k, i in STATE.items()}
+
+    def set_scalars(self, **kw):
+        self.stream.synchronize()
+        st = self.state.cpu()
+        for k, v in kw.items():
+            st[STATE[k.upper()]] = float(v)
+        with torch.cuda.stream(self.stream):
+            self.state.copy_(st)
+        self.stream.synchronize()
+
+    # ------------------------------------------------------------------ one step
+    def step(self, images, action_ids, eps=None, adam=True):
+        """images (b,64,64,3), action_ids (b) float64 CUDA tensors; eps (b,L) or None (on-device N(0,1)).
+        Runs forward, reverse, (clip), TF1 Adam when `adam`, and the scalar epilogue."""
+        b = images.shape[0]
+        assert b <= self.b_max and b % self.seg_len == 0
+        p, g, s, L = self.params, self.grads, self.stream.cuda_stream, self.L
+        cfg = MnistCfg(b=b, b_global=b, **self.base)
+        self.cfg = cfg
+        cp = C.byref(cfg)
+        ws, st = self.ws.data_ptr(), self.state.data_ptr()
+        f64 = dict(dtype=_F64, device=self.dev)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.stream):
+            images = images.contiguous()
+            # ---------------- encoder
+            a, x = [], images
+            for i, lay in enumerate(self.enc, 1):
+                out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
+                lay.forward(x, p[f"enc_c{i}_w"], p[f"enc_c{i}_b"], out, s)
+                a.append(out); x = out
+            enc = torch.empty(b, 2 * L, **f64)
+            self._gemm(0, 0, b, 2 * L, 1024, 1.0, x, 1024, p["enc_d_w"], 2 * L, 0.0, enc, 2 * L)
+            mu, var_raw, var = self._v("qnet_mu", (b, L)), self._v("qnet_var_raw", (b, L)), self._v("qnet_var", (b, L))
+            call("svgp_enc_head_fwd", b, L, int(self.clip_qs), p["enc_d_b"].data_ptr(), enc.data_ptr(), mu.data_ptr(),
+                 var_raw.data_ptr(), var.data_ptr(), s)
+            # ---------------- representation network -> aux data
+            r, x = [], images
+            for i, lay in enumerate(self.rep, 1):
+                out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
+                lay.forward(x, p[f"repr_c{i}_w"], p[f"repr_c{i}_b"], out, s)
+                r.append(out); x = out
+            rvec = torch.empty(b, self.Lc, **f64)
+            call("svgp_avgpool_fwd", b, 64, self.Lc, x.data_ptr(), rvec.data_ptr(), s)
+            aux = torch.empty(b, 1 + self.Lc, **f64)
+            aid = action_ids.to(_F64).contiguous()
+            call("svgp_sprites_aux_fwd", b, self.seg_len, self.Lc, rvec.data_ptr(), aid.data_ptr(), aux.data_ptr(), s)
+            # ---------------- kernel matrices + sparse-GP block
+            kc = SpritesKcfg(b=b, m=self.m, La=self.La, Lc=self.Lc, n_act=self.n_act,
+                             normalize=int(self.svgp.K_obj_normalize), k_se=int(self.svgp.K_SE), rep_weight=1.0)
+            K, Kn, knn = self._v("K", (self.m, self.m)), self._v("Kn", (b, self.m)), self._v("knn", (b,))
+            call("svgp_sprites_kernel_matrix_fwd", C.byref(kc), aux.data_ptr(), p["inducing_index_points"].data_ptr(),
+                 p["GPLVM_action"].data_ptr(), p["se"].data_ptr(), K.data_ptr(), Kn.data_ptr(), knn.data_ptr(), s)
+            call("svgp_gp_stats_fwd", cp, ws, s)
+            call("svgp_gp_factor_fwd", cp, ws, s)
+            call("svgp_gp_posterior_fwd", cp, None if eps is None else eps.contiguous().data_ptr(), ws, st, s)
+            # ---------------- decoder
+            z = self._v("z", (b, L))
+            h0 = torch.empty(b, 1024, **f64)
+            self._gemm(0, 0, b, 1024, L, 1.0, z, L, p["dec_d_w"], 1024, 0.0, h0, 1024)
+            call("svgp_bias_add", b, 1024, p["dec_d_b"].data_ptr(), h0.data_ptr(), s)
+            d, x = [], h0.view(b, 8, 8, 16)
+            for i, lay in enumerate(self.dec, 1):
+                out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
+                lay.forward(x, p[f"dec_c{i}_w"], p[f"dec_c{i}_b"], out, s)
+                d.append(out); x = out
+            recon = x
+            tot = b * 64 * 64 * 3
+            call("svgp_sqerr_fwd", tot, min(b, 256), images.data_ptr(), recon.data_ptr(),
+                 self._v("part_sums", (1,)).data_ptr(), s)
+            # ================ reverse
+            dx = torch.empty_like(recon)
+            call("svgp_sqerr_bwd", tot, int(self.geco), b, 64 * 64 * 3, st, images.data_ptr(), recon.data_ptr(),
+                 dx.data_ptr(), s)
+            for i in range(7, 0, -1):
+                lay = self.dec[i - 1]
+                xin = d[i - 2] if i > 1 else h0.view(b, 8, 8, 16)
+                dx = lay.backward(xin, p[f"dec_c{i}_w"], d[i - 1], dx, g[f"dec_c{i}_w"], g[f"dec_c{i}_b"], self.scratch,
+                                  s, nwg=self.nwg)
+            dh0 = dx.view(b, 1024)
+            self._gemm(1, 0, L, 1024, b, 1.0, z, L, dh0, 1024, 0.0, g["dec_d_w"], 1024)
+            g["dec_d_b"].copy_(dh0.sum(0))          # column sum of a (b,1024) matrix: O(b*1024) glue
+            zbar = self._v("zbar", (b, L))
+            self._gemm(0, 1, b, L, 1024, 1.0, dh0, 1024, p["dec_d_w"], 1024, 0.0, zbar, L)
+            call("svgp_gp_stats_bwd", cp, ws, st, s)
+            call("svgp_gp_factor_bwd", cp, ws, st, s)
+            call("svgp_gp_posterior_bwd", cp, ws, st, s)
+            d_char = torch.empty(b, self.Lc, **f64)
+            call("svgp_sprites_kernel_matrix_bwd", C.byref(kc), aux.data_ptr(), p["inducing_index_points"].data_ptr(),
+                 p["GPLVM_action"].data_ptr(), p["se"].data_ptr(), self._v("Kbar", (1,)).data_ptr(),
+                 self._v("Knbar", (1,)).data_ptr(), self._v("knnbar", (1,)).data_ptr(),
+                 g["inducing_index_points"].data_ptr(), g["GPLVM_action"].data_ptr(), d_char.data_ptr(),
+                 g["se"].data_ptr(), self.kscratch.data_ptr(), s)
+            d_rvec = torch.empty(b, self.Lc, **f64)
+            call("svgp_sprites_aux_bwd", b, self.seg_len, self.Lc, d_char.data_ptr(), d_rvec.data_ptr(), s)
+            dx = torch.empty(b, 8, 8, self.Lc, **f64)
+            call("svgp_avgpool_bwd", b, 64, self.Lc, d_rvec.data_ptr(), dx.data_ptr(), s)
+            for i in range(3, 0, -1):
+                xin = r[i - 2] if i > 1 else images
+                dx = self.rep[i - 1].backward(xin, p[f"repr_c{i}_w"], r[i - 1], dx, g[f"repr_c{i}_w"], g[f"repr_c{i}_b"],
+                                              self.scratch, s, need_dx=i > 1, nwg=self.nwg)
+            d_enc = torch.empty(b, 2 * L, **f64)
+            call("svgp_enc_head_bwd", b, L, int(self.clip_qs), var_raw.data_ptr(), self._v("ybar", (1,)).data_ptr(),
+                 self._v("s2bar", (1,)).data_ptr(), d_enc.data_ptr(), s)
+            a6 = a[5].view(b, 1024)
+            self._gemm(1, 0, 1024, 2 * L, b, 1.0, a6, 1024, d_enc, 2 * L, 0.0, g["enc_d_w"], 2 * L)
+            g["enc_d_b"].copy_(d_enc.sum(0))
+            dx = torch.empty(b, 8, 8, 16, **f64)
+            self._gemm(0, 1, b, 1024, 2 * L, 1.0, d_enc, 2 * L, p["enc_d_w"], 2 * L, 0.0, dx, 1024)
+            for i in range(6, 0, -1):
+                xin = a[i - 2] if i > 1 else images
+                dx = self.enc[i - 1].backward(xin, p[f"enc_c{i}_w"], a[i - 1], dx, g[f"enc_c{i}_w"], g[f"enc_c{i}_b"],
+                                              self.scratch, s, need_dx=i > 1, nwg=self.nwg)
+            # frozen parameter groups (inverted flags of SPRITES_experiment.py:109-111)
+            if self.svgp.fixed_inducing_points:
+                g["inducing_index_points"].zero_()
+            if self.svgp.fixed_GPLVM:
+                g["GPLVM_action"].zero_()
+            if self.svgp.fixed_GP_params or not self.svgp.K_SE:
+                g["se"].zero_()
+            call("svgp_mnist_grad_reduce", cp, ws, s)           # scalar partial sums -> ws.sums
+            if self.clip_grad is not None:
+                call("svgp_clip_by_value", self.grad.numel(), float(self.clip_grad), self.grad.data_ptr(), s)
+            if adam:
+                call("svgp_adam_tf1_step", self.theta.numel(), self.theta.data_ptr(), self.grad.data_ptr(),
+                     self.adam_m.data_ptr(), self.adam_v.data_ptr(), st, 0.9, 0.999, 1e-8, s)
+                call("svgp_elbo_finalize", cp, ws, st, s)
+            else:
+                call("svgp_elbo_finalize_noadam", cp, ws, st, s)
+            self.act = dict(recon=recon, aux=aux, enc=enc)
+        return self
+
+    def outputs(self):
+        """The 16-tuple of forward_pass_SVGPVAE for the last step (mean_vectors slot = aux data)."""
+        self.stream.synchronize()
+        b, L = self.cfg.b, self.L
+        sc = self.scalars()
+        t = lambda v: torch.tensor(v, dtype=_F64, device=self.dev)
+        w = lambda n: self._v(n, (b, L)).clone()
+        return (t(sc["elbo"]), t(sc["recon_loss"]), t(sc["kl_term"]), t(sc["inside_elbo"]), t(sc["ce_term"]), w("p_m"),
+                w("p_v"), w("qnet_mu"), w("qnet_var"), self.act["recon"], t(sc["inside_recon"]), t(sc["inside_kl"]),
+                w("z"), t(sc["c_ma"]), t(sc["lagrange"]), self.act["aux"])
+
+
+def forward_pass_SVGPVAE(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha, kappa, clipping_qs=False, GECO=False,
+                         repr_NN=None, segment_ids=None, repeats=None, bias_analysis=False, epsilon=None, params=None,
+                         engine=None):
+    """SVGPVAE_model.py:823-936 with repr_NN set (SPRITES).  data_batch = (frames (b,64,64,3), action_IDs (b)).
+    segment_ids / repeats as produced by aux_data_sprites_utils: equal-length contiguous segments."""
+    if repr_NN is None:
+        raise ValueError("SPRITES path needs the representation network (use SVGPVAE_model.forward_pass_SVGPVAE for MNIST)")
+    frames, action_ids = data_batch
+    b = frames.shape[0]
+    seg_len = int(repeats[0]) if repeats is not None else b
+    eng = engine or getattr(svgp, "_engine", None)
+    if eng is None or eng.b_max < b or eng.seg_len != seg_len or eng.geco != bool(GECO) or eng.clip_qs != bool(clipping_qs):
+        eng = SpritesStepEngine(vae, repr_NN, svgp, b_max=b, seg_len=seg_len, clip_qs=clipping_qs, geco=GECO,
+                                kappa_squared=float(kappa) ** 2, beta=float(beta), params=params)
+        svgp._engine = eng
+    eng.set_scalars(beta=float(beta), c_ma=float(C_ma), lagrange=float(lagrange_mult), alpha=float(alpha))
+    dev = eng.dev
+    eng.step(frames.to(dev, _F64), action_ids.to(dev, _F64), None if epsilon is None else epsilon.to(dev, _F64),
+             adam=False)
+    return eng.outputs()

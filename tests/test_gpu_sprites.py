@@ -1,0 +1,100 @@
+"""SPRITES SVGPVAE_Hensman step (spritesVAE + representation network + spritesSVGP product kernel) on the GPU
+against the oracle restatement: the 16-tuple, and every gradient (networks, inducing points, GPLVM action table,
+SE hyper-parameters), for the linear / cosine-normalised / squared-exponential kernels, both GP paths (m <= 64 LDS,
+m = 72 global-memory GEMM), beta-ELBO and GECO, with the reference's p_v clipping and gradient clipping."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sprites_oracle as SO
+
+pytestmark = pytest.mark.gpu
+DT = torch.float64
+
+
+def _problem(b, frames, L, La, Lc, m, n_act, seed):
+    g = torch.Generator().manual_seed(seed)
+    params = {k: torch.tensor(v, dtype=DT) for k, v in SO.glorot_init(L, Lc, seed).items()}
+    for k in params:
+        if k.endswith("_b"):
+            params[k] = 0.05 * torch.randn(*params[k].shape, dtype=DT, generator=g)
+    gp = dict(inducing_index_points=torch.randn(m, La + Lc, dtype=DT, generator=g) * 1.5,
+              GPLVM_action=torch.randn(n_act, La, dtype=DT, generator=g) * 1.5,
+              # SE scales chosen so that kernel values are O(0.1..1) for N(0,1.5^2) features (distances ~6-8)
+              l_action=torch.tensor(5.0, dtype=DT), sigma_action=torch.tensor(1.4, dtype=DT),
+              l_character=torch.tensor(7.0, dtype=DT), sigma_character=torch.tensor(1.2, dtype=DT))
+    images = torch.rand(b, 64, 64, 3, dtype=DT, generator=g)
+    ids = torch.randint(0, n_act, (b,), generator=g)
+    eps = torch.randn(b, L, dtype=DT, generator=g)
+    seg, rep = SO.aux_data_sprites_utils(b, frames, frames)
+    return params, gp, images, ids, eps, seg, rep
+
+
+def _rel(a, c):
+    a, c = torch.as_tensor(a, dtype=DT).cpu().reshape(-1), torch.as_tensor(c, dtype=DT).cpu().reshape(-1)
+    return float((a - c).abs().max() / max(float(c.abs().max()), 1e-9))     # gradients below 1e-9 are noise
+
+
+@pytest.mark.parametrize("K_SE,norm,GECO,m,clip", [(False, False, False, 10, None), (False, True, True, 12, None),
+                                                  (True, False, True, 10, 0.05), (False, False, True, 72, None)])
+def test_sprites_step_matches_oracle(K_SE, norm, GECO, m, clip):
+    from svgp_vae_amd import sprites as S
+    b, frames, L, La, Lc, n_act = 8, 4, 6, 8, 16, 9
+    params, gp, images, ids, eps, seg, rep = _problem(b, frames, L, La, Lc, m, n_act, seed=m + int(K_SE))
+    kappa, jitter, N_train = math.sqrt(0.0075), 0.01, 100.0
+    kw = dict(beta=0.001, C_ma=torch.tensor(0.02, dtype=DT), lagrange_mult=torch.tensor(1.4, dtype=DT), alpha=0.9,
+              kappa=kappa, L=L, L_action=La, jitter=jitter, N_train=N_train, segment_ids=seg, repeats=rep,
+              clipping_qs=True, GECO=GECO, K_obj_normalize=norm, K_SE=K_SE, clip_grad=clip)
+    want, wgrads = SO.loss_and_grads(params, gp, (images, ids), eps, formulation="efficient", **kw)
+
+    vae = S.spritesVAE(L)
+    rnn = S.sprites_representation_network(Lc)
+    svgp = S.spritesSVGP(False, False, gp["inducing_index_points"].numpy(), 'main', jitter, N_train, La,
+                         gp["GPLVM_action"].numpy(), Lc, L, fixed_GP_params=False, fixed_GPLVM=False,
+                         K_obj_normalize=norm, K_SE=K_SE)
+    init = dict(params)
+    init["se"] = torch.stack([gp["l_action"], gp["sigma_action"], gp["l_character"], gp["sigma_character"]])
+    eng = S.SpritesStepEngine(vae, rnn, svgp, b_max=b, seg_len=frames, clip_qs=True, geco=GECO,
+                              kappa_squared=0.0075, beta=0.001, clip_grad=clip, params=init)
+    eng.set_scalars(c_ma=0.02, lagrange=1.4, alpha=0.9)
+    dev = eng.dev
+    eng.step(images.to(dev), ids.to(dev, DT), eps.to(dev), adam=False)
+    got = eng.outputs()
+    bad = []
+    for i in range(16):
+        e = _rel(got[i], want[i])
+        if not e < 1e-8:
+            bad.append(f"tuple[{i}] rel {e:.3e}")
+    g = eng.grads
+    for k, w in wgrads.items():
+        if k in ("l_action", "sigma_action", "l_character", "sigma_character"):
+            continue
+        e = _rel(g[k], w)
+        if not e < 1e-6:
+            bad.append(f"grad {k} rel {e:.3e} (max {float(w.abs().max()):.2e})")
+    if K_SE:
+        wse = torch.stack([wgrads[k] for k in ("l_action", "sigma_action", "l_character", "sigma_character")])
+        e = _rel(g["se"], wse)
+        if not e < 1e-6:
+            bad.append(f"grad se rel {e:.3e}")
+    assert not bad, "\n".join(bad)
+
+
+def test_sprites_training_steps_reduce_the_loss():
+    from svgp_vae_amd import sprites as S
+    b, frames, L, La, Lc, m, n_act = 8, 4, 6, 8, 16, 18, 9
+    params, gp, images, ids, eps, seg, rep = _problem(b, frames, L, La, Lc, m, n_act, seed=3)
+    svgp = S.spritesSVGP(False, False, gp["inducing_index_points"].numpy(), 'main', 0.01, 100.0, La,
+                         gp["GPLVM_action"].numpy(), Lc, L, K_obj_normalize=True)
+    eng = S.SpritesStepEngine(S.spritesVAE(L), S.sprites_representation_network(Lc), svgp, b_max=b, seg_len=frames,
+                              geco=True, lr=3e-3, clip_grad=1e6)
+    dev = eng.dev
+    di, da = images.to(dev), ids.to(dev, DT)
+    losses = []
+    for _ in range(8):
+        eng.step(di, da, None, adam=True)
+        losses.append(eng.scalars()["recon_loss"])
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    assert eng.scalars()["adam_t"] == 8.0

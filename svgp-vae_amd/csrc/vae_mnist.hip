@@ -19,145 +19,178 @@ namespace {
 #define VAE_NT 512          // threads per workgroup of the VAE kernels (8 waves: 2 per SIMD)
 #define VAE_SCRATCH 4096    // reals of LDS scratch for the weight-gradient chunk reduction
 
-// 3x3 convolution on an LDS-resident NHWC tile.  Stored input is HS x HS x CIN; the effective
-// input is its nearest-neighbour upsampling by UPS (HE = HS*UPS) zero-padded by PAD.
-// All loops are branch-free inside (clamped address + select), so the unrolled bodies expose many
-// independent LDS reads per thread; each thread produces a small register tile.
+typedef double d4v_t __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// In-LDS gather-GEMM on the f64 MFMA: the conv im2col-GEMMs of the per-image kernels.
+//   gg_fwd  : out[(y*osy+ooy)*Wo + x*osx+oox][co] = epi(bias[co] + sum_t sum_ci in[(y*sy+oy_t)*Wi + x*sx+ox_t][ci] W_t[ci][co])
+//             A[i = pixel][k = ci] gathered per lane (zero outside the tile), B[k = ci][j = co] from LDS weights,
+//             one v_mfma_f64_16x16x4 per (tap, 4 channels); a wave owns 16 consecutive pixels of the iteration space.
+//             TW: weights stored [co][ci] are read transposed (data gradient).
+//   gg_wgrad: gW_t[ci][co] += sum_pixels in_t[pixel][ci] * dout[pixel][co]; A[i = ci][k = pixel], B[k = pixel][j = co];
+//             a wave owns whole taps, so the LDS accumulators need no atomics.
+// LDS bank conflicts of the 16-pixel gathers (stride Ci doubles) cost a few cycles per fetch and hide under the
+// 64-cycle issue of the f64 MFMA.
+// ---------------------------------------------------------------------------------------------
+template <int NTAP, bool TW, bool ELU_BIAS, int CI, int CO>
+__device__ __forceinline__ void gg_fwd(const real* in, int Hi, int Wi, int Hs, int Ws, int sy, int sx,
+                                       const int (&oy)[NTAP], const int (&ox)[NTAP], const int (&woff)[NTAP],
+                                       const real* W, int ldw, const real* bias, real* out, int Wo, int osy, int osx,
+                                       int ooy, int oox) {
+    constexpr int KQ = (CI + 3) / 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = VAE_NT >> 6, r = lane & 15, q = lane >> 4;
+    const int NP = Hs * Ws, ngrp = (NP + 15) >> 4;
+    // B operands (weights) do not depend on the pixel group: fetched once, unconditionally (clamped index + select)
+    real breg[NTAP * KQ];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int kq = 0; kq < KQ; ++kq) {
+            const int c = kq * 4 + q, cc = c < CI ? c : CI - 1, rc = r < CO ? r : CO - 1;
+            const real v = W[woff[t] + (TW ? rc * ldw + cc : cc * ldw + rc)];
+            breg[t * KQ + kq] = (c < CI && r < CO) ? v : real(0);
+        }
+    for (int grp = wave; grp < ngrp; grp += nwave) {
+        const int pa = grp * 16 + r;
+        const bool pv = pa < NP;
+        const int ya = pv ? pa / Ws : 0, xa = pv ? pa % Ws : 0;
+        // A operands of the whole group first (independent LDS reads in flight together), then the MFMA chain
+        real areg[NTAP * KQ];
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            const int iy = ya * sy + oy[t], ix = xa * sx + ox[t];
+            const bool valid = pv && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
+            const real* ap = in + (valid ? (iy * Wi + ix) * CI : 0);
+#pragma unroll
+            for (int kq = 0; kq < KQ; ++kq) {
+                const int c = kq * 4 + q, cc = c < CI ? c : CI - 1;
+                const real v = ap[cc];
+                areg[t * KQ + kq] = (valid && c < CI) ? v : real(0);
+            }
+        }
+        d4v_t acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < NTAP * KQ; ++i) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(areg[i], breg[i], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int po = grp * 16 + q + 4 * e;
+            if (po < NP && r < CO) {
+                const int y = po / Ws, x = po % Ws;
+                real v = acc[e];
+                if (ELU_BIAS) v = elu_f(v + bias[r]);
+                out[((y * osy + ooy) * Wo + x * osx + oox) * CO + r] = v;
+            }
+        }
+    }
+}
+
+struct TapP { int oy, ox, woff, ooy, oox; };
+template <int NTAP, int CI, int CO, typename TapFn>
+__device__ __forceinline__ void gg_wgrad(const real* in, int Hi, int Wi, int Hs, int Ws, int sy, int sx, TapFn tapfn,
+                                         const real* dout, int Wo, int osy, int osx, real* gW) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = VAE_NT >> 6, r = lane & 15, q = lane >> 4;
+    const int NP = Hs * Ws;
+    const int rci = r < CI ? r : CI - 1, rco = r < CO ? r : CO - 1;
+#pragma unroll 1
+    for (int t = wave; t < NTAP; t += nwave) {
+        const TapP tp = tapfn(t);
+        d4v_t acc = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < NP; k0 += 16) {       // four k-steps per trip, operands fetched together
+            real av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = k0 + 4 * u + q;
+                const bool pv = p < NP;
+                const int y = pv ? p / Ws : 0, x = pv ? p % Ws : 0;
+                const int iy = y * sy + tp.oy, ix = x * sx + tp.ox;
+                const bool valid = pv && ((unsigned)iy < (unsigned)Hi) && ((unsigned)ix < (unsigned)Wi);
+                const real a0 = in[(valid ? (iy * Wi + ix) * CI : 0) + rci];
+                const real b0 = dout[((y * osy + tp.ooy) * Wo + x * osx + tp.oox) * CO + rco];
+                av[u] = (valid && r < CI) ? a0 : real(0);
+                bv[u] = (pv && r < CO) ? b0 : real(0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ci = q + 4 * e;
+            if (ci < CI && r < CO) gW[tp.woff + ci * CO + r] += acc[e];
+        }
+    }
+}
+
+// bias gradient: gb[co] += sum_pixels dpre[p][co]; 32 pixel chunks per channel combined through scratch
+template <int NPIX, int COUT>
+__device__ __forceinline__ void bias_grad(const real* dpre, real* gb, real* scratch) {
+    constexpr int BCH = 32;
+    if (threadIdx.x < BCH * COUT) {
+        const int co = threadIdx.x % COUT, chunk2 = threadIdx.x / COUT;
+        real s = 0;
+        for (int p = chunk2; p < NPIX; p += BCH) s += dpre[p * COUT + co];
+        scratch[threadIdx.x] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < COUT) {
+        real t = 0;
+#pragma unroll
+        for (int c = 0; c < BCH; ++c) t += scratch[c * COUT + threadIdx.x];
+        gb[threadIdx.x] += t;
+    }
+    __syncthreads();
+}
+
+// 3x3 convolution, stride STRIDE, no padding, no upsampling (the mnistVAE encoder layers, VAE_utils.py:117-122)
+// on an LDS-resident NHWC tile, via the MFMA gather-GEMMs above.
 template <int HS, int UPS, int PAD, int STRIDE, int CIN, int COUT, int HOUT>
 struct Conv3 {
-    static constexpr int HE = HS * UPS;
+    static_assert(UPS == 1 && PAD == 0 && STRIDE == 2, "encoder layers: stride-2 valid convolutions");
     static constexpr int NW = 9 * CIN * COUT;
-    static constexpr int NOUT = HOUT * HOUT * COUT;
-    static constexpr int NIN = HS * HS * CIN;
     static constexpr int NPIX = HOUT * HOUT;
-    static constexpr int COG = (COUT % 2 == 0) ? 2 : 1;   // outputs per forward item
-    static constexpr int NCG = COUT / COG;
-    static constexpr int CIG = (CIN % 2 == 0) ? 2 : 1;    // inputs per bwd-data item
-    static constexpr int NIG = CIN / CIG;
 
-    // out = elu(conv(in) + bias); item = (pixel, group of COG output channels)
     static __device__ void fwd(const real* in, const real* w, const real* bias, real* out) {
-        for (int it = threadIdx.x; it < NPIX * NCG; it += VAE_NT) {
-            const int cg = it % NCG, p = it / NCG, x = p % HOUT, y = p / HOUT;
-            real acc[COG];
+        const int oy[9] = {0, 0, 0, 1, 1, 1, 2, 2, 2}, ox[9] = {0, 1, 2, 0, 1, 2, 0, 1, 2};
+        int wo[9];
 #pragma unroll
-            for (int g = 0; g < COG; ++g) acc[g] = bias[cg * COG + g];
-#pragma unroll 1
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = y * STRIDE + ky - PAD;
-                const bool vy = (unsigned)iy < (unsigned)HE;
-                const int cy = vy ? iy / UPS : 0;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = x * STRIDE + kx - PAD;
-                    const bool valid = vy && ((unsigned)ix < (unsigned)HE);
-                    const int cx = valid ? ix / UPS : 0;
-                    const real* src = in + (cy * HS + cx) * CIN;
-                    const real* wk = w + ((ky * 3 + kx) * CIN) * COUT + cg * COG;
-#pragma unroll
-                    for (int ci = 0; ci < CIN; ++ci) {
-                        const real a = valid ? src[ci] : real(0);
-#pragma unroll
-                        for (int g = 0; g < COG; ++g) acc[g] += a * wk[ci * COUT + g];
-                    }
-                }
-            }
-#pragma unroll
-            for (int g = 0; g < COG; ++g) out[p * COUT + cg * COG + g] = elu_f(acc[g]);
-        }
+        for (int t = 0; t < 9; ++t) wo[t] = t * CIN * COUT;
+        gg_fwd<9, false, true, CIN, COUT>(in, HS, HS, HOUT, HOUT, 2, 2, oy, ox, wo, w, COUT, bias, out, HOUT, 1, 1, 0, 0);
     }
 
-    // din (stored coordinates) = conv^T(dpre) summed over the UPS x UPS replicas;
-    // item = (stored pixel, group of CIG input channels)
+    // din[iy][ix][ci] = sum_{ky,kx: (iy-ky), (ix-kx) even} dpre[(iy-ky)/2][(ix-kx)/2][co] w[ky][kx][ci][co]:
+    // four input-parity classes, each a gather-GEMM with the taps of matching parity
     static __device__ void bwd_data(const real* dpre, const real* w, real* din) {
-        for (int it = threadIdx.x; it < HS * HS * NIG; it += VAE_NT) {
-            const int ig = it % NIG, ps = it / NIG, xs = ps % HS, ys = ps / HS;
-            real acc[CIG];
-#pragma unroll
-            for (int g = 0; g < CIG; ++g) acc[g] = 0;
-#pragma unroll 1
-            for (int dy = 0; dy < UPS; ++dy)
-#pragma unroll 1
-                for (int dx = 0; dx < UPS; ++dx) {
-                    const int ye = ys * UPS + dy, xe = xs * UPS + dx;
-#pragma unroll 1
-                    for (int ky = 0; ky < 3; ++ky) {
-                        const int ty = ye + PAD - ky;
-                        const bool vy = ty >= 0 && (ty % STRIDE) == 0 && (ty / STRIDE) < HOUT;
-                        const int y = vy ? ty / STRIDE : 0;
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) {
-                            const int tx = xe + PAD - kx;
-                            const bool valid = vy && tx >= 0 && (tx % STRIDE) == 0 && (tx / STRIDE) < HOUT;
-                            const int x = valid ? tx / STRIDE : 0;
-                            const real* dp = dpre + (y * HOUT + x) * COUT;
-                            const real* wk = w + ((ky * 3 + kx) * CIN + ig * CIG) * COUT;
-#pragma unroll
-                            for (int co = 0; co < COUT; ++co) {
-                                const real d = valid ? dp[co] : real(0);
-#pragma unroll
-                                for (int g = 0; g < CIG; ++g) acc[g] += d * wk[g * COUT + co];
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-            for (int g = 0; g < CIG; ++g) din[ps * CIN + ig * CIG + g] = acc[g];
+        // parity 0: ky in {0, 2} (offsets 0, -1);  parity 1: ky = 1 (offset 0)
+        {   // (py, px) = (0, 0): 4 taps
+            const int oy[4] = {0, 0, -1, -1}, ox[4] = {0, -1, 0, -1};
+            const int wo[4] = {(0 * 3 + 0) * CIN * COUT, (0 * 3 + 2) * CIN * COUT, (2 * 3 + 0) * CIN * COUT, (2 * 3 + 2) * CIN * COUT};
+            gg_fwd<4, true, false, COUT, CIN>(dpre, HOUT, HOUT, (HS + 1) / 2, (HS + 1) / 2, 1, 1, oy, ox, wo, w, COUT, nullptr,
+                                              din, HS, 2, 2, 0, 0);
+        }
+        {   // (0, 1): ky in {0,2}, kx = 1
+            const int oy[2] = {0, -1}, ox[2] = {0, 0};
+            const int wo[2] = {(0 * 3 + 1) * CIN * COUT, (2 * 3 + 1) * CIN * COUT};
+            gg_fwd<2, true, false, COUT, CIN>(dpre, HOUT, HOUT, (HS + 1) / 2, HS / 2, 1, 1, oy, ox, wo, w, COUT, nullptr, din,
+                                              HS, 2, 2, 0, 1);
+        }
+        {   // (1, 0): ky = 1, kx in {0,2}
+            const int oy[2] = {0, 0}, ox[2] = {0, -1};
+            const int wo[2] = {(1 * 3 + 0) * CIN * COUT, (1 * 3 + 2) * CIN * COUT};
+            gg_fwd<2, true, false, COUT, CIN>(dpre, HOUT, HOUT, HS / 2, (HS + 1) / 2, 1, 1, oy, ox, wo, w, COUT, nullptr, din,
+                                              HS, 2, 2, 1, 0);
+        }
+        {   // (1, 1): ky = kx = 1
+            const int oy[1] = {0}, ox[1] = {0};
+            const int wo[1] = {(1 * 3 + 1) * CIN * COUT};
+            gg_fwd<1, true, false, COUT, CIN>(dpre, HOUT, HOUT, HS / 2, HS / 2, 1, 1, oy, ox, wo, w, COUT, nullptr, din, HS, 2,
+                                              2, 1, 1);
         }
     }
 
-    // gw[(ky,kx,ci,co)] += sum_pixels in * dpre ;  gb[co] += sum_pixels dpre.
-    // item = (tap, ci, pixel chunk) producing all COUT outputs; chunks are combined through
-    // `scratch` (>= VAE_SCRATCH reals) in a fixed order.  Ends with a barrier.
+    // gw += sum_pixels in * dpre ; gb += sum_pixels dpre.  Ends with a barrier.
     static __device__ void bwd_weight(const real* in, const real* dpre, real* gw, real* gb, real* scratch) {
-        constexpr int NTC = 9 * CIN;
-        constexpr int NCH0 = VAE_NT / NTC;
-        constexpr int NCH1 = VAE_SCRATCH / NW;
-        constexpr int NCH = NCH0 < NCH1 ? (NCH0 < 1 ? 1 : NCH0) : NCH1;
-        const int tc = threadIdx.x % NTC, chunk = threadIdx.x / NTC;
-        if (chunk < NCH) {
-            const int ci = tc % CIN, kx = (tc / CIN) % 3, ky = tc / (CIN * 3);
-            real acc[COUT];
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) acc[co] = 0;
-#pragma unroll 2
-            for (int p = chunk; p < NPIX; p += NCH) {
-                const int y = p / HOUT, x = p % HOUT;
-                const int iy = y * STRIDE + ky - PAD, ix = x * STRIDE + kx - PAD;
-                const bool valid = ((unsigned)iy < (unsigned)HE) && ((unsigned)ix < (unsigned)HE);
-                const int cy = valid ? iy / UPS : 0, cx = valid ? ix / UPS : 0;
-                const real a = valid ? in[(cy * HS + cx) * CIN + ci] : real(0);
-                const real* dp = dpre + p * COUT;
-#pragma unroll
-                for (int co = 0; co < COUT; ++co) acc[co] += a * dp[co];
-            }
-#pragma unroll
-            for (int co = 0; co < COUT; ++co) scratch[chunk * NW + tc * COUT + co] = acc[co];
-        }
-        __syncthreads();
-        for (int widx = threadIdx.x; widx < NW; widx += VAE_NT) {
-            real s = 0;
-#pragma unroll
-            for (int c = 0; c < NCH; ++c) s += scratch[c * NW + widx];
-            gw[widx] += s;
-        }
-        __syncthreads();
-        // bias: item (co, pixel chunk), 32 chunks
-        constexpr int BCH = 32;
-        if (threadIdx.x < BCH * COUT) {
-            const int co = threadIdx.x % COUT, chunk2 = threadIdx.x / COUT;
-            real s = 0;
-            for (int p = chunk2; p < NPIX; p += BCH) s += dpre[p * COUT + co];
-            scratch[threadIdx.x] = s;
-        }
-        __syncthreads();
-        if (threadIdx.x < COUT) {
-            real t = 0;
-#pragma unroll
-            for (int c = 0; c < BCH; ++c) t += scratch[c * COUT + threadIdx.x];
-            gb[threadIdx.x] += t;
-        }
-        __syncthreads();
+        auto tapfn = [](int t) { return TapP{t / 3, t % 3, t * CIN * COUT, 0, 0}; };
+        gg_wgrad<9, CIN, COUT>(in, HS, HS, HOUT, HOUT, 2, 2, tapfn, dpre, HOUT, 1, 1, gw);
+        bias_grad<NPIX, COUT>(dpre, gb, scratch);
     }
 };
 
@@ -211,8 +244,10 @@ struct UpConv3 {
         }
     }
 
+    // ---- VALU variants (register-tiled LDS loops): faster than the MFMA forms where the tile would be mostly
+    //      padding (single output channel) or the gather arithmetic dominates; chosen per layer from ablation timings
     // out = elu(conv(up(in)) + bias); item = (output pixel, group of COG channels)
-    static __device__ void fwd(const real* in, const real* We, const real* bias, real* out) {
+    static __device__ void fwd_valu(const real* in, const real* We, const real* bias, real* out) {
         for (int it = threadIdx.x; it < NPIX * NCG; it += VAE_NT) {
             const int cg = it % NCG, p = it / NCG, x = p % HOUT, y = p / HOUT;
             const int by = y - PAD, bx = x - PAD, py = by & 1, px = bx & 1, Y = by >> 1, X = bx >> 1;
@@ -244,7 +279,7 @@ struct UpConv3 {
     }
 
     // din (HS x HS x CIN) from dpre (HOUT x HOUT x COUT); item = (stored pixel, group of CIG channels)
-    static __device__ void bwd_data(const real* dpre, const real* We, real* din) {
+    static __device__ void bwd_data_valu(const real* dpre, const real* We, real* din) {
         for (int it = threadIdx.x; it < HS * HS * NIG; it += VAE_NT) {
             const int ig = it % NIG, ps = it / NIG, Xs = ps % HS, Ys = ps / HS;
             real acc[CIG];
@@ -277,7 +312,7 @@ struct UpConv3 {
 
     // gWe += sum_pixels in * dpre ; gb += sum_pixels dpre.  item = (class, tap, ci, pixel chunk) -> COUT
     // outputs; chunks combined through `scratch` (>= VAE_SCRATCH reals) in fixed order.  Ends with a barrier.
-    static __device__ void bwd_weight(const real* in, const real* dpre, real* gWe, real* gb, real* scratch) {
+    static __device__ void bwd_weight_valu(const real* in, const real* dpre, real* gWe, real* gb, real* scratch) {
         constexpr int NTC = 16 * CIN;
         constexpr int NCH0 = VAE_NT / NTC, NCH1 = VAE_SCRATCH / NWE;
         constexpr int NCH = NCH0 < NCH1 ? (NCH0 < 1 ? 1 : NCH0) : NCH1;
@@ -326,6 +361,77 @@ struct UpConv3 {
             gb[threadIdx.x] += t;
         }
         __syncthreads();
+    }
+
+    // out = elu(conv(up(in)) + bias): four output-parity classes, each a 4-tap MFMA gather-GEMM on the low-res input
+    static __device__ void fwd_mfma(const real* in, const real* We, const real* bias, real* out) {
+#pragma unroll
+        for (int cls = 0; cls < 4; ++cls) {
+            const int opy = cls >> 1, opx = cls & 1;
+            const int by = opy - PAD, bx = opx - PAD, py = by & 1, px = bx & 1, dY = (by - py) / 2, dX = (bx - px) / 2;
+            const int oy[4] = {dY, dY, dY + 1, dY + 1}, ox[4] = {dX, dX + 1, dX, dX + 1};
+            int wo[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) wo[t] = ((py * 2 + px) * 4 + t) * CIN * COUT;
+            gg_fwd<4, false, true, CIN, COUT>(in, HS, HS, HOUT / 2, HOUT / 2, 1, 1, oy, ox, wo, We, COUT, bias, out, HOUT, 2, 2,
+                                              opy, opx);
+        }
+    }
+
+    // din (HS x HS x CIN) from dpre (HOUT x HOUT x COUT): one 16-tap gather-GEMM with input stride 2 over dpre
+    static __device__ void bwd_data_mfma(const real* dpre, const real* We, real* din) {
+        int oy[16], ox[16], wo[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int py = (t >> 3) & 1, ty = (t >> 2) & 1, px = (t >> 1) & 1, tx = t & 1;
+            oy[t] = py + PAD - 2 * ty;
+            ox[t] = px + PAD - 2 * tx;
+            wo[t] = ((py * 2 + px) * 4 + ty * 2 + tx) * CIN * COUT;
+        }
+        gg_fwd<16, true, false, COUT, CIN>(dpre, HOUT, HOUT, HS, HS, 2, 2, oy, ox, wo, We, COUT, nullptr, din, HS, 1, 1, 0, 0);
+    }
+
+    // gWe += sum_pixels in * dpre ; gb += sum_pixels dpre.  Ends with a barrier.
+    static __device__ void bwd_weight_mfma(const real* in, const real* dpre, real* gWe, real* gb, real* scratch) {
+        if (COUT >= 2) {
+            // 16 (class, tap) pairs = 16 "taps" of one gather-GEMM over the HOUT/2 x HOUT/2 class grid
+            auto tapfn = [](int t) {
+                const int opy = (t >> 3) & 1, opx = (t >> 2) & 1, ty = (t >> 1) & 1, tx = t & 1;
+                const int by = opy - PAD, bx = opx - PAD, py = by & 1, px = bx & 1;
+                return TapP{(by - py) / 2 + ty, (bx - px) / 2 + tx, ((py * 2 + px) * 4 + ty * 2 + tx) * CIN * COUT, opy, opx};
+            };
+            gg_wgrad<16, CIN, COUT>(in, HS, HS, HOUT / 2, HOUT / 2, 1, 1, tapfn, dpre, HOUT, 2, 2, gWe);
+        } else {
+            // single output channel: item = (class, tap, pixel chunk), 32 chunks; all CIN inputs of a pixel per item
+            constexpr int NCH = VAE_NT / 16;
+            constexpr int NG = HS + 1;                  // candidate Y (and X): -1 .. HS-1
+            const int ct = threadIdx.x & 15, chunk = threadIdx.x >> 4;
+            const int cls = ct >> 2, tap = ct & 3, ty = tap >> 1, tx = tap & 1, py = cls >> 1, px = cls & 1;
+            real acc[CIN];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) acc[ci] = 0;
+            for (int idx = chunk; idx < NG * NG; idx += NCH) {
+                const int Y = idx / NG - 1, X = idx % NG - 1;
+                const int y = 2 * Y + py + PAD, x = 2 * X + px + PAD, sy = Y + ty, sx = X + tx;
+                const bool valid = ((unsigned)y < (unsigned)HOUT) && ((unsigned)x < (unsigned)HOUT) &&
+                                   ((unsigned)sy < (unsigned)HS) && ((unsigned)sx < (unsigned)HS);
+                const real d = valid ? dpre[y * HOUT + x] : real(0);
+                const real* ip = in + (valid ? (sy * HS + sx) * CIN : 0);
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) acc[ci] += ip[ci] * d;
+            }
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) scratch[chunk * (16 * CIN) + ct * CIN + ci] = acc[ci];
+            __syncthreads();
+            for (int widx = threadIdx.x; widx < 16 * CIN; widx += VAE_NT) {
+                real s = 0;
+#pragma unroll 8
+                for (int c = 0; c < NCH; ++c) s += scratch[c * (16 * CIN) + widx];
+                gWe[widx] += s;
+            }
+        }
+        __syncthreads();
+        bias_grad<NPIX, COUT>(dpre, gb, scratch);
     }
 };
 
@@ -498,9 +604,10 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_fwd(int b, int L, const real
     real* We2 = We1 + UpC1::NWE;
     real* We3 = We2 + UpC2::NWE;
     lds_copy_in(w, th_dec, od.n);
-    UpC1::build_weff(th_dec + od.c1w, We1);
-    UpC2::build_weff(th_dec + od.c2w, We2);
-    UpC3::build_weff(th_dec + od.c3w, We3);
+    __syncthreads();
+    UpC1::build_weff(w + od.c1w, We1);       // from the LDS copy (one coalesced read of the raw weights)
+    UpC2::build_weff(w + od.c2w, We2);
+    UpC3::build_weff(w + od.c3w, We3);
     real sq = 0;
     for (int n = blockIdx.x; n < b; n += gridDim.x) {
         __syncthreads();
@@ -512,11 +619,11 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_fwd(int b, int L, const real
             h0[threadIdx.x] = acc;
         }
         __syncthreads();
-        UpC1::fwd(h0, We1, w + od.c1b, a1);
+        UpC1::fwd_valu(h0, We1, w + od.c1b, a1);
         __syncthreads();
-        UpC2::fwd(a1, We2, w + od.c2b, a2);
+        UpC2::fwd_valu(a1, We2, w + od.c2b, a2);
         __syncthreads();
-        UpC3::fwd(a2, We3, w + od.c3b, out);
+        UpC3::fwd_valu(a2, We3, w + od.c3b, out);
         __syncthreads();
         lds_copy_out(h0g + (size_t)n * 128, h0, 128);
         lds_copy_out(a1g + (size_t)n * 512, a1, 512);
@@ -566,9 +673,11 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int dbg_stop, int b, int
     lds_copy_in(w, th_dec + od.dw, L * 128);
     lds_zero(g, od.n);
     lds_zero(gWe1, DEC_NWE);
-    UpC1::build_weff(th_dec + od.c1w, We1);
-    UpC2::build_weff(th_dec + od.c2w, We2);
-    UpC3::build_weff(th_dec + od.c3w, We3);
+    lds_copy_in(scratch, th_dec + od.c1w, od.n - od.c1w);      // raw conv weights (+biases), staged once
+    __syncthreads();
+    UpC1::build_weff(scratch, We1);
+    UpC2::build_weff(scratch + (od.c2w - od.c1w), We2);
+    UpC3::build_weff(scratch + (od.c3w - od.c1w), We3);
     const real gscale = (geco ? state[SVGP_ST_LAGRANGE] * inv_bglobal : real(1)) / real(784);
     for (int n = blockIdx.x; n < b; n += gridDim.x) {
         __syncthreads();
@@ -582,23 +691,23 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int dbg_stop, int b, int
         }
         __syncthreads();
         if (dbg_stop == 1) continue;
-        UpC3::bwd_weight(a2, d3, gWe3, g + od.c3b, scratch);
+        UpC3::bwd_weight_mfma(a2, d3, gWe3, g + od.c3b, scratch);     // COUT = 1: chunked VALU form inside
         if (dbg_stop == 2) continue;
-        UpC3::bwd_data(d3, We3, d2);
+        UpC3::bwd_data_valu(d3, We3, d2);
         if (dbg_stop == 3) continue;
         __syncthreads();
         for (int i = threadIdx.x; i < 1568; i += blockDim.x) d2[i] *= elu_grad_from_out(a2[i]);
         __syncthreads();
-        UpC2::bwd_weight(a1, d2, gWe2, g + od.c2b, scratch);
+        UpC2::bwd_weight_valu(a1, d2, gWe2, g + od.c2b, scratch);
         if (dbg_stop == 4) continue;
-        UpC2::bwd_data(d2, We2, d1);
+        UpC2::bwd_data_mfma(d2, We2, d1);
         if (dbg_stop == 5) continue;
         __syncthreads();
         for (int i = threadIdx.x; i < 512; i += blockDim.x) d1[i] *= elu_grad_from_out(a1[i]);
         __syncthreads();
-        UpC1::bwd_weight(h0, d1, gWe1, g + od.c1b, scratch);
+        UpC1::bwd_weight_mfma(h0, d1, gWe1, g + od.c1b, scratch);
         if (dbg_stop == 6) continue;
-        UpC1::bwd_data(d1, We1, dh0);
+        UpC1::bwd_data_mfma(d1, We1, dh0);
         if (dbg_stop == 7) continue;
         __syncthreads();
         // dense (no activation): weight / bias gradients and zbar

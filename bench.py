@@ -163,6 +163,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl",
+                    help="N>1: who enqueues the three all-reduces -- the library on the compute stream (rccl) or "
+                         "torch.distributed between per-phase graphs (torch); both are RCCL over xGMI")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="N=1: run the data-parallel entry point with a 1-rank communicator (plumbing check)")
     ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
                     help="cfg2 = BASELINE configs[1] (the metric's configuration, default); cfg3 = configs[2] "
                          "(m=256, b=1024, GPLVM dim 32: large-m path) for information only")
@@ -202,16 +207,31 @@ def main():
 
     # ---- timed region: eps drawn on device every step (tf.random.normal, SVGPVAE_model.py:901)
     eng.bind(d_img, d_aux, None)
-    use_graph = world == 1 and not args.no_graph
+    use_graph = world == 1 and not args.no_graph and not args.force_comm
     if use_graph:
         eng.capture("step", adam=True)
         step = lambda: eng.replay("step")
-    elif not args.no_graph:
-        # N > 1: one hipGraph per phase, RCCL all-reduces (not captured) in between
-        eng.capture_phases("step", adam=True)
-        step = lambda: eng.run_phase_graphs("step")
     else:
-        step = lambda: eng.run(adam=True)
+        launch = None
+        if (world > 1 or args.force_comm) and args.exchange == "rccl":
+            # the three all-reduces are issued by the library on the compute stream (svgp_mnist_train_step_dp)
+            try:
+                from svgp_vae_amd.engine import RcclComm
+                comm = RcclComm.from_process_group() if world > 1 else RcclComm(0, 1, RcclComm.unique_id())
+                eng.attach_comm(comm)
+                step = lambda: eng.run(adam=True)
+                launch = "one in-order stream: phases + in-library RCCL all-reduce x3"
+            except Exception as e:   # both legs are RCCL; this only changes who enqueues the collective
+                print(f"[bench] rank {rank}: in-library RCCL communicator unavailable ({e}); "
+                      f"using torch.distributed all_reduce between per-phase graphs", file=sys.stderr, flush=True)
+        if launch is None and not args.no_graph:
+            # one hipGraph per phase, torch.distributed (RCCL) all-reduces (not captured) in between
+            eng.capture_phases("step", adam=True)
+            step = lambda: eng.run_phase_graphs("step")
+            launch = "per-phase hipGraphs + torch.distributed RCCL all-reduce x3"
+        elif launch is None:
+            step = lambda: eng.run(adam=True)
+            launch = "eager phases + torch.distributed RCCL all-reduce x3"
     for _ in range(args.warmup):
         step()
     eng.synchronize()
@@ -245,7 +265,7 @@ def main():
                        ("BASELINE configs[2] (information only): m=256 inducing, L=16, GPLVM dim 32, batch 1024 per "
                         "GPU, N_train=4050, GECO + clip_qs, float64, large-m GEMM path"),
                        "global_batch": B * world, "rows_per_gpu": B,
-                       "launch": "hipGraph replay" if use_graph else ("eager phases" if args.no_graph else "per-phase hipGraphs") + " + RCCL all-reduce x3",
+                       "launch": "hipGraph replay" if use_graph else launch,
                        "parallelism": f"dp{world}"},
         }
         if world == 1 and args.workload == "cfg2":
@@ -276,6 +296,10 @@ def main():
             line["step_flops"] = sum(r["flops"] for r in rows)
             if not args.no_cpu_baseline and args.workload == "cfg2":
                 line["cpu_baseline"] = cpu_baseline(params, images, aux, eps, gpu_elbo)
+        # RCCL prints a version banner through C stdio at communicator creation; flush it first so the
+        # JSON line is the last line on stdout
+        C.CDLL(None).fflush(None)
+        sys.stdout.flush()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

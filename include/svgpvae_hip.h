@@ -35,7 +35,8 @@ typedef enum {
     SVGP_OK = 0,
     SVGP_ERR_INVALID = -1,     /* bad argument / null pointer / inconsistent shapes            */
     SVGP_ERR_UNSUPPORTED = -2, /* shape outside what this build implements (e.g. m > 2048)     */
-    SVGP_ERR_HIP = -3          /* a HIP runtime call failed (message has hipGetErrorString)    */
+    SVGP_ERR_HIP = -3,         /* a HIP runtime call failed (message has hipGetErrorString)    */
+    SVGP_ERR_COMM = -4         /* an RCCL call failed (message has ncclGetErrorString)         */
 } svgp_status;
 
 /* Shapes + constants of one rank's share of a rotated-MNIST SVGPVAE step.
@@ -128,6 +129,7 @@ typedef enum {
     SVGP_ST_INSIDE_RECON = 11,
     SVGP_ST_INSIDE_KL = 12,
     SVGP_ST_RNG_CTR = 13,    /* counter of the on-device N(0,1) generator (bit pattern of u64)   */
+    SVGP_ST_TICKET = 15,     /* u64 workgroup ticket of svgp_adam_tf1_finalize; 0 between launches */
     SVGP_STATE_LEN = 16
 } svgp_state_slot;
 
@@ -182,6 +184,10 @@ int svgp_adam_tf1_step(int64_t n, double* theta, const double* grad, double* ada
 /* scalar members of the 16-tuple + GECO state update + global_step (SVGPVAE_model.py:880-925,
  * MNIST_experiment.py:334-355) */
 int svgp_elbo_finalize(const svgp_mnist_cfg*, double* ws, double* state, void* stream);
+/* svgp_adam_tf1_step + svgp_elbo_finalize in one launch (what phase 3 uses) */
+int svgp_adam_tf1_finalize(const svgp_mnist_cfg*, int64_t n, double* theta, const double* grad, double* adam_m,
+                           double* adam_v, double* ws, double* state, double beta1, double beta2, double epsilon,
+                           void* stream);
 /* same, but global_step is not advanced (forward/backward only, no optimiser update) */
 int svgp_elbo_finalize_noadam(const svgp_mnist_cfg*, double* ws, double* state, void* stream);
 
@@ -199,6 +205,25 @@ int svgp_mnist_step_phase(const svgp_mnist_cfg*, int phase, double* theta, const
 int svgp_mnist_train_step(const svgp_mnist_cfg*, double* theta, const double* images,
                           const double* aux, const double* eps, double* ws, double* state,
                           double* adam_m, double* adam_v, void* stream);
+
+/* ---- data-parallel exchange over RCCL on the compute stream -------------------------
+ * The reference is single-process; these are the three sum-exchanges the row-sharded step needs
+ * (statistics S_l, v_l of SVGPVAE_model.py:328-334,339-340; their reverse-mode counterparts; the
+ * parameter gradients of MNIST_experiment.py:197-208).  One communicator per process (= per GPU).
+ * Bootstrap: rank 0 calls svgp_comm_unique_id, the bytes reach the other ranks by any side channel
+ * (torch.distributed broadcast_object_list in engine.py), every rank calls svgp_comm_init with its
+ * device current.  RCCL itself is resolved with dlopen at the first call (SVGP_ERR_UNSUPPORTED when
+ * absent).  svgp_mnist_train_step_dp = phase 0 | all-reduce statA | phase 1 | all-reduce statB |
+ * phase 2 | all-reduce gradC | phase 3, all enqueued on `stream` with no host synchronisation;
+ * cfg->b is the rank's row count, cfg->b_global the global batch, cfg->rep_weight 1 on one rank.   */
+int svgp_comm_unique_id_bytes(void);
+int svgp_comm_unique_id(void* out, int nbytes);
+int svgp_comm_init(const void* unique_id, int nbytes, int rank, int nranks, void** comm_out);
+int svgp_comm_destroy(void* comm);
+int svgp_allreduce_sum_f64(void* comm, double* buf, int64_t count, void* stream);
+int svgp_mnist_train_step_dp(const svgp_mnist_cfg*, void* comm, double* theta, const double* images,
+                             const double* aux, const double* eps, double* ws, double* state,
+                             double* adam_m, double* adam_v, void* stream);
 
 /* ---- batched float64 linear algebra on device matrices (large-m path; also usable on their own) ---
  * replace tf.matmul / tf.linalg.inv / tf.linalg.cholesky+log(diag) (SVGPVAE_model.py:239,270-274,319,328-341)

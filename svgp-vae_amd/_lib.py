@@ -82,9 +82,15 @@ SIGNATURES = {
     "svgp_mnist_grad_reduce": [_CFG, _P, _P],
     "svgp_adam_tf1_step": [C.c_int64, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P],
     "svgp_elbo_finalize": [_CFG, _P, _P, _P],
+    "svgp_adam_tf1_finalize": [_CFG, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P],
     "svgp_elbo_finalize_noadam": [_CFG, _P, _P, _P],
     "svgp_mnist_step_phase": [_CFG, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "svgp_mnist_train_step": [_CFG, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "svgp_comm_unique_id": [_P, C.c_int],
+    "svgp_comm_init": [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)],
+    "svgp_comm_destroy": [_P],
+    "svgp_allreduce_sum_f64": [_P, _P, C.c_int64, _P],
+    "svgp_mnist_train_step_dp": [_CFG, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "svgp_dgemm_batched": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.c_int, C.c_longlong, _P,
                            C.c_int, C.c_longlong, C.c_double, _P, C.c_int, C.c_longlong, C.c_int, _P],
     "svgp_spd_inverse_batched": [C.c_int, C.c_int, _P, _P, _P, _P],
@@ -116,6 +122,7 @@ SIGNATURES = {
     "svgp_event_destroy": [_P],
 }
 NON_STATUS = {"svgp_version": ([], C.c_int), "svgp_last_error": ([], C.c_char_p),
+              "svgp_comm_unique_id_bytes": ([], C.c_int),
               "svgp_spd_inverse_workspace_elems": ([C.c_int, C.c_int], C.c_size_t)}
 
 _lib = None

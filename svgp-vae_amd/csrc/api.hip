@@ -2,6 +2,8 @@
 #include <cstdarg>
 
 #include "common.hpp"
+#include <mutex>
+#include <cstdlib>
 
 static thread_local char g_err[512] = "";
 
@@ -100,17 +102,85 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
 // ---------------------------------------------------------------------------------------------
 // phases
 // ---------------------------------------------------------------------------------------------
-extern "C" int svgp_mnist_step_phase(const svgp_mnist_cfg* c, int phase, double* theta, const double* images,
-                                     const double* aux, const double* eps, double* ws, double* state,
-                                     double* adam_m, double* adam_v, void* stream) {
+// ---------------------------------------------------------------------------------------------
+// Side streams.  Most stages of the step are short dependent launches that fill only a part of the chip
+// (the GP factor kernels run L workgroups on 256 CUs), so work that is OFF the critical path -- the
+// kernel-matrix reverse pass and the VAE weight gradients -- is forked onto a library-owned side stream
+// and joined where its result is consumed.  hipEventRecord / hipStreamWaitEvent are capturable, so under
+// stream capture the fork becomes a parallel branch of the hipGraph.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct Side {
+    hipStream_t s[2] = {nullptr, nullptr};
+    hipEvent_t fork = nullptr, done[2] = {nullptr, nullptr};
+    bool pending[2] = {false, false};
+    bool ok = false;
+};
+std::mutex g_side_mu;
+Side g_side[64];
+
+int side_get(Side** out) {
+    int dev = 0;
+    SVGP_CHECK_HIP(hipGetDevice(&dev));
+    SVGP_REQUIRE(dev >= 0 && dev < 64, SVGP_ERR_INVALID, "device ordinal %d out of range", dev);
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    Side* sd = &g_side[dev];
+    if (!sd->ok) {
+        for (int k = 0; k < 2; ++k) {
+            SVGP_CHECK_HIP(hipStreamCreateWithFlags(&sd->s[k], hipStreamNonBlocking));
+            SVGP_CHECK_HIP(hipEventCreateWithFlags(&sd->done[k], hipEventDisableTiming));
+        }
+        SVGP_CHECK_HIP(hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming));
+        sd->ok = true;
+    }
+    *out = sd;
+    return SVGP_OK;
+}
+// side stream k continues after everything issued on `main` so far
+int side_fork(Side* sd, int k, hipStream_t main) {
+    SVGP_CHECK_HIP(hipEventRecord(sd->fork, main));
+    SVGP_CHECK_HIP(hipStreamWaitEvent(sd->s[k], sd->fork, 0));
+    sd->pending[k] = true;
+    return SVGP_OK;
+}
+// `main` continues after everything issued on side stream k
+int side_join(Side* sd, int k, hipStream_t main) {
+    if (!sd->pending[k]) return SVGP_OK;
+    SVGP_CHECK_HIP(hipEventRecord(sd->done[k], sd->s[k]));
+    SVGP_CHECK_HIP(hipStreamWaitEvent(main, sd->done[k], 0));
+    sd->pending[k] = false;
+    return SVGP_OK;
+}
+
+// `defer`: the caller issues all four phases back to back on one stream (svgp_mnist_train_step), so a
+// branch forked in one phase may be joined in a later one; otherwise every phase joins before returning
+// (each phase may be captured into its own graph, with a collective in between).
+int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const double* images, const double* aux,
+                    const double* eps, double* ws, double* state, double* adam_m, double* adam_v, void* stream,
+                    bool defer) {
     int rc = svgp_check_cfg(c);
     if (rc) return rc;
     SVGP_REQUIRE(theta && images && aux && ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(phase >= 0 && phase <= 3, SVGP_ERR_INVALID, "phase %d out of range 0..3", phase);
+    hipStream_t ms = (hipStream_t)stream;
+    (void)defer;
+    // Measured on MI355X (tools/fork_probe.py): a fork + join costs ~10 us of cross-stream signalling.  The
+    // kernel-matrix reverse pass || encoder reverse pass branch hides ~20 us, which pays only in the
+    // per-phase-graph replay form (phase 2: 110 -> 100 us) and loses in the eager in-order form
+    // (261 -> 283 us per step), so it is opt-in: SVGP_SIDE_STREAMS=1.
+    const char* fk = getenv("SVGP_SIDE_STREAMS");
+    const bool fork2 = fk && fk[0] == '1';
+    Side* sd = nullptr;
+    if (fork2) {
+        rc = side_get(&sd);
+        if (rc) return rc;
+    }
+    hipStream_t s2 = fork2 ? sd->s[0] : ms;
 #define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
     switch (phase) {
     case 0:
-        RUN(svgp_mnist_encoder_fwd(c, theta, images, ws, stream));
         RUN(svgp_kernel_matrix_fwd(c, theta, aux, ws, stream));
+        RUN(svgp_mnist_encoder_fwd(c, theta, images, ws, stream));
         RUN(svgp_gp_stats_fwd(c, ws, stream));
         break;
     case 1:
@@ -123,8 +193,10 @@ extern "C" int svgp_mnist_step_phase(const svgp_mnist_cfg* c, int phase, double*
     case 2:
         RUN(svgp_gp_factor_bwd(c, ws, state, stream));
         RUN(svgp_gp_posterior_bwd(c, ws, state, stream));
-        RUN(svgp_kernel_matrix_bwd(c, theta, aux, ws, stream));
+        if (fork2) RUN(side_fork(sd, 0, ms));
+        RUN(svgp_kernel_matrix_bwd(c, theta, aux, ws, s2));
         RUN(svgp_mnist_encoder_bwd(c, theta, images, ws, stream));
+        if (fork2) RUN(side_join(sd, 0, ms));
         RUN(svgp_mnist_grad_reduce(c, ws, stream));
         break;
     case 3: {
@@ -134,9 +206,8 @@ extern "C" int svgp_mnist_step_phase(const svgp_mnist_cfg* c, int phase, double*
         RUN(svgp_mnist_ws_layout_get(c, &wl));
         if (adam_m != nullptr) {
             SVGP_REQUIRE(adam_v != nullptr, SVGP_ERR_INVALID, "adam_v is NULL");
-            RUN(svgp_adam_tf1_step(pl.n_total, theta, ws + wl.grad, adam_m, adam_v, state, 0.9, 0.999, 1e-8,
-                                   stream));
-            RUN(svgp_elbo_finalize(c, ws, state, stream));
+            RUN(svgp_adam_tf1_finalize(c, pl.n_total, theta, ws + wl.grad, adam_m, adam_v, ws, state, 0.9, 0.999,
+                                       1e-8, stream));
         } else {
             RUN(svgp_elbo_finalize_noadam(c, ws, state, stream));
         }
@@ -148,6 +219,20 @@ extern "C" int svgp_mnist_step_phase(const svgp_mnist_cfg* c, int phase, double*
 #undef RUN
     return SVGP_OK;
 }
+}  // namespace
+
+extern "C" int svgp_mnist_step_phase(const svgp_mnist_cfg* c, int phase, double* theta, const double* images,
+                                     const double* aux, const double* eps, double* ws, double* state,
+                                     double* adam_m, double* adam_v, void* stream) {
+    return step_phase_impl(c, phase, theta, images, aux, eps, ws, state, adam_m, adam_v, stream, false);
+}
+
+// internal (comm.hip): one phase of a step whose phases are all issued back to back on one stream
+int svgp_mnist_step_phase_deferred(const svgp_mnist_cfg* c, int phase, double* theta, const double* images,
+                                   const double* aux, const double* eps, double* ws, double* state, double* adam_m,
+                                   double* adam_v, void* stream) {
+    return step_phase_impl(c, phase, theta, images, aux, eps, ws, state, adam_m, adam_v, stream, true);
+}
 
 extern "C" int svgp_mnist_train_step(const svgp_mnist_cfg* c, double* theta, const double* images,
                                      const double* aux, const double* eps, double* ws, double* state,
@@ -156,7 +241,7 @@ extern "C" int svgp_mnist_train_step(const svgp_mnist_cfg* c, double* theta, con
                  "svgp_mnist_train_step is the single-GPU form (b == b_global); use svgp_mnist_step_phase "
                  "with all-reduces between phases for data parallelism");
     for (int ph = 0; ph < 4; ++ph) {
-        int rc = svgp_mnist_step_phase(c, ph, theta, images, aux, eps, ws, state, adam_m, adam_v, stream);
+        int rc = step_phase_impl(c, ph, theta, images, aux, eps, ws, state, adam_m, adam_v, stream, true);
         if (rc) return rc;
     }
     return SVGP_OK;

@@ -36,6 +36,10 @@ void svgp_set_error(const char* fmt, ...);
         }                               \
     } while (0)
 
+int svgp_mnist_step_phase_deferred(const svgp_mnist_cfg* c, int phase, double* theta, const double* images,
+                                   const double* aux, const double* eps, double* ws, double* state, double* adam_m,
+                                   double* adam_v, void* stream);
+
 #define SVGP_LAUNCH_CHECK() SVGP_CHECK_HIP(hipGetLastError())
 
 int svgp_check_cfg(const svgp_mnist_cfg* c);

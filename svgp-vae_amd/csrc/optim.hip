@@ -31,8 +31,7 @@ struct FinArgs {
 };
 
 // SVGPVAE_model.py:880-925 (scalar assembly), MNIST_experiment.py:330-340 (GECO state carry)
-__global__ void k_elbo_finalize(FinArgs a) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void elbo_finalize(const FinArgs& a) {
     real* st = a.state;
     const real bg = (real)a.b_global, Lr = (real)a.L;
     real sumKL = 0;
@@ -66,6 +65,42 @@ __global__ void k_elbo_finalize(FinArgs a) {
     st[SVGP_ST_RNG_CTR] += real(1);
 }
 
+__global__ void k_elbo_finalize(FinArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    elbo_finalize(a);
+}
+
+// Adam update and the scalar epilogue in ONE launch.  The epilogue advances state[ADAM_T], which every
+// workgroup of the update reads, so it runs in whichever workgroup takes the last ticket -- by then all
+// the others have read the old value.  The ticket lives in state[SVGP_ST_TICKET] (u64 bits, left at 0).
+__global__ __launch_bounds__(SVGP_BLOCK) void k_adam_tf1_finalize(long long n, real* __restrict__ theta,
+                                                                  const real* __restrict__ grad,
+                                                                  real* __restrict__ mo, real* __restrict__ vo,
+                                                                  real beta1, real beta2, real eps, FinArgs a) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const real* state = a.state;
+    const real t = state[SVGP_ST_ADAM_T] + real(1);
+    const real lr_t = state[SVGP_ST_LR] * sqrt(real(1) - pow(beta2, t)) / (real(1) - pow(beta1, t));
+    if (i < n) {
+        const real g = grad[i];
+        const real mi = beta1 * mo[i] + (real(1) - beta1) * g;
+        const real vi = beta2 * vo[i] + (real(1) - beta2) * g * g;
+        mo[i] = mi;
+        vo[i] = vi;
+        theta[i] -= lr_t * mi / (sqrt(vi) + eps);
+    }
+    __shared__ int last;
+    __syncthreads();   // every lane of this workgroup has read the state
+    if (threadIdx.x == 0) {
+        unsigned long long* ticket = reinterpret_cast<unsigned long long*>(a.state + SVGP_ST_TICKET);
+        last = atomicAdd(ticket, 1ULL) == (unsigned long long)gridDim.x - 1ULL;
+        if (last) {
+            *ticket = 0ULL;
+            elbo_finalize(a);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int svgp_adam_tf1_step(int64_t n, double* theta, const double* grad, double* adam_m, double* adam_v,
@@ -89,6 +124,24 @@ static int finalize_impl(const svgp_mnist_cfg* c, double* ws, double* state, int
     a.N_train = c->N_train; a.kappa_squared = c->kappa_squared; a.alpha_next = c->alpha;
     a.sums = ws + wl.sums; a.KL = ws + wl.KL; a.state = state;
     hipLaunchKernelGGL(k_elbo_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+extern "C" int svgp_adam_tf1_finalize(const svgp_mnist_cfg* c, int64_t n, double* theta, const double* grad,
+                                      double* adam_m, double* adam_v, double* ws, double* state, double beta1,
+                                      double beta2, double epsilon, void* stream) {
+    svgp_mnist_ws_layout wl;
+    int rc = svgp_mnist_ws_layout_get(c, &wl);
+    if (rc) return rc;
+    SVGP_REQUIRE(n > 0 && theta && grad && adam_m && adam_v && ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    FinArgs a;
+    a.b_global = c->b_global; a.L = c->L; a.geco = c->geco; a.did_adam = 1;
+    a.n_pix = c->n_pix > 0 ? c->n_pix : 784;
+    a.N_train = c->N_train; a.kappa_squared = c->kappa_squared; a.alpha_next = c->alpha;
+    a.sums = ws + wl.sums; a.KL = ws + wl.KL; a.state = state;
+    hipLaunchKernelGGL(k_adam_tf1_finalize, dim3((unsigned)((n + SVGP_BLOCK - 1) / SVGP_BLOCK)), dim3(SVGP_BLOCK), 0,
+                       (hipStream_t)stream, (long long)n, theta, grad, adam_m, adam_v, beta1, beta2, epsilon, a);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

@@ -73,6 +73,46 @@ class DataParallelStep:
         be.phase(3)
 
 
+class RcclComm:
+    """RCCL communicator owned by libsvgpvae_hip.so (svgp_comm_*), one per process / GPU.  Its all-reduces
+    are enqueued on the engine's compute stream by svgp_mnist_train_step_dp, so a data-parallel step is one
+    in-order queue with no host synchronisation.  torch.distributed is used only to hand rank 0's unique
+    id to the other ranks (any backend)."""
+
+    def __init__(self, rank, world_size, unique_id):
+        self.lib = _lib.load_library()
+        self.rank, self.world_size = rank, world_size
+        self.handle = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), len(unique_id))
+        call("svgp_comm_init", buf, len(unique_id), rank, world_size, C.byref(self.handle))
+
+    @staticmethod
+    def unique_id():
+        lib = _lib.load_library()
+        n = lib.svgp_comm_unique_id_bytes()
+        buf = C.create_string_buffer(n)
+        call("svgp_comm_unique_id", buf, n)
+        return buf.raw
+
+    @classmethod
+    def from_process_group(cls, group=None):
+        """Collective over `group`: rank 0 creates the id, broadcast_object_list distributes it."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, box[0])
+
+    def all_reduce(self, tensor, stream):
+        assert tensor.dtype == torch.float64 and tensor.is_contiguous() and tensor.is_cuda
+        call("svgp_allreduce_sum_f64", self.handle, tensor.data_ptr(), tensor.numel(), stream)
+
+    def close(self):
+        if self.handle:
+            self.lib.svgp_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
 class MnistStepEngine:
     """One rank's HIP execution state for the rotated-MNIST SVGPVAE_Hensman step."""
 
@@ -109,6 +149,7 @@ class MnistStepEngine:
         self.reset_state(beta=beta, lr=lr)
         self._graphs = {}
         self._bound = None
+        self.comm = None
         self.set_batch_size(b_max, b_max * world_size)
 
     # ------------------------------------------------------------------ configuration
@@ -201,12 +242,35 @@ class MnistStepEngine:
              self.state.data_ptr(), self.adam_m.data_ptr() if adam else None,
              self.adam_v.data_ptr() if adam else None, self.stream.cuda_stream)
 
+    def full_step(self, adam=True):
+        """svgp_mnist_train_step: the four phases issued back to back (single GPU), which lets the library
+        keep its side-stream branches open across phase boundaries."""
+        images, aux, eps = self._bound
+        call("svgp_mnist_train_step", C.byref(self.cfg), self.theta.data_ptr(), images.data_ptr(),
+             aux.data_ptr(), eps.data_ptr() if eps is not None else None, self.ws.data_ptr(),
+             self.state.data_ptr(), self.adam_m.data_ptr() if adam else None,
+             self.adam_v.data_ptr() if adam else None, self.stream.cuda_stream)
+
+    def attach_comm(self, comm):
+        """Use the library's RCCL communicator for the three exchanges (svgp_mnist_train_step_dp)."""
+        assert comm.world_size == self.world_size and comm.rank == self.rank
+        self.comm = comm
+
+    def full_step_dp(self, adam=True):
+        images, aux, eps = self._bound
+        call("svgp_mnist_train_step_dp", C.byref(self.cfg), self.comm.handle, self.theta.data_ptr(),
+             images.data_ptr(), aux.data_ptr(), eps.data_ptr() if eps is not None else None, self.ws.data_ptr(),
+             self.state.data_ptr(), self.adam_m.data_ptr() if adam else None,
+             self.adam_v.data_ptr() if adam else None, self.stream.cuda_stream)
+
     def run(self, adam=True, group=None):
-        """All four phases on self.stream, with all-reduces when world_size > 1."""
+        """All four phases on self.stream, with all-reduces when world_size > 1 (in-stream RCCL when a
+        communicator is attached, torch.distributed between the phases otherwise)."""
         with torch.cuda.stream(self.stream):
-            if self.world_size == 1:
-                for k in range(4):
-                    self.phase(k, adam)
+            if self.comm is not None:
+                self.full_step_dp(adam)
+            elif self.world_size == 1:
+                self.full_step(adam)
             else:
                 be = _PhaseAdapter(self, adam)
                 DataParallelStep(be, group).step()
@@ -219,8 +283,7 @@ class MnistStepEngine:
         self.stream.synchronize()
         call("svgp_graph_begin", s)
         try:
-            for k in range(4):
-                self.phase(k, adam)
+            self.full_step(adam)
         finally:
             exe = C.c_void_p()
             call("svgp_graph_end", s, C.byref(exe))

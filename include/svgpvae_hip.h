@@ -225,6 +225,34 @@ int svgp_mnist_train_step_dp(const svgp_mnist_cfg*, void* comm, double* theta, c
                              const double* aux, const double* eps, double* ws, double* state,
                              double* adam_m, double* adam_v, void* stream);
 
+/* ---- full-data statistics in float32, streamed over N (8f rank 1) -----------------
+ * replace precompute_GP_params_SVGPVAE's K_nm build and its per-channel
+ *   K_mn (K_nm * 1/var_l)  and  K_mn (mean_l / var_l)        (SVGPVAE_model.py:1004-1017)
+ * for N-sized inputs: N = 2^20 rows / m = 2048 per the stress config, or the SPRITES training set
+ * (SPRITES_experiment.py:176-182).  float32 is the reference's dtype for SPRITES (tf.float32).
+ * kind 0: periodic(angle) x linear(object vector)   mnistSVGP.kernel_matrix   :427-476, p = [l_GP, amplitude]
+ * kind 1: linear(action) x linear(character)         spritesSVGP.kernel_matrix :550-600
+ * kind 2: SE(action) x SE(character), --K_SE         :530-544,                 p = [l1, sigma1, l2, sigma2]
+ * normalize = cosine normalisation of the linear factors (:465-474, :576-598).
+ * Batch rows x: kind 0 (n, 2+d2) [id, angle, o..] with o gathered from `table` (n_table, d2) when
+ * n_table > 0; kinds 1,2 (n, 1+d2) [action_id, chr..] with the action vector gathered from `table`
+ * (n_table, d1).  Inducing rows: kind 0 (m, 2+d2); kinds 1,2 (m, d1+d2).
+ * svgp_stream_features_f32 writes feature_elems(n) floats; svgp_stream_knm_f32 writes K_nm (n, m) row-major;
+ * svgp_stream_stats_f32 writes S (L, m, m) = K_nm^T diag(1/var_l) K_nm and v (L, m) = K_nm^T (mean_l/var_l),
+ * means / vars (n, L) row-major, 1/var via reciprocal_no_nan.  Nothing is added or inverted here.       */
+typedef struct {
+    int32_t kind, d1, d2, normalize, n_table;
+    float   p[4];
+} svgp_stream_kdesc;
+int64_t svgp_stream_feature_elems(const svgp_stream_kdesc*, int64_t n);
+int svgp_stream_features_f32(const svgp_stream_kdesc*, int64_t n, const float* x, int ldx, int inducing,
+                             const float* table, float* feat, void* stream);
+int svgp_stream_knm_f32(const svgp_stream_kdesc*, int64_t n, int m, const float* feat_rows,
+                        const float* feat_inducing, float* K_nm, void* stream);
+int64_t svgp_stream_stats_workspace_elems(int64_t n, int m, int L);
+int svgp_stream_stats_f32(int64_t n, int m, int L, const float* K_nm, const float* means, const float* vars,
+                          float* S, float* v, float* ws, int64_t ws_elems, void* stream);
+
 /* ---- batched float64 linear algebra on device matrices (large-m path; also usable on their own) ---
  * replace tf.matmul / tf.linalg.inv / tf.linalg.cholesky+log(diag) (SVGPVAE_model.py:239,270-274,319,328-341)
  * svgp_dgemm_batched: C[l] = alpha op(A[l]) op(B[l]) + beta C[l]; C is M x N, contraction K; ta/tb = 1 means

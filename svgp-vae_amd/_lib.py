@@ -86,6 +86,9 @@ SIGNATURES = {
     "svgp_elbo_finalize_noadam": [_CFG, _P, _P, _P],
     "svgp_mnist_step_phase": [_CFG, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "svgp_mnist_train_step": [_CFG, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "svgp_stream_features_f32": [_P, C.c_int64, _P, C.c_int, C.c_int, _P, _P, _P],
+    "svgp_stream_knm_f32": [_P, C.c_int64, C.c_int, _P, _P, _P, _P],
+    "svgp_stream_stats_f32": [C.c_int64, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int64, _P],
     "svgp_comm_unique_id": [_P, C.c_int],
     "svgp_comm_init": [_P, C.c_int, C.c_int, C.c_int, C.POINTER(_P)],
     "svgp_comm_destroy": [_P],
@@ -121,8 +124,15 @@ SIGNATURES = {
     "svgp_event_elapsed_ms": [_P, _P, C.POINTER(C.c_float)],
     "svgp_event_destroy": [_P],
 }
+class StreamKdesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("d1", C.c_int32), ("d2", C.c_int32), ("normalize", C.c_int32),
+                ("n_table", C.c_int32), ("p", C.c_float * 4)]
+
+
 NON_STATUS = {"svgp_version": ([], C.c_int), "svgp_last_error": ([], C.c_char_p),
               "svgp_comm_unique_id_bytes": ([], C.c_int),
+              "svgp_stream_feature_elems": ([C.c_void_p, C.c_int64], C.c_int64),
+              "svgp_stream_stats_workspace_elems": ([C.c_int64, C.c_int, C.c_int], C.c_int64),
               "svgp_spd_inverse_workspace_elems": ([C.c_int, C.c_int], C.c_size_t)}
 
 _lib = None

@@ -117,6 +117,7 @@ def run_experiment_rotated_mnist_SVGPVAE(args, args_dict=None):
     d_test_img, d_test_aux = t64(te["images"]), t64(te["aux_data"])
     stage_img = torch.zeros(args.batch_size, 28, 28, 1, dtype=torch.float64, device=dev)
     stage_aux = torch.zeros(args.batch_size, 2 + args.M, dtype=torch.float64, device=dev)
+    eng.stream.wait_stream(torch.cuda.current_stream(dev))   # uploads / zero-fills above ran on torch's stream
     graphs = {}
 
     def train_batch(lo, hi):

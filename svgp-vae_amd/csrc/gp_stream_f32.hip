@@ -97,66 +97,88 @@ __global__ __launch_bounds__(256) void k_features_f32(FeatArgs a) {
 // ------------------------------------------------------------------------------------------------
 struct KnmArgs {
     long long n;
-    int m;
+    int m, rb, npanel;
     float c0, s1, s2;
     const float* fa;   // (n, D) | r (n)
     const float* fb;   // (m, D) | r (m)
     float* K;          // (n, m)
 };
 
-constexpr int KNM_CPT = 4, KNM_RB = 64;
+constexpr int KNM_RB = 32;
 
-template <int D1, int D2, int MODE>
+// G column groups of 4 per lane, 1024 columns apart: with G = 2 and m = 2048 a workgroup writes whole rows,
+// i.e. one contiguous RB x 8 KB region.
+template <int D1, int D2, int MODE, int G = 1, bool NT = true>
 __global__ __launch_bounds__(256) void k_knm_f32(KnmArgs a) {
     constexpr int D = D1 + D2;
-    const int col0 = (blockIdx.y * 256 + threadIdx.x) * KNM_CPT;
-    if (col0 >= a.m) return;
-    float fb[KNM_CPT][D], rb[KNM_CPT];
+    // the column panel is the fastest-varying part of the workgroup index, so concurrently resident
+    // workgroups write whole rows back to back
+    const unsigned panel = blockIdx.x % a.npanel;
+    const long long rblk = blockIdx.x / a.npanel;
+    int col0[G];
+    float fb[G][4][D], rb[G][4];
 #pragma unroll
-    for (int c = 0; c < KNM_CPT; ++c) {
-        const int col = col0 + c < a.m ? col0 + c : a.m - 1;
+    for (int g = 0; g < G; ++g) {
+        col0[g] = ((panel * G + g) * 256 + threadIdx.x) * 4;
 #pragma unroll
-        for (int k = 0; k < D; ++k) fb[c][k] = a.fb[(size_t)col * D + k];
-        rb[c] = a.fb[(size_t)a.m * D + col];
+        for (int c = 0; c < 4; ++c) {
+            const int col = col0[g] + c < a.m ? col0[g] + c : a.m - 1;
+#pragma unroll
+            for (int k = 0; k < D; ++k) fb[g][c][k] = a.fb[(size_t)col * D + k];
+            rb[g][c] = a.fb[(size_t)a.m * D + col];
+        }
     }
+    if (col0[0] >= a.m) return;
     const bool vec = (a.m & 3) == 0;   // then col0 + 3 < m and every row start is 16-byte aligned
-    const long long r0 = (long long)blockIdx.x * KNM_RB;
+    const long long r0 = rblk * a.rb;
     const float* __restrict__ ra = a.fa + a.n * D;
 #pragma unroll 2
-    for (int r = 0; r < KNM_RB; ++r) {
+    for (int r = 0; r < a.rb; ++r) {
         const long long row = r0 + r;
         if (row >= a.n) break;
         const float* __restrict__ fa = a.fa + row * D;
-        float d1[KNM_CPT], d2[KNM_CPT], out[KNM_CPT];
+        float d1[G][4], d2[G][4];
 #pragma unroll
-        for (int c = 0; c < KNM_CPT; ++c) d1[c] = d2[c] = 0.0f;
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d1[g][c] = d2[g][c] = 0.0f;
 #pragma unroll
         for (int k = 0; k < D1; ++k) {
             const float x = fa[k];
 #pragma unroll
-            for (int c = 0; c < KNM_CPT; ++c) d1[c] = fmaf(x, fb[c][k], d1[c]);
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d1[g][c] = fmaf(x, fb[g][c][k], d1[g][c]);
         }
 #pragma unroll
         for (int k = 0; k < D2; ++k) {
             const float x = fa[D1 + k];
 #pragma unroll
-            for (int c = 0; c < KNM_CPT; ++c) d2[c] = fmaf(x, fb[c][D1 + k], d2[c]);
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) d2[g][c] = fmaf(x, fb[g][c][D1 + k], d2[g][c]);
         }
         const float rr = ra[row];
 #pragma unroll
-        for (int c = 0; c < KNM_CPT; ++c) {
-            if (MODE == KM_EXP_DOT) out[c] = a.c0 * __expf(a.s1 * (d1[c] - 1.0f)) * d2[c];
-            else if (MODE == KM_DOT_DOT) out[c] = d1[c] * d2[c];
-            else out[c] = a.c0 * __expf(fmaf(a.s1, d1[c], fmaf(a.s2, d2[c], -rr - rb[c])));
-        }
-        float* dst = a.K + row * a.m + col0;
-        if (vec) {
-            f32x4 o = {out[0], out[1], out[2], out[3]};
-            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dst));
-        } else {
+        for (int g = 0; g < G; ++g) {
+            if (col0[g] >= a.m) continue;
+            float out[4];
 #pragma unroll
-            for (int c = 0; c < KNM_CPT; ++c)
-                if (col0 + c < a.m) dst[c] = out[c];
+            for (int c = 0; c < 4; ++c) {
+                if (MODE == KM_EXP_DOT) out[c] = a.c0 * __expf(a.s1 * (d1[g][c] - 1.0f)) * d2[g][c];
+                else if (MODE == KM_DOT_DOT) out[c] = d1[g][c] * d2[g][c];
+                else out[c] = a.c0 * __expf(fmaf(a.s1, d1[g][c], fmaf(a.s2, d2[g][c], -rr - rb[g][c])));
+            }
+            float* dst = a.K + row * a.m + col0[g];
+            if (vec) {
+                f32x4 o = {out[0], out[1], out[2], out[3]};
+                if (NT) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(dst));
+                else *reinterpret_cast<f32x4*>(dst) = o;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (col0[g] + c < a.m) dst[c] = out[c];
+            }
         }
     }
 }
@@ -181,15 +203,15 @@ __global__ __launch_bounds__(256) void k_stats_weights_f32(long long n, int L, c
 // S_l = K^T diag(p_l) K on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
 //
 // One workgroup (8 waves) owns a 256 x 256 tile of one S_l and one slice of the rows; only tile pairs
-// ti <= tj are computed (S is symmetric), the mirror is written by the reduction.  Per 16-row chunk the
-// two 16 x 256 slabs K[:, i-tile] and p_l * K[:, j-tile] go global -> registers -> LDS (double buffered,
+// ti <= tj are computed (S is symmetric), the mirror is written by the reduction.  Per row chunk the
+// two KC x 256 slabs K[:, i-tile] and p_l * K[:, j-tile] go global -> registers -> LDS (double buffered,
 // one barrier per chunk) and every wave runs 64 MFMAs on its 128 x 64 sub-tile: 64 flop per slab byte,
 // so the slab traffic (L2 hits: all (pair, l) workgroups of one row slice walk the same rows) stays
-// ~2.5 TB/s at full MFMA rate.
+// ~2.5 TB/s at full MFMA rate.  Chunks are 32 rows (template parameter).
 // MFMA operand layout: A[i = lane & 31][k = lane >> 5], B[k = lane >> 5][j = lane & 31],
 // D reg r -> row 8 (r / 4) + 4 (lane >> 5) + (r & 3), column lane & 31.
 // ------------------------------------------------------------------------------------------------
-constexpr int ST_T = 256, ST_KC = 16, ST_LD = ST_T + 32, ST_NT = 512;
+constexpr int ST_T = 256, ST_LD = ST_T + 32, ST_NT = 512;
 
 struct StatsArgs {
     long long n, rows_per_split;
@@ -216,6 +238,7 @@ __device__ __forceinline__ f32x4 load_row4(const float* __restrict__ K, long lon
     return v;
 }
 
+template <int ST_KC>
 __global__ __launch_bounds__(ST_NT) void k_stats_mfma_f32(StatsArgs a) {
     extern __shared__ __align__(16) float lds[];
     float* As = lds;                          // [2][ST_KC][ST_LD]
@@ -243,10 +266,11 @@ __global__ __launch_bounds__(ST_NT) void k_stats_mfma_f32(StatsArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.0f;
 
-    f32x4 ga[2], gb[2];
+    constexpr int NH = ST_KC / 8;
+    f32x4 ga[NH], gb[NH];
     auto fetch = [&](long long nb) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             const long long row = nb + lr + 8 * h;
             ga[h] = load_row4(a.K, row, n_end, a.m, i0 + lc, vec);
             gb[h] = load_row4(a.K, row, n_end, a.m, j0 + lc, vec);
@@ -256,7 +280,7 @@ __global__ __launch_bounds__(ST_NT) void k_stats_mfma_f32(StatsArgs a) {
     };
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NH; ++h) {
             *reinterpret_cast<f32x4*>(As + (buf * ST_KC + lr + 8 * h) * ST_LD + lc) = ga[h];
             *reinterpret_cast<f32x4*>(Bs + (buf * ST_KC + lr + 8 * h) * ST_LD + lc) = gb[h];
         }
@@ -371,8 +395,7 @@ StatsPlan stats_plan(long long n, int m, int L) {
     if (ns > 64) ns = 64;
     p.nsplit = (int)ns;
     long long rps = (n + ns - 1) / ns;
-    p.rows_per_split = (rps + ST_KC - 1) / ST_KC * ST_KC;
-    if (p.rows_per_split < ST_KC) p.rows_per_split = ST_KC;
+    p.rows_per_split = (rps + 31) / 32 * 32;
     const int mt = (m + 255) / 256;
     long long nv = (2048 + mt - 1) / mt;
     long long capv = n / 256 > 1 ? n / 256 : 1;
@@ -448,14 +471,23 @@ extern "C" int svgp_stream_knm_f32(const svgp_stream_kdesc* kd, int64_t n, int m
         a.s1 = 1.0f / (kd->p[0] * kd->p[0]);
         a.s2 = 1.0f / (kd->p[2] * kd->p[2]);
     }
-    const dim3 grid((unsigned)((n + KNM_RB - 1) / KNM_RB), (unsigned)((m + 256 * KNM_CPT - 1) / (256 * KNM_CPT)));
+    // the per-lane inducing features (4 D strided loads) are the prologue; wide features amortise it over more rows
+    a.rb = kd->d1 + kd->d2 <= 12 ? KNM_RB : 4 * KNM_RB;
     hipStream_t s = (hipStream_t)stream;
-#define KNM_CASE(K_, D1_, D2_, MODE_)                                                    \
-    if (kd->kind == K_ && kd->d1 == D1_ && kd->d2 == D2_) {                              \
-        hipLaunchKernelGGL((k_knm_f32<D1_, D2_, MODE_>), grid, dim3(256), 0, s, a);      \
-        SVGP_LAUNCH_CHECK();                                                             \
-        return SVGP_OK;                                                                  \
-    }
+#define KNM_LAUNCH(G_, ...)                                                                   \
+    do {                                                                                      \
+        a.npanel = (m + 1024 * G_ - 1) / (1024 * G_);                                         \
+        const dim3 grid((unsigned)(((n + a.rb - 1) / a.rb) * a.npanel));                      \
+        hipLaunchKernelGGL((k_knm_f32<__VA_ARGS__>), grid, dim3(256), 0, s, a);               \
+        SVGP_LAUNCH_CHECK();                                                                  \
+        return SVGP_OK;                                                                       \
+    } while (0)
+    // measured on MI355X at n = 131072, m = 2048 (round-1 probe): 32-64 rows per workgroup and
+    // non-temporal 16-byte stores give 5.0-5.4 TB/s; plain stores 3.5-4.5; 8 adjacent columns per lane 2.4;
+    // two column groups per lane (whole rows per workgroup) no better than one.  torch's fill_ reaches 6.9
+    // on the same buffer, its broadcast add (generated data) 3.9.
+#define KNM_CASE(K_, D1_, D2_, MODE_) \
+    if (kd->kind == K_ && kd->d1 == D1_ && kd->d2 == D2_) KNM_LAUNCH(1, D1_, D2_, MODE_, 1, true);
     KNM_CASE(0, 2, 4, KM_EXP_DOT)
     KNM_CASE(0, 2, 8, KM_EXP_DOT)
     KNM_CASE(0, 2, 16, KM_EXP_DOT)
@@ -465,6 +497,7 @@ extern "C" int svgp_stream_knm_f32(const svgp_stream_kdesc* kd, int64_t n, int m
     KNM_CASE(1, 4, 6, KM_DOT_DOT)
     KNM_CASE(2, 4, 6, KM_EXP)
 #undef KNM_CASE
+#undef KNM_LAUNCH
     SVGP_REQUIRE(false, SVGP_ERR_UNSUPPORTED,
                  "float32 K_nm build: feature split (%d, %d) of kind %d has no instantiation (periodic x linear: "
                  "M in {4, 8, 16, 32}; SPRITES: (8, 16), (4, 6))", kd->d1, kd->d2, kd->kind);
@@ -495,10 +528,12 @@ extern "C" int svgp_stream_stats_f32(int64_t n, int m, int L, const float* K_nm,
     StatsArgs a;
     a.n = n; a.rows_per_split = p.rows_per_split; a.m = m; a.L = L; a.ntile = p.ntile;
     a.K = K_nm; a.pT = pT; a.part = part;
-    const size_t lds = (size_t)4 * ST_KC * ST_LD * sizeof(float);
-    int rc = set_lds(k_stats_mfma_f32, lds);
+    // 32-row chunks: 128 MFMAs per wave between barriers (16-row chunks measured 6 % slower)
+    constexpr int KC = 32;
+    const size_t lds = (size_t)4 * KC * ST_LD * sizeof(float);
+    int rc = set_lds(k_stats_mfma_f32<KC>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_stats_mfma_f32, dim3(p.npair, L, p.nsplit), dim3(ST_NT), lds, s, a);
+    hipLaunchKernelGGL(k_stats_mfma_f32<KC>, dim3(p.npair, L, p.nsplit), dim3(ST_NT), lds, s, a);
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_stats_reduce_f32, dim3((m + 255) / 256, m, L), dim3(256), 0, s, m, L, p.nsplit, part, S);
     SVGP_LAUNCH_CHECK();

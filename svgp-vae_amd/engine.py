@@ -146,6 +146,8 @@ class MnistStepEngine:
         self.shapes = param_shapes(m, L, M, n_obj)
         self.params = {k: self._pview(self.theta, k) for k in self.shapes}
         self.stream = torch.cuda.Stream(device=self.device)
+        # the zero-fills above were enqueued on torch's current stream; everything below writes on self.stream
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
         self.reset_state(beta=beta, lr=lr)
         self._graphs = {}
         self._bound = None

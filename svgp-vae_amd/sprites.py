@@ -132,6 +132,8 @@ class SpritesStepEngine:
             off += n
         init = glorot_uniform_params(self.L, self.Lc, vae.seed) if params is None else params
         init = dict(init)
+        # zero-fills run on torch's current stream; the writes below run on self.stream
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         init.setdefault("inducing_index_points", svgp.inducing_index_points)
         init.setdefault("GPLVM_action", svgp.GPLVM_action)
         init.setdefault("se", svgp.se)
@@ -151,6 +153,7 @@ class SpritesStepEngine:
         call("svgp_mnist_ws_layout_get", C.byref(self.cfg), C.byref(self.wl))
         self.ws = torch.zeros(self.wl.total, **f64)
         self.state = torch.zeros(STATE_LEN, **f64)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         st = torch.zeros(STATE_LEN, dtype=_F64)
         st[STATE["LAGRANGE"]], st[STATE["ALPHA"]] = 1.0, (0.0 if geco else alpha)
         st[STATE["LR"]], st[STATE["BETA"]] = lr, beta

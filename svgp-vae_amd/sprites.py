@@ -107,7 +107,8 @@ class SpritesStepEngine:
     """Buffers + kernel schedule of one rank's SPRITES step."""
 
     def __init__(self, vae, repr_nn, svgp, *, b_max, seg_len=50, clip_qs=False, geco=False, kappa_squared=0.0075,
-                 alpha=0.99, beta=0.001, lr=1e-3, clip_grad=None, device="cuda:0", params=None):
+                 alpha=0.99, beta=0.001, lr=1e-3, clip_grad=None, device="cuda:0", params=None, rank=0, world_size=1,
+                 comm=None):
         self.lib = _lib.load_library()
         if not torch.cuda.is_available():
             raise _lib.SvgpError("SpritesStepEngine needs a HIP device; there is no CPU execution path")
@@ -116,6 +117,9 @@ class SpritesStepEngine:
         self.n_act = svgp.GPLVM_action.shape[0]
         self.seg_len, self.clip_grad, self.geco, self.clip_qs = seg_len, clip_grad, bool(geco), bool(clip_qs)
         self.svgp, self.b_max = svgp, b_max
+        # data parallelism over whole character groups: rank r holds b rows of a b_global batch;
+        # `comm` (engine.RcclComm) sums the three exchange blocks on the compute stream
+        self.rank, self.world_size, self.comm = rank, world_size, comm
         self.stream = torch.cuda.Stream(device=self.dev)
         f64 = dict(dtype=_F64, device=self.dev)
         # ---- flat parameter vector: networks, inducing points, GPLVM table, SE hyper-parameters
@@ -147,7 +151,7 @@ class SpritesStepEngine:
         self.base = dict(m=self.m, L=self.L, M=1, n_obj=0, normalize_obj=0, clip_qs=int(clip_qs), geco=int(geco),
                          train_ip=1, train_gp=1, train_ov=0, b_cap=b_max, clip_pv=1, n_pix=64 * 64 * 3,
                          N_train=svgp.N_train, jitter=svgp.jitter, kappa_squared=float(kappa_squared),
-                         alpha=float(alpha), rep_weight=1.0)
+                         alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0)
         self.cfg = MnistCfg(b=b_max, b_global=b_max, **self.base)
         self.wl = WsLayout()
         call("svgp_mnist_ws_layout_get", C.byref(self.cfg), C.byref(self.wl))
@@ -195,13 +199,26 @@ class SpritesStepEngine:
         self.stream.synchronize()
 
     # ------------------------------------------------------------------ one step
-    def step(self, images, action_ids, eps=None, adam=True):
+    def step(self, images, action_ids, eps=None, adam=True, b_global=None):
         """images (b,64,64,3), action_ids (b) float64 CUDA tensors; eps (b,L) or None (on-device N(0,1)).
-        Runs forward, reverse, (clip), TF1 Adam when `adam`, and the scalar epilogue."""
+        Runs forward, reverse, (clip), TF1 Adam when `adam`, and the scalar epilogue.  With world_size > 1
+        the three exchange blocks are summed over ranks by `self.comm` between the phases."""
+        if self.world_size > 1 and self.comm is None:
+            raise _lib.SvgpError("world_size > 1 needs a communicator (engine.RcclComm)")
+        for blocks in self.phases(images, action_ids, eps, adam, b_global):
+            if self.comm is not None:
+                for t in blocks:
+                    self.comm.all_reduce(t, self.stream.cuda_stream)
+        return self
+
+    def phases(self, images, action_ids, eps=None, adam=True, b_global=None):
+        """Generator over the step: yields the list of flat tensors to be summed over ranks at each of the
+        three exchange points (forward statistics, backward statistics, gradients + scalar sums)."""
         b = images.shape[0]
         assert b <= self.b_max and b % self.seg_len == 0
+        b_global = b * self.world_size if b_global is None else b_global
         p, g, s, L = self.params, self.grads, self.stream.cuda_stream, self.L
-        cfg = MnistCfg(b=b, b_global=b, **self.base)
+        cfg = MnistCfg(b=b, b_global=b_global, **self.base)
         self.cfg = cfg
         cp = C.byref(cfg)
         ws, st = self.ws.data_ptr(), self.state.data_ptr()
@@ -233,11 +250,14 @@ class SpritesStepEngine:
             call("svgp_sprites_aux_fwd", b, self.seg_len, self.Lc, rvec.data_ptr(), aid.data_ptr(), aux.data_ptr(), s)
             # ---------------- kernel matrices + sparse-GP block
             kc = SpritesKcfg(b=b, m=self.m, La=self.La, Lc=self.Lc, n_act=self.n_act,
-                             normalize=int(self.svgp.K_obj_normalize), k_se=int(self.svgp.K_SE), rep_weight=1.0)
+                             normalize=int(self.svgp.K_obj_normalize), k_se=int(self.svgp.K_SE),
+                             rep_weight=1.0 if self.rank == 0 else 0.0)
             K, Kn, knn = self._v("K", (self.m, self.m)), self._v("Kn", (b, self.m)), self._v("knn", (b,))
             call("svgp_sprites_kernel_matrix_fwd", C.byref(kc), aux.data_ptr(), p["inducing_index_points"].data_ptr(),
                  p["GPLVM_action"].data_ptr(), p["se"].data_ptr(), K.data_ptr(), Kn.data_ptr(), knn.data_ptr(), s)
             call("svgp_gp_stats_fwd", cp, ws, s)
+        yield [self.ws[self.wl.statA:self.wl.statA + self.wl.statA_len]]
+        with torch.cuda.stream(self.stream):
             call("svgp_gp_factor_fwd", cp, ws, s)
             call("svgp_gp_posterior_fwd", cp, None if eps is None else eps.contiguous().data_ptr(), ws, st, s)
             # ---------------- decoder
@@ -256,7 +276,7 @@ class SpritesStepEngine:
                  self._v("part_sums", (1,)).data_ptr(), s)
             # ================ reverse
             dx = torch.empty_like(recon)
-            call("svgp_sqerr_bwd", tot, int(self.geco), b, 64 * 64 * 3, st, images.data_ptr(), recon.data_ptr(),
+            call("svgp_sqerr_bwd", tot, int(self.geco), b_global, 64 * 64 * 3, st, images.data_ptr(), recon.data_ptr(),
                  dx.data_ptr(), s)
             for i in range(7, 0, -1):
                 lay = self.dec[i - 1]
@@ -269,6 +289,8 @@ class SpritesStepEngine:
             zbar = self._v("zbar", (b, L))
             self._gemm(0, 1, b, L, 1024, 1.0, dh0, 1024, p["dec_d_w"], 1024, 0.0, zbar, L)
             call("svgp_gp_stats_bwd", cp, ws, st, s)
+        yield [self.ws[self.wl.statB:self.wl.statB + self.wl.statB_len]]
+        with torch.cuda.stream(self.stream):
             call("svgp_gp_factor_bwd", cp, ws, st, s)
             call("svgp_gp_posterior_bwd", cp, ws, st, s)
             d_char = torch.empty(b, self.Lc, **f64)
@@ -305,6 +327,8 @@ class SpritesStepEngine:
             if self.svgp.fixed_GP_params or not self.svgp.K_SE:
                 g["se"].zero_()
             call("svgp_mnist_grad_reduce", cp, ws, s)           # scalar partial sums -> ws.sums
+        yield [self.grad, self.ws[self.wl.sums:self.wl.sums + 8]]
+        with torch.cuda.stream(self.stream):
             if self.clip_grad is not None:
                 call("svgp_clip_by_value", self.grad.numel(), float(self.clip_grad), self.grad.data_ptr(), s)
             if adam:
@@ -314,7 +338,6 @@ class SpritesStepEngine:
             else:
                 call("svgp_elbo_finalize_noadam", cp, ws, st, s)
             self.act = dict(recon=recon, aux=aux, enc=enc)
-        return self
 
     def outputs(self):
         """The 16-tuple of forward_pass_SVGPVAE for the last step (mean_vectors slot = aux data)."""

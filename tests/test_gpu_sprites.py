@@ -98,3 +98,54 @@ def test_sprites_training_steps_reduce_the_loss():
         losses.append(eng.scalars()["recon_loss"])
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
     assert eng.scalars()["adam_t"] == 8.0
+
+
+@pytest.mark.parametrize("G,K_SE,m,clip", [(2, False, 12, None), (3, True, 72, 0.05)])
+def test_sprites_virtual_ranks_equal_single_engine(G, K_SE, m, clip):
+    """Data parallelism over whole character groups: G engines on one GPU run the step's phases in
+    lockstep, the three exchange blocks are summed by hand (what the RCCL all-reduce does); scalars, gradients
+    and the parameters after two Adam steps must equal the single-engine run at the same global batch."""
+    from svgp_vae_amd import sprites as S
+    frames, L, La, Lc, n_act = 4, 6, 8, 16, 9
+    b = frames * 2 * G
+    params, gp, images, ids, eps, _, _ = _problem(b, frames, L, La, Lc, m, n_act, seed=G + m)
+    init = dict(params)
+    init["se"] = torch.stack([gp["l_action"], gp["sigma_action"], gp["l_character"], gp["sigma_character"]])
+
+    def make(rank, world, b_max):
+        svgp = S.spritesSVGP(False, False, gp["inducing_index_points"].numpy(), 'main', 0.01, 100.0, La,
+                             gp["GPLVM_action"].numpy(), Lc, L, fixed_GP_params=False, fixed_GPLVM=False,
+                             K_obj_normalize=not K_SE, K_SE=K_SE)
+        e = S.SpritesStepEngine(S.spritesVAE(L), S.sprites_representation_network(Lc), svgp, b_max=b_max,
+                                seg_len=frames, clip_qs=True, geco=True, kappa_squared=0.0075, clip_grad=clip,
+                                params=init, rank=rank, world_size=world)
+        e.set_scalars(c_ma=0.02, lagrange=1.4, alpha=0.9)
+        return e
+
+    single = make(0, 1, b)
+    dev = single.dev
+    di, da, de = images.to(dev), ids.to(dev, DT), eps.to(dev)
+    ranks = [make(r, G, b // G) for r in range(G)]
+    rows = [slice(r * (b // G), (r + 1) * (b // G)) for r in range(G)]
+    for step in range(2):
+        single.step(di, da, de, adam=True)
+        gens = [e.phases(di[sl].contiguous(), da[sl].contiguous(), de[sl].contiguous(), True, b)
+                for e, sl in zip(ranks, rows)]
+        for _ in range(3):
+            blocks = [next(gn) for gn in gens]
+            for e in ranks:
+                e.stream.synchronize()
+            for parts in zip(*blocks):
+                tot = sum(parts)
+                for t in parts:
+                    t.copy_(tot)
+            torch.cuda.synchronize()
+        for gn in gens:
+            assert next(gn, None) is None
+        ref = single.scalars()
+        for e in ranks:
+            sc = e.scalars()
+            for k in ("elbo", "recon_loss", "kl_term", "ce_term", "c_ma", "lagrange"):
+                assert abs(sc[k] - ref[k]) <= 1e-9 * max(1.0, abs(ref[k])), (step, k, sc[k], ref[k])
+            assert _rel(e.grad, single.grad) < 1e-8
+            assert _rel(e.theta, single.theta) < 1e-9

@@ -1,5 +1,5 @@
 // Batched float64 linear algebra on global-memory matrices for the large-m (m > 64) GP path:
-//   svgp_dgemm_batched        C[l] = alpha op(A[l]) op(B[l]) + beta C[l]     (f64 MFMA, 64x64 tiles)
+//   svgp_dgemm_batched        C[l] = alpha op(A[l]) op(B[l]) + beta C[l]     (f64 MFMA, 128x128 / 64x64 tiles)
 //   svgp_spd_inverse_batched  A[l] <- A[l]^-1, logdet[l]                      (blocked Gauss-Jordan)
 // They replace tf.matmul / tf.linalg.inv / tf.linalg.cholesky+log(diag) of the reference
 // (SVGPVAE_model.py:239,270-274,319,328-341) when the m x m matrices no longer fit in LDS.
@@ -10,13 +10,11 @@ namespace {
 typedef double d4_t __attribute__((ext_vector_type(4)));
 
 // ---------------------------------------------------------------------------------------------
-// GEMM.  Workgroup = 256 threads = 4 waves; output tile 64 x 64; wave w owns the 32 x 32 quadrant
-// (w>>1, w&1) = 2 x 2 MFMA 16x16 tiles; k-panels of 16 staged in LDS as As[k][i], Bs[k][j] (k-major:
+// GEMM.  Workgroup = 256 threads = 4 waves; output tile 32 WT x 32 WT; wave w owns the quadrant
+// (w>>1, w&1) = WT x WT MFMA 16x16 tiles; k-panels of 16 staged in LDS as As[k][i], Bs[k][j] (k-major:
 // the MFMA operand fetch A[i=lane&15][k=lane>>4] walks 16 consecutive i -> conflict-free).
 // ---------------------------------------------------------------------------------------------
-#define GT 64
 #define GK 16
-#define GLD (GT + 2)
 
 struct GemmArgs {
     int M, N, K;            // C is M x N, contraction K
@@ -27,66 +25,99 @@ struct GemmArgs {
     const real* A; const real* B; real* C;
 };
 
-__global__ __launch_bounds__(256) void k_dgemm_batched(GemmArgs g) {
-    __shared__ real As[GK][GLD];
-    __shared__ real Bs[GK][GLD];
-    const int l = blockIdx.z, i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
-    const real* A = g.A + (size_t)l * g.sa;
-    const real* B = g.B + (size_t)l * g.sb;
+// k-panels of 16 are double-buffered in LDS: the global loads of panel p+1 are in flight while the MFMAs of
+// panel p run, one barrier per panel.  Loads are 8-byte, arranged so that 16 lanes cover 128 contiguous
+// bytes of the operand whichever way it is stored.  WT = 4: 128 x 128 tile, 16 flop per staged byte, used
+// when that still gives >= 192 workgroups; WT = 2: 64 x 64 tile for small problems.
+template <bool TA, bool TB, int WT>
+__global__ __launch_bounds__(256, 2) void k_dgemm_batched(GemmArgs g) {
+    constexpr int HT = 32 * WT, HLD = HT + 2, NH = HT / 16;
+    extern __shared__ __align__(16) real hs[];
+    real* As = hs;                       // [2][GK][HLD]
+    real* Bs = hs + 2 * GK * HLD;        // [2][GK][HLD]
+    const int l = blockIdx.z, i0 = blockIdx.y * HT, j0 = blockIdx.x * HT;
+    const real* __restrict__ A = g.A + (size_t)l * g.sa;
+    const real* __restrict__ B = g.B + (size_t)l * g.sb;
     real* C = g.C + (size_t)l * g.sc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
-    d4_t acc[2][2];
+    const int wi = (wave >> 1) * 16 * WT, wj = (wave & 1) * 16 * WT;
+    d4_t acc[WT][WT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = d4_t{0, 0, 0, 0};
+        for (int b = 0; b < WT; ++b) acc[a][b] = d4_t{0, 0, 0, 0};
+    // staging coordinates: NH elements per operand per thread
+    //   operand stored [x][k] (k contiguous): k = tid & 15, x = (tid >> 4) + 16 h
+    //   operand stored [k][x] (x contiguous): x = tid % HT, k = tid / HT + (256 / HT) h
+    constexpr int KS = 256 / HT;
+    real ra[NH], rb[NH];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            if (TA) {
+                const int i = tid % HT, k = tid / HT + KS * h, gi = i0 + i, gk = k0 + k;
+                ra[h] = (gi < g.M && gk < g.K) ? A[(size_t)gk * g.lda + gi] : real(0);
+            } else {
+                const int k = tid & 15, i = (tid >> 4) + 16 * h, gi = i0 + i, gk = k0 + k;
+                ra[h] = (gi < g.M && gk < g.K) ? A[(size_t)gi * g.lda + gk] : real(0);
+            }
+            if (TB) {
+                const int k = tid & 15, j = (tid >> 4) + 16 * h, gj = j0 + j, gk = k0 + k;
+                rb[h] = (gj < g.N && gk < g.K) ? B[(size_t)gj * g.ldb + gk] : real(0);
+            } else {
+                const int j = tid % HT, k = tid / HT + KS * h, gj = j0 + j, gk = k0 + k;
+                rb[h] = (gj < g.N && gk < g.K) ? B[(size_t)gk * g.ldb + gj] : real(0);
+            }
+        }
+    };
+    auto stage = [&](int buf) {
+        real* Ad = As + buf * GK * HLD;
+        real* Bd = Bs + buf * GK * HLD;
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            if (TA) Ad[(tid / HT + KS * h) * HLD + tid % HT] = ra[h];
+            else Ad[(tid & 15) * HLD + (tid >> 4) + 16 * h] = ra[h];
+            if (TB) Bd[(tid & 15) * HLD + (tid >> 4) + 16 * h] = rb[h];
+            else Bd[(tid / HT + KS * h) * HLD + tid % HT] = rb[h];
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
     for (int k0 = 0; k0 < g.K; k0 += GK) {
-        __syncthreads();
-        // stage A panel: As[k][i] = op(A)[i0+i][k0+k]
-        if (g.ta) {          // A stored [k][i]: consecutive i
-            for (int t = tid; t < GK * GT; t += 256) {
-                const int k = t / GT, i = t % GT, gi = i0 + i, gk = k0 + k;
-                As[k][i] = (gi < g.M && gk < g.K) ? A[(size_t)gk * g.lda + gi] : real(0);
-            }
-        } else {             // A stored [i][k]: consecutive k
-            for (int t = tid; t < GK * GT; t += 256) {
-                const int i = t / GK, k = t % GK, gi = i0 + i, gk = k0 + k;
-                As[k][i] = (gi < g.M && gk < g.K) ? A[(size_t)gi * g.lda + gk] : real(0);
-            }
-        }
-        if (g.tb) {          // B stored [j][k]
-            for (int t = tid; t < GK * GT; t += 256) {
-                const int j = t / GK, k = t % GK, gj = j0 + j, gk = k0 + k;
-                Bs[k][j] = (gj < g.N && gk < g.K) ? B[(size_t)gj * g.ldb + gk] : real(0);
-            }
-        } else {             // B stored [k][j]
-            for (int t = tid; t < GK * GT; t += 256) {
-                const int k = t / GT, j = t % GT, gj = j0 + j, gk = k0 + k;
-                Bs[k][j] = (gj < g.N && gk < g.K) ? B[(size_t)gk * g.ldb + gj] : real(0);
-            }
-        }
-        __syncthreads();
+        const bool more = k0 + GK < g.K;
+        if (more) fetch(k0 + GK);
+        const real* Ab = As + cur * GK * HLD + wi + r;
+        const real* Bb = Bs + cur * GK * HLD + wj + r;
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
-            const real a0 = As[kk + q][wi + r], a1 = As[kk + q][wi + 16 + r];
-            const real b0 = Bs[kk + q][wj + r], b1 = Bs[kk + q][wj + 16 + r];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            real av[WT], bv[WT];
+#pragma unroll
+            for (int a = 0; a < WT; ++a) av[a] = Ab[(kk + q) * HLD + 16 * a];
+#pragma unroll
+            for (int b = 0; b < WT; ++b) bv[b] = Bb[(kk + q) * HLD + 16 * b];
+#pragma unroll
+            for (int a = 0; a < WT; ++a)
+#pragma unroll
+                for (int b = 0; b < WT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
     }
+    const bool has_beta = g.beta != real(0);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < WT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < WT; ++b)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int gi = i0 + wi + a * 16 + q + 4 * e, gj = j0 + wj + b * 16 + r;
                 if (gi < g.M && gj < g.N) {
                     const size_t o = (size_t)gi * g.ldc + gj;
-                    C[o] = g.alpha * acc[a][b][e] + (g.beta != real(0) ? g.beta * C[o] : real(0));
+                    C[o] = g.alpha * acc[a][b][e] + (has_beta ? g.beta * C[o] : real(0));
                 }
             }
 }
@@ -266,8 +297,27 @@ extern "C" int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double al
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.ta = ta; g.tb = tb; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sa = strideA; g.sb = strideB; g.sc = strideC; g.alpha = alpha; g.beta = beta; g.A = A; g.B = B; g.C = C;
-    hipLaunchKernelGGL(k_dgemm_batched, dim3((N + GT - 1) / GT, (M + GT - 1) / GT, batch), dim3(256), 0,
-                       (hipStream_t)stream, g);
+    const long long blocks128 = (long long)((N + 127) / 128) * ((M + 127) / 128) * batch;
+    const int wt = blocks128 >= 192 ? 4 : 2, ht = 32 * wt;
+    const size_t lds = (size_t)4 * GK * (ht + 2) * sizeof(real);
+    const dim3 grid((N + ht - 1) / ht, (M + ht - 1) / ht, batch);
+#define LAUNCH_G(TA_, TB_, WT_)                                                                              \
+    do {                                                                                                     \
+        SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgemm_batched<TA_, TB_, WT_>),     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
+        hipLaunchKernelGGL((k_dgemm_batched<TA_, TB_, WT_>), grid, dim3(256), lds, (hipStream_t)stream, g);   \
+    } while (0)
+#define LAUNCH_T(WT_)                                \
+    do {                                             \
+        if (ta && tb) LAUNCH_G(true, true, WT_);     \
+        else if (ta) LAUNCH_G(true, false, WT_);     \
+        else if (tb) LAUNCH_G(false, true, WT_);     \
+        else LAUNCH_G(false, false, WT_);            \
+    } while (0)
+    if (wt == 4) LAUNCH_T(4);
+    else LAUNCH_T(2);
+#undef LAUNCH_T
+#undef LAUNCH_G
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

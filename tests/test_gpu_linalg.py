@@ -38,7 +38,7 @@ def test_dgemm_batched(ta, tb, M, N, K, batch):
     assert float((Cn - want).abs().max()) <= 1e-12 * K * float(want.abs().max() + 1)
 
 
-@pytest.mark.parametrize("m,batch", [(32, 1), (64, 3), (72, 2), (100, 1), (256, 17), (513, 2)])
+@pytest.mark.parametrize("m,batch", [(32, 1), (64, 3), (72, 2), (100, 1), (128, 2), (130, 3), (256, 17), (513, 2), (640, 2), (800, 3)])
 def test_spd_inverse_batched(m, batch):
     g = torch.Generator(device="cuda").manual_seed(m)
     X = torch.randn(batch, m, m + 8, dtype=DT, device="cuda", generator=g)
@@ -55,3 +55,33 @@ def test_spd_inverse_batched(m, batch):
     assert float((logdet - torch.linalg.slogdet(A)[1]).abs().max()) < 1e-9 * m
     eye = torch.eye(m, dtype=DT, device="cuda")
     assert float((inv @ A - eye).abs().max()) < 1e-8
+
+
+@pytest.mark.parametrize("m,jitter", [(128, 1e-6), (512, 1e-6), (800, 1e-4), (800, 1e-6)])
+def test_spd_inverse_residual_on_kernel_like_spectrum(m, jitter):
+    """K + jitter I with a fast-decaying spectrum (what the GP block inverts, SVGPVAE_model.py:239,319,331): the
+    residuals |A X - I|, |X A - I| and the sandwich K X K must stay at torch.linalg.inv's level.  This is the property
+    the two-level (m >= 512) inverse keeps only because it regroups the 32-block sweep's arithmetic instead of taking
+    128-wide explicit products (those lose cond(P) here: 1e-2 residual at jitter 1e-6)."""
+    g = torch.Generator(device="cuda").manual_seed(m)
+    Q, _ = torch.linalg.qr(torch.randn(m, m, dtype=DT, device="cuda", generator=g))
+    lam = 50 * torch.exp(-torch.arange(m, dtype=DT, device="cuda") / 8)
+    K = (Q * lam) @ Q.T
+    K = 0.5 * (K + K.T)
+    eye = torch.eye(m, dtype=DT, device="cuda")
+    A = K + jitter * eye
+    X = A.clone()[None].contiguous()
+    logdet = torch.zeros(1, dtype=DT, device="cuda")
+    lib = _lib.load_library()
+    work = torch.zeros(lib.svgp_spd_inverse_workspace_elems(m, 1), dtype=DT, device="cuda")
+    _lib.call("svgp_spd_inverse_batched", m, 1, X.data_ptr(), logdet.data_ptr(), work.data_ptr(),
+              torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    X = X[0]
+    T = torch.linalg.inv(A)
+    res = lambda Z: max(float((A @ Z - eye).abs().max()), float((Z @ A - eye).abs().max()))
+    sand = (Q * (lam * lam / (lam + jitter))) @ Q.T
+    sw = lambda Z: float((K @ Z @ K - sand).abs().max() / sand.abs().max())
+    assert res(X) <= 10 * res(T) + 1e-12
+    assert sw(X) <= 10 * sw(T) + 1e-13
+    assert abs(float(logdet[0]) - float(torch.log(lam + jitter).sum())) < 1e-8 * m

@@ -60,6 +60,8 @@ typedef struct {
     int32_t clip_pv;       /* 1: clip the posterior variance p_v to [1e-4, 100] (SPRITES,          */
                            /* SVGPVAE_model.py:891-892); the clip mask enters the reverse pass     */
     int32_t n_pix;         /* pixels per image in the reconstruction loss (0 = 784 = MNIST)        */
+    int32_t titsias;       /* 1: mainSVGP(titsias=True): inside-ELBO = sum_l L_2 (SVGPVAE_model.py:246-259,  */
+                           /* 882-883) instead of the Hensman L_3 / KL pair                          */
     double  N_train;       /* mainSVGP.N_train                                                  */
     double  jitter;        /* mainSVGP.jitter                                                   */
     double  kappa_squared; /* GECO kappa^2                                                      */
@@ -87,7 +89,7 @@ typedef struct {
     int64_t qnet_mu, qnet_var_raw, qnet_var; /* (b,L) each; var = clip(exp(.))                    */
     /* kernel matrices (SVGPVAE_model.py:427-476) */
     int64_t K, Kn, knn;                   /* (m,m) (b,m) (b)                                      */
-    /* forward statistics: ONE contiguous all-reduce block [S | v] */
+    /* forward statistics: ONE contiguous all-reduce block [S | v] (titsias: [S | v | tit_S2 | tit_v2]) */
     int64_t statA, statA_len, S, v;       /* S (L,m,m), v (L,m)                                   */
     /* m x m factor stage (SVGPVAE_model.py:239,270-279,319-341) */
     int64_t Ki, ldK, Si, t, G, A, Aji, mu_hat, u, M2, KL, q; /* M2 = Ki A Ki (L,m,m); q (b)       */
@@ -109,6 +111,9 @@ typedef struct {
     int64_t part_sums, n_post;            /* (n_part,4) [.,.,recon sq,.] then (n_post,2) [L3 data, CE] */
     /* final all-reduce block: [grad (n_total) | sums (8)] */
     int64_t gradC, gradC_len, grad, sums;
+    /* Titsias branch (cfg.titsias; zero-sized otherwise): statistics with weights 1/(var + jitter) inside statA,
+     * (K + jI + S2)^-1, its product with v2, scalars [logdet (L) | v2.t2 (L) | row sum (1)] */
+    int64_t tit_S2, tit_v2, tit_Si, tit_t, tit_scal;
     int64_t total;                        /* workspace size in float64 elements                   */
 } svgp_mnist_ws_layout;
 
@@ -164,6 +169,21 @@ int svgp_mnist_decoder_fwd(const svgp_mnist_cfg*, const double* theta, const dou
 /* reverse of the decoder; writes zbar and decoder weight-gradient partials */
 int svgp_mnist_decoder_bwd(const svgp_mnist_cfg*, const double* theta, const double* images,
                            double* ws, const double* state, void* stream);
+/* Titsias branch (cfg.titsias = 1), SVGPVAE_model.py:246-259: L_2 = -1/2 [b log 2pi + log det C + y^T C^-1 y +
+ * sum_n (k_nn - q_n)/var_n], C = diag(var) + K_nm (K_mm + jI)^-1 K_mn + jI (b x b).  Computed in m x m space through
+ * the Woodbury identity with the statistics S2_l = sum_n k_n k_n^T/(var_nl + j), v2_l = sum_n y_nl k_n/(var_nl + j):
+ *   log det C = sum_n log(var_n + j) + log det(K + jI + S2) - log det(K + jI)
+ *   y^T C^-1 y = sum_n y_n^2/(var_n + j) - v2^T (K + jI + S2)^-1 v2
+ * so the b x b inverse and Cholesky of the reference never exist and the branch shards over rows like the Hensman
+ * one (S2, v2 ride in the statA all-reduce).  p_m, p_v, the cross-entropy term and everything downstream are the
+ * shared stages; with cfg.titsias the L_3 / KL seeds of their reverse passes are zero and
+ * svgp_gp_titsias_bwd adds the L_2 gradients to ybar, s2bar, Knbar, knnbar, Kbar.
+ *   svgp_gp_titsias_stats : after svgp_gp_stats_fwd (phase 0)        -> ws[tit_S2], ws[tit_v2]
+ *   svgp_gp_titsias_fwd   : after svgp_gp_posterior_fwd (phase 1)    -> ws[tit_Si], ws[tit_t], ws[tit_scal]
+ *   svgp_gp_titsias_bwd   : after svgp_gp_posterior_bwd (phase 2), before svgp_kernel_matrix_bwd            */
+int svgp_gp_titsias_stats(const svgp_mnist_cfg*, double* ws, void* stream);
+int svgp_gp_titsias_fwd(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+int svgp_gp_titsias_bwd(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 /* upstream gradients of p_m, p_v + backward statistics block statB (DP all-reduces it) */
 int svgp_gp_stats_bwd(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 /* all m x m reverse algebra -> Kbar and the per-channel matrices of the row stage */

@@ -223,6 +223,27 @@ def gp_block_efficient(K, Kn, knn, y, s2, jitter, N_train, b_global=None, want_a
     return p_m, p_v, L3, KL
 
 
+def titsias_block_efficient(K, Kn, knn, y, s2, jitter):
+    """sum over channels of the Titsias L_2 (SVGPVAE_model.py:246-259) WITHOUT b x b matrices: Woodbury / matrix
+    determinant lemma on C = diag(s2 + j) + Kn (K + jI)^-1 Kn^T.  This is the formulation the HIP path implements
+    (gp_titsias.hip); tests/test_oracle_kat.py pins it against the literal branch of MnistSVGP.variational_loss."""
+    b, m = Kn.shape
+    L = y.shape[1]
+    eye = torch.eye(m, dtype=DT)
+    Kj = K + jitter * eye
+    Ki = torch.linalg.inv(Kj)
+    ldK = 2 * torch.sum(torch.log(torch.diagonal(torch.linalg.cholesky(Kj))))
+    d = s2 + jitter                                       # (b,L)
+    S2 = torch.einsum('nl,ni,nj->lij', 1.0 / d, Kn, Kn)
+    v2 = torch.einsum('nl,ni->li', y / d, Kn)
+    Sig = Kj[None] + S2
+    ld2 = 2 * torch.sum(torch.log(torch.diagonal(torch.linalg.cholesky(Sig), dim1=-2, dim2=-1)), dim=-1)
+    t2 = torch.einsum('lij,lj->li', torch.linalg.inv(Sig), v2)
+    q = torch.sum((Kn @ Ki) * Kn, dim=1)
+    rows = (torch.log(d) + y * y / d + reciprocal_no_nan(s2) * (knn - q)[:, None]).sum(0)    # (L,)
+    return -0.5 * (b * LOG_2PI + rows + ld2 - ldK - (v2 * t2).sum(1))
+
+
 # --------------------------------------------------------------------------------------
 # mnistVAE (VAE_utils.py:99-162), Keras semantics on NHWC tensors
 # --------------------------------------------------------------------------------------
@@ -415,14 +436,14 @@ def make_models(params, titsias, jitter, N_train, L, K_obj_normalize=False):
 
 def loss_and_grads(params, images, aux, epsilon, *, beta, C_ma, lagrange_mult, alpha, kappa,
                    clipping_qs, GECO, jitter, N_train, L, formulation="literal",
-                   K_obj_normalize=False, b_global=None):
+                   K_obj_normalize=False, b_global=None, titsias=False):
     """Returns (16-tuple detached, grads dict) of the minimised objective:
     GECO -> `elbo` slot itself, else `-elbo` (MNIST_experiment.py:202-205)."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
-    vae, svgp = make_models(leaf, False, jitter, N_train, L, K_obj_normalize)
+    vae, svgp = make_models(leaf, titsias, jitter, N_train, L, K_obj_normalize)
     out = forward_pass_SVGPVAE((images, aux), beta, vae, svgp, C_ma, lagrange_mult, alpha, kappa,
                                clipping_qs=clipping_qs, GECO=GECO, epsilon=epsilon,
-                               formulation=formulation, b_global=b_global)
+                               formulation="literal" if titsias else formulation, b_global=b_global)
     objective = out[0] if GECO else -out[0]
     names = list(leaf.keys())
     gs = torch.autograd.grad(objective, [leaf[k] for k in names], allow_unused=True)

@@ -16,7 +16,8 @@ Additional (no reference counterpart - TF's tf.gradients + AdamOptimizer live in
   gradients_SVGPVAE(...) and train_step_SVGPVAE(...).
 
   bacthing_predict_SVGPVAE_rotated_mnist(test_data_batch, vae, svgp, qnet_mu, qnet_var, aux_data_train)  :1026-1083
-Not implemented in this build (raise NotImplementedError): the Titsias branch (titsias=True), the
+titsias=True selects the SVGPVAE_Titsias inside-ELBO (:246-259), computed in m x m space (Woodbury; see
+gp_titsias.hip).  Not implemented in this build (raise NotImplementedError): the
 single-channel approximate_posterior_params with test != train points (the batched conditional-generation
 function above covers that use), SPRITES.
 """
@@ -33,10 +34,8 @@ _F64 = torch.float64
 class mnistSVGP:
     def __init__(self, titsias, fixed_inducing_points, initial_inducing_points, fixed_gp_params,
                  object_vectors_init, name, jitter, N_train, L, K_obj_normalize=False, device="cuda:0"):
-        if titsias:
-            raise NotImplementedError("SVGPVAE_Titsias branch (SVGPVAE_model.py:246-259) is not built yet")
         self.dtype = _F64
-        self.titsias = titsias
+        self.titsias = bool(titsias)
         self.jitter = float(jitter)
         self.N_train = float(N_train)
         self.L = L
@@ -66,7 +65,7 @@ class mnistSVGP:
         M = self.inducing_index_points.shape[1] - 2
         n_obj = 0 if self.object_vectors is None else self.object_vectors.shape[0]
         eng = MnistStepEngine(self.nr_inducing, L, M, n_obj, N_train=self.N_train, jitter=self.jitter,
-                              clip_qs=False, geco=False, K_obj_normalize=self.K_obj_normalize,
+                              clip_qs=False, geco=False, K_obj_normalize=self.K_obj_normalize, titsias=self.titsias,
                               b_max=b, device=self.device)
         eng.load_params({k: v for k, v in self._params().items()})
         return eng
@@ -114,8 +113,12 @@ class mnistSVGP:
             eng.stream.wait_stream(torch.cuda.current_stream(dev))
             call("svgp_kernel_matrix_fwd", cfg, th, d_aux.data_ptr(), ws, s)
             call("svgp_gp_stats_fwd", cfg, ws, s)
+            if self.titsias:
+                call("svgp_gp_titsias_stats", cfg, ws, s)
             call("svgp_gp_factor_fwd", cfg, ws, s)
             call("svgp_gp_posterior_fwd", cfg, zeros.data_ptr(), ws, st, s)
+            if self.titsias:
+                call("svgp_gp_titsias_fwd", cfg, ws, st, s)
         eng.synchronize()
         return eng, b
 
@@ -136,6 +139,10 @@ class mnistSVGP:
         ones approximate_posterior_params returns for the same (x, y, noise) - the only use in the
         reference (:869-873); they are recomputed on device."""
         eng, b = self._channel(x, y, noise)
+        if self.titsias:   # (L_2, 0)  :246-259
+            sc = eng.ws_view("tit_scal", (3,))       # [log det Sigma2, v2.t2, row sum]  (L = 1)
+            l2 = -0.5 * (b * 1.8378770664093453 + sc[2] + sc[0] - eng.ws_view("ldK", (1,))[0] - sc[1])
+            return l2.clone(), torch.zeros((), dtype=_F64, device=eng.device)
         p = 1.0 / eng.ws_view("qnet_var", (b,))
         l3 = -0.5 * (torch.sum(p * eng.ws_view("d", (b,))) + torch.sum(torch.log(eng.ws_view("qnet_var", (b,))))
                      + b * 1.8378770664093453)
@@ -158,6 +165,7 @@ class _Runtime:
         self.key = (bool(clipping_qs), bool(GECO), float(kappa))
         self.eng = MnistStepEngine(svgp.nr_inducing, vae.L, M, n_obj, N_train=svgp.N_train, jitter=svgp.jitter,
                                    clip_qs=clipping_qs, geco=GECO, K_obj_normalize=svgp.K_obj_normalize,
+                                   titsias=svgp.titsias,
                                    kappa_squared=float(kappa) ** 2, alpha=alpha_flag, beta=beta, lr=lr,
                                    train_ip=not svgp.fixed_inducing_points, train_gp=not svgp.fixed_gp_params,
                                    train_ov=svgp.object_vectors is not None, b_max=b_max, device=svgp.device,

@@ -15,7 +15,8 @@ class SvgpError(RuntimeError):
 
 class MnistCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("b", "b_global", "m", "L", "M", "n_obj", "normalize_obj", "clip_qs",
-                                         "geco", "train_ip", "train_gp", "train_ov", "b_cap", "clip_pv", "n_pix")] + \
+                                         "geco", "train_ip", "train_gp", "train_ov", "b_cap", "clip_pv", "n_pix",
+                                         "titsias")] + \
                [(n, C.c_double) for n in ("N_train", "jitter", "kappa_squared", "alpha", "rep_weight")]
 
 
@@ -39,7 +40,8 @@ WS_FIELDS = ("enc_a1", "enc_a2", "enc_a3", "qnet_mu", "qnet_var_raw", "qnet_var"
              "scr_bm", "scr_mm", "scr_vec", "scr_inv", "scr_bl",
              "Knbar", "knnbar", "ybar", "s2bar", "d_on",
              "part_dec", "part_enc", "n_part", "part_gp", "part_sums", "n_post",
-             "gradC", "gradC_len", "grad", "sums", "total")
+             "gradC", "gradC_len", "grad", "sums",
+             "tit_S2", "tit_v2", "tit_Si", "tit_t", "tit_scal", "total")
 
 
 class WsLayout(C.Structure):
@@ -77,6 +79,9 @@ SIGNATURES = {
     "svgp_gp_stats_bwd": [_CFG, _P, _P, _P],
     "svgp_gp_factor_bwd": [_CFG, _P, _P, _P],
     "svgp_gp_posterior_bwd": [_CFG, _P, _P, _P],
+    "svgp_gp_titsias_stats": [_CFG, _P, _P],
+    "svgp_gp_titsias_fwd": [_CFG, _P, _P, _P],
+    "svgp_gp_titsias_bwd": [_CFG, _P, _P, _P],
     "svgp_kernel_matrix_bwd": [_CFG, _P, _P, _P, _P],
     "svgp_mnist_encoder_bwd": [_CFG, _P, _P, _P, _P],
     "svgp_mnist_grad_reduce": [_CFG, _P, _P],

@@ -70,7 +70,10 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->enc_a1 = take(b * 13 * 13 * 8); o->enc_a2 = take(b * 6 * 6 * 8); o->enc_a3 = take(b * 32);
     o->qnet_mu = take(b * L); o->qnet_var_raw = take(b * L); o->qnet_var = take(b * L);
     o->K = take(m * m); o->Kn = take(b * m); o->knn = take(b);
-    o->statA = p; o->S = p; p += L * m * m; o->v = p; p += L * m; o->statA_len = p - o->statA; take(0);
+    o->statA = p; o->S = p; p += L * m * m; o->v = p; p += L * m;
+    o->tit_S2 = p; if (c->titsias) p += L * m * m;
+    o->tit_v2 = p; if (c->titsias) p += L * m;
+    o->statA_len = p - o->statA; take(0);
     o->Ki = take(m * m); o->ldK = take(1);
     o->Si = take(L * m * m); o->t = take(L * m); o->G = take(L * m * m); o->A = take(L * m * m);
     o->Aji = take(L * m * m); o->mu_hat = take(L * m); o->u = take(L * m); o->M2 = take(L * m * m);
@@ -95,6 +98,8 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->n_post = (int64_t)L * svgp_n_postblk(&cc);
     o->part_sums = take(o->n_part * 4 + o->n_post * 2);
     o->gradC = p; o->grad = p; p += pl.n_total; o->sums = p; p += 8; o->gradC_len = p - o->gradC; take(0);
+    o->tit_Si = take(c->titsias ? L * m * m : 0); o->tit_t = take(c->titsias ? L * m : 0);
+    o->tit_scal = take(c->titsias ? 2 * L + 1 : 0);
     o->total = p;
     return SVGP_OK;
 }
@@ -182,10 +187,12 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         RUN(svgp_kernel_matrix_fwd(c, theta, aux, ws, stream));
         RUN(svgp_mnist_encoder_fwd(c, theta, images, ws, stream));
         RUN(svgp_gp_stats_fwd(c, ws, stream));
+        if (c->titsias) RUN(svgp_gp_titsias_stats(c, ws, stream));
         break;
     case 1:
         RUN(svgp_gp_factor_fwd(c, ws, stream));
         RUN(svgp_gp_posterior_fwd(c, eps, ws, state, stream));
+        if (c->titsias) RUN(svgp_gp_titsias_fwd(c, ws, state, stream));
         RUN(svgp_mnist_decoder_fwd(c, theta, images, ws, stream));
         RUN(svgp_mnist_decoder_bwd(c, theta, images, ws, state, stream));
         RUN(svgp_gp_stats_bwd(c, ws, state, stream));
@@ -193,6 +200,7 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
     case 2:
         RUN(svgp_gp_factor_bwd(c, ws, state, stream));
         RUN(svgp_gp_posterior_bwd(c, ws, state, stream));
+        if (c->titsias) RUN(svgp_gp_titsias_bwd(c, ws, state, stream));
         if (fork2) RUN(side_fork(sd, 0, ms));
         RUN(svgp_kernel_matrix_bwd(c, theta, aux, ws, s2));
         RUN(svgp_mnist_encoder_bwd(c, theta, images, ws, stream));

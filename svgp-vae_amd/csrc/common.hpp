@@ -40,6 +40,22 @@ int svgp_mnist_step_phase_deferred(const svgp_mnist_cfg* c, int phase, double* t
                                    const double* aux, const double* eps, double* ws, double* state, double* adam_m,
                                    double* adam_v, void* stream);
 
+// Loss seeds of the reverse passes.  `flags` = cfg.geco | cfg.titsias << 1 (SVGP_LOSS_FLAGS).
+//   seed_T : d(minimised objective)/d(KL_term): GECO -1 (SVGPVAE_model.py:913), beta-ELBO -beta/L (:925); also
+//            the seed of the cross-entropy term and, for Titsias, of sum_l L_2
+//   seed_3 : seed of the Hensman L_3 terms  (0 for Titsias: L_2 is handled by gp_titsias.hip)
+//   seed_K : seed of the Hensman KL terms   (0 for Titsias)
+#define SVGP_LOSS_FLAGS(c) ((c)->geco | ((c)->titsias ? 2 : 0))
+#ifdef __HIPCC__
+__device__ __forceinline__ real svgp_seed_T(int flags, int L, const real* state) {
+    return (flags & 1) ? real(-1) : -state[SVGP_ST_BETA] / (real)L;
+}
+__device__ __forceinline__ real svgp_seed_3(int flags, real gT) { return (flags & 2) ? real(0) : gT; }
+__device__ __forceinline__ real svgp_seed_K(int flags, real gT, real b_over_N) {
+    return (flags & 2) ? real(0) : -gT * b_over_N;
+}
+#endif
+
 #define SVGP_LAUNCH_CHECK() SVGP_CHECK_HIP(hipGetLastError())
 
 int svgp_check_cfg(const svgp_mnist_cfg* c);

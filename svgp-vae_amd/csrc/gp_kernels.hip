@@ -504,10 +504,7 @@ struct StatArgs {
     const real* K; real* Ki; real* ldK;
 };
 
-__device__ __forceinline__ real grad_KL_term(int geco, int L, const real* state) {
-    // d(minimised objective)/d(KL_term): GECO -1 (SVGPVAE_model.py:913), beta-ELBO -beta/L (:925)
-    return geco ? real(-1) : -state[SVGP_ST_BETA] / (real)L;
-}
+__device__ __forceinline__ real grad_KL_term(int flags, int L, const real* state) { return svgp_seed_T(flags, L, state); }
 
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
     extern __shared__ __align__(16) real smem[];
@@ -563,7 +560,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
                 real gpv = real(0.5) * gT * p + zb * a.eps[e] / (real(2) * sqrt(pv));
                 if (a.clip_pv && !(pv > 1e-4 && pv < 100.0)) gpv = 0;      // tf.clip_by_value mask (:891-892)
                 const real gpm = gT * p * (a.p_m[e] - a.y[e]) + zb;
-                const real mvb = gT * p * a.e[e];
+                const real mvb = svgp_seed_3(a.geco, gT) * p * a.e[e];
                 w[rr] = gpv;
                 va[rr] = mvb;
                 vb[rr] = a.c * gpm;
@@ -861,7 +858,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     real* muv = vv + m;        // m  (mu_hat_l)
     const size_t om = (size_t)l * m * m, ov = (size_t)l * m;
     const real gT = grad_KL_term(a.geco, a.L, a.state);
-    const real g3 = gT, gK = -gT * ((real)a.b_global / a.N_train);
+    const real g3 = svgp_seed_3(a.geco, gT), gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
     real* Kb = a.Kbar_part + om;
     real* Kib = a.Kibar_part + om;
 
@@ -953,7 +950,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd_final(FactBwdArgs 
     const int m = a.m, o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= m * m) return;
     const real gT = grad_KL_term(a.geco, a.L, a.state);
-    const real gK = -gT * ((real)a.b_global / a.N_train);
+    const real gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
     real s = 0;
 #pragma unroll 8
     for (int l = 0; l < a.L; ++l) s += a.Kbar_part[(size_t)l * m * m + o];
@@ -997,7 +994,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_l(PostBwdArgs a
     if (act) kr[nl * m + i] = a.Kn[(size_t)n * m + i];
     __syncthreads();
     const real gT = grad_KL_term(a.geco, a.L, a.state);
-    const real g3 = gT;
+    const real g3 = svgp_seed_3(a.geco, gT);
     real ksk = 0, kv = 0;
     if (act) {
         const size_t e = (size_t)n * a.L + l;
@@ -1048,7 +1045,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_sum(PostBwdArgs
         real qbar = 0;
         for (int l = 0; l < a.L; ++l) {
             const size_t e = (size_t)n * a.L + l;
-            qbar += real(0.5) * gT * recip_no_nan(a.s2[e]) - a.g_pv[e];
+            qbar += real(0.5) * svgp_seed_3(a.geco, gT) * recip_no_nan(a.s2[e]) - a.g_pv[e];
         }
         qb[nl] = qbar;
         a.knnbar[n] = -qbar;
@@ -1144,7 +1141,7 @@ static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     StatArgs a;
     memset(&a, 0, sizeof(a));
     a.b = c->b; a.m = c->m; a.L = c->L; a.mode = mode; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;
-    a.geco = c->geco; a.clip_pv = c->clip_pv;
+    a.geco = SVGP_LOSS_FLAGS(c); a.clip_pv = c->clip_pv;
     a.Kn = ws + wl.Kn; a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var;
     a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v; a.e = ws + wl.e; a.eps = ws + wl.eps; a.zbar = ws + wl.zbar;
     a.state = state;
@@ -1225,7 +1222,7 @@ extern "C" int svgp_gp_posterior_fwd(const svgp_mnist_cfg* c, const double* eps,
 
 static FactBwdArgs make_fb(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state) {
     FactBwdArgs a;
-    a.b_global = c->b_global; a.m = c->m; a.L = c->L; a.geco = c->geco; a.c = c->N_train / (double)c->b_global;
+    a.b_global = c->b_global; a.m = c->m; a.L = c->L; a.geco = SVGP_LOSS_FLAGS(c); a.c = c->N_train / (double)c->b_global;
     a.N_train = c->N_train; a.state = state;
     a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.S = ws + wl.S; a.v = ws + wl.v; a.Si = ws + wl.Si; a.t = ws + wl.t;
     a.G = ws + wl.G; a.A = ws + wl.A; a.Aji = ws + wl.Aji; a.mu = ws + wl.mu_hat; a.u = ws + wl.u; a.M2 = ws + wl.M2;
@@ -1258,7 +1255,7 @@ extern "C" int svgp_gp_posterior_bwd(const svgp_mnist_cfg* c, double* ws, const 
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     if (c->m > SVGP_M_MAX) return svgp_big_posterior_bwd(c, wl, ws, state, stream);
     PostBwdArgs a;
-    a.b = c->b; a.m = c->m; a.L = c->L; a.geco = c->geco; a.c = c->N_train / (double)c->b_global; a.state = state;
+    a.b = c->b; a.m = c->m; a.L = c->L; a.geco = SVGP_LOSS_FLAGS(c); a.c = c->N_train / (double)c->b_global; a.state = state;
     a.Kn = ws + wl.Kn; a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var; a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v;
     a.e = ws + wl.e; a.d = ws + wl.d; a.g_pv = ws + wl.g_pv; a.g_pm = ws + wl.g_pm; a.mvbar = ws + wl.mvbar;
     a.Si = ws + wl.Si; a.Qm = ws + wl.Qm; a.Ssym = ws + wl.Ssym; a.u = ws + wl.u; a.t = ws + wl.t; a.vbar = ws + wl.vbar;

@@ -12,9 +12,7 @@ extern "C" int svgp_spd_inverse_batched(int m, int batch, double* A, double* log
 
 namespace {
 
-__device__ __forceinline__ real gradKL(int geco, int L, const real* state) {
-    return geco ? real(-1) : -state[SVGP_ST_BETA] / (real)L;
-}
+__device__ __forceinline__ real gradKL(int flags, int L, const real* state) { return svgp_seed_T(flags, L, state); }
 
 // ---- element-wise / reduction kernels ---------------------------------------------------------
 // weights of the statistics.  mode 0: w = 1/s2, a = y/s2.  mode 1: g_pv, g_pm, mvbar (stored), b = c g_pm.
@@ -35,7 +33,7 @@ __global__ void k_big_weights(int n_el, int L, int mode, int geco, int clip_pv, 
         real gpv = real(0.5) * gT * p + zb * eps[i] / (real(2) * sqrt(pv));
         if (clip_pv && !(pv > 1e-4 && pv < 100.0)) gpv = 0;
         const real gpm = gT * p * (p_m[i] - y[i]) + zb;
-        w[i] = gpv; bv[i] = gpm; a[i] = gT * p * e[i];       // g_pv, g_pm, mvbar buffers
+        w[i] = gpv; bv[i] = gpm; a[i] = svgp_seed_3(geco, gT) * p * e[i];       // g_pv, g_pm, mvbar buffers
     }
 }
 // W[l][n][j] = wt[n][l] * scale * Kn[n][j]
@@ -155,7 +153,7 @@ struct FbArgs {
 };
 __device__ __forceinline__ void fb_scalars(const FbArgs& a, real& g3, real& gK) {
     const real gT = gradKL(a.geco, a.L, a.state);
-    g3 = gT; gK = -gT * ((real)a.b_global / a.N_train);
+    g3 = svgp_seed_3(a.geco, gT); gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
 }
 __global__ void k_big_fb_abar(FbArgs a) {     // Abar, ubar
     real g3, gK; fb_scalars(a, g3, gK);
@@ -208,7 +206,7 @@ __global__ void k_big_fb_final(int m, int L, int geco, int b_global, real N_trai
                                const real* __restrict__ Kb, const real* __restrict__ Ki, real* __restrict__ Kbar) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= m * m) return;
-    const real gT = gradKL(geco, L, state), gK = -gT * ((real)b_global / N_train);
+    const real gT = gradKL(geco, L, state), gK = svgp_seed_K(geco, gT, (real)b_global / N_train);
     real s = 0;
     for (int l = 0; l < L; ++l) s += Kb[(size_t)l * m * m + o];
     Kbar[o] = s + real(0.5) * gK * (real)L * Ki[o];
@@ -245,7 +243,7 @@ __global__ void k_big_pb_part2(PbArgs a) {    // part += p (Kn Q) + mvbar u + c 
 __global__ void k_big_pb_elem(PbArgs a) {     // ybar, s2bar
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.b * a.L) return;
-    const real gT = gradKL(a.geco, a.L, a.state), g3 = gT;
+    const real gT = gradKL(a.geco, a.L, a.state), g3 = svgp_seed_3(a.geco, gT);
     const real y = a.y[i], s2 = a.s2[i], p = recip_no_nan(s2), dm = a.p_m[i] - y, kV = a.kv[i];
     const real pbar = real(-0.5) * g3 * a.d[i] + a.kSk[i] + y * kV;
     a.ybar[i] = -gT * p * dm - g3 * p * a.e[i] + p * kV;
@@ -259,7 +257,7 @@ __global__ void k_big_pb_sum(PbArgs a) {      // Knbar = sum_l part + 2 qbar (Kn
     real qbar = 0, acc = 0;
     for (int l = 0; l < a.L; ++l) {
         const size_t e = (size_t)n * a.L + l;
-        qbar += real(0.5) * gT * recip_no_nan(a.s2[e]) - a.g_pv[e];
+        qbar += real(0.5) * svgp_seed_3(a.geco, gT) * recip_no_nan(a.s2[e]) - a.g_pv[e];
         acc += a.part[(size_t)l * bm + i];
     }
     a.Knbar[i] = acc + real(2) * qbar * a.KnKi[i];
@@ -299,7 +297,7 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
     real* wbuf = ws + wl.g_pv;
     real* abuf = mode == 0 ? ws + wl.g_pm : ws + wl.mvbar;
     real* bbuf = ws + wl.g_pm;
-    hipLaunchKernelGGL(k_big_weights, dim3(nblk((long long)b * L)), dim3(256), 0, st, b * L, L, mode, c->geco, c->clip_pv, cc, state,
+    hipLaunchKernelGGL(k_big_weights, dim3(nblk((long long)b * L)), dim3(256), 0, st, b * L, L, mode, SVGP_LOSS_FLAGS(c), c->clip_pv, cc, state,
                        ws + wl.qnet_mu, ws + wl.qnet_var, ws + wl.p_m, ws + wl.p_v, ws + wl.e, ws + wl.eps,
                        ws + wl.zbar, wbuf, abuf, bbuf);
     SVGP_LAUNCH_CHECK();
@@ -397,7 +395,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     real* Kb = ws + wl.fb_part;
     real* Kib = Kb + (size_t)L * mm;
     FbArgs a;
-    a.m = m; a.L = L; a.geco = c->geco; a.b_global = c->b_global; a.c = cc; a.N_train = c->N_train; a.state = state;
+    a.m = m; a.L = L; a.geco = SVGP_LOSS_FLAGS(c); a.b_global = c->b_global; a.c = cc; a.N_train = c->N_train; a.state = state;
     a.Ki = Ki; a.Aji = ws + wl.Aji; a.A = A; a.S = S; a.A2 = ws + wl.A2; a.M2 = ws + wl.M2; a.mu = ws + wl.mu_hat;
     a.u = ws + wl.u; a.ud = ws + wl.ud; a.td = ws + wl.td; a.t = ws + wl.t; a.v = ws + wl.v;
     a.X1 = s.mm1; a.T1A = s.mm2; a.Kib = Kib; a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2;
@@ -429,7 +427,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     SVGP_LAUNCH_CHECK();
     GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, Kib, m, mm, 0.0, s.mm0, m, mm, L);          // Ki Kib
     GEMM(0, 0, m, m, m, -1.0, s.mm0, m, mm, Ki, m, 0, 1.0, Kb, m, mm, L);          // Kb -= Ki Kib Ki
-    hipLaunchKernelGGL(k_big_fb_final, dim3(nblk(mm)), dim3(256), 0, st, m, L, c->geco, c->b_global, c->N_train, state, Kb,
+    hipLaunchKernelGGL(k_big_fb_final, dim3(nblk(mm)), dim3(256), 0, st, m, L, SVGP_LOSS_FLAGS(c), c->b_global, c->N_train, state, Kb,
                        Ki, ws + wl.Kbar);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
@@ -444,7 +442,7 @@ int svgp_big_posterior_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     hipStream_t st = (hipStream_t)stream;
     real* Kn = ws + wl.Kn;
     PbArgs a;
-    a.b = b; a.m = m; a.L = L; a.geco = c->geco; a.c = cc; a.state = state;
+    a.b = b; a.m = m; a.L = L; a.geco = SVGP_LOSS_FLAGS(c); a.c = cc; a.state = state;
     a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var; a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v; a.e = ws + wl.e;
     a.d = ws + wl.d; a.g_pv = ws + wl.g_pv; a.g_pm = ws + wl.g_pm; a.mvbar = ws + wl.mvbar;
     a.u = ws + wl.u; a.t = ws + wl.t; a.vbar = ws + wl.vbar; a.R = s.bm; a.kSk = s.bl0; a.kv = s.bl1; a.KnKi = s.bm;

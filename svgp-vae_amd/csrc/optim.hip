@@ -25,8 +25,10 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_adam_tf1(long long n, real* __re
 struct FinArgs {
     int b_global, L, geco, did_adam, n_pix;
     real N_train, kappa_squared, alpha_next;
-    const real* sums;   // [L3 data term, CE, recon sq, rows] summed over ranks
+    const real* sums;   // [L3 data term, CE, recon sq, rows, Titsias row sum] summed over ranks
     const real* KL;     // (L)
+    const real* tit;    // Titsias: [log det Sigma2 (L) | v2.t2 (L)], else NULL
+    const real* ldK;
     real* state;
 };
 
@@ -36,8 +38,15 @@ __device__ __forceinline__ void elbo_finalize(const FinArgs& a) {
     const real bg = (real)a.b_global, Lr = (real)a.L;
     real sumKL = 0;
     for (int l = 0; l < a.L; ++l) sumKL += a.KL[l];
-    const real inside_recon = a.sums[0] - real(0.5) * Lr * bg * real(SVGP_LOG_2PI);
-    const real inside = inside_recon - (bg / a.N_train) * sumKL;
+    real inside_recon = a.sums[0] - real(0.5) * Lr * bg * real(SVGP_LOG_2PI);
+    real inside = inside_recon - (bg / a.N_train) * sumKL;
+    if (a.tit) {   // SVGPVAE_model.py:246-259, 882-883: inside-ELBO = sum_l L_2, no KL part
+        real mat = 0;
+        for (int l = 0; l < a.L; ++l) mat += a.tit[l] - a.ldK[0] - a.tit[a.L + l];
+        inside_recon = real(-0.5) * (Lr * bg * real(SVGP_LOG_2PI) + a.sums[4] + mat);
+        inside = inside_recon;
+        sumKL = 0;
+    }
     const real ce = a.sums[1];
     const real KL_term = -ce + inside;
     const real sq = a.sums[2];
@@ -123,6 +132,7 @@ static int finalize_impl(const svgp_mnist_cfg* c, double* ws, double* state, int
     a.n_pix = c->n_pix > 0 ? c->n_pix : 784;
     a.N_train = c->N_train; a.kappa_squared = c->kappa_squared; a.alpha_next = c->alpha;
     a.sums = ws + wl.sums; a.KL = ws + wl.KL; a.state = state;
+    a.tit = c->titsias ? ws + wl.tit_scal : nullptr; a.ldK = ws + wl.ldK;
     hipLaunchKernelGGL(k_elbo_finalize, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
@@ -140,6 +150,7 @@ extern "C" int svgp_adam_tf1_finalize(const svgp_mnist_cfg* c, int64_t n, double
     a.n_pix = c->n_pix > 0 ? c->n_pix : 784;
     a.N_train = c->N_train; a.kappa_squared = c->kappa_squared; a.alpha_next = c->alpha;
     a.sums = ws + wl.sums; a.KL = ws + wl.KL; a.state = state;
+    a.tit = c->titsias ? ws + wl.tit_scal : nullptr; a.ldK = ws + wl.ldK;
     hipLaunchKernelGGL(k_adam_tf1_finalize, dim3((unsigned)((n + SVGP_BLOCK - 1) / SVGP_BLOCK)), dim3(SVGP_BLOCK), 0,
                        (hipStream_t)stream, (long long)n, theta, grad, adam_m, adam_v, beta1, beta2, epsilon, a);
     SVGP_LAUNCH_CHECK();

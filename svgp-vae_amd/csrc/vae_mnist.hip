@@ -742,6 +742,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_grad_reduce(int n_part, int n_en
                                                             int n_post, int b, const real* __restrict__ part_enc,
                                                             const real* __restrict__ part_dec,
                                                             const real* __restrict__ part_sums,
+                                                            const real* __restrict__ tit_rowsum,
                                                             real* __restrict__ grad, real* __restrict__ sums) {
     __shared__ real s[16][17];
     __shared__ real red[16];
@@ -755,7 +756,8 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_grad_reduce(int n_part, int n_en
         sq = block_sum(sq, red);
         if (threadIdx.x == 0) {
             sums[0] = l3; sums[1] = ce; sums[2] = sq; sums[3] = (real)b;
-            sums[4] = 0; sums[5] = 0; sums[6] = 0; sums[7] = 0;
+            sums[4] = tit_rowsum ? *tit_rowsum : real(0);   // Titsias: this rank's sum_n,l [log d + y^2/d + (k_nn - q)/var]
+            sums[5] = 0; sums[6] = 0; sums[7] = 0;
         }
         return;
     }
@@ -866,7 +868,8 @@ extern "C" int svgp_mnist_grad_reduce(const svgp_mnist_cfg* c, double* ws, void*
     const int nb_enc = (n_enc + 15) / 16, nb_dec = (n_dec + 15) / 16;
     hipLaunchKernelGGL(k_grad_reduce, dim3(nb_enc + nb_dec + 1), dim3(SVGP_BLOCK), 0, (hipStream_t)stream, n_part, n_enc,
                        n_dec, nb_enc, nb_dec, svgp_n_post_actual(c), c->b, ws + wl.part_enc, ws + wl.part_dec,
-                       ws + wl.part_sums, ws + wl.grad, ws + wl.sums);
+                       ws + wl.part_sums, c->titsias ? ws + wl.tit_scal + 2 * c->L : (const real*)nullptr, ws + wl.grad,
+                       ws + wl.sums);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

@@ -117,7 +117,7 @@ class MnistStepEngine:
     """One rank's HIP execution state for the rotated-MNIST SVGPVAE_Hensman step."""
 
     def __init__(self, m, L=16, M=8, n_obj=400, *, N_train=4050.0, jitter=1e-6, clip_qs=True, geco=False,
-                 K_obj_normalize=False, kappa_squared=0.020, alpha=0.99, beta=0.001, lr=1e-3,
+                 K_obj_normalize=False, titsias=False, kappa_squared=0.020, alpha=0.99, beta=0.001, lr=1e-3,
                  train_ip=True, train_gp=True, train_ov=True, b_max=256, device="cuda:0",
                  rank=0, world_size=1):
         self.lib = _lib.load_library()          # raises if the HIP extension is missing
@@ -127,7 +127,7 @@ class MnistStepEngine:
         self.device = torch.device(device)
         self.rank, self.world_size = rank, world_size
         self.base = dict(m=m, L=L, M=M, n_obj=n_obj, normalize_obj=int(K_obj_normalize), clip_qs=int(clip_qs),
-                         geco=int(geco), train_ip=int(train_ip), train_gp=int(train_gp), train_ov=int(train_ov),
+                         geco=int(geco), titsias=int(titsias), train_ip=int(train_ip), train_gp=int(train_gp), train_ov=int(train_ov),
                          N_train=float(N_train), jitter=float(jitter), kappa_squared=float(kappa_squared),
                          alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0)
         self.b_max = b_max

@@ -41,10 +41,17 @@ def test_layouts_match_reference_parameter_count_and_are_disjoint():
     _lib.call("svgp_mnist_ws_layout_get", C.byref(cfg), C.byref(wl))
     # 5721 VAE + 32x10 inducing + l, amp + 400x8 object vectors = 9243 trainables
     assert (pl.n_enc, pl.n_vae, pl.n_total) == (2304, 5721, 9243)
+    tit = ("tit_S2", "tit_v2", "tit_Si", "tit_t", "tit_scal")     # zero-sized unless cfg.titsias
     offs = sorted(getattr(wl, f) for f in _lib.WS_FIELDS
                   if f not in ("statA_len", "statB_len", "gradC_len", "n_part", "n_post", "total",
-                               "statA", "statB", "gradC"))
+                               "statA", "statB", "gradC") + tit)
     assert all(o >= 0 for o in offs) and offs[-1] < wl.total
+    # Titsias: S2 | v2 extend the statA exchange block, the rest sits at the end
+    cfg_t = _lib.MnistCfg(b=256, b_global=256, m=32, L=16, M=8, n_obj=400, N_train=4050.0, jitter=1e-6, titsias=1)
+    wt = _lib.WsLayout()
+    _lib.call("svgp_mnist_ws_layout_get", C.byref(cfg_t), C.byref(wt))
+    assert wt.statA_len == 2 * 16 * 32 * 33 and wt.tit_S2 == wt.v + 16 * 32 and wt.tit_v2 == wt.tit_S2 + 16 * 32 * 32
+    assert wt.tit_scal + 2 * 16 + 1 <= wt.total and wt.total > wl.total
     assert wl.statA == wl.S and wl.v == wl.S + 16 * 32 * 32 and wl.statA_len == 16 * 32 * 33
     assert wl.statB_len == 16 * 32 * 34 and wl.gradC_len == 9243 + 8 and wl.sums == wl.grad + 9243
 

@@ -82,6 +82,21 @@ def test_literal_equals_efficient_gp_block():
         assert abs(float(kl - KL[l])) < 1e-9 * abs(float(kl))
 
 
+@pytest.mark.parametrize("jitter", [1e-6, 1e-3])
+def test_titsias_literal_equals_woodbury(jitter):
+    """Titsias L_2 (SVGPVAE_model.py:246-259): the literal b x b form (inverse + Cholesky of diag(var) + K_nm K_mm^-1
+    K_mn + jI) equals the m x m Woodbury form the HIP path implements."""
+    t = _toy(b=60, m=14)
+    one = torch.tensor(1.1, dtype=DT)
+    sv = O.MnistSVGP(True, t["ip"], t["ov"], one, 0.9 * one, jitter, 300.0)
+    K, Kn, knn = SG.kernel_matrix_fwd(t["aux"], t["ip"], t["ov"], one, 0.9 * one)
+    L2 = O.titsias_block_efficient(K, Kn, knn, t["y"], t["s2"], jitter)
+    for l in range(t["y"].shape[1]):
+        l2, zero = sv.variational_loss(t["aux"], t["y"][:, l], None, None, t["s2"][:, l])
+        assert float(zero) == 0.0
+        assert abs(float(l2 - L2[l])) < 1e-9 * abs(float(l2))
+
+
 @pytest.mark.parametrize("normalize", [False, True])
 @pytest.mark.parametrize("use_ov", [False, True])
 def test_staged_kernel_vjp_matches_autograd(normalize, use_ov):

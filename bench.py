@@ -76,9 +76,9 @@ def stage_table(eng):
         ("gp_stats_bwd", "svgp_gp_stats_bwd", (cfg, ws, st, s), 3 * Lc * b * m * m, f8 * (b * m + 9 * b * Lc + Lc * m * (m + 2))),
         ("gp_factor_bwd", "svgp_gp_factor_bwd", (cfg, ws, st, s), Lc * 9 * 2 * m ** 3, f8 * Lc * 14 * m * m),
         ("gp_posterior_bwd", "svgp_gp_posterior_bwd", (cfg, ws, st, s), 6 * Lc * b * m * m, f8 * (Lc * 3 * m * m + 2 * Lc * b * m + 12 * b * Lc)),
-        ("kernel_matrix_bwd", "svgp_kernel_matrix_bwd", (cfg, th, aux, ws, s), (2 * b * m + 2 * m * m) * (2 * 9 + 20), f8 * (2 * b * m + 2 * m * m + b * 10 + N_OBJ * 8)),
+        ("kernel_matrix_bwd", "svgp_kernel_matrix_bwd_partials", (cfg, th, aux, ws, s), (2 * b * m + 2 * m * m) * (2 * 9 + 20), f8 * (2 * b * m + 2 * m * m + b * 10 + N_OBJ * 8)),
         ("encoder_bwd", "svgp_mnist_encoder_bwd", (cfg, th, img, ws, s), 4 * enc_mac * b, f8 * (b * (784 + act_enc + 3 * Lc) + eng.wl.n_part * n_enc)),
-        ("grad_reduce", "svgp_mnist_grad_reduce", (cfg, ws, s), eng.wl.n_part * (n_enc + n_dec), f8 * eng.wl.n_part * (n_enc + n_dec)),
+        ("grad_reduce", "svgp_mnist_grad_reduce_all", (cfg, aux, ws, s), eng.wl.n_part * (n_enc + n_dec), f8 * eng.wl.n_part * (n_enc + n_dec)),
     ]
 
 

@@ -198,6 +198,13 @@ int svgp_mnist_encoder_bwd(const svgp_mnist_cfg*, const double* theta, const dou
                            double* ws, void* stream);
 /* fixed-order reduction of all partials into the final block [grad | sums] (DP all-reduces it) */
 int svgp_mnist_grad_reduce(const svgp_mnist_cfg*, double* ws, void* stream);
+/* What the training phases use instead of the pair (svgp_kernel_matrix_bwd, svgp_mnist_grad_reduce): the
+ * kernel-matrix VJP without its last launch (the deterministic scatter of the gathered-row gradients into the object
+ * table and the two hyper-parameter sums), and the reduction launch with those workgroups appended -- one dependent
+ * launch less on the critical path.  Results are identical. */
+int svgp_kernel_matrix_bwd_partials(const svgp_mnist_cfg*, const double* theta, const double* aux, double* ws,
+                                    void* stream);
+int svgp_mnist_grad_reduce_all(const svgp_mnist_cfg*, const double* aux, double* ws, void* stream);
 /* tf.train.AdamOptimizer.apply_gradients, TF1 formula (MNIST_experiment.py:200,207-208) */
 int svgp_adam_tf1_step(int64_t n, double* theta, const double* grad, double* adam_m, double* adam_v,
                        const double* state, double beta1, double beta2, double epsilon, void* stream);
@@ -215,7 +222,7 @@ int svgp_elbo_finalize_noadam(const svgp_mnist_cfg*, double* ws, double* state, 
  * phase 0: encoder_fwd, kernel_matrix_fwd, gp_stats_fwd            -> all-reduce ws[statA]
  * phase 1: gp_factor_fwd, gp_posterior_fwd, decoder_fwd, decoder_bwd, gp_stats_bwd
  *                                                                   -> all-reduce ws[statB]
- * phase 2: gp_factor_bwd, gp_posterior_bwd, kernel_matrix_bwd, encoder_bwd, grad_reduce
+ * phase 2: gp_factor_bwd, gp_posterior_bwd, kernel_matrix_bwd_partials, encoder_bwd, grad_reduce_all
  *                                                                   -> all-reduce ws[gradC]
  * phase 3: adam_tf1_step (skipped when adam_m == NULL), elbo_finalize
  * svgp_mnist_train_step runs phases 0..3 back to back (single GPU).                            */

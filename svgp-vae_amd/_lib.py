@@ -85,6 +85,8 @@ SIGNATURES = {
     "svgp_kernel_matrix_bwd": [_CFG, _P, _P, _P, _P],
     "svgp_mnist_encoder_bwd": [_CFG, _P, _P, _P, _P],
     "svgp_mnist_grad_reduce": [_CFG, _P, _P],
+    "svgp_kernel_matrix_bwd_partials": [_CFG, _P, _P, _P, _P],
+    "svgp_mnist_grad_reduce_all": [_CFG, _P, _P, _P],
     "svgp_adam_tf1_step": [C.c_int64, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P],
     "svgp_elbo_finalize": [_CFG, _P, _P, _P],
     "svgp_adam_tf1_finalize": [_CFG, C.c_int64, _P, _P, _P, _P, _P, _P, C.c_double, C.c_double, C.c_double, _P],

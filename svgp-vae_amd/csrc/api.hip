@@ -202,10 +202,10 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         RUN(svgp_gp_posterior_bwd(c, ws, state, stream));
         if (c->titsias) RUN(svgp_gp_titsias_bwd(c, ws, state, stream));
         if (fork2) RUN(side_fork(sd, 0, ms));
-        RUN(svgp_kernel_matrix_bwd(c, theta, aux, ws, s2));
+        RUN(svgp_kernel_matrix_bwd_partials(c, theta, aux, ws, s2));
         RUN(svgp_mnist_encoder_bwd(c, theta, images, ws, stream));
         if (fork2) RUN(side_join(sd, 0, ms));
-        RUN(svgp_mnist_grad_reduce(c, ws, stream));
+        RUN(svgp_mnist_grad_reduce_all(c, aux, ws, stream));
         break;
     case 3: {
         svgp_mnist_param_layout pl;

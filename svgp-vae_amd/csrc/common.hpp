@@ -115,3 +115,59 @@ __device__ __forceinline__ real elu_f(real x) { return x > 0 ? x : expm1(x); }
 __device__ __forceinline__ real elu_grad_from_out(real out) { return out > 0 ? real(1) : out + real(1); }
 
 __device__ __forceinline__ real recip_no_nan(real x) { return x == real(0) ? real(0) : real(1) / x; }
+
+#ifdef __HIPCC__
+// Object-table scatter of the kernel-matrix VJP, one workgroup of SVGP_BLOCK threads (dynamic LDS: 256 * M doubles at
+// `dbuf`).  Workgroups [0, nblk - 1): element o = blk * 256 + tid of the (n_obj, M) table gradient = sum of the d_on
+// rows whose id matches, in row order (duplicate ids sum deterministically): per chunk of 256 staged rows a bit mask per
+// table row is built with LDS atomicOr and walked with ffs.  Workgroup nblk - 1: the amplitude / length-scale partial sums.
+__device__ __forceinline__ void svgp_km_scatter_block(int blk, int nblk, int b, int M, int n_obj,
+                                                      const real* __restrict__ aux, int n_gp_part, int train_gp,
+                                                      int train_ov, const real* __restrict__ d_on,
+                                                      const real* __restrict__ part_gp, real* __restrict__ d_ov,
+                                                      real* __restrict__ d_ls, real* __restrict__ d_amp) {
+    extern __shared__ __align__(16) real svgp_dyn_lds[];
+    __shared__ real sred[16];
+    if (blk == nblk - 1) {
+        real sa = 0, sl = 0;
+        for (int i = threadIdx.x; i < n_gp_part; i += blockDim.x) { sa += part_gp[i * 2]; sl += part_gp[i * 2 + 1]; }
+        sa = block_sum(sa, sred);
+        sl = block_sum(sl, sred);
+        if (threadIdx.x == 0) { *d_amp = train_gp ? sa : real(0); *d_ls = train_gp ? sl : real(0); }
+        return;
+    }
+    real* dbuf = svgp_dyn_lds;      // 256 x M
+    __shared__ unsigned mask[256][8];    // per table row of this workgroup: which of the 256 staged batch rows match
+    const int o = blk * blockDim.x + threadIdx.x;
+    const bool act = o < n_obj * M;
+    const int r_first = (blk * (int)blockDim.x) / M, r_last = (blk * (int)blockDim.x + (int)blockDim.x - 1) / M;
+    const int r = act ? o / M : -1, k = act ? o % M : 0, st = 2 + M;
+    real acc = 0;
+    for (int n0 = 0; n0 < b; n0 += 256) {
+        const int cnt = min(256, b - n0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < 256 * 8; t += blockDim.x) (&mask[0][0])[t] = 0u;
+        for (int t = threadIdx.x; t < cnt * M; t += blockDim.x) dbuf[t] = d_on[(size_t)n0 * M + t];
+        __syncthreads();
+        // set bits are order-independent (atomicOr), the sums below walk them in increasing row order: the result
+        // is the row-order sum whatever the execution order
+        if ((int)threadIdx.x < cnt) {
+            const int id = (int)aux[(size_t)(n0 + threadIdx.x) * st];
+            if (id >= r_first && id <= r_last) atomicOr(&mask[id - r_first][threadIdx.x >> 5], 1u << (threadIdx.x & 31));
+        }
+        __syncthreads();
+        if (train_ov && act) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                unsigned bits = mask[r - r_first][w];
+                while (bits) {
+                    const int n = w * 32 + __ffs(bits) - 1;
+                    acc += dbuf[n * M + k];
+                    bits &= bits - 1;
+                }
+            }
+        }
+    }
+    if (act) d_ov[o] = acc;
+}
+#endif

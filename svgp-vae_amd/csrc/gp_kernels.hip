@@ -280,15 +280,12 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_fwd(KernArgs a, re
 // VJP, inducing side: one workgroup per inducing point j.
 // d_ip[j] = [0, d_theta_j, d_o_j], partial amplitude / length-scale sums -> part_gp[j].
 #define KM_MAXM 32
-__global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_cols(KernArgs a, real rep_weight, int train_ip,
-                                                                       const real* __restrict__ K,
-                                                                       const real* __restrict__ Kn,
-                                                                       const real* __restrict__ Kbar,
-                                                                       const real* __restrict__ Knbar,
-                                                                       real* __restrict__ d_ip,
-                                                                       real* __restrict__ part_gp) {
+__device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real rep_weight, int train_ip,
+                                            const real* __restrict__ K, const real* __restrict__ Kn,
+                                            const real* __restrict__ Kbar, const real* __restrict__ Knbar,
+                                            real* __restrict__ d_ip, real* __restrict__ part_gp) {
     __shared__ real res[KM_MAXM + 4];
-    const int j = blockIdx.x, st = 2 + a.M, M = a.M;
+    const int st = 2 + a.M, M = a.M;
     const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
     const real* oj = a.ip + (size_t)j * st + 2;
     const real thj = a.ip[(size_t)j * st + 1];
@@ -369,11 +366,9 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_cols(KernArgs 
 // VJP, batch-row side.  grid ceil(b/RB), RB = 256/m rows per workgroup.  Phase 1: thread (row, j)
 // computes c = Knbar * view(theta_n - theta_j) / |o_j|; phase 2: thread (row, k) reduces over j ->
 // d_on (b,M), the gradient of the gathered object row.  Also the k_nn part of the amplitude gradient.
-__global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_rows(KernArgs a, const real* __restrict__ Knbar,
-                                                                       const real* __restrict__ knnbar,
-                                                                       const real* __restrict__ knn,
-                                                                       real* __restrict__ d_on,
-                                                                       real* __restrict__ part_gp) {
+__device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, const real* __restrict__ Knbar,
+                                            const real* __restrict__ knnbar, const real* __restrict__ knn,
+                                            real* __restrict__ d_on, real* __restrict__ part_gp) {
     extern __shared__ __align__(16) real smem[];
     __shared__ real red[16];
     const int m = a.m, M = a.M, st = 2 + M, RB = m >= (int)blockDim.x ? 1 : blockDim.x / m;
@@ -388,7 +383,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_rows(KernArgs 
         O[o] = oj[o % M] / nj;
     }
     for (int it = threadIdx.x; it < RB * m; it += blockDim.x) {
-        const int nl = it / m, j = it % m, n = blockIdx.x * RB + nl;
+        const int nl = it / m, j = it % m, n = rblk * RB + nl;
         real c = 0;
         if (n < a.b)
             c = Knbar[(size_t)n * m + j] * view_k(a.aux[(size_t)n * st + 1] - a.ip[(size_t)j * st + 1], a2, inv_l2);
@@ -396,7 +391,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_rows(KernArgs 
     }
     __syncthreads();
     for (int it = threadIdx.x; it < RB * M; it += blockDim.x) {
-        const int nl = it / M, k = it % M, n = blockIdx.x * RB + nl;
+        const int nl = it / M, k = it % M, n = rblk * RB + nl;
         real g = 0;
         if (n < a.b) {
             for (int j = 0; j < m; ++j) g += cbuf[nl * m + j] * O[j * M + k];
@@ -408,7 +403,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_rows(KernArgs 
     }
     __syncthreads();
     for (int it = threadIdx.x; it < RB * M; it += blockDim.x) {
-        const int nl = it / M, k = it % M, n = blockIdx.x * RB + nl;
+        const int nl = it / M, k = it % M, n = rblk * RB + nl;
         if (n < a.b) {
             real v = gbuf[it];
             if (a.normalize) {       // o_hat = o/|o| : d_o = (d_oh - <d_oh,o_hat> o_hat)/|o|
@@ -423,19 +418,33 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_rows(KernArgs 
     }
     real acc_amp = 0;
     {
-        const int n = blockIdx.x * RB + threadIdx.x;
+        const int n = rblk * RB + threadIdx.x;
         if (threadIdx.x < RB && n < a.b) acc_amp = real(2) * knnbar[n] * knn[n] / amp;
     }
     acc_amp = block_sum(acc_amp, red);
     if (threadIdx.x == 0) {
-        part_gp[(m + blockIdx.x) * 2 + 0] = acc_amp;
-        part_gp[(m + blockIdx.x) * 2 + 1] = 0;
+        part_gp[(m + rblk) * 2 + 0] = acc_amp;
+        part_gp[(m + rblk) * 2 + 1] = 0;
     }
 }
 
-// Deterministic scatter-add of d_on into the object table gradient (duplicate ids sum in row
-// order).  Rows are processed in chunks of 256 with ids AND the d_on rows staged in LDS, so the scan
-// touches no global memory.  The last block does the final amplitude / length-scale sums.
+// one launch for both sides of the VJP: workgroups [0, m) = inducing side, [m, m + nrb) = batch-row side
+__global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_cr(KernArgs a, real rep_weight, int train_ip,
+                                                                     const real* __restrict__ K,
+                                                                     const real* __restrict__ Kn,
+                                                                     const real* __restrict__ Kbar,
+                                                                     const real* __restrict__ Knbar,
+                                                                     const real* __restrict__ knnbar,
+                                                                     const real* __restrict__ knn,
+                                                                     real* __restrict__ d_ip, real* __restrict__ d_on,
+                                                                     real* __restrict__ part_gp) {
+    if ((int)blockIdx.x < a.m) km_bwd_cols(blockIdx.x, a, rep_weight, train_ip, K, Kn, Kbar, Knbar, d_ip, part_gp);
+    else km_bwd_rows(blockIdx.x - a.m, a, Knbar, knnbar, knn, d_on, part_gp);
+}
+
+// Deterministic scatter-add of d_on into the object table gradient + the final amplitude / length-scale sums
+// (svgp_km_scatter_block in common.hpp; the training phases run these workgroups inside the gradient-reduction
+// launch instead, see svgp_mnist_grad_reduce_all).
 __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernArgs a, int n_gp_part, int train_gp,
                                                                           int train_ov,
                                                                           const real* __restrict__ d_on,
@@ -443,42 +452,8 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernAr
                                                                           real* __restrict__ d_ov,
                                                                           real* __restrict__ d_ls,
                                                                           real* __restrict__ d_amp) {
-    extern __shared__ __align__(16) real smem[];
-    __shared__ __align__(16) int ids[256];
-    __shared__ real red[16];
-    if (blockIdx.x == gridDim.x - 1) {
-        real sa = 0, sl = 0;
-        for (int i = threadIdx.x; i < n_gp_part; i += blockDim.x) { sa += part_gp[i * 2]; sl += part_gp[i * 2 + 1]; }
-        sa = block_sum(sa, red);
-        sl = block_sum(sl, red);
-        if (threadIdx.x == 0) { *d_amp = train_gp ? sa : real(0); *d_ls = train_gp ? sl : real(0); }
-        return;
-    }
-    real* dbuf = smem;      // 256 x M
-    const int o = blockIdx.x * blockDim.x + threadIdx.x, M = a.M;
-    const bool act = o < a.n_obj * M;
-    const int r = act ? o / M : -1, k = act ? o % M : 0, st = 2 + M;
-    real acc = 0;
-    for (int n0 = 0; n0 < a.b; n0 += 256) {
-        const int cnt = min(256, a.b - n0);
-        __syncthreads();
-        if (threadIdx.x < 256) ids[threadIdx.x] = threadIdx.x < cnt ? (int)a.aux[(size_t)(n0 + threadIdx.x) * st] : -2;
-        for (int t = threadIdx.x; t < cnt * M; t += blockDim.x) dbuf[t] = d_on[(size_t)n0 * M + t];
-        __syncthreads();
-        if (train_ov && act) {
-            // 16 ids per iteration through four 16-byte LDS reads issued together; matches are rare
-            const int4* idv = reinterpret_cast<const int4*>(ids);
-            for (int t = 0; t < cnt; t += 16) {
-                const int4 q0 = idv[(t >> 2)], q1 = idv[(t >> 2) + 1], q2 = idv[(t >> 2) + 2], q3 = idv[(t >> 2) + 3];
-                const int qq[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
-                                    q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (qq[u] == r) acc += dbuf[(t + u) * M + k];
-            }
-        }
-    }
-    if (act) d_ov[o] = acc;
+    svgp_km_scatter_block(blockIdx.x, gridDim.x, a.b, a.M, a.n_obj, a.aux, n_gp_part, train_gp, train_ov, d_on, part_gp,
+                          d_ov, d_ls, d_amp);
 }
 
 // =============================================================================================
@@ -1107,33 +1082,41 @@ extern "C" int svgp_kernel_matrix_fwd(const svgp_mnist_cfg* c, const double* the
     return SVGP_OK;
 }
 
-extern "C" int svgp_kernel_matrix_bwd(const svgp_mnist_cfg* c, const double* theta, const double* aux, double* ws,
-                                      void* stream) {
+static int kernel_matrix_bwd_impl(const svgp_mnist_cfg* c, const double* theta, const double* aux, double* ws,
+                                  bool scatter, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(theta && aux && ws, SVGP_ERR_INVALID, "NULL device pointer");
     KernArgs a = make_kern_args(c, pl, theta, aux);
     real* grad = ws + wl.grad;
-    hipLaunchKernelGGL(k_kernel_matrix_bwd_cols, dim3(c->m), dim3(SVGP_BLOCK), 0, (hipStream_t)stream, a,
-                       c->rep_weight, c->train_ip, ws + wl.K, ws + wl.Kn, ws + wl.Kbar, ws + wl.Knbar, grad + pl.ip,
-                       ws + wl.part_gp);
-    SVGP_LAUNCH_CHECK();
     const int RBk = svgp_rows_per_block(c), nrb = (c->b + RBk - 1) / RBk;
     const size_t lds_rows = (size_t)(c->m * c->M + RBk * c->m + RBk * c->M) * sizeof(real);
     {
-        int rc_ = set_dyn_lds(k_kernel_matrix_bwd_rows, lds_rows);
+        int rc_ = set_dyn_lds(k_kernel_matrix_bwd_cr, lds_rows);
         if (rc_) return rc_;
     }
-    hipLaunchKernelGGL(k_kernel_matrix_bwd_rows, dim3(nrb), dim3(SVGP_BLOCK), lds_rows, (hipStream_t)stream, a,
-                       ws + wl.Knbar, ws + wl.knnbar, ws + wl.knn, ws + wl.d_on, ws + wl.part_gp);
+    hipLaunchKernelGGL(k_kernel_matrix_bwd_cr, dim3(c->m + nrb), dim3(SVGP_BLOCK), lds_rows, (hipStream_t)stream, a,
+                       c->rep_weight, c->train_ip, ws + wl.K, ws + wl.Kn, ws + wl.Kbar, ws + wl.Knbar, ws + wl.knnbar,
+                       ws + wl.knn, grad + pl.ip, ws + wl.d_on, ws + wl.part_gp);
     SVGP_LAUNCH_CHECK();
-    const int n_ov = c->n_obj * c->M;
-    {
+    if (scatter) {
+        const int n_ov = c->n_obj * c->M;
         hipLaunchKernelGGL(k_kernel_matrix_bwd_scatter, dim3((n_ov + SVGP_BLOCK - 1) / SVGP_BLOCK + 1), dim3(SVGP_BLOCK),
-                           (size_t)256 * c->M * sizeof(real), (hipStream_t)stream, a, c->m + nrb, c->train_gp, c->train_ov, ws + wl.d_on, ws + wl.part_gp,
-                           grad + pl.ov, grad + pl.l_GP, grad + pl.amplitude);
+                           (size_t)256 * c->M * sizeof(real), (hipStream_t)stream, a, c->m + nrb, c->train_gp, c->train_ov,
+                           ws + wl.d_on, ws + wl.part_gp, grad + pl.ov, grad + pl.l_GP, grad + pl.amplitude);
+        SVGP_LAUNCH_CHECK();
     }
-    SVGP_LAUNCH_CHECK();
     return SVGP_OK;
+}
+
+extern "C" int svgp_kernel_matrix_bwd(const svgp_mnist_cfg* c, const double* theta, const double* aux, double* ws,
+                                      void* stream) {
+    return kernel_matrix_bwd_impl(c, theta, aux, ws, true, stream);
+}
+
+// everything except the object-table scatter and the two scalar sums, which svgp_mnist_grad_reduce_all performs
+extern "C" int svgp_kernel_matrix_bwd_partials(const svgp_mnist_cfg* c, const double* theta, const double* aux,
+                                               double* ws, void* stream) {
+    return kernel_matrix_bwd_impl(c, theta, aux, ws, false, stream);
 }
 
 static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,

@@ -735,17 +735,30 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int dbg_stop, int b, int
 
 // ------------------------------------------------------------------------------------------
 // fixed-order reduction of the per-workgroup partials into [grad | sums] in ONE launch.
-// blocks [0, nb_enc): encoder weights, [nb_enc, nb_enc+nb_dec): decoder weights, last block: scalars.
+// blocks [0, nb_enc): encoder weights, [nb_enc, nb_enc+nb_dec): decoder weights, next block: scalars, then (training
+// phases only, n_scatter > 0) the object-table scatter / GP hyper-parameter sums of the kernel-matrix VJP.
 // thread (i_local = tid % 16, chunk = tid / 16): 16 chunks over the partial rows, LDS combine.
 // ------------------------------------------------------------------------------------------
+struct KmScatter {
+    int n_blocks, M, n_obj, n_gp_part, train_gp, train_ov;
+    const real* aux; const real* d_on; const real* part_gp;
+    real* d_ov; real* d_ls; real* d_amp;
+};
+
 __global__ __launch_bounds__(SVGP_BLOCK) void k_grad_reduce(int n_part, int n_enc, int n_dec, int nb_enc, int nb_dec,
                                                             int n_post, int b, const real* __restrict__ part_enc,
                                                             const real* __restrict__ part_dec,
                                                             const real* __restrict__ part_sums,
                                                             const real* __restrict__ tit_rowsum,
-                                                            real* __restrict__ grad, real* __restrict__ sums) {
+                                                            real* __restrict__ grad, real* __restrict__ sums,
+                                                            KmScatter ks) {
     __shared__ real s[16][17];
     __shared__ real red[16];
+    if ((int)blockIdx.x > nb_enc + nb_dec) {
+        svgp_km_scatter_block(blockIdx.x - (nb_enc + nb_dec + 1), ks.n_blocks, b, ks.M, ks.n_obj, ks.aux, ks.n_gp_part,
+                              ks.train_gp, ks.train_ov, ks.d_on, ks.part_gp, ks.d_ov, ks.d_ls, ks.d_amp);
+        return;
+    }
     if ((int)blockIdx.x == nb_enc + nb_dec) {
         real l3 = 0, ce = 0, sq = 0;
         for (int i = threadIdx.x; i < n_part; i += blockDim.x) sq += part_sums[i * 4 + 2];
@@ -860,16 +873,39 @@ extern "C" int svgp_mnist_decoder_bwd(const svgp_mnist_cfg* c, const double* the
     return SVGP_OK;
 }
 
-extern "C" int svgp_mnist_grad_reduce(const svgp_mnist_cfg* c, double* ws, void* stream) {
+static int grad_reduce_impl(const svgp_mnist_cfg* c, const double* aux, double* ws, bool with_scatter, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
     const int n_part = svgp_n_part(c);
     const int n_enc = (int)pl.n_enc, n_dec = (int)(pl.n_vae - pl.n_enc);
     const int nb_enc = (n_enc + 15) / 16, nb_dec = (n_dec + 15) / 16;
-    hipLaunchKernelGGL(k_grad_reduce, dim3(nb_enc + nb_dec + 1), dim3(SVGP_BLOCK), 0, (hipStream_t)stream, n_part, n_enc,
-                       n_dec, nb_enc, nb_dec, svgp_n_post_actual(c), c->b, ws + wl.part_enc, ws + wl.part_dec,
+    KmScatter ks;
+    memset(&ks, 0, sizeof(ks));
+    size_t lds = 0;
+    if (with_scatter) {
+        SVGP_REQUIRE(aux, SVGP_ERR_INVALID, "NULL device pointer");
+        const int RBk = svgp_rows_per_block(c), nrb = (c->b + RBk - 1) / RBk;
+        ks.n_blocks = (c->n_obj * c->M + SVGP_BLOCK - 1) / SVGP_BLOCK + 1;
+        ks.M = c->M; ks.n_obj = c->n_obj; ks.n_gp_part = c->m + nrb; ks.train_gp = c->train_gp; ks.train_ov = c->train_ov;
+        ks.aux = aux; ks.d_on = ws + wl.d_on; ks.part_gp = ws + wl.part_gp;
+        ks.d_ov = ws + wl.grad + pl.ov; ks.d_ls = ws + wl.grad + pl.l_GP; ks.d_amp = ws + wl.grad + pl.amplitude;
+        lds = (size_t)256 * c->M * sizeof(real);
+        int rc = set_dyn_lds(k_grad_reduce, lds);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_grad_reduce, dim3(nb_enc + nb_dec + 1 + ks.n_blocks), dim3(SVGP_BLOCK), lds, (hipStream_t)stream,
+                       n_part, n_enc, n_dec, nb_enc, nb_dec, svgp_n_post_actual(c), c->b, ws + wl.part_enc, ws + wl.part_dec,
                        ws + wl.part_sums, c->titsias ? ws + wl.tit_scal + 2 * c->L : (const real*)nullptr, ws + wl.grad,
-                       ws + wl.sums);
+                       ws + wl.sums, ks);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
+}
+
+extern "C" int svgp_mnist_grad_reduce(const svgp_mnist_cfg* c, double* ws, void* stream) {
+    return grad_reduce_impl(c, nullptr, ws, false, stream);
+}
+
+// + the object-table scatter and hyper-parameter sums left open by svgp_kernel_matrix_bwd_partials
+extern "C" int svgp_mnist_grad_reduce_all(const svgp_mnist_cfg* c, const double* aux, double* ws, void* stream) {
+    return grad_reduce_impl(c, aux, ws, true, stream);
 }

@@ -208,3 +208,49 @@ def loss_and_grads(params, gp_params, data_batch, epsilon, *, beta, C_ma, lagran
     if clip_grad is not None:
         grads = {k: torch.clamp(g, -clip_grad, clip_grad) for k, g in grads.items()}
     return tuple(o.detach() if torch.is_tensor(o) else o for o in out), grads
+
+
+# ---------------------------------------------------------------------------------------------
+# conditional generation for a test character (test infrastructure, as everything in oracle/)
+# ---------------------------------------------------------------------------------------------
+def precompute_GP_params_SVGPVAE(means, vars_, aux_data, svgp):
+    """SVGPVAE_model.py:989-1023, literal: per channel Sigma_l = K_mm + K_mn (K_nm / var_l), inverse WITHOUT jitter."""
+    K_mm = svgp.kernel_matrix(svgp.inducing_index_points, svgp.inducing_index_points)
+    K_nm = svgp.kernel_matrix(aux_data, svgp.inducing_index_points, x_inducing=False)
+    mean_terms, inv = [], []
+    for l in range(means.shape[1]):
+        p = O.reciprocal_no_nan(vars_[:, l])
+        Sigma_l = K_mm + K_nm.T @ (K_nm * p[:, None])
+        Si = torch.linalg.inv(Sigma_l)
+        mean_terms.append(Si @ (K_nm.T @ (p * means[:, l])))
+        inv.append(Si)
+    return torch.stack(mean_terms), torch.stack(inv)
+
+
+def approximate_posterior_params_precomputed(svgp, index_points, mean_term, sigma_term, K_mm_inv):
+    """SVGPVAE_model.py:610-635 for one channel."""
+    K_bb = svgp.kernel_matrix(index_points, index_points, False, False, diag_only=True)
+    K_bm = svgp.kernel_matrix(index_points, svgp.inducing_index_points, x_inducing=False)
+    mean_vector = K_bm @ mean_term
+    B = K_bb + torch.diagonal(-K_bm @ (K_mm_inv @ K_bm.T) + K_bm @ (sigma_term @ K_bm.T))
+    return mean_vector, B
+
+
+def predict_SVGPVAE_sprites_test_character(data_batch, params, svgp, mean_terms, var_terms, N_context, N_actions,
+                                           batch_size_test, segment_ids, repeats, K_mm_inv, epsilon, L):
+    """SVGPVAE_model.py:1118-1195 with context_full_actions=True and the N(0,1) draw as an input."""
+    images, action_ids = data_batch
+    context = np.sort(np.array([list(range(i * N_actions, i * N_actions + N_context))
+                                for i in range(int(batch_size_test / N_actions))]).reshape(-1))
+    target = np.array([x for x in range(batch_size_test) if x not in set(context.tolist())])
+    images_context, images_t = images[context], images[target]
+    aux_t = aux_data_SVGPVAE_sprites((images_context, action_ids[target]), params, segment_ids, repeats)
+    p_m, p_v = [], []
+    for l in range(L):
+        a, b_ = approximate_posterior_params_precomputed(svgp, aux_t, mean_terms[l], var_terms[l], K_mm_inv)
+        p_m.append(a); p_v.append(b_)
+    p_m, p_v = torch.stack(p_m, 1), torch.stack(p_v, 1)
+    p_v = torch.clamp(p_v, 1e-4, 100.0)
+    z = p_m + epsilon * torch.sqrt(p_v)
+    recon = SpritesVAE(params, L).decode(z)
+    return recon, images_t, torch.sum((images_t - recon) ** 2) / float(64 * 64 * 3), p_m, p_v, aux_t

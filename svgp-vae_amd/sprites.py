@@ -198,6 +198,106 @@ class SpritesStepEngine:
             self.state.copy_(st)
         self.stream.synchronize()
 
+    # ------------------------------------------------------------------ forward pieces (run inside self.stream)
+    def _encoder_forward(self, images, b):
+        """spritesVAE.encode (VAE_utils.py:294-315,343-349): 6 convs, Dense(2L), exp / clip head."""
+        p, s, L = self.params, self.stream.cuda_stream, self.L
+        f64 = dict(dtype=_F64, device=self.dev)
+        a, x = [], images
+        for i, lay in enumerate(self.enc, 1):
+            out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
+            lay.forward(x, p[f"enc_c{i}_w"], p[f"enc_c{i}_b"], out, s)
+            a.append(out); x = out
+        enc = torch.empty(b, 2 * L, **f64)
+        self._gemm(0, 0, b, 2 * L, 1024, 1.0, x, 1024, p["enc_d_w"], 2 * L, 0.0, enc, 2 * L)
+        mu, var_raw, var = self._v("qnet_mu", (b, L)), self._v("qnet_var_raw", (b, L)), self._v("qnet_var", (b, L))
+        call("svgp_enc_head_fwd", b, L, int(self.clip_qs), p["enc_d_b"].data_ptr(), enc.data_ptr(), mu.data_ptr(),
+             var_raw.data_ptr(), var.data_ptr(), s)
+        return a, enc, mu, var_raw, var
+
+    def _repr_forward(self, images, b):
+        """sprites_representation_network (VAE_utils.py:375-391): per-frame character vectors (b, L_character)."""
+        p, s = self.params, self.stream.cuda_stream
+        f64 = dict(dtype=_F64, device=self.dev)
+        r, x = [], images
+        for i, lay in enumerate(self.rep, 1):
+            out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
+            lay.forward(x, p[f"repr_c{i}_w"], p[f"repr_c{i}_b"], out, s)
+            r.append(out); x = out
+        rvec = torch.empty(b, self.Lc, **f64)
+        call("svgp_avgpool_fwd", b, 64, self.Lc, x.data_ptr(), rvec.data_ptr(), s)
+        return r, rvec
+
+    def _decoder_forward(self, z, b):
+        """spritesVAE.decode (VAE_utils.py:317-338,352-360): Dense(1024) -> (8,8,16) -> 7 (up)convs."""
+        p, s, L = self.params, self.stream.cuda_stream, self.L
+        f64 = dict(dtype=_F64, device=self.dev)
+        h0 = torch.empty(b, 1024, **f64)
+        self._gemm(0, 0, b, 1024, L, 1.0, z, L, p["dec_d_w"], 1024, 0.0, h0, 1024)
+        call("svgp_bias_add", b, 1024, p["dec_d_b"].data_ptr(), h0.data_ptr(), s)
+        d, x = [], h0.view(b, 8, 8, 16)
+        for i, lay in enumerate(self.dec, 1):
+            out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
+            lay.forward(x, p[f"dec_c{i}_w"], p[f"dec_c{i}_b"], out, s)
+            d.append(out); x = out
+        return h0, d
+
+    # ------------------------------------------------------------------ forward-only entry points (test pipeline)
+    def _chunks(self, n):
+        return [(lo, min(lo + self.b_max, n)) for lo in range(0, n, self.b_max)]
+
+    def encode(self, images):
+        """(qnet_mu, qnet_var) of spritesVAE.encode with the clip of SVGPVAE_model.py:961-962, any number of frames."""
+        n = images.shape[0]
+        mu_o, var_o = torch.empty(n, self.L, dtype=_F64, device=self.dev), torch.empty(n, self.L, dtype=_F64, device=self.dev)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.stream):
+            for lo, hi in self._chunks(n):
+                _, _, mu, _, var = self._encoder_forward(images[lo:hi].contiguous(), hi - lo)
+                mu_o[lo:hi].copy_(mu); var_o[lo:hi].copy_(var)
+        self.stream.synchronize()
+        return mu_o, var_o
+
+    def character_vectors(self, images):
+        """repr_nn.repr_nn(frames): (n, L_character)."""
+        n = images.shape[0]
+        out = torch.empty(n, self.Lc, dtype=_F64, device=self.dev)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.stream):
+            for lo, hi in self._chunks(n):
+                out[lo:hi].copy_(self._repr_forward(images[lo:hi].contiguous(), hi - lo)[1])
+        self.stream.synchronize()
+        return out
+
+    def decode(self, z):
+        """spritesVAE.decode for any number of latent rows: (n, 64, 64, 3)."""
+        n = z.shape[0]
+        out = torch.empty(n, 64, 64, 3, dtype=_F64, device=self.dev)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.stream):
+            for lo, hi in self._chunks(n):
+                out[lo:hi].copy_(self._decoder_forward(z[lo:hi].contiguous(), hi - lo)[1][-1])
+        self.stream.synchronize()
+        return out
+
+    def kernel_matrices(self, aux):
+        """spritesSVGP.kernel_matrix for batch rows `aux` (n, 1 + L_character) against the inducing points:
+        (K_mm (m,m), K_nm (n,m), diag K_nn (n)), float64 (svgp_sprites_kernel_matrix_fwd)."""
+        n = aux.shape[0]
+        p, s = self.params, self.stream.cuda_stream
+        K = torch.empty(self.m, self.m, dtype=_F64, device=self.dev)
+        Kn = torch.empty(n, self.m, dtype=_F64, device=self.dev)
+        knn = torch.empty(n, dtype=_F64, device=self.dev)
+        kc = SpritesKcfg(b=n, m=self.m, La=self.La, Lc=self.Lc, n_act=self.n_act,
+                         normalize=int(self.svgp.K_obj_normalize), k_se=int(self.svgp.K_SE), rep_weight=1.0)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.stream):
+            aux = aux.to(self.dev, _F64).contiguous()
+            call("svgp_sprites_kernel_matrix_fwd", C.byref(kc), aux.data_ptr(), p["inducing_index_points"].data_ptr(),
+                 p["GPLVM_action"].data_ptr(), p["se"].data_ptr(), K.data_ptr(), Kn.data_ptr(), knn.data_ptr(), s)
+        self.stream.synchronize()
+        return K, Kn, knn
+
     # ------------------------------------------------------------------ one step
     def step(self, images, action_ids, eps=None, adam=True, b_global=None):
         """images (b,64,64,3), action_ids (b) float64 CUDA tensors; eps (b,L) or None (on-device N(0,1)).
@@ -226,25 +326,8 @@ class SpritesStepEngine:
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.stream):
             images = images.contiguous()
-            # ---------------- encoder
-            a, x = [], images
-            for i, lay in enumerate(self.enc, 1):
-                out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
-                lay.forward(x, p[f"enc_c{i}_w"], p[f"enc_c{i}_b"], out, s)
-                a.append(out); x = out
-            enc = torch.empty(b, 2 * L, **f64)
-            self._gemm(0, 0, b, 2 * L, 1024, 1.0, x, 1024, p["enc_d_w"], 2 * L, 0.0, enc, 2 * L)
-            mu, var_raw, var = self._v("qnet_mu", (b, L)), self._v("qnet_var_raw", (b, L)), self._v("qnet_var", (b, L))
-            call("svgp_enc_head_fwd", b, L, int(self.clip_qs), p["enc_d_b"].data_ptr(), enc.data_ptr(), mu.data_ptr(),
-                 var_raw.data_ptr(), var.data_ptr(), s)
-            # ---------------- representation network -> aux data
-            r, x = [], images
-            for i, lay in enumerate(self.rep, 1):
-                out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
-                lay.forward(x, p[f"repr_c{i}_w"], p[f"repr_c{i}_b"], out, s)
-                r.append(out); x = out
-            rvec = torch.empty(b, self.Lc, **f64)
-            call("svgp_avgpool_fwd", b, 64, self.Lc, x.data_ptr(), rvec.data_ptr(), s)
+            a, enc, mu, var_raw, var = self._encoder_forward(images, b)
+            r, rvec = self._repr_forward(images, b)
             aux = torch.empty(b, 1 + self.Lc, **f64)
             aid = action_ids.to(_F64).contiguous()
             call("svgp_sprites_aux_fwd", b, self.seg_len, self.Lc, rvec.data_ptr(), aid.data_ptr(), aux.data_ptr(), s)
@@ -262,14 +345,8 @@ class SpritesStepEngine:
             call("svgp_gp_posterior_fwd", cp, None if eps is None else eps.contiguous().data_ptr(), ws, st, s)
             # ---------------- decoder
             z = self._v("z", (b, L))
-            h0 = torch.empty(b, 1024, **f64)
-            self._gemm(0, 0, b, 1024, L, 1.0, z, L, p["dec_d_w"], 1024, 0.0, h0, 1024)
-            call("svgp_bias_add", b, 1024, p["dec_d_b"].data_ptr(), h0.data_ptr(), s)
-            d, x = [], h0.view(b, 8, 8, 16)
-            for i, lay in enumerate(self.dec, 1):
-                out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
-                lay.forward(x, p[f"dec_c{i}_w"], p[f"dec_c{i}_b"], out, s)
-                d.append(out); x = out
+            h0, d = self._decoder_forward(z, b)
+            x = d[-1]
             recon = x
             tot = b * 64 * 64 * 3
             call("svgp_sqerr_fwd", tot, min(b, 256), images.data_ptr(), recon.data_ptr(),
@@ -371,3 +448,116 @@ def forward_pass_SVGPVAE(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha
     eng.step(frames.to(dev, _F64), action_ids.to(dev, _F64), None if epsilon is None else epsilon.to(dev, _F64),
              adam=False)
     return eng.outputs()
+
+
+# ---------------------------------------------------------------------------------------------
+# conditional generation for a test character (SPRITES_experiment.py:160-205, 364-372, 500-560)
+# ---------------------------------------------------------------------------------------------
+def _engine_of(svgp, vae, repr_nn, engine, b_hint, clipping_qs):
+    eng = engine or getattr(svgp, "_engine", None)
+    if eng is None:
+        eng = SpritesStepEngine(vae, repr_nn, svgp, b_max=max(int(b_hint), 1), seg_len=1, clip_qs=clipping_qs)
+        svgp._engine = eng
+    return eng
+
+
+def _segment_mean_repeat(cv, segment_ids, repeats):
+    """tf.segment_mean + tf.repeat of aux_data_SVGPVAE_sprites (SVGPVAE_model.py:1103-1109); O(n L_character) glue."""
+    seg = torch.as_tensor(np.asarray(segment_ids), device=cv.device, dtype=torch.long)
+    n_seg = int(seg.max().item()) + 1
+    sums = torch.zeros(n_seg, cv.shape[1], dtype=cv.dtype, device=cv.device).index_add_(0, seg, cv)
+    cnt = torch.bincount(seg, minlength=n_seg).to(cv.dtype)[:, None]
+    return torch.repeat_interleave(sums / cnt, torch.as_tensor(np.asarray(repeats), device=cv.device), dim=0)
+
+
+def aux_data_SVGPVAE_sprites(data_batch, repr_nn, segment_ids, repeats, engine):
+    """SVGPVAE_model.py:1086-1115 for arbitrary (segment_ids, repeats): representation network on the frames,
+    segment mean per character, repeat, prepend the action ids of the OUTPUT rows."""
+    images, action_IDs = data_batch
+    cv = engine.character_vectors(images.to(engine.dev, _F64))
+    cv = _segment_mean_repeat(cv, segment_ids, repeats)
+    return torch.cat([action_IDs.to(engine.dev, _F64)[:, None], cv], dim=1).contiguous()
+
+
+def batching_encode_SVGPVAE(data_batch, vae, clipping_qs=False, repr_nn=None, segment_ids=None, repeats=None, svgp=None,
+                            engine=None):
+    """SVGPVAE_model.py:939-968 (SPRITES form): (qnet_mu, qnet_var, aux_data) of a batch of train frames."""
+    images, action_IDs = data_batch
+    eng = _engine_of(svgp, vae, repr_nn, engine, images.shape[0], clipping_qs)
+    assert eng.clip_qs == bool(clipping_qs), "engine was built with a different clipping_qs"
+    mu, var = eng.encode(images.to(eng.dev, _F64))
+    aux = aux_data_SVGPVAE_sprites(data_batch, repr_nn, segment_ids, repeats, eng)
+    return mu, var, aux
+
+
+def precompute_GP_params_SVGPVAE(means, vars, aux_data, svgp, engine=None):
+    """SVGPVAE_model.py:989-1023 over ALL train frames: (mean_terms (L, m), inverse Sigma_l (L, m, m)).
+    K_nm and the statistics K_mn diag(1/var_l) K_nm, K_mn (mean_l / var_l) run as the float32 streaming kernels
+    (float32 is the reference's SPRITES dtype); Sigma_l = K_mm + S_l is inverted in float64, no jitter (:1014)."""
+    from . import stream_stats as SS
+    eng = engine or svgp._engine
+    dev = eng.dev
+    se = eng.params["se"].detach().cpu().tolist()
+    kd = SS.kernel_desc(SS.SE_SE if svgp.K_SE else SS.LINEAR_LINEAR, svgp.L_action, svgp.L_character,
+                        normalize=svgp.K_obj_normalize and not svgp.K_SE, n_table=eng.n_act, params=se if svgp.K_SE else ())
+    f32 = lambda t: t.to(dev, torch.float32).contiguous()
+    mt, inv = SS.precompute_GP_params_f32(kd, f32(means), f32(vars), f32(aux_data), f32(eng.params["inducing_index_points"]),
+                                          table=f32(eng.params["GPLVM_action"]))
+    return mt.double(), inv.double()
+
+
+def approximate_posterior_params_precomputed_GP_posterior_params(svgp, index_points, mean_terms, sigma_terms, K_mm_inv=None,
+                                                                 engine=None):
+    """spritesSVGP.approximate_posterior_params_precomputed_GP_posterior_params (SVGPVAE_model.py:610-635) for all L
+    channels at once: mean (b, L) = K_bm mean_term_l, B (b, L) = K_bb + diag(-K_bm K_mm^-1 K_mb + K_bm Sigma_l^-1 K_mb)."""
+    eng = engine or svgp._engine
+    K, Kb, kbb = eng.kernel_matrices(index_points)
+    m, b, L = eng.m, Kb.shape[0], mean_terms.shape[0]
+    dev = eng.dev
+    if K_mm_inv is None:   # :620-622 (with jitter)
+        Kj = (K + svgp.jitter * torch.eye(m, dtype=_F64, device=dev))[None].contiguous()
+        w = torch.empty(max(int(eng.lib.svgp_spd_inverse_workspace_elems(m, 1)), 1), dtype=_F64, device=dev)
+        ld = torch.empty(1, dtype=_F64, device=dev)
+        call("svgp_spd_inverse_batched", m, 1, Kj.data_ptr(), ld.data_ptr(), w.data_ptr(),
+             torch.cuda.current_stream(dev).cuda_stream)
+        K_mm_inv = Kj[0]
+    s = torch.cuda.current_stream(dev).cuda_stream
+    mean = torch.empty(b, L, dtype=_F64, device=dev)
+    mt = mean_terms.to(dev, _F64).contiguous()
+    call("svgp_dgemm_batched", 0, 1, b, L, m, 1.0, Kb.data_ptr(), m, 0, mt.data_ptr(), m, 0, 0.0, mean.data_ptr(), L, 0, 1, s)
+    # X_l = Sigma_l^-1 - K_mm^-1 ;  B_l = k_bb + rowsum((K_bm X_l) o K_bm)
+    X = (sigma_terms.to(dev, _F64) - K_mm_inv.to(dev, _F64)[None]).contiguous()
+    P = torch.empty(L, b, m, dtype=_F64, device=dev)
+    call("svgp_dgemm_batched", 0, 0, b, m, m, 1.0, Kb.data_ptr(), m, 0, X.data_ptr(), m, m * m, 0.0, P.data_ptr(), m, b * m,
+         L, s)
+    B = kbb[:, None] + (P * Kb[None]).sum(-1).t()
+    return mean, B
+
+
+def predict_SVGPVAE_sprites_test_character(data_batch, vae, svgp, repr_NN, mean_terms, var_terms, N_context, N_actions,
+                                           batch_size_test, segment_ids, repeats, K_mm_inv, context_full_actions=True,
+                                           epsilon=None, engine=None):
+    """SVGPVAE_model.py:1118-1195: context / target split of a test-character batch, aux data of the targets from the
+    context frames, latents from the precomputed GP posterior (clip [1e-4, 100]), decode, summed squared error / pixels.
+    Returns (recon_images_test, target images, recon_loss).  `epsilon` (n_target, L) makes the N(0,1) draw an input."""
+    if not context_full_actions:
+        raise NotImplementedError("context_full_actions=False draws the context with np.random inside the reference")
+    images, aux_data_target = data_batch
+    eng = _engine_of(svgp, vae, repr_NN, engine, batch_size_test, False)
+    dev = eng.dev
+    context = np.sort(np.array([list(range(i * N_actions, i * N_actions + N_context))
+                                for i in range(int(batch_size_test / N_actions))]).reshape(-1))
+    target = np.array([x for x in range(batch_size_test) if x not in set(context.tolist())])
+    images = images.to(dev, _F64)
+    ids = aux_data_target.to(dev, _F64)
+    images_context, images_t = images[context].contiguous(), images[target].contiguous()
+    aux_t = aux_data_SVGPVAE_sprites((images_context, ids[target]), repr_NN, segment_ids, repeats, eng)
+    p_m, p_v = approximate_posterior_params_precomputed_GP_posterior_params(svgp, aux_t, mean_terms, var_terms, K_mm_inv,
+                                                                           engine=eng)
+    p_v = torch.clamp(p_v, 1e-4, 100.0)
+    if epsilon is None:
+        epsilon = torch.randn(p_m.shape, dtype=_F64, device=dev)
+    z = (p_m + epsilon.to(dev, _F64) * torch.sqrt(p_v)).contiguous()
+    recon = eng.decode(z)
+    recon_loss = torch.sum((images_t - recon) ** 2) / float(64 * 64 * 3)
+    return recon, images_t, recon_loss

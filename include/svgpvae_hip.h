@@ -248,6 +248,7 @@ int svgp_comm_unique_id(void* out, int nbytes);
 int svgp_comm_init(const void* unique_id, int nbytes, int rank, int nranks, void** comm_out);
 int svgp_comm_destroy(void* comm);
 int svgp_allreduce_sum_f64(void* comm, double* buf, int64_t count, void* stream);
+int svgp_allreduce_sum_f32(void* comm, float* buf, int64_t count, void* stream);   /* float32 streaming statistics */
 int svgp_mnist_train_step_dp(const svgp_mnist_cfg*, void* comm, double* theta, const double* images,
                              const double* aux, const double* eps, double* ws, double* state,
                              double* adam_m, double* adam_v, void* stream);

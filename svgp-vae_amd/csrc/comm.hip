@@ -122,6 +122,17 @@ extern "C" int svgp_allreduce_sum_f64(void* comm, double* buf, int64_t count, vo
     return SVGP_OK;
 }
 
+extern "C" int svgp_allreduce_sum_f32(void* comm, float* buf, int64_t count, void* stream) {
+    SVGP_REQUIRE(comm && buf && count >= 0, SVGP_ERR_INVALID, "NULL communicator / buffer");
+    if (count == 0) return SVGP_OK;
+    Rccl* r;
+    int rc = rccl_get(&r);
+    if (rc) return rc;
+    Comm* c = (Comm*)comm;
+    SVGP_CHECK_RCCL(r, r->AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream));
+    return SVGP_OK;
+}
+
 // One data-parallel step, everything enqueued on `stream`:
 //   phase 0 | all-reduce statA | phase 1 | all-reduce statB | phase 2 | all-reduce gradC | phase 3
 // c->b is this rank's row count, c->b_global the global batch, c->rep_weight 1 on exactly one rank.

@@ -104,8 +104,9 @@ class RcclComm:
         return cls(rank, world, box[0])
 
     def all_reduce(self, tensor, stream):
-        assert tensor.dtype == torch.float64 and tensor.is_contiguous() and tensor.is_cuda
-        call("svgp_allreduce_sum_f64", self.handle, tensor.data_ptr(), tensor.numel(), stream)
+        assert tensor.dtype in (torch.float64, torch.float32) and tensor.is_contiguous() and tensor.is_cuda
+        fn = "svgp_allreduce_sum_f64" if tensor.dtype == torch.float64 else "svgp_allreduce_sum_f32"
+        call(fn, self.handle, tensor.data_ptr(), tensor.numel(), stream)
 
     def close(self):
         if self.handle:

@@ -64,8 +64,10 @@ def stats_workspace(n, m, L, device):
     return torch.empty(lib.svgp_stream_stats_workspace_elems(n, m, L), dtype=torch.float32, device=device)
 
 
-def stats(K_nm, means, vars, ws=None, S=None, v=None):
-    """S (L, m, m) = K_nm^T diag(1/var_l) K_nm and v (L, m) = K_nm^T (mean_l / var_l)."""
+def stats(K_nm, means, vars, ws=None, S=None, v=None, comm=None):
+    """S (L, m, m) = K_nm^T diag(1/var_l) K_nm and v (L, m) = K_nm^T (mean_l / var_l).  With `comm` (engine.RcclComm)
+    every rank passes its row shard and the two results are summed over ranks on the same stream (the
+    all-reduce of (L, m, m) of config 5)."""
     _check(K_nm, "K_nm"); _check(means, "means"); _check(vars, "vars")
     n, m = K_nm.shape
     L = means.shape[1]
@@ -76,6 +78,9 @@ def stats(K_nm, means, vars, ws=None, S=None, v=None):
     v = torch.empty((L, m), dtype=torch.float32, device=dev) if v is None else v
     call("svgp_stream_stats_f32", n, m, L, K_nm.data_ptr(), means.data_ptr(), vars.data_ptr(), S.data_ptr(),
          v.data_ptr(), ws.data_ptr(), ws.numel(), _stream(K_nm))
+    if comm is not None:
+        comm.all_reduce(S, _stream(K_nm))
+        comm.all_reduce(v, _stream(K_nm))
     return S, v
 
 

@@ -24,6 +24,26 @@ def test_unique_id_and_allreduce_identity():
     comm.close()
 
 
+def test_float32_allreduce_and_sharded_statistics():
+    """svgp_allreduce_sum_f32 on a 1-rank communicator + the row-sharded form of the float32 statistics: two shards
+    computed separately and added equal the unsharded pass (what the all-reduce does across ranks)."""
+    from svgp_vae_amd import stream_stats as SS
+    from svgp_vae_amd.engine import RcclComm
+    comm = RcclComm(0, 1, RcclComm.unique_id())
+    g = torch.Generator(device="cuda").manual_seed(0)
+    n, m, L = 3000, 200, 3
+    K = torch.randn(n, m, device="cuda", generator=g)
+    mu = torch.randn(n, L, device="cuda", generator=g)
+    var = torch.rand(n, L, device="cuda", generator=g) + 0.1
+    S, v = SS.stats(K, mu, var, comm=comm)
+    torch.cuda.synchronize()
+    Sa, va = SS.stats(K[:1700].contiguous(), mu[:1700].contiguous(), var[:1700].contiguous())
+    Sb, vb = SS.stats(K[1700:].contiguous(), mu[1700:].contiguous(), var[1700:].contiguous())
+    assert float((Sa + Sb - S).abs().max() / S.abs().max()) < 1e-5
+    assert float((va + vb - v).abs().max() / v.abs().max()) < 1e-5
+    comm.close()
+
+
 def test_dp_entry_equals_single_gpu_step(golden):
     from svgp_vae_amd.engine import RcclComm
     params, images, aux, eps = H.golden_problem(golden)

@@ -34,8 +34,8 @@ class SpritesSVGP(O.MnistSVGP):
     """mainSVGP + spritesSVGP.kernel_matrix (SVGPVAE_model.py:487-600)."""
 
     def __init__(self, inducing_index_points, GPLVM_action, jitter, N_train, L_action, K_obj_normalize=False,
-                 K_SE=False, se_params=None):
-        super().__init__(False, inducing_index_points, None, None, None, jitter, N_train, K_obj_normalize)
+                 K_SE=False, se_params=None, titsias=False):
+        super().__init__(titsias, inducing_index_points, None, None, None, jitter, N_train, K_obj_normalize)
         self.GPLVM_action = GPLVM_action
         self.L_action = L_action
         self.K_SE = K_SE
@@ -138,7 +138,7 @@ def aux_data_SVGPVAE_sprites(data_batch, p, segment_ids, repeats):
 
 def forward_pass_SVGPVAE_sprites(data_batch, beta, params, gp, C_ma, lagrange_mult, alpha, kappa, *, L,
                                  segment_ids, repeats, clipping_qs=False, GECO=False, epsilon=None,
-                                 formulation="efficient"):
+                                 formulation="efficient", titsias=False):
     """forward_pass_SVGPVAE with repr_NN set (SVGPVAE_model.py:823-936): computed aux data, p_v clipped to
     [1e-4, 100] (:891-892).  `gp` = dict(ip, GPLVM_action, jitter, N_train, L_action, K_obj_normalize, K_SE, se)."""
     images, action_ids = data_batch
@@ -147,7 +147,9 @@ def forward_pass_SVGPVAE_sprites(data_batch, beta, params, gp, C_ma, lagrange_mu
     b = float(images.shape[0])
     vae = SpritesVAE(params, L)
     svgp = SpritesSVGP(gp["ip"], gp["GPLVM_action"], gp["jitter"], gp["N_train"], gp["L_action"],
-                       gp.get("K_obj_normalize", False), gp.get("K_SE", False), gp.get("se"))
+                       gp.get("K_obj_normalize", False), gp.get("K_SE", False), gp.get("se"), titsias=titsias)
+    if titsias:
+        formulation = "literal"        # the b x b branch of variational_loss (:246-259)
     qnet_mu, qnet_var = vae.encode(images)
     if clipping_qs:
         qnet_var = O.clip_by_value(qnet_var, 1e-3, 10.0)
@@ -167,7 +169,7 @@ def forward_pass_SVGPVAE_sprites(data_batch, beta, params, gp, C_ma, lagrange_mu
         knn = svgp.kernel_matrix(aux, aux, False, False, diag_only=True)
         p_m, p_v, L3, KL = O.gp_block_efficient(K, Kn, knn, qnet_mu, qnet_var, gp["jitter"], gp["N_train"])
         inside_recon, inside_kl = L3.sum(), KL.sum()
-    inside_elbo = inside_recon - (b / gp["N_train"]) * inside_kl
+    inside_elbo = inside_recon - inside_kl if titsias else inside_recon - (b / gp["N_train"]) * inside_kl   # :882-885
     p_v = O.clip_by_value(p_v, 1e-4, 100.0)
     ce_term = O.gauss_cross_entropy(p_m, p_v, qnet_mu, qnet_var).sum()
     KL_term = -ce_term + inside_elbo
@@ -189,7 +191,7 @@ def forward_pass_SVGPVAE_sprites(data_batch, beta, params, gp, C_ma, lagrange_mu
 
 def loss_and_grads(params, gp_params, data_batch, epsilon, *, beta, C_ma, lagrange_mult, alpha, kappa, L, L_action,
                    jitter, N_train, segment_ids, repeats, clipping_qs=False, GECO=False, K_obj_normalize=False,
-                   K_SE=False, clip_grad=None, formulation="efficient"):
+                   K_SE=False, clip_grad=None, formulation="efficient", titsias=False):
     """Gradients of the minimised objective w.r.t. all network parameters and GP parameters
     (inducing points, GPLVM action table, SE hyper-parameters when K_SE); optional element-wise clipping."""
     leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
@@ -199,7 +201,7 @@ def loss_and_grads(params, gp_params, data_batch, epsilon, *, beta, C_ma, lagran
               L_action=L_action, K_obj_normalize=K_obj_normalize, K_SE=K_SE, se=se)
     out = forward_pass_SVGPVAE_sprites(data_batch, beta, leaf, gp, C_ma, lagrange_mult, alpha, kappa, L=L,
                                        segment_ids=segment_ids, repeats=repeats, clipping_qs=clipping_qs, GECO=GECO,
-                                       epsilon=epsilon, formulation=formulation)
+                                       epsilon=epsilon, formulation=formulation, titsias=titsias)
     objective = out[0] if GECO else -out[0]
     names = list(leaf) + list(gleaf)
     tensors = [leaf[k] for k in leaf] + [gleaf[k] for k in gleaf]

@@ -177,6 +177,9 @@ class MnistStepEngine:
         st[STATE["ALPHA"]] = 0.0 if self.base["geco"] else self.base["alpha"]
         st[STATE["LR"]] = float(self.state[STATE["LR"]]) if lr is None else lr
         st[STATE["BETA"]] = float(self.state[STATE["BETA"]]) if beta is None else beta
+        # on-device N(0,1): Philox(counter, local row * L + l).  Ranks hold different rows, so each gets its own
+        # counter range (the epilogue advances it by 1 per step); 2^32 * rank is exact in float64
+        st[STATE["RNG_CTR"]] = float(self.rank) * 4294967296.0
         with torch.cuda.stream(self.stream):
             self.state.copy_(st)
         self.stream.synchronize()

@@ -86,9 +86,7 @@ class spritesSVGP:
     def __init__(self, titsias, fixed_inducing_points, initial_inducing_points, name, jitter, N_train, L_action,
                  initial_GPLVM_action, L_character, L, fixed_GP_params=False, fixed_GPLVM=False,
                  K_obj_normalize=False, K_SE=False):
-        if titsias:
-            raise NotImplementedError("SVGPVAE_Titsias branch is not built")
-        self.titsias, self.jitter, self.N_train, self.L = titsias, float(jitter), float(N_train), L
+        self.titsias, self.jitter, self.N_train, self.L = bool(titsias), float(jitter), float(N_train), L
         self.L_action, self.L_character = L_action, L_character
         self.fixed_inducing_points, self.fixed_GP_params, self.fixed_GPLVM = \
             bool(fixed_inducing_points), bool(fixed_GP_params), bool(fixed_GPLVM)
@@ -150,6 +148,7 @@ class SpritesStepEngine:
         # ---- GP workspace (shared stage kernels of the MNIST path; model-agnostic fields only)
         self.base = dict(m=self.m, L=self.L, M=1, n_obj=0, normalize_obj=0, clip_qs=int(clip_qs), geco=int(geco),
                          train_ip=1, train_gp=1, train_ov=0, b_cap=b_max, clip_pv=1, n_pix=64 * 64 * 3,
+                         titsias=int(svgp.titsias),
                          N_train=svgp.N_train, jitter=svgp.jitter, kappa_squared=float(kappa_squared),
                          alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0)
         self.cfg = MnistCfg(b=b_max, b_global=b_max, **self.base)
@@ -161,6 +160,7 @@ class SpritesStepEngine:
         st = torch.zeros(STATE_LEN, dtype=_F64)
         st[STATE["LAGRANGE"]], st[STATE["ALPHA"]] = 1.0, (0.0 if geco else alpha)
         st[STATE["LR"]], st[STATE["BETA"]] = lr, beta
+        st[STATE["RNG_CTR"]] = float(rank) * 4294967296.0     # per-rank Philox counter range (see engine.reset_state)
         with torch.cuda.stream(self.stream):
             self.state.copy_(st)
         # ---- layers
@@ -339,10 +339,14 @@ class SpritesStepEngine:
             call("svgp_sprites_kernel_matrix_fwd", C.byref(kc), aux.data_ptr(), p["inducing_index_points"].data_ptr(),
                  p["GPLVM_action"].data_ptr(), p["se"].data_ptr(), K.data_ptr(), Kn.data_ptr(), knn.data_ptr(), s)
             call("svgp_gp_stats_fwd", cp, ws, s)
+            if self.svgp.titsias:
+                call("svgp_gp_titsias_stats", cp, ws, s)
         yield [self.ws[self.wl.statA:self.wl.statA + self.wl.statA_len]]
         with torch.cuda.stream(self.stream):
             call("svgp_gp_factor_fwd", cp, ws, s)
             call("svgp_gp_posterior_fwd", cp, None if eps is None else eps.contiguous().data_ptr(), ws, st, s)
+            if self.svgp.titsias:
+                call("svgp_gp_titsias_fwd", cp, ws, st, s)
             # ---------------- decoder
             z = self._v("z", (b, L))
             h0, d = self._decoder_forward(z, b)
@@ -370,6 +374,8 @@ class SpritesStepEngine:
         with torch.cuda.stream(self.stream):
             call("svgp_gp_factor_bwd", cp, ws, st, s)
             call("svgp_gp_posterior_bwd", cp, ws, st, s)
+            if self.svgp.titsias:
+                call("svgp_gp_titsias_bwd", cp, ws, st, s)
             d_char = torch.empty(b, self.Lc, **f64)
             call("svgp_sprites_kernel_matrix_bwd", C.byref(kc), aux.data_ptr(), p["inducing_index_points"].data_ptr(),
                  p["GPLVM_action"].data_ptr(), p["se"].data_ptr(), self._v("Kbar", (1,)).data_ptr(),

@@ -107,10 +107,7 @@ def test_train_step_SVGPVAE_updates_the_models_in_place(golden):
 
 
 def test_not_yet_built_branches_say_so():
-    from svgp_vae_amd.sprites import spritesSVGP
     from svgp_vae_amd.MNIST_experiment import main
-    with pytest.raises(NotImplementedError, match="[Tt]itsias"):
-        spritesSVGP(True, False, np.zeros((4, 24)), 'main', 1e-2, 100, 8, np.zeros((72, 8)), 16, 16)
     with pytest.raises(NotImplementedError, match="CVAE"):
         main(["--elbo", "CVAE"])
 

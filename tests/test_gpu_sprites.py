@@ -37,21 +37,23 @@ def _rel(a, c):
     return float((a - c).abs().max() / max(float(c.abs().max()), 1e-9))     # gradients below 1e-9 are noise
 
 
-@pytest.mark.parametrize("K_SE,norm,GECO,m,clip", [(False, False, False, 10, None), (False, True, True, 12, None),
-                                                  (True, False, True, 10, 0.05), (False, False, True, 72, None)])
-def test_sprites_step_matches_oracle(K_SE, norm, GECO, m, clip):
+@pytest.mark.parametrize("K_SE,norm,GECO,m,clip,titsias", [
+    (False, False, False, 10, None, False), (False, True, True, 12, None, False), (True, False, True, 10, 0.05, False),
+    (False, False, True, 72, None, False),
+    (True, False, True, 10, None, True), (False, True, False, 72, None, True)])      # SVGPVAE_Titsias (:246-259)
+def test_sprites_step_matches_oracle(K_SE, norm, GECO, m, clip, titsias):
     from svgp_vae_amd import sprites as S
     b, frames, L, La, Lc, n_act = 8, 4, 6, 8, 16, 9
     params, gp, images, ids, eps, seg, rep = _problem(b, frames, L, La, Lc, m, n_act, seed=m + int(K_SE))
     kappa, jitter, N_train = math.sqrt(0.0075), 0.01, 100.0
     kw = dict(beta=0.001, C_ma=torch.tensor(0.02, dtype=DT), lagrange_mult=torch.tensor(1.4, dtype=DT), alpha=0.9,
               kappa=kappa, L=L, L_action=La, jitter=jitter, N_train=N_train, segment_ids=seg, repeats=rep,
-              clipping_qs=True, GECO=GECO, K_obj_normalize=norm, K_SE=K_SE, clip_grad=clip)
+              clipping_qs=True, GECO=GECO, K_obj_normalize=norm, K_SE=K_SE, clip_grad=clip, titsias=titsias)
     want, wgrads = SO.loss_and_grads(params, gp, (images, ids), eps, formulation="efficient", **kw)
 
     vae = S.spritesVAE(L)
     rnn = S.sprites_representation_network(Lc)
-    svgp = S.spritesSVGP(False, False, gp["inducing_index_points"].numpy(), 'main', jitter, N_train, La,
+    svgp = S.spritesSVGP(titsias, False, gp["inducing_index_points"].numpy(), 'main', jitter, N_train, La,
                          gp["GPLVM_action"].numpy(), Lc, L, fixed_GP_params=False, fixed_GPLVM=False,
                          K_obj_normalize=norm, K_SE=K_SE)
     init = dict(params)

@@ -148,10 +148,10 @@ __device__ __forceinline__ real wave_sum_la(real x) {
 // shifted by c0 columns: the square case is nrows = ncols = m, c0 = 0; the two-level inverse below runs them on
 // the 128-row panel of one outer block step (c0 = first column of that block).
 struct BgjArgs {
-    int nrows, ncols, lda, c0, kb, acc;   // acc: add to logdet instead of starting it at block step 0
+    int nrows, ncols, lda, c0, kb, acc, batch;   // acc: add to logdet instead of starting it at block step 0
     long long sA;          // batch stride of A
     real* A;               // (batch, nrows, lda)
-    real* Pinv;            // (batch, 32, 32)
+    real* Pinv;            // (2, batch, 32, 32): inverse of pivot kb at [kb & 1] (written one step ahead)
     real* Cold;            // (batch, nrows, 32)
     real* logdet;          // (batch)
     // two-level inverse only: capture of every scaled pivot row block V_kk = P_kk^-1 (row block kk), (batch, 128,
@@ -167,60 +167,61 @@ __device__ __forceinline__ real blk_get(const real* A, const BgjArgs& g, int bi,
     return (gi < g.nrows && gj < g.ncols) ? A[(size_t)gi * g.lda + gj] : ((pivot && i == j) ? real(1) : real(0));
 }
 
+// Wave 0 of the workgroup inverts the 32 x 32 block staged in LDS (single-wave Gauss-Jordan on an 8 x 8 lane grid of
+// 4 x 4 register blocks), writes P^-1 to `Pinv` (and `Pcap`), adds log det to logdet[l] (sets it when `first`).
+__device__ __forceinline__ void gj32_sweep(const real (*P)[NB + 1], real* __restrict__ Pinv, real* __restrict__ Pcap,
+                                           real* __restrict__ logdet_l, bool first) {
+    if (threadIdx.x >= 64) return;
+    const int lane = threadIdx.x, bi = lane >> 3, bj = lane & 7;
+    real a[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a[r][c] = P[bi * 4 + r][bj * 4 + c];
+    real mypiv = 1;
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int kq = k / 4, kr = k % 4;
+        real rowk[4], colk[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rowk[c] = __shfl(a[kr][c], kq * 8 + bj, 64);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) colk[r] = __shfl(a[r][kr], bi * 8 + kq, 64);
+        const real piv = __shfl(a[kr][kr], kq * 8 + kq, 64);
+        const real ipiv = fast_rcp_la(piv);
+        if (lane == k) mypiv = piv;
+        real rkj[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rkj[c] = (bj * 4 + c == k) ? ipiv : rowk[c] * ipiv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bool ik = (bi * 4 + r == k), jk = (bj * 4 + c == k);
+                a[r][c] = ik ? rkj[c] : ((jk ? real(0) : a[r][c]) - colk[r] * rkj[c]);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            Pinv[(bi * 4 + r) * NB + bj * 4 + c] = a[r][c];
+            if (Pcap) Pcap[(bi * 4 + r) * NB + bj * 4 + c] = a[r][c];
+        }
+    const real lg = wave_sum_la(log(mypiv));
+    if (lane == 0) *logdet_l = (first ? real(0) : *logdet_l) + lg;
+}
+
+// pivot of block step 0 only: the later pivots are inverted by the trailing-update launch of the step before
+// (look-ahead, k_bgj_trail), which takes this 20 us launch off every later step's critical path
 __global__ __launch_bounds__(256) void k_bgj_pivot(BgjArgs g) {
     __shared__ real P[NB][NB + 1];
     const int l = blockIdx.x, kb = g.kb, kc = g.c0 / NB + kb;
     real* A = g.A + (size_t)l * g.sA;
     for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) P[t / NB][t % NB] = blk_get(A, g, kb, kc, t / NB, t % NB, true);
-    // copy the old block column of the pivot (all panel rows)
-    real* Cold = g.Cold + (size_t)l * g.nrows * NB;
-    for (int t = threadIdx.x; t < g.nrows * NB; t += blockDim.x) {
-        const int i = t / NB, j = t % NB, gj = kc * NB + j;
-        Cold[t] = (gj < g.ncols) ? A[(size_t)i * g.lda + gj] : real(0);
-    }
     __syncthreads();
-    if (threadIdx.x < 64) {      // single-wave Gauss-Jordan on an 8 x 8 lane grid of 4 x 4 blocks
-        const int lane = threadIdx.x, bi = lane >> 3, bj = lane & 7;
-        real a[4][4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) a[r][c] = P[bi * 4 + r][bj * 4 + c];
-        real mypiv = 1;
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int kq = k / 4, kr = k % 4;
-            real rowk[4], colk[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) rowk[c] = __shfl(a[kr][c], kq * 8 + bj, 64);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) colk[r] = __shfl(a[r][kr], bi * 8 + kq, 64);
-            const real piv = __shfl(a[kr][kr], kq * 8 + kq, 64);
-            const real ipiv = fast_rcp_la(piv);
-            if (lane == k) mypiv = piv;
-            real rkj[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) rkj[c] = (bj * 4 + c == k) ? ipiv : rowk[c] * ipiv;
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const bool ik = (bi * 4 + r == k), jk = (bj * 4 + c == k);
-                    a[r][c] = ik ? rkj[c] : ((jk ? real(0) : a[r][c]) - colk[r] * rkj[c]);
-                }
-        }
-        real* Pinv = g.Pinv + (size_t)l * NB * NB;
-        real* Pcap = g.Pcap ? g.Pcap + ((size_t)l * 4 + kb) * NB * NB : nullptr;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                Pinv[(bi * 4 + r) * NB + bj * 4 + c] = a[r][c];
-                if (Pcap) Pcap[(bi * 4 + r) * NB + bj * 4 + c] = a[r][c];
-            }
-        const real lg = wave_sum_la(log(mypiv));
-        if (lane == 0) g.logdet[l] = ((kb == 0 && !g.acc) ? real(0) : g.logdet[l]) + lg;
-    }
+    gj32_sweep(P, g.Pinv + ((size_t)(kb & 1) * g.batch + l) * NB * NB,
+               g.Pcap ? g.Pcap + ((size_t)l * 4 + kb) * NB * NB : nullptr, g.logdet + l, kb == 0 && !g.acc);
 }
 
 // C (32x32, registers -> out) = X (32x32, LDS) * Y (32x32, LDS) on one workgroup of 256 threads:
@@ -241,8 +242,16 @@ __global__ __launch_bounds__(256) void k_bgj_row(BgjArgs g) {
     __shared__ real Y[NB][NB + 1];
     const int j = blockIdx.x, l = blockIdx.y, kb = g.kb, kc = g.c0 / NB + kb;
     real* A = g.A + (size_t)l * g.sA;
-    const real* Pinv = g.Pinv + (size_t)l * NB * NB;
+    const real* Pinv = g.Pinv + ((size_t)(kb & 1) * g.batch + l) * NB * NB;
     const int i = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+    // copy of the OLD block column of the pivot, row block j (needed by every trailing update; row block kb unused)
+    if (j != kb && j * NB < g.nrows) {
+        real* Cold = g.Cold + (size_t)l * g.nrows * NB;
+        for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) {
+            const int r = j * NB + t / NB, c = t % NB, gj = kc * NB + c;
+            if (r < g.nrows) Cold[(size_t)r * NB + c] = (gj < g.ncols) ? A[(size_t)r * g.lda + gj] : real(0);
+        }
+    }
     if (j == kc) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(256) void k_bgj_trail(BgjArgs g) {
     if (bi == kb) return;
     real* A = g.A + (size_t)l * g.sA;
     const real* Cold = g.Cold + (size_t)l * g.nrows * NB;
-    const real* Pinv = g.Pinv + (size_t)l * NB * NB;
+    const real* Pinv = g.Pinv + ((size_t)(kb & 1) * g.batch + l) * NB * NB;
     for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) {
         const int r = t / NB, cidx = t % NB, gi = bi * NB + r;
         X[r][cidx] = (gi < g.nrows) ? Cold[(size_t)gi * NB + cidx] : real(0);          // old A[i][kb]
@@ -295,8 +304,20 @@ __global__ __launch_bounds__(256) void k_bgj_trail(BgjArgs g) {
         const int gi = bi * NB + i, gj = bj * NB + c0 + e;
         if (gi < g.nrows && gj < g.ncols) {
             const size_t o = (size_t)gi * g.lda + gj;
-            A[o] = (bj == kc) ? -out[e] : A[o] - out[e];
+            out[e] = (bj == kc) ? -out[e] : A[o] - out[e];
+            A[o] = out[e];
+        } else {
+            out[e] = (gi - bi * NB == gj - bj * NB) ? real(1) : real(0);     // identity pad (only read below when pivot)
         }
+    }
+    // look-ahead: this workgroup just produced the NEXT pivot block -> invert it now
+    if (bi == kb + 1 && bj == kc + 1 && (kb + 1) * NB < g.nrows) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) X[i][c0 + e] = out[e];
+        __syncthreads();
+        gj32_sweep(X, g.Pinv + ((size_t)((kb + 1) & 1) * g.batch + l) * NB * NB,
+                   g.Pcap ? g.Pcap + ((size_t)l * 4 + kb + 1) * NB * NB : nullptr, g.logdet + l, false);
     }
 }
 
@@ -458,7 +479,7 @@ extern "C" int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double al
     return SVGP_OK;
 }
 
-static size_t inv_ws_inner(int nrows, int batch) { return (size_t)batch * (NB * NB + (size_t)nrows * NB); }
+static size_t inv_ws_inner(int nrows, int batch) { return (size_t)batch * (2 * NB * NB + (size_t)nrows * NB); }
 
 extern "C" size_t svgp_spd_inverse_workspace_elems(int m, int batch) {
     if (m < TWO_LEVEL_MIN_M) return inv_ws_inner(m, batch);
@@ -471,13 +492,15 @@ static int bgj_sweep(int nrows, int ncols, int lda, int c0, long long sA, int ba
                      double* work, int acc, double* Vcap, double* Pcap, void* stream) {
     BgjArgs g;
     g.nrows = nrows; g.ncols = ncols; g.lda = lda; g.c0 = c0; g.acc = acc; g.sA = sA; g.A = A;
-    g.Pinv = work; g.Cold = work + (size_t)batch * NB * NB; g.logdet = logdet;
+    g.Pinv = work; g.Cold = work + (size_t)batch * 2 * NB * NB; g.logdet = logdet; g.batch = batch;
     g.Vcap = Vcap; g.Pcap = Pcap;
     const int nbr = (nrows + NB - 1) / NB, nbc = (ncols + NB - 1) / NB;
     for (int kb = 0; kb < nbr; ++kb) {
         g.kb = kb;
-        hipLaunchKernelGGL(k_bgj_pivot, dim3(batch), dim3(256), 0, (hipStream_t)stream, g);
-        SVGP_LAUNCH_CHECK();
+        if (kb == 0) {     // later pivots come out of the previous step's trailing update (look-ahead)
+            hipLaunchKernelGGL(k_bgj_pivot, dim3(batch), dim3(256), 0, (hipStream_t)stream, g);
+            SVGP_LAUNCH_CHECK();
+        }
         hipLaunchKernelGGL(k_bgj_row, dim3(nbc, batch), dim3(256), 0, (hipStream_t)stream, g);
         SVGP_LAUNCH_CHECK();
         if (nbr > 1) {

@@ -465,6 +465,8 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_scatter(KernAr
 // =============================================================================================
 struct StatArgs {
     int b, m, L, mode, rc_rows, clip_pv;   // rc_rows: rows of K_nm staged per pass
+    int with_aji;                          // backward mode: workgroups y in [L, 2L) finish (A_hat + jI)^-1 and KL
+    const real* Ahat; real* Aji; real* KL; // ... of channel y - L (deferred from svgp_gp_factor_fwd, off its critical path)
     real c, jitter, beta_over_L_unused;
     int geco;
     const real* Kn;      // (b,m)
@@ -484,7 +486,7 @@ __device__ __forceinline__ real grad_KL_term(int flags, int L, const real* state
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
     extern __shared__ __align__(16) real smem[];
     const int m = a.m, l = blockIdx.y;
-    if (l == a.L) {   // ---- K_mm inverse block (forward mode only, blockIdx.x == 0)
+    if (a.mode == 0 && l == a.L) {   // ---- K_mm inverse block (forward mode only, blockIdx.x == 0)
         if (blockIdx.x != 0) return;
         const int ld = m + 1;
         real* A = smem;
@@ -495,6 +497,22 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
         const real logdet = chol_inv(A, W, ld, m);
         mat_store(a.Ki, A, ld, m);
         if (threadIdx.x == 0) *a.ldK = logdet;
+        return;
+    }
+    if (a.mode == 1 && (int)blockIdx.y >= a.L) {
+        // ---- deferred tail of the forward factor stage: Aji = (A_hat + jitter I)^-1 and the log det term of KL
+        // (SVGPVAE_model.py:271-279).  Only the reverse pass and the KL scalar need them, so they run here, beside
+        // the L statistics workgroups that leave most CUs idle, instead of on the forward critical path.
+        if (blockIdx.x != 0) return;
+        const int l2 = blockIdx.y - a.L, ld = m + 1;
+        real* A = smem;
+        real* W = A + m * ld;
+        mat_load(A, ld, a.Ahat + (size_t)l2 * m * m, m);
+        __syncthreads();
+        if (threadIdx.x < m) A[threadIdx.x * ld + threadIdx.x] += a.jitter;
+        const real ldA = chol_inv(A, W, ld, m);
+        mat_store(a.Aji + (size_t)l2 * m * m, A, ld, m);
+        if (threadIdx.x == 0) a.KL[l2] -= real(0.5) * ldA;
         return;
     }
     // ---- statistics of channel l: S = Kn^T diag(w) Kn on the f64 MFMA (A[i][k=n] = w_n Kn[n][i],
@@ -608,6 +626,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
 // =============================================================================================
 struct FactArgs {
     int b, m, L, dbg_stop;   // dbg_stop: timing ablation only (env SVGP_DBG_STOP), 0 in production
+    int defer_aji;           // 1: (A_hat + jI)^-1 and its log det are finished by svgp_gp_stats_bwd's extra workgroups
     real c, jitter;
     const real* K; const real* Ki; const real* ldK; const real* S; const real* v; const real* Kn;
     real* Si; real* t; real* G; real* A; real* Aji; real* mu; real* u; real* M2; real* KL; real* q;
@@ -694,6 +713,10 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
     __syncthreads();
     mat_store(a.M2 + om, R0, ld, m);
     if (a.dbg_stop == 4) return;
+    if (a.defer_aji) {
+        if (threadIdx.x == 0) a.KL[l] = real(0.5) * (*a.ldK - (real)m + tr + muu);     // - ldA / 2 follows
+        return;
+    }
     if (threadIdx.x < m) R3[threadIdx.x * ld + threadIdx.x] += a.jitter;     // A + jitter I
     const real ldA = chol_inv(R3, R2, ld, m);
     mat_store(a.Aji + om, R3, ld, m);
@@ -1120,7 +1143,7 @@ extern "C" int svgp_kernel_matrix_bwd_partials(const svgp_mnist_cfg* c, const do
 }
 
 static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
-                        int mode, void* stream) {
+                        int mode, int with_aji, void* stream) {
     StatArgs a;
     memset(&a, 0, sizeof(a));
     a.b = c->b; a.m = c->m; a.L = c->L; a.mode = mode; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;
@@ -1132,16 +1155,18 @@ static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     if (mode == 0) { a.S = ws + wl.S; a.v1 = ws + wl.v; a.v2 = nullptr; }
     else { a.S = ws + wl.A2; a.v1 = ws + wl.ud; a.v2 = ws + wl.td; }
     a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.ldK = ws + wl.ldK;
+    a.with_aji = with_aji; a.Ahat = ws + wl.A; a.Aji = ws + wl.Aji; a.KL = ws + wl.KL;
     const int m = c->m;
     const int mp_ = (m + 15) & ~15;
     a.rc_rows = (8192 / (mp_ + 2)) & ~3;        // <= 64 KB tile of K_nm rows per pass, multiple of 4
     if (a.rc_rows > ((c->b + 3) & ~3)) a.rc_rows = (c->b + 3) & ~3;
     size_t lds = (size_t)(a.rc_rows * (mp_ + 2) + 3 * a.rc_rows + 2 * SVGP_BLOCK) * sizeof(real);
     const size_t lds_inv = mat_lds(m, 1) + (size_t)(5 * m + 80) * sizeof(real);
-    if (mode == 0 && lds_inv > lds) lds = lds_inv;
+    if ((mode == 0 || with_aji) && lds_inv > lds) lds = lds_inv;
     int rc = set_dyn_lds(k_gp_stats, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gp_stats, dim3(1, c->L + (mode == 0 ? 1 : 0)), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_gp_stats, dim3(1, c->L + (mode == 0 ? 1 : (with_aji ? c->L : 0))), dim3(SVGP_BLOCK), lds,
+                       (hipStream_t)stream, a);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
@@ -1150,23 +1175,40 @@ extern "C" int svgp_gp_stats_fwd(const svgp_mnist_cfg* c, double* ws, void* stre
     GET_LAYOUTS();
     SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
     if (c->m > SVGP_M_MAX) return svgp_big_stats(c, wl, ws, nullptr, 0, stream);
-    return launch_stats(c, wl, ws, nullptr, 0, stream);
+    return launch_stats(c, wl, ws, nullptr, 0, 0, stream);
 }
 
 extern "C" int svgp_gp_stats_bwd(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     if (c->m > SVGP_M_MAX) return svgp_big_stats(c, wl, ws, state, 1, stream);
-    return launch_stats(c, wl, ws, state, 1, stream);
+    return launch_stats(c, wl, ws, state, 1, 0, stream);
+}
+
+// Training-phase pair (m <= 64): the factor stage without its last inverse, and the backward statistics launch with
+// L extra workgroups that finish it.  Same results as svgp_gp_factor_fwd ... svgp_gp_stats_bwd.
+int svgp_gp_stats_bwd_with_aji(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    if (c->m > SVGP_M_MAX) return svgp_big_stats(c, wl, ws, state, 1, stream);
+    return launch_stats(c, wl, ws, state, 1, 1, stream);
 }
 
 static inline int rows_per_block(int m) { return SVGP_BLOCK / m; }
 
+static int factor_fwd_impl(const svgp_mnist_cfg* c, double* ws, int defer_aji, void* stream);
 extern "C" int svgp_gp_factor_fwd(const svgp_mnist_cfg* c, double* ws, void* stream) {
+    return factor_fwd_impl(c, ws, 0, stream);
+}
+int svgp_gp_factor_fwd_defer_aji(const svgp_mnist_cfg* c, double* ws, void* stream) {
+    return factor_fwd_impl(c, ws, 1, stream);
+}
+static int factor_fwd_impl(const svgp_mnist_cfg* c, double* ws, int defer_aji, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
     if (c->m > SVGP_M_MAX) return svgp_big_factor_fwd(c, wl, ws, stream);
     FactArgs a;
+    a.defer_aji = defer_aji;
     a.b = c->b; a.m = c->m; a.L = c->L; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;
     { const char* e_ = getenv("SVGP_DBG_STOP"); a.dbg_stop = e_ ? atoi(e_) : 0; }
     a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.ldK = ws + wl.ldK; a.S = ws + wl.S; a.v = ws + wl.v; a.Kn = ws + wl.Kn;

@@ -198,8 +198,8 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         RUN(svgp_gp_stats_bwd_with_aji(c, ws, state, stream));
         break;
     case 2:
-        RUN(svgp_gp_factor_bwd(c, ws, state, stream));
-        RUN(svgp_gp_posterior_bwd(c, ws, state, stream));
+        RUN(svgp_gp_factor_bwd_nofinal(c, ws, state, stream));          // channel sum Kbar: inside the next launch
+        RUN(svgp_gp_posterior_bwd_with_final(c, ws, state, stream));
         if (c->titsias) RUN(svgp_gp_titsias_bwd(c, ws, state, stream));
         if (fork2) RUN(side_fork(sd, 0, ms));
         RUN(svgp_kernel_matrix_bwd_partials(c, theta, aux, ws, s2));

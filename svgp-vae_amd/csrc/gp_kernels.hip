@@ -968,6 +968,11 @@ struct PostBwdArgs {
     const real* Si; const real* Qm; const real* Ssym; const real* u; const real* t; const real* vbar; const real* Ki;
     real* Knbar_part;   // (L, b, m)
     real* Knbar; real* knnbar; real* ybar; real* s2bar;
+    // training phases: workgroups [nb_rows, nb_rows + n_final) of k_gp_posterior_bwd_sum do k_gp_factor_bwd_final's work
+    // (Kbar = sum_l Kbar_l + (L gK / 2) Ki; independent of this stage, consumed by the kernel-matrix reverse pass)
+    int nb_rows, n_final, b_global;
+    real N_train;
+    const real* Kbar_part; real* Kbar;
 };
 
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_l(PostBwdArgs a) {
@@ -1029,6 +1034,17 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_l(PostBwdArgs a
 
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_sum(PostBwdArgs a) {
     extern __shared__ __align__(16) real smem[];
+    if (a.n_final > 0 && (int)blockIdx.x >= a.nb_rows) {
+        const int m = a.m, o = (blockIdx.x - a.nb_rows) * blockDim.x + threadIdx.x;
+        if (o >= m * m) return;
+        const real gT = grad_KL_term(a.geco, a.L, a.state);
+        const real gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
+        real s = 0;
+#pragma unroll 8
+        for (int l = 0; l < a.L; ++l) s += a.Kbar_part[(size_t)l * m * m + o];
+        a.Kbar[o] = s + real(0.5) * gK * (real)a.L * a.Ki[o];
+        return;
+    }
     const int m = a.m, ld = m + 1, mm = m * ld;
     real* R0 = smem;            // Ki
     real* kr = R0 + mm;         // RB x m
@@ -1258,7 +1274,15 @@ static FactBwdArgs make_fb(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     return a;
 }
 
+static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream);
 extern "C" int svgp_gp_factor_bwd(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    return factor_bwd_impl(c, ws, state, true, stream);
+}
+// training-phase pair (m <= 64): the channel sum Kbar is formed by extra workgroups of the posterior reverse launch
+int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    return factor_bwd_impl(c, ws, state, false, stream);
+}
+static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     if (c->m > SVGP_M_MAX) return svgp_big_factor_bwd(c, wl, ws, state, stream);
@@ -1269,13 +1293,22 @@ extern "C" int svgp_gp_factor_bwd(const svgp_mnist_cfg* c, double* ws, const dou
     if (rc) return rc;
     hipLaunchKernelGGL(k_gp_factor_bwd, dim3(c->L), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_gp_factor_bwd_final, dim3((m * m + SVGP_BLOCK - 1) / SVGP_BLOCK), dim3(SVGP_BLOCK), 0,
-                       (hipStream_t)stream, a);
-    SVGP_LAUNCH_CHECK();
+    if (with_final) {
+        hipLaunchKernelGGL(k_gp_factor_bwd_final, dim3((m * m + SVGP_BLOCK - 1) / SVGP_BLOCK), dim3(SVGP_BLOCK), 0,
+                           (hipStream_t)stream, a);
+        SVGP_LAUNCH_CHECK();
+    }
     return SVGP_OK;
 }
 
+static int posterior_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream);
 extern "C" int svgp_gp_posterior_bwd(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    return posterior_bwd_impl(c, ws, state, false, stream);
+}
+int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    return posterior_bwd_impl(c, ws, state, true, stream);
+}
+static int posterior_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     if (c->m > SVGP_M_MAX) return svgp_big_posterior_bwd(c, wl, ws, state, stream);
@@ -1296,7 +1329,10 @@ extern "C" int svgp_gp_posterior_bwd(const svgp_mnist_cfg* c, double* ws, const 
     const size_t lds2 = mat_lds(m, 1) + (size_t)(SVGP_BLOCK + SVGP_BLOCK) * sizeof(real);
     rc = set_dyn_lds(k_gp_posterior_bwd_sum, lds2);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gp_posterior_bwd_sum, dim3(nb), dim3(SVGP_BLOCK), lds2, (hipStream_t)stream, a);
+    a.nb_rows = nb; a.n_final = with_final ? (m * m + SVGP_BLOCK - 1) / SVGP_BLOCK : 0;
+    a.b_global = c->b_global; a.N_train = c->N_train;
+    a.Kbar_part = ws + wl.fb_part; a.Kbar = ws + wl.Kbar;
+    hipLaunchKernelGGL(k_gp_posterior_bwd_sum, dim3(nb + a.n_final), dim3(SVGP_BLOCK), lds2, (hipStream_t)stream, a);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

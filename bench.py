@@ -69,13 +69,13 @@ def stage_table(eng):
         ("encoder_fwd", "svgp_mnist_encoder_fwd", (cfg, th, img, ws, s), 2 * enc_mac * b, f8 * b * (784 + act_enc + 3 * Lc)),
         ("kernel_matrix_fwd", "svgp_kernel_matrix_fwd", (cfg, th, aux, ws, s), (b * m + m * m) * (2 * 9 + 12), f8 * (b * m + m * m + b + b * 10)),
         ("gp_stats_fwd", "svgp_gp_stats_fwd", (cfg, ws, s), 3 * Lc * b * m * m + 2 * m ** 3, f8 * (b * m + 2 * b * Lc + Lc * m * (m + 1))),
-        ("gp_factor_fwd", "svgp_gp_factor_fwd", (cfg, ws, s), Lc * (2 * (m ** 3 / 3 + 2 * m ** 3 / 3) + 4 * 2 * m ** 3) + 2 * b * m * m, f8 * Lc * 7 * m * m),
+        ("gp_factor_fwd", "svgp_gp_factor_fwd_defer_aji", (cfg, ws, s), Lc * (2 * (m ** 3 / 3 + 2 * m ** 3 / 3) + 4 * 2 * m ** 3) + 2 * b * m * m, f8 * Lc * 7 * m * m),
         ("gp_posterior_fwd", "svgp_gp_posterior_fwd", (cfg, eps, ws, st, s), 4 * Lc * b * m * m, f8 * (Lc * 2 * m * m + b * m + 8 * b * Lc)),
         ("decoder_fwd", "svgp_mnist_decoder_fwd", (cfg, th, img, ws, s), 2 * dec_mac * b, f8 * b * (Lc + act_dec + 2 * 784)),
         ("decoder_bwd", "svgp_mnist_decoder_bwd", (cfg, th, img, ws, st, s), 4 * dec_mac * b, f8 * (b * (Lc + act_dec + 2 * 784 + Lc) + eng.wl.n_part * n_dec)),
-        ("gp_stats_bwd", "svgp_gp_stats_bwd", (cfg, ws, st, s), 3 * Lc * b * m * m, f8 * (b * m + 9 * b * Lc + Lc * m * (m + 2))),
-        ("gp_factor_bwd", "svgp_gp_factor_bwd", (cfg, ws, st, s), Lc * 9 * 2 * m ** 3, f8 * Lc * 14 * m * m),
-        ("gp_posterior_bwd", "svgp_gp_posterior_bwd", (cfg, ws, st, s), 6 * Lc * b * m * m, f8 * (Lc * 3 * m * m + 2 * Lc * b * m + 12 * b * Lc)),
+        ("gp_stats_bwd", "svgp_gp_stats_bwd_with_aji", (cfg, ws, st, s), 3 * Lc * b * m * m, f8 * (b * m + 9 * b * Lc + Lc * m * (m + 2))),
+        ("gp_factor_bwd", "svgp_gp_factor_bwd_nofinal", (cfg, ws, st, s), Lc * 9 * 2 * m ** 3, f8 * Lc * 14 * m * m),
+        ("gp_posterior_bwd", "svgp_gp_posterior_bwd_with_final", (cfg, ws, st, s), 6 * Lc * b * m * m, f8 * (Lc * 3 * m * m + 2 * Lc * b * m + 12 * b * Lc)),
         ("kernel_matrix_bwd", "svgp_kernel_matrix_bwd_partials", (cfg, th, aux, ws, s), (2 * b * m + 2 * m * m) * (2 * 9 + 20), f8 * (2 * b * m + 2 * m * m + b * 10 + N_OBJ * 8)),
         ("encoder_bwd", "svgp_mnist_encoder_bwd", (cfg, th, img, ws, s), 4 * enc_mac * b, f8 * (b * (784 + act_enc + 3 * Lc) + eng.wl.n_part * n_enc)),
         ("grad_reduce", "svgp_mnist_grad_reduce_all", (cfg, aux, ws, s), eng.wl.n_part * (n_enc + n_dec), f8 * eng.wl.n_part * (n_enc + n_dec)),

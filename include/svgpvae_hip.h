@@ -205,6 +205,14 @@ int svgp_mnist_grad_reduce(const svgp_mnist_cfg*, double* ws, void* stream);
 int svgp_kernel_matrix_bwd_partials(const svgp_mnist_cfg*, const double* theta, const double* aux, double* ws,
                                     void* stream);
 int svgp_mnist_grad_reduce_all(const svgp_mnist_cfg*, const double* aux, double* ws, void* stream);
+/* Two more phase-form pairs with identical results (m <= 64; for larger m they are the plain stages).  A piece of work
+ * that is off the critical path moves into extra workgroups of a later launch that leaves most CUs idle:
+ *   (A_hat + jI)^-1 and the log det term of KL:  svgp_gp_factor_fwd_defer_aji ... svgp_gp_stats_bwd_with_aji
+ *   the channel sum Kbar:                        svgp_gp_factor_bwd_nofinal   ... svgp_gp_posterior_bwd_with_final */
+int svgp_gp_factor_fwd_defer_aji(const svgp_mnist_cfg*, double* ws, void* stream);
+int svgp_gp_stats_bwd_with_aji(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 /* tf.train.AdamOptimizer.apply_gradients, TF1 formula (MNIST_experiment.py:200,207-208) */
 int svgp_adam_tf1_step(int64_t n, double* theta, const double* grad, double* adam_m, double* adam_v,
                        const double* state, double beta1, double beta2, double epsilon, void* stream);
@@ -220,9 +228,10 @@ int svgp_elbo_finalize_noadam(const svgp_mnist_cfg*, double* ws, double* state, 
 
 /* ---- phases: the stages above grouped between the data-parallel exchange points -------------
  * phase 0: encoder_fwd, kernel_matrix_fwd, gp_stats_fwd            -> all-reduce ws[statA]
- * phase 1: gp_factor_fwd, gp_posterior_fwd, decoder_fwd, decoder_bwd, gp_stats_bwd
+ * phase 1: gp_factor_fwd_defer_aji, gp_posterior_fwd, decoder_fwd, decoder_bwd, gp_stats_bwd_with_aji
  *                                                                   -> all-reduce ws[statB]
- * phase 2: gp_factor_bwd, gp_posterior_bwd, kernel_matrix_bwd_partials, encoder_bwd, grad_reduce_all
+ * phase 2: gp_factor_bwd_nofinal, gp_posterior_bwd_with_final, kernel_matrix_bwd_partials, encoder_bwd,
+ *          grad_reduce_all
  *                                                                   -> all-reduce ws[gradC]
  * phase 3: adam_tf1_step (skipped when adam_m == NULL), elbo_finalize
  * svgp_mnist_train_step runs phases 0..3 back to back (single GPU).                            */

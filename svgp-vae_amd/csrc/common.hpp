@@ -36,10 +36,6 @@ void svgp_set_error(const char* fmt, ...);
         }                               \
     } while (0)
 
-int svgp_gp_factor_fwd_defer_aji(const svgp_mnist_cfg* c, double* ws, void* stream);
-int svgp_gp_stats_bwd_with_aji(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream);
-int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream);
-int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream);
 int svgp_mnist_step_phase_deferred(const svgp_mnist_cfg* c, int phase, double* theta, const double* images,
                                    const double* aux, const double* eps, double* ws, double* state, double* adam_m,
                                    double* adam_v, void* stream);

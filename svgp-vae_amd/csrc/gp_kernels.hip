@@ -1203,7 +1203,7 @@ extern "C" int svgp_gp_stats_bwd(const svgp_mnist_cfg* c, double* ws, const doub
 
 // Training-phase pair (m <= 64): the factor stage without its last inverse, and the backward statistics launch with
 // L extra workgroups that finish it.  Same results as svgp_gp_factor_fwd ... svgp_gp_stats_bwd.
-int svgp_gp_stats_bwd_with_aji(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+extern "C" int svgp_gp_stats_bwd_with_aji(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     if (c->m > SVGP_M_MAX) return svgp_big_stats(c, wl, ws, state, 1, stream);
@@ -1216,7 +1216,7 @@ static int factor_fwd_impl(const svgp_mnist_cfg* c, double* ws, int defer_aji, v
 extern "C" int svgp_gp_factor_fwd(const svgp_mnist_cfg* c, double* ws, void* stream) {
     return factor_fwd_impl(c, ws, 0, stream);
 }
-int svgp_gp_factor_fwd_defer_aji(const svgp_mnist_cfg* c, double* ws, void* stream) {
+extern "C" int svgp_gp_factor_fwd_defer_aji(const svgp_mnist_cfg* c, double* ws, void* stream) {
     return factor_fwd_impl(c, ws, 1, stream);
 }
 static int factor_fwd_impl(const svgp_mnist_cfg* c, double* ws, int defer_aji, void* stream) {
@@ -1279,7 +1279,7 @@ extern "C" int svgp_gp_factor_bwd(const svgp_mnist_cfg* c, double* ws, const dou
     return factor_bwd_impl(c, ws, state, true, stream);
 }
 // training-phase pair (m <= 64): the channel sum Kbar is formed by extra workgroups of the posterior reverse launch
-int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+extern "C" int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     return factor_bwd_impl(c, ws, state, false, stream);
 }
 static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream) {
@@ -1305,7 +1305,7 @@ static int posterior_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double*
 extern "C" int svgp_gp_posterior_bwd(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     return posterior_bwd_impl(c, ws, state, false, stream);
 }
-int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+extern "C" int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     return posterior_bwd_impl(c, ws, state, true, stream);
 }
 static int posterior_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream) {

@@ -625,7 +625,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
 // for a block of rows (shared by all channels).
 // =============================================================================================
 struct FactArgs {
-    int b, m, L, dbg_stop;   // dbg_stop: timing ablation only (env SVGP_DBG_STOP), 0 in production
+    int b, m, L;
     int defer_aji;           // 1: (A_hat + jI)^-1 and its log det are finished by svgp_gp_stats_bwd's extra workgroups
     real c, jitter;
     const real* K; const real* Ki; const real* ldK; const real* S; const real* v; const real* Kn;
@@ -679,9 +679,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
         R1[i * ld + j] = a.K[o] + a.c * a.S[om + o] + (i == j ? a.jitter : real(0));
     }
     if (threadIdx.x < m) vx[threadIdx.x] = a.v[ov + threadIdx.x];
-    if (a.dbg_stop == 1) return;
     chol_inv(R1, R2, ld, m);                       // R1 = Sigma_l^{-1}
-    if (a.dbg_stop == 2) return;
     mat_store(a.Si + om, R1, ld, m);
     mat_vec(vy, R1, ld, vx, m, real(1));           // t = Si v
     mat_gemm<false, false>(R2, R1, R0, ld, m, real(1));   // G = Si K
@@ -692,7 +690,6 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
     mat_vec(vz, R0, ld, vy, m, a.c);               // mu_hat = c K t
     __syncthreads();
     mat_store(a.A + om, R3, ld, m);
-    if (a.dbg_stop == 3) return;
     if (threadIdx.x < m) a.mu[ov + threadIdx.x] = vz[threadIdx.x];
     mat_load(R1, ld, a.Ki, m);                     // R1 = Ki   (Si, G no longer needed in LDS)
     __syncthreads();
@@ -712,7 +709,6 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
     mat_gemm<false, false>(R0, R1, R2, ld, m, real(1));   // M2 = Ki A Ki   (K no longer needed)
     __syncthreads();
     mat_store(a.M2 + om, R0, ld, m);
-    if (a.dbg_stop == 4) return;
     if (a.defer_aji) {
         if (threadIdx.x == 0) a.KL[l] = real(0.5) * (*a.ldK - (real)m + tr + muu);     // - ldA / 2 follows
         return;
@@ -1226,7 +1222,6 @@ static int factor_fwd_impl(const svgp_mnist_cfg* c, double* ws, int defer_aji, v
     FactArgs a;
     a.defer_aji = defer_aji;
     a.b = c->b; a.m = c->m; a.L = c->L; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;
-    { const char* e_ = getenv("SVGP_DBG_STOP"); a.dbg_stop = e_ ? atoi(e_) : 0; }
     a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.ldK = ws + wl.ldK; a.S = ws + wl.S; a.v = ws + wl.v; a.Kn = ws + wl.Kn;
     a.Si = ws + wl.Si; a.t = ws + wl.t; a.G = ws + wl.G; a.A = ws + wl.A; a.Aji = ws + wl.Aji; a.mu = ws + wl.mu_hat;
     a.u = ws + wl.u; a.M2 = ws + wl.M2; a.KL = ws + wl.KL; a.q = ws + wl.q;

@@ -643,7 +643,7 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_fwd(int b, int L, const real
 // decoder reverse: d loss / d recon -> zbar, decoder weight-gradient partials
 // gscale = d loss / d (sum of squared errors): beta-ELBO 1/784; GECO lagrange_mult/(b_global*784)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int dbg_stop, int b, int L, int geco, real inv_bglobal,
+__global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int b, int L, int geco, real inv_bglobal,
                                                             const real* __restrict__ state,
                                                             const real* __restrict__ th_dec,
                                                             const real* __restrict__ images,
@@ -690,25 +690,18 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int dbg_stop, int b, int
             d3[i] = real(2) * gscale * (o - images[(size_t)n * 784 + i]) * elu_grad_from_out(o);
         }
         __syncthreads();
-        if (dbg_stop == 1) continue;
         UpC3::bwd_weight_mfma(a2, d3, gWe3, g + od.c3b, scratch);     // COUT = 1: chunked VALU form inside
-        if (dbg_stop == 2) continue;
         UpC3::bwd_data_valu(d3, We3, d2);
-        if (dbg_stop == 3) continue;
         __syncthreads();
         for (int i = threadIdx.x; i < 1568; i += blockDim.x) d2[i] *= elu_grad_from_out(a2[i]);
         __syncthreads();
         UpC2::bwd_weight_valu(a1, d2, gWe2, g + od.c2b, scratch);
-        if (dbg_stop == 4) continue;
         UpC2::bwd_data_mfma(d2, We2, d1);
-        if (dbg_stop == 5) continue;
         __syncthreads();
         for (int i = threadIdx.x; i < 512; i += blockDim.x) d1[i] *= elu_grad_from_out(a1[i]);
         __syncthreads();
         UpC1::bwd_weight_mfma(h0, d1, gWe1, g + od.c1b, scratch);
-        if (dbg_stop == 6) continue;
         UpC1::bwd_data_mfma(d1, We1, dh0);
-        if (dbg_stop == 7) continue;
         __syncthreads();
         // dense (no activation): weight / bias gradients and zbar
         for (int o = threadIdx.x; o < L * 128; o += blockDim.x) g[od.dw + o] += z[o / 128] * dh0[o % 128];
@@ -865,8 +858,7 @@ extern "C" int svgp_mnist_decoder_bwd(const svgp_mnist_cfg* c, const double* the
     const size_t lds = (size_t)(c->L * 128 + n_dec + 2 * DEC_NWE + 64 + 128 + 512 + 1568 + 784 + 1568 + 512 + 128 + VAE_SCRATCH) * sizeof(real);
     int rc = set_dyn_lds(k_decoder_bwd, lds);
     if (rc) return rc;
-    const char* e_ = getenv("SVGP_DBG_STOP");
-    hipLaunchKernelGGL(k_decoder_bwd, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, e_ ? atoi(e_) : 0, c->b, c->L,
+    hipLaunchKernelGGL(k_decoder_bwd, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
                        c->geco, 1.0 / (double)c->b_global, state, theta + pl.n_enc, images, ws + wl.z, ws + wl.dec_h0,
                        ws + wl.dec_a1, ws + wl.dec_a2, ws + wl.recon, ws + wl.zbar, ws + wl.part_dec);
     SVGP_LAUNCH_CHECK();

@@ -268,7 +268,20 @@ __global__ __launch_bounds__(ST_NT) void k_stats_mfma_f32(StatsArgs a) {
 
     constexpr int NH = ST_KC / 8;
     f32x4 ga[NH], gb[NH];
+    // interior tiles / full chunks (all of them at the stress shape) take a branch-free path: plain 16-byte loads
+    const bool tile_full = vec && i0 + ST_T <= a.m && j0 + ST_T <= a.m;
     auto fetch = [&](long long nb) {
+        if (tile_full && nb + ST_KC <= n_end) {
+#pragma unroll
+            for (int h = 0; h < NH; ++h) {
+                const long long row = nb + lr + 8 * h;
+                const float* src = a.K + row * a.m;
+                ga[h] = *reinterpret_cast<const f32x4*>(src + i0 + lc);
+                gb[h] = *reinterpret_cast<const f32x4*>(src + j0 + lc);
+                gb[h] *= pl[row];
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             const long long row = nb + lr + 8 * h;

@@ -355,29 +355,62 @@ __global__ __launch_bounds__(256) void k_stats_reduce_f32(int m, int L, int nspl
     S[((size_t)l * m + i) * m + j] = acc;
 }
 
-// v_l = K^T (p_l y_l): one column per lane, 16 channels per pass, rows split over blockIdx.y
+// v_l = K^T (p_l y_l): rows split over blockIdx.y, 16 channels per pass.  VEC: 4 adjacent columns per lane (16-byte
+// loads, 4 rows in flight); the scalar form handles m % 4 != 0.  HBM-read-bound (reads K_nm once).
 constexpr int SV_LC = 16;
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_stats_v_f32(long long n, long long rows_per_split, int m, int L,
                                                      const float* __restrict__ K, const float* __restrict__ pyT,
                                                      float* __restrict__ partv) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    constexpr int CW = VEC ? 4 : 1;
+    const int i = (blockIdx.x * 256 + threadIdx.x) * CW;
     const long long nb = (long long)blockIdx.y * rows_per_split;
     long long ne = nb + rows_per_split;
     if (ne > n) ne = n;
     if (i >= m) return;
     for (int l0 = 0; l0 < L; l0 += SV_LC) {
-        float acc[SV_LC];
+        float acc[SV_LC][CW];
 #pragma unroll
-        for (int q = 0; q < SV_LC; ++q) acc[q] = 0.0f;
-        for (long long r = nb; r < ne; ++r) {
-            const float kv = K[r * m + i];
+        for (int q = 0; q < SV_LC; ++q)
+#pragma unroll
+            for (int c = 0; c < CW; ++c) acc[q][c] = 0.0f;
+        long long r = nb;
+        if (VEC) {
+            for (; r + 4 <= ne; r += 4) {
+                f32x4 kv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) kv[u] = *reinterpret_cast<const f32x4*>(K + (r + u) * m + i);
+#pragma unroll
+                for (int q = 0; q < SV_LC; ++q) {
+                    if (l0 + q < L) {
+                        const float* py = pyT + (size_t)(l0 + q) * n + r;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float w = py[u];
+#pragma unroll
+                            for (int c = 0; c < CW; ++c) acc[q][c] = fmaf(kv[u][c], w, acc[q][c]);
+                        }
+                    }
+                }
+            }
+        }
+        for (; r < ne; ++r) {
+            float kv[CW];
+#pragma unroll
+            for (int c = 0; c < CW; ++c) kv[c] = K[r * m + i + c];
 #pragma unroll
             for (int q = 0; q < SV_LC; ++q)
-                if (l0 + q < L) acc[q] = fmaf(kv, pyT[(size_t)(l0 + q) * n + r], acc[q]);
+                if (l0 + q < L) {
+                    const float w = pyT[(size_t)(l0 + q) * n + r];
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) acc[q][c] = fmaf(kv[c], w, acc[q][c]);
+                }
         }
 #pragma unroll
         for (int q = 0; q < SV_LC; ++q)
-            if (l0 + q < L) partv[((size_t)blockIdx.y * L + l0 + q) * m + i] = acc[q];
+            if (l0 + q < L)
+#pragma unroll
+                for (int c = 0; c < CW; ++c) partv[((size_t)blockIdx.y * L + l0 + q) * m + i + c] = acc[q][c];
     }
 }
 
@@ -409,7 +442,7 @@ StatsPlan stats_plan(long long n, int m, int L) {
     p.nsplit = (int)ns;
     long long rps = (n + ns - 1) / ns;
     p.rows_per_split = (rps + 31) / 32 * 32;
-    const int mt = (m + 255) / 256;
+    const int mt = (m & 3) == 0 ? (m / 4 + 255) / 256 : (m + 255) / 256;
     long long nv = (2048 + mt - 1) / mt;
     long long capv = n / 256 > 1 ? n / 256 : 1;
     if (nv > capv) nv = capv;
@@ -550,8 +583,12 @@ extern "C" int svgp_stream_stats_f32(int64_t n, int m, int L, const float* K_nm,
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_stats_reduce_f32, dim3((m + 255) / 256, m, L), dim3(256), 0, s, m, L, p.nsplit, part, S);
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_stats_v_f32, dim3((m + 255) / 256, p.nsplit_v), dim3(256), 0, s, (long long)n,
-                       p.rows_per_split_v, m, L, K_nm, pyT, partv);
+    if ((m & 3) == 0)
+        hipLaunchKernelGGL(k_stats_v_f32<true>, dim3((m / 4 + 255) / 256, p.nsplit_v), dim3(256), 0, s, (long long)n,
+                           p.rows_per_split_v, m, L, K_nm, pyT, partv);
+    else
+        hipLaunchKernelGGL(k_stats_v_f32<false>, dim3((m + 255) / 256, p.nsplit_v), dim3(256), 0, s, (long long)n,
+                           p.rows_per_split_v, m, L, K_nm, pyT, partv);
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_stats_v_reduce_f32, dim3((L * m + 255) / 256), dim3(256), 0, s, m, L, p.nsplit_v, partv, v);
     SVGP_LAUNCH_CHECK();

@@ -141,8 +141,9 @@ def test_bacthing_predict_conditional_generation(golden):
     assert float(loss) / 128 > 0
 
 
-def test_cli_driver_trains_and_reports_cgen(golden, tmp_path):
-    """`MNIST_experiment.py --elbo SVGPVAE_Hensman ...` counterpart end to end on a small split of the
+@pytest.mark.parametrize("elbo", ["SVGPVAE_Hensman", "SVGPVAE_Titsias"])
+def test_cli_driver_trains_and_reports_cgen(golden, tmp_path, elbo):
+    """`MNIST_experiment.py --elbo SVGPVAE_Hensman | SVGPVAE_Titsias ...` counterpart end to end on a small split of the
     reference's eval images: 6 epochs of GECO training must lower the train MSE, and the eval / conditional
     generation metrics must be finite and written to pics/test_metrics.txt."""
     import pickle
@@ -153,7 +154,7 @@ def test_cli_driver_trains_and_reports_cgen(golden, tmp_path):
         pickle.dump({"images": gin["images"][sl], "aux_data": gin["aux"][sl]}, open(d + name, "wb"))
     pickle.dump(gin["object_vectors"], open(d + "pca_ov_init3.p", "wb"))
     args = E.build_parser().parse_args(
-        ["--elbo", "SVGPVAE_Hensman", "--mnist_data_path", d, "--train_file", d + "train_data3.p", "--ip_joint",
+        ["--elbo", elbo, "--mnist_data_path", d, "--train_file", d + "train_data3.p", "--ip_joint",
          "--GP_joint", "--ov_joint", "--clip_qs", "--GECO", "--PCA", "--opt_regime", "joint-6", "--eval_every", "3",
          "--save", "--base_dir", d, "--lr", "0.003"])
     log = E.run_experiment_rotated_mnist_SVGPVAE(args)

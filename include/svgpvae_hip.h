@@ -1,6 +1,7 @@
 /*
  * svgpvae_hip.h - C ABI of libsvgpvae_hip.so, the MI355X (gfx950) implementation of the
- * SVGPVAE_Hensman training step of ratschlab/SVGP-VAE (rotated-MNIST path).
+ * SVGPVAE_Hensman / SVGPVAE_Titsias training step of ratschlab/SVGP-VAE (rotated-MNIST path), of the
+ * building blocks of its SPRITES path, and of the N-sized float32 statistics pass of its test pipeline.
  *
  * The reference has no native/FFI layer (it is TensorFlow-1.15 graph code), so each entry point
  * below cites the reference Python it replaces (file:line into the reference checkout) instead of
@@ -9,14 +10,16 @@
  * Conventions
  *   - every function returns int: 0 = ok, <0 = svgp_status; svgp_last_error() gives a
  *     thread-local message.  No C++ exception crosses the boundary.
- *   - all tensor pointers are CALLER-OWNED DEVICE pointers (row-major, contiguous, float64);
- *     nothing is retained after return.  Scratch lives in the caller-provided workspace whose
+ *   - all tensor pointers are CALLER-OWNED DEVICE pointers (row-major, contiguous; float64 everywhere
+ *     except the svgp_stream_*_f32 entry points); nothing is retained after return.  Scratch lives in the caller-provided workspace whose
  *     layout svgp_mnist_ws_layout() describes (offsets in float64 elements).
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it,
  *     no hidden synchronisation, no allocation -> every call is hipGraph-capturable.
  *   - per-step scalars (GECO state, Adam step, lr, beta, alpha) live in a small DEVICE state
  *     vector (svgp_state_slot) so that a captured graph can be replayed unchanged.
- *   - no global mutable state: re-entrant, usable from several threads on different streams.
+ *   - re-entrant, usable from several threads on different streams.  Process-wide state is limited to
+ *     what is created once and then only read: the dlopen'd RCCL entry points (svgp_comm_*) and, only with
+ *     SVGP_SIDE_STREAMS=1, one pair of library-owned side streams per device.
  */
 #ifndef SVGPVAE_HIP_H
 #define SVGPVAE_HIP_H

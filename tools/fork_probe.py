@@ -1,4 +1,5 @@
-"""Development probe: cost/benefit of the side-stream branches (env SVGP_FORK bit mask) in graph replay."""
+"""Development probe: cost / benefit of the opt-in side-stream branch (env SVGP_SIDE_STREAMS=1: kernel-matrix reverse pass
+beside the encoder reverse pass) in whole-step graph replay, per-phase graph replay and the eager in-order form."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import bench, torch
@@ -16,11 +17,11 @@ def timeit(fn, reps=300):
     for _ in range(reps): fn()
     eng.synchronize(); return (time.perf_counter() - t0) / reps * 1e6
 
-for mask in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,1,2,3").split(",")]:
-    os.environ["SVGP_FORK"] = str(mask)
+for flag in ("0", "1"):
+    os.environ["SVGP_SIDE_STREAMS"] = flag
     eng.capture("full", adam=False)
     eng.capture_phases("ph", adam=False)
     full = timeit(lambda: eng.replay("full"))
     ph = [timeit(lambda k=k: eng.replay(("ph", k))) for k in range(4)]
     eager = timeit(lambda: eng.run(adam=False), reps=100)
-    print("fork mask", mask, "full graph %.1f us" % full, "phase graphs", [round(x, 1) for x in ph], "eager %.1f" % eager, flush=True)
+    print("SVGP_SIDE_STREAMS=" + flag, "full graph %.1f us" % full, "phase graphs", [round(x, 1) for x in ph], "eager %.1f" % eager, flush=True)

@@ -195,6 +195,7 @@ class MnistStepEngine:
         self.stream.synchronize()
 
     def scalars(self):
+        self.stream.synchronize()      # the state vector is written on self.stream, .cpu() runs on torch's stream
         st = self.state.cpu()
         return {k.lower(): float(st[i]) for k, i in STATE.items()}
 

@@ -252,6 +252,11 @@ def main():
         el = float(t.item())
     sc = eng.scalars()
     assert math.isfinite(sc["elbo"]) and sc["adam_t"] >= args.steps, sc
+    # per-stage HIP-event timings of this rank's launches (rank-local kernels, no collective inside): every rank runs
+    # them so that nobody waits on rank 0, rank 0 reports
+    stage_rows = time_stages(eng) if args.workload == "cfg2" else None
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         line = {
@@ -268,8 +273,8 @@ def main():
                        "launch": "hipGraph replay" if use_graph else launch,
                        "parallelism": f"dp{world}"},
         }
-        if world == 1 and args.workload == "cfg2":
-            rows = time_stages(eng)
+        if args.workload == "cfg2":
+            rows = stage_rows
             top = rows[0]
             ai = top["flops"] / top["bytes"]
             if ai >= F64_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
@@ -294,7 +299,7 @@ def main():
             line["roofline"] = roof
             line["stages_us"] = {r["stage"]: round(r["us"], 2) for r in rows}
             line["step_flops"] = sum(r["flops"] for r in rows)
-            if not args.no_cpu_baseline and args.workload == "cfg2":
+            if world == 1 and not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(params, images, aux, eps, gpu_elbo)
         # RCCL prints a version banner through C stdio at communicator creation; flush it first so the
         # JSON line is the last line on stdout

@@ -70,24 +70,32 @@ __global__ __launch_bounds__(256) void k_big_rowdot(int b, int m, int L, real sc
     s = wave_sum(s);
     if (lane == 0) out[(size_t)n * ld_out + col0 + l] = scale * s;
 }
-// tr(Ki A_l) and mu_l . u_l  -> trm (L,2)
+// tr(Ki A_l) = sum_ij Ki_ij A_ji and mu_l . u_l.  grid (KL_NCH, L): each workgroup sums a contiguous slice of A_l
+// (coalesced; the transposed operand is the shared Ki, an L2 hit) -> part (L, KL_NCH, 2); k_big_kl adds the slices in
+// index order.
+#define KL_NCH 32
 __global__ __launch_bounds__(256) void k_big_kl_terms(int m, const real* __restrict__ Ki, const real* __restrict__ A,
                                                       const real* __restrict__ mu, const real* __restrict__ u,
-                                                      real* __restrict__ trm) {
+                                                      real* __restrict__ part) {
     __shared__ real red[16];
-    const int l = blockIdx.x;
-    const real* Al = A + (size_t)l * m * m;
+    const int l = blockIdx.y, ch = blockIdx.x;
+    const long long mm = (long long)m * m, per = (mm + KL_NCH - 1) / KL_NCH, lo = ch * per, hi = lo + per < mm ? lo + per : mm;
+    const real* Al = A + (size_t)l * mm;
     real tr = 0, muu = 0;
-    for (int o = threadIdx.x; o < m * m; o += blockDim.x) tr += Ki[o] * Al[(size_t)(o % m) * m + o / m];
-    for (int i = threadIdx.x; i < m; i += blockDim.x) muu += mu[(size_t)l * m + i] * u[(size_t)l * m + i];
+    for (long long o = lo + threadIdx.x; o < hi; o += blockDim.x) tr += Ki[(size_t)(o % m) * m + o / m] * Al[o];
+    if (ch == 0)
+        for (int i = threadIdx.x; i < m; i += blockDim.x) muu += mu[(size_t)l * m + i] * u[(size_t)l * m + i];
     tr = block_sum(tr, red);
     muu = block_sum(muu, red);
-    if (threadIdx.x == 0) { trm[l * 2] = tr; trm[l * 2 + 1] = muu; }
+    if (threadIdx.x == 0) { part[((size_t)l * KL_NCH + ch) * 2] = tr; part[((size_t)l * KL_NCH + ch) * 2 + 1] = muu; }
 }
 __global__ void k_big_kl(int m, int L, const real* __restrict__ ldK, const real* __restrict__ ldA,
-                         const real* __restrict__ trm, real* __restrict__ KL) {
+                         const real* __restrict__ part, real* __restrict__ KL) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l < L) KL[l] = real(0.5) * (*ldK - ldA[l] - (real)m + trm[l * 2] + trm[l * 2 + 1]);
+    if (l >= L) return;
+    real tr = 0;
+    for (int ch = 0; ch < KL_NCH; ++ch) tr += part[((size_t)l * KL_NCH + ch) * 2];
+    KL[l] = real(0.5) * (*ldK - ldA[l] - (real)m + tr + part[(size_t)l * KL_NCH * 2 + 1]);
 }
 // final element-wise part of the per-sample forward + partial sums
 struct PostFinArgs {
@@ -338,13 +346,14 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     GEMM(0, 0, m, 1, m, 1.0, Ki, m, 0, mu, 1, (long long)m, 0.0, u, 1, (long long)m, L);          // u = Ki mu
     GEMM(0, 0, m, m, m, 1.0, A, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);                          // T = A Ki
     GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, M2, m, mm, L);                         // M2 = Ki A Ki
-    hipLaunchKernelGGL(k_big_kl_terms, dim3(L), dim3(256), 0, st, m, Ki, A, mu, u, s.trm);
+    // s.mm0 (T = A Ki) is free once M2 is formed: its head holds the (L, KL_NCH, 2) trace partials
+    hipLaunchKernelGGL(k_big_kl_terms, dim3(KL_NCH, L), dim3(256), 0, st, m, Ki, A, mu, u, s.mm0);
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, real(0), c->jitter, A,
                        (const real*)nullptr, mm, Aji);
     SVGP_LAUNCH_CHECK();
     RUNC(svgp_spd_inverse_batched(m, L, Aji, s.ldtmp, s.inv, stream));
-    hipLaunchKernelGGL(k_big_kl, dim3(nblk(L)), dim3(256), 0, st, m, L, ws + wl.ldK, s.ldtmp, s.trm, ws + wl.KL);
+    hipLaunchKernelGGL(k_big_kl, dim3(nblk(L)), dim3(256), 0, st, m, L, ws + wl.ldK, s.ldtmp, s.mm0, ws + wl.KL);
     SVGP_LAUNCH_CHECK();
     // q_n = k_n^T Ki k_n
     GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, Ki, m, 0, 0.0, s.bm, m, 0, 1);

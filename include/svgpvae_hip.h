@@ -363,6 +363,11 @@ int svgp_enc_head_fwd(int b, int L, int clip, const double* bias, double* enc, d
 int svgp_enc_head_bwd(int b, int L, int clip, const double* var_raw, const double* ybar, const double* s2bar,
                       double* d_enc, void* stream);
 int svgp_bias_add(long long rows, int C, const double* bias, double* x, void* stream);
+/* classification loss of the representation-network pre-training (SPRITES_utils.py:335-368): mean sparse softmax
+ * cross-entropy over n rows of C logits, labels = class ids as float64; writes per-row losses, their mean and
+ * d mean / d logits */
+int svgp_softmax_xent(int n, int C, const double* logits, const double* labels, double* row_loss, double* loss,
+                      double* dlogits, void* stream);
 /* sum (x - xhat)^2 partials into the workspace's partial-sum area (block g writes part_sums[4g+2]) and
  * d loss / d xhat (beta-ELBO: 2(xhat-x)/n_pix; GECO: lagrange_mult/(b_global n_pix) times that)              */
 int svgp_sqerr_fwd(long long tot, int n_part, const double* x, const double* xhat, double* part_sums, void* stream);

@@ -7,8 +7,8 @@ Differences that are stated, not hidden:
     frames (N,64,64,3), char_IDs (N), action_IDs (N), rows ordered by character as in the TFRecords
     (N_frames_per_character consecutive rows per character; test characters: all N_actions frames).
     `--synthetic n_train_chars,n_test_chars` generates random data of that layout instead.
-  * `--repr_nn_pretrain yes_*` (classification pre-training of the representation network, :139-151,325-357) is not
-    built: the default here is 'no'.
+  * `--repr_nn_pretrain yes_fixed|yes_joint` (classification pre-training of the representation network,
+    :139-151,325-357) runs `sprites.pretrain_repr_NN` on the train frames (classes = char_IDs); the default here is 'no'.
   * `--elbo VAE`, pandas / matplotlib logging, `--show_pics`, `--ram` are accepted and ignored or rejected with a message.
 Only SVGPVAE_Hensman / SVGPVAE_Titsias are built.  float64 (the reference uses float32)."""
 import argparse
@@ -104,8 +104,6 @@ def _load(args):
 def run_experiment_sprites_SVGPVAE(args, dict_=None):
     if "SVGPVAE" not in args.elbo:
         raise NotImplementedError(f"--elbo {args.elbo}: only SVGPVAE_Hensman / SVGPVAE_Titsias are built")
-    if 'yes' in args.repr_nn_pretrain:
-        raise NotImplementedError("--repr_nn_pretrain yes_*: pre-training of the representation network is not built")
     assert np.sum([args.object_kernel_normalize, args.K_SE]) <= 1, \
         "At most one of GP kernel engineering flags can be used at once!"                      # :43-44
     fpc, N_actions = args.frames_per_character, args.N_actions
@@ -152,6 +150,12 @@ def run_experiment_sprites_SVGPVAE(args, dict_=None):
                                                   N_actions - args.N_context)                # :370-372
     nr_epochs, training_regime = parse_opt_regime(args.opt_regime)
     log = dict(elbo=[], recon_loss=[], recon_mse_test=[], cgen_mse=[])
+    if 'yes' in args.repr_nn_pretrain:                                     # :325-357
+        bs = min(args.batch_size_repr_nn, N_train)
+        log["repr_pretrain"] = S.pretrain_repr_NN(eng, d_tr, t64(train["char_IDs"]), nr_epochs=args.nr_epochs_repr_nn,
+                                                  lr=args.lr_repr_nn, batch_size=bs,
+                                                  n_classes=max(1000, int(train["char_IDs"].max()) + 1), seed=args.seed)
+        eng.freeze_repr = 'fixed' in args.repr_nn_pretrain
     first_step = True
     start = time.time()
     for epoch in range(nr_epochs):

@@ -120,6 +120,7 @@ SIGNATURES = {
     "svgp_avgpool_bwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P],
     "svgp_enc_head_fwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P],
     "svgp_enc_head_bwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
+    "svgp_softmax_xent": [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P],
     "svgp_bias_add": [C.c_longlong, C.c_int, _P, _P, _P],
     "svgp_sqerr_fwd": [C.c_longlong, C.c_int, _P, _P, _P, _P],
     "svgp_sqerr_bwd": [C.c_longlong, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],

@@ -412,6 +412,55 @@ extern "C" int svgp_sqerr_bwd(long long tot, int geco, int b_global, int n_pix, 
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
+namespace {
+// one workgroup per row: numerically stable log-sum-exp, loss_n = lse - logit[label], dlogits = (softmax - onehot) / n
+__global__ __launch_bounds__(256) void k_softmax_xent(int n, int C, const real* __restrict__ logits,
+                                                      const real* __restrict__ labels, real* __restrict__ row_loss,
+                                                      real* __restrict__ dlogits) {
+    __shared__ real red[16];
+    __shared__ real bc[2];
+    const int r = blockIdx.x;
+    const real* z = logits + (size_t)r * C;
+    real mx = -1e300;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) mx = fmax(mx, z[c]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) { real t = red[0]; for (int w = 1; w < (int)(blockDim.x >> 6); ++w) t = fmax(t, red[w]); bc[0] = t; }
+    __syncthreads();
+    mx = bc[0];
+    real se = 0;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) se += exp(z[c] - mx);
+    se = block_sum(se, red);
+    if (threadIdx.x == 0) bc[1] = se;
+    __syncthreads();
+    se = bc[1];
+    const int lab = (int)labels[r];
+    const real inv_n = real(1) / (real)n;
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+        dlogits[(size_t)r * C + c] = (exp(z[c] - mx) / se - (c == lab ? real(1) : real(0))) * inv_n;
+    if (threadIdx.x == 0) row_loss[r] = log(se) + mx - z[lab];
+}
+__global__ __launch_bounds__(256) void k_mean_rows(int n, const real* __restrict__ x, real* __restrict__ out) {
+    __shared__ real red[16];
+    real acc = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) acc += x[i];
+    acc = block_sum(acc, red);
+    if (threadIdx.x == 0) *out = acc / (real)n;
+}
+}  // namespace
+
+// tf.reduce_mean(tf.nn.sparse_softmax_cross_entropy_with_logits(labels, logits)) (SPRITES_utils.py:358) and its
+// gradient w.r.t. the logits; labels are class ids stored as float64
+extern "C" int svgp_softmax_xent(int n, int C, const double* logits, const double* labels, double* row_loss,
+                                 double* loss, double* dlogits, void* stream) {
+    SVGP_REQUIRE(n >= 1 && C >= 1 && logits && labels && row_loss && loss && dlogits, SVGP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_softmax_xent, dim3(n), dim3(256), 0, (hipStream_t)stream, n, C, logits, labels, row_loss, dlogits);
+    SVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mean_rows, dim3(1), dim3(256), 0, (hipStream_t)stream, n, row_loss, loss);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
 extern "C" int svgp_clip_by_value(long long tot, double thr, double* g, void* stream) {
     SVGP_REQUIRE(tot >= 0 && thr > 0 && (g || tot == 0), SVGP_ERR_INVALID, "bad argument");
     if (tot == 0) return SVGP_OK;

@@ -403,6 +403,10 @@ class SpritesStepEngine:
                 dx = self.enc[i - 1].backward(xin, p[f"enc_c{i}_w"], a[i - 1], dx, g[f"enc_c{i}_w"], g[f"enc_c{i}_b"],
                                               self.scratch, s, need_dx=i > 1, nwg=self.nwg)
             # frozen parameter groups (inverted flags of SPRITES_experiment.py:109-111)
+            if getattr(self, "freeze_repr", False):           # --repr_nn_pretrain yes_fixed (SPRITES_experiment.py:214-216)
+                for k in g:
+                    if k.startswith("repr_"):
+                        g[k].zero_()
             if self.svgp.fixed_inducing_points:
                 g["inducing_index_points"].zero_()
             if self.svgp.fixed_GPLVM:
@@ -567,3 +571,83 @@ def predict_SVGPVAE_sprites_test_character(data_batch, vae, svgp, repr_NN, mean_
     recon = eng.decode(z)
     recon_loss = torch.sum((images_t - recon) ** 2) / float(64 * 64 * 3)
     return recon, images_t, recon_loss
+
+
+# ---------------------------------------------------------------------------------------------
+# pre-training of the representation network (SPRITES_experiment.py:139-151,325-357; SPRITES_utils.py:335-368)
+# ---------------------------------------------------------------------------------------------
+def pretrain_repr_NN(engine, frames, char_IDs, *, nr_epochs, lr, batch_size, n_classes=1000, seed=0, log=print):
+    """Character classification: embeddings = repr_nn(frames) -> Dense(n_classes) -> mean sparse softmax cross-entropy,
+    TF1 Adam on the representation network + the classification layer (which is discarded afterwards).  Updates the
+    engine's repr_c* parameters in place; returns the list of (epoch, mean loss, accuracy)."""
+    dev, Lc, s = engine.dev, engine.Lc, engine.stream.cuda_stream
+    f64 = dict(dtype=_F64, device=dev)
+    names = [k for k in engine.shapes if k.startswith("repr_")]
+    sizes = [int(np.prod(engine.shapes[k])) for k in names]
+    n_rep = sum(sizes)
+    theta = torch.zeros(n_rep + Lc * n_classes + n_classes, **f64)
+    grad, am, av = torch.zeros_like(theta), torch.zeros_like(theta), torch.zeros_like(theta)
+    views, gviews, off = {}, {}, 0
+    for k, n in zip(names, sizes):
+        views[k] = theta[off:off + n].view(engine.shapes[k]); gviews[k] = grad[off:off + n].view(engine.shapes[k])
+        off += n
+    W, gW = theta[off:off + Lc * n_classes].view(Lc, n_classes), grad[off:off + Lc * n_classes].view(Lc, n_classes)
+    bC, gb = theta[off + Lc * n_classes:], grad[off + Lc * n_classes:]
+    rs = np.random.RandomState(seed)
+    lim = math.sqrt(6.0 / (Lc + n_classes))                          # Keras Dense default: glorot_uniform, zero bias
+    state = torch.zeros(STATE_LEN, **f64)
+    engine.stream.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(engine.stream):
+        for k in names:
+            views[k].copy_(engine.params[k])
+        W.copy_(torch.tensor(rs.uniform(-lim, lim, (Lc, n_classes)), **f64))
+        state[STATE["LR"]] = lr
+    n = frames.shape[0]
+    ones = torch.ones(batch_size, 1, **f64)
+    history = []
+    for epoch in range(nr_epochs):
+        tot, correct, seen = 0.0, 0, 0
+        for lo in range(0, n - batch_size + 1, batch_size):
+            b = batch_size
+            with torch.cuda.stream(engine.stream):
+                x0 = frames[lo:lo + b].contiguous()
+                lab = char_IDs[lo:lo + b].to(_F64).contiguous()
+                r, x = [], x0
+                for i, lay in enumerate(engine.rep, 1):
+                    out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
+                    lay.forward(x, views[f"repr_c{i}_w"], views[f"repr_c{i}_b"], out, s)
+                    r.append(out); x = out
+                emb = torch.empty(b, Lc, **f64)
+                call("svgp_avgpool_fwd", b, 64, Lc, x.data_ptr(), emb.data_ptr(), s)
+                logits = torch.empty(b, n_classes, **f64)
+                engine._gemm(0, 0, b, n_classes, Lc, 1.0, emb, Lc, W, n_classes, 0.0, logits, n_classes)
+                call("svgp_bias_add", b, n_classes, bC.data_ptr(), logits.data_ptr(), s)
+                rowloss, loss, dlog = torch.empty(b, **f64), torch.empty(1, **f64), torch.empty(b, n_classes, **f64)
+                call("svgp_softmax_xent", b, n_classes, logits.data_ptr(), lab.data_ptr(), rowloss.data_ptr(), loss.data_ptr(),
+                     dlog.data_ptr(), s)
+                engine._gemm(1, 0, Lc, n_classes, b, 1.0, emb, Lc, dlog, n_classes, 0.0, gW, n_classes)      # emb^T dlogits
+                engine._gemm(1, 0, 1, n_classes, b, 1.0, ones, 1, dlog, n_classes, 0.0, gb, n_classes)       # column sums
+                demb = torch.empty(b, Lc, **f64)
+                engine._gemm(0, 1, b, Lc, n_classes, 1.0, dlog, n_classes, W, n_classes, 0.0, demb, Lc)      # dlogits W^T
+                dx = torch.empty(b, 8, 8, Lc, **f64)
+                call("svgp_avgpool_bwd", b, 64, Lc, demb.data_ptr(), dx.data_ptr(), s)
+                for i in range(3, 0, -1):
+                    xin = r[i - 2] if i > 1 else x0
+                    dx = engine.rep[i - 1].backward(xin, views[f"repr_c{i}_w"], r[i - 1], dx, gviews[f"repr_c{i}_w"],
+                                                    gviews[f"repr_c{i}_b"], engine.scratch, s, need_dx=i > 1, nwg=engine.nwg)
+                call("svgp_adam_tf1_step", theta.numel(), theta.data_ptr(), grad.data_ptr(), am.data_ptr(), av.data_ptr(),
+                     state.data_ptr(), 0.9, 0.999, 1e-8, s)
+                state[STATE["ADAM_T"]] += 1.0
+                pred = torch.argmax(logits, dim=1)
+            engine.stream.synchronize()
+            tot += float(loss); seen += b
+            correct += int((pred == lab.long()).sum())
+        nb = max(1, (n - batch_size) // batch_size + 1)
+        history.append((epoch, tot / nb, correct / max(seen, 1)))
+        if log is not None and ((epoch + 1) % 50 == 0 or epoch == nr_epochs - 1):
+            log(f"repr NN pretraining epoch {epoch}: mean loss {history[-1][1]:.4f}  accuracy {history[-1][2]:.4f}")
+    with torch.cuda.stream(engine.stream):
+        for k in names:
+            engine.params[k].copy_(views[k])
+    engine.stream.synchronize()
+    return history

@@ -101,3 +101,35 @@ def test_sprites_cli_driver_end_to_end(tmp_path):
     assert files and len(open(files[0]).read().strip().splitlines()) == 2
     with pytest.raises(NotImplementedError):
         E.main(["--elbo", "VAE", "--synthetic", "2,1"])
+
+
+def test_softmax_xent_kernel_matches_torch():
+    from svgp_vae_amd import _lib
+    g = torch.Generator(device="cuda").manual_seed(0)
+    n, C = 37, 1000
+    logits = torch.randn(n, C, dtype=DT, device="cuda", generator=g) * 3
+    labels = torch.randint(0, C, (n,), device="cuda", generator=g)
+    row, loss, dl = torch.empty(n, dtype=DT, device="cuda"), torch.empty(1, dtype=DT, device="cuda"), torch.empty_like(logits)
+    _lib.call("svgp_softmax_xent", n, C, logits.data_ptr(), labels.to(DT).data_ptr(), row.data_ptr(), loss.data_ptr(),
+              dl.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    lt = logits.clone().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(lt, labels)
+    want.backward()
+    assert abs(float(loss) - float(want)) < 1e-12 * abs(float(want))
+    assert float((dl - lt.grad).abs().max()) < 1e-14
+
+
+def test_repr_nn_pretraining_learns_the_characters(tmp_path):
+    """--repr_nn_pretrain yes_joint (SPRITES_experiment.py:325-357): the classification loss falls and the accuracy on
+    the (synthetic, separable) characters rises; the SVGPVAE training that follows still runs."""
+    from svgp_vae_amd import SPRITES_experiment as E
+    args = E.build_parser().parse_args(
+        ["--elbo", "SVGPVAE_Hensman", "--synthetic", "6,2", "--N_actions", "8", "--frames_per_character", "5",
+         "--batch_size", "10", "--batch_size_test_char", "16", "--N_context", "3", "--L", "8", "--m", "2", "--K_SE", "--GECO",
+         "--clip_qs", "--opt_regime", "joint-1", "--eval_every", "5", "--repr_nn_pretrain", "yes_joint",
+         "--nr_epochs_repr_nn", "40", "--batch_size_repr_nn", "30", "--lr_repr_nn", "0.01", "--base_dir", str(tmp_path)])
+    log = E.run_experiment_sprites_SVGPVAE(args)
+    h = log["repr_pretrain"]
+    assert len(h) == 40 and h[-1][1] < 0.5 * h[0][1] and h[-1][2] > h[0][2]
+    assert np.isfinite(log["elbo"][0])

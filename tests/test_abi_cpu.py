@@ -73,6 +73,28 @@ def test_null_pointers_are_rejected_before_any_launch():
         _lib.call("svgp_mnist_step_phase", C.byref(cfg), 7, 1, 1, 1, None, 1, 1, None, None, None)
 
 
+def test_newer_entry_points_validate_their_arguments():
+    """Argument checks of the streaming / communicator / Titsias entry points happen before any device call."""
+    fake = C.c_void_p(4096)                                     # never dereferenced: every case fails validation first
+    kd = _lib.StreamKdesc(kind=0, d1=2, d2=5, normalize=0, n_table=0)       # GPLVM dim 5 has no float32 instantiation
+    with pytest.raises(svgp_vae_amd.SvgpError, match="no instantiation"):
+        _lib.call("svgp_stream_knm_f32", C.byref(kd), 10, 8, fake, fake, fake, None)
+    kd_bad = _lib.StreamKdesc(kind=0, d1=3, d2=8)
+    with pytest.raises(svgp_vae_amd.SvgpError, match="d1 = 2"):
+        _lib.call("svgp_stream_features_f32", C.byref(kd_bad), 10, fake, 10, 0, None, fake, None)
+    lib = svgp_vae_amd.load_library()
+    need = lib.svgp_stream_stats_workspace_elems(1000, 64, 3)
+    assert need > 0
+    with pytest.raises(svgp_vae_amd.SvgpError, match="workspace"):
+        _lib.call("svgp_stream_stats_f32", 1000, 64, 3, fake, fake, fake, fake, fake, fake, need - 1, None)
+    with pytest.raises(svgp_vae_amd.SvgpError, match="unique id"):
+        _lib.call("svgp_comm_init", fake, 7, 0, 1, C.byref(C.c_void_p()))
+    cfg = _lib.MnistCfg(b=4, b_global=4, m=8, L=2, M=2, n_obj=0, N_train=10.0, jitter=1e-6)       # titsias = 0
+    with pytest.raises(svgp_vae_amd.SvgpError, match="titsias"):
+        _lib.call("svgp_gp_titsias_stats", C.byref(cfg), fake, None)
+    assert lib.svgp_spd_inverse_workspace_elems(800, 4) > lib.svgp_spd_inverse_workspace_elems(400, 4)
+
+
 def test_missing_extension_fails_loudly(tmp_path):
     with pytest.raises(svgp_vae_amd.SvgpError, match="no CPU fallback"):
         svgp_vae_amd.load_library(str(tmp_path / "nope.so"))

@@ -9,7 +9,6 @@ sprites_representation_network (VAE_utils.py:294-338, 375-391):
 Weights keep the TF layout (kh, kw, cin, cout).  Only descriptor construction and O(#weights) re-layouts
 (transpose / effective-weight sums) happen here; every per-pixel operation is a HIP kernel.
 """
-import ctypes as C
 import math
 
 import torch

@@ -7,7 +7,6 @@ Counterpart of the reference's graph construction + `sess.run([optim_step, ...])
 torch.distributed only; every kernel is in libsvgpvae_hip.so.
 """
 import ctypes as C
-import math
 
 import numpy as np
 import torch

@@ -176,6 +176,9 @@ def main():
     ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl",
                     help="N>1: who enqueues the three all-reduces -- the library on the compute stream (rccl) or "
                          "torch.distributed between per-phase graphs (torch); both are RCCL over xGMI")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="N=1 under torchrun: take the N>1 code path (process group, communicator bootstrap through "
+                         "broadcast_object_list, barriers, MAX all-reduce of the time) with world size 1")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1: run the data-parallel entry point with a 1-rank communicator (plumbing check)")
     ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
@@ -193,7 +196,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
 
@@ -217,17 +221,17 @@ def main():
 
     # ---- timed region: eps drawn on device every step (tf.random.normal, SVGPVAE_model.py:901)
     eng.bind(d_img, d_aux, None)
-    use_graph = world == 1 and not args.no_graph and not args.force_comm
+    use_graph = not multi and not args.no_graph and not args.force_comm
     if use_graph:
         eng.capture("step", adam=True)
         step = lambda: eng.replay("step")
     else:
         launch = None
-        if (world > 1 or args.force_comm) and args.exchange == "rccl":
+        if (multi or args.force_comm) and args.exchange == "rccl":
             # the three all-reduces are issued by the library on the compute stream (svgp_mnist_train_step_dp)
             try:
                 from svgp_vae_amd.engine import RcclComm
-                comm = RcclComm.from_process_group() if world > 1 else RcclComm(0, 1, RcclComm.unique_id())
+                comm = RcclComm.from_process_group() if multi else RcclComm(0, 1, RcclComm.unique_id())
                 eng.attach_comm(comm)
                 step = lambda: eng.run(adam=True)
                 launch = "one in-order stream: phases + in-library RCCL all-reduce x3"
@@ -246,17 +250,17 @@ def main():
         step()
     eng.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     eng.synchronize()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     el = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -265,7 +269,7 @@ def main():
     # per-stage HIP-event timings of this rank's launches (rank-local kernels, no collective inside): every rank runs
     # them so that nobody waits on rank 0, rank 0 reports
     stage_rows = time_stages(eng) if args.workload == "cfg2" else None
-    if world > 1:
+    if multi:
         dist.barrier()
 
     if rank == 0:
@@ -316,7 +320,7 @@ def main():
         C.CDLL(None).fflush(None)
         sys.stdout.flush()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -60,3 +60,22 @@ def test_dp_entry_equals_single_gpu_step(golden):
     assert torch.equal(a.theta, b_.theta)
     assert a.scalars() == b_.scalars()
     b_.comm.close()
+
+
+def test_bench_multi_gpu_code_path_at_world_size_one():
+    """`bench.py --force-dist` under torchrun with ONE rank: the N>1 code path end to end -- NCCL process group, the
+    communicator bootstrap through broadcast_object_list, barriers, the MAX all-reduce of the time, teardown -- for both
+    exchange forms.  (More than one rank needs more than one GPU; the driver's scaling bench is the first such run.)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for ex, port in (("rccl", 29531), ("torch", 29532)):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20",
+               "--warmup", "3", "--no-cpu-baseline", "--force-dist", "--exchange", ex]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 1 and line["value"] > 100 and "RCCL" in line["config"]["launch"]

@@ -66,8 +66,9 @@ def stage_table(eng):
     n_enc, n_dec = eng.pl.n_enc, eng.pl.n_vae - eng.pl.n_enc
     f8 = 8.0
     return [
-        ("encoder_fwd", "svgp_mnist_encoder_fwd", (cfg, th, img, ws, s), 2 * enc_mac * b, f8 * b * (784 + act_enc + 3 * Lc)),
-        ("kernel_matrix_fwd", "svgp_kernel_matrix_fwd", (cfg, th, aux, ws, s), (b * m + m * m) * (2 * 9 + 12), f8 * (b * m + m * m + b + b * 10)),
+        ("encoder_kernel_matrix_fwd", "svgp_mnist_encoder_kernel_matrix_fwd", (cfg, th, img, aux, ws, s),
+         2 * enc_mac * b + (b * m + m * m) * (2 * 9 + 12),
+         f8 * (b * (784 + act_enc + 3 * Lc) + b * m + m * m + b + b * 10)),
         ("gp_stats_fwd", "svgp_gp_stats_fwd", (cfg, ws, s), 3 * Lc * b * m * m + 2 * m ** 3, f8 * (b * m + 2 * b * Lc + Lc * m * (m + 1))),
         ("gp_factor_fwd", "svgp_gp_factor_fwd_defer_aji", (cfg, ws, s), Lc * (2 * (m ** 3 / 3 + 2 * m ** 3 / 3) + 4 * 2 * m ** 3) + 2 * b * m * m, f8 * Lc * 7 * m * m),
         ("gp_posterior_fwd", "svgp_gp_posterior_fwd", (cfg, eps, ws, st, s), 4 * Lc * b * m * m, f8 * (Lc * 2 * m * m + b * m + 8 * b * Lc)),

@@ -213,6 +213,10 @@ int svgp_mnist_grad_reduce_all(const svgp_mnist_cfg*, const double* aux, double*
  *   (A_hat + jI)^-1 and the log det term of KL:  svgp_gp_factor_fwd_defer_aji ... svgp_gp_stats_bwd_with_aji
  *   the channel sum Kbar:                        svgp_gp_factor_bwd_nofinal   ... svgp_gp_posterior_bwd_with_final */
 int svgp_gp_factor_fwd_defer_aji(const svgp_mnist_cfg*, double* ws, void* stream);
+/* svgp_mnist_encoder_fwd + svgp_kernel_matrix_fwd (independent of each other) in one launch: the kernel-matrix
+ * elements are computed by extra workgroups of the encoder launch */
+int svgp_mnist_encoder_kernel_matrix_fwd(const svgp_mnist_cfg*, const double* theta, const double* images,
+                                         const double* aux, double* ws, void* stream);
 int svgp_gp_stats_bwd_with_aji(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
@@ -230,7 +234,7 @@ int svgp_adam_tf1_finalize(const svgp_mnist_cfg*, int64_t n, double* theta, cons
 int svgp_elbo_finalize_noadam(const svgp_mnist_cfg*, double* ws, double* state, void* stream);
 
 /* ---- phases: the stages above grouped between the data-parallel exchange points -------------
- * phase 0: encoder_fwd, kernel_matrix_fwd, gp_stats_fwd            -> all-reduce ws[statA]
+ * phase 0: encoder_kernel_matrix_fwd, gp_stats_fwd                 -> all-reduce ws[statA]
  * phase 1: gp_factor_fwd_defer_aji, gp_posterior_fwd, decoder_fwd, decoder_bwd, gp_stats_bwd_with_aji
  *                                                                   -> all-reduce ws[statB]
  * phase 2: gp_factor_bwd_nofinal, gp_posterior_bwd_with_final, kernel_matrix_bwd_partials, encoder_bwd,

@@ -184,8 +184,7 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
 #define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
     switch (phase) {
     case 0:
-        RUN(svgp_kernel_matrix_fwd(c, theta, aux, ws, stream));
-        RUN(svgp_mnist_encoder_fwd(c, theta, images, ws, stream));
+        RUN(svgp_mnist_encoder_kernel_matrix_fwd(c, theta, images, aux, ws, stream));   // one launch for the two
         RUN(svgp_gp_stats_fwd(c, ws, stream));
         if (c->titsias) RUN(svgp_gp_titsias_stats(c, ws, stream));
         break;

@@ -116,7 +116,66 @@ __device__ __forceinline__ real elu_grad_from_out(real out) { return out > 0 ? r
 
 __device__ __forceinline__ real recip_no_nan(real x) { return x == real(0) ? real(0) : real(1) / x; }
 
+// mnistSVGP.kernel_matrix arguments (SVGPVAE_model.py:427-476), shared by gp_kernels.hip and the encoder launch that
+// carries the kernel-matrix build in its spare workgroups
+struct SvgpKernArgs {
+    int b, m, M, n_obj, normalize;
+    const real* aux;   // (b, 2+M)
+    const real* ip;    // (m, 2+M)
+    const real* ov;    // (n_obj, M) or unused
+    const real* ls;    // scalar
+    const real* amp;   // scalar
+};
+inline SvgpKernArgs svgp_make_kern_args(const svgp_mnist_cfg* c, const svgp_mnist_param_layout& pl, const double* theta,
+                                        const double* aux) {
+    SvgpKernArgs a;
+    a.b = c->b; a.m = c->m; a.M = c->M; a.n_obj = c->n_obj; a.normalize = c->normalize_obj;
+    a.aux = aux; a.ip = theta + pl.ip; a.ov = theta + pl.ov; a.ls = theta + pl.l_GP; a.amp = theta + pl.amplitude;
+    return a;
+}
+
 #ifdef __HIPCC__
+__device__ __forceinline__ const real* svgp_obj_row(const SvgpKernArgs& a, int n) {
+    return a.n_obj > 0 ? a.ov + (size_t)((long long)a.aux[(size_t)n * (2 + a.M)]) * a.M
+                       : a.aux + (size_t)n * (2 + a.M) + 2;
+}
+__device__ __forceinline__ real svgp_view_k(real d, real a2, real inv_l2) {
+    const real s = sin(real(0.5) * d);
+    return a2 * exp(real(-2) * s * s * inv_l2);
+}
+__device__ __forceinline__ real svgp_dotM(const real* x, const real* y, int M) {
+    real s = 0;
+    for (int k = 0; k < M; ++k) s += x[k] * y[k];
+    return s;
+}
+// element idx of [K_nm (b m) | K_mm (m m) | k_nn (b)]; idx beyond: nothing
+__device__ __forceinline__ void svgp_km_fwd_element(const SvgpKernArgs& a, long long idx, real* __restrict__ K,
+                                                    real* __restrict__ Kn, real* __restrict__ knn) {
+    const long long nbm = (long long)a.b * a.m, nmm = (long long)a.m * a.m;
+    const int st = 2 + a.M;
+    const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
+    if (idx < nbm) {
+        const int n = (int)(idx / a.m), j = (int)(idx % a.m);
+        const real* on = svgp_obj_row(a, n);
+        const real* oj = a.ip + (size_t)j * st + 2;
+        real D = svgp_dotM(on, oj, a.M);
+        if (a.normalize) D /= sqrt(svgp_dotM(on, on, a.M)) * sqrt(svgp_dotM(oj, oj, a.M));
+        Kn[idx] = svgp_view_k(a.aux[(size_t)n * st + 1] - a.ip[(size_t)j * st + 1], a2, inv_l2) * D;
+    } else if (idx < nbm + nmm) {
+        const long long o = idx - nbm;
+        const int i = (int)(o / a.m), j = (int)(o % a.m);
+        const real* oi = a.ip + (size_t)i * st + 2;
+        const real* oj = a.ip + (size_t)j * st + 2;
+        real D = svgp_dotM(oi, oj, a.M);
+        if (a.normalize) D /= sqrt(svgp_dotM(oi, oi, a.M)) * sqrt(svgp_dotM(oj, oj, a.M));
+        K[o] = svgp_view_k(a.ip[(size_t)i * st + 1] - a.ip[(size_t)j * st + 1], a2, inv_l2) * D;
+    } else if (idx < nbm + nmm + a.b) {
+        const int n = (int)(idx - nbm - nmm);
+        const real* on = svgp_obj_row(a, n);
+        knn[n] = a.normalize ? a2 : a2 * svgp_dotM(on, on, a.M);
+    }
+}
+
 // Object-table scatter of the kernel-matrix VJP, one workgroup of SVGP_BLOCK threads (dynamic LDS: 256 * M doubles at
 // `dbuf`).  Workgroups [0, nblk - 1): element o = blk * 256 + tid of the (n_obj, M) table gradient = sum of the d_on
 // rows whose id matches, in row order (duplicate ids sum deterministically): per chunk of 256 staged rows a bit mask per

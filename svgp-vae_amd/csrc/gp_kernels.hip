@@ -226,55 +226,14 @@ __device__ __forceinline__ real chol_inv(real* A, real* W, int ld, int m) {
 // =============================================================================================
 // kernel matrices  (SVGPVAE_model.py:427-476; TFP ExpSinSquared x Linear)
 // =============================================================================================
-struct KernArgs {
-    int b, m, M, n_obj, normalize;
-    const real* aux;   // (b, 2+M)
-    const real* ip;    // (m, 2+M)
-    const real* ov;    // (n_obj, M) or unused
-    const real* ls;    // scalar
-    const real* amp;   // scalar
-};
-
-__device__ __forceinline__ const real* obj_row(const KernArgs& a, int n) {
-    return a.n_obj > 0 ? a.ov + (size_t)((long long)a.aux[(size_t)n * (2 + a.M)]) * a.M
-                       : a.aux + (size_t)n * (2 + a.M) + 2;
-}
-__device__ __forceinline__ real view_k(real d, real a2, real inv_l2) {
-    const real s = sin(real(0.5) * d);
-    return a2 * exp(real(-2) * s * s * inv_l2);
-}
-__device__ __forceinline__ real dotM(const real* x, const real* y, int M) {
-    real s = 0;
-    for (int k = 0; k < M; ++k) s += x[k] * y[k];
-    return s;
-}
+typedef SvgpKernArgs KernArgs;
+__device__ __forceinline__ const real* obj_row(const KernArgs& a, int n) { return svgp_obj_row(a, n); }
+__device__ __forceinline__ real view_k(real d, real a2, real inv_l2) { return svgp_view_k(d, a2, inv_l2); }
+__device__ __forceinline__ real dotM(const real* x, const real* y, int M) { return svgp_dotM(x, y, M); }
 
 __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_fwd(KernArgs a, real* __restrict__ K,
                                                                   real* __restrict__ Kn, real* __restrict__ knn) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long nbm = (long long)a.b * a.m, nmm = (long long)a.m * a.m;
-    const int st = 2 + a.M;
-    const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
-    if (idx < nbm) {
-        const int n = (int)(idx / a.m), j = (int)(idx % a.m);
-        const real* on = obj_row(a, n);
-        const real* oj = a.ip + (size_t)j * st + 2;
-        real D = dotM(on, oj, a.M);
-        if (a.normalize) D /= sqrt(dotM(on, on, a.M)) * sqrt(dotM(oj, oj, a.M));
-        Kn[idx] = view_k(a.aux[(size_t)n * st + 1] - a.ip[(size_t)j * st + 1], a2, inv_l2) * D;
-    } else if (idx < nbm + nmm) {
-        const long long o = idx - nbm;
-        const int i = (int)(o / a.m), j = (int)(o % a.m);
-        const real* oi = a.ip + (size_t)i * st + 2;
-        const real* oj = a.ip + (size_t)j * st + 2;
-        real D = dotM(oi, oj, a.M);
-        if (a.normalize) D /= sqrt(dotM(oi, oi, a.M)) * sqrt(dotM(oj, oj, a.M));
-        K[o] = view_k(a.ip[(size_t)i * st + 1] - a.ip[(size_t)j * st + 1], a2, inv_l2) * D;
-    } else if (idx < nbm + nmm + a.b) {
-        const int n = (int)(idx - nbm - nmm);
-        const real* on = obj_row(a, n);
-        knn[n] = a.normalize ? a2 : a2 * dotM(on, on, a.M);
-    }
+    svgp_km_fwd_element(a, (long long)blockIdx.x * blockDim.x + threadIdx.x, K, Kn, knn);
 }
 
 // VJP, inducing side: one workgroup per inducing point j.
@@ -1081,10 +1040,7 @@ int set_dyn_lds(F kernel, size_t bytes) {
 
 KernArgs make_kern_args(const svgp_mnist_cfg* c, const svgp_mnist_param_layout& pl, const double* theta,
                         const double* aux) {
-    KernArgs a;
-    a.b = c->b; a.m = c->m; a.M = c->M; a.n_obj = c->n_obj; a.normalize = c->normalize_obj;
-    a.aux = aux; a.ip = theta + pl.ip; a.ov = theta + pl.ov; a.ls = theta + pl.l_GP; a.amp = theta + pl.amplitude;
-    return a;
+    return svgp_make_kern_args(c, pl, theta, aux);
 }
 
 }  // namespace

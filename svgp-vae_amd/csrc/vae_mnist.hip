@@ -477,8 +477,15 @@ __global__ __launch_bounds__(VAE_NT) void k_encoder_fwd(int b, int L, int clip, 
                                                             const real* __restrict__ images, real* __restrict__ a1g,
                                                             real* __restrict__ a2g, real* __restrict__ a3g,
                                                             real* __restrict__ mu, real* __restrict__ var_raw,
-                                                            real* __restrict__ var) {
+                                                            real* __restrict__ var, int n_img_blocks, SvgpKernArgs ka,
+                                                            real* __restrict__ Kmm, real* __restrict__ Knm,
+                                                            real* __restrict__ knn) {
     extern __shared__ __align__(16) real smem[];
+    if ((int)blockIdx.x >= n_img_blocks) {
+        // training phases: the kernel-matrix build (independent of the encoder) rides in extra workgroups of this launch
+        svgp_km_fwd_element(ka, (long long)(blockIdx.x - n_img_blocks) * blockDim.x + threadIdx.x, Kmm, Knm, knn);
+        return;
+    }
     const EncOff eo = enc_off(L);
     real* w = smem;                 // eo.n
     real* img = w + eo.n;           // 784
@@ -486,7 +493,7 @@ __global__ __launch_bounds__(VAE_NT) void k_encoder_fwd(int b, int L, int clip, 
     real* a2 = a1 + 1352;           // 288
     real* a3 = a2 + 288;            // 32
     lds_copy_in(w, th_enc, eo.n);
-    for (int n = blockIdx.x; n < b; n += gridDim.x) {
+    for (int n = blockIdx.x; n < b; n += n_img_blocks) {
         __syncthreads();
         lds_copy_in(img, images + (size_t)n * 784, 784);
         __syncthreads();
@@ -807,18 +814,39 @@ int set_dyn_lds(F kernel, size_t bytes) {
         if (rc_) return rc_;                                   \
     }
 
-extern "C" int svgp_mnist_encoder_fwd(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
-                                      void* stream) {
+static int encoder_fwd_impl(const svgp_mnist_cfg* c, const double* theta, const double* images, const double* aux,
+                            double* ws, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(theta && images && ws, SVGP_ERR_INVALID, "NULL device pointer");
     const size_t lds = (size_t)(pl.n_enc + 784 + 1352 + 288 + 32) * sizeof(real);
     int rc = set_dyn_lds(k_encoder_fwd, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_encoder_fwd, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
+    const int n_img = svgp_n_part(c);
+    SvgpKernArgs ka;
+    memset(&ka, 0, sizeof(ka));
+    int n_km = 0;
+    if (aux) {
+        ka = svgp_make_kern_args(c, pl, theta, aux);
+        const long long nel = (long long)c->b * c->m + (long long)c->m * c->m + c->b;
+        n_km = (int)((nel + VAE_NT - 1) / VAE_NT);
+    }
+    hipLaunchKernelGGL(k_encoder_fwd, dim3(n_img + n_km), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
                        c->clip_qs, theta, images, ws + wl.enc_a1, ws + wl.enc_a2, ws + wl.enc_a3, ws + wl.qnet_mu,
-                       ws + wl.qnet_var_raw, ws + wl.qnet_var);
+                       ws + wl.qnet_var_raw, ws + wl.qnet_var, n_img, ka, ws + wl.K, ws + wl.Kn, ws + wl.knn);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
+}
+
+extern "C" int svgp_mnist_encoder_fwd(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
+                                      void* stream) {
+    return encoder_fwd_impl(c, theta, images, nullptr, ws, stream);
+}
+
+// phase form: svgp_mnist_encoder_fwd + svgp_kernel_matrix_fwd in one launch (the two are independent)
+extern "C" int svgp_mnist_encoder_kernel_matrix_fwd(const svgp_mnist_cfg* c, const double* theta, const double* images,
+                                                    const double* aux, double* ws, void* stream) {
+    SVGP_REQUIRE(aux, SVGP_ERR_INVALID, "NULL device pointer");
+    return encoder_fwd_impl(c, theta, images, aux, ws, stream);
 }
 
 extern "C" int svgp_mnist_encoder_bwd(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,

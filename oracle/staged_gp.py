@@ -110,8 +110,9 @@ def gp_stats(Kn, w, a, bvec=None):
 
 
 # ------------------------------------------------------------------ m x m factor stage
-def gp_factor_fwd(K, S, v, jitter, c):
-    """svgp_gp_factor_fwd: shared Ki, ldK and per-channel Si, t, mu_hat, A_hat, G, Aji, u, KL."""
+def gp_factor_fwd(K, S, v, jitter, c, kl_form=0):
+    """svgp_gp_factor_fwd: shared Ki, ldK and per-channel Si, t, mu_hat, A_hat, G, Aji, u, KL.
+    kl_form 1 (moving-ball SVGP, SVGPVAE_model.py:135-137): KL's last summand is L tr(Ki A_l A_l) (stored as klq)."""
     m = K.shape[0]
     eye = torch.eye(m, dtype=DT)
     Kj = K + jitter * eye
@@ -126,8 +127,10 @@ def gp_factor_fwd(K, S, v, jitter, c):
     Aj = A + jitter * eye[None]
     Aji = torch.linalg.inv(Aj)
     ldA = 2 * torch.log(torch.diagonal(torch.linalg.cholesky(Aj), dim1=-2, dim2=-1)).sum(-1)
-    KL = 0.5 * (ldK - ldA - m + torch.einsum('ij,lji->l', Ki, A) + (mu * u).sum(1))
-    return dict(Ki=Ki, ldK=ldK, Si=Si, t=t, G=G, A=A, mu=mu, u=u, Aji=Aji, ldA=ldA, KL=KL)
+    klq = torch.einsum('ij,ljk,lki->l', Ki, A, A)
+    last = (mu * u).sum(1) if kl_form == 0 else S.shape[0] * klq
+    KL = 0.5 * (ldK - ldA - m + torch.einsum('ij,lji->l', Ki, A) + last)
+    return dict(Ki=Ki, ldK=ldK, Si=Si, t=t, G=G, A=A, mu=mu, u=u, Aji=Aji, ldA=ldA, KL=KL, klq=klq)
 
 
 # ------------------------------------------------------------------ per-sample stage
@@ -161,7 +164,7 @@ def gp_posterior_bwd_weights(y, s2, eps, ps, zbar, gT, c):
     return g_pv, g_pm, mvbar
 
 
-def gp_factor_bwd(K, S, v, f, A2, ud, td, gT, c, N_train, b_global):
+def gp_factor_bwd(K, S, v, f, A2, ud, td, gT, c, N_train, b_global, kl_form=0):
     """svgp_gp_factor_bwd: all m x m reverse algebra (identical on every rank once S, v, A2, ud, td
     are the global sums).  Returns K_bar (m,m), and per channel P = 2 Si, Q = Ssym - g3 Ki A Ki,
     v_bar, Ssym (for the per-sample stage)."""
@@ -171,9 +174,16 @@ def gp_factor_bwd(K, S, v, f, A2, ud, td, gT, c, N_train, b_global):
     Ki, Si, A, G, Aji, mu, u, t = (f[k] for k in ('Ki', 'Si', 'A', 'G', 'Aji', 'mu', 'u', 't'))
     KiSKi = Ki[None] @ S @ Ki[None]
     Abar = -0.5 * g3 * KiSKi + 0.5 * gK * (Ki[None] - Aji)
-    ubar = ud + 0.5 * gK * mu
-    mubar = 0.5 * gK * u + ubar @ Ki.T
-    Kibar = 0.5 * gK * A.sum(0) + torch.einsum('li,lj->ij', ubar, mu)
+    if kl_form == 0:
+        ubar = ud + 0.5 * gK * mu
+        mubar = 0.5 * gK * u + ubar @ Ki.T
+        Kibar = 0.5 * gK * A.sum(0) + torch.einsum('li,lj->ij', ubar, mu)
+    else:   # mu_hat enters only through mean_vector; the KL summand L tr(Ki A A) feeds Abar and Kibar
+        KiA = Ki[None] @ A
+        Abar = Abar + 0.5 * gK * L * (KiA + KiA.transpose(1, 2))
+        ubar = ud
+        mubar = ubar @ Ki.T
+        Kibar = 0.5 * gK * A.sum(0) + torch.einsum('li,lj->ij', ubar, mu) + 0.5 * gK * L * (A @ A).sum(0)
     Gbar = K[None] @ Abar
     Kbar = (Abar @ G.transpose(1, 2)).sum(0) + (Si @ Gbar).sum(0)
     Sibar = Gbar @ K[None] + A2
@@ -214,7 +224,7 @@ def gp_posterior_bwd_rows(Kn, knn, y, s2, ps, f, fb, g_pv, g_pm, mvbar, gT, c):
     return Knbar, knnbar, ybar, s2bar
 
 
-def gp_block_manual(K, Kn, knn, y, s2, eps, zbar, gT, jitter, N_train, b_global=None):
+def gp_block_manual(K, Kn, knn, y, s2, eps, zbar, gT, jitter, N_train, b_global=None, kl_form=0):
     """Whole block forward + hand-derived backward (single rank).  Returns forward dicts and
     (K_bar, Kn_bar, knn_bar, y_bar, s2_bar)."""
     b = Kn.shape[0]
@@ -222,11 +232,11 @@ def gp_block_manual(K, Kn, knn, y, s2, eps, zbar, gT, jitter, N_train, b_global=
     c = N_train / bg
     p = reciprocal_no_nan(s2)
     S, v, _ = gp_stats(Kn, p, p * y)
-    f = gp_factor_fwd(K, S, v, jitter, c)
+    f = gp_factor_fwd(K, S, v, jitter, c, kl_form)
     ps = gp_posterior_fwd(Kn, knn, y, s2, eps, f, c)
     g_pv, g_pm, mvbar = gp_posterior_bwd_weights(y, s2, eps, ps, zbar, gT, c)
     A2, ud, td = gp_stats(Kn, g_pv, mvbar, c * g_pm)
-    fb = gp_factor_bwd(K, S, v, f, A2, ud, td, gT, c, N_train, bg)
+    fb = gp_factor_bwd(K, S, v, f, A2, ud, td, gT, c, N_train, bg, kl_form)
     Knbar, knnbar, ybar, s2bar = gp_posterior_bwd_rows(Kn, knn, y, s2, ps, f, fb, g_pv, g_pm,
                                                        mvbar, gT, c)
     return f, ps, fb, (fb['Kbar'], Knbar, knnbar, ybar, s2bar)

@@ -181,8 +181,11 @@ class MnistSVGP:
 # --------------------------------------------------------------------------------------
 # Efficient O(L b m^2 + L m^3) formulation of the same Hensman block
 # --------------------------------------------------------------------------------------
-def gp_block_efficient(K, Kn, knn, y, s2, jitter, N_train, b_global=None, want_aux=False):
-    """All L channels at once.  K (m,m), Kn (b,m), knn (b), y/s2 (b,L) (s2 already clipped).
+def gp_block_efficient(K, Kn, knn, y, s2, jitter, N_train, b_global=None, want_aux=False, kl_form=0):
+    """kl_form 1 = the moving-ball SVGP's KL (SVGPVAE_model.py:135-137: A_hat in the place of mu_hat, summed over the
+    whole batch of videos = channels here): the last KL summand of channel l becomes L tr(Ki A_l A_l), which has the
+    same sum over channels as the reference's per-video scalar sum_l' tr(Ki A_l' A_l').
+    All L channels at once.  K (m,m), Kn (b,m), knn (b), y/s2 (b,L) (s2 already clipped).
     Returns p_m (b,L), p_v (b,L), L3 (L,), KL (L,).  Same arithmetic as the literal
     MnistSVGP methods (explicit inverses of K+jI, Sigma+jI; Cholesky only for log-dets)
     but without the (b,m,m) / (b,b) temporaries."""
@@ -211,7 +214,8 @@ def gp_block_efficient(K, Kn, knn, y, s2, jitter, N_train, b_global=None, want_a
     mv = Kn @ u.T                                         # (b,L)
     ldA = 2 * torch.sum(torch.log(torch.diagonal(
         torch.linalg.cholesky(A_hat + jitter * eye[None]), dim1=-2, dim2=-1)), dim=-1)
-    KL = 0.5 * (ldK - ldA - m + torch.einsum('ij,lji->l', Ki, A_hat) + torch.sum(mu_hat * u, dim=1))
+    last = torch.sum(mu_hat * u, dim=1) if kl_form == 0 else L * torch.einsum('ij,ljk,lki->l', Ki, A_hat, A_hat)
+    KL = 0.5 * (ldK - ldA - m + torch.einsum('ij,lji->l', Ki, A_hat) + last)
     Ktil = p * (knn - q)[:, None]
     tr = p * torch.einsum('ni,lij,nj->nl', W, A_hat, W)
     L3 = -0.5 * (Ktil.sum(0) + tr.sum(0) + torch.log(s2).sum(0) + b * LOG_2PI

@@ -61,10 +61,17 @@ typedef struct {
     int32_t b_cap;         /* row capacity the workspace LAYOUT is computed for (0 = b); keeps    */
                            /* offsets fixed across ragged batches / train-vs-test row counts      */
     int32_t clip_pv;       /* 1: clip the posterior variance p_v to [1e-4, 100] (SPRITES,          */
-                           /* SVGPVAE_model.py:891-892); the clip mask enters the reverse pass     */
+                           /* SVGPVAE_model.py:891-892); the clip mask enters the reverse pass.    */
+                           /* 2: moving ball (:693): only the sampling step uses clip(p_v, 1e-4,   */
+                           /* 1000); p_v itself and the cross-entropy keep the raw value           */
     int32_t n_pix;         /* pixels per image in the reconstruction loss (0 = 784 = MNIST)        */
     int32_t titsias;       /* 1: mainSVGP(titsias=True): inside-ELBO = sum_l L_2 (SVGPVAE_model.py:246-259,  */
                            /* 882-883) instead of the Hensman L_3 / KL pair                          */
+    int32_t kl_form;       /* 0: Hensman KL of mainSVGP (:270-279).  1: KL of the moving-ball SVGP (:128-137), which  */
+                           /* has A_hat where mu_hat is meant and reduces over the whole batch of videos (= the L      */
+                           /* channels here): KL_l = 1/2 [.. + L tr(K_mm^-1 A_l A_l)], same sum over l as the          */
+                           /* reference; the KL field is then [KL (L) | tr(K_mm^-1 A_l A_l) (L)]                       */
+    int32_t reserved_;     /* keeps the doubles 8-byte aligned; must be 0                                             */
     double  N_train;       /* mainSVGP.N_train                                                  */
     double  jitter;        /* mainSVGP.jitter                                                   */
     double  kappa_squared; /* GECO kappa^2                                                      */
@@ -379,6 +386,46 @@ int svgp_sqerr_bwd(long long tot, int geco, int b_global, int n_pix, const doubl
                    const double* xhat, double* dxhat, void* stream);
 /* tf.clip_by_value(grad, -thr, thr) (SPRITES_experiment.py:234-235) */
 int svgp_clip_by_value(long long tot, double thr, double* g, void* stream);
+
+/* ---- moving-ball experiment (ball.hip): BALL_experiment.py --elbo SVGPVAE_Hensman | SVGPVAE_Titsias ----------
+ * build_SVGPVAE_elbo_graph (SVGPVAE_model.py:638-715) runs its two SVGP objects (:17-171) on the shared GP stage
+ * entry points above with rows = the tmax frames, channels = the videos of the batch (all videos share the time
+ * stamps 1..tmax, :663-664), N_train = b = tmax, kl_form = 1, clip_pv = 2: one workspace per latent coordinate.
+ * svgp_se1d_kernel_matrix_fwd/bwd: tfk.ExponentiatedQuadratic(amplitude=None, length_scale) on scalar inputs (:60,
+ *   :80-86): K (m,m), Kn (T,m), knn (T) = 1 from times x (T), inducing points z (m), *ls; VJP -> d_z (m), d_ls (1).
+ * svgp_bias_act_fwd / svgp_act_bwd_bias: x = act(x + bias) in place (act 0 none, 1 tanh); dpre = dout act'(out) in
+ *   place and db = column sums, part = svgp_act_bwd_bias_scratch_elems(C) doubles - the layers of
+ *   build_MLP_inference_graph / build_MLP_decoder_graph (VAE_utils.py:9-96); the matmuls are svgp_dgemm_batched.
+ * svgp_ball_head_fwd/bwd: h (B*T,4) + bias -> qnet_mu, exp, clip [1e-6,1e3] (VAE_utils.py:50-55, SVGPVAE_model.py:
+ *   670-671) written in the (T,B) channel layout of the x / y workspaces; reverse through exp and the clip mask.
+ * svgp_ball_pack_z / unpack_zbar: latent samples (T,B) x 2 <-> (B*T,2).
+ * svgp_sigmoid_xent: per frame -sum_pix sigmoid_cross_entropy_with_logits (:697-700), pred = sigmoid, and
+ *   dlogits = scale (sigmoid - label); pred / dlogits may be NULL.
+ * svgp_ball_elbo_assemble: per-video [elbo, recon, KL_term, inside_elbo, ce_term, inside_recon, inside_kl] (7,B)
+ *   (:677-705), incl. the reference's batch-wide KL scalar; svgp_ball_finalize: their means over videos into the
+ *   state's output slots (BALL_experiment.py:116-123), Adam step counter and RNG counter advance.               */
+int svgp_se1d_kernel_matrix_fwd(int T, int m, const double* x, const double* z, const double* ls, double* K,
+                                double* Kn, double* knn, void* stream);
+int svgp_se1d_kernel_matrix_bwd(int T, int m, const double* x, const double* z, const double* ls, const double* Kbar,
+                                const double* Knbar, double* d_z, double* d_ls, void* stream);
+int svgp_bias_act_fwd(long long rows, int C, int act, const double* bias, double* x, void* stream);
+int svgp_act_bwd_bias_scratch_elems(int C);
+int svgp_act_bwd_bias(int rows, int C, int act, const double* out, double* dout, double* part, double* db,
+                      void* stream);
+int svgp_ball_head_fwd(int B, int T, int clip, const double* bias, const double* h, double* mu_x, double* var_raw_x,
+                       double* var_x, double* mu_y, double* var_raw_y, double* var_y, void* stream);
+int svgp_ball_head_bwd(int B, int T, int clip, const double* var_raw_x, const double* ybar_x, const double* s2bar_x,
+                       const double* var_raw_y, const double* ybar_y, const double* s2bar_y, double* dh, void* stream);
+int svgp_ball_pack_z(int B, int T, const double* zx, const double* zy, double* z, void* stream);
+int svgp_ball_unpack_zbar(int B, int T, const double* dz, double* zbar_x, double* zbar_y, void* stream);
+int svgp_sigmoid_xent(int rows, int P, double scale, const double* logits, const double* labels, double* pred,
+                      double* row_recon, double* dlogits, void* stream);
+int svgp_ball_elbo_assemble(const svgp_mnist_cfg* cfg_x, const double* ws_x, const double* ws_y,
+                            const double* row_recon, const double* state, double* out, void* stream);
+int svgp_ball_finalize(int B, int did_adam, long long rng_advance, const double* out, double* state, void* stream);
+int svgp_state_add(double* state, int slot, double v, void* stream);
+/* build_video_batch_graph's rasterisation (utils.py:172-187): vid[f][i][j] = (i - paths[f][0])^2 + (j - paths[f][1])^2 < r^2 */
+int svgp_ball_rasterize(long long frames, int px, int py, double r, const double* paths, double* vid, void* stream);
 
 /* ---- runtime helpers: HIP graphs and events without going through torch ---------------------*/
 int svgp_stream_create(void** stream_out);

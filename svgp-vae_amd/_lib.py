@@ -16,7 +16,7 @@ class SvgpError(RuntimeError):
 class MnistCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("b", "b_global", "m", "L", "M", "n_obj", "normalize_obj", "clip_qs",
                                          "geco", "train_ip", "train_gp", "train_ov", "b_cap", "clip_pv", "n_pix",
-                                         "titsias")] + \
+                                         "titsias", "kl_form", "reserved_")] + \
                [(n, C.c_double) for n in ("N_train", "jitter", "kappa_squared", "alpha", "rep_weight")]
 
 
@@ -126,6 +126,19 @@ SIGNATURES = {
     "svgp_sqerr_fwd": [C.c_longlong, C.c_int, _P, _P, _P, _P],
     "svgp_sqerr_bwd": [C.c_longlong, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "svgp_clip_by_value": [C.c_longlong, C.c_double, _P, _P],
+    "svgp_se1d_kernel_matrix_fwd": [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P],
+    "svgp_se1d_kernel_matrix_bwd": [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P],
+    "svgp_bias_act_fwd": [C.c_longlong, C.c_int, C.c_int, _P, _P, _P],
+    "svgp_act_bwd_bias": [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
+    "svgp_ball_head_fwd": [C.c_int, C.c_int, C.c_int] + [_P] * 9,
+    "svgp_ball_head_bwd": [C.c_int, C.c_int, C.c_int] + [_P] * 8,
+    "svgp_ball_pack_z": [C.c_int, C.c_int, _P, _P, _P, _P],
+    "svgp_ball_unpack_zbar": [C.c_int, C.c_int, _P, _P, _P, _P],
+    "svgp_sigmoid_xent": [C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P],
+    "svgp_ball_elbo_assemble": [_CFG, _P, _P, _P, _P, _P, _P],
+    "svgp_ball_finalize": [C.c_int, C.c_int, C.c_longlong, _P, _P, _P],
+    "svgp_state_add": [_P, C.c_int, C.c_double, _P],
+    "svgp_ball_rasterize": [C.c_longlong, C.c_int, C.c_int, C.c_double, _P, _P, _P],
     "svgp_stream_create": [C.POINTER(_P)],
     "svgp_stream_destroy": [_P],
     "svgp_stream_sync": [_P],
@@ -147,7 +160,8 @@ NON_STATUS = {"svgp_version": ([], C.c_int), "svgp_last_error": ([], C.c_char_p)
               "svgp_comm_unique_id_bytes": ([], C.c_int),
               "svgp_stream_feature_elems": ([C.c_void_p, C.c_int64], C.c_int64),
               "svgp_stream_stats_workspace_elems": ([C.c_int64, C.c_int, C.c_int], C.c_int64),
-              "svgp_spd_inverse_workspace_elems": ([C.c_int, C.c_int], C.c_size_t)}
+              "svgp_spd_inverse_workspace_elems": ([C.c_int, C.c_int], C.c_size_t),
+              "svgp_act_bwd_bias_scratch_elems": ([C.c_int], C.c_int)}
 
 _lib = None
 

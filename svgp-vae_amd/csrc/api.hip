@@ -28,6 +28,12 @@ int svgp_check_cfg(const svgp_mnist_cfg* c) {
     SVGP_REQUIRE(c->M <= 32, SVGP_ERR_UNSUPPORTED, "M=%d: object-vector dimension > 32 not supported", c->M);
     SVGP_REQUIRE(c->L <= 64, SVGP_ERR_UNSUPPORTED, "L=%d: more than 64 latent channels not supported", c->L);
     SVGP_REQUIRE(c->N_train > 0 && c->jitter >= 0, SVGP_ERR_INVALID, "bad N_train / jitter");
+    SVGP_REQUIRE(c->kl_form == 0 || c->kl_form == 1, SVGP_ERR_INVALID, "kl_form=%d (0 or 1)", c->kl_form);
+    SVGP_REQUIRE(c->clip_pv >= 0 && c->clip_pv <= 2, SVGP_ERR_INVALID, "clip_pv=%d (0, 1 or 2)", c->clip_pv);
+    SVGP_REQUIRE(!(c->kl_form && c->m > SVGP_M_MAX), SVGP_ERR_UNSUPPORTED,
+                 "kl_form=1 (moving-ball SVGP) is implemented for m <= %d inducing points (m=%d)", SVGP_M_MAX, c->m);
+    SVGP_REQUIRE(!(c->kl_form && c->b != c->b_global), SVGP_ERR_UNSUPPORTED,
+                 "kl_form=1 couples all channels of the batch; it is not sharded over ranks");
     return SVGP_OK;
 }
 
@@ -77,7 +83,7 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->Ki = take(m * m); o->ldK = take(1);
     o->Si = take(L * m * m); o->t = take(L * m); o->G = take(L * m * m); o->A = take(L * m * m);
     o->Aji = take(L * m * m); o->mu_hat = take(L * m); o->u = take(L * m); o->M2 = take(L * m * m);
-    o->KL = take(L); o->q = take(b);
+    o->KL = take(2 * L); o->q = take(b);   // [KL | kl_form 1: tr(Ki A_l A_l)]
     o->p_m = take(b * L); o->p_v = take(b * L); o->e = take(b * L); o->d = take(b * L);
     o->eps = take(b * L); o->z = take(b * L);
     o->dec_h0 = take(b * 128); o->dec_a1 = take(b * 512); o->dec_a2 = take(b * 1568); o->recon = take(b * 784);

@@ -51,6 +51,14 @@ __device__ __forceinline__ real svgp_seed_T(int flags, int L, const real* state)
     return (flags & 1) ? real(-1) : -state[SVGP_ST_BETA] / (real)L;
 }
 __device__ __forceinline__ real svgp_seed_3(int flags, real gT) { return (flags & 2) ? real(0) : gT; }
+// d loss / d p_v: cross-entropy part + sampling part z = p_m + eps sqrt(clip(p_v)).  clip_pv 1: p_v itself is clipped
+// to [1e-4, 100] (SVGPVAE_model.py:891-892), the mask kills both parts; 2: only the sample clips, to [1e-4, 1000] (:693)
+__device__ __forceinline__ real svgp_gpv(int clip_pv, real gT, real p, real zbar, real eps, real pv) {
+    const real ce = real(0.5) * gT * p, sm = zbar * eps / (real(2) * sqrt(pv));
+    if (clip_pv == 1) return (pv > 1e-4 && pv < 100.0) ? ce + sm : real(0);
+    if (clip_pv == 2) return (pv > 1e-4 && pv < 1000.0) ? ce + sm : ce;
+    return ce + sm;
+}
 __device__ __forceinline__ real svgp_seed_K(int flags, real gT, real b_over_N) {
     return (flags & 2) ? real(0) : -gT * b_over_N;
 }

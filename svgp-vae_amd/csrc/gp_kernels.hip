@@ -509,8 +509,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
             } else {
                 const real zb = a.zbar[e];
                 const real pv = a.p_v[e];
-                real gpv = real(0.5) * gT * p + zb * a.eps[e] / (real(2) * sqrt(pv));
-                if (a.clip_pv && !(pv > 1e-4 && pv < 100.0)) gpv = 0;      // tf.clip_by_value mask (:891-892)
+                real gpv = svgp_gpv(a.clip_pv, gT, p, zb, a.eps[e], pv);
                 const real gpm = gT * p * (a.p_m[e] - a.y[e]) + zb;
                 const real mvb = svgp_seed_3(a.geco, gT) * p * a.e[e];
                 w[rr] = gpv;
@@ -586,6 +585,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
 struct FactArgs {
     int b, m, L;
     int defer_aji;           // 1: (A_hat + jI)^-1 and its log det are finished by svgp_gp_stats_bwd's extra workgroups
+    int kl_form;             // cfg.kl_form
     real c, jitter;
     const real* K; const real* Ki; const real* ldK; const real* S; const real* v; const real* Kn;
     real* Si; real* t; real* G; real* A; real* Aji; real* mu; real* u; real* M2; real* KL; real* q;
@@ -665,6 +665,14 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
         muu = vz[threadIdx.x] * vx[threadIdx.x];
     }
     muu = block_sum(muu, red);
+    if (a.kl_form) {
+        // moving-ball KL (SVGPVAE_model.py:135-137): tr(Ki A A) = sum_ij (A Ki)_ij A_ji in the place of mu.u
+        real qq = 0;
+        for (int o = threadIdx.x; o < m * m; o += blockDim.x) qq += R2[(o / m) * ld + (o % m)] * R3[(o % m) * ld + (o / m)];
+        qq = block_sum(qq, red);
+        if (threadIdx.x == 0) a.KL[a.L + l] = qq;
+        muu = (real)a.L * qq;
+    }
     mat_gemm<false, false>(R0, R1, R2, ld, m, real(1));   // M2 = Ki A Ki   (K no longer needed)
     __syncthreads();
     mat_store(a.M2 + om, R0, ld, m);
@@ -759,13 +767,13 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_fwd(PostArgs a) {
         const real kq = a.knn[n] - a.q[n];
         const real p_m = a.c * pms, ee = y - mvs, dd = kq + ss + ee * ee;
         real p_v = kq + rs;
-        if (a.clip_pv) p_v = fmin(fmax(p_v, 1e-4), 100.0);
+        if (a.clip_pv == 1) p_v = fmin(fmax(p_v, 1e-4), 100.0);
         real ep;
         if (a.use_rng) ep = philox_normal((unsigned long long)a.state[SVGP_ST_RNG_CTR], (unsigned long long)e);
         else ep = a.eps_in[e];
         a.eps[e] = ep;
         a.p_m[e] = p_m; a.p_v[e] = p_v; a.e[e] = ee; a.d[e] = dd;
-        a.z[e] = p_m + ep * sqrt(p_v);
+        a.z[e] = p_m + ep * sqrt(a.clip_pv == 2 ? fmin(fmax(p_v, 1e-4), 1000.0) : p_v);
         const real ls2 = log(s2);
         l3 = real(-0.5) * (p * dd + ls2);
         const real dm = p_m - y;
@@ -783,7 +791,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_fwd(PostArgs a) {
 // m x m factor stage, reverse (per channel) + final K_bar assembly.
 // =============================================================================================
 struct FactBwdArgs {
-    int b_global, m, L, geco;
+    int b_global, m, L, geco, kl_form;
     real c, N_train;
     const real* state;
     const real* K; const real* Ki; const real* S; const real* v; const real* Si; const real* t; const real* G;
@@ -819,7 +827,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     mat_load(R1, ld, a.S + om, m);
     if (threadIdx.x < m) {
         muv[threadIdx.x] = a.mu[ov + threadIdx.x];
-        ubar[threadIdx.x] = a.ud[ov + threadIdx.x] + real(0.5) * gK * muv[threadIdx.x];
+        ubar[threadIdx.x] = a.ud[ov + threadIdx.x] + (a.kl_form ? real(0) : real(0.5) * gK * muv[threadIdx.x]);
         tv[threadIdx.x] = a.t[ov + threadIdx.x];
         vv[threadIdx.x] = a.v[ov + threadIdx.x];
     }
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     mat_vec(mubar, R0, ld, ubar, m, real(1));                       // Ki ubar
     mat_gemm<false, false>(R2, R1, R0, ld, m, real(1));             // T1 = S Ki
     __syncthreads();
-    if (threadIdx.x < m) mubar[threadIdx.x] += real(0.5) * gK * a.u[ov + threadIdx.x];
+    if (threadIdx.x < m && !a.kl_form) mubar[threadIdx.x] += real(0.5) * gK * a.u[ov + threadIdx.x];
     mat_gemm<false, false>(R3, R0, R2, ld, m, real(1));             // Ki S Ki
     __syncthreads();
     mat_load(R1, ld, a.Aji + om, m);
@@ -847,6 +855,23 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
                  a.A2[om + o];
     }
     __syncthreads();
+    if (a.kl_form) {
+        // moving-ball KL: the summand (L/2) tr(Ki A A) feeds Abar += (gK L / 2)(Ki A + A Ki), Kibar += (gK L / 2) A A.
+        // Here R1 = A, R3 = Abar; R0, R2 are free.
+        const real w = real(0.5) * gK * (real)a.L;
+        mat_load(R0, ld, a.Ki, m);
+        __syncthreads();
+        mat_gemm<false, false>(R2, R0, R1, ld, m, real(1));         // Ki A
+        __syncthreads();
+        for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
+            const int i = o / m, j = o % m;
+            R3[i * ld + j] += w * (R2[i * ld + j] + R2[j * ld + i]);
+        }
+        mat_gemm<false, false>(R0, R1, R1, ld, m, real(1));         // A A   (Ki no longer needed)
+        __syncthreads();
+        for (int o = threadIdx.x; o < m * m; o += blockDim.x) Kib[o] += w * R0[(o / m) * ld + (o % m)];
+        __syncthreads();
+    }
     mat_load(R0, ld, a.K, m);
     __syncthreads();
     mat_gemm<false, false>(R1, R0, R3, ld, m, real(1));             // Gbar = K Abar
@@ -1176,7 +1201,7 @@ static int factor_fwd_impl(const svgp_mnist_cfg* c, double* ws, int defer_aji, v
     SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
     if (c->m > SVGP_M_MAX) return svgp_big_factor_fwd(c, wl, ws, stream);
     FactArgs a;
-    a.defer_aji = defer_aji;
+    a.defer_aji = defer_aji; a.kl_form = c->kl_form;
     a.b = c->b; a.m = c->m; a.L = c->L; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;
     a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.ldK = ws + wl.ldK; a.S = ws + wl.S; a.v = ws + wl.v; a.Kn = ws + wl.Kn;
     a.Si = ws + wl.Si; a.t = ws + wl.t; a.G = ws + wl.G; a.A = ws + wl.A; a.Aji = ws + wl.Aji; a.mu = ws + wl.mu_hat;
@@ -1214,7 +1239,7 @@ extern "C" int svgp_gp_posterior_fwd(const svgp_mnist_cfg* c, const double* eps,
 
 static FactBwdArgs make_fb(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state) {
     FactBwdArgs a;
-    a.b_global = c->b_global; a.m = c->m; a.L = c->L; a.geco = SVGP_LOSS_FLAGS(c); a.c = c->N_train / (double)c->b_global;
+    a.b_global = c->b_global; a.m = c->m; a.L = c->L; a.geco = SVGP_LOSS_FLAGS(c); a.kl_form = c->kl_form; a.c = c->N_train / (double)c->b_global;
     a.N_train = c->N_train; a.state = state;
     a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.S = ws + wl.S; a.v = ws + wl.v; a.Si = ws + wl.Si; a.t = ws + wl.t;
     a.G = ws + wl.G; a.A = ws + wl.A; a.Aji = ws + wl.Aji; a.mu = ws + wl.mu_hat; a.u = ws + wl.u; a.M2 = ws + wl.M2;

@@ -30,8 +30,7 @@ __global__ void k_big_weights(int n_el, int L, int mode, int geco, int clip_pv, 
     } else {
         const real gT = gradKL(geco, L, state), zb = zbar[i];
         const real pv = p_v[i];
-        real gpv = real(0.5) * gT * p + zb * eps[i] / (real(2) * sqrt(pv));
-        if (clip_pv && !(pv > 1e-4 && pv < 100.0)) gpv = 0;
+        const real gpv = svgp_gpv(clip_pv, gT, p, zb, eps[i], pv);
         const real gpm = gT * p * (p_m[i] - y[i]) + zb;
         w[i] = gpv; bv[i] = gpm; a[i] = svgp_seed_3(geco, gT) * p * e[i];       // g_pv, g_pm, mvbar buffers
     }
@@ -132,11 +131,11 @@ __global__ __launch_bounds__(256) void k_big_post_final(PostFinArgs a) {
         const real y = a.y[i], s2 = a.s2[i], p = recip_no_nan(s2), kq = a.knn[n] - a.q[n];
         const real p_m = a.p_m[i], ee = y - a.e[i], dd = kq + a.d[i] + ee * ee;
         real p_v = kq + a.p_v[i];
-        if (a.clip_pv) p_v = fmin(fmax(p_v, 1e-4), 100.0);
+        if (a.clip_pv == 1) p_v = fmin(fmax(p_v, 1e-4), 100.0);
         const real ep = a.use_rng ? philox_normal_big((unsigned long long)a.state[SVGP_ST_RNG_CTR], (unsigned long long)i)
                                   : a.eps_in[i];
         a.eps[i] = ep; a.p_v[i] = p_v; a.e[i] = ee; a.d[i] = dd;
-        a.z[i] = p_m + ep * sqrt(p_v);
+        a.z[i] = p_m + ep * sqrt(a.clip_pv == 2 ? fmin(fmax(p_v, 1e-4), 1000.0) : p_v);
         const real ls2 = log(s2), dm = p_m - y;
         l3 = real(-0.5) * (p * dd + ls2);
         ce = real(-0.5) * (real(SVGP_LOG_2PI) + ls2 + (p_v + dm * dm) * p);

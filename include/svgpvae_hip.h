@@ -427,6 +427,34 @@ int svgp_state_add(double* state, int slot, double v, void* stream);
 /* build_video_batch_graph's rasterisation (utils.py:172-187): vid[f][i][j] = (i - paths[f][0])^2 + (j - paths[f][1])^2 < r^2 */
 int svgp_ball_rasterize(long long frames, int px, int py, double r, const double* paths, double* vid, void* stream);
 
+/* ---- Pearce baseline of the moving-ball experiment: BALL_experiment.py --elbo GPVAE_Pearce | VAE | NP ----------
+ * build_1d_gp (GPVAE_Pearce_model.py:8-86) with X_test = X: exact GP regression per (video, latent coordinate),
+ * one workgroup each, n <= 64 points:  A = K_SE(l) + diag(var), alpha = A^-1 y,
+ *   lhood = -1/2 (n log 2pi + y.alpha + log det A),  p_m = K alpha,  p_v = 1 - diag(K A^-1 K),
+ *   z = p_m + eps sqrt(p_v), per-frame -gauss_cross_entropy (utils.py:483-504) and their sums.
+ * All per-frame buffers are (T, B) (frame-major, the layout svgp_ball_head_fwd writes); times (T).
+ * idx (B, n) int32 != NULL: the points are times[idx[b][.]] (neural-process context sets, :121-155): forward gives
+ * lhood only, reverse seeds it with seed_lh_scale (-1: the context likelihood is subtracted, :186) and accumulates.
+ * tmask (B, T): weights of the cross-entropy terms (NP: 1 on target frames, :178-182).
+ * svgp_pearce_elbo_assemble: per-video [elbo, recon, prior_kl, lhood, ce, context lhood, 0] (7,B) (:157-236). */
+typedef struct {
+    int32_t B, T, n;
+    const double* times; const int32_t* idx; const double* tmask;
+    const double* ls_x; const double* ls_y;
+    double* y_x; double* y_y; double* s2_x; double* s2_y;
+    double* p_m_x; double* p_m_y; double* p_v_x; double* p_v_y; double* eps_x; double* eps_y; double* z_x; double* z_y;
+    double* zbar_x; double* zbar_y; double* ybar_x; double* ybar_y; double* s2bar_x; double* s2bar_y;
+    double* Ai; double* alpha; double* lh; double* ce; double* row_ce; double* dl_part;
+} svgp_pearce_bufs;
+int svgp_pearce_gp_fwd(const svgp_pearce_bufs*, const double* eps_x, const double* eps_y, const double* state,
+                       void* stream);
+int svgp_pearce_gp_bwd(const svgp_pearce_bufs*, double seed_lh_scale, int accumulate, const double* state,
+                       double* d_ls_x, double* d_ls_y, void* stream);
+int svgp_pearce_elbo_assemble(int B, int T, const double* lh, const double* ce, const double* con_lh,
+                              const double* row_recon, const double* row_ce, const double* tmask, const double* state,
+                              double* out, void* stream);
+int svgp_scale_rows(long long rows, int C, const double* w, double* x, void* stream);
+
 /* ---- runtime helpers: HIP graphs and events without going through torch ---------------------*/
 int svgp_stream_create(void** stream_out);
 int svgp_stream_destroy(void* stream);

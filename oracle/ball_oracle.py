@@ -165,3 +165,53 @@ def train_trajectory(params, vids, epsilons, *, beta, titsias, jitter, clipping_
                       {k: vs[k] for k in keys}, t, lr)
         elbos.append(float(out[0].mean()))
     return p, elbos
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Pearce baseline with trainable length scales and the neural-process ELBO (GPVAE_Pearce_model.py:89-236)
+# ---------------------------------------------------------------------------------------------------------
+def pearce_elbo_graphs(p, vid_batch, beta, type_elbo, l_x, l_y, lt, epsilon, ran_ind=None, con_tf=None):
+    """build_pearce_elbo_graphs for type_elbo in {GPVAE_Pearce, VAE, NP}.  l_x / l_y: the length scales of the two
+    full-data GPs (trainable under GP_joint, else equal to lt); lt: the constant model length scale the NP context
+    likelihoods use (:152-153).  ran_ind (batch,tmax) long permutations, con_tf = number of context frames (:121-137;
+    injected instead of drawn).  Returns (elbo, elbo_recon, elbo_prior_kl, full_p_mu, full_p_var, qnet_mu, qnet_var, pred)."""
+    from .pearce_vae_oracle import build_1d_gp
+    batch, tmax, px, py = vid_batch.shape
+    T = torch.arange(tmax, dtype=vid_batch.dtype)
+    batch_T = T.repeat(batch, 1)
+    qnet_mu, qnet_var = mlp_inference(p, vid_batch)
+    if type_elbo == "NP":
+        con_ind, tar_ind = ran_ind[:, :con_tf], ran_ind[:, con_tf:]
+        con_T = T[con_ind]
+        con_lm = torch.gather(qnet_mu, 1, con_ind[:, :, None].expand(-1, -1, 2))
+        con_lv = torch.gather(qnet_var, 1, con_ind[:, :, None].expand(-1, -1, 2))
+        con_lhood = build_1d_gp(con_T, con_lm[:, :, 0], con_lv[:, :, 0], batch_T, lt)[2] + \
+            build_1d_gp(con_T, con_lm[:, :, 1], con_lv[:, :, 1], batch_T, lt)[2]
+    p_mx, p_vx, lhx = build_1d_gp(batch_T, qnet_mu[:, :, 0], qnet_var[:, :, 0], batch_T, l_x)
+    p_my, p_vy, lhy = build_1d_gp(batch_T, qnet_mu[:, :, 1], qnet_var[:, :, 1], batch_T, l_y)
+    full_p_mu, full_p_var = torch.stack([p_mx, p_my], 2), torch.stack([p_vx, p_vy], 2)
+    full_lhood = lhx + lhy
+    sin_ce = gauss_cross_entropy(full_p_mu, full_p_var, qnet_mu, qnet_var).sum(2)          # (batch,tmax)
+    if epsilon is None:
+        epsilon = torch.randn(batch, tmax, 2, dtype=vid_batch.dtype)
+    logits = mlp_decoder(p, full_p_mu + epsilon * torch.sqrt(full_p_var), px, py)
+    sin_recon = -torch.nn.functional.binary_cross_entropy_with_logits(logits, vid_batch, reduction="none").sum((2, 3))
+    if type_elbo == "NP":
+        prior_kl = full_lhood - torch.gather(sin_ce, 1, tar_ind).sum(1) - con_lhood
+        recon = torch.gather(sin_recon, 1, tar_ind).sum(1)
+    else:
+        prior_kl = full_lhood - sin_ce.sum(1)
+        recon = sin_recon.sum(1)
+    return recon + beta * prior_kl, recon, prior_kl, full_p_mu, full_p_var, qnet_mu, qnet_var, torch.sigmoid(logits)
+
+
+PEARCE_PARAM_ORDER = ("encW1", "encB1", "encW2", "encB2", "decW1", "decB1", "decW2", "decB2", "l_x", "l_y")
+
+
+def pearce_loss_and_grads(params, vid_batch, epsilon, *, beta, type_elbo, lt, ran_ind=None, con_tf=None):
+    leaf = {k: v.detach().clone().requires_grad_(True) for k, v in params.items()}
+    out = pearce_elbo_graphs(leaf, vid_batch, beta, type_elbo, leaf["l_x"], leaf["l_y"], lt, epsilon, ran_ind, con_tf)
+    loss = -out[0].mean()
+    gs = torch.autograd.grad(loss, [leaf[k] for k in PEARCE_PARAM_ORDER], allow_unused=True)
+    grads = {k: (torch.zeros_like(leaf[k]) if g is None else g) for k, g in zip(PEARCE_PARAM_ORDER, gs)}
+    return tuple(o.detach() for o in out), loss.detach(), grads

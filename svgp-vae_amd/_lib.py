@@ -58,6 +58,15 @@ class ConvDesc(C.Structure):
                [("oy", C.c_int32 * 16), ("ox", C.c_int32 * 16), ("woff", C.c_int32 * 16)]
 
 
+class PearceBufs(C.Structure):
+    """svgp_pearce_bufs (include/svgpvae_hip.h)."""
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("n", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("times", "idx", "tmask", "ls_x", "ls_y", "y_x", "y_y", "s2_x", "s2_y", "p_m_x",
+                                          "p_m_y", "p_v_x", "p_v_y", "eps_x", "eps_y", "z_x", "z_y", "zbar_x", "zbar_y",
+                                          "ybar_x", "ybar_y", "s2bar_x", "s2bar_y", "Ai", "alpha", "lh", "ce", "row_ce",
+                                          "dl_part")]
+
+
 STATE = dict(C_MA=0, LAGRANGE=1, ALPHA=2, ADAM_T=3, LR=4, BETA=5, ELBO=6, RECON_LOSS=7, KL_TERM=8,
              INSIDE_ELBO=9, CE_TERM=10, INSIDE_RECON=11, INSIDE_KL=12, RNG_CTR=13)
 STATE_LEN = 16
@@ -138,6 +147,10 @@ SIGNATURES = {
     "svgp_ball_elbo_assemble": [_CFG, _P, _P, _P, _P, _P, _P],
     "svgp_ball_finalize": [C.c_int, C.c_int, C.c_longlong, _P, _P, _P],
     "svgp_state_add": [_P, C.c_int, C.c_double, _P],
+    "svgp_pearce_gp_fwd": [C.POINTER(PearceBufs), _P, _P, _P, _P],
+    "svgp_pearce_gp_bwd": [C.POINTER(PearceBufs), C.c_double, C.c_int, _P, _P, _P, _P],
+    "svgp_pearce_elbo_assemble": [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "svgp_scale_rows": [C.c_longlong, C.c_int, _P, _P, _P],
     "svgp_ball_rasterize": [C.c_longlong, C.c_int, C.c_int, C.c_double, _P, _P, _P],
     "svgp_stream_create": [C.POINTER(_P)],
     "svgp_stream_destroy": [_P],

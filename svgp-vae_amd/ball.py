@@ -138,26 +138,22 @@ def truncated_normal_mlp_params(px=32, py=32, hidden=500, seed=0):
     return out
 
 
-class BallStepEngine:
-    """Buffers + kernel schedule of one moving-ball training step (SVGPVAE_Hensman / SVGPVAE_Titsias)."""
+class _BallMlpEngine:
+    """Shared part of the two moving-ball engines: flat parameters, the MLP encoder / decoder
+    (build_MLP_inference_graph / build_MLP_decoder_graph, VAE_utils.py:9-96) forward and reverse, the Bernoulli
+    reconstruction term, gradient clip + TF1 Adam (BALL_experiment.py:116-136)."""
 
-    def __init__(self, svgp_x, svgp_y, *, batch=35, tmax=30, px=32, py=32, hidden=500, clip_qs=False, beta=1.0,
-                 lr=1e-3, clip_grad=False, device="cuda:0", params=None, seed=0):
+    def _init_common(self, extra_shapes, init, *, batch, tmax, px, py, hidden, beta, lr, clip_grad, device, seed):
         self.lib = _lib.load_library()
         if not torch.cuda.is_available():
-            raise _lib.SvgpError("BallStepEngine needs a HIP device; there is no CPU execution path")
-        if svgp_x.titsias != svgp_y.titsias or svgp_x.num_inducing_points != svgp_y.num_inducing_points:
-            raise ValueError("svgp_x and svgp_y must agree on the ELBO branch and on the number of inducing points")
+            raise _lib.SvgpError(f"{type(self).__name__} needs a HIP device; there is no CPU execution path")
         self.dev = torch.device(device)
         self.B, self.T, self.px, self.py, self.P, self.H = batch, tmax, px, py, px * py, hidden
-        self.m, self.titsias = svgp_x.num_inducing_points, svgp_x.titsias
-        self.svgp = (svgp_x, svgp_y)
-        self.clip_qs, self.clip_grad = bool(clip_qs), bool(clip_grad)
+        self.clip_grad = bool(clip_grad)
         self.stream = torch.cuda.Stream(device=self.dev)
         f64 = dict(dtype=_F64, device=self.dev)
-        # ---- flat parameter vector: MLPs, then per coordinate inducing points and length scale
         self.shapes = dict(mlp_param_shapes(px, py, hidden))
-        self.shapes.update(ip_x=(self.m,), l_x=(1,), ip_y=(self.m,), l_y=(1,))
+        self.shapes.update(extra_shapes)
         n_tot = sum(int(np.prod(s)) for s in self.shapes.values())
         self.theta, self.grad = torch.zeros(n_tot, **f64), torch.zeros(n_tot, **f64)
         self.adam_m, self.adam_v = torch.zeros(n_tot, **f64), torch.zeros(n_tot, **f64)
@@ -166,31 +162,16 @@ class BallStepEngine:
             n = int(np.prod(s))
             self.params[k], self.grads[k] = self.theta[off:off + n].view(s), self.grad[off:off + n].view(s)
             off += n
-        init = dict(truncated_normal_mlp_params(px, py, hidden, seed) if params is None else params)
-        for c, sv in zip("xy", self.svgp):
-            init.setdefault(f"ip_{c}", sv.inducing_index_points)
-            init.setdefault(f"l_{c}", sv.l_GP)
+        full = dict(truncated_normal_mlp_params(px, py, hidden, seed))
+        full.update(init)
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))     # zero-fills ran on torch's stream
         with torch.cuda.stream(self.stream):
             for k, s in self.shapes.items():
-                v = init[k]
+                v = full[k]
                 self.params[k].copy_(torch.as_tensor(np.asarray(v) if not torch.is_tensor(v) else v.detach().cpu(),
                                                      dtype=_F64).reshape(s))
-        for c, sv in zip("xy", self.svgp):
-            sv.inducing_index_points, sv.l_GP = self.params[f"ip_{c}"], self.params[f"l_{c}"]
-        # ---- one GP workspace per latent coordinate: rows = frames, channels = videos
-        self.cfg = MnistCfg(b=tmax, b_global=tmax, m=self.m, L=batch, M=1, n_obj=0, normalize_obj=0, clip_qs=0, geco=0,
-                            train_ip=1, train_gp=1, train_ov=0, b_cap=tmax, clip_pv=2, n_pix=self.P,
-                            titsias=int(self.titsias), kl_form=1, reserved_=0, N_train=float(tmax),
-                            jitter=svgp_x.jitter, kappa_squared=0.0, alpha=0.0, rep_weight=1.0)
-        if svgp_x.jitter != svgp_y.jitter:
-            raise ValueError("svgp_x and svgp_y must use the same jitter")
-        self.wl = WsLayout()
-        call("svgp_mnist_ws_layout_get", C.byref(self.cfg), C.byref(self.wl))
-        self.ws = [torch.zeros(self.wl.total, **f64) for _ in range(2)]
         self.state = torch.zeros(STATE_LEN, **f64)
         self.out = torch.zeros(len(OUT_ROWS), batch, **f64)
-        self.times = torch.arange(1, tmax + 1, **f64)                   # SVGPVAE_model.py:663
         self.part = torch.zeros(int(self.lib.svgp_act_bwd_bias_scratch_elems(max(self.P, hidden))), **f64)
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         st = torch.zeros(STATE_LEN, dtype=_F64)
@@ -199,11 +180,6 @@ class BallStepEngine:
             self.state.copy_(st)
         self.stream.synchronize()
         self.act = {}
-
-    # ------------------------------------------------------------------ helpers
-    def _v(self, c, name, shape):
-        off = getattr(self.wl, name)
-        return self.ws[c][off:off + int(np.prod(shape))].view(shape)
 
     def _gemm(self, ta, tb, M, N, K, A, lda, Bm, ldb, Cm, ldc):
         call("svgp_dgemm_batched", ta, tb, M, N, K, 1.0, A.data_ptr(), lda, 0, Bm.data_ptr(), ldb, 0, 0.0, Cm.data_ptr(),
@@ -223,11 +199,113 @@ class BallStepEngine:
             self.state.copy_(st)
         self.stream.synchronize()
 
+    # ---- pieces of a step; all run inside `with torch.cuda.stream(self.stream)`
+    def _encode(self, X):
+        """(R,P) frames -> h1 (R,H) post-tanh, h2 (R,4) pre-bias head input (VAE_utils.py:26-49)."""
+        R, P, H, p, s = X.shape[0], self.P, self.H, self.params, self.stream.cuda_stream
+        f64 = dict(dtype=_F64, device=self.dev)
+        h1 = torch.empty(R, H, **f64)
+        self._gemm(0, 0, R, H, P, X, P, p["encW1"], H, h1, H)
+        call("svgp_bias_act_fwd", R, H, 1, p["encB1"].data_ptr(), h1.data_ptr(), s)
+        h2 = torch.empty(R, 4, **f64)
+        self._gemm(0, 0, R, 4, H, h1, H, p["encW2"], 4, h2, 4)
+        return h1, h2
+
+    def _decode_recon(self, z, X, want_grad, row_weights=None):
+        """z (R,2) -> logits, pred = sigmoid, per-frame reconstruction term, dlogits (VAE_utils.py:73-94,
+        SVGPVAE_model.py:697-700).  row_weights (R): frames whose reconstruction term counts (NP targets)."""
+        R, P, H, p, s = z.shape[0], self.P, self.H, self.params, self.stream.cuda_stream
+        f64 = dict(dtype=_F64, device=self.dev)
+        g1 = torch.empty(R, H, **f64)
+        self._gemm(0, 0, R, H, 2, z, 2, p["decW1"], H, g1, H)
+        call("svgp_bias_act_fwd", R, H, 1, p["decB1"].data_ptr(), g1.data_ptr(), s)
+        logits = torch.empty(R, P, **f64)
+        self._gemm(0, 0, R, P, H, g1, H, p["decW2"], P, logits, P)
+        call("svgp_bias_act_fwd", R, P, 0, p["decB2"].data_ptr(), logits.data_ptr(), s)
+        pred, row_recon = torch.empty(R, P, **f64), torch.empty(R, **f64)
+        dlog = torch.empty(R, P, **f64) if want_grad else None
+        call("svgp_sigmoid_xent", R, P, 1.0 / self.B, logits.data_ptr(), X.data_ptr(), pred.data_ptr(),
+             row_recon.data_ptr(), None if dlog is None else dlog.data_ptr(), s)
+        if dlog is not None and row_weights is not None:
+            call("svgp_scale_rows", R, P, row_weights.data_ptr(), dlog.data_ptr(), s)
+        return g1, pred, row_recon, dlog
+
+    def _decoder_backward(self, z, g1, dlog):
+        """-> dz (R,2); writes the decoder gradients."""
+        R, P, H, p, g, s = z.shape[0], self.P, self.H, self.params, self.grads, self.stream.cuda_stream
+        f64 = dict(dtype=_F64, device=self.dev)
+        self._gemm(1, 0, H, P, R, g1, H, dlog, P, g["decW2"], P)
+        call("svgp_act_bwd_bias", R, P, 0, None, dlog.data_ptr(), self.part.data_ptr(), g["decB2"].data_ptr(), s)
+        dg1 = torch.empty(R, H, **f64)
+        self._gemm(0, 1, R, H, P, dlog, P, p["decW2"], P, dg1, H)
+        call("svgp_act_bwd_bias", R, H, 1, g1.data_ptr(), dg1.data_ptr(), self.part.data_ptr(), g["decB1"].data_ptr(), s)
+        self._gemm(1, 0, 2, H, R, z, 2, dg1, H, g["decW1"], H)
+        dz = torch.empty(R, 2, **f64)
+        self._gemm(0, 1, R, 2, H, dg1, H, p["decW1"], H, dz, 2)
+        return dz
+
+    def _encoder_backward(self, X, h1, dh2):
+        R, P, H, p, g, s = X.shape[0], self.P, self.H, self.params, self.grads, self.stream.cuda_stream
+        f64 = dict(dtype=_F64, device=self.dev)
+        self._gemm(1, 0, H, 4, R, h1, H, dh2, 4, g["encW2"], 4)
+        call("svgp_act_bwd_bias", R, 4, 0, None, dh2.data_ptr(), self.part.data_ptr(), g["encB2"].data_ptr(), s)
+        dh1 = torch.empty(R, H, **f64)
+        self._gemm(0, 1, R, H, 4, dh2, 4, p["encW2"], 4, dh1, H)
+        call("svgp_act_bwd_bias", R, H, 1, h1.data_ptr(), dh1.data_ptr(), self.part.data_ptr(), g["encB1"].data_ptr(), s)
+        self._gemm(1, 0, P, H, R, X, P, dh1, H, g["encW1"], H)
+
+    def _clip_and_adam(self, adam):
+        s = self.stream.cuda_stream
+        if self.clip_grad:                                              # BALL_experiment.py:125-127
+            call("svgp_clip_by_value", self.grad.numel(), 100000.0, self.grad.data_ptr(), s)
+        if adam:
+            call("svgp_adam_tf1_step", self.theta.numel(), self.theta.data_ptr(), self.grad.data_ptr(),
+                 self.adam_m.data_ptr(), self.adam_v.data_ptr(), self.state.data_ptr(), 0.9, 0.999, 1e-8, s)
+
+
+class BallStepEngine(_BallMlpEngine):
+    """Buffers + kernel schedule of one moving-ball training step (SVGPVAE_Hensman / SVGPVAE_Titsias)."""
+
+    def __init__(self, svgp_x, svgp_y, *, batch=35, tmax=30, px=32, py=32, hidden=500, clip_qs=False, beta=1.0,
+                 lr=1e-3, clip_grad=False, device="cuda:0", params=None, seed=0):
+        if svgp_x.titsias != svgp_y.titsias or svgp_x.num_inducing_points != svgp_y.num_inducing_points:
+            raise ValueError("svgp_x and svgp_y must agree on the ELBO branch and on the number of inducing points")
+        if svgp_x.jitter != svgp_y.jitter:
+            raise ValueError("svgp_x and svgp_y must use the same jitter")
+        self.m, self.titsias = svgp_x.num_inducing_points, svgp_x.titsias
+        self.svgp = (svgp_x, svgp_y)
+        self.clip_qs = bool(clip_qs)
+        # ---- one GP workspace per latent coordinate: rows = frames, channels = videos (validated before any allocation)
+        self.cfg = MnistCfg(b=tmax, b_global=tmax, m=self.m, L=batch, M=1, n_obj=0, normalize_obj=0, clip_qs=0, geco=0,
+                            train_ip=1, train_gp=1, train_ov=0, b_cap=tmax, clip_pv=2, n_pix=px * py,
+                            titsias=int(self.titsias), kl_form=1, reserved_=0, N_train=float(tmax),
+                            jitter=svgp_x.jitter, kappa_squared=0.0, alpha=0.0, rep_weight=1.0)
+        _lib.load_library()
+        self.wl = WsLayout()
+        call("svgp_mnist_ws_layout_get", C.byref(self.cfg), C.byref(self.wl))
+        init = dict(params or {})
+        for c, sv in zip("xy", self.svgp):
+            init.setdefault(f"ip_{c}", sv.inducing_index_points)
+            init.setdefault(f"l_{c}", sv.l_GP)
+        self._init_common(dict(ip_x=(self.m,), l_x=(1,), ip_y=(self.m,), l_y=(1,)), init, batch=batch, tmax=tmax, px=px,
+                          py=py, hidden=hidden, beta=beta, lr=lr, clip_grad=clip_grad, device=device, seed=seed)
+        for c, sv in zip("xy", self.svgp):
+            sv.inducing_index_points, sv.l_GP = self.params[f"ip_{c}"], self.params[f"l_{c}"]
+        f64 = dict(dtype=_F64, device=self.dev)
+        self.ws = [torch.zeros(self.wl.total, **f64) for _ in range(2)]
+        self.times = torch.arange(1, tmax + 1, **f64)                   # SVGPVAE_model.py:663
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        self.stream.synchronize()
+
+    def _v(self, c, name, shape):
+        off = getattr(self.wl, name)
+        return self.ws[c][off:off + int(np.prod(shape))].view(shape)
+
     # ------------------------------------------------------------------ one step
     def step(self, vid_batch, epsilon=None, adam=True, backward=True):
         """vid_batch (batch,tmax,px,py) float64 CUDA tensor; epsilon (batch,tmax,2) or None (on-device N(0,1)).
         Forward, reverse, optional gradient clip, TF1 Adam when `adam`, per-video ELBO terms and their means."""
-        B, T, P, H, m = self.B, self.T, self.P, self.H, self.m
+        B, T, P, m = self.B, self.T, self.P, self.m
         assert tuple(vid_batch.shape) == (B, T, self.px, self.py)
         p, g, s = self.params, self.grads, self.stream.cuda_stream
         cp, st = C.byref(self.cfg), self.state.data_ptr()
@@ -236,12 +314,7 @@ class BallStepEngine:
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.stream):
             X = vid_batch.to(self.dev, _F64).contiguous().view(R, P)
-            # ---------------- encoder MLP (VAE_utils.py:26-55)
-            h1 = torch.empty(R, H, **f64)
-            self._gemm(0, 0, R, H, P, X, P, p["encW1"], H, h1, H)
-            call("svgp_bias_act_fwd", R, H, 1, p["encB1"].data_ptr(), h1.data_ptr(), s)
-            h2 = torch.empty(R, 4, **f64)
-            self._gemm(0, 0, R, 4, H, h1, H, p["encW2"], 4, h2, 4)
+            h1, h2 = self._encode(X)
             fld = lambda n: [self._v(c, n, (T, B)) for c in range(2)]
             mu, var_raw, var = fld("qnet_mu"), fld("qnet_var_raw"), fld("qnet_var")
             call("svgp_ball_head_fwd", B, T, int(self.clip_qs), p["encB2"].data_ptr(), h2.data_ptr(), mu[0].data_ptr(),
@@ -269,31 +342,12 @@ class BallStepEngine:
             z = torch.empty(R, 2, **f64)
             call("svgp_ball_pack_z", B, T, self._v(0, "z", (1,)).data_ptr(), self._v(1, "z", (1,)).data_ptr(),
                  z.data_ptr(), s)
-            g1 = torch.empty(R, H, **f64)
-            self._gemm(0, 0, R, H, 2, z, 2, p["decW1"], H, g1, H)
-            call("svgp_bias_act_fwd", R, H, 1, p["decB1"].data_ptr(), g1.data_ptr(), s)
-            logits = torch.empty(R, P, **f64)
-            self._gemm(0, 0, R, P, H, g1, H, p["decW2"], P, logits, P)
-            call("svgp_bias_act_fwd", R, P, 0, p["decB2"].data_ptr(), logits.data_ptr(), s)
-            pred, row_recon = torch.empty(R, P, **f64), torch.empty(R, **f64)
-            dlog = torch.empty(R, P, **f64) if backward else None
-            call("svgp_sigmoid_xent", R, P, 1.0 / B, logits.data_ptr(), X.data_ptr(), pred.data_ptr(),
-                 row_recon.data_ptr(), None if dlog is None else dlog.data_ptr(), s)
+            g1, pred, row_recon, dlog = self._decode_recon(z, X, backward)
             self.act = dict(pred=pred.view(B, T, self.px, self.py), z=z.view(B, T, 2))
             if backward:
-                # ================ reverse: decoder
-                self._gemm(1, 0, H, P, R, g1, H, dlog, P, g["decW2"], P)
-                call("svgp_act_bwd_bias", R, P, 0, None, dlog.data_ptr(), self.part.data_ptr(), g["decB2"].data_ptr(), s)
-                dg1 = torch.empty(R, H, **f64)
-                self._gemm(0, 1, R, H, P, dlog, P, p["decW2"], P, dg1, H)
-                call("svgp_act_bwd_bias", R, H, 1, g1.data_ptr(), dg1.data_ptr(), self.part.data_ptr(),
-                     g["decB1"].data_ptr(), s)
-                self._gemm(1, 0, 2, H, R, z, 2, dg1, H, g["decW1"], H)
-                dz = torch.empty(R, 2, **f64)
-                self._gemm(0, 1, R, 2, H, dg1, H, p["decW1"], H, dz, 2)
+                dz = self._decoder_backward(z, g1, dlog)
                 call("svgp_ball_unpack_zbar", B, T, dz.data_ptr(), self._v(0, "zbar", (1,)).data_ptr(),
                      self._v(1, "zbar", (1,)).data_ptr(), s)
-                # ================ reverse: the two GPs
                 for c, cn in enumerate("xy"):
                     ws = self.ws[c].data_ptr()
                     call("svgp_gp_stats_bwd", cp, ws, st, s)
@@ -308,23 +362,12 @@ class BallStepEngine:
                         g[f"ip_{cn}"].zero_()
                     if self.svgp[c].fixed_gp_params:
                         g[f"l_{cn}"].zero_()
-                # ================ reverse: encoder
                 dh2 = torch.empty(R, 4, **f64)
                 yb, sb = fld("ybar"), fld("s2bar")
                 call("svgp_ball_head_bwd", B, T, int(self.clip_qs), var_raw[0].data_ptr(), yb[0].data_ptr(),
                      sb[0].data_ptr(), var_raw[1].data_ptr(), yb[1].data_ptr(), sb[1].data_ptr(), dh2.data_ptr(), s)
-                self._gemm(1, 0, H, 4, R, h1, H, dh2, 4, g["encW2"], 4)
-                call("svgp_act_bwd_bias", R, 4, 0, None, dh2.data_ptr(), self.part.data_ptr(), g["encB2"].data_ptr(), s)
-                dh1 = torch.empty(R, H, **f64)
-                self._gemm(0, 1, R, H, 4, dh2, 4, p["encW2"], 4, dh1, H)
-                call("svgp_act_bwd_bias", R, H, 1, h1.data_ptr(), dh1.data_ptr(), self.part.data_ptr(),
-                     g["encB1"].data_ptr(), s)
-                self._gemm(1, 0, P, H, R, X, P, dh1, H, g["encW1"], H)
-                if self.clip_grad:                                      # BALL_experiment.py:125-127
-                    call("svgp_clip_by_value", self.grad.numel(), 100000.0, self.grad.data_ptr(), s)
-                if adam:
-                    call("svgp_adam_tf1_step", self.theta.numel(), self.theta.data_ptr(), self.grad.data_ptr(),
-                         self.adam_m.data_ptr(), self.adam_v.data_ptr(), st, 0.9, 0.999, 1e-8, s)
+                self._encoder_backward(X, h1, dh2)
+                self._clip_and_adam(adam)
             call("svgp_ball_elbo_assemble", cp, self.ws[0].data_ptr(), self.ws[1].data_ptr(), row_recon.data_ptr(), st,
                  self.out.data_ptr(), s)
             call("svgp_ball_finalize", B, int(bool(adam and backward)), 1, self.out.data_ptr(), st, s)
@@ -351,6 +394,152 @@ class BallStepEngine:
         return (o["elbo"], o["recon"], o["KL_term"], o["inside_elbo"], o["ce_term"], full_p_mu, full_p_var, qnet_mu,
                 qnet_var, self.act["pred"], p["l_x"][0].clone(), p["l_y"][0].clone(), o["inside_elbo_recon"],
                 o["inside_elbo_kl"], p["ip_x"].clone(), p["ip_y"].clone(), cov[0], cov[1], self)
+
+
+class PearceStepEngine(_BallMlpEngine):
+    """BALL_experiment.py --elbo GPVAE_Pearce | VAE | NP: exact per-video GP regression on the recognition network's
+    outputs (build_pearce_elbo_graphs, GPVAE_Pearce_model.py:89-236)."""
+
+    def __init__(self, type_elbo="GPVAE_Pearce", lt=5.0, context_ratio=0.5, GP_joint=False, GP_init=2.0, *, batch=35,
+                 tmax=30, px=32, py=32, hidden=500, beta=1.0, lr=1e-3, clip_grad=False, device="cuda:0", params=None,
+                 seed=0):
+        if type_elbo not in ("GPVAE_Pearce", "VAE", "NP"):
+            raise ValueError(f"type_elbo {type_elbo!r}")
+        if tmax > 64:
+            raise _lib.SvgpError("the exact per-video GP keeps its tmax x tmax matrices in LDS (tmax <= 64)")
+        self.type_elbo, self.lt, self.context_ratio, self.GP_joint = type_elbo, float(lt), float(context_ratio), bool(GP_joint)
+        l0 = float(GP_init) if GP_joint else float(lt)                  # GPVAE_Pearce_model.py:35-41
+        init = dict(params or {})
+        init.setdefault("l_x", torch.tensor([l0], dtype=_F64))
+        init.setdefault("l_y", torch.tensor([l0], dtype=_F64))
+        self._init_common(dict(l_x=(1,), l_y=(1,)), init, batch=batch, tmax=tmax, px=px, py=py, hidden=hidden, beta=beta,
+                          lr=lr, clip_grad=clip_grad, device=device, seed=seed)
+        f64 = dict(dtype=_F64, device=self.dev)
+        B, T = batch, tmax
+        self.times = torch.arange(0, tmax, **f64)                       # GPVAE_Pearce_model.py:119-120 (0-based)
+        self.buf = {k: torch.zeros(2, T, B, **f64) for k in ("y", "var_raw", "s2", "p_m", "p_v", "eps", "z", "zbar", "ybar",
+                                                            "s2bar", "row_ce")}
+        self.Ai, self.alpha = torch.zeros(2, B, T, T, **f64), torch.zeros(2, B, T, **f64)
+        self.lh, self.ce, self.dl_part = torch.zeros(2, B, **f64), torch.zeros(2, B, **f64), torch.zeros(2, B, **f64)
+        # neural-process context sets
+        self.c_Ai, self.c_alpha = torch.zeros(2, B, T, T, **f64), torch.zeros(2, B, T, **f64)
+        self.c_lh, self.c_dl, self.c_ls = torch.zeros(2, B, **f64), torch.zeros(2, **f64), torch.full((2,), float(lt), **f64)
+        self.np_gen = np.random.RandomState(seed + 1)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        self.stream.synchronize()
+
+    def _bufs(self, n=None, idx=None, tmask=None, context=False):
+        from ._lib import PearceBufs
+        b, p = self.buf, self.params
+        q = PearceBufs(B=self.B, T=self.T, n=self.T if n is None else n)
+        q.times, q.idx, q.tmask = self.times.data_ptr(), None if idx is None else idx.data_ptr(), \
+            None if tmask is None else tmask.data_ptr()
+        # the context likelihoods use the constant model length scale (GPVAE_Pearce_model.py:152-153: lt=lt, GP_joint off)
+        q.ls_x, q.ls_y = (self.c_ls[0:].data_ptr(), self.c_ls[1:].data_ptr()) if context else \
+            (p["l_x"].data_ptr(), p["l_y"].data_ptr())
+        for k in ("y", "s2", "p_m", "p_v", "eps", "z", "zbar", "ybar", "s2bar"):
+            setattr(q, k + "_x", b[k][0].data_ptr()); setattr(q, k + "_y", b[k][1].data_ptr())
+        q.Ai, q.alpha, q.lh = (self.c_Ai if context else self.Ai).data_ptr(), (self.c_alpha if context else self.alpha).data_ptr(), \
+            (self.c_lh if context else self.lh).data_ptr()
+        q.ce, q.row_ce, q.dl_part = self.ce.data_ptr(), b["row_ce"].data_ptr(), self.dl_part.data_ptr()
+        return q
+
+    def draw_context_split(self):
+        """GPVAE_Pearce_model.py:121-137: number of context frames ~ round(N(ratio tmax, ratio (1-ratio) tmax)) clipped
+        to [2, tmax-2]; an independent random permutation of the frames per video."""
+        T, r = self.T, self.context_ratio
+        con_tf = int(np.round(min(max(self.np_gen.normal(r * T, math.sqrt(r * (1 - r) * T)), 2), T - 2)))
+        ran_ind = np.stack([self.np_gen.permutation(T) for _ in range(self.B)])
+        return ran_ind, con_tf
+
+    def step(self, vid_batch, epsilon=None, adam=True, backward=True, ran_ind=None, con_tf=None):
+        """One step.  NP: `ran_ind` (batch,tmax) permutations and `con_tf` are drawn when not given."""
+        B, T, P = self.B, self.T, self.P
+        assert tuple(vid_batch.shape) == (B, T, self.px, self.py)
+        p, g, s, b = self.params, self.grads, self.stream.cuda_stream, self.buf
+        st = self.state.data_ptr()
+        f64 = dict(dtype=_F64, device=self.dev)
+        R = B * T
+        is_np = self.type_elbo == "NP"
+        idx = tmask = None
+        if is_np:
+            if ran_ind is None:
+                ran_ind, con_tf = self.draw_context_split()
+            ran_ind = np.asarray(ran_ind)
+            idx = torch.as_tensor(ran_ind[:, :con_tf].astype(np.int32)).contiguous()
+            tm = np.zeros((B, T))
+            np.put_along_axis(tm, ran_ind[:, con_tf:], 1.0, axis=1)
+            tmask = torch.as_tensor(tm, dtype=_F64)
+        self.stream.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(self.stream):
+            if is_np:
+                idx, tmask = idx.to(self.dev), tmask.to(self.dev)
+            X = vid_batch.to(self.dev, _F64).contiguous().view(R, P)
+            h1, h2 = self._encode(X)
+            call("svgp_ball_head_fwd", B, T, 0, p["encB2"].data_ptr(), h2.data_ptr(), b["y"][0].data_ptr(),
+                 b["var_raw"][0].data_ptr(), b["s2"][0].data_ptr(), b["y"][1].data_ptr(), b["var_raw"][1].data_ptr(),
+                 b["s2"][1].data_ptr(), s)
+            ex = ey = None
+            if epsilon is not None:
+                e = epsilon.to(self.dev, _F64)
+                ex, ey = e[:, :, 0].t().contiguous(), e[:, :, 1].t().contiguous()
+            full = self._bufs(tmask=tmask)
+            call("svgp_pearce_gp_fwd", C.byref(full), None if ex is None else ex.data_ptr(),
+                 None if ey is None else ey.data_ptr(), st, s)
+            ctx = None
+            if is_np:
+                ctx = self._bufs(n=con_tf, idx=idx, context=True)
+                call("svgp_pearce_gp_fwd", C.byref(ctx), None, None, st, s)
+            z = torch.empty(R, 2, **f64)
+            call("svgp_ball_pack_z", B, T, b["z"][0].data_ptr(), b["z"][1].data_ptr(), z.data_ptr(), s)
+            g1, pred, row_recon, dlog = self._decode_recon(z, X, backward, None if tmask is None else tmask.view(-1))
+            self.act = dict(pred=pred.view(B, T, self.px, self.py), z=z.view(B, T, 2))
+            if backward:
+                dz = self._decoder_backward(z, g1, dlog)
+                call("svgp_ball_unpack_zbar", B, T, dz.data_ptr(), b["zbar"][0].data_ptr(), b["zbar"][1].data_ptr(), s)
+                call("svgp_pearce_gp_bwd", C.byref(full), 1.0, 0, st, g["l_x"].data_ptr(), g["l_y"].data_ptr(), s)
+                if is_np:
+                    call("svgp_pearce_gp_bwd", C.byref(ctx), -1.0, 1, st, self.c_dl[0:].data_ptr(), self.c_dl[1:].data_ptr(), s)
+                if not self.GP_joint:
+                    g["l_x"].zero_(); g["l_y"].zero_()
+                dh2 = torch.empty(R, 4, **f64)
+                call("svgp_ball_head_bwd", B, T, 0, b["var_raw"][0].data_ptr(), b["ybar"][0].data_ptr(),
+                     b["s2bar"][0].data_ptr(), b["var_raw"][1].data_ptr(), b["ybar"][1].data_ptr(),
+                     b["s2bar"][1].data_ptr(), dh2.data_ptr(), s)
+                self._encoder_backward(X, h1, dh2)
+                self._clip_and_adam(adam)
+            call("svgp_pearce_elbo_assemble", B, T, self.lh.data_ptr(), self.ce.data_ptr(),
+                 self.c_lh.data_ptr() if is_np else None, row_recon.data_ptr(), b["row_ce"].data_ptr(),
+                 None if tmask is None else tmask.data_ptr(), st, self.out.data_ptr(), s)
+            call("svgp_ball_finalize", B, int(bool(adam and backward)), 1, self.out.data_ptr(), st, s)
+            self._keep = (idx, tmask, ex, ey)
+        return self
+
+    train_step = step
+
+    def outputs(self):
+        """build_pearce_elbo_graphs' return tuple (elbo, elbo_recon, elbo_prior_kl, full_p_mu, full_p_var, qnet_mu, qnet_var,
+        pred_vid, l_GP_x, l_GP_y, engine)."""
+        self.stream.synchronize()
+        b = self.buf
+        st2 = lambda k: torch.stack([b[k][0].t(), b[k][1].t()], 2).contiguous()
+        return (self.out[0].clone(), self.out[1].clone(), self.out[2].clone(), st2("p_m"), st2("p_v"), st2("y"), st2("s2"),
+                self.act["pred"], self.params["l_x"][0].clone(), self.params["l_y"][0].clone(), self)
+
+
+def build_pearce_elbo_graphs(vid_batch, beta, type_elbo="GPVAE_Pearce", lt=5, context_ratio=0.5, GP_joint=False,
+                             GP_init=2.0, epsilon=None, params=None, engine=None, ran_ind=None, con_tf=None):
+    """GPVAE_Pearce_model.py:89-236: one forward pass on the HIP library; returns the reference's 11-tuple (last slot =
+    the engine instead of globals())."""
+    B, T, px, py = vid_batch.shape
+    eng = engine
+    if eng is None:
+        hidden = 500 if params is None else int(np.asarray(params["encB1"]).size)
+        eng = PearceStepEngine(type_elbo, lt, context_ratio, GP_joint, GP_init, batch=B, tmax=T, px=px, py=py,
+                               hidden=hidden, beta=float(beta), params=params)
+    eng.set_scalars(beta=float(beta))
+    eng.step(vid_batch, epsilon, adam=False, backward=False, ran_ind=ran_ind, con_tf=con_tf)
+    return eng.outputs()
 
 
 def build_SVGPVAE_elbo_graph(vid_batch, beta, svgp_x, svgp_y, clipping_qs=False, epsilon=None, params=None, engine=None):

@@ -235,6 +235,268 @@ __global__ __launch_bounds__(64) void k_ball_finalize(int B, int did_adam, long 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Exact per-video GP regression of the Pearce baseline (build_1d_gp, GPVAE_Pearce_model.py:8-86), X_test = X.
+// One workgroup per (video, latent coordinate); T <= 64 frames, all T x T matrices in LDS.
+//   A = K_SE(l) + diag(var);  alpha = A^-1 y;  lhood = -1/2 (n log 2pi + y.alpha + log det A)
+//   p_m = K alpha;  p_v = 1 - diag(K A^-1 K);  z = p_m + eps sqrt(p_v)        (:201-202 of the ELBO builder)
+// idx != NULL (neural-process context sets, :121-155): the n points are times[idx[b][0..n)] and only lhood is produced.
+// Values of y / var / p_m / p_v / eps / z / zbar are in the (T, B) channel layout of the head kernels.
+// ---------------------------------------------------------------------------------------------------------
+struct PearceArgs {
+    int B, T, n, use_rng, geco_unused;
+    const real* times; const int* idx;          // idx (B, n) or NULL
+    const real* ls[2];
+    const real* y[2]; const real* s2[2];
+    const real* eps_in[2]; const real* state;
+    real* Ai;                                    // (2, B, n, n)
+    real* alpha;                                 // (2, B, n)
+    real* p_m[2]; real* p_v[2]; real* eps[2]; real* z[2];
+    real* lh;                                    // (2, B)
+    real* ce;                                    // (2, B)   sum_t -gauss_cross_entropy
+    real* row_ce;                                // (2, T, B) the summands (neural-process target sums)
+    const real* tmask;                           // (B, T) 1 = target frame, or NULL (reverse: weights of the CE terms)
+    // reverse
+    const real* zbar[2];
+    real* ybar[2]; real* s2bar[2];
+    real* dl_part;                               // (2, B) length-scale gradient partials
+    real seed_lh_scale;                          // lhood enters the loss with seed gT * seed_lh_scale (NP context: -1)
+    int accumulate;                              // reverse: add into ybar / s2bar (context sets) instead of writing
+};
+
+// in-place Gauss-Jordan inverse of an SPD n x n LDS matrix (leading dimension ld), no pivoting; returns log det
+__device__ real lds_spd_inverse(real* A, int ld, int n, real* colbuf, real* red) {
+    real logdet = 0;
+    for (int k = 0; k < n; ++k) {
+        __syncthreads();
+        const real piv = A[k * ld + k];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) colbuf[i] = A[i * ld + k];
+        __syncthreads();
+        logdet += log(piv);
+        const real ip = real(1) / piv;
+        for (int o = threadIdx.x; o < n * n; o += blockDim.x) {
+            const int i = o / n, j = o % n;
+            if (i == k) continue;
+            const real f = colbuf[i] * ip;
+            A[i * ld + j] = (j == k) ? -f : A[i * ld + j] - f * A[k * ld + j];
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += blockDim.x) A[k * ld + j] = (j == k) ? ip : A[k * ld + j] * ip;
+    }
+    __syncthreads();
+    (void)red;
+    return logdet;
+}
+
+__device__ __forceinline__ real pearce_time(const PearceArgs& a, int b, int i) {
+    return a.idx ? a.times[a.idx[(size_t)b * a.n + i]] : a.times[i];
+}
+__device__ __forceinline__ size_t pearce_elem(const PearceArgs& a, int b, int i) {
+    const int t = a.idx ? a.idx[(size_t)b * a.n + i] : i;
+    return (size_t)t * a.B + b;
+}
+
+__global__ __launch_bounds__(256) void k_pearce_fwd(PearceArgs a) {
+    extern __shared__ __align__(16) real smem[];
+    const int b = blockIdx.x, c = blockIdx.y, n = a.n, ld = n + 1;
+    real* K = smem;               // n x ld
+    real* A = K + n * ld;         // -> Ai
+    real* W = A + n * ld;         // Ai K
+    real* yv = W + n * ld;        // n
+    real* al = yv + n;            // n
+    real* tv = al + n;            // n
+    real* col = tv + n;           // n
+    real* red = col + n;          // 16
+    const real l = *a.ls[c], il2 = real(-0.5) / (l * l);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { tv[i] = pearce_time(a, b, i); yv[i] = a.y[c][pearce_elem(a, b, i)]; }
+    __syncthreads();
+    for (int o = threadIdx.x; o < n * n; o += blockDim.x) {
+        const int i = o / n, j = o % n;
+        const real d = tv[i] - tv[j], k = exp(d * d * il2);
+        K[i * ld + j] = k;
+        A[i * ld + j] = k + (i == j ? a.s2[c][pearce_elem(a, b, i)] : real(0));
+    }
+    const real logdet = lds_spd_inverse(A, ld, n, col, red);
+    const size_t om = ((size_t)c * a.B + b) * n * n, ov = ((size_t)c * a.B + b) * n;
+    for (int o = threadIdx.x; o < n * n; o += blockDim.x) a.Ai[om + o] = A[(o / n) * ld + (o % n)];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        real s = 0;
+        for (int j = 0; j < n; ++j) s += A[i * ld + j] * yv[j];
+        al[i] = s; a.alpha[ov + i] = s;
+    }
+    __syncthreads();
+    real quad = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) quad += yv[i] * al[i];
+    quad = block_sum(quad, red);
+    if (threadIdx.x == 0) a.lh[c * a.B + b] = real(-0.5) * ((real)n * real(SVGP_LOG_2PI) + quad + logdet);
+    if (a.idx) return;                                            // context likelihood only
+    for (int o = threadIdx.x; o < n * n; o += blockDim.x) {       // W = Ai K
+        const int i = o / n, j = o % n;
+        real s = 0;
+        for (int k = 0; k < n; ++k) s += A[i * ld + k] * K[k * ld + j];
+        W[i * ld + j] = s;
+    }
+    __syncthreads();
+    real ce = 0;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) {
+        real pm = 0, kak = 0;
+        for (int i = 0; i < n; ++i) { pm += K[t * ld + i] * al[i]; kak += K[t * ld + i] * W[i * ld + t]; }
+        const real pv = real(1) - kak;
+        const size_t e = (size_t)t * a.B + b;
+        const real ep = a.use_rng ? svgp_philox_normal((unsigned long long)a.state[SVGP_ST_RNG_CTR],
+                                                       (unsigned long long)(e * 2 + c))
+                                  : a.eps_in[c][e];
+        a.p_m[c][e] = pm; a.p_v[c][e] = pv; a.eps[c][e] = ep; a.z[c][e] = pm + ep * sqrt(pv);
+        const real s2 = a.s2[c][e], p = recip_no_nan(s2), dm = pm - yv[t];
+        const real cev = real(0.5) * (real(SVGP_LOG_2PI) + log(s2) + (pv + dm * dm) * p);
+        a.row_ce[((size_t)c * a.T + t) * a.B + b] = cev;
+        ce += cev;
+    }
+    ce = block_sum(ce, red);
+    if (threadIdx.x == 0) a.ce[c * a.B + b] = ce;
+}
+
+// reverse of k_pearce_fwd.  gT = d loss / d (prior-KL term) = -beta / B.
+__global__ __launch_bounds__(256) void k_pearce_bwd(PearceArgs a) {
+    extern __shared__ __align__(16) real smem[];
+    const int b = blockIdx.x, c = blockIdx.y, n = a.n, ld = n + 1;
+    real* K = smem;
+    real* Ai = K + n * ld;
+    real* M = Ai + n * ld;        // K diag(g_pv) K, then Ai M Ai
+    real* W = M + n * ld;         // Ai K, then Ai M
+    real* al = W + n * ld;        // n
+    real* gpm = al + n;
+    real* gpv = gpm + n;
+    real* u = gpv + n;            // K g_pm, then w = Ai K g_pm
+    real* tv = u + n;
+    real* red = tv + n;           // 16
+    const real gT = svgp_seed_T(0, a.B, a.state), gl = gT * a.seed_lh_scale;
+    const real l = *a.ls[c], il2 = real(-0.5) / (l * l);
+    const size_t om = ((size_t)c * a.B + b) * n * n, ov = ((size_t)c * a.B + b) * n;
+    const bool full = a.idx == nullptr;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        tv[i] = pearce_time(a, b, i); al[i] = a.alpha[ov + i];
+        real g_m = 0, g_v = 0;
+        if (full) {
+            const size_t e = (size_t)i * a.B + b;
+            const real s2 = a.s2[c][e], p = recip_no_nan(s2), zb = a.zbar[c][e], pv = a.p_v[c][e];
+            const real gC = gT * (a.tmask ? a.tmask[(size_t)b * a.T + i] : real(1));   // seed of this frame's CE term
+            g_v = real(0.5) * gC * p + zb * a.eps[c][e] / (real(2) * sqrt(pv));
+            g_m = gC * p * (a.p_m[c][e] - a.y[c][e]) + zb;
+        }
+        gpm[i] = g_m; gpv[i] = g_v;
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < n * n; o += blockDim.x) {
+        const int i = o / n, j = o % n;
+        const real d = tv[i] - tv[j];
+        K[i * ld + j] = exp(d * d * il2);
+        Ai[i * ld + j] = a.Ai[om + o];
+    }
+    __syncthreads();
+    if (full) {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            real s = 0;
+            for (int j = 0; j < n; ++j) s += K[i * ld + j] * gpm[j];
+            u[i] = s;
+        }
+        for (int o = threadIdx.x; o < n * n; o += blockDim.x) {
+            const int i = o / n, j = o % n;
+            real s = 0, w = 0;
+            for (int t = 0; t < n; ++t) { s += K[i * ld + t] * gpv[t] * K[t * ld + j]; w += Ai[i * ld + t] * K[t * ld + j]; }
+            M[i * ld + j] = s; W[i * ld + j] = w;
+        }
+        __syncthreads();
+        // K-bar (direct part) needs Ai K: fold it into the length-scale sum now, then reuse W for Ai M
+        // dl += sum_ij (g_pm_i alpha_j - 2 (Ai K)_ij g_pv_j) K_ij d_ij^2 / l^3   (the Abar part follows below)
+    }
+    real dl = 0;
+    const real il3 = real(1) / (l * l * l);
+    if (full) {
+        for (int o = threadIdx.x; o < n * n; o += blockDim.x) {
+            const int i = o / n, j = o % n;
+            const real d = tv[i] - tv[j];
+            dl += (gpm[i] * al[j] - real(2) * W[i * ld + j] * gpv[j]) * K[i * ld + j] * d * d * il3;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {       // w = Ai u
+            real s = 0;
+            for (int j = 0; j < n; ++j) s += Ai[i * ld + j] * u[j];
+            gpm[i] = s;                                            // g_pm no longer needed: holds w
+        }
+        for (int o = threadIdx.x; o < n * n; o += blockDim.x) {   // W = Ai M
+            const int i = o / n, j = o % n;
+            real s = 0;
+            for (int t = 0; t < n; ++t) s += Ai[i * ld + t] * M[t * ld + j];
+            W[i * ld + j] = s;
+        }
+        __syncthreads();
+        for (int o = threadIdx.x; o < n * n; o += blockDim.x) {   // M = Ai M Ai
+            const int i = o / n, j = o % n;
+            real s = 0;
+            for (int t = 0; t < n; ++t) s += W[i * ld + t] * Ai[t * ld + j];
+            M[i * ld + j] = s;
+        }
+        __syncthreads();
+    }
+    // Abar_ij = gl/2 (alpha_i alpha_j - Ai_ij) - w_i alpha_j + (Ai M Ai)_ij ;  A = K + diag(var)
+    for (int o = threadIdx.x; o < n * n; o += blockDim.x) {
+        const int i = o / n, j = o % n;
+        real ab = real(0.5) * gl * (al[i] * al[j] - Ai[i * ld + j]);
+        if (full) ab += M[i * ld + j] - gpm[i] * al[j];
+        const real d = tv[i] - tv[j];
+        dl += ab * K[i * ld + j] * d * d * il3;
+        if (i == j) {
+            const size_t e = pearce_elem(a, b, i);
+            real sb = ab, yb = -gl * al[i];
+            if (full) {
+                const real s2 = a.s2[c][e], p = recip_no_nan(s2), dm = a.p_m[c][e] - a.y[c][e];
+                const real gC = gT * (a.tmask ? a.tmask[(size_t)b * a.T + i] : real(1));
+                sb += real(0.5) * gC * (p - (a.p_v[c][e] + dm * dm) * p * p);
+                yb += gpm[i] - gC * p * dm;
+            }
+            if (a.accumulate) { a.s2bar[c][e] += sb; a.ybar[c][e] += yb; }
+            else { a.s2bar[c][e] = sb; a.ybar[c][e] = yb; }
+        }
+    }
+    dl = block_sum(dl, red);
+    if (threadIdx.x == 0) a.dl_part[c * a.B + b] = dl;
+}
+
+// d_ls[c] (+)= sum_b part[c][b]
+__global__ void k_pearce_dl(int B, int accumulate, const real* __restrict__ part, real* dl_x, real* dl_y) {
+    if (threadIdx.x >= 2) return;
+    real s = 0;
+    for (int b = 0; b < B; ++b) s += part[threadIdx.x * B + b];
+    real* o = threadIdx.x ? dl_y : dl_x;
+    *o = accumulate ? *o + s : s;
+}
+
+// per-video [elbo, recon, prior_kl, lhood, ce, context lhood, 0] (GPVAE_Pearce_model.py:157-236)
+__global__ void k_pearce_assemble(int B, int T, const real* __restrict__ lh, const real* __restrict__ ce,
+                                  const real* __restrict__ con_lh, const real* __restrict__ row_recon,
+                                  const real* __restrict__ row_ce, const real* __restrict__ tmask,
+                                  const real* __restrict__ state, real* __restrict__ o) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    real rec = 0, cev = ce[b] + ce[B + b];
+    if (tmask) {       // neural-process ELBO: reconstruction and cross-entropy over the target frames only (:178-182,213-222)
+        cev = 0;
+        for (int t = 0; t < T; ++t) {
+            const real w = tmask[(size_t)b * T + t];
+            rec += w * row_recon[(size_t)b * T + t];
+            cev += w * (row_ce[(size_t)t * B + b] + row_ce[(size_t)(T + t) * B + b]);
+        }
+    } else {
+        for (int t = 0; t < T; ++t) rec += row_recon[(size_t)b * T + t];
+    }
+    const real lhood = lh[b] + lh[B + b], clh = con_lh ? con_lh[b] + con_lh[B + b] : real(0);
+    const real kl = lhood + cev - clh, beta = state[SVGP_ST_BETA];
+    o[b] = rec + beta * kl; o[B + b] = rec; o[2 * B + b] = kl; o[3 * B + b] = lhood; o[4 * B + b] = cev;
+    o[5 * B + b] = clh; o[6 * B + b] = 0;
+}
+
 __global__ void k_state_add(int slot, real v, real* __restrict__ st) { st[slot] += v; }
 
 // binary ball frames from pixel-space centres (utils.py:177-187): frame[i][j] = (i - x)^2 + (j - y)^2 < r^2
@@ -397,6 +659,98 @@ extern "C" int svgp_ball_rasterize(long long frames, int px, int py, double r, c
     REQ_PTRS(paths, vid);
     const long long tot = frames * px * py;
     hipLaunchKernelGGL(k_ball_rasterize, dim3(nb256(tot)), dim3(256), 0, (hipStream_t)stream, tot, px, py, r * r, paths, vid);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+// ---- Pearce baseline: exact per-video GP (GPVAE_Pearce_model.py:8-86) ------------------------------------------
+// Buffers (caller-owned): per coordinate c in {x, y}, all (T, B): y, s2, p_m, p_v, eps, z, zbar, ybar, s2bar;
+// Ai (2,B,n,n), alpha (2,B,n), lh (2,B), ce (2,B), row_ce (2,T,B), dl_part (2,B).  idx (B,n) int32 selects a context set
+// (forward: lhood only; reverse: seeds -gT, accumulates into ybar / s2bar).  tmask (B,T) restricts the CE terms.
+
+static int pearce_args(const svgp_pearce_bufs* q, PearceArgs* a) {
+    SVGP_REQUIRE(q != nullptr, SVGP_ERR_INVALID, "bufs is NULL");
+    SVGP_REQUIRE(q->B >= 1 && q->T >= 1 && q->n >= 1 && q->n <= q->T, SVGP_ERR_INVALID, "bad shape B=%d T=%d n=%d", q->B,
+                 q->T, q->n);
+    SVGP_REQUIRE(q->n <= 64, SVGP_ERR_UNSUPPORTED, "n=%d: the exact per-video GP keeps its n x n matrices in LDS (n <= 64)",
+                 q->n);
+    SVGP_REQUIRE(q->idx != nullptr || q->n == q->T, SVGP_ERR_INVALID, "n != T needs an index set");
+    REQ_PTRS(q->times, q->ls_x, q->ls_y, q->y_x, q->y_y, q->s2_x, q->s2_y, q->Ai, q->alpha, q->lh);
+    memset(a, 0, sizeof(*a));
+    a->B = q->B; a->T = q->T; a->n = q->n; a->times = q->times; a->idx = q->idx; a->tmask = q->tmask;
+    a->ls[0] = q->ls_x; a->ls[1] = q->ls_y; a->y[0] = q->y_x; a->y[1] = q->y_y; a->s2[0] = q->s2_x; a->s2[1] = q->s2_y;
+    a->p_m[0] = q->p_m_x; a->p_m[1] = q->p_m_y; a->p_v[0] = q->p_v_x; a->p_v[1] = q->p_v_y;
+    a->eps[0] = q->eps_x; a->eps[1] = q->eps_y; a->z[0] = q->z_x; a->z[1] = q->z_y;
+    a->zbar[0] = q->zbar_x; a->zbar[1] = q->zbar_y; a->ybar[0] = q->ybar_x; a->ybar[1] = q->ybar_y;
+    a->s2bar[0] = q->s2bar_x; a->s2bar[1] = q->s2bar_y;
+    a->Ai = q->Ai; a->alpha = q->alpha; a->lh = q->lh; a->ce = q->ce; a->row_ce = q->row_ce; a->dl_part = q->dl_part;
+    return SVGP_OK;
+}
+static int set_lds(const void* fn, size_t bytes) {
+    SVGP_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return SVGP_OK;
+}
+
+extern "C" int svgp_pearce_gp_fwd(const svgp_pearce_bufs* q, const double* eps_x, const double* eps_y, const double* state,
+                                  void* stream) {
+    PearceArgs a;
+    int rc = pearce_args(q, &a);
+    if (rc) return rc;
+    if (!q->idx) {
+        REQ_PTRS(q->p_m_x, q->p_m_y, q->p_v_x, q->p_v_y, q->eps_x, q->eps_y, q->z_x, q->z_y, q->ce, q->row_ce, state);
+        SVGP_REQUIRE((eps_x == nullptr) == (eps_y == nullptr), SVGP_ERR_INVALID, "give both eps or neither");
+    }
+    a.eps_in[0] = eps_x; a.eps_in[1] = eps_y; a.use_rng = eps_x == nullptr; a.state = state;
+    const size_t lds = ((size_t)3 * a.n * (a.n + 1) + 4 * a.n + 16) * sizeof(real);
+    rc = set_lds((const void*)k_pearce_fwd, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pearce_fwd, dim3(a.B, 2), dim3(256), lds, (hipStream_t)stream, a);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+// seed_lh_scale: +1 for the full-data likelihood, -1 for a context likelihood (subtracted in the NP ELBO);
+// d_ls_x / d_ls_y: length-scale gradients (accumulate != 0 adds to them and to ybar / s2bar)
+extern "C" int svgp_pearce_gp_bwd(const svgp_pearce_bufs* q, double seed_lh_scale, int accumulate, const double* state,
+                                  double* d_ls_x, double* d_ls_y, void* stream) {
+    PearceArgs a;
+    int rc = pearce_args(q, &a);
+    if (rc) return rc;
+    REQ_PTRS(q->ybar_x, q->ybar_y, q->s2bar_x, q->s2bar_y, q->dl_part, state, d_ls_x, d_ls_y);
+    if (!q->idx) REQ_PTRS(q->p_m_x, q->p_m_y, q->p_v_x, q->p_v_y, q->eps_x, q->eps_y, q->zbar_x, q->zbar_y);
+    a.state = state; a.seed_lh_scale = seed_lh_scale; a.accumulate = accumulate;
+    const size_t lds = ((size_t)4 * a.n * (a.n + 1) + 5 * a.n + 16) * sizeof(real);
+    rc = set_lds((const void*)k_pearce_bwd, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pearce_bwd, dim3(a.B, 2), dim3(256), lds, (hipStream_t)stream, a);
+    SVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pearce_dl, dim3(1), dim3(64), 0, (hipStream_t)stream, a.B, accumulate, q->dl_part, d_ls_x, d_ls_y);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+// out (7,B) = per-video [elbo, recon, prior_kl, lhood, ce, context lhood, 0]; con_lh (2,B) / tmask (B,T) NULL unless NP
+extern "C" int svgp_pearce_elbo_assemble(int B, int T, const double* lh, const double* ce, const double* con_lh,
+                                         const double* row_recon, const double* row_ce, const double* tmask,
+                                         const double* state, double* out, void* stream) {
+    SVGP_REQUIRE(B >= 1 && T >= 1, SVGP_ERR_INVALID, "bad shape");
+    REQ_PTRS(lh, ce, row_recon, state, out);
+    SVGP_REQUIRE(tmask == nullptr || row_ce != nullptr, SVGP_ERR_INVALID, "a target mask needs the per-frame CE terms");
+    hipLaunchKernelGGL(k_pearce_assemble, dim3(nb256(B)), dim3(256), 0, (hipStream_t)stream, B, T, lh, ce, con_lh, row_recon,
+                       row_ce, tmask, state, out);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+// rows of x scaled by w (n rows of C values): dlogits of the context frames are zero in the NP ELBO
+__global__ void k_scale_rows(long long tot, int C, const real* __restrict__ w, real* __restrict__ x) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < tot) x[i] *= w[i / C];
+}
+extern "C" int svgp_scale_rows(long long rows, int C, const double* w, double* x, void* stream) {
+    SVGP_REQUIRE(rows >= 1 && C >= 1, SVGP_ERR_INVALID, "bad shape");
+    REQ_PTRS(w, x);
+    hipLaunchKernelGGL(k_scale_rows, dim3(nb256(rows * C)), dim3(256), 0, (hipStream_t)stream, rows * C, C, w, x);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

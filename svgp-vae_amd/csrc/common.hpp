@@ -122,6 +122,27 @@ __device__ __forceinline__ real elu_f(real x) { return x > 0 ? x : expm1(x); }
 // derivative of ELU expressed through its OUTPUT: out > 0 -> 1, else exp(pre) = out + 1
 __device__ __forceinline__ real elu_grad_from_out(real out) { return out > 0 ? real(1) : out + real(1); }
 
+// Philox4x32-10 -> one N(0,1) double (Box-Muller on two 53-bit uniforms... 2 x 32-bit + 2 x 32-bit)
+__device__ __forceinline__ real svgp_philox_normal(unsigned long long ctr, unsigned long long idx) {
+    unsigned int c0 = (unsigned int)idx, c1 = (unsigned int)(idx >> 32), c2 = (unsigned int)ctr,
+                 c3 = (unsigned int)(ctr >> 32);
+    unsigned int k0 = 0x5356u, k1 = 0x47505641u;   // fixed key
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned int)p1;
+        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned int)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const real u1 = ((real)(((unsigned long long)c0 << 21) ^ (unsigned long long)(c1 >> 11)) + real(0.5)) *
+                    (real(1) / real(9007199254740992.0));   // (0,1), 53 bits
+    const real u2 = ((real)(((unsigned long long)c2 << 21) ^ (unsigned long long)(c3 >> 11)) + real(0.5)) *
+                    (real(1) / real(9007199254740992.0));
+    return sqrt(real(-2) * log(u1)) * cos(real(6.283185307179586) * u2);
+}
+
 __device__ __forceinline__ real recip_no_nan(real x) { return x == real(0) ? real(0) : real(1) / x; }
 
 // mnistSVGP.kernel_matrix arguments (SVGPVAE_model.py:427-476), shared by gp_kernels.hip and the encoder launch that

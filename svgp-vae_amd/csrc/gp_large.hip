@@ -102,25 +102,7 @@ struct PostFinArgs {
     const real* knn; const real* q; const real* y; const real* s2; const real* eps_in; const real* state;
     real* p_m; real* p_v; real* e; real* d; real* eps; real* z; real* part;
 };
-__device__ __forceinline__ real philox_normal_big(unsigned long long ctr, unsigned long long idx) {
-    unsigned int c0 = (unsigned int)idx, c1 = (unsigned int)(idx >> 32), c2 = (unsigned int)ctr,
-                 c3 = (unsigned int)(ctr >> 32);
-    unsigned int k0 = 0x5356u, k1 = 0x47505641u;
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
-        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
-        const unsigned int n0 = (unsigned int)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned int)p1;
-        const unsigned int n2 = (unsigned int)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned int)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    const real u1 = ((real)(((unsigned long long)c0 << 21) ^ (unsigned long long)(c1 >> 11)) + real(0.5)) *
-                    (real(1) / real(9007199254740992.0));
-    const real u2 = ((real)(((unsigned long long)c2 << 21) ^ (unsigned long long)(c3 >> 11)) + real(0.5)) *
-                    (real(1) / real(9007199254740992.0));
-    return sqrt(real(-2) * log(u1)) * cos(real(6.283185307179586) * u2);
-}
+__device__ __forceinline__ real philox_normal_big(unsigned long long ctr, unsigned long long idx) { return svgp_philox_normal(ctr, idx); }
 // in: p_m = c k.t (done), p_v = r, e = mv, d = s  -> out: final values
 __global__ __launch_bounds__(256) void k_big_post_final(PostFinArgs a) {
     __shared__ real red[16];

@@ -138,3 +138,97 @@ def test_unsupported_shapes_fail_loudly():
         ball.BallStepEngine(mk("x", 80), mk("y", 80), batch=4, tmax=30, px=8, py=8, hidden=8)     # m > 64
     with pytest.raises(_lib.SvgpError):
         ball.BallStepEngine(mk("x", 8), mk("y", 8), batch=70, tmax=30, px=8, py=8, hidden=8)      # > 64 videos
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Pearce baseline (BASELINE configs[0]: BALL_experiment.py --elbo VAE; also GPVAE_Pearce and NP)
+# ---------------------------------------------------------------------------------------------------------
+def _pearce_engine(p, type_elbo, lt, GP_joint, batch, T, px, hidden, beta, **kw):
+    from svgp_vae_amd import ball
+    flat = {k: (v.reshape(-1) if k.startswith(("encB", "decB", "l_")) else v) for k, v in p.items()}
+    return ball.PearceStepEngine(type_elbo, lt, 0.5, GP_joint, 2.0, batch=batch, tmax=T, px=px, py=px, hidden=hidden,
+                                 beta=beta, params=flat, **kw)
+
+
+PEARCE_CASES = {
+    "vae_small": dict(shape=(5, 12, 8, 16), type_elbo="VAE", lt=0.001, joint=False),
+    "pearce_small_joint": dict(shape=(5, 12, 8, 16), type_elbo="GPVAE_Pearce", lt=2.0, joint=True),
+    "np_small_joint": dict(shape=(6, 14, 8, 16), type_elbo="NP", lt=2.0, joint=True),
+    "vae_config1_shape": dict(shape=(35, 30, 32, 500), type_elbo="VAE", lt=0.001, joint=False),
+    "pearce_config1_shape": dict(shape=(35, 30, 32, 500), type_elbo="GPVAE_Pearce", lt=2.0, joint=False),
+    "np_config1_shape": dict(shape=(35, 30, 32, 500), type_elbo="NP", lt=2.0, joint=False),
+}
+
+
+@pytest.mark.parametrize("case", list(PEARCE_CASES))
+def test_pearce_step_matches_oracle(case):
+    cs = PEARCE_CASES[case]
+    batch, T, px, hidden = cs["shape"]
+    p, vid, eps = _problem(batch, T, px, hidden, 4, seed=4)
+    p = {k: v for k, v in p.items() if not k.startswith("ip_")}
+    lt = cs["lt"]
+    p["l_x"] = torch.tensor(lt * (1.2 if cs["joint"] else 1.0), dtype=DT)
+    p["l_y"] = torch.tensor(lt * (0.9 if cs["joint"] else 1.0), dtype=DT)
+    ran_ind = con_tf = None
+    if cs["type_elbo"] == "NP":
+        g = torch.Generator().manual_seed(9)
+        ran_ind = torch.stack([torch.randperm(T, generator=g) for _ in range(batch)])
+        con_tf = T // 2 - 1
+    beta = 0.9
+    out, loss, grads = BO.pearce_loss_and_grads(p, vid, eps, beta=beta, type_elbo=cs["type_elbo"], lt=lt, ran_ind=ran_ind,
+                                                con_tf=con_tf)
+    eng = _pearce_engine(p, cs["type_elbo"], lt, cs["joint"], batch, T, px, hidden, beta)
+    eng.step(vid.cuda(), eps.cuda(), adam=False, ran_ind=None if ran_ind is None else ran_ind.numpy(), con_tf=con_tf)
+    got = eng.outputs()
+    names = ("elbo", "recon", "prior_kl", "full_p_mu", "full_p_var", "qnet_mu", "qnet_var", "pred_vid")
+    bad = []
+    for i, n in enumerate(names):
+        e = H.relerr(got[i], out[i])
+        if not e < 1e-8:
+            bad.append(f"{n}: {e:.2e}")
+    if not abs(eng.scalars()["elbo"] - float(out[0].mean())) <= 1e-9 * abs(float(out[0].mean())):
+        bad.append("mean elbo")
+    eng.stream.synchronize()
+    for k in BO.PEARCE_PARAM_ORDER:
+        if k.startswith("l_") and not cs["joint"]:
+            assert float(eng.grads[k].abs().max()) == 0.0          # constants when not --GP_joint
+            continue
+        e = H.relerr(eng.grads[k].reshape(-1), grads[k].reshape(-1))
+        if not e < 1e-7:
+            bad.append(f"grad {k}: {e:.2e}")
+    assert not bad, "\n".join(bad)
+
+
+def test_vae_limit_is_the_closed_form_standard_vae():
+    """lt = 0.001 (BALL_experiment.py:46-48): prior KL term = -KL(N(p_m, p_v) || N(0, 1)) summed over frames and
+    coordinates, with p_m = y/(1+var), p_v = var/(1+var)."""
+    batch, T, px, hidden = 6, 10, 8, 16
+    p, vid, eps = _problem(batch, T, px, hidden, 4, seed=6)
+    p = {k: v for k, v in p.items() if not k.startswith("ip_")}
+    p["l_x"] = p["l_y"] = torch.tensor(0.001, dtype=DT)
+    eng = _pearce_engine(p, "VAE", 0.001, False, batch, T, px, hidden, 1.0)
+    eng.step(vid.cuda(), eps.cuda(), adam=False, backward=False)
+    elbo, recon, kl, p_m, p_v, q_m, q_v = [t.cpu() for t in eng.outputs()[:7]]
+    assert torch.allclose(p_m, q_m / (1 + q_v), atol=1e-12) and torch.allclose(p_v, q_v / (1 + q_v), atol=1e-12)
+    want = -torch.distributions.kl_divergence(torch.distributions.Normal(p_m, p_v.sqrt()),
+                                              torch.distributions.Normal(torch.zeros_like(p_m), torch.ones_like(p_m))).sum((1, 2))
+    assert torch.allclose(kl, want, rtol=1e-9, atol=1e-9)
+    assert torch.allclose(elbo, recon + kl)
+
+
+def test_pearce_three_adam_steps_raise_the_elbo_and_track_the_oracle():
+    batch, T, px, hidden = 6, 10, 8, 16
+    p, vid, eps = _problem(batch, T, px, hidden, 4, seed=8)
+    p = {k: v for k, v in p.items() if not k.startswith("ip_")}
+    p["l_x"], p["l_y"] = torch.tensor(2.0, dtype=DT), torch.tensor(2.0, dtype=DT)
+    eng = _pearce_engine(p, "GPVAE_Pearce", 2.0, True, batch, T, px, hidden, 1.0, lr=1e-3)
+    from oracle import svgpvae_oracle as O
+    q = {k: v.clone() for k, v in p.items()}
+    ms, vs = {k: torch.zeros_like(v) for k, v in q.items()}, {k: torch.zeros_like(v) for k, v in q.items()}
+    for t in range(1, 4):
+        out, loss, g = BO.pearce_loss_and_grads(q, vid, eps, beta=1.0, type_elbo="GPVAE_Pearce", lt=2.0)
+        O.adam_tf1_step(q, g, ms, vs, t, 1e-3)
+        eng.step(vid.cuda(), eps.cuda(), adam=True)
+        assert abs(eng.scalars()["elbo"] - float(out[0].mean())) < 1e-8 * abs(float(out[0].mean()))
+    for k in BO.PEARCE_PARAM_ORDER:
+        assert H.relerr(eng.params[k].reshape(-1), q[k].reshape(-1)) < 1e-8, k

@@ -232,3 +232,37 @@ def test_pearce_three_adam_steps_raise_the_elbo_and_track_the_oracle():
         assert abs(eng.scalars()["elbo"] - float(out[0].mean())) < 1e-8 * abs(float(out[0].mean()))
     for k in BO.PEARCE_PARAM_ORDER:
         assert H.relerr(eng.params[k].reshape(-1), q[k].reshape(-1)) < 1e-8, k
+
+
+@pytest.mark.parametrize("elbo,extra", [("VAE", []), ("GPVAE_Pearce", ["--GP_joint"]), ("NP", []),
+                                         ("SVGPVAE_Hensman", ["--clip_qs", "--GP_joint", "--ip_joint", "--jitter", "1e-6"]),
+                                         ("SVGPVAE_Titsias", ["--clip_qs", "--jitter", "1e-6"])])
+def test_ball_cli_end_to_end(tmp_path, elbo, extra):
+    """BALL_experiment.py driver: reference flags, fresh synthetic batch per step, test-batch diagnostics, log file."""
+    from svgp_vae_amd import BALL_experiment as BE
+    argv = ["--elbo", elbo, "--steps", "8", "--eval_every", "4", "--hidden", "32", "--tmax", "12", "--m", "6", "--ip_max",
+            "12", "--base_dir", str(tmp_path), "--save", "--save_model", "--seed", "3"] + extra
+    log = BE.main(argv)
+    assert [r["Step"] for r in log] == [4, 8]
+    for r in log:
+        assert np.isfinite(r["elbo"]) and np.isfinite(r["MSE"]) and r["min q_var"] > 0
+    runs = [d for d in tmp_path.iterdir() if d.is_dir()]
+    assert len(runs) == 1 and (runs[0] / "res" / "ELBO_log.jsonl").exists() and (runs[0] / "model.pt").exists()
+    assert (tmp_path / "Test_Batches_2_12.pkl").exists()
+
+
+def test_vae_training_improves_the_test_elbo():
+    """BASELINE configs[0] (`BALL_experiment.py --elbo VAE`) at full shape: 60 Adam steps on fresh synthetic batches
+    raise the ELBO of the fixed test batch by a wide margin (untrained: about -35 * 30 * 1024 * log 2)."""
+    from svgp_vae_amd import BALL_experiment as BE
+    args = BE.build_parser().parse_args(["--elbo", "VAE", "--steps", "60", "--seed", "0"])
+    eng = BE.build_engine(args)
+    TT, TD = __import__("svgp_vae_amd.ball", fromlist=["x"]).Make_Video_batch(tmax=30, px=32, py=32, lt=2, batch=35, seed=0, r=3)
+    before = BE.evaluate(eng, TT, TD, 1.0)["elbo"]
+    src = __import__("svgp_vae_amd.ball", fromlist=["x"]).VideoBatchSource(tmax=30, px=32, py=32, lt=2, batch=35, seed=1, r=3)
+    for _ in range(60):
+        v = src(); v.record_stream(eng.stream)
+        eng.step(v, None, adam=True)
+    after = BE.evaluate(eng, TT, TD, 1.0)["elbo"]
+    assert eng.scalars()["adam_t"] == 60.0
+    assert after > before + 0.5 * abs(before), (before, after)

@@ -95,6 +95,31 @@ def test_newer_entry_points_validate_their_arguments():
     assert lib.svgp_spd_inverse_workspace_elems(800, 4) > lib.svgp_spd_inverse_workspace_elems(400, 4)
 
 
+def test_moving_ball_entry_points_validate_their_arguments():
+    fake = C.c_void_p(4096)                                     # never dereferenced
+    cfg = _lib.MnistCfg(b=30, b_global=30, m=80, L=35, M=1, n_obj=0, N_train=30.0, jitter=1e-6, kl_form=1, clip_pv=2)
+    with pytest.raises(svgp_vae_amd.SvgpError, match="moving-ball"):
+        _lib.call("svgp_mnist_ws_layout_get", C.byref(cfg), C.byref(_lib.WsLayout()))
+    cfg = _lib.MnistCfg(b=30, b_global=30, m=15, L=35, M=1, n_obj=0, N_train=30.0, jitter=1e-6, clip_pv=3)
+    with pytest.raises(svgp_vae_amd.SvgpError, match="clip_pv"):
+        _lib.call("svgp_mnist_ws_layout_get", C.byref(cfg), C.byref(_lib.WsLayout()))
+    # the ball configuration itself lays out: KL field holds [KL | traces]
+    cfg = _lib.MnistCfg(b=30, b_global=30, m=15, L=35, M=1, n_obj=0, N_train=30.0, jitter=1e-9, kl_form=1, clip_pv=2, b_cap=30)
+    wl = _lib.WsLayout()
+    _lib.call("svgp_mnist_ws_layout_get", C.byref(cfg), C.byref(wl))
+    assert wl.q - wl.KL >= 2 * 35
+    q = _lib.PearceBufs(B=35, T=100, n=100)
+    with pytest.raises(svgp_vae_amd.SvgpError, match="n <= 64"):
+        _lib.call("svgp_pearce_gp_fwd", C.byref(q), None, None, fake, None)
+    q = _lib.PearceBufs(B=35, T=30, n=12)                       # a context set needs its index list
+    with pytest.raises(svgp_vae_amd.SvgpError, match="index set"):
+        _lib.call("svgp_pearce_gp_fwd", C.byref(q), None, None, fake, None)
+    with pytest.raises(svgp_vae_amd.SvgpError, match="NULL"):
+        _lib.call("svgp_se1d_kernel_matrix_fwd", 30, 15, None, fake, fake, fake, fake, fake, None)
+    with pytest.raises(svgp_vae_amd.SvgpError, match="slot"):
+        _lib.call("svgp_state_add", fake, 99, 1.0, None)
+
+
 def test_missing_extension_fails_loudly(tmp_path):
     with pytest.raises(svgp_vae_amd.SvgpError, match="no CPU fallback"):
         svgp_vae_amd.load_library(str(tmp_path / "nope.so"))
@@ -107,6 +132,12 @@ def test_engine_refuses_to_run_without_a_gpu():
     from svgp_vae_amd.engine import MnistStepEngine
     with pytest.raises(svgp_vae_amd.SvgpError, match="no CPU execution path"):
         MnistStepEngine(32)
+    from svgp_vae_amd import ball
+    with pytest.raises(svgp_vae_amd.SvgpError, match="no CPU execution path"):
+        ball.PearceStepEngine("VAE", 0.001, batch=4, tmax=8, px=8, py=8, hidden=8)
+    mk = lambda n: ball.SVGP(False, 5, False, 1, 8, 2.0, False, n, 1e-6, 1, 8, 2.0)
+    with pytest.raises(svgp_vae_amd.SvgpError, match="no CPU execution path"):
+        ball.BallStepEngine(mk("x"), mk("y"), batch=4, tmax=8, px=8, py=8, hidden=8)
 
 
 def test_product_package_never_imports_the_oracle():

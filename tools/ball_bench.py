@@ -18,12 +18,13 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--cpu-steps", type=int, default=3, help="0 skips the CPU oracle")
+    ap.add_argument("--elbo", nargs="+", default=["VAE", "GPVAE_Pearce", "NP", "SVGPVAE_Hensman", "SVGPVAE_Titsias"])
     a = ap.parse_args()
     from svgp_vae_amd import BALL_experiment as BE, ball
     from oracle import ball_oracle as BO, pearce_vae_oracle as PO
     res = {}
-    for elbo in ("VAE", "GPVAE_Pearce", "NP", "SVGPVAE_Hensman", "SVGPVAE_Titsias"):
+    for elbo in a.elbo:
         args = BE.build_parser().parse_args(["--elbo", elbo, "--clip_qs", "--GP_joint", "--ip_joint", "--jitter", "1e-6"])
         eng = BE.build_engine(args)
         src = ball.VideoBatchSource(tmax=30, px=32, py=32, lt=2, batch=35, seed=1, r=3)
@@ -57,7 +58,7 @@ def main():
                 q = dict(p); q["l_x"] = q["l_y"] = torch.tensor(lt, dtype=DT)
                 ri = torch.stack([torch.randperm(30, generator=g) for _ in range(35)]) if elbo == "NP" else None
                 BO.pearce_loss_and_grads(q, vid, eps, beta=1.0, type_elbo=elbo, lt=lt, ran_ind=ri, con_tf=15 if ri is not None else None)
-        cpu = (time.perf_counter() - t1) / a.cpu_steps
+        cpu = (time.perf_counter() - t1) / max(a.cpu_steps, 1) if a.cpu_steps else float("nan")
         res[elbo] = dict(hip_steps_per_s=a.steps / dt, hip_ms_per_step=1e3 * dt / a.steps, cpu_oracle_ms_per_step=1e3 * cpu,
                          cpu_threads=torch.get_num_threads(), elbo_after=eng.scalars()["elbo"])
     print(json.dumps(dict(workload="BASELINE configs[0] shape: batch 35, tmax 30, 32x32, MLP 500, m 15, float64; wall clock "

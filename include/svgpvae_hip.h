@@ -455,6 +455,30 @@ int svgp_pearce_elbo_assemble(int B, int T, const double* lh, const double* ce, 
                               double* out, void* stream);
 int svgp_scale_rows(long long rows, int C, const double* w, double* x, void* stream);
 
+/* ---- deep SVIGP_Hensman baseline on rotated MNIST (svigp.hip): MNIST_experiment.py --elbo SVIGP_Hensman -------------
+ * SVIGP_Hensman.variational_loss / approximate_posterior_params (SVIGP_Hensman_model.py:135-227) and the ELBO assembly
+ * of forward_pass_deep_SVIGP_Hensman (:230-289) with free variational parameters loc (L,m), scale (L,m,m)
+ * (S_l = scale_l scale_l^T) and a likelihood noise (1); kernel matrices from svgp_kernel_matrix_fwd, decoder =
+ * svgp_mnist_decoder_fwd/bwd.  svgp_svigp_fwd: Z (b,L) = K_nm (K_mm + jI)^-1 loc_l (training mean vectors, and with
+ * test-point kernel matrices the prediction of :292-339).  svgp_svigp_bwd: reverse pass of -elbo given the decoder's
+ * Zbar (beta-ELBO seed, scaled here by n_pix / (2 noise^2)) and its squared-error partial sums; writes Kbar / Knbar /
+ * knnbar for svgp_kernel_matrix_bwd and the gradients of loc, scale, noise.  svgp_svigp_assemble: out (7) = [elbo,
+ * recon_loss / n_pix, KL_term, inside_elbo, 0, inside_recon, inside_kl].  ws: svgp_svigp_workspace_elems doubles;
+ * ws[svgp_svigp_scale_offset] holds n_pix / (2 noise^2), the factor the decoder's weight gradients take
+ * (svgp_scale_by_device_scalar).                                                                                    */
+long long svgp_svigp_workspace_elems(int b, int m, int L);
+long long svgp_svigp_scale_offset(int b, int m, int L);
+int svgp_svigp_fwd(int b, int b_global, int m, int L, int n_pix, double jitter, const double* K, const double* Kn,
+                   const double* knn, const double* loc, const double* scale, const double* noise, double* Z,
+                   double* ws, void* stream);
+int svgp_svigp_bwd(int b, int b_global, int m, int L, int n_pix, double N_train, const double* Kn, const double* loc,
+                   const double* scale, const double* noise, double* Zbar, const double* part_sums, int n_part,
+                   double* Kbar, double* Knbar, double* knnbar, double* d_loc, double* d_scale, double* d_noise,
+                   double* ws, void* stream);
+int svgp_svigp_assemble(int b, int b_global, int m, int L, int n_pix, double N_train, const double* noise,
+                        const double* part_sums, int n_part, const double* ws, double* out, void* stream);
+int svgp_scale_by_device_scalar(long long n, const double* f, double* x, void* stream);
+
 /* ---- runtime helpers: HIP graphs and events without going through torch ---------------------*/
 int svgp_stream_create(void** stream_out);
 int svgp_stream_destroy(void* stream);

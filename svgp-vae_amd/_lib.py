@@ -151,6 +151,10 @@ SIGNATURES = {
     "svgp_pearce_gp_bwd": [C.POINTER(PearceBufs), C.c_double, C.c_int, _P, _P, _P, _P],
     "svgp_pearce_elbo_assemble": [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "svgp_scale_rows": [C.c_longlong, C.c_int, _P, _P, _P],
+    "svgp_svigp_fwd": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double] + [_P] * 9,
+    "svgp_svigp_bwd": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, _P, _P, _P, _P, C.c_int] + [_P] * 8,
+    "svgp_svigp_assemble": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, _P, C.c_int, _P, _P, _P],
+    "svgp_scale_by_device_scalar": [C.c_longlong, _P, _P, _P],
     "svgp_ball_rasterize": [C.c_longlong, C.c_int, C.c_int, C.c_double, _P, _P, _P],
     "svgp_stream_create": [C.POINTER(_P)],
     "svgp_stream_destroy": [_P],
@@ -174,7 +178,9 @@ NON_STATUS = {"svgp_version": ([], C.c_int), "svgp_last_error": ([], C.c_char_p)
               "svgp_stream_feature_elems": ([C.c_void_p, C.c_int64], C.c_int64),
               "svgp_stream_stats_workspace_elems": ([C.c_int64, C.c_int, C.c_int], C.c_int64),
               "svgp_spd_inverse_workspace_elems": ([C.c_int, C.c_int], C.c_size_t),
-              "svgp_act_bwd_bias_scratch_elems": ([C.c_int], C.c_int)}
+              "svgp_act_bwd_bias_scratch_elems": ([C.c_int], C.c_int),
+              "svgp_svigp_workspace_elems": ([C.c_int, C.c_int, C.c_int], C.c_longlong),
+              "svgp_svigp_scale_offset": ([C.c_int, C.c_int, C.c_int], C.c_longlong)}
 
 _lib = None
 

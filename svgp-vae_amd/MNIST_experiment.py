@@ -1,5 +1,5 @@
 """Rotated-MNIST experiment driver with the reference's CLI (MNIST_experiment.py:1115-1174 flags and
-defaults) for `--elbo SVGPVAE_Hensman`, running every step on the HIP library.
+defaults) for `--elbo SVGPVAE_Hensman | SVGPVAE_Titsias | SVIGP_Hensman`, running every step on the HIP library.
 
     python -m svgp_vae_amd.MNIST_experiment --elbo SVGPVAE_Hensman --ip_joint --GP_joint --ov_joint \
         --clip_qs --GECO --PCA --mnist_data_path "MNIST data/"
@@ -9,7 +9,9 @@ inverted `fixed_*` flags (:96-98), the un-shuffled epoch loop with ragged last b
 carry / first-step alpha=0 (kept on device), and every 10 epochs: eval-set reconstruction MSE, conditional
 generation MSE on the test set (:457-486) and `pics/test_metrics.txt` lines `epoch,recon MSE,cgen MSE`
 (:509-510).  Plotting / pandas logging of the reference are not reproduced.
-Other --elbo values (VAE, CVAE, SVGPVAE_Titsias, GPVAE_Casale*, SVIGP_Hensman) are baselines outside this build.
+`--elbo SVIGP_Hensman` mirrors run_experiment_rotated_mnist_SVIGP_Hensman (:544-760): deep SVIGP with free variational
+parameters, same loaders / inducing-point init, per-epoch train MSE and the conditional-generation MSE on the test set.
+Other --elbo values (VAE, CVAE, GPVAE_Casale*) are baselines outside this build.
 """
 import argparse
 import json
@@ -189,11 +191,80 @@ def run_experiment_rotated_mnist_SVGPVAE(args, args_dict=None):
     return log
 
 
+def run_experiment_rotated_mnist_SVIGP_Hensman(args, args_dict=None):
+    """MNIST_experiment.py:544-760.  Returns a dict of the logged series."""
+    from .SVIGP_Hensman_model import SVIGP_Hensman, SVIGP_Hensman_decoder, SvigpStepEngine
+    np.random.seed(args.seed)
+    n = len(args.dataset)
+    ending = args.dataset + ".p"
+    train, ev, te, train_batches = import_rotated_mnist(args.mnist_data_path, ending, args.batch_size,
+                                                        train_file=args.train_file)
+    N_train = len(train["images"]) if args.train_file else n * 4050
+    N_test = len(te["images"])
+    chkpnt_dir = None
+    if args.save:
+        stamp = time.strftime("%d_%m_%Y__at__%H_%M_%S")
+        chkpnt_dir = os.path.join(args.base_dir, args.expid, f"{args.elbo}_{args.beta}__on__{stamp}") + "/"
+        os.makedirs(chkpnt_dir + "pics/", exist_ok=True)
+        json.dump(args_dict or vars(args), open(chkpnt_dir + "args.json", "wt"))
+    VAE = SVIGP_Hensman_decoder(L=args.L, seed=args.seed)                                  # :591
+    inducing_points_init = generate_init_inducing_points(None, n=args.nr_inducing_points, remove_test_angle=None,
+                                                         PCA=args.PCA, M=args.M, aux_data=train["aux_data"])
+    if args.ov_joint:                                                                        # :603-612
+        if args.PCA:
+            object_vectors_init = pickle.load(open(args.mnist_data_path + f'pca_ov_init{args.dataset}.p', 'rb'))
+        else:
+            object_vectors_init = np.random.normal(0, 1.5, n * 400 * args.M).reshape(n * 400, args.M)
+    else:
+        object_vectors_init = None
+    SVGP_ = SVIGP_Hensman(fixed_inducing_points=not args.ip_joint, initial_inducing_points=inducing_points_init,
+                          fixed_gp_params=not args.GP_joint, object_vectors_init=object_vectors_init, name='main',
+                          jitter=args.jitter, N_train=N_train, L=args.L, K_obj_normalize=args.object_kernel_normalize,
+                          dtype=np.float64)                                                  # :616-620
+    eng = SvigpStepEngine(VAE, SVGP_, b_max=args.batch_size, lr=args.lr)
+    dev = eng.dev
+    t64 = lambda a: torch.tensor(a, dtype=torch.float64, device=dev).contiguous()
+    d_train_img, d_train_aux = t64(train["images"]), t64(train["aux_data"])
+    d_test_img, d_test_aux = t64(te["images"]), t64(te["aux_data"])
+    nr_epochs = args.nr_epochs if args.opt_regime == ['joint-1000'] else parse_opt_regime(args.opt_regime)[0]
+    log = dict(epoch=[], elbo=[], recon_loss=[], cgen_mse=[], epoch_time=[])
+    start = time.time()
+    for epoch in range(nr_epochs):
+        t0 = time.time()
+        elbos, losses = [], []
+        for lo, hi in train_batches:                                                         # :700-706
+            eng.step(d_train_img[lo:hi], d_train_aux[lo:hi], adam=True)
+            sc = eng.scalars()
+            elbos.append(sc["elbo"]); losses.append(sc["recon_loss"])
+        mse = float(np.sum(losses) / N_train)
+        log["epoch"].append(epoch); log["elbo"].append(float(np.mean(elbos))); log["recon_loss"].append(mse)
+        log["epoch_time"].append(time.time() - t0)
+        if (epoch + 1) % args.eval_every == 0 or epoch + 1 == nr_epochs:
+            print(f"Epoch {epoch}, mean ELBO per batch: {np.mean(elbos)}")
+            print(f"MSE loss on train set for epoch {epoch} : {mse}")
+            cg = [float(eng.predict(d_test_img[lo:hi], d_test_aux[lo:hi])[1]) for lo, hi in batches(N_test, args.batch_size)]
+            cgen = float(np.sum(cg) / N_test)                                               # :733-748
+            log["cgen_mse"].append((epoch, cgen))
+            l_GP, amp, _, _ = SVGP_.variable_summary()
+            print(f"Conditional generation MSE loss on test set for epoch {epoch}: {cgen}   "
+                  f"(l_GP {float(l_GP):.4f}, amplitude {float(amp):.4f}, noise {float(eng.vp['noise'][0]):.4f})", flush=True)
+            if chkpnt_dir:
+                with open(chkpnt_dir + "pics/test_metrics.txt", "a") as f:
+                    f.write(f"{epoch},{mse},{cgen}\n")
+                if args.save_model_weights:
+                    torch.save({"theta": eng.mn.theta.cpu(), "phi": eng.phi.cpu(), "state": eng.mn.state.cpu()},
+                               chkpnt_dir + f"model_{epoch}.pt")
+    log["total_time"] = time.time() - start
+    return log
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.elbo in ("SVGPVAE_Hensman", "SVGPVAE_Titsias"):
         return run_experiment_rotated_mnist_SVGPVAE(args, vars(args))
-    raise NotImplementedError(f"--elbo {args.elbo}: only SVGPVAE_Hensman / SVGPVAE_Titsias are built "
+    if args.elbo == "SVIGP_Hensman":
+        return run_experiment_rotated_mnist_SVIGP_Hensman(args, vars(args))
+    raise NotImplementedError(f"--elbo {args.elbo}: only SVGPVAE_Hensman / SVGPVAE_Titsias / SVIGP_Hensman are built "
                               f"(see DESIGN.md section 9)")
 
 

@@ -99,8 +99,11 @@ typedef struct {
     int64_t qnet_mu, qnet_var_raw, qnet_var; /* (b,L) each; var = clip(exp(.))                    */
     /* kernel matrices (SVGPVAE_model.py:427-476) */
     int64_t K, Kn, knn;                   /* (m,m) (b,m) (b)                                      */
-    /* forward statistics: ONE contiguous all-reduce block [S | v] (titsias: [S | v | tit_S2 | tit_v2]) */
-    int64_t statA, statA_len, S, v;       /* S (L,m,m), v (L,m)                                   */
+    /* forward statistics: ONE contiguous all-reduce block [S | v] (titsias: [S | v | tit_S2 | tit_v2]).
+     * S (P,L,m,m), v (P,L,m) with P = stat_parts ROW PARTIALS (the LDS-resident path splits the rows of every channel
+     * over P workgroups; the statistics are the sums over p, taken by the consumers on load; 1 for m > 64).  The
+     * backward block [A2 | ud | td] has the same partial structure.  Sums over ranks commute with the sum over p. */
+    int64_t statA, statA_len, S, v, stat_parts;
     /* m x m factor stage (SVGPVAE_model.py:239,270-279,319-341) */
     int64_t Ki, ldK, Si, t, G, A, Aji, mu_hat, u, M2, KL, q; /* M2 = Ki A Ki (L,m,m); q (b)       */
     /* per-sample stage (:264-299,332-337, 888-902; utils.py:498-504) */

@@ -30,7 +30,7 @@ class ParamLayout(C.Structure):
 
 
 WS_FIELDS = ("enc_a1", "enc_a2", "enc_a3", "qnet_mu", "qnet_var_raw", "qnet_var", "K", "Kn", "knn",
-             "statA", "statA_len", "S", "v",
+             "statA", "statA_len", "S", "v", "stat_parts",
              "Ki", "ldK", "Si", "t", "G", "A", "Aji", "mu_hat", "u", "M2", "KL", "q",
              "p_m", "p_v", "e", "d", "eps", "z",
              "dec_h0", "dec_a1", "dec_a2", "recon",

@@ -76,7 +76,9 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->enc_a1 = take(b * 13 * 13 * 8); o->enc_a2 = take(b * 6 * 6 * 8); o->enc_a3 = take(b * 32);
     o->qnet_mu = take(b * L); o->qnet_var_raw = take(b * L); o->qnet_var = take(b * L);
     o->K = take(m * m); o->Kn = take(b * m); o->knn = take(b);
-    o->statA = p; o->S = p; p += L * m * m; o->v = p; p += L * m;
+    const int64_t P = svgp_stat_parts(&cc);
+    o->stat_parts = P;
+    o->statA = p; o->S = p; p += P * L * m * m; o->v = p; p += P * L * m;
     o->tit_S2 = p; if (c->titsias) p += L * m * m;
     o->tit_v2 = p; if (c->titsias) p += L * m;
     o->statA_len = p - o->statA; take(0);
@@ -88,7 +90,7 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->eps = take(b * L); o->z = take(b * L);
     o->dec_h0 = take(b * 128); o->dec_a1 = take(b * 512); o->dec_a2 = take(b * 1568); o->recon = take(b * 784);
     o->zbar = take(b * L); o->g_pv = take(b * L); o->g_pm = take(b * L); o->mvbar = take(b * L);
-    o->statB = p; o->A2 = p; p += L * m * m; o->ud = p; p += L * m; o->td = p; p += L * m;
+    o->statB = p; o->A2 = p; p += P * L * m * m; o->ud = p; p += P * L * m; o->td = p; p += P * L * m;
     o->statB_len = p - o->statB; take(0);
     o->Kbar = take(m * m); o->fb_part = take(2 * L * m * m); o->Qm = take(L * m * m); o->vbar = take(L * m);
     o->Ssym = take(L * m * m); o->Knbar_part = take(L * b * m);

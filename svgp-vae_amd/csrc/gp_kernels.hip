@@ -490,8 +490,12 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
     for (int tt = 0; tt < 4; ++tt) acc[tt] = d4_t{0, 0, 0, 0};
     real acc1 = 0, acc2 = 0;
     const real gT = a.mode ? grad_KL_term(a.geco, a.L, a.state) : real(0);
-    for (int r0 = 0; r0 < a.b; r0 += STAT_RC) {
-        const int rows = min(STAT_RC, a.b - r0), rows4 = (rows + 3) & ~3;
+    // row partial blockIdx.x of gridDim.x: rows [rlo, rhi) -> partial block `part` of the outputs
+    const int part = blockIdx.x, RP = ((a.b + (int)gridDim.x - 1) / (int)gridDim.x + 3) & ~3;
+    const int rlo = min(a.b, part * RP), rhi = min(a.b, rlo + RP);
+    const size_t pl_ = (size_t)part * a.L + l;
+    for (int r0 = rlo; r0 < rhi; r0 += STAT_RC) {
+        const int rows = min(STAT_RC, rhi - r0), rows4 = (rows + 3) & ~3;
         __syncthreads();
         if (vpart < nparts) {          // thread = (column vi, row lane vpart): no division in the loop
 #pragma unroll 4
@@ -562,7 +566,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int i = ti * 16 + q + 4 * g, j = tj * 16 + r16;
-                if (i < m && j < m) a.S[(size_t)l * m * m + (size_t)i * m + j] = acc[tt][g];
+                if (i < m && j < m) a.S[pl_ * m * m + (size_t)i * m + j] = acc[tt][g];
             }
         }
     }
@@ -573,8 +577,8 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
     if (threadIdx.x < m) {
         real s1 = 0, s2 = 0;
         for (int pp = 0; pp < nparts; ++pp) { s1 += scr[pp * mp + threadIdx.x]; s2 += scr[SVGP_BLOCK + pp * mp + threadIdx.x]; }
-        a.v1[(size_t)l * m + threadIdx.x] = s1;
-        if (a.v2) a.v2[(size_t)l * m + threadIdx.x] = s2;
+        a.v1[pl_ * m + threadIdx.x] = s1;
+        if (a.v2) a.v2[pl_ * m + threadIdx.x] = s2;
     }
 }
 
@@ -582,10 +586,24 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
 // m x m factor stage, forward.  blockIdx.x < L: channel l.  blockIdx.x >= L: q_n = k_n^T Ki k_n
 // for a block of rows (shared by all channels).
 // =============================================================================================
+// sum of the row partials of one statistics element (stride between partial blocks); P is 1 or SVGP_STAT_PARTS, the
+// loads of the unrolled form are independent
+__device__ __forceinline__ real part_sum(const real* __restrict__ p, size_t stride, int P) {
+    if (P == 1) return p[0];
+    real s[SVGP_STAT_PARTS];
+#pragma unroll
+    for (int pp = 0; pp < SVGP_STAT_PARTS; ++pp) s[pp] = p[pp * stride];
+    real t = s[0];
+#pragma unroll
+    for (int pp = 1; pp < SVGP_STAT_PARTS; ++pp) t += s[pp];
+    return t;
+}
+
 struct FactArgs {
     int b, m, L;
     int defer_aji;           // 1: (A_hat + jI)^-1 and its log det are finished by svgp_gp_stats_bwd's extra workgroups
     int kl_form;             // cfg.kl_form
+    int P;                   // row partials of S, v
     real c, jitter;
     const real* K; const real* Ki; const real* ldK; const real* S; const real* v; const real* Kn;
     real* Si; real* t; real* G; real* A; real* Aji; real* mu; real* u; real* M2; real* KL; real* q;
@@ -635,9 +653,9 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
     mat_load(R0, ld, a.K, m);
     for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
         const int i = o / m, j = o % m;
-        R1[i * ld + j] = a.K[o] + a.c * a.S[om + o] + (i == j ? a.jitter : real(0));
+        R1[i * ld + j] = a.K[o] + a.c * part_sum(a.S + om + o, (size_t)a.L * m * m, a.P) + (i == j ? a.jitter : real(0));
     }
-    if (threadIdx.x < m) vx[threadIdx.x] = a.v[ov + threadIdx.x];
+    if (threadIdx.x < m) vx[threadIdx.x] = part_sum(a.v + ov + threadIdx.x, (size_t)a.L * m, a.P);
     chol_inv(R1, R2, ld, m);                       // R1 = Sigma_l^{-1}
     mat_store(a.Si + om, R1, ld, m);
     mat_vec(vy, R1, ld, vx, m, real(1));           // t = Si v
@@ -772,7 +790,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_fwd(PostArgs a) {
 // m x m factor stage, reverse (per channel) + final K_bar assembly.
 // =============================================================================================
 struct FactBwdArgs {
-    int b_global, m, L, geco, kl_form;
+    int b_global, m, L, geco, kl_form, P;
     real c, N_train;
     const real* state;
     const real* K; const real* Ki; const real* S; const real* v; const real* Si; const real* t; const real* G;
@@ -804,13 +822,30 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     real* Kb = a.Kbar_part + om;
     real* Kib = a.Kibar_part + om;
 
+    const size_t sM = (size_t)a.L * m * m, sV = (size_t)a.L * m;     // strides between row partials
     mat_load(R0, ld, a.Ki, m);
-    mat_load(R1, ld, a.S + om, m);
+    // S and A2 are needed twice each; for m <= 32 (<= 4 elements per thread) their partial sums stay in registers
+    const bool keep = m * m <= 4 * (int)blockDim.x;
+    real kS[4] = {0, 0, 0, 0}, kA2[4] = {0, 0, 0, 0};
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = threadIdx.x + k * blockDim.x;
+            if (o < m * m) {
+                kS[k] = part_sum(a.S + om + o, sM, a.P);
+                kA2[k] = part_sum(a.A2 + om + o, sM, a.P);
+                R1[(o / m) * ld + (o % m)] = kS[k];
+            }
+        }
+    } else {
+        for (int o = threadIdx.x; o < m * m; o += blockDim.x) R1[(o / m) * ld + (o % m)] = part_sum(a.S + om + o, sM, a.P);
+    }
     if (threadIdx.x < m) {
         muv[threadIdx.x] = a.mu[ov + threadIdx.x];
-        ubar[threadIdx.x] = a.ud[ov + threadIdx.x] + (a.kl_form ? real(0) : real(0.5) * gK * muv[threadIdx.x]);
+        ubar[threadIdx.x] = part_sum(a.ud + ov + threadIdx.x, sV, a.P) +
+                            (a.kl_form ? real(0) : real(0.5) * gK * muv[threadIdx.x]);
         tv[threadIdx.x] = a.t[ov + threadIdx.x];
-        vv[threadIdx.x] = a.v[ov + threadIdx.x];
+        vv[threadIdx.x] = part_sum(a.v + ov + threadIdx.x, sV, a.P);
     }
     __syncthreads();
     mat_vec(mubar, R0, ld, ubar, m, real(1));                       // Ki ubar
@@ -832,8 +867,15 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     __syncthreads();
     for (int o = threadIdx.x; o < m * m; o += blockDim.x) {         // Kibar_l
         const int i = o / m, j = o % m, idx = i * ld + j;
-        Kib[o] = -g3 * R0[idx] + real(0.5) * gK * R1[idx] + ubar[i] * muv[j] + real(0.5) * g3 * a.S[om + o] -
-                 a.A2[om + o];
+        real sS, sA2;
+        if (keep) {
+            const int k = o / (int)blockDim.x;
+            sS = k == 0 ? kS[0] : k == 1 ? kS[1] : k == 2 ? kS[2] : kS[3];
+            sA2 = k == 0 ? kA2[0] : k == 1 ? kA2[1] : k == 2 ? kA2[2] : kA2[3];
+        } else {
+            sS = part_sum(a.S + om + o, sM, a.P); sA2 = part_sum(a.A2 + om + o, sM, a.P);
+        }
+        Kib[o] = -g3 * R0[idx] + real(0.5) * gK * R1[idx] + ubar[i] * muv[j] + real(0.5) * g3 * sS - sA2;
     }
     __syncthreads();
     if (a.kl_form) {
@@ -863,7 +905,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     if (threadIdx.x < m) {
         real acc = 0;
         for (int j = 0; j < m; ++j) acc += R0[threadIdx.x * ld + j] * mubar[j];
-        tbar[threadIdx.x] = a.td[ov + threadIdx.x] + a.c * acc;
+        tbar[threadIdx.x] = part_sum(a.td + ov + threadIdx.x, sV, a.P) + a.c * acc;
     }
     __syncthreads();
     mat_load(R2, ld, a.Si + om, m);
@@ -873,7 +915,14 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     __syncthreads();
     for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
         const int i = o / m, j = o % m;
-        R3[i * ld + j] += a.A2[om + o] + tbar[i] * vv[j];           // Sibar
+        real sA2;
+        if (keep) {
+            const int k = o / (int)blockDim.x;
+            sA2 = k == 0 ? kA2[0] : k == 1 ? kA2[1] : k == 2 ? kA2[2] : kA2[3];
+        } else {
+            sA2 = part_sum(a.A2 + om + o, sM, a.P);
+        }
+        R3[i * ld + j] += sA2 + tbar[i] * vv[j];                    // Sibar
         Kb[o] += a.c * mubar[i] * tv[j];
     }
     if (threadIdx.x < m) {                                          // vbar = Si tbar
@@ -1133,13 +1182,14 @@ static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     const int m = c->m;
     const int mp_ = (m + 15) & ~15;
     a.rc_rows = (8192 / (mp_ + 2)) & ~3;        // <= 64 KB tile of K_nm rows per pass, multiple of 4
-    if (a.rc_rows > ((c->b + 3) & ~3)) a.rc_rows = (c->b + 3) & ~3;
+    const int P = svgp_stat_parts(c), RPh = ((c->b + P - 1) / P + 3) & ~3;
+    if (a.rc_rows > RPh) a.rc_rows = RPh;
     size_t lds = (size_t)(a.rc_rows * (mp_ + 2) + 3 * a.rc_rows + 2 * SVGP_BLOCK) * sizeof(real);
     const size_t lds_inv = mat_lds(m, 1) + (size_t)(5 * m + 80) * sizeof(real);
     if ((mode == 0 || with_aji) && lds_inv > lds) lds = lds_inv;
     int rc = set_dyn_lds(k_gp_stats, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gp_stats, dim3(1, c->L + (mode == 0 ? 1 : (with_aji ? c->L : 0))), dim3(SVGP_BLOCK), lds,
+    hipLaunchKernelGGL(k_gp_stats, dim3(P, c->L + (mode == 0 ? 1 : (with_aji ? c->L : 0))), dim3(SVGP_BLOCK), lds,
                        (hipStream_t)stream, a);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
@@ -1182,7 +1232,7 @@ static int factor_fwd_impl(const svgp_mnist_cfg* c, double* ws, int defer_aji, v
     SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
     if (c->m > SVGP_M_MAX) return svgp_big_factor_fwd(c, wl, ws, stream);
     FactArgs a;
-    a.defer_aji = defer_aji; a.kl_form = c->kl_form;
+    a.defer_aji = defer_aji; a.kl_form = c->kl_form; a.P = svgp_stat_parts(c);
     a.b = c->b; a.m = c->m; a.L = c->L; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;
     a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.ldK = ws + wl.ldK; a.S = ws + wl.S; a.v = ws + wl.v; a.Kn = ws + wl.Kn;
     a.Si = ws + wl.Si; a.t = ws + wl.t; a.G = ws + wl.G; a.A = ws + wl.A; a.Aji = ws + wl.Aji; a.mu = ws + wl.mu_hat;
@@ -1220,7 +1270,7 @@ extern "C" int svgp_gp_posterior_fwd(const svgp_mnist_cfg* c, const double* eps,
 
 static FactBwdArgs make_fb(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state) {
     FactBwdArgs a;
-    a.b_global = c->b_global; a.m = c->m; a.L = c->L; a.geco = SVGP_LOSS_FLAGS(c); a.kl_form = c->kl_form; a.c = c->N_train / (double)c->b_global;
+    a.b_global = c->b_global; a.m = c->m; a.L = c->L; a.geco = SVGP_LOSS_FLAGS(c); a.kl_form = c->kl_form; a.P = svgp_stat_parts(c); a.c = c->N_train / (double)c->b_global;
     a.N_train = c->N_train; a.state = state;
     a.K = ws + wl.K; a.Ki = ws + wl.Ki; a.S = ws + wl.S; a.v = ws + wl.v; a.Si = ws + wl.Si; a.t = ws + wl.t;
     a.G = ws + wl.G; a.A = ws + wl.A; a.Aji = ws + wl.Aji; a.mu = ws + wl.mu_hat; a.u = ws + wl.u; a.M2 = ws + wl.M2;

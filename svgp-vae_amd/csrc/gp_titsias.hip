@@ -241,7 +241,7 @@ extern "C" int svgp_gp_titsias_bwd(const svgp_mnist_cfg* c, double* ws, const do
                        ws + wl.qnet_var, U, ws + wl.tit_t, W, cA, cB, ws + wl.Knbar, ws + wl.knnbar);
     SVGP_LAUNCH_CHECK();
     // Kbar += sum_l Sb_l + g2/2 (L Ki - Ki (sum_l S_l) Ki)
-    hipLaunchKernelGGL(k_tit_sum_l, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, ws + wl.S, Ssum);
+    hipLaunchKernelGGL(k_tit_sum_l, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L * svgp_stat_parts(c), ws + wl.S, Ssum);   // sum over channels and row partials
     SVGP_LAUNCH_CHECK();
     RUNC(svgp_dgemm_batched(0, 0, m, m, m, 1.0, ws + wl.Ki, m, 0, Ssum, m, 0, 0.0, T1, m, 0, 1, stream));
     RUNC(svgp_dgemm_batched(0, 0, m, m, m, 1.0, T1, m, 0, ws + wl.Ki, m, 0, 0.0, T2, m, 0, 1, stream));

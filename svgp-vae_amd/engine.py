@@ -215,7 +215,12 @@ class MnistStepEngine:
         self.stream.synchronize()
 
     def ws_view(self, name, shape=None):
+        """View of a workspace field.  The statistics fields S, v, A2, ud, td are stored as wl.stat_parts row partials;
+        with a shape given, their sum (= the statistic itself) is returned."""
         off = getattr(self.wl, name)
+        if shape is not None and name in ("S", "v", "A2", "ud", "td") and self.wl.stat_parts > 1:
+            n, P = int(np.prod(shape, dtype=np.int64)), int(self.wl.stat_parts)
+            return self.ws[off:off + P * n].view(P, *shape).sum(0)
         if shape is None:
             length = getattr(self.wl, name + "_len")
             return self.ws[off:off + length]

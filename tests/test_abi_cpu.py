@@ -50,10 +50,18 @@ def test_layouts_match_reference_parameter_count_and_are_disjoint():
     cfg_t = _lib.MnistCfg(b=256, b_global=256, m=32, L=16, M=8, n_obj=400, N_train=4050.0, jitter=1e-6, titsias=1)
     wt = _lib.WsLayout()
     _lib.call("svgp_mnist_ws_layout_get", C.byref(cfg_t), C.byref(wt))
-    assert wt.statA_len == 2 * 16 * 32 * 33 and wt.tit_S2 == wt.v + 16 * 32 and wt.tit_v2 == wt.tit_S2 + 16 * 32 * 32
+    P = wl.stat_parts                       # row partials of the statistics blocks (b_cap >= 128, m <= 64)
+    assert P == 4 and wt.stat_parts == 4
+    assert wt.statA_len == (P + 1) * 16 * 32 * 33 and wt.tit_S2 == wt.v + P * 16 * 32 and wt.tit_v2 == wt.tit_S2 + 16 * 32 * 32
     assert wt.tit_scal + 2 * 16 + 1 <= wt.total and wt.total > wl.total
-    assert wl.statA == wl.S and wl.v == wl.S + 16 * 32 * 32 and wl.statA_len == 16 * 32 * 33
-    assert wl.statB_len == 16 * 32 * 34 and wl.gradC_len == 9243 + 8 and wl.sums == wl.grad + 9243
+    assert wl.statA == wl.S and wl.v == wl.S + P * 16 * 32 * 32 and wl.statA_len == P * 16 * 32 * 33
+    assert wl.statB_len == P * 16 * 32 * 34 and wl.gradC_len == 9243 + 8 and wl.sums == wl.grad + 9243
+    small = _lib.MnistCfg(b=64, b_global=64, m=32, L=16, M=8, n_obj=400, N_train=4050.0, jitter=1e-6)
+    big_m = _lib.MnistCfg(b=256, b_global=256, m=72, L=16, M=16, n_obj=400, N_train=4050.0, jitter=1e-6)
+    for c_ in (small, big_m):               # few rows / the global-memory path: one block
+        w_ = _lib.WsLayout()
+        _lib.call("svgp_mnist_ws_layout_get", C.byref(c_), C.byref(w_))
+        assert w_.stat_parts == 1
 
 
 def test_bad_shapes_are_rejected_with_a_message():

@@ -316,6 +316,12 @@ int svgp_stream_stats_f32(int64_t n, int m, int L, const float* K_nm, const floa
 int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
                        long long strideA, const double* B, int ldb, long long strideB, double beta, double* C,
                        int ldc, long long strideC, int batch, void* stream);
+/* one GEMM with few output tiles and a long contraction (dense layers / their weight gradients): K is cut into slices
+ * that run as a batch into partial products in `scratch` (svgp_dgemm_splitk_scratch_elems doubles, 0 = no split) and
+ * are added in fixed order; same operand conventions as svgp_dgemm_batched with batch 1 */
+long long svgp_dgemm_splitk_scratch_elems(int M, int N, int K);
+int svgp_dgemm_splitk(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda, const double* B,
+                      int ldb, double beta, double* C, int ldc, double* scratch, long long scratch_elems, void* stream);
 size_t svgp_spd_inverse_workspace_elems(int m, int batch);
 int svgp_spd_inverse_batched(int m, int batch, double* A, double* logdet, double* work, void* stream);
 
@@ -397,7 +403,7 @@ int svgp_clip_by_value(long long tot, double thr, double* g, void* stream);
  * svgp_se1d_kernel_matrix_fwd/bwd: tfk.ExponentiatedQuadratic(amplitude=None, length_scale) on scalar inputs (:60,
  *   :80-86): K (m,m), Kn (T,m), knn (T) = 1 from times x (T), inducing points z (m), *ls; VJP -> d_z (m), d_ls (1).
  * svgp_bias_act_fwd / svgp_act_bwd_bias: x = act(x + bias) in place (act 0 none, 1 tanh); dpre = dout act'(out) in
- *   place and db = column sums, part = svgp_act_bwd_bias_scratch_elems(C) doubles - the layers of
+ *   place and db = column sums (one launch, fixed summation order; `part` is unused and may be NULL) - the layers of
  *   build_MLP_inference_graph / build_MLP_decoder_graph (VAE_utils.py:9-96); the matmuls are svgp_dgemm_batched.
  * svgp_ball_head_fwd/bwd: h (B*T,4) + bias -> qnet_mu, exp, clip [1e-6,1e3] (VAE_utils.py:50-55, SVGPVAE_model.py:
  *   670-671) written in the (T,B) channel layout of the x / y workspaces; reverse through exp and the clip mask.

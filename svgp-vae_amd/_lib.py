@@ -119,6 +119,8 @@ SIGNATURES = {
     "svgp_dgemm_batched": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.c_int, C.c_longlong, _P,
                            C.c_int, C.c_longlong, C.c_double, _P, C.c_int, C.c_longlong, C.c_int, _P],
     "svgp_spd_inverse_batched": [C.c_int, C.c_int, _P, _P, _P, _P],
+    "svgp_dgemm_splitk": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.c_int, _P, C.c_int, C.c_double, _P,
+                          C.c_int, _P, C.c_longlong, _P],
     "svgp_conv_taps_fwd": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P],
     "svgp_conv_taps_wgrad": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P],
     "svgp_elu_bwd_bias": [C.c_longlong, C.c_int, _P, _P, _P, _P, _P],
@@ -179,6 +181,7 @@ NON_STATUS = {"svgp_version": ([], C.c_int), "svgp_last_error": ([], C.c_char_p)
               "svgp_stream_stats_workspace_elems": ([C.c_int64, C.c_int, C.c_int], C.c_int64),
               "svgp_spd_inverse_workspace_elems": ([C.c_int, C.c_int], C.c_size_t),
               "svgp_act_bwd_bias_scratch_elems": ([C.c_int], C.c_int),
+              "svgp_dgemm_splitk_scratch_elems": ([C.c_int, C.c_int, C.c_int], C.c_longlong),
               "svgp_svigp_workspace_elems": ([C.c_int, C.c_int, C.c_int], C.c_longlong),
               "svgp_svigp_scale_offset": ([C.c_int, C.c_int, C.c_int], C.c_longlong)}
 

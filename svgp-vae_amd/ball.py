@@ -172,6 +172,7 @@ class _BallMlpEngine:
                                                      dtype=_F64).reshape(s))
         self.state = torch.zeros(STATE_LEN, **f64)
         self.out = torch.zeros(len(OUT_ROWS), batch, **f64)
+        self._gemm_scratch = torch.empty(0, **f64)
         self.part = torch.zeros(int(self.lib.svgp_act_bwd_bias_scratch_elems(max(self.P, hidden))), **f64)
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         st = torch.zeros(STATE_LEN, dtype=_F64)
@@ -182,8 +183,12 @@ class _BallMlpEngine:
         self.act = {}
 
     def _gemm(self, ta, tb, M, N, K, A, lda, Bm, ldb, Cm, ldc):
-        call("svgp_dgemm_batched", ta, tb, M, N, K, 1.0, A.data_ptr(), lda, 0, Bm.data_ptr(), ldb, 0, 0.0, Cm.data_ptr(),
-             ldc, 0, 1, self.stream.cuda_stream)
+        """Dense-layer GEMM; few output tiles + long contraction -> split-K (svgp_dgemm_splitk)."""
+        need = int(self.lib.svgp_dgemm_splitk_scratch_elems(M, N, K))
+        if self._gemm_scratch.numel() < need:                           # grows once, at the first step
+            self._gemm_scratch = torch.empty(need, dtype=_F64, device=self.dev)
+        call("svgp_dgemm_splitk", ta, tb, M, N, K, 1.0, A.data_ptr(), lda, Bm.data_ptr(), ldb, 0.0, Cm.data_ptr(), ldc,
+             self._gemm_scratch.data_ptr(), self._gemm_scratch.numel(), self.stream.cuda_stream)
 
     def scalars(self):
         self.stream.synchronize()

@@ -72,27 +72,30 @@ __global__ void k_bias_act(long long tot, int C, int act, const real* __restrict
     const real v = x[i] + bias[i % C];
     x[i] = act == 1 ? tanh(v) : v;
 }
-// grid (ceil(C/256), NCH): thread = column, rows strided by NCH; part (NCH, C)
-#define ACT_NCH 32
+// one workgroup per 16-column tile over ALL rows: thread = (column c16, row lane rl of 16); the 16 row lanes are added
+// through LDS in fixed order, so the column sums need no partial buffer and no second launch
 __global__ __launch_bounds__(256) void k_act_bwd_colsum(int rows, int C, int act, const real* __restrict__ out,
-                                                        real* __restrict__ dout, real* __restrict__ part) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+                                                        real* __restrict__ dout, real* __restrict__ db) {
+    __shared__ real sh[16][17];
+    const int c16 = threadIdx.x & 15, rl = threadIdx.x >> 4, c = blockIdx.x * 16 + c16;
     real s = 0;
-    for (int r = blockIdx.y; r < rows; r += gridDim.y) {
-        const size_t o = (size_t)r * C + c;
-        real dv = dout[o];
-        if (act == 1) { const real ov = out[o]; dv *= (real(1) - ov * ov); dout[o] = dv; }
-        s += dv;
+    if (c < C) {
+#pragma unroll 4
+        for (int r = rl; r < rows; r += 16) {
+            const size_t o = (size_t)r * C + c;
+            real dv = dout[o];
+            if (act == 1) { const real ov = out[o]; dv *= (real(1) - ov * ov); dout[o] = dv; }
+            s += dv;
+        }
     }
-    part[(size_t)blockIdx.y * C + c] = s;
-}
-__global__ void k_colsum_final(int C, int nch, const real* __restrict__ part, real* __restrict__ db) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    real s = 0;
-    for (int g = 0; g < nch; ++g) s += part[(size_t)g * C + c];
-    db[c] = s;
+    sh[rl][c16] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        real t = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sh[k][c16];
+        db[c] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -265,27 +268,42 @@ struct PearceArgs {
     int accumulate;                              // reverse: add into ybar / s2bar (context sets) instead of writing
 };
 
-// in-place Gauss-Jordan inverse of an SPD n x n LDS matrix (leading dimension ld), no pivoting; returns log det
-__device__ real lds_spd_inverse(real* A, int ld, int n, real* colbuf, real* red) {
+// Thread layout of the T x T work below (256 threads), CW = 32 (n <= 32) or 64 columns: column j = tid & (CW-1), row
+// lane i0 = tid / CW of RL = 256 / CW; a thread owns the elements (i0 + RL r, j).  No integer division in the loops.
+#define PEARCE_IJ for (int i = i0; i < n; i += RL) if (j < n)
+
+// in-place Gauss-Jordan inverse of an SPD n x n LDS matrix (leading dimension ld, n <= 64), no pivoting; returns log det
+template <int CW>
+__device__ real lds_spd_inverse(real* A, int ld, int n, real* pivbuf) {
+    constexpr int RL = 256 / CW, RMAX = CW / RL;
+    const int j = threadIdx.x & (CW - 1), i0 = threadIdx.x / CW;
     real logdet = 0;
     for (int k = 0; k < n; ++k) {
         __syncthreads();
-        const real piv = A[k * ld + k];
-        for (int i = threadIdx.x; i < n; i += blockDim.x) colbuf[i] = A[i * ld + k];
+        const real piv = A[k * ld + k], ip = real(1) / piv;
+        const real rowk = j < n ? A[k * ld + j] : real(0);
+        real f[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) { const int i = i0 + RL * r; f[r] = i < n ? A[i * ld + k] * ip : real(0); }
+        if (threadIdx.x == 0) pivbuf[k] = piv;           // the logs are taken once, in parallel, after the sweep
         __syncthreads();
-        logdet += log(piv);
-        const real ip = real(1) / piv;
-        for (int o = threadIdx.x; o < n * n; o += blockDim.x) {
-            const int i = o / n, j = o % n;
-            if (i == k) continue;
-            const real f = colbuf[i] * ip;
-            A[i * ld + j] = (j == k) ? -f : A[i * ld + j] - f * A[k * ld + j];
+        if (j < n) {
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r) {
+                const int i = i0 + RL * r;
+                if (i < n && i != k) A[i * ld + j] = (j == k) ? -f[r] : A[i * ld + j] - f[r] * rowk;
+            }
+            if (i0 == 0) A[k * ld + j] = (j == k) ? ip : rowk * ip;
         }
-        __syncthreads();
-        for (int j = threadIdx.x; j < n; j += blockDim.x) A[k * ld + j] = (j == k) ? ip : A[k * ld + j] * ip;
     }
     __syncthreads();
-    (void)red;
+    if (threadIdx.x < 64) {                              // n <= 64: one wave, fixed-order shuffle sum
+        const real lg = wave_sum((int)threadIdx.x < n ? log(pivbuf[threadIdx.x]) : real(0));
+        if (threadIdx.x == 0) pivbuf[0] = lg;
+    }
+    __syncthreads();
+    logdet = pivbuf[0];
+    __syncthreads();
     return logdet;
 }
 
@@ -297,32 +315,33 @@ __device__ __forceinline__ size_t pearce_elem(const PearceArgs& a, int b, int i)
     return (size_t)t * a.B + b;
 }
 
+template <int CW>
 __global__ __launch_bounds__(256) void k_pearce_fwd(PearceArgs a) {
     extern __shared__ __align__(16) real smem[];
+    constexpr int RL = 256 / CW;
     const int b = blockIdx.x, c = blockIdx.y, n = a.n, ld = n + 1;
+    const int j = threadIdx.x & (CW - 1), i0 = threadIdx.x / CW;
     real* K = smem;               // n x ld
     real* A = K + n * ld;         // -> Ai
     real* W = A + n * ld;         // Ai K
     real* yv = W + n * ld;        // n
     real* al = yv + n;            // n
     real* tv = al + n;            // n
-    real* col = tv + n;           // n
-    real* red = col + n;          // 16
+    real* red = tv + n;           // 16
     const real l = *a.ls[c], il2 = real(-0.5) / (l * l);
     for (int i = threadIdx.x; i < n; i += blockDim.x) { tv[i] = pearce_time(a, b, i); yv[i] = a.y[c][pearce_elem(a, b, i)]; }
     __syncthreads();
-    for (int o = threadIdx.x; o < n * n; o += blockDim.x) {
-        const int i = o / n, j = o % n;
+    PEARCE_IJ {
         const real d = tv[i] - tv[j], k = exp(d * d * il2);
         K[i * ld + j] = k;
         A[i * ld + j] = k + (i == j ? a.s2[c][pearce_elem(a, b, i)] : real(0));
     }
-    const real logdet = lds_spd_inverse(A, ld, n, col, red);
+    const real logdet = lds_spd_inverse<CW>(A, ld, n, al);       // al (n reals) is free until alpha is formed
     const size_t om = ((size_t)c * a.B + b) * n * n, ov = ((size_t)c * a.B + b) * n;
-    for (int o = threadIdx.x; o < n * n; o += blockDim.x) a.Ai[om + o] = A[(o / n) * ld + (o % n)];
+    PEARCE_IJ a.Ai[om + (size_t)i * n + j] = A[i * ld + j];
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         real s = 0;
-        for (int j = 0; j < n; ++j) s += A[i * ld + j] * yv[j];
+        for (int k = 0; k < n; ++k) s += A[i * ld + k] * yv[k];
         al[i] = s; a.alpha[ov + i] = s;
     }
     __syncthreads();
@@ -331,8 +350,7 @@ __global__ __launch_bounds__(256) void k_pearce_fwd(PearceArgs a) {
     quad = block_sum(quad, red);
     if (threadIdx.x == 0) a.lh[c * a.B + b] = real(-0.5) * ((real)n * real(SVGP_LOG_2PI) + quad + logdet);
     if (a.idx) return;                                            // context likelihood only
-    for (int o = threadIdx.x; o < n * n; o += blockDim.x) {       // W = Ai K
-        const int i = o / n, j = o % n;
+    PEARCE_IJ {                                                   // W = Ai K
         real s = 0;
         for (int k = 0; k < n; ++k) s += A[i * ld + k] * K[k * ld + j];
         W[i * ld + j] = s;
@@ -358,9 +376,12 @@ __global__ __launch_bounds__(256) void k_pearce_fwd(PearceArgs a) {
 }
 
 // reverse of k_pearce_fwd.  gT = d loss / d (prior-KL term) = -beta / B.
+template <int CW>
 __global__ __launch_bounds__(256) void k_pearce_bwd(PearceArgs a) {
     extern __shared__ __align__(16) real smem[];
+    constexpr int RL = 256 / CW;
     const int b = blockIdx.x, c = blockIdx.y, n = a.n, ld = n + 1;
+    const int j = threadIdx.x & (CW - 1), i0 = threadIdx.x / CW;
     real* K = smem;
     real* Ai = K + n * ld;
     real* M = Ai + n * ld;        // K diag(g_pv) K, then Ai M Ai
@@ -368,11 +389,11 @@ __global__ __launch_bounds__(256) void k_pearce_bwd(PearceArgs a) {
     real* al = W + n * ld;        // n
     real* gpm = al + n;
     real* gpv = gpm + n;
-    real* u = gpv + n;            // K g_pm, then w = Ai K g_pm
+    real* u = gpv + n;            // K g_pm
     real* tv = u + n;
     real* red = tv + n;           // 16
     const real gT = svgp_seed_T(0, a.B, a.state), gl = gT * a.seed_lh_scale;
-    const real l = *a.ls[c], il2 = real(-0.5) / (l * l);
+    const real l = *a.ls[c], il2 = real(-0.5) / (l * l), il3 = real(1) / (l * l * l);
     const size_t om = ((size_t)c * a.B + b) * n * n, ov = ((size_t)c * a.B + b) * n;
     const bool full = a.idx == nullptr;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -388,52 +409,43 @@ __global__ __launch_bounds__(256) void k_pearce_bwd(PearceArgs a) {
         gpm[i] = g_m; gpv[i] = g_v;
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < n * n; o += blockDim.x) {
-        const int i = o / n, j = o % n;
+    PEARCE_IJ {
         const real d = tv[i] - tv[j];
         K[i * ld + j] = exp(d * d * il2);
-        Ai[i * ld + j] = a.Ai[om + o];
+        Ai[i * ld + j] = a.Ai[om + (size_t)i * n + j];
     }
     __syncthreads();
+    real dl = 0;
     if (full) {
         for (int i = threadIdx.x; i < n; i += blockDim.x) {
             real s = 0;
-            for (int j = 0; j < n; ++j) s += K[i * ld + j] * gpm[j];
+            for (int k = 0; k < n; ++k) s += K[i * ld + k] * gpm[k];
             u[i] = s;
         }
-        for (int o = threadIdx.x; o < n * n; o += blockDim.x) {
-            const int i = o / n, j = o % n;
+        PEARCE_IJ {
             real s = 0, w = 0;
             for (int t = 0; t < n; ++t) { s += K[i * ld + t] * gpv[t] * K[t * ld + j]; w += Ai[i * ld + t] * K[t * ld + j]; }
             M[i * ld + j] = s; W[i * ld + j] = w;
         }
         __syncthreads();
-        // K-bar (direct part) needs Ai K: fold it into the length-scale sum now, then reuse W for Ai M
-        // dl += sum_ij (g_pm_i alpha_j - 2 (Ai K)_ij g_pv_j) K_ij d_ij^2 / l^3   (the Abar part follows below)
-    }
-    real dl = 0;
-    const real il3 = real(1) / (l * l * l);
-    if (full) {
-        for (int o = threadIdx.x; o < n * n; o += blockDim.x) {
-            const int i = o / n, j = o % n;
+        // direct K-bar part folded into the length-scale sum: (g_pm_i alpha_j - 2 (Ai K)_ij g_pv_j) K_ij d_ij^2 / l^3
+        PEARCE_IJ {
             const real d = tv[i] - tv[j];
             dl += (gpm[i] * al[j] - real(2) * W[i * ld + j] * gpv[j]) * K[i * ld + j] * d * d * il3;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {       // w = Ai u
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {       // w = Ai u   (g_pm no longer needed: holds w)
             real s = 0;
-            for (int j = 0; j < n; ++j) s += Ai[i * ld + j] * u[j];
-            gpm[i] = s;                                            // g_pm no longer needed: holds w
+            for (int k = 0; k < n; ++k) s += Ai[i * ld + k] * u[k];
+            gpm[i] = s;
         }
-        for (int o = threadIdx.x; o < n * n; o += blockDim.x) {   // W = Ai M
-            const int i = o / n, j = o % n;
+        PEARCE_IJ {                                               // W = Ai M
             real s = 0;
             for (int t = 0; t < n; ++t) s += Ai[i * ld + t] * M[t * ld + j];
             W[i * ld + j] = s;
         }
         __syncthreads();
-        for (int o = threadIdx.x; o < n * n; o += blockDim.x) {   // M = Ai M Ai
-            const int i = o / n, j = o % n;
+        PEARCE_IJ {                                               // M = Ai M Ai
             real s = 0;
             for (int t = 0; t < n; ++t) s += W[i * ld + t] * Ai[t * ld + j];
             M[i * ld + j] = s;
@@ -441,8 +453,7 @@ __global__ __launch_bounds__(256) void k_pearce_bwd(PearceArgs a) {
         __syncthreads();
     }
     // Abar_ij = gl/2 (alpha_i alpha_j - Ai_ij) - w_i alpha_j + (Ai M Ai)_ij ;  A = K + diag(var)
-    for (int o = threadIdx.x; o < n * n; o += blockDim.x) {
-        const int i = o / n, j = o % n;
+    PEARCE_IJ {
         real ab = real(0.5) * gl * (al[i] * al[j] - Ai[i * ld + j]);
         if (full) ab += M[i * ld + j] - gpm[i] * al[j];
         const real d = tv[i] - tv[j];
@@ -549,16 +560,14 @@ extern "C" int svgp_bias_act_fwd(long long rows, int C, int act, const double* b
 extern "C" int svgp_act_bwd_bias(int rows, int C, int act, const double* out, double* dout, double* part, double* db,
                                  void* stream) {
     SVGP_REQUIRE(rows >= 1 && C >= 1 && (act == 0 || act == 1), SVGP_ERR_INVALID, "bad argument");
-    REQ_PTRS(dout, part, db);
+    REQ_PTRS(dout, db);
     SVGP_REQUIRE(act == 0 || out != nullptr, SVGP_ERR_INVALID, "activation output is NULL");
-    hipLaunchKernelGGL(k_act_bwd_colsum, dim3((C + 255) / 256, ACT_NCH), dim3(256), 0, (hipStream_t)stream, rows, C, act,
-                       out, dout, part);
-    SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_colsum_final, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, C, ACT_NCH, part, db);
+    (void)part;
+    hipLaunchKernelGGL(k_act_bwd_colsum, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, rows, C, act, out, dout, db);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
-extern "C" int svgp_act_bwd_bias_scratch_elems(int C) { return ACT_NCH * C; }
+extern "C" int svgp_act_bwd_bias_scratch_elems(int C) { (void)C; return 1; }   // the single-launch form needs none
 
 extern "C" int svgp_ball_head_fwd(int B, int T, int clip, const double* bias, const double* h, double* mu_x,
                                   double* var_raw_x, double* var_x, double* mu_y, double* var_raw_y, double* var_y,
@@ -701,10 +710,16 @@ extern "C" int svgp_pearce_gp_fwd(const svgp_pearce_bufs* q, const double* eps_x
         SVGP_REQUIRE((eps_x == nullptr) == (eps_y == nullptr), SVGP_ERR_INVALID, "give both eps or neither");
     }
     a.eps_in[0] = eps_x; a.eps_in[1] = eps_y; a.use_rng = eps_x == nullptr; a.state = state;
-    const size_t lds = ((size_t)3 * a.n * (a.n + 1) + 4 * a.n + 16) * sizeof(real);
-    rc = set_lds((const void*)k_pearce_fwd, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_pearce_fwd, dim3(a.B, 2), dim3(256), lds, (hipStream_t)stream, a);
+    const size_t lds = ((size_t)3 * a.n * (a.n + 1) + 3 * a.n + 16) * sizeof(real);
+    if (a.n <= 32) {
+        rc = set_lds((const void*)k_pearce_fwd<32>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_pearce_fwd<32>, dim3(a.B, 2), dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+        rc = set_lds((const void*)k_pearce_fwd<64>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_pearce_fwd<64>, dim3(a.B, 2), dim3(256), lds, (hipStream_t)stream, a);
+    }
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
@@ -720,9 +735,15 @@ extern "C" int svgp_pearce_gp_bwd(const svgp_pearce_bufs* q, double seed_lh_scal
     if (!q->idx) REQ_PTRS(q->p_m_x, q->p_m_y, q->p_v_x, q->p_v_y, q->eps_x, q->eps_y, q->zbar_x, q->zbar_y);
     a.state = state; a.seed_lh_scale = seed_lh_scale; a.accumulate = accumulate;
     const size_t lds = ((size_t)4 * a.n * (a.n + 1) + 5 * a.n + 16) * sizeof(real);
-    rc = set_lds((const void*)k_pearce_bwd, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_pearce_bwd, dim3(a.B, 2), dim3(256), lds, (hipStream_t)stream, a);
+    if (a.n <= 32) {
+        rc = set_lds((const void*)k_pearce_bwd<32>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_pearce_bwd<32>, dim3(a.B, 2), dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+        rc = set_lds((const void*)k_pearce_bwd<64>, lds);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_pearce_bwd<64>, dim3(a.B, 2), dim3(256), lds, (hipStream_t)stream, a);
+    }
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pearce_dl, dim3(1), dim3(64), 0, (hipStream_t)stream, a.B, accumulate, q->dl_part, d_ls_x, d_ls_y);
     SVGP_LAUNCH_CHECK();

@@ -492,6 +492,64 @@ extern "C" int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double al
     return SVGP_OK;
 }
 
+// ---- split-K form for one GEMM with few output tiles and a long contraction (the dense layers of the moving-ball
+// MLPs: 1050 x 1024 x 500 and their weight gradients with K = 1050 rows).  The contraction is cut into S slices that
+// run as the batch dimension of k_dgemm_batched into S partial products in `scratch`; one kernel adds them in fixed
+// order: C = alpha * sum_s P_s + beta * C.  Deterministic (no atomics).
+namespace {
+__global__ void k_splitk_reduce(int M, int N, int S, real alpha, real beta, const real* __restrict__ part,
+                                real* __restrict__ C, int ldc) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long MN = (long long)M * N;
+    if (i >= MN) return;
+    real s = 0;
+    for (int k = 0; k < S; ++k) s += part[(size_t)k * MN + i];
+    real* c = C + (size_t)(i / N) * ldc + (i % N);
+    *c = alpha * s + (beta != real(0) ? beta * *c : real(0));
+}
+// number of K slices: enough workgroups to cover the chip a few times, slices of at least 64
+int splitk_slices(int M, int N, int K) {
+    const long long tiles = (long long)((M + 63) / 64) * ((N + 63) / 64);
+    if (tiles >= 256 || K < 256) return 1;
+    long long s = (512 + tiles - 1) / tiles;
+    if (s > K / 64) s = K / 64;
+    if (s > 32) s = 32;
+    return s < 2 ? 1 : (int)s;
+}
+}  // namespace
+
+extern "C" long long svgp_dgemm_splitk_scratch_elems(int M, int N, int K) {
+    if (M < 0 || N < 0 || K < 0) return -1;
+    const int S = splitk_slices(M, N, K);
+    return S == 1 ? 0 : (long long)(S + 1) * M * N;
+}
+
+extern "C" int svgp_dgemm_splitk(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
+                                 const double* B, int ldb, double beta, double* C, int ldc, double* scratch,
+                                 long long scratch_elems, void* stream) {
+    SVGP_REQUIRE(M >= 0 && N >= 0 && K >= 0, SVGP_ERR_INVALID, "negative dimension");
+    if (M == 0 || N == 0) return SVGP_OK;
+    const int S = splitk_slices(M, N, K);
+    if (S == 1) return svgp_dgemm_batched(ta, tb, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1, stream);
+    SVGP_REQUIRE(scratch && scratch_elems >= (long long)(S + 1) * M * N, SVGP_ERR_INVALID,
+                 "split-K scratch too small: need %lld doubles", (long long)(S + 1) * M * N);
+    const int Kc = (K / S) & ~3, rem = K - S * Kc;          // equal slices (multiple of 4) + one remainder slice
+    const long long sA = ta ? (long long)Kc * lda : Kc, sB = tb ? Kc : (long long)Kc * ldb, MN = (long long)M * N;
+    int rc = svgp_dgemm_batched(ta, tb, M, N, Kc, 1.0, A, lda, sA, B, ldb, sB, 0.0, scratch, N, MN, S, stream);
+    if (rc) return rc;
+    int nparts = S;
+    if (rem > 0) {
+        rc = svgp_dgemm_batched(ta, tb, M, N, rem, 1.0, A + (size_t)S * sA, lda, 0, B + (size_t)S * sB, ldb, 0, 0.0,
+                                scratch + (size_t)S * MN, N, 0, 1, stream);
+        if (rc) return rc;
+        nparts = S + 1;
+    }
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, N, nparts,
+                       alpha, beta, scratch, C, ldc);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
 static size_t inv_ws_inner(int nrows, int batch) { return (size_t)batch * (2 * NB * NB + (size_t)nrows * NB); }
 
 extern "C" size_t svgp_spd_inverse_workspace_elems(int m, int batch) {

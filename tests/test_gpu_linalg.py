@@ -38,6 +38,34 @@ def test_dgemm_batched(ta, tb, M, N, K, batch):
     assert float((Cn - want).abs().max()) <= 1e-12 * K * float(want.abs().max() + 1)
 
 
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(1050, 500, 1024), (500, 1024, 1050), (1024, 500, 1050), (1050, 4, 500), (2, 500, 1050),
+                                   (1050, 2, 500), (300, 300, 1031), (64, 64, 255), (2048, 2048, 512)])
+def test_dgemm_splitk(ta, tb, M, N, K):
+    """One GEMM, K cut into slices + fixed-order reduction; shapes of the moving-ball MLP layers, a contraction that is
+    not a multiple of the slice count, a shape below the split threshold and one with enough tiles not to split."""
+    lib = _lib.load_library()
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N + K)
+    A = torch.randn((K, M) if ta else (M, K), dtype=DT, device="cuda", generator=g)
+    B = torch.randn((N, K) if tb else (K, N), dtype=DT, device="cuda", generator=g)
+    C0 = torch.randn(M, N, dtype=DT, device="cuda", generator=g)
+    need = lib.svgp_dgemm_splitk_scratch_elems(M, N, K)
+    assert (need == 0) == (K < 256 or ((M + 63) // 64) * ((N + 63) // 64) >= 256)
+    scratch = torch.full((max(need, 1),), float("nan"), dtype=DT, device="cuda")
+    want_ab = (A.t() if ta else A) @ (B.t() if tb else B)
+    for alpha, beta in ((0.7, -0.3), (1.0, 0.0)):
+        Cm = C0.clone() if beta != 0 else torch.full((M, N), float("nan"), dtype=DT, device="cuda")
+        _lib.call("svgp_dgemm_splitk", ta, tb, M, N, K, alpha, A.data_ptr(), A.shape[-1], B.data_ptr(), B.shape[-1], beta,
+                  Cm.data_ptr(), N, scratch.data_ptr(), scratch.numel(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want = alpha * want_ab + (beta * C0 if beta != 0 else 0)
+        assert float((Cm - want).abs().max()) <= 1e-12 * K * float(want.abs().max() + 1)
+    if need:
+        with pytest.raises(_lib.SvgpError, match="scratch"):
+            _lib.call("svgp_dgemm_splitk", ta, tb, M, N, K, 1.0, A.data_ptr(), A.shape[-1], B.data_ptr(), B.shape[-1], 0.0,
+                      C0.data_ptr(), N, scratch.data_ptr(), need - 1, None)
+
+
 @pytest.mark.parametrize("m,batch", [(32, 1), (64, 3), (72, 2), (100, 1), (128, 2), (130, 3), (256, 17), (513, 2), (640, 2), (800, 3)])
 def test_spd_inverse_batched(m, batch):
     g = torch.Generator(device="cuda").manual_seed(m)

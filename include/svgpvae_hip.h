@@ -71,7 +71,8 @@ typedef struct {
                            /* has A_hat where mu_hat is meant and reduces over the whole batch of videos (= the L      */
                            /* channels here): KL_l = 1/2 [.. + L tr(K_mm^-1 A_l A_l)], same sum over l as the          */
                            /* reference; the KL field is then [KL (L) | tr(K_mm^-1 A_l A_l) (L)]                       */
-    int32_t reserved_;     /* keeps the doubles 8-byte aligned; must be 0                                             */
+    int32_t single_stat_block; /* 1: the statistics launches write ONE block per channel instead of row partials (set by  */
+                           /* the engines when the batch is sharded over ranks: the blocks are then all-reduced)      */
     double  N_train;       /* mainSVGP.N_train                                                  */
     double  jitter;        /* mainSVGP.jitter                                                   */
     double  kappa_squared; /* GECO kappa^2                                                      */
@@ -101,7 +102,8 @@ typedef struct {
     int64_t K, Kn, knn;                   /* (m,m) (b,m) (b)                                      */
     /* forward statistics: ONE contiguous all-reduce block [S | v] (titsias: [S | v | tit_S2 | tit_v2]).
      * S (P,L,m,m), v (P,L,m) with P = stat_parts ROW PARTIALS (the LDS-resident path splits the rows of every channel
-     * over P workgroups; the statistics are the sums over p, taken by the consumers on load; 1 for m > 64).  The
+     * over P workgroups; the statistics are the sums over p, taken by the consumers on load; 1 for m > 64 and
+     * with cfg.single_stat_block, which the engines set when the blocks travel through an all-reduce).  The
      * backward block [A2 | ud | td] has the same partial structure.  Sums over ranks commute with the sum over p. */
     int64_t statA, statA_len, S, v, stat_parts;
     /* m x m factor stage (SVGPVAE_model.py:239,270-279,319-341) */

@@ -16,7 +16,7 @@ class SvgpError(RuntimeError):
 class MnistCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("b", "b_global", "m", "L", "M", "n_obj", "normalize_obj", "clip_qs",
                                          "geco", "train_ip", "train_gp", "train_ov", "b_cap", "clip_pv", "n_pix",
-                                         "titsias", "kl_form", "reserved_")] + \
+                                         "titsias", "kl_form", "single_stat_block")] + \
                [(n, C.c_double) for n in ("N_train", "jitter", "kappa_squared", "alpha", "rep_weight")]
 
 

@@ -283,7 +283,7 @@ class BallStepEngine(_BallMlpEngine):
         # ---- one GP workspace per latent coordinate: rows = frames, channels = videos (validated before any allocation)
         self.cfg = MnistCfg(b=tmax, b_global=tmax, m=self.m, L=batch, M=1, n_obj=0, normalize_obj=0, clip_qs=0, geco=0,
                             train_ip=1, train_gp=1, train_ov=0, b_cap=tmax, clip_pv=2, n_pix=px * py,
-                            titsias=int(self.titsias), kl_form=1, reserved_=0, N_train=float(tmax),
+                            titsias=int(self.titsias), kl_form=1, single_stat_block=0, N_train=float(tmax),
                             jitter=svgp_x.jitter, kappa_squared=0.0, alpha=0.0, rep_weight=1.0)
         _lib.load_library()
         self.wl = WsLayout()

@@ -76,7 +76,7 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->enc_a1 = take(b * 13 * 13 * 8); o->enc_a2 = take(b * 6 * 6 * 8); o->enc_a3 = take(b * 32);
     o->qnet_mu = take(b * L); o->qnet_var_raw = take(b * L); o->qnet_var = take(b * L);
     o->K = take(m * m); o->Kn = take(b * m); o->knn = take(b);
-    const int64_t P = svgp_stat_parts(&cc);
+    const int64_t P = svgp_stat_parts(c);      // capacity from b_cap
     o->stat_parts = P;
     o->statA = p; o->S = p; p += P * L * m * m; o->v = p; p += P * L * m;
     o->tit_S2 = p; if (c->titsias) p += L * m * m;

@@ -68,11 +68,12 @@ __device__ __forceinline__ real svgp_seed_K(int flags, real gT, real b_over_N) {
 
 // Row partials of the statistics launches (LDS-resident path): the rows of every channel are split over this many
 // workgroups, each writing its own partial block; consumers add the partials on load.  A function of the row CAPACITY
-// (like every offset of the layout).
+// (like every offset of the layout).  One block when the batch is sharded over ranks: the statistics blocks are then
+// all-reduced, and 4x the bytes on the xGMI ring (~+14 us per exchange at 8 GPUs) costs more than the split saves.
 #define SVGP_STAT_PARTS 4
 inline int svgp_stat_parts(const svgp_mnist_cfg* c) {
     const int cap = c->b_cap > 0 ? c->b_cap : c->b;
-    return (c->m <= SVGP_M_MAX && cap >= 128) ? SVGP_STAT_PARTS : 1;
+    return (c->m <= SVGP_M_MAX && cap >= 128 && !c->single_stat_block) ? SVGP_STAT_PARTS : 1;
 }
 
 int svgp_check_cfg(const svgp_mnist_cfg* c);

@@ -129,7 +129,9 @@ class MnistStepEngine:
         self.base = dict(m=m, L=L, M=M, n_obj=n_obj, normalize_obj=int(K_obj_normalize), clip_qs=int(clip_qs),
                          geco=int(geco), titsias=int(titsias), train_ip=int(train_ip), train_gp=int(train_gp), train_ov=int(train_ov),
                          N_train=float(N_train), jitter=float(jitter), kappa_squared=float(kappa_squared),
-                         alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0)
+                         alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0,
+                         # sharded over ranks: the statistics blocks are all-reduced -> one block per channel, not 4 row partials
+                         single_stat_block=int(world_size > 1))
         self.b_max = b_max
         self.cfg = None
         self.pl = ParamLayout()

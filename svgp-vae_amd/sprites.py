@@ -150,7 +150,7 @@ class SpritesStepEngine:
                          train_ip=1, train_gp=1, train_ov=0, b_cap=b_max, clip_pv=1, n_pix=64 * 64 * 3,
                          titsias=int(svgp.titsias),
                          N_train=svgp.N_train, jitter=svgp.jitter, kappa_squared=float(kappa_squared),
-                         alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0)
+                         alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0, single_stat_block=int(world_size > 1))
         self.cfg = MnistCfg(b=b_max, b_global=b_max, **self.base)
         self.wl = WsLayout()
         call("svgp_mnist_ws_layout_get", C.byref(self.cfg), C.byref(self.wl))

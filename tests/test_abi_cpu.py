@@ -58,7 +58,8 @@ def test_layouts_match_reference_parameter_count_and_are_disjoint():
     assert wl.statB_len == P * 16 * 32 * 34 and wl.gradC_len == 9243 + 8 and wl.sums == wl.grad + 9243
     small = _lib.MnistCfg(b=64, b_global=64, m=32, L=16, M=8, n_obj=400, N_train=4050.0, jitter=1e-6)
     big_m = _lib.MnistCfg(b=256, b_global=256, m=72, L=16, M=16, n_obj=400, N_train=4050.0, jitter=1e-6)
-    for c_ in (small, big_m):               # few rows / the global-memory path: one block
+    sharded = _lib.MnistCfg(b=256, b_global=512, m=32, L=16, M=8, n_obj=400, N_train=4050.0, jitter=1e-6, single_stat_block=1)
+    for c_ in (small, big_m, sharded):      # few rows / the global-memory path / blocks that are all-reduced: one block
         w_ = _lib.WsLayout()
         _lib.call("svgp_mnist_ws_layout_get", C.byref(c_), C.byref(w_))
         assert w_.stat_parts == 1

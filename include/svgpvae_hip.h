@@ -351,6 +351,10 @@ int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const double* in, co
                          int nwg, int part_stride, double* dw, int accumulate, void* stream);
 /* dpre = dout * elu'(out) in place on dout (out == NULL: no activation) and db[c] = sum over pixels of dpre;
  * part: (256, C) scratch.                                                                                   */
+/* UpSampling2D(2) + Conv2D 3x3 as four parity classes: effective weights we (2,2,2,2,Ci,Co) from w (3,3,Ci,Co), and the
+ * gradient of w from the gradient of we (VAE_utils.py:317-338 decoder layers) */
+int svgp_upconv_weights(int Ci, int Co, const double* w, double* we, void* stream);
+int svgp_upconv_fold_wgrad(int Ci, int Co, const double* ge, double* g, void* stream);
 int svgp_elu_bwd_bias(long long npix, int C, const double* out, double* dout, double* part, double* db,
                       void* stream);
 

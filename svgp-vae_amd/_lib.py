@@ -124,6 +124,8 @@ SIGNATURES = {
     "svgp_conv_taps_fwd": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P],
     "svgp_conv_taps_wgrad": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P],
     "svgp_elu_bwd_bias": [C.c_longlong, C.c_int, _P, _P, _P, _P, _P],
+    "svgp_upconv_weights": [C.c_int, C.c_int, _P, _P, _P],
+    "svgp_upconv_fold_wgrad": [C.c_int, C.c_int, _P, _P, _P],
     "svgp_sprites_kernel_matrix_fwd": [C.POINTER(SpritesKcfg), _P, _P, _P, _P, _P, _P, _P, _P],
     "svgp_sprites_kernel_matrix_bwd": [C.POINTER(SpritesKcfg)] + [_P] * 13,
     "svgp_sprites_aux_fwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P],

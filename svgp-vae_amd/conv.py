@@ -54,33 +54,26 @@ class ConvLayer:
         self.n_w = k * k * Ci * Co
 
     # ------------------------------------------------------------------ weight re-layouts (O(#weights))
-    def weights_fwd(self, w):
-        """Weights in the layout the forward / weight-gradient descriptors index."""
+    def weights_fwd(self, w, stream=None):
+        """Weights in the layout the forward / weight-gradient descriptors index (svgp_upconv_weights for up layers)."""
         if not self.up:
             return w.contiguous()
-        we = torch.zeros(2, 2, 2, 2, self.Ci, self.Co, dtype=_F64, device=w.device)
-        for py in range(2):
-            for px in range(2):
-                for ky in range(3):
-                    for kx in range(3):
-                        we[py, px, _T(py, ky), _T(px, kx)] += w[ky, kx]
-        return we.contiguous()
+        we = torch.empty(2, 2, 2, 2, self.Ci, self.Co, dtype=_F64, device=w.device)
+        s = torch.cuda.current_stream(w.device).cuda_stream if stream is None else stream
+        call("svgp_upconv_weights", self.Ci, self.Co, w.contiguous().data_ptr(), we.data_ptr(), s)
+        return we
 
-    def weights_bwd(self, w):
+    def weights_bwd(self, w, stream=None):
         """Transposed (Co x Ci per tap) weights for the data gradient."""
-        return self.weights_fwd(w).transpose(-1, -2).contiguous()
+        return self.weights_fwd(w, stream).transpose(-1, -2).contiguous()
 
-    def fold_wgrad(self, gwf):
-        """Gradient in forward layout -> gradient of the raw (k,k,Ci,Co) weights."""
+    def fold_wgrad(self, gwf, stream=None):
+        """Gradient in forward layout -> gradient of the raw (k,k,Ci,Co) weights (svgp_upconv_fold_wgrad for up layers)."""
         if not self.up:
             return gwf.view(self.k, self.k, self.Ci, self.Co)
-        ge = gwf.view(2, 2, 2, 2, self.Ci, self.Co)
-        g = torch.zeros(3, 3, self.Ci, self.Co, dtype=_F64, device=gwf.device)
-        for ky in range(3):
-            for kx in range(3):
-                for py in range(2):
-                    for px in range(2):
-                        g[ky, kx] += ge[py, px, _T(py, ky), _T(px, kx)]
+        g = torch.empty(3, 3, self.Ci, self.Co, dtype=_F64, device=gwf.device)
+        s = torch.cuda.current_stream(gwf.device).cuda_stream if stream is None else stream
+        call("svgp_upconv_fold_wgrad", self.Ci, self.Co, gwf.data_ptr(), g.data_ptr(), s)
         return g
 
     @property
@@ -138,7 +131,7 @@ class ConvLayer:
         n = x.shape[0]
         ds = self.descs_fwd(n)
         arr = (ConvDesc * len(ds))(*ds)
-        wf = self.weights_fwd(w)
+        wf = self.weights_fwd(w, stream)
         call("svgp_conv_taps_fwd", arr, len(ds), x.data_ptr(), wf.data_ptr(), b.data_ptr(), out.data_ptr(), stream)
         return out
 
@@ -155,12 +148,12 @@ class ConvLayer:
         gwf = torch.empty(self.n_wf, dtype=_F64, device=x.device)
         call("svgp_conv_taps_wgrad", arr, len(ds), x.data_ptr(), dout.data_ptr(), part_w.data_ptr(), nwg, self.n_wf,
              gwf.data_ptr(), 0, stream)
-        gw.copy_(self.fold_wgrad(gwf))
+        gw.copy_(self.fold_wgrad(gwf, stream))
         if not need_dx:
             return None
         db = self.descs_bwd_data(n)
         arrb = (ConvDesc * len(db))(*db)
-        wb = self.weights_bwd(w)
+        wb = self.weights_bwd(w, stream)
         if dx is None:
             dx = torch.empty(n, self.Hi, self.Hi, self.Ci, dtype=_F64, device=x.device)
         call("svgp_conv_taps_fwd", arrb, len(db), dout.data_ptr(), wb.data_ptr(), None, dx.data_ptr(), stream)

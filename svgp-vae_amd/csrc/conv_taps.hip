@@ -36,58 +36,112 @@ __device__ __forceinline__ void tap_range(const svgp_conv_desc& d, int& omin_y, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_conv_taps_fwd(ConvLaunch L, const real* __restrict__ in,
+
+// Staging helpers.  The loads of a chunk are all issued before the first LDS store (U independent loads in flight per
+// thread): a workgroup has only 4 waves, so a load-then-store loop would expose one full memory latency per element.
+// Thread = (channel pair, pixel lane); channels of a pixel are contiguous in NHWC, pixels of a tile row as well.
+#define CT_U 8
+// tile[(py * hw + px) * ps + c] = in[hy0 + py][hx0 + px][c]   (zero outside the image / for padded channels)
+__device__ __forceinline__ void stage_halo(real* __restrict__ tile, const real* __restrict__ inn, int Hi, int Wi, int Ci,
+                                           int hy0, int hx0, int hh, int hw, int Ci4, int ps) {
+    const int cp = Ci4 >> 1, npl = (int)blockDim.x / cp;
+    const int c2 = ((int)threadIdx.x % cp) * 2, pl = (int)threadIdx.x / cp, npix = hh * hw;
+    if (pl >= npl) return;
+    const bool pair = (Ci & 1) == 0;              // even channel count: 16-byte aligned pairs
+    for (int p0 = pl; p0 < npix; p0 += npl * CT_U) {
+        real v0[CT_U], v1[CT_U];
+#pragma unroll
+        for (int u = 0; u < CT_U; ++u) {
+            const int p = p0 + u * npl, py = p / hw, px = p - py * hw, gy = hy0 + py, gx = hx0 + px;
+            v0[u] = 0; v1[u] = 0;
+            if (p < npix && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi) {
+                const real* src = inn + ((size_t)gy * Wi + gx) * Ci + c2;
+                if (pair && c2 + 1 < Ci) {
+                    const double2 t = *reinterpret_cast<const double2*>(src);
+                    v0[u] = t.x; v1[u] = t.y;
+                } else {
+                    if (c2 < Ci) v0[u] = src[0];
+                    if (c2 + 1 < Ci) v1[u] = src[1];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CT_U; ++u) {
+            const int p = p0 + u * npl;
+            if (p < npix) { tile[p * ps + c2] = v0[u]; tile[p * ps + c2 + 1] = v1[u]; }
+        }
+    }
+}
+
+// union of the tap ranges of all classes of a launch (they share the staged input tile)
+__device__ __forceinline__ void tap_range_all(const ConvLaunch& L, int& oy0, int& oy1, int& ox0, int& ox1) {
+    tap_range(L.d[0], oy0, oy1, ox0, ox1);
+    for (int c = 1; c < L.ncls; ++c) {
+        int a0, a1, b0, b1;
+        tap_range(L.d[c], a0, a1, b0, b1);
+        oy0 = min(oy0, a0); oy1 = max(oy1, a1); ox0 = min(ox0, b0); ox1 = max(ox1, b1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_conv_taps_fwd(ConvLaunch L, int nchunk, const real* __restrict__ in,
                                                        const real* __restrict__ w, const real* __restrict__ bias,
                                                        real* __restrict__ out) {
     extern __shared__ __align__(16) real smem[];
-    const int cls = blockIdx.z % L.ncls, n = blockIdx.z / L.ncls;
-    const svgp_conv_desc& d = L.d[cls];
+    // The workgroup keeps ONE tile position and walks the images blockIdx.z, blockIdx.z + nchunk, ...: the tap weights of
+    // every class are staged once, and the classes of a launch (the four output parities of an upsample-fused or
+    // stride-2-transposed layer) share one staged input tile per image.
+    const svgp_conv_desc& d = L.d[0];                      // geometry shared by the classes: n, Hs, Ws, sy, sx, input
     const int tiles_x = (d.Ws + CT_TW - 1) / CT_TW;
     const int x0 = (blockIdx.x % tiles_x) * CT_TW, y0 = (blockIdx.x / tiles_x) * CT_TH;
     if (y0 >= d.Hs) return;
     const int Ci4 = (d.Ci + 3) & ~3, ps = Ci4 + 2;         // channels padded to 4, pixel stride
     int oy0, oy1, ox0, ox1;
-    tap_range(d, oy0, oy1, ox0, ox1);
+    tap_range_all(L, oy0, oy1, ox0, ox1);
     const int hy0 = y0 * d.sy + oy0, hx0 = x0 * d.sx + ox0;
     const int hh = (CT_TH - 1) * d.sy + (oy1 - oy0) + 1, hw = (CT_TW - 1) * d.sx + (ox1 - ox0) + 1;
     real* tile = smem;                                     // hh x hw x ps
-    real* wl = tile + hh * hw * ps;                        // nt x Ci4 x 16 (co padded to 16)
-    const real* inn = in + (size_t)n * d.Hi * d.Wi * d.Ci;
-    for (int t = threadIdx.x; t < hh * hw * Ci4; t += blockDim.x) {
-        const int c = t % Ci4, px = (t / Ci4) % hw, py = t / (Ci4 * hw);
-        const int gy = hy0 + py, gx = hx0 + px;
-        real v = 0;
-        if (c < d.Ci && (unsigned)gy < (unsigned)d.Hi && (unsigned)gx < (unsigned)d.Wi)
-            v = inn[((size_t)gy * d.Wi + gx) * d.Ci + c];
-        tile[(py * hw + px) * ps + c] = v;
-    }
-    for (int t = threadIdx.x; t < d.nt * Ci4 * 16; t += blockDim.x) {
-        const int co = t & 15, c = (t >> 4) % Ci4, tp = t / (16 * Ci4);
-        wl[t] = (c < d.Ci && co < d.Co) ? w[d.woff[tp] + c * d.Co + co] : real(0);
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-#pragma unroll 1
-    for (int rr = 0; rr < 2; ++rr) {
-        const int ly = wave * 2 + rr, y = y0 + ly;
-        if (y >= d.Hs) continue;
-        d4c_t acc = {0, 0, 0, 0};
-        for (int tp = 0; tp < d.nt; ++tp) {
-            const real* ap = tile + ((ly * d.sy + d.oy[tp] - oy0) * hw + (r * d.sx + d.ox[tp] - ox0)) * ps + q;
-            const real* bp = wl + (tp * Ci4 + q) * 16 + r;
-            for (int c0 = 0; c0 < Ci4; c0 += 4)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[c0], bp[c0 * 16], acc, 0, 0, 0);
+    real* wl = tile + hh * hw * ps;                        // per class: nt x Ci4 x 16 (co padded to 16), packed
+    int wbase[4] = {0, 0, 0, 0};
+    for (int cls = 0, o = 0; cls < L.ncls; ++cls) {
+        const svgp_conv_desc& dc = L.d[cls];
+        wbase[cls] = o;
+        for (int t = threadIdx.x; t < dc.nt * Ci4 * 16; t += blockDim.x) {
+            const int co = t & 15, c = (t >> 4) % Ci4, tp = t / (16 * Ci4);
+            wl[o + t] = (c < dc.Ci && co < dc.Co) ? w[dc.woff[tp] + c * dc.Co + co] : real(0);
         }
-        // D: column (co) = lane & 15, row (pixel) = q + 4 g
-        const int gy = y * d.osy + d.ooy;
+        o += dc.nt * Ci4 * 16;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    const real bias_r = (d.act && r < d.Co) ? bias[r] : real(0);
+    for (int n = blockIdx.z; n < d.n; n += nchunk) {
+        __syncthreads();                                   // previous image's MFMA reads of `tile` are done
+        stage_halo(tile, in + (size_t)n * d.Hi * d.Wi * d.Ci, d.Hi, d.Wi, d.Ci, hy0, hx0, hh, hw, Ci4, ps);
+        __syncthreads();
+#pragma unroll 1
+        for (int it = 0; it < 2 * L.ncls; ++it) {
+            const int rr = it & 1, cls = it >> 1;
+            const svgp_conv_desc& dc = L.d[cls];
+            const int ly = wave * 2 + rr, y = y0 + ly;
+            if (y >= dc.Hs) continue;
+            const int wb = cls == 0 ? wbase[0] : cls == 1 ? wbase[1] : cls == 2 ? wbase[2] : wbase[3];
+            d4c_t acc = {0, 0, 0, 0};
+            for (int tp = 0; tp < dc.nt; ++tp) {
+                const real* ap = tile + ((ly * d.sy + dc.oy[tp] - oy0) * hw + (r * d.sx + dc.ox[tp] - ox0)) * ps + q;
+                const real* bp = wl + wb + (tp * Ci4 + q) * 16 + r;
+                for (int c0 = 0; c0 < Ci4; c0 += 4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[c0], bp[c0 * 16], acc, 0, 0, 0);
+            }
+            // D: column (co) = lane & 15, row (pixel) = q + 4 g
+            const int gy = y * dc.osy + dc.ooy;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int x = x0 + q + 4 * g;
-            if (x < d.Ws && r < d.Co) {
-                real v = acc[g];
-                if (d.act) v += bias[r];
-                if (d.act == 1) v = v > 0 ? v : exp(v) - real(1);
-                out[(((size_t)n * d.Ho + gy) * d.Wo + (x * d.osx + d.oox)) * d.Co + r] = v;
+            for (int g = 0; g < 4; ++g) {
+                const int x = x0 + q + 4 * g;
+                if (x < dc.Ws && r < dc.Co) {
+                    real v = acc[g];
+                    if (dc.act) v += bias_r;
+                    if (dc.act == 1) v = v > 0 ? v : exp(v) - real(1);
+                    out[(((size_t)n * dc.Ho + gy) * dc.Wo + (x * dc.osx + dc.oox)) * dc.Co + r] = v;
+                }
             }
         }
     }
@@ -122,21 +176,19 @@ __global__ __launch_bounds__(256) void k_conv_taps_wgrad(ConvLaunch L, int nwg, 
         const int hy0 = y0 * d.sy + oy0, hx0 = x0 * d.sx + ox0;
         const real* inn = in + (size_t)n * d.Hi * d.Wi * d.Ci;
         __syncthreads();
-        for (int t = threadIdx.x; t < hh * hw * Ci4; t += blockDim.x) {
-            const int c = t % Ci4, px = (t / Ci4) % hw, py = t / (Ci4 * hw);
-            const int gy = hy0 + py, gx = hx0 + px;
-            real v = 0;
-            if (c < d.Ci && (unsigned)gy < (unsigned)d.Hi && (unsigned)gx < (unsigned)d.Wi)
-                v = inn[((size_t)gy * d.Wi + gx) * d.Ci + c];
-            tile[(py * hw + px) * ps + c] = v;
-        }
-        for (int t = threadIdx.x; t < CT_TH * CT_TW * 16; t += blockDim.x) {
-            const int co = t & 15, px = (t >> 4) % CT_TW, py = t / (16 * CT_TW);
-            const int y = y0 + py, x = x0 + px;
-            real v = 0;
-            if (co < d.Co && y < d.Hs && x < d.Ws)
-                v = dout[(((size_t)n * d.Ho + (y * d.osy + d.ooy)) * d.Wo + (x * d.osx + d.oox)) * d.Co + co];
-            dt[(py * CT_TW + px) * 18 + co] = v;
+        stage_halo(tile, inn, d.Hi, d.Wi, d.Ci, hy0, hx0, hh, hw, Ci4, ps);
+        {   // dout tile: thread = (co, pixel lane of 16), 8 pixels in flight per thread
+            const int co = threadIdx.x & 15, pl = threadIdx.x >> 4;
+            real v[CT_TH];
+#pragma unroll
+            for (int u = 0; u < CT_TH; ++u) {
+                const int p = pl + 16 * u, px = p % CT_TW, py = p / CT_TW, y = y0 + py, x = x0 + px;
+                v[u] = 0;
+                if (co < d.Co && y < d.Hs && x < d.Ws)
+                    v[u] = dout[(((size_t)n * d.Ho + (y * d.osy + d.ooy)) * d.Wo + (x * d.osx + d.oox)) * d.Co + co];
+            }
+#pragma unroll
+            for (int u = 0; u < CT_TH; ++u) dt[(pl + 16 * u) * 18 + co] = v[u];
         }
         __syncthreads();
         // wave w handles taps w, w+4, w+8, w+12 (acc[a] <-> tap w + 4a)
@@ -171,6 +223,32 @@ __global__ __launch_bounds__(256) void k_conv_taps_wgrad(ConvLaunch L, int nwg, 
             }
         }
     }
+}
+
+// UpSampling2D(2) + 3x3 conv as four parity classes: effective weights we[py][px][ty][tx] = sum of the raw taps (ky,kx) that
+// land on low-resolution offset (ty,tx) for output parity (py,px): tap group T(p,k) = (k + p >= 2).  fold = the transpose
+// of that sum (gradient of the raw weights from the gradient of the effective ones).
+__global__ void k_upconv_weff(int cc, const real* __restrict__ w, real* __restrict__ we) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (py,px,ty,tx, ci*co)
+    if (i >= 16 * cc) return;
+    const int e = i % cc, g = i / cc, tx = g & 1, ty = (g >> 1) & 1, px = (g >> 2) & 1, py = g >> 3;
+    real s = 0;
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx)
+            if (((ky + py >= 2) ? 1 : 0) == ty && ((kx + px >= 2) ? 1 : 0) == tx) s += w[(ky * 3 + kx) * cc + e];
+    we[i] = s;
+}
+__global__ void k_upconv_fold(int cc, const real* __restrict__ ge, real* __restrict__ g) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (ky,kx, ci*co)
+    if (i >= 9 * cc) return;
+    const int e = i % cc, k = i / cc, kx = k % 3, ky = k / 3;
+    real s = 0;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            const int ty = (ky + py >= 2) ? 1 : 0, tx = (kx + px >= 2) ? 1 : 0;
+            s += ge[((((py * 2 + px) * 2 + ty) * 2 + tx)) * cc + e];
+        }
+    g[i] = s;
 }
 
 // out[i] (+)= sum_g part[g][i]   (fixed order)
@@ -219,6 +297,18 @@ size_t fwd_lds(const svgp_conv_desc& d) {
     return (size_t)hh * hw * ps;
 }
 
+size_t fwd_lds_all(const svgp_conv_desc* d, int ncls) {      // halo tile over the union of the classes' tap ranges
+    int oy0 = d[0].oy[0], oy1 = oy0, ox0 = d[0].ox[0], ox1 = ox0;
+    for (int c = 0; c < ncls; ++c)
+        for (int t = 0; t < d[c].nt; ++t) {
+            oy0 = oy0 < d[c].oy[t] ? oy0 : d[c].oy[t]; oy1 = oy1 > d[c].oy[t] ? oy1 : d[c].oy[t];
+            ox0 = ox0 < d[c].ox[t] ? ox0 : d[c].ox[t]; ox1 = ox1 > d[c].ox[t] ? ox1 : d[c].ox[t];
+        }
+    const int Ci4 = (d[0].Ci + 3) & ~3, ps = Ci4 + 2;
+    const int hh = (CT_TH - 1) * d[0].sy + (oy1 - oy0) + 1, hw = (CT_TW - 1) * d[0].sx + (ox1 - ox0) + 1;
+    return (size_t)hh * hw * ps;
+}
+
 int check_desc(const svgp_conv_desc* d, int ncls) {
     SVGP_REQUIRE(d && ncls >= 1 && ncls <= 4, SVGP_ERR_INVALID, "need 1..4 conv classes");
     for (int c = 0; c < ncls; ++c) {
@@ -242,20 +332,28 @@ extern "C" int svgp_conv_taps_fwd(const svgp_conv_desc* d, int ncls, const doubl
     SVGP_REQUIRE(in && w && out, SVGP_ERR_INVALID, "NULL device pointer");
     ConvLaunch L;
     L.ncls = ncls;
-    size_t lds = 0;
     for (int c = 0; c < ncls; ++c) {
         L.d[c] = d[c];
         SVGP_REQUIRE(!d[c].act || bias, SVGP_ERR_INVALID, "bias is NULL but act != 0");
-        const size_t e = fwd_lds(d[c]) + (size_t)d[c].nt * ((d[c].Ci + 3) & ~3) * 16;
-        lds = e > lds ? e : lds;
+        SVGP_REQUIRE(d[c].n == d[0].n && d[c].Hs == d[0].Hs && d[c].Ws == d[0].Ws && d[c].sy == d[0].sy &&
+                         d[c].sx == d[0].sx && d[c].Hi == d[0].Hi && d[c].Wi == d[0].Wi && d[c].Ci == d[0].Ci &&
+                         d[c].Co == d[0].Co && d[c].act == d[0].act,
+                     SVGP_ERR_INVALID, "the classes of one launch share the input geometry (n, Hs, Ws, strides, Ci, Co, act)");
     }
+    // union halo tile of all classes + the packed tap weights of every class
+    size_t lds = fwd_lds_all(d, ncls);
+    for (int c = 0; c < ncls; ++c) lds += (size_t)d[c].nt * ((d[0].Ci + 3) & ~3) * 16;
     lds *= sizeof(real);
     SVGP_REQUIRE(lds <= 160 * 1024, SVGP_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
     SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_taps_fwd),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int tiles = ((d[0].Ws + CT_TW - 1) / CT_TW) * ((d[0].Hs + CT_TH - 1) / CT_TH);
-    hipLaunchKernelGGL(k_conv_taps_fwd, dim3(tiles, 1, d[0].n * ncls), dim3(256), lds, (hipStream_t)stream, L, in, w,
-                       bias, out);
+    // enough workgroups for ~8 per CU, each walking n / nchunk images of its tile position
+    int nchunk = (2048 + tiles - 1) / tiles;
+    if (nchunk > d[0].n) nchunk = d[0].n;
+    if (nchunk < 1) nchunk = 1;
+    hipLaunchKernelGGL(k_conv_taps_fwd, dim3(tiles, 1, nchunk), dim3(256), lds, (hipStream_t)stream, L, nchunk, in, w, bias,
+                       out);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
@@ -299,6 +397,23 @@ extern "C" int svgp_elu_bwd_bias(long long npix, int C, const double* out, doubl
     hipLaunchKernelGGL(k_elu_bwd_colsum, dim3(nblk), dim3(256), 0, (hipStream_t)stream, npix, C, out, dout, part);
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, nblk, C, C, part, db, 0);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+// effective weights of an upsample-fused 3x3 convolution (conv.py ConvLayer(up=True)): w (3,3,Ci,Co) -> we (2,2,2,2,Ci,Co);
+// and the gradient of w from the gradient of we
+extern "C" int svgp_upconv_weights(int Ci, int Co, const double* w, double* we, void* stream) {
+    SVGP_REQUIRE(Ci >= 1 && Co >= 1 && w && we, SVGP_ERR_INVALID, "bad argument");
+    const int cc = Ci * Co;
+    hipLaunchKernelGGL(k_upconv_weff, dim3((16 * cc + 255) / 256), dim3(256), 0, (hipStream_t)stream, cc, w, we);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_upconv_fold_wgrad(int Ci, int Co, const double* ge, double* g, void* stream) {
+    SVGP_REQUIRE(Ci >= 1 && Co >= 1 && ge && g, SVGP_ERR_INVALID, "bad argument");
+    const int cc = Ci * Co;
+    hipLaunchKernelGGL(k_upconv_fold, dim3((9 * cc + 255) / 256), dim3(256), 0, (hipStream_t)stream, cc, ge, g);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

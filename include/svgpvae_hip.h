@@ -350,7 +350,7 @@ int svgp_conv_taps_fwd(const svgp_conv_desc* d, int ncls, const double* in, cons
 int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const double* in, const double* dout, double* part,
                          int nwg, int part_stride, double* dw, int accumulate, void* stream);
 /* dpre = dout * elu'(out) in place on dout (out == NULL: no activation) and db[c] = sum over pixels of dpre;
- * part: (256, C) scratch.                                                                                   */
+ * part: (1024, C) scratch.                                                                                  */
 /* UpSampling2D(2) + Conv2D 3x3 as four parity classes: effective weights we (2,2,2,2,Ci,Co) from w (3,3,Ci,Co), and the
  * gradient of w from the gradient of we (VAE_utils.py:317-338 decoder layers) */
 int svgp_upconv_weights(int Ci, int Co, const double* w, double* we, void* stream);

@@ -135,12 +135,12 @@ class ConvLayer:
         call("svgp_conv_taps_fwd", arr, len(ds), x.data_ptr(), wf.data_ptr(), b.data_ptr(), out.data_ptr(), stream)
         return out
 
-    def backward(self, x, w, out, dout, gw, gb, scratch, stream, need_dx=True, dx=None, nwg=256):
+    def backward(self, x, w, out, dout, gw, gb, scratch, stream, need_dx=True, dx=None, nwg=512):
         """dout (n,Ho,Ho,Co) is overwritten with dpre.  gw (k,k,Ci,Co), gb (Co) receive the gradients.
-        scratch: float64 buffer of >= 4*nwg*n_wf + 256*16 elements.  Returns dx (n,Hi,Hi,Ci) or None."""
+        scratch: float64 buffer of >= scratch_elems(nwg) elements.  Returns dx (n,Hi,Hi,Ci) or None."""
         n = x.shape[0]
-        part_b = scratch[:256 * 16]
-        part_w = scratch[256 * 16:]
+        part_b = scratch[:1024 * 16]
+        part_w = scratch[1024 * 16:]
         call("svgp_elu_bwd_bias", n * self.Ho * self.Ho, self.Co, out.data_ptr() if self.elu else None, dout.data_ptr(),
              part_b.data_ptr(), gb.data_ptr(), stream)
         ds = self.descs_fwd(n, act=0)
@@ -159,5 +159,5 @@ class ConvLayer:
         call("svgp_conv_taps_fwd", arrb, len(db), dout.data_ptr(), wb.data_ptr(), None, dx.data_ptr(), stream)
         return dx
 
-    def scratch_elems(self, nwg=256):
-        return 256 * 16 + 4 * nwg * self.n_wf
+    def scratch_elems(self, nwg=512):
+        return 1024 * 16 + 4 * nwg * self.n_wf

@@ -166,10 +166,12 @@ __global__ __launch_bounds__(256) void k_conv_taps_wgrad(ConvLaunch L, int nwg, 
     real* dt = tile + hh * hw * ps;             // CT_TH x CT_TW x 18 (dout tile, co padded to 16)
     real* red = dt + CT_TH * CT_TW * 18;        // 4 waves x 64 lanes x 4  (cross-wave combine)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-    // accumulators: per tap one 16x16 tile (rows ci, cols co); Ci4 <= 16.  Taps are split over the 4 waves.
-    d4c_t acc[4];
+    // accumulators: per tap one 16x16 tile (rows ci, cols co); Ci4 <= 16.  Every wave takes ALL taps of 2 of the 8 tile rows
+    // (balanced for any tap count; the dout fragment of a row is loaded once and reused by every tap); the four waves'
+    // partial tiles are added through LDS once per workgroup, after the last tile.
+    d4c_t acc[CT_MAXT];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) acc[a] = d4c_t{0, 0, 0, 0};
+    for (int a = 0; a < CT_MAXT; ++a) acc[a] = d4c_t{0, 0, 0, 0};
     for (int tl = blockIdx.x; tl < ntile; tl += nwg) {
         const int n = tl / (tiles_x * tiles_y), tt = tl % (tiles_x * tiles_y);
         const int x0 = (tt % tiles_x) * CT_TW, y0 = (tt / tiles_x) * CT_TH;
@@ -191,35 +193,42 @@ __global__ __launch_bounds__(256) void k_conv_taps_wgrad(ConvLaunch L, int nwg, 
             for (int u = 0; u < CT_TH; ++u) dt[(pl + 16 * u) * 18 + co] = v[u];
         }
         __syncthreads();
-        // wave w handles taps w, w+4, w+8, w+12 (acc[a] <-> tap w + 4a)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int tp = wave + 4 * a;
-            if (tp < d.nt) {
-                for (int py = 0; py < CT_TH; ++py) {
+        for (int rr = 0; rr < 2; ++rr) {
+            const int py = wave * 2 + rr;
+            real bv[4];
+#pragma unroll
+            for (int k4 = 0; k4 < 4; ++k4) bv[k4] = dt[(py * CT_TW + 4 * k4 + q) * 18 + r];          // co = r
+#pragma unroll
+            for (int tp = 0; tp < CT_MAXT; ++tp) {
+                if (tp < d.nt) {
                     const real* ap = tile + ((py * d.sy + d.oy[tp] - oy0) * hw + (d.ox[tp] - ox0)) * ps + r;  // ci = r
-                    const real* bp = dt + (py * CT_TW) * 18 + r;                                              // co = r
 #pragma unroll
-                    for (int px0 = 0; px0 < CT_TW; px0 += 4) {
-                        const real av = (r < Ci4) ? ap[((px0 + q) * d.sx) * ps] : real(0);
-                        const real bv = bp[(px0 + q) * 18];
-                        acc[a] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[a], 0, 0, 0);
+                    for (int k4 = 0; k4 < 4; ++k4) {
+                        const real av = (r < Ci4) ? ap[((4 * k4 + q) * d.sx) * ps] : real(0);
+                        acc[tp] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[k4], acc[tp], 0, 0, 0);
                     }
                 }
             }
         }
     }
-    (void)red;
-    // D: col (co) = r, row (ci) = q + 4 g
+    // cross-wave combine (fixed order) and store.  D: col (co) = r, row (ci) = q + 4 g
     real* po = part + ((size_t)cls * nwg + blockIdx.x) * part_stride;
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const int tp = wave + 4 * a;
+    for (int tp = 0; tp < CT_MAXT; ++tp) {
         if (tp < d.nt) {
+            __syncthreads();
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ci = q + 4 * g;
-                if (ci < d.Ci && r < d.Co) po[d.woff[tp] + ci * d.Co + r] = acc[a][g];
+            for (int g = 0; g < 4; ++g) red[(wave * 64 + lane) * 4 + g] = acc[tp][g];
+            __syncthreads();
+            if (wave == 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const real t = red[lane * 4 + g] + red[(64 + lane) * 4 + g] + red[(128 + lane) * 4 + g] +
+                                   red[(192 + lane) * 4 + g];
+                    const int ci = q + 4 * g;
+                    if (ci < d.Ci && r < d.Co) po[d.woff[tp] + ci * d.Co + r] = t;
+                }
             }
         }
     }
@@ -262,7 +271,8 @@ __global__ void k_sum_partials(int ng, int len, int stride, const real* __restri
     out[i] = s;
 }
 
-// dpre = dout * elu'(out) in place on dout; also per-block column sums for the bias gradient
+// dpre = dout * elu'(out) in place on dout; also per-block column sums for the bias gradient.  HBM-bound (read out, read
+// dout, write dout): 8 independent element pairs in flight per thread
 __global__ __launch_bounds__(256) void k_elu_bwd_colsum(long long npix, int C, const real* __restrict__ outv,
                                                         real* __restrict__ dout, real* __restrict__ part) {
     __shared__ real sh[256];
@@ -270,11 +280,27 @@ __global__ __launch_bounds__(256) void k_elu_bwd_colsum(long long npix, int C, c
     const int c = threadIdx.x % C, lp = threadIdx.x / C, ppb = blockDim.x / C;
     real s = 0;
     if (lp < ppb) {
-        for (long long p = (long long)blockIdx.x * ppb + lp; p < npix; p += (long long)gridDim.x * ppb) {
-            const size_t o = (size_t)p * C + c;
-            real dv = dout[o];
-            if (outv) { const real ov = outv[o]; dv *= (ov > 0 ? real(1) : ov + real(1)); dout[o] = dv; }
-            s += dv;
+        const long long stride = (long long)gridDim.x * ppb;
+        for (long long p0 = (long long)blockIdx.x * ppb + lp; p0 < npix; p0 += stride * 8) {
+            real dv[8], ov[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long p = p0 + u * stride;
+                dv[u] = 0; ov[u] = 1;
+                if (p < npix) {
+                    const size_t o = (size_t)p * C + c;
+                    dv[u] = dout[o];
+                    if (outv) ov[u] = outv[o];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const long long p = p0 + u * stride;
+                if (p < npix) {
+                    if (outv) { dv[u] *= (ov[u] > 0 ? real(1) : ov[u] + real(1)); dout[(size_t)p * C + c] = dv[u]; }
+                    s += dv[u];
+                }
+            }
         }
     }
     sh[threadIdx.x] = (lp < ppb) ? s : real(0);
@@ -389,11 +415,11 @@ extern "C" int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const dou
 }
 
 // dpre = dout * elu'(out) (in place on dout; out == NULL skips the activation) and db[c] = sum dpre[.., c].
-// part: (nblk, C) scratch with nblk = svgp_elu_bwd_blocks().
+// part: (1024, C) scratch.
 extern "C" int svgp_elu_bwd_bias(long long npix, int C, const double* out, double* dout, double* part, double* db,
                                  void* stream) {
     SVGP_REQUIRE(npix >= 1 && C >= 1 && C <= 16 && dout && part && db, SVGP_ERR_INVALID, "bad argument");
-    const int nblk = 256;
+    const int nblk = 1024;     // 4 workgroups per CU keep the HBM queues full
     hipLaunchKernelGGL(k_elu_bwd_colsum, dim3(nblk), dim3(256), 0, (hipStream_t)stream, npix, C, out, dout, part);
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, nblk, C, C, part, db, 0);

@@ -169,7 +169,7 @@ class SpritesStepEngine:
         dec_h = (8, 16, 16, 32, 32, 64, 64)
         self.dec = [ConvLayer(h, 16, 16 if i < 6 else 3, 3, 1, "same", up=u) for i, (h, u) in enumerate(zip(dec_h, DEC_UP))]
         self.rep = [ConvLayer(h, ci, self.Lc, 2, 2, "same") for h, ci in zip((64, 32, 16), (3, self.Lc, self.Lc))]
-        self.nwg = 256
+        self.nwg = 512        # workgroups of the weight-gradient launches (2 per CU)
         self.scratch = torch.zeros(max(l.scratch_elems(self.nwg) for l in self.enc + self.dec + self.rep), **f64)
         self.kscratch = torch.zeros(b_max * self.La + (self.m + b_max) * 4 + 16, **f64)
         self.stream.synchronize()

@@ -23,7 +23,7 @@ for name, lay in (("enc 64x64 3->16 s1", ConvLayer(64, 3, 16, 3, 1, "same")), ("
     out = torch.empty(n, lay.Ho, lay.Ho, lay.Co, dtype=DT, device="cuda")
     dout = torch.randn_like(out)
     gw, gb = torch.empty_like(w), torch.empty_like(b)
-    scratch = torch.zeros(lay.scratch_elems(256), dtype=DT, device="cuda")
+    scratch = torch.zeros(lay.scratch_elems(512), dtype=DT, device="cuda")
     flops = 2.0 * 9 * lay.Ci * lay.Co * n * lay.Ho * lay.Ho
     if lay.up:
         flops = 2.0 * 4 * lay.Ci * lay.Co * n * lay.Ho * lay.Ho       # four 2x2 parity classes

@@ -261,14 +261,30 @@ __global__ void k_upconv_fold(int cc, const real* __restrict__ ge, real* __restr
 }
 
 // out[i] (+)= sum_g part[g][i]   (fixed order)
-__global__ void k_sum_partials(int ng, int len, int stride, const real* __restrict__ part, real* __restrict__ out,
-                               int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= len) return;
-    real s = accumulate ? out[i] : real(0);
-#pragma unroll 4
-    for (int g = 0; g < ng; ++g) s += part[(size_t)g * stride + i];
-    out[i] = s;
+// one workgroup per 16 outputs: thread = (output il = tid & 15, partial lane ch = tid >> 4); lane ch adds partials ch, ch + 16,
+// ... (8 loads in flight), the 16 lanes are combined through LDS in fixed order
+__global__ __launch_bounds__(256) void k_sum_partials(int ng, int len, int stride, const real* __restrict__ part,
+                                                      real* __restrict__ out, int accumulate) {
+    __shared__ real sh[16][17];
+    const int il = threadIdx.x & 15, ch = threadIdx.x >> 4, i = blockIdx.x * 16 + il;
+    real s = 0;
+    if (i < len) {
+        for (int g0 = ch; g0 < ng; g0 += 16 * 8) {
+            real v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int g = g0 + 16 * u; v[u] = g < ng ? part[(size_t)g * stride + i] : real(0); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    }
+    sh[ch][il] = s;
+    __syncthreads();
+    if (ch == 0 && i < len) {
+        real t = accumulate ? out[i] : real(0);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) t += sh[c][il];
+        out[i] = t;
+    }
 }
 
 // dpre = dout * elu'(out) in place on dout; also per-block column sums for the bias gradient.  HBM-bound (read out, read
@@ -408,7 +424,7 @@ extern "C" int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const dou
     hipLaunchKernelGGL(k_conv_taps_wgrad, dim3(nwg, ncls), dim3(256), lds, (hipStream_t)stream, L, nwg, in, dout, part,
                        part_stride);
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_partials, dim3((part_stride + 255) / 256), dim3(256), 0, (hipStream_t)stream, ncls * nwg,
+    hipLaunchKernelGGL(k_sum_partials, dim3((part_stride + 15) / 16), dim3(256), 0, (hipStream_t)stream, ncls * nwg,
                        part_stride, part_stride, part, dw, accumulate);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;

@@ -345,7 +345,7 @@ typedef struct {
 } svgp_conv_desc;
 int svgp_conv_taps_fwd(const svgp_conv_desc* d, int ncls, const double* in, const double* w, const double* bias,
                        double* out, void* stream);
-/* dW_t[ci][co] = sum_{n,y,x} in[...] * dout[...] for the same tap tables; part: (ncls*nwg, part_stride) scratch;
+/* dW_t[ci][co] = sum_{n,y,x} in[...] * dout[...] for the same tap tables; part: (nwg, part_stride) scratch (the classes' tap ranges must be disjoint);
  * dw (part_stride values, laid out by woff) = fixed-order sum (accumulate != 0 adds to dw).               */
 int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const double* in, const double* dout, double* part,
                          int nwg, int part_stride, double* dw, int accumulate, void* stream);

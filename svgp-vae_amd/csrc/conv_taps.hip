@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void k_conv_taps_fwd(ConvLaunch L, int nchunk,
 
 // Weight gradient.  grid (nwg, ncls): workgroup g of a class walks tiles g, g+nwg, ... of ALL images and
 // keeps dW_t (Ci4 x 16 per tap) in MFMA accumulators: A[i=ci][k=pixel] = in, B[k=pixel][j=co] = dout,
-// k-steps of 4 consecutive pixels of a row segment.  Partials: part[(cls*nwg + g)][t][ci][co] (Ci x Co).
+// k-steps of 4 consecutive pixels of a row segment.  Partials: part[g][woff_t + ci * Co + co]; the classes' tap ranges are
+// disjoint, so they share row g.
 __global__ __launch_bounds__(256) void k_conv_taps_wgrad(ConvLaunch L, int nwg, const real* __restrict__ in,
                                                          const real* __restrict__ dout, real* __restrict__ part,
                                                          int part_stride) {
@@ -213,7 +214,8 @@ __global__ __launch_bounds__(256) void k_conv_taps_wgrad(ConvLaunch L, int nwg, 
         }
     }
     // cross-wave combine (fixed order) and store.  D: col (co) = r, row (ci) = q + 4 g
-    real* po = part + ((size_t)cls * nwg + blockIdx.x) * part_stride;
+    // the classes of a launch write disjoint weight ranges (their own taps), so they share partial row blockIdx.x
+    real* po = part + (size_t)blockIdx.x * part_stride;
 #pragma unroll
     for (int tp = 0; tp < CT_MAXT; ++tp) {
         if (tp < d.nt) {
@@ -418,13 +420,13 @@ extern "C" int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const dou
     }
     lds *= sizeof(real);
     SVGP_REQUIRE(lds <= 160 * 1024, SVGP_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
-    SVGP_CHECK_HIP(hipMemsetAsync(part, 0, (size_t)ncls * nwg * part_stride * sizeof(real), (hipStream_t)stream));
+    SVGP_CHECK_HIP(hipMemsetAsync(part, 0, (size_t)nwg * part_stride * sizeof(real), (hipStream_t)stream));
     SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_taps_wgrad),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_conv_taps_wgrad, dim3(nwg, ncls), dim3(256), lds, (hipStream_t)stream, L, nwg, in, dout, part,
                        part_stride);
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_partials, dim3((part_stride + 15) / 16), dim3(256), 0, (hipStream_t)stream, ncls * nwg,
+    hipLaunchKernelGGL(k_sum_partials, dim3((part_stride + 15) / 16), dim3(256), 0, (hipStream_t)stream, nwg,
                        part_stride, part_stride, part, dw, accumulate);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;

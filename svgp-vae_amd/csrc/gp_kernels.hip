@@ -20,8 +20,18 @@ namespace {
 // column walks hit distinct banks with 8-byte elements).  All helpers are workgroup-cooperative
 // and do NOT end with a barrier unless stated.
 // =============================================================================================
+// global -> LDS matrix copy with 4 loads in flight per thread (m = 32: the whole matrix in ONE batch).  A plain
+// `R[..] = g[o]` loop compiles to load / wait / store per trip; these kernels run one workgroup of 4 waves per CU, so every
+// trip would expose a full memory latency.
 __device__ __forceinline__ void mat_load(real* R, int ld, const real* __restrict__ g, int m) {
-    for (int o = threadIdx.x; o < m * m; o += blockDim.x) R[(o / m) * ld + (o % m)] = g[o];
+    const int mm = m * m, nt = blockDim.x;
+    for (int o0 = threadIdx.x; o0 < mm; o0 += 4 * nt) {
+        real v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int o = o0 + u * nt; v[u] = o < mm ? g[o] : real(0); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int o = o0 + u * nt; if (o < mm) R[(o / m) * ld + (o % m)] = v[u]; }
+    }
 }
 __device__ __forceinline__ void mat_store(real* __restrict__ g, const real* R, int ld, int m) {
     for (int o = threadIdx.x; o < m * m; o += blockDim.x) g[o] = R[(o / m) * ld + (o % m)];

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64) void k_ball_finalize(int B, int did_adam, long 
 // Values of y / var / p_m / p_v / eps / z / zbar are in the (T, B) channel layout of the head kernels.
 // ---------------------------------------------------------------------------------------------------------
 struct PearceArgs {
-    int B, T, n, use_rng, geco_unused;
+    int B, T, n, use_rng;
     const real* times; const int* idx;          // idx (B, n) or NULL
     const real* ls[2];
     const real* y[2]; const real* s2[2];

@@ -468,7 +468,9 @@ extern "C" int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double al
     // TFLOP/s), so compare padded area / rate; below ~192 large tiles the small ones also fill the chip better
     const double cost4 = (double)((M + 127) / 128) * ((N + 127) / 128) * 16384.0 / 57.6;
     const double cost2 = (double)((M + 63) / 64) * ((N + 63) / 64) * 4096.0 / 52.9;
-    const int wt = (blocks128 >= 192 && cost4 <= cost2) ? 4 : 2, ht = 32 * wt;
+    // fewer than one 64 x 64 tile per CU: 32 x 32 tiles (4x the workgroups; 256^3 batch 1: 18.3 -> 9.0 us)
+    const long long blocks64 = (long long)((N + 63) / 64) * ((M + 63) / 64) * batch;
+    const int wt = (blocks128 >= 192 && cost4 <= cost2) ? 4 : (blocks64 < 256 ? 1 : 2), ht = 32 * wt;
     const size_t lds = (size_t)4 * GK * (ht + 2) * sizeof(real);
     g.tiles_n = (N + ht - 1) / ht; g.tiles_m = (M + ht - 1) / ht; g.batch = batch;
     g.xcd_remap = 1;     // measured neutral (+-1 %) at 800^3 x 64 and 2048^3 x 16: the Infinity Cache already absorbs the
@@ -490,6 +492,7 @@ extern "C" int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double al
         else LAUNCH_G(false, false, WT_);            \
     } while (0)
     if (wt == 4) LAUNCH_T(4);
+    else if (wt == 1) LAUNCH_T(1);
     else LAUNCH_T(2);
 #undef LAUNCH_T
 #undef LAUNCH_G

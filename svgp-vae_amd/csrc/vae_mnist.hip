@@ -188,8 +188,33 @@ struct Conv3 {
 
     // gw += sum_pixels in * dpre ; gb += sum_pixels dpre.  Ends with a barrier.
     static __device__ void bwd_weight(const real* in, const real* dpre, real* gw, real* gb, real* scratch) {
-        auto tapfn = [](int t) { return TapP{t / 3, t % 3, t * CIN * COUT, 0, 0}; };
-        gg_wgrad<9, CIN, COUT>(in, HS, HS, HOUT, HOUT, 2, 2, tapfn, dpre, HOUT, 1, 1, gw);
+        if constexpr (CIN == 1) {
+            // one input channel (first encoder layer): 9 * COUT outputs of NPIX MACs each.  On the MFMA this uses 1 of 16
+            // rows (9.7 us of the 23.4 us launch, in-kernel timestamps); here thread = (output o = tap * COUT + co, pixel
+            // chunk), the chunks are combined through LDS in fixed order (2.7 us incl. the bias gradient).
+            constexpr int NO = 9 * COUT, NCH = VAE_NT / NO;
+            static_assert(NCH >= 1 && NO * NCH <= VAE_SCRATCH, "chunk layout");
+            const int o = threadIdx.x % NO, ch = threadIdx.x / NO, t = o / COUT, co = o % COUT, ky = t / 3, kx = t % 3;
+            if (ch < NCH) {
+                real acc = 0;
+                for (int p = ch; p < NPIX; p += NCH) {
+                    const int y = p / HOUT, x = p % HOUT;
+                    acc += in[(2 * y + ky) * HS + 2 * x + kx] * dpre[p * COUT + co];
+                }
+                scratch[ch * NO + o] = acc;
+            }
+            __syncthreads();
+            if (threadIdx.x < NO) {
+                real tsum = 0;
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) tsum += scratch[c * NO + threadIdx.x];
+                gw[threadIdx.x] += tsum;           // raw layout (ky, kx, 0, co) = o
+            }
+            __syncthreads();
+        } else {
+            auto tapfn = [](int t) { return TapP{t / 3, t % 3, t * CIN * COUT, 0, 0}; };
+            gg_wgrad<9, CIN, COUT>(in, HS, HS, HOUT, HOUT, 2, 2, tapfn, dpre, HOUT, 1, 1, gw);
+        }
         bias_grad<NPIX, COUT>(dpre, gb, scratch);
     }
 };

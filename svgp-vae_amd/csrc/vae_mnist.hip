@@ -149,6 +149,19 @@ struct Conv3 {
     static constexpr int NPIX = HOUT * HOUT;
 
     static __device__ void fwd(const real* in, const real* w, const real* bias, real* out) {
+        if constexpr (CIN == 1) {
+            // one input channel (first encoder layer): 9 MACs per output; the MFMA gather-GEMM would use 1 of 4 k-lanes
+            for (int it = threadIdx.x; it < NPIX * COUT; it += VAE_NT) {
+                const int co = it % COUT, p = it / COUT, y = p / HOUT, x = p % HOUT;
+                real acc = bias[co];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc += in[(2 * y + ky) * HS + 2 * x + kx] * w[(ky * 3 + kx) * COUT + co];
+                out[it] = elu_f(acc);
+            }
+            return;
+        }
         const int oy[9] = {0, 0, 0, 1, 1, 1, 2, 2, 2}, ox[9] = {0, 1, 2, 0, 1, 2, 0, 1, 2};
         int wo[9];
 #pragma unroll

@@ -155,6 +155,10 @@ typedef enum {
 
 int         svgp_version(void);
 const char* svgp_last_error(void);
+/* sizeof() of the ABI structs as compiled into the library, so a binding can verify its own mirror of a struct at load
+ * time (a stale mirror shifts every later field silently): which = 0 svgp_mnist_cfg, 1 svgp_mnist_param_layout,
+ * 2 svgp_mnist_ws_layout, 3 svgp_stream_kdesc, 4 svgp_conv_desc, 5 svgp_sprites_kcfg, 6 svgp_pearce_bufs; -1 otherwise. */
+int         svgp_struct_sizeof(int which);
 
 int svgp_mnist_param_layout_get(const svgp_mnist_cfg* cfg, svgp_mnist_param_layout* out);
 int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* cfg, svgp_mnist_ws_layout* out);
@@ -168,6 +172,13 @@ int svgp_mnist_encoder_fwd(const svgp_mnist_cfg*, const double* theta, const dou
 /* mnistSVGP.kernel_matrix x3: K_mm, K_nm, diag K_nn (SVGPVAE_model.py:427-476) */
 int svgp_kernel_matrix_fwd(const svgp_mnist_cfg*, const double* theta, const double* aux,
                            double* ws, void* stream);
+/* mnistSVGP.kernel_matrix(x, y, x_inducing, y_inducing, diag_only) for ARBITRARY row sets (SVGPVAE_model.py:427-476):
+ * x (nx, 2+M), y (ny, 2+M), rows [id, angle, o_1..o_M].  x_gather / y_gather != 0: that side's object vector is
+ * table[(int)row[0]] (the reference's `not *_inducing` with a GPLVM table, :451,455), else the row's columns 2:.
+ * diag_only: out (nx) = k(x_i, y_i), nx == ny (kernel.apply, :458-467); else out (nx, ny) row-major.                 */
+int svgp_kernel_matrix_xy(int M, int normalize, int nx, const double* x, int x_gather, int ny, const double* y,
+                          int y_gather, const double* table, const double* l_GP, const double* amplitude,
+                          int diag_only, double* out, void* stream);
 /* S_l = K_mn diag(1/var_l) K_nm, v_l = K_mn (y_l/var_l)  (SVGPVAE_model.py:328-334) and, in the
  * same launch, K_mm_inv / logdet (:239,270,273).  Output block statA is what DP all-reduces.     */
 int svgp_gp_stats_fwd(const svgp_mnist_cfg*, double* ws, void* stream);

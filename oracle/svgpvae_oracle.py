@@ -139,6 +139,17 @@ class MnistSVGP:
         A_hat = K_mm @ (sigma_l_inv @ K_mm)
         return mean_vector, B, mu_hat, A_hat
 
+    # SVGPVAE_model.py:345-378
+    def mean_vector_bias_analysis(self, index_points, y, noise):
+        b = float(index_points.shape[0])
+        ip = self.inducing_index_points
+        K_mm = self.kernel_matrix(ip, ip)
+        K_bm = self.kernel_matrix(index_points, ip, x_inducing=False)
+        K_mb = K_bm.T
+        sigma_l = K_mm + (self.N_train / b) * (K_mb @ (torch.diag(reciprocal_no_nan(noise)) @ K_bm))
+        sigma_l_inv = torch.linalg.inv(add_diagonal_jitter(sigma_l, self.jitter))
+        return (self.N_train / b) * ((K_mm @ (sigma_l_inv @ K_mb)) @ (reciprocal_no_nan(noise) * y))
+
     # SVGPVAE_model.py:220-301
     def variational_loss(self, x, y, mu_hat, A_hat, noise):
         b = float(x.shape[0])
@@ -346,7 +357,7 @@ class MnistVAE:
 # --------------------------------------------------------------------------------------
 def forward_pass_SVGPVAE(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha, kappa,
                          clipping_qs=False, GECO=False, epsilon=None, formulation="literal",
-                         b_global=None):
+                         b_global=None, bias_analysis=False):
     """Returns the reference's 16-tuple.  `epsilon` (b,L) is the N(0,1) draw of :901 made an
     explicit input (the reference never seeds TF).  formulation: 'literal' follows the
     reference op by op per channel; 'efficient' uses gp_block_efficient."""
@@ -404,7 +415,10 @@ def forward_pass_SVGPVAE(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha
         recon_loss = torch.sum((images - recon_images) ** 2) / Kpix
         elbo = -recon_loss + (beta / float(L)) * KL_term
 
-    mean_vectors = torch.ones((), dtype=DT)
+    if bias_analysis:   # :927-931
+        mean_vectors = [svgp.mean_vector_bias_analysis(aux_data, qnet_mu[:, l], qnet_var[:, l]) for l in range(L)]
+    else:
+        mean_vectors = torch.ones((), dtype=DT)
     return (elbo, recon_loss, KL_term, inside_elbo, ce_term, p_m, p_v, qnet_mu, qnet_var,
             recon_images, inside_elbo_recon, inside_elbo_kl, latent_samples, C_ma, lagrange_mult,
             mean_vectors)

@@ -154,7 +154,8 @@ def run_experiment_sprites_SVGPVAE(args, dict_=None):
         bs = min(args.batch_size_repr_nn, N_train)
         log["repr_pretrain"] = S.pretrain_repr_NN(eng, d_tr, t64(train["char_IDs"]), nr_epochs=args.nr_epochs_repr_nn,
                                                   lr=args.lr_repr_nn, batch_size=bs,
-                                                  n_classes=max(1000, int(train["char_IDs"].max()) + 1), seed=args.seed)
+                                                  n_classes=max(1000, int(train["char_IDs"].max()) + 1), seed=args.seed,
+                                                  carry_slots='fixed' not in args.repr_nn_pretrain)
         eng.freeze_repr = 'fixed' in args.repr_nn_pretrain
     first_step = True
     start = time.time()

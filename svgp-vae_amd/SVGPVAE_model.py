@@ -16,10 +16,10 @@ Additional (no reference counterpart - TF's tf.gradients + AdamOptimizer live in
   gradients_SVGPVAE(...) and train_step_SVGPVAE(...).
 
   bacthing_predict_SVGPVAE_rotated_mnist(test_data_batch, vae, svgp, qnet_mu, qnet_var, aux_data_train)  :1026-1083
+    .mean_vector_bias_analysis(index_points, y, noise)                            :345-378
 titsias=True selects the SVGPVAE_Titsias inside-ELBO (:246-259), computed in m x m space (Woodbury; see
-gp_titsias.hip).  Not implemented in this build (raise NotImplementedError): the
-single-channel approximate_posterior_params with test != train points (the batched conditional-generation
-function above covers that use), SPRITES.
+gp_titsias.hip).  kernel_matrix accepts every (x_inducing, y_inducing, diag_only) pattern on arbitrary row sets;
+approximate_posterior_params accepts test points != train points.  SPRITES lives in sprites.py.
 """
 import math
 
@@ -71,74 +71,108 @@ class mnistSVGP:
         return eng
 
     def kernel_matrix(self, x, y, x_inducing=True, y_inducing=True, diag_only=False):
-        """K(x, y) for the three argument patterns the Hensman path uses (SVGPVAE_model.py:238-243,
-        318-325): (inducing, inducing) -> (m,m); (batch, inducing) -> (b,m); (batch, batch, diag_only) -> (b)."""
+        """K(x, y), SVGPVAE_model.py:427-476, for any argument pattern: rows (n, 2+M) [id, angle, o_1..o_M]; a side that
+        is not `*_inducing` takes its object vector from the GPLVM table by the row's id when there is a table
+        (:451,455), otherwise columns 2: are used (:444-445).  diag_only -> vector k(x_i, y_i) (:458-467)."""
         import ctypes as C
-        from ._lib import call
-        ip = self.inducing_index_points
-        if x_inducing and y_inducing and not diag_only:
-            aux = torch.zeros(1, ip.shape[1], dtype=_F64)
-            which = "K"
-        elif (not x_inducing) and y_inducing and not diag_only:
-            aux, which = x, "Kn"
-        elif (not x_inducing) and (not y_inducing) and diag_only and (x is y or torch.equal(x, y)):
-            aux, which = x, "knn"
-        else:
-            raise NotImplementedError("kernel_matrix: argument pattern not used by the SVGPVAE_Hensman path")
-        b = aux.shape[0]
-        eng = self._gp_engine(b, 1)
-        d_aux = aux.to(eng.device, _F64).contiguous()
-        with torch.cuda.stream(eng.stream):
-            eng.stream.wait_stream(torch.cuda.current_stream(eng.device))
-            call("svgp_kernel_matrix_fwd", C.byref(eng.cfg), eng.theta.data_ptr(), d_aux.data_ptr(),
-                 eng.ws.data_ptr(), eng.stream.cuda_stream)
-        eng.synchronize()
-        m = self.nr_inducing
-        shape = {"K": (m, m), "Kn": (b, m), "knn": (b,)}[which]
-        return eng.ws_view(which, shape).clone()
+        from ._lib import call, load_library
+        load_library()
+        if not torch.cuda.is_available():
+            from ._lib import SvgpError
+            raise SvgpError("kernel_matrix needs a HIP device; there is no CPU execution path")
+        dev = torch.device(self.device)
+        M = self.inducing_index_points.shape[1] - 2
+        dx = x.to(dev, _F64).contiguous()
+        dy = dx if y is x else y.to(dev, _F64).contiguous()
+        if dx.shape[1] != 2 + M or dy.shape[1] != 2 + M:
+            raise ValueError(f"rows must have {2 + M} columns [id, angle, object vector]")
+        nx, ny = dx.shape[0], dy.shape[0]
+        if diag_only and nx != ny:
+            raise ValueError("diag_only needs the same number of rows in x and y")
+        table = None if self.object_vectors is None else self.object_vectors.to(dev, _F64).contiguous()
+        xg = int(table is not None and not x_inducing)
+        yg = int(table is not None and not y_inducing)
+        ls = self.l_GP.to(dev, _F64).reshape(1).contiguous()
+        amp = self.amplitude.to(dev, _F64).reshape(1).contiguous()
+        out = torch.empty((nx,) if diag_only else (nx, ny), dtype=_F64, device=dev)
+        call("svgp_kernel_matrix_xy", M, int(self.K_obj_normalize), nx, dx.data_ptr(), xg, ny, dy.data_ptr(), yg,
+             None if table is None else table.data_ptr(), ls.data_ptr(), amp.data_ptr(), int(diag_only),
+             out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+        return out
 
-    def _channel(self, index_points_train, y, noise):
+    def _channel(self, index_points_train, y, noise, index_points_test=None):
+        """Runs the GP stages for one channel.  Statistics S, v come from the train rows; the factor stage and the
+        per-row stage run at the test rows (= the train rows when index_points_test is None) with c = N_train / (number
+        of train rows), the reference's `self.N_train / b` (:316,328).  The workspace layout depends only on the row
+        capacity, so both passes share offsets."""
         import ctypes as C
         from ._lib import call
         b = index_points_train.shape[0]
+        bt = b if index_points_test is None else index_points_test.shape[0]
         eng = self._gp_engine(b, 1)
         dev = eng.device
         d_aux = index_points_train.to(dev, _F64).contiguous()
+        d_aux_te = None if index_points_test is None else index_points_test.to(dev, _F64).contiguous()
+        eng.set_batch_size(b, b)
         eng.ws_view("qnet_mu", (b, 1)).copy_(y.to(dev, _F64).reshape(b, 1))
         eng.ws_view("qnet_var", (b, 1)).copy_(noise.to(dev, _F64).reshape(b, 1))
         zeros = torch.zeros(b, 1, dtype=_F64, device=dev)
-        cfg, th, ws, st, s = C.byref(eng.cfg), eng.theta.data_ptr(), eng.ws.data_ptr(), eng.state.data_ptr(), \
-            eng.stream.cuda_stream
+        th, ws, st, s = eng.theta.data_ptr(), eng.ws.data_ptr(), eng.state.data_ptr(), eng.stream.cuda_stream
         with torch.cuda.stream(eng.stream):
             eng.stream.wait_stream(torch.cuda.current_stream(dev))
+            cfg = C.byref(eng.cfg)
             call("svgp_kernel_matrix_fwd", cfg, th, d_aux.data_ptr(), ws, s)
             call("svgp_gp_stats_fwd", cfg, ws, s)
             if self.titsias:
                 call("svgp_gp_titsias_stats", cfg, ws, s)
-            call("svgp_gp_factor_fwd", cfg, ws, s)
-            call("svgp_gp_posterior_fwd", cfg, zeros.data_ptr(), ws, st, s)
-            if self.titsias:
-                call("svgp_gp_titsias_fwd", cfg, ws, st, s)
+            if d_aux_te is None:
+                call("svgp_gp_factor_fwd", cfg, ws, s)
+                call("svgp_gp_posterior_fwd", cfg, zeros.data_ptr(), ws, st, s)
+                if self.titsias:
+                    call("svgp_gp_titsias_fwd", cfg, ws, st, s)
+            else:
+                # per-row quantities of the factor / posterior stages at the test rows, in chunks of at most b rows
+                # (a rank's rows never exceed the global rows); the L3 / CE integrands those kernels also write use
+                # y / noise of the leading train rows and are not part of this method's result
+                p_m = torch.empty(bt, dtype=_F64, device=dev)
+                p_v = torch.empty(bt, dtype=_F64, device=dev)
+                for lo in range(0, bt, b):
+                    n = min(b, bt - lo)
+                    eng.set_batch_size(n, b)
+                    cfg = C.byref(eng.cfg)
+                    call("svgp_kernel_matrix_fwd", cfg, th, d_aux_te[lo:lo + n].data_ptr(), ws, s)
+                    call("svgp_gp_factor_fwd", cfg, ws, s)
+                    call("svgp_gp_posterior_fwd", cfg, zeros.data_ptr(), ws, st, s)
+                    p_m[lo:lo + n].copy_(eng.ws_view("p_m", (n,)))
+                    p_v[lo:lo + n].copy_(eng.ws_view("p_v", (n,)))
         eng.synchronize()
-        return eng, b
+        if d_aux_te is not None:
+            return eng, (p_m, p_v)
+        return eng, (eng.ws_view("p_m", (b,)).clone(), eng.ws_view("p_v", (b,)).clone())
 
     def approximate_posterior_params(self, index_points_test, index_points_train=None, y=None, noise=None):
-        """(mean_vector, B, mu_hat, A_hat) of q_S for one latent channel (SVGPVAE_model.py:303-343);
-        test points must be the train points (the training-step use, :869)."""
+        """(mean_vector, B, mu_hat, A_hat) of q_S for one latent channel (SVGPVAE_model.py:303-343): posterior mean and
+        (diagonal) covariance at index_points_test given (index_points_train, y, noise)."""
         if index_points_train is None:
             index_points_train = index_points_test
-        if not (index_points_test is index_points_train or torch.equal(index_points_test, index_points_train)):
-            raise NotImplementedError("test points != train points (conditional generation) is a next-round row")
-        eng, b = self._channel(index_points_train, y, noise)
+        same = index_points_test is index_points_train or (index_points_test.shape == index_points_train.shape
+                                                           and torch.equal(index_points_test, index_points_train))
+        eng, (p_m, p_v) = self._channel(index_points_train, y, noise, None if same else index_points_test)
         m = self.nr_inducing
-        return (eng.ws_view("p_m", (b,)).clone(), eng.ws_view("p_v", (b,)).clone(),
-                eng.ws_view("mu_hat", (m,)).clone(), eng.ws_view("A", (m, m)).clone())
+        return p_m, p_v, eng.ws_view("mu_hat", (m,)).clone(), eng.ws_view("A", (m, m)).clone()
+
+    def mean_vector_bias_analysis(self, index_points, y=None, noise=None):
+        """SVGPVAE_model.py:345-378 (Supplementary C.4): c K_mm Sigma_l^-1 K_mb (y / noise), c = N_train / b -- the same
+        expression as mu_hat of approximate_posterior_params (:339-340)."""
+        eng, _ = self._channel(index_points, y, noise)
+        return eng.ws_view("mu_hat", (self.nr_inducing,)).clone()
 
     def variational_loss(self, x, y, mu_hat, A_hat, noise=None):
         """(L_3 sum term, KL term) of one channel (SVGPVAE_model.py:261-301).  mu_hat / A_hat must be the
         ones approximate_posterior_params returns for the same (x, y, noise) - the only use in the
         reference (:869-873); they are recomputed on device."""
-        eng, b = self._channel(x, y, noise)
+        eng, _ = self._channel(x, y, noise)
+        b = x.shape[0]
         if self.titsias:   # (L_2, 0)  :246-259
             sc = eng.ws_view("tit_scal", (3,))       # [log det Sigma2, v2.t2, row sum]  (L = 1)
             l2 = -0.5 * (b * 1.8378770664093453 + sc[2] + sc[0] - eng.ws_view("ldK", (1,))[0] - sc[1])
@@ -184,16 +218,35 @@ class _Runtime:
 
 
 def _runtime(vae, svgp, clipping_qs, GECO, kappa, b, **kw):
+    """The engine bound to (vae, svgp).  It is rebuilt when the flags change or more rows are needed than it was sized
+    for (conditional generation over the whole train set after training at b = 256); a rebuild carries the COMPLETE
+    training state over: parameters, Adam moments, and the device state vector (global step, GECO C_ma / lagrange
+    multiplier / first-step alpha, learning rate, beta, RNG counter) -- replacing the engine must not restart the
+    optimiser or the GECO trajectory."""
     rt = svgp._rt
     if rt is None or rt.key != (bool(clipping_qs), bool(GECO), float(kappa)) or rt.eng.b_max < b:
-        if rt is not None:   # carry the current parameter values into the new engine
+        old = rt
+        if old is not None:
+            old.eng.synchronize()
             vae.params = {k: v.detach().cpu().clone() for k, v in vae.params.items()}
             vae._engine = None
             for k in ("inducing_index_points", "l_GP", "amplitude", "object_vectors"):
                 v = getattr(svgp, k)
                 if v is not None:
                     setattr(svgp, k, v.detach().cpu().clone())
-        rt = _Runtime(vae, svgp, clipping_qs, GECO, kappa, b_max=max(b, 256), **kw)
+            kw.setdefault("alpha_flag", old.eng.base["alpha"])
+            kw.setdefault("rank", old.eng.rank)
+            kw.setdefault("world_size", old.eng.world_size)
+        rt = _Runtime(vae, svgp, clipping_qs, GECO, kappa, b_max=max(b, 256 if old is None else old.eng.b_max), **kw)
+        if old is not None:
+            new, prev = rt.eng, old.eng
+            with torch.cuda.stream(new.stream):
+                new.adam_m.copy_(prev.adam_m)
+                new.adam_v.copy_(prev.adam_v)
+                new.state.copy_(prev.state)
+            new.synchronize()
+            if rt.key[1] != old.key[1]:       # GECO switched on / off: alpha-for-next-step follows the new objective
+                new.set_scalars(alpha=0.0 if (rt.key[1] and new.scalars()["adam_t"] == 0) else new.base["alpha"])
     return rt
 
 
@@ -229,8 +282,8 @@ def forward_pass_SVGPVAE(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha
     qnet_var, recon_images, inside_elbo_recon, inside_elbo_kl, latent_samples, C_ma, lagrange_mult,
     mean_vectors).  With GECO the `elbo` slot holds the GECO loss and recon_loss is kappa^2-shifted, as in
     the reference (:909-913).  epsilon (b,L): the N(0,1) draw of :901; None -> drawn on device."""
-    if repr_NN is not None or bias_analysis:
-        raise NotImplementedError("SPRITES representation network / bias analysis are not part of this build")
+    if repr_NN is not None:
+        raise NotImplementedError("the SPRITES representation-network form is svgp_vae_amd.sprites.forward_pass_SVGPVAE")
     eng, b = _prepare(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha, kappa, clipping_qs, GECO, epsilon)
     with torch.cuda.stream(eng.stream):
         eng.phase(0)
@@ -238,7 +291,13 @@ def forward_pass_SVGPVAE(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha
         eng.phase(2)                 # gradients come with the forward at negligible cost
         eng.phase(3, adam=False)
     eng.synchronize()
-    return _tuple16(eng, b)
+    out = _tuple16(eng, b)
+    if bias_analysis:
+        # :927-931: one mean_vector_bias_analysis per channel = c K_mm Sigma_l^-1 K_mb (y_l / noise_l) = mu_hat_l, which
+        # the factor stage of the step has just computed for every channel
+        mu_hat = eng.ws_view("mu_hat", (eng.base["L"], eng.base["m"])).clone()
+        out = out[:15] + ([mu_hat[l] for l in range(eng.base["L"])],)
+    return out
 
 
 def gradients_SVGPVAE(vae, svgp):
@@ -255,6 +314,7 @@ def train_step_SVGPVAE(data_batch, beta, vae, svgp, alpha, kappa, lr, clipping_q
     images = data_batch[0]
     rt = _runtime(vae, svgp, clipping_qs, GECO, kappa, images.shape[0], alpha_flag=alpha)
     eng = rt.eng
+    eng.base["alpha"] = float(alpha)      # cfg.alpha = the moving-average constant from the 2nd step on; not in rt.key
     if reset:
         eng.reset_state()
     eng.set_batch_size(images.shape[0])
@@ -294,6 +354,7 @@ def bacthing_predict_SVGPVAE_rotated_mnist(test_data_batch, vae, svgp, qnet_mu, 
     N, bt, L = aux_data_train.shape[0], aux_test.shape[0], vae.L
     rt = svgp._rt
     if rt is None or rt.eng.b_max < max(N, bt):
+        # a larger engine; _runtime carries parameters, Adam moments and the GECO / step state of the old one over
         rt = _runtime(vae, svgp, True if rt is None else rt.key[0], False if rt is None else rt.key[1],
                       math.sqrt(0.020) if rt is None else rt.key[2], max(N, bt))
     eng = rt.eng

@@ -47,11 +47,10 @@ class mnistVAE:
     #    parameters are views into that runtime's flat vector and the same kernels are used.
     def _solo_engine(self, b):
         from .engine import MnistStepEngine
-        if self._engine is not None:
-            eng = self._engine
-            if b > eng.b_max:
-                raise ValueError(f"batch {b} exceeds runtime b_max {eng.b_max}")
-            return eng
+        if self._engine is not None and b <= self._engine.b_max:
+            return self._engine
+        # stand-alone, or more rows than the training runtime was sized for: a private forward-only engine with the
+        # current parameter values (the training engine and its optimiser state stay untouched)
         if self._solo is None or self._solo.b_max < b:
             self._solo = MnistStepEngine(1, self.L, 1, 0, b_max=max(b, 256), device=self.device)
         self._solo.load_params({k: v for k, v in self.params.items()})
@@ -67,6 +66,8 @@ class mnistVAE:
         eng.cfg.clip_qs = 0
         img = images.to(eng.device, torch.float64).contiguous()
         with torch.cuda.stream(eng.stream):
+            # `img` may have been cast / copied / produced on torch's current stream just now
+            eng.stream.wait_stream(torch.cuda.current_stream(eng.device))
             call("svgp_mnist_encoder_fwd", C.byref(eng.cfg), eng.theta.data_ptr(), img.data_ptr(), eng.ws.data_ptr(),
                  eng.stream.cuda_stream)
         eng.synchronize()

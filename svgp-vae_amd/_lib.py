@@ -80,6 +80,7 @@ SIGNATURES = {
     "svgp_mnist_ws_layout_get": [_CFG, C.POINTER(WsLayout)],
     "svgp_mnist_encoder_fwd": [_CFG, _P, _P, _P, _P],
     "svgp_kernel_matrix_fwd": [_CFG, _P, _P, _P, _P],
+    "svgp_kernel_matrix_xy": [C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, C.c_int, _P, _P],
     "svgp_gp_stats_fwd": [_CFG, _P, _P],
     "svgp_gp_factor_fwd": [_CFG, _P, _P],
     "svgp_gp_posterior_fwd": [_CFG, _P, _P, _P, _P],
@@ -178,6 +179,7 @@ class StreamKdesc(C.Structure):
 
 
 NON_STATUS = {"svgp_version": ([], C.c_int), "svgp_last_error": ([], C.c_char_p),
+              "svgp_struct_sizeof": ([C.c_int], C.c_int),
               "svgp_comm_unique_id_bytes": ([], C.c_int),
               "svgp_stream_feature_elems": ([C.c_void_p, C.c_int64], C.c_int64),
               "svgp_stream_stats_workspace_elems": ([C.c_int64, C.c_int, C.c_int], C.c_int64),
@@ -212,6 +214,11 @@ def load_library(path=None):
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = restype
+    # the ctypes mirrors must have the layout the library was compiled with (svgp_struct_sizeof)
+    for which, cls in enumerate((MnistCfg, ParamLayout, WsLayout, StreamKdesc, ConvDesc, SpritesKcfg, PearceBufs)):
+        if lib.svgp_struct_sizeof(which) != C.sizeof(cls):
+            raise SvgpError(f"{p}: sizeof({cls.__name__}) is {lib.svgp_struct_sizeof(which)} in the library but "
+                            f"{C.sizeof(cls)} in the binding; rebuild the library or update _lib.py")
     if path is None:
         _lib = lib
     return lib

@@ -16,6 +16,18 @@ void svgp_set_error(const char* fmt, ...) {
 
 extern "C" const char* svgp_last_error(void) { return g_err; }
 extern "C" int svgp_version(void) { return SVGP_VERSION_MAJOR * 100 + SVGP_VERSION_MINOR; }
+extern "C" int svgp_struct_sizeof(int which) {
+    switch (which) {
+    case 0: return (int)sizeof(svgp_mnist_cfg);
+    case 1: return (int)sizeof(svgp_mnist_param_layout);
+    case 2: return (int)sizeof(svgp_mnist_ws_layout);
+    case 3: return (int)sizeof(svgp_stream_kdesc);
+    case 4: return (int)sizeof(svgp_conv_desc);
+    case 5: return (int)sizeof(svgp_sprites_kcfg);
+    case 6: return (int)sizeof(svgp_pearce_bufs);
+    default: return -1;
+    }
+}
 
 int svgp_check_cfg(const svgp_mnist_cfg* c) {
     SVGP_REQUIRE(c != nullptr, SVGP_ERR_INVALID, "cfg is NULL");

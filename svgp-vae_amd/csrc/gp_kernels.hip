@@ -246,6 +246,28 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_fwd(KernArgs a, re
     svgp_km_fwd_element(a, (long long)blockIdx.x * blockDim.x + threadIdx.x, K, Kn, knn);
 }
 
+// General argument patterns of mnistSVGP.kernel_matrix (SVGPVAE_model.py:427-476): each side's object vector is either
+// the row's own columns 2: (`*_inducing`, or no GPLVM table) or gathered from the table by the row's id (:451,455).
+struct KernXYArgs {
+    int M, normalize, nx, ny, xg, yg, diag;
+    const real *x, *y, *table, *ls, *amp;
+};
+__global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_xy(KernXYArgs a, real* __restrict__ out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = a.diag ? (long long)a.nx : (long long)a.nx * a.ny;
+    if (idx >= total) return;
+    const int st = 2 + a.M;
+    const long long i = a.diag ? idx : idx / a.ny, j = a.diag ? idx : idx % a.ny;
+    const real* xr = a.x + (size_t)i * st;
+    const real* yr = a.y + (size_t)j * st;
+    const real* xo = a.xg ? a.table + (size_t)((long long)xr[0]) * a.M : xr + 2;
+    const real* yo = a.yg ? a.table + (size_t)((long long)yr[0]) * a.M : yr + 2;
+    const real amp = *a.amp, ls = *a.ls;
+    real D = dotM(xo, yo, a.M);
+    if (a.normalize) D /= sqrt(dotM(xo, xo, a.M)) * sqrt(dotM(yo, yo, a.M));
+    out[idx] = view_k(xr[1] - yr[1], amp * amp, real(1) / (ls * ls)) * D;
+}
+
 // VJP, inducing side: one workgroup per inducing point j.
 // d_ip[j] = [0, d_theta_j, d_o_j], partial amplitude / length-scale sums -> part_gp[j].
 #define KM_MAXM 32
@@ -1134,6 +1156,23 @@ extern "C" int svgp_kernel_matrix_fwd(const svgp_mnist_cfg* c, const double* the
     const long long total = (long long)c->b * c->m + (long long)c->m * c->m + c->b;
     hipLaunchKernelGGL(k_kernel_matrix_fwd, dim3((unsigned)((total + SVGP_BLOCK - 1) / SVGP_BLOCK)), dim3(SVGP_BLOCK), 0,
                        (hipStream_t)stream, a, ws + wl.K, ws + wl.Kn, ws + wl.knn);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+extern "C" int svgp_kernel_matrix_xy(int M, int normalize, int nx, const double* x, int x_gather, int ny, const double* y,
+                                     int y_gather, const double* table, const double* l_GP, const double* amplitude,
+                                     int diag_only, double* out, void* stream) {
+    SVGP_REQUIRE(M >= 1 && nx >= 1 && ny >= 1, SVGP_ERR_INVALID, "bad shape M=%d nx=%d ny=%d", M, nx, ny);
+    SVGP_REQUIRE(x && y && l_GP && amplitude && out, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(!(x_gather || y_gather) || table, SVGP_ERR_INVALID, "a gathered side needs the object-vector table");
+    SVGP_REQUIRE(!diag_only || nx == ny, SVGP_ERR_INVALID, "diag_only needs nx == ny (nx=%d ny=%d)", nx, ny);
+    KernXYArgs a;
+    a.M = M; a.normalize = normalize; a.nx = nx; a.ny = ny; a.xg = x_gather; a.yg = y_gather; a.diag = diag_only;
+    a.x = x; a.y = y; a.table = table; a.ls = l_GP; a.amp = amplitude;
+    const long long total = diag_only ? (long long)nx : (long long)nx * ny;
+    hipLaunchKernelGGL(k_kernel_matrix_xy, dim3((unsigned)((total + SVGP_BLOCK - 1) / SVGP_BLOCK)), dim3(SVGP_BLOCK), 0,
+                       (hipStream_t)stream, a, out);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

@@ -576,10 +576,17 @@ def predict_SVGPVAE_sprites_test_character(data_batch, vae, svgp, repr_NN, mean_
 # ---------------------------------------------------------------------------------------------
 # pre-training of the representation network (SPRITES_experiment.py:139-151,325-357; SPRITES_utils.py:335-368)
 # ---------------------------------------------------------------------------------------------
-def pretrain_repr_NN(engine, frames, char_IDs, *, nr_epochs, lr, batch_size, n_classes=1000, seed=0, log=print):
+def pretrain_repr_NN(engine, frames, char_IDs, *, nr_epochs, lr, batch_size, n_classes=1000, seed=0, log=print,
+                     carry_slots=True):
     """Character classification: embeddings = repr_nn(frames) -> Dense(n_classes) -> mean sparse softmax cross-entropy,
     TF1 Adam on the representation network + the classification layer (which is discarded afterwards).  Updates the
-    engine's repr_c* parameters in place; returns the list of (epoch, mean loss, accuracy)."""
+    engine's repr_c* parameters in place; returns the list of (epoch, mean loss, accuracy).
+
+    The reference runs pre-training and the joint phase on ONE tf.train.AdamOptimizer (SPRITES_experiment.py:210-238):
+    its beta1/beta2 power accumulators keep advancing through pre-training, so the joint phase starts at global step
+    K_pretrain + 1, and with `yes_joint` the m / v slots of the representation network carry over.  Both are reproduced:
+    the engine's Adam step counter is advanced by the number of pre-training updates, and (carry_slots, = not
+    `yes_fixed`) the repr_* slices of the moments are copied into the engine's."""
     dev, Lc, s = engine.dev, engine.Lc, engine.stream.cuda_stream
     f64 = dict(dtype=_F64, device=dev)
     names = [k for k in engine.shapes if k.startswith("repr_")]
@@ -647,7 +654,18 @@ def pretrain_repr_NN(engine, frames, char_IDs, *, nr_epochs, lr, batch_size, n_c
         if log is not None and ((epoch + 1) % 50 == 0 or epoch == nr_epochs - 1):
             log(f"repr NN pretraining epoch {epoch}: mean loss {history[-1][1]:.4f}  accuracy {history[-1][2]:.4f}")
     with torch.cuda.stream(engine.stream):
-        for k in names:
+        off_p = 0
+        for k, n in zip(names, sizes):
             engine.params[k].copy_(views[k])
+            if carry_slots:
+                off_e = 0
+                for ke, se in engine.shapes.items():
+                    if ke == k:
+                        break
+                    off_e += int(np.prod(se))
+                engine.adam_m[off_e:off_e + n].copy_(am[off_p:off_p + n])
+                engine.adam_v[off_e:off_e + n].copy_(av[off_p:off_p + n])
+            off_p += n
+        engine.state[STATE["ADAM_T"]] += state[STATE["ADAM_T"]]
     engine.stream.synchronize()
     return history

@@ -155,3 +155,51 @@ def test_product_package_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), fn
+
+
+def _header_struct_fields(name):
+    """[(ctype, field)] of `typedef struct { ... } name;` in include/svgpvae_hip.h, in declaration order."""
+    src = open(os.path.join(ROOT, "include", "svgpvae_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    body = re.search(r"typedef\s+struct\s*\{([^}]*)\}\s*" + name + r"\s*;", src, flags=re.S).group(1)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        mm = re.match(r"(const\s+)?([A-Za-z_0-9]+)\s*(\*?)\s*(.*)$", decl, flags=re.S)
+        ctype = mm.group(2) + mm.group(3)
+        for fld in mm.group(4).split(","):
+            fld = fld.strip().lstrip("*").strip()
+            out.append((ctype, re.sub(r"\[.*\]", "", fld)))
+    return out
+
+
+_CT = {"int32_t": C.c_int32, "int64_t": C.c_int64, "double": C.c_double, "float": C.c_float}
+
+
+def test_ctypes_mirrors_follow_the_header_field_for_field():
+    """a stale mirror of svgp_mnist_cfg mis-aligns every double.  The header is the source of truth:
+    _lib's structures, the INTEGRATION.md stub and the compiled library must agree with it."""
+    for cname, cls in (("svgp_mnist_cfg", _lib.MnistCfg), ("svgp_mnist_param_layout", _lib.ParamLayout),
+                       ("svgp_mnist_ws_layout", _lib.WsLayout), ("svgp_sprites_kcfg", _lib.SpritesKcfg)):
+        want = _header_struct_fields(cname)
+        got = [(n, t) for n, t in cls._fields_]
+        assert [f for _, f in want] == [n for n, _ in got], cname
+        assert [_CT[t] for t, _ in want] == [t for _, t in got], cname
+    # array members: names + order only
+    for cname, cls in (("svgp_conv_desc", _lib.ConvDesc), ("svgp_stream_kdesc", _lib.StreamKdesc),
+                       ("svgp_pearce_bufs", _lib.PearceBufs)):
+        assert [f for _, f in _header_struct_fields(cname)] == [n for n, _ in cls._fields_], cname
+    lib = svgp_vae_amd.load_library()
+    for which, cls in enumerate((_lib.MnistCfg, _lib.ParamLayout, _lib.WsLayout, _lib.StreamKdesc, _lib.ConvDesc,
+                                 _lib.SpritesKcfg, _lib.PearceBufs)):
+        assert lib.svgp_struct_sizeof(which) == C.sizeof(cls), cls.__name__
+    assert lib.svgp_struct_sizeof(99) == -1
+    # the INTEGRATION.md stub: executed as written (minus the CDLL / call lines) it must define the same structure
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    snippet = re.search(r"(class MnistCfg\(C\.Structure\):.*?)\nlib\.svgp_struct_sizeof", doc, flags=re.S).group(1)
+    ns = {"C": C}
+    exec(snippet, ns)
+    assert [(n, t) for n, t in ns["MnistCfg"]._fields_] == [(n, t) for n, t in _lib.MnistCfg._fields_]
+    assert C.sizeof(ns["MnistCfg"]) == lib.svgp_struct_sizeof(0)

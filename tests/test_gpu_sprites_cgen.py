@@ -133,3 +133,32 @@ def test_repr_nn_pretraining_learns_the_characters(tmp_path):
     h = log["repr_pretrain"]
     assert len(h) == 40 and h[-1][1] < 0.5 * h[0][1] and h[-1][2] > h[0][2]
     assert np.isfinite(log["elbo"][0])
+
+
+def test_pretraining_advances_the_shared_adam_state():
+    """the reference uses ONE AdamOptimizer for the repr-NN pre-training and the joint phase
+    (SPRITES_experiment.py:210-238): after K pre-training updates the joint phase starts at global step K + 1 and,
+    for yes_joint, with the repr-NN moment slots filled; for yes_fixed the slots stay empty."""
+    from svgp_vae_amd import sprites as S
+    L, La, Lc, m, n_act, b = 4, 8, 16, 6, 5, 10
+    g = torch.Generator().manual_seed(3)
+    for carry in (True, False):
+        svgp = S.spritesSVGP(False, False, (torch.randn(m, La + Lc, dtype=torch.float64, generator=g) * 1.5).numpy(), 'main',
+                             0.01, 100.0, La, (torch.randn(n_act, La, dtype=torch.float64, generator=g) * 1.5).numpy(), Lc, L,
+                             fixed_GP_params=False, fixed_GPLVM=False, K_obj_normalize=False, K_SE=True)
+        eng = S.SpritesStepEngine(S.spritesVAE(L), S.sprites_representation_network(Lc), svgp, b_max=b, seg_len=5)
+        frames = torch.rand(20, 64, 64, 3, dtype=torch.float64, generator=g).to(eng.dev)
+        chars = torch.arange(20).to(eng.dev) // 5
+        before = {k: v.clone() for k, v in eng.params.items()}
+        S.pretrain_repr_NN(eng, frames, chars, nr_epochs=3, lr=1e-2, batch_size=10, n_classes=8, log=None, carry_slots=carry)
+        assert eng.scalars()["adam_t"] == 6.0            # 3 epochs x 2 batches
+        off = 0
+        for k, shp in eng.shapes.items():
+            n = int(np.prod(shp))
+            mm = float(eng.adam_m[off:off + n].abs().sum())
+            if k.startswith("repr_"):
+                assert (mm > 0) == carry, k
+                assert not torch.equal(eng.params[k], before[k]), k
+            else:
+                assert mm == 0.0 and torch.equal(eng.params[k], before[k]), k
+            off += n

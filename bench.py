@@ -1,18 +1,27 @@
-"""SVGPVAE_Hensman train steps/sec on MI355X (BASELINE.json metric).
+"""SVGPVAE_Hensman train steps/sec on MI355X (BASELINE.json metric) and the roofline-relevant side workloads.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 1 --steps 200 --warmup 20                      # BASELINE configs[1] (the metric)
+    python bench.py --workload cfg3|sprites800|cfg5                       # BASELINE configs[2] / [3] / [4]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one full training step (encoder, kernel matrices, sparse-GP block, decoder, reverse
-pass, TF1 Adam, GECO state update) on one 256-row rotated-MNIST-shaped batch per GPU (BASELINE
-config 2: m=32 inducing points, L=16, GPLVM dim 8, N_train=4050, float64 like the reference).
-Weak scaling: every rank keeps 256 rows, the global batch is 256*N rows coupled through the
-sufficient-statistics all-reduces; `value` = N * steps / time = 256-row batches trained per second.
+Default workload (cfg2): one "step" = one full training step (encoder, kernel matrices, sparse-GP block, decoder,
+reverse pass, TF1 Adam, GECO state update) on one 256-row rotated-MNIST-shaped batch per GPU (BASELINE configs[1]:
+m=32 inducing points, L=16, GPLVM dim 8, N_train=4050, float64 like the reference).  Weak scaling: every rank keeps
+256 rows, the global batch is 256*N rows coupled through the sufficient-statistics all-reduces; `value` =
+N * steps / time = 256-row batches trained per second (`--scaling strong` keeps the global batch fixed instead).
 Inputs are synthetic, generated once and resident in HBM before the timed region.
+
+Timing: after W warm-up steps, R (`--repeats`, default 5) blocks of EXACTLY K steps, each bracketed by barrier +
+synchronize on both sides and reduced with MAX over ranks; the reported ms_per_step / value come from the MEDIAN block
+(a 20-step block is a 4 ms sample; one scheduling hiccup would move a single block by 10 %).
+
+Every workload prints ONE JSON line with `roofline` (dominant stage, HIP events on the launch stream, algorithmic
+work model of SURVEY 8d / DESIGN section 5) and `cpu_baseline` (the oracle timed on this host's cores; N=1 only).
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import math
 import os
@@ -26,14 +35,105 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-B, M_IND, L, MDIM, N_OBJ, N_TRAIN = 256, 32, 16, 8, 400, 4050.0
+L, N_OBJ, N_TRAIN = 16, 400, 4050.0
 F64_PEAK_TFLOPS = 78.6     # MI355X FP64 vector = matrix peak (AMD datasheet; = 1/2 of the 157.3 TF f32 rate
                            # listed in MI355X_MICROARCH.md, which has no f64 row)
+F32_PEAK_TFLOPS = 157.3    # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak
 HBM_PEAK_GBS = 8000.0
 
 
-def synthetic_problem(rank, seed=0):
-    """SURVEY 8d config 2 synthetic inputs; parameters identical on all ranks, data differs per rank."""
+# =====================================================================================================================
+# shared helpers
+# =====================================================================================================================
+def dist_env():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def timed_blocks(step, sync, steps, warmup, repeats, multi, dev):
+    """W warm-up steps, then `repeats` blocks of exactly `steps` steps; per block barrier + synchronize on both sides,
+    MAX over ranks.  Returns the list of block times in seconds (identical on every rank)."""
+    import torch.distributed as dist
+    for _ in range(warmup):
+        step()
+    out = []
+    for _ in range(repeats):
+        sync()
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        sync()
+        torch.cuda.synchronize()
+        if multi:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if multi:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        out.append(el)
+    return out
+
+
+def roofline_of(flops, nbytes, us, peak_tflops, **extra):
+    """Roofline object of one launch: bound chosen by the arithmetic intensity of the ALGORITHMIC work."""
+    ai = flops / max(nbytes, 1.0)
+    if ai >= peak_tflops * 1e12 / (HBM_PEAK_GBS * 1e9):
+        ach = flops / (us * 1e-6) / 1e12
+        r = {"bound": "mfma", "achieved": ach, "peak": peak_tflops, "unit": "TFLOP/s", "frac": ach / peak_tflops}
+    else:
+        ach = nbytes / (us * 1e-6) / 1e9
+        r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
+    r.update(traffic=None, launch_us=us, algorithmic_flops=float(flops), algorithmic_bytes=float(nbytes))
+    r.update(extra)
+    return r
+
+
+def committed_traffic(kernel_key):
+    """HBM bytes per launch of `kernel_key` from the newest committed rocprofv3 PMC summary (profiles/*_pmc_traffic.json,
+    collected with tools/pmc_summary.py in separate --pmc passes).  bench.py cannot run the profiler on itself, so this
+    is an EARLIER measurement: the source file is reported next to the value and it is null when none matches."""
+    try:
+        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+        pmc = json.load(open(path))
+        return pmc["kernels"][kernel_key]["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT)
+    except Exception:
+        return None, None
+
+
+def pick_threads(one, candidates=(4, 8, 16, 32, 64)):
+    """torch-CPU on a many-core host is slowest with all threads on these small ops: probe a few thread counts with
+    one call each and keep the fastest for the reported baseline."""
+    ncpu = os.cpu_count() or 8
+    best = (torch.get_num_threads(), float("inf"))
+    for nt in sorted({min(c, ncpu) for c in candidates}):
+        torch.set_num_threads(nt)
+        one()
+        t1 = time.perf_counter()
+        one()
+        dt = time.perf_counter() - t1
+        if dt < best[1]:
+            best = (nt, dt)
+    torch.set_num_threads(best[0])
+    return best[0]
+
+
+def emit(line):
+    # RCCL prints a version banner through C stdio at communicator creation; flush it first so the JSON line is the
+    # last line on stdout
+    C.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
+
+
+# =====================================================================================================================
+# cfg2 / cfg3: rotated-MNIST SVGPVAE_Hensman step
+# =====================================================================================================================
+def synthetic_problem(rank, B, M_IND, MDIM, seed=0):
+    """SURVEY 8d config 2/3 synthetic inputs; parameters identical on all ranks, data differs per rank."""
     from svgp_vae_amd.VAE_utils import glorot_uniform_params
     rs = np.random.RandomState(seed)
     params = dict(glorot_uniform_params(L, seed))
@@ -53,37 +153,50 @@ def synthetic_problem(rank, seed=0):
     return params, images, aux, eps
 
 
-def stage_table(eng):
-    """(name, C symbol, args builder, algorithmic flops, algorithmic bytes) per stage, config 2 per GPU.
-    Flop/byte models: DESIGN.md section 5."""
-    from svgp_vae_amd import _lib
+def stage_table(eng, B, M_IND):
+    """(name, C symbol, args, algorithmic flops, algorithmic bytes, implementation-partials bytes) per stage and GPU.
+    Flop/byte models: DESIGN.md section 5.  ALGORITHMIC bytes = inputs read once + outputs written once; the
+    per-workgroup weight-gradient partials the two conv reverse kernels write (and the reduction re-reads) are
+    implementation traffic and are listed separately."""
     cfg, th, ws, st = C.byref(eng.cfg), eng.theta.data_ptr(), eng.ws.data_ptr(), eng.state.data_ptr()
     img, aux, eps = (t.data_ptr() if t is not None else None for t in eng._bound)
     s = eng.stream.cuda_stream
     b, m, Lc = B, M_IND, L
+    D = eng.base["M"] + 1
     enc_mac, dec_mac = 35_592, 207_872            # MACs per image (SURVEY App. B shapes)
     act_enc, act_dec = 1352 + 288 + 32, 128 + 512 + 1568
     n_enc, n_dec = eng.pl.n_enc, eng.pl.n_vae - eng.pl.n_enc
+    n_part = eng.wl.n_part
     f8 = 8.0
     return [
         ("encoder_kernel_matrix_fwd", "svgp_mnist_encoder_kernel_matrix_fwd", (cfg, th, img, aux, ws, s),
-         2 * enc_mac * b + (b * m + m * m) * (2 * 9 + 12),
-         f8 * (b * (784 + act_enc + 3 * Lc) + b * m + m * m + b + b * 10)),
-        ("gp_stats_fwd", "svgp_gp_stats_fwd", (cfg, ws, s), 3 * Lc * b * m * m + 2 * m ** 3, f8 * (b * m + 2 * b * Lc + Lc * m * (m + 1))),
-        ("gp_factor_fwd", "svgp_gp_factor_fwd_defer_aji", (cfg, ws, s), Lc * (2 * (m ** 3 / 3 + 2 * m ** 3 / 3) + 4 * 2 * m ** 3) + 2 * b * m * m, f8 * Lc * 7 * m * m),
-        ("gp_posterior_fwd", "svgp_gp_posterior_fwd", (cfg, eps, ws, st, s), 4 * Lc * b * m * m, f8 * (Lc * 2 * m * m + b * m + 8 * b * Lc)),
-        ("decoder_fwd", "svgp_mnist_decoder_fwd", (cfg, th, img, ws, s), 2 * dec_mac * b, f8 * b * (Lc + act_dec + 2 * 784)),
-        ("decoder_bwd", "svgp_mnist_decoder_bwd", (cfg, th, img, ws, st, s), 4 * dec_mac * b, f8 * (b * (Lc + act_dec + 2 * 784 + Lc) + eng.wl.n_part * n_dec)),
-        ("gp_stats_bwd", "svgp_gp_stats_bwd_with_aji", (cfg, ws, st, s), 3 * Lc * b * m * m, f8 * (b * m + 9 * b * Lc + Lc * m * (m + 2))),
-        ("gp_factor_bwd", "svgp_gp_factor_bwd_nofinal", (cfg, ws, st, s), Lc * 9 * 2 * m ** 3, f8 * Lc * 14 * m * m),
-        ("gp_posterior_bwd", "svgp_gp_posterior_bwd_with_final", (cfg, ws, st, s), 6 * Lc * b * m * m, f8 * (Lc * 3 * m * m + 2 * Lc * b * m + 12 * b * Lc)),
-        ("kernel_matrix_bwd", "svgp_kernel_matrix_bwd_partials", (cfg, th, aux, ws, s), (2 * b * m + 2 * m * m) * (2 * 9 + 20), f8 * (2 * b * m + 2 * m * m + b * 10 + N_OBJ * 8)),
-        ("encoder_bwd", "svgp_mnist_encoder_bwd", (cfg, th, img, ws, s), 4 * enc_mac * b, f8 * (b * (784 + act_enc + 3 * Lc) + eng.wl.n_part * n_enc)),
-        ("grad_reduce", "svgp_mnist_grad_reduce_all", (cfg, aux, ws, s), eng.wl.n_part * (n_enc + n_dec), f8 * eng.wl.n_part * (n_enc + n_dec)),
+         2 * enc_mac * b + (b * m + m * m) * (2 * D + 12),
+         f8 * (b * (784 + act_enc + 3 * Lc) + b * m + m * m + b + b * (D + 1) + n_enc), 0.0),
+        ("gp_stats_fwd", "svgp_gp_stats_fwd", (cfg, ws, s), 3 * Lc * b * m * m + 2 * m ** 3,
+         f8 * (b * m + 2 * b * Lc + Lc * m * (m + 1)), 0.0),
+        ("gp_factor_fwd", "svgp_gp_factor_fwd_defer_aji", (cfg, ws, s),
+         Lc * (2 * (m ** 3 / 3 + 2 * m ** 3 / 3) + 4 * 2 * m ** 3) + 2 * b * m * m, f8 * Lc * 7 * m * m, 0.0),
+        ("gp_posterior_fwd", "svgp_gp_posterior_fwd", (cfg, eps, ws, st, s), 4 * Lc * b * m * m,
+         f8 * (Lc * 2 * m * m + b * m + 8 * b * Lc), 0.0),
+        ("decoder_fwd", "svgp_mnist_decoder_fwd", (cfg, th, img, ws, s), 2 * dec_mac * b,
+         f8 * (b * (Lc + act_dec + 2 * 784) + n_dec), 0.0),
+        ("decoder_bwd", "svgp_mnist_decoder_bwd", (cfg, th, img, ws, st, s), 4 * dec_mac * b,
+         f8 * (b * (Lc + act_dec + 2 * 784 + Lc) + 2 * n_dec), f8 * n_part * n_dec),
+        ("gp_stats_bwd", "svgp_gp_stats_bwd_with_aji", (cfg, ws, st, s), 3 * Lc * b * m * m,
+         f8 * (b * m + 9 * b * Lc + Lc * m * (m + 2)), 0.0),
+        ("gp_factor_bwd", "svgp_gp_factor_bwd_nofinal", (cfg, ws, st, s), Lc * 9 * 2 * m ** 3, f8 * Lc * 14 * m * m, 0.0),
+        ("gp_posterior_bwd", "svgp_gp_posterior_bwd_with_final", (cfg, ws, st, s), 6 * Lc * b * m * m,
+         f8 * (Lc * 3 * m * m + 2 * Lc * b * m + 12 * b * Lc), 0.0),
+        ("kernel_matrix_bwd", "svgp_kernel_matrix_bwd_partials", (cfg, th, aux, ws, s),
+         (2 * b * m + 2 * m * m) * (2 * D + 20), f8 * (2 * b * m + 2 * m * m + b * (D + 1) + N_OBJ * (D - 1)), 0.0),
+        ("encoder_bwd", "svgp_mnist_encoder_bwd", (cfg, th, img, ws, s), 4 * enc_mac * b,
+         f8 * (b * (784 + act_enc + 3 * Lc) + 2 * n_enc), f8 * n_part * n_enc),
+        ("grad_reduce", "svgp_mnist_grad_reduce_all", (cfg, aux, ws, s), n_part * (n_enc + n_dec),
+         f8 * (n_enc + n_dec), f8 * n_part * (n_enc + n_dec)),
     ]
 
 
-def time_stages(eng, reps=50):
+def time_stages(eng, B, M_IND, reps=50):
     """HIP events on the engine's own stream around `reps` back-to-back launches of each stage
     (inputs of every stage are valid after one full step).  Returns list of dicts sorted by time."""
     from svgp_vae_amd import _lib
@@ -92,7 +205,7 @@ def time_stages(eng, reps=50):
     e0, e1 = C.c_void_p(), C.c_void_p()
     _lib.call("svgp_event_create", C.byref(e0)); _lib.call("svgp_event_create", C.byref(e1))
     rows = []
-    for name, sym, args, flops, nbytes in stage_table(eng):
+    for name, sym, args, flops, nbytes, pbytes in stage_table(eng, B, M_IND):
         fn = getattr(lib, sym)
         for _ in range(3):
             _lib.check(fn(*args))
@@ -102,15 +215,14 @@ def time_stages(eng, reps=50):
         _lib.call("svgp_event_record", e1, s)
         ms = C.c_float()
         _lib.call("svgp_event_elapsed_ms", e0, e1, C.byref(ms))
-        rows.append(dict(stage=name, us=ms.value * 1e3 / reps, flops=float(flops), bytes=float(nbytes)))
+        rows.append(dict(stage=name, us=ms.value * 1e3 / reps, flops=float(flops), bytes=float(nbytes),
+                         partials_bytes=float(pbytes)))
     _lib.call("svgp_event_destroy", e0); _lib.call("svgp_event_destroy", e1)
     return sorted(rows, key=lambda r: -r["us"])
 
 
-def cpu_baseline(params, images, aux, eps, gpu_elbo, budget_s=15.0):
-    """The oracle's LITERAL formulation (same op sequence as the reference incl. the (b,m,m) tensor,
-    explicit inverses, autograd + TF1 Adam) timed on this host's cores.  kind = "port".
-    Also the parity gate of the run: the GPU's ELBO of the explicit-eps step vs the oracle's."""
+def oracle_elbo(params, images, aux, eps):
+    """ELBO of the explicit-eps GECO step from the oracle's efficient formulation (float64 torch-CPU)."""
     from oracle import svgpvae_oracle as O
     p = {k: torch.tensor(np.asarray(v), dtype=O.DT) for k, v in params.items()}
     ti, ta, te = (torch.tensor(x, dtype=O.DT) for x in (images, aux, eps))
@@ -118,61 +230,441 @@ def cpu_baseline(params, images, aux, eps, gpu_elbo, budget_s=15.0):
                               lagrange_mult=torch.ones((), dtype=O.DT), alpha=0.0, kappa=math.sqrt(0.020),
                               clipping_qs=True, GECO=True, jitter=1e-6, N_train=N_TRAIN, L=L,
                               formulation="efficient")
-    elbo_rel = abs(gpu_elbo - float(out[0])) / abs(float(out[0]))
-    assert elbo_rel < 1e-3, f"ELBO parity failed: GPU {gpu_elbo} oracle {float(out[0])}"
+    return float(out[0])
+
+
+def cpu_baseline_mnist(params, images, aux, eps, literal, budget_s=15.0):
+    """The oracle timed on this host's cores (kind = "port": a restatement, TF1 cannot run here).  literal=True: the
+    reference's own op sequence incl. the (b,m,m) tensor, explicit inverses and b x b diagonals (config 2); False: the
+    O(L b m^2) efficient formulation -- the literal form needs (b,m,m) tensors of 0.5 GB per channel at config 3."""
+    from oracle import svgpvae_oracle as O
+    p = {k: torch.tensor(np.asarray(v), dtype=O.DT) for k, v in params.items()}
+    ti, ta, te = (torch.tensor(x, dtype=O.DT) for x in (images, aux, eps))
     ms = {k: torch.zeros_like(v) for k, v in p.items()}
     vs = {k: torch.zeros_like(v) for k, v in p.items()}
     kw = dict(beta=0.001, C_ma=torch.zeros((), dtype=O.DT), lagrange_mult=torch.ones((), dtype=O.DT), alpha=0.0,
-              kappa=math.sqrt(0.020), clipping_qs=True, GECO=True, jitter=1e-6, N_train=N_TRAIN, L=L,
-              formulation="literal")
+              kappa=math.sqrt(0.020), clipping_qs=True, GECO=True, jitter=1e-6, N_train=N_TRAIN, L=L)
+    ctr = [1]
 
-    def one(t):
-        _, g = O.loss_and_grads(p, ti, ta, te, **kw)
-        O.adam_tf1_step(p, g, ms, vs, t, 1e-3)
+    def one(form):
+        _, g = O.loss_and_grads(p, ti, ta, te, formulation=form, **kw)
+        O.adam_tf1_step(p, g, ms, vs, ctr[0], 1e-3)
+        ctr[0] += 1
 
-    # torch-CPU on a many-core host is slowest with all threads on these small ops (128 threads: 0.11 steps/s);
-    # probe a few thread counts and keep the fastest for the reported baseline
-    one(1)
-    best, step_no = (None, float("inf")), 2
-    for nt in sorted({4, 8, 16, 32, min(64, os.cpu_count() or 8)}):
-        if nt > (os.cpu_count() or 8):
-            continue
-        torch.set_num_threads(nt)
-        one(step_no); step_no += 1
-        t1 = time.perf_counter(); one(step_no); step_no += 1
-        dt = time.perf_counter() - t1
-        if dt < best[1]:
-            best = (nt, dt)
-    torch.set_num_threads(best[0])
+    main = "literal" if literal else "efficient"
+    threads = pick_threads(lambda: one(main))
     n, t0 = 0, time.perf_counter()
     while True:
-        one(step_no + n)
+        one(main)
         n += 1
         el = time.perf_counter() - t0
-        if (el > budget_s and n >= 5) or n >= 400:
+        if (el > budget_s and n >= 3) or n >= 400:
             break
-    # the O(L b m^2) restatement on the same threads, for reference: 4 s
-    kw_eff = dict(kw, formulation="efficient")
-    ne, te0 = 0, time.perf_counter()
+    out = dict(value=n / el, unit="steps/s", cores=os.cpu_count(), threads=threads, kind="port",
+               formulation=main,
+               sample=f"{n} {main}-formulation float64 steps (torch-CPU autograd + TF1 Adam) of the same "
+                      f"{images.shape[0]}-row batch, {el:.1f} s, {threads} threads (fastest probed) on a "
+                      f"{os.cpu_count()}-core host")
+    if literal:      # the O(L b m^2) restatement on the same threads, for reference (BASELINE.md section 3): 4 s
+        ne, te0 = 0, time.perf_counter()
+        while True:
+            one("efficient")
+            ne += 1
+            ele = time.perf_counter() - te0
+            if (ele > 4.0 and ne >= 3) or ne >= 400:
+                break
+        out["efficient_formulation_steps_per_s"] = ne / ele
+    return out
+
+
+def run_mnist(args):
+    rank, local_rank, world = dist_env()
+    cfg3 = args.workload == "cfg3"
+    B, M_IND, MDIM = (1024, 256, 32) if cfg3 else (256, 32, 8)
+    if args.scaling == "strong":
+        gb = args.global_batch or B * 8
+        if gb % world:
+            raise SystemExit(f"--global-batch {gb} is not divisible by {world} ranks")
+        B = gb // world
+    import torch.distributed as dist
+    multi = world > 1 or args.force_dist
+    if multi:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    from svgp_vae_amd.engine import MnistStepEngine
+    params, images, aux, eps = synthetic_problem(rank, B, M_IND, MDIM)
+    dev = torch.device(f"cuda:{local_rank}")
+    eng = MnistStepEngine(M_IND, L, MDIM, N_OBJ, N_train=N_TRAIN, jitter=1e-6, clip_qs=True, geco=True,
+                          kappa_squared=0.020, alpha=0.99, beta=0.001, lr=1e-3, b_max=B, device=str(dev),
+                          rank=rank, world_size=world)
+    eng.load_params(params)
+    d_img, d_aux, d_eps = (torch.tensor(x, dtype=torch.float64, device=dev).contiguous() for x in (images, aux, eps))
+
+    use_graph = not multi and not args.no_graph and not args.force_comm
+    launch, comm_ranks = None, None
+    if (multi or args.force_comm) and args.exchange == "rccl":
+        # the three all-reduces are issued by the library on the compute stream (svgp_mnist_train_step_dp)
+        try:
+            from svgp_vae_amd.engine import RcclComm
+            comm = RcclComm.from_process_group() if multi else RcclComm(0, 1, RcclComm.unique_id())
+            eng.attach_comm(comm)
+            comm_ranks = comm.world_size
+            launch = "one in-order stream: phases + in-library RCCL all-reduce x3"
+        except Exception as e:   # both legs are RCCL; this only changes who enqueues the collective
+            print(f"[bench] rank {rank}: in-library RCCL communicator unavailable ({e}); "
+                  f"using torch.distributed all_reduce between per-phase graphs", file=sys.stderr, flush=True)
+
+    # ---- parity gate: ONE explicit-eps step (no optimiser update) through the same exchange path the timed region
+    # uses; its ELBO is checked against the oracle's efficient formulation on the GLOBAL batch (all ranks' rows are
+    # regenerated on rank 0 from their seeds).  north_star: "1/2/4/8-GPU ELBO equal at the same global batch".
+    eng.bind(d_img, d_aux, d_eps)
+    eng.run(adam=False)
+    eng.synchronize()
+    gpu_elbo = eng.scalars()["elbo"]
+    eng.reset_state()
+    elbo_rel = None
+    if rank == 0 and not args.no_parity_gate:
+        parts = [synthetic_problem(r, B, M_IND, MDIM) for r in range(world)]
+        want = oracle_elbo(params, *(np.concatenate([p[i] for p in parts], 0) for i in (1, 2, 3)))
+        elbo_rel = abs(gpu_elbo - want) / abs(want)
+        assert elbo_rel < 1e-3, f"ELBO parity failed at {world} rank(s): GPU {gpu_elbo} oracle {want}"
+    if multi:
+        dist.barrier()
+
+    # ---- timed region: eps drawn on device every step (tf.random.normal, SVGPVAE_model.py:901)
+    eng.bind(d_img, d_aux, None)
+    if use_graph:
+        eng.capture("step", adam=True)
+        step = lambda: eng.replay("step")
+        launch = "hipGraph replay"
+    elif launch is not None:
+        step = lambda: eng.run(adam=True)
+    elif not args.no_graph and multi:
+        # one hipGraph per phase, torch.distributed (RCCL) all-reduces (not captured) in between
+        eng.capture_phases("step", adam=True)
+        step = lambda: eng.run_phase_graphs("step")
+        launch = "per-phase hipGraphs + torch.distributed RCCL all-reduce x3"
+        comm_ranks = dist.get_world_size()
+    else:
+        step = lambda: eng.run(adam=True)
+        launch = "eager phases" + (" + torch.distributed RCCL all-reduce x3" if multi else "")
+    blocks = timed_blocks(step, eng.synchronize, args.steps, args.warmup, args.repeats, multi, dev)
+    el = float(np.median(blocks))
+    sc = eng.scalars()
+    assert math.isfinite(sc["elbo"]) and sc["adam_t"] >= args.steps * args.repeats, sc
+    # per-stage HIP-event timings of this rank's launches (rank-local kernels, no collective inside): every rank runs
+    # them so that nobody waits on rank 0, rank 0 reports
+    stage_rows = time_stages(eng, B, M_IND, reps=20 if cfg3 else 50)
+    if multi:
+        dist.barrier()
+
+    if rank == 0:
+        step_flops = sum(r["flops"] for r in stage_rows)
+        name = ("BASELINE configs[1]: rotated-MNIST SVGPVAE_Hensman, m=32 inducing, L=16, GPLVM dim 8, batch 256 per "
+                "GPU, N_train=4050, GECO + clip_qs, float64") if not cfg3 else \
+               ("BASELINE configs[2]: rotated-MNIST SVGPVAE_Hensman, m=256 inducing, L=16, GPLVM dim 32 (SURVEY F9), "
+                "batch 1024 per GPU, N_train=4050, GECO + clip_qs, float64, large-m GEMM path")
+        line = {
+            "metric": "SVGPVAE train steps/sec, rotated MNIST (N=4050, M=32, L=16)" if not cfg3 else
+                      "SVGPVAE train steps/sec, rotated MNIST (N=4050, M=256, L=16, batch 1024)",
+            "value": world * args.steps / el if args.scaling == "weak" else args.steps / el,
+            "unit": f"steps/s ({B}-row batches, whole job)" if args.scaling == "weak" else
+                    f"steps/s ({B * world}-row global batches)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "repeats": args.repeats, "block_ms": [round(x * 1e3, 3) for x in blocks], "timing": "median block",
+            "config": {"workload": name, "global_batch": B * world, "rows_per_gpu": B, "launch": launch,
+                       "parallelism": f"dp{world}", "rccl_ranks": comm_ranks,
+                       "scaling_note": ("weak: rows per GPU fixed, the global batch (and so c = N_train / b_global of "
+                                        "SVGPVAE_model.py:328) grows with N" if args.scaling == "weak" else
+                                        "strong: global batch fixed, rows per GPU = global / N")},
+            "elbo_rel_err_gpu_vs_oracle": elbo_rel,
+        }
+        top = stage_rows[0]
+        traffic, src = committed_traffic("k_" + top["stage"]) if not cfg3 else (None, None)
+        roof = roofline_of(top["flops"], top["bytes"], top["us"], F64_PEAK_TFLOPS, kernel=top["stage"],
+                           implementation_partials_bytes=top["partials_bytes"],
+                           note="config 2 is latency-bound (DESIGN.md section 5); " * (not cfg3) +
+                                "stage = one C entry point, HIP events on the launch stream")
+        roof["traffic"], roof["traffic_source"] = traffic, src
+        line["roofline"] = roof
+        line["step_roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": F64_PEAK_TFLOPS,
+                                 "algorithmic_flops": step_flops,
+                                 "achieved": step_flops / (el / args.steps) / 1e12,
+                                 "frac": step_flops / (el / args.steps) / 1e12 / F64_PEAK_TFLOPS}
+        line["stages_us"] = {r["stage"]: round(r["us"], 2) for r in stage_rows}
+        line["step_flops"] = step_flops
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_mnist(params, images, aux, eps, literal=not cfg3)
+        emit(line)
+    if multi:
+        dist.destroy_process_group()
+
+
+# =====================================================================================================================
+# sprites800: BASELINE configs[3] shape, one GPU's share (500 frames, L=64, m=800)
+# =====================================================================================================================
+def sprites_problem(rank, b, L_, La, Lc, n_act, m, seed=0):
+    rs = np.random.RandomState(seed)
+    ip = rs.normal(0, 1.5, (m, La + Lc))
+    table = rs.normal(0, 1.5, (n_act, La))
+    g = torch.Generator().manual_seed(rank)
+    img = torch.rand(b, 64, 64, 3, dtype=torch.float64, generator=g)
+    ids = torch.tensor(np.random.RandomState(rank).randint(0, n_act, b), dtype=torch.float64)
+    eps = torch.randn(b, L_, dtype=torch.float64, generator=g)
+    return ip, table, img, ids, eps
+
+
+def sprites_flops(b, L_, m, D=24):
+    """nets 35 MMAC/frame fwd (x3 fwd+bwd), GP block F_gp = (5L+2) b m^2 + 5.33 L m^3 (x3) + kernel build."""
+    nets = 3 * 2 * 35.0e6 * b
+    gp = 3 * ((5 * L_ + 2) * b * m * m + 5.33 * L_ * m ** 3) + 3 * (b * m + m * m) * (2 * D + 12)
+    return nets, gp
+
+
+def run_sprites(args):
+    rank, local_rank, world = dist_env()
+    import torch.distributed as dist
+    from svgp_vae_amd import sprites as S
+    from svgp_vae_amd.engine import RcclComm
+    multi = world > 1
+    comm = None
+    if multi:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        comm = RcclComm.from_process_group()
+    elif args.force_comm:
+        comm = RcclComm(0, 1, RcclComm.unique_id())
+    b, frames, L_, La, Lc, n_act, m = 500, 50, 64, 8, 16, 72, args.m or 800
+    ip, table, img, ids, eps = sprites_problem(rank, b, L_, La, Lc, n_act, m)
+    svgp = S.spritesSVGP(False, False, ip, 'main', 0.01, 50000, La, table, Lc, L_, K_obj_normalize=True)
+    eng = S.SpritesStepEngine(S.spritesVAE(L_), S.sprites_representation_network(Lc), svgp, b_max=b, seg_len=frames,
+                              geco=True, kappa_squared=0.0075, clip_grad=1e6, device=f"cuda:{local_rank}", rank=rank,
+                              world_size=world, comm=comm)
+    dev = eng.dev
+    d_img, d_ids, d_eps = img.to(dev), ids.to(dev), eps.to(dev)
+    # parity gate (N = 1): explicit-eps step, ELBO against the oracle's efficient formulation -- inside cpu_baseline
+    eng.step(d_img, d_ids, d_eps, adam=False)
+    gpu_elbo = eng.scalars()["elbo"]
+    eng.set_scalars(c_ma=0.0, lagrange=1.0, alpha=0.0)
+    step = lambda: eng.step(d_img, d_ids, None, adam=True)
+    blocks = timed_blocks(step, eng.stream.synchronize, args.steps, args.warmup, args.repeats, multi, dev)
+    el = float(np.median(blocks))
+    # ---- stage times: HIP events recorded on the engine's stream at the stage boundaries of one more step
+    eng.trace = []
+    step()
+    eng.stream.synchronize()
+    marks, eng.trace = eng.trace, None
+    stages = {}
+    for (n0, e0), (_, e1) in zip(marks[:-1], marks[1:]):
+        stages[n0] = stages.get(n0, 0.0) + e0.elapsed_time(e1) * 1e3
+    sc = eng.scalars()
+    assert math.isfinite(sc["elbo"]), sc
+    if rank == 0:
+        nets, gp = sprites_flops(b, L_, m)
+        ms = el / args.steps * 1e3
+        line = {
+            "metric": f"SVGPVAE train steps/sec, SPRITES 64x64 (m={m}, L=64, 500 frames per GPU)",
+            "value": world * args.steps / el, "unit": "steps/s (500-frame batches, whole job)", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": eng.dtype_name if hasattr(eng, "dtype_name") else "f64", "data": "synthetic",
+            "repeats": args.repeats, "block_ms": [round(x * 1e3, 3) for x in blocks], "timing": "median block",
+            "config": {"workload": f"BASELINE configs[3] shape: SPRITES SVGPVAE_Hensman + GPLVM, {b} frames per GPU "
+                                   f"(10 characters x 50), L=64, L_action=8, L_character=16, m={m}, jitter 0.01, "
+                                   f"cosine-normalised linear x linear kernel, GECO, gradient clip 1e6",
+                       "global_batch": b * world, "rows_per_gpu": b, "parallelism": f"dp{world}",
+                       "rccl_ranks": None if comm is None else comm.world_size,
+                       "launch": "eager stream" + ("" if comm is None else " + in-library RCCL all-reduce x3")},
+        }
+        peak = F64_PEAK_TFLOPS
+        top = max(stages, key=stages.get)
+        gflops = {"gp_fwd": gp / 3, "gp_bwd": 2 * gp / 3, "nets_fwd": nets / 3, "nets_bwd": 2 * nets / 3}
+        grp = "gp_" + ("fwd" if "fwd" in top else "bwd") if top.startswith("gp") else \
+              "nets_" + ("fwd" if "fwd" in top else "bwd")
+        grp_us = sum(v for k, v in stages.items() if (k.startswith("gp") == grp.startswith("gp")) and
+                     (("fwd" in k) == ("fwd" in grp)))
+        line["roofline"] = roofline_of(gflops[grp], 1.0, grp_us, peak, kernel=grp,
+                                       note="stage group = the launches between two HIP events on the engine stream; "
+                                            "algorithmic flops of SURVEY 8d split 1/3 forward, 2/3 reverse")
+        line["step_roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "algorithmic_flops": nets + gp,
+                                 "achieved": (nets + gp) / (ms * 1e-3) / 1e12,
+                                 "frac": (nets + gp) / (ms * 1e-3) / 1e12 / peak,
+                                 "frac_of_f32_peak": (nets + gp) / (ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS}
+        line["stages_us"] = {k: round(v, 1) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_sprites(ip, table, img, ids, eps, gpu_elbo, L_, La, Lc, m, frames)
+            line["elbo_rel_err_gpu_vs_oracle"] = line["cpu_baseline"].pop("elbo_rel_err_gpu_vs_oracle")
+        emit(line)
+    if multi:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_sprites(ip, table, img, ids, eps, gpu_elbo, L_, La, Lc, m, frames):
+    """ONE efficient-formulation float64 step of the oracle (torch-CPU autograd) on the same 500-frame batch: the
+    literal form's (b,m,m) tensors are 2.6 GB per channel x 64 channels.  Also the run's ELBO parity gate."""
+    from oracle import sprites_oracle as SO
+    DT = torch.float64
+    from svgp_vae_amd.sprites import glorot_uniform_params
+    params = {k: torch.as_tensor(np.asarray(v), dtype=DT) for k, v in glorot_uniform_params(L_, Lc, 0).items()}
+    gp = dict(inducing_index_points=torch.tensor(ip, dtype=DT), GPLVM_action=torch.tensor(table, dtype=DT),
+              l_action=torch.tensor(1.0, dtype=DT), sigma_action=torch.tensor(1.0, dtype=DT),
+              l_character=torch.tensor(1.0, dtype=DT), sigma_character=torch.tensor(1.0, dtype=DT))
+    b = img.shape[0]
+    seg, rep = SO.aux_data_sprites_utils(b, frames, frames)
+    kw = dict(beta=0.001, C_ma=torch.tensor(0.0, dtype=DT), lagrange_mult=torch.tensor(1.0, dtype=DT), alpha=0.0,
+              kappa=math.sqrt(0.0075), L=L_, L_action=La, jitter=0.01, N_train=50000.0, segment_ids=seg, repeats=rep,
+              clipping_qs=False, GECO=True, K_obj_normalize=True, K_SE=False, clip_grad=1e6, titsias=False)
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    t0 = time.perf_counter()
+    want, _ = SO.loss_and_grads(params, gp, (img, ids.long()), eps, formulation="efficient", **kw)
+    el = time.perf_counter() - t0
+    rel = abs(gpu_elbo - float(want[0])) / abs(float(want[0]))
+    assert rel < 1e-3, f"ELBO parity failed: GPU {gpu_elbo} oracle {float(want[0])}"
+    return dict(value=1.0 / el, unit="steps/s", cores=os.cpu_count(), threads=torch.get_num_threads(), kind="port",
+                formulation="efficient", elbo_rel_err_gpu_vs_oracle=rel,
+                sample=f"1 efficient-formulation float64 forward + autograd reverse of the same {b}-frame batch "
+                       f"(no Adam update), {el:.1f} s")
+
+
+# =====================================================================================================================
+# cfg5: BASELINE configs[4], one GPU's shard: N = 131072 rows, m = 2048, L = 16, float32
+# =====================================================================================================================
+def run_cfg5(args):
+    rank, local_rank, world = dist_env()
+    import torch.distributed as dist
+    from svgp_vae_amd import stream_stats as SS
+    multi = world > 1
+    comm = None
+    if multi:
+        from svgp_vae_amd.engine import RcclComm
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        comm = RcclComm.from_process_group()
+    dev = torch.device(f"cuda:{local_rank}")
+    torch.cuda.set_device(dev)
+    n, m, L_, M = args.rows or 131072, args.m or 2048, 16, 8
+    g = torch.Generator(device="cpu").manual_seed(rank)
+    n_obj = 400
+    kd = SS.kernel_desc(SS.PERIODIC_LINEAR, 2, M, n_table=n_obj, params=(1.0, 1.0))
+    tab = (torch.randn(n_obj, M, generator=g) * 1.5).to(dev)
+    x = torch.cat([torch.randint(0, n_obj, (n, 1), generator=g).float(), torch.rand(n, 1, generator=g) * 6.2832,
+                   torch.randn(n, M, generator=g)], 1).to(dev).contiguous()
+    z = torch.cat([torch.zeros(m, 1), torch.rand(m, 1, generator=g) * 6.2832,
+                   torch.randn(m, M, generator=g) * 1.5], 1).to(dev).contiguous()
+    D = 2 + M
+    means = torch.randn(n, L_, generator=g).to(dev)
+    vars_ = (torch.rand(n, L_, generator=g) * 9.999 + 1e-3).to(dev)
+    fi = SS.features(kd, z, inducing=True)
+    K = torch.empty((n, m), dtype=torch.float32, device=dev)
+    ws = SS.stats_workspace(n, m, L_, dev)
+    S = torch.empty((L_, m, m), dtype=torch.float32, device=dev)
+    v = torch.empty((L_, m), dtype=torch.float32, device=dev)
+    fr_box = [SS.features(kd, x, inducing=False, table=tab)]
+
+    def step():      # one pass of the N-sized statistics: features -> K_nm (materialised, 5a) -> S_l, v_l (5b) [-> all-reduce]
+        fr_box[0] = SS.features(kd, x, inducing=False, table=tab)
+        SS.knm(kd, fr_box[0], n, fi, m, out=K)
+        SS.stats(K, means, vars_, ws=ws, S=S, v=v, comm=comm)
+
+    blocks = timed_blocks(step, torch.cuda.synchronize, args.steps, args.warmup, args.repeats, multi, dev)
+    el = float(np.median(blocks))
+
+    def ev_time(fn, reps=5):         # SS.* launch on torch's current stream: torch events see them
+        fn(); torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev[0].record()
+        for i in range(reps):
+            fn(); ev[i + 1].record()
+        torch.cuda.synchronize()
+        return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))[reps // 2] * 1e3
+
+    us_feat = ev_time(lambda: SS.features(kd, x, inducing=False, table=tab))
+    us_knm = ev_time(lambda: SS.knm(kd, fr_box[0], n, fi, m, out=K))
+    us_stats = ev_time(lambda: SS.stats(K, means, vars_, ws=ws, S=S, v=v))
+    # parity probe at the full size (float64 GEMV chain): S_l w == K^T (p_l * (K w)), v_l == K^T (p_l * mean_l)
+    w = torch.randn(m, generator=g).to(dev).double()
+    Kw = K.double() @ w
+    p = torch.where(vars_ == 0, torch.zeros_like(vars_), 1.0 / vars_).double()
+    SS.stats(K, means, vars_, ws=ws, S=S, v=v)
+    err = 0.0
+    for l in range(L_):
+        ref = K.t().double() @ (p[:, l] * Kw)
+        err = max(err, float(((S[l].double() @ w) - ref).abs().max() / ref.abs().max()))
+    assert err < 1e-4, err
+    if rank == 0:
+        alg_flops = float(L_) * n * m * m          # symmetric count (SURVEY 8d: L N m^2)
+        knm_bytes = 4.0 * (n * m + n * D + m * D)
+        line = {
+            "metric": "SVGP statistics pass rows/sec (N=2^20 frames, m=2048, L=16, fp32; K_nm build + S_l, v_l)",
+            "value": world * n * args.steps / el, "unit": "rows/s (whole job)", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic", "repeats": args.repeats,
+            "block_ms": [round(x * 1e3, 3) for x in blocks], "timing": "median block",
+            "config": {"workload": f"BASELINE configs[4], one GPU's shard: {n} rows x m={m} inducing, L={L_}, "
+                                   f"periodic x linear kernel (D={D}), float32: features, materialised K_nm (5a), "
+                                   f"S_l / v_l statistics (5b)" + (", RCCL all-reduce of S, v" if multi else ""),
+                       "rows_per_gpu": n, "parallelism": f"dp{world}",
+                       "rccl_ranks": None if comm is None else comm.world_size},
+            "probe_rel_err_S": err,
+        }
+        t_s, src_s = committed_traffic("k_stats_mfma_f32")
+        line["roofline"] = roofline_of(alg_flops, 4.0 * (n * m + 2 * n * L_ + L_ * m * m), us_stats, F32_PEAK_TFLOPS,
+                                       kernel="stream_stats_f32 (k_stats_mfma_f32 + v_l + reduction)",
+                                       note="algorithmic flops L N m^2 (symmetric count, SURVEY 8d); executed 1.125x")
+        line["roofline"]["traffic"], line["roofline"]["traffic_source"] = t_s, src_s
+        t_k, src_k = committed_traffic("k_knm_f32")
+        line["roofline_knm"] = roofline_of((2 * D + 8) * n * m, knm_bytes, us_knm, F32_PEAK_TFLOPS,
+                                           kernel="stream_knm_f32 (materialised K_nm, HBM-write-bound)")
+        line["roofline_knm"]["traffic"], line["roofline_knm"]["traffic_source"] = t_k, src_k
+        line["stages_us"] = {"features": round(us_feat, 1), "knm": round(us_knm, 1), "stats": round(us_stats, 1)}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_cfg5(x, z, tab, means, vars_, m, L_, M)
+        emit(line)
+    if multi:
+        dist.destroy_process_group()
+
+
+def cpu_baseline_cfg5(x, z, tab, means, vars_, m, L_, M, budget_s=12.0):
+    """float32 torch-CPU restatement of the same pass (kernel matrix of mnistSVGP.kernel_matrix, then per channel
+    K_mn (K_nm / var_l), K_mn (mean_l / var_l), SVGPVAE_model.py:1004-1017) on a bounded row sample."""
+    xs, zs, tb = x.cpu(), z.cpu(), tab.cpu()
+    mu, var = means.cpu(), vars_.cpu()
+    rows = 4096
+
+    def one(lo):
+        xr = xs[lo:lo + rows]
+        o = tb[xr[:, 0].long()]
+        d = xr[:, 1:2] - zs[:, 1][None, :]
+        K = torch.exp(-2.0 * torch.sin(0.5 * d) ** 2) * (o @ zs[:, 2:].t())
+        p = 1.0 / var[lo:lo + rows]
+        S = torch.einsum('nl,ni,nj->lij', p, K, K) if False else torch.stack([(K * p[:, l:l + 1]).t() @ K for l in range(L_)])
+        vv = K.t() @ (p * mu[lo:lo + rows])
+        return S, vv
+
+    torch.set_num_threads(min(os.cpu_count() or 8, 64))
+    one(0)
+    n, t0 = 0, time.perf_counter()
     while True:
-        _, g = O.loss_and_grads(p, ti, ta, te, **kw_eff)
-        O.adam_tf1_step(p, g, ms, vs, step_no + n + ne, 1e-3)
-        ne += 1
-        ele = time.perf_counter() - te0
-        if (ele > 4.0 and ne >= 3) or ne >= 400:
+        one((n * rows) % (xs.shape[0] - rows + 1))
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s and n >= 2:
             break
-    return dict(value=n / el, unit="steps/s", cores=torch.get_num_threads(), kind="port",
-                elbo_rel_err_gpu_vs_oracle=elbo_rel, efficient_formulation_steps_per_s=ne / ele,
-                sample=f"{n} literal-formulation float64 steps (torch-CPU autograd + TF1 Adam) of the same "
-                       f"config-2 batch, {el:.1f} s")
+    return dict(value=n * rows / el, unit="rows/s", cores=os.cpu_count(), threads=torch.get_num_threads(), kind="port",
+                sample=f"{n} chunks of {rows} rows (of {xs.shape[0]}) through float32 torch-CPU K_nm + S_l, v_l for "
+                       f"m={m}, L={L_}, {el:.1f} s")
 
 
+# =====================================================================================================================
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--repeats", type=int, default=5, help="blocks of --steps steps; the median block is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-gate", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--exchange", choices=["rccl", "torch"], default="rccl",
                     help="N>1: who enqueues the three all-reduces -- the library on the compute stream (rccl) or "
@@ -182,147 +674,26 @@ def main():
                          "broadcast_object_list, barriers, MAX all-reduce of the time) with world size 1")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1: run the data-parallel entry point with a 1-rank communicator (plumbing check)")
-    ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--global-batch", type=int, default=None, help="--scaling strong: rows of the fixed global batch")
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "sprites800", "cfg5"], default="cfg2",
                     help="cfg2 = BASELINE configs[1] (the metric's configuration, default); cfg3 = configs[2] "
-                         "(m=256, b=1024, GPLVM dim 32: large-m path) for information only")
+                         "(m=256, b=1024, GPLVM dim 32); sprites800 = configs[3] shape on one GPU's share; "
+                         "cfg5 = configs[4] shard (N=131072, m=2048, float32 statistics pass)")
+    ap.add_argument("--m", type=int, default=None, help="sprites800 / cfg5: inducing points (default 800 / 2048)")
+    ap.add_argument("--rows", type=int, default=None, help="cfg5: rows per GPU (default 131072)")
     args = ap.parse_args()
-    global B, M_IND, MDIM
-    if args.workload == "cfg3":
-        B, M_IND, MDIM = 1024, 256, 32
+    dflt = {"cfg2": (300, 30), "cfg3": (30, 5), "sprites800": (3, 1), "cfg5": (3, 1)}[args.workload]
+    args.steps = dflt[0] if args.steps is None else args.steps
+    args.warmup = dflt[1] if args.warmup is None else args.warmup
+    if args.workload in ("sprites800", "cfg5") and args.repeats > 3:
+        args.repeats = 3
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = dist_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
-    import torch.distributed as dist
-    multi = world > 1 or args.force_dist
-    if multi:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-
-    from svgp_vae_amd.engine import MnistStepEngine
-    params, images, aux, eps = synthetic_problem(rank)
-    dev = torch.device(f"cuda:{local_rank}")
-    eng = MnistStepEngine(M_IND, L, MDIM, N_OBJ, N_train=N_TRAIN, jitter=1e-6, clip_qs=True, geco=True,
-                          kappa_squared=0.020, alpha=0.99, beta=0.001, lr=1e-3, b_max=B, device=str(dev),
-                          rank=rank, world_size=world)
-    eng.load_params(params)
-    d_img, d_aux, d_eps = (torch.tensor(x, dtype=torch.float64, device=dev).contiguous() for x in (images, aux, eps))
-
-    # ---- one explicit-eps step whose ELBO the cpu_baseline leg checks against the oracle
-    gpu_elbo = None
-    if world == 1:
-        eng.bind(d_img, d_aux, d_eps)
-        eng.run(adam=False)
-        eng.synchronize()
-        gpu_elbo = eng.scalars()["elbo"]
-        eng.reset_state()
-
-    # ---- timed region: eps drawn on device every step (tf.random.normal, SVGPVAE_model.py:901)
-    eng.bind(d_img, d_aux, None)
-    use_graph = not multi and not args.no_graph and not args.force_comm
-    if use_graph:
-        eng.capture("step", adam=True)
-        step = lambda: eng.replay("step")
-    else:
-        launch = None
-        if (multi or args.force_comm) and args.exchange == "rccl":
-            # the three all-reduces are issued by the library on the compute stream (svgp_mnist_train_step_dp)
-            try:
-                from svgp_vae_amd.engine import RcclComm
-                comm = RcclComm.from_process_group() if multi else RcclComm(0, 1, RcclComm.unique_id())
-                eng.attach_comm(comm)
-                step = lambda: eng.run(adam=True)
-                launch = "one in-order stream: phases + in-library RCCL all-reduce x3"
-            except Exception as e:   # both legs are RCCL; this only changes who enqueues the collective
-                print(f"[bench] rank {rank}: in-library RCCL communicator unavailable ({e}); "
-                      f"using torch.distributed all_reduce between per-phase graphs", file=sys.stderr, flush=True)
-        if launch is None and not args.no_graph:
-            # one hipGraph per phase, torch.distributed (RCCL) all-reduces (not captured) in between
-            eng.capture_phases("step", adam=True)
-            step = lambda: eng.run_phase_graphs("step")
-            launch = "per-phase hipGraphs + torch.distributed RCCL all-reduce x3"
-        elif launch is None:
-            step = lambda: eng.run(adam=True)
-            launch = "eager phases + torch.distributed RCCL all-reduce x3"
-    for _ in range(args.warmup):
-        step()
-    eng.synchronize()
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    eng.synchronize()
-    torch.cuda.synchronize()
-    if multi:
-        dist.barrier()
-    el = time.perf_counter() - t0
-    if multi:
-        t = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    sc = eng.scalars()
-    assert math.isfinite(sc["elbo"]) and sc["adam_t"] >= args.steps, sc
-    # per-stage HIP-event timings of this rank's launches (rank-local kernels, no collective inside): every rank runs
-    # them so that nobody waits on rank 0, rank 0 reports
-    stage_rows = time_stages(eng) if args.workload == "cfg2" else None
-    if multi:
-        dist.barrier()
-
-    if rank == 0:
-        line = {
-            "metric": "SVGPVAE train steps/sec, rotated MNIST (N=4050, M=32, L=16)",
-            "value": world * args.steps / el, "unit": f"steps/s ({B}-row batches, whole job)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": ("BASELINE configs[1]: rotated-MNIST SVGPVAE_Hensman, m=32 inducing, L=16, "
-                                    "GPLVM dim 8, batch 256 per GPU, N_train=4050, GECO + clip_qs, float64")
-                       if args.workload == "cfg2" else
-                       ("BASELINE configs[2] (information only): m=256 inducing, L=16, GPLVM dim 32, batch 1024 per "
-                        "GPU, N_train=4050, GECO + clip_qs, float64, large-m GEMM path"),
-                       "global_batch": B * world, "rows_per_gpu": B,
-                       "launch": "hipGraph replay" if use_graph else launch,
-                       "parallelism": f"dp{world}"},
-        }
-        if args.workload == "cfg2":
-            rows = stage_rows
-            top = rows[0]
-            ai = top["flops"] / top["bytes"]
-            if ai >= F64_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
-                ach = top["flops"] / (top["us"] * 1e-6) / 1e12
-                roof = {"bound": "mfma", "achieved": ach, "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / F64_PEAK_TFLOPS}
-            else:
-                ach = top["bytes"] / (top["us"] * 1e-6) / 1e9
-                roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS}
-            # HBM traffic per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json);
-            # bench.py cannot run the profiler on itself, so the value is null when no summary is committed
-            traffic = None
-            try:
-                import glob
-                pmc = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]))
-                traffic = pmc["kernels"]["k_" + top["stage"]]["hbm_bytes_per_launch_corrected"]
-            except Exception:
-                pass
-            roof.update(traffic=traffic, kernel=top["stage"], launch_us=top["us"], algorithmic_bytes=top["bytes"],
-                        algorithmic_flops=top["flops"], note="latency-bound config: see DESIGN.md section 5")
-            line["roofline"] = roof
-            line["stages_us"] = {r["stage"]: round(r["us"], 2) for r in rows}
-            line["step_flops"] = sum(r["flops"] for r in rows)
-            if world == 1 and not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline(params, images, aux, eps, gpu_elbo)
-        # RCCL prints a version banner through C stdio at communicator creation; flush it first so the
-        # JSON line is the last line on stdout
-        C.CDLL(None).fflush(None)
-        sys.stdout.flush()
-        print(json.dumps(line), flush=True)
-    if multi:
-        dist.destroy_process_group()
+    {"cfg2": run_mnist, "cfg3": run_mnist, "sprites800": run_sprites, "cfg5": run_cfg5}[args.workload](args)
 
 
 if __name__ == "__main__":

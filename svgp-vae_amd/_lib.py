@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsvgpvae_hip.so")
+# SVGP_LIB_PATH: load another build of the SAME library (the host-ASan build of `make asan`); never a fallback
+LIB_PATH = os.environ.get("SVGP_LIB_PATH") or os.path.join(_HERE, "libsvgpvae_hip.so")
 
 
 class SvgpError(RuntimeError):

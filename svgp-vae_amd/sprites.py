@@ -176,6 +176,14 @@ class SpritesStepEngine:
         self.act = {}
 
     # ------------------------------------------------------------------ helpers
+    trace = None     # bench.py: a list -> (stage name, event) appended at the stage boundaries of phases()
+
+    def _mark(self, name):
+        if self.trace is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(self.stream)
+            self.trace.append((name, e))
+
     def _v(self, name, shape):
         off = getattr(self.wl, name)
         return self.ws[off:off + int(np.prod(shape))].view(shape)
@@ -326,12 +334,14 @@ class SpritesStepEngine:
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.stream):
             images = images.contiguous()
+            self._mark("nets_fwd_enc")
             a, enc, mu, var_raw, var = self._encoder_forward(images, b)
             r, rvec = self._repr_forward(images, b)
             aux = torch.empty(b, 1 + self.Lc, **f64)
             aid = action_ids.to(_F64).contiguous()
             call("svgp_sprites_aux_fwd", b, self.seg_len, self.Lc, rvec.data_ptr(), aid.data_ptr(), aux.data_ptr(), s)
             # ---------------- kernel matrices + sparse-GP block
+            self._mark("gp_fwd_stats")
             kc = SpritesKcfg(b=b, m=self.m, La=self.La, Lc=self.Lc, n_act=self.n_act,
                              normalize=int(self.svgp.K_obj_normalize), k_se=int(self.svgp.K_SE),
                              rep_weight=1.0 if self.rank == 0 else 0.0)
@@ -343,12 +353,14 @@ class SpritesStepEngine:
                 call("svgp_gp_titsias_stats", cp, ws, s)
         yield [self.ws[self.wl.statA:self.wl.statA + self.wl.statA_len]]
         with torch.cuda.stream(self.stream):
+            self._mark("gp_fwd_factor")
             call("svgp_gp_factor_fwd", cp, ws, s)
             call("svgp_gp_posterior_fwd", cp, None if eps is None else eps.contiguous().data_ptr(), ws, st, s)
             if self.svgp.titsias:
                 call("svgp_gp_titsias_fwd", cp, ws, st, s)
             # ---------------- decoder
             z = self._v("z", (b, L))
+            self._mark("nets_fwd_dec")
             h0, d = self._decoder_forward(z, b)
             x = d[-1]
             recon = x
@@ -356,6 +368,7 @@ class SpritesStepEngine:
             call("svgp_sqerr_fwd", tot, min(b, 256), images.data_ptr(), recon.data_ptr(),
                  self._v("part_sums", (1,)).data_ptr(), s)
             # ================ reverse
+            self._mark("nets_bwd_dec")
             dx = torch.empty_like(recon)
             call("svgp_sqerr_bwd", tot, int(self.geco), b_global, 64 * 64 * 3, st, images.data_ptr(), recon.data_ptr(),
                  dx.data_ptr(), s)
@@ -369,9 +382,11 @@ class SpritesStepEngine:
             g["dec_d_b"].copy_(dh0.sum(0))          # column sum of a (b,1024) matrix: O(b*1024) glue
             zbar = self._v("zbar", (b, L))
             self._gemm(0, 1, b, L, 1024, 1.0, dh0, 1024, p["dec_d_w"], 1024, 0.0, zbar, L)
+            self._mark("gp_bwd_stats")
             call("svgp_gp_stats_bwd", cp, ws, st, s)
         yield [self.ws[self.wl.statB:self.wl.statB + self.wl.statB_len]]
         with torch.cuda.stream(self.stream):
+            self._mark("gp_bwd_factor")
             call("svgp_gp_factor_bwd", cp, ws, st, s)
             call("svgp_gp_posterior_bwd", cp, ws, st, s)
             if self.svgp.titsias:
@@ -382,6 +397,7 @@ class SpritesStepEngine:
                  self._v("Knbar", (1,)).data_ptr(), self._v("knnbar", (1,)).data_ptr(),
                  g["inducing_index_points"].data_ptr(), g["GPLVM_action"].data_ptr(), d_char.data_ptr(),
                  g["se"].data_ptr(), self.kscratch.data_ptr(), s)
+            self._mark("nets_bwd_enc")
             d_rvec = torch.empty(b, self.Lc, **f64)
             call("svgp_sprites_aux_bwd", b, self.seg_len, self.Lc, d_char.data_ptr(), d_rvec.data_ptr(), s)
             dx = torch.empty(b, 8, 8, self.Lc, **f64)
@@ -416,6 +432,7 @@ class SpritesStepEngine:
             call("svgp_mnist_grad_reduce", cp, ws, s)           # scalar partial sums -> ws.sums
         yield [self.grad, self.ws[self.wl.sums:self.wl.sums + 8]]
         with torch.cuda.stream(self.stream):
+            self._mark("optim")
             if self.clip_grad is not None:
                 call("svgp_clip_by_value", self.grad.numel(), float(self.clip_grad), self.grad.data_ptr(), s)
             if adam:
@@ -424,6 +441,7 @@ class SpritesStepEngine:
                 call("svgp_elbo_finalize", cp, ws, st, s)
             else:
                 call("svgp_elbo_finalize_noadam", cp, ws, st, s)
+            self._mark("end")
             self.act = dict(recon=recon, aux=aux, enc=enc)
 
     def outputs(self):

@@ -1,0 +1,200 @@
+"""Oracle parity at the DEFINING sizes of BASELINE configs[2], [3] and [4].
+
+  configs[2]: rotated MNIST, b = 1024, m = 256, L = 16, GPLVM dim 32, jitter 1e-6 -- the whole step against the oracle's
+              efficient formulation (the literal (b,m,m) tensors are 0.5 GB per channel and operation).
+  configs[3]: SPRITES, m = 800 inducing points, L = 64, cosine-normalised linear x linear kernel (rank <= 128, SURVEY F9:
+              relies on jitter 0.01, SPRITES_experiment.py:615-617), 100 frames -- the whole step against
+              oracle/sprites_oracle.py.
+  configs[4]: one GPU's shard N = 131072 rows, m = 2048, L = 16, float32 -- size-independent properties (the oracle
+              cannot finish this size in seconds): K_nm rows against the float64 restatement, S_l w == K^T (p_l * (K w))
+              and v_l in float64, symmetry.
+
+Tolerances.  These matrices are far worse conditioned than the m = 32 case (cond(K + 1e-6 I) ~ 1e8 and beyond for
+A_hat + jI), so two backward-stable float64 evaluations of the same formulas need not agree to 1e-9.  The bar is
+therefore derived from the ORACLE ITSELF: the same oracle is evaluated on inputs perturbed by one unit in the last
+place (every real input multiplied by 1 +- 2^-52), and a quantity's tolerance is max(base, 20 x its response to that
+perturbation).  What the model consumes (ELBO, p_m, p_v, z, reconstruction) stays far inside north_star's 1e-3."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sprites_oracle as SO
+from oracle import svgpvae_oracle as O
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+DT = torch.float64
+ULP = 2.0 ** -52
+
+
+def _ulp_perturbed(t, gen):
+    s = torch.randint(0, 2, t.shape, generator=gen).to(DT) * 2 - 1
+    return t * (1.0 + ULP * s)
+
+
+def _tol(base, pert, want, factor=20.0, floor=1e-9):
+    return max(floor, factor * H.relerr(pert, want)) if base is None else max(base, factor * H.relerr(pert, want))
+
+
+def test_config3_full_size_step_matches_oracle():
+    b, m, L, M = 1024, 256, 16, 32
+    params, images, aux, eps = H.toy_problem(b=b, m=m, L=L, M=M, n_obj=400, seed=21)
+    kw = dict(N_train=4050.0, jitter=1e-6, clip_qs=True, geco=True, beta=0.001)
+    eng = H.engine_for(params, b, geco=True, N_train=4050.0, jitter=1e-6)
+    dev = eng.device
+    eng.bind(images.to(dev), aux.to(dev), eps.to(dev))
+    eng.run(adam=False)
+    eng.synchronize()
+
+    def oracle(p, img):
+        ref = H.oracle_stages(p, img, aux, eps, **kw)
+        out, grads = O.loss_and_grads(p, img, aux, eps, beta=0.001, C_ma=torch.zeros((), dtype=DT),
+                                      lagrange_mult=torch.ones((), dtype=DT), alpha=0.0, kappa=math.sqrt(0.020),
+                                      clipping_qs=True, GECO=True, jitter=1e-6, N_train=4050.0, L=L,
+                                      formulation="efficient")
+        return ref, out, grads
+
+    ref, out, grads = oracle(params, images)
+    gen = torch.Generator().manual_seed(5)
+    p2 = {k: _ulp_perturbed(v, gen) for k, v in params.items()}
+    p2["inducing_index_points"][:, 0] = params["inducing_index_points"][:, 0]
+    ref2, out2, grads2 = oracle(p2, _ulp_perturbed(images, gen))
+
+    bad, report = [], []
+    shapes = dict(qnet_mu=(b, L), qnet_var=(b, L), K=(m, m), Kn=(b, m), knn=(b,), S=(L, m, m), v=(L, m), Ki=(m, m),
+                  ldK=(1,), Si=(L, m, m), t=(L, m), A=(L, m, m), mu_hat=(L, m), u=(L, m), KL=(L,), q=(b,), p_m=(b, L),
+                  p_v=(b, L), e=(b, L), d=(b, L), z=(b, L), recon=(b, 784))
+    for name, shp in shapes.items():
+        err, tol = H.relerr(eng.ws_view(name, shp), ref[name]), _tol(1e-9, ref2[name], ref[name])
+        report.append(f"fwd {name}: rel {err:.2e} (tol {tol:.2e})")
+        if not err < tol:
+            bad.append(report[-1])
+    # what the rest of the model consumes must be good in absolute terms, whatever the conditioning
+    for name in ("p_m", "p_v", "z", "recon"):
+        assert H.relerr(eng.ws_view(name, shapes[name]), ref[name]) < 1e-6, name
+    sc = eng.scalars()
+    for key, idx in (("elbo", 0), ("recon_loss", 1), ("kl_term", 2), ("inside_elbo", 3), ("ce_term", 4),
+                     ("inside_recon", 10), ("inside_kl", 11), ("c_ma", 13), ("lagrange", 14)):
+        want, pert = float(out[idx]), float(out2[idx])
+        tol = max(1e-9, 20 * abs(pert - want) / max(1.0, abs(want)))
+        err = abs(sc[key] - want) / max(1.0, abs(want))
+        report.append(f"scalar {key}: rel {err:.2e} (tol {tol:.2e})")
+        if not err <= tol:
+            bad.append(report[-1])
+    assert abs(sc["elbo"] - float(out[0])) <= 1e-6 * abs(float(out[0]))          # north_star: 1e-3
+    g = eng.grads()
+    for k, want in grads.items():
+        err, tol = H.relerr(g[k], want), _tol(1e-7, grads2[k], want)
+        report.append(f"grad {k}: rel {err:.2e} (tol {tol:.2e}, max|want| {float(want.abs().max()):.2e})")
+        if not err < tol:
+            bad.append(report[-1])
+        assert err < 1e-3, report[-1]
+    print("\n".join(report))
+    assert not bad, "\n".join(bad)
+
+
+@pytest.mark.parametrize("GECO", [True])
+def test_sprites_m800_step_matches_oracle(GECO):
+    """BASELINE configs[3]'s GP shape inside the SPRITES step: m = 800 > rank(K_mm) = 128 (8-dim x 16-dim linear
+    kernels), so every m x m factorisation leans on jitter 0.01; two-level blocked inverse (m >= 512) in the step."""
+    from svgp_vae_amd import sprites as S
+    b, frames, L, La, Lc, n_act, m = 100, 50, 64, 8, 16, 72, 800
+    g = torch.Generator().manual_seed(800)
+    params = {k: torch.tensor(v, dtype=DT) for k, v in SO.glorot_init(L, Lc, 3).items()}
+    for k in params:
+        if k.endswith("_b"):
+            params[k] = 0.05 * torch.randn(*params[k].shape, dtype=DT, generator=g)
+    gp = dict(inducing_index_points=torch.randn(m, La + Lc, dtype=DT, generator=g) * 1.5,
+              GPLVM_action=torch.randn(n_act, La, dtype=DT, generator=g) * 1.5,
+              l_action=torch.tensor(1.0, dtype=DT), sigma_action=torch.tensor(1.0, dtype=DT),
+              l_character=torch.tensor(1.0, dtype=DT), sigma_character=torch.tensor(1.0, dtype=DT))
+    images = torch.rand(b, 64, 64, 3, dtype=DT, generator=g)
+    ids = torch.randint(0, n_act, (b,), generator=g)
+    eps = torch.randn(b, L, dtype=DT, generator=g)
+    seg, rep = SO.aux_data_sprites_utils(b, frames, frames)
+    jitter, N_train = 0.01, 50000.0
+    kw = dict(beta=0.001, C_ma=torch.tensor(0.0, dtype=DT), lagrange_mult=torch.tensor(1.0, dtype=DT), alpha=0.0,
+              kappa=math.sqrt(0.0075), L=L, L_action=La, jitter=jitter, N_train=N_train, segment_ids=seg, repeats=rep,
+              clipping_qs=False, GECO=GECO, K_obj_normalize=True, K_SE=False, clip_grad=1e6, titsias=False)
+    want, wgrads = SO.loss_and_grads(params, gp, (images, ids), eps, formulation="efficient", **kw)
+    gen = torch.Generator().manual_seed(6)
+    params2 = {k: _ulp_perturbed(v, gen) for k, v in params.items()}
+    gp2 = {k: (_ulp_perturbed(v, gen) if v.ndim else v) for k, v in gp.items()}
+    want2, wgrads2 = SO.loss_and_grads(params2, gp2, (_ulp_perturbed(images, gen), ids), eps, formulation="efficient", **kw)
+
+    svgp = S.spritesSVGP(False, False, gp["inducing_index_points"].numpy(), 'main', jitter, N_train, La,
+                         gp["GPLVM_action"].numpy(), Lc, L, fixed_GP_params=False, fixed_GPLVM=False,
+                         K_obj_normalize=True, K_SE=False)
+    eng = S.SpritesStepEngine(S.spritesVAE(L), S.sprites_representation_network(Lc), svgp, b_max=b, seg_len=frames,
+                              clip_qs=False, geco=GECO, kappa_squared=0.0075, beta=0.001, clip_grad=1e6, params=dict(params))
+    eng.set_scalars(c_ma=0.0, lagrange=1.0, alpha=0.0)
+    dev = eng.dev
+    eng.step(images.to(dev), ids.to(dev, DT), eps.to(dev), adam=False)
+    got = eng.outputs()
+    bad, report = [], []
+    for i in range(15):
+        err, tol = H.relerr(got[i], want[i]), _tol(1e-8, want2[i], want[i])
+        report.append(f"tuple[{i}]: rel {err:.2e} (tol {tol:.2e})")
+        if not err < tol:
+            bad.append(report[-1])
+        assert err < 1e-5, report[-1]                                            # north_star: 1e-3
+    gr = eng.grads
+    for k, w in wgrads.items():
+        if k in ("l_action", "sigma_action", "l_character", "sigma_character"):
+            continue
+        err, tol = H.relerr(gr[k], w), _tol(1e-6, wgrads2[k], w)
+        report.append(f"grad {k}: rel {err:.2e} (tol {tol:.2e}, max|want| {float(w.abs().max()):.2e})")
+        if not err < tol:
+            bad.append(report[-1])
+        assert err < 1e-3, report[-1]
+    print("\n".join(report))
+    assert not bad, "\n".join(bad)
+
+
+def test_config5_shard_properties_at_full_size():
+    """N = 131072 rows (one GPU's share of 2^20), m = 2048, L = 16, float32: K_nm build + S_l / v_l statistics."""
+    from svgp_vae_amd import stream_stats as SS
+    from tests.test_gpu_stream_f32 import _mnist_kernel64
+    dev = torch.device("cuda:0")
+    n, m, L, M, n_obj = 131072, 2048, 16, 8, 400
+    g = torch.Generator().manual_seed(55)
+    l_gp, amp = 1.3, 0.9
+    kd = SS.kernel_desc(SS.PERIODIC_LINEAR, 2, M, n_table=n_obj, params=(l_gp, amp))
+    tab = torch.randn(n_obj, M, generator=g) * 1.5
+    x = torch.cat([torch.randint(0, n_obj, (n, 1), generator=g).float(), torch.rand(n, 1, generator=g) * 6.2832,
+                   torch.randn(n, M, generator=g)], 1).contiguous()
+    z = torch.cat([torch.zeros(m, 1), torch.rand(m, 1, generator=g) * 6.2832, torch.randn(m, M, generator=g) * 1.5], 1).contiguous()
+    means = torch.randn(n, L, generator=g)
+    vars_ = torch.rand(n, L, generator=g) * 9.999 + 1e-3
+    vars_[::1000, 3] = 0.0                                       # reciprocal_no_nan rows
+    d = lambda t: t.to(dev)
+    fr = SS.features(kd, d(x), inducing=False, table=d(tab))
+    fi = SS.features(kd, d(z), inducing=True)
+    K = SS.knm(kd, fr, n, fi, m)
+    S, v = SS.stats(K, d(means), d(vars_))
+    torch.cuda.synchronize()
+    assert K.shape == (n, m) and S.shape == (L, m, m) and v.shape == (L, m)
+    # (1) K_nm rows against the float64 restatement of mnistSVGP.kernel_matrix: first, last and 509 strided rows
+    rows = torch.cat([torch.arange(0, 3), torch.arange(7, n, 257)[:509], torch.arange(n - 3, n)])
+    want = _mnist_kernel64(x[rows].numpy(), z.numpy(), l_gp, amp, tab.numpy(), False, False)
+    assert float(np.abs(K[rows.to(dev)].cpu().double().numpy() - want).max()) < 2e-5 * float(np.abs(want).max())
+    # (2) statistics in float64 through a probe: S_l w == K^T (p_l * (K w)), v_l == K^T (p_l * mean_l)
+    Kd = K.double()
+    p = torch.where(d(vars_) == 0, torch.zeros_like(d(vars_)), 1.0 / d(vars_)).double()
+    for seed in (0, 1):
+        w = torch.randn(m, generator=torch.Generator().manual_seed(seed)).to(dev).double()
+        Kw = Kd @ w
+        for l in range(L):
+            ref = Kd.t() @ (p[:, l] * Kw)
+            assert float(((S[l].double() @ w) - ref).abs().max() / ref.abs().max()) < 5e-5, l
+    vref = Kd.t() @ (p * d(means).double())
+    assert float((v.double().t() - vref).abs().max() / vref.abs().max()) < 2e-5
+    # (3) exact symmetry (the mirror tile is written from the same accumulators) and a positive diagonal
+    assert float((S - S.transpose(1, 2)).abs().max()) == 0.0
+    assert bool((torch.diagonal(S, dim1=1, dim2=2) > 0).all())
+    # (4) linearity in the weights: doubling 1/var doubles S and v (scaling by 2 is exact in float32)
+    S2, v2 = SS.stats(K, d(means), d(vars_) * 0.5)
+    torch.cuda.synchronize()
+    assert torch.equal(S2, 2 * S) and torch.equal(v2, 2 * v)

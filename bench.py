@@ -104,21 +104,25 @@ def committed_traffic(kernel_key):
         return None, None
 
 
-def pick_threads(one, candidates=(4, 8, 16, 32, 64)):
-    """torch-CPU on a many-core host is slowest with all threads on these small ops: probe a few thread counts with
-    one call each and keep the fastest for the reported baseline."""
-    ncpu = os.cpu_count() or 8
-    best = (torch.get_num_threads(), float("inf"))
-    for nt in sorted({min(c, ncpu) for c in candidates}):
-        torch.set_num_threads(nt)
-        one()
-        t1 = time.perf_counter()
-        one()
-        dt = time.perf_counter() - t1
-        if dt < best[1]:
-            best = (nt, dt)
-    torch.set_num_threads(best[0])
-    return best[0]
+def cpu_worker_call(kind, threads, budget_s, extra=()):
+    """Runs one CPU-baseline leg in a CHILD process whose OpenMP / MKL thread count is fixed by the environment before
+    torch is imported.  (torch.set_num_threads after the pools exist is not safe with this build: on the GPU box the
+    batched LU behind torch.linalg.inv returned corrupt pivots after a thread-count change, in the build container the
+    same call dead-locked.)  The child regenerates the synthetic problem from its seeds and prints one JSON object."""
+    import subprocess
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads), CUDA_VISIBLE_DEVICES="",
+               HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", kind, "--budget", str(budget_s), *extra],
+                       env=env, capture_output=True, text=True, timeout=900)
+    if r.returncode != 0:
+        raise RuntimeError(f"cpu baseline worker {kind} failed:\n{r.stderr[-2000:]}")
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def host_threads(cap):
+    return max(1, min(cap, os.cpu_count() or 8))
 
 
 def emit(line):
@@ -233,11 +237,14 @@ def oracle_elbo(params, images, aux, eps):
     return float(out[0])
 
 
-def cpu_baseline_mnist(params, images, aux, eps, literal, budget_s=15.0):
-    """The oracle timed on this host's cores (kind = "port": a restatement, TF1 cannot run here).  literal=True: the
-    reference's own op sequence incl. the (b,m,m) tensor, explicit inverses and b x b diagonals (config 2); False: the
-    O(L b m^2) efficient formulation -- the literal form needs (b,m,m) tensors of 0.5 GB per channel at config 3."""
+def cpu_worker_mnist(cfg3, budget_s, steps_only=0):
+    """CHILD: the oracle timed on this host's cores (kind = "port": a restatement, TF1 cannot run here).  cfg2: the
+    reference's own op sequence incl. the (b,m,m) tensor, explicit inverses and b x b diagonals ("literal"), then the
+    O(L b m^2) efficient formulation for reference; cfg3: efficient only -- the literal form needs (b,m,m) tensors of
+    0.5 GB per channel and operation."""
     from oracle import svgpvae_oracle as O
+    B, M_IND, MDIM = (1024, 256, 32) if cfg3 else (256, 32, 8)
+    params, images, aux, eps = synthetic_problem(0, B, M_IND, MDIM)
     p = {k: torch.tensor(np.asarray(v), dtype=O.DT) for k, v in params.items()}
     ti, ta, te = (torch.tensor(x, dtype=O.DT) for x in (images, aux, eps))
     ms = {k: torch.zeros_like(v) for k, v in p.items()}
@@ -251,29 +258,39 @@ def cpu_baseline_mnist(params, images, aux, eps, literal, budget_s=15.0):
         O.adam_tf1_step(p, g, ms, vs, ctr[0], 1e-3)
         ctr[0] += 1
 
-    main = "literal" if literal else "efficient"
-    threads = pick_threads(lambda: one(main))
-    n, t0 = 0, time.perf_counter()
-    while True:
-        one(main)
-        n += 1
-        el = time.perf_counter() - t0
-        if (el > budget_s and n >= 3) or n >= 400:
-            break
-    out = dict(value=n / el, unit="steps/s", cores=os.cpu_count(), threads=threads, kind="port",
-               formulation=main,
-               sample=f"{n} {main}-formulation float64 steps (torch-CPU autograd + TF1 Adam) of the same "
-                      f"{images.shape[0]}-row batch, {el:.1f} s, {threads} threads (fastest probed) on a "
-                      f"{os.cpu_count()}-core host")
-    if literal:      # the O(L b m^2) restatement on the same threads, for reference: 4 s
-        ne, te0 = 0, time.perf_counter()
+    def timed(form, budget, nmin):
+        one(form)
+        n, t0 = 0, time.perf_counter()
         while True:
-            one("efficient")
-            ne += 1
-            ele = time.perf_counter() - te0
-            if (ele > 4.0 and ne >= 3) or ne >= 400:
-                break
+            one(form)
+            n += 1
+            el = time.perf_counter() - t0
+            if (el > budget and n >= nmin) or n >= 400 or (steps_only and n >= steps_only):
+                return n, el
+
+    main = "efficient" if cfg3 else "literal"
+    n, el = timed(main, budget_s, 3)
+    out = dict(value=n / el, n=n, seconds=el, formulation=main, threads=torch.get_num_threads(), rows=B)
+    if not cfg3 and not steps_only:
+        ne, ele = timed("efficient", 4.0, 3)
         out["efficient_formulation_steps_per_s"] = ne / ele
+    print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_mnist(cfg3, budget_s=15.0):
+    kind = "cfg3" if cfg3 else "cfg2"
+    cands = sorted({host_threads(c) for c in ((16, 32) if cfg3 else (8, 16, 32))})
+    probe = {nt: cpu_worker_call(kind, nt, 0.0, ("--probe-steps", "2"))["value"] for nt in cands} if len(cands) > 1 \
+        else {cands[0]: 0.0}
+    nt = max(probe, key=probe.get)
+    r = cpu_worker_call(kind, nt, budget_s)
+    out = dict(value=r["value"], unit="steps/s", cores=os.cpu_count(), threads=nt, kind="port",
+               formulation=r["formulation"],
+               sample=f"{r['n']} {r['formulation']}-formulation float64 steps (torch-CPU autograd + TF1 Adam) of the same "
+                      f"{r['rows']}-row batch, {r['seconds']:.1f} s, {nt} OpenMP threads (fastest of {cands}) on a "
+                      f"{os.cpu_count()}-core host")
+    if "efficient_formulation_steps_per_s" in r:
+        out["efficient_formulation_steps_per_s"] = r["efficient_formulation_steps_per_s"]
     return out
 
 
@@ -396,7 +413,7 @@ def run_mnist(args):
         line["stages_us"] = {r["stage"]: round(r["us"], 2) for r in stage_rows}
         line["step_flops"] = step_flops
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_mnist(params, images, aux, eps, literal=not cfg3)
+            line["cpu_baseline"] = cpu_baseline_mnist(cfg3)
         emit(line)
     if multi:
         dist.destroy_process_group()
@@ -493,38 +510,43 @@ def run_sprites(args):
                                  "frac_of_f32_peak": (nets + gp) / (ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS}
         line["stages_us"] = {k: round(v, 1) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_sprites(ip, table, img, ids, eps, gpu_elbo, L_, La, Lc, m, frames)
+            line["cpu_baseline"] = cpu_baseline_sprites(gpu_elbo, m)
             line["elbo_rel_err_gpu_vs_oracle"] = line["cpu_baseline"].pop("elbo_rel_err_gpu_vs_oracle")
         emit(line)
     if multi:
         dist.destroy_process_group()
 
 
-def cpu_baseline_sprites(ip, table, img, ids, eps, gpu_elbo, L_, La, Lc, m, frames):
-    """ONE efficient-formulation float64 step of the oracle (torch-CPU autograd) on the same 500-frame batch: the
-    literal form's (b,m,m) tensors are 2.6 GB per channel x 64 channels.  Also the run's ELBO parity gate."""
+def cpu_worker_sprites(m):
+    """CHILD: ONE efficient-formulation float64 step of the oracle (torch-CPU autograd) on the same 500-frame batch: the
+    literal form's (b,m,m) tensors are 2.6 GB per channel x 64 channels."""
     from oracle import sprites_oracle as SO
     DT = torch.float64
-    from svgp_vae_amd.sprites import glorot_uniform_params
-    params = {k: torch.as_tensor(np.asarray(v), dtype=DT) for k, v in glorot_uniform_params(L_, Lc, 0).items()}
+    b, frames, L_, La, Lc, n_act = 500, 50, 64, 8, 16, 72
+    ip, table, img, ids, eps = sprites_problem(0, b, L_, La, Lc, n_act, m)
+    params = {k: torch.as_tensor(np.asarray(v), dtype=DT) for k, v in SO.glorot_init(L_, Lc, 0).items()}
     gp = dict(inducing_index_points=torch.tensor(ip, dtype=DT), GPLVM_action=torch.tensor(table, dtype=DT),
               l_action=torch.tensor(1.0, dtype=DT), sigma_action=torch.tensor(1.0, dtype=DT),
               l_character=torch.tensor(1.0, dtype=DT), sigma_character=torch.tensor(1.0, dtype=DT))
-    b = img.shape[0]
     seg, rep = SO.aux_data_sprites_utils(b, frames, frames)
     kw = dict(beta=0.001, C_ma=torch.tensor(0.0, dtype=DT), lagrange_mult=torch.tensor(1.0, dtype=DT), alpha=0.0,
               kappa=math.sqrt(0.0075), L=L_, L_action=La, jitter=0.01, N_train=50000.0, segment_ids=seg, repeats=rep,
               clipping_qs=False, GECO=True, K_obj_normalize=True, K_SE=False, clip_grad=1e6, titsias=False)
-    torch.set_num_threads(min(os.cpu_count() or 8, 32))
     t0 = time.perf_counter()
     want, _ = SO.loss_and_grads(params, gp, (img, ids.long()), eps, formulation="efficient", **kw)
     el = time.perf_counter() - t0
-    rel = abs(gpu_elbo - float(want[0])) / abs(float(want[0]))
-    assert rel < 1e-3, f"ELBO parity failed: GPU {gpu_elbo} oracle {float(want[0])}"
-    return dict(value=1.0 / el, unit="steps/s", cores=os.cpu_count(), threads=torch.get_num_threads(), kind="port",
+    print(json.dumps(dict(seconds=el, elbo=float(want[0]), threads=torch.get_num_threads(), rows=b)), flush=True)
+
+
+def cpu_baseline_sprites(gpu_elbo, m):
+    nt = host_threads(32)
+    r = cpu_worker_call("sprites800", nt, 0.0, ("--m", str(m)))
+    rel = abs(gpu_elbo - r["elbo"]) / abs(r["elbo"])
+    assert rel < 1e-3, f"ELBO parity failed: GPU {gpu_elbo} oracle {r['elbo']}"
+    return dict(value=1.0 / r["seconds"], unit="steps/s", cores=os.cpu_count(), threads=nt, kind="port",
                 formulation="efficient", elbo_rel_err_gpu_vs_oracle=rel,
-                sample=f"1 efficient-formulation float64 forward + autograd reverse of the same {b}-frame batch "
-                       f"(no Adam update), {el:.1f} s")
+                sample=f"1 efficient-formulation float64 forward + autograd reverse of the same {r['rows']}-frame batch "
+                       f"(no Adam update), {r['seconds']:.1f} s, {nt} OpenMP threads on a {os.cpu_count()}-core host")
 
 
 # =====================================================================================================================
@@ -544,17 +566,11 @@ def run_cfg5(args):
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     n, m, L_, M = args.rows or 131072, args.m or 2048, 16, 8
-    g = torch.Generator(device="cpu").manual_seed(rank)
     n_obj = 400
     kd = SS.kernel_desc(SS.PERIODIC_LINEAR, 2, M, n_table=n_obj, params=(1.0, 1.0))
-    tab = (torch.randn(n_obj, M, generator=g) * 1.5).to(dev)
-    x = torch.cat([torch.randint(0, n_obj, (n, 1), generator=g).float(), torch.rand(n, 1, generator=g) * 6.2832,
-                   torch.randn(n, M, generator=g)], 1).to(dev).contiguous()
-    z = torch.cat([torch.zeros(m, 1), torch.rand(m, 1, generator=g) * 6.2832,
-                   torch.randn(m, M, generator=g) * 1.5], 1).to(dev).contiguous()
+    g, tab, x, z, means, vars_ = cfg5_inputs(rank, n, m, L_, M, n_obj)
+    tab, x, z, means, vars_ = (t.to(dev) for t in (tab, x, z, means, vars_))
     D = 2 + M
-    means = torch.randn(n, L_, generator=g).to(dev)
-    vars_ = (torch.rand(n, L_, generator=g) * 9.999 + 1e-3).to(dev)
     fi = SS.features(kd, z, inducing=True)
     K = torch.empty((n, m), dtype=torch.float32, device=dev)
     ws = SS.stats_workspace(n, m, L_, dev)
@@ -619,18 +635,29 @@ def run_cfg5(args):
         line["roofline_knm"]["traffic"], line["roofline_knm"]["traffic_source"] = t_k, src_k
         line["stages_us"] = {"features": round(us_feat, 1), "knm": round(us_knm, 1), "stats": round(us_stats, 1)}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_cfg5(x, z, tab, means, vars_, m, L_, M)
+            line["cpu_baseline"] = cpu_baseline_cfg5(m, n)
         emit(line)
     if multi:
         dist.destroy_process_group()
 
 
-def cpu_baseline_cfg5(x, z, tab, means, vars_, m, L_, M, budget_s=12.0):
-    """float32 torch-CPU restatement of the same pass (kernel matrix of mnistSVGP.kernel_matrix, then per channel
+def cfg5_inputs(rank, n, m, L_, M, n_obj=400):
+    g = torch.Generator(device="cpu").manual_seed(rank)
+    tab = torch.randn(n_obj, M, generator=g) * 1.5
+    x = torch.cat([torch.randint(0, n_obj, (n, 1), generator=g).float(), torch.rand(n, 1, generator=g) * 6.2832,
+                   torch.randn(n, M, generator=g)], 1).contiguous()
+    z = torch.cat([torch.zeros(m, 1), torch.rand(m, 1, generator=g) * 6.2832,
+                   torch.randn(m, M, generator=g) * 1.5], 1).contiguous()
+    means = torch.randn(n, L_, generator=g)
+    vars_ = torch.rand(n, L_, generator=g) * 9.999 + 1e-3
+    return g, tab, x, z, means, vars_
+
+
+def cpu_worker_cfg5(m, budget_s):
+    """CHILD: float32 torch-CPU restatement of the same pass (kernel matrix of mnistSVGP.kernel_matrix, then per channel
     K_mn (K_nm / var_l), K_mn (mean_l / var_l), SVGPVAE_model.py:1004-1017) on a bounded row sample."""
-    xs, zs, tb = x.cpu(), z.cpu(), tab.cpu()
-    mu, var = means.cpu(), vars_.cpu()
-    rows = 4096
+    L_, M, rows, n = 16, 8, 4096, 32768
+    _, tb, xs, zs, mu, var = cfg5_inputs(0, n, m, L_, M)
 
     def one(lo):
         xr = xs[lo:lo + rows]
@@ -638,22 +665,28 @@ def cpu_baseline_cfg5(x, z, tab, means, vars_, m, L_, M, budget_s=12.0):
         d = xr[:, 1:2] - zs[:, 1][None, :]
         K = torch.exp(-2.0 * torch.sin(0.5 * d) ** 2) * (o @ zs[:, 2:].t())
         p = 1.0 / var[lo:lo + rows]
-        S = torch.einsum('nl,ni,nj->lij', p, K, K) if False else torch.stack([(K * p[:, l:l + 1]).t() @ K for l in range(L_)])
+        S = torch.stack([(K * p[:, l:l + 1]).t() @ K for l in range(L_)])
         vv = K.t() @ (p * mu[lo:lo + rows])
         return S, vv
 
-    torch.set_num_threads(min(os.cpu_count() or 8, 64))
     one(0)
-    n, t0 = 0, time.perf_counter()
+    k, t0 = 0, time.perf_counter()
     while True:
-        one((n * rows) % (xs.shape[0] - rows + 1))
-        n += 1
+        one((k * rows) % (n - rows + 1))
+        k += 1
         el = time.perf_counter() - t0
-        if el > budget_s and n >= 2:
+        if el > budget_s and k >= 2:
             break
-    return dict(value=n * rows / el, unit="rows/s", cores=os.cpu_count(), threads=torch.get_num_threads(), kind="port",
-                sample=f"{n} chunks of {rows} rows (of {xs.shape[0]}) through float32 torch-CPU K_nm + S_l, v_l for "
-                       f"m={m}, L={L_}, {el:.1f} s")
+    print(json.dumps(dict(value=k * rows / el, chunks=k, rows=rows, seconds=el, threads=torch.get_num_threads())), flush=True)
+
+
+def cpu_baseline_cfg5(m, n_rows, budget_s=12.0):
+    nt = host_threads(64)
+    r = cpu_worker_call("cfg5", nt, budget_s, ("--m", str(m)))
+    return dict(value=r["value"], unit="rows/s", cores=os.cpu_count(), threads=nt, kind="port",
+                sample=f"{r['chunks']} chunks of {r['rows']} rows (the GPU shard has {n_rows}) through float32 torch-CPU "
+                       f"K_nm + S_l, v_l for m={m}, L=16, {r['seconds']:.1f} s, {nt} OpenMP threads on a "
+                       f"{os.cpu_count()}-core host")
 
 
 # =====================================================================================================================
@@ -682,7 +715,19 @@ def main():
                          "cfg5 = configs[4] shard (N=131072, m=2048, float32 statistics pass)")
     ap.add_argument("--m", type=int, default=None, help="sprites800 / cfg5: inducing points (default 800 / 2048)")
     ap.add_argument("--rows", type=int, default=None, help="cfg5: rows per GPU (default 131072)")
+    ap.add_argument("--cpu-worker", choices=["cfg2", "cfg3", "sprites800", "cfg5"], default=None,
+                    help="internal: run one CPU-baseline leg in this (child) process and print its JSON")
+    ap.add_argument("--budget", type=float, default=15.0)
+    ap.add_argument("--probe-steps", type=int, default=0)
     args = ap.parse_args()
+    if args.cpu_worker is not None:
+        if args.cpu_worker in ("cfg2", "cfg3"):
+            cpu_worker_mnist(args.cpu_worker == "cfg3", args.budget, args.probe_steps)
+        elif args.cpu_worker == "sprites800":
+            cpu_worker_sprites(args.m or 800)
+        else:
+            cpu_worker_cfg5(args.m or 2048, args.budget)
+        return
     dflt = {"cfg2": (300, 30), "cfg3": (30, 5), "sprites800": (3, 1), "cfg5": (3, 1)}[args.workload]
     args.steps = dflt[0] if args.steps is None else args.steps
     args.warmup = dflt[1] if args.warmup is None else args.warmup

@@ -337,6 +337,25 @@ int svgp_dgemm_splitk(int ta, int tb, int M, int N, int K, double alpha, const d
                       int ldb, double beta, double* C, int ldc, double* scratch, long long scratch_elems, void* stream);
 size_t svgp_spd_inverse_workspace_elems(int m, int batch);
 int svgp_spd_inverse_batched(int m, int batch, double* A, double* logdet, double* work, void* stream);
+/* Cholesky family (cholesky.hip) -- north_star's "Cholesky of K_mm and the triangular solves"; they replace
+ * tf.linalg.cholesky + log(diag_part) (SVGPVAE_model.py:270-274) and the solves / inverses behind :239,319,331.
+ * Blocked right-looking with 64 x 64 diagonal blocks factored in LDS; panel solve, trailing update and every product of
+ * the triangular inverse are the batched f64 MFMA GEMM with tiles / k-panels skipped where an operand is structurally 0.
+ * svgp_potrf_batched: A (batch; m x m, row stride lda, batch stride strideA) SPD -> lower factor L in place (strict upper
+ *   triangle zeroed), logdet[l] = log det A[l] = 2 sum log diag L.  A non-positive pivot gives NaNs (no error code: no
+ *   host synchronisation).  On return the head of `work` holds the inverses of the 64 x 64 diagonal blocks of L,
+ *   (batch, ceil(m/64), 64, 64), which svgp_potri_batched accepts as `linv_blocks`.
+ * svgp_trsm_batched: side 0: op(L) X = B with B (batch; m x n);  side 1: X op(L) = B with B (batch; n x m);  trans 1:
+ *   op(L) = L^T.  L lower triangular (its strict upper part is ignored), strideL = 0: one L for the whole batch.  B <- X.
+ * svgp_potri_batched: A (batch, m, m) contiguous holding L -> A^-1 = L^-T L^-1 (full symmetric matrix); linv_blocks
+ *   may be NULL (recomputed).  svgp_spd_inverse_batched is potrf + potri for m >= 512.                               */
+size_t svgp_potrf_workspace_elems(int m, int batch);
+size_t svgp_trsm_workspace_elems(int m, int n, int batch);
+size_t svgp_potri_workspace_elems(int m, int batch);
+int svgp_potrf_batched(int m, int batch, double* A, int lda, long long strideA, double* logdet, double* work, void* stream);
+int svgp_trsm_batched(int side, int trans, int m, int n, const double* L, int ldl, long long strideL, double* B, int ldb,
+                      long long strideB, int batch, double* work, void* stream);
+int svgp_potri_batched(int m, int batch, double* A, const double* linv_blocks, double* work, void* stream);
 
 /* ---- generic NHWC float64 convolution as a tap-table gather-GEMM on the f64 MFMA (conv_taps.hip) ---------
  * out[n][y*osy+ooy][x*osx+oox][co] = act(bias[co] + sum_t sum_ci in[n][y*sy+oy_t][x*sx+ox_t][ci] W_t[ci][co]),

@@ -121,6 +121,10 @@ SIGNATURES = {
     "svgp_dgemm_batched": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.c_int, C.c_longlong, _P,
                            C.c_int, C.c_longlong, C.c_double, _P, C.c_int, C.c_longlong, C.c_int, _P],
     "svgp_spd_inverse_batched": [C.c_int, C.c_int, _P, _P, _P, _P],
+    "svgp_potrf_batched": [C.c_int, C.c_int, _P, C.c_int, C.c_longlong, _P, _P, _P],
+    "svgp_trsm_batched": [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_longlong, _P, C.c_int, C.c_longlong,
+                          C.c_int, _P, _P],
+    "svgp_potri_batched": [C.c_int, C.c_int, _P, _P, _P, _P],
     "svgp_dgemm_splitk": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.c_int, _P, C.c_int, C.c_double, _P,
                           C.c_int, _P, C.c_longlong, _P],
     "svgp_conv_taps_fwd": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P],
@@ -185,6 +189,9 @@ NON_STATUS = {"svgp_version": ([], C.c_int), "svgp_last_error": ([], C.c_char_p)
               "svgp_stream_feature_elems": ([C.c_void_p, C.c_int64], C.c_int64),
               "svgp_stream_stats_workspace_elems": ([C.c_int64, C.c_int, C.c_int], C.c_int64),
               "svgp_spd_inverse_workspace_elems": ([C.c_int, C.c_int], C.c_size_t),
+              "svgp_potrf_workspace_elems": ([C.c_int, C.c_int], C.c_size_t),
+              "svgp_trsm_workspace_elems": ([C.c_int, C.c_int, C.c_int], C.c_size_t),
+              "svgp_potri_workspace_elems": ([C.c_int, C.c_int], C.c_size_t),
               "svgp_act_bwd_bias_scratch_elems": ([C.c_int], C.c_int),
               "svgp_dgemm_splitk_scratch_elems": ([C.c_int, C.c_int, C.c_int], C.c_longlong),
               "svgp_svigp_workspace_elems": ([C.c_int, C.c_int, C.c_int], C.c_longlong),

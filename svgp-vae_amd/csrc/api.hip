@@ -108,7 +108,7 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->Ssym = take(L * m * m); o->Knbar_part = take(L * b * m);
     // scratch of the large-m path (gp_large.hip)
     o->scr_bm = take(L * b * m); o->scr_mm = take(4 * L * m * m); o->scr_vec = take(3 * L * m + 3 * L);
-    o->scr_inv = take((int64_t)svgp_spd_inverse_workspace_elems((int)m, (int)L)); o->scr_bl = take(2 * b * L);
+    o->scr_inv = take((int64_t)svgp_spd_inverse_workspace_elems((int)m, (int)L + 1)); o->scr_bl = take(2 * b * L);
     o->Knbar = take(b * m); o->knnbar = take(b); o->ybar = take(b * L); o->s2bar = take(b * L);
     o->d_on = take(b * M);
     o->n_part = svgp_n_part(&cc);

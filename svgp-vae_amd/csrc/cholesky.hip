@@ -1,0 +1,310 @@
+// Batched float64 Cholesky family on device matrices (north_star: "Cholesky of K_mm and the triangular solves"):
+//   svgp_potrf_batched   A = L L^T, lower, blocked right-looking; log det = 2 sum log diag(L)
+//   svgp_trsm_batched    op(L) X = B  /  X op(L) = B
+//   svgp_potri_batched   A^-1 = L^-T L^-1 from the factor (triangular inverse by recursive halving + L^-T L^-1 product)
+// They replace tf.linalg.cholesky + log(diag_part) (SVGPVAE_model.py:270-274), tf.linalg.inv of the SPD matrices
+// (:239,319,331) and the solves behind them.  Blocked with 64 x 64 diagonal blocks: one workgroup factors a diagonal
+// block in LDS and inverts its triangular factor; everything else -- panel solve, trailing update, the products of the
+// triangular inverse and of L^-T L^-1 -- is the batched f64 MFMA GEMM of linalg.hip with triangular structure hints
+// (tiles above the diagonal and k-panels where an operand is structurally zero are skipped).
+#include "common.hpp"
+
+#define CB 64          // diagonal block
+#define CLD (CB + 1)
+
+namespace {
+
+__device__ __forceinline__ real wave_sum_c(real x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+    return x;
+}
+
+// In-LDS lower Cholesky of the n x n block in Ls (n <= 64, 256 threads), unblocked right-looking; returns nothing,
+// Ls lower triangle = L, strict upper triangle zeroed.  A non-positive pivot yields NaN (sqrt), as LAPACK's failure would.
+__device__ __forceinline__ void chol64_lds(real (*Ls)[CLD], int n) {
+    const int tid = threadIdx.x;
+    for (int k = 0; k < n; ++k) {
+        __syncthreads();
+        const real sd = sqrt(Ls[k][k]), rd = real(1) / sd;
+        __syncthreads();
+        if (tid >= k && tid < n) Ls[tid][k] = (tid == k) ? sd : Ls[tid][k] * rd;
+        __syncthreads();
+        const int w = n - 1 - k;                       // trailing size
+        for (int e = tid; e < w * w; e += blockDim.x) {
+            const int i = k + 1 + e / w, j = k + 1 + e % w;
+            if (j <= i) Ls[i][j] -= Ls[i][k] * Ls[j][k];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < CB * CB; e += blockDim.x) {
+        const int i = e / CB, j = e % CB;
+        if (j > i || i >= n || j >= n) Ls[i][j] = (i == j) ? real(1) : real(0);     // identity pad beyond n
+    }
+    __syncthreads();
+}
+
+// X = L^-1 for the lower-triangular 64 x 64 block in Ls (identity-padded): 4 threads per column split the inner
+// products, forward substitution down the column; Xs gets the full block (zeros above the diagonal).
+__device__ __forceinline__ void trinv64_lds(const real (*Ls)[CLD], real (*Xs)[CLD]) {
+    const int tid = threadIdx.x, j = tid >> 2, part = tid & 3;        // column j, quarter `part` of the k-range
+    for (int e = tid; e < CB * CB; e += blockDim.x) Xs[e / CB][e % CB] = real(0);
+    __syncthreads();
+    if (part == 0) Xs[j][j] = real(1) / Ls[j][j];
+    __syncthreads();
+    for (int i = 1; i < CB; ++i) {
+        // x_ij = -(sum_{k=j}^{i-1} l_ik x_kj) / l_ii   for every column j < i
+        real s = 0;
+        if (j < i)
+            for (int k = j + part; k < i; k += 4) s += Ls[i][k] * Xs[k][j];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (part == 0 && j < i) Xs[i][j] = -s / Ls[i][i];
+        __syncthreads();
+    }
+}
+
+struct DiagArgs {
+    int m, r0, nbk, lda, batch, first;     // block rows r0 .. r0 + nbk of an m x m matrix
+    long long sA;
+    real* A;          // (batch, m, lda): block read, L written back (upper part of the block zeroed)
+    real* Linv;       // (batch, nblk, 64, 64): slot r0 / 64 receives L_kk^-1 (identity-padded)
+    int nblk;
+    real* logdet;     // (batch): += 2 sum log diag  (= when first)
+};
+// one workgroup per matrix: Cholesky of the diagonal block + inverse of its factor + log det contribution
+__global__ __launch_bounds__(256) void k_chol_diag(DiagArgs g) {
+    __shared__ real Ls[CB][CLD];
+    __shared__ real Xs[CB][CLD];
+    const int l = blockIdx.x, n = g.nbk;
+    real* A = g.A + (size_t)l * g.sA + (size_t)g.r0 * g.lda + g.r0;
+    for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
+        const int i = e / CB, j = e % CB;
+        Ls[i][j] = (i < n && j < n) ? A[(size_t)i * g.lda + j] : (i == j ? real(1) : real(0));
+    }
+    chol64_lds(Ls, n);
+    real lg = (threadIdx.x < n) ? log(Ls[threadIdx.x][threadIdx.x]) : real(0);
+    lg = wave_sum_c(lg);
+    if (threadIdx.x == 0) g.logdet[l] = (g.first ? real(0) : g.logdet[l]) + real(2) * lg;
+    trinv64_lds(Ls, Xs);
+    real* Xo = g.Linv + ((size_t)l * g.nblk + g.r0 / CB) * CB * CB;
+    for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
+        const int i = e / CB, j = e % CB;
+        Xo[e] = Xs[i][j];
+        if (i < n && j < n) A[(size_t)i * g.lda + j] = Ls[i][j];
+    }
+}
+
+// inverse of every 64 x 64 diagonal block of a lower-triangular L: grid (nblk, batch)
+struct TriDiagArgs {
+    int m, ldl, nblk;
+    long long sL;
+    const real* L;
+    real* Linv;       // (batch, nblk, 64, 64)
+};
+__global__ __launch_bounds__(256) void k_tri_diag_inv(TriDiagArgs g) {
+    __shared__ real Ls[CB][CLD];
+    __shared__ real Xs[CB][CLD];
+    const int kb = blockIdx.x, l = blockIdx.y, r0 = kb * CB, n = min(CB, g.m - r0);
+    const real* L = g.L + (size_t)l * g.sL + (size_t)r0 * g.ldl + r0;
+    for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
+        const int i = e / CB, j = e % CB;
+        Ls[i][j] = (i < n && j < n && j <= i) ? L[(size_t)i * g.ldl + j] : (i == j ? real(1) : real(0));
+    }
+    __syncthreads();
+    trinv64_lds(Ls, Xs);
+    real* Xo = g.Linv + ((size_t)l * g.nblk + kb) * CB * CB;
+    for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) Xo[e] = Xs[e / CB][e % CB];
+}
+
+// dst[l][r0 + i][c0 + j] = src[l][i][j] for an (nr x nc) block; grid (ceil(nr*nc/256), batch)
+__global__ void k_copy_block(int nr, int nc, const real* __restrict__ src, int lds, long long ss, real* __restrict__ dst,
+                             int ldd, long long sd) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)nr * nc) return;
+    const int i = (int)(e / nc), j = (int)(e % nc), l = blockIdx.y;
+    dst[(size_t)l * sd + (size_t)i * ldd + j] = src[(size_t)l * ss + (size_t)i * lds + j];
+}
+// strict upper triangle of every (m x m, ld) matrix <- 0
+__global__ void k_zero_upper(int m, int ld, long long sA, real* __restrict__ A) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)m * m) return;
+    const int i = (int)(e / m), j = (int)(e % m);
+    if (j > i) A[(size_t)blockIdx.y * sA + (size_t)i * ld + j] = real(0);
+}
+// diagonal blocks of X (m x m, zero-initialised) <- Linv blocks; grid (nblk * 16, batch)
+__global__ void k_place_diag_blocks(int m, int nblk, const real* __restrict__ Linv, real* __restrict__ X) {
+    const int kb = blockIdx.x / 16, l = blockIdx.y, r0 = kb * CB, n = min(CB, m - r0);
+    const real* src = Linv + ((size_t)l * nblk + kb) * CB * CB;
+    real* dst = X + (size_t)l * m * m + (size_t)r0 * m + r0;
+    for (int e = (blockIdx.x % 16) * 256 + threadIdx.x; e < CB * CB; e += 16 * 256) {
+        const int i = e / CB, j = e % CB;
+        if (i < n && j < n) dst[(size_t)i * m + j] = src[e];
+    }
+}
+
+inline unsigned nblk256(long long n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+#define RUNC(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
+
+// ---- workspace sizes -----------------------------------------------------------------------------------------
+extern "C" size_t svgp_potrf_workspace_elems(int m, int batch) {
+    if (m < 1 || batch < 0) return 0;
+    const size_t nblk = (size_t)(m + CB - 1) / CB;
+    return (size_t)batch * (nblk * CB * CB + (size_t)m * CB);            // L_kk^-1 blocks + one scaled panel
+}
+extern "C" size_t svgp_trsm_workspace_elems(int m, int n, int batch) {
+    if (m < 1 || n < 0 || batch < 0) return 0;
+    const size_t nblk = (size_t)(m + CB - 1) / CB;
+    return (size_t)batch * (nblk * CB * CB + (size_t)CB * n);            // L_kk^-1 blocks + one solved block
+}
+extern "C" size_t svgp_potri_workspace_elems(int m, int batch) {
+    if (m < 1 || batch < 0) return 0;
+    const size_t nblk = (size_t)(m + CB - 1) / CB, h = (size_t)(m + 1) / 2 + CB;
+    return (size_t)batch * (nblk * CB * CB + (size_t)m * m + h * h);     // L_kk^-1 blocks + L^-1 + one product T
+}
+
+// ---- potrf ----------------------------------------------------------------------------------------------------
+// A (batch, m, lda) SPD -> lower Cholesky factor in place (strict upper triangle zeroed), logdet[l] = log det A[l].
+// On return work[0 .. batch * nblk * 4096) holds the inverses of the 64 x 64 diagonal blocks of L, (batch, nblk, 64, 64).
+extern "C" int svgp_potrf_batched(int m, int batch, double* A, int lda, long long strideA, double* logdet, double* work,
+                                  void* stream) {
+    SVGP_REQUIRE(m >= 1 && batch >= 0 && lda >= m, SVGP_ERR_INVALID, "bad m / batch / lda (m=%d batch=%d lda=%d)", m, batch, lda);
+    if (batch == 0) return SVGP_OK;
+    SVGP_REQUIRE(A && logdet && work, SVGP_ERR_INVALID, "NULL device pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (m + CB - 1) / CB;
+    real* Linv = work;
+    real* Pn = work + (size_t)batch * nblk * CB * CB;           // (batch, m, 64) scaled panel of the current step
+    DiagArgs d;
+    d.m = m; d.lda = lda; d.batch = batch; d.sA = strideA; d.A = A; d.Linv = Linv; d.nblk = nblk; d.logdet = logdet;
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int r0 = kb * CB, nbk = m - r0 < CB ? m - r0 : CB, rem = m - r0 - nbk;
+        d.r0 = r0; d.nbk = nbk; d.first = kb == 0;
+        hipLaunchKernelGGL(k_chol_diag, dim3(batch), dim3(256), 0, s, d);
+        SVGP_LAUNCH_CHECK();
+        if (rem == 0) break;
+        real* panel = A + (size_t)(r0 + nbk) * lda + r0;        // A[r0+nbk:, r0:r0+nbk]
+        real* trail = A + (size_t)(r0 + nbk) * lda + r0 + nbk;
+        // L_ik = A_ik L_kk^-T   (Linv stored row-major: B^T form)
+        RUNC(svgp_dgemm_tri_batched(0, 0, 1, rem, nbk, nbk, 1.0, panel, lda, strideA, Linv + (size_t)kb * CB * CB, CB,
+                                    (long long)nblk * CB * CB, 0.0, Pn, CB, (long long)m * CB, batch, stream));
+        // A_ij -= L_ik L_jk^T on the tiles that touch the lower triangle
+        RUNC(svgp_dgemm_tri_batched(1, 0, 1, rem, rem, nbk, -1.0, Pn, CB, (long long)m * CB, Pn, CB, (long long)m * CB, 1.0,
+                                    trail, lda, strideA, batch, stream));
+        hipLaunchKernelGGL(k_copy_block, dim3(nblk256((long long)rem * nbk), batch), dim3(256), 0, s, rem, nbk, Pn, CB,
+                           (long long)m * CB, panel, lda, strideA);
+        SVGP_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_zero_upper, dim3(nblk256((long long)m * m), batch), dim3(256), 0, s, m, lda, strideA, A);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+// ---- trsm -----------------------------------------------------------------------------------------------------
+// side 0: op(L) X = B, B (batch, m, n);  side 1: X op(L) = B, B (batch, n, m);  trans: op(L) = L^T.  L (m x m, ldl)
+// lower triangular (strict upper part ignored), strideL 0 = one L for the whole batch.  B is overwritten by X.
+extern "C" int svgp_trsm_batched(int side, int trans, int m, int n, const double* L, int ldl, long long strideL, double* B,
+                                 int ldb, long long strideB, int batch, double* work, void* stream) {
+    SVGP_REQUIRE(m >= 1 && n >= 0 && batch >= 0 && ldl >= m, SVGP_ERR_INVALID, "bad shape m=%d n=%d batch=%d ldl=%d", m, n, batch, ldl);
+    SVGP_REQUIRE((side == 0 || side == 1) && (trans == 0 || trans == 1), SVGP_ERR_INVALID, "side / trans must be 0 or 1");
+    SVGP_REQUIRE(ldb >= (side == 0 ? n : m), SVGP_ERR_INVALID, "ldb=%d too small", ldb);
+    if (batch == 0 || n == 0) return SVGP_OK;
+    SVGP_REQUIRE(L && B && work, SVGP_ERR_INVALID, "NULL device pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (m + CB - 1) / CB, nL = strideL == 0 ? 1 : batch;
+    real* Linv = work;
+    real* T = work + (size_t)batch * nblk * CB * CB;            // (batch, 64, n) or (batch, n, 64): the solved block
+    const long long sLi = strideL == 0 ? 0 : (long long)nblk * CB * CB;
+    TriDiagArgs td;
+    td.m = m; td.ldl = ldl; td.nblk = nblk; td.sL = strideL; td.L = L; td.Linv = Linv;
+    hipLaunchKernelGGL(k_tri_diag_inv, dim3(nblk, nL), dim3(256), 0, s, td);
+    SVGP_LAUNCH_CHECK();
+    // forward over the blocks when (left, no-trans) or (right, trans); backward otherwise
+    const bool fwd = (side == 0) == (trans == 0);
+    for (int step = 0; step < nblk; ++step) {
+        const int kb = fwd ? step : nblk - 1 - step, r0 = kb * CB, nbk = m - r0 < CB ? m - r0 : CB;
+        const real* Lk = Linv + (size_t)kb * CB * CB;
+        const int lo = fwd ? r0 + nbk : 0, cnt = fwd ? m - r0 - nbk : r0;        // the blocks still to be updated
+        if (side == 0) {
+            real* Bk = B + (size_t)r0 * ldb;
+            // X_k = op(Linv_kk) B_k
+            RUNC(svgp_dgemm_batched(trans, 0, nbk, n, nbk, 1.0, Lk, CB, sLi, Bk, ldb, strideB, 0.0, T, n, (long long)CB * n,
+                                    batch, stream));
+            hipLaunchKernelGGL(k_copy_block, dim3(nblk256((long long)nbk * n), batch), dim3(256), 0, s, nbk, n, T, n,
+                               (long long)CB * n, Bk, ldb, strideB);
+            SVGP_LAUNCH_CHECK();
+            if (cnt > 0) {
+                // no-trans: B_i -= L[i, k] X_k (i > k);  trans: B_i -= L[k, i]^T X_k (i < k)
+                const real* Lik = trans ? L + (size_t)r0 * ldl + lo : L + (size_t)lo * ldl + r0;
+                RUNC(svgp_dgemm_batched(trans, 0, cnt, n, nbk, -1.0, Lik, ldl, strideL, T, n, (long long)CB * n, 1.0,
+                                        B + (size_t)lo * ldb, ldb, strideB, batch, stream));
+            }
+        } else {
+            real* Bk = B + r0;                                   // columns r0 .. r0 + nbk of the (n x m) right-hand side
+            // X_k = B_k op(Linv_kk)
+            RUNC(svgp_dgemm_batched(0, trans, n, nbk, nbk, 1.0, Bk, ldb, strideB, Lk, CB, sLi, 0.0, T, CB, (long long)n * CB,
+                                    batch, stream));
+            hipLaunchKernelGGL(k_copy_block, dim3(nblk256((long long)n * nbk), batch), dim3(256), 0, s, n, nbk, T, CB,
+                               (long long)n * CB, Bk, ldb, strideB);
+            SVGP_LAUNCH_CHECK();
+            if (cnt > 0) {
+                // no-trans (backward): B[:, j] -= X_k L[k, j] (j < k);  trans (forward): B[:, j] -= X_k L[j, k]^T (j > k)
+                const real* Lkj = trans ? L + (size_t)lo * ldl + r0 : L + (size_t)r0 * ldl + lo;
+                RUNC(svgp_dgemm_batched(0, trans, n, cnt, nbk, -1.0, T, CB, (long long)n * CB, Lkj, ldl, strideL, 1.0,
+                                        B + lo, ldb, strideB, batch, stream));
+            }
+        }
+    }
+    return SVGP_OK;
+}
+
+// ---- potri ----------------------------------------------------------------------------------------------------
+namespace {
+// X[lo:hi, lo:hi] (in 64-blocks) <- inverse of the lower-triangular L[lo:hi, lo:hi]; diagonal blocks are already placed.
+int trtri_rec(int m, int batch, const real* L, real* X, real* T, int blo, int bhi, void* stream) {
+    if (bhi - blo <= 1) return SVGP_OK;
+    const int bmid = blo + (bhi - blo + 1) / 2;
+    RUNC(trtri_rec(m, batch, L, X, T, blo, bmid, stream));
+    RUNC(trtri_rec(m, batch, L, X, T, bmid, bhi, stream));
+    const int r1 = blo * CB, r2 = bmid * CB, r3 = bhi * CB < m ? bhi * CB : m, n1 = r2 - r1, n2 = r3 - r2;
+    const long long mm = (long long)m * m, sT = (long long)n2 * n1;
+    // T = L21 X11  (X11 lower triangular: the contraction starts at the tile's first column)
+    RUNC(svgp_dgemm_tri_batched(4, 0, 0, n2, n1, n1, 1.0, L + (size_t)r2 * m + r1, m, mm, X + (size_t)r1 * m + r1, m, mm, 0.0,
+                                T, n1, sT, batch, stream));
+    // X21 = -X22 T  (X22 lower triangular: the contraction ends with the tile's last row)
+    RUNC(svgp_dgemm_tri_batched(8, 0, 0, n2, n1, n2, -1.0, X + (size_t)r2 * m + r2, m, mm, T, n1, sT, 0.0,
+                                X + (size_t)r2 * m + r1, m, mm, batch, stream));
+    return SVGP_OK;
+}
+}  // namespace
+
+// A (batch, m, m) contiguous holding the factor L of svgp_potrf_batched -> A^-1 = L^-T L^-1 (full symmetric matrix).
+// `linv_blocks` = the potrf workspace head (inverses of the diagonal blocks of L), or NULL: they are recomputed.
+extern "C" int svgp_potri_batched(int m, int batch, double* A, const double* linv_blocks, double* work, void* stream) {
+    SVGP_REQUIRE(m >= 1 && batch >= 0, SVGP_ERR_INVALID, "bad m / batch");
+    if (batch == 0) return SVGP_OK;
+    SVGP_REQUIRE(A && work, SVGP_ERR_INVALID, "NULL device pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = (m + CB - 1) / CB;
+    const long long mm = (long long)m * m;
+    real* Linv = work;
+    real* X = work + (size_t)batch * nblk * CB * CB;
+    real* T = X + (size_t)batch * mm;
+    if (linv_blocks == nullptr) {
+        TriDiagArgs td;
+        td.m = m; td.ldl = m; td.nblk = nblk; td.sL = mm; td.L = A; td.Linv = Linv;
+        hipLaunchKernelGGL(k_tri_diag_inv, dim3(nblk, batch), dim3(256), 0, s, td);
+        SVGP_LAUNCH_CHECK();
+        linv_blocks = Linv;
+    }
+    SVGP_CHECK_HIP(hipMemsetAsync(X, 0, (size_t)batch * mm * sizeof(real), s));
+    hipLaunchKernelGGL(k_place_diag_blocks, dim3(nblk * 16, batch), dim3(256), 0, s, m, nblk, linv_blocks, X);
+    SVGP_LAUNCH_CHECK();
+    RUNC(trtri_rec(m, batch, A, X, T, 0, nblk, stream));
+    // A^-1 = X^T X, X lower triangular: the contraction starts at max(first row, first column) of the tile
+    RUNC(svgp_dgemm_tri_batched(2 | 4, 1, 0, m, m, m, 1.0, X, m, mm, X, m, mm, 0.0, A, m, mm, batch, stream));
+    return SVGP_OK;
+}

@@ -300,12 +300,8 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
     // v1 (L x m) = a^T Kn
     GEMM(1, 0, L, m, b, 1.0, abuf, L, 0, Kn, m, 0, 0.0, v1, m, 0, 1);
     if (mode == 1) GEMM(1, 0, L, m, b, cc, bbuf, L, 0, Kn, m, 0, 0.0, ws + wl.td, m, 0, 1);
-    if (mode == 0) {   // K_mm inverse + log det (SVGPVAE_model.py:239,270,273)
-        hipLaunchKernelGGL(k_big_add_diag, dim3(nblk((long long)m * m)), dim3(256), 0, st, m, 1, real(0), c->jitter,
-                           ws + wl.K, (const real*)nullptr, 0LL, ws + wl.Ki);
-        SVGP_LAUNCH_CHECK();
-        RUNC(svgp_spd_inverse_batched(m, 1, ws + wl.Ki, ws + wl.ldK, s.inv, stream));
-    }
+    // (K_mm + jI)^-1 and its log det (SVGPVAE_model.py:239,270,273) are formed by svgp_big_factor_fwd, in the same
+    // launches as the L channel inverses
     return SVGP_OK;
 }
 
@@ -319,7 +315,16 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     real *t = ws + wl.t, *mu = ws + wl.mu_hat, *u = ws + wl.u, *v = ws + wl.v, *M2 = ws + wl.M2, *Kn = ws + wl.Kn;
     hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, cc, c->jitter, K, ws + wl.S, 0LL, Si);
     SVGP_LAUNCH_CHECK();
-    RUNC(svgp_spd_inverse_batched(m, L, Si, s.ldtmp, s.inv, stream));
+    // K_mm inverse + log det (SVGPVAE_model.py:239,270,273) next to the L channel matrices (:331)
+    hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm)), dim3(256), 0, st, m, 1, real(0), c->jitter, K, (const real*)nullptr,
+                       0LL, Ki);
+    SVGP_LAUNCH_CHECK();
+    if (m < SVGP_TWO_LEVEL_MIN_M) {
+        RUNC(svgp_spd_inverse_fused(m, L, Si, s.ldtmp, 1, Ki, ws + wl.ldK, s.inv, stream));
+    } else {
+        RUNC(svgp_spd_inverse_batched(m, 1, Ki, ws + wl.ldK, s.inv, stream));
+        RUNC(svgp_spd_inverse_batched(m, L, Si, s.ldtmp, s.inv, stream));
+    }
     GEMM(0, 0, m, 1, m, 1.0, Si, m, mm, v, 1, (long long)m, 0.0, t, 1, (long long)m, L);          // t = Si v
     GEMM(0, 0, m, m, m, 1.0, Si, m, mm, K, m, 0, 0.0, G, m, mm, L);                              // G = Si K
     GEMM(0, 0, m, m, m, 1.0, K, m, 0, G, m, mm, 0.0, A, m, mm, L);                               // A = K G

@@ -24,6 +24,10 @@ struct GemmArgs {
     long long sa, sb, sc;   // batch strides in elements (0 = shared)
     real alpha, beta;
     const real* A; const real* B; real* C;
+    // triangular structure (svgp_dgemm_tri_batched): bit 0 = only tiles that touch the lower triangle (j0 <= i0 + tile - 1);
+    // bit 1 / bit 2 = contraction starts at the tile's first row / first column (operands that are zero for k < i / k < j);
+    // bit 3 = contraction ends with the tile's last row (operand zero for k > i)
+    int tri;
 };
 
 // k-panels of 16 are double-buffered in LDS: the global loads of panel p+1 are in flight while the MFMAs of
@@ -44,6 +48,11 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_batched(GemmArgs g) {
     if (lid >= total) return;
     const int l = lid / (g.tiles_n * g.tiles_m), tt = lid % (g.tiles_n * g.tiles_m);
     const int i0 = (tt / g.tiles_n) * HT, j0 = (tt % g.tiles_n) * HT;
+    if ((g.tri & 1) && j0 > i0 + HT - 1) return;
+    int klo = 0, khi = g.K;
+    if (g.tri & 2) klo = i0;
+    if ((g.tri & 4) && j0 > klo) klo = j0;
+    if ((g.tri & 8) && i0 + HT < khi) khi = i0 + HT;
     const real* __restrict__ A = g.A + (size_t)l * g.sa;
     const real* __restrict__ B = g.B + (size_t)l * g.sb;
     real* C = g.C + (size_t)l * g.sc;
@@ -89,12 +98,12 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_batched(GemmArgs g) {
             else Bd[(tid / HT + KS * h) * HLD + tid % HT] = rb[h];
         }
     };
-    fetch(0);
+    fetch(klo);
     stage(0);
     __syncthreads();
     int cur = 0;
-    for (int k0 = 0; k0 < g.K; k0 += GK) {
-        const bool more = k0 + GK < g.K;
+    for (int k0 = klo; k0 < khi; k0 += GK) {
+        const bool more = k0 + GK < khi;
         if (more) fetch(k0 + GK);
         const real* Ab = As + cur * GK * HLD + wi + r;
         const real* Bb = Bs + cur * GK * HLD + wj + r;
@@ -329,6 +338,95 @@ __global__ __launch_bounds__(256) void k_bgj_trail(BgjArgs g) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused form of the 32-block sweep for m < TWO_LEVEL_MIN_M: ONE launch per block step.  The three-kernel form above
+// needs a row-panel launch before the trailing update (every trailing tile reads the scaled pivot row block) and a
+// copy of the old pivot column; here a tile recomputes the scaled pivot row block it needs (one extra 32^3 product)
+// and the step reads buffer X and writes buffer Y (ping-pong between the matrix and the workspace), so nothing is
+// read after it was overwritten.  Same arithmetic per element, 1 + m/32 launches instead of 1 + 2 m/32: at m = 256
+// the sweep is a chain of dependent ~10 us launches, not flops.  A second matrix set (Xe / Ye) rides in the same
+// launches: the (K_mm + jI) inverse next to the L channel matrices (K_mm + c S_l + jI).
+// ---------------------------------------------------------------------------------------------
+struct BgjfArgs {
+    int m, kb, batch, nmain;
+    const real* X; real* Y;        // (nmain, m, m)
+    const real* Xe; real* Ye;      // (batch - nmain, m, m)
+    real* Pinv;                    // (2, batch, 32, 32)
+    real* logdet; real* logdet_e;  // (nmain), (batch - nmain)
+};
+__device__ __forceinline__ real bgjf_get(const real* X, int m, int bi, int bj, int i, int j, bool pivot) {
+    const int gi = bi * NB + i, gj = bj * NB + j;
+    return (gi < m && gj < m) ? X[(size_t)gi * m + gj] : ((pivot && i == j) ? real(1) : real(0));
+}
+__global__ __launch_bounds__(256) void k_bgjf_pivot0(BgjfArgs g) {
+    __shared__ real P[NB][NB + 1];
+    const int l = blockIdx.x;
+    const real* X = l < g.nmain ? g.X + (size_t)l * g.m * g.m : g.Xe + (size_t)(l - g.nmain) * g.m * g.m;
+    for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) P[t / NB][t % NB] = bgjf_get(X, g.m, 0, 0, t / NB, t % NB, true);
+    __syncthreads();
+    gj32_sweep(P, g.Pinv + (size_t)l * NB * NB, nullptr, l < g.nmain ? g.logdet + l : g.logdet_e + (l - g.nmain), true);
+}
+// grid (nb, nb, batch): tile (bi = y, bj = x) of block step kb
+__global__ __launch_bounds__(256) void k_bgjf_step(BgjfArgs g) {
+    __shared__ real Pv[NB][NB + 1];
+    __shared__ real Rk[NB][NB + 1];
+    __shared__ real Ck[NB][NB + 1];
+    const int bj = blockIdx.x, bi = blockIdx.y, l = blockIdx.z, kb = g.kb, m = g.m;
+    const size_t mo = (size_t)(l < g.nmain ? l : l - g.nmain) * m * m;
+    const real* X = (l < g.nmain ? g.X : g.Xe) + mo;
+    real* Y = (l < g.nmain ? g.Y : g.Ye) + mo;
+    const real* Pinv = g.Pinv + ((size_t)(kb & 1) * g.batch + l) * NB * NB;
+    for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) {
+        const int r = t / NB, c = t % NB;
+        Pv[r][c] = Pinv[t];
+        Rk[r][c] = bgjf_get(X, m, kb, bj, r, c, false);
+        Ck[r][c] = bi == kb ? real(0) : bgjf_get(X, m, bi, kb, r, c, false);
+    }
+    __syncthreads();
+    const int i = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+    real out[4];
+    if (bj == kb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[e] = Pv[i][c0 + e];
+    } else {
+        mm32(Pv, Rk, out);                               // scaled pivot row block P^-1 X[kb][bj]
+    }
+    if (bi == kb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int gi = kb * NB + i, gj = bj * NB + c0 + e;
+            if (gi < m && gj < m) Y[(size_t)gi * m + gj] = out[e];
+        }
+        return;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) Rk[i][c0 + e] = out[e];
+    __syncthreads();
+    mm32(Ck, Rk, out);                                   // old column block times the scaled pivot row block
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int gi = bi * NB + i, gj = bj * NB + c0 + e;
+        if (gi < m && gj < m) {
+            const size_t o = (size_t)gi * m + gj;
+            out[e] = (bj == kb) ? -out[e] : X[o] - out[e];
+            Y[o] = out[e];
+        } else {
+            out[e] = (gi - bi * NB == gj - bj * NB) ? real(1) : real(0);     // identity pad (read below when pivot)
+        }
+    }
+    // look-ahead: this workgroup just produced the NEXT pivot block -> invert it now
+    if (bi == kb + 1 && bj == kb + 1 && (kb + 1) * NB < m) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Pv[i][c0 + e] = out[e];
+        __syncthreads();
+        gj32_sweep(Pv, g.Pinv + ((size_t)((kb + 1) & 1) * g.batch + l) * NB * NB, nullptr,
+                   l < g.nmain ? g.logdet + l : g.logdet_e + (l - g.nmain), false);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Two-level inverse for m > 128: outer Gauss-Jordan block steps of 128, so the matrix is streamed m/128 times
 // (instead of m/32) and the trailing update is one K = 128 GEMM on the MFMA -- while every number is produced by
@@ -344,7 +442,7 @@ __global__ __launch_bounds__(256) void k_bgj_trail(BgjArgs g) {
 //   write back: A[kb-rows][:] <- R;  A[i][kb-cols] <- C
 // ---------------------------------------------------------------------------------------------
 #define NO 128
-#define TWO_LEVEL_MIN_M 512   // below this the one-level sweep is as fast (measured: m = 256, batch 17)
+#define TWO_LEVEL_MIN_M SVGP_TWO_LEVEL_MIN_M   // below this the one-level sweep is as fast (measured: m = 256, batch 17)
 
 struct Bgj2Args {
     int m, kb, nbk;
@@ -456,12 +554,22 @@ __global__ __launch_bounds__(NO) void k_bgj2_writeback(Bgj2Args g) {
 extern "C" int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
                                   long long strideA, const double* B, int ldb, long long strideB, double beta,
                                   double* C, int ldc, long long strideC, int batch, void* stream) {
+    return svgp_dgemm_tri_batched(0, ta, tb, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch,
+                                  stream);
+}
+
+// the same GEMM with triangular structure hints (see GemmArgs::tri); tiles / k-panels that the hints exclude are
+// skipped, everything else is computed as usual (excluded operand parts must hold zeros where a tile straddles them)
+int svgp_dgemm_tri_batched(int tri, int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
+                           long long strideA, const double* B, int ldb, long long strideB, double beta, double* C, int ldc,
+                           long long strideC, int batch, void* stream) {
     SVGP_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, SVGP_ERR_INVALID, "negative dimension");
     if (M == 0 || N == 0 || batch == 0) return SVGP_OK;
     SVGP_REQUIRE(A && B && C, SVGP_ERR_INVALID, "NULL device pointer");
     GemmArgs g;
     g.M = M; g.N = N; g.K = K; g.ta = ta; g.tb = tb; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sa = strideA; g.sb = strideB; g.sc = strideC; g.alpha = alpha; g.beta = beta; g.A = A; g.B = B; g.C = C;
+    g.tri = tri;
     const long long blocks128 = (long long)((N + 127) / 128) * ((M + 127) / 128) * batch;
     // tile choice: 128 x 128 tiles run ~9 % faster per useful flop than 64 x 64 (57.6 vs 52.9 TFLOP/s at 2048^3, no padding)
     // but pad M, N up to multiples of 128: at 800 x 800 that is 25 % wasted tile area against 8 % (measured 39.7 vs 41.3-45.6
@@ -561,7 +669,7 @@ extern "C" int svgp_dgemm_splitk(int ta, int tb, int M, int N, int K, double alp
 static size_t inv_ws_inner(int nrows, int batch) { return (size_t)batch * (2 * NB * NB + (size_t)nrows * NB); }
 
 extern "C" size_t svgp_spd_inverse_workspace_elems(int m, int batch) {
-    if (m < TWO_LEVEL_MIN_M) return inv_ws_inner(m, batch);
+    if (m < TWO_LEVEL_MIN_M) return (size_t)batch * (2 * NB * NB + (size_t)m * m);     // pivots + the ping-pong copy
     // R, V, T, C panels + the captured pivot inverses of the outer level + the 32-block workspace of the panel
     return (size_t)batch * (4 * (size_t)m * NO + 4 * NB * NB) + inv_ws_inner(NO, batch);
 }
@@ -590,12 +698,41 @@ static int bgj_sweep(int nrows, int ncols, int lda, int c0, long long sA, int ba
     return SVGP_OK;
 }
 
+// Fused one-launch-per-block-step sweep (m < TWO_LEVEL_MIN_M) over `nmain` matrices at A plus `nextra` at Ae; work
+// holds svgp_spd_inverse_workspace_elems(m, nmain + nextra) doubles.
+int svgp_spd_inverse_fused(int m, int nmain, double* A, double* logdet, int nextra, double* Ae, double* logdet_e,
+                           double* work, void* stream) {
+    const int batch = nmain + nextra, nb = (m + NB - 1) / NB;
+    const size_t mm = (size_t)m * m;
+    BgjfArgs g;
+    g.m = m; g.batch = batch; g.nmain = nmain; g.Pinv = work; g.logdet = logdet; g.logdet_e = logdet_e;
+    real* W = work + (size_t)batch * 2 * NB * NB;
+    real* We = W + (size_t)nmain * mm;
+    g.X = A; g.Xe = Ae; g.kb = 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bgjf_pivot0, dim3(batch), dim3(256), 0, s, g);
+    SVGP_LAUNCH_CHECK();
+    for (int kb = 0; kb < nb; ++kb) {
+        g.kb = kb;
+        const bool fwd = (kb & 1) == 0;             // even steps read the matrices and write the workspace copy
+        g.X = fwd ? A : W; g.Y = fwd ? W : A;
+        g.Xe = fwd ? Ae : We; g.Ye = fwd ? We : Ae;
+        hipLaunchKernelGGL(k_bgjf_step, dim3(nb, nb, batch), dim3(256), 0, s, g);
+        SVGP_LAUNCH_CHECK();
+    }
+    if (nb & 1) {                                   // result sits in the workspace copy
+        SVGP_CHECK_HIP(hipMemcpyAsync(A, W, (size_t)nmain * mm * sizeof(real), hipMemcpyDeviceToDevice, s));
+        if (nextra) SVGP_CHECK_HIP(hipMemcpyAsync(Ae, We, (size_t)nextra * mm * sizeof(real), hipMemcpyDeviceToDevice, s));
+    }
+    return SVGP_OK;
+}
+
 // A (batch, m, m) SPD, contiguous -> inverse in place; logdet (batch).  work: svgp_spd_inverse_workspace_elems.
 extern "C" int svgp_spd_inverse_batched(int m, int batch, double* A, double* logdet, double* work, void* stream) {
     SVGP_REQUIRE(m >= 1 && batch >= 0, SVGP_ERR_INVALID, "bad m / batch");
     if (batch == 0) return SVGP_OK;
     SVGP_REQUIRE(A && logdet && work, SVGP_ERR_INVALID, "NULL device pointer");
-    if (m < TWO_LEVEL_MIN_M) return bgj_sweep(m, m, m, 0, (long long)m * m, batch, A, logdet, work, 0, nullptr, nullptr, stream);
+    if (m < TWO_LEVEL_MIN_M) return svgp_spd_inverse_fused(m, batch, A, logdet, 0, nullptr, nullptr, work, stream);
     Bgj2Args g;
     g.m = m; g.A = A; g.R = work;
     g.V = g.R + (size_t)batch * NO * m;

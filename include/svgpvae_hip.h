@@ -73,6 +73,11 @@ typedef struct {
                            /* reference; the KL field is then [KL (L) | tr(K_mm^-1 A_l A_l) (L)]                       */
     int32_t single_stat_block; /* 1: the statistics launches write ONE block per channel instead of row partials (set by  */
                            /* the engines when the batch is sharded over ranks: the blocks are then all-reduced)      */
+    int32_t gemm_f32;      /* large-m path (m > 64) only.  1: every product of the GP block runs on the float32 MFMA  */
+                           /* (svgp_dgemm_f32c_batched: float64 storage, float32 products and sums) -- the arithmetic */
+                           /* of the reference's float32 SPRITES graph (SVGPVAE_model.py:516); 2: only the statistics */
+                           /* S_l = K_mn diag(w) K_nm (sums of non-negative terms for the forward weights) do.  The   */
+                           /* m x m factorisations / inverses stay float64 in every mode               */
     double  N_train;       /* mainSVGP.N_train                                                  */
     double  jitter;        /* mainSVGP.jitter                                                   */
     double  kappa_squared; /* GECO kappa^2                                                      */
@@ -329,6 +334,15 @@ int svgp_stream_stats_f32(int64_t n, int m, int L, const float* K_nm, const floa
 int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
                        long long strideA, const double* B, int ldb, long long strideB, double beta, double* C,
                        int ldc, long long strideC, int batch, void* stream);
+/* the same GEMM on float64 matrices with the products and sums on the float32 MFMA (operands rounded to float32 while
+ * staged into LDS, float32 accumulation; twice the matrix rate): the arithmetic of the reference's float32 SPRITES graph
+ * (VAE_utils.py:277, SVGPVAE_model.py:516) on float64 storage; and the float32 GEMM of the float32 networks            */
+int svgp_dgemm_f32c_batched(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
+                            long long strideA, const double* B, int ldb, long long strideB, double beta, double* C,
+                            int ldc, long long strideC, int batch, void* stream);
+int svgp_sgemm_batched(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda, long long strideA,
+                       const float* B, int ldb, long long strideB, float beta, float* C, int ldc, long long strideC,
+                       int batch, void* stream);
 /* one GEMM with few output tiles and a long contraction (dense layers / their weight gradients): K is cut into slices
  * that run as a batch into partial products in `scratch` (svgp_dgemm_splitk_scratch_elems doubles, 0 = no split) and
  * are added in fixed order; same operand conventions as svgp_dgemm_batched with batch 1 */
@@ -387,6 +401,16 @@ int svgp_upconv_weights(int Ci, int Co, const double* w, double* we, void* strea
 int svgp_upconv_fold_wgrad(int Ci, int Co, const double* ge, double* g, void* stream);
 int svgp_elu_bwd_bias(long long npix, int C, const double* out, double* dout, double* part, double* db,
                       void* stream);
+/* float32 instantiations of the five convolution entry points above: the reference's dtype for the SPRITES networks
+ * (VAE_utils.py:277 `dtype = tf.float32`).  Same descriptors and tap tables; the gather-GEMM runs on
+ * v_mfma_f32_16x16x4_f32.                                                                                             */
+int svgp_conv_taps_fwd_f32(const svgp_conv_desc* d, int ncls, const float* in, const float* w, const float* bias,
+                           float* out, void* stream);
+int svgp_conv_taps_wgrad_f32(const svgp_conv_desc* d, int ncls, const float* in, const float* dout, float* part, int nwg,
+                             int part_stride, float* dw, int accumulate, void* stream);
+int svgp_upconv_weights_f32(int Ci, int Co, const float* w, float* we, void* stream);
+int svgp_upconv_fold_wgrad_f32(int Ci, int Co, const float* ge, float* g, void* stream);
+int svgp_elu_bwd_bias_f32(long long npix, int C, const float* out, float* dout, float* part, float* db, void* stream);
 
 /* ---- SPRITES pieces (gp_sprites.hip) ----------------------------------------------------------------------
  * spritesSVGP.kernel_matrix (SVGPVAE_model.py:550-600): K = k_action * k_character, each Linear (optionally
@@ -429,6 +453,14 @@ int svgp_softmax_xent(int n, int C, const double* logits, const double* labels, 
 int svgp_sqerr_fwd(long long tot, int n_part, const double* x, const double* xhat, double* part_sums, void* stream);
 int svgp_sqerr_bwd(long long tot, int geco, int b_global, int n_pix, const double* state, const double* x,
                    const double* xhat, double* dxhat, void* stream);
+/* float32 forms of the per-frame glue of the float32 networks; the squared-error partial sums and the device state stay
+ * float64 (they feed the float64 scalar epilogue)                                                                     */
+int svgp_avgpool_fwd_f32(int n, int HW, int C, const float* x, float* y, void* stream);
+int svgp_avgpool_bwd_f32(int n, int HW, int C, const float* dy, float* dx, void* stream);
+int svgp_bias_add_f32(long long rows, int C, const float* bias, float* x, void* stream);
+int svgp_sqerr_fwd_f32(long long tot, int n_part, const float* x, const float* xhat, double* part_sums, void* stream);
+int svgp_sqerr_bwd_f32(long long tot, int geco, int b_global, int n_pix, const double* state, const float* x,
+                       const float* xhat, float* dxhat, void* stream);
 /* tf.clip_by_value(grad, -thr, thr) (SPRITES_experiment.py:234-235) */
 int svgp_clip_by_value(long long tot, double thr, double* g, void* stream);
 

@@ -17,7 +17,7 @@ class SvgpError(RuntimeError):
 class MnistCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("b", "b_global", "m", "L", "M", "n_obj", "normalize_obj", "clip_qs",
                                          "geco", "train_ip", "train_gp", "train_ov", "b_cap", "clip_pv", "n_pix",
-                                         "titsias", "kl_form", "single_stat_block")] + \
+                                         "titsias", "kl_form", "single_stat_block", "gemm_f32")] + \
                [(n, C.c_double) for n in ("N_train", "jitter", "kappa_squared", "alpha", "rep_weight")]
 
 
@@ -120,6 +120,10 @@ SIGNATURES = {
     "svgp_mnist_train_step_dp": [_CFG, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "svgp_dgemm_batched": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.c_int, C.c_longlong, _P,
                            C.c_int, C.c_longlong, C.c_double, _P, C.c_int, C.c_longlong, C.c_int, _P],
+    "svgp_dgemm_f32c_batched": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.c_int, C.c_longlong, _P,
+                                C.c_int, C.c_longlong, C.c_double, _P, C.c_int, C.c_longlong, C.c_int, _P],
+    "svgp_sgemm_batched": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, C.c_int, C.c_longlong, _P,
+                           C.c_int, C.c_longlong, C.c_float, _P, C.c_int, C.c_longlong, C.c_int, _P],
     "svgp_spd_inverse_batched": [C.c_int, C.c_int, _P, _P, _P, _P],
     "svgp_potrf_batched": [C.c_int, C.c_int, _P, C.c_int, C.c_longlong, _P, _P, _P],
     "svgp_trsm_batched": [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_longlong, _P, C.c_int, C.c_longlong,
@@ -132,6 +136,16 @@ SIGNATURES = {
     "svgp_elu_bwd_bias": [C.c_longlong, C.c_int, _P, _P, _P, _P, _P],
     "svgp_upconv_weights": [C.c_int, C.c_int, _P, _P, _P],
     "svgp_upconv_fold_wgrad": [C.c_int, C.c_int, _P, _P, _P],
+    "svgp_conv_taps_fwd_f32": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P],
+    "svgp_conv_taps_wgrad_f32": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P],
+    "svgp_elu_bwd_bias_f32": [C.c_longlong, C.c_int, _P, _P, _P, _P, _P],
+    "svgp_upconv_weights_f32": [C.c_int, C.c_int, _P, _P, _P],
+    "svgp_upconv_fold_wgrad_f32": [C.c_int, C.c_int, _P, _P, _P],
+    "svgp_avgpool_fwd_f32": [C.c_int, C.c_int, C.c_int, _P, _P, _P],
+    "svgp_avgpool_bwd_f32": [C.c_int, C.c_int, C.c_int, _P, _P, _P],
+    "svgp_bias_add_f32": [C.c_longlong, C.c_int, _P, _P, _P],
+    "svgp_sqerr_fwd_f32": [C.c_longlong, C.c_int, _P, _P, _P, _P],
+    "svgp_sqerr_bwd_f32": [C.c_longlong, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "svgp_sprites_kernel_matrix_fwd": [C.POINTER(SpritesKcfg), _P, _P, _P, _P, _P, _P, _P, _P],
     "svgp_sprites_kernel_matrix_bwd": [C.POINTER(SpritesKcfg)] + [_P] * 13,
     "svgp_sprites_aux_fwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P],

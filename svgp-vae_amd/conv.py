@@ -41,8 +41,11 @@ def same_pad(H, k, s):
 class ConvLayer:
     """One (optionally upsample-fused) convolution layer with bias and optional ELU."""
 
-    def __init__(self, Hi, Ci, Co, k=3, stride=1, padding="same", up=False, elu=True):
+    def __init__(self, Hi, Ci, Co, k=3, stride=1, padding="same", up=False, elu=True, dtype=_F64):
         self.Hi, self.Ci, self.Co, self.k, self.s, self.up, self.elu = Hi, Ci, Co, k, stride, up, elu
+        # float64, or float32 = the reference's dtype for the SPRITES networks (VAE_utils.py:277): the *_f32 entry points
+        assert dtype in (torch.float64, torch.float32)
+        self.dt, self.sfx = dtype, ("" if dtype == torch.float64 else "_f32")
         if up:
             assert k == 3 and stride == 1
             self.pad = 1 if padding == "same" else 0
@@ -58,9 +61,9 @@ class ConvLayer:
         """Weights in the layout the forward / weight-gradient descriptors index (svgp_upconv_weights for up layers)."""
         if not self.up:
             return w.contiguous()
-        we = torch.empty(2, 2, 2, 2, self.Ci, self.Co, dtype=_F64, device=w.device)
+        we = torch.empty(2, 2, 2, 2, self.Ci, self.Co, dtype=self.dt, device=w.device)
         s = torch.cuda.current_stream(w.device).cuda_stream if stream is None else stream
-        call("svgp_upconv_weights", self.Ci, self.Co, w.contiguous().data_ptr(), we.data_ptr(), s)
+        call("svgp_upconv_weights" + self.sfx, self.Ci, self.Co, w.contiguous().data_ptr(), we.data_ptr(), s)
         return we
 
     def weights_bwd(self, w, stream=None):
@@ -71,9 +74,9 @@ class ConvLayer:
         """Gradient in forward layout -> gradient of the raw (k,k,Ci,Co) weights (svgp_upconv_fold_wgrad for up layers)."""
         if not self.up:
             return gwf.view(self.k, self.k, self.Ci, self.Co)
-        g = torch.empty(3, 3, self.Ci, self.Co, dtype=_F64, device=gwf.device)
+        g = torch.empty(3, 3, self.Ci, self.Co, dtype=self.dt, device=gwf.device)
         s = torch.cuda.current_stream(gwf.device).cuda_stream if stream is None else stream
-        call("svgp_upconv_fold_wgrad", self.Ci, self.Co, gwf.data_ptr(), g.data_ptr(), s)
+        call("svgp_upconv_fold_wgrad" + self.sfx, self.Ci, self.Co, gwf.data_ptr(), g.data_ptr(), s)
         return g
 
     @property
@@ -132,21 +135,23 @@ class ConvLayer:
         ds = self.descs_fwd(n)
         arr = (ConvDesc * len(ds))(*ds)
         wf = self.weights_fwd(w, stream)
-        call("svgp_conv_taps_fwd", arr, len(ds), x.data_ptr(), wf.data_ptr(), b.data_ptr(), out.data_ptr(), stream)
+        assert x.dtype == self.dt and w.dtype == self.dt and out.dtype == self.dt
+        call("svgp_conv_taps_fwd" + self.sfx, arr, len(ds), x.data_ptr(), wf.data_ptr(), b.data_ptr(), out.data_ptr(), stream)
         return out
 
     def backward(self, x, w, out, dout, gw, gb, scratch, stream, need_dx=True, dx=None, nwg=512):
         """dout (n,Ho,Ho,Co) is overwritten with dpre.  gw (k,k,Ci,Co), gb (Co) receive the gradients.
-        scratch: float64 buffer of >= scratch_elems(nwg) elements.  Returns dx (n,Hi,Hi,Ci) or None."""
+        scratch: buffer (layer dtype) of >= scratch_elems(nwg) elements.  Returns dx (n,Hi,Hi,Ci) or None."""
         n = x.shape[0]
+        assert x.dtype == self.dt and dout.dtype == self.dt and scratch.dtype == self.dt and gw.dtype == self.dt
         part_b = scratch[:1024 * 16]
         part_w = scratch[1024 * 16:]
-        call("svgp_elu_bwd_bias", n * self.Ho * self.Ho, self.Co, out.data_ptr() if self.elu else None, dout.data_ptr(),
+        call("svgp_elu_bwd_bias" + self.sfx, n * self.Ho * self.Ho, self.Co, out.data_ptr() if self.elu else None, dout.data_ptr(),
              part_b.data_ptr(), gb.data_ptr(), stream)
         ds = self.descs_fwd(n, act=0)
         arr = (ConvDesc * len(ds))(*ds)
-        gwf = torch.empty(self.n_wf, dtype=_F64, device=x.device)
-        call("svgp_conv_taps_wgrad", arr, len(ds), x.data_ptr(), dout.data_ptr(), part_w.data_ptr(), nwg, self.n_wf,
+        gwf = torch.empty(self.n_wf, dtype=self.dt, device=x.device)
+        call("svgp_conv_taps_wgrad" + self.sfx, arr, len(ds), x.data_ptr(), dout.data_ptr(), part_w.data_ptr(), nwg, self.n_wf,
              gwf.data_ptr(), 0, stream)
         gw.copy_(self.fold_wgrad(gwf, stream))
         if not need_dx:
@@ -155,8 +160,8 @@ class ConvLayer:
         arrb = (ConvDesc * len(db))(*db)
         wb = self.weights_bwd(w, stream)
         if dx is None:
-            dx = torch.empty(n, self.Hi, self.Hi, self.Ci, dtype=_F64, device=x.device)
-        call("svgp_conv_taps_fwd", arrb, len(db), dout.data_ptr(), wb.data_ptr(), None, dx.data_ptr(), stream)
+            dx = torch.empty(n, self.Hi, self.Hi, self.Ci, dtype=self.dt, device=x.device)
+        call("svgp_conv_taps_fwd" + self.sfx, arrb, len(db), dout.data_ptr(), wb.data_ptr(), None, dx.data_ptr(), stream)
         return dx
 
     def scratch_elems(self, nwg=512):

@@ -42,6 +42,7 @@ int svgp_check_cfg(const svgp_mnist_cfg* c) {
     SVGP_REQUIRE(c->N_train > 0 && c->jitter >= 0, SVGP_ERR_INVALID, "bad N_train / jitter");
     SVGP_REQUIRE(c->kl_form == 0 || c->kl_form == 1, SVGP_ERR_INVALID, "kl_form=%d (0 or 1)", c->kl_form);
     SVGP_REQUIRE(c->clip_pv >= 0 && c->clip_pv <= 2, SVGP_ERR_INVALID, "clip_pv=%d (0, 1 or 2)", c->clip_pv);
+    SVGP_REQUIRE(c->gemm_f32 >= 0 && c->gemm_f32 <= 2, SVGP_ERR_INVALID, "gemm_f32=%d (0, 1 or 2)", c->gemm_f32);
     SVGP_REQUIRE(!(c->kl_form && c->m > SVGP_M_MAX), SVGP_ERR_UNSUPPORTED,
                  "kl_form=1 (moving-ball SVGP) is implemented for m <= %d inducing points (m=%d)", SVGP_M_MAX, c->m);
     SVGP_REQUIRE(!(c->kl_form && c->b != c->b_global), SVGP_ERR_UNSUPPORTED,

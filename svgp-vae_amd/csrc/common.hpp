@@ -67,6 +67,25 @@ __device__ __forceinline__ real svgp_seed_K(int flags, real gT, real b_over_N) {
 
 #define SVGP_LAUNCH_CHECK() SVGP_CHECK_HIP(hipGetLastError())
 
+#ifdef __HIPCC__
+// MFMA traits of the two arithmetic types (16 x 16 x 4 forms; A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][j = lane & 15])
+typedef double svgp_d4_t __attribute__((ext_vector_type(4)));
+typedef float svgp_f4_t __attribute__((ext_vector_type(4)));
+template <typename TC> struct SvgpMfma;
+template <> struct SvgpMfma<double> {
+    typedef svgp_d4_t acc_t;
+    typedef double2 pair_t;
+    __device__ static __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int q, int e) { return q + 4 * e; }       // C/D: row = (lane >> 4) + 4 reg
+};
+template <> struct SvgpMfma<float> {
+    typedef svgp_f4_t acc_t;
+    typedef float2 pair_t;
+    __device__ static __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int q, int e) { return 4 * q + e; }       // C/D: row = 4 (lane >> 4) + reg
+};
+#endif
+
 // Row partials of the statistics launches (LDS-resident path): the rows of every channel are split over this many
 // workgroups, each writing its own partial block; consumers add the partials on load.  A function of the row CAPACITY
 // (like every offset of the layout).  One block when the batch is sharded over ranks: the statistics blocks are then

@@ -15,7 +15,6 @@
 // v_mfma_f64_16x16x4 per (tap, 4 input channels).  Workgroup = 4 waves = 16 x 8 output pixels.
 #include "common.hpp"
 
-typedef double d4c_t __attribute__((ext_vector_type(4)));
 
 #define CT_TW 16      // tile width  (pixels per MFMA row segment)
 #define CT_TH 8       // tile height (2 rows per wave)
@@ -42,22 +41,24 @@ __device__ __forceinline__ void tap_range(const svgp_conv_desc& d, int& omin_y, 
 // Thread = (channel pair, pixel lane); channels of a pixel are contiguous in NHWC, pixels of a tile row as well.
 #define CT_U 8
 // tile[(py * hw + px) * ps + c] = in[hy0 + py][hx0 + px][c]   (zero outside the image / for padded channels)
-__device__ __forceinline__ void stage_halo(real* __restrict__ tile, const real* __restrict__ inn, int Hi, int Wi, int Ci,
+template <typename T>
+__device__ __forceinline__ void stage_halo(T* __restrict__ tile, const T* __restrict__ inn, int Hi, int Wi, int Ci,
                                            int hy0, int hx0, int hh, int hw, int Ci4, int ps) {
+    typedef typename SvgpMfma<T>::pair_t pair_t;
     const int cp = Ci4 >> 1, npl = (int)blockDim.x / cp;
     const int c2 = ((int)threadIdx.x % cp) * 2, pl = (int)threadIdx.x / cp, npix = hh * hw;
     if (pl >= npl) return;
     const bool pair = (Ci & 1) == 0;              // even channel count: 16-byte aligned pairs
     for (int p0 = pl; p0 < npix; p0 += npl * CT_U) {
-        real v0[CT_U], v1[CT_U];
+        T v0[CT_U], v1[CT_U];
 #pragma unroll
         for (int u = 0; u < CT_U; ++u) {
             const int p = p0 + u * npl, py = p / hw, px = p - py * hw, gy = hy0 + py, gx = hx0 + px;
             v0[u] = 0; v1[u] = 0;
             if (p < npix && (unsigned)gy < (unsigned)Hi && (unsigned)gx < (unsigned)Wi) {
-                const real* src = inn + ((size_t)gy * Wi + gx) * Ci + c2;
+                const T* src = inn + ((size_t)gy * Wi + gx) * Ci + c2;
                 if (pair && c2 + 1 < Ci) {
-                    const double2 t = *reinterpret_cast<const double2*>(src);
+                    const pair_t t = *reinterpret_cast<const pair_t*>(src);
                     v0[u] = t.x; v1[u] = t.y;
                 } else {
                     if (c2 < Ci) v0[u] = src[0];
@@ -83,10 +84,13 @@ __device__ __forceinline__ void tap_range_all(const ConvLaunch& L, int& oy0, int
     }
 }
 
-__global__ __launch_bounds__(256) void k_conv_taps_fwd(ConvLaunch L, int nchunk, const real* __restrict__ in,
-                                                       const real* __restrict__ w, const real* __restrict__ bias,
-                                                       real* __restrict__ out) {
-    extern __shared__ __align__(16) real smem[];
+template <typename T>
+__global__ __launch_bounds__(256) void k_conv_taps_fwd(ConvLaunch L, int nchunk, const T* __restrict__ in,
+                                                       const T* __restrict__ w, const T* __restrict__ bias,
+                                                       T* __restrict__ out) {
+    typedef SvgpMfma<T> MF;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
     // The workgroup keeps ONE tile position and walks the images blockIdx.z, blockIdx.z + nchunk, ...: the tap weights of
     // every class are staged once, and the classes of a launch (the four output parities of an upsample-fused or
     // stride-2-transposed layer) share one staged input tile per image.
@@ -99,20 +103,20 @@ __global__ __launch_bounds__(256) void k_conv_taps_fwd(ConvLaunch L, int nchunk,
     tap_range_all(L, oy0, oy1, ox0, ox1);
     const int hy0 = y0 * d.sy + oy0, hx0 = x0 * d.sx + ox0;
     const int hh = (CT_TH - 1) * d.sy + (oy1 - oy0) + 1, hw = (CT_TW - 1) * d.sx + (ox1 - ox0) + 1;
-    real* tile = smem;                                     // hh x hw x ps
-    real* wl = tile + hh * hw * ps;                        // per class: nt x Ci4 x 16 (co padded to 16), packed
+    T* tile = smem;                                        // hh x hw x ps
+    T* wl = tile + hh * hw * ps;                           // per class: nt x Ci4 x 16 (co padded to 16), packed
     int wbase[4] = {0, 0, 0, 0};
     for (int cls = 0, o = 0; cls < L.ncls; ++cls) {
         const svgp_conv_desc& dc = L.d[cls];
         wbase[cls] = o;
         for (int t = threadIdx.x; t < dc.nt * Ci4 * 16; t += blockDim.x) {
             const int co = t & 15, c = (t >> 4) % Ci4, tp = t / (16 * Ci4);
-            wl[o + t] = (c < dc.Ci && co < dc.Co) ? w[dc.woff[tp] + c * dc.Co + co] : real(0);
+            wl[o + t] = (c < dc.Ci && co < dc.Co) ? w[dc.woff[tp] + c * dc.Co + co] : T(0);
         }
         o += dc.nt * Ci4 * 16;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
-    const real bias_r = (d.act && r < d.Co) ? bias[r] : real(0);
+    const T bias_r = (d.act && r < d.Co) ? bias[r] : T(0);
     for (int n = blockIdx.z; n < d.n; n += nchunk) {
         __syncthreads();                                   // previous image's MFMA reads of `tile` are done
         stage_halo(tile, in + (size_t)n * d.Hi * d.Wi * d.Ci, d.Hi, d.Wi, d.Ci, hy0, hx0, hh, hw, Ci4, ps);
@@ -124,22 +128,21 @@ __global__ __launch_bounds__(256) void k_conv_taps_fwd(ConvLaunch L, int nchunk,
             const int ly = wave * 2 + rr, y = y0 + ly;
             if (y >= dc.Hs) continue;
             const int wb = cls == 0 ? wbase[0] : cls == 1 ? wbase[1] : cls == 2 ? wbase[2] : wbase[3];
-            d4c_t acc = {0, 0, 0, 0};
+            typename MF::acc_t acc = {0, 0, 0, 0};
             for (int tp = 0; tp < dc.nt; ++tp) {
-                const real* ap = tile + ((ly * d.sy + dc.oy[tp] - oy0) * hw + (r * d.sx + dc.ox[tp] - ox0)) * ps + q;
-                const real* bp = wl + wb + (tp * Ci4 + q) * 16 + r;
-                for (int c0 = 0; c0 < Ci4; c0 += 4)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[c0], bp[c0 * 16], acc, 0, 0, 0);
+                const T* ap = tile + ((ly * d.sy + dc.oy[tp] - oy0) * hw + (r * d.sx + dc.ox[tp] - ox0)) * ps + q;
+                const T* bp = wl + wb + (tp * Ci4 + q) * 16 + r;
+                for (int c0 = 0; c0 < Ci4; c0 += 4) acc = MF::mma(ap[c0], bp[c0 * 16], acc);
             }
-            // D: column (co) = lane & 15, row (pixel) = q + 4 g
+            // D: column (co) = lane & 15, row (pixel) = MF::row(q, g)
             const int gy = y * dc.osy + dc.ooy;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int x = x0 + q + 4 * g;
+                const int x = x0 + MF::row(q, g);
                 if (x < dc.Ws && r < dc.Co) {
-                    real v = acc[g];
+                    T v = acc[g];
                     if (dc.act) v += bias_r;
-                    if (dc.act == 1) v = v > 0 ? v : exp(v) - real(1);
+                    if (dc.act == 1) v = v > 0 ? v : (T)(exp(v) - T(1));
                     out[(((size_t)n * dc.Ho + gy) * dc.Wo + (x * dc.osx + dc.oox)) * dc.Co + r] = v;
                 }
             }
@@ -151,10 +154,13 @@ __global__ __launch_bounds__(256) void k_conv_taps_fwd(ConvLaunch L, int nchunk,
 // keeps dW_t (Ci4 x 16 per tap) in MFMA accumulators: A[i=ci][k=pixel] = in, B[k=pixel][j=co] = dout,
 // k-steps of 4 consecutive pixels of a row segment.  Partials: part[g][woff_t + ci * Co + co]; the classes' tap ranges are
 // disjoint, so they share row g.
-__global__ __launch_bounds__(256) void k_conv_taps_wgrad(ConvLaunch L, int nwg, const real* __restrict__ in,
-                                                         const real* __restrict__ dout, real* __restrict__ part,
+template <typename T>
+__global__ __launch_bounds__(256) void k_conv_taps_wgrad(ConvLaunch L, int nwg, const T* __restrict__ in,
+                                                         const T* __restrict__ dout, T* __restrict__ part,
                                                          int part_stride) {
-    extern __shared__ __align__(16) real smem[];
+    typedef SvgpMfma<T> MF;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    T* smem = reinterpret_cast<T*>(smem_raw);
     const int cls = blockIdx.y;
     const svgp_conv_desc& d = L.d[cls];
     const int tiles_x = (d.Ws + CT_TW - 1) / CT_TW, tiles_y = (d.Hs + CT_TH - 1) / CT_TH;
@@ -163,26 +169,26 @@ __global__ __launch_bounds__(256) void k_conv_taps_wgrad(ConvLaunch L, int nwg, 
     int oy0, oy1, ox0, ox1;
     tap_range(d, oy0, oy1, ox0, ox1);
     const int hh = (CT_TH - 1) * d.sy + (oy1 - oy0) + 1, hw = (CT_TW - 1) * d.sx + (ox1 - ox0) + 1;
-    real* tile = smem;                          // hh x hw x ps      (input halo)
-    real* dt = tile + hh * hw * ps;             // CT_TH x CT_TW x 18 (dout tile, co padded to 16)
-    real* red = dt + CT_TH * CT_TW * 18;        // 4 waves x 64 lanes x 4  (cross-wave combine)
+    T* tile = smem;                             // hh x hw x ps      (input halo)
+    T* dt = tile + hh * hw * ps;                // CT_TH x CT_TW x 18 (dout tile, co padded to 16)
+    T* red = dt + CT_TH * CT_TW * 18;           // 4 waves x 64 lanes x 4  (cross-wave combine)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
     // accumulators: per tap one 16x16 tile (rows ci, cols co); Ci4 <= 16.  Every wave takes ALL taps of 2 of the 8 tile rows
     // (balanced for any tap count; the dout fragment of a row is loaded once and reused by every tap); the four waves'
     // partial tiles are added through LDS once per workgroup, after the last tile.
-    d4c_t acc[CT_MAXT];
+    typename MF::acc_t acc[CT_MAXT];
 #pragma unroll
-    for (int a = 0; a < CT_MAXT; ++a) acc[a] = d4c_t{0, 0, 0, 0};
+    for (int a = 0; a < CT_MAXT; ++a) acc[a] = typename MF::acc_t{0, 0, 0, 0};
     for (int tl = blockIdx.x; tl < ntile; tl += nwg) {
         const int n = tl / (tiles_x * tiles_y), tt = tl % (tiles_x * tiles_y);
         const int x0 = (tt % tiles_x) * CT_TW, y0 = (tt / tiles_x) * CT_TH;
         const int hy0 = y0 * d.sy + oy0, hx0 = x0 * d.sx + ox0;
-        const real* inn = in + (size_t)n * d.Hi * d.Wi * d.Ci;
+        const T* inn = in + (size_t)n * d.Hi * d.Wi * d.Ci;
         __syncthreads();
         stage_halo(tile, inn, d.Hi, d.Wi, d.Ci, hy0, hx0, hh, hw, Ci4, ps);
         {   // dout tile: thread = (co, pixel lane of 16), 8 pixels in flight per thread
             const int co = threadIdx.x & 15, pl = threadIdx.x >> 4;
-            real v[CT_TH];
+            T v[CT_TH];
 #pragma unroll
             for (int u = 0; u < CT_TH; ++u) {
                 const int p = pl + 16 * u, px = p % CT_TW, py = p / CT_TW, y = y0 + py, x = x0 + px;
@@ -197,25 +203,25 @@ __global__ __launch_bounds__(256) void k_conv_taps_wgrad(ConvLaunch L, int nwg, 
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             const int py = wave * 2 + rr;
-            real bv[4];
+            T bv[4];
 #pragma unroll
             for (int k4 = 0; k4 < 4; ++k4) bv[k4] = dt[(py * CT_TW + 4 * k4 + q) * 18 + r];          // co = r
 #pragma unroll
             for (int tp = 0; tp < CT_MAXT; ++tp) {
                 if (tp < d.nt) {
-                    const real* ap = tile + ((py * d.sy + d.oy[tp] - oy0) * hw + (d.ox[tp] - ox0)) * ps + r;  // ci = r
+                    const T* ap = tile + ((py * d.sy + d.oy[tp] - oy0) * hw + (d.ox[tp] - ox0)) * ps + r;  // ci = r
 #pragma unroll
                     for (int k4 = 0; k4 < 4; ++k4) {
-                        const real av = (r < Ci4) ? ap[((4 * k4 + q) * d.sx) * ps] : real(0);
-                        acc[tp] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[k4], acc[tp], 0, 0, 0);
+                        const T av = (r < Ci4) ? ap[((4 * k4 + q) * d.sx) * ps] : T(0);
+                        acc[tp] = MF::mma(av, bv[k4], acc[tp]);
                     }
                 }
             }
         }
     }
-    // cross-wave combine (fixed order) and store.  D: col (co) = r, row (ci) = q + 4 g
+    // cross-wave combine (fixed order) and store.  D: col (co) = r, row (ci) = MF::row(q, g)
     // the classes of a launch write disjoint weight ranges (their own taps), so they share partial row blockIdx.x
-    real* po = part + (size_t)blockIdx.x * part_stride;
+    T* po = part + (size_t)blockIdx.x * part_stride;
 #pragma unroll
     for (int tp = 0; tp < CT_MAXT; ++tp) {
         if (tp < d.nt) {
@@ -226,9 +232,9 @@ __global__ __launch_bounds__(256) void k_conv_taps_wgrad(ConvLaunch L, int nwg, 
             if (wave == 0) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const real t = red[lane * 4 + g] + red[(64 + lane) * 4 + g] + red[(128 + lane) * 4 + g] +
-                                   red[(192 + lane) * 4 + g];
-                    const int ci = q + 4 * g;
+                    const T t = red[lane * 4 + g] + red[(64 + lane) * 4 + g] + red[(128 + lane) * 4 + g] +
+                                red[(192 + lane) * 4 + g];
+                    const int ci = MF::row(q, g);
                     if (ci < d.Ci && r < d.Co) po[d.woff[tp] + ci * d.Co + r] = t;
                 }
             }
@@ -239,21 +245,23 @@ __global__ __launch_bounds__(256) void k_conv_taps_wgrad(ConvLaunch L, int nwg, 
 // UpSampling2D(2) + 3x3 conv as four parity classes: effective weights we[py][px][ty][tx] = sum of the raw taps (ky,kx) that
 // land on low-resolution offset (ty,tx) for output parity (py,px): tap group T(p,k) = (k + p >= 2).  fold = the transpose
 // of that sum (gradient of the raw weights from the gradient of the effective ones).
-__global__ void k_upconv_weff(int cc, const real* __restrict__ w, real* __restrict__ we) {
+template <typename T>
+__global__ void k_upconv_weff(int cc, const T* __restrict__ w, T* __restrict__ we) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (py,px,ty,tx, ci*co)
     if (i >= 16 * cc) return;
     const int e = i % cc, g = i / cc, tx = g & 1, ty = (g >> 1) & 1, px = (g >> 2) & 1, py = g >> 3;
-    real s = 0;
+    T s = 0;
     for (int ky = 0; ky < 3; ++ky)
         for (int kx = 0; kx < 3; ++kx)
             if (((ky + py >= 2) ? 1 : 0) == ty && ((kx + px >= 2) ? 1 : 0) == tx) s += w[(ky * 3 + kx) * cc + e];
     we[i] = s;
 }
-__global__ void k_upconv_fold(int cc, const real* __restrict__ ge, real* __restrict__ g) {
+template <typename T>
+__global__ void k_upconv_fold(int cc, const T* __restrict__ ge, T* __restrict__ g) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (ky,kx, ci*co)
     if (i >= 9 * cc) return;
     const int e = i % cc, k = i / cc, kx = k % 3, ky = k / 3;
-    real s = 0;
+    T s = 0;
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
             const int ty = (ky + py >= 2) ? 1 : 0, tx = (kx + px >= 2) ? 1 : 0;
@@ -265,16 +273,17 @@ __global__ void k_upconv_fold(int cc, const real* __restrict__ ge, real* __restr
 // out[i] (+)= sum_g part[g][i]   (fixed order)
 // one workgroup per 16 outputs: thread = (output il = tid & 15, partial lane ch = tid >> 4); lane ch adds partials ch, ch + 16,
 // ... (8 loads in flight), the 16 lanes are combined through LDS in fixed order
-__global__ __launch_bounds__(256) void k_sum_partials(int ng, int len, int stride, const real* __restrict__ part,
-                                                      real* __restrict__ out, int accumulate) {
-    __shared__ real sh[16][17];
+template <typename T>
+__global__ __launch_bounds__(256) void k_sum_partials(int ng, int len, int stride, const T* __restrict__ part,
+                                                      T* __restrict__ out, int accumulate) {
+    __shared__ T sh[16][17];
     const int il = threadIdx.x & 15, ch = threadIdx.x >> 4, i = blockIdx.x * 16 + il;
-    real s = 0;
+    T s = 0;
     if (i < len) {
         for (int g0 = ch; g0 < ng; g0 += 16 * 8) {
-            real v[8];
+            T v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int g = g0 + 16 * u; v[u] = g < ng ? part[(size_t)g * stride + i] : real(0); }
+            for (int u = 0; u < 8; ++u) { const int g = g0 + 16 * u; v[u] = g < ng ? part[(size_t)g * stride + i] : T(0); }
 #pragma unroll
             for (int u = 0; u < 8; ++u) s += v[u];
         }
@@ -282,7 +291,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(int ng, int len, int strid
     sh[ch][il] = s;
     __syncthreads();
     if (ch == 0 && i < len) {
-        real t = accumulate ? out[i] : real(0);
+        T t = accumulate ? out[i] : T(0);
 #pragma unroll
         for (int c = 0; c < 16; ++c) t += sh[c][il];
         out[i] = t;
@@ -291,16 +300,17 @@ __global__ __launch_bounds__(256) void k_sum_partials(int ng, int len, int strid
 
 // dpre = dout * elu'(out) in place on dout; also per-block column sums for the bias gradient.  HBM-bound (read out, read
 // dout, write dout): 8 independent element pairs in flight per thread
-__global__ __launch_bounds__(256) void k_elu_bwd_colsum(long long npix, int C, const real* __restrict__ outv,
-                                                        real* __restrict__ dout, real* __restrict__ part) {
-    __shared__ real sh[256];
+template <typename T>
+__global__ __launch_bounds__(256) void k_elu_bwd_colsum(long long npix, int C, const T* __restrict__ outv,
+                                                        T* __restrict__ dout, T* __restrict__ part) {
+    __shared__ T sh[256];
     // thread t handles channel t % C of pixels t / C + k * (256 / C)   (C <= 16 divides into 256 evenly enough)
     const int c = threadIdx.x % C, lp = threadIdx.x / C, ppb = blockDim.x / C;
-    real s = 0;
+    T s = 0;
     if (lp < ppb) {
         const long long stride = (long long)gridDim.x * ppb;
         for (long long p0 = (long long)blockIdx.x * ppb + lp; p0 < npix; p0 += stride * 8) {
-            real dv[8], ov[8];
+            T dv[8], ov[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const long long p = p0 + u * stride;
@@ -315,16 +325,16 @@ __global__ __launch_bounds__(256) void k_elu_bwd_colsum(long long npix, int C, c
             for (int u = 0; u < 8; ++u) {
                 const long long p = p0 + u * stride;
                 if (p < npix) {
-                    if (outv) { dv[u] *= (ov[u] > 0 ? real(1) : ov[u] + real(1)); dout[(size_t)p * C + c] = dv[u]; }
+                    if (outv) { dv[u] *= (ov[u] > 0 ? T(1) : ov[u] + T(1)); dout[(size_t)p * C + c] = dv[u]; }
                     s += dv[u];
                 }
             }
         }
     }
-    sh[threadIdx.x] = (lp < ppb) ? s : real(0);
+    sh[threadIdx.x] = (lp < ppb) ? s : T(0);
     __syncthreads();
     if (threadIdx.x < C) {
-        real t = 0;
+        T t = 0;
         for (int k = 0; k < ppb; ++k) t += sh[k * C + threadIdx.x];
         part[blockIdx.x * C + threadIdx.x] = t;
     }
@@ -369,8 +379,9 @@ int check_desc(const svgp_conv_desc* d, int ncls) {
 
 }  // namespace
 
-extern "C" int svgp_conv_taps_fwd(const svgp_conv_desc* d, int ncls, const double* in, const double* w,
-                                  const double* bias, double* out, void* stream) {
+template <typename T>
+static int conv_taps_fwd_impl(const svgp_conv_desc* d, int ncls, const T* in, const T* w, const T* bias, T* out,
+                              void* stream) {
     int rc = check_desc(d, ncls);
     if (rc) return rc;
     SVGP_REQUIRE(in && w && out, SVGP_ERR_INVALID, "NULL device pointer");
@@ -387,16 +398,16 @@ extern "C" int svgp_conv_taps_fwd(const svgp_conv_desc* d, int ncls, const doubl
     // union halo tile of all classes + the packed tap weights of every class
     size_t lds = fwd_lds_all(d, ncls);
     for (int c = 0; c < ncls; ++c) lds += (size_t)d[c].nt * ((d[0].Ci + 3) & ~3) * 16;
-    lds *= sizeof(real);
+    lds *= sizeof(T);
     SVGP_REQUIRE(lds <= 160 * 1024, SVGP_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
-    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_taps_fwd),
+    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_taps_fwd<T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int tiles = ((d[0].Ws + CT_TW - 1) / CT_TW) * ((d[0].Hs + CT_TH - 1) / CT_TH);
     // enough workgroups for ~8 per CU, each walking n / nchunk images of its tile position
     int nchunk = (2048 + tiles - 1) / tiles;
     if (nchunk > d[0].n) nchunk = d[0].n;
     if (nchunk < 1) nchunk = 1;
-    hipLaunchKernelGGL(k_conv_taps_fwd, dim3(tiles, 1, nchunk), dim3(256), lds, (hipStream_t)stream, L, nchunk, in, w, bias,
+    hipLaunchKernelGGL(k_conv_taps_fwd<T>, dim3(tiles, 1, nchunk), dim3(256), lds, (hipStream_t)stream, L, nchunk, in, w, bias,
                        out);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
@@ -404,9 +415,9 @@ extern "C" int svgp_conv_taps_fwd(const svgp_conv_desc* d, int ncls, const doubl
 
 // part: (ncls * nwg, part_stride) scratch; dw (part_stride values, the layer's weight layout via woff) receives
 // the fixed-order sum over workgroups and classes (accumulate != 0 adds to dw).
-extern "C" int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const double* in, const double* dout,
-                                    double* part, int nwg, int part_stride, double* dw, int accumulate,
-                                    void* stream) {
+template <typename T>
+static int conv_taps_wgrad_impl(const svgp_conv_desc* d, int ncls, const T* in, const T* dout, T* part, int nwg,
+                                int part_stride, T* dw, int accumulate, void* stream) {
     int rc = check_desc(d, ncls);
     if (rc) return rc;
     SVGP_REQUIRE(in && dout && part && dw && nwg >= 1 && part_stride >= 1, SVGP_ERR_INVALID, "bad argument");
@@ -418,46 +429,87 @@ extern "C" int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const dou
         const size_t e = fwd_lds(d[c]) + (size_t)CT_TH * CT_TW * 18 + 1024;
         lds = e > lds ? e : lds;
     }
-    lds *= sizeof(real);
+    lds *= sizeof(T);
     SVGP_REQUIRE(lds <= 160 * 1024, SVGP_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
-    SVGP_CHECK_HIP(hipMemsetAsync(part, 0, (size_t)nwg * part_stride * sizeof(real), (hipStream_t)stream));
-    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_taps_wgrad),
+    SVGP_CHECK_HIP(hipMemsetAsync(part, 0, (size_t)nwg * part_stride * sizeof(T), (hipStream_t)stream));
+    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_taps_wgrad<T>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_conv_taps_wgrad, dim3(nwg, ncls), dim3(256), lds, (hipStream_t)stream, L, nwg, in, dout, part,
+    hipLaunchKernelGGL(k_conv_taps_wgrad<T>, dim3(nwg, ncls), dim3(256), lds, (hipStream_t)stream, L, nwg, in, dout, part,
                        part_stride);
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_partials, dim3((part_stride + 15) / 16), dim3(256), 0, (hipStream_t)stream, nwg,
-                       part_stride, part_stride, part, dw, accumulate);
+    hipLaunchKernelGGL(k_sum_partials<T>, dim3((part_stride + 15) / 16), dim3(256), 0, (hipStream_t)stream, nwg,
+                       part_stride, part_stride, (const T*)part, dw, accumulate);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
 
 // dpre = dout * elu'(out) (in place on dout; out == NULL skips the activation) and db[c] = sum dpre[.., c].
 // part: (1024, C) scratch.
-extern "C" int svgp_elu_bwd_bias(long long npix, int C, const double* out, double* dout, double* part, double* db,
-                                 void* stream) {
+template <typename T>
+static int elu_bwd_bias_impl(long long npix, int C, const T* out, T* dout, T* part, T* db, void* stream) {
     SVGP_REQUIRE(npix >= 1 && C >= 1 && C <= 16 && dout && part && db, SVGP_ERR_INVALID, "bad argument");
     const int nblk = 1024;     // 4 workgroups per CU keep the HBM queues full
-    hipLaunchKernelGGL(k_elu_bwd_colsum, dim3(nblk), dim3(256), 0, (hipStream_t)stream, npix, C, out, dout, part);
+    hipLaunchKernelGGL(k_elu_bwd_colsum<T>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, npix, C, out, dout, part);
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, (hipStream_t)stream, nblk, C, C, part, db, 0);
+    hipLaunchKernelGGL(k_sum_partials<T>, dim3(1), dim3(256), 0, (hipStream_t)stream, nblk, C, C, (const T*)part, db, 0);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
 
 // effective weights of an upsample-fused 3x3 convolution (conv.py ConvLayer(up=True)): w (3,3,Ci,Co) -> we (2,2,2,2,Ci,Co);
 // and the gradient of w from the gradient of we
-extern "C" int svgp_upconv_weights(int Ci, int Co, const double* w, double* we, void* stream) {
+template <typename T>
+static int upconv_weights_impl(int Ci, int Co, const T* w, T* we, void* stream) {
     SVGP_REQUIRE(Ci >= 1 && Co >= 1 && w && we, SVGP_ERR_INVALID, "bad argument");
     const int cc = Ci * Co;
-    hipLaunchKernelGGL(k_upconv_weff, dim3((16 * cc + 255) / 256), dim3(256), 0, (hipStream_t)stream, cc, w, we);
+    hipLaunchKernelGGL(k_upconv_weff<T>, dim3((16 * cc + 255) / 256), dim3(256), 0, (hipStream_t)stream, cc, w, we);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
-extern "C" int svgp_upconv_fold_wgrad(int Ci, int Co, const double* ge, double* g, void* stream) {
+template <typename T>
+static int upconv_fold_impl(int Ci, int Co, const T* ge, T* g, void* stream) {
     SVGP_REQUIRE(Ci >= 1 && Co >= 1 && ge && g, SVGP_ERR_INVALID, "bad argument");
     const int cc = Ci * Co;
-    hipLaunchKernelGGL(k_upconv_fold, dim3((9 * cc + 255) / 256), dim3(256), 0, (hipStream_t)stream, cc, ge, g);
+    hipLaunchKernelGGL(k_upconv_fold<T>, dim3((9 * cc + 255) / 256), dim3(256), 0, (hipStream_t)stream, cc, ge, g);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
+}
+
+extern "C" int svgp_conv_taps_fwd(const svgp_conv_desc* d, int ncls, const double* in, const double* w,
+                                  const double* bias, double* out, void* stream) {
+    return conv_taps_fwd_impl<double>(d, ncls, in, w, bias, out, stream);
+}
+extern "C" int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const double* in, const double* dout,
+                                    double* part, int nwg, int part_stride, double* dw, int accumulate, void* stream) {
+    return conv_taps_wgrad_impl<double>(d, ncls, in, dout, part, nwg, part_stride, dw, accumulate, stream);
+}
+extern "C" int svgp_elu_bwd_bias(long long npix, int C, const double* out, double* dout, double* part, double* db,
+                                 void* stream) {
+    return elu_bwd_bias_impl<double>(npix, C, out, dout, part, db, stream);
+}
+extern "C" int svgp_upconv_weights(int Ci, int Co, const double* w, double* we, void* stream) {
+    return upconv_weights_impl<double>(Ci, Co, w, we, stream);
+}
+extern "C" int svgp_upconv_fold_wgrad(int Ci, int Co, const double* ge, double* g, void* stream) {
+    return upconv_fold_impl<double>(Ci, Co, ge, g, stream);
+}
+// ---- float32 instantiations: the reference's dtype for the SPRITES networks (VAE_utils.py:277); same tap tables, the
+// gather-GEMM runs on v_mfma_f32_16x16x4_f32 (twice the matrix rate of the f64 form, half the LDS and HBM bytes)
+extern "C" int svgp_conv_taps_fwd_f32(const svgp_conv_desc* d, int ncls, const float* in, const float* w, const float* bias,
+                                      float* out, void* stream) {
+    return conv_taps_fwd_impl<float>(d, ncls, in, w, bias, out, stream);
+}
+extern "C" int svgp_conv_taps_wgrad_f32(const svgp_conv_desc* d, int ncls, const float* in, const float* dout, float* part,
+                                        int nwg, int part_stride, float* dw, int accumulate, void* stream) {
+    return conv_taps_wgrad_impl<float>(d, ncls, in, dout, part, nwg, part_stride, dw, accumulate, stream);
+}
+extern "C" int svgp_elu_bwd_bias_f32(long long npix, int C, const float* out, float* dout, float* part, float* db,
+                                     void* stream) {
+    return elu_bwd_bias_impl<float>(npix, C, out, dout, part, db, stream);
+}
+extern "C" int svgp_upconv_weights_f32(int Ci, int Co, const float* w, float* we, void* stream) {
+    return upconv_weights_impl<float>(Ci, Co, w, we, stream);
+}
+extern "C" int svgp_upconv_fold_wgrad_f32(int Ci, int Co, const float* ge, float* g, void* stream) {
+    return upconv_fold_impl<float>(Ci, Co, ge, g, stream);
 }

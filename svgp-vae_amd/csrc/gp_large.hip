@@ -8,6 +8,9 @@
 extern "C" int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
                                   long long strideA, const double* B, int ldb, long long strideB, double beta,
                                   double* C, int ldc, long long strideC, int batch, void* stream);
+extern "C" int svgp_dgemm_f32c_batched(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
+                                       long long strideA, const double* B, int ldb, long long strideB, double beta,
+                                       double* C, int ldc, long long strideC, int batch, void* stream);
 extern "C" int svgp_spd_inverse_batched(int m, int batch, double* A, double* logdet, double* work, void* stream);
 
 namespace {
@@ -258,7 +261,9 @@ inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
 #define RUNC(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
-#define GEMM(...) RUNC(svgp_dgemm_batched(__VA_ARGS__, stream))
+// cfg.gemm_f32 = 1: every product on the float32 MFMA (float64 storage); GEMM_S: the statistics products, also with 2
+#define GEMM(...) RUNC((c->gemm_f32 == 1 ? svgp_dgemm_f32c_batched : svgp_dgemm_batched)(__VA_ARGS__, stream))
+#define GEMM_S(...) RUNC((c->gemm_f32 ? svgp_dgemm_f32c_batched : svgp_dgemm_batched)(__VA_ARGS__, stream))
 
 // scratch carving (layout fields scr_bm / scr_mm / scr_vec / scr_inv / scr_bl are allocated by api.hip)
 struct BigScr {
@@ -296,7 +301,7 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
     real* S = mode == 0 ? ws + wl.S : ws + wl.A2;
     real* v1 = mode == 0 ? ws + wl.v : ws + wl.ud;
     // S_l = Kn^T (w_l o Kn)
-    GEMM(1, 0, m, m, b, 1.0, Kn, m, 0, s.bm, m, (long long)b * m, 0.0, S, m, (long long)m * m, L);
+    GEMM_S(1, 0, m, m, b, 1.0, Kn, m, 0, s.bm, m, (long long)b * m, 0.0, S, m, (long long)m * m, L);
     // v1 (L x m) = a^T Kn
     GEMM(1, 0, L, m, b, 1.0, abuf, L, 0, Kn, m, 0, 0.0, v1, m, 0, 1);
     if (mode == 1) GEMM(1, 0, L, m, b, cc, bbuf, L, 0, Kn, m, 0, 0.0, ws + wl.td, m, 0, 1);

@@ -225,20 +225,22 @@ __global__ void k_sprites_aux_bwd(int b, int seg_len, int Lc, const real* __rest
     d_repr[i] = s / (real)seg_len;
 }
 // ---- average pooling over all HW positions of an (n, HW, C) map and its reverse ---------------------------
-__global__ void k_avgpool_fwd(int n, int HW, int Cc, const real* __restrict__ x, real* __restrict__ y) {
+template <typename T>
+__global__ void k_avgpool_fwd(int n, int HW, int Cc, const T* __restrict__ x, T* __restrict__ y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * Cc) return;
     const int im = i / Cc, c = i % Cc;
-    real s = 0;
+    T s = 0;
     for (int p = 0; p < HW; ++p) s += x[((size_t)im * HW + p) * Cc + c];
-    y[i] = s / (real)HW;
+    y[i] = s / (T)HW;
 }
-__global__ void k_avgpool_bwd(long long tot, int HW, int Cc, const real* __restrict__ dy, real* __restrict__ dx) {
+template <typename T>
+__global__ void k_avgpool_bwd(long long tot, int HW, int Cc, const T* __restrict__ dy, T* __restrict__ dx) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= tot) return;
     const int c = (int)(i % Cc);
     const long long im = i / ((long long)HW * Cc);
-    dx[i] = dy[im * Cc + c] / (real)HW;
+    dx[i] = dy[im * Cc + c] / (T)HW;
 }
 // ---- encoder head: enc (b,2L) (+bias) -> mu, var_raw = exp, var = clip; and its reverse -----------------
 __global__ void k_enc_head_fwd(int b, int L, int clip, const real* __restrict__ bias, real* __restrict__ enc,
@@ -267,28 +269,33 @@ __global__ void k_enc_head_bwd(int b, int L, int clip, const real* __restrict__ 
         d_enc[i] = pass ? s2bar[(size_t)n * L + j - L] * vr : real(0);
     }
 }
-__global__ void k_bias_add(long long tot, int Cc, const real* __restrict__ bias, real* __restrict__ x) {
+template <typename T>
+__global__ void k_bias_add(long long tot, int Cc, const T* __restrict__ bias, T* __restrict__ x) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < tot) x[i] += bias[i % Cc];
 }
 // ---- squared reconstruction error: per-block partial sums (n_part blocks) and its gradient -----------------
-__global__ __launch_bounds__(256) void k_sqerr_fwd(long long tot, const real* __restrict__ x, const real* __restrict__ xh,
+// (float32 inputs: the differences and their squares are formed and summed in float64 -- the partial sums feed the
+// float64 scalar epilogue)
+template <typename T>
+__global__ __launch_bounds__(256) void k_sqerr_fwd(long long tot, const T* __restrict__ x, const T* __restrict__ xh,
                                                    real* __restrict__ part_sums) {
     __shared__ real red[16];
     real s = 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
-        const real d = x[i] - xh[i];
+        const real d = (real)x[i] - (real)xh[i];
         s += d * d;
     }
     s = block_sum(s, red);
     if (threadIdx.x == 0) part_sums[blockIdx.x * 4 + 2] = s;
 }
+template <typename T>
 __global__ void k_sqerr_bwd(long long tot, int geco, real inv_bglobal, real inv_npix, const real* __restrict__ state,
-                            const real* __restrict__ x, const real* __restrict__ xh, real* __restrict__ dxh) {
+                            const T* __restrict__ x, const T* __restrict__ xh, T* __restrict__ dxh) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= tot) return;
     const real gscale = (geco ? state[SVGP_ST_LAGRANGE] * inv_bglobal : real(1)) * inv_npix;
-    dxh[i] = real(2) * gscale * (xh[i] - x[i]);
+    dxh[i] = (T)(real(2) * gscale * ((real)xh[i] - (real)x[i]));
 }
 __global__ void k_clip(long long tot, real thr, real* __restrict__ g) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -363,14 +370,14 @@ extern "C" int svgp_sprites_aux_bwd(int b, int seg_len, int Lc, const double* d_
 }
 extern "C" int svgp_avgpool_fwd(int n, int HW, int Cc, const double* x, double* y, void* stream) {
     SVGP_REQUIRE(n >= 1 && HW >= 1 && Cc >= 1 && x && y, SVGP_ERR_INVALID, "bad argument");
-    hipLaunchKernelGGL(k_avgpool_fwd, dim3(nb256((long long)n * Cc)), dim3(256), 0, (hipStream_t)stream, n, HW, Cc, x, y);
+    hipLaunchKernelGGL(k_avgpool_fwd<double>, dim3(nb256((long long)n * Cc)), dim3(256), 0, (hipStream_t)stream, n, HW, Cc, x, y);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
 extern "C" int svgp_avgpool_bwd(int n, int HW, int Cc, const double* dy, double* dx, void* stream) {
     SVGP_REQUIRE(n >= 1 && HW >= 1 && Cc >= 1 && dy && dx, SVGP_ERR_INVALID, "bad argument");
     const long long tot = (long long)n * HW * Cc;
-    hipLaunchKernelGGL(k_avgpool_bwd, dim3(nb256(tot)), dim3(256), 0, (hipStream_t)stream, tot, HW, Cc, dy, dx);
+    hipLaunchKernelGGL(k_avgpool_bwd<double>, dim3(nb256(tot)), dim3(256), 0, (hipStream_t)stream, tot, HW, Cc, dy, dx);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
@@ -392,7 +399,7 @@ extern "C" int svgp_enc_head_bwd(int b, int L, int clip, const double* var_raw, 
 }
 extern "C" int svgp_bias_add(long long rows, int Cc, const double* bias, double* x, void* stream) {
     SVGP_REQUIRE(rows >= 1 && Cc >= 1 && bias && x, SVGP_ERR_INVALID, "bad argument");
-    hipLaunchKernelGGL(k_bias_add, dim3(nb256(rows * Cc)), dim3(256), 0, (hipStream_t)stream, rows * Cc, Cc, bias, x);
+    hipLaunchKernelGGL(k_bias_add<double>, dim3(nb256(rows * Cc)), dim3(256), 0, (hipStream_t)stream, rows * Cc, Cc, bias, x);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
@@ -400,14 +407,50 @@ extern "C" int svgp_bias_add(long long rows, int Cc, const double* bias, double*
 extern "C" int svgp_sqerr_fwd(long long tot, int n_part, const double* x, const double* xhat, double* part_sums,
                               void* stream) {
     SVGP_REQUIRE(tot >= 1 && n_part >= 1 && x && xhat && part_sums, SVGP_ERR_INVALID, "bad argument");
-    hipLaunchKernelGGL(k_sqerr_fwd, dim3(n_part), dim3(256), 0, (hipStream_t)stream, tot, x, xhat, part_sums);
+    hipLaunchKernelGGL(k_sqerr_fwd<double>, dim3(n_part), dim3(256), 0, (hipStream_t)stream, tot, x, xhat, part_sums);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
 extern "C" int svgp_sqerr_bwd(long long tot, int geco, int b_global, int n_pix, const double* state, const double* x,
                               const double* xhat, double* dxhat, void* stream) {
     SVGP_REQUIRE(tot >= 1 && b_global >= 1 && n_pix >= 1 && state && x && xhat && dxhat, SVGP_ERR_INVALID, "bad argument");
-    hipLaunchKernelGGL(k_sqerr_bwd, dim3(nb256(tot)), dim3(256), 0, (hipStream_t)stream, tot, geco, 1.0 / b_global,
+    hipLaunchKernelGGL(k_sqerr_bwd<double>, dim3(nb256(tot)), dim3(256), 0, (hipStream_t)stream, tot, geco, 1.0 / b_global,
+                       1.0 / n_pix, state, x, xhat, dxhat);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+// ---- float32 instantiations of the per-frame network glue (reference dtype of the SPRITES networks, VAE_utils.py:277);
+// the partial sums of the reconstruction error and the device state stay float64
+extern "C" int svgp_avgpool_fwd_f32(int n, int HW, int Cc, const float* x, float* y, void* stream) {
+    SVGP_REQUIRE(n >= 1 && HW >= 1 && Cc >= 1 && x && y, SVGP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_avgpool_fwd<float>, dim3(nb256((long long)n * Cc)), dim3(256), 0, (hipStream_t)stream, n, HW, Cc, x, y);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_avgpool_bwd_f32(int n, int HW, int Cc, const float* dy, float* dx, void* stream) {
+    SVGP_REQUIRE(n >= 1 && HW >= 1 && Cc >= 1 && dy && dx, SVGP_ERR_INVALID, "bad argument");
+    const long long tot = (long long)n * HW * Cc;
+    hipLaunchKernelGGL(k_avgpool_bwd<float>, dim3(nb256(tot)), dim3(256), 0, (hipStream_t)stream, tot, HW, Cc, dy, dx);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_bias_add_f32(long long rows, int Cc, const float* bias, float* x, void* stream) {
+    SVGP_REQUIRE(rows >= 1 && Cc >= 1 && bias && x, SVGP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_bias_add<float>, dim3(nb256(rows * Cc)), dim3(256), 0, (hipStream_t)stream, rows * Cc, Cc, bias, x);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_sqerr_fwd_f32(long long tot, int n_part, const float* x, const float* xhat, double* part_sums,
+                                  void* stream) {
+    SVGP_REQUIRE(tot >= 1 && n_part >= 1 && x && xhat && part_sums, SVGP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_sqerr_fwd<float>, dim3(n_part), dim3(256), 0, (hipStream_t)stream, tot, x, xhat, part_sums);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_sqerr_bwd_f32(long long tot, int geco, int b_global, int n_pix, const double* state, const float* x,
+                                  const float* xhat, float* dxhat, void* stream) {
+    SVGP_REQUIRE(tot >= 1 && b_global >= 1 && n_pix >= 1 && state && x && xhat && dxhat, SVGP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_sqerr_bwd<float>, dim3(nb256(tot)), dim3(256), 0, (hipStream_t)stream, tot, geco, 1.0 / b_global,
                        1.0 / n_pix, state, x, xhat, dxhat);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;

@@ -23,7 +23,7 @@ struct GemmArgs {
     int lda, ldb, ldc;
     long long sa, sb, sc;   // batch strides in elements (0 = shared)
     real alpha, beta;
-    const real* A; const real* B; real* C;
+    const void* A; const void* B; void* C;      // element type = the kernel's storage type TS
     // triangular structure (svgp_dgemm_tri_batched): bit 0 = only tiles that touch the lower triangle (j0 <= i0 + tile - 1);
     // bit 1 / bit 2 = contraction starts at the tile's first row / first column (operands that are zero for k < i / k < j);
     // bit 3 = contraction ends with the tile's last row (operand zero for k > i)
@@ -31,15 +31,36 @@ struct GemmArgs {
 };
 
 // k-panels of 16 are double-buffered in LDS: the global loads of panel p+1 are in flight while the MFMAs of
-// panel p run, one barrier per panel.  Loads are 8-byte, arranged so that 16 lanes cover 128 contiguous
+// panel p run, one barrier per panel.  Loads are arranged so that 16 lanes cover 128 (f64) / 64 (f32) contiguous
 // bytes of the operand whichever way it is stored.  WT = 4: 128 x 128 tile, 16 flop per staged byte, used
 // when that still gives >= 192 workgroups; WT = 2: 64 x 64 tile for small problems.
-template <bool TA, bool TB, int WT>
-__global__ __launch_bounds__(256, 2) void k_dgemm_batched(GemmArgs g) {
-    constexpr int HT = 32 * WT, HLD = HT + 2, NH = HT / 16;
-    extern __shared__ __align__(16) real hs[];
-    real* As = hs;                       // [2][GK][HLD]
-    real* Bs = hs + 2 * GK * HLD;        // [2][GK][HLD]
+// TS = storage type of A, B, C; TC = arithmetic type of the MFMA (operands converted while staging, accumulation in TC):
+//   <double, double>  the float64 GEMM                       v_mfma_f64_16x16x4_f64
+//   <double, float>   float64 matrices, float32 arithmetic   v_mfma_f32_16x16x4_f32 (twice the matrix rate, half the LDS)
+//   <float,  float>   the float32 GEMM
+typedef float f4_t __attribute__((ext_vector_type(4)));
+template <typename TC> struct MfmaT;
+template <> struct MfmaT<double> {
+    typedef d4_t acc_t;
+    static constexpr int PAD = 2;          // LDS row pad (elements): conflict-free 16-wide operand fetch
+    __device__ static __forceinline__ acc_t mma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int q, int e) { return q + 4 * e; }       // C/D: row = (lane >> 4) + 4 reg
+};
+template <> struct MfmaT<float> {
+    typedef f4_t acc_t;
+    static constexpr int PAD = 16;         // q rows 16 banks apart: the 32-lane ds_read_b32 group covers 32 banks
+    __device__ static __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+    __device__ static __forceinline__ int row(int q, int e) { return 4 * q + e; }       // C/D: row = 4 (lane >> 4) + reg
+};
+
+template <bool TA, bool TB, int WT, typename TS, typename TC>
+__global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
+    typedef MfmaT<TC> MF;
+    constexpr int HT = 32 * WT, HLD = HT + MF::PAD, NH = HT / 16;
+    extern __shared__ __align__(16) unsigned char hs_raw[];
+    TC* hs = reinterpret_cast<TC*>(hs_raw);
+    TC* As = hs;                         // [2][GK][HLD]
+    TC* Bs = hs + 2 * GK * HLD;          // [2][GK][HLD]
     // XCD-aware order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2);
     // remapping id -> (id % 8) * ceil(total / 8) + id / 8 gives every XCD a contiguous run of tiles, i.e. whole
     // matrices of the batch, so the operand panels a tile row / column shares are fetched into ONE L2
@@ -53,43 +74,43 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_batched(GemmArgs g) {
     if (g.tri & 2) klo = i0;
     if ((g.tri & 4) && j0 > klo) klo = j0;
     if ((g.tri & 8) && i0 + HT < khi) khi = i0 + HT;
-    const real* __restrict__ A = g.A + (size_t)l * g.sa;
-    const real* __restrict__ B = g.B + (size_t)l * g.sb;
-    real* C = g.C + (size_t)l * g.sc;
+    const TS* __restrict__ A = static_cast<const TS*>(g.A) + (size_t)l * g.sa;
+    const TS* __restrict__ B = static_cast<const TS*>(g.B) + (size_t)l * g.sb;
+    TS* C = static_cast<TS*>(g.C) + (size_t)l * g.sc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wi = (wave >> 1) * 16 * WT, wj = (wave & 1) * 16 * WT;
-    d4_t acc[WT][WT];
+    typename MF::acc_t acc[WT][WT];
 #pragma unroll
     for (int a = 0; a < WT; ++a)
 #pragma unroll
-        for (int b = 0; b < WT; ++b) acc[a][b] = d4_t{0, 0, 0, 0};
+        for (int b = 0; b < WT; ++b) acc[a][b] = typename MF::acc_t{0, 0, 0, 0};
     // staging coordinates: NH elements per operand per thread
     //   operand stored [x][k] (k contiguous): k = tid & 15, x = (tid >> 4) + 16 h
     //   operand stored [k][x] (x contiguous): x = tid % HT, k = tid / HT + (256 / HT) h
     constexpr int KS = 256 / HT;
-    real ra[NH], rb[NH];
+    TC ra[NH], rb[NH];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             if (TA) {
                 const int i = tid % HT, k = tid / HT + KS * h, gi = i0 + i, gk = k0 + k;
-                ra[h] = (gi < g.M && gk < g.K) ? A[(size_t)gk * g.lda + gi] : real(0);
+                ra[h] = (gi < g.M && gk < g.K) ? (TC)A[(size_t)gk * g.lda + gi] : TC(0);
             } else {
                 const int k = tid & 15, i = (tid >> 4) + 16 * h, gi = i0 + i, gk = k0 + k;
-                ra[h] = (gi < g.M && gk < g.K) ? A[(size_t)gi * g.lda + gk] : real(0);
+                ra[h] = (gi < g.M && gk < g.K) ? (TC)A[(size_t)gi * g.lda + gk] : TC(0);
             }
             if (TB) {
                 const int k = tid & 15, j = (tid >> 4) + 16 * h, gj = j0 + j, gk = k0 + k;
-                rb[h] = (gj < g.N && gk < g.K) ? B[(size_t)gj * g.ldb + gk] : real(0);
+                rb[h] = (gj < g.N && gk < g.K) ? (TC)B[(size_t)gj * g.ldb + gk] : TC(0);
             } else {
                 const int j = tid % HT, k = tid / HT + KS * h, gj = j0 + j, gk = k0 + k;
-                rb[h] = (gj < g.N && gk < g.K) ? B[(size_t)gk * g.ldb + gj] : real(0);
+                rb[h] = (gj < g.N && gk < g.K) ? (TC)B[(size_t)gk * g.ldb + gj] : TC(0);
             }
         }
     };
     auto stage = [&](int buf) {
-        real* Ad = As + buf * GK * HLD;
-        real* Bd = Bs + buf * GK * HLD;
+        TC* Ad = As + buf * GK * HLD;
+        TC* Bd = Bs + buf * GK * HLD;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             if (TA) Ad[(tid / HT + KS * h) * HLD + tid % HT] = ra[h];
@@ -105,11 +126,11 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_batched(GemmArgs g) {
     for (int k0 = klo; k0 < khi; k0 += GK) {
         const bool more = k0 + GK < khi;
         if (more) fetch(k0 + GK);
-        const real* Ab = As + cur * GK * HLD + wi + r;
-        const real* Bb = Bs + cur * GK * HLD + wj + r;
+        const TC* Ab = As + cur * GK * HLD + wi + r;
+        const TC* Bb = Bs + cur * GK * HLD + wj + r;
 #pragma unroll
         for (int kk = 0; kk < GK; kk += 4) {
-            real av[WT], bv[WT];
+            TC av[WT], bv[WT];
 #pragma unroll
             for (int a = 0; a < WT; ++a) av[a] = Ab[(kk + q) * HLD + 16 * a];
 #pragma unroll
@@ -117,8 +138,7 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_batched(GemmArgs g) {
 #pragma unroll
             for (int a = 0; a < WT; ++a)
 #pragma unroll
-                for (int b = 0; b < WT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < WT; ++b) acc[a][b] = MF::mma(av[a], bv[b], acc[a][b]);
         }
         if (more) stage(cur ^ 1);
         __syncthreads();
@@ -131,10 +151,10 @@ __global__ __launch_bounds__(256, 2) void k_dgemm_batched(GemmArgs g) {
         for (int b = 0; b < WT; ++b)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int gi = i0 + wi + a * 16 + q + 4 * e, gj = j0 + wj + b * 16 + r;
+                const int gi = i0 + wi + a * 16 + MF::row(q, e), gj = j0 + wj + b * 16 + r;
                 if (gi < g.M && gj < g.N) {
                     const size_t o = (size_t)gi * g.ldc + gj;
-                    C[o] = g.alpha * acc[a][b][e] + (has_beta ? g.beta * C[o] : real(0));
+                    C[o] = (TS)(g.alpha * (real)acc[a][b][e] + (has_beta ? g.beta * (real)C[o] : real(0)));
                 }
             }
 }
@@ -367,6 +387,17 @@ __global__ __launch_bounds__(256) void k_bgjf_pivot0(BgjfArgs g) {
     __syncthreads();
     gj32_sweep(P, g.Pinv + (size_t)l * NB * NB, nullptr, l < g.nmain ? g.logdet + l : g.logdet_e + (l - g.nmain), true);
 }
+// 32 x 32 product on the f64 MFMA: wave w of the 4 owns the 16 x 16 quadrant (w >> 1, w & 1); lane (r = lane & 15,
+// q = lane >> 4) receives elements (row 16 (w >> 1) + q + 4 e, column 16 (w & 1) + r), e = 0..3.  A tenth of the LDS
+// traffic of the VALU form mm32 (which is LDS-bound: 5 reads per 4 FMAs).
+__device__ __forceinline__ d4_t mm32_mfma(const real (*X)[NB + 1], const real (*Y)[NB + 1]) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    const int wi = 16 * (w >> 1), wj = 16 * (w & 1);
+    d4_t acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int k0 = 0; k0 < NB; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[wi + r][k0 + q], Y[k0 + q][wj + r], acc, 0, 0, 0);
+    return acc;
+}
 // grid (nb, nb, batch): tile (bi = y, bj = x) of block step kb
 __global__ __launch_bounds__(256) void k_bgjf_step(BgjfArgs g) {
     __shared__ real Pv[NB][NB + 1];
@@ -377,41 +408,48 @@ __global__ __launch_bounds__(256) void k_bgjf_step(BgjfArgs g) {
     const real* X = (l < g.nmain ? g.X : g.Xe) + mo;
     real* Y = (l < g.nmain ? g.Y : g.Ye) + mo;
     const real* Pinv = g.Pinv + ((size_t)(kb & 1) * g.batch + l) * NB * NB;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    const int ti = 16 * (w >> 1) + q, tj = 16 * (w & 1) + r;      // this thread's elements: rows ti + 4 e, column tj
+    real xo[4];                                                    // the tile's own old values, in flight under the products
+    if (bi != kb && bj != kb) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xo[e] = bgjf_get(X, m, bi, bj, ti + 4 * e, tj, false);
+    }
     for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) {
-        const int r = t / NB, c = t % NB;
-        Pv[r][c] = Pinv[t];
-        Rk[r][c] = bgjf_get(X, m, kb, bj, r, c, false);
-        Ck[r][c] = bi == kb ? real(0) : bgjf_get(X, m, bi, kb, r, c, false);
+        const int rr = t / NB, c = t % NB;
+        Pv[rr][c] = Pinv[t];
+        Rk[rr][c] = bj == kb ? Pinv[t] : bgjf_get(X, m, kb, bj, rr, c, false);
+        Ck[rr][c] = bi == kb ? real(0) : bgjf_get(X, m, bi, kb, rr, c, false);
     }
     __syncthreads();
-    const int i = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
-    real out[4];
+    d4_t out;
     if (bj == kb) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) out[e] = Pv[i][c0 + e];
+        for (int e = 0; e < 4; ++e) out[e] = Pv[ti + 4 * e][tj];
     } else {
-        mm32(Pv, Rk, out);                               // scaled pivot row block P^-1 X[kb][bj]
+        out = mm32_mfma(Pv, Rk);                         // scaled pivot row block P^-1 X[kb][bj]
     }
     if (bi == kb) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int gi = kb * NB + i, gj = bj * NB + c0 + e;
+            const int gi = kb * NB + ti + 4 * e, gj = bj * NB + tj;
             if (gi < m && gj < m) Y[(size_t)gi * m + gj] = out[e];
         }
         return;
     }
-    __syncthreads();
+    if (bj != kb) {                                      // (for bj == kb Rk already holds P^-1)
+        __syncthreads();
 #pragma unroll
-    for (int e = 0; e < 4; ++e) Rk[i][c0 + e] = out[e];
-    __syncthreads();
-    mm32(Ck, Rk, out);                                   // old column block times the scaled pivot row block
+        for (int e = 0; e < 4; ++e) Rk[ti + 4 * e][tj] = out[e];
+        __syncthreads();
+    }
+    out = mm32_mfma(Ck, Rk);                             // old column block times the scaled pivot row block
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const int gi = bi * NB + i, gj = bj * NB + c0 + e;
+        const int gi = bi * NB + ti + 4 * e, gj = bj * NB + tj;
         if (gi < m && gj < m) {
-            const size_t o = (size_t)gi * m + gj;
-            out[e] = (bj == kb) ? -out[e] : X[o] - out[e];
-            Y[o] = out[e];
+            out[e] = (bj == kb) ? -out[e] : xo[e] - out[e];
+            Y[(size_t)gi * m + gj] = out[e];
         } else {
             out[e] = (gi - bi * NB == gj - bj * NB) ? real(1) : real(0);     // identity pad (read below when pivot)
         }
@@ -420,7 +458,7 @@ __global__ __launch_bounds__(256) void k_bgjf_step(BgjfArgs g) {
     if (bi == kb + 1 && bj == kb + 1 && (kb + 1) * NB < m) {
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) Pv[i][c0 + e] = out[e];
+        for (int e = 0; e < 4; ++e) Pv[ti + 4 * e][tj] = out[e];
         __syncthreads();
         gj32_sweep(Pv, g.Pinv + ((size_t)((kb + 1) & 1) * g.batch + l) * NB * NB, nullptr,
                    l < g.nmain ? g.logdet + l : g.logdet_e + (l - g.nmain), false);
@@ -551,18 +589,10 @@ __global__ __launch_bounds__(NO) void k_bgj2_writeback(Bgj2Args g) {
 
 }  // namespace
 
-extern "C" int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
-                                  long long strideA, const double* B, int ldb, long long strideB, double beta,
-                                  double* C, int ldc, long long strideC, int batch, void* stream) {
-    return svgp_dgemm_tri_batched(0, ta, tb, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch,
-                                  stream);
-}
-
-// the same GEMM with triangular structure hints (see GemmArgs::tri); tiles / k-panels that the hints exclude are
-// skipped, everything else is computed as usual (excluded operand parts must hold zeros where a tile straddles them)
-int svgp_dgemm_tri_batched(int tri, int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
-                           long long strideA, const double* B, int ldb, long long strideB, double beta, double* C, int ldc,
-                           long long strideC, int batch, void* stream) {
+// prec 0: float64 storage + arithmetic; 1: float64 storage, float32 MFMA arithmetic; 2: float32 storage + arithmetic
+static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, double alpha, const void* A, int lda,
+                       long long strideA, const void* B, int ldb, long long strideB, double beta, void* C, int ldc,
+                       long long strideC, int batch, void* stream) {
     SVGP_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, SVGP_ERR_INVALID, "negative dimension");
     if (M == 0 || N == 0 || batch == 0) return SVGP_OK;
     SVGP_REQUIRE(A && B && C, SVGP_ERR_INVALID, "NULL device pointer");
@@ -579,33 +609,66 @@ int svgp_dgemm_tri_batched(int tri, int ta, int tb, int M, int N, int K, double 
     // fewer than one 64 x 64 tile per CU: 32 x 32 tiles (4x the workgroups; 256^3 batch 1: 18.3 -> 9.0 us)
     const long long blocks64 = (long long)((N + 63) / 64) * ((M + 63) / 64) * batch;
     const int wt = (blocks128 >= 192 && cost4 <= cost2) ? 4 : (blocks64 < 256 ? 1 : 2), ht = 32 * wt;
-    const size_t lds = (size_t)4 * GK * (ht + 2) * sizeof(real);
+    const size_t lds = prec == 0 ? (size_t)4 * GK * (ht + 2) * sizeof(double) : (size_t)4 * GK * (ht + 16) * sizeof(float);
     g.tiles_n = (N + ht - 1) / ht; g.tiles_m = (M + ht - 1) / ht; g.batch = batch;
     g.xcd_remap = 1;     // measured neutral (+-1 %) at 800^3 x 64 and 2048^3 x 16: the Infinity Cache already absorbs the
                          // cross-XCD panel re-fetches; kept because it never hurts and is the layout the hardware deals
     const long long total = (long long)g.tiles_n * g.tiles_m * batch;
     SVGP_REQUIRE(total < (1LL << 30), SVGP_ERR_UNSUPPORTED, "GEMM grid too large");
     const dim3 grid((unsigned)(g.xcd_remap ? (total + 7) / 8 * 8 : total));
-#define LAUNCH_G(TA_, TB_, WT_)                                                                              \
-    do {                                                                                                     \
-        SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_dgemm_batched<TA_, TB_, WT_>),     \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));           \
-        hipLaunchKernelGGL((k_dgemm_batched<TA_, TB_, WT_>), grid, dim3(256), lds, (hipStream_t)stream, g);   \
+#define LAUNCH_G(TA_, TB_, WT_, TS_, TC_)                                                                            \
+    do {                                                                                                             \
+        SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_batched<TA_, TB_, WT_, TS_, TC_>),    \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+        hipLaunchKernelGGL((k_gemm_batched<TA_, TB_, WT_, TS_, TC_>), grid, dim3(256), lds, (hipStream_t)stream, g);  \
     } while (0)
-#define LAUNCH_T(WT_)                                \
-    do {                                             \
-        if (ta && tb) LAUNCH_G(true, true, WT_);     \
-        else if (ta) LAUNCH_G(true, false, WT_);     \
-        else if (tb) LAUNCH_G(false, true, WT_);     \
-        else LAUNCH_G(false, false, WT_);            \
+#define LAUNCH_T(WT_, TS_, TC_)                                \
+    do {                                                       \
+        if (ta && tb) LAUNCH_G(true, true, WT_, TS_, TC_);     \
+        else if (ta) LAUNCH_G(true, false, WT_, TS_, TC_);     \
+        else if (tb) LAUNCH_G(false, true, WT_, TS_, TC_);     \
+        else LAUNCH_G(false, false, WT_, TS_, TC_);            \
     } while (0)
-    if (wt == 4) LAUNCH_T(4);
-    else if (wt == 1) LAUNCH_T(1);
-    else LAUNCH_T(2);
+#define LAUNCH_P(TS_, TC_)                    \
+    do {                                      \
+        if (wt == 4) LAUNCH_T(4, TS_, TC_);   \
+        else if (wt == 1) LAUNCH_T(1, TS_, TC_); \
+        else LAUNCH_T(2, TS_, TC_);           \
+    } while (0)
+    if (prec == 0) LAUNCH_P(double, double);
+    else if (prec == 1) LAUNCH_P(double, float);
+    else LAUNCH_P(float, float);
+#undef LAUNCH_P
 #undef LAUNCH_T
 #undef LAUNCH_G
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
+}
+
+extern "C" int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
+                                  long long strideA, const double* B, int ldb, long long strideB, double beta,
+                                  double* C, int ldc, long long strideC, int batch, void* stream) {
+    return gemm_launch(0, 0, ta, tb, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, stream);
+}
+// float64 matrices, products and sums on the float32 MFMA (operands rounded to float32 while staged, float32
+// accumulation): the arithmetic of the reference's float32 SPRITES graph on float64 storage
+extern "C" int svgp_dgemm_f32c_batched(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
+                                       long long strideA, const double* B, int ldb, long long strideB, double beta,
+                                       double* C, int ldc, long long strideC, int batch, void* stream) {
+    return gemm_launch(1, 0, ta, tb, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, stream);
+}
+extern "C" int svgp_sgemm_batched(int ta, int tb, int M, int N, int K, float alpha, const float* A, int lda,
+                                  long long strideA, const float* B, int ldb, long long strideB, float beta, float* C,
+                                  int ldc, long long strideC, int batch, void* stream) {
+    return gemm_launch(2, 0, ta, tb, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, stream);
+}
+
+// the float64 GEMM with triangular structure hints (see GemmArgs::tri); tiles / k-panels that the hints exclude are
+// skipped, everything else is computed as usual (excluded operand parts must hold zeros where a tile straddles them)
+int svgp_dgemm_tri_batched(int tri, int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
+                           long long strideA, const double* B, int ldb, long long strideB, double beta, double* C, int ldc,
+                           long long strideC, int batch, void* stream) {
+    return gemm_launch(0, tri, ta, tb, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, stream);
 }
 
 // ---- split-K form for one GEMM with few output tiles and a long contraction (the dense layers of the moving-ball
@@ -668,7 +731,18 @@ extern "C" int svgp_dgemm_splitk(int ta, int tb, int M, int N, int K, double alp
 
 static size_t inv_ws_inner(int nrows, int batch) { return (size_t)batch * (2 * NB * NB + (size_t)nrows * NB); }
 
+extern "C" size_t svgp_potrf_workspace_elems(int m, int batch);
+extern "C" size_t svgp_potri_workspace_elems(int m, int batch);
+extern "C" int svgp_potrf_batched(int m, int batch, double* A, int lda, long long strideA, double* logdet, double* work,
+                                  void* stream);
+extern "C" int svgp_potri_batched(int m, int batch, double* A, const double* linv_blocks, double* work, void* stream);
+// From here on the inverse is formed from the Cholesky factor (cholesky.hip): half the flops of the elimination (m^3
+// against 2 m^3), nearly all of them in MFMA GEMMs.  Measured (tools/inverse_probe.py, float64, us): m = 512 x 16:
+// two-level Gauss-Jordan 889 / potrf + potri 1271;  800 x 65: 5981 / 3655;  2048 x 17: 18029 / 12386.
+#define CHOL_INVERSE_MIN_M 640
+
 extern "C" size_t svgp_spd_inverse_workspace_elems(int m, int batch) {
+    if (m >= CHOL_INVERSE_MIN_M) return svgp_potrf_workspace_elems(m, batch) + svgp_potri_workspace_elems(m, batch);
     if (m < TWO_LEVEL_MIN_M) return (size_t)batch * (2 * NB * NB + (size_t)m * m);     // pivots + the ping-pong copy
     // R, V, T, C panels + the captured pivot inverses of the outer level + the 32-block workspace of the panel
     return (size_t)batch * (4 * (size_t)m * NO + 4 * NB * NB) + inv_ws_inner(NO, batch);
@@ -733,6 +807,11 @@ extern "C" int svgp_spd_inverse_batched(int m, int batch, double* A, double* log
     if (batch == 0) return SVGP_OK;
     SVGP_REQUIRE(A && logdet && work, SVGP_ERR_INVALID, "NULL device pointer");
     if (m < TWO_LEVEL_MIN_M) return svgp_spd_inverse_fused(m, batch, A, logdet, 0, nullptr, nullptr, work, stream);
+    if (m >= CHOL_INVERSE_MIN_M) {
+        int rc = svgp_potrf_batched(m, batch, A, m, (long long)m * m, logdet, work, stream);
+        if (rc) return rc;
+        return svgp_potri_batched(m, batch, A, work, work + svgp_potrf_workspace_elems(m, batch), stream);
+    }
     Bgj2Args g;
     g.m = m; g.A = A; g.R = work;
     g.V = g.R + (size_t)batch * NO * m;

@@ -14,7 +14,12 @@ and `SpritesStepEngine.train_step` = the reference's `sess.run([optim_step_joint
 Every per-pixel / per-row / per-matrix operation is a HIP kernel: tap-table MFMA convolutions
 (conv_taps.hip), batched MFMA GEMMs for the dense layers (linalg.hip), the product-kernel matrices and
 their VJP (gp_sprites.hip), the sparse-GP stages (gp_kernels.hip / gp_large.hip for m > 64), TF1 Adam.
-The reference runs SPRITES in float32; this build computes in float64 (a superset precision).
+Precision.  The reference runs SPRITES in float32 end to end (VAE_utils.py:277, SVGPVAE_model.py:516).
+SpritesStepEngine(net_dtype=torch.float64, gemm_f32=0) computes everything in float64 (a superset).  With
+net_dtype=torch.float32 the three networks run in float32 (activations, weights cast from the float64 master copy each
+step, gradients cast back; tap-table convolutions and dense layers on v_mfma_f32_16x16x4_f32); gemm_f32=1 additionally
+runs every product of the large-m GP block on the float32 MFMA (float64 storage), gemm_f32=2 only the statistics
+products.  The m x m factorisations / inverses, the scalar epilogue, Adam and the master parameters stay float64.
 """
 import ctypes as C
 import math
@@ -106,7 +111,7 @@ class SpritesStepEngine:
 
     def __init__(self, vae, repr_nn, svgp, *, b_max, seg_len=50, clip_qs=False, geco=False, kappa_squared=0.0075,
                  alpha=0.99, beta=0.001, lr=1e-3, clip_grad=None, device="cuda:0", params=None, rank=0, world_size=1,
-                 comm=None):
+                 comm=None, net_dtype=torch.float64, gemm_f32=0):
         self.lib = _lib.load_library()
         if not torch.cuda.is_available():
             raise _lib.SvgpError("SpritesStepEngine needs a HIP device; there is no CPU execution path")
@@ -120,6 +125,11 @@ class SpritesStepEngine:
         self.rank, self.world_size, self.comm = rank, world_size, comm
         self.stream = torch.cuda.Stream(device=self.dev)
         f64 = dict(dtype=_F64, device=self.dev)
+        assert net_dtype in (torch.float64, torch.float32) and gemm_f32 in (0, 1, 2)
+        self.ndt, self.f32 = net_dtype, net_dtype == torch.float32
+        self.sfx = "_f32" if self.f32 else ""
+        self.dtype_name = ("f32 networks" if self.f32 else "f64 networks") + \
+            {0: " + f64 GP block", 1: " + f32-MFMA GP products (f64 factorisations)", 2: " + f32-MFMA GP statistics"}[gemm_f32]
         # ---- flat parameter vector: networks, inducing points, GPLVM table, SE hyper-parameters
         self.shapes = dict(sprites_param_shapes(self.L, self.Lc))
         self.shapes.update(inducing_index_points=(self.m, self.La + self.Lc), GPLVM_action=(self.n_act, self.La), se=(4,))
@@ -127,10 +137,18 @@ class SpritesStepEngine:
         self.theta, self.grad = torch.zeros(n_tot, **f64), torch.zeros(n_tot, **f64)
         self.adam_m, self.adam_v = torch.zeros(n_tot, **f64), torch.zeros(n_tot, **f64)
         self.params, self.grads, off = {}, {}, 0
+        self.n_net = sum(int(np.prod(s)) for _, s in sprites_param_shapes(self.L, self.Lc))   # networks = vector prefix
+        # networks' view of the parameters / gradients: the float64 vectors themselves, or float32 copies
+        self.theta_n = torch.zeros(self.n_net, dtype=self.ndt, device=self.dev) if self.f32 else self.theta
+        self.grad_n = torch.zeros(self.n_net, dtype=self.ndt, device=self.dev) if self.f32 else self.grad
+        self.np_, self.ng = {}, {}
         for k, s in self.shapes.items():
             n = int(np.prod(s))
             self.params[k] = self.theta[off:off + n].view(s)
             self.grads[k] = self.grad[off:off + n].view(s)
+            if off < self.n_net:
+                self.np_[k] = self.theta_n[off:off + n].view(s)
+                self.ng[k] = self.grad_n[off:off + n].view(s)
             off += n
         init = glorot_uniform_params(self.L, self.Lc, vae.seed) if params is None else params
         init = dict(init)
@@ -150,7 +168,8 @@ class SpritesStepEngine:
                          train_ip=1, train_gp=1, train_ov=0, b_cap=b_max, clip_pv=1, n_pix=64 * 64 * 3,
                          titsias=int(svgp.titsias),
                          N_train=svgp.N_train, jitter=svgp.jitter, kappa_squared=float(kappa_squared),
-                         alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0, single_stat_block=int(world_size > 1))
+                         alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0, single_stat_block=int(world_size > 1),
+                         gemm_f32=int(gemm_f32))
         self.cfg = MnistCfg(b=b_max, b_global=b_max, **self.base)
         self.wl = WsLayout()
         call("svgp_mnist_ws_layout_get", C.byref(self.cfg), C.byref(self.wl))
@@ -164,13 +183,15 @@ class SpritesStepEngine:
         with torch.cuda.stream(self.stream):
             self.state.copy_(st)
         # ---- layers
-        self.enc = [ConvLayer(h, ci, 16, 3, s, "same") for h, ci, s in
+        self.enc = [ConvLayer(h, ci, 16, 3, s, "same", dtype=self.ndt) for h, ci, s in
                     zip((64, 64, 32, 32, 16, 16), (3, 16, 16, 16, 16, 16), ENC_STRIDES)]
         dec_h = (8, 16, 16, 32, 32, 64, 64)
-        self.dec = [ConvLayer(h, 16, 16 if i < 6 else 3, 3, 1, "same", up=u) for i, (h, u) in enumerate(zip(dec_h, DEC_UP))]
-        self.rep = [ConvLayer(h, ci, self.Lc, 2, 2, "same") for h, ci in zip((64, 32, 16), (3, self.Lc, self.Lc))]
+        self.dec = [ConvLayer(h, 16, 16 if i < 6 else 3, 3, 1, "same", up=u, dtype=self.ndt)
+                    for i, (h, u) in enumerate(zip(dec_h, DEC_UP))]
+        self.rep = [ConvLayer(h, ci, self.Lc, 2, 2, "same", dtype=self.ndt) for h, ci in zip((64, 32, 16), (3, self.Lc, self.Lc))]
         self.nwg = 512        # workgroups of the weight-gradient launches (2 per CU)
-        self.scratch = torch.zeros(max(l.scratch_elems(self.nwg) for l in self.enc + self.dec + self.rep), **f64)
+        self.scratch = torch.zeros(max(l.scratch_elems(self.nwg) for l in self.enc + self.dec + self.rep),
+                                   dtype=self.ndt, device=self.dev)
         self.kscratch = torch.zeros(b_max * self.La + (self.m + b_max) * 4 + 16, **f64)
         self.stream.synchronize()
         self.act = {}
@@ -189,8 +210,14 @@ class SpritesStepEngine:
         return self.ws[off:off + int(np.prod(shape))].view(shape)
 
     def _gemm(self, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, Cm, ldc):
-        call("svgp_dgemm_batched", ta, tb, M, N, K, float(alpha), A.data_ptr(), lda, 0, B.data_ptr(), ldb, 0, float(beta),
-             Cm.data_ptr(), ldc, 0, 1, self.stream.cuda_stream)
+        assert A.dtype == B.dtype == Cm.dtype
+        call("svgp_sgemm_batched" if A.dtype == torch.float32 else "svgp_dgemm_batched", ta, tb, M, N, K, float(alpha),
+             A.data_ptr(), lda, 0, B.data_ptr(), ldb, 0, float(beta), Cm.data_ptr(), ldc, 0, 1, self.stream.cuda_stream)
+
+    def _sync_net_params(self):
+        """float32 networks: refresh the float32 copy of the network weights from the float64 master vector."""
+        if self.f32:
+            self.theta_n.copy_(self.theta[:self.n_net])
 
     def scalars(self):
         self.stream.synchronize()
@@ -209,43 +236,45 @@ class SpritesStepEngine:
     # ------------------------------------------------------------------ forward pieces (run inside self.stream)
     def _encoder_forward(self, images, b):
         """spritesVAE.encode (VAE_utils.py:294-315,343-349): 6 convs, Dense(2L), exp / clip head."""
-        p, s, L = self.params, self.stream.cuda_stream, self.L
-        f64 = dict(dtype=_F64, device=self.dev)
+        p, s, L = self.np_, self.stream.cuda_stream, self.L
+        nd = dict(dtype=self.ndt, device=self.dev)
         a, x = [], images
         for i, lay in enumerate(self.enc, 1):
-            out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
+            out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **nd)
             lay.forward(x, p[f"enc_c{i}_w"], p[f"enc_c{i}_b"], out, s)
             a.append(out); x = out
-        enc = torch.empty(b, 2 * L, **f64)
+        enc = torch.empty(b, 2 * L, **nd)
         self._gemm(0, 0, b, 2 * L, 1024, 1.0, x, 1024, p["enc_d_w"], 2 * L, 0.0, enc, 2 * L)
+        enc = enc.double() if self.f32 else enc               # the head (bias, exp, clip) and the GP block are float64
         mu, var_raw, var = self._v("qnet_mu", (b, L)), self._v("qnet_var_raw", (b, L)), self._v("qnet_var", (b, L))
-        call("svgp_enc_head_fwd", b, L, int(self.clip_qs), p["enc_d_b"].data_ptr(), enc.data_ptr(), mu.data_ptr(),
+        call("svgp_enc_head_fwd", b, L, int(self.clip_qs), self.params["enc_d_b"].data_ptr(), enc.data_ptr(), mu.data_ptr(),
              var_raw.data_ptr(), var.data_ptr(), s)
         return a, enc, mu, var_raw, var
 
     def _repr_forward(self, images, b):
         """sprites_representation_network (VAE_utils.py:375-391): per-frame character vectors (b, L_character)."""
-        p, s = self.params, self.stream.cuda_stream
-        f64 = dict(dtype=_F64, device=self.dev)
+        p, s = self.np_, self.stream.cuda_stream
+        nd = dict(dtype=self.ndt, device=self.dev)
         r, x = [], images
         for i, lay in enumerate(self.rep, 1):
-            out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
+            out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **nd)
             lay.forward(x, p[f"repr_c{i}_w"], p[f"repr_c{i}_b"], out, s)
             r.append(out); x = out
-        rvec = torch.empty(b, self.Lc, **f64)
-        call("svgp_avgpool_fwd", b, 64, self.Lc, x.data_ptr(), rvec.data_ptr(), s)
-        return r, rvec
+        rvec = torch.empty(b, self.Lc, **nd)
+        call("svgp_avgpool_fwd" + self.sfx, b, 64, self.Lc, x.data_ptr(), rvec.data_ptr(), s)
+        return r, (rvec.double() if self.f32 else rvec)
 
     def _decoder_forward(self, z, b):
         """spritesVAE.decode (VAE_utils.py:317-338,352-360): Dense(1024) -> (8,8,16) -> 7 (up)convs."""
-        p, s, L = self.params, self.stream.cuda_stream, self.L
-        f64 = dict(dtype=_F64, device=self.dev)
-        h0 = torch.empty(b, 1024, **f64)
+        p, s, L = self.np_, self.stream.cuda_stream, self.L
+        nd = dict(dtype=self.ndt, device=self.dev)
+        z = z.to(self.ndt)
+        h0 = torch.empty(b, 1024, **nd)
         self._gemm(0, 0, b, 1024, L, 1.0, z, L, p["dec_d_w"], 1024, 0.0, h0, 1024)
-        call("svgp_bias_add", b, 1024, p["dec_d_b"].data_ptr(), h0.data_ptr(), s)
+        call("svgp_bias_add" + self.sfx, b, 1024, p["dec_d_b"].data_ptr(), h0.data_ptr(), s)
         d, x = [], h0.view(b, 8, 8, 16)
         for i, lay in enumerate(self.dec, 1):
-            out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
+            out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **nd)
             lay.forward(x, p[f"dec_c{i}_w"], p[f"dec_c{i}_b"], out, s)
             d.append(out); x = out
         return h0, d
@@ -260,8 +289,9 @@ class SpritesStepEngine:
         mu_o, var_o = torch.empty(n, self.L, dtype=_F64, device=self.dev), torch.empty(n, self.L, dtype=_F64, device=self.dev)
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.stream):
+            self._sync_net_params()
             for lo, hi in self._chunks(n):
-                _, _, mu, _, var = self._encoder_forward(images[lo:hi].contiguous(), hi - lo)
+                _, _, mu, _, var = self._encoder_forward(images[lo:hi].to(self.ndt).contiguous(), hi - lo)
                 mu_o[lo:hi].copy_(mu); var_o[lo:hi].copy_(var)
         self.stream.synchronize()
         return mu_o, var_o
@@ -272,8 +302,9 @@ class SpritesStepEngine:
         out = torch.empty(n, self.Lc, dtype=_F64, device=self.dev)
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.stream):
+            self._sync_net_params()
             for lo, hi in self._chunks(n):
-                out[lo:hi].copy_(self._repr_forward(images[lo:hi].contiguous(), hi - lo)[1])
+                out[lo:hi].copy_(self._repr_forward(images[lo:hi].to(self.ndt).contiguous(), hi - lo)[1])
         self.stream.synchronize()
         return out
 
@@ -283,6 +314,7 @@ class SpritesStepEngine:
         out = torch.empty(n, 64, 64, 3, dtype=_F64, device=self.dev)
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.stream):
+            self._sync_net_params()
             for lo, hi in self._chunks(n):
                 out[lo:hi].copy_(self._decoder_forward(z[lo:hi].contiguous(), hi - lo)[1][-1])
         self.stream.synchronize()
@@ -326,6 +358,8 @@ class SpritesStepEngine:
         assert b <= self.b_max and b % self.seg_len == 0
         b_global = b * self.world_size if b_global is None else b_global
         p, g, s, L = self.params, self.grads, self.stream.cuda_stream, self.L
+        pn, gn, sfx = self.np_, self.ng, self.sfx            # the networks' (possibly float32) parameters / gradients
+        nd = dict(dtype=self.ndt, device=self.dev)
         cfg = MnistCfg(b=b, b_global=b_global, **self.base)
         self.cfg = cfg
         cp = C.byref(cfg)
@@ -333,7 +367,8 @@ class SpritesStepEngine:
         f64 = dict(dtype=_F64, device=self.dev)
         self.stream.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(self.stream):
-            images = images.contiguous()
+            images = images.to(self.ndt).contiguous()
+            self._sync_net_params()
             self._mark("nets_fwd_enc")
             a, enc, mu, var_raw, var = self._encoder_forward(images, b)
             r, rvec = self._repr_forward(images, b)
@@ -365,23 +400,29 @@ class SpritesStepEngine:
             x = d[-1]
             recon = x
             tot = b * 64 * 64 * 3
-            call("svgp_sqerr_fwd", tot, min(b, 256), images.data_ptr(), recon.data_ptr(),
+            call("svgp_sqerr_fwd" + sfx, tot, min(b, 256), images.data_ptr(), recon.data_ptr(),
                  self._v("part_sums", (1,)).data_ptr(), s)
             # ================ reverse
             self._mark("nets_bwd_dec")
             dx = torch.empty_like(recon)
-            call("svgp_sqerr_bwd", tot, int(self.geco), b_global, 64 * 64 * 3, st, images.data_ptr(), recon.data_ptr(),
+            call("svgp_sqerr_bwd" + sfx, tot, int(self.geco), b_global, 64 * 64 * 3, st, images.data_ptr(), recon.data_ptr(),
                  dx.data_ptr(), s)
             for i in range(7, 0, -1):
                 lay = self.dec[i - 1]
                 xin = d[i - 2] if i > 1 else h0.view(b, 8, 8, 16)
-                dx = lay.backward(xin, p[f"dec_c{i}_w"], d[i - 1], dx, g[f"dec_c{i}_w"], g[f"dec_c{i}_b"], self.scratch,
+                dx = lay.backward(xin, pn[f"dec_c{i}_w"], d[i - 1], dx, gn[f"dec_c{i}_w"], gn[f"dec_c{i}_b"], self.scratch,
                                   s, nwg=self.nwg)
             dh0 = dx.view(b, 1024)
-            self._gemm(1, 0, L, 1024, b, 1.0, z, L, dh0, 1024, 0.0, g["dec_d_w"], 1024)
-            g["dec_d_b"].copy_(dh0.sum(0))          # column sum of a (b,1024) matrix: O(b*1024) glue
+            zn = z.to(self.ndt)
+            self._gemm(1, 0, L, 1024, b, 1.0, zn, L, dh0, 1024, 0.0, gn["dec_d_w"], 1024)
+            gn["dec_d_b"].copy_(dh0.sum(0))          # column sum of a (b,1024) matrix: O(b*1024) glue
             zbar = self._v("zbar", (b, L))
-            self._gemm(0, 1, b, L, 1024, 1.0, dh0, 1024, p["dec_d_w"], 1024, 0.0, zbar, L)
+            if self.f32:
+                zb = torch.empty(b, L, **nd)
+                self._gemm(0, 1, b, L, 1024, 1.0, dh0, 1024, pn["dec_d_w"], 1024, 0.0, zb, L)
+                zbar.copy_(zb)
+            else:
+                self._gemm(0, 1, b, L, 1024, 1.0, dh0, 1024, pn["dec_d_w"], 1024, 0.0, zbar, L)
             self._mark("gp_bwd_stats")
             call("svgp_gp_stats_bwd", cp, ws, st, s)
         yield [self.ws[self.wl.statB:self.wl.statB + self.wl.statB_len]]
@@ -400,24 +441,28 @@ class SpritesStepEngine:
             self._mark("nets_bwd_enc")
             d_rvec = torch.empty(b, self.Lc, **f64)
             call("svgp_sprites_aux_bwd", b, self.seg_len, self.Lc, d_char.data_ptr(), d_rvec.data_ptr(), s)
-            dx = torch.empty(b, 8, 8, self.Lc, **f64)
-            call("svgp_avgpool_bwd", b, 64, self.Lc, d_rvec.data_ptr(), dx.data_ptr(), s)
+            d_rvec = d_rvec.to(self.ndt)
+            dx = torch.empty(b, 8, 8, self.Lc, **nd)
+            call("svgp_avgpool_bwd" + sfx, b, 64, self.Lc, d_rvec.data_ptr(), dx.data_ptr(), s)
             for i in range(3, 0, -1):
                 xin = r[i - 2] if i > 1 else images
-                dx = self.rep[i - 1].backward(xin, p[f"repr_c{i}_w"], r[i - 1], dx, g[f"repr_c{i}_w"], g[f"repr_c{i}_b"],
+                dx = self.rep[i - 1].backward(xin, pn[f"repr_c{i}_w"], r[i - 1], dx, gn[f"repr_c{i}_w"], gn[f"repr_c{i}_b"],
                                               self.scratch, s, need_dx=i > 1, nwg=self.nwg)
             d_enc = torch.empty(b, 2 * L, **f64)
             call("svgp_enc_head_bwd", b, L, int(self.clip_qs), var_raw.data_ptr(), self._v("ybar", (1,)).data_ptr(),
                  self._v("s2bar", (1,)).data_ptr(), d_enc.data_ptr(), s)
+            d_enc = d_enc.to(self.ndt)
             a6 = a[5].view(b, 1024)
-            self._gemm(1, 0, 1024, 2 * L, b, 1.0, a6, 1024, d_enc, 2 * L, 0.0, g["enc_d_w"], 2 * L)
-            g["enc_d_b"].copy_(d_enc.sum(0))
-            dx = torch.empty(b, 8, 8, 16, **f64)
-            self._gemm(0, 1, b, 1024, 2 * L, 1.0, d_enc, 2 * L, p["enc_d_w"], 2 * L, 0.0, dx, 1024)
+            self._gemm(1, 0, 1024, 2 * L, b, 1.0, a6, 1024, d_enc, 2 * L, 0.0, gn["enc_d_w"], 2 * L)
+            gn["enc_d_b"].copy_(d_enc.sum(0))
+            dx = torch.empty(b, 8, 8, 16, **nd)
+            self._gemm(0, 1, b, 1024, 2 * L, 1.0, d_enc, 2 * L, pn["enc_d_w"], 2 * L, 0.0, dx, 1024)
             for i in range(6, 0, -1):
                 xin = a[i - 2] if i > 1 else images
-                dx = self.enc[i - 1].backward(xin, p[f"enc_c{i}_w"], a[i - 1], dx, g[f"enc_c{i}_w"], g[f"enc_c{i}_b"],
+                dx = self.enc[i - 1].backward(xin, pn[f"enc_c{i}_w"], a[i - 1], dx, gn[f"enc_c{i}_w"], gn[f"enc_c{i}_b"],
                                               self.scratch, s, need_dx=i > 1, nwg=self.nwg)
+            if self.f32:                                       # float32 network gradients -> the float64 gradient vector
+                self.grad[:self.n_net].copy_(self.grad_n)
             # frozen parameter groups (inverted flags of SPRITES_experiment.py:109-111)
             if getattr(self, "freeze_repr", False):           # --repr_nn_pretrain yes_fixed (SPRITES_experiment.py:214-216)
                 for k in g:
@@ -442,7 +487,7 @@ class SpritesStepEngine:
             else:
                 call("svgp_elbo_finalize_noadam", cp, ws, st, s)
             self._mark("end")
-            self.act = dict(recon=recon, aux=aux, enc=enc)
+            self.act = dict(recon=recon.double() if self.f32 else recon, aux=aux, enc=enc)
 
     def outputs(self):
         """The 16-tuple of forward_pass_SVGPVAE for the last step (mean_vectors slot = aux data)."""
@@ -605,6 +650,8 @@ def pretrain_repr_NN(engine, frames, char_IDs, *, nr_epochs, lr, batch_size, n_c
     K_pretrain + 1, and with `yes_joint` the m / v slots of the representation network carry over.  Both are reproduced:
     the engine's Adam step counter is advanced by the number of pre-training updates, and (carry_slots, = not
     `yes_fixed`) the repr_* slices of the moments are copied into the engine's."""
+    if engine.f32:
+        raise NotImplementedError("pretrain_repr_NN runs on a float64-network engine (net_dtype=torch.float64)")
     dev, Lc, s = engine.dev, engine.Lc, engine.stream.cuda_stream
     f64 = dict(dtype=_F64, device=dev)
     names = [k for k in engine.shapes if k.startswith("repr_")]

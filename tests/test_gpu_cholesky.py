@@ -83,7 +83,8 @@ def test_trsm_against_torch(side, trans, m, n, batch, shared):
     lib = _lib.load_library()
     A = _spd(m, 1 if shared else batch, m + n)
     Lt = torch.linalg.cholesky(A)
-    Lt = Lt + torch.triu(torch.full_like(Lt, 3.0), 1)                # garbage above the diagonal must be ignored
+    # garbage above the diagonal must be ignored; .contiguous(): torch.linalg.cholesky returns column-major batches
+    Lt = (Lt + torch.triu(torch.full_like(Lt, 3.0), 1)).contiguous()
     g = torch.Generator(device="cuda").manual_seed(n)
     B = torch.randn((batch, m, n) if side == 0 else (batch, n, m), dtype=DT, device="cuda", generator=g)
     X = B.clone()

@@ -456,11 +456,16 @@ def run_sprites(args):
     b, frames, L_, La, Lc, n_act, m = 500, 50, 64, 8, 16, 72, args.m or 800
     ip, table, img, ids, eps = sprites_problem(rank, b, L_, La, Lc, n_act, m)
     svgp = S.spritesSVGP(False, False, ip, 'main', 0.01, 50000, La, table, Lc, L_, K_obj_normalize=True)
+    f32 = args.precision == "f32"
+    # f32: the networks in float32 (the reference's dtype, VAE_utils.py:277) and the GP statistics products on the float32
+    # MFMA; the K Sigma^-1 K sandwiches and every factorisation stay float64 (gemm_f32 = 1 loses parity at m = 800:
+    # tests/test_gpu_f32.py)
     eng = S.SpritesStepEngine(S.spritesVAE(L_), S.sprites_representation_network(Lc), svgp, b_max=b, seg_len=frames,
                               geco=True, kappa_squared=0.0075, clip_grad=1e6, device=f"cuda:{local_rank}", rank=rank,
-                              world_size=world, comm=comm)
+                              world_size=world, comm=comm, net_dtype=torch.float32 if f32 else torch.float64,
+                              gemm_f32=2 if f32 else 0)
     dev = eng.dev
-    d_img, d_ids, d_eps = img.to(dev), ids.to(dev), eps.to(dev)
+    d_img, d_ids, d_eps = img.to(dev, eng.ndt), ids.to(dev), eps.to(dev)
     # parity gate (N = 1): explicit-eps step, ELBO against the oracle's efficient formulation -- inside cpu_baseline
     eng.step(d_img, d_ids, d_eps, adam=False)
     gpu_elbo = eng.scalars()["elbo"]
@@ -485,16 +490,19 @@ def run_sprites(args):
             "metric": f"SVGPVAE train steps/sec, SPRITES 64x64 (m={m}, L=64, 500 frames per GPU)",
             "value": world * args.steps / el, "unit": "steps/s (500-frame batches, whole job)", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": eng.dtype_name if hasattr(eng, "dtype_name") else "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": eng.dtype_name, "data": "synthetic",
             "repeats": args.repeats, "block_ms": [round(x * 1e3, 3) for x in blocks], "timing": "median block",
             "config": {"workload": f"BASELINE configs[3] shape: SPRITES SVGPVAE_Hensman + GPLVM, {b} frames per GPU "
                                    f"(10 characters x 50), L=64, L_action=8, L_character=16, m={m}, jitter 0.01, "
                                    f"cosine-normalised linear x linear kernel, GECO, gradient clip 1e6",
                        "global_batch": b * world, "rows_per_gpu": b, "parallelism": f"dp{world}",
                        "rccl_ranks": None if comm is None else comm.world_size,
-                       "launch": "eager stream" + ("" if comm is None else " + in-library RCCL all-reduce x3")},
+                       "exchange": None if comm is None else (
+                           "channel-sharded: reduce-scatter S,v | all-gather Sigma^-1,M2,t,u,KL | reduce-scatter A2,ud,td | "
+                           "all-gather Qm,Ssym,vbar | all-reduce gradients" if eng.chan_shard else "all-reduce x3"),
+                       "launch": "eager stream" + ("" if comm is None else " + in-library RCCL collectives")},
         }
-        peak = F64_PEAK_TFLOPS
+        peak = F64_PEAK_TFLOPS          # the dominant stage groups are the float64 GP factor stages in both precisions
         top = max(stages, key=stages.get)
         gflops = {"gp_fwd": gp / 3, "gp_bwd": 2 * gp / 3, "nets_fwd": nets / 3, "nets_bwd": 2 * nets / 3}
         grp = "gp_" + ("fwd" if "fwd" in top else "bwd") if top.startswith("gp") else \
@@ -714,6 +722,9 @@ def main():
                          "(m=256, b=1024, GPLVM dim 32); sprites800 = configs[3] shape on one GPU's share; "
                          "cfg5 = configs[4] shard (N=131072, m=2048, float32 statistics pass)")
     ap.add_argument("--m", type=int, default=None, help="sprites800 / cfg5: inducing points (default 800 / 2048)")
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
+                    help="sprites800: f64 = everything float64; f32 = float32 networks + float32-MFMA GP statistics "
+                         "(float64 sandwiches and factorisations)")
     ap.add_argument("--rows", type=int, default=None, help="cfg5: rows per GPU (default 131072)")
     ap.add_argument("--cpu-worker", choices=["cfg2", "cfg3", "sprites800", "cfg5"], default=None,
                     help="internal: run one CPU-baseline leg in this (child) process and print its JSON")

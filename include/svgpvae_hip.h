@@ -293,6 +293,18 @@ int svgp_comm_init(const void* unique_id, int nbytes, int rank, int nranks, void
 int svgp_comm_destroy(void* comm);
 int svgp_allreduce_sum_f64(void* comm, double* buf, int64_t count, void* stream);
 int svgp_allreduce_sum_f32(void* comm, float* buf, int64_t count, void* stream);   /* float32 streaming statistics */
+/* Channel-sharded exchange for large (L,m,m) blocks (SURVEY 8e "reduce-scatter over L -> factorize L/G channels per rank
+ * -> all-gather"): in-place on a buffer of nranks equal chunks, rank r owning buf[r * count, (r+1) * count).  The
+ * schedule (sprites.py / engine.ChannelShardedExchange): reduce-scatter S, v over channels | svgp_gp_factor_fwd_channels
+ * on the rank's window | all-gather Sigma_l^-1, M2, t, u, KL | ... | reduce-scatter A2, ud, td |
+ * svgp_gp_factor_bwd_channels | all-gather Qm, Ssym, vbar.  Kbar needs no exchange: each rank's window share flows
+ * through svgp_kernel_matrix_bwd (linear in Kbar) into the gradient all-reduce (cfg.rep_weight = 1 on every rank).    */
+int svgp_reduce_scatter_sum_f64(void* comm, double* buf, int64_t count_per_rank, void* stream);
+int svgp_allgather_f64(void* comm, double* buf, int64_t count_per_rank, void* stream);
+/* the factor stages restricted to the channel window [l0, l0 + nl) (m > 64): (K_mm + jI)^-1 and q_n are formed by every
+ * call; with l0 = 0, nl = L they are svgp_gp_factor_fwd / svgp_gp_factor_bwd                                            */
+int svgp_gp_factor_fwd_channels(const svgp_mnist_cfg*, int l0, int nl, double* ws, void* stream);
+int svgp_gp_factor_bwd_channels(const svgp_mnist_cfg*, int l0, int nl, double* ws, const double* state, void* stream);
 int svgp_mnist_train_step_dp(const svgp_mnist_cfg*, void* comm, double* theta, const double* images,
                              const double* aux, const double* eps, double* ws, double* state,
                              double* adam_m, double* adam_v, void* stream);

@@ -117,6 +117,10 @@ SIGNATURES = {
     "svgp_comm_destroy": [_P],
     "svgp_allreduce_sum_f64": [_P, _P, C.c_int64, _P],
     "svgp_allreduce_sum_f32": [_P, _P, C.c_int64, _P],
+    "svgp_reduce_scatter_sum_f64": [_P, _P, C.c_int64, _P],
+    "svgp_allgather_f64": [_P, _P, C.c_int64, _P],
+    "svgp_gp_factor_fwd_channels": [_CFG, C.c_int, C.c_int, _P, _P],
+    "svgp_gp_factor_bwd_channels": [_CFG, C.c_int, C.c_int, _P, _P, _P],
     "svgp_mnist_train_step_dp": [_CFG, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "svgp_dgemm_batched": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.c_int, C.c_longlong, _P,
                            C.c_int, C.c_longlong, C.c_double, _P, C.c_int, C.c_longlong, C.c_int, _P],

@@ -95,8 +95,12 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->tit_S2 = p; if (c->titsias) p += L * m * m;
     o->tit_v2 = p; if (c->titsias) p += L * m;
     o->statA_len = p - o->statA; take(0);
-    o->Ki = take(m * m); o->ldK = take(1);
-    o->Si = take(L * m * m); o->t = take(L * m); o->G = take(L * m * m); o->A = take(L * m * m);
+    // Si (L,m,m) and Ki (m,m) form ONE contiguous (L+1, m, m) block whenever that keeps Ki on a 16-element boundary
+    // (m a multiple of 4): the large-m path then inverts them as one batch
+    o->ldK = take(1);
+    o->Si = take(L * m * m + ((L * m * m) % 16 == 0 ? m * m : 0));
+    o->Ki = (L * m * m) % 16 == 0 ? o->Si + L * m * m : take(m * m);
+    o->t = take(L * m); o->G = take(L * m * m); o->A = take(L * m * m);
     o->Aji = take(L * m * m); o->mu_hat = take(L * m); o->u = take(L * m); o->M2 = take(L * m * m);
     o->KL = take(2 * L); o->q = take(b);   // [KL | kl_form 1: tr(Ki A_l A_l)]
     o->p_m = take(b * L); o->p_v = take(b * L); o->e = take(b * L); o->d = take(b * L);
@@ -108,7 +112,7 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->Kbar = take(m * m); o->fb_part = take(2 * L * m * m); o->Qm = take(L * m * m); o->vbar = take(L * m);
     o->Ssym = take(L * m * m); o->Knbar_part = take(L * b * m);
     // scratch of the large-m path (gp_large.hip)
-    o->scr_bm = take(L * b * m); o->scr_mm = take(4 * L * m * m); o->scr_vec = take(3 * L * m + 3 * L);
+    o->scr_bm = take(L * b * m); o->scr_mm = take(4 * L * m * m); o->scr_vec = take(3 * L * m + 3 * L + 16);
     o->scr_inv = take((int64_t)svgp_spd_inverse_workspace_elems((int)m, (int)L + 1)); o->scr_bl = take(2 * b * L);
     o->Knbar = take(b * m); o->knnbar = take(b); o->ybar = take(b * L); o->s2bar = take(b * L);
     o->d_on = take(b * M);

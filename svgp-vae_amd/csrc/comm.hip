@@ -21,6 +21,8 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -43,6 +45,8 @@ int rccl_get(Rccl** out) {
         SYM(CommInitRank, "ncclCommInitRank");
         SYM(CommDestroy, "ncclCommDestroy");
         SYM(AllReduce, "ncclAllReduce");
+        SYM(ReduceScatter, "ncclReduceScatter");
+        SYM(AllGather, "ncclAllGather");
         SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
         g_rccl.ok = true;
@@ -130,6 +134,32 @@ extern "C" int svgp_allreduce_sum_f32(void* comm, float* buf, int64_t count, voi
     if (rc) return rc;
     Comm* c = (Comm*)comm;
     SVGP_CHECK_RCCL(r, r->AllReduce(buf, buf, (size_t)count, ncclFloat32, ncclSum, c->comm, (hipStream_t)stream));
+    return SVGP_OK;
+}
+
+// In-place reduce-scatter / all-gather of a buffer of nranks equal chunks: rank r's chunk is buf[r * count, (r + 1) * count).
+// Channel-sharded exchange of the large statistics blocks: reduce-scatter S (L,m,m) over the channels,
+// every rank factors its L / nranks channels, all-gather of what the row stage needs.
+extern "C" int svgp_reduce_scatter_sum_f64(void* comm, double* buf, int64_t count_per_rank, void* stream) {
+    SVGP_REQUIRE(comm && buf && count_per_rank >= 0, SVGP_ERR_INVALID, "NULL communicator / buffer");
+    if (count_per_rank == 0) return SVGP_OK;
+    Rccl* r;
+    int rc = rccl_get(&r);
+    if (rc) return rc;
+    Comm* c = (Comm*)comm;
+    SVGP_CHECK_RCCL(r, r->ReduceScatter(buf, buf + (size_t)c->rank * count_per_rank, (size_t)count_per_rank, ncclFloat64, ncclSum,
+                                        c->comm, (hipStream_t)stream));
+    return SVGP_OK;
+}
+extern "C" int svgp_allgather_f64(void* comm, double* buf, int64_t count_per_rank, void* stream) {
+    SVGP_REQUIRE(comm && buf && count_per_rank >= 0, SVGP_ERR_INVALID, "NULL communicator / buffer");
+    if (count_per_rank == 0) return SVGP_OK;
+    Rccl* r;
+    int rc = rccl_get(&r);
+    if (rc) return rc;
+    Comm* c = (Comm*)comm;
+    SVGP_CHECK_RCCL(r, r->AllGather(buf + (size_t)c->rank * count_per_rank, buf, (size_t)count_per_rank, ncclFloat64, c->comm,
+                                    (hipStream_t)stream));
     return SVGP_OK;
 }
 

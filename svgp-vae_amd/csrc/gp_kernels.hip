@@ -1276,10 +1276,29 @@ extern "C" int svgp_gp_factor_fwd(const svgp_mnist_cfg* c, double* ws, void* str
 extern "C" int svgp_gp_factor_fwd_defer_aji(const svgp_mnist_cfg* c, double* ws, void* stream) {
     return factor_fwd_impl(c, ws, 1, stream);
 }
+// channel windows of the factor stages (large-m path): see svgp_big_factor_fwd
+extern "C" int svgp_gp_factor_fwd_channels(const svgp_mnist_cfg* c, int l0, int nl, double* ws, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED,
+                 "channel windows exist for the large-m path (m > %d); below it the factor stage is L small workgroups", SVGP_M_MAX);
+    SVGP_REQUIRE(l0 >= 0 && nl >= 1 && l0 + nl <= c->L, SVGP_ERR_INVALID, "channel window [%d, %d) outside 0..%d", l0, l0 + nl, c->L);
+    return svgp_big_factor_fwd(c, wl, ws, stream, l0, nl);
+}
+extern "C" int svgp_gp_factor_bwd_channels(const svgp_mnist_cfg* c, int l0, int nl, double* ws, const double* state,
+                                           void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED,
+                 "channel windows exist for the large-m path (m > %d); below it the factor stage is L small workgroups", SVGP_M_MAX);
+    SVGP_REQUIRE(l0 >= 0 && nl >= 1 && l0 + nl <= c->L, SVGP_ERR_INVALID, "channel window [%d, %d) outside 0..%d", l0, l0 + nl, c->L);
+    return svgp_big_factor_bwd(c, wl, ws, state, stream, l0, nl);
+}
+
 static int factor_fwd_impl(const svgp_mnist_cfg* c, double* ws, int defer_aji, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
-    if (c->m > SVGP_M_MAX) return svgp_big_factor_fwd(c, wl, ws, stream);
+    if (c->m > SVGP_M_MAX) return svgp_big_factor_fwd(c, wl, ws, stream, 0, c->L);
     FactArgs a;
     a.defer_aji = defer_aji; a.kl_form = c->kl_form; a.P = svgp_stat_parts(c);
     a.b = c->b; a.m = c->m; a.L = c->L; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;
@@ -1341,7 +1360,7 @@ extern "C" int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg* c, double* ws, c
 static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
-    if (c->m > SVGP_M_MAX) return svgp_big_factor_bwd(c, wl, ws, state, stream);
+    if (c->m > SVGP_M_MAX) return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L);
     FactBwdArgs a = make_fb(c, wl, ws, state);
     const int m = c->m;
     const size_t lds = mat_lds_pad(m, 4) + (size_t)(6 * m) * sizeof(real);

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_big_post_final(PostFinArgs a) {
 
 // ---- factor backward element-wise pieces (device scalars g3 = gT, gK) ----------------------------
 struct FbArgs {
-    int m, L, geco, b_global;
+    int m, L, Ltot, geco, b_global;      // L = channels of this call (loops), Ltot = channels of the model (loss seeds)
     real c, N_train;
     const real* state;
     const real* Ki; const real* Aji; const real* A; const real* S; const real* A2; const real* M2;
@@ -144,7 +144,7 @@ struct FbArgs {
     real* Sibar; real* Kb; real* Sg; real* Ssym; real* Qm;
 };
 __device__ __forceinline__ void fb_scalars(const FbArgs& a, real& g3, real& gK) {
-    const real gT = gradKL(a.geco, a.L, a.state);
+    const real gT = gradKL(a.geco, a.Ltot, a.state);
     g3 = svgp_seed_3(a.geco, gT); gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
 }
 __global__ void k_big_fb_abar(FbArgs a) {     // Abar, ubar
@@ -194,11 +194,11 @@ __global__ void k_big_fb_ssym(FbArgs a) {     // Kb += Sg ; Ssym = c (Sg + Sg^T)
     a.Ssym[i] = ss;
     a.Qm[i] = ss - g3 * a.M2[i];
 }
-__global__ void k_big_fb_final(int m, int L, int geco, int b_global, real N_train, const real* __restrict__ state,
+__global__ void k_big_fb_final(int m, int L, int Ltot, int geco, int b_global, real N_train, const real* __restrict__ state,
                                const real* __restrict__ Kb, const real* __restrict__ Ki, real* __restrict__ Kbar) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= m * m) return;
-    const real gT = gradKL(geco, L, state), gK = svgp_seed_K(geco, gT, (real)b_global / N_train);
+    const real gT = gradKL(geco, Ltot, state), gK = svgp_seed_K(geco, gT, (real)b_global / N_train);
     real s = 0;
     for (int l = 0; l < L; ++l) s += Kb[(size_t)l * m * m + o];
     Kbar[o] = s + real(0.5) * gK * (real)L * Ki[o];
@@ -310,22 +310,30 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
     return SVGP_OK;
 }
 
-int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, void* stream) {
-    const int b = c->b, m = c->m, L = c->L;
+// Channel window [l0, l0 + nl): the factor stage of those channels only (all of them: l0 = 0, nl = L).  With the batch
+// sharded over ranks and the statistics reduce-SCATTERED over channels, every rank factors L / G channels instead of all
+// L redundantly; (K_mm + jI)^-1 and q_n are channel-independent and computed by every caller.
+int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, void* stream, int l0, int nl) {
+    const int b = c->b, m = c->m, L = nl;
     const long long mm = (long long)m * m;
     const real cc = c->N_train / (double)c->b_global;
     const BigScr s = big_scr(c, wl, ws);
     hipStream_t st = (hipStream_t)stream;
-    real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si, *G = ws + wl.G, *A = ws + wl.A, *Aji = ws + wl.Aji;
-    real *t = ws + wl.t, *mu = ws + wl.mu_hat, *u = ws + wl.u, *v = ws + wl.v, *M2 = ws + wl.M2, *Kn = ws + wl.Kn;
-    hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, cc, c->jitter, K, ws + wl.S, 0LL, Si);
+    const size_t om = (size_t)l0 * mm, ov = (size_t)l0 * m;
+    real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si + om, *G = ws + wl.G + om, *A = ws + wl.A + om, *Aji = ws + wl.Aji + om;
+    real *t = ws + wl.t + ov, *mu = ws + wl.mu_hat + ov, *u = ws + wl.u + ov, *v = ws + wl.v + ov, *M2 = ws + wl.M2 + om, *Kn = ws + wl.Kn;
+    hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, cc, c->jitter, K, ws + wl.S + om, 0LL, Si);
     SVGP_LAUNCH_CHECK();
-    // K_mm inverse + log det (SVGPVAE_model.py:239,270,273) next to the L channel matrices (:331)
+    // K_mm inverse + log det (SVGPVAE_model.py:239,270,273) next to the channel matrices (:331)
     hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm)), dim3(256), 0, st, m, 1, real(0), c->jitter, K, (const real*)nullptr,
                        0LL, Ki);
     SVGP_LAUNCH_CHECK();
     if (m < SVGP_TWO_LEVEL_MIN_M) {
         RUNC(svgp_spd_inverse_fused(m, L, Si, s.ldtmp, 1, Ki, ws + wl.ldK, s.inv, stream));
+    } else if (Ki == Si + (size_t)L * mm) {
+        // one batch of L + 1: Ki sits right behind Si in the workspace (api.hip); its log det is the last entry
+        RUNC(svgp_spd_inverse_batched(m, L + 1, Si, s.ldtmp, s.inv, stream));
+        SVGP_CHECK_HIP(hipMemcpyAsync(ws + wl.ldK, s.ldtmp + L, sizeof(real), hipMemcpyDeviceToDevice, st));
     } else {
         RUNC(svgp_spd_inverse_batched(m, 1, Ki, ws + wl.ldK, s.inv, stream));
         RUNC(svgp_spd_inverse_batched(m, L, Si, s.ldtmp, s.inv, stream));
@@ -344,7 +352,7 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
                        (const real*)nullptr, mm, Aji);
     SVGP_LAUNCH_CHECK();
     RUNC(svgp_spd_inverse_batched(m, L, Aji, s.ldtmp, s.inv, stream));
-    hipLaunchKernelGGL(k_big_kl, dim3(nblk(L)), dim3(256), 0, st, m, L, ws + wl.ldK, s.ldtmp, s.mm0, ws + wl.KL);
+    hipLaunchKernelGGL(k_big_kl, dim3(nblk(L)), dim3(256), 0, st, m, L, ws + wl.ldK, s.ldtmp, s.mm0, ws + wl.KL + l0);
     SVGP_LAUNCH_CHECK();
     // q_n = k_n^T Ki k_n
     GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, Ki, m, 0, 0.0, s.bm, m, 0, 1);
@@ -384,22 +392,25 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     return SVGP_OK;
 }
 
+// channel window [l0, l0 + nl) as in svgp_big_factor_fwd; Kbar then holds the window's share of the gradient of K_mm
+// (the shares of the ranks add up in the gradient exchange: kernel_matrix_bwd is linear in Kbar)
 int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
-                        void* stream) {
-    const int m = c->m, L = c->L;
+                        void* stream, int l0, int nl) {
+    const int m = c->m, L = nl;
     const long long mm = (long long)m * m, lm = (long long)m;
     const real cc = c->N_train / (double)c->b_global;
     const BigScr s = big_scr(c, wl, ws);
     hipStream_t st = (hipStream_t)stream;
-    real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si, *G = ws + wl.G, *A = ws + wl.A, *S = ws + wl.S;
+    const size_t om = (size_t)l0 * mm, ov = (size_t)l0 * m;
+    real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si + om, *G = ws + wl.G + om, *A = ws + wl.A + om, *S = ws + wl.S + om;
     real* Kb = ws + wl.fb_part;
-    real* Kib = Kb + (size_t)L * mm;
+    real* Kib = Kb + (size_t)c->L * mm;
     FbArgs a;
-    a.m = m; a.L = L; a.geco = SVGP_LOSS_FLAGS(c); a.b_global = c->b_global; a.c = cc; a.N_train = c->N_train; a.state = state;
-    a.Ki = Ki; a.Aji = ws + wl.Aji; a.A = A; a.S = S; a.A2 = ws + wl.A2; a.M2 = ws + wl.M2; a.mu = ws + wl.mu_hat;
-    a.u = ws + wl.u; a.ud = ws + wl.ud; a.td = ws + wl.td; a.t = ws + wl.t; a.v = ws + wl.v;
+    a.m = m; a.L = L; a.Ltot = c->L; a.geco = SVGP_LOSS_FLAGS(c); a.b_global = c->b_global; a.c = cc; a.N_train = c->N_train; a.state = state;
+    a.Ki = Ki; a.Aji = ws + wl.Aji + om; a.A = A; a.S = S; a.A2 = ws + wl.A2 + om; a.M2 = ws + wl.M2 + om; a.mu = ws + wl.mu_hat + ov;
+    a.u = ws + wl.u + ov; a.ud = ws + wl.ud + ov; a.td = ws + wl.td + ov; a.t = ws + wl.t + ov; a.v = ws + wl.v + ov;
     a.X1 = s.mm1; a.T1A = s.mm2; a.Kib = Kib; a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2;
-    a.Sibar = s.mm3; a.Kb = Kb; a.Sg = s.mm1; a.Ssym = ws + wl.Ssym; a.Qm = ws + wl.Qm;
+    a.Sibar = s.mm3; a.Kb = Kb; a.Sg = s.mm1; a.Ssym = ws + wl.Ssym + om; a.Qm = ws + wl.Qm + om;
     const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m);
     GEMM(0, 0, m, m, m, 1.0, S, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);            // T1 = S Ki
     GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, s.mm1, m, mm, L);        // Ki S Ki
@@ -420,14 +431,14 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     GEMM(0, 0, m, m, m, 1.0, s.mm2, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);         // Gbar K  (mm3)
     hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);            // Sibar, Kb += c mubar t^T
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, m, 1, m, 1.0, Si, m, mm, s.vec2, 1, lm, 0.0, ws + wl.vbar, 1, lm, L);   // vbar = Si tbar
+    GEMM(0, 0, m, 1, m, 1.0, Si, m, mm, s.vec2, 1, lm, 0.0, ws + wl.vbar + ov, 1, lm, L);   // vbar = Si tbar
     GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm3, m, mm, 0.0, s.mm0, m, mm, L);       // Si Sibar (mm0)
     GEMM(0, 0, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);      // Sg = -Si Sibar Si (mm1)
     hipLaunchKernelGGL(k_big_fb_ssym, dim3(gmm), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
     GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, Kib, m, mm, 0.0, s.mm0, m, mm, L);          // Ki Kib
     GEMM(0, 0, m, m, m, -1.0, s.mm0, m, mm, Ki, m, 0, 1.0, Kb, m, mm, L);          // Kb -= Ki Kib Ki
-    hipLaunchKernelGGL(k_big_fb_final, dim3(nblk(mm)), dim3(256), 0, st, m, L, SVGP_LOSS_FLAGS(c), c->b_global, c->N_train, state, Kb,
+    hipLaunchKernelGGL(k_big_fb_final, dim3(nblk(mm)), dim3(256), 0, st, m, L, c->L, SVGP_LOSS_FLAGS(c), c->b_global, c->N_train, state, Kb,
                        Ki, ws + wl.Kbar);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;

@@ -72,6 +72,101 @@ class DataParallelStep:
         be.phase(3)
 
 
+class ChannelShardedStep:
+    """Exchange schedule of one step with the factor stage sharded over the latent channels ("reduce-scatter
+    over L -> factorize L/G channels per rank -> all-gather"), independent of what executes the stages.
+
+    backend: `.stage(k)` for k in 0..5 and `.ops(k)` -> list of ExchangeOp to run after stage k (k in 0..4):
+      stage 0  encoder, kernel matrices, forward statistics          ops: reduce_scatter S, v over channels
+      stage 1  factor stage of the rank's channel window             ops: allgather Sigma^-1, M2 (or A), t, u, KL
+      stage 2  row stage, decoder fwd + bwd, backward statistics     ops: reduce_scatter A2, ud, td
+      stage 3  reverse factor stage of the window                    ops: allgather Qm, Ssym, vbar
+      stage 4  row gradients, kernel-matrix VJP (the rank's Kbar share counts on EVERY rank), encoder reverse pass
+                                                                     ops: allreduce gradients + scalar sums
+      stage 5  optimiser + epilogue
+    SpritesStepEngine.phases yields exactly these op lists on the GPU; tests/test_dp_gloo.py runs the schedule with
+    real processes over an oracle-backed backend."""
+
+    def __init__(self, backend, group=None):
+        self.backend, self.group = backend, group
+
+    def step(self):
+        for k in range(6):
+            self.backend.stage(k)
+            if k < 5:
+                dist_exchange(self.backend.ops(k), self.group)
+
+
+class ExchangeOp:
+    """One collective of a data-parallel step on a flat, contiguous tensor.
+      allreduce      : every rank ends with the sum;
+      reduce_scatter : the tensor is `world` equal chunks, rank r ends with the SUM of chunk r in its chunk r (the other
+                       chunks are then unspecified);
+      allgather      : rank r contributes its chunk r, every rank ends with all chunks.
+    In-place semantics of ncclAllReduce / ncclReduceScatter / ncclAllGather (svgp_comm_*)."""
+    __slots__ = ("kind", "tensor")
+
+    def __init__(self, kind, tensor):
+        assert kind in ("allreduce", "reduce_scatter", "allgather") and tensor.is_contiguous()
+        self.kind, self.tensor = kind, tensor
+
+
+def virtual_exchange(ops_per_rank):
+    """Executes one exchange point for G virtual ranks that live on ONE device (the single-GPU data-parallel tests):
+    ops_per_rank[r] = the list of ExchangeOp rank r reached.  Defines by construction what the collectives must do."""
+    G = len(ops_per_rank)
+    for ops in zip(*ops_per_rank):
+        kind = ops[0].kind
+        assert all(o.kind == kind and o.tensor.numel() == ops[0].tensor.numel() for o in ops)
+        if kind == "allreduce":
+            tot = sum(o.tensor for o in ops)
+            for o in ops:
+                o.tensor.copy_(tot)
+            continue
+        n = ops[0].tensor.numel()
+        assert n % G == 0
+        c = n // G
+        if kind == "reduce_scatter":
+            sums = [sum(o.tensor[r * c:(r + 1) * c] for o in ops) for r in range(G)]
+            for r, o in enumerate(ops):
+                o.tensor.fill_(float("nan"))                 # the other chunks are unspecified: poison them
+                o.tensor[r * c:(r + 1) * c].copy_(sums[r])
+        else:
+            chunks = [ops[r].tensor[r * c:(r + 1) * c].clone() for r in range(G)]
+            for o in ops:
+                for r in range(G):
+                    o.tensor[r * c:(r + 1) * c].copy_(chunks[r])
+
+
+def dist_exchange(ops, group=None):
+    """The same exchange point through torch.distributed (any backend; used by the gloo schedule tests)."""
+    import torch.distributed as dist
+    G, r = dist.get_world_size(group), dist.get_rank(group)
+    for o in ops:
+        if o.kind == "allreduce":
+            dist.all_reduce(o.tensor, op=dist.ReduceOp.SUM, group=group)
+        else:
+            c = o.tensor.numel() // G
+            chunks = [o.tensor[i * c:(i + 1) * c] for i in range(G)]
+            if o.kind == "reduce_scatter":
+                out = torch.empty_like(chunks[r])
+                dist.reduce_scatter(out, [ch.clone() for ch in chunks], op=dist.ReduceOp.SUM, group=group) \
+                    if dist.get_backend(group) != "gloo" else _gloo_reduce_scatter(out, chunks, r, group)
+                chunks[r].copy_(out)
+            else:
+                dist.all_gather([ch for ch in chunks], chunks[r].clone(), group=group)
+
+
+def _gloo_reduce_scatter(out, chunks, r, group):
+    """gloo has no reduce_scatter: all-reduce every chunk, keep one's own (test backend only)."""
+    import torch.distributed as dist
+    for i, ch in enumerate(chunks):
+        t = ch.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if i == r:
+            out.copy_(t)
+
+
 class RcclComm:
     """RCCL communicator owned by libsvgpvae_hip.so (svgp_comm_*), one per process / GPU.  Its all-reduces
     are enqueued on the engine's compute stream by svgp_mnist_train_step_dp, so a data-parallel step is one
@@ -106,6 +201,20 @@ class RcclComm:
         assert tensor.dtype in (torch.float64, torch.float32) and tensor.is_contiguous() and tensor.is_cuda
         fn = "svgp_allreduce_sum_f64" if tensor.dtype == torch.float64 else "svgp_allreduce_sum_f32"
         call(fn, self.handle, tensor.data_ptr(), tensor.numel(), stream)
+
+    def reduce_scatter(self, tensor, stream):
+        assert tensor.dtype == torch.float64 and tensor.is_contiguous() and tensor.numel() % self.world_size == 0
+        call("svgp_reduce_scatter_sum_f64", self.handle, tensor.data_ptr(), tensor.numel() // self.world_size, stream)
+
+    def all_gather(self, tensor, stream):
+        assert tensor.dtype == torch.float64 and tensor.is_contiguous() and tensor.numel() % self.world_size == 0
+        call("svgp_allgather_f64", self.handle, tensor.data_ptr(), tensor.numel() // self.world_size, stream)
+
+    def run(self, ops, stream):
+        """Enqueues one exchange point (list of ExchangeOp) on `stream`."""
+        for o in ops:
+            {"allreduce": self.all_reduce, "reduce_scatter": self.reduce_scatter, "allgather": self.all_gather}[o.kind](
+                o.tensor, stream)
 
     def close(self):
         if self.handle:

@@ -30,6 +30,7 @@ import torch
 from . import _lib
 from ._lib import STATE, STATE_LEN, MnistCfg, SpritesKcfg, WsLayout, call
 from .conv import ConvLayer
+from .engine import ExchangeOp
 
 _F64 = torch.float64
 ENC_STRIDES = (1, 2, 1, 2, 1, 2)
@@ -111,7 +112,7 @@ class SpritesStepEngine:
 
     def __init__(self, vae, repr_nn, svgp, *, b_max, seg_len=50, clip_qs=False, geco=False, kappa_squared=0.0075,
                  alpha=0.99, beta=0.001, lr=1e-3, clip_grad=None, device="cuda:0", params=None, rank=0, world_size=1,
-                 comm=None, net_dtype=torch.float64, gemm_f32=0):
+                 comm=None, net_dtype=torch.float64, gemm_f32=0, channel_shard=None):
         self.lib = _lib.load_library()
         if not torch.cuda.is_available():
             raise _lib.SvgpError("SpritesStepEngine needs a HIP device; there is no CPU execution path")
@@ -170,6 +171,16 @@ class SpritesStepEngine:
                          N_train=svgp.N_train, jitter=svgp.jitter, kappa_squared=float(kappa_squared),
                          alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0, single_stat_block=int(world_size > 1),
                          gemm_f32=int(gemm_f32))
+        # Channel-sharded factor stage: with more than one rank and the large-m path, the (L,m,m) statistics
+        # are reduce-SCATTERED over the channels, every rank factors L / G channels and the row stage's inputs are
+        # all-gathered -- instead of all-reducing the blocks and factoring all L channels on every rank.
+        if channel_shard is None:
+            channel_shard = world_size > 1 and self.m > 64 and self.L % world_size == 0 and not svgp.titsias
+        if channel_shard and (self.m <= 64 or self.L % world_size or svgp.titsias):
+            raise _lib.SvgpError("channel_shard needs m > 64, L divisible by the number of ranks and the Hensman branch")
+        self.chan_shard = bool(channel_shard)
+        if self.chan_shard:
+            self.base["rep_weight"] = 1.0        # every rank's Kbar holds its channel window's share (sums in the gradient exchange)
         self.cfg = MnistCfg(b=b_max, b_global=b_max, **self.base)
         self.wl = WsLayout()
         call("svgp_mnist_ws_layout_get", C.byref(self.cfg), C.byref(self.wl))
@@ -345,15 +356,16 @@ class SpritesStepEngine:
         the three exchange blocks are summed over ranks by `self.comm` between the phases."""
         if self.world_size > 1 and self.comm is None:
             raise _lib.SvgpError("world_size > 1 needs a communicator (engine.RcclComm)")
-        for blocks in self.phases(images, action_ids, eps, adam, b_global):
+        for ops in self.phases(images, action_ids, eps, adam, b_global):
             if self.comm is not None:
-                for t in blocks:
-                    self.comm.all_reduce(t, self.stream.cuda_stream)
+                self.comm.run(ops, self.stream.cuda_stream)
         return self
 
     def phases(self, images, action_ids, eps=None, adam=True, b_global=None):
-        """Generator over the step: yields the list of flat tensors to be summed over ranks at each of the
-        three exchange points (forward statistics, backward statistics, gradients + scalar sums)."""
+        """Generator over the step: yields, at every exchange point, the list of engine.ExchangeOp to run across the
+        ranks.  Three points (all-reduce of the forward statistics, the backward statistics, gradients + scalar sums) in
+        the plain form; five in the channel-sharded form (reduce-scatter S, v | all-gather Sigma^-1, M2, t, u, KL |
+        reduce-scatter A2, ud, td | all-gather Qm, Ssym, vbar | all-reduce gradients + sums)."""
         b = images.shape[0]
         assert b <= self.b_max and b % self.seg_len == 0
         b_global = b * self.world_size if b_global is None else b_global
@@ -379,17 +391,32 @@ class SpritesStepEngine:
             self._mark("gp_fwd_stats")
             kc = SpritesKcfg(b=b, m=self.m, La=self.La, Lc=self.Lc, n_act=self.n_act,
                              normalize=int(self.svgp.K_obj_normalize), k_se=int(self.svgp.K_SE),
-                             rep_weight=1.0 if self.rank == 0 else 0.0)
+                             # Kbar-derived terms: replicated on every rank (counted on rank 0) -- or, channel-sharded,
+                             # every rank's Kbar is its window's share and all shares count
+                             rep_weight=1.0 if (self.rank == 0 or self.chan_shard) else 0.0)
             K, Kn, knn = self._v("K", (self.m, self.m)), self._v("Kn", (b, self.m)), self._v("knn", (b,))
             call("svgp_sprites_kernel_matrix_fwd", C.byref(kc), aux.data_ptr(), p["inducing_index_points"].data_ptr(),
                  p["GPLVM_action"].data_ptr(), p["se"].data_ptr(), K.data_ptr(), Kn.data_ptr(), knn.data_ptr(), s)
             call("svgp_gp_stats_fwd", cp, ws, s)
             if self.svgp.titsias:
                 call("svgp_gp_titsias_stats", cp, ws, s)
-        yield [self.ws[self.wl.statA:self.wl.statA + self.wl.statA_len]]
+        mm_, G_, r_ = self.m * self.m, self.world_size, self.rank
+        nl = L // G_ if self.chan_shard else L
+        fld = lambda name, per: self.ws[getattr(self.wl, name):getattr(self.wl, name) + L * per]       # an (L, per) field
+        if self.chan_shard:
+            yield [ExchangeOp("reduce_scatter", fld("S", mm_)), ExchangeOp("reduce_scatter", fld("v", self.m))]
+        else:
+            yield [ExchangeOp("allreduce", self.ws[self.wl.statA:self.wl.statA + self.wl.statA_len])]
         with torch.cuda.stream(self.stream):
             self._mark("gp_fwd_factor")
-            call("svgp_gp_factor_fwd", cp, ws, s)
+            if self.chan_shard:
+                call("svgp_gp_factor_fwd_channels", cp, r_ * nl, nl, ws, s)
+            else:
+                call("svgp_gp_factor_fwd", cp, ws, s)
+        if self.chan_shard:
+            yield [ExchangeOp("allgather", fld(n_, per)) for n_, per in (("Si", mm_), ("M2", mm_), ("t", self.m), ("u", self.m),
+                                                                         ("KL", 1))]
+        with torch.cuda.stream(self.stream):
             call("svgp_gp_posterior_fwd", cp, None if eps is None else eps.contiguous().data_ptr(), ws, st, s)
             if self.svgp.titsias:
                 call("svgp_gp_titsias_fwd", cp, ws, st, s)
@@ -425,10 +452,19 @@ class SpritesStepEngine:
                 self._gemm(0, 1, b, L, 1024, 1.0, dh0, 1024, pn["dec_d_w"], 1024, 0.0, zbar, L)
             self._mark("gp_bwd_stats")
             call("svgp_gp_stats_bwd", cp, ws, st, s)
-        yield [self.ws[self.wl.statB:self.wl.statB + self.wl.statB_len]]
+        if self.chan_shard:
+            yield [ExchangeOp("reduce_scatter", fld(n_, per)) for n_, per in (("A2", mm_), ("ud", self.m), ("td", self.m))]
+        else:
+            yield [ExchangeOp("allreduce", self.ws[self.wl.statB:self.wl.statB + self.wl.statB_len])]
         with torch.cuda.stream(self.stream):
             self._mark("gp_bwd_factor")
-            call("svgp_gp_factor_bwd", cp, ws, st, s)
+            if self.chan_shard:
+                call("svgp_gp_factor_bwd_channels", cp, r_ * nl, nl, ws, st, s)
+            else:
+                call("svgp_gp_factor_bwd", cp, ws, st, s)
+        if self.chan_shard:
+            yield [ExchangeOp("allgather", fld(n_, per)) for n_, per in (("Qm", mm_), ("Ssym", mm_), ("vbar", self.m))]
+        with torch.cuda.stream(self.stream):
             call("svgp_gp_posterior_bwd", cp, ws, st, s)
             if self.svgp.titsias:
                 call("svgp_gp_titsias_bwd", cp, ws, st, s)
@@ -475,7 +511,7 @@ class SpritesStepEngine:
             if self.svgp.fixed_GP_params or not self.svgp.K_SE:
                 g["se"].zero_()
             call("svgp_mnist_grad_reduce", cp, ws, s)           # scalar partial sums -> ws.sums
-        yield [self.grad, self.ws[self.wl.sums:self.wl.sums + 8]]
+        yield [ExchangeOp("allreduce", self.grad), ExchangeOp("allreduce", self.ws[self.wl.sums:self.wl.sums + 8])]
         with torch.cuda.stream(self.stream):
             self._mark("optim")
             if self.clip_grad is not None:

@@ -100,6 +100,149 @@ class OracleBackend:
         pass
 
 
+class ShardedOracleBackend(OracleBackend):
+    """Stage contract of engine.ChannelShardedStep over the same oracle arithmetic: the m x m factor stages run on the
+    rank's channel window only.  (The oracle's row stage consumes A_l where the HIP kernels consume M2_l = Ki A_l Ki,
+    so A is what is all-gathered here; same schedule, same op kinds and sizes.)"""
+
+    def __init__(self, *a, world, **kw):
+        super().__init__(*a, **kw)
+        self.world = world
+
+    def stage(self, k):
+        getattr(self, f"_stage{k}")()
+
+    def ops(self, k):
+        from svgp_vae_amd.engine import ExchangeOp
+        return [ExchangeOp(kind, t) for kind, t in self._ops[k]]
+
+    def _win(self):
+        nl = self.L // self.world
+        return self.rank * nl, (self.rank + 1) * nl
+
+    def _stage0(self):
+        self._phase0()
+        nS = math.prod(self.shapeS)
+        blk = self.blocks["statA"]
+        self.S, self.v = blk[:nS].view(self.shapeS), blk[nS:].view(self.shapev)
+        self._ops = {0: [("reduce_scatter", blk[:nS]), ("reduce_scatter", blk[nS:])]}
+
+    def _stage1(self):
+        l0, l1 = self._win()
+        fw = SG.gp_factor_fwd(self.K, self.S[l0:l1], self.v[l0:l1], self.j, self.c)
+        self.fw = fw
+        L, m = self.L, self.K.shape[0]
+        self.full = {k: torch.full((L,) + tuple(fw[k].shape[1:]), float("nan"), dtype=DT) for k in ("Si", "A", "t", "u", "KL")}
+        for k in self.full:
+            self.full[k][l0:l1] = fw[k]
+        self._ops[1] = [("allgather", self.full[k].view(-1)) for k in ("Si", "A", "t", "u", "KL")]
+
+    def _stage2(self):
+        f = dict(self.fw)
+        f.update({k: self.full[k] for k in ("Si", "A", "t", "u", "KL")})
+        self.f = f
+        self.ps = SG.gp_posterior_fwd(self.Kn, self.knn, self.y, self.s2, self.eps, f, self.c)
+        z = self.ps["z"].clone().requires_grad_(True)
+        recon = self.vae.decode(z)
+        self.sq = torch.sum((self.images - recon) ** 2)
+        gscale = (self.lam / self.bg if self.geco else 1.0) / 784.0
+        dec_keys = [k for k in VAE_KEYS if k.startswith("dec_")]
+        gs = torch.autograd.grad(gscale * self.sq, [z] + [self.p[k] for k in dec_keys])
+        self.zbar = gs[0]
+        self.g = {k: g for k, g in zip(dec_keys, gs[1:])}
+        self.gT = -1.0 if self.geco else -self.beta / self.L
+        self.gw = SG.gp_posterior_bwd_weights(self.y, self.s2, self.eps, self.ps, self.zbar, self.gT, self.c)
+        self.A2, self.ud, self.td = (t.contiguous() for t in SG.gp_stats(self.Kn, self.gw[0], self.gw[2], self.c * self.gw[1]))
+        self._ops[2] = [("reduce_scatter", t.view(-1)) for t in (self.A2, self.ud, self.td)]
+
+    def _stage3(self):
+        l0, l1 = self._win()
+        fwin = dict(self.fw)                       # the window's own factors (G, Aji, mu are never exchanged)
+        fb = SG.gp_factor_bwd(self.K, self.S[l0:l1], self.v[l0:l1], fwin, self.A2[l0:l1], self.ud[l0:l1], self.td[l0:l1],
+                              self.gT, self.c, self.N, self.bg)
+        self.Kbar_share = fb["Kbar"]
+        L = self.L
+        self.fbfull = {k: torch.full((L,) + tuple(fb[k].shape[1:]), float("nan"), dtype=DT) for k in ("Q", "Ssym", "vbar")}
+        for k in self.fbfull:
+            self.fbfull[k][l0:l1] = fb[k]
+        self._ops[3] = [("allgather", self.fbfull[k].view(-1)) for k in ("Q", "Ssym", "vbar")]
+
+    def _stage4(self):
+        fb = dict(Q=self.fbfull["Q"], Ssym=self.fbfull["Ssym"], vbar=self.fbfull["vbar"], P=2.0 * self.full["Si"])
+        Knbar, knnbar, ybar, s2bar = SG.gp_posterior_bwd_rows(self.Kn, self.knn, self.y, self.s2, self.ps, self.f, fb,
+                                                              self.gw[0], self.gw[1], self.gw[2], self.gT, self.c)
+        p = self.p
+        # every rank's Kbar share counts (rep_weight = 1 everywhere): the kernel-matrix VJP is linear in Kbar
+        d_ip, d_ls, d_amp, d_ov = SG.kernel_matrix_bwd(self.aux, p["inducing_index_points"].detach(),
+                                                       p["object_vectors"].detach(), p["l_GP"].detach(),
+                                                       p["amplitude"].detach(), self.Kbar_share, Knbar, knnbar)
+        enc_keys = [k for k in VAE_KEYS if k.startswith("enc_")]
+        gs = torch.autograd.grad((ybar * self.mu).sum() + (s2bar * self.var).sum(), [p[k] for k in enc_keys])
+        self.g.update({k: g for k, g in zip(enc_keys, gs)})
+        self.g.update(inducing_index_points=d_ip, l_GP=d_ls, amplitude=d_amp, object_vectors=d_ov)
+        pr = O.reciprocal_no_nan(self.s2)
+        l3data = -0.5 * ((pr * self.ps["d"]).sum() + torch.log(self.s2).sum())
+        sums = torch.stack([l3data, self.ps["CE"], self.sq.detach(), torch.tensor(float(self.y.shape[0]), dtype=DT)])
+        self.blocks["gradC"] = torch.cat([self.g[k].reshape(-1) for k in ORDER] + [sums])
+        self._ops[4] = [("allreduce", self.blocks["gradC"])]
+
+    def _stage5(self):
+        pass
+
+
+def _worker_sharded(rank, world, port, b_global, geco, L, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from svgp_vae_amd.engine import ChannelShardedStep, shard_rows
+        params, images, aux, eps = H.toy_problem(b=b_global, m=12, L=L, M=4, n_obj=20, seed=0)
+        lo, hi = shard_rows(b_global, world, rank)
+        be = ShardedOracleBackend(params, images[lo:hi], aux[lo:hi], eps[lo:hi], b_global=b_global, rank=rank, world=world,
+                                  N_train=300.0, jitter=1e-6, geco=geco, beta=0.001, lagrange=1.7)
+        ChannelShardedStep(be).step()
+        if rank == 0:
+            ret.put((be.block("gradC").clone().numpy(), be.full["KL"].clone().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,b_global,geco,L", [(2, 40, True, 4), (3, 41, False, 3), (2, 40, False, 6)])
+def test_channel_sharded_schedule_reproduces_single_process(world, b_global, geco, L):
+    """Reduce-scatter over the channels -> factor L / G channels per rank -> all-gather:
+    gradients, scalar sums and the per-channel KL terms equal the single-process oracle."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sharded, args=(r, world, port, b_global, geco, L, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import time
+    t0 = time.time()
+    while ret.empty():                           # a failed worker must fail the test, not hang it on the queue
+        if any(p.exitcode not in (None, 0) for p in procs) or time.time() - t0 > 300:
+            for q in procs:
+                if q.is_alive():
+                    q.terminate()
+            pytest.fail(f"worker exit codes {[p.exitcode for p in procs]}")
+        time.sleep(0.05)
+    got, KL = (torch.from_numpy(a) for a in ret.get())
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    params, images, aux, eps = H.toy_problem(b=b_global, m=12, L=L, M=4, n_obj=20, seed=0)
+    out, grads = O.loss_and_grads(params, images, aux, eps, beta=0.001, C_ma=torch.zeros((), dtype=DT),
+                                  lagrange_mult=torch.tensor(1.7, dtype=DT), alpha=0.9, kappa=math.sqrt(0.02),
+                                  clipping_qs=True, GECO=geco, jitter=1e-6, N_train=300.0, L=L, formulation="efficient")
+    keys = [k for k, _ in O.mnist_vae_param_shapes(L)] + ["inducing_index_points", "l_GP", "amplitude", "object_vectors"]
+    want = torch.cat([grads[k].reshape(-1) for k in keys])
+    n = want.numel()
+    assert float((got[:n] - want).abs().max() / want.abs().max()) < 1e-9
+    assert abs(float(KL.sum()) - float(out[11])) < 1e-9 * abs(float(out[11]))       # inside_elbo_kl = sum_l KL_l
+    sums = got[n:]
+    assert abs(float(sums[1]) - float(out[4])) < 1e-9 * abs(float(out[4]))          # ce_term
+    assert float(sums[3]) == b_global
+
+
 def _worker(rank, world, port, b_global, geco, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)

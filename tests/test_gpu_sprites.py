@@ -102,13 +102,18 @@ def test_sprites_training_steps_reduce_the_loss():
     assert eng.scalars()["adam_t"] == 8.0
 
 
-@pytest.mark.parametrize("G,K_SE,m,clip", [(2, False, 12, None), (3, True, 72, 0.05)])
-def test_sprites_virtual_ranks_equal_single_engine(G, K_SE, m, clip):
+@pytest.mark.parametrize("G,K_SE,m,clip,shard,L", [(2, False, 12, None, None, 6), (3, True, 72, 0.05, None, 6),
+                                                    (2, False, 72, None, False, 6), (2, True, 72, None, True, 6),
+                                                    (8, False, 72, None, True, 8)])
+def test_sprites_virtual_ranks_equal_single_engine(G, K_SE, m, clip, shard, L):
     """Data parallelism over whole character groups: G engines on one GPU run the step's phases in
-    lockstep, the three exchange blocks are summed by hand (what the RCCL all-reduce does); scalars, gradients
-    and the parameters after two Adam steps must equal the single-engine run at the same global batch."""
+    lockstep and every exchange point is executed by hand (engine.virtual_exchange: what the RCCL collectives do);
+    scalars, gradients and the parameters after two Adam steps must equal the single-engine run at the same global
+    batch.  m <= 64: three all-reduces.  m > 64 and L divisible by G (shard None -> on): the channel-sharded schedule --
+    reduce-scatter of S, v / A2, ud, td over the channels, each rank factors its L / G channels
+    (svgp_gp_factor_*_channels), all-gather of Sigma^-1, M2, t, u, KL / Qm, Ssym, vbar."""
     from svgp_vae_amd import sprites as S
-    frames, L, La, Lc, n_act = 4, 6, 8, 16, 9
+    frames, La, Lc, n_act = 4, 8, 16, 9
     b = frames * 2 * G
     params, gp, images, ids, eps, _, _ = _problem(b, frames, L, La, Lc, m, n_act, seed=G + m)
     init = dict(params)
@@ -120,7 +125,7 @@ def test_sprites_virtual_ranks_equal_single_engine(G, K_SE, m, clip):
                              K_obj_normalize=not K_SE, K_SE=K_SE)
         e = S.SpritesStepEngine(S.spritesVAE(L), S.sprites_representation_network(Lc), svgp, b_max=b_max,
                                 seg_len=frames, clip_qs=True, geco=True, kappa_squared=0.0075, clip_grad=clip,
-                                params=init, rank=rank, world_size=world)
+                                params=init, rank=rank, world_size=world, channel_shard=shard if world > 1 else False)
         e.set_scalars(c_ma=0.02, lagrange=1.4, alpha=0.9)
         return e
 
@@ -128,22 +133,22 @@ def test_sprites_virtual_ranks_equal_single_engine(G, K_SE, m, clip):
     dev = single.dev
     di, da, de = images.to(dev), ids.to(dev, DT), eps.to(dev)
     ranks = [make(r, G, b // G) for r in range(G)]
+    assert ranks[0].chan_shard == (m > 64 and shard is not False)
     rows = [slice(r * (b // G), (r + 1) * (b // G)) for r in range(G)]
     for step in range(2):
         single.step(di, da, de, adam=True)
         gens = [e.phases(di[sl].contiguous(), da[sl].contiguous(), de[sl].contiguous(), True, b)
                 for e, sl in zip(ranks, rows)]
-        for _ in range(3):
-            blocks = [next(gn) for gn in gens]
+        from svgp_vae_amd.engine import virtual_exchange
+        while True:
+            ops = [next(gn, None) for gn in gens]
+            if ops[0] is None:
+                assert all(o is None for o in ops)
+                break
             for e in ranks:
                 e.stream.synchronize()
-            for parts in zip(*blocks):
-                tot = sum(parts)
-                for t in parts:
-                    t.copy_(tot)
+            virtual_exchange(ops)
             torch.cuda.synchronize()
-        for gn in gens:
-            assert next(gn, None) is None
         ref = single.scalars()
         for e in ranks:
             sc = e.scalars()

@@ -457,13 +457,12 @@ def run_sprites(args):
     ip, table, img, ids, eps = sprites_problem(rank, b, L_, La, Lc, n_act, m)
     svgp = S.spritesSVGP(False, False, ip, 'main', 0.01, 50000, La, table, Lc, L_, K_obj_normalize=True)
     f32 = args.precision == "f32"
-    # f32: the networks in float32 (the reference's dtype, VAE_utils.py:277) and the GP statistics products on the float32
-    # MFMA; the K Sigma^-1 K sandwiches and every factorisation stay float64 (gemm_f32 = 1 loses parity at m = 800:
-    # tests/test_gpu_f32.py)
+    # f32: the networks in float32 (the reference's dtype, VAE_utils.py:277); the GP block stays float64 unless --gemm-f32
+    # asks otherwise (float32 products lose parity / stability at m = 800: tests/test_gpu_f32.py)
     eng = S.SpritesStepEngine(S.spritesVAE(L_), S.sprites_representation_network(Lc), svgp, b_max=b, seg_len=frames,
                               geco=True, kappa_squared=0.0075, clip_grad=1e6, device=f"cuda:{local_rank}", rank=rank,
                               world_size=world, comm=comm, net_dtype=torch.float32 if f32 else torch.float64,
-                              gemm_f32=2 if f32 else 0)
+                              gemm_f32=args.gemm_f32)
     dev = eng.dev
     d_img, d_ids, d_eps = img.to(dev, eng.ndt), ids.to(dev), eps.to(dev)
     # parity gate (N = 1): explicit-eps step, ELBO against the oracle's efficient formulation -- inside cpu_baseline
@@ -723,8 +722,11 @@ def main():
                          "cfg5 = configs[4] shard (N=131072, m=2048, float32 statistics pass)")
     ap.add_argument("--m", type=int, default=None, help="sprites800 / cfg5: inducing points (default 800 / 2048)")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
-                    help="sprites800: f64 = everything float64; f32 = float32 networks + float32-MFMA GP statistics "
-                         "(float64 sandwiches and factorisations)")
+                    help="sprites800: f64 = everything float64; f32 = the three networks in float32 (the reference's "
+                         "dtype), GP block float64")
+    ap.add_argument("--gemm-f32", type=int, choices=[0, 1, 2], default=0,
+                    help="sprites800: cfg.gemm_f32 of the large-m GP block (1 = every product on the float32 MFMA, "
+                         "2 = the statistics products only); both lose stability at m = 800 (DESIGN.md)")
     ap.add_argument("--rows", type=int, default=None, help="cfg5: rows per GPU (default 131072)")
     ap.add_argument("--cpu-worker", choices=["cfg2", "cfg3", "sprites800", "cfg5"], default=None,
                     help="internal: run one CPU-baseline leg in this (child) process and print its JSON")

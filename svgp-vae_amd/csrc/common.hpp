@@ -122,6 +122,10 @@ int svgp_dgemm_tri_batched(int tri, int ta, int tb, int M, int N, int K, double 
                            long long strideA, const double* B, int ldb, long long strideB, double beta, double* C, int ldc,
                            long long strideC, int batch, void* stream);
 
+int svgp_dgemm_symout_batched(int f32c, int ta, int tb, int M, int K, double alpha, const double* A, int lda, long long strideA,
+                              const double* B, int ldb, long long strideB, double beta, double* C, int ldc, long long strideC,
+                              int batch, void* stream);
+
 // large-m implementations (gp_large.hip)
 int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state, int mode,
                    void* stream);

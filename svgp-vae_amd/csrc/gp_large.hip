@@ -194,14 +194,24 @@ __global__ void k_big_fb_ssym(FbArgs a) {     // Kb += Sg ; Ssym = c (Sg + Sg^T)
     a.Ssym[i] = ss;
     a.Qm[i] = ss - g3 * a.M2[i];
 }
+// out (m x m) = sum over the L channel matrices
+__global__ void k_big_sum_channels(int mm, int L, const real* __restrict__ in, real* __restrict__ out) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= mm) return;
+    real s = 0;
+    for (int l = 0; l < L; ++l) s += in[(size_t)l * mm + o];
+    out[o] = s;
+}
+// Kbar = sum_l Kb_l - Ki (sum_l Kib_l) Ki + gK/2 L Ki ;  KiKibKi = the middle product, formed once for the channel sum
 __global__ void k_big_fb_final(int m, int L, int Ltot, int geco, int b_global, real N_train, const real* __restrict__ state,
-                               const real* __restrict__ Kb, const real* __restrict__ Ki, real* __restrict__ Kbar) {
+                               const real* __restrict__ Kb, const real* __restrict__ Ki, const real* __restrict__ KiKibKi,
+                               real* __restrict__ Kbar) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= m * m) return;
     const real gT = gradKL(geco, Ltot, state), gK = svgp_seed_K(geco, gT, (real)b_global / N_train);
     real s = 0;
     for (int l = 0; l < L; ++l) s += Kb[(size_t)l * m * m + o];
-    Kbar[o] = s + real(0.5) * gK * (real)L * Ki[o];
+    Kbar[o] = s - KiKibKi[o] + real(0.5) * gK * (real)L * Ki[o];
 }
 
 // ---- per-sample backward element-wise pieces ----------------------------------------------------
@@ -264,6 +274,10 @@ inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 // cfg.gemm_f32 = 1: every product on the float32 MFMA (float64 storage); GEMM_S: the statistics products, also with 2
 #define GEMM(...) RUNC((c->gemm_f32 == 1 ? svgp_dgemm_f32c_batched : svgp_dgemm_batched)(__VA_ARGS__, stream))
 #define GEMM_S(...) RUNC((c->gemm_f32 ? svgp_dgemm_f32c_batched : svgp_dgemm_batched)(__VA_ARGS__, stream))
+// products whose result is symmetric (K Si K, Ki A Ki, Ki S Ki, K Abar K, Kn^T diag(w) Kn): lower tiles + mirrored stores.
+// arguments: ta, tb, M (= N), K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch
+#define GEMM_SYM(...) RUNC(svgp_dgemm_symout_batched(c->gemm_f32 == 1, __VA_ARGS__, stream))
+#define GEMM_S_SYM(...) RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, __VA_ARGS__, stream))
 
 // scratch carving (layout fields scr_bm / scr_mm / scr_vec / scr_inv / scr_bl are allocated by api.hip)
 struct BigScr {
@@ -301,7 +315,7 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
     real* S = mode == 0 ? ws + wl.S : ws + wl.A2;
     real* v1 = mode == 0 ? ws + wl.v : ws + wl.ud;
     // S_l = Kn^T (w_l o Kn)
-    GEMM_S(1, 0, m, m, b, 1.0, Kn, m, 0, s.bm, m, (long long)b * m, 0.0, S, m, (long long)m * m, L);
+    GEMM_S_SYM(1, 0, m, b, 1.0, Kn, m, 0, s.bm, m, (long long)b * m, 0.0, S, m, (long long)m * m, L);
     // v1 (L x m) = a^T Kn
     GEMM(1, 0, L, m, b, 1.0, abuf, L, 0, Kn, m, 0, 0.0, v1, m, 0, 1);
     if (mode == 1) GEMM(1, 0, L, m, b, cc, bbuf, L, 0, Kn, m, 0, 0.0, ws + wl.td, m, 0, 1);
@@ -340,11 +354,11 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     }
     GEMM(0, 0, m, 1, m, 1.0, Si, m, mm, v, 1, (long long)m, 0.0, t, 1, (long long)m, L);          // t = Si v
     GEMM(0, 0, m, m, m, 1.0, Si, m, mm, K, m, 0, 0.0, G, m, mm, L);                              // G = Si K
-    GEMM(0, 0, m, m, m, 1.0, K, m, 0, G, m, mm, 0.0, A, m, mm, L);                               // A = K G
+    GEMM_SYM(0, 0, m, m, 1.0, K, m, 0, G, m, mm, 0.0, A, m, mm, L);                              // A = K G = K Si K
     GEMM(0, 0, m, 1, m, cc, K, m, 0, t, 1, (long long)m, 0.0, mu, 1, (long long)m, L);            // mu = c K t
     GEMM(0, 0, m, 1, m, 1.0, Ki, m, 0, mu, 1, (long long)m, 0.0, u, 1, (long long)m, L);          // u = Ki mu
     GEMM(0, 0, m, m, m, 1.0, A, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);                          // T = A Ki
-    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, M2, m, mm, L);                         // M2 = Ki A Ki
+    GEMM_SYM(0, 0, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, M2, m, mm, L);                        // M2 = Ki A Ki
     // s.mm0 (T = A Ki) is free once M2 is formed: its head holds the (L, KL_NCH, 2) trace partials
     hipLaunchKernelGGL(k_big_kl_terms, dim3(KL_NCH, L), dim3(256), 0, st, m, Ki, A, mu, u, s.mm0);
     SVGP_LAUNCH_CHECK();
@@ -413,7 +427,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     a.Sibar = s.mm3; a.Kb = Kb; a.Sg = s.mm1; a.Ssym = ws + wl.Ssym + om; a.Qm = ws + wl.Qm + om;
     const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m);
     GEMM(0, 0, m, m, m, 1.0, S, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);            // T1 = S Ki
-    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, s.mm1, m, mm, L);        // Ki S Ki
+    GEMM_SYM(0, 0, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, s.mm1, m, mm, L);       // Ki S Ki
     hipLaunchKernelGGL(k_big_fb_abar, dim3(gmm), dim3(256), 0, st, a);             // Abar (mm1), ubar
     SVGP_LAUNCH_CHECK();
     GEMM(0, 0, m, 1, m, 1.0, Ki, m, 0, s.vec0, 1, lm, 0.0, s.vec1, 1, lm, L);      // Ki ubar
@@ -428,7 +442,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     GEMM(0, 0, m, 1, m, 1.0, K, m, 0, s.vec1, 1, lm, 0.0, s.vec2, 1, lm, L);       // K mubar
     hipLaunchKernelGGL(k_big_fb_tbar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, m, m, m, 1.0, s.mm2, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);         // Gbar K  (mm3)
+    GEMM_SYM(0, 0, m, m, 1.0, s.mm2, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);        // Gbar K = K Abar K  (mm3)
     hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);            // Sibar, Kb += c mubar t^T
     SVGP_LAUNCH_CHECK();
     GEMM(0, 0, m, 1, m, 1.0, Si, m, mm, s.vec2, 1, lm, 0.0, ws + wl.vbar + ov, 1, lm, L);   // vbar = Si tbar
@@ -436,10 +450,14 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     GEMM(0, 0, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);      // Sg = -Si Sibar Si (mm1)
     hipLaunchKernelGGL(k_big_fb_ssym, dim3(gmm), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, Kib, m, mm, 0.0, s.mm0, m, mm, L);          // Ki Kib
-    GEMM(0, 0, m, m, m, -1.0, s.mm0, m, mm, Ki, m, 0, 1.0, Kb, m, mm, L);          // Kb -= Ki Kib Ki
+    // sum_l Ki Kib_l Ki = Ki (sum_l Kib_l) Ki: Ki is shared by the channels and only the channel sum of Kb reaches Kbar,
+    // so the two products run once on the summed matrix instead of once per channel (2 of the 13 m^3 L products of this stage)
+    hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, Kib, s.mm0);
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, 0, 0.0, s.mm0 + mm, m, 0, 1);      // Ki (sum Kib)
+    GEMM(0, 0, m, m, m, 1.0, s.mm0 + mm, m, 0, Ki, m, 0, 0.0, s.mm0, m, 0, 1);      // Ki (sum Kib) Ki
     hipLaunchKernelGGL(k_big_fb_final, dim3(nblk(mm)), dim3(256), 0, st, m, L, c->L, SVGP_LOSS_FLAGS(c), c->b_global, c->N_train, state, Kb,
-                       Ki, ws + wl.Kbar);
+                       Ki, s.mm0, ws + wl.Kbar);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

@@ -26,7 +26,8 @@ struct GemmArgs {
     const void* A; const void* B; void* C;      // element type = the kernel's storage type TS
     // triangular structure (svgp_dgemm_tri_batched): bit 0 = only tiles that touch the lower triangle (j0 <= i0 + tile - 1);
     // bit 1 / bit 2 = contraction starts at the tile's first row / first column (operands that are zero for k < i / k < j);
-    // bit 3 = contraction ends with the tile's last row (operand zero for k > i)
+    // bit 3 = contraction ends with the tile's last row (operand zero for k > i);
+    // bit 4 (with bit 0, M == N) = the result is symmetric: every computed tile below the diagonal is also stored transposed
     int tri;
 };
 
@@ -54,7 +55,7 @@ template <> struct MfmaT<float> {
 };
 
 template <bool TA, bool TB, int WT, typename TS, typename TC>
-__global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
+__global__ __launch_bounds__(256, (WT >= 4 ? 2 : 4)) void k_gemm_batched(GemmArgs g) {
     typedef MfmaT<TC> MF;
     constexpr int HT = 32 * WT, HLD = HT + MF::PAD, NH = HT / 16;
     extern __shared__ __align__(16) unsigned char hs_raw[];
@@ -86,14 +87,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
         for (int b = 0; b < WT; ++b) acc[a][b] = typename MF::acc_t{0, 0, 0, 0};
     // staging coordinates: NH elements per operand per thread
     //   operand stored [x][k] (k contiguous): k = tid & 15, x = (tid >> 4) + 16 h
-    //   operand stored [k][x] (x contiguous): x = tid % HT, k = tid / HT + (256 / HT) h
-    constexpr int KS = 256 / HT;
+    //   operand stored [k][x] (x contiguous): element e = tid + 256 h of the GK x HT panel, k = e / HT, x = e % HT
+    //   (for HT | 256 that is x = tid % HT, k = tid / HT + (256 / HT) h; HT = 160 needs the general form)
     TC ra[NH], rb[NH];
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             if (TA) {
-                const int i = tid % HT, k = tid / HT + KS * h, gi = i0 + i, gk = k0 + k;
+                const int e = tid + 256 * h, i = e % HT, k = e / HT, gi = i0 + i, gk = k0 + k;
                 ra[h] = (gi < g.M && gk < g.K) ? (TC)A[(size_t)gk * g.lda + gi] : TC(0);
             } else {
                 const int k = tid & 15, i = (tid >> 4) + 16 * h, gi = i0 + i, gk = k0 + k;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
                 const int k = tid & 15, j = (tid >> 4) + 16 * h, gj = j0 + j, gk = k0 + k;
                 rb[h] = (gj < g.N && gk < g.K) ? (TC)B[(size_t)gj * g.ldb + gk] : TC(0);
             } else {
-                const int j = tid % HT, k = tid / HT + KS * h, gj = j0 + j, gk = k0 + k;
+                const int e = tid + 256 * h, j = e % HT, k = e / HT, gj = j0 + j, gk = k0 + k;
                 rb[h] = (gj < g.N && gk < g.K) ? (TC)B[(size_t)gk * g.ldb + gj] : TC(0);
             }
         }
@@ -113,10 +114,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
         TC* Bd = Bs + buf * GK * HLD;
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
-            if (TA) Ad[(tid / HT + KS * h) * HLD + tid % HT] = ra[h];
+            if (TA) Ad[((tid + 256 * h) / HT) * HLD + (tid + 256 * h) % HT] = ra[h];
             else Ad[(tid & 15) * HLD + (tid >> 4) + 16 * h] = ra[h];
             if (TB) Bd[(tid & 15) * HLD + (tid >> 4) + 16 * h] = rb[h];
-            else Bd[(tid / HT + KS * h) * HLD + tid % HT] = rb[h];
+            else Bd[((tid + 256 * h) / HT) * HLD + (tid + 256 * h) % HT] = rb[h];
         }
     };
     fetch(klo);
@@ -155,6 +156,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
                 if (gi < g.M && gj < g.N) {
                     const size_t o = (size_t)gi * g.ldc + gj;
                     C[o] = (TS)(g.alpha * (real)acc[a][b][e] + (has_beta ? g.beta * (real)C[o] : real(0)));
+                    if ((g.tri & 16) && i0 != j0) {          // mirror of a below-diagonal tile
+                        const size_t oT = (size_t)gj * g.ldc + gi;
+                        C[oT] = (TS)(g.alpha * (real)acc[a][b][e] + (has_beta ? g.beta * (real)C[oT] : real(0)));
+                    }
                 }
             }
 }
@@ -608,6 +613,8 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     const double cost2 = (double)((M + 63) / 64) * ((N + 63) / 64) * 4096.0 / 52.9;
     // fewer than one 64 x 64 tile per CU: 32 x 32 tiles (4x the workgroups; 256^3 batch 1: 18.3 -> 9.0 us)
     const long long blocks64 = (long long)((N + 63) / 64) * ((M + 63) / 64) * batch;
+    // (tried: 160 x 160 tiles, 5 x 5 MFMA tiles per wave, no padding at m = 800 -- 512 registers per lane plus spills and one
+    // wave per SIMD: 25-38 TFLOP/s at 800^3 x 64 against 41-46 for the 64-tiles; removed)
     const int wt = (blocks128 >= 192 && cost4 <= cost2) ? 4 : (blocks64 < 256 ? 1 : 2), ht = 32 * wt;
     const size_t lds = prec == 0 ? (size_t)4 * GK * (ht + 2) * sizeof(double) : (size_t)4 * GK * (ht + 16) * sizeof(float);
     g.tiles_n = (N + ht - 1) / ht; g.tiles_m = (M + ht - 1) / ht; g.batch = batch;
@@ -661,6 +668,16 @@ extern "C" int svgp_sgemm_batched(int ta, int tb, int M, int N, int K, float alp
                                   long long strideA, const float* B, int ldb, long long strideB, float beta, float* C,
                                   int ldc, long long strideC, int batch, void* stream) {
     return gemm_launch(2, 0, ta, tb, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, stream);
+}
+
+// C = alpha op(A) op(B) + beta C for a product known to be SYMMETRIC (M == N): only the tiles that touch the lower triangle
+// are computed, each below-diagonal tile is stored twice (itself and transposed) -- 45 % fewer tiles at 13 x 13.
+// f32c != 0: float32 MFMA arithmetic on the float64 matrices.
+int svgp_dgemm_symout_batched(int f32c, int ta, int tb, int M, int K, double alpha, const double* A, int lda, long long strideA,
+                              const double* B, int ldb, long long strideB, double beta, double* C, int ldc, long long strideC,
+                              int batch, void* stream) {
+    return gemm_launch(f32c ? 1 : 0, 1 | 16, ta, tb, M, M, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch,
+                       stream);
 }
 
 // the float64 GEMM with triangular structure hints (see GemmArgs::tri); tiles / k-panels that the hints exclude are

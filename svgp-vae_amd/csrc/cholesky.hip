@@ -20,48 +20,98 @@ __device__ __forceinline__ real wave_sum_c(real x) {
     return x;
 }
 
-// In-LDS lower Cholesky of the n x n block in Ls (n <= 64, 256 threads), unblocked right-looking; returns nothing,
-// Ls lower triangle = L, strict upper triangle zeroed.  A non-positive pivot yields NaN (sqrt), as LAPACK's failure would.
-__device__ __forceinline__ void chol64_lds(real (*Ls)[CLD], int n) {
-    const int tid = threadIdx.x;
-    for (int k = 0; k < n; ++k) {
+// Lower Cholesky of the 64 x 64 block in Ls (identity-padded beyond n; 256 threads), unblocked right-looking with the
+// matrix in REGISTERS: thread (ti = tid >> 4, tj = tid & 15) owns the 16 elements (ti + 16 a, tj + 16 b).  Per column k the
+// owners of that column publish it (64 values) through a double-buffered LDS vector -- one barrier per column and 16 FMAs
+// per thread; the first version kept the matrix in LDS (3 barriers, 4 LDS accesses per update, an integer division per
+// element): 113 us per diagonal block at m = 800 against the GEMMs' 40-90 us per block step.
+// Ls lower triangle <- L, strict upper triangle <- 0.  A non-positive pivot yields NaN (sqrt), as LAPACK's failure would.
+// 1 / sqrt(x): v_rsq_f64 (about 2^-26) + two Newton steps y <- y + y/2 (1 - x y^2); sqrt(x) = x * (1 / sqrt(x)).  The library
+// sqrt() and the IEEE division each expand to a chain of ~25 dependent float64 instructions, and one of each sat on the
+// critical path of every column of the diagonal-block factorisation.  A non-positive x gives NaN / inf, as sqrt would.
+__device__ __forceinline__ real fast_rsqrt(real x) {
+    real y = __builtin_amdgcn_rsq(x);
+    real e = fma(-x * y, y, real(1));
+    y = fma(real(0.5) * y, e, y);
+    e = fma(-x * y, y, real(1));
+    y = fma(real(0.5) * y, e, y);
+    return y;
+}
+// rdiag[k] receives 1 / L_kk (the triangular inverse multiplies by it instead of dividing)
+// (Loading the thread's 16 elements straight from global memory instead of through the LDS image was measured slower:
+// 79 against 58 us per launch of the diagonal-block kernel at m = 800, batch 65.)
+__device__ __forceinline__ void chol64_lds(real (*Ls)[CLD], real (*colk)[CB], real* rdiag) {
+    const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+    real r[4][4];
+    __syncthreads();                                  // the caller has just filled Ls
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) r[a][b] = Ls[ti + 16 * a][tj + 16 * b];
+#pragma unroll
+    for (int k = 0; k < CB; ++k) {
+        const int kb = k >> 4, kr = k & 15;          // compile-time after unrolling
+        real* ck = colk[k & 1];
+        if (tj == kr) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) ck[ti + 16 * a] = r[a][kb];
+        }
         __syncthreads();
-        const real sd = sqrt(Ls[k][k]), rd = real(1) / sd;
-        __syncthreads();
-        if (tid >= k && tid < n) Ls[tid][k] = (tid == k) ? sd : Ls[tid][k] * rd;
-        __syncthreads();
-        const int w = n - 1 - k;                       // trailing size
-        for (int e = tid; e < w * w; e += blockDim.x) {
-            const int i = k + 1 + e / w, j = k + 1 + e % w;
-            if (j <= i) Ls[i][j] -= Ls[i][k] * Ls[j][k];
+        const real rd = fast_rsqrt(ck[k]), sd = ck[k] * rd;
+        if (tid == 0) rdiag[k] = rd;
+        real li[4], lj[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) li[a] = (ti + 16 * a > k) ? ck[ti + 16 * a] * rd : real(0);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) lj[b] = (tj + 16 * b > k) ? ck[tj + 16 * b] * rd : real(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) r[a][b] -= li[a] * lj[b];
+        if (tj == kr) {                               // the finished column k
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int i = ti + 16 * a;
+                r[a][kb] = i == k ? sd : (i > k ? li[a] : r[a][kb]);
+            }
         }
     }
     __syncthreads();
-    for (int e = tid; e < CB * CB; e += blockDim.x) {
-        const int i = e / CB, j = e % CB;
-        if (j > i || i >= n || j >= n) Ls[i][j] = (i == j) ? real(1) : real(0);     // identity pad beyond n
-    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int i = ti + 16 * a, j = tj + 16 * b;
+            Ls[i][j] = j <= i ? r[a][b] : real(0);
+        }
     __syncthreads();
 }
 
-// X = L^-1 for the lower-triangular 64 x 64 block in Ls (identity-padded): 4 threads per column split the inner
-// products, forward substitution down the column; Xs gets the full block (zeros above the diagonal).
-__device__ __forceinline__ void trinv64_lds(const real (*Ls)[CLD], real (*Xs)[CLD]) {
-    const int tid = threadIdx.x, j = tid >> 2, part = tid & 3;        // column j, quarter `part` of the k-range
-    for (int e = tid; e < CB * CB; e += blockDim.x) Xs[e / CB][e % CB] = real(0);
+// X = L^-1 for the lower-triangular 64 x 64 block in Ls (identity-padded).  Lane j of wave 0 solves L x = e_j with x in
+// registers: x_i = ((i == j) - sum_{k < i} l_ik x_k) / l_ii -- entries above the diagonal come out as exact zeros, so the
+// code is lane-uniform, the l_ik reads are LDS broadcasts and there is no barrier (the first version walked the rows
+// with 4 threads per column and one barrier per row: most of the 77 us the diagonal-block kernel still took).
+// Xs gets the full block (zeros above the diagonal).
+__device__ __forceinline__ void trinv64_lds(const real (*Ls)[CLD], real (*Xs)[CLD], const real* rdiag) {
     __syncthreads();
-    if (part == 0) Xs[j][j] = real(1) / Ls[j][j];
-    __syncthreads();
-    for (int i = 1; i < CB; ++i) {
-        // x_ij = -(sum_{k=j}^{i-1} l_ik x_kj) / l_ii   for every column j < i
-        real s = 0;
-        if (j < i)
-            for (int k = j + part; k < i; k += 4) s += Ls[i][k] * Xs[k][j];
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
-        if (part == 0 && j < i) Xs[i][j] = -s / Ls[i][i];
-        __syncthreads();
+    if (threadIdx.x < CB) {
+        const int j = threadIdx.x;
+        real x[CB];
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+            real s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // four partial sums: the chain of dependent FMAs is the cost
+#pragma unroll
+            for (int k = 0; k + 3 < i; k += 4) {
+                s0 += Ls[i][k] * x[k]; s1 += Ls[i][k + 1] * x[k + 1]; s2 += Ls[i][k + 2] * x[k + 2]; s3 += Ls[i][k + 3] * x[k + 3];
+            }
+#pragma unroll
+            for (int k = i & ~3; k < i; ++k) s0 += Ls[i][k] * x[k];
+            x[i] = ((i == j ? real(1) : real(0)) - ((s0 + s1) + (s2 + s3))) * rdiag[i];
+        }
+#pragma unroll
+        for (int i = 0; i < CB; ++i) Xs[i][j] = x[i];
     }
+    __syncthreads();
 }
 
 struct DiagArgs {
@@ -73,20 +123,26 @@ struct DiagArgs {
     real* logdet;     // (batch): += 2 sum log diag  (= when first)
 };
 // one workgroup per matrix: Cholesky of the diagonal block + inverse of its factor + log det contribution
+// dynamic LDS (DIAG_LDS_BYTES: two padded 64 x 64 blocks + the column buffer = 67.6 KB, above the 64 KB a kernel gets
+// without hipFuncAttributeMaxDynamicSharedMemorySize)
+#define DIAG_LDS_BYTES ((2 * CB * CLD + 3 * CB) * sizeof(real))
 __global__ __launch_bounds__(256) void k_chol_diag(DiagArgs g) {
-    __shared__ real Ls[CB][CLD];
-    __shared__ real Xs[CB][CLD];
+    extern __shared__ __align__(16) unsigned char diag_lds[];
+    real (*Ls)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds);
+    real (*Xs)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + CB * CLD * sizeof(real));
+    real (*colk)[CB] = reinterpret_cast<real (*)[CB]>(diag_lds + 2 * CB * CLD * sizeof(real));
+    real* rdiag = reinterpret_cast<real*>(diag_lds + (2 * CB * CLD + 2 * CB) * sizeof(real));
     const int l = blockIdx.x, n = g.nbk;
     real* A = g.A + (size_t)l * g.sA + (size_t)g.r0 * g.lda + g.r0;
     for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
         const int i = e / CB, j = e % CB;
-        Ls[i][j] = (i < n && j < n) ? A[(size_t)i * g.lda + j] : (i == j ? real(1) : real(0));
+        Ls[i][j] = (i < n && j < n) ? A[(size_t)i * g.lda + j] : (i == j ? real(1) : real(0));     // identity pad
     }
-    chol64_lds(Ls, n);
+    chol64_lds(Ls, colk, rdiag);
     real lg = (threadIdx.x < n) ? log(Ls[threadIdx.x][threadIdx.x]) : real(0);
     lg = wave_sum_c(lg);
     if (threadIdx.x == 0) g.logdet[l] = (g.first ? real(0) : g.logdet[l]) + real(2) * lg;
-    trinv64_lds(Ls, Xs);
+    trinv64_lds(Ls, Xs, rdiag);
     real* Xo = g.Linv + ((size_t)l * g.nblk + g.r0 / CB) * CB * CB;
     for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
         const int i = e / CB, j = e % CB;
@@ -103,16 +159,30 @@ struct TriDiagArgs {
     real* Linv;       // (batch, nblk, 64, 64)
 };
 __global__ __launch_bounds__(256) void k_tri_diag_inv(TriDiagArgs g) {
-    __shared__ real Ls[CB][CLD];
-    __shared__ real Xs[CB][CLD];
+    extern __shared__ __align__(16) unsigned char diag_lds[];
+    real (*Ls)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds);
+    real (*Xs)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + CB * CLD * sizeof(real));
     const int kb = blockIdx.x, l = blockIdx.y, r0 = kb * CB, n = min(CB, g.m - r0);
     const real* L = g.L + (size_t)l * g.sL + (size_t)r0 * g.ldl + r0;
-    for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
-        const int i = e / CB, j = e % CB;
-        Ls[i][j] = (i < n && j < n && j <= i) ? L[(size_t)i * g.ldl + j] : (i == j ? real(1) : real(0));
+    {   // 16 independent loads per thread in flight, then the LDS stores
+        const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+        real r[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int i = ti + 16 * a, j = tj + 16 * b;
+                r[a][b] = (i < n && j < n && j <= i) ? L[(size_t)i * g.ldl + j] : (i == j ? real(1) : real(0));
+            }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) Ls[ti + 16 * a][tj + 16 * b] = r[a][b];
     }
+    real* rdiag = reinterpret_cast<real*>(diag_lds + (2 * CB * CLD + 2 * CB) * sizeof(real));
     __syncthreads();
-    trinv64_lds(Ls, Xs);
+    if (threadIdx.x < CB) rdiag[threadIdx.x] = real(1) / Ls[threadIdx.x][threadIdx.x];
+    trinv64_lds(Ls, Xs, rdiag);
     real* Xo = g.Linv + ((size_t)l * g.nblk + kb) * CB * CB;
     for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) Xo[e] = Xs[e / CB][e % CB];
 }
@@ -178,12 +248,14 @@ extern "C" int svgp_potrf_batched(int m, int batch, double* A, int lda, long lon
     const int nblk = (m + CB - 1) / CB;
     real* Linv = work;
     real* Pn = work + (size_t)batch * nblk * CB * CB;           // (batch, m, 64) scaled panel of the current step
+    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)DIAG_LDS_BYTES));
     DiagArgs d;
     d.m = m; d.lda = lda; d.batch = batch; d.sA = strideA; d.A = A; d.Linv = Linv; d.nblk = nblk; d.logdet = logdet;
     for (int kb = 0; kb < nblk; ++kb) {
         const int r0 = kb * CB, nbk = m - r0 < CB ? m - r0 : CB, rem = m - r0 - nbk;
         d.r0 = r0; d.nbk = nbk; d.first = kb == 0;
-        hipLaunchKernelGGL(k_chol_diag, dim3(batch), dim3(256), 0, s, d);
+        hipLaunchKernelGGL(k_chol_diag, dim3(batch), dim3(256), DIAG_LDS_BYTES, s, d);
         SVGP_LAUNCH_CHECK();
         if (rem == 0) break;
         real* panel = A + (size_t)(r0 + nbk) * lda + r0;        // A[r0+nbk:, r0:r0+nbk]
@@ -220,7 +292,9 @@ extern "C" int svgp_trsm_batched(int side, int trans, int m, int n, const double
     const long long sLi = strideL == 0 ? 0 : (long long)nblk * CB * CB;
     TriDiagArgs td;
     td.m = m; td.ldl = ldl; td.nblk = nblk; td.sL = strideL; td.L = L; td.Linv = Linv;
-    hipLaunchKernelGGL(k_tri_diag_inv, dim3(nblk, nL), dim3(256), 0, s, td);
+    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tri_diag_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)DIAG_LDS_BYTES));
+    hipLaunchKernelGGL(k_tri_diag_inv, dim3(nblk, nL), dim3(256), DIAG_LDS_BYTES, s, td);
     SVGP_LAUNCH_CHECK();
     // forward over the blocks when (left, no-trans) or (right, trans); backward otherwise
     const bool fwd = (side == 0) == (trans == 0);
@@ -296,7 +370,9 @@ extern "C" int svgp_potri_batched(int m, int batch, double* A, const double* lin
     if (linv_blocks == nullptr) {
         TriDiagArgs td;
         td.m = m; td.ldl = m; td.nblk = nblk; td.sL = mm; td.L = A; td.Linv = Linv;
-        hipLaunchKernelGGL(k_tri_diag_inv, dim3(nblk, batch), dim3(256), 0, s, td);
+        SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_tri_diag_inv),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIAG_LDS_BYTES));
+        hipLaunchKernelGGL(k_tri_diag_inv, dim3(nblk, batch), dim3(256), DIAG_LDS_BYTES, s, td);
         SVGP_LAUNCH_CHECK();
         linv_blocks = Linv;
     }

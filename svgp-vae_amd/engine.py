@@ -397,6 +397,53 @@ class MnistStepEngine:
                 be = _PhaseAdapter(self, adam)
                 DataParallelStep(be, group).step()
 
+    def channel_sharded(self):
+        """True when svgp_mnist_train_step_dp takes the channel-sharded schedule for this engine (large-m path, L
+        divisible by the rank count, Hensman branch)."""
+        return (self.world_size > 1 and self.base["m"] > 64 and self.base["L"] % self.world_size == 0
+                and not self.base["titsias"] and not self.base.get("kl_form", 0))
+
+    def sharded_stages(self, adam=True):
+        """The channel-sharded data-parallel step (svgp_mnist_train_step_dp, m > 64) stage by stage: a generator that
+        enqueues the stages between two exchange points and yields the list of ExchangeOp of that point.  The C entry
+        point issues exactly this sequence with the RCCL collectives in between; this form exists so that the schedule
+        can be executed with virtual ranks on one GPU (tests/test_gpu_dp_virtual.py)."""
+        assert self.base["m"] > 64 and self.base["L"] % self.world_size == 0
+        images, aux, eps = self._bound
+        cfg = self._make_cfg(self.cfg.b, self.cfg.b_global)
+        cfg.rep_weight = 1.0                      # every rank's Kbar share counts
+        cp, th, ws, st, s = C.byref(cfg), self.theta.data_ptr(), self.ws.data_ptr(), self.state.data_ptr(), \
+            self.stream.cuda_stream
+        im, ax, ep = images.data_ptr(), aux.data_ptr(), (eps.data_ptr() if eps is not None else None)
+        L, m, G = self.base["L"], self.base["m"], self.world_size
+        nl, l0 = L // G, self.rank * (L // G)
+        fld = lambda name, per: self.ws[getattr(self.wl, name):getattr(self.wl, name) + L * per]
+        ops = lambda kind, *fields: [ExchangeOp(kind, fld(n, per)) for n, per in fields]
+        mm = m * m
+        with torch.cuda.stream(self.stream):
+            call("svgp_mnist_encoder_kernel_matrix_fwd", cp, th, im, ax, ws, s)
+            call("svgp_gp_stats_fwd", cp, ws, s)
+        yield ops("reduce_scatter", ("S", mm), ("v", m))
+        with torch.cuda.stream(self.stream):
+            call("svgp_gp_factor_fwd_channels", cp, l0, nl, ws, s)
+        yield ops("allgather", ("Si", mm), ("M2", mm), ("t", m), ("u", m), ("KL", 1))
+        with torch.cuda.stream(self.stream):
+            call("svgp_gp_posterior_fwd", cp, ep, ws, st, s)
+            call("svgp_mnist_decoder_fwd", cp, th, im, ws, s)
+            call("svgp_mnist_decoder_bwd", cp, th, im, ws, st, s)
+            call("svgp_gp_stats_bwd", cp, ws, st, s)
+        yield ops("reduce_scatter", ("A2", mm), ("ud", m), ("td", m))
+        with torch.cuda.stream(self.stream):
+            call("svgp_gp_factor_bwd_channels", cp, l0, nl, ws, st, s)
+        yield ops("allgather", ("Qm", mm), ("Ssym", mm), ("vbar", m))
+        with torch.cuda.stream(self.stream):
+            call("svgp_gp_posterior_bwd", cp, ws, st, s)
+            call("svgp_kernel_matrix_bwd_partials", cp, th, ax, ws, s)
+            call("svgp_mnist_encoder_bwd", cp, th, im, ws, s)
+            call("svgp_mnist_grad_reduce_all", cp, ax, ws, s)
+        yield [ExchangeOp("allreduce", self.block("gradC"))]
+        self.phase(3, adam)
+
     # hipGraph capture / replay through the library (not torch.cuda.graphs)
     def capture(self, key, adam=True):
         """Captures the 4 phases (single GPU) into a hipGraph stored under `key`."""

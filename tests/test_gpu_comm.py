@@ -62,6 +62,36 @@ def test_dp_entry_equals_single_gpu_step(golden):
     b_.comm.close()
 
 
+def test_channel_sharded_dp_entry_equals_single_gpu_step_large_m():
+    """m > 64: svgp_mnist_train_step_dp takes the channel-sharded sequence (reduce-scatter / window factor stages /
+    all-gather); with a 1-rank communicator the collectives are identities and the window is all channels, so three
+    Adam steps must reproduce svgp_mnist_train_step (same kernels; the deferred phase forms do not exist for m > 64)."""
+    from svgp_vae_amd.engine import RcclComm
+    params, images, aux, eps = H.toy_problem(b=96, m=72, L=4, M=16, n_obj=40, seed=5)
+    kw = dict(geco=True, N_train=4050.0, jitter=1e-4)
+    a = H.engine_for(params, 96, **kw)
+    b_ = H.engine_for(params, 96, **kw)
+    comm = RcclComm(0, 1, RcclComm.unique_id())
+    x = torch.arange(24, dtype=torch.float64, device="cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    comm.reduce_scatter(x, s); comm.all_gather(x, s)
+    torch.cuda.synchronize()
+    assert torch.equal(x.cpu(), torch.arange(24, dtype=torch.float64))
+    b_.attach_comm(comm)
+    dev = a.device
+    di, da, de = images.to(dev), aux.to(dev), eps.to(dev)
+    a.bind(di, da, de); b_.bind(di, da, de)
+    for _ in range(3):
+        a.run(adam=True)
+        b_.run(adam=True)
+    a.synchronize(); b_.synchronize()
+    assert H.relerr(b_.theta, a.theta) < 1e-12
+    sa, sb = a.scalars(), b_.scalars()
+    for k in ("elbo", "recon_loss", "kl_term", "c_ma", "lagrange", "adam_t"):
+        assert abs(sa[k] - sb[k]) <= 1e-12 * max(1.0, abs(sa[k])), k
+    comm.close()
+
+
 def test_bench_multi_gpu_code_path_at_world_size_one():
     """`bench.py --force-dist` under torchrun with ONE rank: the N>1 code path end to end -- NCCL process group, the
     communicator bootstrap through broadcast_object_list, barriers, the MAX all-reduce of the time, teardown -- for both

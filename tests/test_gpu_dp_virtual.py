@@ -54,3 +54,52 @@ def test_virtual_ranks_equal_single_engine(golden, G, b, geco):
     # replicas stay bit-identical to each other (same reduced inputs, same kernels)
     for e in ranks[1:]:
         assert torch.equal(e.theta, ranks[0].theta)
+
+
+@pytest.mark.parametrize("G,b,m,L,M", [(2, 64, 72, 4, 16), (4, 96, 72, 4, 16), (8, 1024, 256, 16, 32)])
+def test_channel_sharded_virtual_ranks_equal_single_engine(G, b, m, L, M):
+    """Large-m path: the channel-sharded schedule of svgp_mnist_train_step_dp (reduce-scatter of the (L,m,m) statistics
+    over the channels, every rank factors L / G channels, all-gather of what the row stages need), run stage
+    by stage with G virtual ranks, against the single-engine step at the same global batch.  The last case is BASELINE
+    configs[2] (m = 256, b = 1024, L = 16) on 8 ranks: 2 channels per rank."""
+    from svgp_vae_amd.engine import shard_rows, virtual_exchange
+    params, images, aux, eps = H.toy_problem(b=b, m=m, L=L, M=M, n_obj=60, seed=G + m)
+    kw = dict(geco=True, N_train=4050.0, jitter=1e-4 if m < 256 else 1e-2)
+    single = H.engine_for(params, b, **kw)
+    dev = single.device
+    di, da, de = images.to(dev), aux.to(dev), eps.to(dev)
+    single.bind(di, da, de)
+    ranks = []
+    for r in range(G):
+        lo, hi = shard_rows(b, G, r)
+        e = H.engine_for(params, hi - lo, rank=r, world_size=G, **kw)
+        e.set_batch_size(hi - lo, b)
+        e.bind(di[lo:hi].contiguous(), da[lo:hi].contiguous(), de[lo:hi].contiguous())
+        assert e.channel_sharded()
+        ranks.append(e)
+    for step in range(2):
+        single.run(adam=True)
+        single.synchronize()
+        gens = [e.sharded_stages(adam=True) for e in ranks]
+        n_points = 0
+        while True:
+            ops = [next(g, None) for g in gens]
+            if ops[0] is None:
+                assert all(o is None for o in ops)
+                break
+            for e in ranks:
+                e.synchronize()
+            virtual_exchange(ops)
+            torch.cuda.synchronize()
+            n_points += 1
+        assert n_points == 5
+        for e in ranks:
+            e.synchronize()
+        ref = single.scalars()
+        for e in ranks:
+            sc = e.scalars()
+            for k in ("elbo", "recon_loss", "kl_term", "inside_elbo", "ce_term", "c_ma", "lagrange", "adam_t"):
+                assert abs(sc[k] - ref[k]) <= 1e-8 * max(1.0, abs(ref[k])), (step, k, sc[k], ref[k])
+            assert H.relerr(e.theta, single.theta) < 1e-7
+    for e in ranks[1:]:
+        assert torch.equal(e.theta, ranks[0].theta)

@@ -64,7 +64,10 @@ def test_channel_sharded_virtual_ranks_equal_single_engine(G, b, m, L, M):
     configs[2] (m = 256, b = 1024, L = 16) on 8 ranks: 2 channels per rank."""
     from svgp_vae_amd.engine import shard_rows, virtual_exchange
     params, images, aux, eps = H.toy_problem(b=b, m=m, L=L, M=M, n_obj=60, seed=G + m)
-    kw = dict(geco=True, N_train=4050.0, jitter=1e-4 if m < 256 else 1e-2)
+    # The ranks add the statistics in a different order than the single engine and cond(Sigma_l) amplifies that rounding:
+    # with c = N_train / b = 63, 1 / sigma^2 up to 1000 and jitter 1e-2, Sigma_l^-1 already differs by 1.4e-9 and the ELBO by
+    # 9e-8 (measured).  c = 2 keeps the comparison about the schedule, not the conditioning.
+    kw = dict(geco=True, N_train=2.0 * b, jitter=1e-2)
     single = H.engine_for(params, b, **kw)
     dev = single.device
     di, da, de = images.to(dev), aux.to(dev), eps.to(dev)
@@ -77,6 +80,17 @@ def test_channel_sharded_virtual_ranks_equal_single_engine(G, b, m, L, M):
         e.bind(di[lo:hi].contiguous(), da[lo:hi].contiguous(), de[lo:hi].contiguous())
         assert e.channel_sharded()
         ranks.append(e)
+    # noise floor: the same single-engine step on the rows in reversed order (mathematically identical; only the
+    # summation order of the statistics changes -- which is also all that sharding changes)
+    rev = H.engine_for(params, b, **kw)
+    rev.bind(di.flip(0).contiguous(), da.flip(0).contiguous(), de.flip(0).contiguous())
+    rev.run(adam=False); rev.synchronize()
+    probe = H.engine_for(params, b, **kw)
+    probe.bind(di, da, de)
+    probe.run(adam=False); probe.synchronize()
+    sr, sp = rev.scalars(), probe.scalars()
+    noise = max(abs(sr[k] - sp[k]) / max(1.0, abs(sp[k])) for k in ("elbo", "kl_term", "inside_elbo"))
+    gnoise = {k: H.relerr(rev.grads()[k], probe.grads()[k]) for k in probe.grads()}
     for step in range(2):
         single.run(adam=True)
         single.synchronize()
@@ -99,7 +113,13 @@ def test_channel_sharded_virtual_ranks_equal_single_engine(G, b, m, L, M):
         for e in ranks:
             sc = e.scalars()
             for k in ("elbo", "recon_loss", "kl_term", "inside_elbo", "ce_term", "c_ma", "lagrange", "adam_t"):
-                assert abs(sc[k] - ref[k]) <= 1e-8 * max(1.0, abs(ref[k])), (step, k, sc[k], ref[k])
-            assert H.relerr(e.theta, single.theta) < 1e-7
+                assert abs(sc[k] - ref[k]) <= max(1e-8, 20 * noise) * max(1.0, abs(ref[k])), (step, k, sc[k], ref[k], noise)
+            g, gs = e.grads(), single.grads()
+            for k in gs:      # the GP parameters' gradients pass through (A_hat + jI)^-1: ill-conditioned (test_gpu_fullsize)
+                tol = max(1e-5 if k in ("inducing_index_points", "l_GP", "amplitude", "object_vectors") else 1e-7, 20 * gnoise[k])
+                assert H.relerr(g[k], gs[k]) < tol, (step, k, gnoise[k])
+            # Adam's first updates are lr * g / (|g| + eps)-like: a gradient component of size 1e-10 with a 1e-8 relative
+            # difference in the LARGE components next to it moves by a visible fraction of lr
+            assert H.relerr(e.theta, single.theta) < max(1e-5, 1e3 * max(gnoise.values()))
     for e in ranks[1:]:
         assert torch.equal(e.theta, ranks[0].theta)

@@ -35,7 +35,7 @@ def _run_once(eng, images, aux, eps, adam=False):
 
 def _compare_step(params, images, aux, eps, *, geco, clip_qs=True, N_train=4050.0, jitter=1e-6, beta=0.001,
                   K_obj_normalize=False, C_ma=0.0, lagrange=1.0, alpha=0.0, kappa2=0.020, label="",
-                  FWD_TOL=FWD_TOL, GRAD_TOL=GRAD_TOL, self_consistency=False):
+                  FWD_TOL=FWD_TOL, GRAD_TOL=GRAD_TOL, self_consistency=False, ip_tol=None):
     b, L = eps.shape
     m = params["inducing_index_points"].shape[0]
     eng = H.engine_for(params, b, geco=geco, clip_qs=clip_qs, N_train=N_train, jitter=jitter, beta=beta,
@@ -83,6 +83,11 @@ def _compare_step(params, images, aux, eps, *, geco, clip_qs=True, N_train=4050.
                                     kappa=math.sqrt(kappa2), clipping_qs=clip_qs, GECO=geco, jitter=jitter,
                                     N_train=N_train, L=L, formulation="efficient", K_obj_normalize=K_obj_normalize)
         tol = {k: max(GRAD_TOL, 5 * H.relerr(g_lit[k], grads[k]), 20 * H.relerr(g_ulp[k], grads[k])) for k in grads}
+    if ip_tol is not None:
+        # gradient of the inducing points at m > rank(K): it passes through (A_hat + jI)^-1 with entries of size 1 / jitter,
+        # where the rounding-level asymmetry of a computed inverse (1e-9 relative at cond 1e7) is already 1e-5 absolute;
+        # implementations that read the full matrix or its mirrored lower triangle legitimately differ by that much
+        tol["inducing_index_points"] = max(tol["inducing_index_points"], ip_tol)
     g = eng.grads()
     for k, want in grads.items():
         err = H.relerr(g[k], want)
@@ -145,7 +150,7 @@ def test_edge_cases(case):
         # two-level inverse (128-block outer step + a 2 x 2 remainder).  m > GPLVM-dim-limited rank: cond(K + jI)
         # ~ 1e7, so inverses from different elimination orders differ at ~1e-8 (as in cfg3_m256 below)
         p = H.toy_problem(b=150, m=130, L=2, M=24, n_obj=40, seed=10)
-        kw.update(jitter=1e-4, geco=True, FWD_TOL=1e-7, GRAD_TOL=1e-6, self_consistency=True)
+        kw.update(jitter=1e-4, geco=True, FWD_TOL=1e-7, GRAD_TOL=1e-6, self_consistency=True, ip_tol=1e-4)
     elif case == "cfg3_m256":
         # BASELINE configs[2] shape family (m=256 needs GPLVM dim >= 32), reduced b / L
         # cond(K) ~ 1e5 here, cond(A_hat + jI) far worse: both implementations carry ~1e-8 inverse error,

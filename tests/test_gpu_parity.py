@@ -35,7 +35,7 @@ def _run_once(eng, images, aux, eps, adam=False):
 
 def _compare_step(params, images, aux, eps, *, geco, clip_qs=True, N_train=4050.0, jitter=1e-6, beta=0.001,
                   K_obj_normalize=False, C_ma=0.0, lagrange=1.0, alpha=0.0, kappa2=0.020, label="",
-                  FWD_TOL=FWD_TOL, GRAD_TOL=GRAD_TOL, self_consistency=False, ip_tol=None):
+                  FWD_TOL=FWD_TOL, GRAD_TOL=GRAD_TOL, self_consistency=False):
     b, L = eps.shape
     m = params["inducing_index_points"].shape[0]
     eng = H.engine_for(params, b, geco=geco, clip_qs=clip_qs, N_train=N_train, jitter=jitter, beta=beta,
@@ -45,20 +45,44 @@ def _compare_step(params, images, aux, eps, *, geco, clip_qs=True, N_train=4050.
     bad = []
     ref = H.oracle_stages(params, images, aux, eps, N_train=N_train, jitter=jitter, clip_qs=clip_qs, geco=geco,
                           beta=beta, K_obj_normalize=K_obj_normalize)
+    fwd_tol = {name: FWD_TOL for name in FIELD_SHAPES(b, m, L)}
+    p2 = img2 = None
+    if self_consistency:
+        # ill-conditioned cases: the yardstick is the oracle's own response to a one-ulp perturbation of its real inputs
+        # (what any two backward-stable float64 evaluations of these formulas may differ by; tests/test_gpu_fullsize.py);
+        # the HIP result must sit within 20x of it, forward fields, scalars and gradients alike
+        gen = torch.Generator().manual_seed(17)
+        ulp = lambda t: t * (1.0 + 2.0 ** -52 * (torch.randint(0, 2, t.shape, generator=gen).to(DT) * 2 - 1))
+        p2 = {k: ulp(v) for k, v in params.items()}
+        p2["inducing_index_points"][:, 0] = params["inducing_index_points"][:, 0]
+        img2 = ulp(images)
+        ref2 = H.oracle_stages(p2, img2, aux, eps, N_train=N_train, jitter=jitter, clip_qs=clip_qs, geco=geco,
+                               beta=beta, K_obj_normalize=K_obj_normalize)
+        fwd_tol = {name: max(FWD_TOL, 20 * H.relerr(ref2[name], ref[name])) for name in fwd_tol}
     for name, shp in FIELD_SHAPES(b, m, L).items():
         err = H.relerr(eng.ws_view(name, shp), ref[name])
-        if not err < FWD_TOL:
-            bad.append(f"{label} fwd {name}: rel {err:.3e}")
+        if not err < fwd_tol[name]:
+            bad.append(f"{label} fwd {name}: rel {err:.3e} (tol {fwd_tol[name]:.1e})")
     out, grads = O.loss_and_grads(params, images, aux, eps, beta=beta, C_ma=torch.tensor(C_ma, dtype=DT),
                                   lagrange_mult=torch.tensor(lagrange, dtype=DT), alpha=alpha,
                                   kappa=math.sqrt(kappa2), clipping_qs=clip_qs, GECO=geco, jitter=jitter,
                                   N_train=N_train, L=L, formulation="efficient", K_obj_normalize=K_obj_normalize)
     sc = eng.scalars()
+    out_ulp = g_ulp = None
+    if self_consistency:
+        out_ulp, g_ulp = O.loss_and_grads(p2, img2, aux, eps, beta=beta, C_ma=torch.tensor(C_ma, dtype=DT),
+                                          lagrange_mult=torch.tensor(lagrange, dtype=DT), alpha=alpha,
+                                          kappa=math.sqrt(kappa2), clipping_qs=clip_qs, GECO=geco, jitter=jitter,
+                                          N_train=N_train, L=L, formulation="efficient",
+                                          K_obj_normalize=K_obj_normalize)
     for key, idx in (("elbo", 0), ("recon_loss", 1), ("kl_term", 2), ("inside_elbo", 3), ("ce_term", 4),
                      ("inside_recon", 10), ("inside_kl", 11)):
         want = float(out[idx])
-        if not abs(sc[key] - want) <= SCALAR_TOL * max(1.0, abs(want)):
-            bad.append(f"{label} scalar {key}: got {sc[key]!r} want {want!r}")
+        stol = SCALAR_TOL * max(1.0, abs(want))
+        if out_ulp is not None:
+            stol = max(stol, 20 * abs(float(out_ulp[idx]) - want))
+        if not abs(sc[key] - want) <= stol:
+            bad.append(f"{label} scalar {key}: got {sc[key]!r} want {want!r} (tol {stol:.1e})")
     if geco:
         for key, idx in (("c_ma", 13), ("lagrange", 14)):
             want = float(out[idx])
@@ -72,22 +96,8 @@ def _compare_step(params, images, aux, eps, *, geco, clip_qs=True, N_train=4050.
                                     lagrange_mult=torch.tensor(lagrange, dtype=DT), alpha=alpha,
                                     kappa=math.sqrt(kappa2), clipping_qs=clip_qs, GECO=geco, jitter=jitter,
                                     N_train=N_train, L=L, formulation="literal", K_obj_normalize=K_obj_normalize)
-        # ... or within 20x of the oracle's own response to a one-ulp perturbation of its real inputs (what any two
-        # backward-stable float64 evaluations of these formulas may differ by; tests/test_gpu_fullsize.py)
-        gen = torch.Generator().manual_seed(17)
-        ulp = lambda t: t * (1.0 + 2.0 ** -52 * (torch.randint(0, 2, t.shape, generator=gen).to(DT) * 2 - 1))
-        p2 = {k: ulp(v) for k, v in params.items()}
-        p2["inducing_index_points"][:, 0] = params["inducing_index_points"][:, 0]
-        _, g_ulp = O.loss_and_grads(p2, ulp(images), aux, eps, beta=beta, C_ma=torch.tensor(C_ma, dtype=DT),
-                                    lagrange_mult=torch.tensor(lagrange, dtype=DT), alpha=alpha,
-                                    kappa=math.sqrt(kappa2), clipping_qs=clip_qs, GECO=geco, jitter=jitter,
-                                    N_train=N_train, L=L, formulation="efficient", K_obj_normalize=K_obj_normalize)
+        # ... or within 20x of the oracle's response to the one-ulp input perturbation above
         tol = {k: max(GRAD_TOL, 5 * H.relerr(g_lit[k], grads[k]), 20 * H.relerr(g_ulp[k], grads[k])) for k in grads}
-    if ip_tol is not None:
-        # gradient of the inducing points at m > rank(K): it passes through (A_hat + jI)^-1 with entries of size 1 / jitter,
-        # where the rounding-level asymmetry of a computed inverse (1e-9 relative at cond 1e7) is already 1e-5 absolute;
-        # implementations that read the full matrix or its mirrored lower triangle legitimately differ by that much
-        tol["inducing_index_points"] = max(tol["inducing_index_points"], ip_tol)
     g = eng.grads()
     for k, want in grads.items():
         err = H.relerr(g[k], want)
@@ -150,7 +160,7 @@ def test_edge_cases(case):
         # two-level inverse (128-block outer step + a 2 x 2 remainder).  m > GPLVM-dim-limited rank: cond(K + jI)
         # ~ 1e7, so inverses from different elimination orders differ at ~1e-8 (as in cfg3_m256 below)
         p = H.toy_problem(b=150, m=130, L=2, M=24, n_obj=40, seed=10)
-        kw.update(jitter=1e-4, geco=True, FWD_TOL=1e-7, GRAD_TOL=1e-6, self_consistency=True, ip_tol=1e-4)
+        kw.update(jitter=1e-4, geco=True, FWD_TOL=1e-7, GRAD_TOL=1e-6, self_consistency=True)
     elif case == "cfg3_m256":
         # BASELINE configs[2] shape family (m=256 needs GPLVM dim >= 32), reduced b / L
         # cond(K) ~ 1e5 here, cond(A_hat + jI) far worse: both implementations carry ~1e-8 inverse error,

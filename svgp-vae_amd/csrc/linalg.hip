@@ -15,7 +15,9 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // (w>>1, w&1) = WT x WT MFMA 16x16 tiles; k-panels of 16 staged in LDS as As[k][i], Bs[k][j] (k-major:
 // the MFMA operand fetch A[i=lane&15][k=lane>>4] walks 16 consecutive i -> conflict-free).
 // ---------------------------------------------------------------------------------------------
-#define GK 16
+// panel depth: 16 for the 128-tiles (64 MFMAs per wave per panel already cover the load latency), 32 for the 64- and
+// 32-tiles (16 / 4 MFMAs per panel of 16 do not when one workgroup per CU is all the grid offers: config-3 statistics)
+#define GK_OF(WT) 16
 
 struct GemmArgs {
     int M, N, K;            // C is M x N, contraction K
@@ -32,8 +34,8 @@ struct GemmArgs {
     int tri;
 };
 
-// k-panels of 16 are double-buffered in LDS: the global loads of panel p+1 are in flight while the MFMAs of
-// panel p run, one barrier per panel.  Loads are arranged so that 16 lanes cover 128 (f64) / 64 (f32) contiguous
+// k-panels of 16 are double-buffered in LDS and a third one is in flight in registers (see the main loop), one
+// barrier per panel.  Loads are arranged so that 16 lanes cover 128 (f64) / 64 (f32) contiguous
 // bytes of the operand whichever way it is stored.  WT = 4: 128 x 128 tile, 16 flop per staged byte, used
 // when that still gives >= 192 workgroups; WT = 2: 64 x 64 tile for small problems.
 // TS = storage type of A, B, C; TC = arithmetic type of the MFMA (operands converted while staging, accumulation in TC):
@@ -55,10 +57,13 @@ template <> struct MfmaT<float> {
     __device__ static __forceinline__ int row(int q, int e) { return 4 * q + e; }       // C/D: row = 4 (lane >> 4) + reg
 };
 
-template <bool TA, bool TB, int WT, typename TS, typename TC>
+template <bool TA, bool TB, int WT, typename TS, typename TC, bool VEC>
 __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
     typedef MfmaT<TC> MF;
-    constexpr int HT = 32 * WT, HLD = HT + MF::PAD, NH = HT / 16;
+    typedef TS TS2 __attribute__((ext_vector_type(2)));
+    typedef TC TC2 __attribute__((ext_vector_type(2)));
+    constexpr int GK = GK_OF(WT), HT = 32 * WT, HLD = HT + MF::PAD, NP = HT * GK / 512;
+    static_assert(GK == 16 && HLD % 2 == 0, "staging map below: 8 k-pairs x 32 rows per 256 threads");
     extern __shared__ __align__(16) unsigned char hs_raw[];
     TC* hs = reinterpret_cast<TC*>(hs_raw);
     TC* As = hs;                         // [2][GK][HLD]
@@ -86,27 +91,46 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
     for (int a = 0; a < WT; ++a)
 #pragma unroll
         for (int b = 0; b < WT; ++b) acc[a][b] = typename MF::acc_t{0, 0, 0, 0};
-    // staging coordinates: NH elements per operand per thread
-    //   operand stored [x][k] (k contiguous): k = tid & 15, x = (tid >> 4) + 16 h
-    //   operand stored [k][x] (x contiguous): element e = tid + 256 h of the GK x HT panel, k = e / HT, x = e % HT
-    //   (for HT | 256 that is x = tid % HT, k = tid / HT + (256 / HT) h; HT = 160 needs the general form)
-    TC ra[NH], rb[NH];
-    auto fetch = [&](int k0) {
-#pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            if (TA) {
-                const int e = tid + 256 * h, i = e % HT, k = e / HT, gi = i0 + i, gk = k0 + k;
-                ra[h] = (gi < g.M && gk < g.K) ? (TC)A[(size_t)gk * g.lda + gi] : TC(0);
+    // Staging: NP pairs of memory-adjacent elements per operand per thread.
+    //   operand stored [x][k] (k contiguous): the pair (k, k + 1), k = 2 (tid & 7), of row x = (tid >> 3) + 32 h
+    //   operand stored [k][x] (x contiguous): pair e = tid + 256 h of the GK x HT / 2 panel, k = e / (HT / 2), x = 2 (e % (HT / 2))
+    // A tile that lies inside the matrix takes its full panels without bounds checks, as one 16-byte load per pair when
+    // the host found the operands 16-byte aligned with even leading dimensions (VEC): 60 -> 64 TFLOP/s on exact tiles
+    // (tools/micro/gemm_stages.hip), and the checks were worth another 5 %.
+    const bool inside = i0 + HT <= g.M && j0 + HT <= g.N;
+    TC ra[2 * NP], rb[2 * NP];
+    auto ldpair = [&](const TS* __restrict__ p, bool ok0, bool ok1, bool fast, TC& v0, TC& v1) {
+        if (fast) {
+            if (VEC) {
+                const TS2 v = *reinterpret_cast<const TS2*>(p);
+                v0 = (TC)v.x; v1 = (TC)v.y;
             } else {
-                const int k = tid & 15, i = (tid >> 4) + 16 * h, gi = i0 + i, gk = k0 + k;
-                ra[h] = (gi < g.M && gk < g.K) ? (TC)A[(size_t)gi * g.lda + gk] : TC(0);
+                v0 = (TC)p[0]; v1 = (TC)p[1];
+            }
+        } else {
+            v0 = ok0 ? (TC)p[0] : TC(0);
+            v1 = ok1 ? (TC)p[1] : TC(0);
+        }
+    };
+    auto fetch = [&](int k0) {
+        const bool fast = inside && k0 + GK <= g.K;
+#pragma unroll
+        for (int h = 0; h < NP; ++h) {
+            const int e = tid + 256 * h, kx = e / (HT / 2), xx = 2 * (e % (HT / 2));    // [k][x] map
+            const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;                      // [x][k] map
+            if (TA) {
+                const int gi = i0 + xx, gk = k0 + kx;
+                ldpair(A + (size_t)gk * g.lda + gi, gk < g.K && gi < g.M, gk < g.K && gi + 1 < g.M, fast, ra[2 * h], ra[2 * h + 1]);
+            } else {
+                const int gi = i0 + xk, gk = k0 + kk;
+                ldpair(A + (size_t)gi * g.lda + gk, gi < g.M && gk < g.K, gi < g.M && gk + 1 < g.K, fast, ra[2 * h], ra[2 * h + 1]);
             }
             if (TB) {
-                const int k = tid & 15, j = (tid >> 4) + 16 * h, gj = j0 + j, gk = k0 + k;
-                rb[h] = (gj < g.N && gk < g.K) ? (TC)B[(size_t)gj * g.ldb + gk] : TC(0);
+                const int gj = j0 + xk, gk = k0 + kk;
+                ldpair(B + (size_t)gj * g.ldb + gk, gj < g.N && gk < g.K, gj < g.N && gk + 1 < g.K, fast, rb[2 * h], rb[2 * h + 1]);
             } else {
-                const int e = tid + 256 * h, j = e % HT, k = e / HT, gj = j0 + j, gk = k0 + k;
-                rb[h] = (gj < g.N && gk < g.K) ? (TC)B[(size_t)gk * g.ldb + gj] : TC(0);
+                const int gj = j0 + xx, gk = k0 + kx;
+                ldpair(B + (size_t)gk * g.ldb + gj, gk < g.K && gj < g.N, gk < g.K && gj + 1 < g.N, fast, rb[2 * h], rb[2 * h + 1]);
             }
         }
     };
@@ -114,35 +138,59 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
         TC* Ad = As + buf * GK * HLD;
         TC* Bd = Bs + buf * GK * HLD;
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-            if (TA) Ad[((tid + 256 * h) / HT) * HLD + (tid + 256 * h) % HT] = ra[h];
-            else Ad[(tid & 15) * HLD + (tid >> 4) + 16 * h] = ra[h];
-            if (TB) Bd[(tid & 15) * HLD + (tid >> 4) + 16 * h] = rb[h];
-            else Bd[((tid + 256 * h) / HT) * HLD + (tid + 256 * h) % HT] = rb[h];
+        for (int h = 0; h < NP; ++h) {
+            const int e = tid + 256 * h, kx = e / (HT / 2), xx = 2 * (e % (HT / 2));
+            const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;
+            if (TA) {
+                *reinterpret_cast<TC2*>(&Ad[kx * HLD + xx]) = TC2{ra[2 * h], ra[2 * h + 1]};
+            } else {
+                Ad[kk * HLD + xk] = ra[2 * h]; Ad[(kk + 1) * HLD + xk] = ra[2 * h + 1];
+            }
+            if (TB) {
+                Bd[kk * HLD + xk] = rb[2 * h]; Bd[(kk + 1) * HLD + xk] = rb[2 * h + 1];
+            } else {
+                *reinterpret_cast<TC2*>(&Bd[kx * HLD + xx]) = TC2{rb[2 * h], rb[2 * h + 1]};
+            }
         }
     };
+    // Three panels in flight: panel p is multiplied out of LDS buffer `cur`; panel p + 1 (fetched into registers during
+    // panel p - 1) is written to the other LDS buffer after the first of the four MFMA groups has been issued, so that
+    // the LDS stores complete under the remaining three; panel p + 2 then starts its global loads, a full panel of
+    // MFMAs ahead of its use -- the barrier at the end of a panel waits neither for memory nor for the LDS.  The operand
+    // fragments of MFMA group s + 1 are read from LDS before group s issues.  (61.8 -> 64.6 TFLOP/s on exact tiles.)
     fetch(klo);
     stage(0);
+    if (klo + GK < khi) fetch(klo + GK);
     __syncthreads();
     int cur = 0;
     for (int k0 = klo; k0 < khi; k0 += GK) {
-        const bool more = k0 + GK < khi;
-        if (more) fetch(k0 + GK);
         const TC* Ab = As + cur * GK * HLD + wi + r;
         const TC* Bb = Bs + cur * GK * HLD + wj + r;
+        TC av[2][WT], bv[2][WT];
 #pragma unroll
-        for (int kk = 0; kk < GK; kk += 4) {
-            TC av[WT], bv[WT];
+        for (int a = 0; a < WT; ++a) av[0][a] = Ab[q * HLD + 16 * a];
 #pragma unroll
-            for (int a = 0; a < WT; ++a) av[a] = Ab[(kk + q) * HLD + 16 * a];
+        for (int b = 0; b < WT; ++b) bv[0][b] = Bb[q * HLD + 16 * b];
 #pragma unroll
-            for (int b = 0; b < WT; ++b) bv[b] = Bb[(kk + q) * HLD + 16 * b];
+        for (int st = 0; st < GK / 4; ++st) {
+            if (st + 1 < GK / 4) {
+#pragma unroll
+                for (int a = 0; a < WT; ++a) av[(st + 1) & 1][a] = Ab[(4 * (st + 1) + q) * HLD + 16 * a];
+#pragma unroll
+                for (int b = 0; b < WT; ++b) bv[(st + 1) & 1][b] = Bb[(4 * (st + 1) + q) * HLD + 16 * b];
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int a = 0; a < WT; ++a)
 #pragma unroll
-                for (int b = 0; b < WT; ++b) acc[a][b] = MF::mma(av[a], bv[b], acc[a][b]);
+                for (int b = 0; b < WT; ++b) acc[a][b] = MF::mma(av[st & 1][a], bv[st & 1][b], acc[a][b]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (st == 0) {
+                if (k0 + GK < khi) stage(cur ^ 1);
+                if (k0 + 2 * GK < khi) fetch(k0 + 2 * GK);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        if (more) stage(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
@@ -411,12 +459,30 @@ __device__ __forceinline__ d4_t mm32_mfma(const real (*X)[NB + 1], const real (*
     for (int k0 = 0; k0 < NB; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[wi + r][k0 + q], Y[k0 + q][wj + r], acc, 0, 0, 0);
     return acc;
 }
-// grid (nb, nb, batch): tile (bi = y, bj = x) of block step kb
+// grid (nb * nb * batch): one 32 x 32 tile (bi, bj) of matrix l per workgroup, block step kb.  The workgroups that own
+// the NEXT pivot tile (kb + 1, kb + 1) carry the single-wave 32 x 32 sweep (8 us) on top of their tile: they take the
+// first `batch` workgroup ids, so that the sweep runs under the other tiles' updates instead of after them (in
+// (x, y, z) dispatch order the last matrix's pivot tile started in the last round: 17.7 us per step at m = 256 x 17,
+// against 9.3 us for the final step, which has no sweep).
 __global__ __launch_bounds__(256) void k_bgjf_step(BgjfArgs g) {
     __shared__ real Pv[NB][NB + 1];
     __shared__ real Rk[NB][NB + 1];
     __shared__ real Ck[NB][NB + 1];
-    const int bj = blockIdx.x, bi = blockIdx.y, l = blockIdx.z, kb = g.kb, m = g.m;
+    const int kb = g.kb, m = g.m, nb = (m + NB - 1) / NB, nb2 = nb * nb;
+    int bi, bj, l;
+    if ((kb + 1) * NB < m) {
+        const int id = blockIdx.x;
+        if (id < g.batch) {
+            l = id; bi = bj = kb + 1;
+        } else {
+            l = (id - g.batch) / (nb2 - 1);
+            int t = (id - g.batch) % (nb2 - 1);
+            if (t >= (kb + 1) * nb + kb + 1) ++t;
+            bi = t / nb; bj = t % nb;
+        }
+    } else {
+        l = blockIdx.x / nb2; bi = (blockIdx.x % nb2) / nb; bj = blockIdx.x % nb;
+    }
     const size_t mo = (size_t)(l < g.nmain ? l : l - g.nmain) * m * m;
     const real* X = (l < g.nmain ? g.X : g.Xe) + mo;
     real* Y = (l < g.nmain ? g.Y : g.Ye) + mo;
@@ -620,22 +686,33 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     const double cost4 = (double)((M + 127) / 128) * ((N + 127) / 128) * 16384.0 / 57.6;
     const double cost2 = (double)((M + 63) / 64) * ((N + 63) / 64) * 4096.0 / 52.9;
     // fewer than one 64 x 64 tile per CU: 32 x 32 tiles (4x the workgroups; 256^3 batch 1: 18.3 -> 9.0 us)
-    const long long blocks64 = (long long)((N + 63) / 64) * ((M + 63) / 64) * batch;
+    // (lower-triangle products count the tiles that run: config-3 statistics, 256 x 256 x 1024 x 16, are 160 workgroups of 64)
+    const long long nt64 = (M + 63) / 64;
+    const long long blocks64 = ((tri & 1) && M == N ? nt64 * (nt64 + 1) / 2 : (long long)((N + 63) / 64) * nt64) * batch;
     // (tried: 160 x 160 tiles, 5 x 5 MFMA tiles per wave, no padding at m = 800 -- 512 registers per lane plus spills and one
     // wave per SIMD: 25-38 TFLOP/s at 800^3 x 64 against 41-46 for the 64-tiles; removed)
     const int wt = (blocks128 >= 192 && cost4 <= cost2) ? 4 : (blocks64 < 256 ? 1 : 2), ht = 32 * wt;
-    const size_t lds = prec == 0 ? (size_t)4 * GK * (ht + 2) * sizeof(double) : (size_t)4 * GK * (ht + 16) * sizeof(float);
+    const size_t lds = prec == 0 ? (size_t)4 * GK_OF(wt) * (ht + 2) * sizeof(double) : (size_t)4 * GK_OF(wt) * (ht + 16) * sizeof(float);
     g.tiles_n = (N + ht - 1) / ht; g.tiles_m = (M + ht - 1) / ht; g.batch = batch;
     g.xcd_remap = 1;     // measured neutral (+-1 %) at 800^3 x 64 and 2048^3 x 16: the Infinity Cache already absorbs the
                          // cross-XCD panel re-fetches; kept because it never hurts and is the layout the hardware deals
     const long long total = (long long)g.tiles_n * g.tiles_m * batch;
     SVGP_REQUIRE(total < (1LL << 30), SVGP_ERR_UNSUPPORTED, "GEMM grid too large");
     const dim3 grid((unsigned)(g.xcd_remap ? (total + 7) / 8 * 8 : total));
-#define LAUNCH_G(TA_, TB_, WT_, TS_, TC_)                                                                            \
-    do {                                                                                                             \
-        SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_batched<TA_, TB_, WT_, TS_, TC_>),    \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
-        hipLaunchKernelGGL((k_gemm_batched<TA_, TB_, WT_, TS_, TC_>), grid, dim3(256), lds, (hipStream_t)stream, g);  \
+    // 16-byte pair loads: both operands 16-byte aligned (8 for float32 storage) with even leading dimensions / batch strides
+    const uintptr_t al = prec == 2 ? 8 : 16;
+    const bool vec = ((uintptr_t)A % al) == 0 && ((uintptr_t)B % al) == 0 && lda % 2 == 0 && ldb % 2 == 0 && strideA % 2 == 0 &&
+                     strideB % 2 == 0;
+#define LAUNCH_V(TA_, TB_, WT_, TS_, TC_, V_)                                                                            \
+    do {                                                                                                                 \
+        SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_batched<TA_, TB_, WT_, TS_, TC_, V_>),    \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                       \
+        hipLaunchKernelGGL((k_gemm_batched<TA_, TB_, WT_, TS_, TC_, V_>), grid, dim3(256), lds, (hipStream_t)stream, g);  \
+    } while (0)
+#define LAUNCH_G(TA_, TB_, WT_, TS_, TC_)                     \
+    do {                                                      \
+        if (vec) LAUNCH_V(TA_, TB_, WT_, TS_, TC_, true);     \
+        else LAUNCH_V(TA_, TB_, WT_, TS_, TC_, false);        \
     } while (0)
 #define LAUNCH_T(WT_, TS_, TC_)                                \
     do {                                                       \
@@ -656,6 +733,7 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
 #undef LAUNCH_P
 #undef LAUNCH_T
 #undef LAUNCH_G
+#undef LAUNCH_V
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
@@ -846,7 +924,7 @@ int svgp_spd_inverse_fused(int m, int nmain, double* A, double* logdet, int next
         const bool fwd = (kb & 1) == 0;             // even steps read the matrices and write the workspace copy
         g.X = fwd ? A : W; g.Y = fwd ? W : A;
         g.Xe = fwd ? Ae : We; g.Ye = fwd ? We : Ae;
-        hipLaunchKernelGGL(k_bgjf_step, dim3(nb, nb, batch), dim3(256), 0, s, g);
+        hipLaunchKernelGGL(k_bgjf_step, dim3((unsigned)nb * nb * batch), dim3(256), 0, s, g);
         SVGP_LAUNCH_CHECK();
     }
     // the result sits in the workspace copy after an odd number of steps; either way it lands in A / Ae symmetrised

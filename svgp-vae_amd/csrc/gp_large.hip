@@ -142,6 +142,7 @@ struct FbArgs {
     real* Kib;  // out
     real* ubar; real* mubar; real* tbar;   // (L,m) each; mubar/tbar come in holding Ki ubar / K mubar
     real* Sibar; real* Kb; real* Sg; real* Ssym; real* Qm;
+    const real* Z;   // Si K Abar
 };
 __device__ __forceinline__ void fb_scalars(const FbArgs& a, real& g3, real& gK) {
     const real gT = gradKL(a.geco, a.Ltot, a.state);
@@ -174,13 +175,15 @@ __global__ void k_big_fb_tbar(FbArgs a) {     // tbar = td + c (K mubar)  (tbar 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.L * a.m) a.tbar[i] = a.td[i] + a.c * a.tbar[i];
 }
-__global__ void k_big_fb_sibar(FbArgs a) {    // Sibar += A2 + tbar v^T ; Kb += c mubar t^T
+// Sibar += A2 + tbar v^T ;  Kb = Z + Z^T + c mubar t^T with Z = Si (K Abar): the two products Abar G^T + Si Gbar of the
+// reverse pass are transposes of each other (Abar, K, Si symmetric), so one GEMM and a transposed read replace two GEMMs
+__global__ void k_big_fb_sibar(FbArgs a) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)a.m * a.m;
     if (i >= mm * a.L) return;
     const long long o = i % mm, l = i / mm;
     const int r = (int)(o / a.m), cidx = (int)(o % a.m);
     a.Sibar[i] += a.A2[i] + a.tbar[l * a.m + r] * a.v[l * a.m + cidx];
-    a.Kb[i] += a.c * a.mubar[l * a.m + r] * a.t[l * a.m + cidx];
+    a.Kb[i] = a.Z[i] + a.Z[l * mm + (long long)cidx * a.m + r] + a.c * a.mubar[l * a.m + r] * a.t[l * a.m + cidx];
 }
 __global__ void k_big_fb_ssym(FbArgs a) {     // Kb += Sg ; Ssym = c (Sg + Sg^T) ; Q = Ssym - g3 M2
     real g3, gK; fb_scalars(a, g3, gK);
@@ -423,7 +426,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     const BigScr s = big_scr(c, wl, ws);
     hipStream_t st = (hipStream_t)stream;
     const size_t om = (size_t)l0 * mm, ov = (size_t)l0 * m;
-    real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si + om, *G = ws + wl.G + om, *A = ws + wl.A + om, *S = ws + wl.S + om;
+    real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si + om, *A = ws + wl.A + om, *S = ws + wl.S + om;
     real* Kb = ws + wl.fb_part;
     real* Kib = Kb + (size_t)c->L * mm;
     FbArgs a;
@@ -431,7 +434,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     a.Ki = Ki; a.Aji = ws + wl.Aji + om; a.A = A; a.S = S; a.A2 = ws + wl.A2 + om; a.M2 = ws + wl.M2 + om; a.mu = ws + wl.mu_hat + ov;
     a.u = ws + wl.u + ov; a.ud = ws + wl.ud + ov; a.td = ws + wl.td + ov; a.t = ws + wl.t + ov; a.v = ws + wl.v + ov;
     a.X1 = s.mm1; a.T1A = s.mm2; a.Kib = Kib; a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2;
-    a.Sibar = s.mm3; a.Kb = Kb; a.Sg = s.mm1; a.Ssym = ws + wl.Ssym + om; a.Qm = ws + wl.Qm + om;
+    a.Sibar = s.mm3; a.Kb = Kb; a.Sg = s.mm1; a.Z = s.mm0; a.Ssym = ws + wl.Ssym + om; a.Qm = ws + wl.Qm + om;
     const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m);
     GEMM(0, 1, m, m, m, 1.0, S, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);            // T1 = S Ki
     GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, s.mm1, m, mm, L);        // Ki S Ki (full product, see M2)
@@ -444,8 +447,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     hipLaunchKernelGGL(k_big_fb_kibar, dim3(gmm), dim3(256), 0, st, a);            // Kib
     SVGP_LAUNCH_CHECK();
     GEMM(0, 1, m, m, m, 1.0, K, m, 0, s.mm1, m, mm, 0.0, s.mm2, m, mm, L);         // Gbar = K Abar   (mm2)
-    GEMM(0, 1, m, m, m, 1.0, s.mm1, m, mm, G, m, mm, 0.0, Kb, m, mm, L);           // Kb = Abar G^T
-    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm2, m, mm, 1.0, Kb, m, mm, L);          // Kb += Si Gbar
+    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm2, m, mm, 0.0, s.mm0, m, mm, L);       // Z = Si Gbar (mm0: T1 is done); Kb = Z + Z^T below
     GEMM(0, 0, m, 1, m, 1.0, K, m, 0, s.vec1, 1, lm, 0.0, s.vec2, 1, lm, L);       // K mubar
     hipLaunchKernelGGL(k_big_fb_tbar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round artefacts on the MI355X box: bench lines of every workload, rocprofv3 kernel stats, PMC traffic passes, GEMM / inverse probes.
+# usage (through gpurun, from the repo root): bash tools/collect_profiles.sh r02a     -> files under gpurun_out/r02a_*
+# (copy what is to be judged into profiles/ afterwards; see profiles/README.md)
+tag=${1:-rXX}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+python bench.py > $O/${tag}_bench.json 2> $O/${tag}_bench.err
+python bench.py --workload cfg3 > $O/${tag}_cfg3.json 2>> $O/${tag}_bench.err
+python bench.py --workload sprites800 > $O/${tag}_sprites800_f64.json 2>> $O/${tag}_bench.err
+python bench.py --workload sprites800 --precision f32 > $O/${tag}_sprites800_f32.json 2>> $O/${tag}_bench.err
+python bench.py --workload cfg5 > $O/${tag}_cfg5.json 2>> $O/${tag}_bench.err
+python tools/gemm_sweep.py 2>/dev/null > $O/${tag}_gemm_sweep.txt
+python tools/inverse_probe.py 2>/dev/null > $O/${tag}_inverse_probe.txt
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_prof_cfg2 -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $O/${tag}_prof_cfg2.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_prof_cfg3 -- python3 $R/bench.py --workload cfg3 --steps 50 --warmup 10 --repeats 1 --no-cpu-baseline > $O/${tag}_prof_cfg3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_prof_sp800 -- python3 $R/bench.py --workload sprites800 --precision f32 --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline > $O/${tag}_prof_sp800.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_prof_cfg5 -- python3 $R/bench.py --workload cfg5 --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline > $O/${tag}_prof_cfg5.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $O/${tag}_pmc_$c/cfg2 -- python3 $R/bench.py --steps 20 --warmup 2 --no-cpu-baseline > $O/${tag}_pmc_$c.log 2>&1
+  rocprofv3 --pmc $c --output-format csv -d $O/${tag}_pmc_$c/cfg5 -- python3 $R/bench.py --workload cfg5 --steps 2 --warmup 1 --repeats 1 --no-cpu-baseline >> $O/${tag}_pmc_$c.log 2>&1
+done
+cd $R
+python tools/pmc_summary.py $O/${tag}_pmc_FETCH_SIZE $O/${tag}_pmc_WRITE_SIZE $O/${tag}_pmc_traffic.json
+for w in cfg2 cfg3 sp800 cfg5; do f=$(find $O/${tag}_prof_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${tag}_${w}_kernel_stats.csv; done
+# the raw traces / counter dumps are large: keep the summaries only
+rm -rf $O/${tag}_prof_* $O/${tag}_pmc_FETCH_SIZE $O/${tag}_pmc_WRITE_SIZE
+ls -la $O | grep ${tag}_

@@ -122,9 +122,10 @@ int svgp_dgemm_tri_batched(int tri, int ta, int tb, int M, int N, int K, double 
                            long long strideA, const double* B, int ldb, long long strideB, double beta, double* C, int ldc,
                            long long strideC, int batch, void* stream);
 
+// wk (optional): weights of the contraction index, op(B)[k][:] *= wk[k * ldw + l * strideW] while staged (C symmetric iff A = B)
 int svgp_dgemm_symout_batched(int f32c, int ta, int tb, int M, int K, double alpha, const double* A, int lda, long long strideA,
                               const double* B, int ldb, long long strideB, double beta, double* C, int ldc, long long strideC,
-                              int batch, void* stream);
+                              int batch, void* stream, const double* wk = nullptr, int ldw = 0, long long strideW = 0);
 
 // large-m implementations (gp_large.hip)
 int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state, int mode,

@@ -32,6 +32,9 @@ struct GemmArgs {
     // bit 3 = contraction ends with the tile's last row (operand zero for k > i);
     // bit 4 (with bit 0, M == N) = the result is symmetric: every computed tile below the diagonal is also stored transposed
     int tri;
+    // optional weights of the contraction index: op(B)[k][j] is multiplied by wk[k * ldw + l * sw] while it is staged
+    // (S_l = Kn^T diag(w_l) Kn without materialising diag(w_l) Kn); element type = TS
+    const void* wk; int ldw; long long sw;
 };
 
 // k-panels of 16 are double-buffered in LDS and a third one is in flight in registers (see the main loop), one
@@ -84,6 +87,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
     const TS* __restrict__ A = static_cast<const TS*>(g.A) + (size_t)l * g.sa;
     const TS* __restrict__ B = static_cast<const TS*>(g.B) + (size_t)l * g.sb;
     TS* C = static_cast<TS*>(g.C) + (size_t)l * g.sc;
+    const TS* __restrict__ wk = g.wk ? static_cast<const TS*>(g.wk) + (size_t)l * g.sw : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wi = (wave >> 1) * 16 * WT, wj = (wave & 1) * 16 * WT;
     typename MF::acc_t acc[WT][WT];
@@ -128,9 +132,17 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
             if (TB) {
                 const int gj = j0 + xk, gk = k0 + kk;
                 ldpair(B + (size_t)gj * g.ldb + gk, gj < g.N && gk < g.K, gj < g.N && gk + 1 < g.K, fast, rb[2 * h], rb[2 * h + 1]);
+                if (wk) {
+                    rb[2 * h] *= gk < g.K ? (TC)wk[(size_t)gk * g.ldw] : TC(0);
+                    rb[2 * h + 1] *= gk + 1 < g.K ? (TC)wk[(size_t)(gk + 1) * g.ldw] : TC(0);
+                }
             } else {
                 const int gj = j0 + xx, gk = k0 + kx;
                 ldpair(B + (size_t)gk * g.ldb + gj, gk < g.K && gj < g.N, gk < g.K && gj + 1 < g.N, fast, rb[2 * h], rb[2 * h + 1]);
+                if (wk) {
+                    const TC wv = gk < g.K ? (TC)wk[(size_t)gk * g.ldw] : TC(0);
+                    rb[2 * h] *= wv; rb[2 * h + 1] *= wv;
+                }
             }
         }
     };
@@ -671,7 +683,8 @@ __global__ __launch_bounds__(NO) void k_bgj2_writeback(Bgj2Args g) {
 // prec 0: float64 storage + arithmetic; 1: float64 storage, float32 MFMA arithmetic; 2: float32 storage + arithmetic
 static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, double alpha, const void* A, int lda,
                        long long strideA, const void* B, int ldb, long long strideB, double beta, void* C, int ldc,
-                       long long strideC, int batch, void* stream) {
+                       long long strideC, int batch, void* stream, const void* wk = nullptr, int ldw = 0,
+                       long long strideW = 0) {
     SVGP_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, SVGP_ERR_INVALID, "negative dimension");
     if (M == 0 || N == 0 || batch == 0) return SVGP_OK;
     SVGP_REQUIRE(A && B && C, SVGP_ERR_INVALID, "NULL device pointer");
@@ -679,6 +692,7 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     g.M = M; g.N = N; g.K = K; g.ta = ta; g.tb = tb; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.sa = strideA; g.sb = strideB; g.sc = strideC; g.alpha = alpha; g.beta = beta; g.A = A; g.B = B; g.C = C;
     g.tri = tri;
+    g.wk = wk; g.ldw = ldw; g.sw = strideW;
     const long long blocks128 = (long long)((N + 127) / 128) * ((M + 127) / 128) * batch;
     // tile choice: 128 x 128 tiles run ~9 % faster per useful flop than 64 x 64 (57.6 vs 52.9 TFLOP/s at 2048^3, no padding)
     // but pad M, N up to multiples of 128: at 800 x 800 that is 25 % wasted tile area against 8 % (measured 39.7 vs 41.3-45.6
@@ -761,9 +775,9 @@ extern "C" int svgp_sgemm_batched(int ta, int tb, int M, int N, int K, float alp
 // f32c != 0: float32 MFMA arithmetic on the float64 matrices.
 int svgp_dgemm_symout_batched(int f32c, int ta, int tb, int M, int K, double alpha, const double* A, int lda, long long strideA,
                               const double* B, int ldb, long long strideB, double beta, double* C, int ldc, long long strideC,
-                              int batch, void* stream) {
+                              int batch, void* stream, const double* wk, int ldw, long long strideW) {
     return gemm_launch(f32c ? 1 : 0, 1 | 16, ta, tb, M, M, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch,
-                       stream);
+                       stream, wk, ldw, strideW);
 }
 
 // the float64 GEMM with triangular structure hints (see GemmArgs::tri); tiles / k-panels that the hints exclude are

@@ -103,5 +103,9 @@ def precompute_GP_params_f32(kd, means, vars, aux_data, inducing_index_points, t
     logdet = torch.empty(L, dtype=torch.float64, device=Sigma.device)
     call("svgp_spd_inverse_batched", m, L, Sigma.data_ptr(), logdet.data_ptr(), w.data_ptr(), _stream(Sigma))
     inv = Sigma   # inverted in place
-    mean_terms = torch.einsum("lij,lj->li", inv, v.double())
+    vd = v.double().contiguous()
+    mean_terms = torch.empty(L, m, dtype=torch.float64, device=Sigma.device)
+    # mean_terms_l = Sigma_l^-1 v_l: the library's batched GEMM with one right-hand column per channel
+    call("svgp_dgemm_batched", 0, 0, m, 1, m, 1.0, inv.data_ptr(), m, m * m, vd.data_ptr(), 1, m, 0.0, mean_terms.data_ptr(), 1, m,
+         L, _stream(Sigma))
     return mean_terms.float(), inv.float()

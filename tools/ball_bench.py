@@ -25,7 +25,10 @@ def main():
     from oracle import ball_oracle as BO, pearce_vae_oracle as PO
     res = {}
     for elbo in a.elbo:
-        args = BE.build_parser().parse_args(["--elbo", elbo, "--clip_qs", "--GP_joint", "--ip_joint", "--jitter", "1e-6"])
+        # BASELINE configs[0] (`BALL_experiment.py --elbo VAE`, no --GP_joint: the length scale is the constant model_lt =
+        # 0.001 of BALL_experiment.py:46-50); the GP variants run with the joint optimisation of the README command
+        flags = ["--elbo", elbo, "--clip_qs", "--jitter", "1e-6"] + ([] if elbo == "VAE" else ["--GP_joint", "--ip_joint"])
+        args = BE.build_parser().parse_args(flags)
         eng = BE.build_engine(args)
         src = ball.VideoBatchSource(tmax=30, px=32, py=32, lt=2, batch=35, seed=1, r=3)
 

@@ -122,7 +122,8 @@ typedef struct {
     int64_t statB, statB_len, A2, ud, td; /* ONE contiguous all-reduce block [A2 | ud | td]       */
     int64_t Kbar, fb_part, Qm, vbar, Ssym; /* (m,m) (2,L,m,m) scratch (L,m,m) (L,m) (L,m,m)        */
     int64_t Knbar_part;                   /* (L,b,m) per-channel row gradients before the sum     */
-    int64_t scr_bm, scr_mm, scr_vec, scr_inv, scr_bl; /* scratch of the large-m (m > 64) path     */
+    int64_t scr_bm, scr_mm, scr_vec, scr_inv, scr_bl; /* scratch of the large-m (m > 64) path; scr_bm also holds the
+                                           * forward products Kn Si_l, Kn M2_l, Kn Ki that the reverse pass re-reads */
     int64_t Knbar, knnbar, ybar, s2bar;   /* (b,m) (b) (b,L) (b,L)                                */
     int64_t d_on;                         /* (b,M) gradient of gathered object rows               */
     /* partial sums */

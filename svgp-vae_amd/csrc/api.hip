@@ -112,7 +112,8 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->Kbar = take(m * m); o->fb_part = take(2 * L * m * m); o->Qm = take(L * m * m); o->vbar = take(L * m);
     o->Ssym = take(L * m * m); o->Knbar_part = take(L * b * m);
     // scratch of the large-m path (gp_large.hip)
-    o->scr_bm = take(L * b * m); o->scr_mm = take(4 * L * m * m); o->scr_vec = take(3 * L * m + 3 * L + 16);
+    // m > 64: (L,b,m) scratch + the forward products Kn Si_l, Kn M2_l (L,b,m each) and Kn Ki (b,m) kept for the reverse pass
+    o->scr_bm = take(m > 64 ? 3 * L * b * m + b * m : L * b * m); o->scr_mm = take(4 * L * m * m); o->scr_vec = take(3 * L * m + 3 * L + 16);
     o->scr_inv = take((int64_t)svgp_spd_inverse_workspace_elems((int)m, (int)L + 1)); o->scr_bl = take(2 * b * L);
     o->Knbar = take(b * m); o->knnbar = take(b); o->ybar = take(b * L); o->s2bar = take(b * L);
     o->d_on = take(b * M);

@@ -216,25 +216,24 @@ struct PbArgs {
     const real* y; const real* s2; const real* p_m; const real* p_v; const real* e; const real* d;
     const real* g_pv; const real* g_pm; const real* mvbar;
     const real* u; const real* t; const real* vbar;
-    const real* R;      // (L,b,m) product with Kn rows (meaning depends on the pass)
+    const real* R;      // (L,b,m) Kn Ssym_l
+    const real* KnSi; const real* KnM2;   // (L,b,m) forward products
     const real* kSk; const real* kv;   // (b,L)
     const real* KnKi;   // (b,m)
     real* part;         // Knbar_part (L,b,m)
     real* Knbar; real* knnbar; real* ybar; real* s2bar;
 };
-__global__ void k_big_pb_part1(PbArgs a) {    // part = 2 g_pv (Kn Si)
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, bm = (long long)a.b * a.m;
-    if (i >= bm * a.L) return;
-    const int n = (int)((i % bm) / a.m), l = (int)(i / bm);
-    a.part[i] = real(2) * a.g_pv[(size_t)n * a.L + l] * a.R[i];
-}
-__global__ void k_big_pb_part2(PbArgs a) {    // part += p (Kn Q) + mvbar u + c g_pm t + p y vbar
+// part = 2 g_pv (Kn Si) + p (Kn Q) + mvbar u + c g_pm t + p y vbar,  Kn Q = Kn Ssym - g3 Kn M2  (Q = Ssym - g3 M2);
+// Kn Si and Kn M2 are the forward pass's products, R = Kn Ssym
+__global__ void k_big_pb_part(PbArgs a) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, bm = (long long)a.b * a.m;
     if (i >= bm * a.L) return;
     const int j = (int)(i % a.m), n = (int)((i % bm) / a.m), l = (int)(i / bm);
     const size_t e = (size_t)n * a.L + l, vi = (size_t)l * a.m + j;
+    const real g3 = svgp_seed_3(a.geco, gradKL(a.geco, a.L, a.state));
     const real p = recip_no_nan(a.s2[e]);
-    a.part[i] += p * a.R[i] + a.mvbar[e] * a.u[vi] + a.c * a.g_pm[e] * a.t[vi] + p * a.y[e] * a.vbar[vi];
+    a.part[i] = real(2) * a.g_pv[e] * a.KnSi[i] + p * (a.R[i] - g3 * a.KnM2[i]) + a.mvbar[e] * a.u[vi] +
+                a.c * a.g_pm[e] * a.t[vi] + p * a.y[e] * a.vbar[vi];
 }
 __global__ void k_big_pb_elem(PbArgs a) {     // ybar, s2bar
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -280,11 +279,15 @@ inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 // scratch carving (layout fields scr_bm / scr_mm / scr_vec / scr_inv / scr_bl are allocated by api.hip)
 struct BigScr {
     real *bm, *bm2, *mm0, *mm1, *mm2, *mm3, *vec0, *vec1, *vec2, *trm, *ldtmp, *inv, *bl0, *bl1;
+    // forward products kept for the reverse pass (behind the (L, b, m) scratch in scr_bm): Kn Si_l, Kn M2_l (L, b, m), Kn Ki (b, m)
+    real *KnSi, *KnM2, *KnKi;
 };
 static BigScr big_scr(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws) {
     const size_t Lmm = (size_t)c->L * c->m * c->m, Lm = (size_t)c->L * c->m, bL = (size_t)c->b * c->L;
     BigScr s;
     s.bm = ws + wl.scr_bm; s.bm2 = ws + wl.Knbar_part;
+    const size_t Lbm_cap = (size_t)c->L * (c->b_cap > 0 ? c->b_cap : c->b) * c->m;      // the layout is sized for the capacity
+    s.KnSi = s.bm + Lbm_cap; s.KnM2 = s.KnSi + Lbm_cap; s.KnKi = s.KnM2 + Lbm_cap;
     s.mm0 = ws + wl.scr_mm; s.mm1 = s.mm0 + Lmm; s.mm2 = s.mm1 + Lmm; s.mm3 = s.mm2 + Lmm;
     s.vec0 = ws + wl.scr_vec; s.vec1 = s.vec0 + Lm; s.vec2 = s.vec1 + Lm; s.trm = s.vec2 + Lm; s.ldtmp = s.trm + 2 * c->L;
     s.inv = ws + wl.scr_inv;
@@ -371,8 +374,8 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     hipLaunchKernelGGL(k_big_kl, dim3(nblk(L)), dim3(256), 0, st, m, L, ws + wl.ldK, s.ldtmp, s.mm0, ws + wl.KL + l0);
     SVGP_LAUNCH_CHECK();
     // q_n = k_n^T Ki k_n
-    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, Ki, m, 0, 0.0, s.bm, m, 0, 1);
-    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * 64)), dim3(256), 0, st, b, m, 1, real(1), s.bm, 0LL, Kn,
+    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, Ki, m, 0, 0.0, s.KnKi, m, 0, 1);           // kept: the reverse pass reads Kn Ki again
+    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * 64)), dim3(256), 0, st, b, m, 1, real(1), s.KnKi, 0LL, Kn,
                        ws + wl.q, 1, 0);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
@@ -386,12 +389,13 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     const BigScr s = big_scr(c, wl, ws);
     hipStream_t st = (hipStream_t)stream;
     real* Kn = ws + wl.Kn;
-    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Si, m, mm, 0.0, s.bm, m, bm, L);                  // Kn Si_l
-    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.bm, bm, Kn,
+    // Kn Si_l and Kn M2_l are kept for svgp_big_posterior_bwd (2 of its 3 (b, m, m, L) products; 2 x L b m doubles of HBM)
+    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Si, m, mm, 0.0, s.KnSi, m, bm, L);                // Kn Si_l
+    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.KnSi, bm, Kn,
                        ws + wl.p_v, L, 0);                                                      // r -> p_v slot
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.M2, m, mm, 0.0, s.bm, m, bm, L);                  // Kn M2_l
-    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.bm, bm, Kn,
+    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.M2, m, mm, 0.0, s.KnM2, m, bm, L);                // Kn M2_l
+    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.KnM2, bm, Kn,
                        ws + wl.d, L, 0);                                                        // s -> d slot
     SVGP_LAUNCH_CHECK();
     GEMM(0, 1, b, L, m, cc, Kn, m, 0, ws + wl.t, m, 0, 0.0, ws + wl.p_m, L, 0, 1);               // p_m = c Kn t^T
@@ -475,24 +479,22 @@ int svgp_big_posterior_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     a.b = b; a.m = m; a.L = L; a.geco = SVGP_LOSS_FLAGS(c); a.c = cc; a.state = state;
     a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var; a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v; a.e = ws + wl.e;
     a.d = ws + wl.d; a.g_pv = ws + wl.g_pv; a.g_pm = ws + wl.g_pm; a.mvbar = ws + wl.mvbar;
-    a.u = ws + wl.u; a.t = ws + wl.t; a.vbar = ws + wl.vbar; a.R = s.bm; a.kSk = s.bl0; a.kv = s.bl1; a.KnKi = s.bm;
+    a.u = ws + wl.u; a.t = ws + wl.t; a.vbar = ws + wl.vbar; a.R = s.bm; a.kSk = s.bl0; a.kv = s.bl1; a.KnKi = s.KnKi;
+    a.KnSi = s.KnSi; a.KnM2 = s.KnM2;
     a.part = ws + wl.Knbar_part; a.Knbar = ws + wl.Knbar; a.knnbar = ws + wl.knnbar; a.ybar = ws + wl.ybar;
     a.s2bar = ws + wl.s2bar;
     const unsigned gbm = nblk(bm * L);
-    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Si, m, mm, 0.0, s.bm, m, bm, L);
-    hipLaunchKernelGGL(k_big_pb_part1, dim3(gbm), dim3(256), 0, st, a);
-    SVGP_LAUNCH_CHECK();
-    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Qm, m, mm, 0.0, s.bm, m, bm, L);
-    hipLaunchKernelGGL(k_big_pb_part2, dim3(gbm), dim3(256), 0, st, a);
-    SVGP_LAUNCH_CHECK();
+    // one (b, m, m, L) product instead of three: Kn Si_l and Kn M2_l come from the forward pass (svgp_big_posterior_fwd on
+    // this workspace), Kn Ki from svgp_big_factor_fwd
     GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Ssym, m, mm, 0.0, s.bm, m, bm, L);
+    hipLaunchKernelGGL(k_big_pb_part, dim3(gbm), dim3(256), 0, st, a);
+    SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(0.5), s.bm, bm, Kn,
                        s.bl0, L, 0);
     SVGP_LAUNCH_CHECK();
     GEMM(0, 1, b, L, m, 1.0, Kn, m, 0, ws + wl.vbar, m, 0, 0.0, s.bl1, L, 0, 1);   // kv = Kn vbar^T
     hipLaunchKernelGGL(k_big_pb_elem, dim3(nblk((long long)b * L)), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Ki, m, 0, 0.0, s.bm, m, 0, 1);       // Kn Ki
     hipLaunchKernelGGL(k_big_pb_sum, dim3(nblk(bm)), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;

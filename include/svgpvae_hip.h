@@ -299,7 +299,7 @@ int svgp_allreduce_sum_f32(void* comm, float* buf, int64_t count, void* stream);
  * -> all-gather"): in-place on a buffer of nranks equal chunks, rank r owning buf[r * count, (r+1) * count).  The
  * schedule (sprites.py / engine.ChannelShardedExchange): reduce-scatter S, v over channels | svgp_gp_factor_fwd_channels
  * on the rank's window | all-gather Sigma_l^-1, M2, t, u, KL | ... | reduce-scatter A2, ud, td |
- * svgp_gp_factor_bwd_channels | all-gather Qm, Ssym, vbar.  Kbar needs no exchange: each rank's window share flows
+ * svgp_gp_factor_bwd_channels | all-gather Ssym, vbar.  Kbar needs no exchange: each rank's window share flows
  * through svgp_kernel_matrix_bwd (linear in Kbar) into the gradient all-reduce (cfg.rep_weight = 1 on every rank).    */
 int svgp_reduce_scatter_sum_f64(void* comm, double* buf, int64_t count_per_rank, void* stream);
 int svgp_allgather_f64(void* comm, double* buf, int64_t count_per_rank, void* stream);

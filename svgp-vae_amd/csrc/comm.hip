@@ -172,7 +172,8 @@ extern "C" int svgp_allgather_f64(void* comm, double* buf, int64_t count_per_ran
 // (svgp_gp_factor_*_channels) and what the row stages need is all-gathered:
 //   encoder + kernel matrices + statistics | reduce-scatter S, v | window factor stage | all-gather Sigma^-1, M2, t, u, KL |
 //   row stage, decoder fwd + bwd, backward statistics | reduce-scatter A2, ud, td | window reverse factor stage |
-//   all-gather Qm, Ssym, vbar | row gradients, kernel-matrix VJP (every rank's Kbar share counts), encoder reverse pass,
+//   all-gather Ssym, vbar (Kn Q is formed from Kn Ssym and the forward pass's Kn M2: Q itself is not exchanged) |
+//   row gradients, kernel-matrix VJP (every rank's Kbar share counts), encoder reverse pass,
 //   gradient reduction | all-reduce gradC | phase 3
 // At config 3 on 8 ranks: 2 channels of 256 x 256 per rank instead of 16, 8.4 MB blocks moved as 7/8 of their size.
 namespace {
@@ -228,7 +229,6 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     RUN(rs(comm, ws + wl.ud, Lm, G, stream));
     RUN(rs(comm, ws + wl.td, Lm, G, stream));
     RUN(svgp_gp_factor_bwd_channels(&cc, l0, nl, ws, state, stream));
-    RUN(ag(comm, ws + wl.Qm, Lmm, G, stream));
     RUN(ag(comm, ws + wl.Ssym, Lmm, G, stream));
     RUN(ag(comm, ws + wl.vbar, Lm, G, stream));
     RUN(svgp_gp_posterior_bwd(&cc, ws, state, stream));

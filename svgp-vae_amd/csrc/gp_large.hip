@@ -259,6 +259,34 @@ __global__ void k_big_pb_sum(PbArgs a) {      // Knbar = sum_l part + 2 qbar (Kn
     if (i % a.m == 0) a.knnbar[n] = -qbar;
 }
 
+// y_l = alpha A_l x_l for L channels (A_l: m x m row-major at A + l sA, sA = 0: one shared matrix; x, y: (L, m)).
+// grid (ceil(m / 16), L), 256 threads: wave w takes rows 4 w .. 4 w + 3 of the block, lanes stride the row, x_l sits in LDS.
+// The batched GEMM spends a 32- or 64-wide tile on the single column (m = 800, L = 64: 130 us; this: one pass over A).
+__global__ __launch_bounds__(256) void k_big_gemv(int m, real alpha, const real* __restrict__ A, long long sA,
+                                                  const real* __restrict__ x, real* __restrict__ y) {
+    extern __shared__ real xs[];
+    const int l = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const real* xl = x + (size_t)l * m;
+    for (int k = threadIdx.x; k < m; k += 256) xs[k] = xl[k];
+    __syncthreads();
+    const int i0 = blockIdx.x * 16 + w * 4;
+    const real* Al = A + (size_t)l * sA;
+    real acc[4] = {0, 0, 0, 0};
+    for (int k = lane; k < m; k += 64) {
+        const real xv = xs[k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (i0 + r < m) acc[r] += Al[(size_t)(i0 + r) * m + k] * xv;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        real v = acc[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0 && i0 + r < m) y[(size_t)l * m + i0 + r] = alpha * v;
+    }
+}
+
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -273,6 +301,12 @@ inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 #define GEMM_S(...) RUNC((c->gemm_f32 ? svgp_dgemm_f32c_batched : svgp_dgemm_batched)(__VA_ARGS__, stream))
 // products whose result is symmetric (K Si K, Ki A Ki, Ki S Ki, K Abar K, Kn^T diag(w) Kn): lower tiles + mirrored stores.
 // arguments: ta, tb, M (= N), K, alpha, A, lda, sA, B, ldb, sB, beta, C, ldc, sC, batch
+#define GEMV(alpha_, A_, sA_, x_, y_, L_)                                                                                \
+    do {                                                                                                                 \
+        hipLaunchKernelGGL(k_big_gemv, dim3((m + 15) / 16, (L_)), dim3(256), (size_t)m * sizeof(real), (hipStream_t)stream, m,  \
+                           real(alpha_), A_, (long long)(sA_), x_, y_);                                                   \
+        SVGP_LAUNCH_CHECK();                                                                                             \
+    } while (0)
 #define GEMM_SYM(...) RUNC(svgp_dgemm_symout_batched(c->gemm_f32 == 1, __VA_ARGS__, stream))
 #define GEMM_S_SYM(...) RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, __VA_ARGS__, stream))
 
@@ -354,11 +388,11 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
         RUNC(svgp_spd_inverse_batched(m, 1, Ki, ws + wl.ldK, s.inv, stream));
         RUNC(svgp_spd_inverse_batched(m, L, Si, s.ldtmp, s.inv, stream));
     }
-    GEMM(0, 0, m, 1, m, 1.0, Si, m, mm, v, 1, (long long)m, 0.0, t, 1, (long long)m, L);          // t = Si v
+    GEMV(1.0, Si, mm, v, t, L);                                                                  // t = Si v
     GEMM(0, 1, m, m, m, 1.0, Si, m, mm, K, m, 0, 0.0, G, m, mm, L);                              // G = Si K   (K = K^T read as [j][k])
     GEMM_SYM(0, 0, m, m, 1.0, K, m, 0, G, m, mm, 0.0, A, m, mm, L);                              // A = K G = K Si K
-    GEMM(0, 0, m, 1, m, cc, K, m, 0, t, 1, (long long)m, 0.0, mu, 1, (long long)m, L);            // mu = c K t
-    GEMM(0, 0, m, 1, m, 1.0, Ki, m, 0, mu, 1, (long long)m, 0.0, u, 1, (long long)m, L);          // u = Ki mu
+    GEMV(cc, K, 0, t, mu, L);                                                                    // mu = c K t
+    GEMV(1.0, Ki, 0, mu, u, L);                                                                  // u = Ki mu
     GEMM(0, 1, m, m, m, 1.0, A, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);                          // T = A Ki
     // M2 and Ki S Ki below are full products, not lower-triangle-and-mirror: their rounding error has the form Ki E (norm
     // eps |Ki||A||Ki|, far above eps |M2|), harmless in k^T M2 k for k in the range of K_mm (k^T Ki is small) but not once
@@ -417,7 +451,7 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
 int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
                         void* stream, int l0, int nl) {
     const int m = c->m, L = nl;
-    const long long mm = (long long)m * m, lm = (long long)m;
+    const long long mm = (long long)m * m;
     const real cc = c->N_train / (double)c->b_global;
     const BigScr s = big_scr(c, wl, ws);
     hipStream_t st = (hipStream_t)stream;
@@ -436,7 +470,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, s.mm1, m, mm, L);        // Ki S Ki (full product, see M2)
     hipLaunchKernelGGL(k_big_fb_abar, dim3(gmm), dim3(256), 0, st, a);             // Abar (mm1), ubar
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, m, 1, m, 1.0, Ki, m, 0, s.vec0, 1, lm, 0.0, s.vec1, 1, lm, L);      // Ki ubar
+    GEMV(1.0, Ki, 0, s.vec0, s.vec1, L);                                           // Ki ubar
     hipLaunchKernelGGL(k_big_fb_mubar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
     GEMM(0, 1, m, m, m, 1.0, s.mm0, m, mm, A, m, mm, 0.0, s.mm2, m, mm, L);        // T1 A
@@ -444,13 +478,13 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     SVGP_LAUNCH_CHECK();
     GEMM(0, 1, m, m, m, 1.0, K, m, 0, s.mm1, m, mm, 0.0, s.mm2, m, mm, L);         // Gbar = K Abar   (mm2)
     GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm2, m, mm, 0.0, s.mm0, m, mm, L);       // Z = Si Gbar (mm0: T1 is done); Kb = Z + Z^T below
-    GEMM(0, 0, m, 1, m, 1.0, K, m, 0, s.vec1, 1, lm, 0.0, s.vec2, 1, lm, L);       // K mubar
+    GEMV(1.0, K, 0, s.vec1, s.vec2, L);                                            // K mubar
     hipLaunchKernelGGL(k_big_fb_tbar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
     GEMM_SYM(0, 1, m, m, 1.0, s.mm2, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);        // Gbar K = K Abar K  (mm3)
     hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);            // Sibar, Kb += c mubar t^T
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, m, 1, m, 1.0, Si, m, mm, s.vec2, 1, lm, 0.0, ws + wl.vbar + ov, 1, lm, L);   // vbar = Si tbar
+    GEMV(1.0, Si, mm, s.vec2, ws + wl.vbar + ov, L);                                        // vbar = Si tbar
     GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm3, m, mm, 0.0, s.mm0, m, mm, L);       // Si Sibar (mm0)
     GEMM(0, 1, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);      // Sg = -Si Sibar Si (mm1)
     hipLaunchKernelGGL(k_big_fb_ssym, dim3(gmm), dim3(256), 0, st, a);

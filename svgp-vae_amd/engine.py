@@ -80,7 +80,7 @@ class ChannelShardedStep:
       stage 0  encoder, kernel matrices, forward statistics          ops: reduce_scatter S, v over channels
       stage 1  factor stage of the rank's channel window             ops: allgather Sigma^-1, M2 (or A), t, u, KL
       stage 2  row stage, decoder fwd + bwd, backward statistics     ops: reduce_scatter A2, ud, td
-      stage 3  reverse factor stage of the window                    ops: allgather Qm, Ssym, vbar
+      stage 3  reverse factor stage of the window                    ops: allgather Ssym, vbar
       stage 4  row gradients, kernel-matrix VJP (the rank's Kbar share counts on EVERY rank), encoder reverse pass
                                                                      ops: allreduce gradients + scalar sums
       stage 5  optimiser + epilogue
@@ -435,7 +435,7 @@ class MnistStepEngine:
         yield ops("reduce_scatter", ("A2", mm), ("ud", m), ("td", m))
         with torch.cuda.stream(self.stream):
             call("svgp_gp_factor_bwd_channels", cp, l0, nl, ws, st, s)
-        yield ops("allgather", ("Qm", mm), ("Ssym", mm), ("vbar", m))
+        yield ops("allgather", ("Ssym", mm), ("vbar", m))      # (Q = Ssym - g3 M2 is not exchanged: M2 was, in stage 1)
         with torch.cuda.stream(self.stream):
             call("svgp_gp_posterior_bwd", cp, ws, st, s)
             call("svgp_kernel_matrix_bwd_partials", cp, th, ax, ws, s)

@@ -365,7 +365,7 @@ class SpritesStepEngine:
         """Generator over the step: yields, at every exchange point, the list of engine.ExchangeOp to run across the
         ranks.  Three points (all-reduce of the forward statistics, the backward statistics, gradients + scalar sums) in
         the plain form; five in the channel-sharded form (reduce-scatter S, v | all-gather Sigma^-1, M2, t, u, KL |
-        reduce-scatter A2, ud, td | all-gather Qm, Ssym, vbar | all-reduce gradients + sums)."""
+        reduce-scatter A2, ud, td | all-gather Ssym, vbar | all-reduce gradients + sums)."""
         b = images.shape[0]
         assert b <= self.b_max and b % self.seg_len == 0
         b_global = b * self.world_size if b_global is None else b_global
@@ -463,7 +463,7 @@ class SpritesStepEngine:
             else:
                 call("svgp_gp_factor_bwd", cp, ws, st, s)
         if self.chan_shard:
-            yield [ExchangeOp("allgather", fld(n_, per)) for n_, per in (("Qm", mm_), ("Ssym", mm_), ("vbar", self.m))]
+            yield [ExchangeOp("allgather", fld(n_, per)) for n_, per in (("Ssym", mm_), ("vbar", self.m))]
         with torch.cuda.stream(self.stream):
             call("svgp_gp_posterior_bwd", cp, ws, st, s)
             if self.svgp.titsias:

@@ -111,7 +111,7 @@ def test_sprites_virtual_ranks_equal_single_engine(G, K_SE, m, clip, shard, L):
     scalars, gradients and the parameters after two Adam steps must equal the single-engine run at the same global
     batch.  m <= 64: three all-reduces.  m > 64 and L divisible by G (shard None -> on): the channel-sharded schedule --
     reduce-scatter of S, v / A2, ud, td over the channels, each rank factors its L / G channels
-    (svgp_gp_factor_*_channels), all-gather of Sigma^-1, M2, t, u, KL / Qm, Ssym, vbar."""
+    (svgp_gp_factor_*_channels), all-gather of Sigma^-1, M2, t, u, KL / Ssym, vbar."""
     from svgp_vae_amd import sprites as S
     frames, La, Lc, n_act = 4, 8, 16, 9
     b = frames * 2 * G

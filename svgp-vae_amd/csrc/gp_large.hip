@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_big_kl_terms(int m, const real* __restr
     const long long mm = (long long)m * m, per = (mm + KL_NCH - 1) / KL_NCH, lo = ch * per, hi = lo + per < mm ? lo + per : mm;
     const real* Al = A + (size_t)l * mm;
     real tr = 0, muu = 0;
-    for (long long o = lo + threadIdx.x; o < hi; o += blockDim.x) tr += Ki[(size_t)(o % m) * m + o / m] * Al[o];
+    for (long long o = lo + threadIdx.x; o < hi; o += blockDim.x) tr += Ki[o] * Al[o];      // Ki is exactly symmetric (k_symmetrize)
     if (ch == 0)
         for (int i = threadIdx.x; i < m; i += blockDim.x) muu += mu[(size_t)l * m + i] * u[(size_t)l * m + i];
     tr = block_sum(tr, red);
@@ -166,27 +166,76 @@ __global__ void k_big_fb_tbar(FbArgs a) {     // tbar = td + c (K mubar)  (tbar 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.L * a.m) a.tbar[i] = a.td[i] + a.c * a.tbar[i];
 }
+// The two kernels below need X and X^T of a full (non-symmetric) product.  A workgroup owns the PAIR of 32 x 32 tiles (ti, tj),
+// (tj, ti), ti <= tj, of one channel: both tiles go through LDS, every global access is coalesced (the element-per-thread form
+// read the transposed operand with a stride of m doubles: 0.55 + 0.61 ms per step at m = 800, L = 64).
+// grid (nt, nt, L), 256 threads; thread (c = tid & 31, r0 = tid >> 5) handles rows r0 + 8 h.
+#define TP 32
+struct TilePair {
+    int ti, tj, l, c, r0;
+    __device__ __forceinline__ bool init() {
+        ti = blockIdx.y; tj = blockIdx.x; l = blockIdx.z; c = threadIdx.x & 31; r0 = threadIdx.x >> 5;
+        return ti <= tj;
+    }
+};
+__device__ __forceinline__ void tp_load(const real* __restrict__ X, int m, const TilePair& t, real (*U)[TP + 1], real (*V)[TP + 1]) {
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int r = t.r0 + 8 * h;
+        const int ui = t.ti * TP + r, uj = t.tj * TP + t.c, vi = t.tj * TP + r, vj = t.ti * TP + t.c;
+        U[r][t.c] = (ui < m && uj < m) ? X[(size_t)ui * m + uj] : real(0);
+        V[r][t.c] = (vi < m && vj < m) ? X[(size_t)vi * m + vj] : real(0);
+    }
+    __syncthreads();
+}
 // Sibar += A2 + tbar v^T ;  Kb = Z + Z^T + c mubar t^T with Z = Si (K Abar): the two products Abar G^T + Si Gbar of the
 // reverse pass are transposes of each other (Abar, K, Si symmetric), so one GEMM and a transposed read replace two GEMMs
-__global__ void k_big_fb_sibar(FbArgs a) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)a.m * a.m;
-    if (i >= mm * a.L) return;
-    const long long o = i % mm, l = i / mm;
-    const int r = (int)(o / a.m), cidx = (int)(o % a.m);
-    a.Sibar[i] += a.A2[i] + a.tbar[l * a.m + r] * a.v[l * a.m + cidx];
-    a.Kb[i] = a.Z[i] + a.Z[l * mm + (long long)cidx * a.m + r] + a.c * a.mubar[l * a.m + r] * a.t[l * a.m + cidx];
+__global__ __launch_bounds__(256) void k_big_fb_sibar(FbArgs a) {
+    __shared__ real U[TP][TP + 1], V[TP][TP + 1];
+    TilePair t;
+    if (!t.init()) return;
+    const int m = a.m;
+    const size_t mm = (size_t)m * m, lo = (size_t)t.l * mm, lv = (size_t)t.l * m;
+    tp_load(a.Z + lo, m, t, U, V);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int r = t.r0 + 8 * h;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            if (side == 1 && t.ti == t.tj) break;
+            const int gi = (side ? t.tj : t.ti) * TP + r, gj = (side ? t.ti : t.tj) * TP + t.c;
+            if (gi < m && gj < m) {
+                const size_t i = lo + (size_t)gi * m + gj;
+                const real z = side ? V[r][t.c] : U[r][t.c], zt = side ? U[t.c][r] : V[t.c][r];
+                a.Sibar[i] += a.A2[i] + a.tbar[lv + gi] * a.v[lv + gj];
+                a.Kb[i] = z + zt + a.c * a.mubar[lv + gi] * a.t[lv + gj];
+            }
+        }
+    }
 }
-__global__ void k_big_fb_ssym(FbArgs a) {     // Kb += Sg ; Ssym = c (Sg + Sg^T) ; Q = Ssym - g3 M2
-    real g3, gK; fb_scalars(a, g3, gK);
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)a.m * a.m;
-    if (i >= mm * a.L) return;
-    const long long o = i % mm, l = i / mm;
-    const int r = (int)(o / a.m), cidx = (int)(o % a.m);
-    const real sg = a.Sg[i], sgt = a.Sg[l * mm + (long long)cidx * a.m + r];
-    a.Kb[i] += sg;
-    const real ss = a.c * (sg + sgt);
-    a.Ssym[i] = ss;
-    a.Qm[i] = ss - g3 * a.M2[i];
+// Kb += Sg ; Ssym = c (Sg + Sg^T)    (Q = Ssym - g3 M2 is not formed on this path: the row stage uses Kn Ssym - g3 Kn M2)
+__global__ __launch_bounds__(256) void k_big_fb_ssym(FbArgs a) {
+    __shared__ real U[TP][TP + 1], V[TP][TP + 1];
+    TilePair t;
+    if (!t.init()) return;
+    const int m = a.m;
+    const size_t mm = (size_t)m * m, lo = (size_t)t.l * mm;
+    tp_load(a.Sg + lo, m, t, U, V);
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const int r = t.r0 + 8 * h;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            if (side == 1 && t.ti == t.tj) break;
+            const int gi = (side ? t.tj : t.ti) * TP + r, gj = (side ? t.ti : t.tj) * TP + t.c;
+            if (gi < m && gj < m) {
+                const size_t i = lo + (size_t)gi * m + gj;
+                const real sg = side ? V[r][t.c] : U[r][t.c], sgt = side ? U[t.c][r] : V[t.c][r];
+                a.Kb[i] += sg;
+                a.Ssym[i] = a.c * (sg + sgt);
+            }
+        }
+    }
 }
 // out (m x m) = sum over the L channel matrices
 __global__ void k_big_sum_channels(int mm, int L, const real* __restrict__ in, real* __restrict__ out) {
@@ -465,7 +514,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     a.u = ws + wl.u + ov; a.ud = ws + wl.ud + ov; a.td = ws + wl.td + ov; a.t = ws + wl.t + ov; a.v = ws + wl.v + ov;
     a.X1 = s.mm1; a.T1A = s.mm2; a.Kib = Kib; a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2;
     a.Sibar = s.mm3; a.Kb = Kb; a.Sg = s.mm1; a.Z = s.mm0; a.Ssym = ws + wl.Ssym + om; a.Qm = ws + wl.Qm + om;
-    const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m);
+    const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m), ntp = (unsigned)((m + TP - 1) / TP);
     GEMM(0, 1, m, m, m, 1.0, S, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);            // T1 = S Ki
     GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, s.mm1, m, mm, L);        // Ki S Ki (full product, see M2)
     hipLaunchKernelGGL(k_big_fb_abar, dim3(gmm), dim3(256), 0, st, a);             // Abar (mm1), ubar
@@ -482,12 +531,12 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     hipLaunchKernelGGL(k_big_fb_tbar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
     GEMM_SYM(0, 1, m, m, 1.0, s.mm2, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);        // Gbar K = K Abar K  (mm3)
-    hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);            // Sibar, Kb += c mubar t^T
+    hipLaunchKernelGGL(k_big_fb_sibar, dim3(ntp, ntp, L), dim3(256), 0, st, a);    // Sibar, Kb = Z + Z^T + c mubar t^T
     SVGP_LAUNCH_CHECK();
     GEMV(1.0, Si, mm, s.vec2, ws + wl.vbar + ov, L);                                        // vbar = Si tbar
     GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm3, m, mm, 0.0, s.mm0, m, mm, L);       // Si Sibar (mm0)
     GEMM(0, 1, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);      // Sg = -Si Sibar Si (mm1)
-    hipLaunchKernelGGL(k_big_fb_ssym, dim3(gmm), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_big_fb_ssym, dim3(ntp, ntp, L), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
     // sum_l Ki Kib_l Ki = Ki (sum_l Kib_l) Ki: Ki is shared by the channels and only the channel sum of Kb reaches Kbar,
     // so the two products run once on the summed matrix instead of once per channel (2 of the 13 m^3 L products of this stage)

@@ -87,30 +87,59 @@ __device__ __forceinline__ void chol64_lds(real (*Ls)[CLD], real (*colk)[CB], re
     __syncthreads();
 }
 
-// X = L^-1 for the lower-triangular 64 x 64 block in Ls (identity-padded).  Lane j of wave 0 solves L x = e_j with x in
-// registers: x_i = ((i == j) - sum_{k < i} l_ik x_k) / l_ii -- entries above the diagonal come out as exact zeros, so the
-// code is lane-uniform, the l_ik reads are LDS broadcasts and there is no barrier (the first version walked the rows
-// with 4 threads per column and one barrier per row: most of the 77 us the diagonal-block kernel still took).
-// Xs gets the full block (zeros above the diagonal).
-__device__ __forceinline__ void trinv64_lds(const real (*Ls)[CLD], real (*Xs)[CLD], const real* rdiag) {
+// X = L^-1 for the lower-triangular 64 x 64 block in Ls (identity-padded), by halves:
+//   X11 = L11^-1 (wave 0), X22 = L22^-1 (wave 1): lane j solves L x = e_j with x in registers, x_i = ((i == j) - sum_{k<i} l_ik x_k) / l_ii
+//     -- entries above the diagonal come out as exact zeros, so the code is lane-uniform, the l_ik reads are LDS
+//     broadcasts and there is no barrier (32 rows: 496 dependent-chain FMAs per lane instead of the 2016 of a 64-row solve);
+//   X21 = -X22 (L21 X11): two 32 x 32 x 32 products on the f64 MFMA, one 16 x 16 tile per wave, through the (zero, unused)
+//     upper-right quadrant of Ls as scratch, which is zeroed again.
+// In-kernel timestamps of the diagonal-block kernel (m = 800, batch 65; 100 MHz s_memrealtime): block load 2.2 us, Cholesky
+// 30 us (475 ns per column: one barrier + an LDS round trip + the rsqrt chain), log det 0.7, this inverse 15.7 -> 4.8 us
+// (it was one 64-row solve on one wave), stores 1.4.  Xs gets the full block (zeros above the diagonal).
+__device__ __forceinline__ void trinv64_lds(real (*Ls)[CLD], real (*Xs)[CLD], const real* rdiag) {
+    typedef double d4c __attribute__((ext_vector_type(4)));
+    constexpr int H = CB / 2;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     __syncthreads();
-    if (threadIdx.x < CB) {
-        const int j = threadIdx.x;
-        real x[CB];
+    if (wave < 2 && lane < H) {
+        const int o = wave * H, j = lane;
+        real x[H];
 #pragma unroll
-        for (int i = 0; i < CB; ++i) {
+        for (int i = 0; i < H; ++i) {
             real s0 = 0, s1 = 0, s2 = 0, s3 = 0;      // four partial sums: the chain of dependent FMAs is the cost
 #pragma unroll
             for (int k = 0; k + 3 < i; k += 4) {
-                s0 += Ls[i][k] * x[k]; s1 += Ls[i][k + 1] * x[k + 1]; s2 += Ls[i][k + 2] * x[k + 2]; s3 += Ls[i][k + 3] * x[k + 3];
+                s0 += Ls[o + i][o + k] * x[k]; s1 += Ls[o + i][o + k + 1] * x[k + 1];
+                s2 += Ls[o + i][o + k + 2] * x[k + 2]; s3 += Ls[o + i][o + k + 3] * x[k + 3];
             }
 #pragma unroll
-            for (int k = i & ~3; k < i; ++k) s0 += Ls[i][k] * x[k];
-            x[i] = ((i == j ? real(1) : real(0)) - ((s0 + s1) + (s2 + s3))) * rdiag[i];
+            for (int k = i & ~3; k < i; ++k) s0 += Ls[o + i][o + k] * x[k];
+            x[i] = ((i == j ? real(1) : real(0)) - ((s0 + s1) + (s2 + s3))) * rdiag[o + i];
         }
 #pragma unroll
-        for (int i = 0; i < CB; ++i) Xs[i][j] = x[i];
+        for (int i = 0; i < H; ++i) Xs[o + i][o + j] = x[i];
+    } else if (wave >= 2) {                           // upper-right quadrant of X: zeros
+        for (int e = tid - 128; e < H * H; e += 128) Xs[e / H][H + e % H] = real(0);
     }
+    __syncthreads();
+    const int r = lane & 15, q = lane >> 4, ti = 16 * (wave >> 1), tj = 16 * (wave & 1);
+    {   // T = L21 X11 -> Ls[0:32][32:64]
+        d4c acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int k0 = 0; k0 < H; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[H + ti + r][k0 + q], Xs[k0 + q][tj + r], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Ls[ti + q + 4 * e][H + tj + r] = acc[e];
+    }
+    __syncthreads();
+    {   // X21 = -X22 T
+        d4c acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int k0 = 0; k0 < H; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[H + ti + r][H + k0 + q], Ls[k0 + q][H + tj + r], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Xs[H + ti + q + 4 * e][tj + r] = -acc[e];
+    }
+    __syncthreads();
+    for (int e = tid; e < H * H; e += blockDim.x) Ls[e / H][H + e % H] = real(0);
     __syncthreads();
 }
 

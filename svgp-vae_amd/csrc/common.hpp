@@ -14,7 +14,7 @@ typedef double real;
 #define SVGP_MAX_PART 256      // max workgroups that write weight-gradient partials (= CUs)
 #define SVGP_M_MAX 64          // up to here the m x m stages stay LDS-resident (gp_kernels.hip)
 #define SVGP_M_LIMIT 2048      // beyond SVGP_M_MAX: global-memory matrices + batched MFMA GEMMs (gp_large.hip)
-#define SVGP_TWO_LEVEL_MIN_M 512   // spd inverse: fused one-level 32-block sweep below, two-level (128 / 32) from here on
+#define SVGP_CHOL_INVERSE_MIN_M 512   // spd inverse: fused 32-block Gauss-Jordan sweep below, potrf + potri from here on
 #define SVGP_LOG_2PI 1.8378770664093453
 
 void svgp_set_error(const char* fmt, ...);
@@ -114,7 +114,7 @@ static inline int svgp_n_post_actual(const svgp_mnist_cfg* c) {
     return c->m > SVGP_M_MAX ? (c->b * c->L + SVGP_BLOCK - 1) / SVGP_BLOCK : c->L * svgp_n_postblk(c);
 }
 
-// linalg.hip: fused one-launch-per-block-step inverse of nmain + nextra matrices (m < SVGP_TWO_LEVEL_MIN_M)
+// linalg.hip: fused one-launch-per-block-step inverse of nmain + nextra matrices (m < SVGP_CHOL_INVERSE_MIN_M)
 int svgp_spd_inverse_fused(int m, int nmain, double* A, double* logdet, int nextra, double* Ae, double* logdet_e,
                            double* work, void* stream);
 

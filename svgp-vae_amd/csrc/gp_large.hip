@@ -427,7 +427,7 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm)), dim3(256), 0, st, m, 1, real(0), c->jitter, K, (const real*)nullptr,
                        0LL, Ki);
     SVGP_LAUNCH_CHECK();
-    if (m < SVGP_TWO_LEVEL_MIN_M) {
+    if (m < SVGP_CHOL_INVERSE_MIN_M) {
         RUNC(svgp_spd_inverse_fused(m, L, Si, s.ldtmp, 1, Ki, ws + wl.ldK, s.inv, stream));
     } else if (Ki == Si + (size_t)L * mm) {
         // one batch of L + 1: Ki sits right behind Si in the workspace (api.hip); its log det is the last entry

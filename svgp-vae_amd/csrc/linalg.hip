@@ -233,12 +233,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
 // at waitcnt / barrier 19 % of their lifetime; the B-operand layout [j][k] (tb = 1) runs 46 vs 42 TFLOP/s for [k][j].)
 
 // ---------------------------------------------------------------------------------------------
-// Blocked Gauss-Jordan inverse (no pivoting; SPD inputs), block size 32.  Per block step kb:
-//   k_bgj_pivot : P^-1 of the (updated) diagonal block via the single-wave register sweep, log det
-//                 accumulation, and a copy of the OLD block column kb (needed by every trailing update);
-//   k_bgj_row   : row panel  A[kb][j] <- P^-1 A[kb][j]  (j != kb),  A[kb][kb] <- P^-1;
-//   k_bgj_trail : A[i][j] <- A[i][j] - Cold[i] A[kb][j]  (i != kb, j != kb);  A[i][kb] <- -Cold[i] P^-1.
-// Rows / columns >= m of the last block behave as an identity pad.
+// Blocked Gauss-Jordan inverse (no pivoting; SPD inputs), block size 32, for m < SVGP_CHOL_INVERSE_MIN_M: the pivot blocks
+// are inverted by a single-wave register sweep (gj32_sweep), the block steps run as ONE launch each (k_bgjf_step below).
+// Rows / columns >= m of the last block behave as an identity pad.  From SVGP_CHOL_INVERSE_MIN_M on the inverse comes
+// from the Cholesky factor (cholesky.hip).  (Rounds 1-2 also had a three-launch-per-step form and a two-level form with
+// 128-wide outer steps for 512 <= m < 640; potrf + potri is faster there since its triangular inverse went to the MFMA:
+// 727 against 905 us at 512 x 16.  What that work established stays true for any wider block step: the textbook form --
+// explicit P^-1 A[kb][:] and A[:, kb] P^-1 products with a 128 x 128 pivot inverse -- loses the residual |A X - I| by
+// cond(P_128) on the K + jitter matrices of this model, 3e-4 .. 3e-2 at jitter 1e-6 where the 32-block sweep gives 8e-9.)
 // ---------------------------------------------------------------------------------------------
 #define NB 32
 
@@ -252,29 +254,6 @@ __device__ __forceinline__ real wave_sum_la(real x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
     return x;
-}
-
-// The kernels work on a (nrows x ncols) panel with row stride lda whose pivot blocks sit on the diagonal
-// shifted by c0 columns: the square case is nrows = ncols = m, c0 = 0; the two-level inverse below runs them on
-// the 128-row panel of one outer block step (c0 = first column of that block).
-struct BgjArgs {
-    int nrows, ncols, lda, c0, kb, acc, batch;   // acc: add to logdet instead of starting it at block step 0
-    long long sA;          // batch stride of A
-    real* A;               // (batch, nrows, lda)
-    real* Pinv;            // (2, batch, 32, 32): inverse of pivot kb at [kb & 1] (written one step ahead)
-    real* Cold;            // (batch, nrows, 32)
-    real* logdet;          // (batch)
-    // two-level inverse only: capture of every scaled pivot row block V_kk = P_kk^-1 (row block kk), (batch, 128,
-    // ncols), and of the P_kk^-1 themselves, (batch, 4, 32, 32)
-    real* Vcap;
-    real* Pcap;
-};
-
-// element (i, j) of the 32 x 32 block at panel rows bi*32.., columns cb*32..; outside the panel the pivot block
-// is padded with the identity, every other block with zeros
-__device__ __forceinline__ real blk_get(const real* A, const BgjArgs& g, int bi, int cb, int i, int j, bool pivot) {
-    const int gi = bi * NB + i, gj = cb * NB + j;
-    return (gi < g.nrows && gj < g.ncols) ? A[(size_t)gi * g.lda + gj] : ((pivot && i == j) ? real(1) : real(0));
 }
 
 // Wave 0 of the workgroup inverts the 32 x 32 block staged in LDS (single-wave Gauss-Jordan on an 8 x 8 lane grid of
@@ -322,118 +301,8 @@ __device__ __forceinline__ void gj32_sweep(const real (*P)[NB + 1], real* __rest
     if (lane == 0) *logdet_l = (first ? real(0) : *logdet_l) + lg;
 }
 
-// pivot of block step 0 only: the later pivots are inverted by the trailing-update launch of the step before
-// (look-ahead, k_bgj_trail), which takes this 20 us launch off every later step's critical path
-__global__ __launch_bounds__(256) void k_bgj_pivot(BgjArgs g) {
-    __shared__ real P[NB][NB + 1];
-    const int l = blockIdx.x, kb = g.kb, kc = g.c0 / NB + kb;
-    real* A = g.A + (size_t)l * g.sA;
-    for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) P[t / NB][t % NB] = blk_get(A, g, kb, kc, t / NB, t % NB, true);
-    __syncthreads();
-    gj32_sweep(P, g.Pinv + ((size_t)(kb & 1) * g.batch + l) * NB * NB,
-               g.Pcap ? g.Pcap + ((size_t)l * 4 + kb) * NB * NB : nullptr, g.logdet + l, kb == 0 && !g.acc);
-}
-
-// C (32x32, registers -> out) = X (32x32, LDS) * Y (32x32, LDS) on one workgroup of 256 threads:
-// thread (i = tid/8, 4 consecutive columns j0 = (tid%8)*4)
-__device__ __forceinline__ void mm32(const real (*X)[NB + 1], const real (*Y)[NB + 1], real out[4]) {
-    const int i = threadIdx.x >> 3, j0 = (threadIdx.x & 7) * 4;
-    out[0] = out[1] = out[2] = out[3] = 0;
-#pragma unroll 8
-    for (int k = 0; k < NB; ++k) {
-        const real x = X[i][k];
-        out[0] += x * Y[k][j0]; out[1] += x * Y[k][j0 + 1]; out[2] += x * Y[k][j0 + 2]; out[3] += x * Y[k][j0 + 3];
-    }
-}
-
-// grid (column blocks, batch): block column j of the pivot row
-__global__ __launch_bounds__(256) void k_bgj_row(BgjArgs g) {
-    __shared__ real X[NB][NB + 1];
-    __shared__ real Y[NB][NB + 1];
-    const int j = blockIdx.x, l = blockIdx.y, kb = g.kb, kc = g.c0 / NB + kb;
-    real* A = g.A + (size_t)l * g.sA;
-    const real* Pinv = g.Pinv + ((size_t)(kb & 1) * g.batch + l) * NB * NB;
-    const int i = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
-    // copy of the OLD block column of the pivot, row block j (needed by every trailing update; row block kb unused)
-    if (j != kb && j * NB < g.nrows) {
-        real* Cold = g.Cold + (size_t)l * g.nrows * NB;
-        for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) {
-            const int r = j * NB + t / NB, c = t % NB, gj = kc * NB + c;
-            if (r < g.nrows) Cold[(size_t)r * NB + c] = (gj < g.ncols) ? A[(size_t)r * g.lda + gj] : real(0);
-        }
-    }
-    if (j == kc) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int gi = kb * NB + i, gj = kc * NB + c0 + e;
-            if (gi < g.nrows && gj < g.ncols) {
-                A[(size_t)gi * g.lda + gj] = Pinv[i * NB + c0 + e];
-                if (g.Vcap) g.Vcap[((size_t)l * 128 + gi) * g.ncols + gj] = real(0);
-            }
-        }
-        return;
-    }
-    for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) {
-        X[t / NB][t % NB] = Pinv[t];
-        Y[t / NB][t % NB] = blk_get(A, g, kb, j, t / NB, t % NB, false);
-    }
-    __syncthreads();
-    real out[4];
-    mm32(X, Y, out);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int gi = kb * NB + i, gj = j * NB + c0 + e;
-        if (gi < g.nrows && gj < g.ncols) {
-            A[(size_t)gi * g.lda + gj] = out[e];
-            if (g.Vcap) g.Vcap[((size_t)l * 128 + gi) * g.ncols + gj] = out[e];
-        }
-    }
-}
-
-// grid (column blocks, row blocks, batch): block (i, j), i != kb
-__global__ __launch_bounds__(256) void k_bgj_trail(BgjArgs g) {
-    __shared__ real X[NB][NB + 1];
-    __shared__ real Y[NB][NB + 1];
-    const int bj = blockIdx.x, bi = blockIdx.y, l = blockIdx.z, kb = g.kb, kc = g.c0 / NB + kb;
-    if (bi == kb) return;
-    real* A = g.A + (size_t)l * g.sA;
-    const real* Cold = g.Cold + (size_t)l * g.nrows * NB;
-    const real* Pinv = g.Pinv + ((size_t)(kb & 1) * g.batch + l) * NB * NB;
-    for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) {
-        const int r = t / NB, cidx = t % NB, gi = bi * NB + r;
-        X[r][cidx] = (gi < g.nrows) ? Cold[(size_t)gi * NB + cidx] : real(0);          // old A[i][kb]
-        if (bj == kc) Y[r][cidx] = Pinv[t];
-        else Y[r][cidx] = blk_get(A, g, kb, bj, r, cidx, false);                       // new row panel A[kb][j]
-    }
-    __syncthreads();
-    real out[4];
-    mm32(X, Y, out);
-    const int i = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const int gi = bi * NB + i, gj = bj * NB + c0 + e;
-        if (gi < g.nrows && gj < g.ncols) {
-            const size_t o = (size_t)gi * g.lda + gj;
-            out[e] = (bj == kc) ? -out[e] : A[o] - out[e];
-            A[o] = out[e];
-        } else {
-            out[e] = (gi - bi * NB == gj - bj * NB) ? real(1) : real(0);     // identity pad (only read below when pivot)
-        }
-    }
-    // look-ahead: this workgroup just produced the NEXT pivot block -> invert it now
-    if (bi == kb + 1 && bj == kc + 1 && (kb + 1) * NB < g.nrows) {
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) X[i][c0 + e] = out[e];
-        __syncthreads();
-        gj32_sweep(X, g.Pinv + ((size_t)((kb + 1) & 1) * g.batch + l) * NB * NB,
-                   g.Pcap ? g.Pcap + ((size_t)l * 4 + kb + 1) * NB * NB : nullptr, g.logdet + l, false);
-    }
-}
-
-
 // ---------------------------------------------------------------------------------------------
-// Fused form of the 32-block sweep for m < TWO_LEVEL_MIN_M: ONE launch per block step.  The three-kernel form above
+// The 32-block sweep with ONE launch per block step.  A three-kernel form
 // needs a row-panel launch before the trailing update (every trailing tile reads the scaled pivot row block) and a
 // copy of the old pivot column; here a tile recomputes the scaled pivot row block it needs (one extra 32^3 product)
 // and the step reads buffer X and writes buffer Y (ping-pong between the matrix and the workspace), so nothing is
@@ -553,128 +422,6 @@ __global__ __launch_bounds__(256) void k_bgjf_step(BgjfArgs g) {
         __syncthreads();
         gj32_sweep(Pv, g.Pinv + ((size_t)((kb + 1) & 1) * g.batch + l) * NB * NB, nullptr,
                    l < g.nmain ? g.logdet + l : g.logdet_e + (l - g.nmain), false);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Two-level inverse for m > 128: outer Gauss-Jordan block steps of 128, so the matrix is streamed m/128 times
-// (instead of m/32) and the trailing update is one K = 128 GEMM on the MFMA -- while every number is produced by
-// the SAME arithmetic as the one-level 32-block sweep (just regrouped).  That matters: on the K + jitter matrices
-// of this model the textbook 128-wide step (explicit P^-1 A[kb][:] and A[:, kb] P^-1 products, or mirroring the row
-// panel into the column panel) loses the residual |A X - I| by cond(P_128): measured 3e-4 .. 3e-2 at jitter 1e-6
-// where the 32-block sweep and this regrouping give 8e-9 (torch.linalg.inv: 2e-9).  Per outer step kb (rows r0..):
-//   extract   : R <- A[kb-rows][:]                              (128 x m row panel)
-//   row sweep : the 32-block sweep above on R; its scaled pivot row blocks V_kk and pivot inverses P_kk^-1 are kept
-//   col sweep : the same 4 sub-steps on the column panel C = A[i not in kb][kb-cols]:  T_kk <- C[:, kk];
-//               C[:, k'' != kk] -= T_kk V_kk[:, k''];  C[:, kk] <- -T_kk P_kk^-1          (T: the multipliers, m x 128)
-//   trail     : A[i][j] <- A[i][j] - sum_kk T_kk[i] V_kk[j]    = A - T V, one GEMM with K = 128
-//   write back: A[kb-rows][:] <- R;  A[i][kb-cols] <- C
-// ---------------------------------------------------------------------------------------------
-#define NO 128
-#define TWO_LEVEL_MIN_M SVGP_TWO_LEVEL_MIN_M   // below this the one-level sweep is as fast (measured: m = 256, batch 17)
-
-struct Bgj2Args {
-    int m, kb, nbk;
-    real* A;       // (batch, m, m)
-    real* R;       // (batch, NO, m)   row panel, becomes the new block row
-    real* V;       // (batch, NO, m)   captured scaled pivot rows
-    real* T;       // (batch, m, NO)   multipliers of the outside rows (0 for the rows of block kb)
-    real* C;       // (batch, m, NO)   new column panel
-    real* Pcap;    // (batch, 4, 32, 32)
-};
-
-// grid (nbk, batch), 256 threads: one contiguous row of the panel per workgroup
-__global__ __launch_bounds__(256) void k_bgj2_extract(Bgj2Args g) {
-    const int l = blockIdx.y, c = blockIdx.x, m = g.m;
-    const real* src = g.A + ((size_t)l * m + g.kb * NO + c) * m;
-    real* dst = g.R + ((size_t)l * NO + c) * m;
-    for (int i = threadIdx.x; i < m; i += blockDim.x) dst[i] = src[i];
-}
-
-// grid (ceil(m / 32), batch), 256 threads: 32 rows of the column panel through the 4 sub-steps, products on the
-// f64 MFMA
-__global__ __launch_bounds__(256) void k_bgj2_colsweep(Bgj2Args g) {
-    __shared__ real Cs[NB][NO + 1];
-    __shared__ real Ts[NB][NB + 1];
-    __shared__ real Vs[NB][NO + 1];
-    __shared__ real Ps[NB][NB + 1];
-    const int l = blockIdx.y, i0 = blockIdx.x * NB, m = g.m, r0 = g.kb * NO, nbk = g.nbk;
-    const real* A = g.A + (size_t)l * m * m;
-    for (int t = threadIdx.x; t < NB * NO; t += blockDim.x) {
-        const int r = t / NO, c = t % NO, gi = i0 + r;
-        const bool outside = gi < m && (gi < r0 || gi >= r0 + nbk);
-        Cs[r][c] = (outside && c < nbk) ? A[(size_t)gi * m + r0 + c] : real(0);
-    }
-    const int nkk = (nbk + NB - 1) / NB;
-    for (int kk = 0; kk < nkk; ++kk) {
-        __syncthreads();
-        for (int t = threadIdx.x; t < NB * NO; t += blockDim.x) {
-            const int r = t / NO, c = t % NO, pr = kk * NB + r;
-            Vs[r][c] = (pr < nbk && c < nbk) ? g.V[((size_t)l * NO + pr) * m + r0 + c] : real(0);
-        }
-        for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) {
-            Ps[t / NB][t % NB] = g.Pcap[((size_t)l * 4 + kk) * NB * NB + t];
-            Ts[t / NB][t % NB] = Cs[t / NB][kk * NB + t % NB];
-        }
-        __syncthreads();
-        // wave w owns columns [32 w, 32 w + 32) of the tile = 2 x 2 MFMA tiles, contraction over the 32 multipliers;
-        // wave kk's columns are the pivot block: there the right operand is P_kk^-1 and the result replaces C
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, mr = lane & 15, mq = lane >> 4;
-        const bool pivcols = w == kk;
-        d4_t acc[2][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2) acc[a][b2] = d4_t{0, 0, 0, 0};
-#pragma unroll
-        for (int k0 = 0; k0 < NB; k0 += 4) {
-            const real a0 = Ts[mr][k0 + mq], a1 = Ts[16 + mr][k0 + mq];
-            const real b0 = pivcols ? Ps[k0 + mq][mr] : Vs[k0 + mq][32 * w + mr];
-            const real b1 = pivcols ? Ps[k0 + mq][16 + mr] : Vs[k0 + mq][32 * w + 16 + mr];
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b2 = 0; b2 < 2; ++b2)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 16 * a + mq + 4 * e, c = 32 * w + 16 * b2 + mr;
-                    Cs[r][c] = pivcols ? -acc[a][b2][e] : Cs[r][c] - acc[a][b2][e];
-                }
-        // multipliers out: T[gi][kk*32 + 0..31]
-        for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) {
-            const int r = t / NB, c = t % NB, gi = i0 + r;
-            if (gi < m) g.T[((size_t)l * m + gi) * NO + kk * NB + c] = Ts[r][c];
-        }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < NB * NO; t += blockDim.x) {
-        const int r = t / NO, c = t % NO, gi = i0 + r;
-        if (gi < m) {
-            g.C[((size_t)l * m + gi) * NO + c] = Cs[r][c];
-            if (c >= nkk * NB) g.T[((size_t)l * m + gi) * NO + c] = real(0);
-        }
-    }
-}
-
-// grid (m + nbk, batch), 128 threads.  Workgroups [0, m): A[i outside][kb-cols] <- C[i] (128 contiguous elements);
-// workgroups [m, m + nbk): A[kb-row c][:] <- R[c] (one contiguous row)
-__global__ __launch_bounds__(NO) void k_bgj2_writeback(Bgj2Args g) {
-    const int l = blockIdx.y, m = g.m, r0 = g.kb * NO;
-    real* A = g.A + (size_t)l * m * m;
-    if ((int)blockIdx.x < m) {
-        const int i = blockIdx.x, c = threadIdx.x;
-        if ((i < r0 || i >= r0 + g.nbk) && c < g.nbk) A[(size_t)i * m + r0 + c] = g.C[((size_t)l * m + i) * NO + c];
-    } else {
-        const int c = blockIdx.x - m;
-        const real* src = g.R + ((size_t)l * NO + c) * m;
-        real* dst = A + (size_t)(r0 + c) * m;
-        for (int i = threadIdx.x; i < m; i += blockDim.x) dst[i] = src[i];
     }
 }
 
@@ -846,47 +593,19 @@ extern "C" int svgp_dgemm_splitk(int ta, int tb, int M, int N, int K, double alp
     return SVGP_OK;
 }
 
-static size_t inv_ws_inner(int nrows, int batch) { return (size_t)batch * (2 * NB * NB + (size_t)nrows * NB); }
-
 extern "C" size_t svgp_potrf_workspace_elems(int m, int batch);
 extern "C" size_t svgp_potri_workspace_elems(int m, int batch);
 extern "C" int svgp_potrf_batched(int m, int batch, double* A, int lda, long long strideA, double* logdet, double* work,
                                   void* stream);
 extern "C" int svgp_potri_batched(int m, int batch, double* A, const double* linv_blocks, double* work, void* stream);
-// From here on the inverse is formed from the Cholesky factor (cholesky.hip): half the flops of the elimination (m^3
-// against 2 m^3), nearly all of them in MFMA GEMMs.  Measured (tools/inverse_probe.py, float64, us): m = 512 x 16:
-// two-level Gauss-Jordan 889 / potrf + potri 1271;  800 x 65: 5981 / 3655;  2048 x 17: 18029 / 12386.
-#define CHOL_INVERSE_MIN_M 640
+// From SVGP_CHOL_INVERSE_MIN_M on the inverse is formed from the Cholesky factor (cholesky.hip): half the flops of the
+// elimination (m^3 against 2 m^3), nearly all of them in MFMA GEMMs.  Measured (tools/inverse_probe.py, float64, us):
+// 256 x 17: fused Gauss-Jordan 150 / potrf + potri 305;  512 x 16: (two-level Gauss-Jordan 905) / 727;  800 x 65: 2714.
+#define CHOL_INVERSE_MIN_M SVGP_CHOL_INVERSE_MIN_M
 
 extern "C" size_t svgp_spd_inverse_workspace_elems(int m, int batch) {
     if (m >= CHOL_INVERSE_MIN_M) return svgp_potrf_workspace_elems(m, batch) + svgp_potri_workspace_elems(m, batch);
-    if (m < TWO_LEVEL_MIN_M) return (size_t)batch * (2 * NB * NB + (size_t)m * m);     // pivots + the ping-pong copy
-    // R, V, T, C panels + the captured pivot inverses of the outer level + the 32-block workspace of the panel
-    return (size_t)batch * (4 * (size_t)m * NO + 4 * NB * NB) + inv_ws_inner(NO, batch);
-}
-
-// 32-block Gauss-Jordan sweep over the pivot blocks of a (nrows x ncols) panel (see BgjArgs)
-static int bgj_sweep(int nrows, int ncols, int lda, int c0, long long sA, int batch, double* A, double* logdet,
-                     double* work, int acc, double* Vcap, double* Pcap, void* stream) {
-    BgjArgs g;
-    g.nrows = nrows; g.ncols = ncols; g.lda = lda; g.c0 = c0; g.acc = acc; g.sA = sA; g.A = A;
-    g.Pinv = work; g.Cold = work + (size_t)batch * 2 * NB * NB; g.logdet = logdet; g.batch = batch;
-    g.Vcap = Vcap; g.Pcap = Pcap;
-    const int nbr = (nrows + NB - 1) / NB, nbc = (ncols + NB - 1) / NB;
-    for (int kb = 0; kb < nbr; ++kb) {
-        g.kb = kb;
-        if (kb == 0) {     // later pivots come out of the previous step's trailing update (look-ahead)
-            hipLaunchKernelGGL(k_bgj_pivot, dim3(batch), dim3(256), 0, (hipStream_t)stream, g);
-            SVGP_LAUNCH_CHECK();
-        }
-        hipLaunchKernelGGL(k_bgj_row, dim3(nbc, batch), dim3(256), 0, (hipStream_t)stream, g);
-        SVGP_LAUNCH_CHECK();
-        if (nbr > 1) {
-            hipLaunchKernelGGL(k_bgj_trail, dim3(nbc, nbr, batch), dim3(256), 0, (hipStream_t)stream, g);
-            SVGP_LAUNCH_CHECK();
-        }
-    }
-    return SVGP_OK;
+    return (size_t)batch * (2 * NB * NB + (size_t)m * m);     // pivots + the ping-pong copy
 }
 
 // The inverse of a symmetric matrix, made exactly symmetric: Y = (X + X^T) / 2 per 32 x 32 tile pair (X == Y allowed: a
@@ -919,7 +638,7 @@ __global__ __launch_bounds__(256) void k_symmetrize(int m, int nmain, const real
     }
 }
 
-// Fused one-launch-per-block-step sweep (m < TWO_LEVEL_MIN_M) over `nmain` matrices at A plus `nextra` at Ae; work
+// Fused one-launch-per-block-step sweep (m < SVGP_CHOL_INVERSE_MIN_M) over `nmain` matrices at A plus `nextra` at Ae; work
 // holds svgp_spd_inverse_workspace_elems(m, nmain + nextra) doubles.
 int svgp_spd_inverse_fused(int m, int nmain, double* A, double* logdet, int nextra, double* Ae, double* logdet_e,
                            double* work, void* stream) {
@@ -953,39 +672,8 @@ extern "C" int svgp_spd_inverse_batched(int m, int batch, double* A, double* log
     SVGP_REQUIRE(m >= 1 && batch >= 0, SVGP_ERR_INVALID, "bad m / batch");
     if (batch == 0) return SVGP_OK;
     SVGP_REQUIRE(A && logdet && work, SVGP_ERR_INVALID, "NULL device pointer");
-    if (m < TWO_LEVEL_MIN_M) return svgp_spd_inverse_fused(m, batch, A, logdet, 0, nullptr, nullptr, work, stream);
-    if (m >= CHOL_INVERSE_MIN_M) {
-        int rc = svgp_potrf_batched(m, batch, A, m, (long long)m * m, logdet, work, stream);
-        if (rc) return rc;
-        return svgp_potri_batched(m, batch, A, work, work + svgp_potrf_workspace_elems(m, batch), stream);
-    }
-    Bgj2Args g;
-    g.m = m; g.A = A; g.R = work;
-    g.V = g.R + (size_t)batch * NO * m;
-    g.T = g.V + (size_t)batch * NO * m;
-    g.C = g.T + (size_t)batch * NO * m;
-    g.Pcap = g.C + (size_t)batch * NO * m;
-    double* inner = g.Pcap + (size_t)batch * 4 * NB * NB;
-    const int nbo = (m + NO - 1) / NO;
-    hipStream_t s = (hipStream_t)stream;
-    int rc;
-    for (int kb = 0; kb < nbo; ++kb) {
-        g.kb = kb;
-        g.nbk = m - kb * NO < NO ? m - kb * NO : NO;
-        hipLaunchKernelGGL(k_bgj2_extract, dim3(g.nbk, batch), dim3(256), 0, s, g);
-        SVGP_LAUNCH_CHECK();
-        rc = bgj_sweep(g.nbk, m, m, kb * NO, (long long)NO * m, batch, g.R, logdet, inner, kb > 0, g.V, g.Pcap, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_bgj2_colsweep, dim3((m + NB - 1) / NB, batch), dim3(256), 0, s, g);
-        SVGP_LAUNCH_CHECK();
-        rc = svgp_dgemm_batched(0, 0, m, m, g.nbk, -1.0, g.T, NO, (long long)m * NO, g.V, m, (long long)NO * m, 1.0, A, m,
-                                (long long)m * m, batch, stream);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_bgj2_writeback, dim3(m + g.nbk, batch), dim3(NO), 0, s, g);
-        SVGP_LAUNCH_CHECK();
-    }
-    hipLaunchKernelGGL(k_symmetrize, dim3((m + NB - 1) / NB, (m + NB - 1) / NB, batch), dim3(256), 0, s, m, batch, A, A,
-                       (const real*)nullptr, (real*)nullptr);
-    SVGP_LAUNCH_CHECK();
-    return SVGP_OK;
+    if (m < CHOL_INVERSE_MIN_M) return svgp_spd_inverse_fused(m, batch, A, logdet, 0, nullptr, nullptr, work, stream);
+    int rc = svgp_potrf_batched(m, batch, A, m, (long long)m * m, logdet, work, stream);
+    if (rc) return rc;
+    return svgp_potri_batched(m, batch, A, work, work + svgp_potrf_workspace_elems(m, batch), stream);
 }

@@ -103,7 +103,7 @@ def test_config3_full_size_step_matches_oracle():
 @pytest.mark.parametrize("GECO", [True])
 def test_sprites_m800_step_matches_oracle(GECO):
     """BASELINE configs[3]'s GP shape inside the SPRITES step: m = 800 > rank(K_mm) = 128 (8-dim x 16-dim linear
-    kernels), so every m x m factorisation leans on jitter 0.01; two-level blocked inverse (m >= 512) in the step."""
+    kernels), so every m x m factorisation leans on jitter 0.01; inverse from the Cholesky factor (m >= 512) in the step."""
     from svgp_vae_amd import sprites as S
     b, frames, L, La, Lc, n_act, m = 100, 50, 64, 8, 16, 72, 800
     g = torch.Generator().manual_seed(800)

@@ -89,9 +89,9 @@ def test_spd_inverse_batched(m, batch):
 @pytest.mark.parametrize("m,jitter", [(128, 1e-6), (512, 1e-6), (800, 1e-4), (800, 1e-6)])
 def test_spd_inverse_residual_on_kernel_like_spectrum(m, jitter):
     """K + jitter I with a fast-decaying spectrum (what the GP block inverts, SVGPVAE_model.py:239,319,331): the
-    residuals |A X - I|, |X A - I| and the sandwich K X K must stay at torch.linalg.inv's level.  This is the property
-    the two-level (m >= 512) inverse keeps only because it regroups the 32-block sweep's arithmetic instead of taking
-    128-wide explicit products (those lose cond(P) here: 1e-2 residual at jitter 1e-6)."""
+    residuals |A X - I|, |X A - I| and the sandwich K X K must stay at torch.linalg.inv's level.  (A blocked elimination
+    with 128-wide explicit pivot-inverse products loses cond(P) here: 1e-2 residual at jitter 1e-6; the library uses the
+    32-block sweep below m = 512 and potrf + potri from there on.)"""
     g = torch.Generator(device="cuda").manual_seed(m)
     Q, _ = torch.linalg.qr(torch.randn(m, m, dtype=DT, device="cuda", generator=g))
     lam = 50 * torch.exp(-torch.arange(m, dtype=DT, device="cuda") / 8)

@@ -157,7 +157,7 @@ def test_edge_cases(case):
         # m > 64: global-memory matrices, batched MFMA GEMMs, blocked Gauss-Jordan (gp_large.hip)
         p = H.toy_problem(b=100, m=72, L=3, M=16, n_obj=30, seed=9); kw["jitter"] = 1e-4
     elif case == "m130_large_path":
-        # two-level inverse (128-block outer step + a 2 x 2 remainder).  m > GPLVM-dim-limited rank: cond(K + jI)
+        # m not a multiple of 32 (identity-padded last pivot block).  m > GPLVM-dim-limited rank: cond(K + jI)
         # ~ 1e7, so inverses from different elimination orders differ at ~1e-8 (as in cfg3_m256 below)
         p = H.toy_problem(b=150, m=130, L=2, M=24, n_obj=40, seed=10)
         kw.update(jitter=1e-4, geco=True, FWD_TOL=1e-7, GRAD_TOL=1e-6, self_consistency=True)

@@ -1,5 +1,5 @@
 """Timing of the batched SPD inverse forms at the sizes the GP block uses (information; HIP events via torch):
-fused / two-level Gauss-Jordan (svgp_spd_inverse_batched) against potrf + potri, and torch.linalg.inv (rocSOLVER)."""
+fused Gauss-Jordan / potrf + potri (svgp_spd_inverse_batched) against potrf + potri, and torch.linalg.inv (rocSOLVER)."""
 import os, sys, json
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch

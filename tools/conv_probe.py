@@ -4,8 +4,8 @@ import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 from svgp_vae_amd.conv import ConvLayer
-DT = torch.float64
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+DT = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "f32") else torch.float64      # conv_probe.py [frames] [f32]
 s = torch.cuda.current_stream().cuda_stream
 def timeit(fn, reps=5):
     fn(); torch.cuda.synchronize()
@@ -14,9 +14,9 @@ def timeit(fn, reps=5):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3
-for name, lay in (("enc 64x64 3->16 s1", ConvLayer(64, 3, 16, 3, 1, "same")), ("enc 64x64 16->16 s2", ConvLayer(64, 16, 16, 3, 2, "same")),
-                  ("enc 32x32 16->16 s1", ConvLayer(32, 16, 16, 3, 1, "same")), ("dec up 32->64 16->16", ConvLayer(32, 16, 16, 3, 1, "same", up=True)),
-                  ("dec 64x64 16->16 s1", ConvLayer(64, 16, 16, 3, 1, "same")), ("dec 64x64 16->3 s1", ConvLayer(64, 16, 3, 3, 1, "same"))):
+for name, lay in (("enc 64x64 3->16 s1", ConvLayer(64, 3, 16, 3, 1, "same", dtype=DT)), ("enc 64x64 16->16 s2", ConvLayer(64, 16, 16, 3, 2, "same", dtype=DT)),
+                  ("enc 32x32 16->16 s1", ConvLayer(32, 16, 16, 3, 1, "same", dtype=DT)), ("dec up 32->64 16->16", ConvLayer(32, 16, 16, 3, 1, "same", up=True, dtype=DT)),
+                  ("dec 64x64 16->16 s1", ConvLayer(64, 16, 16, 3, 1, "same", dtype=DT)), ("dec 64x64 16->3 s1", ConvLayer(64, 16, 3, 3, 1, "same", dtype=DT))):
     x = torch.randn(n, lay.Hi, lay.Hi, lay.Ci, dtype=DT, device="cuda")
     w = torch.randn(3, 3, lay.Ci, lay.Co, dtype=DT, device="cuda") * 0.1
     b = torch.zeros(lay.Co, dtype=DT, device="cuda")

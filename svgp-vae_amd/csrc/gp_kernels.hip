@@ -641,9 +641,12 @@ struct FactArgs {
     real* Si; real* t; real* G; real* A; real* Aji; real* mu; real* u; real* M2; real* KL; real* q;
 };
 
+// MC: compile-time m (0: a.m at run time).  With m = 32 known (config 2) the index arithmetic of every element loop (o / m,
+// o % m with a run-time divisor: ~35 instructions each) folds to shifts and the loops unroll.
+template <int MC>
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
     extern __shared__ __align__(16) real smem[];
-    const int m = a.m, mp = pad16(m), ld = mp + 2, mm = mp * ld;
+    const int m = MC ? MC : a.m, mp = pad16(m), ld = mp + 2, mm = mp * ld;
     real* R0 = smem;
     real* R1 = R0 + mm;
     real* R2 = R1 + mm;
@@ -833,9 +836,10 @@ struct FactBwdArgs {
     real* Kbar;                             // final (m,m)
 };
 
+template <int MC>
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     extern __shared__ __align__(16) real smem[];
-    const int m = a.m, mp = pad16(m), ld = mp + 2, mm = mp * ld, l = blockIdx.x;
+    const int m = MC ? MC : a.m, mp = pad16(m), ld = mp + 2, mm = mp * ld, l = blockIdx.x;
     real* R0 = smem;
     real* R1 = R0 + mm;
     real* R2 = R1 + mm;
@@ -1307,9 +1311,11 @@ static int factor_fwd_impl(const svgp_mnist_cfg* c, double* ws, int defer_aji, v
     a.u = ws + wl.u; a.M2 = ws + wl.M2; a.KL = ws + wl.KL; a.q = ws + wl.q;
     const int m = c->m, RB = rows_per_block(m);
     const size_t lds = mat_lds_pad(m, 4) + (size_t)(3 * m + 16 + SVGP_BLOCK) * sizeof(real);
-    int rc = set_dyn_lds(k_gp_factor_fwd, lds);
+    int rc = m == 32 ? set_dyn_lds(k_gp_factor_fwd<32>, lds) : set_dyn_lds(k_gp_factor_fwd<0>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gp_factor_fwd, dim3(c->L + (c->b + RB - 1) / RB), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    const dim3 grid(c->L + (c->b + RB - 1) / RB);
+    if (m == 32) hipLaunchKernelGGL(k_gp_factor_fwd<32>, grid, dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_gp_factor_fwd<0>, grid, dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
@@ -1364,9 +1370,10 @@ static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* st
     FactBwdArgs a = make_fb(c, wl, ws, state);
     const int m = c->m;
     const size_t lds = mat_lds_pad(m, 4) + (size_t)(6 * m) * sizeof(real);
-    int rc = set_dyn_lds(k_gp_factor_bwd, lds);
+    int rc = m == 32 ? set_dyn_lds(k_gp_factor_bwd<32>, lds) : set_dyn_lds(k_gp_factor_bwd<0>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_gp_factor_bwd, dim3(c->L), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    if (m == 32) hipLaunchKernelGGL(k_gp_factor_bwd<32>, dim3(c->L), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_gp_factor_bwd<0>, dim3(c->L), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
     SVGP_LAUNCH_CHECK();
     if (with_final) {
         hipLaunchKernelGGL(k_gp_factor_bwd_final, dim3((m * m + SVGP_BLOCK - 1) / SVGP_BLOCK), dim3(SVGP_BLOCK), 0,

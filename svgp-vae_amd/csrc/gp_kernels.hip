@@ -474,9 +474,10 @@ struct StatArgs {
 
 __device__ __forceinline__ real grad_KL_term(int flags, int L, const real* state) { return svgp_seed_T(flags, L, state); }
 
+template <int MC>
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
     extern __shared__ __align__(16) real smem[];
-    const int m = a.m, l = blockIdx.y;
+    const int m = MC ? MC : a.m, l = blockIdx.y;
     if (a.mode == 0 && l == a.L) {   // ---- K_mm inverse block (forward mode only, blockIdx.x == 0)
         if (blockIdx.x != 0) return;
         const int ld = m + 1;
@@ -755,9 +756,10 @@ struct PostArgs {
 
 __device__ __forceinline__ real philox_normal(unsigned long long ctr, unsigned long long idx) { return svgp_philox_normal(ctr, idx); }
 
+template <int MC>
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_fwd(PostArgs a) {
     extern __shared__ __align__(16) real smem[];
-    const int m = a.m, ld = m + 1, mm = m * ld, l = blockIdx.y;
+    const int m = MC ? MC : a.m, ld = m + 1, mm = m * ld, l = blockIdx.y;
     real* R0 = smem;            // Si_l
     real* R1 = R0 + mm;         // M2_l
     real* tv = R1 + mm;         // t_l
@@ -1021,9 +1023,10 @@ struct PostBwdArgs {
     const real* Kbar_part; real* Kbar;
 };
 
+template <int MC>
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_l(PostBwdArgs a) {
     extern __shared__ __align__(16) real smem[];
-    const int m = a.m, ld = m + 1, mm = m * ld, l = blockIdx.y;
+    const int m = MC ? MC : a.m, ld = m + 1, mm = m * ld, l = blockIdx.y;
     real* R0 = smem;            // Si_l
     real* R1 = R0 + mm;         // Q_l
     real* R2 = R1 + mm;         // Ssym_l
@@ -1078,10 +1081,11 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_l(PostBwdArgs a
     }
 }
 
+template <int MC>
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_sum(PostBwdArgs a) {
     extern __shared__ __align__(16) real smem[];
     if (a.n_final > 0 && (int)blockIdx.x >= a.nb_rows) {
-        const int m = a.m, o = (blockIdx.x - a.nb_rows) * blockDim.x + threadIdx.x;
+        const int m = MC ? MC : a.m, o = (blockIdx.x - a.nb_rows) * blockDim.x + threadIdx.x;
         if (o >= m * m) return;
         const real gT = grad_KL_term(a.geco, a.L, a.state);
         const real gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
@@ -1091,7 +1095,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_sum(PostBwdArgs
         a.Kbar[o] = s + real(0.5) * gK * (real)a.L * a.Ki[o];
         return;
     }
-    const int m = a.m, ld = m + 1, mm = m * ld;
+    const int m = MC ? MC : a.m, ld = m + 1, mm = m * ld;
     real* R0 = smem;            // Ki
     real* kr = R0 + mm;         // RB x m
     real* qb = kr + SVGP_BLOCK; // RB
@@ -1128,6 +1132,15 @@ int set_dyn_lds(F kernel, size_t bytes) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
     return SVGP_OK;
 }
+// launch of a kernel template <int MC> (compile-time m): the m = 32 instance for config 2, the run-time-m instance otherwise
+#define LAUNCH_MC(kern, m_, grid_, lds_, stream_, args_)                                                              \
+    do {                                                                                                              \
+        int rc_mc = (m_) == 32 ? set_dyn_lds(kern<32>, lds_) : set_dyn_lds(kern<0>, lds_);                             \
+        if (rc_mc) return rc_mc;                                                                                      \
+        if ((m_) == 32) hipLaunchKernelGGL(kern<32>, grid_, dim3(SVGP_BLOCK), lds_, (hipStream_t)(stream_), args_);    \
+        else hipLaunchKernelGGL(kern<0>, grid_, dim3(SVGP_BLOCK), lds_, (hipStream_t)(stream_), args_);                \
+        SVGP_LAUNCH_CHECK();                                                                                          \
+    } while (0)
 
 KernArgs make_kern_args(const svgp_mnist_cfg* c, const svgp_mnist_param_layout& pl, const double* theta,
                         const double* aux) {
@@ -1240,11 +1253,7 @@ static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     size_t lds = (size_t)(a.rc_rows * (mp_ + 2) + 3 * a.rc_rows + 2 * SVGP_BLOCK) * sizeof(real);
     const size_t lds_inv = mat_lds(m, 1) + (size_t)(5 * m + 80) * sizeof(real);
     if ((mode == 0 || with_aji) && lds_inv > lds) lds = lds_inv;
-    int rc = set_dyn_lds(k_gp_stats, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_gp_stats, dim3(P, c->L + (mode == 0 ? 1 : (with_aji ? c->L : 0))), dim3(SVGP_BLOCK), lds,
-                       (hipStream_t)stream, a);
-    SVGP_LAUNCH_CHECK();
+    LAUNCH_MC(k_gp_stats, m, dim3(P, c->L + (mode == 0 ? 1 : (with_aji ? c->L : 0))), lds, stream, a);
     return SVGP_OK;
 }
 
@@ -1335,10 +1344,7 @@ extern "C" int svgp_gp_posterior_fwd(const svgp_mnist_cfg* c, const double* eps,
     const int m = c->m, RB = rows_per_block(m), nb = (c->b + RB - 1) / RB;
     SVGP_REQUIRE((int64_t)c->L * nb <= wl.n_post, SVGP_ERR_INVALID, "partial-sum layout mismatch");
     const size_t lds = mat_lds(m, 2) + (size_t)(2 * m + SVGP_BLOCK + 4 * SVGP_BLOCK + 16) * sizeof(real);
-    int rc = set_dyn_lds(k_gp_posterior_fwd, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_gp_posterior_fwd, dim3(nb, c->L), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
-    SVGP_LAUNCH_CHECK();
+    LAUNCH_MC(k_gp_posterior_fwd, m, dim3(nb, c->L), lds, stream, a);
     return SVGP_OK;
 }
 
@@ -1404,17 +1410,11 @@ static int posterior_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double*
     a.Knbar = ws + wl.Knbar; a.knnbar = ws + wl.knnbar; a.ybar = ws + wl.ybar; a.s2bar = ws + wl.s2bar;
     const int m = c->m, RB = rows_per_block(m), nb = (c->b + RB - 1) / RB;
     const size_t lds = mat_lds(m, 3) + (size_t)(3 * m + SVGP_BLOCK + 2 * SVGP_BLOCK) * sizeof(real);
-    int rc = set_dyn_lds(k_gp_posterior_bwd_l, lds);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_gp_posterior_bwd_l, dim3(nb, c->L), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
-    SVGP_LAUNCH_CHECK();
+    LAUNCH_MC(k_gp_posterior_bwd_l, m, dim3(nb, c->L), lds, stream, a);
     const size_t lds2 = mat_lds(m, 1) + (size_t)(SVGP_BLOCK + SVGP_BLOCK) * sizeof(real);
-    rc = set_dyn_lds(k_gp_posterior_bwd_sum, lds2);
-    if (rc) return rc;
     a.nb_rows = nb; a.n_final = with_final ? (m * m + SVGP_BLOCK - 1) / SVGP_BLOCK : 0;
     a.b_global = c->b_global; a.N_train = c->N_train;
     a.Kbar_part = ws + wl.fb_part; a.Kbar = ws + wl.Kbar;
-    hipLaunchKernelGGL(k_gp_posterior_bwd_sum, dim3(nb + a.n_final), dim3(SVGP_BLOCK), lds2, (hipStream_t)stream, a);
-    SVGP_LAUNCH_CHECK();
+    LAUNCH_MC(k_gp_posterior_bwd_sum, m, dim3(nb + a.n_final), lds2, stream, a);
     return SVGP_OK;
 }

@@ -271,12 +271,15 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_xy(KernXYArgs a, r
 // VJP, inducing side: one workgroup per inducing point j.
 // d_ip[j] = [0, d_theta_j, d_o_j], partial amplitude / length-scale sums -> part_gp[j].
 #define KM_MAXM 32
+// MC / MM: compile-time m / GPLVM dimension M (0: run time); config 2 runs the <32, 8> instance (8 instead of 32 predicated
+// accumulators per thread, index divisions folded)
+template <int MC, int MM>
 __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real rep_weight, int train_ip,
                                             const real* __restrict__ K, const real* __restrict__ Kn,
                                             const real* __restrict__ Kbar, const real* __restrict__ Knbar,
                                             real* __restrict__ d_ip, real* __restrict__ part_gp) {
     __shared__ real res[KM_MAXM + 4];
-    const int st = 2 + a.M, M = a.M;
+    const int M = MM ? MM : a.M, m = MC ? MC : a.m, st = 2 + M;
     const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
     const real* oj = a.ip + (size_t)j * st + 2;
     const real thj = a.ip[(size_t)j * st + 1];
@@ -286,10 +289,10 @@ __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real
     for (int k = 0; k < KM_MAXM; ++k) acc_o[k] = 0;
     // ---- K_nm column j
     for (int n = threadIdx.x; n < a.b; n += blockDim.x) {
-        const real gk = Knbar[(size_t)n * a.m + j];
+        const real gk = Knbar[(size_t)n * m + j];
         const real d = a.aux[(size_t)n * st + 1] - thj;
         const real V = view_k(d, a2, inv_l2);
-        const real G = gk * Kn[(size_t)n * a.m + j];
+        const real G = gk * Kn[(size_t)n * m + j];
         const real sh = sin(real(0.5) * d);
         acc_amp += G;
         acc_ls += G * sh * sh;
@@ -301,14 +304,14 @@ __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real
             if (k < M) acc_o[k] += c * on[k];
     }
     // ---- K_mm: row j (first argument) and column j (second argument), replicated across ranks
-    for (int i = threadIdx.x; i < a.m; i += blockDim.x) {
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
         const real* oi = a.ip + (size_t)i * st + 2;
         const real ni = a.normalize ? sqrt(dotM(oi, oi, M)) : real(1);
         const real d = thj - a.ip[(size_t)i * st + 1];          // theta_j - theta_i  (entry (j,i))
         const real V = view_k(d, a2, inv_l2);                   // even in d
         const real sh = sin(real(0.5) * d);
-        const real g_ji = rep_weight * Kbar[(size_t)j * a.m + i], g_ij = rep_weight * Kbar[(size_t)i * a.m + j];
-        const real G_ji = g_ji * K[(size_t)j * a.m + i], G_ij = g_ij * K[(size_t)i * a.m + j];
+        const real g_ji = rep_weight * Kbar[(size_t)j * m + i], g_ij = rep_weight * Kbar[(size_t)i * m + j];
+        const real G_ji = g_ji * K[(size_t)j * m + i], G_ij = g_ij * K[(size_t)i * m + j];
         acc_amp += G_ji;
         acc_ls += G_ji * sh * sh;
         // entry (j,i): dK/dtheta_j = -K sin(d);  entry (i,j): dK/dtheta_j = +K sin(theta_i - theta_j) = -K sin(d)
@@ -357,12 +360,13 @@ __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real
 // VJP, batch-row side.  grid ceil(b/RB), RB = 256/m rows per workgroup.  Phase 1: thread (row, j)
 // computes c = Knbar * view(theta_n - theta_j) / |o_j|; phase 2: thread (row, k) reduces over j ->
 // d_on (b,M), the gradient of the gathered object row.  Also the k_nn part of the amplitude gradient.
+template <int MC, int MM>
 __device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, const real* __restrict__ Knbar,
                                             const real* __restrict__ knnbar, const real* __restrict__ knn,
                                             real* __restrict__ d_on, real* __restrict__ part_gp) {
     extern __shared__ __align__(16) real smem[];
     __shared__ real red[16];
-    const int m = a.m, M = a.M, st = 2 + M, RB = m >= (int)blockDim.x ? 1 : blockDim.x / m;
+    const int m = MC ? MC : a.m, M = MM ? MM : a.M, st = 2 + M, RB = m >= (int)blockDim.x ? 1 : blockDim.x / m;
     real* O = smem;                 // m x M inducing object vectors, divided by their norm when normalising
     real* cbuf = O + m * M;         // RB x m
     real* gbuf = cbuf + RB * m;     // RB x M (<= 256*32/m ... bounded by RB*M <= 8192/m*... see host check)
@@ -420,6 +424,7 @@ __device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, c
 }
 
 // one launch for both sides of the VJP: workgroups [0, m) = inducing side, [m, m + nrb) = batch-row side
+template <int MC, int MM>
 __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_cr(KernArgs a, real rep_weight, int train_ip,
                                                                      const real* __restrict__ K,
                                                                      const real* __restrict__ Kn,
@@ -429,8 +434,9 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_cr(KernArgs a,
                                                                      const real* __restrict__ knn,
                                                                      real* __restrict__ d_ip, real* __restrict__ d_on,
                                                                      real* __restrict__ part_gp) {
-    if ((int)blockIdx.x < a.m) km_bwd_cols(blockIdx.x, a, rep_weight, train_ip, K, Kn, Kbar, Knbar, d_ip, part_gp);
-    else km_bwd_rows(blockIdx.x - a.m, a, Knbar, knnbar, knn, d_on, part_gp);
+    const int m = MC ? MC : a.m;
+    if ((int)blockIdx.x < m) km_bwd_cols<MC, MM>(blockIdx.x, a, rep_weight, train_ip, K, Kn, Kbar, Knbar, d_ip, part_gp);
+    else km_bwd_rows<MC, MM>(blockIdx.x - m, a, Knbar, knnbar, knn, d_on, part_gp);
 }
 
 // Deterministic scatter-add of d_on into the object table gradient + the final amplitude / length-scale sums
@@ -1202,13 +1208,16 @@ static int kernel_matrix_bwd_impl(const svgp_mnist_cfg* c, const double* theta, 
     real* grad = ws + wl.grad;
     const int RBk = svgp_rows_per_block(c), nrb = (c->b + RBk - 1) / RBk;
     const size_t lds_rows = (size_t)(c->m * c->M + RBk * c->m + RBk * c->M) * sizeof(real);
+    const bool cfg2_shape = c->m == 32 && c->M == 8;
     {
-        int rc_ = set_dyn_lds(k_kernel_matrix_bwd_cr, lds_rows);
+        int rc_ = cfg2_shape ? set_dyn_lds(k_kernel_matrix_bwd_cr<32, 8>, lds_rows) : set_dyn_lds(k_kernel_matrix_bwd_cr<0, 0>, lds_rows);
         if (rc_) return rc_;
     }
-    hipLaunchKernelGGL(k_kernel_matrix_bwd_cr, dim3(c->m + nrb), dim3(SVGP_BLOCK), lds_rows, (hipStream_t)stream, a,
-                       c->rep_weight, c->train_ip, ws + wl.K, ws + wl.Kn, ws + wl.Kbar, ws + wl.Knbar, ws + wl.knnbar,
-                       ws + wl.knn, grad + pl.ip, ws + wl.d_on, ws + wl.part_gp);
+#define KM_BWD_ARGS a, c->rep_weight, c->train_ip, ws + wl.K, ws + wl.Kn, ws + wl.Kbar, ws + wl.Knbar, ws + wl.knnbar, ws + wl.knn, \
+                    grad + pl.ip, ws + wl.d_on, ws + wl.part_gp
+    if (cfg2_shape) hipLaunchKernelGGL((k_kernel_matrix_bwd_cr<32, 8>), dim3(c->m + nrb), dim3(SVGP_BLOCK), lds_rows, (hipStream_t)stream, KM_BWD_ARGS);
+    else hipLaunchKernelGGL((k_kernel_matrix_bwd_cr<0, 0>), dim3(c->m + nrb), dim3(SVGP_BLOCK), lds_rows, (hipStream_t)stream, KM_BWD_ARGS);
+#undef KM_BWD_ARGS
     SVGP_LAUNCH_CHECK();
     if (scatter) {
         const int n_ov = c->n_obj * c->M;

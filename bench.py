@@ -180,13 +180,13 @@ def stage_table(eng, B, M_IND):
          f8 * (b * m + 2 * b * Lc + Lc * m * (m + 1)), 0.0),
         ("gp_factor_fwd", "svgp_gp_factor_fwd_defer_aji", (cfg, ws, s),
          Lc * (2 * (m ** 3 / 3 + 2 * m ** 3 / 3) + 4 * 2 * m ** 3) + 2 * b * m * m, f8 * Lc * 7 * m * m, 0.0),
-        ("gp_posterior_fwd", "svgp_gp_posterior_fwd", (cfg, eps, ws, st, s), 4 * Lc * b * m * m,
+        ("gp_posterior_fwd", "svgp_gp_posterior_fwd_with_aji", (cfg, eps, ws, st, s), 4 * Lc * b * m * m,
          f8 * (Lc * 2 * m * m + b * m + 8 * b * Lc), 0.0),
         ("decoder_fwd", "svgp_mnist_decoder_fwd", (cfg, th, img, ws, s), 2 * dec_mac * b,
          f8 * (b * (Lc + act_dec + 2 * 784) + n_dec), 0.0),
         ("decoder_bwd", "svgp_mnist_decoder_bwd", (cfg, th, img, ws, st, s), 4 * dec_mac * b,
          f8 * (b * (Lc + act_dec + 2 * 784 + Lc) + 2 * n_dec), f8 * n_part * n_dec),
-        ("gp_stats_bwd", "svgp_gp_stats_bwd_with_aji", (cfg, ws, st, s), 3 * Lc * b * m * m,
+        ("gp_stats_bwd", "svgp_gp_stats_bwd", (cfg, ws, st, s), 3 * Lc * b * m * m,
          f8 * (b * m + 9 * b * Lc + Lc * m * (m + 2)), 0.0),
         ("gp_factor_bwd", "svgp_gp_factor_bwd_nofinal", (cfg, ws, st, s), Lc * 9 * 2 * m ** 3, f8 * Lc * 14 * m * m, 0.0),
         ("gp_posterior_bwd", "svgp_gp_posterior_bwd_with_final", (cfg, ws, st, s), 6 * Lc * b * m * m,

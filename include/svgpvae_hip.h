@@ -248,6 +248,10 @@ int svgp_gp_factor_fwd_defer_aji(const svgp_mnist_cfg*, double* ws, void* stream
 int svgp_mnist_encoder_kernel_matrix_fwd(const svgp_mnist_cfg*, const double* theta, const double* images,
                                          const double* aux, double* ws, void* stream);
 int svgp_gp_stats_bwd_with_aji(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+/* what the training phases use since round 2 for the same deferred work: svgp_gp_factor_fwd_defer_aji ...
+ * svgp_gp_posterior_fwd_with_aji (L more workgroups of the row-stage launch, which has several workgroups per CU in
+ * flight) ... svgp_gp_stats_bwd.  Results identical. */
+int svgp_gp_posterior_fwd_with_aji(const svgp_mnist_cfg*, const double* eps, double* ws, double* state, void* stream);
 int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 /* tf.train.AdamOptimizer.apply_gradients, TF1 formula (MNIST_experiment.py:200,207-208) */

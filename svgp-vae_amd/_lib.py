@@ -85,6 +85,7 @@ SIGNATURES = {
     "svgp_gp_stats_fwd": [_CFG, _P, _P],
     "svgp_gp_factor_fwd": [_CFG, _P, _P],
     "svgp_gp_posterior_fwd": [_CFG, _P, _P, _P, _P],
+    "svgp_gp_posterior_fwd_with_aji": [_CFG, _P, _P, _P, _P],
     "svgp_mnist_decoder_fwd": [_CFG, _P, _P, _P, _P],
     "svgp_mnist_decoder_bwd": [_CFG, _P, _P, _P, _P, _P],
     "svgp_gp_stats_bwd": [_CFG, _P, _P, _P],

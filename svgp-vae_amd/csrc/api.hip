@@ -215,12 +215,12 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         if (c->titsias) RUN(svgp_gp_titsias_stats(c, ws, stream));
         break;
     case 1:
-        RUN(svgp_gp_factor_fwd_defer_aji(c, ws, stream));      // (A_hat + jI)^-1 finishes inside gp_stats_bwd's launch
-        RUN(svgp_gp_posterior_fwd(c, eps, ws, state, stream));
+        RUN(svgp_gp_factor_fwd_defer_aji(c, ws, stream));      // (A_hat + jI)^-1 finishes inside the row-stage launch
+        RUN(svgp_gp_posterior_fwd_with_aji(c, eps, ws, state, stream));
         if (c->titsias) RUN(svgp_gp_titsias_fwd(c, ws, state, stream));
         RUN(svgp_mnist_decoder_fwd(c, theta, images, ws, stream));
         RUN(svgp_mnist_decoder_bwd(c, theta, images, ws, state, stream));
-        RUN(svgp_gp_stats_bwd_with_aji(c, ws, state, stream));
+        RUN(svgp_gp_stats_bwd(c, ws, state, stream));
         break;
     case 2:
         RUN(svgp_gp_factor_bwd_nofinal(c, ws, state, stream));          // channel sum Kbar: inside the next launch

@@ -757,7 +757,10 @@ struct PostArgs {
     const real* Si; const real* M2; const real* t; const real* u;
     const real* eps_in; const real* state;
     real* eps; real* p_m; real* p_v; real* e; real* d; real* z;
-    real* part;     // (L * gridDim.x, 2) partial [L3 data term, CE]
+    real* part;     // (L * nb, 2) partial [L3 data term, CE]
+    int nb;         // row blocks (grid x; one more column of workgroups when with_aji)
+    // with_aji: workgroup (nb, l) finishes (A_hat_l + jI)^-1 and the log det term of KL_l (deferred by svgp_gp_factor_fwd_defer_aji)
+    int with_aji; real jitter; const real* Ahat; real* Aji; real* KL;
 };
 
 __device__ __forceinline__ real philox_normal(unsigned long long ctr, unsigned long long idx) { return svgp_philox_normal(ctr, idx); }
@@ -766,6 +769,23 @@ template <int MC>
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_fwd(PostArgs a) {
     extern __shared__ __align__(16) real smem[];
     const int m = MC ? MC : a.m, ld = m + 1, mm = m * ld, l = blockIdx.y;
+    const int bx = (int)blockIdx.x - a.with_aji;      // the riders take x = 0: first in dispatch order, they run longest
+    if (bx < 0) {
+        // ---- deferred tail of the forward factor stage: Aji = (A_hat + jitter I)^-1 and the log det term of KL
+        // (SVGPVAE_model.py:271-279).  Only the reverse pass and the KL scalar need them.  This launch has several
+        // workgroups per CU in flight, so the 8.8 us single-wave sweep runs beside the row blocks instead of bounding
+        // the reverse statistics launch (which needs 5.7 us without it; riding in the decoder launch does not work:
+        // its 256 image workgroups fill the chip one per CU and a rider would wait for the first of them to finish).
+        real* A = smem;
+        real* W = A + m * ld;
+        mat_load(A, ld, a.Ahat + (size_t)l * m * m, m);
+        __syncthreads();
+        if ((int)threadIdx.x < m) A[threadIdx.x * ld + threadIdx.x] += a.jitter;
+        const real ldA = chol_inv(A, W, ld, m);
+        mat_store(a.Aji + (size_t)l * m * m, A, ld, m);
+        if (threadIdx.x == 0) a.KL[l] -= real(0.5) * ldA;
+        return;
+    }
     real* R0 = smem;            // Si_l
     real* R1 = R0 + mm;         // M2_l
     real* tv = R1 + mm;         // t_l
@@ -774,7 +794,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_fwd(PostArgs a) {
     real* sc = kr + SVGP_BLOCK; // 4 x 256 partial products
     real* red = sc + 4 * SVGP_BLOCK;
     const int RB = blockDim.x / m;
-    const int nl = threadIdx.x / m, i = threadIdx.x % m, n = blockIdx.x * RB + nl;
+    const int nl = threadIdx.x / m, i = threadIdx.x % m, n = bx * RB + nl;
     const bool act = nl < RB && n < a.b;
     const size_t om = (size_t)l * m * m;
     mat_load(R0, ld, a.Si + om, m);
@@ -824,7 +844,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_fwd(PostArgs a) {
     l3 = block_sum(l3, red);
     ce = block_sum(ce, red);
     if (threadIdx.x == 0) {
-        const size_t pi = ((size_t)l * gridDim.x + blockIdx.x) * 2;
+        const size_t pi = ((size_t)l * a.nb + bx) * 2;
         a.part[pi] = l3; a.part[pi + 1] = ce;
     }
 }
@@ -1338,8 +1358,20 @@ static int factor_fwd_impl(const svgp_mnist_cfg* c, double* ws, int defer_aji, v
     return SVGP_OK;
 }
 
+static int posterior_fwd_impl(const svgp_mnist_cfg* c, const double* eps, double* ws, double* state, bool with_aji,
+                              void* stream);
 extern "C" int svgp_gp_posterior_fwd(const svgp_mnist_cfg* c, const double* eps, double* ws, double* state,
                                      void* stream) {
+    return posterior_fwd_impl(c, eps, ws, state, false, stream);
+}
+// training-phase form (m <= 64; for larger m the plain stage): L more workgroups finish what svgp_gp_factor_fwd_defer_aji
+// left out; svgp_gp_stats_bwd (plain) follows later in the step.
+extern "C" int svgp_gp_posterior_fwd_with_aji(const svgp_mnist_cfg* c, const double* eps, double* ws, double* state,
+                                              void* stream) {
+    return posterior_fwd_impl(c, eps, ws, state, true, stream);
+}
+static int posterior_fwd_impl(const svgp_mnist_cfg* c, const double* eps, double* ws, double* state, bool with_aji,
+                              void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     if (c->m > SVGP_M_MAX) return svgp_big_posterior_fwd(c, wl, eps, ws, state, stream);
@@ -1352,8 +1384,11 @@ extern "C" int svgp_gp_posterior_fwd(const svgp_mnist_cfg* c, const double* eps,
     a.part = ws + wl.part_sums + (size_t)svgp_n_part(c) * 4;
     const int m = c->m, RB = rows_per_block(m), nb = (c->b + RB - 1) / RB;
     SVGP_REQUIRE((int64_t)c->L * nb <= wl.n_post, SVGP_ERR_INVALID, "partial-sum layout mismatch");
-    const size_t lds = mat_lds(m, 2) + (size_t)(2 * m + SVGP_BLOCK + 4 * SVGP_BLOCK + 16) * sizeof(real);
-    LAUNCH_MC(k_gp_posterior_fwd, m, dim3(nb, c->L), lds, stream, a);
+    size_t lds = mat_lds(m, 2) + (size_t)(2 * m + SVGP_BLOCK + 4 * SVGP_BLOCK + 16) * sizeof(real);
+    const size_t lds_inv = mat_lds(m, 1) + (size_t)(5 * m + 80) * sizeof(real);
+    if (with_aji && lds_inv > lds) lds = lds_inv;
+    a.nb = nb; a.with_aji = with_aji; a.jitter = c->jitter; a.Ahat = ws + wl.A; a.Aji = ws + wl.Aji; a.KL = ws + wl.KL;
+    LAUNCH_MC(k_gp_posterior_fwd, m, dim3(nb + (with_aji ? 1 : 0), c->L), lds, stream, a);
     return SVGP_OK;
 }
 

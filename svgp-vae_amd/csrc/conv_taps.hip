@@ -84,7 +84,13 @@ __device__ __forceinline__ void tap_range_all(const ConvLaunch& L, int& oy0, int
     }
 }
 
-template <typename T>
+// CI4 / NT: compile-time padded channel count and tap count (0: run time).  With both known the 9 x 4 (or 4 x 4) MFMA
+// groups of a 16-pixel x 16-channel output tile are straight-line code: the run-time loops paid a taken branch (~32 cycles)
+// per 4-channel step and a scalar load of the tap offsets per tap, next to MFMAs of 32 (f32) / 64 (f64) cycles:
+// 64 x 64, 16 -> 16, 500 frames: 198 -> 168 us in float32 (56 TFLOP/s), 310 -> 280 us in float64.  Where the rest goes
+// (temporary switches, float32): without the halo staging 134 us, without the stores 144, with neither 105 (90 TFLOP/s =
+// 57 % of the f32 MFMA peak) -- the three phases of a workgroup add up although 7 workgroups per CU are resident.
+template <typename T, int CI4, int NT>
 __global__ __launch_bounds__(256) void k_conv_taps_fwd(ConvLaunch L, int nchunk, const T* __restrict__ in,
                                                        const T* __restrict__ w, const T* __restrict__ bias,
                                                        T* __restrict__ out) {
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(256) void k_conv_taps_fwd(ConvLaunch L, int nchunk,
     const int tiles_x = (d.Ws + CT_TW - 1) / CT_TW;
     const int x0 = (blockIdx.x % tiles_x) * CT_TW, y0 = (blockIdx.x / tiles_x) * CT_TH;
     if (y0 >= d.Hs) return;
-    const int Ci4 = (d.Ci + 3) & ~3, ps = Ci4 + 2;         // channels padded to 4, pixel stride
+    const int Ci4 = CI4 ? CI4 : (d.Ci + 3) & ~3, ps = Ci4 + 2;         // channels padded to 4, pixel stride
     int oy0, oy1, ox0, ox1;
     tap_range_all(L, oy0, oy1, ox0, ox1);
     const int hy0 = y0 * d.sy + oy0, hx0 = x0 * d.sx + ox0;
@@ -129,10 +135,27 @@ __global__ __launch_bounds__(256) void k_conv_taps_fwd(ConvLaunch L, int nchunk,
             if (y >= dc.Hs) continue;
             const int wb = cls == 0 ? wbase[0] : cls == 1 ? wbase[1] : cls == 2 ? wbase[2] : wbase[3];
             typename MF::acc_t acc = {0, 0, 0, 0};
-            for (int tp = 0; tp < dc.nt; ++tp) {
-                const T* ap = tile + ((ly * d.sy + dc.oy[tp] - oy0) * hw + (r * d.sx + dc.ox[tp] - ox0)) * ps + q;
-                const T* bp = wl + wb + (tp * Ci4 + q) * 16 + r;
-                for (int c0 = 0; c0 < Ci4; c0 += 4) acc = MF::mma(ap[c0], bp[c0 * 16], acc);
+            if (NT > 0 && CI4 > 0) {
+                // two accumulators: consecutive MFMAs do not wait on each other
+                typename MF::acc_t acc2 = {0, 0, 0, 0};
+#pragma unroll
+                for (int tp = 0; tp < NT; ++tp) {
+                    const T* ap = tile + ((ly * d.sy + dc.oy[tp] - oy0) * hw + (r * d.sx + dc.ox[tp] - ox0)) * ps + q;
+                    const T* bp = wl + wb + (tp * CI4 + q) * 16 + r;
+#pragma unroll
+                    for (int c0 = 0; c0 < CI4; c0 += 4) {
+                        if (((tp * (CI4 / 4) + c0 / 4) & 1) == 0) acc = MF::mma(ap[c0], bp[c0 * 16], acc);
+                        else acc2 = MF::mma(ap[c0], bp[c0 * 16], acc2);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] += acc2[g];
+            } else {
+                for (int tp = 0; tp < dc.nt; ++tp) {
+                    const T* ap = tile + ((ly * d.sy + dc.oy[tp] - oy0) * hw + (r * d.sx + dc.ox[tp] - ox0)) * ps + q;
+                    const T* bp = wl + wb + (tp * Ci4 + q) * 16 + r;
+                    for (int c0 = 0; c0 < Ci4; c0 += 4) acc = MF::mma(ap[c0], bp[c0 * 16], acc);
+                }
             }
             // D: column (co) = lane & 15, row (pixel) = MF::row(q, g)
             const int gy = y * dc.osy + dc.ooy;
@@ -400,15 +423,28 @@ static int conv_taps_fwd_impl(const svgp_conv_desc* d, int ncls, const T* in, co
     for (int c = 0; c < ncls; ++c) lds += (size_t)d[c].nt * ((d[0].Ci + 3) & ~3) * 16;
     lds *= sizeof(T);
     SVGP_REQUIRE(lds <= 160 * 1024, SVGP_ERR_UNSUPPORTED, "conv tile needs %zu bytes of LDS", lds);
-    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_taps_fwd<T>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int tiles = ((d[0].Ws + CT_TW - 1) / CT_TW) * ((d[0].Hs + CT_TH - 1) / CT_TH);
     // enough workgroups for ~8 per CU, each walking n / nchunk images of its tile position
     int nchunk = (2048 + tiles - 1) / tiles;
     if (nchunk > d[0].n) nchunk = d[0].n;
     if (nchunk < 1) nchunk = 1;
-    hipLaunchKernelGGL(k_conv_taps_fwd<T>, dim3(tiles, 1, nchunk), dim3(256), lds, (hipStream_t)stream, L, nchunk, in, w, bias,
-                       out);
+    // straight-line instances for the layer shapes of the SPRITES networks: 16 (or 4 = padded 3) input channels, 9 taps
+    // (3 x 3) or 4 taps (the parity classes of the upsample-fused / transposed stride-2 layers), every class alike
+    const int Ci4 = (d[0].Ci + 3) & ~3;
+    int nt_all = d[0].nt;
+    for (int c = 1; c < ncls; ++c) if (d[c].nt != nt_all) nt_all = 0;
+#define CONV_FWD_LAUNCH(CI4_, NT_)                                                                                          \
+    do {                                                                                                                    \
+        SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_taps_fwd<T, CI4_, NT_>),                     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+        hipLaunchKernelGGL((k_conv_taps_fwd<T, CI4_, NT_>), dim3(tiles, 1, nchunk), dim3(256), lds, (hipStream_t)stream, L,   \
+                           nchunk, in, w, bias, out);                                                                       \
+    } while (0)
+    if (Ci4 == 16 && nt_all == 9) CONV_FWD_LAUNCH(16, 9);
+    else if (Ci4 == 16 && nt_all == 4) CONV_FWD_LAUNCH(16, 4);
+    else if (Ci4 == 4 && nt_all == 9) CONV_FWD_LAUNCH(4, 9);
+    else CONV_FWD_LAUNCH(0, 0);
+#undef CONV_FWD_LAUNCH
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

@@ -23,13 +23,14 @@ for name, lay in (("enc 64x64 3->16 s1", ConvLayer(64, 3, 16, 3, 1, "same", dtyp
     out = torch.empty(n, lay.Ho, lay.Ho, lay.Co, dtype=DT, device="cuda")
     dout = torch.randn_like(out)
     gw, gb = torch.empty_like(w), torch.empty_like(b)
-    scratch = torch.zeros(lay.scratch_elems(512), dtype=DT, device="cuda")
+    NWG = int(os.environ.get("CONV_NWG", "512"))
+    scratch = torch.zeros(lay.scratch_elems(NWG), dtype=DT, device="cuda")
     flops = 2.0 * 9 * lay.Ci * lay.Co * n * lay.Ho * lay.Ho
     if lay.up:
         flops = 2.0 * 4 * lay.Ci * lay.Co * n * lay.Ho * lay.Ho       # four 2x2 parity classes
     tf = timeit(lambda: lay.forward(x, w, b, out, s))
     d2 = dout.clone()
-    tb = timeit(lambda: lay.backward(x, w, out, d2, gw, gb, scratch, s, need_dx=True))
-    tw = timeit(lambda: lay.backward(x, w, out, d2, gw, gb, scratch, s, need_dx=False))
+    tb = timeit(lambda: lay.backward(x, w, out, d2, gw, gb, scratch, s, need_dx=True, nwg=NWG))
+    tw = timeit(lambda: lay.backward(x, w, out, d2, gw, gb, scratch, s, need_dx=False, nwg=NWG))
     print(f"{name}: fwd {tf*1e6:.0f} us ({flops/tf/1e12:.1f} TF)  bwd(elu+wgrad+dgrad) {tb*1e6:.0f} us  elu+wgrad {tw*1e6:.0f} us "
           f"({flops/tw/1e12:.1f} TF)  dgrad {max(tb-tw,1e-9)*1e6:.0f} us ({flops/max(tb-tw,1e-9)/1e12:.1f} TF)", flush=True)

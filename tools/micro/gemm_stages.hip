@@ -166,11 +166,14 @@ template <int WT, int MODE, bool VEC> void run(int m, int batch, const double* A
            5.0 * 2.0 * m * m * m * batch / (ms * 1e-3) * 1e-12);
 }
 
+__global__ void fill(double* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 1e-3 * (double)((i * 2654435761u) % 1000) - 0.5;
+}
 int main() {
     const int m = 768, batch = 64;
     double *A, *B, *C;
     (void)hipMalloc(&A, (size_t)m * m * batch * 8); (void)hipMalloc(&B, (size_t)m * m * batch * 8); (void)hipMalloc(&C, (size_t)m * m * batch * 8);
-    (void)hipMemset(A, 0, (size_t)m * m * batch * 8); (void)hipMemset(B, 0, (size_t)m * m * batch * 8);
+    hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, A, (size_t)m * m * batch); hipLaunchKernelGGL(fill, dim3(1024), dim3(256), 0, 0, B, (size_t)m * m * batch);
     run<2, 3, false>(m, batch, A, B, C); run<2, 6, false>(m, batch, A, B, C); run<2, 6, true>(m, batch, A, B, C);
     run<2, 7, false>(m, batch, A, B, C); run<2, 7, true>(m, batch, A, B, C); run<2, 8, true>(m, batch, A, B, C);
     run<4, 3, false>(m, batch, A, B, C); run<4, 6, false>(m, batch, A, B, C); run<4, 6, true>(m, batch, A, B, C);

@@ -180,6 +180,8 @@ def stage_table(eng, B, M_IND):
          f8 * (b * m + 2 * b * Lc + Lc * m * (m + 1)), 0.0),
         ("gp_factor_fwd", "svgp_gp_factor_fwd_defer_aji", (cfg, ws, s),
          Lc * (2 * (m ** 3 / 3 + 2 * m ** 3 / 3) + 4 * 2 * m ** 3) + 2 * b * m * m, f8 * Lc * 7 * m * m, 0.0),
+    ] + ([("gp_factor_fwd_aji_tail (side stream in the step)", "svgp_gp_factor_fwd_aji_tail", (cfg, ws, s), Lc * 2 * m ** 3,
+           f8 * Lc * 2 * m * m, 0.0)] if m > 64 else []) + [
         ("gp_posterior_fwd", "svgp_gp_posterior_fwd_with_aji", (cfg, eps, ws, st, s), 4 * Lc * b * m * m,
          f8 * (Lc * 2 * m * m + b * m + 8 * b * Lc), 0.0),
         ("decoder_fwd", "svgp_mnist_decoder_fwd", (cfg, th, img, ws, s), 2 * dec_mac * b,

@@ -252,6 +252,12 @@ int svgp_gp_stats_bwd_with_aji(const svgp_mnist_cfg*, double* ws, const double* 
  * svgp_gp_posterior_fwd_with_aji (L more workgroups of the row-stage launch, which has several workgroups per CU in
  * flight) ... svgp_gp_stats_bwd.  Results identical. */
 int svgp_gp_posterior_fwd_with_aji(const svgp_mnist_cfg*, const double* eps, double* ws, double* state, void* stream);
+/* m > 64: svgp_gp_factor_fwd_defer_aji leaves out the whole tail of the stage -- (A_hat_l + jI)^-1, its log det and the KL_l
+ * scalars -- and this call performs it.  It may be issued on a DIFFERENT stream (ordered after svgp_gp_factor_fwd_defer_aji,
+ * joined before svgp_gp_factor_bwd / the final scalars): it shares no buffer with svgp_gp_posterior_fwd, the decoder and
+ * svgp_gp_stats_bwd, so the second batched inverse of the step runs beside them (svgp_mnist_step_phase does this on a
+ * library-owned side stream unless SVGP_SIDE_STREAMS=0). */
+int svgp_gp_factor_fwd_aji_tail(const svgp_mnist_cfg*, double* ws, void* stream);
 int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 /* tf.train.AdamOptimizer.apply_gradients, TF1 formula (MNIST_experiment.py:200,207-208) */

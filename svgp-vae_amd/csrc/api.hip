@@ -194,15 +194,18 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
     SVGP_REQUIRE(theta && images && aux && ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     SVGP_REQUIRE(phase >= 0 && phase <= 3, SVGP_ERR_INVALID, "phase %d out of range 0..3", phase);
     hipStream_t ms = (hipStream_t)stream;
-    (void)defer;
     // Measured on MI355X (tools/fork_probe.py): a fork + join costs ~10 us of cross-stream signalling.  The
     // kernel-matrix reverse pass || encoder reverse pass branch hides ~20 us, which pays only in the
     // per-phase-graph replay form (phase 2: 110 -> 100 us) and loses in the eager in-order form
     // (261 -> 283 us per step), so it is opt-in: SVGP_SIDE_STREAMS=1.
     const char* fk = getenv("SVGP_SIDE_STREAMS");
     const bool fork2 = fk && fk[0] == '1';
+    // Large-m path: the tail of the forward factor stage ((A_hat + jI)^-1, its log det, KL: a whole batched inverse that only
+    // the reverse factor stage and the final ELBO need) runs on side stream 1, beside the row stage, the decoder and the
+    // reverse statistics.  That hides ~140 us at config 3 for ~10 us of signalling, so it is on unless SVGP_SIDE_STREAMS=0.
+    const bool fork1 = c->m > SVGP_M_MAX && !(fk && fk[0] == '0');
     Side* sd = nullptr;
-    if (fork2) {
+    if (fork2 || fork1) {
         rc = side_get(&sd);
         if (rc) return rc;
     }
@@ -215,14 +218,20 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         if (c->titsias) RUN(svgp_gp_titsias_stats(c, ws, stream));
         break;
     case 1:
-        RUN(svgp_gp_factor_fwd_defer_aji(c, ws, stream));      // (A_hat + jI)^-1 finishes inside the row-stage launch
+        RUN(svgp_gp_factor_fwd_defer_aji(c, ws, stream));      // m <= 64: (A_hat + jI)^-1 finishes inside the row-stage launch
+        if (c->m > SVGP_M_MAX) {                               // m > 64: ... on the side stream
+            if (fork1) RUN(side_fork(sd, 1, ms));
+            RUN(svgp_gp_factor_fwd_aji_tail(c, ws, fork1 ? (void*)sd->s[1] : stream));
+        }
         RUN(svgp_gp_posterior_fwd_with_aji(c, eps, ws, state, stream));
         if (c->titsias) RUN(svgp_gp_titsias_fwd(c, ws, state, stream));
         RUN(svgp_mnist_decoder_fwd(c, theta, images, ws, stream));
         RUN(svgp_mnist_decoder_bwd(c, theta, images, ws, state, stream));
         RUN(svgp_gp_stats_bwd(c, ws, state, stream));
+        if (fork1 && !defer) RUN(side_join(sd, 1, ms));        // phase-at-a-time callers: joined before the phase returns
         break;
     case 2:
+        if (fork1) RUN(side_join(sd, 1, ms));                           // (a no-op unless phase 1 left the branch open)
         RUN(svgp_gp_factor_bwd_nofinal(c, ws, state, stream));          // channel sum Kbar: inside the next launch
         RUN(svgp_gp_posterior_bwd_with_final(c, ws, state, stream));
         if (c->titsias) RUN(svgp_gp_titsias_bwd(c, ws, state, stream));

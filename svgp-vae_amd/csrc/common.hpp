@@ -130,7 +130,8 @@ int svgp_dgemm_symout_batched(int f32c, int ta, int tb, int M, int K, double alp
 // large-m implementations (gp_large.hip)
 int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state, int mode,
                    void* stream);
-int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, void* stream, int l0, int nl);
+int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, void* stream, int l0, int nl,
+                        int part = 0);
 int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, const double* eps, double* ws,
                            double* state, void* stream);
 int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,

@@ -1318,6 +1318,15 @@ extern "C" int svgp_gp_factor_fwd(const svgp_mnist_cfg* c, double* ws, void* str
 extern "C" int svgp_gp_factor_fwd_defer_aji(const svgp_mnist_cfg* c, double* ws, void* stream) {
     return factor_fwd_impl(c, ws, 1, stream);
 }
+// m > 64: the tail that svgp_gp_factor_fwd_defer_aji leaves out -- (A_hat_l + jI)^-1, its log det, KL_l; may run on another
+// stream than the stages that follow (it shares no buffer with the row stage, the decoder and the reverse statistics)
+extern "C" int svgp_gp_factor_fwd_aji_tail(const svgp_mnist_cfg* c, double* ws, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED,
+                 "for m <= %d the deferred inverse rides in svgp_gp_posterior_fwd_with_aji / svgp_gp_stats_bwd_with_aji", SVGP_M_MAX);
+    return svgp_big_factor_fwd(c, wl, ws, stream, 0, c->L, 2);
+}
 // channel windows of the factor stages (large-m path): see svgp_big_factor_fwd
 extern "C" int svgp_gp_factor_fwd_channels(const svgp_mnist_cfg* c, int l0, int nl, double* ws, void* stream) {
     GET_LAYOUTS();
@@ -1340,7 +1349,7 @@ extern "C" int svgp_gp_factor_bwd_channels(const svgp_mnist_cfg* c, int l0, int 
 static int factor_fwd_impl(const svgp_mnist_cfg* c, double* ws, int defer_aji, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
-    if (c->m > SVGP_M_MAX) return svgp_big_factor_fwd(c, wl, ws, stream, 0, c->L);
+    if (c->m > SVGP_M_MAX) return svgp_big_factor_fwd(c, wl, ws, stream, 0, c->L, defer_aji ? 1 : 0);
     FactArgs a;
     a.defer_aji = defer_aji; a.kl_form = c->kl_form; a.P = svgp_stat_parts(c);
     a.b = c->b; a.m = c->m; a.L = c->L; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;

@@ -412,7 +412,13 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
 // Channel window [l0, l0 + nl): the factor stage of those channels only (all of them: l0 = 0, nl = L).  With the batch
 // sharded over ranks and the statistics reduce-SCATTERED over channels, every rank factors L / G channels instead of all
 // L redundantly; (K_mm + jI)^-1 and q_n are channel-independent and computed by every caller.
-int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, void* stream, int l0, int nl) {
+// part: 0 = the whole stage; 1 = without its tail -- (A_hat_l + jI)^-1, its log det and the KL_l scalars, which only the
+// reverse factor stage and the final ELBO need; 2 = that tail alone.  The training step issues the tail on a side stream
+// (api.hip, sprites.py) so that the second batched inverse of the step runs beside the row stage, the decoder and the
+// reverse statistics instead of in front of them.  The tail touches A (read), Aji, KL, the inverse workspace, s.ldtmp and
+// the trace partials in fb_part -- nothing the stages between the two factor stages use.
+int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, void* stream, int l0, int nl,
+                        int part) {
     const int b = c->b, m = c->m, L = nl;
     const long long mm = (long long)m * m;
     const real cc = c->N_train / (double)c->b_global;
@@ -421,6 +427,8 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     const size_t om = (size_t)l0 * mm, ov = (size_t)l0 * m;
     real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si + om, *G = ws + wl.G + om, *A = ws + wl.A + om, *Aji = ws + wl.Aji + om;
     real *t = ws + wl.t + ov, *mu = ws + wl.mu_hat + ov, *u = ws + wl.u + ov, *v = ws + wl.v + ov, *M2 = ws + wl.M2 + om, *Kn = ws + wl.Kn;
+    real* klp = ws + wl.fb_part;                 // (L, KL_NCH, 2) trace partials (fb_part is free until the reverse factor stage)
+    if (part == 2) goto aji_tail;
     hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, cc, c->jitter, K, ws + wl.S + om, 0LL, Si);
     SVGP_LAUNCH_CHECK();
     // K_mm inverse + log det (SVGPVAE_model.py:239,270,273) next to the channel matrices (:331)
@@ -447,19 +455,20 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     // eps |Ki||A||Ki|, far above eps |M2|), harmless in k^T M2 k for k in the range of K_mm (k^T Ki is small) but not once
     // a triangular mask breaks that form (config-3 shape at jitter 1e-2: `d` moved by 9e-6; K X K products are fine)
     GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, M2, m, mm, L);                          // M2 = Ki A Ki
-    // s.mm0 (T = A Ki) is free once M2 is formed: its head holds the (L, KL_NCH, 2) trace partials
-    hipLaunchKernelGGL(k_big_kl_terms, dim3(KL_NCH, L), dim3(256), 0, st, m, Ki, A, mu, u, s.mm0);
-    SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, real(0), c->jitter, A,
-                       (const real*)nullptr, mm, Aji);
-    SVGP_LAUNCH_CHECK();
-    RUNC(svgp_spd_inverse_batched(m, L, Aji, s.ldtmp, s.inv, stream));
-    hipLaunchKernelGGL(k_big_kl, dim3(nblk(L)), dim3(256), 0, st, m, L, ws + wl.ldK, s.ldtmp, s.mm0, ws + wl.KL + l0);
+    hipLaunchKernelGGL(k_big_kl_terms, dim3(KL_NCH, L), dim3(256), 0, st, m, Ki, A, mu, u, klp);
     SVGP_LAUNCH_CHECK();
     // q_n = k_n^T Ki k_n
     GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, Ki, m, 0, 0.0, s.KnKi, m, 0, 1);           // kept: the reverse pass reads Kn Ki again
     hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * 64)), dim3(256), 0, st, b, m, 1, real(1), s.KnKi, 0LL, Kn,
                        ws + wl.q, 1, 0);
+    SVGP_LAUNCH_CHECK();
+    if (part == 1) return SVGP_OK;
+aji_tail:
+    hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, real(0), c->jitter, A,
+                       (const real*)nullptr, mm, Aji);
+    SVGP_LAUNCH_CHECK();
+    RUNC(svgp_spd_inverse_batched(m, L, Aji, s.ldtmp, s.inv, stream));
+    hipLaunchKernelGGL(k_big_kl, dim3(nblk(L)), dim3(256), 0, st, m, L, ws + wl.ldK, s.ldtmp, klp, ws + wl.KL + l0);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

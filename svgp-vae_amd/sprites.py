@@ -22,6 +22,7 @@ runs every product of the large-m GP block on the float32 MFMA (float64 storage)
 products.  The m x m factorisations / inverses, the scalar epilogue, Adam and the master parameters stay float64.
 """
 import ctypes as C
+import os
 import math
 
 import numpy as np
@@ -125,6 +126,8 @@ class SpritesStepEngine:
         # `comm` (engine.RcclComm) sums the three exchange blocks on the compute stream
         self.rank, self.world_size, self.comm = rank, world_size, comm
         self.stream = torch.cuda.Stream(device=self.dev)
+        # side stream of the deferred forward-factor tail (None: everything on the one stream; SVGP_SIDE_STREAMS=0)
+        self.side = None if os.environ.get("SVGP_SIDE_STREAMS") == "0" else torch.cuda.Stream(device=self.dev)
         f64 = dict(dtype=_F64, device=self.dev)
         assert net_dtype in (torch.float64, torch.float32) and gemm_f32 in (0, 1, 2)
         self.ndt, self.f32 = net_dtype, net_dtype == torch.float32
@@ -411,6 +414,13 @@ class SpritesStepEngine:
             self._mark("gp_fwd_factor")
             if self.chan_shard:
                 call("svgp_gp_factor_fwd_channels", cp, r_ * nl, nl, ws, s)
+            elif self.m > 64 and self.side is not None:
+                # the tail of the stage -- (A_hat + jI)^-1, its log det, KL_l: a whole batched inverse that only the reverse
+                # factor stage and the final scalars need -- runs on the side stream beside the row stage, the decoder and
+                # the reverse statistics (include/svgpvae_hip.h: svgp_gp_factor_fwd_aji_tail)
+                call("svgp_gp_factor_fwd_defer_aji", cp, ws, s)
+                self.side.wait_stream(self.stream)
+                call("svgp_gp_factor_fwd_aji_tail", cp, ws, self.side.cuda_stream)
             else:
                 call("svgp_gp_factor_fwd", cp, ws, s)
         if self.chan_shard:
@@ -458,6 +468,8 @@ class SpritesStepEngine:
             yield [ExchangeOp("allreduce", self.ws[self.wl.statB:self.wl.statB + self.wl.statB_len])]
         with torch.cuda.stream(self.stream):
             self._mark("gp_bwd_factor")
+            if not self.chan_shard and self.m > 64 and self.side is not None:
+                self.stream.wait_stream(self.side)
             if self.chan_shard:
                 call("svgp_gp_factor_bwd_channels", cp, r_ * nl, nl, ws, st, s)
             else:

@@ -190,7 +190,11 @@ def stage_table(eng, B, M_IND):
          f8 * (b * (Lc + act_dec + 2 * 784 + Lc) + 2 * n_dec), f8 * n_part * n_dec),
         ("gp_stats_bwd", "svgp_gp_stats_bwd", (cfg, ws, st, s), 3 * Lc * b * m * m,
          f8 * (b * m + 9 * b * Lc + Lc * m * (m + 2)), 0.0),
-        ("gp_factor_bwd", "svgp_gp_factor_bwd_nofinal", (cfg, ws, st, s), Lc * 9 * 2 * m ** 3, f8 * Lc * 14 * m * m, 0.0),
+    ] + ([("gp_factor_bwd_early (side stream in the step)", "svgp_gp_factor_bwd_early", (cfg, ws, st, s), Lc * 5.5 * 2 * m ** 3,
+           f8 * Lc * 10 * m * m, 0.0),
+          ("gp_factor_bwd", "svgp_gp_factor_bwd_late", (cfg, ws, st, s), Lc * 2.5 * 2 * m ** 3, f8 * Lc * 10 * m * m, 0.0)]
+         if m > 64 else
+         [("gp_factor_bwd", "svgp_gp_factor_bwd_nofinal", (cfg, ws, st, s), Lc * 9 * 2 * m ** 3, f8 * Lc * 14 * m * m, 0.0)]) + [
         ("gp_posterior_bwd", "svgp_gp_posterior_bwd_with_final", (cfg, ws, st, s), 6 * Lc * b * m * m,
          f8 * (Lc * 3 * m * m + 2 * Lc * b * m + 12 * b * Lc), 0.0),
         ("kernel_matrix_bwd", "svgp_kernel_matrix_bwd_partials", (cfg, th, aux, ws, s),

@@ -258,6 +258,12 @@ int svgp_gp_posterior_fwd_with_aji(const svgp_mnist_cfg*, const double* eps, dou
  * svgp_gp_stats_bwd, so the second batched inverse of the step runs beside them (svgp_mnist_step_phase does this on a
  * library-owned side stream unless SVGP_SIDE_STREAMS=0). */
 int svgp_gp_factor_fwd_aji_tail(const svgp_mnist_cfg*, double* ws, void* stream);
+/* m > 64: svgp_gp_factor_bwd in two halves.  _early (T1 = S Ki, Ki S Ki, T1 A_hat, Abar, Gbar = K Abar, Z = Sigma^-1 Gbar,
+ * Gbar K: 5.5 of the stage's 8 m^3 L products) needs forward quantities, the loss seeds of `state` and (A_hat + jI)^-1 only --
+ * no reverse statistic -- and may run on the stream of svgp_gp_factor_fwd_aji_tail, behind it; _late needs _early, A2 / ud /
+ * td (svgp_gp_stats_bwd and their exchange).  _early + _late == svgp_gp_factor_bwd, operation for operation. */
+int svgp_gp_factor_bwd_early(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+int svgp_gp_factor_bwd_late(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 /* tf.train.AdamOptimizer.apply_gradients, TF1 formula (MNIST_experiment.py:200,207-208) */

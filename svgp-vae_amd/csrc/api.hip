@@ -222,6 +222,9 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         if (c->m > SVGP_M_MAX) {                               // m > 64: ... on the side stream
             if (fork1) RUN(side_fork(sd, 1, ms));
             RUN(svgp_gp_factor_fwd_aji_tail(c, ws, fork1 ? (void*)sd->s[1] : stream));
+            // ... followed there by the early half of the REVERSE factor stage (5.5 of its 8 m^3 L products need no
+            // reverse statistic); phase 2 then runs the late half only
+            if (fork1) RUN(svgp_gp_factor_bwd_early(c, ws, state, (void*)sd->s[1]));
         }
         RUN(svgp_gp_posterior_fwd_with_aji(c, eps, ws, state, stream));
         if (c->titsias) RUN(svgp_gp_titsias_fwd(c, ws, state, stream));
@@ -231,8 +234,12 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         if (fork1 && !defer) RUN(side_join(sd, 1, ms));        // phase-at-a-time callers: joined before the phase returns
         break;
     case 2:
-        if (fork1) RUN(side_join(sd, 1, ms));                           // (a no-op unless phase 1 left the branch open)
-        RUN(svgp_gp_factor_bwd_nofinal(c, ws, state, stream));          // channel sum Kbar: inside the next launch
+        if (fork1) {
+            RUN(side_join(sd, 1, ms));                                  // (a no-op unless phase 1 left the branch open)
+            RUN(svgp_gp_factor_bwd_late(c, ws, state, stream));
+        } else {
+            RUN(svgp_gp_factor_bwd_nofinal(c, ws, state, stream));      // channel sum Kbar: inside the next launch
+        }
         RUN(svgp_gp_posterior_bwd_with_final(c, ws, state, stream));
         if (c->titsias) RUN(svgp_gp_titsias_bwd(c, ws, state, stream));
         if (fork2) RUN(side_fork(sd, 0, ms));

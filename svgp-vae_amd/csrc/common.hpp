@@ -135,7 +135,7 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
 int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, const double* eps, double* ws,
                            double* state, void* stream);
 int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
-                        void* stream, int l0, int nl);
+                        void* stream, int l0, int nl, int part = 0);
 int svgp_big_posterior_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
                            void* stream);
 

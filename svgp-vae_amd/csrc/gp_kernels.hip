@@ -1422,6 +1422,21 @@ extern "C" int svgp_gp_factor_bwd(const svgp_mnist_cfg* c, double* ws, const dou
 extern "C" int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     return factor_bwd_impl(c, ws, state, false, stream);
 }
+// m > 64: the two halves of svgp_gp_factor_bwd (gp_large.hip svgp_big_factor_bwd).  _early needs only forward quantities, the
+// loss seeds in `state` and (A_hat + jI)^-1: it may run on another stream, ordered after svgp_gp_factor_fwd_aji_tail, beside
+// the row stage, the networks and the reverse statistics; _late follows svgp_gp_stats_bwd (and its exchange) and _early.
+extern "C" int svgp_gp_factor_bwd_early(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the split reverse factor stage exists for m > %d", SVGP_M_MAX);
+    return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 1);
+}
+extern "C" int svgp_gp_factor_bwd_late(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the split reverse factor stage exists for m > %d", SVGP_M_MAX);
+    return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 2);
+}
 static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");

@@ -139,14 +139,18 @@ __device__ __forceinline__ void fb_scalars(const FbArgs& a, real& g3, real& gK) 
     const real gT = gradKL(a.geco, a.Ltot, a.state);
     g3 = svgp_seed_3(a.geco, gT); gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
 }
-__global__ void k_big_fb_abar(FbArgs a) {     // Abar, ubar
+__global__ void k_big_fb_abar(FbArgs a) {     // Abar (forward quantities only: part of the EARLY reverse factor stage)
     real g3, gK; fb_scalars(a, g3, gK);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)a.m * a.m;
     if (i < mm * a.L) {
         const long long o = i % mm;
         a.X1[i] = real(-0.5) * g3 * a.X1[i] + real(0.5) * gK * (a.Ki[o] - a.Aji[i]);
     }
-    if (i < (long long)a.L * a.m) a.ubar[i] = a.ud[i] + real(0.5) * gK * a.mu[i];
+}
+__global__ void k_big_fb_ubar(FbArgs a) {     // ubar = ud + gK/2 mu
+    real g3, gK; fb_scalars(a, g3, gK);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.L * a.m) a.ubar[i] = a.ud[i] + real(0.5) * gK * a.mu[i];
 }
 __global__ void k_big_fb_mubar(FbArgs a) {    // mubar = Ki ubar (in place) + gK/2 u
     real g3, gK; fb_scalars(a, g3, gK);
@@ -382,7 +386,6 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
                    void* stream) {
     const int b = c->b, m = c->m, L = c->L;
     const real cc = c->N_train / (double)c->b_global;
-    const BigScr s = big_scr(c, wl, ws);
     hipStream_t st = (hipStream_t)stream;
     real* Kn = ws + wl.Kn;
     // weights: forward uses (g_pv, g_pm) as temporaries for (p, p*y); backward fills g_pv, mvbar, g_pm
@@ -401,9 +404,12 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
                                    1));
     // v1 (L x m) = a^T Kn: L x m outputs and a contraction over the batch -> split-K (8 tiles of 32 otherwise walk all b rows)
     const long long sk = svgp_dgemm_splitk_scratch_elems(L, m, b);
-    SVGP_REQUIRE(sk >= 0 && sk <= 4LL * c->L * m * m, SVGP_ERR_INVALID, "split-K scratch");
-    RUNC(svgp_dgemm_splitk(1, 0, L, m, b, 1.0, abuf, L, Kn, m, 0.0, v1, m, s.mm0, sk, stream));
-    if (mode == 1) RUNC(svgp_dgemm_splitk(1, 0, L, m, b, cc, bbuf, L, Kn, m, 0.0, ws + wl.td, m, s.mm0, sk, stream));
+    SVGP_REQUIRE(sk >= 0 && sk <= (long long)c->L * m * m, SVGP_ERR_INVALID, "split-K scratch");
+    // scratch: the Kibar region of fb_part (written by the late reverse factor stage only; scr_mm may be in use by the early
+    // half on the side stream while the reverse statistics run)
+    real* sks = ws + wl.fb_part + (size_t)c->L * m * m;
+    RUNC(svgp_dgemm_splitk(1, 0, L, m, b, 1.0, abuf, L, Kn, m, 0.0, v1, m, sks, sk, stream));
+    if (mode == 1) RUNC(svgp_dgemm_splitk(1, 0, L, m, b, cc, bbuf, L, Kn, m, 0.0, ws + wl.td, m, sks, sk, stream));
     // (K_mm + jI)^-1 and its log det (SVGPVAE_model.py:239,270,273) are formed by svgp_big_factor_fwd, in the same
     // launches as the L channel inverses
     return SVGP_OK;
@@ -506,8 +512,16 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
 
 // channel window [l0, l0 + nl) as in svgp_big_factor_fwd; Kbar then holds the window's share of the gradient of K_mm
 // (the shares of the ranks add up in the gradient exchange: kernel_matrix_bwd is linear in Kbar)
+// part: 0 = the whole stage; 1 = its EARLY half; 2 = its LATE half.  Five and a half of the eight m^3 L products --
+//   T1 = S Ki, Ki S Ki, T1 A, Abar, Gbar = K Abar, Z = Sigma^-1 Gbar, Gbar K
+// -- depend on forward quantities and the loss seeds only (S is the FORWARD statistic), not on the reverse statistics A2, ud,
+// td.  The training step issues them on the side stream right behind the forward stage's tail, under the row stage, the
+// networks and the reverse statistics; the late half (ubar ... Sigma^-1 Sibar Sigma^-1, the channel sum) stays on the
+// critical path.  Same operations on the same values either way.  Buffers: T1 -> Z in mm0, Abar in mm1, T1 A in mm2 (kept for
+// the late half), Gbar K in mm3, Gbar in the Kb region of fb_part (dead before the late half writes Kb there; the forward
+// tail's trace partials at its head are consumed before: the side stream runs tail and early half in order).
 int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
-                        void* stream, int l0, int nl) {
+                        void* stream, int l0, int nl, int part) {
     const int m = c->m, L = nl;
     const long long mm = (long long)m * m;
     const real cc = c->N_train / (double)c->b_global;
@@ -517,6 +531,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si + om, *A = ws + wl.A + om, *S = ws + wl.S + om;
     real* Kb = ws + wl.fb_part;
     real* Kib = Kb + (size_t)c->L * mm;
+    real* Gb = Kb;                                   // Gbar (early half only)
     FbArgs a;
     a.m = m; a.L = L; a.Ltot = c->L; a.geco = SVGP_LOSS_FLAGS(c); a.b_global = c->b_global; a.c = cc; a.N_train = c->N_train; a.state = state;
     a.Ki = Ki; a.Aji = ws + wl.Aji + om; a.A = A; a.S = S; a.A2 = ws + wl.A2 + om; a.M2 = ws + wl.M2 + om; a.mu = ws + wl.mu_hat + ov;
@@ -524,35 +539,40 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     a.X1 = s.mm1; a.T1A = s.mm2; a.Kib = Kib; a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2;
     a.Sibar = s.mm3; a.Kb = Kb; a.Sg = s.mm1; a.Z = s.mm0; a.Ssym = ws + wl.Ssym + om; a.Qm = ws + wl.Qm + om;
     const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m), ntp = (unsigned)((m + TP - 1) / TP);
-    GEMM(0, 1, m, m, m, 1.0, S, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);            // T1 = S Ki
-    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, s.mm1, m, mm, L);        // Ki S Ki (full product, see M2)
-    hipLaunchKernelGGL(k_big_fb_abar, dim3(gmm), dim3(256), 0, st, a);             // Abar (mm1), ubar
+    if (part != 2) {
+        GEMM(0, 1, m, m, m, 1.0, S, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);            // T1 = S Ki
+        GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, s.mm1, m, mm, L);        // Ki S Ki (full product, see M2)
+        hipLaunchKernelGGL(k_big_fb_abar, dim3(gmm), dim3(256), 0, st, a);             // Abar (mm1)
+        SVGP_LAUNCH_CHECK();
+        GEMM(0, 1, m, m, m, 1.0, s.mm0, m, mm, A, m, mm, 0.0, s.mm2, m, mm, L);        // T1 A (mm2, read by the late half)
+        GEMM(0, 1, m, m, m, 1.0, K, m, 0, s.mm1, m, mm, 0.0, Gb, m, mm, L);            // Gbar = K Abar
+        GEMM(0, 0, m, m, m, 1.0, Si, m, mm, Gb, m, mm, 0.0, s.mm0, m, mm, L);          // Z = Si Gbar (mm0: T1 is done); Kb = Z + Z^T below
+        GEMM_SYM(0, 1, m, m, 1.0, Gb, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);           // Gbar K = K Abar K  (mm3)
+    }
+    if (part == 1) return SVGP_OK;
+    hipLaunchKernelGGL(k_big_fb_ubar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    GEMV(1.0, Ki, 0, s.vec0, s.vec1, L);                                           // Ki ubar
+    GEMV(1.0, Ki, 0, s.vec0, s.vec1, L);                                               // Ki ubar
     hipLaunchKernelGGL(k_big_fb_mubar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 1, m, m, m, 1.0, s.mm0, m, mm, A, m, mm, 0.0, s.mm2, m, mm, L);        // T1 A
-    hipLaunchKernelGGL(k_big_fb_kibar, dim3(gmm), dim3(256), 0, st, a);            // Kib
+    hipLaunchKernelGGL(k_big_fb_kibar, dim3(gmm), dim3(256), 0, st, a);                // Kib
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 1, m, m, m, 1.0, K, m, 0, s.mm1, m, mm, 0.0, s.mm2, m, mm, L);         // Gbar = K Abar   (mm2)
-    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm2, m, mm, 0.0, s.mm0, m, mm, L);       // Z = Si Gbar (mm0: T1 is done); Kb = Z + Z^T below
-    GEMV(1.0, K, 0, s.vec1, s.vec2, L);                                            // K mubar
+    GEMV(1.0, K, 0, s.vec1, s.vec2, L);                                                // K mubar
     hipLaunchKernelGGL(k_big_fb_tbar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    GEMM_SYM(0, 1, m, m, 1.0, s.mm2, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);        // Gbar K = K Abar K  (mm3)
-    hipLaunchKernelGGL(k_big_fb_sibar, dim3(ntp, ntp, L), dim3(256), 0, st, a);    // Sibar, Kb = Z + Z^T + c mubar t^T
+    hipLaunchKernelGGL(k_big_fb_sibar, dim3(ntp, ntp, L), dim3(256), 0, st, a);        // Sibar, Kb = Z + Z^T + c mubar t^T
     SVGP_LAUNCH_CHECK();
-    GEMV(1.0, Si, mm, s.vec2, ws + wl.vbar + ov, L);                                        // vbar = Si tbar
-    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm3, m, mm, 0.0, s.mm0, m, mm, L);       // Si Sibar (mm0)
-    GEMM(0, 1, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);      // Sg = -Si Sibar Si (mm1)
+    GEMV(1.0, Si, mm, s.vec2, ws + wl.vbar + ov, L);                                            // vbar = Si tbar
+    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm3, m, mm, 0.0, s.mm0, m, mm, L);           // Si Sibar (mm0)
+    GEMM(0, 1, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);          // Sg = -Si Sibar Si (mm1)
     hipLaunchKernelGGL(k_big_fb_ssym, dim3(ntp, ntp, L), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
     // sum_l Ki Kib_l Ki = Ki (sum_l Kib_l) Ki: Ki is shared by the channels and only the channel sum of Kb reaches Kbar,
     // so the two products run once on the summed matrix instead of once per channel (2 of the 13 m^3 L products of this stage)
     hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, Kib, s.mm0);
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, 0, 0.0, s.mm0 + mm, m, 0, 1);      // Ki (sum Kib)
-    GEMM(0, 1, m, m, m, 1.0, s.mm0 + mm, m, 0, Ki, m, 0, 0.0, s.mm0, m, 0, 1);      // Ki (sum Kib) Ki
+    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, 0, 0.0, s.mm0 + mm, m, 0, 1);          // Ki (sum Kib)
+    GEMM(0, 1, m, m, m, 1.0, s.mm0 + mm, m, 0, Ki, m, 0, 0.0, s.mm0, m, 0, 1);          // Ki (sum Kib) Ki
     hipLaunchKernelGGL(k_big_fb_final, dim3(nblk(mm)), dim3(256), 0, st, m, L, c->L, SVGP_LOSS_FLAGS(c), c->b_global, c->N_train, state, Kb,
                        Ki, s.mm0, ws + wl.Kbar);
     SVGP_LAUNCH_CHECK();

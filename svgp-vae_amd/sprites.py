@@ -421,6 +421,8 @@ class SpritesStepEngine:
                 call("svgp_gp_factor_fwd_defer_aji", cp, ws, s)
                 self.side.wait_stream(self.stream)
                 call("svgp_gp_factor_fwd_aji_tail", cp, ws, self.side.cuda_stream)
+                # ... and behind it the early half of the reverse factor stage (no reverse statistic needed)
+                call("svgp_gp_factor_bwd_early", cp, ws, st, self.side.cuda_stream)
             else:
                 call("svgp_gp_factor_fwd", cp, ws, s)
         if self.chan_shard:
@@ -468,10 +470,11 @@ class SpritesStepEngine:
             yield [ExchangeOp("allreduce", self.ws[self.wl.statB:self.wl.statB + self.wl.statB_len])]
         with torch.cuda.stream(self.stream):
             self._mark("gp_bwd_factor")
-            if not self.chan_shard and self.m > 64 and self.side is not None:
-                self.stream.wait_stream(self.side)
             if self.chan_shard:
                 call("svgp_gp_factor_bwd_channels", cp, r_ * nl, nl, ws, st, s)
+            elif self.m > 64 and self.side is not None:
+                self.stream.wait_stream(self.side)
+                call("svgp_gp_factor_bwd_late", cp, ws, st, s)
             else:
                 call("svgp_gp_factor_bwd", cp, ws, st, s)
         if self.chan_shard:

@@ -1,0 +1,129 @@
+"""m > 64: the split stages of the two-stream step equal the unsplit ones bit for bit.
+
+svgp_gp_factor_fwd == svgp_gp_factor_fwd_defer_aji + svgp_gp_factor_fwd_aji_tail, and
+svgp_gp_factor_bwd == svgp_gp_factor_bwd_early + svgp_gp_factor_bwd_late (include/svgpvae_hip.h), with the tail / early half on
+the caller's stream or on a second stream ordered by events -- the form svgp_mnist_step_phase and sprites.py use.
+A whole step with SVGP_SIDE_STREAMS=0 (one stream) equals the default two-stream step.
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+FWD_FIELDS = ("Ki", "ldK", "Si", "t", "G", "A", "Aji", "mu_hat", "u", "M2", "KL", "q")
+BWD_FIELDS = ("Kbar", "vbar", "Ssym")
+
+
+def _engine():
+    p, images, aux, eps = H.toy_problem(b=150, m=130, L=3, M=24, n_obj=40, seed=4)
+    eng = H.engine_for(p, 150, geco=True, N_train=500.0, jitter=1e-4)
+    dev = eng.device
+    eng.bind(images.to(dev), aux.to(dev), eps.to(dev))
+    eng.run(adam=False)
+    eng.synchronize()
+    return eng
+
+
+def _field(eng, name):
+    off = getattr(eng.wl, name)
+    m, L = eng.cfg.m, eng.cfg.L
+    n = {"Ki": m * m, "ldK": 1, "Kbar": m * m, "KL": L, "q": eng.cfg.b, "t": L * m, "mu_hat": L * m, "u": L * m,
+         "vbar": L * m}.get(name, L * m * m)
+    return eng.ws[off:off + n].clone()
+
+
+@pytest.mark.parametrize("two_streams", [False, True])
+def test_split_factor_stages_equal_the_unsplit_ones(two_streams):
+    from svgp_vae_amd import _lib
+    eng = _engine()
+    cfg, ws, st = C.byref(eng.cfg), eng.ws.data_ptr(), eng.state.data_ptr()
+    main = eng.stream
+    side = torch.cuda.Stream(device=eng.device) if two_streams else main
+    ws0 = eng.ws.clone()                         # workspace after a full step: every stage input is valid
+
+    def restore():
+        main.synchronize(); side.synchronize()
+        eng.ws.copy_(ws0)
+        torch.cuda.synchronize()
+
+    # ---- forward factor stage
+    restore()
+    _lib.call("svgp_gp_factor_fwd", cfg, ws, main.cuda_stream)
+    main.synchronize()
+    want = {k: _field(eng, k) for k in FWD_FIELDS}
+    restore()
+    _lib.call("svgp_gp_factor_fwd_defer_aji", cfg, ws, main.cuda_stream)
+    side.wait_stream(main)
+    _lib.call("svgp_gp_factor_fwd_aji_tail", cfg, ws, side.cuda_stream)
+    main.wait_stream(side)
+    main.synchronize()
+    for k in FWD_FIELDS:
+        assert torch.equal(_field(eng, k), want[k]), k
+
+    # ---- reverse factor stage (inputs: the forward stage above + the step's reverse statistics)
+    _lib.call("svgp_gp_factor_bwd", cfg, ws, st, main.cuda_stream)
+    main.synchronize()
+    wantb = {k: _field(eng, k) for k in BWD_FIELDS}
+    ws1 = eng.ws.clone()
+    for k in BWD_FIELDS:                          # poison the outputs, keep every input
+        off = getattr(eng.wl, k)
+        eng.ws[off:off + wantb[k].numel()].fill_(float("nan"))
+    torch.cuda.synchronize()
+    side.wait_stream(main)
+    _lib.call("svgp_gp_factor_bwd_early", cfg, ws, st, side.cuda_stream)
+    main.wait_stream(side)
+    _lib.call("svgp_gp_factor_bwd_late", cfg, ws, st, main.cuda_stream)
+    main.synchronize()
+    for k in BWD_FIELDS:
+        assert torch.equal(_field(eng, k), wantb[k]), k
+    del ws1
+
+
+def test_split_entry_points_reject_the_lds_path():
+    from svgp_vae_amd import _lib
+    p, images, aux, eps = H.toy_problem(b=40, m=12, L=3, M=4, n_obj=20, seed=0)
+    eng = H.engine_for(p, 40, geco=False, N_train=300.0)
+    for sym, args in (("svgp_gp_factor_fwd_aji_tail", (eng.ws.data_ptr(),)),
+                      ("svgp_gp_factor_bwd_early", (eng.ws.data_ptr(), eng.state.data_ptr())),
+                      ("svgp_gp_factor_bwd_late", (eng.ws.data_ptr(), eng.state.data_ptr()))):
+        with pytest.raises(_lib.SvgpError):
+            _lib.call(sym, C.byref(eng.cfg), *args, eng.stream.cuda_stream)
+
+
+_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from tests import helpers as H
+p, images, aux, eps = H.toy_problem(b=150, m=130, L=3, M=24, n_obj=40, seed=4)
+eng = H.engine_for(p, 150, geco=True, N_train=500.0, jitter=1e-4)
+dev = eng.device
+eng.bind(images.to(dev), aux.to(dev), eps.to(dev))
+for _ in range(2):
+    eng.run(adam=True)
+eng.synchronize()
+torch.save({"theta": eng.theta.cpu(), "state": eng.state.cpu()}, sys.argv[2])
+"""
+
+
+def test_two_stream_step_equals_one_stream_step(tmp_path):
+    """Two Adam steps with the default two-stream schedule and with SVGP_SIDE_STREAMS=0: identical parameters and state
+    (child processes: the switch is read from the environment of the library)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for val in ("", "0"):
+        out = tmp_path / f"s{val or 'default'}.pt"
+        env = dict(os.environ)
+        env.pop("SVGP_SIDE_STREAMS", None)
+        if val:
+            env["SVGP_SIDE_STREAMS"] = val
+        subprocess.run([sys.executable, "-c", _CHILD, root, str(out)], check=True, env=env, timeout=600)
+        outs.append(torch.load(out))
+    assert torch.equal(outs[0]["theta"], outs[1]["theta"])
+    assert torch.equal(outs[0]["state"], outs[1]["state"])

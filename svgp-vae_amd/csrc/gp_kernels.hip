@@ -171,6 +171,13 @@ __device__ __forceinline__ real fast_rcp(real x) {
     r = fma(fma(-x, r, real(1)), r, r);
     return r;
 }
+// value of lane `src` (compile-time constant) in every lane: two v_readlane_b32 (scalar path, a few cycles) where __shfl
+// issues two ds_bpermute_b32 (~50 cycles through the LDS crossbar) -- the pivot sits at the head of every step's chain
+__device__ __forceinline__ real readlane_f64(real v, int src) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 template <int MP>
 __device__ __forceinline__ real spd_inv_wave(real* A, real* W, int ld, int m) {
     constexpr int BS = MP / 8;
@@ -195,7 +202,7 @@ __device__ __forceinline__ real spd_inv_wave(real* A, real* W, int ld, int m) {
                 for (int c = 0; c < BS; ++c) rowk[c] = __shfl(a[kr][c], kb * 8 + bj, 64);
 #pragma unroll
                 for (int r = 0; r < BS; ++r) colk[r] = __shfl(a[r][kr], bi * 8 + kb, 64);
-                const real piv = __shfl(a[kr][kr], kb * 8 + kb, 64);
+                const real piv = readlane_f64(a[kr][kr], kb * 9);      // uniform source lane: v_readlane, not ds_bpermute
                 const real ipiv = fast_rcp(piv);
                 if (lane == k) mypiv = piv;
                 real rkj[BS];

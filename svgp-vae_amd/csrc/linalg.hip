@@ -256,6 +256,11 @@ __device__ __forceinline__ real wave_sum_la(real x) {
     return x;
 }
 
+__device__ __forceinline__ real readlane_f64_la(real v, int src) {
+    const unsigned long long u = __double_as_longlong(v);
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
 // Wave 0 of the workgroup inverts the 32 x 32 block staged in LDS (single-wave Gauss-Jordan on an 8 x 8 lane grid of
 // 4 x 4 register blocks), writes P^-1 to `Pinv` (and `Pcap`), adds log det to logdet[l] (sets it when `first`).
 __device__ __forceinline__ void gj32_sweep(const real (*P)[NB + 1], real* __restrict__ Pinv, real* __restrict__ Pcap,
@@ -276,7 +281,7 @@ __device__ __forceinline__ void gj32_sweep(const real (*P)[NB + 1], real* __rest
         for (int c = 0; c < 4; ++c) rowk[c] = __shfl(a[kr][c], kq * 8 + bj, 64);
 #pragma unroll
         for (int r = 0; r < 4; ++r) colk[r] = __shfl(a[r][kr], bi * 8 + kq, 64);
-        const real piv = __shfl(a[kr][kr], kq * 8 + kq, 64);
+        const real piv = readlane_f64_la(a[kr][kr], kq * 9);      // uniform source lane: v_readlane, not ds_bpermute
         const real ipiv = fast_rcp_la(piv);
         if (lane == k) mypiv = piv;
         real rkj[4];

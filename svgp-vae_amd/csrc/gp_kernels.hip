@@ -1235,14 +1235,17 @@ static int kernel_matrix_bwd_impl(const svgp_mnist_cfg* c, const double* theta, 
     real* grad = ws + wl.grad;
     const int RBk = svgp_rows_per_block(c), nrb = (c->b + RBk - 1) / RBk;
     const size_t lds_rows = (size_t)(c->m * c->M + RBk * c->m + RBk * c->M) * sizeof(real);
-    const bool cfg2_shape = c->m == 32 && c->M == 8;
+    const bool cfg2_shape = c->m == 32 && c->M == 8, cfg3_shape = c->m == 256 && c->M == 32;
     {
-        int rc_ = cfg2_shape ? set_dyn_lds(k_kernel_matrix_bwd_cr<32, 8>, lds_rows) : set_dyn_lds(k_kernel_matrix_bwd_cr<0, 0>, lds_rows);
+        int rc_ = cfg2_shape ? set_dyn_lds(k_kernel_matrix_bwd_cr<32, 8>, lds_rows)
+                  : cfg3_shape ? set_dyn_lds(k_kernel_matrix_bwd_cr<256, 32>, lds_rows)
+                               : set_dyn_lds(k_kernel_matrix_bwd_cr<0, 0>, lds_rows);
         if (rc_) return rc_;
     }
 #define KM_BWD_ARGS a, c->rep_weight, c->train_ip, ws + wl.K, ws + wl.Kn, ws + wl.Kbar, ws + wl.Knbar, ws + wl.knnbar, ws + wl.knn, \
                     grad + pl.ip, ws + wl.d_on, ws + wl.part_gp
     if (cfg2_shape) hipLaunchKernelGGL((k_kernel_matrix_bwd_cr<32, 8>), dim3(c->m + nrb), dim3(SVGP_BLOCK), lds_rows, (hipStream_t)stream, KM_BWD_ARGS);
+    else if (cfg3_shape) hipLaunchKernelGGL((k_kernel_matrix_bwd_cr<256, 32>), dim3(c->m + nrb), dim3(SVGP_BLOCK), lds_rows, (hipStream_t)stream, KM_BWD_ARGS);
     else hipLaunchKernelGGL((k_kernel_matrix_bwd_cr<0, 0>), dim3(c->m + nrb), dim3(SVGP_BLOCK), lds_rows, (hipStream_t)stream, KM_BWD_ARGS);
 #undef KM_BWD_ARGS
     SVGP_LAUNCH_CHECK();

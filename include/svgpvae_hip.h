@@ -264,6 +264,10 @@ int svgp_gp_factor_fwd_aji_tail(const svgp_mnist_cfg*, double* ws, void* stream)
  * td (svgp_gp_stats_bwd and their exchange).  _early + _late == svgp_gp_factor_bwd, operation for operation. */
 int svgp_gp_factor_bwd_early(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_late(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+/* _early = _early_a + _early_b: _early_a (T1, Ki S Ki, T1 A_hat) does not even need (A_hat + jI)^-1 and may run beside
+ * svgp_gp_factor_fwd_aji_tail on a third stream; _early_b (Abar, Gbar, Z, Gbar K) is ordered behind both. */
+int svgp_gp_factor_bwd_early_a(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+int svgp_gp_factor_bwd_early_b(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 /* tf.train.AdamOptimizer.apply_gradients, TF1 formula (MNIST_experiment.py:200,207-208) */

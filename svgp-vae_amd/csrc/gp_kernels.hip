@@ -1441,6 +1441,21 @@ extern "C" int svgp_gp_factor_bwd_early(const svgp_mnist_cfg* c, double* ws, con
     SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the split reverse factor stage exists for m > %d", SVGP_M_MAX);
     return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 1);
 }
+// _early in two parts: _early_a (T1, Ki S Ki, T1 A_hat) needs no (A_hat + jI)^-1 and may run BESIDE svgp_gp_factor_fwd_aji_tail
+// (a third stream); _early_b (Abar, Gbar, Z, Gbar K) needs both.  The gp_large.hip fb_part hazard: _early_b overwrites the trace
+// partials the tail's last kernel reads -- it is ordered behind the tail anyway (it needs (A_hat + jI)^-1).
+extern "C" int svgp_gp_factor_bwd_early_a(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the split reverse factor stage exists for m > %d", SVGP_M_MAX);
+    return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 3);
+}
+extern "C" int svgp_gp_factor_bwd_early_b(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the split reverse factor stage exists for m > %d", SVGP_M_MAX);
+    return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 4);
+}
 extern "C" int svgp_gp_factor_bwd_late(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");

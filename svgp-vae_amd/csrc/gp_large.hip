@@ -512,7 +512,7 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
 
 // channel window [l0, l0 + nl) as in svgp_big_factor_fwd; Kbar then holds the window's share of the gradient of K_mm
 // (the shares of the ranks add up in the gradient exchange: kernel_matrix_bwd is linear in Kbar)
-// part: 0 = the whole stage; 1 = its EARLY half; 2 = its LATE half.  Five and a half of the eight m^3 L products --
+// part: 0 = the whole stage; 1 = its EARLY half (3 + 4: its two parts separately); 2 = its LATE half.  Five and a half of the eight m^3 L products --
 //   T1 = S Ki, Ki S Ki, T1 A, Abar, Gbar = K Abar, Z = Sigma^-1 Gbar, Gbar K
 // -- depend on forward quantities and the loss seeds only (S is the FORWARD statistic), not on the reverse statistics A2, ud,
 // td.  The training step issues them on the side stream right behind the forward stage's tail, under the row stage, the
@@ -539,17 +539,22 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     a.X1 = s.mm1; a.T1A = s.mm2; a.Kib = Kib; a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2;
     a.Sibar = s.mm3; a.Kb = Kb; a.Sg = s.mm1; a.Z = s.mm0; a.Ssym = ws + wl.Ssym + om; a.Qm = ws + wl.Qm + om;
     const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m), ntp = (unsigned)((m + TP - 1) / TP);
-    if (part != 2) {
+    // early half, first part (3): needs S, Ki, A_hat only -- not even (A_hat + jI)^-1, so it can run beside the forward tail
+    if (part == 0 || part == 1 || part == 3) {
         GEMM(0, 1, m, m, m, 1.0, S, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);            // T1 = S Ki
         GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, s.mm1, m, mm, L);        // Ki S Ki (full product, see M2)
+        GEMM(0, 1, m, m, m, 1.0, s.mm0, m, mm, A, m, mm, 0.0, s.mm2, m, mm, L);        // T1 A (mm2, read by the late half)
+    }
+    if (part == 3) return SVGP_OK;
+    // early half, second part (4): + (A_hat + jI)^-1
+    if (part == 0 || part == 1 || part == 4) {
         hipLaunchKernelGGL(k_big_fb_abar, dim3(gmm), dim3(256), 0, st, a);             // Abar (mm1)
         SVGP_LAUNCH_CHECK();
-        GEMM(0, 1, m, m, m, 1.0, s.mm0, m, mm, A, m, mm, 0.0, s.mm2, m, mm, L);        // T1 A (mm2, read by the late half)
         GEMM(0, 1, m, m, m, 1.0, K, m, 0, s.mm1, m, mm, 0.0, Gb, m, mm, L);            // Gbar = K Abar
         GEMM(0, 0, m, m, m, 1.0, Si, m, mm, Gb, m, mm, 0.0, s.mm0, m, mm, L);          // Z = Si Gbar (mm0: T1 is done); Kb = Z + Z^T below
         GEMM_SYM(0, 1, m, m, 1.0, Gb, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);           // Gbar K = K Abar K  (mm3)
     }
-    if (part == 1) return SVGP_OK;
+    if (part == 1 || part == 4) return SVGP_OK;
     hipLaunchKernelGGL(k_big_fb_ubar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
     GEMV(1.0, Ki, 0, s.vec0, s.vec1, L);                                               // Ki ubar

@@ -18,8 +18,9 @@
  *   - per-step scalars (GECO state, Adam step, lr, beta, alpha) live in a small DEVICE state
  *     vector (svgp_state_slot) so that a captured graph can be replayed unchanged.
  *   - re-entrant, usable from several threads on different streams.  Process-wide state is limited to
- *     what is created once and then only read: the dlopen'd RCCL entry points (svgp_comm_*) and, only with
- *     SVGP_SIDE_STREAMS=1, one pair of library-owned side streams per device.
+ *     what is created once and then only read -- the dlopen'd RCCL entry points (svgp_comm_*) -- and one pair of
+ *     library-owned side streams + events per (device, caller stream), created at the first m > 64 step (or with
+ *     SVGP_SIDE_STREAMS=1) on that stream and used only by calls that pass that stream.
  */
 #ifndef SVGPVAE_HIP_H
 #define SVGPVAE_HIP_H
@@ -291,7 +292,12 @@ int svgp_elbo_finalize_noadam(const svgp_mnist_cfg*, double* ws, double* state, 
  *          grad_reduce_all
  *                                                                   -> all-reduce ws[gradC]
  * phase 3: adam_tf1_step (skipped when adam_m == NULL), elbo_finalize
- * svgp_mnist_train_step runs phases 0..3 back to back (single GPU).                            */
+ * svgp_mnist_train_step runs phases 0..3 back to back (single GPU).
+ * m > 64 without cfg.titsias (unless SVGP_SIDE_STREAMS=0): phase 1 issues svgp_gp_factor_fwd_aji_tail and
+ * svgp_gp_factor_bwd_early on a side stream and records that for `ws`; phase 2 joins the branch and runs
+ * svgp_gp_factor_bwd_late only when that record exists for the same (stream, ws) -- otherwise (phase-1 stages issued
+ * through the individual entry points, switch changed in between, cfg.titsias) it runs the whole reverse factor
+ * stage.  With cfg.titsias nothing is forked: svgp_gp_titsias_fwd uses the inverse scratch the tail would use.    */
 int svgp_mnist_step_phase(const svgp_mnist_cfg*, int phase, double* theta, const double* images,
                           const double* aux, const double* eps, double* ws, double* state,
                           double* adam_m, double* adam_v, void* stream);

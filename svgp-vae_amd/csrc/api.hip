@@ -2,7 +2,10 @@
 #include <cstdarg>
 
 #include "common.hpp"
+#include <map>
 #include <mutex>
+#include <set>
+#include <utility>
 #include <cstdlib>
 
 static thread_local char g_err[512] = "";
@@ -141,47 +144,57 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
 // stream capture the fork becomes a parallel branch of the hipGraph.
 // ---------------------------------------------------------------------------------------------
 namespace {
+// One Side per (device, caller stream): two engines that enqueue on different streams (or from different threads) never
+// share a fork event, a join decision or a side stream.  `open[k]` (branch k forked and not yet joined) and `early_ws`
+// (workspaces whose early reverse factor half was issued by phase 1 and not yet consumed by phase 2) are only touched under
+// the Side's own mutex, which fork / join hold for the whole record + wait pair.
 struct Side {
     hipStream_t s[2] = {nullptr, nullptr};
     hipEvent_t fork = nullptr, done[2] = {nullptr, nullptr};
-    bool pending[2] = {false, false};
-    bool ok = false;
+    bool open[2] = {false, false};
+    std::set<const void*> early_ws;
+    std::mutex mu;
 };
 std::mutex g_side_mu;
-Side g_side[64];
+std::map<std::pair<int, hipStream_t>, Side*> g_side;
 
-int side_get(Side** out) {
+int side_get(hipStream_t main, Side** out) {
     int dev = 0;
     SVGP_CHECK_HIP(hipGetDevice(&dev));
-    SVGP_REQUIRE(dev >= 0 && dev < 64, SVGP_ERR_INVALID, "device ordinal %d out of range", dev);
     std::lock_guard<std::mutex> lk(g_side_mu);
-    Side* sd = &g_side[dev];
-    if (!sd->ok) {
+    auto key = std::make_pair(dev, main);
+    auto it = g_side.find(key);
+    if (it == g_side.end()) {
+        Side* sd = new Side();
         for (int k = 0; k < 2; ++k) {
             SVGP_CHECK_HIP(hipStreamCreateWithFlags(&sd->s[k], hipStreamNonBlocking));
             SVGP_CHECK_HIP(hipEventCreateWithFlags(&sd->done[k], hipEventDisableTiming));
         }
         SVGP_CHECK_HIP(hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming));
-        sd->ok = true;
+        it = g_side.emplace(key, sd).first;
     }
-    *out = sd;
+    *out = it->second;
     return SVGP_OK;
 }
 // side stream k continues after everything issued on `main` so far
 int side_fork(Side* sd, int k, hipStream_t main) {
+    std::lock_guard<std::mutex> lk(sd->mu);
     SVGP_CHECK_HIP(hipEventRecord(sd->fork, main));
     SVGP_CHECK_HIP(hipStreamWaitEvent(sd->s[k], sd->fork, 0));
-    sd->pending[k] = true;
+    sd->open[k] = true;
     return SVGP_OK;
 }
-// `main` continues after everything issued on side stream k
+// `main` continues after everything issued on side stream k (no-op when this Side's branch k is not open)
 int side_join(Side* sd, int k, hipStream_t main) {
-    if (!sd->pending[k]) return SVGP_OK;
+    std::lock_guard<std::mutex> lk(sd->mu);
+    if (!sd->open[k]) return SVGP_OK;
     SVGP_CHECK_HIP(hipEventRecord(sd->done[k], sd->s[k]));
     SVGP_CHECK_HIP(hipStreamWaitEvent(main, sd->done[k], 0));
-    sd->pending[k] = false;
+    sd->open[k] = false;
     return SVGP_OK;
 }
+void side_mark_early(Side* sd, const void* ws) { std::lock_guard<std::mutex> lk(sd->mu); sd->early_ws.insert(ws); }
+bool side_take_early(Side* sd, const void* ws) { std::lock_guard<std::mutex> lk(sd->mu); return sd->early_ws.erase(ws) > 0; }
 
 // `defer`: the caller issues all four phases back to back on one stream (svgp_mnist_train_step), so a
 // branch forked in one phase may be joined in a later one; otherwise every phase joins before returning
@@ -203,10 +216,13 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
     // Large-m path: the tail of the forward factor stage ((A_hat + jI)^-1, its log det, KL: a whole batched inverse that only
     // the reverse factor stage and the final ELBO need) runs on side stream 1, beside the row stage, the decoder and the
     // reverse statistics.  That hides ~140 us at config 3 for ~10 us of signalling, so it is on unless SVGP_SIDE_STREAMS=0.
-    const bool fork1 = c->m > SVGP_M_MAX && !(fk && fk[0] == '0');
+    // Not with cfg.titsias: svgp_gp_titsias_fwd inverts its own batch through the SAME inverse scratch (ws.scr_inv) on the
+    // caller's stream, and the early reverse half would only multiply zero seeds.
+    const bool large = c->m > SVGP_M_MAX;
+    const bool fork1 = large && !c->titsias && !(fk && fk[0] == '0');
     Side* sd = nullptr;
-    if (fork2 || fork1) {
-        rc = side_get(&sd);
+    if (fork2 || large) {
+        rc = side_get(ms, &sd);
         if (rc) return rc;
     }
     hipStream_t s2 = fork2 ? sd->s[0] : ms;
@@ -224,7 +240,10 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
             RUN(svgp_gp_factor_fwd_aji_tail(c, ws, fork1 ? (void*)sd->s[1] : stream));
             // ... followed there by the early half of the REVERSE factor stage (5.5 of its 8 m^3 L products need no
             // reverse statistic); phase 2 then runs the late half only
-            if (fork1) RUN(svgp_gp_factor_bwd_early(c, ws, state, (void*)sd->s[1]));
+            if (fork1) {
+                RUN(svgp_gp_factor_bwd_early(c, ws, state, (void*)sd->s[1]));
+                side_mark_early(sd, ws);                       // phase 2 of THIS workspace may run the late half only
+            }
         }
         RUN(svgp_gp_posterior_fwd_with_aji(c, eps, ws, state, stream));
         if (c->titsias) RUN(svgp_gp_titsias_fwd(c, ws, state, stream));
@@ -234,7 +253,10 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         if (fork1 && !defer) RUN(side_join(sd, 1, ms));        // phase-at-a-time callers: joined before the phase returns
         break;
     case 2:
-        if (fork1) {
+        // The late half alone is valid only if phase 1 of this library issued the early half on this workspace (recorded per
+        // workspace, not inferred from the environment): a caller that ran the phase-1 stages through the individual entry
+        // points, or changed SVGP_SIDE_STREAMS in between, gets the full reverse factor stage.
+        if (large && side_take_early(sd, ws)) {
             RUN(side_join(sd, 1, ms));                                  // (a no-op unless phase 1 left the branch open)
             RUN(svgp_gp_factor_bwd_late(c, ws, state, stream));
         } else {

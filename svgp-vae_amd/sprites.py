@@ -417,7 +417,8 @@ class SpritesStepEngine:
             self._mark("gp_fwd_factor")
             if self.chan_shard:
                 call("svgp_gp_factor_fwd_channels", cp, r_ * nl, nl, ws, s)
-            elif self.m > 64 and self.side is not None:
+            elif self.m > 64 and self.side is not None and not self.svgp.titsias:
+                # (not with titsias: svgp_gp_titsias_fwd inverts through the same scratch, ws.scr_inv, on the main stream)
                 # the tail of the stage -- (A_hat + jI)^-1, its log det, KL_l: a whole batched inverse that only the reverse
                 # factor stage and the final scalars need -- runs on the side stream beside the row stage, the decoder and
                 # the reverse statistics (include/svgpvae_hip.h: svgp_gp_factor_fwd_aji_tail)
@@ -482,7 +483,7 @@ class SpritesStepEngine:
             self._mark("gp_bwd_factor")
             if self.chan_shard:
                 call("svgp_gp_factor_bwd_channels", cp, r_ * nl, nl, ws, st, s)
-            elif self.m > 64 and self.side is not None:
+            elif self.m > 64 and self.side is not None and not self.svgp.titsias:
                 self.stream.wait_stream(self.side)
                 call("svgp_gp_factor_bwd_late", cp, ws, st, s)
             else:

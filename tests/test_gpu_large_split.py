@@ -101,8 +101,11 @@ _CHILD = r"""
 import sys, torch
 sys.path.insert(0, sys.argv[1])
 from tests import helpers as H
-p, images, aux, eps = H.toy_problem(b=150, m=130, L=3, M=24, n_obj=40, seed=4)
-eng = H.engine_for(p, 150, geco=True, N_train=500.0, jitter=1e-4)
+tit = sys.argv[3] == "1"
+# Titsias: enough channels that the batched inverse of the forward tail (side stream, if it were forked) and the Titsias
+# inverse (main stream) would really be in flight together -- both go through ws.scr_inv
+p, images, aux, eps = H.toy_problem(b=150, m=130, L=16 if tit else 3, M=24, n_obj=40, seed=4)
+eng = H.engine_for(p, 150, geco=True, N_train=500.0, jitter=1e-4, titsias=tit)
 dev = eng.device
 eng.bind(images.to(dev), aux.to(dev), eps.to(dev))
 for _ in range(2):
@@ -112,9 +115,11 @@ torch.save({"theta": eng.theta.cpu(), "state": eng.state.cpu()}, sys.argv[2])
 """
 
 
-def test_two_stream_step_equals_one_stream_step(tmp_path):
-    """Two Adam steps with the default two-stream schedule and with SVGP_SIDE_STREAMS=0: identical parameters and state
-    (child processes: the switch is read from the environment of the library)."""
+@pytest.mark.parametrize("titsias", [False, True])
+def test_two_stream_step_equals_one_stream_step(tmp_path, titsias):
+    """Two Adam steps with the default schedule and with SVGP_SIDE_STREAMS=0: identical parameters and state
+    (child processes: the switch is read from the environment of the library).  With cfg.titsias the default schedule
+    must not fork at all (the Titsias stage and the forward tail share the inverse scratch)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for val in ("", "0"):
@@ -123,7 +128,67 @@ def test_two_stream_step_equals_one_stream_step(tmp_path):
         env.pop("SVGP_SIDE_STREAMS", None)
         if val:
             env["SVGP_SIDE_STREAMS"] = val
-        subprocess.run([sys.executable, "-c", _CHILD, root, str(out)], check=True, env=env, timeout=600)
+        subprocess.run([sys.executable, "-c", _CHILD, root, str(out), str(int(titsias))], check=True, env=env,
+                       timeout=600)
         outs.append(torch.load(out))
     assert torch.equal(outs[0]["theta"], outs[1]["theta"])
     assert torch.equal(outs[0]["state"], outs[1]["state"])
+
+
+def _run_stages(eng, order, images, eps):
+    """Phase 1 + the reverse factor stage through the individual entry points, everything on ONE stream, with the work of
+    the side branch (tail + early reverse half) issued either before or after the main-branch stages it runs beside."""
+    from svgp_vae_amd import _lib
+    cfg, ws, st, s = C.byref(eng.cfg), eng.ws.data_ptr(), eng.state.data_ptr(), eng.stream.cuda_stream
+    th, im = eng.theta.data_ptr(), images.data_ptr()
+
+    def side():
+        _lib.call("svgp_gp_factor_fwd_aji_tail", cfg, ws, s)
+        _lib.call("svgp_gp_factor_bwd_early", cfg, ws, st, s)
+
+    def main():
+        _lib.call("svgp_gp_posterior_fwd", cfg, eps.data_ptr(), ws, st, s)
+        _lib.call("svgp_mnist_decoder_fwd", cfg, th, im, ws, s)
+        _lib.call("svgp_mnist_decoder_bwd", cfg, th, im, ws, st, s)
+        _lib.call("svgp_gp_stats_bwd", cfg, ws, st, s)
+
+    _lib.call("svgp_gp_factor_fwd_defer_aji", cfg, ws, s)
+    for part in ((side, main) if order == "side_first" else (main, side)):
+        part()
+    _lib.call("svgp_gp_factor_bwd_late", cfg, ws, st, s)
+    _lib.call("svgp_gp_posterior_bwd", cfg, ws, st, s)
+    eng.stream.synchronize()
+    return eng.ws.clone()
+
+
+def test_side_branch_and_main_branch_share_no_buffer():
+    """The branch that svgp_mnist_step_phase runs on the side stream (forward tail + early reverse half) and the stages
+    it runs beside (row stage, decoder forward / reverse, reverse statistics) are issued in both serial orders on one
+    stream.  If either branch wrote a buffer the other reads or writes, one of the two orders would see different inputs:
+    the whole workspace after the reverse row stage must be bit-identical (deterministic form of the overlap check)."""
+    p, images, aux, eps = H.toy_problem(b=150, m=130, L=5, M=24, n_obj=40, seed=4)
+    eng = H.engine_for(p, 150, geco=True, N_train=500.0, jitter=1e-4)
+    dev = eng.device
+    images, aux, eps = images.to(dev), aux.to(dev), eps.to(dev)
+    eng.bind(images, aux, eps)
+    eng.phase(0)
+    eng.synchronize()
+    ws0 = eng.ws.clone()
+    out = {}
+    for order in ("side_first", "main_first"):
+        eng.ws.copy_(ws0)
+        # scratch regions are poisoned differently per order, so that a stage reading scratch it has not written shows
+        for name, n in (("scr_mm", 4 * eng.cfg.L * 130 * 130), ("fb_part", 2 * eng.cfg.L * 130 * 130)):
+            off = getattr(eng.wl, name)
+            eng.ws[off:off + n].fill_(1e300 if order == "side_first" else -3.0)
+        torch.cuda.synchronize()
+        out[order] = _run_stages(eng, order, images, eps)
+    a, b = out["side_first"], out["main_first"]
+    outputs = ("Kbar", "vbar", "Ssym", "Aji", "KL", "Knbar", "knnbar", "ybar", "s2bar", "p_m", "p_v", "z", "zbar", "A2", "ud",
+               "td", "Qm")
+    for k in outputs:
+        off = getattr(eng.wl, k)
+        nxt = min([getattr(eng.wl, f) for f, _ in eng.wl._fields_ if getattr(eng.wl, f) > off
+                   and f not in ("total", "n_part", "n_post", "stat_parts") and not f.endswith("_len")] + [a.numel()])
+        assert torch.equal(a[off:nxt], b[off:nxt]), k
+        assert torch.isfinite(a[off:nxt]).all(), k

@@ -449,6 +449,18 @@ int svgp_conv_taps_fwd_f32(const svgp_conv_desc* d, int ncls, const float* in, c
 int svgp_conv_taps_wgrad_f32(const svgp_conv_desc* d, int ncls, const float* in, const float* dout, float* part, int nwg,
                              int part_stride, float* dw, int accumulate, void* stream);
 int svgp_upconv_weights_f32(int Ci, int Co, const float* w, float* we, void* stream);
+/* Reverse pass of a layer's activation, bias and weights in ONE pass over dout (tf.gradients of Conv2D + bias + elu,
+ * VAE_utils.py:294-338): dpre = dout * elu'(out) in place on dout (out == NULL: dpre = dout), db[co] = sum of dpre over
+ * pixels, dW_t[ci][co] = sum in * dpre (layout by woff).  The classes' output pixel sets must be disjoint and together
+ * cover dout.  16 input channels with 4 or 9 taps in every class: one fused kernel (every wave stages its own halo, no
+ * workgroup barrier in the pixel loop); any other shape: svgp_elu_bwd_bias + svgp_conv_taps_wgrad in sequence.
+ * part_b: (1024, 16) scratch; part: (nwg, part_stride) scratch. */
+int svgp_conv_taps_wgrad_fused(const svgp_conv_desc* d, int ncls, const double* in, const double* out, double* dout,
+                               double* part, double* part_b, int nwg, int part_stride, double* dw, double* db,
+                               void* stream);
+int svgp_conv_taps_wgrad_fused_f32(const svgp_conv_desc* d, int ncls, const float* in, const float* out, float* dout,
+                                   float* part, float* part_b, int nwg, int part_stride, float* dw, float* db,
+                                   void* stream);
 int svgp_upconv_fold_wgrad_f32(int Ci, int Co, const float* ge, float* g, void* stream);
 int svgp_elu_bwd_bias_f32(long long npix, int C, const float* out, float* dout, float* part, float* db, void* stream);
 

@@ -146,6 +146,8 @@ SIGNATURES = {
     "svgp_elu_bwd_bias": [C.c_longlong, C.c_int, _P, _P, _P, _P, _P],
     "svgp_upconv_weights": [C.c_int, C.c_int, _P, _P, _P],
     "svgp_upconv_fold_wgrad": [C.c_int, C.c_int, _P, _P, _P],
+    "svgp_conv_taps_wgrad_fused": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P],
+    "svgp_conv_taps_wgrad_fused_f32": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P, _P],
     "svgp_conv_taps_fwd_f32": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P],
     "svgp_conv_taps_wgrad_f32": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, C.c_int, C.c_int, _P, C.c_int, _P],
     "svgp_elu_bwd_bias_f32": [C.c_longlong, C.c_int, _P, _P, _P, _P, _P],

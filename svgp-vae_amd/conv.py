@@ -146,13 +146,12 @@ class ConvLayer:
         assert x.dtype == self.dt and dout.dtype == self.dt and scratch.dtype == self.dt and gw.dtype == self.dt
         part_b = scratch[:1024 * 16]
         part_w = scratch[1024 * 16:]
-        call("svgp_elu_bwd_bias" + self.sfx, n * self.Ho * self.Ho, self.Co, out.data_ptr() if self.elu else None, dout.data_ptr(),
-             part_b.data_ptr(), gb.data_ptr(), stream)
         ds = self.descs_fwd(n, act=0)
         arr = (ConvDesc * len(ds))(*ds)
         gwf = torch.empty(self.n_wf, dtype=self.dt, device=x.device)
-        call("svgp_conv_taps_wgrad" + self.sfx, arr, len(ds), x.data_ptr(), dout.data_ptr(), part_w.data_ptr(), nwg, self.n_wf,
-             gwf.data_ptr(), 0, stream)
+        # dpre = dout * elu'(out) in place, gb = column sums, gwf = weight gradient: one pass (svgp_conv_taps_wgrad_fused)
+        call("svgp_conv_taps_wgrad_fused" + self.sfx, arr, len(ds), x.data_ptr(), out.data_ptr() if self.elu else None,
+             dout.data_ptr(), part_w.data_ptr(), part_b.data_ptr(), nwg, self.n_wf, gwf.data_ptr(), gb.data_ptr(), stream)
         gw.copy_(self.fold_wgrad(gwf, stream))
         if not need_dx:
             return None

@@ -363,6 +363,467 @@ __global__ __launch_bounds__(256) void k_elu_bwd_colsum(long long npix, int C, c
     }
 }
 
+
+// =====================================================================================================================
+// Direct kernels for 16 input channels (every spritesVAE layer but the first; all of their data gradients but the last
+// layer's): no workgroup-wide staging and no barrier in the pixel loop.
+//
+// Forward / data gradient, transposed GEMM  out^T[co][pixel] = sum_t W_t^T[co][ci] in^T[ci][pixel + off_t]:
+//   * B operand (input): lane (r = pixel, q) loads ONE 4-vector in[pixel + off_t][4q .. 4q+3] -- a wave reads 16 pixels x 16
+//     channels = 16 x 64 contiguous bytes (float), fully coalesced, straight from global memory (the 3 x 3 overlap of the taps is
+//     served by L1 / L2); its four components are the B operands of four MFMAs whose k index runs over channels {j, 4+j, 8+j,
+//     12+j} -- the order of the contraction index is free as long as A uses the same one;
+//   * A operand (weights): W_t[ci = 4q + j][co = lane & 15], NT x 4 registers per lane, loaded once per workgroup;
+//   * D: lane (r = pixel, q) holds out[pixel][4q .. 4q+3] (float64: the weight rows are permuted so that the q + 4 reg row
+//     map of the f64 MFMA lands on the same channels) -- one 4-vector store per lane, 16 x 64 contiguous bytes per wave.
+// A wave walks the rows of a 16-pixel-wide strip; with several waves per SIMD one wave's loads run under the others' MFMAs.
+// =====================================================================================================================
+// 128 bytes of zeros: an out-of-image tap reads from here (the ADDRESS is selected, not the loaded value: a select on the value
+// would sit right behind the load and put its s_waitcnt in the middle of the MFMA sequence the load is meant to run under)
+__device__ __attribute__((aligned(128))) double g_conv_zero[16];
+template <typename T> struct DirT;
+template <> struct DirT<float> { static __device__ __forceinline__ int corow(int i) { return i; } };
+template <> struct DirT<double> { static __device__ __forceinline__ int corow(int i) { return ((i & 3) << 2) | (i >> 2); } };
+
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void k_conv16_fwd(svgp_conv_desc d, int strips, int R, int nseg, const T* __restrict__ in,
+                                                    const T* __restrict__ w, const T* __restrict__ bias,
+                                                    T* __restrict__ out) {
+    typedef SvgpMfma<T> MF;
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    // consecutive work items (strips of one image) on one XCD: workgroup ids go round-robin over the 8 XCDs
+    int b = blockIdx.x;
+    { const int per = (int)gridDim.x >> 3; if ((per << 3) == (int)gridDim.x) b = (b & 7) * per + (b >> 3); }
+    const int xs = b % nseg, st = (b / nseg) % strips, n = b / (nseg * strips);
+    const int segw = d.Ws < 16 ? d.Ws : 16, rpw = 16 / segw;          // narrow images: a wave step covers rpw rows
+    const int ry = r / segw, px = xs * 16 + (r - ry * segw);
+    const int co_a = DirT<T>::corow(r);
+    T wr[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wr[t][j] = co_a < d.Co ? w[d.woff[t] + (4 * q + j) * d.Co + co_a] : T(0);
+    v4 bv = {0, 0, 0, 0};
+    if (d.act)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[g] = (4 * q + g < d.Co) ? bias[4 * q + g] : T(0);
+    const T* inn = in + (size_t)n * d.Hi * d.Wi * 16;
+    const int y_end = min(d.Hs, (st + 1) * R);
+    constexpr int TCH = NT <= 9 ? NT : 8;                           // taps in flight
+    for (int y0 = st * R + wave * rpw; y0 < y_end; y0 += 4 * rpw) {
+        const int y = y0 + ry;
+        const bool vo = ry < rpw && y < y_end && px < d.Ws;
+        typename MF::acc_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int t0 = 0; t0 < NT; t0 += TCH) {
+            v4 f[TCH];
+#pragma unroll
+            for (int u = 0; u < TCH; ++u) {
+                const int t = t0 + u;
+                f[u] = v4{0, 0, 0, 0};
+                if (t < NT) {
+                    const int yi = y * d.sy + d.oy[t], xi = px * d.sx + d.ox[t];
+                    if (vo && (unsigned)yi < (unsigned)d.Hi && (unsigned)xi < (unsigned)d.Wi)
+                        f[u] = *reinterpret_cast<const v4*>(inn + ((size_t)yi * d.Wi + xi) * 16 + 4 * q);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TCH; ++u) {
+                const int t = t0 + u;
+                if (t < NT) {
+                    acc0 = MF::mma(wr[t][0], f[u][0], acc0);
+                    acc1 = MF::mma(wr[t][1], f[u][1], acc1);
+                    acc0 = MF::mma(wr[t][2], f[u][2], acc0);
+                    acc1 = MF::mma(wr[t][3], f[u][3], acc1);
+                }
+            }
+        }
+        if (vo) {
+            v4 v;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                T e = acc0[g] + acc1[g];
+                if (d.act) e += bv[g];
+                if (d.act == 1) e = e > 0 ? e : (T)(exp(e) - T(1));
+                v[g] = e;
+            }
+            T* o = out + (((size_t)n * d.Ho + (y * d.osy + d.ooy)) * d.Wo + (px * d.osx + d.oox)) * d.Co;
+            if (d.Co == 16) {
+                *reinterpret_cast<v4*>(o + 4 * q) = v;
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) if (4 * q + g < d.Co) o[4 * q + g] = v[g];
+            }
+        }
+    }
+}
+
+// The same GEMM for tap tables that form a full NR x NC grid (rows oy0 + k, any column offsets; conv 3 x 3 / 2 x 2, the parity
+// classes of the fused-upsample and transposed stride-2 layers, the 4 x 4 table of the fused-upsample data gradient): a wave owns
+// RW CONSECUTIVE output rows of its 16-pixel strip and keeps the NR x NC input vectors in registers -- going one output row down
+// shifts them by SH = sy rows, so only min(SH, NR) x NC vectors are new; they are requested before the MFMAs of the current row
+// (PF) and arrive under them.  3 x 3, stride 1: 3 loads per 36 MFMAs instead of 9, none on the critical path.
+template <typename T, int NR, int NC, int SH, bool PF, bool FULL>      // FULL: Ws a multiple of 16 and 16 output channels
+__global__ __launch_bounds__(256) void k_conv16_fwd_roll(svgp_conv_desc d, int strips, int RW, int nseg, int ntask,
+                                                         const T* __restrict__ in, const T* __restrict__ w,
+                                                         const T* __restrict__ bias, T* __restrict__ out) {
+    typedef SvgpMfma<T> MF;
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    constexpr int NEW = SH < NR ? SH : NR, KEEP = NR - NEW;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, q = lane >> 4;
+    // persistent workgroups: workgroup `b` takes a contiguous range of tasks (strip x segment x image); ids that share an XCD
+    // (b mod 8) take neighbouring ranges.  The tap weights are loaded once per workgroup.
+    int b = blockIdx.x;
+    const int G = (int)gridDim.x;
+    { const int per8 = G >> 3; if ((per8 << 3) == G) b = (b & 7) * per8 + (b >> 3); }
+    const int per = (ntask + G - 1) / G, t_beg = b * per, t_end = min(ntask, t_beg + per);
+    const int co_a = DirT<T>::corow(r), co_c = min(co_a, d.Co - 1);
+    T wr[NR][NC][4];
+#pragma unroll
+    for (int k = 0; k < NR; ++k)
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const T v = w[d.woff[k * NC + c] + (4 * q + j) * d.Co + co_c];      // unconditional load, then select
+                wr[k][c][j] = co_a < d.Co ? v : T(0);
+            }
+    v4 bv = {0, 0, 0, 0};
+    if (d.act)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const T v = bias[min(4 * q + g, d.Co - 1)]; bv[g] = (4 * q + g < d.Co) ? v : T(0); }
+    const int oy0 = d.oy[0];
+    for (int task = t_beg; task < t_end; ++task) {
+        const int xs = task % nseg, st = (task / nseg) % strips, n = task / (nseg * strips);
+        const int px = xs * 16 + r;
+        const T* inn = in + (size_t)n * d.Hi * d.Wi * 16 + 4 * q;
+        const int ya = (st * 4 + wave) * RW, yb = min(d.Hs, ya + RW);
+        if (ya >= yb) continue;
+        const bool vx = FULL || px < d.Ws;
+        int xc[NC];
+        bool xok[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int xi = px * d.sx + d.ox[c];
+            xok[c] = vx && (unsigned)xi < (unsigned)d.Wi;
+            xc[c] = min(max(xi, 0), d.Wi - 1) * 16;
+        }
+        // branch-free: out-of-image taps read the zero page
+        const T* zp = reinterpret_cast<const T*>(g_conv_zero) + 4 * q;
+        auto ld = [&](int yi, int c) -> v4 {
+            const T* src = (xok[c] && (unsigned)yi < (unsigned)d.Hi) ? inn + (size_t)yi * d.Wi * 16 + xc[c] : zp;
+            return *reinterpret_cast<const v4*>(src);
+        };
+        v4 buf[NR][NC], nxt[NEW][NC];
+#pragma unroll
+        for (int k = 0; k < NR; ++k)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) buf[k][c] = ld(ya * d.sy + oy0 + k, c);
+        for (int y = ya; y < yb; ++y) {
+            if (PF) {                                           // (last row: a clamped, unused request)
+#pragma unroll
+                for (int k = 0; k < NEW; ++k)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) nxt[k][c] = ld((y + 1) * d.sy + oy0 + KEEP + k, c);
+            }
+            typename MF::acc_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    acc0 = MF::mma(wr[k][c][0], buf[k][c][0], acc0);
+                    acc1 = MF::mma(wr[k][c][1], buf[k][c][1], acc1);
+                    acc0 = MF::mma(wr[k][c][2], buf[k][c][2], acc0);
+                    acc1 = MF::mma(wr[k][c][3], buf[k][c][3], acc1);
+                }
+            if (vx) {
+                v4 v;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    T e = acc0[g] + acc1[g];
+                    if (d.act) e += bv[g];
+                    if (d.act == 1) e = e > 0 ? e : (T)(exp(e) - T(1));
+                    v[g] = e;
+                }
+                T* o = out + (((size_t)n * d.Ho + (y * d.osy + d.ooy)) * d.Wo + (px * d.osx + d.oox)) * d.Co;
+                if (FULL || d.Co == 16) {
+                    *reinterpret_cast<v4*>(o + 4 * q) = v;
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) if (4 * q + g < d.Co) o[4 * q + g] = v[g];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < KEEP; ++k)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) buf[k][c] = buf[k + NEW][c];
+#pragma unroll
+            for (int k = 0; k < NEW; ++k)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) buf[KEEP + k][c] = PF ? nxt[k][c] : ld((y + 1) * d.sy + oy0 + KEEP + k, c);
+        }
+    }
+}
+
+// Weight gradient, rolling form of the kernel below for images at least 16 pixels wide: a wave owns RW consecutive output rows of a
+// 16-pixel strip; its LDS region is a ring of HH = (tap row range) input rows (slot = input row mod HH), so an output row stages only
+// the SY new input rows -- requested (together with the next row's dout / out values) BEFORE the MFMAs of the current row and written
+// to LDS after them.
+template <typename T, int NT, int SY>
+__global__ __launch_bounds__(256) void k_conv16_wgrad_roll(ConvLaunch L, int nwg, int RW, const T* __restrict__ in,
+                                                           const T* __restrict__ outv, T* __restrict__ dout,
+                                                           T* __restrict__ part, int part_stride, T* __restrict__ part_b,
+                                                           int lds_per_wave) {
+    typedef SvgpMfma<T> MF;
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    constexpr int NI = 3;                                              // 16-pixel staging passes per input row (HW <= 48)
+    extern __shared__ __align__(32) unsigned char smem_raw[];
+    const int cls = blockIdx.y;
+    const svgp_conv_desc& d = L.d[cls];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, q = lane >> 4;
+    T* lds = reinterpret_cast<T*>(smem_raw) + (size_t)wave * lds_per_wave;
+    int oy0, oy1, ox0, ox1;
+    tap_range(d, oy0, oy1, ox0, ox1);
+    const int nseg = (d.Ws + 15) / 16, nrb = (d.Hs + RW - 1) / RW;
+    const int HH = oy1 - oy0 + 1, HW = 15 * d.sx + (ox1 - ox0) + 1, PS = d.sx == 1 ? 16 : 24;
+    typename MF::acc_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = typename MF::acc_t{0, 0, 0, 0};
+    T bsum = 0;
+    int aidx[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) aidx[s] = ((4 * s + q) * d.sx) * PS + r;
+    const int sp = lane >> 2, sc = 4 * (lane & 3);                     // staging: pixel sp + 16 i, channels sc ..
+    const int ntask = d.n * nrb * nseg;
+    for (int task = blockIdx.x * 4 + wave; task < ntask; task += nwg * 4) {
+        const int xs = task % nseg, rb = (task / nseg) % nrb, n = task / (nseg * nrb);
+        const T* inn = in + (size_t)n * d.Hi * d.Wi * 16 + sc;
+        const int ya = rb * RW, yb = min(d.Hs, ya + RW), xf = xs * 16;
+        const int X0 = xf * d.sx + ox0;
+        const int ni = (HW + 15) >> 4;
+        const T* zp = reinterpret_cast<const T*>(g_conv_zero) + sc;
+        auto gload = [&](int gy, int i) -> v4 {                          // branch-free: out-of-image pixels read the zero page
+            const int p = sp + 16 * i, gx = X0 + p;
+            v4 v = {0, 0, 0, 0};
+            if (i < ni) {                                               // (uniform)
+                const T* src = (p < HW && (unsigned)gy < (unsigned)d.Hi && (unsigned)gx < (unsigned)d.Wi)
+                                   ? inn + ((size_t)gy * d.Wi + gx) * 16 : zp;
+                v = *reinterpret_cast<const v4*>(src);
+            }
+            return v;
+        };
+        // ring of HH input rows: slot of input row ya * sy + oy0 + rel = rel mod HH, tracked incrementally (`base` = slot of the
+        // first row the current output row needs)
+        auto wrap = [&](int x) -> int { while (x >= HH) x -= HH; while (x < 0) x += HH; return x; };
+        auto lwrite = [&](int sl, int i, v4 v) {
+            const int p = sp + 16 * i;
+            if (p < HW) *reinterpret_cast<v4*>(lds + (sl * HW + p) * PS + sc) = v;
+        };
+        // first row: the whole ring
+        for (int k = 0; k < HH; ++k) {
+            const int gy = ya * d.sy + oy0 + k;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) lwrite(k, i, gload(gy, i));
+        }
+        int base = 0;
+        T cd[4], co_[4];
+        size_t co_off[4];
+        bool cv[4];
+        auto bload = [&](int y, T* dv, T* ov, size_t* off, bool* ok) {
+            const int yc = min(y, d.Hs - 1), rc = min(r, d.Co - 1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int x = xf + 4 * s + q, xc = min(x, d.Ws - 1);
+                ok[s] = x < d.Ws && r < d.Co && y < d.Hs;
+                off[s] = (((size_t)n * d.Ho + (yc * d.osy + d.ooy)) * d.Wo + (xc * d.osx + d.oox)) * d.Co + rc;
+                dv[s] = *(ok[s] ? dout + off[s] : reinterpret_cast<const T*>(g_conv_zero));
+                ov[s] = outv ? outv[off[s]] : T(1);
+            }
+        };
+        bload(ya, cd, co_, co_off, cv);
+        for (int y = ya; y < yb; ++y) {
+            const bool more = y + 1 < yb;
+            v4 pre[SY][NI];
+            T nd[4], no[4];
+            size_t noff[4];
+            bool nv[4];
+            {                                                           // (last row: clamped, unused requests)
+#pragma unroll
+                for (int k = 0; k < SY; ++k)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) pre[k][i] = gload((y + 1) * d.sy + oy1 - (SY - 1) + k, i);
+                bload(y + 1, nd, no, noff, nv);
+            }
+            T bv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                T dv = cd[s];
+                if (outv) { dv *= (co_[s] > 0 ? T(1) : co_[s] + T(1)); if (cv[s]) dout[co_off[s]] = dv; }
+                bv[s] = dv;
+                bsum += dv;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int toff = (wrap(base + d.oy[t] - oy0) * HW + (d.ox[t] - ox0)) * PS;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[t] = MF::mma(lds[aidx[s] + toff], bv[s], acc[t]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (more) {
+                base = wrap(base + SY);
+#pragma unroll
+                for (int k = 0; k < SY; ++k)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) lwrite(wrap(base + HH - SY + k), i, pre[k][i]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { cd[s] = nd[s]; co_[s] = no[s]; co_off[s] = noff[s]; cv[s] = nv[s]; }
+            }
+        }
+    }
+    // ---- cross-wave combine (fixed order) and store.  D: col (co) = r, row (ci) = MF::row(q, g)
+    T* red = reinterpret_cast<T*>(smem_raw);                            // 4 waves x 64 lanes x 4
+    T* po = part + (size_t)blockIdx.x * part_stride;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[(wave * 64 + lane) * 4 + g] = acc[t][g];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const T v = red[lane * 4 + g] + red[(64 + lane) * 4 + g] + red[(128 + lane) * 4 + g] + red[(192 + lane) * 4 + g];
+                const int ci = MF::row(q, g);
+                if (r < d.Co) po[d.woff[t] + ci * d.Co + r] = v;
+            }
+        }
+    }
+    __syncthreads();
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        T v = 0;
+        for (int k = 0; k < 16; ++k) v += red[k * 16 + threadIdx.x];
+        part_b[((size_t)blockIdx.y * nwg + blockIdx.x) * 16 + threadIdx.x] = v;
+    }
+}
+
+// Weight gradient for 16 input channels, fused with the ELU reverse and the bias gradient:
+//   dpre = dout * elu'(out) (written back in place: the data gradient reads it), db[co] = sum dpre, dW_t[ci][co] = sum in * dpre.
+// GEMM per tap: A[i = ci][k = pixel] = in, B[k = pixel][j = co] = dpre, k-steps of 4 pixels of a 16-pixel segment.
+//   * B: lane (r = co, q) loads dout / out [pixel 4s + q][r] directly (64 contiguous bytes per 16 lanes), applies elu', stores;
+//   * A: each WAVE stages the halo of its own segment (all 16 channels of a pixel by four lanes, one 4-vector each) into a
+//     wave-private LDS region and reads it back as [ci = r][pixel]; LDS operations of one wave complete in order, so the pixel
+//     loop has no workgroup barrier; pixel stride 16 (input stride 1) or 24 (stride 2): the four q groups hit distinct banks;
+//   * dW_t stays in NT accumulator tiles per wave; one cross-wave combine per workgroup, fixed-order partial sums after.
+template <typename T, int NT>
+__global__ __launch_bounds__(256) void k_conv16_wgrad(ConvLaunch L, int nwg, int R, const T* __restrict__ in,
+                                                      const T* __restrict__ outv, T* __restrict__ dout, T* __restrict__ part,
+                                                      int part_stride, T* __restrict__ part_b, int lds_per_wave) {
+    typedef SvgpMfma<T> MF;
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    extern __shared__ __align__(32) unsigned char smem_raw[];
+    const int cls = blockIdx.y;
+    const svgp_conv_desc& d = L.d[cls];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+    T* lds = reinterpret_cast<T*>(smem_raw) + (size_t)wave * lds_per_wave;
+    int oy0, oy1, ox0, ox1;
+    tap_range(d, oy0, oy1, ox0, ox1);
+    const int segw = d.Ws < 16 ? d.Ws : 16, rpw = 16 / segw;
+    const int nseg = (d.Ws + 15) / 16, strips = (d.Hs + R - 1) / R;
+    const int HH = (rpw - 1) * d.sy + (oy1 - oy0) + 1, HW = (segw - 1) * d.sx + (ox1 - ox0) + 1, PS = d.sx == 1 ? 16 : 24;
+    const unsigned magic = 0xFFFFFFFFu / (unsigned)HW + 1u;           // p / HW = umulhi(p, magic) for the small p used here
+    // k-step s covers segment pixels 4s + q -> (row ry_s, column pxl_s) of the segment
+    int ry_s[4], px_s[4], aidx[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const int kp = 4 * s + q;
+        ry_s[s] = kp / segw; px_s[s] = kp - ry_s[s] * segw;
+        aidx[s] = ry_s[s] < rpw ? ((ry_s[s] * d.sy) * HW + px_s[s] * d.sx) * PS + r : r;   // (unused pixel: any staged value)
+    }
+    typename MF::acc_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = typename MF::acc_t{0, 0, 0, 0};
+    T bsum = 0;
+    const int ntask = d.n * strips;
+    for (int task = blockIdx.x; task < ntask; task += nwg) {
+        const int n = task / strips, st = task - n * strips;
+        const T* inn = in + (size_t)n * d.Hi * d.Wi * 16;
+        const int y_beg = st * R, y_end = min(d.Hs, y_beg + R);
+        const int nrow_steps = (y_end - y_beg + rpw - 1) / rpw;
+        for (int it = wave; it < nrow_steps * nseg; it += 4) {
+            const int ys = it / nseg, xs = it - ys * nseg;
+            const int yf = y_beg + ys * rpw, xf = xs * 16;               // first row / column of the segment
+            // ---- stage the halo: pixel p = lane / 4 + 16 i, channels 4 (lane % 4) ..
+            const int Y0 = yf * d.sy + oy0, X0 = xf * d.sx + ox0;
+            for (int p = lane >> 2; p < HH * HW; p += 16) {
+                const int yy = (int)__umulhi((unsigned)p, magic), xx = p - yy * HW;
+                const int gy = Y0 + yy, gx = X0 + xx;
+                v4 v = {0, 0, 0, 0};
+                if ((unsigned)gy < (unsigned)d.Hi && (unsigned)gx < (unsigned)d.Wi)
+                    v = *reinterpret_cast<const v4*>(inn + ((size_t)gy * d.Wi + gx) * 16 + 4 * (lane & 3));
+                *reinterpret_cast<v4*>(lds + p * PS + 4 * (lane & 3)) = v;
+            }
+            // ---- B operands: dpre of the segment's 16 pixels, 4 per k-step
+            T bv[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int y = yf + ry_s[s], x = xf + px_s[s];
+                bv[s] = 0;
+                if (ry_s[s] < rpw && y < y_end && x < d.Ws && r < d.Co) {
+                    const size_t o = (((size_t)n * d.Ho + (y * d.osy + d.ooy)) * d.Wo + (x * d.osx + d.oox)) * d.Co + r;
+                    T dv = dout[o];
+                    if (outv) { const T ov = outv[o]; dv *= (ov > 0 ? T(1) : ov + T(1)); dout[o] = dv; }
+                    bv[s] = dv;
+                    bsum += dv;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int toff = ((d.oy[t] - oy0) * HW + (d.ox[t] - ox0)) * PS;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) acc[t] = MF::mma(lds[aidx[s] + toff], bv[s], acc[t]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    // ---- cross-wave combine (fixed order) and store.  D: col (co) = r, row (ci) = MF::row(q, g)
+    T* red = reinterpret_cast<T*>(smem_raw);                            // 4 waves x 64 lanes x 4
+    T* po = part + (size_t)blockIdx.x * part_stride;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[(wave * 64 + lane) * 4 + g] = acc[t][g];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const T v = red[lane * 4 + g] + red[(64 + lane) * 4 + g] + red[(128 + lane) * 4 + g] + red[(192 + lane) * 4 + g];
+                const int ci = MF::row(q, g);
+                if (r < d.Co) po[d.woff[t] + ci * d.Co + r] = v;
+            }
+        }
+    }
+    __syncthreads();
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        T v = 0;
+        for (int k = 0; k < 16; ++k) v += red[k * 16 + threadIdx.x];
+        part_b[((size_t)blockIdx.y * nwg + blockIdx.x) * 16 + threadIdx.x] = v;
+    }
+}
+
 size_t fwd_lds(const svgp_conv_desc& d) {
     int oy0 = d.oy[0], oy1 = d.oy[0], ox0 = d.ox[0], ox1 = d.ox[0];
     for (int t = 1; t < d.nt; ++t) {
@@ -402,6 +863,103 @@ int check_desc(const svgp_conv_desc* d, int ncls) {
 
 }  // namespace
 
+// ---- host side of the direct kernels
+static bool conv16_enabled() {
+    static const int on = [] { const char* e = getenv("SVGP_CONV_DIRECT"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+static bool conv16_nt_ok(int nt) { return nt == 1 || nt == 2 || nt == 3 || nt == 4 || nt == 6 || nt == 9 || nt == 16; }
+static bool conv16_direct_ok(const svgp_conv_desc* d, int ncls, bool same_nt) {
+    if (!conv16_enabled()) return false;
+    for (int c = 0; c < ncls; ++c) {
+        if (d[c].Ci != 16 || !conv16_nt_ok(d[c].nt)) return false;
+        if (same_nt && (d[c].nt != d[0].nt || (d[c].nt != 4 && d[c].nt != 9))) return false;
+    }
+    return true;
+}
+static int conv16_rows(const svgp_conv_desc& d) {            // output rows per wave (rolling kernels) / per strip / 4 (others)
+    static const int forced = [] { const char* e = getenv("SVGP_CONV_ROWS"); return e ? atoi(e) : 0; }();
+    int rw = forced > 0 ? forced : 8;
+    const int q4 = (d.Hs + 3) / 4;
+    return rw < q4 ? rw : (q4 < 1 ? 1 : q4);
+}
+// Tap table = full NR x NC grid with consecutive row offsets?  `g` receives the descriptor with its taps in grid order
+// (row-major; g.oy[k * NC] = row offset k, g.ox[c] = column offset c).
+static bool conv16_grid(const svgp_conv_desc& d, svgp_conv_desc* g, int* NR, int* NC) {
+    int ys[16], xs[16], ny = 0, nx = 0;
+    for (int t = 0; t < d.nt; ++t) {
+        int k = 0;
+        while (k < ny && ys[k] != d.oy[t]) ++k;
+        if (k == ny) ys[ny++] = d.oy[t];
+        k = 0;
+        while (k < nx && xs[k] != d.ox[t]) ++k;
+        if (k == nx) xs[nx++] = d.ox[t];
+    }
+    if (ny * nx != d.nt) return false;
+    for (int a = 0; a < ny; ++a) for (int b2 = a + 1; b2 < ny; ++b2) if (ys[b2] < ys[a]) { int v = ys[a]; ys[a] = ys[b2]; ys[b2] = v; }
+    for (int a = 0; a < nx; ++a) for (int b2 = a + 1; b2 < nx; ++b2) if (xs[b2] < xs[a]) { int v = xs[a]; xs[a] = xs[b2]; xs[b2] = v; }
+    for (int k = 1; k < ny; ++k) if (ys[k] != ys[0] + k) return false;
+    *g = d;
+    for (int k = 0; k < ny; ++k)
+        for (int c = 0; c < nx; ++c) {
+            int t = 0;
+            while (t < d.nt && !(d.oy[t] == ys[k] && d.ox[t] == xs[c])) ++t;
+            if (t == d.nt) return false;
+            g->oy[k * nx + c] = ys[k]; g->ox[k * nx + c] = xs[c]; g->woff[k * nx + c] = d.woff[t];
+        }
+    *NR = ny; *NC = nx;
+    return true;
+}
+
+template <typename T>
+static int conv16_fwd_launch(const svgp_conv_desc* d, int ncls, const T* in, const T* w, const T* bias, T* out,
+                             void* stream) {
+    static const int roll_on = [] { const char* e = getenv("SVGP_CONV_ROLL"); return (e && e[0] == '0') ? 0 : 1; }();
+    for (int c = 0; c < ncls; ++c) {
+        const svgp_conv_desc& dc = d[c];
+        SVGP_REQUIRE(!dc.act || bias, SVGP_ERR_INVALID, "bias is NULL but act != 0");
+        const int RW = conv16_rows(dc), R = 4 * RW, strips = (dc.Hs + R - 1) / R, nseg = (dc.Ws + 15) / 16;
+        const int ntask = dc.n * strips * nseg;
+        const dim3 grid((unsigned)ntask);
+        static const int pgrid = [] { const char* e = getenv("SVGP_CONV_GRID"); return e ? atoi(e) : 1024; }();
+        const dim3 grid_p((unsigned)(ntask < pgrid ? ntask : pgrid));        // persistent form: <= 4 workgroups per CU
+        svgp_conv_desc g;
+        int NR = 0, NC = 0;
+        bool done = false;
+        if (roll_on && dc.Ws >= 16 && conv16_grid(dc, &g, &NR, &NC)) {
+#define C16R(NR_, NC_, SH_, PF_)                                                                                              \
+            if (!done && NR == NR_ && NC == NC_ && dc.sy == SH_) {                                                          \
+                if (dc.Ws % 16 == 0 && dc.Co == 16)                                                                         \
+                    hipLaunchKernelGGL((k_conv16_fwd_roll<T, NR_, NC_, SH_, PF_, true>), grid_p, dim3(256), 0,                \
+                                       (hipStream_t)stream, g, strips, RW, nseg, ntask, in, w, bias, out);                  \
+                else                                                                                                        \
+                    hipLaunchKernelGGL((k_conv16_fwd_roll<T, NR_, NC_, SH_, PF_, false>), grid_p, dim3(256), 0,               \
+                                       (hipStream_t)stream, g, strips, RW, nseg, ntask, in, w, bias, out);                  \
+                done = true;                                                                                                \
+            }
+            C16R(3, 3, 1, true) C16R(3, 3, 2, true) C16R(2, 2, 1, true) C16R(2, 2, 2, true) C16R(4, 4, 2, false)
+            C16R(1, 1, 1, true) C16R(1, 2, 1, true) C16R(2, 1, 1, true)
+#undef C16R
+        }
+        if (!done) {
+#define C16F(NT_) hipLaunchKernelGGL((k_conv16_fwd<T, NT_>), grid, dim3(256), 0, (hipStream_t)stream, dc, strips, R, nseg, in, w, \
+                                     bias, out)
+            switch (dc.nt) {
+            case 1: C16F(1); break;
+            case 2: C16F(2); break;
+            case 3: C16F(3); break;
+            case 4: C16F(4); break;
+            case 6: C16F(6); break;
+            case 9: C16F(9); break;
+            default: C16F(16); break;
+            }
+#undef C16F
+        }
+        SVGP_LAUNCH_CHECK();
+    }
+    return SVGP_OK;
+}
+
 template <typename T>
 static int conv_taps_fwd_impl(const svgp_conv_desc* d, int ncls, const T* in, const T* w, const T* bias, T* out,
                               void* stream) {
@@ -418,6 +976,7 @@ static int conv_taps_fwd_impl(const svgp_conv_desc* d, int ncls, const T* in, co
                          d[c].Co == d[0].Co && d[c].act == d[0].act,
                      SVGP_ERR_INVALID, "the classes of one launch share the input geometry (n, Hs, Ws, strides, Ci, Co, act)");
     }
+    if (conv16_direct_ok(d, ncls, false)) return conv16_fwd_launch<T>(d, ncls, in, w, bias, out, stream);
     // union halo tile of all classes + the packed tap weights of every class
     size_t lds = fwd_lds_all(d, ncls);
     for (int c = 0; c < ncls; ++c) lds += (size_t)d[c].nt * ((d[0].Ci + 3) & ~3) * 16;
@@ -479,6 +1038,79 @@ static int conv_taps_wgrad_impl(const svgp_conv_desc* d, int ncls, const T* in, 
     return SVGP_OK;
 }
 
+// One pass for the reverse of a layer's bias / activation / weights: dpre = dout * elu'(out) in place (out == NULL: dpre = dout),
+// db = column sums of dpre, dW_t = sum in * dpre.  16 input channels with 4 or 9 taps per class: the fused direct kernel;
+// otherwise the separate kernels in sequence.  part_b: (1024, 16) scratch, part: (nwg, part_stride) scratch.
+template <typename T> static int elu_bwd_bias_impl(long long, int, const T*, T*, T*, T*, void*);
+template <typename T>
+static int conv_wgrad_fused_impl(const svgp_conv_desc* d, int ncls, const T* in, const T* outv, T* dout, T* part, T* part_b,
+                                 int nwg, int part_stride, T* dw, T* db, void* stream) {
+    int rc = check_desc(d, ncls);
+    if (rc) return rc;
+    SVGP_REQUIRE(in && dout && part && part_b && dw && db && nwg >= 1 && part_stride >= 1, SVGP_ERR_INVALID, "bad argument");
+    if (!conv16_direct_ok(d, ncls, true)) {
+        rc = elu_bwd_bias_impl<T>((long long)d[0].n * d[0].Ho * d[0].Wo, d[0].Co, outv, dout, part_b, db, stream);
+        if (rc) return rc;
+        return conv_taps_wgrad_impl<T>(d, ncls, in, dout, part, nwg, part_stride, dw, 0, stream);
+    }
+    static const int roll_on = [] { const char* e = getenv("SVGP_CONV_ROLL"); return (e && e[0] == '0') ? 0 : 1; }();
+    ConvLaunch L;
+    L.ncls = ncls;
+    int nwg_c = nwg / ncls;
+    if (nwg_c < 1) nwg_c = 1;
+    if (nwg_c * ncls > 1024) nwg_c = 1024 / ncls;
+    size_t lpw = 0, lpw_roll = 0;
+    const int RW = conv16_rows(d[0]);
+    bool roll = roll_on && d[0].Ws >= 16 && (d[0].sy == 1 || d[0].sy == 2);
+    for (int c = 0; c < ncls; ++c) {
+        L.d[c] = d[c];
+        SVGP_REQUIRE(d[c].Co == d[0].Co && d[c].Hs == d[0].Hs && d[c].Ws == d[0].Ws && d[c].sy == d[0].sy, SVGP_ERR_INVALID,
+                     "classes of one launch share Co, the row stride and the iteration space");
+        int oy0 = d[c].oy[0], oy1 = oy0, ox0 = d[c].ox[0], ox1 = ox0;
+        for (int t = 1; t < d[c].nt; ++t) {
+            oy0 = oy0 < d[c].oy[t] ? oy0 : d[c].oy[t]; oy1 = oy1 > d[c].oy[t] ? oy1 : d[c].oy[t];
+            ox0 = ox0 < d[c].ox[t] ? ox0 : d[c].ox[t]; ox1 = ox1 > d[c].ox[t] ? ox1 : d[c].ox[t];
+        }
+        const int segw = d[c].Ws < 16 ? d[c].Ws : 16, rpw = 16 / segw, PS = d[c].sx == 1 ? 16 : 24;
+        const size_t e = (size_t)((rpw - 1) * d[c].sy + (oy1 - oy0) + 1) * ((segw - 1) * d[c].sx + (ox1 - ox0) + 1) * PS;
+        lpw = e > lpw ? e : lpw;
+        const int HWr = 15 * d[c].sx + (ox1 - ox0) + 1;
+        if (HWr > 48) roll = false;
+        const size_t er = (size_t)(oy1 - oy0 + 1) * HWr * PS;
+        lpw_roll = er > lpw_roll ? er : lpw_roll;
+    }
+    if (roll) lpw = lpw_roll;
+    lpw = (lpw + 7) & ~(size_t)7;
+    size_t lds = 4 * lpw > 1024 ? 4 * lpw : 1024;
+    lds *= sizeof(T);
+    SVGP_REQUIRE(lds <= 160 * 1024, SVGP_ERR_UNSUPPORTED, "conv halo needs %zu bytes of LDS", lds);
+    SVGP_CHECK_HIP(hipMemsetAsync(part, 0, (size_t)nwg_c * part_stride * sizeof(T), (hipStream_t)stream));
+#define C16W(KERNEL_, ROWS_)                                                                                                \
+    do {                                                                                                                    \
+        SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL_),                                          \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                          \
+        hipLaunchKernelGGL(KERNEL_, dim3(nwg_c, ncls), dim3(256), lds, (hipStream_t)stream, L, nwg_c, ROWS_, in,            \
+                           outv, dout, part, part_stride, part_b, (int)lpw);                                                \
+    } while (0)
+    if (roll) {
+        if (d[0].nt == 9 && d[0].sy == 1) C16W((k_conv16_wgrad_roll<T, 9, 1>), RW);
+        else if (d[0].nt == 9) C16W((k_conv16_wgrad_roll<T, 9, 2>), RW);
+        else if (d[0].sy == 1) C16W((k_conv16_wgrad_roll<T, 4, 1>), RW);
+        else C16W((k_conv16_wgrad_roll<T, 4, 2>), RW);
+    } else {
+        if (d[0].nt == 9) C16W((k_conv16_wgrad<T, 9>), 4 * RW); else C16W((k_conv16_wgrad<T, 4>), 4 * RW);
+    }
+#undef C16W
+    SVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sum_partials<T>, dim3((part_stride + 15) / 16), dim3(256), 0, (hipStream_t)stream, nwg_c,
+                       part_stride, part_stride, (const T*)part, dw, 0);
+    SVGP_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sum_partials<T>, dim3(1), dim3(256), 0, (hipStream_t)stream, nwg_c * ncls, d[0].Co, 16,
+                       (const T*)part_b, db, 0);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
 // dpre = dout * elu'(out) (in place on dout; out == NULL skips the activation) and db[c] = sum dpre[.., c].
 // part: (1024, C) scratch.
 template <typename T>
@@ -522,6 +1154,16 @@ extern "C" int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const dou
 extern "C" int svgp_elu_bwd_bias(long long npix, int C, const double* out, double* dout, double* part, double* db,
                                  void* stream) {
     return elu_bwd_bias_impl<double>(npix, C, out, dout, part, db, stream);
+}
+extern "C" int svgp_conv_taps_wgrad_fused(const svgp_conv_desc* d, int ncls, const double* in, const double* out, double* dout,
+                                          double* part, double* part_b, int nwg, int part_stride, double* dw, double* db,
+                                          void* stream) {
+    return conv_wgrad_fused_impl<double>(d, ncls, in, out, dout, part, part_b, nwg, part_stride, dw, db, stream);
+}
+extern "C" int svgp_conv_taps_wgrad_fused_f32(const svgp_conv_desc* d, int ncls, const float* in, const float* out, float* dout,
+                                              float* part, float* part_b, int nwg, int part_stride, float* dw, float* db,
+                                              void* stream) {
+    return conv_wgrad_fused_impl<float>(d, ncls, in, out, dout, part, part_b, nwg, part_stride, dw, db, stream);
 }
 extern "C" int svgp_upconv_weights(int Ci, int Co, const double* w, double* we, void* stream) {
     return upconv_weights_impl<double>(Ci, Co, w, we, stream);

@@ -381,6 +381,12 @@ __global__ __launch_bounds__(256) void k_elu_bwd_colsum(long long npix, int C, c
 // 128 bytes of zeros: an out-of-image tap reads from here (the ADDRESS is selected, not the loaded value: a select on the value
 // would sit right behind the load and put its s_waitcnt in the middle of the MFMA sequence the load is meant to run under)
 __device__ __attribute__((aligned(128))) double g_conv_zero[16];
+// exp of the ELU epilogue of the rolling kernel.  float32: v_exp_f32 on x * log2(e) (2 instructions; the library expf is ~25 per
+// element, and the epilogue's VALU work does not hide under the other waves' MFMAs: tools/micro/mfma_f32_issue.hip -- 36 MFMAs
+// per row alone 144 TFLOP/s, with the register rotation 131, with expf + store 108); arguments are <= 0 here, absolute error
+// <= 2e-7.  float64: the library exp.
+__device__ __forceinline__ float conv_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ double conv_exp(double x) { return exp(x); }
 template <typename T> struct DirT;
 template <> struct DirT<float> { static __device__ __forceinline__ int corow(int i) { return i; } };
 template <> struct DirT<double> { static __device__ __forceinline__ int corow(int i) { return ((i & 3) << 2) | (i >> 2); } };
@@ -543,7 +549,7 @@ __global__ __launch_bounds__(256) void k_conv16_fwd_roll(svgp_conv_desc d, int s
                 for (int g = 0; g < 4; ++g) {
                     T e = acc0[g] + acc1[g];
                     if (d.act) e += bv[g];
-                    if (d.act == 1) e = e > 0 ? e : (T)(exp(e) - T(1));
+                    if (d.act == 1) e = e > 0 ? e : (T)(conv_exp(e) - T(1));
                     v[g] = e;
                 }
                 T* o = out + (((size_t)n * d.Ho + (y * d.osy + d.ooy)) * d.Wo + (px * d.osx + d.oox)) * d.Co;

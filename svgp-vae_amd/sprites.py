@@ -206,7 +206,7 @@ class SpritesStepEngine:
         self.dec = [ConvLayer(h, 16, 16 if i < 6 else 3, 3, 1, "same", up=u, dtype=self.ndt)
                     for i, (h, u) in enumerate(zip(dec_h, DEC_UP))]
         self.rep = [ConvLayer(h, ci, self.Lc, 2, 2, "same", dtype=self.ndt) for h, ci in zip((64, 32, 16), (3, self.Lc, self.Lc))]
-        self.nwg = 512        # workgroups of the weight-gradient launches (2 per CU)
+        self.nwg = 1024       # workgroups of the weight-gradient launches (4 per CU: the fused kernel hides its loads by occupancy)
         self.scratch = torch.zeros(max(l.scratch_elems(self.nwg) for l in self.enc + self.dec + self.rep),
                                    dtype=self.ndt, device=self.dev)
         self.kscratch = torch.zeros(b_max * self.La + (self.m + b_max) * 4 + 16, **f64)

@@ -23,7 +23,10 @@ LAYERS = (("enc_c1 64x64 3->16 s1", ConvLayer(64, 3, 16, 3, 1, "same", dtype=DT)
           ("dec_c6 64x64 16->16 s1", ConvLayer(64, 16, 16, 3, 1, "same", dtype=DT)), ("dec_c7 64x64 16->3 s1", ConvLayer(64, 16, 3, 3, 1, "same", dtype=DT)),
           ("repr_c1 64x64 3->16 k2 s2", ConvLayer(64, 3, 16, 2, 2, "same", dtype=DT)), ("enc_c5 16x16 16->16 s1", ConvLayer(16, 16, 16, 3, 1, "same", dtype=DT)))
 NWG = int(os.environ.get("CONV_NWG", "512"))
-for name, lay in LAYERS:
+ONLY = os.environ.get("CONV_PROBE_ONLY")
+for li, (name, lay) in enumerate(LAYERS):
+    if ONLY is not None and li != int(ONLY):
+        continue
     x = torch.randn(n, lay.Hi, lay.Hi, lay.Ci, dtype=DT, device="cuda")
     w = torch.randn(lay.k, lay.k, lay.Ci, lay.Co, dtype=DT, device="cuda") * 0.1
     b = torch.zeros(lay.Co, dtype=DT, device="cuda")

@@ -22,6 +22,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 struct GemmArgs {
     int M, N, K;            // C is M x N, contraction K
     int tiles_m, tiles_n, batch, xcd_remap;
+    int full_m, full_n;     // k_gemm_mixed: tile rows / columns [0, full) are 128 wide, the last one (if any) is an edge tile
     int ta, tb;             // op(A) = A^T if ta (A stored K x M), op(B) = B^T if tb (B stored N x K)
     int lda, ldb, ldc;
     long long sa, sb, sc;   // batch strides in elements (0 = shared)
@@ -60,49 +61,41 @@ template <> struct MfmaT<float> {
     __device__ static __forceinline__ int row(int q, int e) { return 4 * q + e; }       // C/D: row = 4 (lane >> 4) + reg
 };
 
-template <bool TA, bool TB, int WT, typename TS, typename TC, bool VEC>
-__global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
+// One output tile of 32 WM x 32 WN (wave (w >> 1, w & 1) owns WM x WN MFMA tiles) at rows i0.., columns j0.. of matrix l.
+template <bool TA, bool TB, int WM, int WN, typename TS, typename TC, bool VEC>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int j0, TC* hs) {
     typedef MfmaT<TC> MF;
     typedef TS TS2 __attribute__((ext_vector_type(2)));
     typedef TC TC2 __attribute__((ext_vector_type(2)));
-    constexpr int GK = GK_OF(WT), HT = 32 * WT, HLD = HT + MF::PAD, NP = HT * GK / 512;
-    static_assert(GK == 16 && HLD % 2 == 0, "staging map below: 8 k-pairs x 32 rows per 256 threads");
-    extern __shared__ __align__(16) unsigned char hs_raw[];
-    TC* hs = reinterpret_cast<TC*>(hs_raw);
-    TC* As = hs;                         // [2][GK][HLD]
-    TC* Bs = hs + 2 * GK * HLD;          // [2][GK][HLD]
-    // XCD-aware order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2);
-    // remapping id -> (id % 8) * ceil(total / 8) + id / 8 gives every XCD a contiguous run of tiles, i.e. whole
-    // matrices of the batch, so the operand panels a tile row / column shares are fetched into ONE L2
-    const int total = g.tiles_n * g.tiles_m * g.batch, per = (total + 7) / 8;
-    const int lid = g.xcd_remap ? (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8) : (int)blockIdx.x;
-    if (lid >= total) return;
-    const int l = lid / (g.tiles_n * g.tiles_m), tt = lid % (g.tiles_n * g.tiles_m);
-    const int i0 = (tt / g.tiles_n) * HT, j0 = (tt % g.tiles_n) * HT;
-    if ((g.tri & 1) && j0 > i0 + HT - 1) return;
+    constexpr int GK = 16, HM = 32 * WM, HN = 32 * WN, LDA_ = HM + MF::PAD, LDB_ = HN + MF::PAD;
+    constexpr int NPA = HM * GK / 512, NPB = HN * GK / 512;
+    static_assert(LDA_ % 2 == 0 && LDB_ % 2 == 0, "staging map below: 8 k-pairs x 32 rows per 256 threads");
+    TC* As = hs;                         // [2][GK][LDA_]
+    TC* Bs = hs + 2 * GK * LDA_;         // [2][GK][LDB_]
+    if ((g.tri & 1) && j0 > i0 + HM - 1) return;
     int klo = 0, khi = g.K;
     if (g.tri & 2) klo = i0;
     if ((g.tri & 4) && j0 > klo) klo = j0;
-    if ((g.tri & 8) && i0 + HT < khi) khi = i0 + HT;
+    if ((g.tri & 8) && i0 + HM < khi) khi = i0 + HM;
     const TS* __restrict__ A = static_cast<const TS*>(g.A) + (size_t)l * g.sa;
     const TS* __restrict__ B = static_cast<const TS*>(g.B) + (size_t)l * g.sb;
     TS* C = static_cast<TS*>(g.C) + (size_t)l * g.sc;
     const TS* __restrict__ wk = g.wk ? static_cast<const TS*>(g.wk) + (size_t)l * g.sw : nullptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-    const int wi = (wave >> 1) * 16 * WT, wj = (wave & 1) * 16 * WT;
-    typename MF::acc_t acc[WT][WT];
+    const int wi = (wave >> 1) * 16 * WM, wj = (wave & 1) * 16 * WN;
+    typename MF::acc_t acc[WM][WN];
 #pragma unroll
-    for (int a = 0; a < WT; ++a)
+    for (int a = 0; a < WM; ++a)
 #pragma unroll
-        for (int b = 0; b < WT; ++b) acc[a][b] = typename MF::acc_t{0, 0, 0, 0};
-    // Staging: NP pairs of memory-adjacent elements per operand per thread.
+        for (int b = 0; b < WN; ++b) acc[a][b] = typename MF::acc_t{0, 0, 0, 0};
+    // Staging: NPA / NPB pairs of memory-adjacent elements per operand per thread.
     //   operand stored [x][k] (k contiguous): the pair (k, k + 1), k = 2 (tid & 7), of row x = (tid >> 3) + 32 h
-    //   operand stored [k][x] (x contiguous): pair e = tid + 256 h of the GK x HT / 2 panel, k = e / (HT / 2), x = 2 (e % (HT / 2))
+    //   operand stored [k][x] (x contiguous): pair e = tid + 256 h of the GK x H / 2 panel, k = e / (H / 2), x = 2 (e % (H / 2))
     // A tile that lies inside the matrix takes its full panels without bounds checks, as one 16-byte load per pair when
     // the host found the operands 16-byte aligned with even leading dimensions (VEC): 60 -> 64 TFLOP/s on exact tiles
     // (tools/micro/gemm_stages.hip), and the checks were worth another 5 %.
-    const bool inside = i0 + HT <= g.M && j0 + HT <= g.N;
-    TC ra[2 * NP], rb[2 * NP];
+    const bool inside = i0 + HM <= g.M && j0 + HN <= g.N;
+    TC ra[2 * NPA], rb[2 * NPB];
     auto ldpair = [&](const TS* __restrict__ p, bool ok0, bool ok1, bool fast, TC& v0, TC& v1) {
         if (fast) {
             if (VEC) {
@@ -119,8 +112,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
     auto fetch = [&](int k0) {
         const bool fast = inside && k0 + GK <= g.K;
 #pragma unroll
-        for (int h = 0; h < NP; ++h) {
-            const int e = tid + 256 * h, kx = e / (HT / 2), xx = 2 * (e % (HT / 2));    // [k][x] map
+        for (int h = 0; h < NPA; ++h) {
+            const int e = tid + 256 * h, kx = e / (HM / 2), xx = 2 * (e % (HM / 2));    // [k][x] map
             const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;                      // [x][k] map
             if (TA) {
                 const int gi = i0 + xx, gk = k0 + kx;
@@ -129,6 +122,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
                 const int gi = i0 + xk, gk = k0 + kk;
                 ldpair(A + (size_t)gi * g.lda + gk, gi < g.M && gk < g.K, gi < g.M && gk + 1 < g.K, fast, ra[2 * h], ra[2 * h + 1]);
             }
+        }
+#pragma unroll
+        for (int h = 0; h < NPB; ++h) {
+            const int e = tid + 256 * h, kx = e / (HN / 2), xx = 2 * (e % (HN / 2));
+            const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;
             if (TB) {
                 const int gj = j0 + xk, gk = k0 + kk;
                 ldpair(B + (size_t)gj * g.ldb + gk, gj < g.N && gk < g.K, gj < g.N && gk + 1 < g.K, fast, rb[2 * h], rb[2 * h + 1]);
@@ -147,21 +145,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
         }
     };
     auto stage = [&](int buf) {
-        TC* Ad = As + buf * GK * HLD;
-        TC* Bd = Bs + buf * GK * HLD;
+        TC* Ad = As + buf * GK * LDA_;
+        TC* Bd = Bs + buf * GK * LDB_;
 #pragma unroll
-        for (int h = 0; h < NP; ++h) {
-            const int e = tid + 256 * h, kx = e / (HT / 2), xx = 2 * (e % (HT / 2));
+        for (int h = 0; h < NPA; ++h) {
+            const int e = tid + 256 * h, kx = e / (HM / 2), xx = 2 * (e % (HM / 2));
             const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;
             if (TA) {
-                *reinterpret_cast<TC2*>(&Ad[kx * HLD + xx]) = TC2{ra[2 * h], ra[2 * h + 1]};
+                *reinterpret_cast<TC2*>(&Ad[kx * LDA_ + xx]) = TC2{ra[2 * h], ra[2 * h + 1]};
             } else {
-                Ad[kk * HLD + xk] = ra[2 * h]; Ad[(kk + 1) * HLD + xk] = ra[2 * h + 1];
+                Ad[kk * LDA_ + xk] = ra[2 * h]; Ad[(kk + 1) * LDA_ + xk] = ra[2 * h + 1];
             }
+        }
+#pragma unroll
+        for (int h = 0; h < NPB; ++h) {
+            const int e = tid + 256 * h, kx = e / (HN / 2), xx = 2 * (e % (HN / 2));
+            const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;
             if (TB) {
-                Bd[kk * HLD + xk] = rb[2 * h]; Bd[(kk + 1) * HLD + xk] = rb[2 * h + 1];
+                Bd[kk * LDB_ + xk] = rb[2 * h]; Bd[(kk + 1) * LDB_ + xk] = rb[2 * h + 1];
             } else {
-                *reinterpret_cast<TC2*>(&Bd[kx * HLD + xx]) = TC2{rb[2 * h], rb[2 * h + 1]};
+                *reinterpret_cast<TC2*>(&Bd[kx * LDB_ + xx]) = TC2{rb[2 * h], rb[2 * h + 1]};
             }
         }
     };
@@ -176,26 +179,26 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
     __syncthreads();
     int cur = 0;
     for (int k0 = klo; k0 < khi; k0 += GK) {
-        const TC* Ab = As + cur * GK * HLD + wi + r;
-        const TC* Bb = Bs + cur * GK * HLD + wj + r;
-        TC av[2][WT], bv[2][WT];
+        const TC* Ab = As + cur * GK * LDA_ + wi + r;
+        const TC* Bb = Bs + cur * GK * LDB_ + wj + r;
+        TC av[2][WM], bv[2][WN];
 #pragma unroll
-        for (int a = 0; a < WT; ++a) av[0][a] = Ab[q * HLD + 16 * a];
+        for (int a = 0; a < WM; ++a) av[0][a] = Ab[q * LDA_ + 16 * a];
 #pragma unroll
-        for (int b = 0; b < WT; ++b) bv[0][b] = Bb[q * HLD + 16 * b];
+        for (int b = 0; b < WN; ++b) bv[0][b] = Bb[q * LDB_ + 16 * b];
 #pragma unroll
         for (int st = 0; st < GK / 4; ++st) {
             if (st + 1 < GK / 4) {
 #pragma unroll
-                for (int a = 0; a < WT; ++a) av[(st + 1) & 1][a] = Ab[(4 * (st + 1) + q) * HLD + 16 * a];
+                for (int a = 0; a < WM; ++a) av[(st + 1) & 1][a] = Ab[(4 * (st + 1) + q) * LDA_ + 16 * a];
 #pragma unroll
-                for (int b = 0; b < WT; ++b) bv[(st + 1) & 1][b] = Bb[(4 * (st + 1) + q) * HLD + 16 * b];
+                for (int b = 0; b < WN; ++b) bv[(st + 1) & 1][b] = Bb[(4 * (st + 1) + q) * LDB_ + 16 * b];
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int a = 0; a < WT; ++a)
+            for (int a = 0; a < WM; ++a)
 #pragma unroll
-                for (int b = 0; b < WT; ++b) acc[a][b] = MF::mma(av[st & 1][a], bv[st & 1][b], acc[a][b]);
+                for (int b = 0; b < WN; ++b) acc[a][b] = MF::mma(av[st & 1][a], bv[st & 1][b], acc[a][b]);
             __builtin_amdgcn_sched_barrier(0);
             if (st == 0) {
                 if (k0 + GK < khi) stage(cur ^ 1);
@@ -208,9 +211,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
     }
     const bool has_beta = g.beta != real(0);
 #pragma unroll
-    for (int a = 0; a < WT; ++a)
+    for (int a = 0; a < WM; ++a)
 #pragma unroll
-        for (int b = 0; b < WT; ++b)
+        for (int b = 0; b < WN; ++b)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int gi = i0 + wi + a * 16 + MF::row(q, e), gj = j0 + wj + b * 16 + r;
@@ -223,6 +226,42 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
                     }
                 }
             }
+}
+
+template <bool TA, bool TB, int WT, typename TS, typename TC, bool VEC>
+__global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
+    extern __shared__ __align__(16) unsigned char hs_raw[];
+    // XCD-aware order: hardware deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2);
+    // remapping id -> (id % 8) * ceil(total / 8) + id / 8 gives every XCD a contiguous run of tiles, i.e. whole
+    // matrices of the batch, so the operand panels a tile row / column shares are fetched into ONE L2
+    const int total = g.tiles_n * g.tiles_m * g.batch, per = (total + 7) / 8;
+    const int lid = g.xcd_remap ? (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    if (lid >= total) return;
+    const int l = lid / (g.tiles_n * g.tiles_m), tt = lid % (g.tiles_n * g.tiles_m);
+    gemm_tile<TA, TB, WT, WT, TS, TC, VEC>(g, l, (tt / g.tiles_n) * 32 * WT, (tt % g.tiles_n) * 32 * WT,
+                                           reinterpret_cast<TC*>(hs_raw));
+}
+
+// Mixed tiling for extents that are not multiples of 128: full 128 x 128 tiles in the interior and ONE row / column of
+// 32 E-wide edge tiles (E = 1, 2: remainders up to 32 / 64; larger remainders take a bounds-checked full tile) in the same
+// launch -- m = 800 = 6 x 128 + 32 runs 36 interior tiles at the large-tile rate and pads 13 thin ones instead of padding
+// every tile row and column (128-tiles: 25 % padding, 64-tiles: 8 % at the lower small-tile rate).
+template <bool TA, bool TB, int E, typename TS, typename TC, bool VEC>
+__global__ __launch_bounds__(256, 2) void k_gemm_mixed(GemmArgs g) {
+    extern __shared__ __align__(16) unsigned char hs_raw[];
+    TC* hs = reinterpret_cast<TC*>(hs_raw);
+    const int total = g.tiles_n * g.tiles_m * g.batch, per = (total + 7) / 8;
+    const int lid = g.xcd_remap ? (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    if (lid >= total) return;
+    // (the edge tiles stay interleaved in row-major tile order: collected at the end of the launch they run together, all of
+    // them at the low arithmetic intensity of a thin tile -- measured 43 instead of 53 TFLOP/s at 800^3 x 64)
+    const int l = lid / (g.tiles_n * g.tiles_m), tt = lid % (g.tiles_n * g.tiles_m);
+    const int ti = tt / g.tiles_n, tj = tt % g.tiles_n, i0 = ti * 128, j0 = tj * 128;
+    const bool em = ti >= g.full_m, en = tj >= g.full_n;       // (at most the last tile row / column)
+    if (!em && !en) gemm_tile<TA, TB, 4, 4, TS, TC, VEC>(g, l, i0, j0, hs);
+    else if (!em) gemm_tile<TA, TB, 4, E, TS, TC, VEC>(g, l, i0, j0, hs);
+    else if (!en) gemm_tile<TA, TB, E, 4, TS, TC, VEC>(g, l, i0, j0, hs);
+    else gemm_tile<TA, TB, E, E, TS, TC, VEC>(g, l, i0, j0, hs);
 }
 
 // (Tried and removed, round 2: a persistent form whose LDS double buffer keeps running across tile boundaries -- the first
@@ -457,9 +496,19 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     const long long blocks64 = ((tri & 1) && M == N ? nt64 * (nt64 + 1) / 2 : (long long)((N + 63) / 64) * nt64) * batch;
     // (tried: 160 x 160 tiles, 5 x 5 MFMA tiles per wave, no padding at m = 800 -- 512 registers per lane plus spills and one
     // wave per SIMD: 25-38 TFLOP/s at 800^3 x 64 against 41-46 for the 64-tiles; removed)
-    const int wt = (blocks128 >= 192 && cost4 <= cost2) ? 4 : (blocks64 < 256 ? 1 : 2), ht = 32 * wt;
+    int wt = (blocks128 >= 192 && cost4 <= cost2) ? 4 : (blocks64 < 256 ? 1 : 2);
+    // mixed tiling (k_gemm_mixed, float64): an extent with a remainder of at most 64 modulo 128 gets 128-tiles + one row / column
+    // of 32- or 64-wide edge tiles
+    static const int mixed_on = [] { const char* e = getenv("SVGP_GEMM_MIXED"); return (e && e[0] == '0') ? 0 : 1; }();
+    const int rem_m = M % 128, rem_n = N % 128;
+    const bool edge_m = rem_m > 0 && rem_m <= 64, edge_n = rem_n > 0 && rem_n <= 64;
+    const bool mixed = mixed_on && prec == 0 && M >= 128 && N >= 128 && blocks128 >= 192 && (edge_m || edge_n);
+    const int edge_w = ((edge_m && rem_m > 32) || (edge_n && rem_n > 32)) ? 2 : 1;
+    if (mixed) wt = 4;
+    const int ht = 32 * wt;
     const size_t lds = prec == 0 ? (size_t)4 * GK_OF(wt) * (ht + 2) * sizeof(double) : (size_t)4 * GK_OF(wt) * (ht + 16) * sizeof(float);
     g.tiles_n = (N + ht - 1) / ht; g.tiles_m = (M + ht - 1) / ht; g.batch = batch;
+    g.full_m = (mixed && edge_m) ? M / 128 : g.tiles_m; g.full_n = (mixed && edge_n) ? N / 128 : g.tiles_n;
     g.xcd_remap = 1;     // measured neutral (+-1 %) at 800^3 x 64 and 2048^3 x 16: the Infinity Cache already absorbs the
                          // cross-XCD panel re-fetches; kept because it never hurts and is the layout the hardware deals
     const long long total = (long long)g.tiles_n * g.tiles_m * batch;
@@ -493,10 +542,32 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
         else if (wt == 1) LAUNCH_T(1, TS_, TC_); \
         else LAUNCH_T(2, TS_, TC_);           \
     } while (0)
-    if (prec == 0) LAUNCH_P(double, double);
+#define LAUNCH_MX(TA_, TB_, E_)                                                                                              \
+    do {                                                                                                                 \
+        if (vec) {                                                                                                       \
+            SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_mixed<TA_, TB_, E_, double, double, true>),  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+            hipLaunchKernelGGL((k_gemm_mixed<TA_, TB_, E_, double, double, true>), grid, dim3(256), lds, (hipStream_t)stream, g); \
+        } else {                                                                                                         \
+            SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_mixed<TA_, TB_, E_, double, double, false>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+            hipLaunchKernelGGL((k_gemm_mixed<TA_, TB_, E_, double, double, false>), grid, dim3(256), lds, (hipStream_t)stream, g); \
+        }                                                                                                                \
+    } while (0)
+#define LAUNCH_ME(E_)                                  \
+    do {                                               \
+        if (ta && tb) LAUNCH_MX(true, true, E_);       \
+        else if (ta) LAUNCH_MX(true, false, E_);       \
+        else if (tb) LAUNCH_MX(false, true, E_);       \
+        else LAUNCH_MX(false, false, E_);              \
+    } while (0)
+    if (mixed) { if (edge_w == 1) LAUNCH_ME(1); else LAUNCH_ME(2); }
+    else if (prec == 0) LAUNCH_P(double, double);
     else if (prec == 1) LAUNCH_P(double, float);
     else LAUNCH_P(float, float);
 #undef LAUNCH_P
+#undef LAUNCH_ME
+#undef LAUNCH_MX
 #undef LAUNCH_T
 #undef LAUNCH_G
 #undef LAUNCH_V

@@ -126,6 +126,13 @@ def host_threads(cap):
 
 
 def emit(line):
+    # every line: the minimum next to the median of the timed blocks, and the blocks that took > 3x the median (a fresh box's
+    # first blocks can include a clock ramp or a paged-in library: BENCH_r02 had one 77 ms block among 3.9 ms ones)
+    if "block_ms" in line:
+        b = line["block_ms"]
+        med = float(np.median(b))
+        line["block_ms_min"], line["block_ms_median"] = float(min(b)), med
+        line["block_outliers"] = [{"index": i, "ms": x, "x_median": round(x / med, 1)} for i, x in enumerate(b) if x > 3 * med]
     # RCCL prints a version banner through C stdio at communicator creation; flush it first so the JSON line is the
     # last line on stdout
     C.CDLL(None).fflush(None)
@@ -300,6 +307,12 @@ def cpu_baseline_mnist(cfg3, budget_s=15.0):
     return out
 
 
+def mnist_survey_flops(b, L_, m, D):
+    """one figure per step -- nets 0.49 MFLOP/img forward (x3 fwd + bwd), GP block
+    F_gp = (5L+2) b m^2 + 5.33 L m^3 (x3) + kernel build (b m + m^2)(2D + 12) (x3).  0.45 GFLOP at config 2, 22 at config 3."""
+    return 3 * 0.49e6 * b + 3 * ((5 * L_ + 2) * b * m * m + 5.33 * L_ * m ** 3) + 3 * (b * m + m * m) * (2 * D + 12)
+
+
 def run_mnist(args):
     rank, local_rank, world = dist_env()
     cfg3 = args.workload == "cfg3"
@@ -320,7 +333,10 @@ def run_mnist(args):
     dev = torch.device(f"cuda:{local_rank}")
     eng = MnistStepEngine(M_IND, L, MDIM, N_OBJ, N_train=N_TRAIN, jitter=1e-6, clip_qs=True, geco=True,
                           kappa_squared=0.020, alpha=0.99, beta=0.001, lr=1e-3, b_max=B, device=str(dev),
-                          rank=rank, world_size=world)
+                          rank=rank, world_size=world,
+                          # --force-comm on one GPU: the kernel configuration of a multi-rank step (one statistics block per
+                          # channel) + a 1-rank communicator, i.e. everything of the N > 1 step but the wire
+                          single_stat_block=True if args.force_comm else None)
     eng.load_params(params)
     d_img, d_aux, d_eps = (torch.tensor(x, dtype=torch.float64, device=dev).contiguous() for x in (images, aux, eps))
 
@@ -376,6 +392,21 @@ def run_mnist(args):
     el = float(np.median(blocks))
     sc = eng.scalars()
     assert math.isfinite(sc["elbo"]) and sc["adam_t"] >= args.steps * args.repeats, sc
+    # per-exchange-point microseconds (HIP events around pack + grouped collective + unpack, svgp_comm_timing): a few extra
+    # steps after the timed region, the maximum over ranks of the per-point medians
+    coll_us = None
+    if eng.comm is not None:
+        eng.comm.timing(True)
+        samples = []
+        for _ in range(10):
+            eng.run(adam=True)
+            eng.synchronize()
+            samples.append(eng.comm.timing_read())
+        eng.comm.timing(False)
+        med = torch.tensor(np.median(np.array(samples), 0), dtype=torch.float64, device=dev)
+        if multi:
+            dist.all_reduce(med, op=dist.ReduceOp.MAX)
+        coll_us = [round(float(x), 1) for x in med.cpu()]
     # per-stage HIP-event timings of this rank's launches (rank-local kernels, no collective inside): every rank runs
     # them so that nobody waits on rank 0, rank 0 reports
     stage_rows = time_stages(eng, B, M_IND, reps=20 if cfg3 else 50)
@@ -399,6 +430,7 @@ def run_mnist(args):
             "repeats": args.repeats, "block_ms": [round(x * 1e3, 3) for x in blocks], "timing": "median block",
             "config": {"workload": name, "global_batch": B * world, "rows_per_gpu": B, "launch": launch,
                        "parallelism": f"dp{world}", "rccl_ranks": comm_ranks,
+                       "single_stat_block": int(eng.base["single_stat_block"]),
                        "scaling_note": ("weak: rows per GPU fixed, the global batch (and so c = N_train / b_global of "
                                         "SVGPVAE_model.py:328) grows with N" if args.scaling == "weak" else
                                         "strong: global batch fixed, rows per GPU = global / N")},
@@ -412,12 +444,22 @@ def run_mnist(args):
                                 "stage = one C entry point, HIP events on the launch stream")
         roof["traffic"], roof["traffic_source"] = traffic, src
         line["roofline"] = roof
+        sf = mnist_survey_flops(B, L, M_IND, MDIM + 1)
         line["step_roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": F64_PEAK_TFLOPS,
-                                 "algorithmic_flops": step_flops,
-                                 "achieved": step_flops / (el / args.steps) / 1e12,
-                                 "frac": step_flops / (el / args.steps) / 1e12 / F64_PEAK_TFLOPS}
+                                 "algorithmic_flops": sf,
+                                 "achieved": sf / (el / args.steps) / 1e12,
+                                 "frac": sf / (el / args.steps) / 1e12 / F64_PEAK_TFLOPS,
+                                 "flops_model": "SURVEY 8d / Appendix G (the one figure this file uses for the step)",
+                                 "stage_sum_flops": step_flops}
         line["stages_us"] = {r["stage"]: round(r["us"], 2) for r in stage_rows}
         line["step_flops"] = step_flops
+        if coll_us is not None:
+            names = (["rs[S|v]", "ag[Si|M2|t|u]", "rs[A2|ud|td]", "ag[Ssym|vbar|KL]", "ar[grad|sums]"] if len(coll_us) == 5
+                     else ["ar[S|v]", "ar[A2|ud|td]", "ar[grad|sums]"])
+            line["collectives_us"] = dict(zip(names, coll_us))
+            line["collectives_us_total"] = round(sum(coll_us), 1)
+            line["collectives_note"] = ("HIP events on the compute stream around every exchange point (pack + ONE grouped RCCL "
+                                        "launch + unpack), median of 10 steps, maximum over ranks; compute = ms_per_step - total")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_mnist(cfg3)
         emit(line)
@@ -488,6 +530,20 @@ def run_sprites(args):
         stages[n0] = stages.get(n0, 0.0) + e0.elapsed_time(e1) * 1e3
     sc = eng.scalars()
     assert math.isfinite(sc["elbo"]), sc
+    # per-exchange-point microseconds (events around pack + grouped RCCL launch + unpack), maximum over ranks
+    coll_us = None
+    if comm is not None:
+        samples = []
+        for _ in range(3):
+            eng.exchange_trace = []
+            step()
+            eng.stream.synchronize()
+            samples.append([e0.elapsed_time(e1) * 1e3 for e0, e1 in eng.exchange_trace])
+        eng.exchange_trace = None
+        med = torch.tensor(np.median(np.array(samples), 0), dtype=torch.float64, device=dev)
+        if multi:
+            dist.all_reduce(med, op=dist.ReduceOp.MAX)
+        coll_us = [round(float(x), 1) for x in med.cpu()]
     if rank == 0:
         nets, gp = sprites_flops(b, L_, m)
         ms = el / args.steps * 1e3
@@ -503,8 +559,9 @@ def run_sprites(args):
                        "global_batch": b * world, "rows_per_gpu": b, "parallelism": f"dp{world}",
                        "rccl_ranks": None if comm is None else comm.world_size,
                        "exchange": None if comm is None else (
-                           "channel-sharded: reduce-scatter S,v | all-gather Sigma^-1,M2,t,u,KL | reduce-scatter A2,ud,td | "
-                           "all-gather Qm,Ssym,vbar | all-reduce gradients" if eng.chan_shard else "all-reduce x3"),
+                           "channel-sharded, one grouped RCCL launch per point, symmetric blocks tile-packed: reduce-scatter "
+                           "S,v | all-gather Sigma^-1,M2,t,u | reduce-scatter A2,ud,td | all-gather Ssym,vbar,KL | all-reduce "
+                           "gradients" if eng.chan_shard else "all-reduce x3"),
                        "launch": "eager stream" + ("" if comm is None else " + in-library RCCL collectives")},
         }
         peak = F64_PEAK_TFLOPS          # the dominant stage groups are the float64 GP factor stages in both precisions
@@ -514,14 +571,29 @@ def run_sprites(args):
               "nets_" + ("fwd" if "fwd" in top else "bwd")
         grp_us = sum(v for k, v in stages.items() if (k.startswith("gp") == grp.startswith("gp")) and
                      (("fwd" in k) == ("fwd" in grp)))
-        line["roofline"] = roofline_of(gflops[grp], 1.0, grp_us, peak, kernel=grp,
+        # algorithmic bytes of a stage group: every (L,m,m) float64 intermediate of the group written once and read once (forward
+        # S, Sigma^-1, G, A_hat, M2, (A_hat + jI)^-1; reverse: twice as many), the (L,b,m) row products likewise, the networks'
+        # activations once each way -- 70 flop per byte for the GP groups at m = 800, far on the MFMA side of the ridge
+        blk, rowp = 8.0 * L_ * m * m, 8.0 * L_ * b * m
+        act = (4.0 if f32 else 8.0) * b * 64 * 64 * (3 + 7 * 16 + 5 * 16 / 4 + 3 * 16 / 16)     # rough: 64^2 layers dominate
+        gbytes = {"gp_fwd": 2 * 6 * blk + 2 * 2 * rowp, "gp_bwd": 2 * 12 * blk + 2 * 2 * rowp, "nets_fwd": 2 * act,
+                  "nets_bwd": 4 * act}
+        line["roofline"] = roofline_of(gflops[grp], gbytes[grp], grp_us, peak, kernel=grp,
                                        note="stage group = the launches between two HIP events on the engine stream; "
-                                            "algorithmic flops of SURVEY 8d split 1/3 forward, 2/3 reverse")
+                                            "algorithmic flops of SURVEY 8d split 1/3 forward, 2/3 reverse; bytes: every "
+                                            "intermediate of the group written once and read once")
+        traffic, src = committed_traffic("sprites800_" + grp)
+        line["roofline"]["traffic"], line["roofline"]["traffic_source"] = traffic, src
         line["step_roofline"] = {"bound": "mfma", "unit": "TFLOP/s", "peak": peak, "algorithmic_flops": nets + gp,
                                  "achieved": (nets + gp) / (ms * 1e-3) / 1e12,
                                  "frac": (nets + gp) / (ms * 1e-3) / 1e12 / peak,
                                  "frac_of_f32_peak": (nets + gp) / (ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS}
         line["stages_us"] = {k: round(v, 1) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
+        if coll_us is not None:
+            names = (["rs[S|v]", "ag[Si|M2|t|u]", "rs[A2|ud|td]", "ag[Ssym|vbar|KL]", "ar[grad|sums]"] if len(coll_us) == 5
+                     else ["ar[S|v]", "ar[A2|ud|td]", "ar[grad|sums]"])
+            line["collectives_us"] = dict(zip(names, coll_us))
+            line["collectives_us_total"] = round(sum(coll_us), 1)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_sprites(gpu_elbo, m)
             line["elbo_rel_err_gpu_vs_oracle"] = line["cpu_baseline"].pop("elbo_rel_err_gpu_vs_oracle")

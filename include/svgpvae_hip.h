@@ -136,6 +136,9 @@ typedef struct {
     /* Titsias branch (cfg.titsias; zero-sized otherwise): statistics with weights 1/(var + jitter) inside statA,
      * (K + jI + S2)^-1, its product with v2, scalars [logdet (L) | v2.t2 (L) | row sum (1)] */
     int64_t tit_S2, tit_v2, tit_Si, tit_t, tit_scal;
+    /* m > 64: two tile-packed buffers of L symmetric matrices each (svgp_sym_pack): what the channel-sharded exchange
+     * moves instead of the full (L,m,m) blocks.  xpack_len = 2 * L * svgp_sym_packed_elems(m) (0 for m <= 64).        */
+    int64_t xpack, xpack_len;
     int64_t total;                        /* workspace size in float64 elements                   */
 } svgp_mnist_ws_layout;
 
@@ -333,9 +336,37 @@ int svgp_allgather_f64(void* comm, double* buf, int64_t count_per_rank, void* st
  * call; with l0 = 0, nl = L they are svgp_gp_factor_fwd / svgp_gp_factor_bwd                                            */
 int svgp_gp_factor_fwd_channels(const svgp_mnist_cfg*, int l0, int nl, double* ws, void* stream);
 int svgp_gp_factor_bwd_channels(const svgp_mnist_cfg*, int l0, int nl, double* ws, const double* state, void* stream);
+/* ... and their parts, the split of the two-stream step on a channel window: forward part 0 = the whole stage, 1 = without
+ * the (A_hat + jI)^-1 tail (svgp_gp_factor_fwd_defer_aji), 2 = the tail (svgp_gp_factor_fwd_aji_tail); reverse part 0 = the
+ * whole stage, 1 = early half, 2 = late half, 3 / 4 = the two parts of the early half (svgp_gp_factor_bwd_early_a / _b).  */
+int svgp_gp_factor_fwd_channels_part(const svgp_mnist_cfg*, int l0, int nl, int part, double* ws, void* stream);
+int svgp_gp_factor_bwd_channels_part(const svgp_mnist_cfg*, int l0, int nl, int part, double* ws, const double* state,
+                                     void* stream);
+/* svgp_mnist_train_step_dp, channel-sharded form (m > 64, L divisible by the rank count): five exchange POINTS, each ONE
+ * grouped RCCL launch (ncclGroupStart / End): [S | v] reduce-scatter, [Sigma^-1 | M2 | t | u] all-gather, [A2 | ud | td]
+ * reduce-scatter, [Ssym | vbar | KL] all-gather, gradient all-reduce.  The (L,m,m) members are symmetric and travel
+ * TILE-PACKED (svgp_sym_pack: lower triangle in 32 x 32 tiles, 52 % of the square at m = 800; SURVEY 8e "halve via
+ * symmetry") with SVGP_DP_PACK=1, off with 0; default: from m >= 512.  The tail of the forward factor stage and the early half of the
+ * reverse one run on the library's side stream beside the all-gather, the row stage, the networks and the reverse
+ * statistics (as in the single-GPU step; SVGP_SIDE_STREAMS=0 puts them in line).                                      */
 int svgp_mnist_train_step_dp(const svgp_mnist_cfg*, void* comm, double* theta, const double* images,
                              const double* aux, const double* eps, double* ws, double* state,
                              double* adam_m, double* adam_v, void* stream);
+/* Several collectives as one RCCL launch: everything issued on `comm` between _begin and _end (ncclGroupStart / End). */
+int svgp_comm_group_begin(void* comm);
+int svgp_comm_group_end(void* comm);
+/* HIP events around every exchange point of svgp_mnist_train_step_dp (pack + collective(s) + unpack): enable != 0 switches
+ * the recording on; svgp_comm_timing_read waits for the last recorded step and returns the microseconds of its points
+ * (n <= cap of them, in step order).  bench.py --gpus N reports them as `collectives_us`.                              */
+int svgp_comm_timing(void* comm, int enable);
+int svgp_comm_timing_read(void* comm, float* us, int cap, int* n);
+/* Tile-packed lower triangle of L symmetric m x m matrices: per matrix the nt (nt + 1) / 2 tiles (ti >= tj) of 32 x 32,
+ * nt = ceil(m / 32), tile t = ti (ti + 1) / 2 + tj stored row-major (rows / columns >= m are zero).  avg != 0: the tile
+ * holds (x_ij + x_ji) / 2 (for products that are symmetric only up to rounding, M2 = Ki A Ki); else x_ij of the lower
+ * tiles.  svgp_sym_unpack writes both triangles of the square matrices.  src / dst strides: m * m and packed_elems.   */
+int64_t svgp_sym_packed_elems(int m);
+int svgp_sym_pack(int m, int L, int avg, const double* src, double* dst, void* stream);
+int svgp_sym_unpack(int m, int L, const double* src, double* dst, void* stream);
 
 /* ---- full-data statistics in float32, streamed over N (8f rank 1) -----------------
  * replace precompute_GP_params_SVGPVAE's K_nm build and its per-channel

@@ -42,7 +42,7 @@ WS_FIELDS = ("enc_a1", "enc_a2", "enc_a3", "qnet_mu", "qnet_var_raw", "qnet_var"
              "Knbar", "knnbar", "ybar", "s2bar", "d_on",
              "part_dec", "part_enc", "n_part", "part_gp", "part_sums", "n_post",
              "gradC", "gradC_len", "grad", "sums",
-             "tit_S2", "tit_v2", "tit_Si", "tit_t", "tit_scal", "total")
+             "tit_S2", "tit_v2", "tit_Si", "tit_t", "tit_scal", "xpack", "xpack_len", "total")
 
 
 class WsLayout(C.Structure):
@@ -127,7 +127,15 @@ SIGNATURES = {
     "svgp_allgather_f64": [_P, _P, C.c_int64, _P],
     "svgp_gp_factor_fwd_channels": [_CFG, C.c_int, C.c_int, _P, _P],
     "svgp_gp_factor_bwd_channels": [_CFG, C.c_int, C.c_int, _P, _P, _P],
+    "svgp_gp_factor_fwd_channels_part": [_CFG, C.c_int, C.c_int, C.c_int, _P, _P],
+    "svgp_gp_factor_bwd_channels_part": [_CFG, C.c_int, C.c_int, C.c_int, _P, _P, _P],
     "svgp_mnist_train_step_dp": [_CFG, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "svgp_comm_group_begin": [_P],
+    "svgp_comm_group_end": [_P],
+    "svgp_comm_timing": [_P, C.c_int],
+    "svgp_comm_timing_read": [_P, _P, C.c_int, C.POINTER(C.c_int)],
+    "svgp_sym_pack": [C.c_int, C.c_int, C.c_int, _P, _P, _P],
+    "svgp_sym_unpack": [C.c_int, C.c_int, _P, _P, _P],
     "svgp_dgemm_batched": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.c_int, C.c_longlong, _P,
                            C.c_int, C.c_longlong, C.c_double, _P, C.c_int, C.c_longlong, C.c_int, _P],
     "svgp_dgemm_f32c_batched": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.c_int, C.c_longlong, _P,
@@ -212,6 +220,7 @@ class StreamKdesc(C.Structure):
 NON_STATUS = {"svgp_version": ([], C.c_int), "svgp_last_error": ([], C.c_char_p),
               "svgp_struct_sizeof": ([C.c_int], C.c_int),
               "svgp_comm_unique_id_bytes": ([], C.c_int),
+              "svgp_sym_packed_elems": ([C.c_int], C.c_int64),
               "svgp_stream_feature_elems": ([C.c_void_p, C.c_int64], C.c_int64),
               "svgp_stream_stats_workspace_elems": ([C.c_int64, C.c_int, C.c_int], C.c_int64),
               "svgp_spd_inverse_workspace_elems": ([C.c_int, C.c_int], C.c_size_t),

@@ -129,6 +129,8 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->gradC = p; o->grad = p; p += pl.n_total; o->sums = p; p += 8; o->gradC_len = p - o->gradC; take(0);
     o->tit_Si = take(c->titsias ? L * m * m : 0); o->tit_t = take(c->titsias ? L * m : 0);
     o->tit_scal = take(c->titsias ? 2 * L + 1 : 0);
+    o->xpack_len = m > SVGP_M_MAX ? 2 * L * svgp_sym_packed_elems((int)m) : 0;
+    o->xpack = take(o->xpack_len);
     o->total = p;
     return SVGP_OK;
 }
@@ -196,6 +198,26 @@ int side_join(Side* sd, int k, hipStream_t main) {
 void side_mark_early(Side* sd, const void* ws) { std::lock_guard<std::mutex> lk(sd->mu); sd->early_ws.insert(ws); }
 bool side_take_early(Side* sd, const void* ws) { std::lock_guard<std::mutex> lk(sd->mu); return sd->early_ws.erase(ws) > 0; }
 
+}  // namespace
+
+// comm.hip (channel-sharded step): the side branch of the caller's stream
+int svgp_side_branch_fork(void* main_stream, void** side_stream_out) {
+    Side* sd = nullptr;
+    int rc = side_get((hipStream_t)main_stream, &sd);
+    if (rc) return rc;
+    rc = side_fork(sd, 1, (hipStream_t)main_stream);
+    if (rc) return rc;
+    *side_stream_out = (void*)sd->s[1];
+    return SVGP_OK;
+}
+int svgp_side_branch_join(void* main_stream) {
+    Side* sd = nullptr;
+    int rc = side_get((hipStream_t)main_stream, &sd);
+    if (rc) return rc;
+    return side_join(sd, 1, (hipStream_t)main_stream);
+}
+
+namespace {
 // `defer`: the caller issues all four phases back to back on one stream (svgp_mnist_train_step), so a
 // branch forked in one phase may be joined in a later one; otherwise every phase joins before returning
 // (each phase may be captured into its own graph, with a collective in between).

@@ -23,6 +23,8 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
 };
@@ -47,6 +49,8 @@ int rccl_get(Rccl** out) {
         SYM(AllReduce, "ncclAllReduce");
         SYM(ReduceScatter, "ncclReduceScatter");
         SYM(AllGather, "ncclAllGather");
+        SYM(GroupStart, "ncclGroupStart");
+        SYM(GroupEnd, "ncclGroupEnd");
         SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
         g_rccl.ok = true;
@@ -64,10 +68,74 @@ int rccl_get(Rccl** out) {
         }                                                                                          \
     } while (0)
 
+#define SVGP_COMM_MAX_POINTS 8
 struct Comm {
     ncclComm_t comm;
     int rank, nranks;
+    // optional per-exchange-point timing of svgp_mnist_train_step_dp (svgp_comm_timing)
+    bool timing = false;
+    int npoints = 0;
+    hipEvent_t ev[2 * SVGP_COMM_MAX_POINTS] = {};
 };
+
+// ---- tile-packed symmetric matrices (include/svgpvae_hip.h svgp_sym_pack)
+#define SP_T 32
+__device__ __forceinline__ void sym_tile_of(int t, int& ti, int& tj) {
+    ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (ti * (ti + 1) / 2 > t) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    tj = t - ti * (ti + 1) / 2;
+}
+__global__ __launch_bounds__(256) void k_sym_pack(int m, int avg, long long pe, const double* __restrict__ src,
+                                                  double* __restrict__ dst) {
+    __shared__ double tr[SP_T][SP_T + 1];
+    int ti, tj;
+    sym_tile_of((int)blockIdx.x, ti, tj);
+    const double* X = src + (size_t)blockIdx.y * m * m;
+    double* P = dst + (size_t)blockIdx.y * pe + (size_t)blockIdx.x * SP_T * SP_T;
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+    if (avg && ti != tj) {                       // the mirrored tile (tj, ti), transposed through LDS
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = r0 + 8 * k, gi = tj * SP_T + r, gj = ti * SP_T + c;
+            tr[r][c] = (gi < m && gj < m) ? X[(size_t)gi * m + gj] : 0.0;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + 8 * k, gi = ti * SP_T + r, gj = tj * SP_T + c;
+        double v = (gi < m && gj < m) ? X[(size_t)gi * m + gj] : 0.0;
+        if (avg) {
+            const double w = ti != tj ? tr[c][r] : ((gi < m && gj < m) ? X[(size_t)gj * m + gi] : 0.0);
+            v = 0.5 * (v + w);
+        }
+        P[r * SP_T + c] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_sym_unpack(int m, long long pe, const double* __restrict__ src,
+                                                    double* __restrict__ dst) {
+    __shared__ double tr[SP_T][SP_T + 1];
+    int ti, tj;
+    sym_tile_of((int)blockIdx.x, ti, tj);
+    const double* P = src + (size_t)blockIdx.y * pe + (size_t)blockIdx.x * SP_T * SP_T;
+    double* X = dst + (size_t)blockIdx.y * m * m;
+    const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + 8 * k, gi = ti * SP_T + r, gj = tj * SP_T + c;
+        const double v = P[r * SP_T + c];
+        tr[r][c] = v;
+        // diagonal tiles: the lower part is written here, the upper part below from the transposed read
+        if (gi < m && gj < m && (ti != tj || c <= r)) X[(size_t)gi * m + gj] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + 8 * k, gi = tj * SP_T + r, gj = ti * SP_T + c;      // element (r, c) of the mirrored tile
+        if (gi < m && gj < m && (ti != tj || c > r)) X[(size_t)gi * m + gj] = tr[c][r];
+    }
+}
 
 }  // namespace
 
@@ -163,6 +231,70 @@ extern "C" int svgp_allgather_f64(void* comm, double* buf, int64_t count_per_ran
     return SVGP_OK;
 }
 
+extern "C" int64_t svgp_sym_packed_elems(int m) {
+    if (m < 1) return 0;
+    const int64_t nt = (m + SP_T - 1) / SP_T;
+    return nt * (nt + 1) / 2 * SP_T * SP_T;
+}
+extern "C" int svgp_sym_pack(int m, int L, int avg, const double* src, double* dst, void* stream) {
+    SVGP_REQUIRE(m >= 1 && L >= 0 && src && dst, SVGP_ERR_INVALID, "bad argument");
+    if (L == 0) return SVGP_OK;
+    const int nt = (m + SP_T - 1) / SP_T;
+    hipLaunchKernelGGL(k_sym_pack, dim3(nt * (nt + 1) / 2, L), dim3(256), 0, (hipStream_t)stream, m, avg,
+                       (long long)svgp_sym_packed_elems(m), src, dst);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_sym_unpack(int m, int L, const double* src, double* dst, void* stream) {
+    SVGP_REQUIRE(m >= 1 && L >= 0 && src && dst, SVGP_ERR_INVALID, "bad argument");
+    if (L == 0) return SVGP_OK;
+    const int nt = (m + SP_T - 1) / SP_T;
+    hipLaunchKernelGGL(k_sym_unpack, dim3(nt * (nt + 1) / 2, L), dim3(256), 0, (hipStream_t)stream, m,
+                       (long long)svgp_sym_packed_elems(m), src, dst);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+
+extern "C" int svgp_comm_group_begin(void* comm) {
+    SVGP_REQUIRE(comm, SVGP_ERR_INVALID, "NULL communicator");
+    Rccl* r;
+    int rc = rccl_get(&r);
+    if (rc) return rc;
+    SVGP_CHECK_RCCL(r, r->GroupStart());
+    return SVGP_OK;
+}
+extern "C" int svgp_comm_group_end(void* comm) {
+    SVGP_REQUIRE(comm, SVGP_ERR_INVALID, "NULL communicator");
+    Rccl* r;
+    int rc = rccl_get(&r);
+    if (rc) return rc;
+    SVGP_CHECK_RCCL(r, r->GroupEnd());
+    return SVGP_OK;
+}
+
+extern "C" int svgp_comm_timing(void* comm, int enable) {
+    SVGP_REQUIRE(comm, SVGP_ERR_INVALID, "NULL communicator");
+    Comm* c = (Comm*)comm;
+    if (enable && !c->ev[0])
+        for (int k = 0; k < 2 * SVGP_COMM_MAX_POINTS; ++k) SVGP_CHECK_HIP(hipEventCreate(&c->ev[k]));
+    c->timing = enable != 0;
+    c->npoints = 0;
+    return SVGP_OK;
+}
+extern "C" int svgp_comm_timing_read(void* comm, float* us, int cap, int* n) {
+    SVGP_REQUIRE(comm && us && n && cap >= 0, SVGP_ERR_INVALID, "bad argument");
+    Comm* c = (Comm*)comm;
+    *n = 0;
+    for (int k = 0; k < c->npoints && k < cap; ++k) {
+        float ms = 0;
+        SVGP_CHECK_HIP(hipEventSynchronize(c->ev[2 * k + 1]));
+        SVGP_CHECK_HIP(hipEventElapsedTime(&ms, c->ev[2 * k], c->ev[2 * k + 1]));
+        us[k] = ms * 1000.0f;
+        *n = k + 1;
+    }
+    return SVGP_OK;
+}
+
 // One data-parallel step, everything enqueued on `stream`:
 //   phase 0 | all-reduce statA | phase 1 | all-reduce statB | phase 2 | all-reduce gradC | phase 3
 // c->b is this rank's row count, c->b_global the global batch, c->rep_weight 1 on exactly one rank.
@@ -181,6 +313,25 @@ int rs(void* comm, double* p, int64_t total, int nranks, void* stream) {
     return svgp_reduce_scatter_sum_f64(comm, p, total / nranks, stream);
 }
 int ag(void* comm, double* p, int64_t total, int nranks, void* stream) { return svgp_allgather_f64(comm, p, total / nranks, stream); }
+// exchange-point bracket: optional events + one RCCL group
+struct Point {
+    Comm* cm; hipStream_t st; int idx;
+    int begin() {
+        idx = -1;
+        if (cm->timing && cm->npoints < SVGP_COMM_MAX_POINTS) {
+            idx = cm->npoints++;
+            SVGP_CHECK_HIP(hipEventRecord(cm->ev[2 * idx], st));
+        }
+        return SVGP_OK;
+    }
+    int end() {
+        if (idx >= 0) SVGP_CHECK_HIP(hipEventRecord(cm->ev[2 * idx + 1], st));
+        return SVGP_OK;
+    }
+};
+// (measured with a 1-rank communicator at m = 256, L = 16: the pack / unpack launches cost ~100 us per step, the 44 % of 8.4 MB
+// they take off each of the four points is worth ~15 us apiece on xGMI; at m = 800, L = 64 a point is 328 MB)
+bool dp_pack_default(int m) { return m >= 512; }
 }  // namespace
 
 extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, double* theta, const double* images,
@@ -190,17 +341,20 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     svgp_mnist_ws_layout wl;
     int rc = svgp_mnist_ws_layout_get(c, &wl);
     if (rc) return rc;
-    const Comm* cm = (const Comm*)comm;
+    Comm* cm = (Comm*)comm;
     const int G = cm->nranks, L = c->L, m = c->m;
     const bool sharded = m > SVGP_M_MAX && L % G == 0 && !c->titsias && !c->kl_form;
+    Point pt{cm, (hipStream_t)stream, -1};
+    if (cm->timing) cm->npoints = 0;
+#define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
     if (!sharded) {
         const int64_t off[3] = {wl.statA, wl.statB, wl.gradC}, len[3] = {wl.statA_len, wl.statB_len, wl.gradC_len};
         for (int ph = 0; ph < 4; ++ph) {
-            rc = svgp_mnist_step_phase_deferred(c, ph, theta, images, aux, eps, ws, state, adam_m, adam_v, stream);
-            if (rc) return rc;
+            RUN(svgp_mnist_step_phase_deferred(c, ph, theta, images, aux, eps, ws, state, adam_m, adam_v, stream));
             if (ph < 3) {
-                rc = svgp_allreduce_sum_f64(comm, ws + off[ph], len[ph], stream);
-                if (rc) return rc;
+                RUN(pt.begin());
+                RUN(svgp_allreduce_sum_f64(comm, ws + off[ph], len[ph], stream));
+                RUN(pt.end());
             }
         }
         return SVGP_OK;
@@ -210,32 +364,99 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     cc.rep_weight = 1.0;                         // Kbar = this rank's channel-window share: every share counts
     const int nl = L / G, l0 = cm->rank * nl;
     const int64_t mm = (int64_t)m * m, Lmm = (int64_t)L * mm, Lm = (int64_t)L * m;
-#define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
+    const char* ev_pack = getenv("SVGP_DP_PACK");
+    const bool pack = ev_pack ? ev_pack[0] != '0' : dp_pack_default(m);
+    const char* ev_side = getenv("SVGP_SIDE_STREAMS");
+    const bool fork = !(ev_side && ev_side[0] == '0');
+    const int64_t pe = svgp_sym_packed_elems(m);
+    double *xp0 = ws + wl.xpack, *xp1 = xp0 + (size_t)L * pe;
+    // a symmetric (L,m,m) block on the wire: the tile-packed buffer (all channels / the rank's window) or the block itself
+    auto rs_sym = [&](double* blk, double* xp) -> int {        // (inside a group)
+        return pack ? rs(comm, xp, L * pe, G, stream) : rs(comm, blk, Lmm, G, stream);
+    };
+    auto ag_sym = [&](double* blk, double* xp) -> int {
+        return pack ? ag(comm, xp, L * pe, G, stream) : ag(comm, blk, Lmm, G, stream);
+    };
     RUN(svgp_mnist_encoder_kernel_matrix_fwd(&cc, theta, images, aux, ws, stream));
     RUN(svgp_gp_stats_fwd(&cc, ws, stream));
-    RUN(rs(comm, ws + wl.S, Lmm, G, stream));
+    // ---- point 1: reduce-scatter [S | v] over the channels
+    RUN(pt.begin());
+    if (pack) RUN(svgp_sym_pack(m, L, 0, ws + wl.S, xp0, stream));
+    RUN(svgp_comm_group_begin(comm));
+    RUN(rs_sym(ws + wl.S, xp0));
     RUN(rs(comm, ws + wl.v, Lm, G, stream));
-    RUN(svgp_gp_factor_fwd_channels(&cc, l0, nl, ws, stream));
-    RUN(ag(comm, ws + wl.Si, Lmm, G, stream));
-    RUN(ag(comm, ws + wl.M2, Lmm, G, stream));
+    RUN(svgp_comm_group_end(comm));
+    if (pack) RUN(svgp_sym_unpack(m, nl, xp0 + (size_t)l0 * pe, ws + wl.S + (size_t)l0 * mm, stream));
+    RUN(pt.end());
+    // window factor stage without its tail
+    RUN(svgp_big_factor_fwd(&cc, wl, ws, stream, l0, nl, 1));
+    // ---- point 2: all-gather [Sigma^-1 | M2 | t | u]
+    RUN(pt.begin());
+    if (pack) {
+        // the window goes to the wire format AND back first (M2 = Ki A Ki is symmetric only up to rounding: afterwards every
+        // rank holds bit-identical blocks), so that the side branch below never reads a block that is still being rewritten
+        RUN(svgp_sym_pack(m, nl, 0, ws + wl.Si + (size_t)l0 * mm, xp0 + (size_t)l0 * pe, stream));
+        RUN(svgp_sym_pack(m, nl, 1, ws + wl.M2 + (size_t)l0 * mm, xp1 + (size_t)l0 * pe, stream));
+        RUN(svgp_sym_unpack(m, nl, xp1 + (size_t)l0 * pe, ws + wl.M2 + (size_t)l0 * mm, stream));
+    }
+    // the tail ((A_hat + jI)^-1, log det, KL) and the early half of the reverse factor stage: on the side branch, beside the
+    // all-gather, the row stage, the networks and the reverse statistics
+    void* side = stream;
+    if (fork) RUN(svgp_side_branch_fork(stream, &side));
+    RUN(svgp_big_factor_fwd(&cc, wl, ws, side, l0, nl, 2));
+    if (fork) RUN(svgp_big_factor_bwd(&cc, wl, ws, state, side, l0, nl, 1));
+    RUN(svgp_comm_group_begin(comm));
+    RUN(ag_sym(ws + wl.Si, xp0));
+    RUN(ag_sym(ws + wl.M2, xp1));
     RUN(ag(comm, ws + wl.t, Lm, G, stream));
     RUN(ag(comm, ws + wl.u, Lm, G, stream));
-    RUN(ag(comm, ws + wl.KL, L, G, stream));
+    RUN(svgp_comm_group_end(comm));
+    if (pack) {                                  // the other ranks' windows
+        const int hi0 = l0 + nl, nhi = L - hi0;
+        RUN(svgp_sym_unpack(m, l0, xp0, ws + wl.Si, stream));
+        RUN(svgp_sym_unpack(m, nhi, xp0 + (size_t)hi0 * pe, ws + wl.Si + (size_t)hi0 * mm, stream));
+        RUN(svgp_sym_unpack(m, l0, xp1, ws + wl.M2, stream));
+        RUN(svgp_sym_unpack(m, nhi, xp1 + (size_t)hi0 * pe, ws + wl.M2 + (size_t)hi0 * mm, stream));
+    }
+    RUN(pt.end());
     RUN(svgp_gp_posterior_fwd(&cc, eps, ws, state, stream));
     RUN(svgp_mnist_decoder_fwd(&cc, theta, images, ws, stream));
     RUN(svgp_mnist_decoder_bwd(&cc, theta, images, ws, state, stream));
     RUN(svgp_gp_stats_bwd(&cc, ws, state, stream));
-    RUN(rs(comm, ws + wl.A2, Lmm, G, stream));
+    // ---- point 3: reduce-scatter [A2 | ud | td]
+    RUN(pt.begin());
+    if (pack) RUN(svgp_sym_pack(m, L, 0, ws + wl.A2, xp0, stream));
+    RUN(svgp_comm_group_begin(comm));
+    RUN(rs_sym(ws + wl.A2, xp0));
     RUN(rs(comm, ws + wl.ud, Lm, G, stream));
     RUN(rs(comm, ws + wl.td, Lm, G, stream));
-    RUN(svgp_gp_factor_bwd_channels(&cc, l0, nl, ws, state, stream));
-    RUN(ag(comm, ws + wl.Ssym, Lmm, G, stream));
+    RUN(svgp_comm_group_end(comm));
+    if (pack) RUN(svgp_sym_unpack(m, nl, xp0 + (size_t)l0 * pe, ws + wl.A2 + (size_t)l0 * mm, stream));
+    RUN(pt.end());
+    if (fork) {
+        RUN(svgp_side_branch_join(stream));
+        RUN(svgp_big_factor_bwd(&cc, wl, ws, state, stream, l0, nl, 2));
+    } else {
+        RUN(svgp_big_factor_bwd(&cc, wl, ws, state, stream, l0, nl, 0));
+    }
+    // ---- point 4: all-gather [Ssym | vbar | KL]  (Kn Q is formed from Kn Ssym and the forward pass's Kn M2: Q is not exchanged)
+    RUN(pt.begin());
+    if (pack) RUN(svgp_sym_pack(m, nl, 0, ws + wl.Ssym + (size_t)l0 * mm, xp0 + (size_t)l0 * pe, stream));
+    RUN(svgp_comm_group_begin(comm));
+    RUN(ag_sym(ws + wl.Ssym, xp0));
     RUN(ag(comm, ws + wl.vbar, Lm, G, stream));
+    RUN(ag(comm, ws + wl.KL, L, G, stream));
+    RUN(svgp_comm_group_end(comm));
+    if (pack) RUN(svgp_sym_unpack(m, L, xp0, ws + wl.Ssym, stream));
+    RUN(pt.end());
     RUN(svgp_gp_posterior_bwd(&cc, ws, state, stream));
     RUN(svgp_kernel_matrix_bwd_partials(&cc, theta, aux, ws, stream));
     RUN(svgp_mnist_encoder_bwd(&cc, theta, images, ws, stream));
     RUN(svgp_mnist_grad_reduce_all(&cc, aux, ws, stream));
+    // ---- point 5: gradients + scalar sums
+    RUN(pt.begin());
     RUN(svgp_allreduce_sum_f64(comm, ws + wl.gradC, wl.gradC_len, stream));
+    RUN(pt.end());
     RUN(svgp_mnist_step_phase_deferred(&cc, 3, theta, images, aux, eps, ws, state, adam_m, adam_v, stream));
 #undef RUN
     return SVGP_OK;

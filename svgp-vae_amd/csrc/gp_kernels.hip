@@ -1356,6 +1356,27 @@ extern "C" int svgp_gp_factor_bwd_channels(const svgp_mnist_cfg* c, int l0, int 
     return svgp_big_factor_bwd(c, wl, ws, state, stream, l0, nl);
 }
 
+// ... and their parts (the split of the two-stream step on a window): forward part 0 = whole stage, 1 = without the
+// (A_hat + jI)^-1 tail, 2 = the tail; reverse part 0 = whole stage, 1 = early half, 2 = late half, 3 / 4 = the two parts of the
+// early half (svgp_gp_factor_bwd_early_a / _b)
+extern "C" int svgp_gp_factor_fwd_channels_part(const svgp_mnist_cfg* c, int l0, int nl, int part, double* ws, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "channel windows exist for the large-m path (m > %d)", SVGP_M_MAX);
+    SVGP_REQUIRE(l0 >= 0 && nl >= 1 && l0 + nl <= c->L, SVGP_ERR_INVALID, "channel window [%d, %d) outside 0..%d", l0, l0 + nl, c->L);
+    SVGP_REQUIRE(part >= 0 && part <= 2, SVGP_ERR_INVALID, "forward part %d (0, 1 or 2)", part);
+    return svgp_big_factor_fwd(c, wl, ws, stream, l0, nl, part);
+}
+extern "C" int svgp_gp_factor_bwd_channels_part(const svgp_mnist_cfg* c, int l0, int nl, int part, double* ws,
+                                                const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "channel windows exist for the large-m path (m > %d)", SVGP_M_MAX);
+    SVGP_REQUIRE(l0 >= 0 && nl >= 1 && l0 + nl <= c->L, SVGP_ERR_INVALID, "channel window [%d, %d) outside 0..%d", l0, l0 + nl, c->L);
+    SVGP_REQUIRE(part >= 0 && part <= 4, SVGP_ERR_INVALID, "reverse part %d (0..4)", part);
+    return svgp_big_factor_bwd(c, wl, ws, state, stream, l0, nl, part);
+}
+
 static int factor_fwd_impl(const svgp_mnist_cfg* c, double* ws, int defer_aji, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");

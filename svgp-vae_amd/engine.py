@@ -7,6 +7,7 @@ Counterpart of the reference's graph construction + `sess.run([optim_step, ...])
 torch.distributed only; every kernel is in libsvgpvae_hip.so.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -103,12 +104,35 @@ class ExchangeOp:
       reduce_scatter : the tensor is `world` equal chunks, rank r ends with the SUM of chunk r in its chunk r (the other
                        chunks are then unspecified);
       allgather      : rank r contributes its chunk r, every rank ends with all chunks.
-    In-place semantics of ncclAllReduce / ncclReduceScatter / ncclAllGather (svgp_comm_*)."""
-    __slots__ = ("kind", "tensor")
+    In-place semantics of ncclAllReduce / ncclReduceScatter / ncclAllGather (svgp_comm_*).
 
-    def __init__(self, kind, tensor):
+    sym = SymBlock(...): the tensor is (L, m, m) SYMMETRIC matrices that travel tile-packed (svgp_sym_pack: 52 % of the
+    bytes at m = 800).  What the exchange then DEFINES, whatever executes it: reduce_scatter -- chunk r = the lower triangle
+    of the sum, mirrored; allgather -- every channel (the rank's own too) = the symmetrised block of its owner, lower
+    triangle mirrored, or (X + X^T) / 2 with sym.avg (M2 = Ki A Ki is symmetric only up to rounding; the plain mirror would
+    break the Ki E form of its rounding error)."""
+    __slots__ = ("kind", "tensor", "sym")
+
+    def __init__(self, kind, tensor, sym=None):
         assert kind in ("allreduce", "reduce_scatter", "allgather") and tensor.is_contiguous()
-        self.kind, self.tensor = kind, tensor
+        assert sym is None or kind != "allreduce"
+        self.kind, self.tensor, self.sym = kind, tensor, sym
+
+
+class SymBlock:
+    """Packing description of an (L, m, m) symmetric exchange block: xp = its tile-packed buffer (L * svgp_sym_packed_elems(m)
+    doubles of the workspace's xpack region), avg = symmetrise by averaging, prepacked = the caller has already written the
+    rank's window to xp (and, with avg, the symmetrised window back to the tensor) before forking work that reads it."""
+    __slots__ = ("m", "L", "avg", "xp", "prepacked")
+
+    def __init__(self, m, L, avg=False, xp=None, prepacked=False):
+        self.m, self.L, self.avg, self.xp, self.prepacked = m, L, avg, xp, prepacked
+
+
+def _symmetrise(x, m, avg):
+    """(n, m, m) view of flat x -> the block as it comes out of svgp_sym_pack + svgp_sym_unpack."""
+    X = x.view(-1, m, m)
+    return (0.5 * (X + X.transpose(1, 2))) if avg else (torch.tril(X) + torch.tril(X, -1).transpose(1, 2))
 
 
 def virtual_exchange(ops_per_rank):
@@ -126,13 +150,18 @@ def virtual_exchange(ops_per_rank):
         n = ops[0].tensor.numel()
         assert n % G == 0
         c = n // G
+        sym = ops[0].sym
         if kind == "reduce_scatter":
             sums = [sum(o.tensor[r * c:(r + 1) * c] for o in ops) for r in range(G)]
+            if sym is not None:
+                sums = [_symmetrise(t, sym.m, False).reshape(-1) for t in sums]
             for r, o in enumerate(ops):
                 o.tensor.fill_(float("nan"))                 # the other chunks are unspecified: poison them
                 o.tensor[r * c:(r + 1) * c].copy_(sums[r])
         else:
             chunks = [ops[r].tensor[r * c:(r + 1) * c].clone() for r in range(G)]
+            if sym is not None:
+                chunks = [_symmetrise(t, sym.m, sym.avg).reshape(-1) for t in chunks]
             for o in ops:
                 for r in range(G):
                     o.tensor[r * c:(r + 1) * c].copy_(chunks[r])
@@ -152,8 +181,10 @@ def dist_exchange(ops, group=None):
                 out = torch.empty_like(chunks[r])
                 dist.reduce_scatter(out, [ch.clone() for ch in chunks], op=dist.ReduceOp.SUM, group=group) \
                     if dist.get_backend(group) != "gloo" else _gloo_reduce_scatter(out, chunks, r, group)
-                chunks[r].copy_(out)
+                chunks[r].copy_(_symmetrise(out, o.sym.m, False).reshape(-1) if o.sym is not None else out)
             else:
+                if o.sym is not None:
+                    chunks[r].copy_(_symmetrise(chunks[r].clone(), o.sym.m, o.sym.avg).reshape(-1))
                 dist.all_gather([ch for ch in chunks], chunks[r].clone(), group=group)
 
 
@@ -165,6 +196,14 @@ def _gloo_reduce_scatter(out, chunks, r, group):
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         if i == r:
             out.copy_(t)
+
+
+def dp_pack_enabled(m):
+    """Whether the channel-sharded exchange moves its (L,m,m) blocks tile-packed: SVGP_DP_PACK=0/1, default from m >= 512
+    (the rule of svgp_mnist_train_step_dp)."""
+    import os
+    e = os.environ.get("SVGP_DP_PACK")
+    return (e[0] != "0") if e else m >= 512
 
 
 class RcclComm:
@@ -211,10 +250,49 @@ class RcclComm:
         call("svgp_allgather_f64", self.handle, tensor.data_ptr(), tensor.numel() // self.world_size, stream)
 
     def run(self, ops, stream):
-        """Enqueues one exchange point (list of ExchangeOp) on `stream`."""
+        """Enqueues one exchange point (list of ExchangeOp) on `stream` as ONE grouped RCCL launch (ncclGroupStart / End);
+        symmetric (L,m,m) members travel tile-packed: pack -> collective on the packed buffer -> unpack (the sequence of
+        svgp_mnist_train_step_dp)."""
+        G, r = self.world_size, self.rank
+        pe = lambda o: _lib.load_library().svgp_sym_packed_elems(o.sym.m)
+
+        def win(o, lo, n, packed):          # data pointer of channels [lo, lo + n)
+            return (o.sym.xp.data_ptr() + 8 * lo * pe(o)) if packed else (o.tensor.data_ptr() + 8 * lo * o.sym.m * o.sym.m)
+
         for o in ops:
-            {"allreduce": self.all_reduce, "reduce_scatter": self.reduce_scatter, "allgather": self.all_gather}[o.kind](
-                o.tensor, stream)
+            if o.sym is None or o.sym.prepacked:
+                continue
+            nl = o.sym.L // G
+            if o.kind == "reduce_scatter":
+                call("svgp_sym_pack", o.sym.m, o.sym.L, 0, o.tensor.data_ptr(), o.sym.xp.data_ptr(), stream)
+            else:
+                call("svgp_sym_pack", o.sym.m, nl, int(o.sym.avg), win(o, r * nl, nl, False), win(o, r * nl, nl, True), stream)
+                if o.sym.avg:
+                    call("svgp_sym_unpack", o.sym.m, nl, win(o, r * nl, nl, True), win(o, r * nl, nl, False), stream)
+        call("svgp_comm_group_begin", self.handle)
+        for o in ops:
+            t = o.tensor if o.sym is None else o.sym.xp
+            {"allreduce": self.all_reduce, "reduce_scatter": self.reduce_scatter, "allgather": self.all_gather}[o.kind](t, stream)
+        call("svgp_comm_group_end", self.handle)
+        for o in ops:
+            if o.sym is None:
+                continue
+            nl = o.sym.L // G
+            if o.kind == "reduce_scatter":
+                call("svgp_sym_unpack", o.sym.m, nl, win(o, r * nl, nl, True), win(o, r * nl, nl, False), stream)
+            else:
+                for lo, n in ((0, r * nl), ((r + 1) * nl, o.sym.L - (r + 1) * nl)):
+                    if n > 0:
+                        call("svgp_sym_unpack", o.sym.m, n, win(o, lo, n, True), win(o, lo, n, False), stream)
+
+    def timing(self, enable):
+        call("svgp_comm_timing", self.handle, int(enable))
+
+    def timing_read(self):
+        """Microseconds of the exchange points of the last svgp_mnist_train_step_dp issued with timing on."""
+        us, n = (C.c_float * 8)(), C.c_int(0)
+        call("svgp_comm_timing_read", self.handle, us, 8, C.byref(n))
+        return [float(us[k]) for k in range(n.value)]
 
     def close(self):
         if self.handle:
@@ -228,7 +306,7 @@ class MnistStepEngine:
     def __init__(self, m, L=16, M=8, n_obj=400, *, N_train=4050.0, jitter=1e-6, clip_qs=True, geco=False,
                  K_obj_normalize=False, titsias=False, kappa_squared=0.020, alpha=0.99, beta=0.001, lr=1e-3,
                  train_ip=True, train_gp=True, train_ov=True, b_max=256, device="cuda:0",
-                 rank=0, world_size=1):
+                 rank=0, world_size=1, single_stat_block=None):
         self.lib = _lib.load_library()          # raises if the HIP extension is missing
         if not torch.cuda.is_available():
             raise _lib.SvgpError("MnistStepEngine needs a HIP device (torch.cuda.is_available() is False); "
@@ -240,7 +318,9 @@ class MnistStepEngine:
                          N_train=float(N_train), jitter=float(jitter), kappa_squared=float(kappa_squared),
                          alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0,
                          # sharded over ranks: the statistics blocks are all-reduced -> one block per channel, not 4 row partials
-                         single_stat_block=int(world_size > 1))
+                         # (single_stat_block=True on one rank: the exact kernel configuration of a multi-rank step,
+                         # bench.py --force-comm)
+                         single_stat_block=int(world_size > 1 if single_stat_block is None else single_stat_block))
         self.b_max = b_max
         self.cfg = None
         self.pl = ParamLayout()
@@ -418,24 +498,46 @@ class MnistStepEngine:
         L, m, G = self.base["L"], self.base["m"], self.world_size
         nl, l0 = L // G, self.rank * (L // G)
         fld = lambda name, per: self.ws[getattr(self.wl, name):getattr(self.wl, name) + L * per]
-        ops = lambda kind, *fields: [ExchangeOp(kind, fld(n, per)) for n, per in fields]
         mm = m * m
+        pack = dp_pack_enabled(m)
+        pe = int(self.lib.svgp_sym_packed_elems(m))
+        xp = [self.ws[self.wl.xpack + k * L * pe:self.wl.xpack + (k + 1) * L * pe] for k in range(2)]
+        sym = lambda k, avg=False, pre=False: SymBlock(m, L, avg, xp[k], pre) if pack else None
+        plain = lambda kind, *fields: [ExchangeOp(kind, fld(n, per)) for n, per in fields]
+        fork = os.environ.get("SVGP_SIDE_STREAMS", "1")[0] != "0"
+        side = self._side_stream() if fork else self.stream
+        wptr = lambda name, packed_k=None: (xp[packed_k].data_ptr() + 8 * l0 * pe) if packed_k is not None else \
+            (self.ws.data_ptr() + 8 * (getattr(self.wl, name) + l0 * mm))
         with torch.cuda.stream(self.stream):
             call("svgp_mnist_encoder_kernel_matrix_fwd", cp, th, im, ax, ws, s)
             call("svgp_gp_stats_fwd", cp, ws, s)
-        yield ops("reduce_scatter", ("S", mm), ("v", m))
+        yield [ExchangeOp("reduce_scatter", fld("S", mm), sym(0))] + plain("reduce_scatter", ("v", m))
         with torch.cuda.stream(self.stream):
-            call("svgp_gp_factor_fwd_channels", cp, l0, nl, ws, s)
-        yield ops("allgather", ("Si", mm), ("M2", mm), ("t", m), ("u", m), ("KL", 1))
+            call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 1, ws, s)            # without the (A_hat + jI)^-1 tail
+            if pack:      # the window in wire format (and M2 symmetrised in place) BEFORE the side branch starts reading it
+                call("svgp_sym_pack", m, nl, 0, wptr("Si"), wptr("Si", 0), s)
+                call("svgp_sym_pack", m, nl, 1, wptr("M2"), wptr("M2", 1), s)
+                call("svgp_sym_unpack", m, nl, wptr("M2", 1), wptr("M2"), s)
+            # the tail and the early reverse half: on the side branch, beside the all-gather, the row stage, the decoder and
+            # the reverse statistics
+            side.wait_stream(self.stream)
+            call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 2, ws, side.cuda_stream)
+            if fork:
+                call("svgp_gp_factor_bwd_channels_part", cp, l0, nl, 1, ws, st, side.cuda_stream)
+        yield [ExchangeOp("allgather", fld("Si", mm), sym(0, pre=True)),
+               ExchangeOp("allgather", fld("M2", mm), sym(1, avg=True, pre=True) if pack else None)] + \
+            plain("allgather", ("t", m), ("u", m))
         with torch.cuda.stream(self.stream):
             call("svgp_gp_posterior_fwd", cp, ep, ws, st, s)
             call("svgp_mnist_decoder_fwd", cp, th, im, ws, s)
             call("svgp_mnist_decoder_bwd", cp, th, im, ws, st, s)
             call("svgp_gp_stats_bwd", cp, ws, st, s)
-        yield ops("reduce_scatter", ("A2", mm), ("ud", m), ("td", m))
+        yield [ExchangeOp("reduce_scatter", fld("A2", mm), sym(0))] + plain("reduce_scatter", ("ud", m), ("td", m))
         with torch.cuda.stream(self.stream):
-            call("svgp_gp_factor_bwd_channels", cp, l0, nl, ws, st, s)
-        yield ops("allgather", ("Ssym", mm), ("vbar", m))      # (Q = Ssym - g3 M2 is not exchanged: M2 was, in stage 1)
+            self.stream.wait_stream(side)
+            call("svgp_gp_factor_bwd_channels_part", cp, l0, nl, 2 if fork else 0, ws, st, s)
+        # (Q = Ssym - g3 M2 is not exchanged: M2 was, in stage 1; KL_l comes out of the tail, joined above)
+        yield [ExchangeOp("allgather", fld("Ssym", mm), sym(0))] + plain("allgather", ("vbar", m), ("KL", 1))
         with torch.cuda.stream(self.stream):
             call("svgp_gp_posterior_bwd", cp, ws, st, s)
             call("svgp_kernel_matrix_bwd_partials", cp, th, ax, ws, s)
@@ -443,6 +545,11 @@ class MnistStepEngine:
             call("svgp_mnist_grad_reduce_all", cp, ax, ws, s)
         yield [ExchangeOp("allreduce", self.block("gradC"))]
         self.phase(3, adam)
+
+    def _side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
 
     # hipGraph capture / replay through the library (not torch.cuda.graphs)
     def capture(self, key, adam=True):

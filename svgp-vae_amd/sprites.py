@@ -31,7 +31,7 @@ import torch
 from . import _lib
 from ._lib import STATE, STATE_LEN, MnistCfg, SpritesKcfg, WsLayout, call
 from .conv import ConvLayer
-from .engine import ExchangeOp
+from .engine import ExchangeOp, SymBlock, dp_pack_enabled
 
 _F64 = torch.float64
 ENC_STRIDES = (1, 2, 1, 2, 1, 2)
@@ -362,9 +362,16 @@ class SpritesStepEngine:
         the three exchange blocks are summed over ranks by `self.comm` between the phases."""
         if self.world_size > 1 and self.comm is None:
             raise _lib.SvgpError("world_size > 1 needs a communicator (engine.RcclComm)")
+        tr = getattr(self, "exchange_trace", None)
         for ops in self.phases(images, action_ids, eps, adam, b_global):
             if self.comm is not None:
+                if tr is not None:           # bench.py: events around every exchange point (pack + grouped launch + unpack)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(self.stream)
                 self.comm.run(ops, self.stream.cuda_stream)
+                if tr is not None:
+                    e1.record(self.stream)
+                    tr.append((e0, e1))
         return self
 
     def phases(self, images, action_ids, eps=None, adam=True, b_global=None):
@@ -409,14 +416,35 @@ class SpritesStepEngine:
         mm_, G_, r_ = self.m * self.m, self.world_size, self.rank
         nl = L // G_ if self.chan_shard else L
         fld = lambda name, per: self.ws[getattr(self.wl, name):getattr(self.wl, name) + L * per]       # an (L, per) field
+        plain = lambda kind, *fields: [ExchangeOp(kind, fld(n_, per)) for n_, per in fields]
+        # channel-sharded exchange (the sequence of svgp_mnist_train_step_dp): five points, each ONE grouped RCCL launch; the
+        # symmetric (L,m,m) members travel tile-packed (engine.SymBlock) from m >= 512
+        pack = self.chan_shard and dp_pack_enabled(self.m)
+        pe = int(_lib.load_library().svgp_sym_packed_elems(self.m))
+        xp = [self.ws[self.wl.xpack + k * L * pe:self.wl.xpack + (k + 1) * L * pe] for k in range(2)] if pack else [None, None]
+        sym = lambda k, avg=False, pre=False: SymBlock(self.m, L, avg, xp[k], pre) if pack else None
+        l0 = r_ * nl
+        wptr = lambda name, k=None: (xp[k].data_ptr() + 8 * l0 * pe) if k is not None else \
+            (self.ws.data_ptr() + 8 * (getattr(self.wl, name) + l0 * mm_))
         if self.chan_shard:
-            yield [ExchangeOp("reduce_scatter", fld("S", mm_)), ExchangeOp("reduce_scatter", fld("v", self.m))]
+            yield [ExchangeOp("reduce_scatter", fld("S", mm_), sym(0))] + plain("reduce_scatter", ("v", self.m))
         else:
             yield [ExchangeOp("allreduce", self.ws[self.wl.statA:self.wl.statA + self.wl.statA_len])]
         with torch.cuda.stream(self.stream):
             self._mark("gp_fwd_factor")
             if self.chan_shard:
-                call("svgp_gp_factor_fwd_channels", cp, r_ * nl, nl, ws, s)
+                call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 1, ws, s)         # without the (A_hat + jI)^-1 tail
+                if pack:   # the window in wire format (M2 symmetrised in place) BEFORE the side branch starts reading it
+                    call("svgp_sym_pack", self.m, nl, 0, wptr("Si"), wptr("Si", 0), s)
+                    call("svgp_sym_pack", self.m, nl, 1, wptr("M2"), wptr("M2", 1), s)
+                    call("svgp_sym_unpack", self.m, nl, wptr("M2", 1), wptr("M2"), s)
+                # the tail and the early reverse half of the window: on the side stream, beside the all-gather, the row stage,
+                # the decoder and the reverse statistics
+                sd = self.side if self.side is not None else self.stream
+                sd.wait_stream(self.stream)
+                call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 2, ws, sd.cuda_stream)
+                if self.side is not None:
+                    call("svgp_gp_factor_bwd_channels_part", cp, l0, nl, 1, ws, st, sd.cuda_stream)
             elif self.m > 64 and self.side is not None and not self.svgp.titsias:
                 # (not with titsias: svgp_gp_titsias_fwd inverts through the same scratch, ws.scr_inv, on the main stream)
                 # the tail of the stage -- (A_hat + jI)^-1, its log det, KL_l: a whole batched inverse that only the reverse
@@ -437,8 +465,8 @@ class SpritesStepEngine:
             else:
                 call("svgp_gp_factor_fwd", cp, ws, s)
         if self.chan_shard:
-            yield [ExchangeOp("allgather", fld(n_, per)) for n_, per in (("Si", mm_), ("M2", mm_), ("t", self.m), ("u", self.m),
-                                                                         ("KL", 1))]
+            yield [ExchangeOp("allgather", fld("Si", mm_), sym(0, pre=True)),
+                   ExchangeOp("allgather", fld("M2", mm_), sym(1, avg=True, pre=True))] + plain("allgather", ("t", self.m), ("u", self.m))
         with torch.cuda.stream(self.stream):
             call("svgp_gp_posterior_fwd", cp, None if eps is None else eps.contiguous().data_ptr(), ws, st, s)
             if self.svgp.titsias:
@@ -476,20 +504,22 @@ class SpritesStepEngine:
             self._mark("gp_bwd_stats")
             call("svgp_gp_stats_bwd", cp, ws, st, s)
         if self.chan_shard:
-            yield [ExchangeOp("reduce_scatter", fld(n_, per)) for n_, per in (("A2", mm_), ("ud", self.m), ("td", self.m))]
+            yield [ExchangeOp("reduce_scatter", fld("A2", mm_), sym(0))] + plain("reduce_scatter", ("ud", self.m), ("td", self.m))
         else:
             yield [ExchangeOp("allreduce", self.ws[self.wl.statB:self.wl.statB + self.wl.statB_len])]
         with torch.cuda.stream(self.stream):
             self._mark("gp_bwd_factor")
             if self.chan_shard:
-                call("svgp_gp_factor_bwd_channels", cp, r_ * nl, nl, ws, st, s)
+                if self.side is not None:
+                    self.stream.wait_stream(self.side)
+                call("svgp_gp_factor_bwd_channels_part", cp, l0, nl, 2 if self.side is not None else 0, ws, st, s)
             elif self.m > 64 and self.side is not None and not self.svgp.titsias:
                 self.stream.wait_stream(self.side)
                 call("svgp_gp_factor_bwd_late", cp, ws, st, s)
             else:
                 call("svgp_gp_factor_bwd", cp, ws, st, s)
-        if self.chan_shard:
-            yield [ExchangeOp("allgather", fld(n_, per)) for n_, per in (("Ssym", mm_), ("vbar", self.m))]
+        if self.chan_shard:      # (KL_l comes out of the tail, joined above)
+            yield [ExchangeOp("allgather", fld("Ssym", mm_), sym(0))] + plain("allgather", ("vbar", self.m), ("KL", 1))
         with torch.cuda.stream(self.stream):
             call("svgp_gp_posterior_bwd", cp, ws, st, s)
             if self.svgp.titsias:

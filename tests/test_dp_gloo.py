@@ -105,16 +105,23 @@ class ShardedOracleBackend(OracleBackend):
     rank's channel window only.  (The oracle's row stage consumes A_l where the HIP kernels consume M2_l = Ki A_l Ki,
     so A is what is all-gathered here; same schedule, same op kinds and sizes.)"""
 
-    def __init__(self, *a, world, **kw):
+    def __init__(self, *a, world, packed=False, **kw):
         super().__init__(*a, **kw)
-        self.world = world
+        self.world, self.packed = world, packed
 
     def stage(self, k):
         getattr(self, f"_stage{k}")()
 
     def ops(self, k):
-        from svgp_vae_amd.engine import ExchangeOp
-        return [ExchangeOp(kind, t) for kind, t in self._ops[k]]
+        """Entries (kind, tensor) or (kind, tensor, avg): the three-element form marks an (L,m,m) SYMMETRIC block, which the
+        packed schedule moves as its tile-packed lower triangle (engine.SymBlock; avg: symmetrised by averaging)."""
+        from svgp_vae_amd.engine import ExchangeOp, SymBlock
+        m = self.K.shape[0]
+        out = []
+        for e in self._ops[k]:
+            sym = SymBlock(m, self.L, avg=e[2]) if (self.packed and len(e) == 3) else None
+            out.append(ExchangeOp(e[0], e[1], sym))
+        return out
 
     def _win(self):
         nl = self.L // self.world
@@ -125,7 +132,7 @@ class ShardedOracleBackend(OracleBackend):
         nS = math.prod(self.shapeS)
         blk = self.blocks["statA"]
         self.S, self.v = blk[:nS].view(self.shapeS), blk[nS:].view(self.shapev)
-        self._ops = {0: [("reduce_scatter", blk[:nS]), ("reduce_scatter", blk[nS:])]}
+        self._ops = {0: [("reduce_scatter", blk[:nS], False), ("reduce_scatter", blk[nS:])]}
 
     def _stage1(self):
         l0, l1 = self._win()
@@ -135,7 +142,8 @@ class ShardedOracleBackend(OracleBackend):
         self.full = {k: torch.full((L,) + tuple(fw[k].shape[1:]), float("nan"), dtype=DT) for k in ("Si", "A", "t", "u", "KL")}
         for k in self.full:
             self.full[k][l0:l1] = fw[k]
-        self._ops[1] = [("allgather", self.full[k].view(-1)) for k in ("Si", "A", "t", "u", "KL")]
+        self._ops[1] = [("allgather", self.full["Si"].view(-1), False), ("allgather", self.full["A"].view(-1), True)] + \
+            [("allgather", self.full[k].view(-1)) for k in ("t", "u", "KL")]
 
     def _stage2(self):
         f = dict(self.fw)
@@ -153,7 +161,7 @@ class ShardedOracleBackend(OracleBackend):
         self.gT = -1.0 if self.geco else -self.beta / self.L
         self.gw = SG.gp_posterior_bwd_weights(self.y, self.s2, self.eps, self.ps, self.zbar, self.gT, self.c)
         self.A2, self.ud, self.td = (t.contiguous() for t in SG.gp_stats(self.Kn, self.gw[0], self.gw[2], self.c * self.gw[1]))
-        self._ops[2] = [("reduce_scatter", t.view(-1)) for t in (self.A2, self.ud, self.td)]
+        self._ops[2] = [("reduce_scatter", self.A2.view(-1), False)] + [("reduce_scatter", t.view(-1)) for t in (self.ud, self.td)]
 
     def _stage3(self):
         l0, l1 = self._win()
@@ -165,7 +173,8 @@ class ShardedOracleBackend(OracleBackend):
         self.fbfull = {k: torch.full((L,) + tuple(fb[k].shape[1:]), float("nan"), dtype=DT) for k in ("Q", "Ssym", "vbar")}
         for k in self.fbfull:
             self.fbfull[k][l0:l1] = fb[k]
-        self._ops[3] = [("allgather", self.fbfull[k].view(-1)) for k in ("Q", "Ssym", "vbar")]
+        self._ops[3] = [("allgather", self.fbfull["Ssym"].view(-1), False)] + \
+            [("allgather", self.fbfull[k].view(-1)) for k in ("Q", "vbar")]
 
     def _stage4(self):
         fb = dict(Q=self.fbfull["Q"], Ssym=self.fbfull["Ssym"], vbar=self.fbfull["vbar"], P=2.0 * self.full["Si"])
@@ -190,7 +199,7 @@ class ShardedOracleBackend(OracleBackend):
         pass
 
 
-def _worker_sharded(rank, world, port, b_global, geco, L, ret):
+def _worker_sharded(rank, world, port, b_global, geco, L, ret, packed=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -198,7 +207,7 @@ def _worker_sharded(rank, world, port, b_global, geco, L, ret):
         params, images, aux, eps = H.toy_problem(b=b_global, m=12, L=L, M=4, n_obj=20, seed=0)
         lo, hi = shard_rows(b_global, world, rank)
         be = ShardedOracleBackend(params, images[lo:hi], aux[lo:hi], eps[lo:hi], b_global=b_global, rank=rank, world=world,
-                                  N_train=300.0, jitter=1e-6, geco=geco, beta=0.001, lagrange=1.7)
+                                  N_train=300.0, jitter=1e-6, geco=geco, beta=0.001, lagrange=1.7, packed=packed)
         ChannelShardedStep(be).step()
         if rank == 0:
             ret.put((be.block("gradC").clone().numpy(), be.full["KL"].clone().numpy()))
@@ -206,14 +215,16 @@ def _worker_sharded(rank, world, port, b_global, geco, L, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,b_global,geco,L", [(2, 40, True, 4), (3, 41, False, 3), (2, 40, False, 6)])
-def test_channel_sharded_schedule_reproduces_single_process(world, b_global, geco, L):
+@pytest.mark.parametrize("world,b_global,geco,L,packed", [(2, 40, True, 4, False), (3, 41, False, 3, False), (2, 40, False, 6, False),
+                                                          (2, 40, True, 4, True), (3, 41, False, 3, True)])
+def test_channel_sharded_schedule_reproduces_single_process(world, b_global, geco, L, packed):
     """Reduce-scatter over the channels -> factor L / G channels per rank -> all-gather:
-    gradients, scalar sums and the per-channel KL terms equal the single-process oracle."""
+    gradients, scalar sums and the per-channel KL terms equal the single-process oracle.  packed: the symmetric (L,m,m)
+    members of every exchange point travel as their symmetrised lower triangle (engine.SymBlock)."""
     ctx = mp.get_context("spawn")
     ret = ctx.SimpleQueue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_sharded, args=(r, world, port, b_global, geco, L, ret)) for r in range(world)]
+    procs = [ctx.Process(target=_worker_sharded, args=(r, world, port, b_global, geco, L, ret, packed)) for r in range(world)]
     for p in procs:
         p.start()
     import time

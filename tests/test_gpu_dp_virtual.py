@@ -56,13 +56,22 @@ def test_virtual_ranks_equal_single_engine(golden, G, b, geco):
         assert torch.equal(e.theta, ranks[0].theta)
 
 
-@pytest.mark.parametrize("G,b,m,L,M", [(2, 64, 72, 4, 16), (4, 96, 72, 4, 16), (8, 1024, 256, 16, 32)])
-def test_channel_sharded_virtual_ranks_equal_single_engine(G, b, m, L, M):
+@pytest.mark.parametrize("G,b,m,L,M,pack", [(2, 64, 72, 4, 16, "0"), (4, 96, 72, 4, 16, "0"), (2, 64, 72, 4, 16, "1"),
+                                            (3, 96, 130, 6, 24, "1"), (8, 1024, 256, 16, 32, None), (8, 1024, 256, 16, 32, "1")])
+def test_channel_sharded_virtual_ranks_equal_single_engine(G, b, m, L, M, pack, monkeypatch):
     """Large-m path: the channel-sharded schedule of svgp_mnist_train_step_dp (reduce-scatter of the (L,m,m) statistics
     over the channels, every rank factors L / G channels, all-gather of what the row stages need), run stage
     by stage with G virtual ranks, against the single-engine step at the same global batch.  The last case is BASELINE
-    configs[2] (m = 256, b = 1024, L = 16) on 8 ranks: 2 channels per rank."""
-    from svgp_vae_amd.engine import shard_rows, virtual_exchange
+    configs[2] (m = 256, b = 1024, L = 16) on 8 ranks: 2 channels per rank.  pack: SVGP_DP_PACK -- the symmetric (L,m,m)
+    members of the four large exchange points travel tile-packed (svgp_sym_pack; the window of Sigma^-1 / M2 goes through
+    the HIP pack kernels inside the engine, M2 symmetrised by averaging); None = the library's default (on from m = 512).
+    The forward tail and the early reverse half of every rank run on its side stream beside the exchange."""
+    from svgp_vae_amd.engine import shard_rows, virtual_exchange, dp_pack_enabled
+    if pack is None:
+        monkeypatch.delenv("SVGP_DP_PACK", raising=False)
+    else:
+        monkeypatch.setenv("SVGP_DP_PACK", pack)
+    assert dp_pack_enabled(m) == (pack == "1" or (pack is None and m >= 512))
     params, images, aux, eps = H.toy_problem(b=b, m=m, L=L, M=M, n_obj=60, seed=G + m)
     # The ranks add the statistics in a different order than the single engine and cond(Sigma_l) amplifies that rounding:
     # with c = N_train / b = 63, 1 / sigma^2 up to 1000 and jitter 1e-2, Sigma_l^-1 already differs by 1.4e-9 and the ELBO by
@@ -103,6 +112,11 @@ def test_channel_sharded_virtual_ranks_equal_single_engine(G, b, m, L, M):
                 break
             for e in ranks:
                 e.synchronize()
+            assert all(len(o) == len(ops[0]) for o in ops)
+            if dp_pack_enabled(m) and n_points < 4:            # the (L,m,m) member of every large point is marked symmetric
+                assert ops[0][0].sym is not None
+                if m >= 256:                                   # 56 % of the square at m = 256 (52 % at m = 800)
+                    assert ops[0][0].sym.xp.numel() < 0.6 * ops[0][0].tensor.numel()
             virtual_exchange(ops)
             torch.cuda.synchronize()
             n_points += 1

@@ -102,17 +102,20 @@ def test_sprites_training_steps_reduce_the_loss():
     assert eng.scalars()["adam_t"] == 8.0
 
 
-@pytest.mark.parametrize("G,K_SE,m,clip,shard,L", [(2, False, 12, None, None, 6), (3, True, 72, 0.05, None, 6),
-                                                    (2, False, 72, None, False, 6), (2, True, 72, None, True, 6),
-                                                    (8, False, 72, None, True, 8)])
-def test_sprites_virtual_ranks_equal_single_engine(G, K_SE, m, clip, shard, L):
+@pytest.mark.parametrize("G,K_SE,m,clip,shard,L,pack", [(2, False, 12, None, None, 6, "0"), (3, True, 72, 0.05, None, 6, "0"),
+                                                         (2, False, 72, None, False, 6, "0"), (2, True, 72, None, True, 6, "0"),
+                                                         (8, False, 72, None, True, 8, "0"), (3, True, 72, 0.05, None, 6, "1"),
+                                                         (8, False, 72, None, True, 8, "1")])
+def test_sprites_virtual_ranks_equal_single_engine(G, K_SE, m, clip, shard, L, pack, monkeypatch):
     """Data parallelism over whole character groups: G engines on one GPU run the step's phases in
     lockstep and every exchange point is executed by hand (engine.virtual_exchange: what the RCCL collectives do);
     scalars, gradients and the parameters after two Adam steps must equal the single-engine run at the same global
     batch.  m <= 64: three all-reduces.  m > 64 and L divisible by G (shard None -> on): the channel-sharded schedule --
     reduce-scatter of S, v / A2, ud, td over the channels, each rank factors its L / G channels
-    (svgp_gp_factor_*_channels), all-gather of Sigma^-1, M2, t, u, KL / Ssym, vbar."""
+    (svgp_gp_factor_*_channels), all-gather of Sigma^-1, M2, t, u / Ssym, vbar, KL; pack = 1: the symmetric (L,m,m) members
+    tile-packed (SVGP_DP_PACK), the window's tail and early reverse half on the side stream beside the exchange."""
     from svgp_vae_amd import sprites as S
+    monkeypatch.setenv("SVGP_DP_PACK", pack)
     frames, La, Lc, n_act = 4, 8, 16, 9
     b = frames * 2 * G
     params, gp, images, ids, eps, _, _ = _problem(b, frames, L, La, Lc, m, n_act, seed=G + m)

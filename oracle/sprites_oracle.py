@@ -239,11 +239,16 @@ def approximate_posterior_params_precomputed(svgp, index_points, mean_term, sigm
 
 
 def predict_SVGPVAE_sprites_test_character(data_batch, params, svgp, mean_terms, var_terms, N_context, N_actions,
-                                           batch_size_test, segment_ids, repeats, K_mm_inv, epsilon, L):
-    """SVGPVAE_model.py:1118-1195 with context_full_actions=True and the N(0,1) draw as an input."""
+                                           batch_size_test, segment_ids, repeats, K_mm_inv, epsilon, L, context_draw=None):
+    """SVGPVAE_model.py:1118-1195 with the N(0,1) draw as an input.  context_draw None: context_full_actions=True (:1146-1148);
+    else (n_characters, N_context) offsets standing for the np.random.choice draw of context_full_actions=False (:1149-1151)."""
     images, action_ids = data_batch
-    context = np.sort(np.array([list(range(i * N_actions, i * N_actions + N_context))
-                                for i in range(int(batch_size_test / N_actions))]).reshape(-1))
+    if context_draw is None:
+        context = np.sort(np.array([list(range(i * N_actions, i * N_actions + N_context))
+                                    for i in range(int(batch_size_test / N_actions))]).reshape(-1))
+    else:
+        context = np.sort(np.array([list(i * N_actions + np.asarray(context_draw[i]))
+                                    for i in range(int(batch_size_test / N_actions))]).reshape(-1))
     target = np.array([x for x in range(batch_size_test) if x not in set(context.tolist())])
     images_context, images_t = images[context], images[target]
     aux_t = aux_data_SVGPVAE_sprites((images_context, action_ids[target]), params, segment_ids, repeats)

@@ -120,33 +120,42 @@ def run_experiment_rotated_mnist_SVGPVAE(args, args_dict=None):
     d_test_img, d_test_aux = t64(te["images"]), t64(te["aux_data"])
     stage_img = torch.zeros(args.batch_size, 28, 28, 1, dtype=torch.float64, device=dev)
     stage_aux = torch.zeros(args.batch_size, 2 + args.M, dtype=torch.float64, device=dev)
+    # the N(0,1) draw of SVGPVAE_model.py:901 is made on device; `args.epsilon_fn(epoch, batch index, rows, L) -> array`
+    # (not a CLI flag: set by callers that need a reproducible trajectory, tests/test_gpu_api.py) makes it an input
+    eps_fn = getattr(args, "epsilon_fn", None)
+    stage_eps = torch.zeros(args.batch_size, args.L, dtype=torch.float64, device=dev) if eps_fn else None
     eng.stream.wait_stream(torch.cuda.current_stream(dev))   # uploads / zero-fills above ran on torch's stream
     graphs = {}
 
-    def train_batch(lo, hi):
+    def train_batch(lo, hi, epoch, i):
         b = hi - lo
         with torch.cuda.stream(eng.stream):
             stage_img[:b].copy_(d_train_img[lo:hi])
             stage_aux[:b].copy_(d_train_aux[lo:hi])
+            if eps_fn:
+                stage_eps[:b].copy_(torch.as_tensor(np.asarray(eps_fn(epoch, i, b, args.L)), dtype=torch.float64), non_blocking=False)
         if b not in graphs:
             eng.set_batch_size(b)
-            eng.bind(stage_img[:b], stage_aux[:b], None)       # eps drawn on device (tf.random.normal, :901)
+            eng.bind(stage_img[:b], stage_aux[:b], stage_eps[:b] if eps_fn else None)   # None: drawn on device
             eng.capture(("train", b), adam=True)
             graphs[b] = True
         eng.replay(("train", b))
 
     nr_epochs, training_regime = parse_opt_regime(args.opt_regime)
-    log = dict(epoch=[], elbo=[], recon_loss=[], eval_mse=[], cgen_mse=[], epoch_time=[])
+    log = dict(epoch=[], elbo=[], recon_loss=[], eval_mse=[], cgen_mse=[], epoch_time=[], steps=[])
+    log["_engine"] = eng                     # (the final parameters / optimiser state for callers; not serialised)
     start = time.time()
     for epoch in range(nr_epochs):
         t0 = time.time()
         elbos, losses = [], []
-        for lo, hi in train_batches:
-            train_batch(lo, hi)
-            # the reference fetches elbo / recon_loss every step (:334-340); one 128-byte read-back
+        for i, (lo, hi) in enumerate(train_batches):
+            train_batch(lo, hi, epoch, i)
+            # the reference fetches elbo / recon_loss / C_ma / lagrange_mult every step (:334-340); one 128-byte read-back
             eng.synchronize()
             sc = eng.scalars()
             elbos.append(sc["elbo"]); losses.append(sc["recon_loss"])
+            log["steps"].append(dict(epoch=epoch, rows=hi - lo, elbo=sc["elbo"], recon_loss=sc["recon_loss"],
+                                     C_ma=sc["c_ma"], lagrange_mult=sc["lagrange"]))
         mse = np.sum(losses) / N_train
         log["epoch"].append(epoch); log["elbo"].append(float(np.sum(elbos))); log["recon_loss"].append(float(mse))
         log["epoch_time"].append(time.time() - t0)

@@ -121,11 +121,15 @@ def run_experiment_sprites_SVGPVAE(args, dict_=None):
         json.dump(dict_ or vars(args), open(chkpnt_dir + "args.json", "wt"))
 
     # ---- model (SPRITES_experiment.py:82-121)
-    if args.PCA:
-        raise NotImplementedError("--PCA: sprites_PCA_init needs the reference's sprites_train_dict.p (not shipped)")
-    GPLVM_init = np.random.normal(0, 1.5, N_actions * args.L_action).reshape(N_actions, args.L_action)
-    IP_init = np.random.normal(0, 1.5, N_actions * args.m * (args.L_action + args.L_character)) \
-        .reshape(N_actions * args.m, args.L_action + args.L_character)
+    if args.PCA:        # :96-99 (the reference reads sprites_train_dict.p; here: the loaded / synthetic training set)
+        from .SPRITES_utils import sprites_PCA_init
+        GPLVM_init, IP_init = sprites_PCA_init(
+            dict(frames=train["frames"], aux_data=np.stack([train["char_IDs"], train["action_IDs"]], 1)), m=args.m,
+            L_action=args.L_action, L_character=args.L_character, N_action=N_actions)
+    else:
+        GPLVM_init = np.random.normal(0, 1.5, N_actions * args.L_action).reshape(N_actions, args.L_action)
+        IP_init = np.random.normal(0, 1.5, N_actions * args.m * (args.L_action + args.L_character)) \
+            .reshape(N_actions * args.m, args.L_action + args.L_character)
     VAE = S.spritesVAE(L=args.L, seed=args.seed)
     repr_NN = S.sprites_representation_network(L=args.L_character)
     SVGP_ = S.spritesSVGP(titsias='Titsias' in args.elbo, fixed_inducing_points=not args.ip_joint,

@@ -282,8 +282,11 @@ def forward_pass_SVGPVAE(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha
     qnet_var, recon_images, inside_elbo_recon, inside_elbo_kl, latent_samples, C_ma, lagrange_mult,
     mean_vectors).  With GECO the `elbo` slot holds the GECO loss and recon_loss is kappa^2-shifted, as in
     the reference (:909-913).  epsilon (b,L): the N(0,1) draw of :901; None -> drawn on device."""
-    if repr_NN is not None:
-        raise NotImplementedError("the SPRITES representation-network form is svgp_vae_amd.sprites.forward_pass_SVGPVAE")
+    if repr_NN is not None:          # :861-863: aux_data computed per batch by the representation network (SPRITES)
+        from . import sprites
+        return sprites.forward_pass_SVGPVAE(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha, kappa,
+                                            clipping_qs=clipping_qs, GECO=GECO, repr_NN=repr_NN, segment_ids=segment_ids,
+                                            repeats=repeats, bias_analysis=bias_analysis, epsilon=epsilon)
     eng, b = _prepare(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha, kappa, clipping_qs, GECO, epsilon)
     with torch.cuda.stream(eng.stream):
         eng.phase(0)
@@ -329,8 +332,9 @@ def train_step_SVGPVAE(data_batch, beta, vae, svgp, alpha, kappa, lr, clipping_q
 
 def batching_encode_SVGPVAE(data_batch, vae, clipping_qs=False, repr_nn=None, segment_ids=None, repeats=None):
     """SVGPVAE_model.py:939-968: (qnet_mu, qnet_var, aux_data)."""
-    if repr_nn is not None:
-        raise NotImplementedError("SPRITES representation network is not part of this build")
+    if repr_nn is not None:          # :953-956 (SPRITES form; needs the spritesSVGP object the engine hangs on)
+        raise TypeError("the representation-network form needs the GP object: svgp_vae_amd.sprites.batching_encode_SVGPVAE("
+                        "data_batch, vae, clipping_qs, repr_nn, segment_ids, repeats, svgp=...)")
     images, aux_data = data_batch
     mu, var = vae.encode(images)
     if clipping_qs:

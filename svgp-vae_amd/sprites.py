@@ -701,17 +701,26 @@ def approximate_posterior_params_precomputed_GP_posterior_params(svgp, index_poi
 
 def predict_SVGPVAE_sprites_test_character(data_batch, vae, svgp, repr_NN, mean_terms, var_terms, N_context, N_actions,
                                            batch_size_test, segment_ids, repeats, K_mm_inv, context_full_actions=True,
-                                           epsilon=None, engine=None):
+                                           epsilon=None, engine=None, context_draw=None):
     """SVGPVAE_model.py:1118-1195: context / target split of a test-character batch, aux data of the targets from the
     context frames, latents from the precomputed GP posterior (clip [1e-4, 100]), decode, summed squared error / pixels.
-    Returns (recon_images_test, target images, recon_loss).  `epsilon` (n_target, L) makes the N(0,1) draw an input."""
-    if not context_full_actions:
-        raise NotImplementedError("context_full_actions=False draws the context with np.random inside the reference")
+    Returns (recon_images_test, target images, recon_loss).  `epsilon` (n_target, L) makes the N(0,1) draw an input.
+    context_full_actions=False (:1149-1151): the context of every character is N_context of its N_actions frames chosen
+    without replacement -- `context_draw` (n_characters, N_context) integer offsets makes that draw an input too; None draws
+    with np.random.choice exactly as the reference does."""
     images, aux_data_target = data_batch
     eng = _engine_of(svgp, vae, repr_NN, engine, batch_size_test, False)
     dev = eng.dev
-    context = np.sort(np.array([list(range(i * N_actions, i * N_actions + N_context))
-                                for i in range(int(batch_size_test / N_actions))]).reshape(-1))
+    n_char = int(batch_size_test / N_actions)
+    if context_full_actions:
+        context = np.sort(np.array([list(range(i * N_actions, i * N_actions + N_context)) for i in range(n_char)]).reshape(-1))
+    else:
+        if context_draw is None:
+            context_draw = [np.random.choice(range(N_actions), N_context, replace=False) for _ in range(n_char)]
+        context_draw = np.asarray(context_draw)
+        assert context_draw.shape == (n_char, N_context) and all(len(set(r.tolist())) == N_context for r in context_draw)
+        assert context_draw.min() >= 0 and context_draw.max() < N_actions
+        context = np.sort(np.array([list(i * N_actions + context_draw[i]) for i in range(n_char)]).reshape(-1))
     target = np.array([x for x in range(batch_size_test) if x not in set(context.tolist())])
     images = images.to(dev, _F64)
     ids = aux_data_target.to(dev, _F64)

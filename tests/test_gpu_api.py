@@ -256,3 +256,79 @@ def test_cli_driver_trains_and_reports_cgen(golden, tmp_path, elbo):
     assert files and len(open(files[0]).read().strip().splitlines()) == 2
     with pytest.raises(NotImplementedError):
         E.main(["--elbo", "VAE"])
+
+
+@pytest.mark.parametrize("GECO", [True, False])
+def test_cli_driver_epoch_trajectory_matches_oracle(golden, tmp_path, GECO):
+    """(f)2 driver parity: `run_experiment_rotated_mnist_SVGPVAE` for 2 epochs on a 640-row split whose
+    last batch is ragged (256 + 256 + 128) -- loader, un-shuffled batching, KDE inducing-point initialisation from the train
+    aux data, Keras weight initialisation, first-step alpha = 0, GECO state carry, Adam global step, c = N_train / b
+    recomputed per batch -- against oracle.train_trajectory (MNIST_experiment.py:313-355, utils.py:799-875,691-744) on the
+    same batches with the same N(0,1) draws: the per-step elbo / recon_loss / C_ma / lagrange_mult log and the parameters
+    after the 6 updates."""
+    import pickle
+    from svgp_vae_amd import MNIST_experiment as E
+    from svgp_vae_amd.utils import generate_init_inducing_points
+    gin, _ = golden
+    d = str(tmp_path) + "/"
+    pickle.dump({"images": gin["images"][:640], "aux_data": gin["aux"][:640]}, open(d + "train_data3.p", "wb"))
+    for name, sl in (("eval_data3.p", slice(0, 64)), ("test_data3.p", slice(64, 128))):
+        pickle.dump({"images": gin["images"][sl], "aux_data": gin["aux"][sl]}, open(d + name, "wb"))
+    pickle.dump(gin["object_vectors"], open(d + "pca_ov_init3.p", "wb"))
+    argv = ["--elbo", "SVGPVAE_Hensman", "--mnist_data_path", d, "--train_file", d + "train_data3.p", "--ip_joint", "--GP_joint",
+            "--ov_joint", "--clip_qs", "--PCA", "--opt_regime", "joint-2", "--eval_every", "100", "--lr", "0.002", "--seed", "3"]
+    args = E.build_parser().parse_args(argv + (["--GECO"] if GECO else []))
+    eps_of = lambda epoch, i, b, L: np.random.RandomState(1000 * epoch + i + 7).randn(b, L)
+    args.epsilon_fn = eps_of
+    log = E.run_experiment_rotated_mnist_SVGPVAE(args)
+    assert [s["rows"] for s in log["steps"]] == [256, 256, 128] * 2
+    # ---- the oracle on the same inputs, built the way the reference's driver builds them
+    params = {k: torch.tensor(v, dtype=DT) for k, v in O.glorot_uniform_init(16, seed=3).items()}
+    params["inducing_index_points"] = torch.tensor(
+        generate_init_inducing_points(None, n=2, PCA=True, M=8, aux_data=np.asarray(gin["aux"][:640])), dtype=DT)
+    params["l_GP"], params["amplitude"] = torch.tensor(1.0, dtype=DT), torch.tensor(1.0, dtype=DT)
+    params["object_vectors"] = torch.tensor(gin["object_vectors"], dtype=DT)
+    img, aux = torch.tensor(gin["images"][:640], dtype=DT), torch.tensor(gin["aux"][:640], dtype=DT)
+    spans = [(0, 256), (256, 512), (512, 640)]
+    batches = [(img[lo:hi], aux[lo:hi]) for _ in range(2) for lo, hi in spans]
+    epsilons = [torch.tensor(eps_of(e, i, hi - lo, 16), dtype=DT) for e in range(2) for i, (lo, hi) in enumerate(spans)]
+    olog, oparams, _, _ = O.train_trajectory(params, batches, epsilons, beta=0.001, lr=0.002, alpha_flag=0.99,
+                                             kappa=math.sqrt(0.020), clipping_qs=True, GECO=GECO, jitter=1e-6,
+                                             N_train=640.0, L=16, formulation="efficient")
+    for t, (got, want) in enumerate(zip(log["steps"], olog)):
+        for k in ("elbo", "recon_loss", "C_ma", "lagrange_mult"):
+            assert abs(got[k] - want[k]) <= 1e-8 * max(1.0, abs(want[k])), (t, k, got[k], want[k])
+    eng = log["_engine"]
+    for k, v in oparams.items():
+        assert H.relerr(eng.params[k], v) < 1e-6, k
+    assert eng.scalars()["adam_t"] == 6.0
+
+
+def test_forward_pass_SVGPVAE_dispatches_the_representation_network_form():
+    """SVGPVAE_model.forward_pass_SVGPVAE(..., repr_NN=, segment_ids=, repeats=) (reference :823-825,861-863) is the SPRITES
+    step: same 16-tuple as sprites.forward_pass_SVGPVAE on the same inputs."""
+    from svgp_vae_amd import SVGPVAE_model as M, sprites as S
+    from tests.test_gpu_sprites import _problem
+    frames, La, Lc, n_act, L, m = 4, 8, 16, 9, 4, 12
+    b = frames * 3
+    params, gp, images, ids, eps, _, _ = _problem(b, frames, L, La, Lc, m, n_act, seed=1)
+    init = dict(params)
+    init["se"] = torch.stack([gp["l_action"], gp["sigma_action"], gp["l_character"], gp["sigma_character"]])
+
+    def models():
+        svgp = S.spritesSVGP(False, False, gp["inducing_index_points"].numpy(), 'main', 0.01, 100.0, La,
+                             gp["GPLVM_action"].numpy(), Lc, L, K_obj_normalize=True)
+        return S.spritesVAE(L), S.sprites_representation_network(Lc), svgp
+
+    seg, rep = S.aux_data_sprites_utils(b, b, frames)
+    outs = []
+    for fn in (M.forward_pass_SVGPVAE, S.forward_pass_SVGPVAE):
+        vae, rn, svgp = models()
+        eng = S.SpritesStepEngine(vae, rn, svgp, b_max=b, seg_len=frames, clip_qs=True, geco=True, kappa_squared=0.0075,
+                                  params=init)
+        svgp._engine = eng
+        outs.append(fn((images, ids), 0.001, vae, svgp, 0.02, 1.4, 0.9, math.sqrt(0.0075), clipping_qs=True, GECO=True,
+                       repr_NN=rn, segment_ids=seg, repeats=rep, epsilon=eps))
+    assert len(outs[0]) == len(outs[1]) == 16
+    for a, c in zip(*outs):
+        assert torch.equal(torch.as_tensor(a).cpu(), torch.as_tensor(c).cpu())

@@ -160,6 +160,52 @@ def test_sprites_m800_step_matches_oracle(GECO):
     assert not bad, "\n".join(bad)
 
 
+@pytest.mark.parametrize("net_dtype", [torch.float32, torch.float64])
+def test_sprites_m800_at_500_frames_matches_oracle(net_dtype):
+    """BASELINE configs[3] at the size bench.py --workload sprites800 times: ONE GPU's share, 500 frames
+    = 10 characters x 50, m = 800, L = 64, jitter 0.01, cosine-normalised linear kernels, GECO; networks in float32 (the
+    reference's dtype, and the benchmarked configuration) or float64, GP block float64.  The explicit-eps step's scalar
+    outputs and p_m / p_v against the oracle's efficient forward formulation (torch-CPU float64, no autograd: ~10 s)."""
+    from svgp_vae_amd import sprites as S
+    b, frames, L, La, Lc, n_act, m = 500, 50, 64, 8, 16, 72, 800
+    g = torch.Generator().manual_seed(500)
+    params = {k: torch.tensor(v, dtype=DT) for k, v in SO.glorot_init(L, Lc, 0).items()}
+    gp = dict(inducing_index_points=torch.randn(m, La + Lc, dtype=DT, generator=g) * 1.5,
+              GPLVM_action=torch.randn(n_act, La, dtype=DT, generator=g) * 1.5,
+              l_action=torch.tensor(1.0, dtype=DT), sigma_action=torch.tensor(1.0, dtype=DT),
+              l_character=torch.tensor(1.0, dtype=DT), sigma_character=torch.tensor(1.0, dtype=DT))
+    images = torch.rand(b, 64, 64, 3, dtype=DT, generator=g)
+    ids = torch.randint(0, n_act, (b,), generator=g)
+    eps = torch.randn(b, L, dtype=DT, generator=g)
+    seg, rep = SO.aux_data_sprites_utils(b, frames, frames)
+    jitter, N_train = 0.01, 50000.0
+    ogp = dict(ip=gp["inducing_index_points"], GPLVM_action=gp["GPLVM_action"], jitter=jitter, N_train=N_train, L_action=La,
+               K_obj_normalize=True, K_SE=False, se=None)
+    with torch.no_grad():
+        want = SO.forward_pass_SVGPVAE_sprites((images, ids), 0.001, params, ogp, torch.tensor(0.0, dtype=DT),
+                                               torch.tensor(1.0, dtype=DT), 0.0, math.sqrt(0.0075), L=L, segment_ids=seg,
+                                               repeats=rep, epsilon=eps, clipping_qs=False, GECO=True,
+                                               formulation="efficient")
+    svgp = S.spritesSVGP(False, False, gp["inducing_index_points"].numpy(), 'main', jitter, N_train, La,
+                         gp["GPLVM_action"].numpy(), Lc, L, fixed_GP_params=False, fixed_GPLVM=False,
+                         K_obj_normalize=True, K_SE=False)
+    eng = S.SpritesStepEngine(S.spritesVAE(L), S.sprites_representation_network(Lc), svgp, b_max=b, seg_len=frames,
+                              clip_qs=False, geco=True, kappa_squared=0.0075, beta=0.001, clip_grad=1e6, params=dict(params),
+                              net_dtype=net_dtype)
+    eng.set_scalars(c_ma=0.0, lagrange=1.0, alpha=0.0)
+    dev = eng.dev
+    eng.step(images.to(dev, eng.ndt), ids.to(dev, DT), eps.to(dev), adam=False)
+    got = eng.outputs()
+    f32 = net_dtype == torch.float32
+    tol_s, tol_t = (1e-5, 2e-4) if f32 else (1e-8, 1e-6)          # float32 networks: tests/test_gpu_f32.py's stated tolerances
+    for i in (0, 1, 2, 3, 4):                                     # elbo (GECO loss), recon_loss, KL_term, inside_elbo, ce_term
+        assert abs(float(got[i]) - float(want[i])) <= tol_s * max(1.0, abs(float(want[i]))), (i, float(got[i]), float(want[i]))
+    assert H.relerr(got[5], want[5]) < tol_t and H.relerr(got[6], want[6]) < tol_t            # p_m, p_v
+    assert H.relerr(got[9], want[9]) < (2e-4 if f32 else 1e-7)                                # reconstructed frames
+    g_ = eng.grads
+    assert all(torch.isfinite(v).all() for v in g_.values())
+
+
 def test_config5_shard_properties_at_full_size():
     """N = 131072 rows (one GPU's share of 2^20), m = 2048, L = 16, float32: K_nm build + S_l / v_l statistics."""
     from svgp_vae_amd import stream_stats as SS

@@ -79,6 +79,21 @@ def test_sprites_test_character_pipeline(K_SE):
     # end to end with the float32 streaming statistics
     assert _rel(rec, rec_o) < 2e-3
     assert abs(float(loss) - float(loss_o)) < 1e-3 * float(loss_o)
+    # context_full_actions=False (:1149-1151): N_context of a character's N_actions frames chosen at random -- the draw as an input
+    draw = np.stack([np.random.RandomState(7 + i).choice(N_actions, N_context, replace=False) for i in range(bt // N_actions)])
+    rec_o3, tgt_o3, loss_o3, _, _, _ = SO.predict_SVGPVAE_sprites_test_character(
+        (test_frames, test_ids), params, osvgp, mt_o, inv_o, N_context, N_actions, bt, cseg, crep, Kmm_inv, eps, L, context_draw=draw)
+    rec3, tgt3, loss3 = S.predict_SVGPVAE_sprites_test_character((test_frames, test_ids), vae, svgp, rnn, mt_o, inv_o, N_context,
+                                                                 N_actions, bt, cseg, crep, Kmm_inv, context_full_actions=False,
+                                                                 epsilon=eps, engine=eng, context_draw=draw)
+    assert torch.equal(tgt3.cpu(), tgt_o3) and not torch.equal(tgt3.cpu(), tgt_o)
+    assert _rel(rec3, rec_o3) < 1e-8 and abs(float(loss3) - float(loss_o3)) < 1e-8 * float(loss_o3)
+    # ... and drawn inside, as the reference does (np.random.choice): reproducible under np.random.seed, same split sizes
+    np.random.seed(5)
+    rec4, tgt4, _ = S.predict_SVGPVAE_sprites_test_character((test_frames, test_ids), vae, svgp, rnn, mt_o, inv_o, N_context,
+                                                             N_actions, bt, cseg, crep, Kmm_inv, context_full_actions=False,
+                                                             epsilon=eps, engine=eng)
+    assert tgt4.shape == tgt3.shape and torch.isfinite(rec4).all()
 
 
 def test_sprites_cli_driver_end_to_end(tmp_path):
@@ -97,6 +112,14 @@ def test_sprites_cli_driver_end_to_end(tmp_path):
     assert log["recon_loss"][-1] < log["recon_loss"][0]
     assert len(log["cgen_mse"]) == 2 and all(np.isfinite(v) and v > 0 for _, v in log["cgen_mse"])
     assert len(log["recon_mse_test"]) == 2 and all(np.isfinite(v) and v > 0 for _, v in log["recon_mse_test"])
+    # --PCA (SPRITES_experiment.py:96-99): GPLVM action vectors and inducing points from sprites_PCA_init on the training set
+    args2 = E.build_parser().parse_args(
+        ["--elbo", "SVGPVAE_Hensman", "--synthetic", "6,2", "--N_actions", "8", "--frames_per_character", "5",
+         "--batch_size", "10", "--batch_size_test_char", "16", "--N_context", "3", "--L", "8", "--L_action", "8",
+         "--L_character", "16", "--m", "2", "--object_kernel_normalize", "--GECO", "--clip_qs", "--ip_joint", "--GPLVM_joint",
+         "--PCA", "--opt_regime", "joint-2", "--eval_every", "2", "--lr", "0.002", "--base_dir", str(tmp_path)])
+    log2 = E.run_experiment_sprites_SVGPVAE(args2)
+    assert len(log2["elbo"]) == 2 and all(np.isfinite(log2["elbo"]))
     files = glob.glob(str(tmp_path) + "/debug_SPRITES/*/pics/test_metrics.txt")
     assert files and len(open(files[0]).read().strip().splitlines()) == 2
     with pytest.raises(NotImplementedError):

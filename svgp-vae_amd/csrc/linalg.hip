@@ -242,6 +242,19 @@ __global__ __launch_bounds__(256, 2) void k_gemm_batched(GemmArgs g) {
                                            reinterpret_cast<TC*>(hs_raw));
 }
 
+// Rectangular tiles 32 WM x 32 WN: twice the workgroups of the next larger square tile for problems that would otherwise put one
+// workgroup on a CU (256^3 x 16 with 64-tiles, 1024 x 256 x 256 x 16 with 128-tiles: config 3's products)
+template <bool TA, bool TB, int WM, int WN, typename TS, typename TC, bool VEC>
+__global__ __launch_bounds__(256, 2) void k_gemm_rect(GemmArgs g) {
+    extern __shared__ __align__(16) unsigned char hs_raw[];
+    const int total = g.tiles_n * g.tiles_m * g.batch, per = (total + 7) / 8;
+    const int lid = g.xcd_remap ? (int)(blockIdx.x % 8) * per + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    if (lid >= total) return;
+    const int l = lid / (g.tiles_n * g.tiles_m), tt = lid % (g.tiles_n * g.tiles_m);
+    gemm_tile<TA, TB, WM, WN, TS, TC, VEC>(g, l, (tt / g.tiles_n) * 32 * WM, (tt % g.tiles_n) * 32 * WN,
+                                           reinterpret_cast<TC*>(hs_raw));
+}
+
 // Mixed tiling for extents that are not multiples of 128: full 128 x 128 tiles in the interior and ONE row / column of
 // 32 E-wide edge tiles (E = 1, 2: remainders up to 32 / 64; larger remainders take a bounds-checked full tile) in the same
 // launch -- m = 800 = 6 x 128 + 32 runs 36 interior tiles at the large-tile rate and pads 13 thin ones instead of padding
@@ -505,10 +518,18 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     const bool mixed = mixed_on && prec == 0 && M >= 128 && N >= 128 && blocks128 >= 192 && (edge_m || edge_n);
     const int edge_w = ((edge_m && rem_m > 32) || (edge_n && rem_n > 32)) ? 2 : 1;
     if (mixed) wt = 4;
+    // rectangular tiles (float64): 128 x 64 where 128-tiles leave fewer than two workgroups per CU, 64 x 32 where 64-tiles do
+    static const int rect_on = [] { const char* e = getenv("SVGP_GEMM_RECT"); return (e && e[0] == '0') ? 0 : 1; }();
+    int rwm = 0, rwn = 0;
+    if (rect_on && prec == 0 && !mixed && !(tri & 1)) {
+        if (wt == 4 && blocks128 < 512 && M % 128 == 0 && N % 64 == 0) { rwm = 4; rwn = 2; }
+        else if (wt == 2 && blocks64 < 512 && M % 64 == 0 && N % 32 == 0) { rwm = 2; rwn = 1; }
+    }
     const int ht = 32 * wt;
     const size_t lds = prec == 0 ? (size_t)4 * GK_OF(wt) * (ht + 2) * sizeof(double) : (size_t)4 * GK_OF(wt) * (ht + 16) * sizeof(float);
     g.tiles_n = (N + ht - 1) / ht; g.tiles_m = (M + ht - 1) / ht; g.batch = batch;
     g.full_m = (mixed && edge_m) ? M / 128 : g.tiles_m; g.full_n = (mixed && edge_n) ? N / 128 : g.tiles_n;
+    if (rwm) { g.tiles_m = (M + 32 * rwm - 1) / (32 * rwm); g.tiles_n = (N + 32 * rwn - 1) / (32 * rwn); }
     g.xcd_remap = 1;     // measured neutral (+-1 %) at 800^3 x 64 and 2048^3 x 16: the Infinity Cache already absorbs the
                          // cross-XCD panel re-fetches; kept because it never hurts and is the layout the hardware deals
     const long long total = (long long)g.tiles_n * g.tiles_m * batch;
@@ -561,12 +582,35 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
         else if (tb) LAUNCH_MX(false, true, E_);       \
         else LAUNCH_MX(false, false, E_);              \
     } while (0)
-    if (mixed) { if (edge_w == 1) LAUNCH_ME(1); else LAUNCH_ME(2); }
+#define LAUNCH_RX(TA_, TB_, WM_, WN_)                                                                                        \
+    do {                                                                                                                 \
+        if (vec) {                                                                                                       \
+            SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_rect<TA_, TB_, WM_, WN_, double, double, true>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+            hipLaunchKernelGGL((k_gemm_rect<TA_, TB_, WM_, WN_, double, double, true>), grid, dim3(256), lds, (hipStream_t)stream, g); \
+        } else {                                                                                                         \
+            SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_rect<TA_, TB_, WM_, WN_, double, double, false>), \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
+            hipLaunchKernelGGL((k_gemm_rect<TA_, TB_, WM_, WN_, double, double, false>), grid, dim3(256), lds, (hipStream_t)stream, g); \
+        }                                                                                                                \
+    } while (0)
+#define LAUNCH_RE(WM_, WN_)                                 \
+    do {                                                    \
+        if (ta && tb) LAUNCH_RX(true, true, WM_, WN_);      \
+        else if (ta) LAUNCH_RX(true, false, WM_, WN_);      \
+        else if (tb) LAUNCH_RX(false, true, WM_, WN_);      \
+        else LAUNCH_RX(false, false, WM_, WN_);             \
+    } while (0)
+    if (rwm == 4) LAUNCH_RE(4, 2);
+    else if (rwm == 2) LAUNCH_RE(2, 1);
+    else if (mixed) { if (edge_w == 1) LAUNCH_ME(1); else LAUNCH_ME(2); }
     else if (prec == 0) LAUNCH_P(double, double);
     else if (prec == 1) LAUNCH_P(double, float);
     else LAUNCH_P(float, float);
 #undef LAUNCH_P
 #undef LAUNCH_ME
+#undef LAUNCH_RE
+#undef LAUNCH_RX
 #undef LAUNCH_MX
 #undef LAUNCH_T
 #undef LAUNCH_G

@@ -200,21 +200,23 @@ bool side_take_early(Side* sd, const void* ws) { std::lock_guard<std::mutex> lk(
 
 }  // namespace
 
-// comm.hip (channel-sharded step): the side branch of the caller's stream
-int svgp_side_branch_fork(void* main_stream, void** side_stream_out) {
+// comm.hip (channel-sharded step, branch 1) / cholesky.hip (look-ahead of the blocked factorisation, branch 0): side branch k
+// of the caller's stream.  _fork: the branch continues after everything issued on the caller's stream so far (re-forking an
+// open branch just adds that dependency); _join: the caller's stream continues after everything issued on the branch.
+int svgp_side_branch_fork(void* main_stream, void** side_stream_out, int k) {
     Side* sd = nullptr;
     int rc = side_get((hipStream_t)main_stream, &sd);
     if (rc) return rc;
-    rc = side_fork(sd, 1, (hipStream_t)main_stream);
+    rc = side_fork(sd, k, (hipStream_t)main_stream);
     if (rc) return rc;
-    *side_stream_out = (void*)sd->s[1];
+    *side_stream_out = (void*)sd->s[k];
     return SVGP_OK;
 }
-int svgp_side_branch_join(void* main_stream) {
+int svgp_side_branch_join(void* main_stream, int k) {
     Side* sd = nullptr;
     int rc = side_get((hipStream_t)main_stream, &sd);
     if (rc) return rc;
-    return side_join(sd, 1, (hipStream_t)main_stream);
+    return side_join(sd, k, (hipStream_t)main_stream);
 }
 
 namespace {

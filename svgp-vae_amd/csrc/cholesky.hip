@@ -252,7 +252,7 @@ inline unsigned nblk256(long long n) { return (unsigned)((n + 255) / 256); }
 extern "C" size_t svgp_potrf_workspace_elems(int m, int batch) {
     if (m < 1 || batch < 0) return 0;
     const size_t nblk = (size_t)(m + CB - 1) / CB;
-    return (size_t)batch * (nblk * CB * CB + (size_t)m * CB);            // L_kk^-1 blocks + one scaled panel
+    return (size_t)batch * (nblk * CB * CB + 2 * (size_t)m * CB);        // L_kk^-1 blocks + two scaled panels (look-ahead)
 }
 extern "C" size_t svgp_trsm_workspace_elems(int m, int n, int batch) {
     if (m < 1 || n < 0 || batch < 0) return 0;
@@ -276,13 +276,23 @@ extern "C" int svgp_potrf_batched(int m, int batch, double* A, int lda, long lon
     hipStream_t s = (hipStream_t)stream;
     const int nblk = (m + CB - 1) / CB;
     real* Linv = work;
-    real* Pn = work + (size_t)batch * nblk * CB * CB;           // (batch, m, 64) scaled panel of the current step
+    real* Pn2 = work + (size_t)batch * nblk * CB * CB;          // 2 x (batch, m, 64): scaled panels of the current / previous step
     SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)DIAG_LDS_BYTES));
     DiagArgs d;
     d.m = m; d.lda = lda; d.batch = batch; d.sA = strideA; d.A = A; d.Linv = Linv; d.nblk = nblk; d.logdet = logdet;
+    // Look-ahead (right-looking with the trailing update split): after panel k is solved, ONLY block column k + 1 is updated on
+    // the caller's stream -- that is all the next diagonal block and the next panel solve need -- and the rest of the trailing
+    // update (columns k + 2 ..) runs on a side branch beside them: a block step costs max(trailing update, column update +
+    // diagonal block + panel solve) instead of their sum (the diagonal block alone is ~50 us on `batch` of 256 CUs; 13 steps at
+    // m = 800).  SVGP_POTRF_LOOKAHEAD=0: everything in line.  Same operations on the same values.
+    static const int la_on = [] { const char* e = getenv("SVGP_POTRF_LOOKAHEAD"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool la = la_on && nblk >= 10;          // (m >= 577: below, the fork / join per block step costs more than it hides: 512 x 16 553 -> 578 us)
+    void* side = stream;
+    bool side_open = false;
     for (int kb = 0; kb < nblk; ++kb) {
         const int r0 = kb * CB, nbk = m - r0 < CB ? m - r0 : CB, rem = m - r0 - nbk;
+        real* Pn = Pn2 + (size_t)(kb & 1) * batch * m * CB;
         d.r0 = r0; d.nbk = nbk; d.first = kb == 0;
         hipLaunchKernelGGL(k_chol_diag, dim3(batch), dim3(256), DIAG_LDS_BYTES, s, d);
         SVGP_LAUNCH_CHECK();
@@ -292,13 +302,30 @@ extern "C" int svgp_potrf_batched(int m, int batch, double* A, int lda, long lon
         // L_ik = A_ik L_kk^-T   (Linv stored row-major: B^T form)
         RUNC(svgp_dgemm_tri_batched(0, 0, 1, rem, nbk, nbk, 1.0, panel, lda, strideA, Linv + (size_t)kb * CB * CB, CB,
                                     (long long)nblk * CB * CB, 0.0, Pn, CB, (long long)m * CB, batch, stream));
-        // A_ij -= L_ik L_jk^T on the tiles that touch the lower triangle
-        RUNC(svgp_dgemm_tri_batched(1, 0, 1, rem, rem, nbk, -1.0, Pn, CB, (long long)m * CB, Pn, CB, (long long)m * CB, 1.0,
-                                    trail, lda, strideA, batch, stream));
         hipLaunchKernelGGL(k_copy_block, dim3(nblk256((long long)rem * nbk), batch), dim3(256), 0, s, rem, nbk, Pn, CB,
                            (long long)m * CB, panel, lda, strideA);
         SVGP_LAUNCH_CHECK();
+        const int nb1 = rem < CB ? rem : CB, rem2 = rem - nb1;   // next block column / what lies beyond it
+        if (!la || rem2 == 0) {
+            if (side_open) { RUNC(svgp_side_branch_join(stream, 0)); side_open = false; }
+            // A_ij -= L_ik L_jk^T on the tiles that touch the lower triangle
+            RUNC(svgp_dgemm_tri_batched(1, 0, 1, rem, rem, nbk, -1.0, Pn, CB, (long long)m * CB, Pn, CB, (long long)m * CB, 1.0,
+                                        trail, lda, strideA, batch, stream));
+            continue;
+        }
+        // the previous step's side update wrote column k + 1 too: it must be complete before this step's column update
+        if (side_open) RUNC(svgp_side_branch_join(stream, 0));
+        // column k + 1 (rows r1 .., nb1 columns): A[r1:, r1:r1+nb1] -= Pn[r1-rows] Pn[block k + 1 rows]^T
+        RUNC(svgp_dgemm_tri_batched(1, 0, 1, rem, nb1, nbk, -1.0, Pn, CB, (long long)m * CB, Pn, CB, (long long)m * CB, 1.0,
+                                    trail, lda, strideA, batch, stream));
+        // columns k + 2 ..: on the side branch (forked here: after the panel solve and, through stream order, after the join)
+        RUNC(svgp_side_branch_fork(stream, &side, 0));
+        side_open = true;
+        RUNC(svgp_dgemm_tri_batched(1, 0, 1, rem2, rem2, nbk, -1.0, Pn + (size_t)nb1 * CB, CB, (long long)m * CB,
+                                    Pn + (size_t)nb1 * CB, CB, (long long)m * CB, 1.0, trail + (size_t)nb1 * lda + nb1, lda, strideA,
+                                    batch, side));
     }
+    if (side_open) RUNC(svgp_side_branch_join(stream, 0));
     hipLaunchKernelGGL(k_zero_upper, dim3(nblk256((long long)m * m), batch), dim3(256), 0, s, m, lda, strideA, A);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;

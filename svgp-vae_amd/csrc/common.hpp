@@ -38,8 +38,8 @@ void svgp_set_error(const char* fmt, ...);
     } while (0)
 
 // api.hip: fork / join of the library-owned side branch of a caller stream (one per (device, stream))
-int svgp_side_branch_fork(void* main_stream, void** side_stream_out);
-int svgp_side_branch_join(void* main_stream);
+int svgp_side_branch_fork(void* main_stream, void** side_stream_out, int k = 1);
+int svgp_side_branch_join(void* main_stream, int k = 1);
 int svgp_mnist_step_phase_deferred(const svgp_mnist_cfg* c, int phase, double* theta, const double* images,
                                    const double* aux, const double* eps, double* ws, double* state, double* adam_m,
                                    double* adam_v, void* stream);

@@ -104,6 +104,18 @@ def committed_traffic(kernel_key):
         return None, None
 
 
+def committed_step_traffic(workload):
+    """HBM bytes of ONE optimiser step of `workload` (cfg2 / cfg3 / sp800) from the newest committed PMC summary that has it."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            w = json.load(open(path)).get("workloads", {}).get(workload)
+            if w:
+                return w["hbm_bytes_per_step_corrected"], os.path.relpath(path, ROOT)
+        except Exception:
+            pass
+    return None, None
+
+
 def cpu_worker_call(kind, threads, budget_s, extra=()):
     """Runs one CPU-baseline leg in a CHILD process whose OpenMP / MKL thread count is fixed by the environment before
     torch is imported.  (torch.set_num_threads after the pools exist is not safe with this build: on the GPU box the
@@ -409,7 +421,7 @@ def run_mnist(args):
         coll_us = [round(float(x), 1) for x in med.cpu()]
     # per-stage HIP-event timings of this rank's launches (rank-local kernels, no collective inside): every rank runs
     # them so that nobody waits on rank 0, rank 0 reports
-    stage_rows = time_stages(eng, B, M_IND, reps=20 if cfg3 else 50)
+    stage_rows = time_stages(eng, B, M_IND, reps=(1 if os.environ.get("SVGP_BENCH_NO_STAGES") else 20 if cfg3 else 50))
     if multi:
         dist.barrier()
 
@@ -451,6 +463,7 @@ def run_mnist(args):
                                  "frac": sf / (el / args.steps) / 1e12 / F64_PEAK_TFLOPS,
                                  "flops_model": "SURVEY 8d / Appendix G (the one figure this file uses for the step)",
                                  "stage_sum_flops": step_flops}
+        line["step_roofline"]["traffic"], line["step_roofline"]["traffic_source"] = committed_step_traffic("cfg3" if cfg3 else "cfg2")
         line["stages_us"] = {r["stage"]: round(r["us"], 2) for r in stage_rows}
         line["step_flops"] = step_flops
         if coll_us is not None:
@@ -588,6 +601,7 @@ def run_sprites(args):
                                  "achieved": (nets + gp) / (ms * 1e-3) / 1e12,
                                  "frac": (nets + gp) / (ms * 1e-3) / 1e12 / peak,
                                  "frac_of_f32_peak": (nets + gp) / (ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS}
+        line["step_roofline"]["traffic"], line["step_roofline"]["traffic_source"] = committed_step_traffic("sp800")
         line["stages_us"] = {k: round(v, 1) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
         if coll_us is not None:
             names = (["rs[S|v]", "ag[Si|M2|t|u]", "rs[A2|ud|td]", "ag[Ssym|vbar|KL]", "ar[grad|sums]"] if len(coll_us) == 5

@@ -5,6 +5,7 @@
 // (SVGPVAE_model.py:239,270-274,319,328-341) when the m x m matrices no longer fit in LDS.
 #include "common.hpp"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -94,33 +95,62 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
     // A tile that lies inside the matrix takes its full panels without bounds checks, as one 16-byte load per pair when
     // the host found the operands 16-byte aligned with even leading dimensions (VEC): 60 -> 64 TFLOP/s on exact tiles
     // (tools/micro/gemm_stages.hip), and the checks were worth another 5 %.
-    const bool inside = i0 + HM <= g.M && j0 + HN <= g.N;
+    // A tile whose rows / columns stick out of the matrix still takes the unchecked path: the out-of-range row / column indices are
+    // CLAMPED to the last valid one (their products land in accumulator rows that are never stored).  Only an operand whose
+    // memory-adjacent pair runs along the clamped index needs that extent to be even.
+    const bool a_ok = i0 + HM <= g.M || !TA || g.M % 2 == 0;
+    const bool b_ok = j0 + HN <= g.N || TB || g.N % 2 == 0;
+    const bool tile_fast = a_ok && b_ok && g.M >= 2 && g.N >= 2;
     TC ra[2 * NPA], rb[2 * NPB];
-    auto ldpair = [&](const TS* __restrict__ p, bool ok0, bool ok1, bool fast, TC& v0, TC& v1) {
-        if (fast) {
-            if (VEC) {
-                const TS2 v = *reinterpret_cast<const TS2*>(p);
-                v0 = (TC)v.x; v1 = (TC)v.y;
-            } else {
-                v0 = (TC)p[0]; v1 = (TC)p[1];
-            }
+    auto ldfast = [&](const TS* __restrict__ p, TC& v0, TC& v1) {
+        if (VEC) {
+            const TS2 v = *reinterpret_cast<const TS2*>(p);
+            v0 = (TC)v.x; v1 = (TC)v.y;
         } else {
-            v0 = ok0 ? (TC)p[0] : TC(0);
-            v1 = ok1 ? (TC)p[1] : TC(0);
+            v0 = (TC)p[0]; v1 = (TC)p[1];
         }
     };
+    auto ldchk = [&](const TS* __restrict__ p, bool ok0, bool ok1, TC& v0, TC& v1) {
+        v0 = ok0 ? (TC)p[0] : TC(0);
+        v1 = ok1 ? (TC)p[1] : TC(0);
+    };
+    // one uniform branch per panel: full panel of a clampable tile -> straight-line unchecked loads, else the checked form
+    // (the per-pair branches of a mixed form were ~100 instructions per panel in front of MFMA group 1)
     auto fetch = [&](int k0) {
-        const bool fast = inside && k0 + GK <= g.K;
+        if (tile_fast && k0 + GK <= g.K) {
+#pragma unroll
+            for (int h = 0; h < NPA; ++h) {
+                const int e = tid + 256 * h, kx = e / (HM / 2), xx = 2 * (e % (HM / 2));    // [k][x] map
+                const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;                      // [x][k] map
+                if (TA) ldfast(A + (size_t)(k0 + kx) * g.lda + min(i0 + xx, g.M - 2), ra[2 * h], ra[2 * h + 1]);
+                else ldfast(A + (size_t)min(i0 + xk, g.M - 1) * g.lda + k0 + kk, ra[2 * h], ra[2 * h + 1]);
+            }
+#pragma unroll
+            for (int h = 0; h < NPB; ++h) {
+                const int e = tid + 256 * h, kx = e / (HN / 2), xx = 2 * (e % (HN / 2));
+                const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;
+                if (TB) {
+                    const int gk = k0 + kk;
+                    ldfast(B + (size_t)min(j0 + xk, g.N - 1) * g.ldb + gk, rb[2 * h], rb[2 * h + 1]);
+                    if (wk) { rb[2 * h] *= (TC)wk[(size_t)gk * g.ldw]; rb[2 * h + 1] *= (TC)wk[(size_t)(gk + 1) * g.ldw]; }
+                } else {
+                    const int gk = k0 + kx;
+                    ldfast(B + (size_t)gk * g.ldb + min(j0 + xx, g.N - 2), rb[2 * h], rb[2 * h + 1]);
+                    if (wk) { const TC wv = (TC)wk[(size_t)gk * g.ldw]; rb[2 * h] *= wv; rb[2 * h + 1] *= wv; }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < NPA; ++h) {
             const int e = tid + 256 * h, kx = e / (HM / 2), xx = 2 * (e % (HM / 2));    // [k][x] map
             const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;                      // [x][k] map
             if (TA) {
                 const int gi = i0 + xx, gk = k0 + kx;
-                ldpair(A + (size_t)gk * g.lda + gi, gk < g.K && gi < g.M, gk < g.K && gi + 1 < g.M, fast, ra[2 * h], ra[2 * h + 1]);
+                ldchk(A + (size_t)gk * g.lda + gi, gk < g.K && gi < g.M, gk < g.K && gi + 1 < g.M, ra[2 * h], ra[2 * h + 1]);
             } else {
                 const int gi = i0 + xk, gk = k0 + kk;
-                ldpair(A + (size_t)gi * g.lda + gk, gi < g.M && gk < g.K, gi < g.M && gk + 1 < g.K, fast, ra[2 * h], ra[2 * h + 1]);
+                ldchk(A + (size_t)gi * g.lda + gk, gi < g.M && gk < g.K, gi < g.M && gk + 1 < g.K, ra[2 * h], ra[2 * h + 1]);
             }
         }
 #pragma unroll
@@ -129,14 +159,14 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
             const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;
             if (TB) {
                 const int gj = j0 + xk, gk = k0 + kk;
-                ldpair(B + (size_t)gj * g.ldb + gk, gj < g.N && gk < g.K, gj < g.N && gk + 1 < g.K, fast, rb[2 * h], rb[2 * h + 1]);
+                ldchk(B + (size_t)gj * g.ldb + gk, gj < g.N && gk < g.K, gj < g.N && gk + 1 < g.K, rb[2 * h], rb[2 * h + 1]);
                 if (wk) {
                     rb[2 * h] *= gk < g.K ? (TC)wk[(size_t)gk * g.ldw] : TC(0);
                     rb[2 * h + 1] *= gk + 1 < g.K ? (TC)wk[(size_t)(gk + 1) * g.ldw] : TC(0);
                 }
             } else {
                 const int gj = j0 + xx, gk = k0 + kx;
-                ldpair(B + (size_t)gk * g.ldb + gj, gk < g.K && gj < g.N, gk < g.K && gj + 1 < g.N, fast, rb[2 * h], rb[2 * h + 1]);
+                ldchk(B + (size_t)gk * g.ldb + gj, gk < g.K && gj < g.N, gk < g.K && gj + 1 < g.N, rb[2 * h], rb[2 * h + 1]);
                 if (wk) {
                     const TC wv = gk < g.K ? (TC)wk[(size_t)gk * g.ldw] : TC(0);
                     rb[2 * h] *= wv; rb[2 * h + 1] *= wv;
@@ -178,14 +208,24 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
     if (klo + GK < khi) fetch(klo + GK);
     __syncthreads();
     int cur = 0;
-    for (int k0 = klo; k0 < khi; k0 += GK) {
-        const TC* Ab = As + cur * GK * LDA_ + wi + r;
-        const TC* Bb = Bs + cur * GK * LDB_ + wj + r;
-        TC av[2][WM], bv[2][WN];
+    TC av[2][WM], bv[2][WN];
+    {
+        const TC* Ab = As + wi + r;
+        const TC* Bb = Bs + wj + r;
 #pragma unroll
         for (int a = 0; a < WM; ++a) av[0][a] = Ab[q * LDA_ + 16 * a];
 #pragma unroll
         for (int b = 0; b < WN; ++b) bv[0][b] = Bb[q * LDB_ + 16 * b];
+    }
+    // The one barrier of a panel sits BEFORE its last MFMA group, not after it: by then every wave has issued its last
+    // fragment reads of buffer `cur` (group s + 1 is read before group s issues) and the LDS stores of panel p + 1 (issued
+    // after group 0) are long complete, so the first fragments of panel p + 1 are read from the other buffer under the last
+    // MFMA group and the next panel starts with its operands in registers -- no LDS latency and no barrier wait at the panel
+    // boundary with an empty matrix pipe.
+    for (int k0 = klo; k0 < khi; k0 += GK) {
+        const TC* Ab = As + cur * GK * LDA_ + wi + r;
+        const TC* Bb = Bs + cur * GK * LDB_ + wj + r;
+        const bool more = k0 + GK < khi;
 #pragma unroll
         for (int st = 0; st < GK / 4; ++st) {
             if (st + 1 < GK / 4) {
@@ -193,6 +233,16 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
                 for (int a = 0; a < WM; ++a) av[(st + 1) & 1][a] = Ab[(4 * (st + 1) + q) * LDA_ + 16 * a];
 #pragma unroll
                 for (int b = 0; b < WN; ++b) bv[(st + 1) & 1][b] = Bb[(4 * (st + 1) + q) * LDB_ + 16 * b];
+            } else {
+                __syncthreads();
+                if (more) {
+                    const TC* An = As + (cur ^ 1) * GK * LDA_ + wi + r;
+                    const TC* Bn = Bs + (cur ^ 1) * GK * LDB_ + wj + r;
+#pragma unroll
+                    for (int a = 0; a < WM; ++a) av[0][a] = An[q * LDA_ + 16 * a];
+#pragma unroll
+                    for (int b = 0; b < WN; ++b) bv[0][b] = Bn[q * LDB_ + 16 * b];
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -201,12 +251,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
                 for (int b = 0; b < WN; ++b) acc[a][b] = MF::mma(av[st & 1][a], bv[st & 1][b], acc[a][b]);
             __builtin_amdgcn_sched_barrier(0);
             if (st == 0) {
-                if (k0 + GK < khi) stage(cur ^ 1);
+                if (more) stage(cur ^ 1);
                 if (k0 + 2 * GK < khi) fetch(k0 + 2 * GK);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        __syncthreads();
         cur ^= 1;
     }
     const bool has_beta = g.beta != real(0);

@@ -523,7 +523,10 @@ def run_sprites(args):
     eng = S.SpritesStepEngine(S.spritesVAE(L_), S.sprites_representation_network(Lc), svgp, b_max=b, seg_len=frames,
                               geco=True, kappa_squared=0.0075, clip_grad=1e6, device=f"cuda:{local_rank}", rank=rank,
                               world_size=world, comm=comm, net_dtype=torch.float32 if f32 else torch.float64,
-                              gemm_f32=args.gemm_f32)
+                              gemm_f32=args.gemm_f32,
+                              # --force-comm on one GPU: the channel-sharded sequence of a multi-rank step (five grouped exchange
+                              # points, tile-packed blocks, window = all channels) through a 1-rank communicator
+                              channel_shard=True if (args.force_comm and not multi) else None)
     dev = eng.dev
     d_img, d_ids, d_eps = img.to(dev, eng.ndt), ids.to(dev), eps.to(dev)
     # parity gate (N = 1): explicit-eps step, ELBO against the oracle's efficient formulation -- inside cpu_baseline

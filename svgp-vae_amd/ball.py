@@ -72,6 +72,18 @@ def MSE_rotation(X, Y, VX=None):
     return X_rot, W, MSE, VX_rot
 
 
+def _mm(A, B, tb=False, stream=None):
+    """A (M,K) @ B (K,N) (or B^T with tb: B stored (N,K)) on the library's float64 MFMA GEMM (svgp_dgemm_batched)."""
+    A, B = A.contiguous(), B.contiguous()
+    M, K = A.shape
+    N = B.shape[0] if tb else B.shape[1]
+    out = torch.empty(M, N, dtype=_F64, device=A.device)
+    s = torch.cuda.current_stream(A.device).cuda_stream if stream is None else stream
+    call("svgp_dgemm_batched", 0, int(tb), M, N, K, 1.0, A.data_ptr(), A.shape[1], 0, B.data_ptr(), B.shape[1], 0, 0.0,
+         out.data_ptr(), N, 0, 1, s)
+    return out
+
+
 class VideoBatchSource:
     """build_video_batch_graph (utils.py:138-192): a fresh batch of ball videos per call, synthesised on the device:
     paths = chol(K_SE(lt) + 1e-5 I) N(0,1), scaled 0.2 px + 0.5 px, rasterised by svgp_ball_rasterize."""
@@ -88,7 +100,7 @@ class VideoBatchSource:
 
     def __call__(self, stream=None):
         ran_Z = torch.randn(self.tmax, 2 * self.batch, dtype=_F64, device=self.dev, generator=self.gen)
-        paths = (self.chol_K @ ran_Z).reshape(self.tmax, self.batch, 2).permute(1, 0, 2).contiguous()
+        paths = _mm(self.chol_K, ran_Z).reshape(self.tmax, self.batch, 2).permute(1, 0, 2).contiguous()
         paths = paths * 0.2 * self.px + 0.5 * self.px
         vid = torch.empty(self.batch, self.tmax, self.px, self.py, dtype=_F64, device=self.dev)
         s = torch.cuda.current_stream(self.dev).cuda_stream if stream is None else stream
@@ -395,7 +407,7 @@ class BallStepEngine(_BallMlpEngine):
             Kn, Ki, Si = self._v(c, "Kn", (T, m)), self._v(c, "Ki", (m, m)), self._v(c, "Si", (B, m, m))
             t = self.times
             Knn = torch.exp(-0.5 * (t[:, None] - t[None, :]) ** 2 / p[f"l_{cn}"] ** 2)
-            cov.append(Knn - Kn @ Ki @ Kn.t() + Kn @ Si.mean(0) @ Kn.t())
+            cov.append(Knn - _mm(_mm(Kn, Ki), Kn, tb=True) + _mm(_mm(Kn, Si.mean(0)), Kn, tb=True))
         return (o["elbo"], o["recon"], o["KL_term"], o["inside_elbo"], o["ce_term"], full_p_mu, full_p_var, qnet_mu,
                 qnet_var, self.act["pred"], p["l_x"][0].clone(), p["l_y"][0].clone(), o["inside_elbo_recon"],
                 o["inside_elbo_kl"], p["ip_x"].clone(), p["ip_y"].clone(), cov[0], cov[1], self)

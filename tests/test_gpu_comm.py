@@ -188,3 +188,16 @@ def test_bench_multi_gpu_code_path_at_world_size_one():
         assert r.returncode == 0, r.stderr[-2000:]
         line = json.loads(r.stdout.strip().splitlines()[-1])
         assert line["n_gpus"] == 1 and line["value"] > 100 and "RCCL" in line["config"]["launch"]
+        assert "block_ms_min" in line and "block_outliers" in line
+        if ex == "rccl":      # per-exchange-point event timing of the in-library form (svgp_comm_timing)
+            assert line["config"]["rccl_ranks"] == 1
+            assert list(line["collectives_us"]) == ["ar[S|v]", "ar[A2|ud|td]", "ar[grad|sums]"]
+            assert all(0 < v < 1e4 for v in line["collectives_us"].values())
+    # config 3 (channel-sharded sequence: five grouped points) through the same code path
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "cfg3", "--steps", "5",
+           "--warmup", "2", "--repeats", "1", "--no-cpu-baseline", "--force-dist"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert len(line["collectives_us"]) == 5 and line["elbo_rel_err_gpu_vs_oracle"] < 1e-6

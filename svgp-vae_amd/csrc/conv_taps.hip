@@ -830,6 +830,189 @@ __global__ __launch_bounds__(256) void k_conv16_wgrad(ConvLaunch L, int nwg, int
     }
 }
 
+// =====================================================================================================================
+// Thin layers (3 input OR 3 output channels: the first encoder / representation layers, the last decoder layer): with one
+// 16 x 16 x 4 MFMA per (tap, 4 channels) thirteen of sixteen rows or columns of every MFMA are padding.  Here the TAPS go into a
+// GEMM index instead, gathered per lane:
+//   forward / data gradient, nt * Ci <= 32:   out^T[co][pixel] = sum_k W[k = (t, ci)][co] * in[pixel (+) t][ci]
+//       B operand lane (r = pixel, q): k = 4 s + q -> its own (tap, channel): one dword gather per k-step of 4; 7 MFMAs per 16
+//       pixels for 3 x 3 x 3 instead of 9 + an LDS halo tile; output as one 4-vector store per lane.
+//   weight gradient, nt * Ci <= 32 (MODE 0):  dW[(t, ci)][co] = sum_pix dpre[pix][co] * in[pix (+) t][ci]
+//       A = dpre [co][pixel] (16 channels contiguous; ELU', in-place store and bias sum fused as in k_conv16_wgrad), B = the
+//       gathered input, N = (t, ci) in one or two 16-column blocks: 2 MFMAs per 4 pixels instead of 9.
+//   weight gradient, Ci = 16, nt * Co <= 32, stride 1 (MODE 1):  dW[ci][(t, co)] = sum_pix' in[pix'][ci] * dpre[pix' (-) t][co]
+//       (the sum re-indexed over INPUT pixels, so the 16-channel operand is tap-independent): A = in, B = the gathered dpre
+//       (ELU' applied by a separate pass over the 3-channel tensor).
+// =====================================================================================================================
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void k_convS_fwd(svgp_conv_desc d, int ntask, int nseg, int RW, const T* __restrict__ in,
+                                                   const T* __restrict__ w, const T* __restrict__ bias, T* __restrict__ out) {
+    typedef SvgpMfma<T> MF;
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, q = lane >> 4;
+    int b = blockIdx.x;
+    const int G = (int)gridDim.x;
+    { const int per8 = G >> 3; if ((per8 << 3) == G) b = (b & 7) * per8 + (b >> 3); }
+    const int per = (ntask + G - 1) / G, t_beg = b * per, t_end = min(ntask, t_beg + per);
+    const int co_a = DirT<T>::corow(r), co_c = min(co_a, d.Co - 1), KT = d.nt * d.Ci;
+    // per k-step: this lane's (tap, channel) and the weight it multiplies
+    T wr[KS];
+    int koy[KS], kox[KS], kci[KS];
+    bool kok[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k = 4 * s + q, kc = min(k, KT - 1), t = kc / d.Ci, ci = kc - t * d.Ci;
+        kok[s] = k < KT;
+        koy[s] = d.oy[t]; kox[s] = d.ox[t]; kci[s] = ci;
+        const T v = w[d.woff[t] + ci * d.Co + co_c];
+        wr[s] = (kok[s] && co_a < d.Co) ? v : T(0);
+    }
+    v4 bv = {0, 0, 0, 0};
+    if (d.act)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const T v = bias[min(4 * q + g, d.Co - 1)]; bv[g] = (4 * q + g < d.Co) ? v : T(0); }
+    const T* zp = reinterpret_cast<const T*>(g_conv_zero);
+    const int strips = (d.Hs + 4 * RW - 1) / (4 * RW);
+    for (int task = t_beg; task < t_end; ++task) {
+        const int xs = task % nseg, st = (task / nseg) % strips, n = task / (nseg * strips);
+        const int px = xs * 16 + r;
+        const T* inn = in + (size_t)n * d.Hi * d.Wi * d.Ci;
+        const int ya = (st * 4 + wave) * RW, yb = min(d.Hs, ya + RW);
+        const bool vx = px < d.Ws;
+        for (int y = ya; y < yb; ++y) {
+            T f[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int yi = y * d.sy + koy[s], xi = px * d.sx + kox[s];
+                const bool ok = kok[s] && vx && (unsigned)yi < (unsigned)d.Hi && (unsigned)xi < (unsigned)d.Wi;
+                f[s] = *(ok ? inn + ((size_t)yi * d.Wi + xi) * d.Ci + kci[s] : zp);
+            }
+            typename MF::acc_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s & 1) acc1 = MF::mma(wr[s], f[s], acc1);
+                else acc0 = MF::mma(wr[s], f[s], acc0);
+            }
+            if (vx) {
+                v4 v;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    T e = acc0[g] + acc1[g];
+                    if (d.act) e += bv[g];
+                    if (d.act == 1) e = e > 0 ? e : (T)(conv_exp(e) - T(1));
+                    v[g] = e;
+                }
+                T* o = out + (((size_t)n * d.Ho + (y * d.osy + d.ooy)) * d.Wo + (px * d.osx + d.oox)) * d.Co;
+                if (d.Co == 16) {
+                    *reinterpret_cast<v4*>(o + 4 * q) = v;
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) if (4 * q + g < d.Co) o[4 * q + g] = v[g];
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int NB, int MODE>
+__global__ __launch_bounds__(256) void k_convS_wgrad(svgp_conv_desc d, int nwg, int RW, const T* __restrict__ in,
+                                                     const T* __restrict__ outv, T* __restrict__ dout, T* __restrict__ part,
+                                                     int part_stride, T* __restrict__ part_b) {
+    typedef SvgpMfma<T> MF;
+    __shared__ T red[1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, q = lane >> 4;
+    // MODE 0: rows i = co (A = dpre), columns j = (t, ci) (B = gathered input), iteration over OUTPUT pixels
+    // MODE 1: rows i = ci (A = input), columns j = (t, co) (B = gathered dpre), iteration over INPUT pixels (stride 1)
+    const int CB = MODE == 0 ? d.Ci : d.Co, JT = d.nt * CB;
+    const int Hit = MODE == 0 ? d.Hs : d.Hi, Wit = MODE == 0 ? d.Ws : d.Wi;
+    int joy[NB], jox[NB], jc[NB];
+    bool jok[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int j = 16 * nb + r, jcl = min(j, JT - 1), t = jcl / CB;
+        jok[nb] = j < JT;
+        joy[nb] = d.oy[t]; jox[nb] = d.ox[t]; jc[nb] = jcl - t * CB;
+    }
+    typename MF::acc_t acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = typename MF::acc_t{0, 0, 0, 0};
+    T bsum = 0;
+    const T* zp = reinterpret_cast<const T*>(g_conv_zero);
+    const int nseg = (Wit + 15) / 16, nrb = (Hit + RW - 1) / RW, ntask = d.n * nrb * nseg;
+    for (int task = blockIdx.x * 4 + wave; task < ntask; task += nwg * 4) {
+        const int xs = task % nseg, rb = (task / nseg) % nrb, n = task / (nseg * nrb);
+        const T* inn = in + (size_t)n * d.Hi * d.Wi * d.Ci;
+        T* dn = dout + (size_t)n * d.Ho * d.Wo * d.Co;
+        const T* on = outv ? outv + (size_t)n * d.Ho * d.Wo * d.Co : nullptr;
+        const int ya = rb * RW, yb = min(Hit, ya + RW), xf = xs * 16;
+        for (int y = ya; y < yb; ++y) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int x = xf + 4 * s + q;
+                const bool vx = x < Wit;
+                T av;
+                if (MODE == 0) {
+                    // A = dpre[pixel (y, x)][co = r]: ELU' fused, written back in place, bias sum
+                    const bool ok = vx && r < d.Co;
+                    const size_t o = ((size_t)(y * d.osy + d.ooy) * d.Wo + (min(x, Wit - 1) * d.osx + d.oox)) * d.Co + min(r, d.Co - 1);
+                    T dv = *(ok ? dn + o : zp);
+                    if (on) { const T ov = on[o]; dv *= (ov > 0 ? T(1) : ov + T(1)); if (ok) dn[o] = dv; }
+                    bsum += dv;
+                    av = dv;
+                } else {
+                    av = *(vx ? inn + ((size_t)y * d.Wi + x) * d.Ci + r : zp);           // A = in[pixel'][ci = r], Ci == 16
+                }
+                T bvv[NB];
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    if (MODE == 0) {
+                        const int yi = y * d.sy + joy[nb], xi = x * d.sx + jox[nb];
+                        const bool ok = jok[nb] && vx && (unsigned)yi < (unsigned)d.Hi && (unsigned)xi < (unsigned)d.Wi;
+                        bvv[nb] = *(ok ? inn + ((size_t)yi * d.Wi + xi) * d.Ci + jc[nb] : zp);
+                    } else {
+                        const int yo = y - joy[nb], xo = x - jox[nb];                    // output pixel whose tap t reads (y, x)
+                        const bool ok = jok[nb] && vx && (unsigned)yo < (unsigned)d.Hs && (unsigned)xo < (unsigned)d.Ws;
+                        bvv[nb] = *(ok ? dn + ((size_t)(yo * d.osy + d.ooy) * d.Wo + (xo * d.osx + d.oox)) * d.Co + jc[nb] : zp);
+                    }
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = MF::mma(av, bvv[nb], acc[nb]);
+            }
+        }
+    }
+    // cross-wave combine (fixed order); D: column j = r (+ 16 nb), row i = MF::row(q, g)
+    T* po = part + (size_t)blockIdx.x * part_stride;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[(wave * 64 + lane) * 4 + g] = acc[nb][g];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const T v = red[lane * 4 + g] + red[(64 + lane) * 4 + g] + red[(128 + lane) * 4 + g] + red[(192 + lane) * 4 + g];
+                const int i = MF::row(q, g), j = 16 * nb + r;
+                if (j < JT) {
+                    const int t = j / CB, c = j - t * CB;
+                    const int ci = MODE == 0 ? c : i, co = MODE == 0 ? i : c;
+                    if (ci < d.Ci && co < d.Co) po[d.woff[t] + ci * d.Co + co] = v;
+                }
+            }
+        }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        red[threadIdx.x] = bsum;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            T v = 0;
+            for (int k = 0; k < 16; ++k) v += red[k * 16 + threadIdx.x];
+            part_b[(size_t)blockIdx.x * 16 + threadIdx.x] = v;
+        }
+    }
+}
+
 size_t fwd_lds(const svgp_conv_desc& d) {
     int oy0 = d.oy[0], oy1 = d.oy[0], ox0 = d.ox[0], ox1 = d.ox[0];
     for (int t = 1; t < d.nt; ++t) {
@@ -966,6 +1149,38 @@ static int conv16_fwd_launch(const svgp_conv_desc* d, int ncls, const T* in, con
     return SVGP_OK;
 }
 
+// ---- thin layers (k_convS_*)
+static bool convS_fwd_ok(const svgp_conv_desc* d, int ncls) {
+    if (!conv16_enabled()) return false;
+    for (int c = 0; c < ncls; ++c)
+        if (d[c].Ci >= 16 || d[c].nt * d[c].Ci > 32) return false;
+    return true;
+}
+template <typename T>
+static int convS_fwd_launch(const svgp_conv_desc* d, int ncls, const T* in, const T* w, const T* bias, T* out, void* stream) {
+    for (int c = 0; c < ncls; ++c) {
+        const svgp_conv_desc& dc = d[c];
+        SVGP_REQUIRE(!dc.act || bias, SVGP_ERR_INVALID, "bias is NULL but act != 0");
+        const int RW = conv16_rows(dc), strips = (dc.Hs + 4 * RW - 1) / (4 * RW), nseg = (dc.Ws + 15) / 16;
+        const int ntask = dc.n * strips * nseg, KS = (dc.nt * dc.Ci + 3) / 4;
+        const dim3 grid((unsigned)(ntask < 2048 ? ntask : 2048));
+#define CSF(KS_) hipLaunchKernelGGL((k_convS_fwd<T, KS_>), grid, dim3(256), 0, (hipStream_t)stream, dc, ntask, nseg, RW, in, w, bias, out)
+        switch (KS) {
+        case 1: CSF(1); break;
+        case 2: CSF(2); break;
+        case 3: CSF(3); break;
+        case 4: CSF(4); break;
+        case 5: CSF(5); break;
+        case 6: CSF(6); break;
+        case 7: CSF(7); break;
+        default: CSF(8); break;
+        }
+#undef CSF
+        SVGP_LAUNCH_CHECK();
+    }
+    return SVGP_OK;
+}
+
 template <typename T>
 static int conv_taps_fwd_impl(const svgp_conv_desc* d, int ncls, const T* in, const T* w, const T* bias, T* out,
                               void* stream) {
@@ -983,6 +1198,7 @@ static int conv_taps_fwd_impl(const svgp_conv_desc* d, int ncls, const T* in, co
                      SVGP_ERR_INVALID, "the classes of one launch share the input geometry (n, Hs, Ws, strides, Ci, Co, act)");
     }
     if (conv16_direct_ok(d, ncls, false)) return conv16_fwd_launch<T>(d, ncls, in, w, bias, out, stream);
+    if (convS_fwd_ok(d, ncls)) return convS_fwd_launch<T>(d, ncls, in, w, bias, out, stream);
     // union halo tile of all classes + the packed tap weights of every class
     size_t lds = fwd_lds_all(d, ncls);
     for (int c = 0; c < ncls; ++c) lds += (size_t)d[c].nt * ((d[0].Ci + 3) & ~3) * 16;
@@ -1054,6 +1270,45 @@ static int conv_wgrad_fused_impl(const svgp_conv_desc* d, int ncls, const T* in,
     int rc = check_desc(d, ncls);
     if (rc) return rc;
     SVGP_REQUIRE(in && dout && part && part_b && dw && db && nwg >= 1 && part_stride >= 1, SVGP_ERR_INVALID, "bad argument");
+    // thin layers: the taps in a GEMM index (k_convS_wgrad)
+    {
+        bool m0 = conv16_enabled(), m1 = conv16_enabled() && ncls == 1;
+        for (int c = 0; c < ncls; ++c) {
+            if (d[c].Ci >= 16 || d[c].nt * d[c].Ci > 32) m0 = false;
+            if (d[c].Ci != 16 || d[c].nt * d[c].Co > 32 || d[c].sy != 1 || d[c].sx != 1 || d[c].osy != 1 || d[c].osx != 1 ||
+                d[c].ooy || d[c].oox || d[c].Hs != d[c].Ho || d[c].Ws != d[c].Wo) m1 = false;
+        }
+        if (m0 || m1) {
+            int nw = nwg > 1024 ? 1024 : nwg;
+            if (m1) {       // ELU' + bias sums by their own pass over the thin dout; the kernel then gathers dpre
+                rc = elu_bwd_bias_impl<T>((long long)d[0].n * d[0].Ho * d[0].Wo, d[0].Co, outv, dout, part_b, db, stream);
+                if (rc) return rc;
+            } else if (nw * ncls > 1024) {
+                nw = 1024 / ncls;
+            }
+            SVGP_CHECK_HIP(hipMemsetAsync(part, 0, (size_t)nw * part_stride * sizeof(T), (hipStream_t)stream));
+            for (int c = 0; c < ncls; ++c) {
+                const svgp_conv_desc& dc = d[c];
+                const int RW = conv16_rows(dc), NB = ((m0 ? dc.nt * dc.Ci : dc.nt * dc.Co) + 15) / 16;
+                T* pb = part_b + (size_t)c * nw * 16;
+#define CSW(NB_, MODE_) hipLaunchKernelGGL((k_convS_wgrad<T, NB_, MODE_>), dim3(nw), dim3(256), 0, (hipStream_t)stream, dc, nw, RW, in,  \
+                                           m0 ? outv : (const T*)nullptr, dout, part, part_stride, pb)
+                if (m0) { if (NB == 1) CSW(1, 0); else CSW(2, 0); }
+                else { if (NB == 1) CSW(1, 1); else CSW(2, 1); }
+#undef CSW
+                SVGP_LAUNCH_CHECK();
+            }
+            hipLaunchKernelGGL(k_sum_partials<T>, dim3((part_stride + 15) / 16), dim3(256), 0, (hipStream_t)stream, nw, part_stride,
+                               part_stride, (const T*)part, dw, 0);
+            SVGP_LAUNCH_CHECK();
+            if (m0) {
+                hipLaunchKernelGGL(k_sum_partials<T>, dim3(1), dim3(256), 0, (hipStream_t)stream, nw * ncls, d[0].Co, 16,
+                                   (const T*)part_b, db, 0);
+                SVGP_LAUNCH_CHECK();
+            }
+            return SVGP_OK;
+        }
+    }
     if (!conv16_direct_ok(d, ncls, true)) {
         rc = elu_bwd_bias_impl<T>((long long)d[0].n * d[0].Ho * d[0].Wo, d[0].Co, outv, dout, part_b, db, stream);
         if (rc) return rc;

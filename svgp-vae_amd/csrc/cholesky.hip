@@ -87,6 +87,108 @@ __device__ __forceinline__ void chol64_lds(real (*Ls)[CLD], real (*colk)[CB], re
     __syncthreads();
 }
 
+// The same factorisation on ONE wave with a matrix row per lane (64 float64 registers): per column k every lane publishes its
+// a_ik through the LDS vector, reads the column back as wave-uniform (broadcast) LDS loads and applies
+// a_ij -= (a_ik / a_kk) a_jk to its row -- no workgroup barrier (LDS operations of one wave complete in order), the next
+// column's element is updated and published first so its LDS round trip hides behind the rest of the row update.
+// 2016 FMAs per lane in all (4 cycles each) against 64 x (barrier + LDS round trip + rsqrt chain + 16 FMAs) of chol64_lds:
+// DIAGTIMES in DESIGN.md section 11.  The other three waves wait at the closing barrier.
+#define CHOL_PIN8(r, a) asm volatile("" : "+v"(r[a]), "+v"(r[a + 1]), "+v"(r[a + 2]), "+v"(r[a + 3]), "+v"(r[a + 4]), "+v"(r[a + 5]), \
+                                        "+v"(r[a + 6]), "+v"(r[a + 7]) :: "memory")
+// column k (a template parameter: #pragma unroll gives up on a body this large, and a rolled loop would index the row dynamically).
+// A wave issues in order, so the column is software-pipelined by hand: c1 = a_(k+1)k (published by the previous column right
+// after it was updated) is loaded by the previous column and arrives in `c1`; the pivot a_kk came from lane k's register
+// (v_readlane) and its rsqrt chain ran between the FMAs of the previous column (`ckk`, `rd`).
+__device__ __forceinline__ real chol_lane_bcast(real x, int lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+// fast_rsqrt cut into its dependent stages, so that the caller can place one stage between groups of independent FMAs
+struct RsqPipe { real x, y, a, h, e; };
+__device__ __forceinline__ void rsq_stage(int st, RsqPipe& p) {
+    switch (st) {
+        case 0: p.y = __builtin_amdgcn_rsq(p.x); break;
+        case 1: case 4: p.a = -p.x * p.y; p.h = real(0.5) * p.y; break;
+        case 2: case 5: p.e = fma(p.a, p.y, real(1)); break;
+        case 3: case 6: p.y = fma(p.h, p.e, p.y); break;
+    }
+    asm volatile("" : "+v"(p.y), "+v"(p.a), "+v"(p.h), "+v"(p.e));
+}
+#define RSQ_STAGES 7
+#define CHOL_PIN4(r, a) asm volatile("" : "+v"(r[a]), "+v"(r[a + 1]), "+v"(r[a + 2]), "+v"(r[a + 3]))
+template <int k>
+__device__ __forceinline__ void chol64_wave_col(real (&r)[CB], real (*colk)[CB], real* rdiag, const int i, const real ckk, const real rd,
+                                                const real c1) {
+    const real* ck = colk[k & 1];
+    const real t = i > k ? r[k] * (rd * rd) : real(0);
+    real ckk_n = 0, rd_n = 0, c1_n = 0;
+    constexpr int NQ = CB / 16, q0 = (k + 2) >> 4;
+    real c[16], cn[16];
+    if constexpr (k + 1 < CB) {
+        r[k + 1] -= t * c1;
+        colk[(k + 1) & 1][i] = r[k + 1];
+        asm volatile("" ::: "memory");
+        if constexpr (k + 2 < CB) c1_n = colk[(k + 1) & 1][k + 2];      // the next column's c1 = a_(k+2)(k+1), lane k + 2's store above
+    }                                                                   // (LDS operations of one wave complete in order)
+    if constexpr (q0 < NQ) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[e] = ck[16 * q0 + e];
+    }
+    RsqPipe p = {real(1), real(0), real(0), real(0), real(0)};
+    int st = RSQ_STAGES;
+    if constexpr (k + 1 < CB) {
+        p.x = ckk_n = chol_lane_bcast(r[k + 1], k + 1);
+        st = 0;
+    }
+    // the rest of the row in aligned chunks of 16: the loads of chunk q + 1 are issued before the FMAs of chunk q; the pins keep
+    // each chunk's FMAs where they are written (left alone the compiler lets them sink to their uses with every loaded column
+    // value live: 8 KB of scratch per lane)
+#pragma unroll
+    for (int q = q0; q < NQ; ++q) {
+        if (q + 1 < NQ) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) cn[e] = ck[16 * (q + 1) + e];
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if (16 * q + e >= k + 2) r[16 * q + e] -= t * c[e];
+            if ((e & 3) == 3) {
+                if (e == 15) asm volatile("" ::: "memory");
+                CHOL_PIN4(r, 16 * q + e - 3);
+                if (st < RSQ_STAGES) rsq_stage(st++, p);       // one stage of the next pivot's rsqrt per four FMAs
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) c[e] = cn[e];
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < RSQ_STAGES; ++s2)
+        if (s2 >= st) rsq_stage(s2, p);
+    rd_n = p.y;
+    r[k] = i == k ? ckk * rd : (i > k ? r[k] * rd : r[k]);
+    if (i == 0) rdiag[k] = rd;
+    if constexpr (k + 1 < CB) chol64_wave_col<k + 1>(r, colk, rdiag, i, ckk_n, rd_n, c1_n);
+}
+__device__ __forceinline__ void chol64_wave(real (*Ls)[CLD], real (*colk)[CB], real* rdiag) {
+    __syncthreads();                                  // the caller has just filled Ls
+    if (threadIdx.x < CB) {
+        const int i = threadIdx.x;
+        real r[CB];
+#pragma unroll
+        for (int j = 0; j < CB; ++j) r[j] = Ls[i][j];
+        colk[0][i] = r[0];
+        asm volatile("" ::: "memory");
+        const real c1 = colk[0][1], ckk = chol_lane_bcast(r[0], 0);
+        chol64_wave_col<0>(r, colk, rdiag, i, ckk, fast_rsqrt(ckk), c1);
+#pragma unroll
+        for (int j = 0; j < CB; ++j) Ls[i][j] = j <= i ? r[j] : real(0);
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void chol64(real (*Ls)[CLD], real (*colk)[CB], real* rdiag, int onewave) {
+    if (onewave) chol64_wave(Ls, colk, rdiag);
+    else chol64_lds(Ls, colk, rdiag);
+}
+
 // X = L^-1 for the lower-triangular 64 x 64 block in Ls (identity-padded), by halves:
 //   X11 = L11^-1 (wave 0), X22 = L22^-1 (wave 1): lane j solves L x = e_j with x in registers, x_i = ((i == j) - sum_{k<i} l_ik x_k) / l_ii
 //     -- entries above the diagonal come out as exact zeros, so the code is lane-uniform, the l_ik reads are LDS
@@ -150,6 +252,7 @@ struct DiagArgs {
     real* Linv;       // (batch, nblk, 64, 64): slot r0 / 64 receives L_kk^-1 (identity-padded)
     int nblk;
     real* logdet;     // (batch): += 2 sum log diag  (= when first)
+    int onewave;      // chol64_wave instead of chol64_lds
 };
 // one workgroup per matrix: Cholesky of the diagonal block + inverse of its factor + log det contribution
 // dynamic LDS (DIAG_LDS_BYTES: two padded 64 x 64 blocks + the column buffer = 67.6 KB, above the 64 KB a kernel gets
@@ -157,17 +260,18 @@ struct DiagArgs {
 #define DIAG_LDS_BYTES ((2 * CB * CLD + 3 * CB) * sizeof(real))
 __global__ __launch_bounds__(256) void k_chol_diag(DiagArgs g) {
     extern __shared__ __align__(16) unsigned char diag_lds[];
-    real (*Ls)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds);
-    real (*Xs)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + CB * CLD * sizeof(real));
-    real (*colk)[CB] = reinterpret_cast<real (*)[CB]>(diag_lds + 2 * CB * CLD * sizeof(real));
-    real* rdiag = reinterpret_cast<real*>(diag_lds + (2 * CB * CLD + 2 * CB) * sizeof(real));
+    // column buffer first: its addresses stay below 64 KB, the range of a DS instruction's immediate offset
+    real (*colk)[CB] = reinterpret_cast<real (*)[CB]>(diag_lds);
+    real* rdiag = reinterpret_cast<real*>(diag_lds + 2 * CB * sizeof(real));
+    real (*Ls)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + 3 * CB * sizeof(real));
+    real (*Xs)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + (3 * CB + CB * CLD) * sizeof(real));
     const int l = blockIdx.x, n = g.nbk;
     real* A = g.A + (size_t)l * g.sA + (size_t)g.r0 * g.lda + g.r0;
     for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
         const int i = e / CB, j = e % CB;
         Ls[i][j] = (i < n && j < n) ? A[(size_t)i * g.lda + j] : (i == j ? real(1) : real(0));     // identity pad
     }
-    chol64_lds(Ls, colk, rdiag);
+    chol64(Ls, colk, rdiag, g.onewave);
     real lg = (threadIdx.x < n) ? log(Ls[threadIdx.x][threadIdx.x]) : real(0);
     lg = wave_sum_c(lg);
     if (threadIdx.x == 0) g.logdet[l] = (g.first ? real(0) : g.logdet[l]) + real(2) * lg;
@@ -178,6 +282,123 @@ __global__ __launch_bounds__(256) void k_chol_diag(DiagArgs g) {
         Xo[e] = Xs[i][j];
         if (i < n && j < n) A[(size_t)i * g.lda + j] = Ls[i][j];
     }
+}
+
+// ---- 128-wide block steps ------------------------------------------------------------------------------------------
+// A block step of the right-looking factorisation is a chain of dependent launches (diagonal block, panel solve, column
+// update) with a 64 x 64 diagonal block on `batch` of 256 CUs at its head; at m = 800 that chain, not the flops, is the time.
+// k_chol_diag2 takes a 128 x 128 diagonal block in ONE launch -- L11 = chol(A11), X11 = L11^-1, L21 = A21 X11^T,
+// A22 -= L21 L21^T, L22 = chol(A22), X22 = L22^-1, X21 = -X22 (L21 X11), the 64^3 products on the f64 MFMA out of LDS --
+// so the outer loop has half the steps, and its panel solves / trailing updates are K = 128 products (twice the arithmetic
+// intensity of K = 64).  Writes L, both 64 x 64 inverse blocks (what trsm / potri consume) and the 128 x 128 inverse
+// [[X11, 0], [X21, X22]] for the panel solve.
+typedef double d4k __attribute__((ext_vector_type(4)));
+// acc[u] (u = 0..3) = tile (ti, tj) = ((4 wave + u) / 4, (4 wave + u) % 4) of A (64 x 64) times B or B^T, operands in LDS
+template <bool TB>
+__device__ __forceinline__ void mm64_tiles(const real (*A)[CLD], const real (*B)[CLD], d4k* acc) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = 4 * wave + u, ti = 16 * (t >> 2), tj = 16 * (t & 3);
+        d4k c = {0, 0, 0, 0};
+#pragma unroll
+        for (int k0 = 0; k0 < CB; k0 += 4)
+            c = __builtin_amdgcn_mfma_f64_16x16x4f64(A[ti + r][k0 + q], TB ? B[tj + r][k0 + q] : B[k0 + q][tj + r], c, 0, 0, 0);
+        acc[u] = c;
+    }
+}
+// element (row, col) of accumulator register e of tile u held by this lane
+#define MM64_ROW(u, e) (16 * ((4 * (threadIdx.x >> 6) + (u)) >> 2) + ((threadIdx.x & 63) >> 4) + 4 * (e))
+#define MM64_COL(u) (16 * ((4 * (threadIdx.x >> 6) + (u)) & 3) + (threadIdx.x & 15))
+
+struct Diag2Args {
+    int m, r0, n, lda, batch, first, nblk, nblk2;   // block rows r0 .. r0 + n (64 < n <= 128)
+    long long sA;
+    real* A;
+    real* Linv;       // (batch, nblk, 64, 64)
+    real* Linv2;      // (batch, nblk2, 128, 128): slot r0 / 128
+    real* logdet;
+    int onewave;
+};
+#define DIAG2_LDS_BYTES ((4 * CB * CLD + 3 * CB) * sizeof(real))
+__global__ __launch_bounds__(256) void k_chol_diag2(Diag2Args g) {
+    extern __shared__ __align__(16) unsigned char diag_lds[];
+    real (*colk)[CB] = reinterpret_cast<real (*)[CB]>(diag_lds);
+    real* rdiag = reinterpret_cast<real*>(diag_lds + 2 * CB * sizeof(real));
+    real (*T0)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + 3 * CB * sizeof(real));
+    real (*T1)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + (3 * CB + 1 * CB * CLD) * sizeof(real));
+    real (*T2)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + (3 * CB + 2 * CB * CLD) * sizeof(real));
+    real (*Xs)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + (3 * CB + 3 * CB * CLD) * sizeof(real));
+    const int l = blockIdx.x, n2 = g.n - CB;                 // rows of the second 64-block (1..64)
+    real* A = g.A + (size_t)l * g.sA + (size_t)g.r0 * g.lda + g.r0;
+    for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
+        const int i = e / CB, j = e % CB;
+        T0[i][j] = A[(size_t)i * g.lda + j];
+        T1[i][j] = i < n2 ? A[(size_t)(CB + i) * g.lda + j] : real(0);
+        T2[i][j] = (i < n2 && j < n2) ? A[(size_t)(CB + i) * g.lda + CB + j] : (i == j ? real(1) : real(0));
+    }
+    real* X1o = g.Linv + ((size_t)l * g.nblk + g.r0 / CB) * CB * CB;
+    real* X2o = X1o + CB * CB;
+    real* Xb = g.Linv2 + ((size_t)l * g.nblk2 + g.r0 / (2 * CB)) * (4 * CB * CB);        // 128 x 128, ld 128
+    // ---- first 64-block
+    chol64(T0, colk, rdiag, g.onewave);
+    real lg = (threadIdx.x < CB) ? log(T0[threadIdx.x][threadIdx.x]) : real(0);
+    lg = wave_sum_c(lg);
+    if (threadIdx.x == 0) g.logdet[l] = (g.first ? real(0) : g.logdet[l]) + real(2) * lg;
+    trinv64_lds(T0, Xs, rdiag);                              // X11
+    for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
+        const int i = e / CB, j = e % CB;
+        const real x = Xs[i][j];
+        X1o[e] = x;
+        Xb[(size_t)i * 2 * CB + j] = x;
+        Xb[(size_t)i * 2 * CB + CB + j] = real(0);
+        A[(size_t)i * g.lda + j] = T0[i][j];
+    }
+    // ---- L21 = A21 X11^T
+    d4k acc[4];
+    mm64_tiles<true>(T1, Xs, acc);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T1[MM64_ROW(u, e)][MM64_COL(u)] = acc[u][e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
+        const int i = e / CB, j = e % CB;
+        if (i < n2) A[(size_t)(CB + i) * g.lda + j] = T1[i][j];
+    }
+    // ---- A22 -= L21 L21^T  (every lane updates its own elements)
+    mm64_tiles<true>(T1, T1, acc);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T2[MM64_ROW(u, e)][MM64_COL(u)] -= acc[u][e];
+    // ---- W = L21 X11 -> T1 (L21 is stored; X11 is not needed in LDS afterwards)
+    mm64_tiles<false>(T1, Xs, acc);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) T1[MM64_ROW(u, e)][MM64_COL(u)] = acc[u][e];
+    // ---- second 64-block
+    chol64(T2, colk, rdiag, g.onewave);
+    lg = (threadIdx.x < n2) ? log(T2[threadIdx.x][threadIdx.x]) : real(0);
+    lg = wave_sum_c(lg);
+    if (threadIdx.x == 0) g.logdet[l] += real(2) * lg;
+    trinv64_lds(T2, Xs, rdiag);                              // X22
+    for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
+        const int i = e / CB, j = e % CB;
+        const real x = Xs[i][j];
+        X2o[e] = x;
+        Xb[(size_t)(CB + i) * 2 * CB + CB + j] = x;
+        if (i < n2 && j < n2) A[(size_t)(CB + i) * g.lda + CB + j] = T2[i][j];
+    }
+    // ---- X21 = -X22 W
+    mm64_tiles<false>(Xs, T1, acc);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Xb[(size_t)(CB + MM64_ROW(u, e)) * 2 * CB + MM64_COL(u)] = -acc[u][e];
 }
 
 // inverse of every 64 x 64 diagonal block of a lower-triangular L: grid (nblk, batch)
@@ -252,7 +473,9 @@ inline unsigned nblk256(long long n) { return (unsigned)((n + 255) / 256); }
 extern "C" size_t svgp_potrf_workspace_elems(int m, int batch) {
     if (m < 1 || batch < 0) return 0;
     const size_t nblk = (size_t)(m + CB - 1) / CB;
-    return (size_t)batch * (nblk * CB * CB + 2 * (size_t)m * CB);        // L_kk^-1 blocks + two scaled panels (look-ahead)
+    const size_t nblk2 = (size_t)(m + 2 * CB - 1) / (2 * CB);
+    // L_kk^-1 blocks (64) + 128 x 128 inverses of the outer diagonal blocks + two scaled 128-wide panels (look-ahead)
+    return (size_t)batch * (nblk * CB * CB + nblk2 * 4 * CB * CB + 2 * (size_t)m * 2 * CB);
 }
 extern "C" size_t svgp_trsm_workspace_elems(int m, int n, int batch) {
     if (m < 1 || n < 0 || batch < 0) return 0;
@@ -274,55 +497,78 @@ extern "C" int svgp_potrf_batched(int m, int batch, double* A, int lda, long lon
     if (batch == 0) return SVGP_OK;
     SVGP_REQUIRE(A && logdet && work, SVGP_ERR_INVALID, "NULL device pointer");
     hipStream_t s = (hipStream_t)stream;
-    const int nblk = (m + CB - 1) / CB;
+    const int nblk = (m + CB - 1) / CB, nblk2 = (m + 2 * CB - 1) / (2 * CB);
     real* Linv = work;
-    real* Pn2 = work + (size_t)batch * nblk * CB * CB;          // 2 x (batch, m, 64): scaled panels of the current / previous step
+    real* Linv2 = work + (size_t)batch * nblk * CB * CB;        // (batch, nblk2, 128, 128): inverses of the outer diagonal blocks
+    real* Pn2 = Linv2 + (size_t)batch * nblk2 * 4 * CB * CB;    // 2 x (batch, m, W): scaled panels of the current / previous step
     SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)DIAG_LDS_BYTES));
+    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_chol_diag2), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)DIAG2_LDS_BYTES));
     DiagArgs d;
     d.m = m; d.lda = lda; d.batch = batch; d.sA = strideA; d.A = A; d.Linv = Linv; d.nblk = nblk; d.logdet = logdet;
+    Diag2Args d2;
+    d2.m = m; d2.lda = lda; d2.batch = batch; d2.sA = strideA; d2.A = A; d2.Linv = Linv; d2.Linv2 = Linv2; d2.nblk = nblk;
+    d2.nblk2 = nblk2; d2.logdet = logdet;
+    // diagonal blocks on one wave with a row per lane (chol64_wave); SVGP_CHOL_WAVE=0: the four-wave register-tiled form
+    static const int onewave = [] { const char* e = getenv("SVGP_CHOL_WAVE"); return (e && e[0] == '0') ? 0 : 1; }();
+    d.onewave = d2.onewave = onewave;
+    // Block steps of W = 128 rows from m >= 640 (k_chol_diag2: half the dependent launches, K = 128 products), 64 below
+    // (SVGP_POTRF_BLOCK=64 forces the 64-wide steps).
+    static const int wide_on = [] { const char* e = getenv("SVGP_POTRF_BLOCK"); return (e && atoi(e) == 64) ? 0 : 1; }();
+    const int W = (wide_on && m >= 640) ? 2 * CB : CB, nstep = (m + W - 1) / W;   // (256 x 17: 243 -> 255 us, 512 x 16: 553 -> 561 with the wide steps)
     // Look-ahead (right-looking with the trailing update split): after panel k is solved, ONLY block column k + 1 is updated on
     // the caller's stream -- that is all the next diagonal block and the next panel solve need -- and the rest of the trailing
     // update (columns k + 2 ..) runs on a side branch beside them: a block step costs max(trailing update, column update +
-    // diagonal block + panel solve) instead of their sum (the diagonal block alone is ~50 us on `batch` of 256 CUs; 13 steps at
-    // m = 800).  SVGP_POTRF_LOOKAHEAD=0: everything in line.  Same operations on the same values.
+    // diagonal block + panel solve) instead of their sum.  SVGP_POTRF_LOOKAHEAD=0: everything in line.  Same operations on the
+    // same values.
     static const int la_on = [] { const char* e = getenv("SVGP_POTRF_LOOKAHEAD"); return (e && e[0] == '0') ? 0 : 1; }();
-    const bool la = la_on && nblk >= 10;          // (m >= 577: below, the fork / join per block step costs more than it hides: 512 x 16 553 -> 578 us)
+    const bool la = la_on && m >= 640;            // (below, the fork / join per block step costs more than it hides: 512 x 16 553 -> 578 us)
     void* side = stream;
     bool side_open = false;
-    for (int kb = 0; kb < nblk; ++kb) {
-        const int r0 = kb * CB, nbk = m - r0 < CB ? m - r0 : CB, rem = m - r0 - nbk;
-        real* Pn = Pn2 + (size_t)(kb & 1) * batch * m * CB;
-        d.r0 = r0; d.nbk = nbk; d.first = kb == 0;
-        hipLaunchKernelGGL(k_chol_diag, dim3(batch), dim3(256), DIAG_LDS_BYTES, s, d);
+    for (int kb = 0; kb < nstep; ++kb) {
+        const int r0 = kb * W, nbk = m - r0 < W ? m - r0 : W, rem = m - r0 - nbk;
+        real* Pn = Pn2 + (size_t)(kb & 1) * batch * m * W;
+        const real* Lk;             // inverse of the diagonal block's factor, row-major, leading dimension ldk
+        int ldk;
+        long long sLk;
+        if (nbk > CB) {
+            d2.r0 = r0; d2.n = nbk; d2.first = kb == 0;
+            hipLaunchKernelGGL(k_chol_diag2, dim3(batch), dim3(256), DIAG2_LDS_BYTES, s, d2);
+            Lk = Linv2 + (size_t)kb * 4 * CB * CB; ldk = 2 * CB; sLk = (long long)nblk2 * 4 * CB * CB;
+        } else {
+            d.r0 = r0; d.nbk = nbk; d.first = kb == 0;
+            hipLaunchKernelGGL(k_chol_diag, dim3(batch), dim3(256), DIAG_LDS_BYTES, s, d);
+            Lk = Linv + (size_t)(r0 / CB) * CB * CB; ldk = CB; sLk = (long long)nblk * CB * CB;
+        }
         SVGP_LAUNCH_CHECK();
         if (rem == 0) break;
         real* panel = A + (size_t)(r0 + nbk) * lda + r0;        // A[r0+nbk:, r0:r0+nbk]
         real* trail = A + (size_t)(r0 + nbk) * lda + r0 + nbk;
-        // L_ik = A_ik L_kk^-T   (Linv stored row-major: B^T form)
-        RUNC(svgp_dgemm_tri_batched(0, 0, 1, rem, nbk, nbk, 1.0, panel, lda, strideA, Linv + (size_t)kb * CB * CB, CB,
-                                    (long long)nblk * CB * CB, 0.0, Pn, CB, (long long)m * CB, batch, stream));
-        hipLaunchKernelGGL(k_copy_block, dim3(nblk256((long long)rem * nbk), batch), dim3(256), 0, s, rem, nbk, Pn, CB,
-                           (long long)m * CB, panel, lda, strideA);
+        // L_ik = A_ik L_kk^-T   (the inverse stored row-major: B^T form)
+        RUNC(svgp_dgemm_tri_batched(0, 0, 1, rem, nbk, nbk, 1.0, panel, lda, strideA, Lk, ldk, sLk, 0.0, Pn, W, (long long)m * W,
+                                    batch, stream));
+        hipLaunchKernelGGL(k_copy_block, dim3(nblk256((long long)rem * nbk), batch), dim3(256), 0, s, rem, nbk, Pn, W,
+                           (long long)m * W, panel, lda, strideA);
         SVGP_LAUNCH_CHECK();
-        const int nb1 = rem < CB ? rem : CB, rem2 = rem - nb1;   // next block column / what lies beyond it
+        const int nb1 = rem < W ? rem : W, rem2 = rem - nb1;     // next block column / what lies beyond it
         if (!la || rem2 == 0) {
             if (side_open) { RUNC(svgp_side_branch_join(stream, 0)); side_open = false; }
             // A_ij -= L_ik L_jk^T on the tiles that touch the lower triangle
-            RUNC(svgp_dgemm_tri_batched(1, 0, 1, rem, rem, nbk, -1.0, Pn, CB, (long long)m * CB, Pn, CB, (long long)m * CB, 1.0,
+            RUNC(svgp_dgemm_tri_batched(1, 0, 1, rem, rem, nbk, -1.0, Pn, W, (long long)m * W, Pn, W, (long long)m * W, 1.0,
                                         trail, lda, strideA, batch, stream));
             continue;
         }
         // the previous step's side update wrote column k + 1 too: it must be complete before this step's column update
         if (side_open) RUNC(svgp_side_branch_join(stream, 0));
         // column k + 1 (rows r1 .., nb1 columns): A[r1:, r1:r1+nb1] -= Pn[r1-rows] Pn[block k + 1 rows]^T
-        RUNC(svgp_dgemm_tri_batched(1, 0, 1, rem, nb1, nbk, -1.0, Pn, CB, (long long)m * CB, Pn, CB, (long long)m * CB, 1.0,
+        RUNC(svgp_dgemm_tri_batched(1, 0, 1, rem, nb1, nbk, -1.0, Pn, W, (long long)m * W, Pn, W, (long long)m * W, 1.0,
                                     trail, lda, strideA, batch, stream));
         // columns k + 2 ..: on the side branch (forked here: after the panel solve and, through stream order, after the join)
         RUNC(svgp_side_branch_fork(stream, &side, 0));
         side_open = true;
-        RUNC(svgp_dgemm_tri_batched(1, 0, 1, rem2, rem2, nbk, -1.0, Pn + (size_t)nb1 * CB, CB, (long long)m * CB,
-                                    Pn + (size_t)nb1 * CB, CB, (long long)m * CB, 1.0, trail + (size_t)nb1 * lda + nb1, lda, strideA,
+        RUNC(svgp_dgemm_tri_batched(1, 0, 1, rem2, rem2, nbk, -1.0, Pn + (size_t)nb1 * W, W, (long long)m * W,
+                                    Pn + (size_t)nb1 * W, W, (long long)m * W, 1.0, trail + (size_t)nb1 * lda + nb1, lda, strideA,
                                     batch, side));
     }
     if (side_open) RUNC(svgp_side_branch_join(stream, 0));

@@ -304,12 +304,12 @@ def cpu_worker_mnist(cfg3, budget_s, steps_only=0):
 
 def cpu_baseline_mnist(cfg3, budget_s=15.0):
     kind = "cfg3" if cfg3 else "cfg2"
-    cands = sorted({host_threads(c) for c in ((16, 32) if cfg3 else (8, 16, 32))})
+    cands = sorted({host_threads(c) for c in ((16, 32, 64, 128) if cfg3 else (8, 16, 32, 64, 128))})
     probe = {nt: cpu_worker_call(kind, nt, 0.0, ("--probe-steps", "2"))["value"] for nt in cands} if len(cands) > 1 \
         else {cands[0]: 0.0}
     nt = max(probe, key=probe.get)
     r = cpu_worker_call(kind, nt, budget_s)
-    out = dict(value=r["value"], unit="steps/s", cores=os.cpu_count(), threads=nt, kind="port",
+    out = dict(value=r["value"], unit="steps/s", cores=nt, host_cores=os.cpu_count(), threads=nt, kind="port",
                formulation=r["formulation"],
                sample=f"{r['n']} {r['formulation']}-formulation float64 steps (torch-CPU autograd + TF1 Adam) of the same "
                       f"{r['rows']}-row batch, {r['seconds']:.1f} s, {nt} OpenMP threads (fastest of {cands}) on a "
@@ -645,7 +645,7 @@ def cpu_baseline_sprites(gpu_elbo, m):
     r = cpu_worker_call("sprites800", nt, 0.0, ("--m", str(m)))
     rel = abs(gpu_elbo - r["elbo"]) / abs(r["elbo"])
     assert rel < 1e-3, f"ELBO parity failed: GPU {gpu_elbo} oracle {r['elbo']}"
-    return dict(value=1.0 / r["seconds"], unit="steps/s", cores=os.cpu_count(), threads=nt, kind="port",
+    return dict(value=1.0 / r["seconds"], unit="steps/s", cores=nt, host_cores=os.cpu_count(), threads=nt, kind="port",
                 formulation="efficient", elbo_rel_err_gpu_vs_oracle=rel,
                 sample=f"1 efficient-formulation float64 forward + autograd reverse of the same {r['rows']}-frame batch "
                        f"(no Adam update), {r['seconds']:.1f} s, {nt} OpenMP threads on a {os.cpu_count()}-core host")
@@ -785,7 +785,7 @@ def cpu_worker_cfg5(m, budget_s):
 def cpu_baseline_cfg5(m, n_rows, budget_s=12.0):
     nt = host_threads(64)
     r = cpu_worker_call("cfg5", nt, budget_s, ("--m", str(m)))
-    return dict(value=r["value"], unit="rows/s", cores=os.cpu_count(), threads=nt, kind="port",
+    return dict(value=r["value"], unit="rows/s", cores=nt, host_cores=os.cpu_count(), threads=nt, kind="port",
                 sample=f"{r['chunks']} chunks of {r['rows']} rows (the GPU shard has {n_rows}) through float32 torch-CPU "
                        f"K_nm + S_l, v_l for m={m}, L=16, {r['seconds']:.1f} s, {nt} OpenMP threads on a "
                        f"{os.cpu_count()}-core host")

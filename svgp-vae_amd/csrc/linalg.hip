@@ -48,6 +48,9 @@ struct GemmArgs {
 //   <double, float>   float64 matrices, float32 arithmetic   v_mfma_f32_16x16x4_f32 (twice the matrix rate, half the LDS)
 //   <float,  float>   the float32 GEMM
 typedef float f4_t __attribute__((ext_vector_type(4)));
+#ifndef GEMM_PIPE
+#define GEMM_PIPE 1
+#endif
 template <typename TC> struct MfmaT;
 template <> struct MfmaT<double> {
     typedef d4_t acc_t;
@@ -102,6 +105,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
     const bool b_ok = j0 + HN <= g.N || TB || g.N % 2 == 0;
     const bool tile_fast = a_ok && b_ok && g.M >= 2 && g.N >= 2;
     TC ra[2 * NPA], rb[2 * NPB];
+    // instructions of the steady-state pipeline that go behind each of the first / last eight MFMAs of group 0
+    constexpr int NDSW = (TA ? NPA : 2 * NPA) + (TB ? 2 * NPB : NPB), NMF = WM * WN;
+    constexpr int PIPE_DSW = (NDSW + NMF / 2 - 1) / (NMF / 2 > 0 ? NMF / 2 : 1), PIPE_VMEM = (NPA + NPB + NMF / 2 - 1) / (NMF / 2 > 0 ? NMF / 2 : 1),
+                  PIPE_VALU = 3;
     auto ldfast = [&](const TS* __restrict__ p, TC& v0, TC& v1) {
         if (VEC) {
             const TS2 v = *reinterpret_cast<const TS2*>(p);
@@ -116,6 +123,23 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
     };
     // one uniform branch per panel: full panel of a clampable tile -> straight-line unchecked loads, else the checked form
     // (the per-pair branches of a mixed form were ~100 instructions per panel in front of MFMA group 1)
+    // straight-line unchecked loads of a full panel (tile_fast, no contraction weights)
+    auto fetch_fast = [&](int k0) {
+#pragma unroll
+        for (int h = 0; h < NPA; ++h) {
+            const int e = tid + 256 * h, kx = e / (HM / 2), xx = 2 * (e % (HM / 2));    // [k][x] map
+            const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;                      // [x][k] map
+            if (TA) ldfast(A + (size_t)(k0 + kx) * g.lda + min(i0 + xx, g.M - 2), ra[2 * h], ra[2 * h + 1]);
+            else ldfast(A + (size_t)min(i0 + xk, g.M - 1) * g.lda + k0 + kk, ra[2 * h], ra[2 * h + 1]);
+        }
+#pragma unroll
+        for (int h = 0; h < NPB; ++h) {
+            const int e = tid + 256 * h, kx = e / (HN / 2), xx = 2 * (e % (HN / 2));
+            const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;
+            if (TB) ldfast(B + (size_t)min(j0 + xk, g.N - 1) * g.ldb + k0 + kk, rb[2 * h], rb[2 * h + 1]);
+            else ldfast(B + (size_t)(k0 + kx) * g.ldb + min(j0 + xx, g.N - 2), rb[2 * h], rb[2 * h + 1]);
+        }
+    };
     auto fetch = [&](int k0) {
         if (tile_fast && k0 + GK <= g.K) {
 #pragma unroll
@@ -222,7 +246,67 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
     // after group 0) are long complete, so the first fragments of panel p + 1 are read from the other buffer under the last
     // MFMA group and the next panel starts with its operands in registers -- no LDS latency and no barrier wait at the panel
     // boundary with an empty matrix pipe.
-    for (int k0 = klo; k0 < khi; k0 += GK) {
+    int k0 = klo;
+    // Steady state (panels k0 + GK and k0 + 2 GK exist and are full, no contraction weights): one basic block per panel, so that
+    // the LDS stores of panel p + 1 and the global loads of panel p + 2 can be placed BETWEEN the 16 MFMAs of group 0 instead
+    // of after them (sched_group_barrier pipeline: an f64 MFMA occupies the matrix pipe for 64 cycles, room for three or four
+    // other instructions of the same wave) -- in the generic loop below they sit in their own blocks behind uniform branches
+    // and the matrix pipe of this wave idles for their ~100 instructions.
+    if (GEMM_PIPE && tile_fast && !wk) {
+        while (k0 + 3 * GK <= khi) {
+            const TC* Ab = As + cur * GK * LDA_ + wi + r;
+            const TC* Bb = Bs + cur * GK * LDB_ + wj + r;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < WM; ++a) av[1][a] = Ab[(4 + q) * LDA_ + 16 * a];
+#pragma unroll
+            for (int b = 0; b < WN; ++b) bv[1][b] = Bb[(4 + q) * LDB_ + 16 * b];
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) acc[a][b] = MF::mma(av[0][a], bv[0][b], acc[a][b]);
+            stage(cur ^ 1);
+            fetch_fast(k0 + 2 * GK);
+            __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);                 // the fragment reads of group 1
+#pragma unroll
+            for (int i = 0; i < WM * WN; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                   // one MFMA
+                if (i < WM * WN / 2) {
+                    __builtin_amdgcn_sched_group_barrier(0x200, PIPE_DSW, 0);        // LDS stores of panel p + 1
+                } else {
+                    __builtin_amdgcn_sched_group_barrier(0x002, PIPE_VALU, 0);       // address arithmetic
+                    __builtin_amdgcn_sched_group_barrier(0x020, PIPE_VMEM, 0);       // global loads of panel p + 2
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 1; st < GK / 4; ++st) {
+                if (st + 1 < GK / 4) {
+#pragma unroll
+                    for (int a = 0; a < WM; ++a) av[(st + 1) & 1][a] = Ab[(4 * (st + 1) + q) * LDA_ + 16 * a];
+#pragma unroll
+                    for (int b = 0; b < WN; ++b) bv[(st + 1) & 1][b] = Bb[(4 * (st + 1) + q) * LDB_ + 16 * b];
+                } else {
+                    __syncthreads();
+                    const TC* An = As + (cur ^ 1) * GK * LDA_ + wi + r;
+                    const TC* Bn = Bs + (cur ^ 1) * GK * LDB_ + wj + r;
+#pragma unroll
+                    for (int a = 0; a < WM; ++a) av[0][a] = An[q * LDA_ + 16 * a];
+#pragma unroll
+                    for (int b = 0; b < WN; ++b) bv[0][b] = Bn[q * LDB_ + 16 * b];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+#pragma unroll
+                    for (int b = 0; b < WN; ++b) acc[a][b] = MF::mma(av[st & 1][a], bv[st & 1][b], acc[a][b]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cur ^= 1;
+            k0 += GK;
+        }
+    }
+    for (; k0 < khi; k0 += GK) {
         const TC* Ab = As + cur * GK * LDA_ + wi + r;
         const TC* Bb = Bs + cur * GK * LDB_ + wj + r;
         const bool more = k0 + GK < khi;
@@ -308,6 +392,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_rect(GemmArgs g) {
 // 32 E-wide edge tiles (E = 1, 2: remainders up to 32 / 64; larger remainders take a bounds-checked full tile) in the same
 // launch -- m = 800 = 6 x 128 + 32 runs 36 interior tiles at the large-tile rate and pads 13 thin ones instead of padding
 // every tile row and column (128-tiles: 25 % padding, 64-tiles: 8 % at the lower small-tile rate).
+// E = 3: an extent is cut into a tiles of 128 and b tiles of 96 (every multiple of 32 from 192 on is 128 a + 96 b exactly:
+// 800 = 4 x 128 + 3 x 96), so EVERY tile is a large one.  A 128 x 32 edge tile costs about as much as a 128 x 128 tile (4
+// MFMAs per wave between the same staging, loads and barrier of a k-panel): 512 x 768 x 800 x 64 ran 66.1 TFLOP/s and
+// 512 x 800 x 800 x 64 56.9, i.e. the 32 extra columns cost 21 % more time for 4 % more flops.
 template <bool TA, bool TB, int E, typename TS, typename TC, bool VEC>
 __global__ __launch_bounds__(256, 2) void k_gemm_mixed(GemmArgs g) {
     extern __shared__ __align__(16) unsigned char hs_raw[];
@@ -318,8 +406,10 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mixed(GemmArgs g) {
     // (the edge tiles stay interleaved in row-major tile order: collected at the end of the launch they run together, all of
     // them at the low arithmetic intensity of a thin tile -- measured 43 instead of 53 TFLOP/s at 800^3 x 64)
     const int l = lid / (g.tiles_n * g.tiles_m), tt = lid % (g.tiles_n * g.tiles_m);
-    const int ti = tt / g.tiles_n, tj = tt % g.tiles_n, i0 = ti * 128, j0 = tj * 128;
-    const bool em = ti >= g.full_m, en = tj >= g.full_n;       // (at most the last tile row / column)
+    const int ti = tt / g.tiles_n, tj = tt % g.tiles_n;
+    const bool em = ti >= g.full_m, en = tj >= g.full_n;       // (E = 1, 2: at most the last tile row / column; E = 3: several)
+    const int i0 = em ? g.full_m * 128 + (ti - g.full_m) * 32 * E : ti * 128;
+    const int j0 = en ? g.full_n * 128 + (tj - g.full_n) * 32 * E : tj * 128;
     if (!em && !en) gemm_tile<TA, TB, 4, 4, TS, TC, VEC>(g, l, i0, j0, hs);
     else if (!em) gemm_tile<TA, TB, 4, E, TS, TC, VEC>(g, l, i0, j0, hs);
     else if (!en) gemm_tile<TA, TB, E, 4, TS, TC, VEC>(g, l, i0, j0, hs);
@@ -565,12 +655,26 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     const int rem_m = M % 128, rem_n = N % 128;
     const bool edge_m = rem_m > 0 && rem_m <= 64, edge_n = rem_n > 0 && rem_n <= 64;
     const bool mixed = mixed_on && prec == 0 && M >= 128 && N >= 128 && blocks128 >= 192 && (edge_m || edge_n);
-    const int edge_w = ((edge_m && rem_m > 32) || (edge_n && rem_n > 32)) ? 2 : 1;
+    int edge_w = ((edge_m && rem_m > 32) || (edge_n && rem_n > 32)) ? 2 : 1;
     if (mixed) wt = 4;
+    // 128 a + 96 b decomposition of both extents (E = 3) when neither is small: least padding, then most 128-tiles
+    static const int t96_on = [] { const char* e = getenv("SVGP_GEMM_T96"); return (e && e[0] == '0') ? 0 : 1; }();
+    auto cut = [](int X, int& a, int& b) {
+        int best = 1 << 30;
+        for (int bb = 0; bb <= 3; ++bb) {
+            int aa = X - 96 * bb <= 0 ? 0 : (X - 96 * bb + 127) / 128;
+            const int pad = 128 * aa + 96 * bb;
+            if (pad >= X && pad < best) { best = pad; a = aa; b = bb; }
+        }
+    };
+    int am = 0, bm = 0, an = 0, bn = 0;
+    cut(M, am, bm); cut(N, an, bn);
+    const bool t96 = t96_on && mixed_on && prec == 0 && M >= 192 && N >= 192 && blocks128 >= 192 && (bm > 0 || bn > 0);
+    if (t96) { wt = 4; edge_w = 3; }
     // rectangular tiles (float64): 128 x 64 where 128-tiles leave fewer than two workgroups per CU, 64 x 32 where 64-tiles do
     static const int rect_on = [] { const char* e = getenv("SVGP_GEMM_RECT"); return (e && e[0] == '0') ? 0 : 1; }();
     int rwm = 0, rwn = 0;
-    if (rect_on && prec == 0 && !mixed && !(tri & 1)) {
+    if (rect_on && prec == 0 && !mixed && !t96 && !(tri & 1)) {
         if (wt == 4 && blocks128 < 512 && M % 128 == 0 && N % 64 == 0) { rwm = 4; rwn = 2; }
         else if (wt == 2 && blocks64 < 512 && M % 64 == 0 && N % 32 == 0) { rwm = 2; rwn = 1; }
     }
@@ -579,6 +683,7 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     g.tiles_n = (N + ht - 1) / ht; g.tiles_m = (M + ht - 1) / ht; g.batch = batch;
     g.full_m = (mixed && edge_m) ? M / 128 : g.tiles_m; g.full_n = (mixed && edge_n) ? N / 128 : g.tiles_n;
     if (rwm) { g.tiles_m = (M + 32 * rwm - 1) / (32 * rwm); g.tiles_n = (N + 32 * rwn - 1) / (32 * rwn); }
+    if (t96) { g.full_m = am; g.tiles_m = am + bm; g.full_n = an; g.tiles_n = an + bn; }
     g.xcd_remap = 1;     // measured neutral (+-1 %) at 800^3 x 64 and 2048^3 x 16: the Infinity Cache already absorbs the
                          // cross-XCD panel re-fetches; kept because it never hurts and is the layout the hardware deals
     const long long total = (long long)g.tiles_n * g.tiles_m * batch;
@@ -652,6 +757,7 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     } while (0)
     if (rwm == 4) LAUNCH_RE(4, 2);
     else if (rwm == 2) LAUNCH_RE(2, 1);
+    else if (t96) LAUNCH_ME(3);
     else if (mixed) { if (edge_w == 1) LAUNCH_ME(1); else LAUNCH_ME(2); }
     else if (prec == 0) LAUNCH_P(double, double);
     else if (prec == 1) LAUNCH_P(double, float);

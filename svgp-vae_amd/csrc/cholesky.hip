@@ -320,81 +320,95 @@ struct Diag2Args {
     real* logdet;
     int onewave;
 };
-#define DIAG2_LDS_BYTES ((4 * CB * CLD + 3 * CB) * sizeof(real))
+// Two 64 x 64 blocks of LDS (68 KB, as k_chol_diag), not four: a workgroup with 135 KB needs a CU with no GEMM workgroup on it
+// (66.5 KB each, two per CU), and inside a training step the chip is full of them on the other streams and on the look-ahead
+// branch -- the launch then waits for whole CUs to drain (265 us average in the SPRITES step against 100 us alone).  With 68 KB
+// it fits beside one GEMM workgroup, i.e. into the first slot that retires.  A21, A22 and W = L21 X11 (stashed in the X21 slot
+// of the 128 x 128 inverse, each thread re-reading the elements it wrote) stream through global memory instead.
+#define DIAG2_LDS_BYTES ((2 * CB * CLD + 3 * CB) * sizeof(real))
 __global__ __launch_bounds__(256) void k_chol_diag2(Diag2Args g) {
     extern __shared__ __align__(16) unsigned char diag_lds[];
     real (*colk)[CB] = reinterpret_cast<real (*)[CB]>(diag_lds);
     real* rdiag = reinterpret_cast<real*>(diag_lds + 2 * CB * sizeof(real));
-    real (*T0)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + 3 * CB * sizeof(real));
-    real (*T1)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + (3 * CB + 1 * CB * CLD) * sizeof(real));
-    real (*T2)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + (3 * CB + 2 * CB * CLD) * sizeof(real));
-    real (*Xs)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + (3 * CB + 3 * CB * CLD) * sizeof(real));
+    real (*P)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + 3 * CB * sizeof(real));
+    real (*Q)[CLD] = reinterpret_cast<real (*)[CLD]>(diag_lds + (3 * CB + CB * CLD) * sizeof(real));
     const int l = blockIdx.x, n2 = g.n - CB;                 // rows of the second 64-block (1..64)
     real* A = g.A + (size_t)l * g.sA + (size_t)g.r0 * g.lda + g.r0;
-    for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
-        const int i = e / CB, j = e % CB;
-        T0[i][j] = A[(size_t)i * g.lda + j];
-        T1[i][j] = i < n2 ? A[(size_t)(CB + i) * g.lda + j] : real(0);
-        T2[i][j] = (i < n2 && j < n2) ? A[(size_t)(CB + i) * g.lda + CB + j] : (i == j ? real(1) : real(0));
-    }
     real* X1o = g.Linv + ((size_t)l * g.nblk + g.r0 / CB) * CB * CB;
     real* X2o = X1o + CB * CB;
     real* Xb = g.Linv2 + ((size_t)l * g.nblk2 + g.r0 / (2 * CB)) * (4 * CB * CB);        // 128 x 128, ld 128
-    // ---- first 64-block
-    chol64(T0, colk, rdiag, g.onewave);
-    real lg = (threadIdx.x < CB) ? log(T0[threadIdx.x][threadIdx.x]) : real(0);
+    // ---- first 64-block: P = A11 -> L11, Q = X11
+    for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) P[e / CB][e % CB] = A[(size_t)(e / CB) * g.lda + e % CB];
+    chol64(P, colk, rdiag, g.onewave);
+    real lg = (threadIdx.x < CB) ? log(P[threadIdx.x][threadIdx.x]) : real(0);
     lg = wave_sum_c(lg);
     if (threadIdx.x == 0) g.logdet[l] = (g.first ? real(0) : g.logdet[l]) + real(2) * lg;
-    trinv64_lds(T0, Xs, rdiag);                              // X11
+    trinv64_lds(P, Q, rdiag);
     for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
         const int i = e / CB, j = e % CB;
-        const real x = Xs[i][j];
+        const real x = Q[i][j];
         X1o[e] = x;
         Xb[(size_t)i * 2 * CB + j] = x;
         Xb[(size_t)i * 2 * CB + CB + j] = real(0);
-        A[(size_t)i * g.lda + j] = T0[i][j];
+        A[(size_t)i * g.lda + j] = P[i][j];
     }
-    // ---- L21 = A21 X11^T
+    __syncthreads();
+    // ---- L21 = A21 X11^T (P = A21 -> L21)
+    for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
+        const int i = e / CB, j = e % CB;
+        P[i][j] = i < n2 ? A[(size_t)(CB + i) * g.lda + j] : real(0);
+    }
+    __syncthreads();
     d4k acc[4];
-    mm64_tiles<true>(T1, Xs, acc);
+    mm64_tiles<true>(P, Q, acc);
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) T1[MM64_ROW(u, e)][MM64_COL(u)] = acc[u][e];
+        for (int e = 0; e < 4; ++e) P[MM64_ROW(u, e)][MM64_COL(u)] = acc[u][e];
     __syncthreads();
     for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
         const int i = e / CB, j = e % CB;
-        if (i < n2) A[(size_t)(CB + i) * g.lda + j] = T1[i][j];
+        if (i < n2) A[(size_t)(CB + i) * g.lda + j] = P[i][j];
     }
-    // ---- A22 -= L21 L21^T  (every lane updates its own elements)
-    mm64_tiles<true>(T1, T1, acc);
+    // ---- W = L21 X11 -> the X21 slot of the 128 x 128 inverse (stash)
+    mm64_tiles<false>(P, Q, acc);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) T2[MM64_ROW(u, e)][MM64_COL(u)] -= acc[u][e];
-    // ---- W = L21 X11 -> T1 (L21 is stored; X11 is not needed in LDS afterwards)
-    mm64_tiles<false>(T1, Xs, acc);
-    __syncthreads();
+        for (int e = 0; e < 4; ++e) Xb[(size_t)(CB + MM64_ROW(u, e)) * 2 * CB + MM64_COL(u)] = acc[u][e];
+    // ---- Q = A22 - L21 L21^T (identity pad; the pad rows of L21 are zero)
+    mm64_tiles<true>(P, P, acc);
+    __syncthreads();                                         // every read of X11 (Q) is done
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) T1[MM64_ROW(u, e)][MM64_COL(u)] = acc[u][e];
-    // ---- second 64-block
-    chol64(T2, colk, rdiag, g.onewave);
-    lg = (threadIdx.x < n2) ? log(T2[threadIdx.x][threadIdx.x]) : real(0);
+        for (int e = 0; e < 4; ++e) {
+            const int i = MM64_ROW(u, e), j = MM64_COL(u);
+            const real a22 = (i < n2 && j < n2) ? A[(size_t)(CB + i) * g.lda + CB + j] : (i == j ? real(1) : real(0));
+            Q[i][j] = a22 - acc[u][e];
+        }
+    // ---- second 64-block: Q -> L22, P = X22
+    chol64(Q, colk, rdiag, g.onewave);
+    lg = (threadIdx.x < n2) ? log(Q[threadIdx.x][threadIdx.x]) : real(0);
     lg = wave_sum_c(lg);
     if (threadIdx.x == 0) g.logdet[l] += real(2) * lg;
-    trinv64_lds(T2, Xs, rdiag);                              // X22
+    trinv64_lds(Q, P, rdiag);
     for (int e = threadIdx.x; e < CB * CB; e += blockDim.x) {
         const int i = e / CB, j = e % CB;
-        const real x = Xs[i][j];
+        const real x = P[i][j];
         X2o[e] = x;
         Xb[(size_t)(CB + i) * 2 * CB + CB + j] = x;
-        if (i < n2 && j < n2) A[(size_t)(CB + i) * g.lda + CB + j] = T2[i][j];
+        if (i < n2 && j < n2) A[(size_t)(CB + i) * g.lda + CB + j] = Q[i][j];
     }
-    // ---- X21 = -X22 W
-    mm64_tiles<false>(Xs, T1, acc);
+    __syncthreads();                                         // every read of L22 (Q) is done
+    // ---- X21 = -X22 W (Q = W, each thread the elements it stashed)
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Q[MM64_ROW(u, e)][MM64_COL(u)] = Xb[(size_t)(CB + MM64_ROW(u, e)) * 2 * CB + MM64_COL(u)];
+    __syncthreads();
+    mm64_tiles<false>(P, Q, acc);
 #pragma unroll
     for (int u = 0; u < 4; ++u)
 #pragma unroll

@@ -105,6 +105,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
     const bool b_ok = j0 + HN <= g.N || TB || g.N % 2 == 0;
     const bool tile_fast = a_ok && b_ok && g.M >= 2 && g.N >= 2;
     TC ra[2 * NPA], rb[2 * NPB];
+    TC rw[2 * NPB];        // contraction weights of the fetched B pairs: loaded with them, applied when the panel is staged (a product
+                           // right behind the load would park the wave until the load returns)
     // instructions of the steady-state pipeline that go behind each of the first / last eight MFMAs of group 0
     constexpr int NDSW = (TA ? NPA : 2 * NPA) + (TB ? 2 * NPB : NPB), NMF = WM * WN;
     constexpr int PIPE_DSW = (NDSW + NMF / 2 - 1) / (NMF / 2 > 0 ? NMF / 2 : 1), PIPE_VMEM = (NPA + NPB + NMF / 2 - 1) / (NMF / 2 > 0 ? NMF / 2 : 1),
@@ -123,8 +125,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
     };
     // one uniform branch per panel: full panel of a clampable tile -> straight-line unchecked loads, else the checked form
     // (the per-pair branches of a mixed form were ~100 instructions per panel in front of MFMA group 1)
-    // straight-line unchecked loads of a full panel (tile_fast, no contraction weights)
-    auto fetch_fast = [&](int k0) {
+    // straight-line unchecked loads of a full panel (tile_fast)
+    auto fetch_fast = [&](int k0, auto hw) {
 #pragma unroll
         for (int h = 0; h < NPA; ++h) {
             const int e = tid + 256 * h, kx = e / (HM / 2), xx = 2 * (e % (HM / 2));    // [k][x] map
@@ -138,6 +140,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
             const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;
             if (TB) ldfast(B + (size_t)min(j0 + xk, g.N - 1) * g.ldb + k0 + kk, rb[2 * h], rb[2 * h + 1]);
             else ldfast(B + (size_t)(k0 + kx) * g.ldb + min(j0 + xx, g.N - 2), rb[2 * h], rb[2 * h + 1]);
+            if constexpr (decltype(hw)::value) {
+                if (TB) { rw[2 * h] = (TC)wk[(size_t)(k0 + kk) * g.ldw]; rw[2 * h + 1] = (TC)wk[(size_t)(k0 + kk + 1) * g.ldw]; }
+                else rw[2 * h] = rw[2 * h + 1] = (TC)wk[(size_t)(k0 + kx) * g.ldw];
+            }
         }
     };
     auto fetch = [&](int k0) {
@@ -156,11 +162,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
                 if (TB) {
                     const int gk = k0 + kk;
                     ldfast(B + (size_t)min(j0 + xk, g.N - 1) * g.ldb + gk, rb[2 * h], rb[2 * h + 1]);
-                    if (wk) { rb[2 * h] *= (TC)wk[(size_t)gk * g.ldw]; rb[2 * h + 1] *= (TC)wk[(size_t)(gk + 1) * g.ldw]; }
+                    if (wk) { rw[2 * h] = (TC)wk[(size_t)gk * g.ldw]; rw[2 * h + 1] = (TC)wk[(size_t)(gk + 1) * g.ldw]; }
                 } else {
                     const int gk = k0 + kx;
                     ldfast(B + (size_t)gk * g.ldb + min(j0 + xx, g.N - 2), rb[2 * h], rb[2 * h + 1]);
-                    if (wk) { const TC wv = (TC)wk[(size_t)gk * g.ldw]; rb[2 * h] *= wv; rb[2 * h + 1] *= wv; }
+                    if (wk) rw[2 * h] = rw[2 * h + 1] = (TC)wk[(size_t)gk * g.ldw];
                 }
             }
             return;
@@ -185,22 +191,23 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
                 const int gj = j0 + xk, gk = k0 + kk;
                 ldchk(B + (size_t)gj * g.ldb + gk, gj < g.N && gk < g.K, gj < g.N && gk + 1 < g.K, rb[2 * h], rb[2 * h + 1]);
                 if (wk) {
-                    rb[2 * h] *= gk < g.K ? (TC)wk[(size_t)gk * g.ldw] : TC(0);
-                    rb[2 * h + 1] *= gk + 1 < g.K ? (TC)wk[(size_t)(gk + 1) * g.ldw] : TC(0);
+                    rw[2 * h] = gk < g.K ? (TC)wk[(size_t)gk * g.ldw] : TC(0);
+                    rw[2 * h + 1] = gk + 1 < g.K ? (TC)wk[(size_t)(gk + 1) * g.ldw] : TC(0);
                 }
             } else {
                 const int gj = j0 + xx, gk = k0 + kx;
                 ldchk(B + (size_t)gk * g.ldb + gj, gk < g.K && gj < g.N, gk < g.K && gj + 1 < g.N, rb[2 * h], rb[2 * h + 1]);
-                if (wk) {
-                    const TC wv = gk < g.K ? (TC)wk[(size_t)gk * g.ldw] : TC(0);
-                    rb[2 * h] *= wv; rb[2 * h + 1] *= wv;
-                }
+                if (wk) rw[2 * h] = rw[2 * h + 1] = gk < g.K ? (TC)wk[(size_t)gk * g.ldw] : TC(0);
             }
         }
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, auto hw) {
         TC* Ad = As + buf * GK * LDA_;
         TC* Bd = Bs + buf * GK * LDB_;
+        if constexpr (decltype(hw)::value) {
+#pragma unroll
+            for (int h = 0; h < 2 * NPB; ++h) rb[h] *= rw[h];
+        }
 #pragma unroll
         for (int h = 0; h < NPA; ++h) {
             const int e = tid + 256 * h, kx = e / (HM / 2), xx = 2 * (e % (HM / 2));
@@ -227,8 +234,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
     // the LDS stores complete under the remaining three; panel p + 2 then starts its global loads, a full panel of
     // MFMAs ahead of its use -- the barrier at the end of a panel waits neither for memory nor for the LDS.  The operand
     // fragments of MFMA group s + 1 are read from LDS before group s issues.  (61.8 -> 64.6 TFLOP/s on exact tiles.)
+    const auto W1 = std::true_type{};
+    const auto W0 = std::false_type{};
     fetch(klo);
-    stage(0);
+    if (wk) stage(0, W1); else stage(0, W0);
     if (klo + GK < khi) fetch(klo + GK);
     __syncthreads();
     int cur = 0;
@@ -247,12 +256,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
     // MFMA group and the next panel starts with its operands in registers -- no LDS latency and no barrier wait at the panel
     // boundary with an empty matrix pipe.
     int k0 = klo;
-    // Steady state (panels k0 + GK and k0 + 2 GK exist and are full, no contraction weights): one basic block per panel, so that
+    // Steady state (panels k0 + GK and k0 + 2 GK exist and are full): one basic block per panel, so that
     // the LDS stores of panel p + 1 and the global loads of panel p + 2 can be placed BETWEEN the 16 MFMAs of group 0 instead
     // of after them (sched_group_barrier pipeline: an f64 MFMA occupies the matrix pipe for 64 cycles, room for three or four
     // other instructions of the same wave) -- in the generic loop below they sit in their own blocks behind uniform branches
     // and the matrix pipe of this wave idles for their ~100 instructions.
-    if (GEMM_PIPE && tile_fast && !wk) {
+    auto steady = [&](auto hw) {
         while (k0 + 3 * GK <= khi) {
             const TC* Ab = As + cur * GK * LDA_ + wi + r;
             const TC* Bb = Bs + cur * GK * LDB_ + wj + r;
@@ -265,8 +274,8 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
             for (int a = 0; a < WM; ++a)
 #pragma unroll
                 for (int b = 0; b < WN; ++b) acc[a][b] = MF::mma(av[0][a], bv[0][b], acc[a][b]);
-            stage(cur ^ 1);
-            fetch_fast(k0 + 2 * GK);
+            stage(cur ^ 1, hw);
+            fetch_fast(k0 + 2 * GK, hw);
             __builtin_amdgcn_sched_group_barrier(0x100, WM + WN, 0);                 // the fragment reads of group 1
 #pragma unroll
             for (int i = 0; i < WM * WN; ++i) {
@@ -305,6 +314,9 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
             cur ^= 1;
             k0 += GK;
         }
+    };
+    if (GEMM_PIPE && tile_fast) {
+        if (wk) steady(W1); else steady(W0);
     }
     for (; k0 < khi; k0 += GK) {
         const TC* Ab = As + cur * GK * LDA_ + wi + r;
@@ -335,7 +347,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
                 for (int b = 0; b < WN; ++b) acc[a][b] = MF::mma(av[st & 1][a], bv[st & 1][b], acc[a][b]);
             __builtin_amdgcn_sched_barrier(0);
             if (st == 0) {
-                if (more) stage(cur ^ 1);
+                if (more) { if (wk) stage(cur ^ 1, W1); else stage(cur ^ 1, W0); }
                 if (k0 + 2 * GK < khi) fetch(k0 + 2 * GK);
                 __builtin_amdgcn_sched_barrier(0);
             }

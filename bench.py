@@ -92,16 +92,23 @@ def roofline_of(flops, nbytes, us, peak_tflops, **extra):
     return r
 
 
-def committed_traffic(kernel_key):
+def committed_traffic(kernel_key, per_pass_of=None):
     """HBM bytes per launch of `kernel_key` from the newest committed rocprofv3 PMC summary (profiles/*_pmc_traffic.json,
     collected with tools/pmc_summary.py in separate --pmc passes).  bench.py cannot run the profiler on itself, so this
     is an EARLIER measurement: the source file is reported next to the value and it is null when none matches."""
-    try:
-        path = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
-        pmc = json.load(open(path))
-        return pmc["kernels"][kernel_key]["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT)
-    except Exception:
-        return None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            ks = json.load(open(path))["kernels"]
+            for key in (kernel_key, "cfg5:" + kernel_key, "cfg3:" + kernel_key, "sp800:" + kernel_key):
+                if key in ks:
+                    k = ks[key]
+                    if per_pass_of and (key.split(":")[0] + ":" + per_pass_of) in ks and "hbm_bytes_total_corrected" in k:
+                        # several launches (instantiations) of the kernel per pass: bytes of all of them / passes profiled
+                        return k["hbm_bytes_total_corrected"] / ks[key.split(":")[0] + ":" + per_pass_of]["dispatches"], os.path.relpath(path, ROOT)
+                    return k["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT)
+        except Exception:
+            pass
+    return None, None
 
 
 def committed_step_traffic(workload):
@@ -726,10 +733,10 @@ def run_cfg5(args):
                        "rccl_ranks": None if comm is None else comm.world_size},
             "probe_rel_err_S": err,
         }
-        t_s, src_s = committed_traffic("k_stats_mfma_f32")
+        t_s, src_s = committed_traffic("k_stats_mfma_f32", per_pass_of="k_stats_reduce_f32")
         line["roofline"] = roofline_of(alg_flops, 4.0 * (n * m + 2 * n * L_ + L_ * m * m), us_stats, F32_PEAK_TFLOPS,
                                        kernel="stream_stats_f32 (k_stats_mfma_f32 + v_l + reduction)",
-                                       note="algorithmic flops L N m^2 (symmetric count, SURVEY 8d); executed 1.125x")
+                                       note="algorithmic flops L N m^2 (symmetric count, SURVEY 8d); executed 1.03x (diagonal tiles: upper 32 x 32 blocks only)")
         line["roofline"]["traffic"], line["roofline"]["traffic_source"] = t_s, src_s
         t_k, src_k = committed_traffic("k_knm_f32")
         line["roofline_knm"] = roofline_of((2 * D + 8) * n * m, knm_bytes, us_knm, F32_PEAK_TFLOPS,

@@ -238,15 +238,18 @@ __device__ __forceinline__ f32x4 load_row4(const float* __restrict__ K, long lon
     return v;
 }
 
-template <int ST_KC>
+template <int ST_KC, bool DIAG>
 __global__ __launch_bounds__(ST_NT) void k_stats_mfma_f32(StatsArgs a) {
     extern __shared__ __align__(16) float lds[];
     float* As = lds;                          // [2][ST_KC][ST_LD]
     float* Bs = lds + 2 * ST_KC * ST_LD;      // [2][ST_KC][ST_LD]
     // pair index -> (ti <= tj)
+    // DIAG: the ntile diagonal tiles (blockIdx.x = ti = tj); else the pairs ti < tj
     int ti = 0, rem = blockIdx.x;
-    while (rem >= a.ntile - ti) { rem -= a.ntile - ti; ++ti; }
-    const int tj = ti + rem;
+    if (!DIAG) {
+        while (rem >= a.ntile - 1 - ti) { rem -= a.ntile - 1 - ti; ++ti; }
+    }
+    const int tj = DIAG ? (ti = blockIdx.x) : ti + 1 + rem;
     const int l = blockIdx.y;
     const long long n_begin = (long long)blockIdx.z * a.rows_per_split;
     long long n_end = n_begin + a.rows_per_split;
@@ -257,6 +260,24 @@ __global__ __launch_bounds__(ST_NT) void k_stats_mfma_f32(StatsArgs a) {
     const bool vec = (a.m & 3) == 0;
     const int lr = tid >> 6, lc = (tid & 63) * 4;   // staging: rows lr, lr + 8; columns lc..lc+3
     const float* __restrict__ pl = a.pT + (size_t)l * a.n;
+    // diagonal tiles (ti == tj): S is symmetric, so only the blocks (bi <= bj) of the 8 x 8 grid of 32 x 32 blocks are
+    // computed; the reduction mirrors them.  Block list of wave w (row bi shared with row 7 - bi between two waves):
+    //   even w = 2 r: (r, r) .. (r, r + 4);   odd w = 2 r + 1: the 3 - r remaining blocks of row r, then row 7 - r (r + 1 blocks)
+    constexpr bool diag = DIAG;
+    int dbi[5], dbj[5], dnv = 5;
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(wave), r = wv >> 1;
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            int bi, bj;
+            if (!(wv & 1)) { bi = r; bj = r + t; }
+            else if (t < 3 - r) { bi = r; bj = r + 5 + t; }
+            else { bi = 7 - r; bj = 7 - r + (t - (3 - r)); }
+            if (bj > 7) { bi = 7 - r; bj = 7; }       // the fifth (repeated) block of an odd wave: computed, not stored
+            dbi[t] = 32 * bi; dbj[t] = 32 * bj;
+        }
+        if (wv & 1) dnv = 4;
+    }
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -268,6 +289,11 @@ __global__ __launch_bounds__(ST_NT) void k_stats_mfma_f32(StatsArgs a) {
 
     constexpr int NH = ST_KC / 8;
     f32x4 ga[NH], gb[NH];
+    float gp[NH];      // p_l of the fetched rows: applied when the chunk is staged (a product right behind the loads parks both
+                       // waves of every SIMD -- they sit at the same point of the same workgroup -- for a memory latency per chunk:
+                       // 80.1 -> 77.1 ms per pass at the config-5 shard).  Tried on top and removed: the three-chunks-in-flight
+                       // loop of the float64 GEMM (stores behind the first MFMA group, barrier before the last): 77.1 again; with
+                       // the stores / loads placed between the MFMAs by sched_group_barrier the kernel spills (265 ms).
     // interior tiles / full chunks (all of them at the stress shape) take a branch-free path: plain 16-byte loads
     const bool tile_full = vec && i0 + ST_T <= a.m && j0 + ST_T <= a.m;
     auto fetch = [&](long long nb) {
@@ -278,7 +304,7 @@ __global__ __launch_bounds__(ST_NT) void k_stats_mfma_f32(StatsArgs a) {
                 const float* src = a.K + row * a.m;
                 ga[h] = *reinterpret_cast<const f32x4*>(src + i0 + lc);
                 gb[h] = *reinterpret_cast<const f32x4*>(src + j0 + lc);
-                gb[h] *= pl[row];
+                gp[h] = pl[row];
             }
             return;
         }
@@ -287,15 +313,14 @@ __global__ __launch_bounds__(ST_NT) void k_stats_mfma_f32(StatsArgs a) {
             const long long row = nb + lr + 8 * h;
             ga[h] = load_row4(a.K, row, n_end, a.m, i0 + lc, vec);
             gb[h] = load_row4(a.K, row, n_end, a.m, j0 + lc, vec);
-            const float p = row < n_end ? pl[row] : 0.0f;
-            gb[h] *= p;
+            gp[h] = row < n_end ? pl[row] : 0.0f;
         }
     };
     auto stage = [&](int buf) {
 #pragma unroll
         for (int h = 0; h < NH; ++h) {
             *reinterpret_cast<f32x4*>(As + (buf * ST_KC + lr + 8 * h) * ST_LD + lc) = ga[h];
-            *reinterpret_cast<f32x4*>(Bs + (buf * ST_KC + lr + 8 * h) * ST_LD + lc) = gb[h];
+            *reinterpret_cast<f32x4*>(Bs + (buf * ST_KC + lr + 8 * h) * ST_LD + lc) = gb[h] * gp[h];
         }
     };
 
@@ -310,6 +335,21 @@ __global__ __launch_bounds__(ST_NT) void k_stats_mfma_f32(StatsArgs a) {
         if (more) fetch(nb + ST_KC);
         const float* Ab = As + cur * ST_KC * ST_LD + wi * 128 + (lane & 31);
         const float* Bb = Bs + cur * ST_KC * ST_LD + wj * 64 + (lane & 31);
+        if constexpr (diag) {
+            // diagonal tile: the 36 upper 32 x 32 blocks only, 5 (or 4 + one repeated) per wave -- 5 / 8 of the full tile's MFMAs
+            const float* A0 = As + cur * ST_KC * ST_LD + (lane & 31);
+            const float* B0 = Bs + cur * ST_KC * ST_LD + (lane & 31);
+#pragma unroll
+            for (int kk = 0; kk < ST_KC / 2; ++kk) {
+                const int k = 2 * kk + (lane >> 5);
+                float av[5], bv[5];
+#pragma unroll
+                for (int t = 0; t < 5; ++t) { av[t] = A0[k * ST_LD + dbi[t]]; bv[t] = B0[k * ST_LD + dbj[t]]; }
+#pragma unroll
+                for (int t = 0; t < 5; ++t)
+                    acc[t >> 1][t & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc[t >> 1][t & 1], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int kk = 0; kk < ST_KC / 2; ++kk) {
             const int k = 2 * kk + (lane >> 5);
@@ -324,12 +364,26 @@ __global__ __launch_bounds__(ST_NT) void k_stats_mfma_f32(StatsArgs a) {
                 for (int y = 0; y < 2; ++y)
                     acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[x], bv[y], acc[x][y], 0, 0, 0);
         }
+        }
         if (more) stage(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
 
     float* out = a.part + ((size_t)blockIdx.z * a.L + l) * a.m * a.m;
+    if constexpr (diag) {
+#pragma unroll
+        for (int t = 0; t < 5; ++t) {
+            if (t >= dnv) break;
+            const int j = j0 + dbj[t] + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + dbi[t] + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+                if (i < a.m && j < a.m) out[(size_t)i * a.m + j] = acc[t >> 1][t & 1][r];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -348,7 +402,7 @@ __global__ __launch_bounds__(256) void k_stats_reduce_f32(int m, int L, int nspl
                                                           float* __restrict__ S) {
     const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y, l = blockIdx.z;
     if (j >= m) return;
-    const bool upper = i / ST_T <= j / ST_T;
+    const bool upper = (i >> 5) <= (j >> 5);       // computed: tile pairs ti < tj in full, of a diagonal tile the blocks bi <= bj
     const size_t src = upper ? (size_t)i * m + j : (size_t)j * m + i;
     float acc = 0.0f;
     for (int s = 0; s < nsplit; ++s) acc += part[((size_t)s * L + l) * m * m + src];
@@ -577,9 +631,14 @@ extern "C" int svgp_stream_stats_f32(int64_t n, int m, int L, const float* K_nm,
     // 32-row chunks: 128 MFMAs per wave between barriers (16-row chunks measured 6 % slower)
     constexpr int KC = 32;
     const size_t lds = (size_t)4 * KC * ST_LD * sizeof(float);
-    int rc = set_lds(k_stats_mfma_f32<KC>, lds);
+    int rc = set_lds(k_stats_mfma_f32<KC, false>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_stats_mfma_f32<KC>, dim3(p.npair, L, p.nsplit), dim3(ST_NT), lds, s, a);
+    rc = set_lds(k_stats_mfma_f32<KC, true>, lds);
+    if (rc) return rc;
+    // the full tile pairs first, then the (5 / 8 as expensive) diagonal tiles fill the tail
+    if (p.npair > p.ntile)
+        hipLaunchKernelGGL((k_stats_mfma_f32<KC, false>), dim3(p.npair - p.ntile, L, p.nsplit), dim3(ST_NT), lds, s, a);
+    hipLaunchKernelGGL((k_stats_mfma_f32<KC, true>), dim3(p.ntile, L, p.nsplit), dim3(ST_NT), lds, s, a);
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_stats_reduce_f32, dim3((m + 255) / 256, m, L), dim3(256), 0, s, m, L, p.nsplit, part, S);
     SVGP_LAUNCH_CHECK();

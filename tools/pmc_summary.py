@@ -34,7 +34,8 @@ for w in subs:
         n = max(len(fetch.get(k, [])), len(write.get(k, [])))
         key = k if w in ("", "cfg2") else f"{w}:{k}"
         out["kernels"][key] = {"FETCH_SIZE_KB_mean": f, "dispatches_fetch": len(fetch.get(k, [])), "WRITE_SIZE_KB_mean": wv,
-                               "dispatches_write": len(write.get(k, [])), "hbm_bytes_per_launch_corrected": (2 * f + wv) * 1024}
+                               "dispatches_write": len(write.get(k, [])), "hbm_bytes_per_launch_corrected": (2 * f + wv) * 1024,
+                               "hbm_bytes_total_corrected": (2 * f + wv) * 1024 * n, "dispatches": n}
         tot += (2 * f + wv) * 1024 * n
         if k.startswith("k_adam_tf1"):
             steps += n

@@ -393,9 +393,17 @@ def run_mnist(args):
     # ---- timed region: eps drawn on device every step (tf.random.normal, SVGPVAE_model.py:901)
     eng.bind(d_img, d_aux, None)
     if use_graph:
+        # one GPU: the step as ONE hipGraph replay or as eager launches through the C step entry point -- whichever is faster on
+        # this box in an untimed probe (config 2: 14 launches per step keep the host far ahead and eager wins by ~2.5 %;
+        # config 3: the replayed graph overlaps the two branches of its step slightly better and wins by ~3 %)
         eng.capture("step", adam=True)
-        step = lambda: eng.replay("step")
-        launch = "hipGraph replay"
+        cand = {"hipGraph replay": (lambda: eng.replay("step")), "eager phases": (lambda: eng.run(adam=True))}
+        probe = {}
+        for name, fn in cand.items():
+            probe[name] = min(timed_blocks(fn, eng.synchronize, max(20, args.steps // 4), 5, 3, False, dev))
+        launch = min(probe, key=probe.get)
+        step = cand[launch]
+        launch += " (faster of hipGraph replay / eager phases in an untimed probe)"
     elif launch is not None:
         step = lambda: eng.run(adam=True)
     elif not args.no_graph and multi:

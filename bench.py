@@ -183,6 +183,38 @@ def synthetic_problem(rank, B, M_IND, MDIM, seed=0):
     return params, images, aux, eps
 
 
+def library_comm(multi, local_rank, dev, timeout_s=180.0):
+    """The library's own RCCL communicator (engine.RcclComm), or (None, reason).  With several ranks the decision is COLLECTIVE
+    (MIN over ranks of "I have one"): a rank that failed -- or whose ncclCommInitRank did not return within `timeout_s`; the
+    bootstrap runs in a helper thread for that -- must not leave the others waiting in a collective it never joins."""
+    from svgp_vae_amd.engine import RcclComm
+    if not multi:
+        try:
+            return RcclComm(0, 1, RcclComm.unique_id()), None
+        except Exception as e:
+            return None, repr(e)
+    import threading
+    import torch.distributed as dist
+    box = {}
+
+    def work():
+        try:
+            torch.cuda.set_device(local_rank)          # the current device is per thread; ncclCommInitRank binds to it
+            box["comm"] = RcclComm.from_process_group()
+        except Exception as e:
+            box["err"] = repr(e)
+
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(timeout_s)
+    why = "bootstrap timed out" if t.is_alive() else box.get("err")
+    ok = torch.tensor([1.0 if box.get("comm") is not None else 0.0], dtype=torch.float64, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) < 0.5:
+        return None, why or "another rank has no communicator"
+    return box["comm"], None
+
+
 def stage_table(eng, B, M_IND):
     """(name, C symbol, args, algorithmic flops, algorithmic bytes, implementation-partials bytes) per stage and GPU.
     Flop/byte models: DESIGN.md section 5.  ALGORITHMIC bytes = inputs read once + outputs written once; the
@@ -363,14 +395,13 @@ def run_mnist(args):
     launch, comm_ranks = None, None
     if (multi or args.force_comm) and args.exchange == "rccl":
         # the three all-reduces are issued by the library on the compute stream (svgp_mnist_train_step_dp)
-        try:
-            from svgp_vae_amd.engine import RcclComm
-            comm = RcclComm.from_process_group() if multi else RcclComm(0, 1, RcclComm.unique_id())
+        comm, why = library_comm(multi, local_rank, dev)
+        if comm is not None:
             eng.attach_comm(comm)
             comm_ranks = comm.world_size
             launch = "one in-order stream: phases + in-library RCCL all-reduce x3"
-        except Exception as e:   # both legs are RCCL; this only changes who enqueues the collective
-            print(f"[bench] rank {rank}: in-library RCCL communicator unavailable ({e}); "
+        else:                    # both legs are RCCL; this only changes who enqueues the collective
+            print(f"[bench] rank {rank}: in-library RCCL communicator unavailable ({why}); "
                   f"using torch.distributed all_reduce between per-phase graphs", file=sys.stderr, flush=True)
 
     # ---- parity gate: ONE explicit-eps step (no optimiser update) through the same exchange path the timed region

@@ -39,6 +39,42 @@ def test_dgemm_batched(ta, tb, M, N, K, batch):
     assert float((Cn - want).abs().max()) <= 1e-12 * K * float(want.abs().max() + 1)
 
 
+def test_dgemm_batched_random_tilings():
+    """Seeded sweep over extents that take the 128 a + 96 b tilings, the mixed and the plain tiles, with contractions around the
+    panel depth (steady-state loop / checked tail), padded leading dimensions, pointers that are not 16-byte aligned (scalar loads)
+    and beta = 0 / != 0; the padding columns of C must stay untouched."""
+    import random
+    rnd = random.Random(7)
+    st = torch.cuda.current_stream().cuda_stream
+    for it in range(40):
+        M = rnd.choice([192, 200, 224, 288, 300, 352, 416, 500, 544, 640, 800, 832, 1000, 1056])
+        N = rnd.choice([192, 210, 256, 288, 320, 333, 480, 500, 736, 800, 928, 1024])
+        K = rnd.choice([1, 3, 15, 16, 17, 31, 32, 33, 47, 48, 49, 64, 100, 257])
+        ta, tb = rnd.randint(0, 1), rnd.randint(0, 1)
+        nb = max(1, 200 // (((M + 127) // 128) * ((N + 127) // 128)) + rnd.randint(0, 2))
+        pad_a, pad_b, pad_c, off = rnd.choice([0, 1, 2, 6]), rnd.choice([0, 1, 2, 6]), rnd.choice([0, 3]), rnd.choice([0, 1])
+        ra, ca = (K, M) if ta else (M, K)
+        rb, cb = (N, K) if tb else (K, N)
+        g = torch.Generator(device="cuda").manual_seed(it)
+        Abuf = torch.randn(nb * ra * (ca + pad_a) + 8, dtype=DT, device="cuda", generator=g)
+        Bbuf = torch.randn(nb * rb * (cb + pad_b) + 8, dtype=DT, device="cuda", generator=g)
+        Cbuf = torch.randn(nb * M * (N + pad_c) + 8, dtype=DT, device="cuda", generator=g)
+        A = Abuf[off:off + nb * ra * (ca + pad_a)].view(nb, ra, ca + pad_a)
+        B = Bbuf[off:off + nb * rb * (cb + pad_b)].view(nb, rb, cb + pad_b)
+        Cm = Cbuf[off:off + nb * M * (N + pad_c)].view(nb, M, N + pad_c)
+        C0 = Cm.clone()
+        alpha, beta = 0.7, rnd.choice([0.0, -0.3])
+        _lib.call("svgp_dgemm_batched", ta, tb, M, N, K, alpha, A.data_ptr(), ca + pad_a, ra * (ca + pad_a), B.data_ptr(),
+                  cb + pad_b, rb * (cb + pad_b), beta, Cm.data_ptr(), N + pad_c, M * (N + pad_c), nb, st)
+        torch.cuda.synchronize()
+        opA = A[:, :, :ca].transpose(1, 2) if ta else A[:, :, :ca]
+        opB = B[:, :, :cb].transpose(1, 2) if tb else B[:, :, :cb]
+        want = alpha * opA @ opB + beta * C0[:, :, :N]
+        case = (it, ta, tb, M, N, K, nb, pad_a, pad_b, pad_c, off)
+        assert float((Cm[:, :, :N] - want).abs().max()) <= 1e-12 * K * float(want.abs().max() + 1), case
+        assert pad_c == 0 or torch.equal(Cm[:, :, N:], C0[:, :, N:]), case
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(1050, 500, 1024), (500, 1024, 1050), (1024, 500, 1050), (1050, 4, 500), (2, 500, 1050),
                                    (1050, 2, 500), (300, 300, 1031), (64, 64, 255), (2048, 2048, 512)])

@@ -666,7 +666,13 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     static const int mixed_on = [] { const char* e = getenv("SVGP_GEMM_MIXED"); return (e && e[0] == '0') ? 0 : 1; }();
     const int rem_m = M % 128, rem_n = N % 128;
     const bool edge_m = rem_m > 0 && rem_m <= 64, edge_n = rem_n > 0 && rem_n <= 64;
-    const bool mixed = mixed_on && prec == 0 && M >= 128 && N >= 128 && blocks128 >= 192 && (edge_m || edge_n);
+    // (short contractions -- the K = 128 panel solves / column updates of the blocked Cholesky -- are prologue / epilogue bound and
+    // rarely fill two workgroups per CU with 128-tiles: 672 x 128 x 128 x 65 48.2 -> 38.8 us with the 64-tiles, 544: 46.3 -> 34.5;
+    // potrf 800 x 65 1.32 -> 1.13 ms, SPRITES m = 800 step 25.45 -> 25.10 ms)
+    static const int shortk_on = [] { const char* e = getenv("SVGP_GEMM_SHORTK"); return (e && e[0] == '0') ? 0 : 1; }();
+    const bool short_k = shortk_on && K <= 256 && blocks128 < 1024;
+    const bool mixed = mixed_on && prec == 0 && M >= 128 && N >= 128 && blocks128 >= 192 && (edge_m || edge_n) && !short_k;
+    if (short_k && prec == 0 && wt == 4 && blocks64 >= 512) wt = 2;       // (640 x 128 x 128 x 65: 38.9 -> 37.0 us, 512: 39.0 -> 32.5)
     int edge_w = ((edge_m && rem_m > 32) || (edge_n && rem_n > 32)) ? 2 : 1;
     if (mixed) wt = 4;
     // 128 a + 96 b decomposition of both extents (E = 3) when neither is small: least padding, then most 128-tiles

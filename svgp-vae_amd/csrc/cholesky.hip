@@ -466,7 +466,14 @@ __global__ void k_zero_upper(int m, int ld, long long sA, real* __restrict__ A) 
     const int i = (int)(e / m), j = (int)(e % m);
     if (j > i) A[(size_t)blockIdx.y * sA + (size_t)i * ld + j] = real(0);
 }
-// diagonal blocks of X (m x m, zero-initialised) <- Linv blocks; grid (nblk * 16, batch)
+// the ZBAND columns right of the diagonal of every (m x m, ld) matrix <- 0; grid (ceil(m * ZBAND / 256), batch)
+__global__ void k_zero_band(int m, int ld, long long sA, real* __restrict__ A) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)m * 128) return;
+    const int i = (int)(e / 128), j = i + 1 + (int)(e % 128);
+    if (j < m) A[(size_t)blockIdx.y * sA + (size_t)i * ld + j] = real(0);
+}
+// diagonal blocks of X (m x m, zero above the diagonal where tiles read it) <- Linv blocks; grid (nblk * 16, batch)
 __global__ void k_place_diag_blocks(int m, int nblk, const real* __restrict__ Linv, real* __restrict__ X) {
     const int kb = blockIdx.x / 16, l = blockIdx.y, r0 = kb * CB, n = min(CB, m - r0);
     const real* src = Linv + ((size_t)l * nblk + kb) * CB * CB;
@@ -505,8 +512,11 @@ extern "C" size_t svgp_potri_workspace_elems(int m, int batch) {
 // ---- potrf ----------------------------------------------------------------------------------------------------
 // A (batch, m, lda) SPD -> lower Cholesky factor in place (strict upper triangle zeroed), logdet[l] = log det A[l].
 // On return work[0 .. batch * nblk * 4096) holds the inverses of the 64 x 64 diagonal blocks of L, (batch, nblk, 64, 64).
-extern "C" int svgp_potrf_batched(int m, int batch, double* A, int lda, long long strideA, double* logdet, double* work,
-                                  void* stream) {
+// band != 0 (svgp_potrf_batched_band, for callers inside the library that consume the factor through the tile GEMMs only, like
+// svgp_spd_inverse_batched): instead of the whole strict upper triangle only the `ZBAND` columns right of the diagonal are
+// zeroed -- what a tile of at most ZBAND x ZBAND that touches the diagonal can read of it.
+#define ZBAND 128
+static int potrf_impl(int m, int batch, double* A, int lda, long long strideA, double* logdet, double* work, void* stream, int band) {
     SVGP_REQUIRE(m >= 1 && batch >= 0 && lda >= m, SVGP_ERR_INVALID, "bad m / batch / lda (m=%d batch=%d lda=%d)", m, batch, lda);
     if (batch == 0) return SVGP_OK;
     SVGP_REQUIRE(A && logdet && work, SVGP_ERR_INVALID, "NULL device pointer");
@@ -586,9 +596,17 @@ extern "C" int svgp_potrf_batched(int m, int batch, double* A, int lda, long lon
                                     batch, side));
     }
     if (side_open) RUNC(svgp_side_branch_join(stream, 0));
-    hipLaunchKernelGGL(k_zero_upper, dim3(nblk256((long long)m * m), batch), dim3(256), 0, s, m, lda, strideA, A);
+    if (band) hipLaunchKernelGGL(k_zero_band, dim3(nblk256((long long)m * ZBAND), batch), dim3(256), 0, s, m, lda, strideA, A);
+    else hipLaunchKernelGGL(k_zero_upper, dim3(nblk256((long long)m * m), batch), dim3(256), 0, s, m, lda, strideA, A);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
+}
+extern "C" int svgp_potrf_batched(int m, int batch, double* A, int lda, long long strideA, double* logdet, double* work,
+                                  void* stream) {
+    return potrf_impl(m, batch, A, lda, strideA, logdet, work, stream, 0);
+}
+int svgp_potrf_batched_band(int m, int batch, double* A, int lda, long long strideA, double* logdet, double* work, void* stream) {
+    return potrf_impl(m, batch, A, lda, strideA, logdet, work, stream, 1);
 }
 
 // ---- trsm -----------------------------------------------------------------------------------------------------
@@ -692,7 +710,10 @@ extern "C" int svgp_potri_batched(int m, int batch, double* A, const double* lin
         SVGP_LAUNCH_CHECK();
         linv_blocks = Linv;
     }
-    SVGP_CHECK_HIP(hipMemsetAsync(X, 0, (size_t)batch * mm * sizeof(real), s));
+    // X above the diagonal: only the band a diagonal-touching tile reads (the rest of the upper triangle is never read: every
+    // product below runs with contraction ranges cut to the tile's rows / columns)
+    hipLaunchKernelGGL(k_zero_band, dim3(nblk256((long long)m * 128), batch), dim3(256), 0, s, m, m, (long long)mm, X);
+    SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_place_diag_blocks, dim3(nblk * 16, batch), dim3(256), 0, s, m, nblk, linv_blocks, X);
     SVGP_LAUNCH_CHECK();
     RUNC(trtri_rec(m, batch, A, X, T, 0, nblk, stream));

@@ -29,7 +29,7 @@ def _potrf(A):
     batch, m = A.shape[0], A.shape[1]
     Lf = A.clone()
     logdet = torch.full((batch,), float("nan"), dtype=DT, device="cuda")
-    work = torch.zeros(lib.svgp_potrf_workspace_elems(m, batch), dtype=DT, device="cuda")
+    work = torch.full((lib.svgp_potrf_workspace_elems(m, batch),), float("nan"), dtype=DT, device="cuda")   # poisoned: nothing may be read unwritten
     _lib.call("svgp_potrf_batched", m, batch, Lf.data_ptr(), m, m * m, logdet.data_ptr(), work.data_ptr(),
               torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
@@ -46,7 +46,7 @@ def test_potrf_potri_against_torch(m, batch):
     assert float(torch.triu(Lf, 1).abs().max()) == 0.0
     assert float((logdet - torch.linalg.slogdet(A)[1]).abs().max()) < 1e-10 * max(m, 8)
     lib = _lib.load_library()
-    w2 = torch.zeros(lib.svgp_potri_workspace_elems(m, batch), dtype=DT, device="cuda")
+    w2 = torch.full((lib.svgp_potri_workspace_elems(m, batch),), float("nan"), dtype=DT, device="cuda")
     nb = (m + 63) // 64
     for blocks in (work[:batch * nb * 4096], None):             # diagonal-block inverses from potrf / recomputed
         inv = Lf.clone()
@@ -68,7 +68,7 @@ def test_potrf_strided_and_padded_leading_dimension():
     buf[:, :m, :m] = A
     logdet = torch.zeros(batch, dtype=DT, device="cuda")
     lib = _lib.load_library()
-    work = torch.zeros(lib.svgp_potrf_workspace_elems(m, batch), dtype=DT, device="cuda")
+    work = torch.full((lib.svgp_potrf_workspace_elems(m, batch),), float("nan"), dtype=DT, device="cuda")   # poisoned: nothing may be read unwritten
     _lib.call("svgp_potrf_batched", m, batch, buf.data_ptr(), lda, (m + 5) * lda, logdet.data_ptr(), work.data_ptr(),
               torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
@@ -110,7 +110,7 @@ def test_cholesky_on_kernel_like_spectrum(m, jitter):
     assert float((Lf[0] @ Lf[0].T - A).abs().max()) < 1e-13 * float(A.abs().max()) * m
     assert abs(float(logdet[0]) - float(torch.log(lam + jitter).sum())) < 1e-8 * m
     lib = _lib.load_library()
-    w2 = torch.zeros(lib.svgp_potri_workspace_elems(m, 1), dtype=DT, device="cuda")
+    w2 = torch.full((lib.svgp_potri_workspace_elems(m, 1),), float("nan"), dtype=DT, device="cuda")
     X = Lf.clone()
     _lib.call("svgp_potri_batched", m, 1, X.data_ptr(), None, w2.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()

@@ -111,7 +111,7 @@ def test_spd_inverse_batched(m, batch):
     inv = A.clone()
     logdet = torch.zeros(batch, dtype=DT, device="cuda")
     lib = _lib.load_library()
-    work = torch.zeros(lib.svgp_spd_inverse_workspace_elems(m, batch), dtype=DT, device="cuda")
+    work = torch.full((lib.svgp_spd_inverse_workspace_elems(m, batch),), float("nan"), dtype=DT, device="cuda")   # poisoned scratch
     _lib.call("svgp_spd_inverse_batched", m, batch, inv.data_ptr(), logdet.data_ptr(), work.data_ptr(),
               torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
@@ -138,7 +138,7 @@ def test_spd_inverse_residual_on_kernel_like_spectrum(m, jitter):
     X = A.clone()[None].contiguous()
     logdet = torch.zeros(1, dtype=DT, device="cuda")
     lib = _lib.load_library()
-    work = torch.zeros(lib.svgp_spd_inverse_workspace_elems(m, 1), dtype=DT, device="cuda")
+    work = torch.full((lib.svgp_spd_inverse_workspace_elems(m, 1),), float("nan"), dtype=DT, device="cuda")
     _lib.call("svgp_spd_inverse_batched", m, 1, X.data_ptr(), logdet.data_ptr(), work.data_ptr(),
               torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()

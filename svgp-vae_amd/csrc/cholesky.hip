@@ -484,6 +484,16 @@ __global__ void k_place_diag_blocks(int m, int nblk, const real* __restrict__ Li
     }
 }
 
+// 128 x 128 diagonal blocks of X <- the inverse blocks k_chol_diag2 left in Linv2 (rows r0 .. r0 + n, 64 < n <= 128); grid (64, batch)
+__global__ void k_place_diag_block2(int m, int r0, int n, int slot, int nblk2, const real* __restrict__ Linv2, real* __restrict__ X) {
+    const int l = blockIdx.y;
+    const real* src = Linv2 + ((size_t)l * nblk2 + slot) * (4 * CB * CB);
+    real* dst = X + (size_t)l * m * m + (size_t)r0 * m + r0;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < 4 * CB * CB; e += 64 * 256) {
+        const int i = e / (2 * CB), j = e % (2 * CB);
+        if (i < n && j < n) dst[(size_t)i * m + j] = src[e];
+    }
+}
 inline unsigned nblk256(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -516,6 +526,10 @@ extern "C" size_t svgp_potri_workspace_elems(int m, int batch) {
 // svgp_spd_inverse_batched): instead of the whole strict upper triangle only the `ZBAND` columns right of the diagonal are
 // zeroed -- what a tile of at most ZBAND x ZBAND that touches the diagonal can read of it.
 #define ZBAND 128
+static bool potrf_wide_steps(int m) {
+    static const int wide_on = [] { const char* e = getenv("SVGP_POTRF_BLOCK"); return (e && atoi(e) == 64) ? 0 : 1; }();
+    return wide_on && m >= 640;
+}
 static int potrf_impl(int m, int batch, double* A, int lda, long long strideA, double* logdet, double* work, void* stream, int band) {
     SVGP_REQUIRE(m >= 1 && batch >= 0 && lda >= m, SVGP_ERR_INVALID, "bad m / batch / lda (m=%d batch=%d lda=%d)", m, batch, lda);
     if (batch == 0) return SVGP_OK;
@@ -539,8 +553,7 @@ static int potrf_impl(int m, int batch, double* A, int lda, long long strideA, d
     d.onewave = d2.onewave = onewave;
     // Block steps of W = 128 rows from m >= 640 (k_chol_diag2: half the dependent launches, K = 128 products), 64 below
     // (SVGP_POTRF_BLOCK=64 forces the 64-wide steps).
-    static const int wide_on = [] { const char* e = getenv("SVGP_POTRF_BLOCK"); return (e && atoi(e) == 64) ? 0 : 1; }();
-    const int W = (wide_on && m >= 640) ? 2 * CB : CB, nstep = (m + W - 1) / W;   // (256 x 17: 243 -> 255 us, 512 x 16: 553 -> 561 with the wide steps)
+    const int W = potrf_wide_steps(m) ? 2 * CB : CB, nstep = (m + W - 1) / W;   // (256 x 17: 243 -> 255 us, 512 x 16: 553 -> 561 with the wide steps)
     // Look-ahead (right-looking with the trailing update split): after panel k is solved, ONLY block column k + 1 is updated on
     // the caller's stream -- that is all the next diagonal block and the next panel solve need -- and the rest of the trailing
     // update (columns k + 2 ..) runs on a side branch beside them: a block step costs max(trailing update, column update +
@@ -672,12 +685,12 @@ extern "C" int svgp_trsm_batched(int side, int trans, int m, int n, const double
 // ---- potri ----------------------------------------------------------------------------------------------------
 namespace {
 // X[lo:hi, lo:hi] (in 64-blocks) <- inverse of the lower-triangular L[lo:hi, lo:hi]; diagonal blocks are already placed.
-int trtri_rec(int m, int batch, const real* L, real* X, real* T, int blo, int bhi, void* stream) {
+int trtri_rec(int m, int batch, const real* L, real* X, real* T, int blo, int bhi, void* stream, int bw = CB) {
     if (bhi - blo <= 1) return SVGP_OK;
     const int bmid = blo + (bhi - blo + 1) / 2;
-    RUNC(trtri_rec(m, batch, L, X, T, blo, bmid, stream));
-    RUNC(trtri_rec(m, batch, L, X, T, bmid, bhi, stream));
-    const int r1 = blo * CB, r2 = bmid * CB, r3 = bhi * CB < m ? bhi * CB : m, n1 = r2 - r1, n2 = r3 - r2;
+    RUNC(trtri_rec(m, batch, L, X, T, blo, bmid, stream, bw));
+    RUNC(trtri_rec(m, batch, L, X, T, bmid, bhi, stream, bw));
+    const int r1 = blo * bw, r2 = bmid * bw, r3 = bhi * bw < m ? bhi * bw : m, n1 = r2 - r1, n2 = r3 - r2;
     const long long mm = (long long)m * m, sT = (long long)n2 * n1;
     // T = L21 X11  (X11 lower triangular: the contraction starts at the tile's first column)
     RUNC(svgp_dgemm_tri_batched(4, 0, 0, n2, n1, n1, 1.0, L + (size_t)r2 * m + r1, m, mm, X + (size_t)r1 * m + r1, m, mm, 0.0,
@@ -691,7 +704,10 @@ int trtri_rec(int m, int batch, const real* L, real* X, real* T, int blo, int bh
 
 // A (batch, m, m) contiguous holding the factor L of svgp_potrf_batched -> A^-1 = L^-T L^-1 (full symmetric matrix).
 // `linv_blocks` = the potrf workspace head (inverses of the diagonal blocks of L), or NULL: they are recomputed.
-extern "C" int svgp_potri_batched(int m, int batch, double* A, const double* linv_blocks, double* work, void* stream) {
+// linv2 != NULL (svgp_potri_batched_wide, after a factorisation that ran with 128-wide block steps): the 128 x 128 inverse
+// blocks of those steps are placed as they are and the recursion starts one level higher -- half the leaves, and the twelve
+// (m = 800) smallest product launches of the halving, which are launch-bound, disappear.
+static int potri_impl(int m, int batch, double* A, const double* linv_blocks, const double* linv2, double* work, void* stream) {
     SVGP_REQUIRE(m >= 1 && batch >= 0, SVGP_ERR_INVALID, "bad m / batch");
     if (batch == 0) return SVGP_OK;
     SVGP_REQUIRE(A && work, SVGP_ERR_INVALID, "NULL device pointer");
@@ -716,7 +732,18 @@ extern "C" int svgp_potri_batched(int m, int batch, double* A, const double* lin
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_place_diag_blocks, dim3(nblk * 16, batch), dim3(256), 0, s, m, nblk, linv_blocks, X);
     SVGP_LAUNCH_CHECK();
-    RUNC(trtri_rec(m, batch, A, X, T, 0, nblk, stream));
+    if (linv2) {
+        const int nblk2 = (m + 2 * CB - 1) / (2 * CB);
+        for (int kb = 0; kb < nblk2; ++kb) {
+            const int r0 = kb * 2 * CB, n = m - r0 < 2 * CB ? m - r0 : 2 * CB;
+            if (n <= CB) continue;                      // a last step of at most 64 rows was a plain 64-block
+            hipLaunchKernelGGL(k_place_diag_block2, dim3(64, batch), dim3(256), 0, s, m, r0, n, kb, nblk2, linv2, X);
+            SVGP_LAUNCH_CHECK();
+        }
+        RUNC(trtri_rec(m, batch, A, X, T, 0, nblk2, stream, 2 * CB));
+    } else {
+        RUNC(trtri_rec(m, batch, A, X, T, 0, nblk, stream));
+    }
     // A^-1 = X^T X, X lower triangular: the contraction starts at max(first row, first column) of the tile; the result is
     // symmetric, so only the tiles that touch the lower triangle are computed and stored mirrored (as LAPACK's potri returns one
     // triangle): 28 instead of 49 tiles per matrix at m = 800 (SVGP_POTRI_FULL=1: both triangles computed)
@@ -724,4 +751,13 @@ extern "C" int svgp_potri_batched(int m, int batch, double* A, const double* lin
     RUNC(svgp_dgemm_tri_batched(potri_full ? (2 | 4) : (1 | 2 | 4 | 16), 1, 0, m, m, m, 1.0, X, m, mm, X, m, mm, 0.0, A, m, mm, batch,
                                 stream));
     return SVGP_OK;
+}
+extern "C" int svgp_potri_batched(int m, int batch, double* A, const double* linv_blocks, double* work, void* stream) {
+    return potri_impl(m, batch, A, linv_blocks, nullptr, work, stream);
+}
+// `potrf_work` = the workspace svgp_potrf_batched[_band] has just filled for the same (m, batch)
+int svgp_potri_batched_wide(int m, int batch, double* A, const double* potrf_work, double* work, void* stream) {
+    const int nblk = (m + CB - 1) / CB;
+    const double* linv2 = potrf_wide_steps(m) ? potrf_work + (size_t)batch * nblk * CB * CB : nullptr;
+    return potri_impl(m, batch, A, potrf_work, linv2, work, stream);
 }

@@ -40,6 +40,7 @@ void svgp_set_error(const char* fmt, ...);
 // api.hip: fork / join of the library-owned side branch of a caller stream (one per (device, stream))
 int svgp_side_branch_fork(void* main_stream, void** side_stream_out, int k = 1);
 // cholesky.hip: svgp_potrf_batched that zeroes only the 128 columns right of the diagonal (library-internal consumers)
+int svgp_potri_batched_wide(int m, int batch, double* A, const double* potrf_work, double* work, void* stream);
 int svgp_potrf_batched_band(int m, int batch, double* A, int lda, long long strideA, double* logdet, double* work, void* stream);
 int svgp_side_branch_join(void* main_stream, int k = 1);
 int svgp_mnist_step_phase_deferred(const svgp_mnist_cfg* c, int phase, double* theta, const double* images,

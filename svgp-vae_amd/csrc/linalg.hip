@@ -968,5 +968,5 @@ extern "C" int svgp_spd_inverse_batched(int m, int batch, double* A, double* log
     if (m < CHOL_INVERSE_MIN_M) return svgp_spd_inverse_fused(m, batch, A, logdet, 0, nullptr, nullptr, work, stream);
     int rc = svgp_potrf_batched_band(m, batch, A, m, (long long)m * m, logdet, work, stream);
     if (rc) return rc;
-    return svgp_potri_batched(m, batch, A, work, work + svgp_potrf_workspace_elems(m, batch), stream);
+    return svgp_potri_batched_wide(m, batch, A, work, work + svgp_potrf_workspace_elems(m, batch), stream);
 }

@@ -528,7 +528,7 @@ extern "C" size_t svgp_potri_workspace_elems(int m, int batch) {
 #define ZBAND 128
 static bool potrf_wide_steps(int m) {
     static const int wide_on = [] { const char* e = getenv("SVGP_POTRF_BLOCK"); return (e && atoi(e) == 64) ? 0 : 1; }();
-    return wide_on && m >= 640;
+    return wide_on && m >= 512;
 }
 static int potrf_impl(int m, int batch, double* A, int lda, long long strideA, double* logdet, double* work, void* stream, int band) {
     SVGP_REQUIRE(m >= 1 && batch >= 0 && lda >= m, SVGP_ERR_INVALID, "bad m / batch / lda (m=%d batch=%d lda=%d)", m, batch, lda);
@@ -551,7 +551,8 @@ static int potrf_impl(int m, int batch, double* A, int lda, long long strideA, d
     // diagonal blocks on one wave with a row per lane (chol64_wave); SVGP_CHOL_WAVE=0: the four-wave register-tiled form
     static const int onewave = [] { const char* e = getenv("SVGP_CHOL_WAVE"); return (e && e[0] == '0') ? 0 : 1; }();
     d.onewave = d2.onewave = onewave;
-    // Block steps of W = 128 rows from m >= 640 (k_chol_diag2: half the dependent launches, K = 128 products), 64 below
+    // Block steps of W = 128 rows from m >= 512 (k_chol_diag2: half the dependent launches, K = 128 products; the triangular inverse
+    // of svgp_spd_inverse_batched then starts from 128-blocks: 512 x 16 inverse 557 -> 522 us), 64 below
     // (SVGP_POTRF_BLOCK=64 forces the 64-wide steps).
     const int W = potrf_wide_steps(m) ? 2 * CB : CB, nstep = (m + W - 1) / W;   // (256 x 17: 243 -> 255 us, 512 x 16: 553 -> 561 with the wide steps)
     // Look-ahead (right-looking with the trailing update split): after panel k is solved, ONLY block column k + 1 is updated on

@@ -200,6 +200,8 @@ def library_comm(multi, local_rank, dev, timeout_s=180.0):
     def work():
         try:
             torch.cuda.set_device(local_rank)          # the current device is per thread; ncclCommInitRank binds to it
+            if os.environ.get("SVGP_BENCH_FAIL_LIBCOMM") == "1":      # test hook: the fallback decision path
+                raise RuntimeError("library communicator disabled by SVGP_BENCH_FAIL_LIBCOMM")
             box["comm"] = RcclComm.from_process_group()
         except Exception as e:
             box["err"] = repr(e)

@@ -193,6 +193,15 @@ def test_bench_multi_gpu_code_path_at_world_size_one():
             assert line["config"]["rccl_ranks"] == 1
             assert list(line["collectives_us"]) == ["ar[S|v]", "ar[A2|ud|td]", "ar[grad|sums]"]
             assert all(0 < v < 1e4 for v in line["collectives_us"].values())
+    # a rank whose library communicator cannot be created: the collective decision sends every rank to the torch.distributed form
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29534", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3",
+           "--no-cpu-baseline", "--force-dist"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, SVGP_BENCH_FAIL_LIBCOMM="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "torch.distributed" in line["config"]["launch"] and line["value"] > 100 and line["config"]["rccl_ranks"] == 1
+    assert "in-library RCCL communicator unavailable" in r.stderr
     # config 3 (channel-sharded sequence: five grouped points) through the same code path
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "cfg3", "--steps", "5",

@@ -592,6 +592,22 @@ def run_sprites(args):
     stages = {}
     for (n0, e0), (_, e1) in zip(marks[:-1], marks[1:]):
         stages[n0] = stages.get(n0, 0.0) + e0.elapsed_time(e1) * 1e3
+    # ... and the same step issued on ONE stream (side branches switched off: the same launches in program order, bit-identical
+    # results -- tests/test_gpu_sprites.py), where a stage group's time is the time of its own launches; inside the three-stream
+    # step the groups share the chip with the side branches' GEMMs and their wall time says how the step was scheduled
+    stages_alone = None
+    if getattr(eng, "side", None) is not None and not os.environ.get("SVGP_BENCH_NO_STAGES"):
+        keep = (eng.side, eng.side2)
+        eng.side = eng.side2 = None
+        step(); eng.stream.synchronize()
+        eng.trace = []
+        step()
+        eng.stream.synchronize()
+        marks1, eng.trace = eng.trace, None
+        eng.side, eng.side2 = keep
+        stages_alone = {}
+        for (n0, e0), (_, e1) in zip(marks1[:-1], marks1[1:]):
+            stages_alone[n0] = stages_alone.get(n0, 0.0) + e0.elapsed_time(e1) * 1e3
     sc = eng.scalars()
     assert math.isfinite(sc["elbo"]), sc
     # per-exchange-point microseconds (events around pack + grouped RCCL launch + unpack), maximum over ranks
@@ -654,6 +670,12 @@ def run_sprites(args):
                                  "frac_of_f32_peak": (nets + gp) / (ms * 1e-3) / 1e12 / F32_PEAK_TFLOPS}
         line["step_roofline"]["traffic"], line["step_roofline"]["traffic_source"] = committed_step_traffic("sp800")
         line["stages_us"] = {k: round(v, 1) for k, v in sorted(stages.items(), key=lambda kv: -kv[1])}
+        if stages_alone is not None:
+            line["stages_one_stream_us"] = {k: round(v, 1) for k, v in sorted(stages_alone.items(), key=lambda kv: -kv[1])}
+            line["nets_ms"] = {"in_step": round(sum(v for k, v in stages.items() if k.startswith("nets")) / 1e3, 3),
+                               "one_stream": round(sum(v for k, v in stages_alone.items() if k.startswith("nets")) / 1e3, 3),
+                               "note": "sum of the four network stage groups; in_step = wall time between stage events while the "
+                                       "side branches' GEMMs share the chip, one_stream = the same launches with nothing beside them"}
         if coll_us is not None:
             names = (["rs[S|v]", "ag[Si|M2|t|u]", "rs[A2|ud|td]", "ag[Ssym|vbar|KL]", "ar[grad|sums]"] if len(coll_us) == 5
                      else ["ar[S|v]", "ar[A2|ud|td]", "ar[grad|sums]"])

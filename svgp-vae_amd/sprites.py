@@ -210,6 +210,10 @@ class SpritesStepEngine:
         self.scratch = torch.zeros(max(l.scratch_elems(self.nwg) for l in self.enc + self.dec + self.rep),
                                    dtype=self.ndt, device=self.dev)
         self.kscratch = torch.zeros(b_max * self.La + (self.m + b_max) * 4 + 16, **f64)
+        # second weight-gradient scratch: the encoder reverse pass runs on the side stream beside the kernel-matrix reverse pass
+        # and the representation network's (phases(), end of the step)
+        self.scratch2 = None if self.side is None else torch.zeros(max(l.scratch_elems(self.nwg) for l in self.enc),
+                                                                   dtype=self.ndt, device=self.dev)
         self.stream.synchronize()
         self.act = {}
 
@@ -226,10 +230,11 @@ class SpritesStepEngine:
         off = getattr(self.wl, name)
         return self.ws[off:off + int(np.prod(shape))].view(shape)
 
-    def _gemm(self, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, Cm, ldc):
+    def _gemm(self, ta, tb, M, N, K, alpha, A, lda, B, ldb, beta, Cm, ldc, stream=None):
         assert A.dtype == B.dtype == Cm.dtype
         call("svgp_sgemm_batched" if A.dtype == torch.float32 else "svgp_dgemm_batched", ta, tb, M, N, K, float(alpha),
-             A.data_ptr(), lda, 0, B.data_ptr(), ldb, 0, float(beta), Cm.data_ptr(), ldc, 0, 1, self.stream.cuda_stream)
+             A.data_ptr(), lda, 0, B.data_ptr(), ldb, 0, float(beta), Cm.data_ptr(), ldc, 0, 1,
+             self.stream.cuda_stream if stream is None else stream)
 
     def _sync_net_params(self):
         """float32 networks: refresh the float32 copy of the network weights from the float64 master vector."""
@@ -524,6 +529,31 @@ class SpritesStepEngine:
             call("svgp_gp_posterior_bwd", cp, ws, st, s)
             if self.svgp.titsias:
                 call("svgp_gp_titsias_bwd", cp, ws, st, s)
+            # The end of the step is two independent chains of small launches (5 - 7 us each, the GPU is waiting for the next one
+            # most of the time): kernel-matrix reverse pass -> representation network, and encoder head -> encoder.  Both need
+            # only the reverse row stage above, so the encoder chain goes to the side stream (idle since the reverse factor stage)
+            # with its own weight-gradient scratch: 1.12 -> 0.65 ms for this tail at m = 800.  SVGP_SIDE_STREAMS=0: in line.
+            enc_side = self.side is not None and os.environ.get("SVGP_SPRITES_ENC_SIDE") != "0"
+
+            def encoder_bwd(sx, scratch):
+                d_enc = torch.empty(b, 2 * L, **f64)
+                call("svgp_enc_head_bwd", b, L, int(self.clip_qs), var_raw.data_ptr(), self._v("ybar", (1,)).data_ptr(),
+                     self._v("s2bar", (1,)).data_ptr(), d_enc.data_ptr(), sx)
+                d_enc = d_enc.to(self.ndt)
+                a6 = a[5].view(b, 1024)
+                self._gemm(1, 0, 1024, 2 * L, b, 1.0, a6, 1024, d_enc, 2 * L, 0.0, gn["enc_d_w"], 2 * L, stream=sx)
+                gn["enc_d_b"].copy_(d_enc.sum(0))
+                dxe = torch.empty(b, 8, 8, 16, **nd)
+                self._gemm(0, 1, b, 1024, 2 * L, 1.0, d_enc, 2 * L, pn["enc_d_w"], 2 * L, 0.0, dxe, 1024, stream=sx)
+                for i in range(6, 0, -1):
+                    xin = a[i - 2] if i > 1 else images
+                    dxe = self.enc[i - 1].backward(xin, pn[f"enc_c{i}_w"], a[i - 1], dxe, gn[f"enc_c{i}_w"], gn[f"enc_c{i}_b"],
+                                                   scratch, sx, need_dx=i > 1, nwg=self.nwg)
+
+            if enc_side:
+                self.side.wait_stream(self.stream)
+                with torch.cuda.stream(self.side):
+                    encoder_bwd(self.side.cuda_stream, self.scratch2)
             d_char = torch.empty(b, self.Lc, **f64)
             call("svgp_sprites_kernel_matrix_bwd", C.byref(kc), aux.data_ptr(), p["inducing_index_points"].data_ptr(),
                  p["GPLVM_action"].data_ptr(), p["se"].data_ptr(), self._v("Kbar", (1,)).data_ptr(),
@@ -540,19 +570,10 @@ class SpritesStepEngine:
                 xin = r[i - 2] if i > 1 else images
                 dx = self.rep[i - 1].backward(xin, pn[f"repr_c{i}_w"], r[i - 1], dx, gn[f"repr_c{i}_w"], gn[f"repr_c{i}_b"],
                                               self.scratch, s, need_dx=i > 1, nwg=self.nwg)
-            d_enc = torch.empty(b, 2 * L, **f64)
-            call("svgp_enc_head_bwd", b, L, int(self.clip_qs), var_raw.data_ptr(), self._v("ybar", (1,)).data_ptr(),
-                 self._v("s2bar", (1,)).data_ptr(), d_enc.data_ptr(), s)
-            d_enc = d_enc.to(self.ndt)
-            a6 = a[5].view(b, 1024)
-            self._gemm(1, 0, 1024, 2 * L, b, 1.0, a6, 1024, d_enc, 2 * L, 0.0, gn["enc_d_w"], 2 * L)
-            gn["enc_d_b"].copy_(d_enc.sum(0))
-            dx = torch.empty(b, 8, 8, 16, **nd)
-            self._gemm(0, 1, b, 1024, 2 * L, 1.0, d_enc, 2 * L, pn["enc_d_w"], 2 * L, 0.0, dx, 1024)
-            for i in range(6, 0, -1):
-                xin = a[i - 2] if i > 1 else images
-                dx = self.enc[i - 1].backward(xin, pn[f"enc_c{i}_w"], a[i - 1], dx, gn[f"enc_c{i}_w"], gn[f"enc_c{i}_b"],
-                                              self.scratch, s, need_dx=i > 1, nwg=self.nwg)
+            if enc_side:
+                self.stream.wait_stream(self.side)
+            else:
+                encoder_bwd(s, self.scratch)
             if self.f32:                                       # float32 network gradients -> the float64 gradient vector
                 self.grad[:self.n_net].copy_(self.grad_n)
             # frozen parameter groups (inverted flags of SPRITES_experiment.py:109-111)

@@ -102,6 +102,33 @@ def test_sprites_training_steps_reduce_the_loss():
     assert eng.scalars()["adam_t"] == 8.0
 
 
+@pytest.mark.parametrize("net_dtype", [torch.float64, torch.float32])
+def test_sprites_side_streams_equal_one_stream(net_dtype):
+    """m > 64: three Adam steps with the side branches (forward-factor tail + early reverse half, and the encoder reverse pass
+    beside the kernel-matrix / representation-network reverse pass) against the same engine with every launch on one stream:
+    identical parameters and Adam state, bit for bit (the same kernels on the same values, only the order of issue differs)."""
+    from svgp_vae_amd import sprites as S
+    b, frames, L, La, Lc, m, n_act = 24, 4, 6, 8, 16, 72, 9
+    params, gp, images, ids, eps, seg, rep = _problem(b, frames, L, La, Lc, m, n_act, seed=5)
+    out = []
+    for one_stream in (False, True):
+        svgp = S.spritesSVGP(False, False, gp["inducing_index_points"].numpy(), 'main', 0.01, 100.0, La,
+                             gp["GPLVM_action"].numpy(), Lc, L, K_obj_normalize=True)
+        eng = S.SpritesStepEngine(S.spritesVAE(L), S.sprites_representation_network(Lc), svgp, b_max=b, seg_len=frames,
+                                  geco=True, lr=3e-3, clip_grad=1e6, net_dtype=net_dtype)
+        assert eng.side is not None and eng.scratch2 is not None
+        if one_stream:
+            eng.side = eng.side2 = None
+        dev = eng.dev
+        di, da, de = images.to(dev, net_dtype), ids.to(dev, DT), eps.to(dev)
+        for _ in range(3):
+            eng.step(di, da, de, adam=True)
+        eng.stream.synchronize()
+        out.append((eng.theta.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.state.clone()))
+    for x, y in zip(*out):
+        assert torch.equal(x, y)
+
+
 @pytest.mark.parametrize("G,K_SE,m,clip,shard,L,pack", [(2, False, 12, None, None, 6, "0"), (3, True, 72, 0.05, None, 6, "0"),
                                                          (2, False, 72, None, False, 6, "0"), (2, True, 72, None, True, 6, "0"),
                                                          (8, False, 72, None, True, 8, "0"), (3, True, 72, 0.05, None, 6, "1"),

@@ -273,9 +273,10 @@ class SpritesStepEngine:
              var_raw.data_ptr(), var.data_ptr(), s)
         return a, enc, mu, var_raw, var
 
-    def _repr_forward(self, images, b):
-        """sprites_representation_network (VAE_utils.py:375-391): per-frame character vectors (b, L_character)."""
-        p, s = self.np_, self.stream.cuda_stream
+    def _repr_forward(self, images, b, stream=None):
+        """sprites_representation_network (VAE_utils.py:375-391): per-frame character vectors (b, L_character).
+        stream: torch stream the launches go to (the caller has made it current); default the engine's."""
+        p, s = self.np_, (self.stream if stream is None else stream).cuda_stream
         nd = dict(dtype=self.ndt, device=self.dev)
         r, x = [], images
         for i, lay in enumerate(self.rep, 1):
@@ -400,21 +401,37 @@ class SpritesStepEngine:
             images = images.to(self.ndt).contiguous()
             self._sync_net_params()
             self._mark("nets_fwd_enc")
-            a, enc, mu, var_raw, var = self._encoder_forward(images, b)
-            r, rvec = self._repr_forward(images, b)
-            aux = torch.empty(b, 1 + self.Lc, **f64)
-            aid = action_ids.to(_F64).contiguous()
-            call("svgp_sprites_aux_fwd", b, self.seg_len, self.Lc, rvec.data_ptr(), aid.data_ptr(), aux.data_ptr(), s)
-            # ---------------- kernel matrices + sparse-GP block
-            self._mark("gp_fwd_stats")
             kc = SpritesKcfg(b=b, m=self.m, La=self.La, Lc=self.Lc, n_act=self.n_act,
                              normalize=int(self.svgp.K_obj_normalize), k_se=int(self.svgp.K_SE),
                              # Kbar-derived terms: replicated on every rank (counted on rank 0) -- or, channel-sharded,
                              # every rank's Kbar is its window's share and all shares count
                              rep_weight=1.0 if (self.rank == 0 or self.chan_shard) else 0.0)
             K, Kn, knn = self._v("K", (self.m, self.m)), self._v("Kn", (b, self.m)), self._v("knn", (b,))
-            call("svgp_sprites_kernel_matrix_fwd", C.byref(kc), aux.data_ptr(), p["inducing_index_points"].data_ptr(),
-                 p["GPLVM_action"].data_ptr(), p["se"].data_ptr(), K.data_ptr(), Kn.data_ptr(), knn.data_ptr(), s)
+            aid = action_ids.to(_F64).contiguous()
+
+            def repr_and_kernel_matrices(strm):
+                r_, rvec = self._repr_forward(images, b, stream=strm)
+                aux_ = torch.empty(b, 1 + self.Lc, **f64)
+                call("svgp_sprites_aux_fwd", b, self.seg_len, self.Lc, rvec.data_ptr(), aid.data_ptr(), aux_.data_ptr(),
+                     strm.cuda_stream)
+                call("svgp_sprites_kernel_matrix_fwd", C.byref(kc), aux_.data_ptr(), p["inducing_index_points"].data_ptr(),
+                     p["GPLVM_action"].data_ptr(), p["se"].data_ptr(), K.data_ptr(), Kn.data_ptr(), knn.data_ptr(),
+                     strm.cuda_stream)
+                return r_, aux_
+
+            # the step opens with two independent chains of small launches: representation network -> auxiliary data -> kernel
+            # matrices, and the encoder; the first goes to the side stream (SVGP_SPRITES_ENC_SIDE=0 / one stream: in line)
+            if self.side is not None and os.environ.get("SVGP_SPRITES_ENC_SIDE") != "0":
+                self.side.wait_stream(self.stream)
+                with torch.cuda.stream(self.side):
+                    r, aux = repr_and_kernel_matrices(self.side)
+                a, enc, mu, var_raw, var = self._encoder_forward(images, b)
+                self.stream.wait_stream(self.side)
+            else:
+                a, enc, mu, var_raw, var = self._encoder_forward(images, b)
+                r, aux = repr_and_kernel_matrices(self.stream)
+            # ---------------- sparse-GP block
+            self._mark("gp_fwd_stats")
             call("svgp_gp_stats_fwd", cp, ws, s)
             if self.svgp.titsias:
                 call("svgp_gp_titsias_stats", cp, ws, s)

@@ -183,38 +183,82 @@ def synthetic_problem(rank, B, M_IND, MDIM, seed=0):
     return params, images, aux, eps
 
 
-def library_comm(multi, local_rank, dev, timeout_s=180.0):
+def library_comm(multi, local_rank, dev, timeout_s=180.0, make_id=None, make_comm=None):
     """The library's own RCCL communicator (engine.RcclComm), or (None, reason).  With several ranks the decision is COLLECTIVE
-    (MIN over ranks of "I have one"): a rank that failed -- or whose ncclCommInitRank did not return within `timeout_s`; the
-    bootstrap runs in a helper thread for that -- must not leave the others waiting in a collective it never joins."""
-    from svgp_vae_amd.engine import RcclComm
+    and every collective of the decision is issued by the MAIN thread of every rank in the same order, whatever fails where:
+      1. rank 0 creates the unique id (or None on failure) and broadcasts it -- all ranks take part, always;
+      2. MIN over ranks of "I hold an id and my library loaded" -- a rank that cannot even load the library is seen here,
+         before anybody enters ncclCommInitRank (which would otherwise wait for it);
+      3. ONLY ncclCommInitRank (no torch.distributed call) runs in a helper thread with a time limit;
+      4. MIN over ranks of "my communicator exists".
+    A rank that fails or times out anywhere therefore never leaves the others in a collective it does not join
+    (the id broadcast used to sit inside the helper thread, so a rank failing before it paired its all_reduce
+    with the other ranks' broadcast).  `make_id` / `make_comm(rank, world, id)` are injectable for the CPU (gloo) test of the
+    decision path; test hooks: SVGP_BENCH_FAIL_LIBCOMM=1 (every rank), SVGP_BENCH_FAIL_LIBCOMM_RANK=<r>[:id|:init] (one rank)."""
+    if make_id is None or make_comm is None:
+        from svgp_vae_amd.engine import RcclComm
+        make_id = make_id or RcclComm.unique_id
+        make_comm = make_comm or RcclComm
     if not multi:
         try:
-            return RcclComm(0, 1, RcclComm.unique_id()), None
+            return make_comm(0, 1, make_id()), None
         except Exception as e:
             return None, repr(e)
     import threading
     import torch.distributed as dist
-    box = {}
+    rank, world = dist.get_rank(), dist.get_world_size()
+    hook_all = os.environ.get("SVGP_BENCH_FAIL_LIBCOMM") == "1"
+    hook_rank, _, hook_where = os.environ.get("SVGP_BENCH_FAIL_LIBCOMM_RANK", "").partition(":")
+    hook_me = hook_rank != "" and int(hook_rank) == rank
+    on_gpu = torch.device(dev).type == "cuda"
+
+    def vote(flag):
+        ok = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        return float(ok.item()) >= 0.5
+
+    # 1. the id: created by rank 0 on its main thread, broadcast by every rank's main thread
+    why, box = None, [None]
+    if rank == 0:
+        try:
+            if hook_all or (hook_me and hook_where in ("", "id")):
+                raise RuntimeError("library communicator disabled by SVGP_BENCH_FAIL_LIBCOMM")
+            box[0] = make_id()
+        except Exception as e:
+            why = repr(e)
+    dist.broadcast_object_list(box, src=0)
+    # 2. every rank holds an id and can reach its library
+    mine = box[0] is not None
+    if mine and rank != 0:
+        try:
+            if hook_all or (hook_me and hook_where in ("", "id")):
+                raise RuntimeError("library communicator disabled by SVGP_BENCH_FAIL_LIBCOMM")
+            make_id()                                  # loads the library and resolves RCCL on this rank (id discarded)
+        except Exception as e:
+            mine, why = False, repr(e)
+    if not vote(mine):
+        return None, why or "another rank has no unique id / library"
+    # 3. ncclCommInitRank alone, time-limited
+    res = {}
 
     def work():
         try:
-            torch.cuda.set_device(local_rank)          # the current device is per thread; ncclCommInitRank binds to it
-            if os.environ.get("SVGP_BENCH_FAIL_LIBCOMM") == "1":      # test hook: the fallback decision path
-                raise RuntimeError("library communicator disabled by SVGP_BENCH_FAIL_LIBCOMM")
-            box["comm"] = RcclComm.from_process_group()
+            if on_gpu:
+                torch.cuda.set_device(local_rank)      # the current device is per thread; ncclCommInitRank binds to it
+            if hook_me and hook_where == "init":
+                raise RuntimeError("library communicator disabled by SVGP_BENCH_FAIL_LIBCOMM_RANK")
+            res["comm"] = make_comm(rank, world, box[0])
         except Exception as e:
-            box["err"] = repr(e)
+            res["err"] = repr(e)
 
     t = threading.Thread(target=work, daemon=True)
     t.start()
     t.join(timeout_s)
-    why = "bootstrap timed out" if t.is_alive() else box.get("err")
-    ok = torch.tensor([1.0 if box.get("comm") is not None else 0.0], dtype=torch.float64, device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    if float(ok.item()) < 0.5:
+    why = "ncclCommInitRank timed out" if t.is_alive() else res.get("err")
+    # 4. everybody has a communicator, or nobody uses one
+    if not vote(res.get("comm") is not None and not t.is_alive()):
         return None, why or "another rank has no communicator"
-    return box["comm"], None
+    return res["comm"], None
 
 
 def stage_table(eng, B, M_IND):

@@ -526,6 +526,11 @@ int svgp_enc_head_fwd(int b, int L, int clip, const double* bias, double* enc, d
 int svgp_enc_head_bwd(int b, int L, int clip, const double* var_raw, const double* ybar, const double* s2bar,
                       double* d_enc, void* stream);
 int svgp_bias_add(long long rows, int C, const double* bias, double* x, void* stream);
+/* utils.py:483-504 gauss_cross_entropy, element-wise over n values: out = -1/2 (log 2 pi + log var2 +
+ * (var1 + mu1^2 - 2 mu1 mu2 + mu2^2) / var2).  Inside the training step the same term is evaluated in the
+ * per-sample kernels; this is the stand-alone form behind utils.gauss_cross_entropy                          */
+int svgp_gauss_cross_entropy(long long n, const double* mu1, const double* var1, const double* mu2, const double* var2,
+                             double* out, void* stream);
 /* classification loss of the representation-network pre-training (SPRITES_utils.py:335-368): mean sparse softmax
  * cross-entropy over n rows of C logits, labels = class ids as float64; writes per-row losses, their mean and
  * d mean / d logits */

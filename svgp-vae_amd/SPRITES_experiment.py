@@ -141,7 +141,7 @@ def run_experiment_sprites_SVGPVAE(args, dict_=None):
     eng = S.SpritesStepEngine(VAE, repr_NN, SVGP_, b_max=b_max, seg_len=fpc, clip_qs=args.clip_qs, geco=args.GECO,
                               kappa_squared=args.kappa_squared, alpha=args.alpha, beta=args.beta, lr=args.lr,
                               clip_grad=args.clip_grad_thres if args.clip_grad else None)
-    SVGP_._engine = eng
+    S._attach(eng, SVGP_, VAE, repr_NN)
     dev = eng.dev
     print(f"Number of train params: {eng.theta.numel()}")
     t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, device=dev).contiguous()

@@ -2,6 +2,7 @@
 
   sprites_PCA_init(path_train_dict, m, L_action, L_character, seed, N_action)   SPRITES_utils.py:217-279
   aux_data_sprites_utils(batch_size, N, repeats)                                SPRITES_utils.py:317-332 (sprites.py)
+  forward_pass_pretraining_repr_NN(frames, labels, repr_NN, classification_layer, test_pipeline)   :335-368 (sprites.py)
 
 The reference reads `sprites_train_dict.p` (frames (N,64,64,3), aux_data (N,2) = [character id, action id]); that file is built
 from an external repository and is not obtainable offline, so `path_train_dict` may also be the dict itself (the SPRITES
@@ -11,7 +12,8 @@ import pickle
 
 import numpy as np
 
-from .sprites import aux_data_sprites_utils  # noqa: F401  (same module-level name as the reference)
+from .sprites import (aux_data_sprites_utils, forward_pass_pretraining_repr_NN,  # noqa: F401  (the reference's names)
+                      repr_NN_classification_layer)
 
 
 def sprites_PCA_init(path_train_dict, m=15, L_action=6, L_character=16, seed=42, N_action=72):

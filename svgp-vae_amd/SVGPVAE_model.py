@@ -19,7 +19,12 @@ Additional (no reference counterpart - TF's tf.gradients + AdamOptimizer live in
     .mean_vector_bias_analysis(index_points, y, noise)                            :345-378
 titsias=True selects the SVGPVAE_Titsias inside-ELBO (:246-259), computed in m x m space (Woodbury; see
 gp_titsias.hip).  kernel_matrix accepts every (x_inducing, y_inducing, diag_only) pattern on arbitrary row sets;
-approximate_posterior_params accepts test points != train points.  SPRITES lives in sprites.py.
+approximate_posterior_params accepts test points != train points.
+
+The SPRITES and moving-ball names of the reference's module resolve here as well (SPRITES_experiment.py:14-16,
+BALL_experiment.py:14): spritesSVGP (:487), precompute_GP_params_SVGPVAE (:989), aux_data_SVGPVAE_sprites (:1086),
+predict_SVGPVAE_sprites_test_character (:1118), SVGP (:17), build_SVGPVAE_elbo_graph (:638).  Their code lives beside the
+engines that run them (sprites.py, ball.py); forward_pass_SVGPVAE / batching_encode_SVGPVAE dispatch on `repr_NN`.
 """
 import math
 
@@ -332,9 +337,9 @@ def train_step_SVGPVAE(data_batch, beta, vae, svgp, alpha, kappa, lr, clipping_q
 
 def batching_encode_SVGPVAE(data_batch, vae, clipping_qs=False, repr_nn=None, segment_ids=None, repeats=None):
     """SVGPVAE_model.py:939-968: (qnet_mu, qnet_var, aux_data)."""
-    if repr_nn is not None:          # :953-956 (SPRITES form; needs the spritesSVGP object the engine hangs on)
-        raise TypeError("the representation-network form needs the GP object: svgp_vae_amd.sprites.batching_encode_SVGPVAE("
-                        "data_batch, vae, clipping_qs, repr_nn, segment_ids, repeats, svgp=...)")
+    if repr_nn is not None:          # :953-956 (SPRITES form; runs on the engine attached to `repr_nn` / `vae`)
+        from . import sprites
+        return sprites.batching_encode_SVGPVAE(data_batch, vae, clipping_qs, repr_nn, segment_ids, repeats)
     images, aux_data = data_batch
     mu, var = vae.encode(images)
     if clipping_qs:
@@ -390,3 +395,9 @@ def bacthing_predict_SVGPVAE_rotated_mnist(test_data_batch, vae, svgp, qnet_mu, 
     eng.set_batch_size(*saved)
     recon_loss = torch.sum((d_img_te - recon) ** 2) / 784.0
     return recon, recon_loss
+
+
+# the reference's SVGPVAE_model.py also defines the SPRITES and moving-ball objects (see the module docstring)
+from .sprites import (spritesSVGP, precompute_GP_params_SVGPVAE, aux_data_SVGPVAE_sprites,  # noqa: E402,F401
+                      predict_SVGPVAE_sprites_test_character)
+from .ball import SVGP, build_SVGPVAE_elbo_graph  # noqa: E402,F401

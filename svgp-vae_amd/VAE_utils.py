@@ -3,6 +3,10 @@
 `mnistVAE(im_width=28, im_height=28, L=16)`, `.encode(images) -> (means, vars)`,
 `.decode(latent_samples) -> recon_images`; tensors are float64 CUDA tensors, NHWC, TF weight
 layouts.  Parameters are Keras-initialised (glorot_uniform kernels, zero biases).
+
+The other classes the reference's drivers import from `VAE_utils` resolve here too: `spritesVAE`,
+`sprites_representation_network` (VAE_utils.py:275,363; SPRITES_experiment.py:13), `SVIGP_Hensman_decoder` (:394;
+MNIST_experiment.py:19).  Their code lives beside the engines that run them (sprites.py, SVIGP_Hensman_model.py).
 """
 import math
 
@@ -93,3 +97,14 @@ class mnistVAE:
         out = eng.ws_view("recon", (b, 28, 28, 1)).clone()
         eng.set_batch_size(*saved)
         return out
+
+
+from .sprites import spritesVAE, sprites_representation_network  # noqa: E402,F401  (VAE_utils.py:275,363)
+
+
+def __getattr__(name):
+    # SVIGP_Hensman_model imports this module for the Keras initialiser: resolve its decoder class on first use
+    if name == "SVIGP_Hensman_decoder":
+        from .SVIGP_Hensman_model import SVIGP_Hensman_decoder
+        return SVIGP_Hensman_decoder
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

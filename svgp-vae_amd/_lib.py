@@ -176,6 +176,7 @@ SIGNATURES = {
     "svgp_enc_head_bwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "svgp_softmax_xent": [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P],
     "svgp_bias_add": [C.c_longlong, C.c_int, _P, _P, _P],
+    "svgp_gauss_cross_entropy": [C.c_longlong, _P, _P, _P, _P, _P, _P],
     "svgp_sqerr_fwd": [C.c_longlong, C.c_int, _P, _P, _P, _P],
     "svgp_sqerr_bwd": [C.c_longlong, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "svgp_clip_by_value": [C.c_longlong, C.c_double, _P, _P],

@@ -397,6 +397,23 @@ extern "C" int svgp_enc_head_bwd(int b, int L, int clip, const double* var_raw, 
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
+// element-wise E_{N(mu1,var1)}[log N(.|mu2,var2)] (utils.py:483-504), the stand-alone form of the term the per-sample
+// kernels evaluate in place
+__global__ void k_gauss_cross_entropy(long long n, const double* __restrict__ mu1, const double* __restrict__ var1,
+                                      const double* __restrict__ mu2, const double* __restrict__ var2,
+                                      double* __restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double a = mu1[i], b = mu2[i], v2 = var2[i];
+    out[i] = -0.5 * (1.8378770664093453 + log(v2) + (var1[i] + a * a - 2.0 * a * b + b * b) / v2);
+}
+extern "C" int svgp_gauss_cross_entropy(long long n, const double* mu1, const double* var1, const double* mu2,
+                                        const double* var2, double* out, void* stream) {
+    SVGP_REQUIRE(n >= 1 && mu1 && var1 && mu2 && var2 && out, SVGP_ERR_INVALID, "bad argument");
+    hipLaunchKernelGGL(k_gauss_cross_entropy, dim3(nb256(n)), dim3(256), 0, (hipStream_t)stream, n, mu1, var1, mu2, var2, out);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
 extern "C" int svgp_bias_add(long long rows, int Cc, const double* bias, double* x, void* stream) {
     SVGP_REQUIRE(rows >= 1 && Cc >= 1 && bias && x, SVGP_ERR_INVALID, "bad argument");
     hipLaunchKernelGGL(k_bias_add<double>, dim3(nb256(rows * Cc)), dim3(256), 0, (hipStream_t)stream, rows * Cc, Cc, bias, x);

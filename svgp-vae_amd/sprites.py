@@ -645,7 +645,7 @@ def forward_pass_SVGPVAE(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha
     if eng is None or eng.b_max < b or eng.seg_len != seg_len or eng.geco != bool(GECO) or eng.clip_qs != bool(clipping_qs):
         eng = SpritesStepEngine(vae, repr_NN, svgp, b_max=b, seg_len=seg_len, clip_qs=clipping_qs, geco=GECO,
                                 kappa_squared=float(kappa) ** 2, beta=float(beta), params=params)
-        svgp._engine = eng
+    _attach(eng, svgp, vae, repr_NN)
     eng.set_scalars(beta=float(beta), c_ma=float(C_ma), lagrange=float(lagrange_mult), alpha=float(alpha))
     dev = eng.dev
     eng.step(frames.to(dev, _F64), action_ids.to(dev, _F64), None if epsilon is None else epsilon.to(dev, _F64),
@@ -656,12 +656,33 @@ def forward_pass_SVGPVAE(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha
 # ---------------------------------------------------------------------------------------------
 # conditional generation for a test character (SPRITES_experiment.py:160-205, 364-372, 500-560)
 # ---------------------------------------------------------------------------------------------
-def _engine_of(svgp, vae, repr_nn, engine, b_hint, clipping_qs):
-    eng = engine or getattr(svgp, "_engine", None)
-    if eng is None:
-        eng = SpritesStepEngine(vae, repr_nn, svgp, b_max=max(int(b_hint), 1), seg_len=1, clip_qs=clipping_qs)
-        svgp._engine = eng
+def _attach(eng, *objs):
+    """The reference's functions take the network / GP objects only (e.g. aux_data_SVGPVAE_sprites(data_batch, repr_nn,
+    segment_ids, repeats), SVGPVAE_model.py:1086); the engine that owns their parameters hangs on each of them."""
+    for o in objs:
+        if o is not None:
+            o._engine = eng
     return eng
+
+
+def _attached(*objs):
+    for o in objs:
+        eng = getattr(o, "_engine", None)
+        if eng is not None:
+            return eng
+    return None
+
+
+def _engine_of(svgp, vae, repr_nn, engine, b_hint, clipping_qs):
+    if engine is not None:          # an explicit engine (e.g. the driver's evaluation engine) is used, never attached
+        return engine
+    eng = _attached(svgp, repr_nn, vae)
+    if eng is None:
+        if svgp is None:
+            raise _lib.SvgpError("no step engine is attached to these network objects yet: run forward_pass_SVGPVAE once, "
+                                 "build a SpritesStepEngine(vae, repr_nn, svgp, ...), or pass svgp= / engine=")
+        eng = SpritesStepEngine(vae, repr_nn, svgp, b_max=max(int(b_hint), 1), seg_len=1, clip_qs=clipping_qs)
+    return _attach(eng, svgp, vae, repr_nn)
 
 
 def _segment_mean_repeat(cv, segment_ids, repeats):
@@ -673,10 +694,12 @@ def _segment_mean_repeat(cv, segment_ids, repeats):
     return torch.repeat_interleave(sums / cnt, torch.as_tensor(np.asarray(repeats), device=cv.device), dim=0)
 
 
-def aux_data_SVGPVAE_sprites(data_batch, repr_nn, segment_ids, repeats, engine):
+def aux_data_SVGPVAE_sprites(data_batch, repr_nn, segment_ids, repeats, engine=None):
     """SVGPVAE_model.py:1086-1115 for arbitrary (segment_ids, repeats): representation network on the frames,
-    segment mean per character, repeat, prepend the action ids of the OUTPUT rows."""
+    segment mean per character, repeat, prepend the action ids of the OUTPUT rows.  `engine` defaults to the one
+    attached to `repr_nn` (the reference's four-argument call)."""
     images, action_IDs = data_batch
+    engine = _engine_of(None, None, repr_nn, engine, images.shape[0], False)
     cv = engine.character_vectors(images.to(engine.dev, _F64))
     cv = _segment_mean_repeat(cv, segment_ids, repeats)
     return torch.cat([action_IDs.to(engine.dev, _F64)[:, None], cv], dim=1).contiguous()
@@ -698,7 +721,9 @@ def precompute_GP_params_SVGPVAE(means, vars, aux_data, svgp, engine=None):
     K_nm and the statistics K_mn diag(1/var_l) K_nm, K_mn (mean_l / var_l) run as the float32 streaming kernels
     (float32 is the reference's SPRITES dtype); Sigma_l = K_mm + S_l is inverted in float64, no jitter (:1014)."""
     from . import stream_stats as SS
-    eng = engine or svgp._engine
+    eng = engine or _attached(svgp)
+    if eng is None:
+        raise _lib.SvgpError("precompute_GP_params_SVGPVAE: no step engine attached to `svgp` (pass engine=)")
     dev = eng.dev
     se = eng.params["se"].detach().cpu().tolist()
     kd = SS.kernel_desc(SS.SE_SE if svgp.K_SE else SS.LINEAR_LINEAR, svgp.L_action, svgp.L_character,
@@ -778,6 +803,45 @@ def predict_SVGPVAE_sprites_test_character(data_batch, vae, svgp, repr_NN, mean_
 # ---------------------------------------------------------------------------------------------
 # pre-training of the representation network (SPRITES_experiment.py:139-151,325-357; SPRITES_utils.py:335-368)
 # ---------------------------------------------------------------------------------------------
+class repr_NN_classification_layer:
+    """The `tf.keras.layers.Dense(1000)` of the pre-training phase (SPRITES_experiment.py:139-141): glorot-uniform
+    kernel (L_character, n_classes), zero bias; float64 device tensors `W`, `b`."""
+
+    def __init__(self, n_in, n_classes=1000, seed=0, device="cuda:0"):
+        lim = math.sqrt(6.0 / (n_in + n_classes))
+        rs = np.random.RandomState(seed)
+        self.W = torch.tensor(rs.uniform(-lim, lim, (n_in, n_classes)), dtype=_F64, device=device)
+        self.b = torch.zeros(n_classes, dtype=_F64, device=device)
+
+
+def forward_pass_pretraining_repr_NN(frames, labels, repr_NN, classification_layer, test_pipeline=False, engine=None):
+    """SPRITES_utils.py:335-368: loss = mean sparse softmax cross-entropy of Dense(repr_nn(frames)) against the character
+    ids; with `test_pipeline` also the accuracy of the arg-max prediction.  The in-batch shuffle of :346-351 permutes the
+    rows of a mean and is not reproduced.  Runs the representation network, the average pool, the dense product and
+    `svgp_softmax_xent` of the library on the engine attached to `repr_NN` (or `engine=`); the training loop around it,
+    with its reverse pass and TF1 Adam, is `pretrain_repr_NN`."""
+    eng = _engine_of(None, None, repr_NN, engine, frames.shape[0], False)
+    dev, Lc, n = eng.dev, eng.Lc, frames.shape[0]
+    W, bC = classification_layer.W.to(dev, _F64), classification_layer.b.to(dev, _F64)
+    n_classes = W.shape[1]
+    lab_all = torch.as_tensor(labels).to(dev, _F64).contiguous()
+    emb = eng.character_vectors(frames.to(dev, _F64))                    # chunks of at most b_max frames
+    logits = torch.empty(n, n_classes, dtype=_F64, device=dev)
+    rowloss, loss, dlog = torch.empty(n, dtype=_F64, device=dev), torch.empty(1, dtype=_F64, device=dev), torch.empty_like(logits)
+    eng.stream.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(eng.stream):
+        s = eng.stream.cuda_stream
+        eng._gemm(0, 0, n, n_classes, Lc, 1.0, emb, Lc, W, n_classes, 0.0, logits, n_classes)
+        call("svgp_bias_add", n, n_classes, bC.data_ptr(), logits.data_ptr(), s)
+        call("svgp_softmax_xent", n, n_classes, logits.data_ptr(), lab_all.data_ptr(), rowloss.data_ptr(), loss.data_ptr(),
+             dlog.data_ptr(), s)
+    eng.stream.synchronize()
+    if not test_pipeline:
+        return loss[0]
+    acc = (torch.argmax(logits, dim=1) == lab_all.long()).to(_F64).mean()
+    return loss[0], acc
+
+
 def pretrain_repr_NN(engine, frames, char_IDs, *, nr_epochs, lr, batch_size, n_classes=1000, seed=0, log=print,
                      carry_slots=True):
     """Character classification: embeddings = repr_nn(frames) -> Dense(n_classes) -> mean sparse softmax cross-entropy,

@@ -4,7 +4,9 @@
   import_rotated_mnist(MNIST_path, ending, batch_size)   utils.py:799-875
   generate_init_inducing_points(train_data_path, n, ...) utils.py:691-744
   parse_opt_regime(arr)                                  utils.py:891-899
-  gauss_cross_entropy                                    utils.py:483-504 is fused into the HIP per-sample kernel.
+  gauss_cross_entropy(mu1, var1, mu2, var2)              utils.py:483-504 (element-wise; inside the step it is fused
+                                                         into the HIP per-sample kernel, this is the stand-alone form)
+  Make_Video_batch / build_video_batch_graph / MSE_rotation   utils.py:59-121,138-192,195-245 (moving ball; ball.py)
 """
 import pickle
 import random
@@ -70,3 +72,28 @@ def parse_opt_regime(arr):
         arr[i] = (regime, int(nr_epochs))
     training_regime = [r for regime in arr for r in [regime[0]] * regime[1]]
     return len(training_regime), training_regime
+
+
+def gauss_cross_entropy(mu1, var1, mu2, var2):
+    """utils.py:483-504: element-wise cross-entropy H[N(mu1, var1), N(mu2, var2)] =
+    -1/2 (log 2 pi + log var2 + (var1 + mu1^2 - 2 mu1 mu2 + mu2^2) / var2).  Runs as `svgp_gauss_cross_entropy` on
+    float64 device tensors of any (equal) shape."""
+    import torch
+    from ._lib import call
+    mu1, var1, mu2, var2 = (t.to(torch.float64).contiguous() for t in torch.broadcast_tensors(mu1, var1, mu2, var2))
+    if not mu1.is_cuda:
+        from ._lib import SvgpError
+        raise SvgpError("gauss_cross_entropy needs device tensors; there is no CPU execution path")
+    out = torch.empty_like(mu1)
+    s = torch.cuda.current_stream(mu1.device).cuda_stream
+    call("svgp_gauss_cross_entropy", mu1.numel(), mu1.data_ptr(), var1.data_ptr(), mu2.data_ptr(), var2.data_ptr(),
+         out.data_ptr(), s)
+    return out
+
+
+def __getattr__(name):
+    # the moving-ball data utilities live beside their device kernels in ball.py (BALL_experiment.py:11-12)
+    if name in ("Make_path_batch", "Make_Video_batch", "MSE_rotation", "build_video_batch_graph"):
+        from . import ball
+        return ball.VideoBatchSource if name == "build_video_batch_graph" else getattr(ball, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

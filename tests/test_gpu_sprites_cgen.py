@@ -185,3 +185,59 @@ def test_pretraining_advances_the_shared_adam_state():
             else:
                 assert mm == 0.0 and torch.equal(eng.params[k], before[k]), k
             off += n
+
+
+def test_reference_signature_helpers_match_oracle():
+    """the reference's own call forms — `aux_data_SVGPVAE_sprites(data_batch, repr_nn, segment_ids,
+    repeats)` (SVGPVAE_model.py:1086), `batching_encode_SVGPVAE(data_batch, vae, clipping_qs, repr_nn, segment_ids,
+    repeats)` (:939), `forward_pass_pretraining_repr_NN(frames, labels, repr_NN, classification_layer[, True])`
+    (SPRITES_utils.py:335) and `gauss_cross_entropy` (utils.py:483) — imported from the reference's module names, run
+    on the engine attached to the network objects and agree with the float64 oracle."""
+    import torch.nn.functional as F
+    from svgp_vae_amd import sprites as S
+    from svgp_vae_amd.SPRITES_utils import forward_pass_pretraining_repr_NN, repr_NN_classification_layer
+    from svgp_vae_amd.SVGPVAE_model import aux_data_SVGPVAE_sprites, batching_encode_SVGPVAE, spritesSVGP
+    from svgp_vae_amd.VAE_utils import sprites_representation_network, spritesVAE
+    from svgp_vae_amd.utils import gauss_cross_entropy
+    g = torch.Generator().manual_seed(11)
+    L, La, Lc, m, n_act, n, fpc = 4, 8, 16, 6, 5, 12, 4
+    params = {k: torch.tensor(v, dtype=DT) for k, v in SO.glorot_init(L, Lc, 2).items()}
+    for k in params:
+        if k.endswith("_b"):
+            params[k] = 0.05 * torch.randn(*params[k].shape, dtype=DT, generator=g)
+    gp = dict(inducing_index_points=torch.randn(m, La + Lc, dtype=DT, generator=g) * 1.5,
+              GPLVM_action=torch.randn(n_act, La, dtype=DT, generator=g) * 1.5)
+    vae, rnn = spritesVAE(L), sprites_representation_network(Lc)
+    svgp = spritesSVGP(False, False, gp["inducing_index_points"].numpy(), 'main', 0.01, float(n), La,
+                       gp["GPLVM_action"].numpy(), Lc, L, K_SE=True)
+    with pytest.raises(Exception, match="no step engine"):
+        aux_data_SVGPVAE_sprites((torch.zeros(2, 64, 64, 3), torch.zeros(2)), rnn, [0, 0], [2])
+    eng = S.SpritesStepEngine(vae, rnn, svgp, b_max=8, seg_len=fpc, clip_qs=True, params={**params, **gp})
+    S._attach(eng, svgp, vae, rnn)
+    frames = torch.rand(n, 64, 64, 3, dtype=DT, generator=g)
+    ids = torch.randint(0, n_act, (n,), generator=g)
+    seg, rep = SO.aux_data_sprites_utils(n, fpc, fpc)
+    aux_o = SO.aux_data_SVGPVAE_sprites((frames, ids), params, seg, rep)
+    assert _rel(aux_data_SVGPVAE_sprites((frames, ids), rnn, seg, rep), aux_o) < 1e-12
+    mu, var, aux = batching_encode_SVGPVAE((frames, ids), vae, True, rnn, seg, rep)
+    mu_o, var_o = SO.SpritesVAE(params, L).encode(frames)
+    assert _rel(mu, mu_o) < 1e-11 and _rel(var, O.clip_by_value(var_o, 1e-3, 10.0)) < 1e-11 and _rel(aux, aux_o) < 1e-12
+    # pre-training forward: loss and accuracy of Dense(repr_nn(frames)) against the character ids
+    n_classes = 7
+    cl = repr_NN_classification_layer(Lc, n_classes, seed=4, device=eng.dev)
+    cl.b.copy_(0.1 * torch.randn(n_classes, dtype=DT, generator=g))
+    labels = torch.randint(0, n_classes, (n,), generator=g)
+    logits_o = SO.repr_nn(params, frames) @ cl.W.cpu() + cl.b.cpu()
+    loss_o = F.cross_entropy(logits_o, labels)
+    acc_o = (logits_o.argmax(1) == labels).double().mean()
+    loss = forward_pass_pretraining_repr_NN(frames, labels, rnn, cl)
+    loss_t, acc_t = forward_pass_pretraining_repr_NN(frames, labels, rnn, cl, True)
+    assert abs(float(loss) - float(loss_o)) < 1e-12 * abs(float(loss_o)) + 1e-13 and float(loss_t) == float(loss)
+    assert float(acc_t) == float(acc_o)
+    # element-wise Gaussian cross-entropy, broadcasting like the reference's call sites (SVGPVAE_model.py:896)
+    mu1, var1 = torch.randn(n, L, dtype=DT, generator=g), torch.rand(n, L, dtype=DT, generator=g) + 0.1
+    mu2, var2 = torch.randn(n, L, dtype=DT, generator=g), torch.rand(1, L, dtype=DT, generator=g) + 0.1
+    ce = gauss_cross_entropy(mu1.to(eng.dev), var1.to(eng.dev), mu2.to(eng.dev), var2.to(eng.dev))
+    assert ce.shape == (n, L) and _rel(ce, O.gauss_cross_entropy(mu1, var1, mu2, var2)) < 1e-14
+    with pytest.raises(Exception, match="no CPU execution path"):
+        gauss_cross_entropy(mu1, var1, mu2, var2)

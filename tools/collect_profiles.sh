@@ -39,8 +39,10 @@ python tools/pmc_summary.py $O/${tag}_pmc_FETCH_SIZE $O/${tag}_pmc_WRITE_SIZE $O
 python tools/mfma_busy_summary.py $O/${tag}_pmc_sq $O/${tag}_mfma_busy.json
 python tools/conv_probe.py 500 f32 > $O/${tag}_conv_probe_f32.txt 2>/dev/null
 python tools/conv_probe.py 500 > $O/${tag}_conv_probe_f64.txt 2>/dev/null
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_f32_issue.hip -o tools/micro/mfma_f32_issue 2>/dev/null   # built here, never committed
 ./tools/micro/mfma_f32_issue > $O/${tag}_micro_mfma_f32_issue.txt 2>/dev/null
 for w in cfg2 cfg3 sp800 cfg5; do f=$(find $O/${tag}_prof_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${tag}_${w}_kernel_stats.csv; done
 # the raw traces / counter dumps are large: keep the summaries only
 rm -rf $O/${tag}_prof_* $O/${tag}_pmc_FETCH_SIZE $O/${tag}_pmc_WRITE_SIZE $O/${tag}_pmc_sq
+git -C $R rev-parse HEAD > $O/${tag}_commit.txt 2>/dev/null || true
 ls -la $O | grep ${tag}_

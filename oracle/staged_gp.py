@@ -240,3 +240,121 @@ def gp_block_manual(K, Kn, knn, y, s2, eps, zbar, gT, jitter, N_train, b_global=
     Knbar, knnbar, ybar, s2bar = gp_posterior_bwd_rows(Kn, knn, y, s2, ps, f, fb, g_pv, g_pm,
                                                        mvbar, gT, c)
     return f, ps, fb, (fb['Kbar'], Knbar, knnbar, ybar, s2bar)
+
+
+# ======================================================================================================================
+# Large-m ("W form") staging of the same block: svgp-vae_amd/csrc/gp_large.hip from round 4 on.
+#
+# The L3 integrand's term k_n^T Ki A_l Ki k_n (SVGPVAE_model.py:281-284: K_mm_inv A_hat K_mm_inv inside the (b,m,m) lambda
+# tensor) is evaluated as w_n^T Si_l w_n with the channel-INDEPENDENT rows w_n = K Ki k_n (W = Kn Ki K; Ki K is not
+# simplified to I): identical algebra (A_l = K Si_l K), but the per-channel m^3 products Ki A_l Ki, and in the
+# reverse pass S_l Ki, Ki S_l Ki, S_l Ki A_l, disappear -- their role is taken by one more (b, m, m) row product per channel
+# (W Si_l beside Kn Si_l), by the weighted statistic W^T diag(p_l) W that joins the reverse statistic A2_l, and by a few
+# channel-independent m x m products.  Row sums that enter the gradient of K_mm LINEARLY (Pbar = Kn^T Wbar, Qs = Kn^T diag(
+# qbar) Kn) stay rank-local under data parallelism: the ranks' shares add up in the gradient all-reduce.
+# ======================================================================================================================
+def gp_posterior_fwd_w(Kn, knn, y, s2, eps, f, c, K):
+    """svgp_big_posterior_fwd: as gp_posterior_fwd with s = rowdot(W Si_l, W), W = (Kn Ki) K."""
+    p = reciprocal_no_nan(s2)
+    KnKi = Kn @ f['Ki']
+    W = KnKi @ K
+    q = (KnKi * Kn).sum(1)
+    p_m = c * (Kn @ f['t'].T)
+    KnSi = torch.einsum('ni,lij->lnj', Kn, f['Si'])
+    WSi = torch.einsum('ni,lij->lnj', W, f['Si'])
+    r = torch.einsum('lnj,nj->nl', KnSi, Kn)
+    s = torch.einsum('lnj,nj->nl', WSi, W)
+    p_v = (knn - q)[:, None] + r
+    mv = Kn @ f['u'].T
+    e = y - mv
+    d = (knn - q)[:, None] + s + e * e
+    L3 = -0.5 * ((p * d).sum(0) + torch.log(s2).sum(0) + Kn.shape[0] * LOG_2PI)
+    ce = -0.5 * (LOG_2PI + torch.log(s2) + (p_v + (p_m - y) ** 2) * p)
+    z = p_m + eps * torch.sqrt(p_v)
+    return dict(p=p, W=KnKi, Ww=W, KnSi=KnSi, WSi=WSi, q=q, p_m=p_m, p_v=p_v, mv=mv, e=e, d=d, L3=L3, CE=ce.sum(), z=z)
+
+
+def gp_stats_bwd_w(Kn, ps, g_pv, mvbar, g_pm, gT, c):
+    """svgp_big_stats (mode 1): B2_l = Kn^T diag(g_pv_l) Kn - g3/2 W^T diag(p_l) W -- ONE contraction over the stacked rows
+    [Kn; W] with the stacked weights [g_pv; -g3/2 p] --, ud, td as before.  B2 | ud | td is the reverse exchange block."""
+    g3 = gT
+    A2, ud, td = gp_stats(Kn, g_pv, mvbar, c * g_pm)
+    SW = torch.einsum('nl,ni,nj->lij', ps['p'], ps['Ww'], ps['Ww'])
+    return A2 - 0.5 * g3 * SW, ud, td
+
+
+def gp_rows_local_w(Kn, ps, g_pv, gT, K, Ki):
+    """The rank-local row sums of the reverse pass (forward quantities and loss seeds only, so they run early):
+    Wbar = -g3 sum_l p_l * (W Si_l) (b, m); Pbar = Kn^T Wbar; Qs = Kn^T diag(qbar) Kn, qbar = sum_l (g3/2 p - g_pv)."""
+    g3 = gT
+    Wbar = -g3 * torch.einsum('nl,lnj->nj', ps['p'], ps['WSi'])
+    Pbar = Kn.T @ Wbar
+    qbar = (0.5 * g3 * ps['p'] - g_pv).sum(1)
+    Qs = Kn.T @ (qbar[:, None] * Kn)
+    return dict(Wbar=Wbar, Pbar=Pbar, Qs=Qs, qbar=qbar)
+
+
+def gp_factor_bwd_w(K, v, f, B2, ud, td, loc, gT, c, N_train, b_global, rep_weight=1.0):
+    """svgp_big_factor_bwd: the m x m reverse algebra on a channel window (f, B2, ud, td hold the window's channels).
+    Returns Kbar = rep_weight x (window part) + (rank-local part from `loc`), and per channel Ssym, vbar.
+    No per-channel Kibar / Abar arrays: Abar_l = gK/2 (Ki - Aji_l) enters through Gbar' = K Ki - K Aji_l (the scalar is applied
+    where the products are consumed), the Ki-gradient is formed for the channel SUM only."""
+    L, m = v.shape
+    g3 = gT
+    gK = -gT * (b_global / N_train)
+    Ki, Si, A, Aji, mu, u, t = (f[k] for k in ('Ki', 'Si', 'A', 'Aji', 'mu', 'u', 't'))
+    PT = K @ Ki                                                   # P^T = K Ki (shared)
+    Gb = PT[None] - K[None] @ Aji                                 # Gbar' = K (Ki - Aji_l)
+    Z = Si @ Gb                                                   # Z' = Si K (Ki - Aji)
+    GbK = Gb @ K[None]                                            # K (Ki - Aji) K (symmetric)
+    ubar = ud + 0.5 * gK * mu
+    mubar = 0.5 * gK * u + ubar @ Ki.T
+    tbar = td + c * (mubar @ K.T)
+    Sibar = 0.5 * gK * GbK + B2 + torch.einsum('li,lj->lij', tbar, v)
+    vbar = torch.einsum('lij,lj->li', Si, tbar)
+    Sg = -(Si @ Sibar @ Si)
+    Ssym = c * (Sg + Sg.transpose(1, 2))
+    Zs = Z.sum(0)
+    Kb_win = 0.5 * gK * (Zs + Zs.T) + c * torch.einsum('li,lj->ij', mubar, t) + Sg.sum(0)
+    Kib_win = 0.5 * gK * A.sum(0) + torch.einsum('li,lj->ij', ubar, mu)
+    Kib_loc = loc['Qs'] + loc['Pbar'] @ K                         # q_n = k^T Ki k in d and p_v;  P = Ki K
+    Kbar = rep_weight * (Kb_win - Ki @ Kib_win @ Ki + (0.5 * gK * L) * Ki) + (Ki @ loc['Pbar'] - Ki @ Kib_loc @ Ki)
+    return dict(Kbar=Kbar, vbar=vbar, Ssym=Ssym)
+
+
+def gp_posterior_bwd_rows_w(Kn, knn, y, s2, ps, f, fb, loc, g_pv, g_pm, mvbar, gT, c, K):
+    """svgp_big_posterior_bwd: row-local gradients; the d-term reaches Kn through Wbar P^T = Wbar (Ki K)^T (one (b, m, m)
+    product for all channels) instead of through Kn M2_l."""
+    p = ps['p']
+    g3 = gT
+    qbar = loc['qbar']
+    knnbar = -qbar
+    R = torch.einsum('ni,lij->lnj', Kn, fb['Ssym'])
+    part = (2.0 * g_pv.T[:, :, None] * ps['KnSi'] + p.T[:, :, None] * R + mvbar.T[:, :, None] * f['u'][:, None, :]
+            + c * g_pm.T[:, :, None] * f['t'][:, None, :] + (p * y).T[:, :, None] * fb['vbar'][:, None, :])
+    Knbar = part.sum(0) + 2.0 * qbar[:, None] * ps['W'] + loc['Wbar'] @ (K @ f['Ki'])
+    kv = Kn @ fb['vbar'].T
+    kSk = 0.5 * torch.einsum('lnj,nj->nl', R, Kn)
+    pbar = -0.5 * g3 * ps['d'] + kSk + y * kv
+    ce_y = -gT * p * (ps['p_m'] - y)
+    ce_s2 = 0.5 * gT * (p - (ps['p_v'] + (ps['p_m'] - y) ** 2) * p * p)
+    ybar = ce_y - g3 * p * ps['e'] + p * kv
+    s2bar = ce_s2 - 0.5 * g3 * p - pbar * p * p
+    return Knbar, knnbar, ybar, s2bar
+
+
+def gp_block_manual_w(K, Kn, knn, y, s2, eps, zbar, gT, jitter, N_train, b_global=None):
+    """gp_block_manual in the W form (single rank)."""
+    b = Kn.shape[0]
+    bg = float(b if b_global is None else b_global)
+    c = N_train / bg
+    p = reciprocal_no_nan(s2)
+    S, v, _ = gp_stats(Kn, p, p * y)
+    f = gp_factor_fwd(K, S, v, jitter, c)
+    ps = gp_posterior_fwd_w(Kn, knn, y, s2, eps, f, c, K)
+    g_pv, g_pm, mvbar = gp_posterior_bwd_weights(y, s2, eps, ps, zbar, gT, c)
+    B2, ud, td = gp_stats_bwd_w(Kn, ps, g_pv, mvbar, g_pm, gT, c)
+    loc = gp_rows_local_w(Kn, ps, g_pv, gT, K, f['Ki'])
+    fb = gp_factor_bwd_w(K, v, f, B2, ud, td, loc, gT, c, N_train, bg)
+    Knbar, knnbar, ybar, s2bar = gp_posterior_bwd_rows_w(Kn, knn, y, s2, ps, f, fb, loc, g_pv, g_pm, mvbar, gT, c, K)
+    return f, ps, fb, (fb['Kbar'], Knbar, knnbar, ybar, s2bar)

@@ -210,3 +210,60 @@ def test_oracle_reproduces_committed_golden(golden):
     assert np.allclose(out[5].numpy(), gout["beta_p_m"], rtol=1e-8, atol=1e-10)
     assert np.allclose(grads["enc_c1_w"].numpy(), gout["beta_grad_enc_c1_w"], rtol=1e-6, atol=1e-10)
     assert np.allclose(grads["object_vectors"].numpy(), gout["beta_grad_object_vectors"], rtol=1e-6, atol=1e-10)
+
+
+def test_staged_w_form_matches_autograd_and_the_lds_staging():
+    """Round-4 large-m staging (oracle/staged_gp.py, "W form"): k^T Ki A Ki k evaluated as w^T Si w with w = K Ki k.  Forward
+    values equal the efficient oracle's, every gradient equals autograd of it and the m <= 64 staging's hand-derived ones;
+    the rank-local row sums make a k-way row partition reproduce the single batch with rep_weight 1 on one rank only."""
+    t = _toy(b=48)
+    one = torch.tensor(1.0, dtype=DT)
+    K, Kn, knn = SG.kernel_matrix_fwd(t["aux"], t["ip"], t["ov"], one, one)
+    N, j, gT = 300.0, 1e-6, -0.37
+    lv = [x.clone().requires_grad_() for x in (K, Kn, knn, t["y"], t["s2"])]
+    p_m, p_v, L3, KL = O.gp_block_efficient(*lv, j, N)
+    ce = O.gauss_cross_entropy(p_m, p_v, lv[3], lv[4]).sum()
+    z = p_m + t["eps"] * torch.sqrt(p_v)
+    loss = gT * (-ce + L3.sum() - (Kn.shape[0] / N) * KL.sum()) + (t["zbar"] * z).sum()
+    gs = torch.autograd.grad(loss, lv)
+    f, ps, fb, man = SG.gp_block_manual_w(K, Kn, knn, t["y"], t["s2"], t["eps"], t["zbar"], gT, j, N)
+    _, ps0, _, man0 = SG.gp_block_manual(K, Kn, knn, t["y"], t["s2"], t["eps"], t["zbar"], gT, j, N)
+    assert torch.allclose(ps["p_m"], p_m, atol=1e-12) and torch.allclose(ps["p_v"], p_v, atol=1e-12)
+    assert torch.allclose(ps["L3"], L3, rtol=1e-12) and torch.allclose(ps["d"], ps0["d"], rtol=1e-11, atol=1e-12)
+    sym = lambda a: a + a.T if a.ndim == 2 and a.shape[0] == a.shape[1] else a      # K enters symmetrically: compare Kbar + Kbar^T
+    for a, b_, c_ in zip(gs, man, man0):
+        assert float((sym(a) - sym(b_)).abs().max() / sym(a).abs().max()) < 1e-10
+        assert float((sym(c_) - sym(b_)).abs().max() / sym(c_).abs().max()) < 1e-10
+    # ---- row partition: statistics summed, row-local sums kept per rank, replicated part counted once
+    c = N / 48.0
+    parts = [slice(0, 16), slice(16, 40), slice(40, 48)]
+    p = O.reciprocal_no_nan(t["s2"])
+    S = sum(SG.gp_stats(Kn[s], p[s], (p * t["y"])[s])[0] for s in parts)
+    v = sum(SG.gp_stats(Kn[s], p[s], (p * t["y"])[s])[1] for s in parts)
+    fw = SG.gp_factor_fwd(K, S, v, j, c)
+    pss = [SG.gp_posterior_fwd_w(Kn[s], knn[s], t["y"][s], t["s2"][s], t["eps"][s], fw, c, K) for s in parts]
+    ws = [SG.gp_posterior_bwd_weights(t["y"][s], t["s2"][s], t["eps"][s], q, t["zbar"][s], gT, c) for s, q in zip(parts, pss)]
+    st = [SG.gp_stats_bwd_w(Kn[s], q, w[0], w[2], w[1], gT, c) for s, q, w in zip(parts, pss, ws)]
+    B2, ud, td = (sum(x[i] for x in st) for i in range(3))
+    locs = [SG.gp_rows_local_w(Kn[s], q, w[0], gT, K, fw["Ki"]) for s, q, w in zip(parts, pss, ws)]
+    fbs = [SG.gp_factor_bwd_w(K, v, fw, B2, ud, td, loc, gT, c, N, 48.0, rep_weight=1.0 if r == 0 else 0.0)
+           for r, loc in enumerate(locs)]
+    Kbar = sum(x["Kbar"] for x in fbs)
+    assert float((sym(Kbar) - sym(man[0])).abs().max() / sym(man[0]).abs().max()) < 1e-10
+    rows = [SG.gp_posterior_bwd_rows_w(Kn[s], knn[s], t["y"][s], t["s2"][s], q, fw, fbs[0], loc, w[0], w[1], w[2], gT, c, K)
+            for s, q, w, loc in zip(parts, pss, ws, locs)]
+    for i in range(4):
+        assert torch.allclose(torch.cat([r[i] for r in rows]), man[1 + i], rtol=1e-9, atol=1e-11)
+    # ---- channel windows: every window's share with rep_weight 1, the local part on ONE window call only
+    L = v.shape[0]
+    loc_all = SG.gp_rows_local_w(Kn, ps, SG.gp_posterior_bwd_weights(t["y"], t["s2"], t["eps"], ps, t["zbar"], gT, N / 48.0)[0],
+                                 gT, K, f["Ki"])
+    zero = {k: torch.zeros_like(x) for k, x in loc_all.items()}
+    B2f, udf, tdf = SG.gp_stats_bwd_w(Kn, ps, *[SG.gp_posterior_bwd_weights(t["y"], t["s2"], t["eps"], ps, t["zbar"], gT, c)[i]
+                                              for i in (0, 2, 1)], gT, c)
+    Kb = 0
+    for w0 in range(0, L, 2):
+        sl = slice(w0, min(w0 + 2, L))
+        fwin = {k: (x[sl] if (torch.is_tensor(x) and x.ndim >= 1 and x.shape[0] == L and k not in ("Ki",)) else x) for k, x in f.items()}
+        Kb = Kb + SG.gp_factor_bwd_w(K, v[sl], fwin, B2f[sl], udf[sl], tdf[sl], loc_all if w0 == 0 else zero, gT, c, N, 48.0)["Kbar"]
+    assert float((sym(Kb) - sym(man[0])).abs().max() / sym(man[0]).abs().max()) < 1e-10

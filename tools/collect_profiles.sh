@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round artefacts on the MI355X box: bench lines of every workload, rocprofv3 kernel stats, PMC traffic passes, GEMM / inverse probes.
-# usage (through gpurun, from the repo root): bash tools/collect_profiles.sh r02a     -> files under gpurun_out/r02a_*
+# usage (through gpurun, from the repo root): bash tools/collect_profiles.sh r02a <commit>     -> files under gpurun_out/r02a_*
 # (copy what is to be judged into profiles/ afterwards; see profiles/README.md)
 tag=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -44,5 +44,5 @@ python tools/conv_probe.py 500 > $O/${tag}_conv_probe_f64.txt 2>/dev/null
 for w in cfg2 cfg3 sp800 cfg5; do f=$(find $O/${tag}_prof_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${tag}_${w}_kernel_stats.csv; done
 # the raw traces / counter dumps are large: keep the summaries only
 rm -rf $O/${tag}_prof_* $O/${tag}_pmc_FETCH_SIZE $O/${tag}_pmc_WRITE_SIZE $O/${tag}_pmc_sq
-git -C $R rev-parse HEAD > $O/${tag}_commit.txt 2>/dev/null || true
+echo "${2:-unknown}" > $O/${tag}_commit.txt      # the box has no .git: pass $(git rev-parse --short HEAD) as the 2nd argument
 ls -la $O | grep ${tag}_

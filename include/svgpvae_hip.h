@@ -105,7 +105,7 @@ typedef struct {
     int64_t enc_a1, enc_a2, enc_a3;       /* post-ELU activations (b,13,13,8) (b,6,6,8) (b,32)    */
     int64_t qnet_mu, qnet_var_raw, qnet_var; /* (b,L) each; var = clip(exp(.))                    */
     /* kernel matrices (SVGPVAE_model.py:427-476) */
-    int64_t K, Kn, knn;                   /* (m,m) (b,m) (b)                                      */
+    int64_t K, Kn, knn;                   /* (m,m) (b,m) (b); m > 64: W = Kn Ki K (b,m) behind the b rows of Kn */
     /* forward statistics: ONE contiguous all-reduce block [S | v] (titsias: [S | v | tit_S2 | tit_v2]).
      * S (P,L,m,m), v (P,L,m) with P = stat_parts ROW PARTIALS (the LDS-resident path splits the rows of every channel
      * over P workgroups; the statistics are the sums over p, taken by the consumers on load; 1 for m > 64 and
@@ -113,7 +113,7 @@ typedef struct {
      * backward block [A2 | ud | td] has the same partial structure.  Sums over ranks commute with the sum over p. */
     int64_t statA, statA_len, S, v, stat_parts;
     /* m x m factor stage (SVGPVAE_model.py:239,270-279,319-341) */
-    int64_t Ki, ldK, Si, t, G, A, Aji, mu_hat, u, M2, KL, q; /* M2 = Ki A Ki (L,m,m); q (b)       */
+    int64_t Ki, ldK, Si, t, G, A, Aji, mu_hat, u, M2, KL, q; /* M2 = Ki A Ki (L,m,m; m <= 64 only); q (b) */
     /* per-sample stage (:264-299,332-337, 888-902; utils.py:498-504) */
     int64_t p_m, p_v, e, d, eps, z;       /* (b,L) each                                           */
     /* decoder (VAE_utils.py:128-141,154-162) */
@@ -124,7 +124,8 @@ typedef struct {
     int64_t Kbar, fb_part, Qm, vbar, Ssym; /* (m,m) (2,L,m,m) scratch (L,m,m) (L,m) (L,m,m)        */
     int64_t Knbar_part;                   /* (L,b,m) per-channel row gradients before the sum     */
     int64_t scr_bm, scr_mm, scr_vec, scr_inv, scr_bl; /* scratch of the large-m (m > 64) path; scr_bm also holds the
-                                           * forward products Kn Si_l, Kn M2_l, Kn Ki that the reverse pass re-reads */
+                                           * forward products [Kn; W] Si_l, Kn Ki that the reverse pass re-reads */
+    int64_t scr_sm;                       /* m > 64: 9 channel-independent (m,m) matrices (K Ki, Kn^T Wbar, ...)  */
     int64_t Knbar, knnbar, ybar, s2bar;   /* (b,m) (b) (b,L) (b,L)                                */
     int64_t d_on;                         /* (b,M) gradient of gathered object rows               */
     /* partial sums */
@@ -136,8 +137,9 @@ typedef struct {
     /* Titsias branch (cfg.titsias; zero-sized otherwise): statistics with weights 1/(var + jitter) inside statA,
      * (K + jI + S2)^-1, its product with v2, scalars [logdet (L) | v2.t2 (L) | row sum (1)] */
     int64_t tit_S2, tit_v2, tit_Si, tit_t, tit_scal;
-    /* m > 64: two tile-packed buffers of L symmetric matrices each (svgp_sym_pack): what the channel-sharded exchange
-     * moves instead of the full (L,m,m) blocks.  xpack_len = 2 * L * svgp_sym_packed_elems(m) (0 for m <= 64).        */
+    /* m > 64 with cfg.single_stat_block (batch sharded over ranks): one tile-packed buffer of L symmetric matrices
+     * (svgp_sym_pack): what the channel-sharded exchange moves instead of a full (L,m,m) block.
+     * xpack_len = L * svgp_sym_packed_elems(m) (0 otherwise).                                                          */
     int64_t xpack, xpack_len;
     int64_t total;                        /* workspace size in float64 elements                   */
 } svgp_mnist_ws_layout;
@@ -501,7 +503,8 @@ int svgp_elu_bwd_bias_f32(long long npix, int C, const float* out, float* dout, 
  * aux (b, 1+Lc) = [action id, character vector]; ip (m, La+Lc); table = GPLVM action vectors (n_act, La).        */
 typedef struct {
     int32_t b, m, La, Lc, n_act, normalize, k_se;
-    double rep_weight;          /* weight of the rank-replicated K_mm gradient terms (1 on rank 0)             */
+    double rep_weight;          /* weight of Kbar: m <= 64: 1 on rank 0 (Kbar is replicated); m > 64: 1 on every rank (the
+                                 * reverse factor stage has weighted the replicated part with cfg.rep_weight itself) */
 } svgp_sprites_kcfg;
 int svgp_sprites_kernel_matrix_fwd(const svgp_sprites_kcfg*, const double* aux, const double* ip, const double* table,
                                    const double* se, double* K, double* Kn, double* knn, void* stream);

@@ -38,7 +38,7 @@ WS_FIELDS = ("enc_a1", "enc_a2", "enc_a3", "qnet_mu", "qnet_var_raw", "qnet_var"
              "zbar", "g_pv", "g_pm", "mvbar",
              "statB", "statB_len", "A2", "ud", "td",
              "Kbar", "fb_part", "Qm", "vbar", "Ssym", "Knbar_part",
-             "scr_bm", "scr_mm", "scr_vec", "scr_inv", "scr_bl",
+             "scr_bm", "scr_mm", "scr_vec", "scr_inv", "scr_bl", "scr_sm",
              "Knbar", "knnbar", "ybar", "s2bar", "d_on",
              "part_dec", "part_enc", "n_part", "part_gp", "part_sums", "n_post",
              "gradC", "gradC_len", "grad", "sums",

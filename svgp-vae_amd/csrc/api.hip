@@ -91,7 +91,9 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     auto take = [&](int64_t n) { int64_t r = p; p += (n + 15) / 16 * 16; return r; };
     o->enc_a1 = take(b * 13 * 13 * 8); o->enc_a2 = take(b * 6 * 6 * 8); o->enc_a3 = take(b * 32);
     o->qnet_mu = take(b * L); o->qnet_var_raw = take(b * L); o->qnet_var = take(b * L);
-    o->K = take(m * m); o->Kn = take(b * m); o->knn = take(b);
+    // m > 64: the rows W = Kn Ki K (gp_large.hip, "W form") sit right behind the CURRENT b rows of K_nm, so that [Kn; W] is
+    // one (2 b, m) operand of the row-stage product and of the reverse statistic
+    o->K = take(m * m); o->Kn = take(m > SVGP_M_MAX ? 2 * b * m : b * m); o->knn = take(b);
     const int64_t P = svgp_stat_parts(c);      // capacity from b_cap
     o->stat_parts = P;
     o->statA = p; o->S = p; p += P * L * m * m; o->v = p; p += P * L * m;
@@ -104,7 +106,8 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->Si = take(L * m * m + ((L * m * m) % 16 == 0 ? m * m : 0));
     o->Ki = (L * m * m) % 16 == 0 ? o->Si + L * m * m : take(m * m);
     o->t = take(L * m); o->G = take(L * m * m); o->A = take(L * m * m);
-    o->Aji = take(L * m * m); o->mu_hat = take(L * m); o->u = take(L * m); o->M2 = take(L * m * m);
+    // (M2 = Ki A Ki and Qm exist on the LDS-resident path only: the large-m path evaluates k^T M2 k as w^T Si w)
+    o->Aji = take(L * m * m); o->mu_hat = take(L * m); o->u = take(L * m); o->M2 = take(m > SVGP_M_MAX ? 0 : L * m * m);
     o->KL = take(2 * L); o->q = take(b);   // [KL | kl_form 1: tr(Ki A_l A_l)]
     o->p_m = take(b * L); o->p_v = take(b * L); o->e = take(b * L); o->d = take(b * L);
     o->eps = take(b * L); o->z = take(b * L);
@@ -112,12 +115,15 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->zbar = take(b * L); o->g_pv = take(b * L); o->g_pm = take(b * L); o->mvbar = take(b * L);
     o->statB = p; o->A2 = p; p += P * L * m * m; o->ud = p; p += P * L * m; o->td = p; p += P * L * m;
     o->statB_len = p - o->statB; take(0);
-    o->Kbar = take(m * m); o->fb_part = take(2 * L * m * m); o->Qm = take(L * m * m); o->vbar = take(L * m);
+    o->Kbar = take(m * m); o->fb_part = take(2 * L * m * m); o->Qm = take(m > SVGP_M_MAX ? 0 : L * m * m); o->vbar = take(L * m);
     o->Ssym = take(L * m * m); o->Knbar_part = take(L * b * m);
     // scratch of the large-m path (gp_large.hip)
-    // m > 64: (L,b,m) scratch + the forward products Kn Si_l, Kn M2_l (L,b,m each) and Kn Ki (b,m) kept for the reverse pass
-    o->scr_bm = take(m > 64 ? 3 * L * b * m + b * m : L * b * m); o->scr_mm = take(4 * L * m * m); o->scr_vec = take(3 * L * m + 3 * L + 16);
+    // m > 64: (L,b,m) scratch + the forward products [Kn; W] Si_l (L,2b,m), Kn Ki (b,m) kept for the reverse pass + Wbar (b,m)
+    o->scr_bm = take(m > SVGP_M_MAX ? 3 * L * b * m + 2 * b * m : L * b * m); o->scr_mm = take(4 * L * m * m);
+    o->scr_vec = take(3 * L * m + 3 * L + 16 + b);
     o->scr_inv = take((int64_t)svgp_spd_inverse_workspace_elems((int)m, (int)L + 1)); o->scr_bl = take(2 * b * L);
+    // m > 64: nine channel-independent m x m matrices of the W form (K Ki, Kn^T Wbar, Kn^T diag(qbar) Kn, channel sums, temporaries)
+    o->scr_sm = take(m > SVGP_M_MAX ? 9 * m * m : 0);
     o->Knbar = take(b * m); o->knnbar = take(b); o->ybar = take(b * L); o->s2bar = take(b * L);
     o->d_on = take(b * M);
     o->n_part = svgp_n_part(&cc);
@@ -129,7 +135,9 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->gradC = p; o->grad = p; p += pl.n_total; o->sums = p; p += 8; o->gradC_len = p - o->gradC; take(0);
     o->tit_Si = take(c->titsias ? L * m * m : 0); o->tit_t = take(c->titsias ? L * m : 0);
     o->tit_scal = take(c->titsias ? 2 * L + 1 : 0);
-    o->xpack_len = m > SVGP_M_MAX ? 2 * L * svgp_sym_packed_elems((int)m) : 0;
+    // the wire buffer of the channel-sharded exchange: one tile-packed (L, m, m) block; only when the batch is sharded over
+    // ranks (cfg.single_stat_block, set by the engines for world sizes > 1): a single-GPU workspace does not carry it
+    o->xpack_len = (m > SVGP_M_MAX && c->single_stat_block) ? L * svgp_sym_packed_elems((int)m) : 0;
     o->xpack = take(o->xpack_len);
     o->total = p;
     return SVGP_OK;

@@ -302,9 +302,9 @@ extern "C" int svgp_comm_timing_read(void* comm, float* us, int cap, int* n) {
 // Large-m path (m > 64) with L divisible by the rank count (Hensman branch): the channel-sharded schedule instead
 //  -- the (L,m,m) statistics are reduce-SCATTERED over the channels, every rank factors its L / G channels
 // (svgp_gp_factor_*_channels) and what the row stages need is all-gathered:
-//   encoder + kernel matrices + statistics | reduce-scatter S, v | window factor stage | all-gather Sigma^-1, M2, t, u, KL |
-//   row stage, decoder fwd + bwd, backward statistics | reduce-scatter A2, ud, td | window reverse factor stage |
-//   all-gather Ssym, vbar (Kn Q is formed from Kn Ssym and the forward pass's Kn M2: Q itself is not exchanged) |
+//   encoder + kernel matrices + statistics | reduce-scatter S, v | window factor stage | all-gather Sigma^-1, t, u |
+//   row stage, decoder fwd + bwd, backward statistics | reduce-scatter B2, ud, td | window reverse factor stage |
+//   all-gather Ssym, vbar, KL (round 4: M2 = Ki A Ki is neither formed nor exchanged, gp_large.hip "W form") |
 //   row gradients, kernel-matrix VJP (every rank's Kbar share counts), encoder reverse pass,
 //   gradient reduction | all-reduce gradC | phase 3
 // At config 3 on 8 ranks: 2 channels of 256 x 256 per rank instead of 16, 8.4 MB blocks moved as 7/8 of their size.
@@ -369,7 +369,9 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     const char* ev_side = getenv("SVGP_SIDE_STREAMS");
     const bool fork = !(ev_side && ev_side[0] == '0');
     const int64_t pe = svgp_sym_packed_elems(m);
-    double *xp0 = ws + wl.xpack, *xp1 = xp0 + (size_t)L * pe;
+    SVGP_REQUIRE(!pack || wl.xpack_len >= (int64_t)L * pe, SVGP_ERR_INVALID,
+                 "the packed exchange needs the workspace's wire buffer: lay the workspace out with cfg.single_stat_block = 1");
+    double* xp0 = ws + wl.xpack;
     // a symmetric (L,m,m) block on the wire: the tile-packed buffer (all channels / the rank's window) or the block itself
     auto rs_sym = [&](double* blk, double* xp) -> int {        // (inside a group)
         return pack ? rs(comm, xp, L * pe, G, stream) : rs(comm, blk, Lmm, G, stream);
@@ -390,15 +392,11 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     RUN(pt.end());
     // window factor stage without its tail
     RUN(svgp_big_factor_fwd(&cc, wl, ws, stream, l0, nl, 1));
-    // ---- point 2: all-gather [Sigma^-1 | M2 | t | u]
+    // ---- point 2: all-gather [Sigma^-1 | t | u]
     RUN(pt.begin());
-    if (pack) {
-        // the window goes to the wire format AND back first (M2 = Ki A Ki is symmetric only up to rounding: afterwards every
-        // rank holds bit-identical blocks), so that the side branch below never reads a block that is still being rewritten
-        RUN(svgp_sym_pack(m, nl, 0, ws + wl.Si + (size_t)l0 * mm, xp0 + (size_t)l0 * pe, stream));
-        RUN(svgp_sym_pack(m, nl, 1, ws + wl.M2 + (size_t)l0 * mm, xp1 + (size_t)l0 * pe, stream));
-        RUN(svgp_sym_unpack(m, nl, xp1 + (size_t)l0 * pe, ws + wl.M2 + (size_t)l0 * mm, stream));
-    }
+    // the window goes to the wire format first, so that the side branch below never reads a block that is being rewritten
+    // (Sigma^-1 is exactly symmetric in memory: its lower tiles ARE the matrix and the owner keeps its own window as it is)
+    if (pack) RUN(svgp_sym_pack(m, nl, 0, ws + wl.Si + (size_t)l0 * mm, xp0 + (size_t)l0 * pe, stream));
     // the tail ((A_hat + jI)^-1, log det, KL) and the early half of the reverse factor stage: on the side branch, beside the
     // all-gather, the row stage, the networks and the reverse statistics
     void* side = stream;
@@ -407,7 +405,6 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     if (fork) RUN(svgp_big_factor_bwd(&cc, wl, ws, state, side, l0, nl, 1));
     RUN(svgp_comm_group_begin(comm));
     RUN(ag_sym(ws + wl.Si, xp0));
-    RUN(ag_sym(ws + wl.M2, xp1));
     RUN(ag(comm, ws + wl.t, Lm, G, stream));
     RUN(ag(comm, ws + wl.u, Lm, G, stream));
     RUN(svgp_comm_group_end(comm));
@@ -415,15 +412,13 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
         const int hi0 = l0 + nl, nhi = L - hi0;
         RUN(svgp_sym_unpack(m, l0, xp0, ws + wl.Si, stream));
         RUN(svgp_sym_unpack(m, nhi, xp0 + (size_t)hi0 * pe, ws + wl.Si + (size_t)hi0 * mm, stream));
-        RUN(svgp_sym_unpack(m, l0, xp1, ws + wl.M2, stream));
-        RUN(svgp_sym_unpack(m, nhi, xp1 + (size_t)hi0 * pe, ws + wl.M2 + (size_t)hi0 * mm, stream));
     }
     RUN(pt.end());
     RUN(svgp_gp_posterior_fwd(&cc, eps, ws, state, stream));
     RUN(svgp_mnist_decoder_fwd(&cc, theta, images, ws, stream));
     RUN(svgp_mnist_decoder_bwd(&cc, theta, images, ws, state, stream));
     RUN(svgp_gp_stats_bwd(&cc, ws, state, stream));
-    // ---- point 3: reduce-scatter [A2 | ud | td]
+    // ---- point 3: reduce-scatter [B2 | ud | td]   (B2 = A2 - g3/2 W^T diag(p) W in the A2 field)
     RUN(pt.begin());
     if (pack) RUN(svgp_sym_pack(m, L, 0, ws + wl.A2, xp0, stream));
     RUN(svgp_comm_group_begin(comm));
@@ -439,7 +434,7 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     } else {
         RUN(svgp_big_factor_bwd(&cc, wl, ws, state, stream, l0, nl, 0));
     }
-    // ---- point 4: all-gather [Ssym | vbar | KL]  (Kn Q is formed from Kn Ssym and the forward pass's Kn M2: Q is not exchanged)
+    // ---- point 4: all-gather [Ssym | vbar | KL]
     RUN(pt.begin());
     if (pack) RUN(svgp_sym_pack(m, nl, 0, ws + wl.Ssym + (size_t)l0 * mm, xp0 + (size_t)l0 * pe, stream));
     RUN(svgp_comm_group_begin(comm));

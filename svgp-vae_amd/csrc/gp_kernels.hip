@@ -1242,7 +1242,10 @@ static int kernel_matrix_bwd_impl(const svgp_mnist_cfg* c, const double* theta, 
                                : set_dyn_lds(k_kernel_matrix_bwd_cr<0, 0>, lds_rows);
         if (rc_) return rc_;
     }
-#define KM_BWD_ARGS a, c->rep_weight, c->train_ip, ws + wl.K, ws + wl.Kn, ws + wl.Kbar, ws + wl.Knbar, ws + wl.knnbar, ws + wl.knn, \
+    // m > 64: svgp_big_factor_bwd has applied cfg.rep_weight to the replicated part of Kbar and added the rank-local row sums
+    // unweighted (gp_large.hip header), so Kbar is taken as it is
+    const real km_rep_weight = c->m > SVGP_M_MAX ? real(1) : (real)c->rep_weight;
+#define KM_BWD_ARGS a, km_rep_weight, c->train_ip, ws + wl.K, ws + wl.Kn, ws + wl.Kbar, ws + wl.Knbar, ws + wl.knnbar, ws + wl.knn, \
                     grad + pl.ip, ws + wl.d_on, ws + wl.part_gp
     if (cfg2_shape) hipLaunchKernelGGL((k_kernel_matrix_bwd_cr<32, 8>), dim3(c->m + nrb), dim3(SVGP_BLOCK), lds_rows, (hipStream_t)stream, KM_BWD_ARGS);
     else if (cfg3_shape) hipLaunchKernelGGL((k_kernel_matrix_bwd_cr<256, 32>), dim3(c->m + nrb), dim3(SVGP_BLOCK), lds_rows, (hipStream_t)stream, KM_BWD_ARGS);

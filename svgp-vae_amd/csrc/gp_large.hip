@@ -3,6 +3,16 @@
 // (linalg.hip); inverses are blocked Gauss-Jordan.  Same mathematics, same workspace fields and the
 // same exchange blocks (statA / statB) as the LDS-resident path in gp_kernels.hip, so the phases,
 // data parallelism and parity tests are unchanged.  Reference lines: SVGPVAE_model.py:220-343.
+//
+// Round 4, "W form" (restated in oracle/staged_gp.py, gp_*_w): the L3 integrand's k_n^T Ki A_l Ki k_n (SVGPVAE_model.py:281-284)
+// is evaluated as w_n^T Si_l w_n with the channel-INDEPENDENT rows w_n = K Ki k_n, W = (Kn Ki) K (A_l = K Si_l K; Ki K is
+// not simplified to I).  Same algebra, but the per-channel m^3 products A Ki, Ki A Ki (forward), S Ki, Ki S Ki,
+// S Ki A (reverse) and the row product Kn M2_l are gone: 5 of the 13 full 800^3 x 64 products of the SPRITES step.  In
+// their place: [Kn; W] Si_l as ONE row product, the weighted statistic W^T diag(p_l) W joining the reverse statistic
+// (B2_l = Kn^T diag(g_pv_l) Kn - g3/2 W^T diag(p_l) W: one contraction over the stacked rows), and channel-independent
+// m x m matrices: P^T = K Ki, Pbar = Kn^T Wbar, Qs = Kn^T diag(qbar) Kn.  Row sums that enter the gradient of K_mm linearly
+// (Pbar, Qs) stay rank-local under data parallelism -- the ranks' shares of Kbar add up in the gradient all-reduce -- so
+// cfg.rep_weight is applied HERE to the replicated part of Kbar and the kernel-matrix reverse pass takes Kbar as it is.
 #include "common.hpp"
 
 extern "C" int svgp_dgemm_batched(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
@@ -18,13 +28,14 @@ namespace {
 __device__ __forceinline__ real gradKL(int flags, int L, const real* state) { return svgp_seed_T(flags, L, state); }
 
 // ---- element-wise / reduction kernels ---------------------------------------------------------
-// weights of the statistics.  mode 0: w = 1/s2, a = y/s2.  mode 1: g_pv, g_pm, mvbar (stored), b = c g_pm.
+// weights of the statistics.  mode 0: w = 1/s2, a = y/s2.  mode 1: g_pv, g_pm, mvbar (stored), b = c g_pm, and the stacked
+// weights of the reverse statistic B2 over the rows [Kn; W]: wst[n][l] = g_pv, wst[b + n][l] = -g3/2 p.
 __global__ void k_big_weights(int n_el, int L, int mode, int geco, int clip_pv, real c, const real* __restrict__ state,
                               const real* __restrict__ y, const real* __restrict__ s2,
                               const real* __restrict__ p_m, const real* __restrict__ p_v,
                               const real* __restrict__ e, const real* __restrict__ eps,
                               const real* __restrict__ zbar, real* __restrict__ w, real* __restrict__ a,
-                              real* __restrict__ bv) {
+                              real* __restrict__ bv, real* __restrict__ wst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_el) return;
     const real p = recip_no_nan(s2[i]);
@@ -35,8 +46,31 @@ __global__ void k_big_weights(int n_el, int L, int mode, int geco, int clip_pv, 
         const real pv = p_v[i];
         const real gpv = svgp_gpv(clip_pv, gT, p, zb, eps[i], pv);
         const real gpm = gT * p * (p_m[i] - y[i]) + zb;
-        w[i] = gpv; bv[i] = gpm; a[i] = svgp_seed_3(geco, gT) * p * e[i];       // g_pv, g_pm, mvbar buffers
+        const real g3 = svgp_seed_3(geco, gT);
+        w[i] = gpv; bv[i] = gpm; a[i] = g3 * p * e[i];       // g_pv, g_pm, mvbar buffers
+        wst[i] = gpv; wst[(size_t)n_el + i] = real(-0.5) * g3 * p;
     }
+}
+// qbar_n = sum_l (g3/2 p_nl - g_pv_nl): the weight of k_n k_n^T in the gradient of Ki (q_n = k^T Ki k inside d and p_v)
+__global__ void k_big_qbar(int b, int L, int geco, const real* __restrict__ state, const real* __restrict__ s2,
+                           const real* __restrict__ g_pv, real* __restrict__ qbar) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= b) return;
+    const real g3 = svgp_seed_3(geco, gradKL(geco, L, state));
+    real q = 0;
+    for (int l = 0; l < L; ++l) q += real(0.5) * g3 * recip_no_nan(s2[(size_t)n * L + l]) - g_pv[(size_t)n * L + l];
+    qbar[n] = q;
+}
+// Wbar[n][j] = -g3 sum_l p_nl (W Si_l)[n][j]: the gradient of the rows W = Kn Ki K (channel sum: W is channel-independent)
+__global__ void k_big_wbar(int b, int m, int L, int geco, const real* __restrict__ state, const real* __restrict__ s2,
+                           const real* __restrict__ WSi, long long sW, real* __restrict__ Wbar) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)b * m) return;
+    const int n = (int)(i / m);
+    const real g3 = svgp_seed_3(geco, gradKL(geco, L, state));
+    real s = 0;
+    for (int l = 0; l < L; ++l) s += recip_no_nan(s2[(size_t)n * L + l]) * WSi[(size_t)l * sW + i];
+    Wbar[i] = -g3 * s;
 }
 // out[l] = in (m x m, shared) + c * S[l] + jitter * I     (S may be NULL -> in + jitter I, batch 1)
 __global__ void k_big_add_diag(int m, int L, real c, real jitter, const real* __restrict__ in,
@@ -126,26 +160,14 @@ struct FbArgs {
     int m, L, Ltot, geco, b_global;      // L = channels of this call (loops), Ltot = channels of the model (loss seeds)
     real c, N_train;
     const real* state;
-    const real* Ki; const real* Aji; const real* A; const real* S; const real* A2; const real* M2;
-    const real* mu; const real* u; const real* ud; const real* td; const real* t; const real* v;
-    real* X1;   // in: Ki S Ki  -> out: Abar
-    real* T1A;  // S Ki A
-    real* Kib;  // out
+    const real* A2;                      // B2_l = Kn^T diag(g_pv_l) Kn - g3/2 W^T diag(p_l) W (the reverse statistic; ws.A2)
+    const real* mu; const real* u; const real* ud; const real* td; const real* v;
     real* ubar; real* mubar; real* tbar;   // (L,m) each; mubar/tbar come in holding Ki ubar / K mubar
-    real* Sibar; real* Kb; real* Sg; real* Ssym; real* Qm;
-    const real* Z;   // Si K Abar
+    real* Sibar; const real* Sg; real* Ssym;
 };
 __device__ __forceinline__ void fb_scalars(const FbArgs& a, real& g3, real& gK) {
     const real gT = gradKL(a.geco, a.Ltot, a.state);
     g3 = svgp_seed_3(a.geco, gT); gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
-}
-__global__ void k_big_fb_abar(FbArgs a) {     // Abar (forward quantities only: part of the EARLY reverse factor stage)
-    real g3, gK; fb_scalars(a, g3, gK);
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)a.m * a.m;
-    if (i < mm * a.L) {
-        const long long o = i % mm;
-        a.X1[i] = real(-0.5) * g3 * a.X1[i] + real(0.5) * gK * (a.Ki[o] - a.Aji[i]);
-    }
 }
 __global__ void k_big_fb_ubar(FbArgs a) {     // ubar = ud + gK/2 mu
     real g3, gK; fb_scalars(a, g3, gK);
@@ -157,20 +179,20 @@ __global__ void k_big_fb_mubar(FbArgs a) {    // mubar = Ki ubar (in place) + gK
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.L * a.m) a.mubar[i] += real(0.5) * gK * a.u[i];
 }
-__global__ void k_big_fb_kibar(FbArgs a) {
+__global__ void k_big_fb_tbar(FbArgs a) {     // tbar = td + c (K mubar)  (tbar holds K mubar)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.L * a.m) a.tbar[i] = a.td[i] + a.c * a.tbar[i];
+}
+// Sibar_l = gK/2 K (Ki - Aji_l) K + B2_l + tbar_l v_l^T, in place on the product K (Ki - Aji_l) K
+__global__ void k_big_fb_sibar(FbArgs a) {
     real g3, gK; fb_scalars(a, g3, gK);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)a.m * a.m;
     if (i >= mm * a.L) return;
     const long long o = i % mm, l = i / mm;
     const int r = (int)(o / a.m), cidx = (int)(o % a.m);
-    a.Kib[i] = -g3 * a.T1A[i] + real(0.5) * gK * a.A[i] + a.ubar[l * a.m + r] * a.mu[l * a.m + cidx] +
-               real(0.5) * g3 * a.S[i] - a.A2[i];
+    a.Sibar[i] = real(0.5) * gK * a.Sibar[i] + a.A2[i] + a.tbar[l * a.m + r] * a.v[l * a.m + cidx];
 }
-__global__ void k_big_fb_tbar(FbArgs a) {     // tbar = td + c (K mubar)  (tbar holds K mubar)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.L * a.m) a.tbar[i] = a.td[i] + a.c * a.tbar[i];
-}
-// The two kernels below need X and X^T of a full (non-symmetric) product.  A workgroup owns the PAIR of 32 x 32 tiles (ti, tj),
+// The kernel below needs X and X^T of a full (non-symmetric) product.  A workgroup owns the PAIR of 32 x 32 tiles (ti, tj),
 // (tj, ti), ti <= tj, of one channel: both tiles go through LDS, every global access is coalesced (the element-per-thread form
 // read the transposed operand with a stride of m doubles: 0.55 + 0.61 ms per step at m = 800, L = 64).
 // grid (nt, nt, L), 256 threads; thread (c = tid & 31, r0 = tid >> 5) handles rows r0 + 8 h.
@@ -192,32 +214,7 @@ __device__ __forceinline__ void tp_load(const real* __restrict__ X, int m, const
     }
     __syncthreads();
 }
-// Sibar += A2 + tbar v^T ;  Kb = Z + Z^T + c mubar t^T with Z = Si (K Abar): the two products Abar G^T + Si Gbar of the
-// reverse pass are transposes of each other (Abar, K, Si symmetric), so one GEMM and a transposed read replace two GEMMs
-__global__ __launch_bounds__(256) void k_big_fb_sibar(FbArgs a) {
-    __shared__ real U[TP][TP + 1], V[TP][TP + 1];
-    TilePair t;
-    if (!t.init()) return;
-    const int m = a.m;
-    const size_t mm = (size_t)m * m, lo = (size_t)t.l * mm, lv = (size_t)t.l * m;
-    tp_load(a.Z + lo, m, t, U, V);
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-        const int r = t.r0 + 8 * h;
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            if (side == 1 && t.ti == t.tj) break;
-            const int gi = (side ? t.tj : t.ti) * TP + r, gj = (side ? t.ti : t.tj) * TP + t.c;
-            if (gi < m && gj < m) {
-                const size_t i = lo + (size_t)gi * m + gj;
-                const real z = side ? V[r][t.c] : U[r][t.c], zt = side ? U[t.c][r] : V[t.c][r];
-                a.Sibar[i] += a.A2[i] + a.tbar[lv + gi] * a.v[lv + gj];
-                a.Kb[i] = z + zt + a.c * a.mubar[lv + gi] * a.t[lv + gj];
-            }
-        }
-    }
-}
-// Kb += Sg ; Ssym = c (Sg + Sg^T)    (Q = Ssym - g3 M2 is not formed on this path: the row stage uses Kn Ssym - g3 Kn M2)
+// Ssym = c (Sg + Sg^T)    (Q = Ssym - g3 M2 is not formed on this path)
 __global__ __launch_bounds__(256) void k_big_fb_ssym(FbArgs a) {
     __shared__ real U[TP][TP + 1], V[TP][TP + 1];
     TilePair t;
@@ -235,7 +232,6 @@ __global__ __launch_bounds__(256) void k_big_fb_ssym(FbArgs a) {
             if (gi < m && gj < m) {
                 const size_t i = lo + (size_t)gi * m + gj;
                 const real sg = side ? V[r][t.c] : U[r][t.c], sgt = side ? U[t.c][r] : V[t.c][r];
-                a.Kb[i] += sg;
                 a.Ssym[i] = a.c * (sg + sgt);
             }
         }
@@ -249,16 +245,35 @@ __global__ void k_big_sum_channels(int mm, int L, const real* __restrict__ in, r
     for (int l = 0; l < L; ++l) s += in[(size_t)l * mm + o];
     out[o] = s;
 }
-// Kbar = sum_l Kb_l - Ki (sum_l Kib_l) Ki + gK/2 L Ki ;  KiKibKi = the middle product, formed once for the channel sum
-__global__ void k_big_fb_final(int m, int L, int Ltot, int geco, int b_global, real N_train, const real* __restrict__ state,
-                               const real* __restrict__ Kb, const real* __restrict__ Ki, const real* __restrict__ KiKibKi,
-                               real* __restrict__ Kbar) {
+// The gradient of Ki, channel sum: Kib = rep_weight (gK/2 sum_l A_l + sum_l ubar_l mu_l^T) + Qs + Pbar K
+//   (tr(Ki A) and mu^T Ki mu of the KL term: window part; q_n = k^T Ki k in d and p_v and P = Ki K: rank-local row sums)
+struct FinArgs {
+    int m, L, Ltot, geco, b_global;
+    real c, N_train, rep_weight;
+    const real* state;
+    const real* Asum; const real* ubar; const real* mu; const real* Qs; const real* PbarK;
+    const real* Zs; const real* mubar; const real* t; const real* Sgs; const real* Ki; const real* KiPbar; const real* KiKibKi;
+    real* Kib; real* Kbar;
+};
+__global__ void k_big_fb_kib(FinArgs a) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o >= m * m) return;
-    const real gT = gradKL(geco, Ltot, state), gK = svgp_seed_K(geco, gT, (real)b_global / N_train);
-    real s = 0;
-    for (int l = 0; l < L; ++l) s += Kb[(size_t)l * m * m + o];
-    Kbar[o] = s - KiKibKi[o] + real(0.5) * gK * (real)L * Ki[o];
+    if (o >= a.m * a.m) return;
+    const real gT = gradKL(a.geco, a.Ltot, a.state), gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
+    const int r = o / a.m, cidx = o % a.m;
+    real s = real(0.5) * gK * a.Asum[o];
+    for (int l = 0; l < a.L; ++l) s += a.ubar[(size_t)l * a.m + r] * a.mu[(size_t)l * a.m + cidx];
+    a.Kib[o] = a.rep_weight * s + a.Qs[o] + a.PbarK[o];
+}
+// Kbar = rep_weight (gK/2 (Zs + Zs^T) + c sum_l mubar_l t_l^T + sum_l Sg_l + gK/2 L Ki) + Ki Pbar - Ki Kib Ki
+__global__ void k_big_fb_final(FinArgs a) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= a.m * a.m) return;
+    const real gT = gradKL(a.geco, a.Ltot, a.state), gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
+    const int r = o / a.m, cidx = o % a.m;
+    real s = real(0.5) * gK * (a.Zs[o] + a.Zs[(size_t)cidx * a.m + r]) + a.Sgs[o] + real(0.5) * gK * (real)a.L * a.Ki[o];
+    real rk = 0;
+    for (int l = 0; l < a.L; ++l) rk += a.mubar[(size_t)l * a.m + r] * a.t[(size_t)l * a.m + cidx];
+    a.Kbar[o] = a.rep_weight * (s + a.c * rk) + a.KiPbar[o] - a.KiKibKi[o];
 }
 
 // ---- per-sample backward element-wise pieces ----------------------------------------------------
@@ -270,22 +285,22 @@ struct PbArgs {
     const real* g_pv; const real* g_pm; const real* mvbar;
     const real* u; const real* t; const real* vbar;
     const real* R;      // (L,b,m) Kn Ssym_l
-    const real* KnSi; const real* KnM2;   // (L,b,m) forward products
+    const real* KnSi; long long sKS;   // forward product Kn Si_l: channel l at KnSi + l sKS (the stacked [Kn; W] Si_l block)
     const real* kSk; const real* kv;   // (b,L)
     const real* KnKi;   // (b,m)
+    const real* qbar;   // (b)
     real* part;         // Knbar_part (L,b,m)
     real* Knbar; real* knnbar; real* ybar; real* s2bar;
 };
-// part = 2 g_pv (Kn Si) + p (Kn Q) + mvbar u + c g_pm t + p y vbar,  Kn Q = Kn Ssym - g3 Kn M2  (Q = Ssym - g3 M2);
-// Kn Si and Kn M2 are the forward pass's products, R = Kn Ssym
+// part = 2 g_pv (Kn Si) + p (Kn Ssym) + mvbar u + c g_pm t + p y vbar; Kn Si is the forward pass's product, R = Kn Ssym
+// (the d-term's k^T Ki A Ki k reaches Kn through Wbar (Ki K)^T, one product for all channels: svgp_big_posterior_bwd)
 __global__ void k_big_pb_part(PbArgs a) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, bm = (long long)a.b * a.m;
     if (i >= bm * a.L) return;
     const int j = (int)(i % a.m), n = (int)((i % bm) / a.m), l = (int)(i / bm);
     const size_t e = (size_t)n * a.L + l, vi = (size_t)l * a.m + j;
-    const real g3 = svgp_seed_3(a.geco, gradKL(a.geco, a.L, a.state));
     const real p = recip_no_nan(a.s2[e]);
-    a.part[i] = real(2) * a.g_pv[e] * a.KnSi[i] + p * (a.R[i] - g3 * a.KnM2[i]) + a.mvbar[e] * a.u[vi] +
+    a.part[i] = real(2) * a.g_pv[e] * a.KnSi[(size_t)l * a.sKS + (i % bm)] + p * a.R[i] + a.mvbar[e] * a.u[vi] +
                 a.c * a.g_pm[e] * a.t[vi] + p * a.y[e] * a.vbar[vi];
 }
 __global__ void k_big_pb_elem(PbArgs a) {     // ybar, s2bar
@@ -301,13 +316,9 @@ __global__ void k_big_pb_sum(PbArgs a) {      // Knbar = sum_l part + 2 qbar (Kn
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, bm = (long long)a.b * a.m;
     if (i >= bm) return;
     const int n = (int)(i / a.m);
-    const real gT = gradKL(a.geco, a.L, a.state);
-    real qbar = 0, acc = 0;
-    for (int l = 0; l < a.L; ++l) {
-        const size_t e = (size_t)n * a.L + l;
-        qbar += real(0.5) * svgp_seed_3(a.geco, gT) * recip_no_nan(a.s2[e]) - a.g_pv[e];
-        acc += a.part[(size_t)l * bm + i];
-    }
+    const real qbar = a.qbar[n];
+    real acc = 0;
+    for (int l = 0; l < a.L; ++l) acc += a.part[(size_t)l * bm + i];
     a.Knbar[i] = acc + real(2) * qbar * a.KnKi[i];
     if (i % a.m == 0) a.knnbar[n] = -qbar;
 }
@@ -363,22 +374,33 @@ inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 #define GEMM_SYM(...) RUNC(svgp_dgemm_symout_batched(c->gemm_f32 == 1, __VA_ARGS__, stream))
 #define GEMM_S_SYM(...) RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, __VA_ARGS__, stream))
 
-// scratch carving (layout fields scr_bm / scr_mm / scr_vec / scr_inv / scr_bl are allocated by api.hip)
+// scratch carving (layout fields scr_bm / scr_mm / scr_vec / scr_inv / scr_bl / scr_sm are allocated by api.hip)
 struct BigScr {
-    real *bm, *bm2, *mm0, *mm1, *mm2, *mm3, *vec0, *vec1, *vec2, *trm, *ldtmp, *inv, *bl0, *bl1;
-    // forward products kept for the reverse pass (behind the (L, b, m) scratch in scr_bm): Kn Si_l, Kn M2_l (L, b, m), Kn Ki (b, m)
-    real *KnSi, *KnM2, *KnKi;
+    real *bm, *bm2, *mm0, *mm1, *mm2, *mm3, *vec0, *vec1, *vec2, *trm, *ldtmp, *qbar, *inv, *bl0, *bl1, *wst;
+    // forward products kept for the reverse pass (behind the (L, b, m) scratch in scr_bm): KS = [Kn; W] Si_l (L, 2b, m) --
+    // channel l at KS + l sKS, Kn Si_l first, W Si_l at + b m --, Kn Ki (b, m); Wbar (b, m)
+    real *KS, *KnKi, *Wbar, *W;
+    long long sKS;
+    // channel-independent m x m matrices: P^T = K Ki, Pbar = Kn^T Wbar, Qs = Kn^T diag(qbar) Kn, sum_l A_l, sum_l Z'_l, sum_l Sg_l,
+    // two temporaries
+    real *PT, *Pbar, *Qs, *Asum, *Zs, *Sgs, *tA, *tB, *tC;
 };
 static BigScr big_scr(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws) {
-    const size_t Lmm = (size_t)c->L * c->m * c->m, Lm = (size_t)c->L * c->m, bL = (size_t)c->b * c->L;
+    const size_t Lmm = (size_t)c->L * c->m * c->m, Lm = (size_t)c->L * c->m, bL = (size_t)c->b * c->L, mm = (size_t)c->m * c->m;
+    const size_t bcap = (size_t)(c->b_cap > 0 ? c->b_cap : c->b);
     BigScr s;
     s.bm = ws + wl.scr_bm; s.bm2 = ws + wl.Knbar_part;
-    const size_t Lbm_cap = (size_t)c->L * (c->b_cap > 0 ? c->b_cap : c->b) * c->m;      // the layout is sized for the capacity
-    s.KnSi = s.bm + Lbm_cap; s.KnM2 = s.KnSi + Lbm_cap; s.KnKi = s.KnM2 + Lbm_cap;
+    const size_t Lbm_cap = (size_t)c->L * bcap * c->m;      // the layout is sized for the capacity
+    s.KS = s.bm + Lbm_cap; s.sKS = 2LL * c->b * c->m; s.KnKi = s.KS + 2 * Lbm_cap; s.Wbar = s.KnKi + bcap * c->m;
+    s.W = ws + wl.Kn + (size_t)c->b * c->m;
     s.mm0 = ws + wl.scr_mm; s.mm1 = s.mm0 + Lmm; s.mm2 = s.mm1 + Lmm; s.mm3 = s.mm2 + Lmm;
     s.vec0 = ws + wl.scr_vec; s.vec1 = s.vec0 + Lm; s.vec2 = s.vec1 + Lm; s.trm = s.vec2 + Lm; s.ldtmp = s.trm + 2 * c->L;
+    s.qbar = s.ldtmp + c->L + 16;
     s.inv = ws + wl.scr_inv;
-    s.bl0 = ws + wl.scr_bl; s.bl1 = s.bl0 + bL;
+    s.bl0 = ws + wl.scr_bl; s.bl1 = s.bl0 + bL; s.wst = s.bl0;      // wst (2b, L): alive inside the reverse statistics only
+    real* sm = ws + wl.scr_sm;
+    s.PT = sm; s.Pbar = sm + mm; s.Qs = sm + 2 * mm; s.Asum = sm + 3 * mm; s.Zs = sm + 4 * mm; s.Sgs = sm + 5 * mm;
+    s.tA = sm + 6 * mm; s.tB = sm + 7 * mm; s.tC = sm + 8 * mm;
     return s;
 }
 
@@ -386,6 +408,7 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
                    void* stream) {
     const int b = c->b, m = c->m, L = c->L;
     const real cc = c->N_train / (double)c->b_global;
+    const BigScr s = big_scr(c, wl, ws);
     hipStream_t st = (hipStream_t)stream;
     real* Kn = ws + wl.Kn;
     // weights: forward uses (g_pv, g_pm) as temporaries for (p, p*y); backward fills g_pv, mvbar, g_pm
@@ -394,22 +417,38 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
     real* bbuf = ws + wl.g_pm;
     hipLaunchKernelGGL(k_big_weights, dim3(nblk((long long)b * L)), dim3(256), 0, st, b * L, L, mode, SVGP_LOSS_FLAGS(c), c->clip_pv, cc, state,
                        ws + wl.qnet_mu, ws + wl.qnet_var, ws + wl.p_m, ws + wl.p_v, ws + wl.e, ws + wl.eps,
-                       ws + wl.zbar, wbuf, abuf, bbuf);
+                       ws + wl.zbar, wbuf, abuf, bbuf, s.wst);
     SVGP_LAUNCH_CHECK();
     real* S = mode == 0 ? ws + wl.S : ws + wl.A2;
     real* v1 = mode == 0 ? ws + wl.v : ws + wl.ud;
     // S_l = Kn^T diag(w_l) Kn: the weights w[n][l] scale the rows of the B operand while they are staged (no (L, b, m) copy
-    // of the scaled K_nm: config 3 saved a 15 us launch and 67 MB of traffic per statistics stage)
-    RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, b, 1.0, Kn, m, 0, Kn, m, 0, 0.0, S, m, (long long)m * m, L, stream, wbuf, L,
-                                   1));
+    // of the scaled K_nm: config 3 saved a 15 us launch and 67 MB of traffic per statistics stage).
+    // Reverse: B2_l = Kn^T diag(g_pv_l) Kn - g3/2 W^T diag(p_l) W as ONE contraction over the 2 b stacked rows [Kn; W] (W sits
+    // behind the b rows of Kn) with the stacked weights wst.
+    if (mode == 0)
+        RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, b, 1.0, Kn, m, 0, Kn, m, 0, 0.0, S, m, (long long)m * m, L, stream, wbuf, L,
+                                       1));
+    else
+        RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, 2 * b, 1.0, Kn, m, 0, Kn, m, 0, 0.0, S, m, (long long)m * m, L, stream,
+                                       s.wst, L, 1));
     // v1 (L x m) = a^T Kn: L x m outputs and a contraction over the batch -> split-K (8 tiles of 32 otherwise walk all b rows)
     const long long sk = svgp_dgemm_splitk_scratch_elems(L, m, b);
     SVGP_REQUIRE(sk >= 0 && sk <= (long long)c->L * m * m, SVGP_ERR_INVALID, "split-K scratch");
-    // scratch: the Kibar region of fb_part (written by the late reverse factor stage only; scr_mm may be in use by the early
-    // half on the side stream while the reverse statistics run)
+    // scratch: the second half of fb_part (unused since round 4; scr_mm may be in use by the early reverse half on the side stream
+    // while the reverse statistics run)
     real* sks = ws + wl.fb_part + (size_t)c->L * m * m;
     RUNC(svgp_dgemm_splitk(1, 0, L, m, b, 1.0, abuf, L, Kn, m, 0.0, v1, m, sks, sk, stream));
-    if (mode == 1) RUNC(svgp_dgemm_splitk(1, 0, L, m, b, cc, bbuf, L, Kn, m, 0.0, ws + wl.td, m, sks, sk, stream));
+    if (mode == 1) {
+        RUNC(svgp_dgemm_splitk(1, 0, L, m, b, cc, bbuf, L, Kn, m, 0.0, ws + wl.td, m, sks, sk, stream));
+        // the rank-local row sums of the reverse pass (they enter Kbar linearly: no exchange, see the file header)
+        hipLaunchKernelGGL(k_big_qbar, dim3(nblk(b)), dim3(256), 0, st, b, L, SVGP_LOSS_FLAGS(c), state, ws + wl.qnet_var, wbuf, s.qbar);
+        SVGP_LAUNCH_CHECK();
+        RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, b, 1.0, Kn, m, 0, Kn, m, 0, 0.0, s.Qs, m, 0, 1, stream, s.qbar, 1, 0));
+        hipLaunchKernelGGL(k_big_wbar, dim3(nblk((long long)b * m)), dim3(256), 0, st, b, m, L, SVGP_LOSS_FLAGS(c), state,
+                           ws + wl.qnet_var, s.KS + (size_t)b * m, s.sKS, s.Wbar);
+        SVGP_LAUNCH_CHECK();
+        GEMM_S(1, 0, m, m, b, 1.0, Kn, m, 0, s.Wbar, m, 0, 0.0, s.Pbar, m, 0, 1);                   // Pbar = Kn^T Wbar
+    }
     // (K_mm + jI)^-1 and its log det (SVGPVAE_model.py:239,270,273) are formed by svgp_big_factor_fwd, in the same
     // launches as the L channel inverses
     return SVGP_OK;
@@ -417,7 +456,7 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
 
 // Channel window [l0, l0 + nl): the factor stage of those channels only (all of them: l0 = 0, nl = L).  With the batch
 // sharded over ranks and the statistics reduce-SCATTERED over channels, every rank factors L / G channels instead of all
-// L redundantly; (K_mm + jI)^-1 and q_n are channel-independent and computed by every caller.
+// L redundantly; (K_mm + jI)^-1, q_n and W are channel-independent and computed by every caller.
 // part: 0 = the whole stage; 1 = without its tail -- (A_hat_l + jI)^-1, its log det and the KL_l scalars, which only the
 // reverse factor stage and the final ELBO need; 2 = that tail alone.  The training step issues the tail on a side stream
 // (api.hip, sprites.py) so that the second batched inverse of the step runs beside the row stage, the decoder and the
@@ -432,7 +471,7 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     hipStream_t st = (hipStream_t)stream;
     const size_t om = (size_t)l0 * mm, ov = (size_t)l0 * m;
     real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si + om, *G = ws + wl.G + om, *A = ws + wl.A + om, *Aji = ws + wl.Aji + om;
-    real *t = ws + wl.t + ov, *mu = ws + wl.mu_hat + ov, *u = ws + wl.u + ov, *v = ws + wl.v + ov, *M2 = ws + wl.M2 + om, *Kn = ws + wl.Kn;
+    real *t = ws + wl.t + ov, *mu = ws + wl.mu_hat + ov, *u = ws + wl.u + ov, *v = ws + wl.v + ov, *Kn = ws + wl.Kn;
     real* klp = ws + wl.fb_part;                 // (L, KL_NCH, 2) trace partials (fb_part is free until the reverse factor stage)
     if (part == 2) goto aji_tail;
     hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, cc, c->jitter, K, ws + wl.S + om, 0LL, Si);
@@ -456,18 +495,15 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     GEMM_SYM(0, 0, m, m, 1.0, K, m, 0, G, m, mm, 0.0, A, m, mm, L);                              // A = K G = K Si K
     GEMV(cc, K, 0, t, mu, L);                                                                    // mu = c K t
     GEMV(1.0, Ki, 0, mu, u, L);                                                                  // u = Ki mu
-    GEMM(0, 1, m, m, m, 1.0, A, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);                          // T = A Ki
-    // M2 and Ki S Ki below are full products, not lower-triangle-and-mirror: their rounding error has the form Ki E (norm
-    // eps |Ki||A||Ki|, far above eps |M2|), harmless in k^T M2 k for k in the range of K_mm (k^T Ki is small) but not once
-    // a triangular mask breaks that form (config-3 shape at jitter 1e-2: `d` moved by 9e-6; K X K products are fine)
-    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, M2, m, mm, L);                          // M2 = Ki A Ki
     hipLaunchKernelGGL(k_big_kl_terms, dim3(KL_NCH, L), dim3(256), 0, st, m, Ki, A, mu, u, klp);
     SVGP_LAUNCH_CHECK();
-    // q_n = k_n^T Ki k_n
+    // q_n = k_n^T Ki k_n;  W = (Kn Ki) K behind the rows of Kn;  P^T = K Ki
     GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, Ki, m, 0, 0.0, s.KnKi, m, 0, 1);           // kept: the reverse pass reads Kn Ki again
     hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * 64)), dim3(256), 0, st, b, m, 1, real(1), s.KnKi, 0LL, Kn,
                        ws + wl.q, 1, 0);
     SVGP_LAUNCH_CHECK();
+    GEMM(0, 1, b, m, m, 1.0, s.KnKi, m, 0, K, m, 0, 0.0, s.W, m, 0, 1);
+    GEMM(0, 1, m, m, m, 1.0, K, m, 0, Ki, m, 0, 0.0, s.PT, m, 0, 1);
     if (part == 1) return SVGP_OK;
 aji_tail:
     hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, real(0), c->jitter, A,
@@ -487,14 +523,13 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     const BigScr s = big_scr(c, wl, ws);
     hipStream_t st = (hipStream_t)stream;
     real* Kn = ws + wl.Kn;
-    // Kn Si_l and Kn M2_l are kept for svgp_big_posterior_bwd (2 of its 3 (b, m, m, L) products; 2 x L b m doubles of HBM)
-    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Si, m, mm, 0.0, s.KnSi, m, bm, L);                // Kn Si_l
-    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.KnSi, bm, Kn,
-                       ws + wl.p_v, L, 0);                                                      // r -> p_v slot
+    // [Kn; W] Si_l in one product over the 2 b stacked rows; kept for svgp_big_posterior_bwd / svgp_big_stats (mode 1)
+    GEMM(0, 1, 2 * b, m, m, 1.0, Kn, m, 0, ws + wl.Si, m, mm, 0.0, s.KS, m, s.sKS, L);
+    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.KS, s.sKS, Kn,
+                       ws + wl.p_v, L, 0);                                                      // r = k^T Si k -> p_v slot
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.M2, m, mm, 0.0, s.KnM2, m, bm, L);                // Kn M2_l
-    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.KnM2, bm, Kn,
-                       ws + wl.d, L, 0);                                                        // s -> d slot
+    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.KS + bm, s.sKS, s.W,
+                       ws + wl.d, L, 0);                                                        // s = w^T Si w (= k^T Ki A Ki k) -> d slot
     SVGP_LAUNCH_CHECK();
     GEMM(0, 1, b, L, m, cc, Kn, m, 0, ws + wl.t, m, 0, 0.0, ws + wl.p_m, L, 0, 1);               // p_m = c Kn t^T
     GEMM(0, 1, b, L, m, 1.0, Kn, m, 0, ws + wl.u, m, 0, 0.0, ws + wl.e, L, 0, 1);                // mv -> e slot
@@ -510,16 +545,18 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     return SVGP_OK;
 }
 
-// channel window [l0, l0 + nl) as in svgp_big_factor_fwd; Kbar then holds the window's share of the gradient of K_mm
-// (the shares of the ranks add up in the gradient exchange: kernel_matrix_bwd is linear in Kbar)
-// part: 0 = the whole stage; 1 = its EARLY half (3 + 4: its two parts separately); 2 = its LATE half.  Five and a half of the eight m^3 L products --
-//   T1 = S Ki, Ki S Ki, T1 A, Abar, Gbar = K Abar, Z = Sigma^-1 Gbar, Gbar K
-// -- depend on forward quantities and the loss seeds only (S is the FORWARD statistic), not on the reverse statistics A2, ud,
-// td.  The training step issues them on the side stream right behind the forward stage's tail, under the row stage, the
-// networks and the reverse statistics; the late half (ubar ... Sigma^-1 Sibar Sigma^-1, the channel sum) stays on the
-// critical path.  Same operations on the same values either way.  Buffers: T1 -> Z in mm0, Abar in mm1, T1 A in mm2 (kept for
-// the late half), Gbar K in mm3, Gbar in the Kb region of fb_part (dead before the late half writes Kb there; the forward
-// tail's trace partials at its head are consumed before: the side stream runs tail and early half in order).
+// channel window [l0, l0 + nl) as in svgp_big_factor_fwd; Kbar then holds rep_weight x the window's share of the gradient of
+// K_mm plus this rank's row-local share (the shares of the ranks add up in the gradient exchange: kernel_matrix_bwd is linear
+// in Kbar and takes it unweighted on this path).
+// part: 0 = the whole stage; 1 = its EARLY half (3 + 4: its two parts separately); 2 = its LATE half.  The early half --
+//   Gbar' = K (Ki - Aji) = P^T - K Aji, Z' = Sigma^-1 Gbar', Gbar' K, the channel sums of Z' and A_hat
+// -- depends on forward quantities only (the scalar gK/2 of Abar = gK/2 (Ki - Aji) is applied where the products are consumed),
+// not on the reverse statistics B2, ud, td.  The training step issues it on the side stream right behind the forward stage's
+// tail, under the row stage, the networks and the reverse statistics; the late half (ubar ... Sigma^-1 Sibar Sigma^-1, the
+// Ki-gradient, Kbar) stays on the critical path.  Same operations on the same values either way.  Buffers: Gbar' in the first
+// half of fb_part (the forward tail's trace partials at its head are consumed before: the side stream runs tail and early
+// half in order), Z' in mm0, Gbar' K in mm3 (becomes Sibar), then Sigma^-1 Sibar in mm0 and Sg in mm1.
+// (part 3, the products that needed no (A_hat + jI)^-1 -- S Ki, Ki S Ki, S Ki A_hat -- no longer exists: the W form has none.)
 int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
                         void* stream, int l0, int nl, int part) {
     const int m = c->m, L = nl;
@@ -528,31 +565,25 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     const BigScr s = big_scr(c, wl, ws);
     hipStream_t st = (hipStream_t)stream;
     const size_t om = (size_t)l0 * mm, ov = (size_t)l0 * m;
-    real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si + om, *A = ws + wl.A + om, *S = ws + wl.S + om;
-    real* Kb = ws + wl.fb_part;
-    real* Kib = Kb + (size_t)c->L * mm;
-    real* Gb = Kb;                                   // Gbar (early half only)
+    real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si + om, *A = ws + wl.A + om, *Aji = ws + wl.Aji + om;
+    real* Gb = ws + wl.fb_part;
     FbArgs a;
     a.m = m; a.L = L; a.Ltot = c->L; a.geco = SVGP_LOSS_FLAGS(c); a.b_global = c->b_global; a.c = cc; a.N_train = c->N_train; a.state = state;
-    a.Ki = Ki; a.Aji = ws + wl.Aji + om; a.A = A; a.S = S; a.A2 = ws + wl.A2 + om; a.M2 = ws + wl.M2 + om; a.mu = ws + wl.mu_hat + ov;
-    a.u = ws + wl.u + ov; a.ud = ws + wl.ud + ov; a.td = ws + wl.td + ov; a.t = ws + wl.t + ov; a.v = ws + wl.v + ov;
-    a.X1 = s.mm1; a.T1A = s.mm2; a.Kib = Kib; a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2;
-    a.Sibar = s.mm3; a.Kb = Kb; a.Sg = s.mm1; a.Z = s.mm0; a.Ssym = ws + wl.Ssym + om; a.Qm = ws + wl.Qm + om;
+    a.A2 = ws + wl.A2 + om; a.mu = ws + wl.mu_hat + ov; a.u = ws + wl.u + ov; a.ud = ws + wl.ud + ov; a.td = ws + wl.td + ov;
+    a.v = ws + wl.v + ov;
+    a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2; a.Sibar = s.mm3; a.Sg = s.mm1; a.Ssym = ws + wl.Ssym + om;
     const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m), ntp = (unsigned)((m + TP - 1) / TP);
-    // early half, first part (3): needs S, Ki, A_hat only -- not even (A_hat + jI)^-1, so it can run beside the forward tail
-    if (part == 0 || part == 1 || part == 3) {
-        GEMM(0, 1, m, m, m, 1.0, S, m, mm, Ki, m, 0, 0.0, s.mm0, m, mm, L);            // T1 = S Ki
-        GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, mm, 0.0, s.mm1, m, mm, L);        // Ki S Ki (full product, see M2)
-        GEMM(0, 1, m, m, m, 1.0, s.mm0, m, mm, A, m, mm, 0.0, s.mm2, m, mm, L);        // T1 A (mm2, read by the late half)
-    }
     if (part == 3) return SVGP_OK;
-    // early half, second part (4): + (A_hat + jI)^-1
     if (part == 0 || part == 1 || part == 4) {
-        hipLaunchKernelGGL(k_big_fb_abar, dim3(gmm), dim3(256), 0, st, a);             // Abar (mm1)
+        svgp_gemm_epi ep;
+        ep.E = s.PT; ep.lde = m; ep.se = 0; ep.g1 = 1.0;
+        RUNC(svgp_dgemm_epi_batched(c->gemm_f32 == 1, 0, 1, m, m, m, -1.0, K, m, 0, Aji, m, mm, 0.0, Gb, m, mm, L, stream, &ep));   // Gbar' = P^T - K Aji
+        GEMM(0, 0, m, m, m, 1.0, Si, m, mm, Gb, m, mm, 0.0, s.mm0, m, mm, L);          // Z' = Si Gbar'
+        GEMM_SYM(0, 1, m, m, 1.0, Gb, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);           // Gbar' K = K (Ki - Aji) K  (mm3)
+        hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, s.mm0, s.Zs);
         SVGP_LAUNCH_CHECK();
-        GEMM(0, 1, m, m, m, 1.0, K, m, 0, s.mm1, m, mm, 0.0, Gb, m, mm, L);            // Gbar = K Abar
-        GEMM(0, 0, m, m, m, 1.0, Si, m, mm, Gb, m, mm, 0.0, s.mm0, m, mm, L);          // Z = Si Gbar (mm0: T1 is done); Kb = Z + Z^T below
-        GEMM_SYM(0, 1, m, m, 1.0, Gb, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);           // Gbar K = K Abar K  (mm3)
+        hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, A, s.Asum);
+        SVGP_LAUNCH_CHECK();
     }
     if (part == 1 || part == 4) return SVGP_OK;
     hipLaunchKernelGGL(k_big_fb_ubar, dim3(gv), dim3(256), 0, st, a);
@@ -560,26 +591,33 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     GEMV(1.0, Ki, 0, s.vec0, s.vec1, L);                                               // Ki ubar
     hipLaunchKernelGGL(k_big_fb_mubar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_big_fb_kibar, dim3(gmm), dim3(256), 0, st, a);                // Kib
-    SVGP_LAUNCH_CHECK();
     GEMV(1.0, K, 0, s.vec1, s.vec2, L);                                                // K mubar
     hipLaunchKernelGGL(k_big_fb_tbar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_big_fb_sibar, dim3(ntp, ntp, L), dim3(256), 0, st, a);        // Sibar, Kb = Z + Z^T + c mubar t^T
+    hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);                // Sibar (mm3, in place)
     SVGP_LAUNCH_CHECK();
-    GEMV(1.0, Si, mm, s.vec2, ws + wl.vbar + ov, L);                                            // vbar = Si tbar
-    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm3, m, mm, 0.0, s.mm0, m, mm, L);           // Si Sibar (mm0)
+    GEMV(1.0, Si, mm, s.vec2, ws + wl.vbar + ov, L);                                   // vbar = Si tbar
+    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm3, m, mm, 0.0, s.mm0, m, mm, L);           // Si Sibar (mm0: Z' is summed)
     GEMM(0, 1, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);          // Sg = -Si Sibar Si (mm1)
     hipLaunchKernelGGL(k_big_fb_ssym, dim3(ntp, ntp, L), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    // sum_l Ki Kib_l Ki = Ki (sum_l Kib_l) Ki: Ki is shared by the channels and only the channel sum of Kb reaches Kbar,
-    // so the two products run once on the summed matrix instead of once per channel (2 of the 13 m^3 L products of this stage)
-    hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, Kib, s.mm0);
+    hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, s.mm1, s.Sgs);
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.mm0, m, 0, 0.0, s.mm0 + mm, m, 0, 1);          // Ki (sum Kib)
-    GEMM(0, 1, m, m, m, 1.0, s.mm0 + mm, m, 0, Ki, m, 0, 0.0, s.mm0, m, 0, 1);          // Ki (sum Kib) Ki
-    hipLaunchKernelGGL(k_big_fb_final, dim3(nblk(mm)), dim3(256), 0, st, m, L, c->L, SVGP_LOSS_FLAGS(c), c->b_global, c->N_train, state, Kb,
-                       Ki, s.mm0, ws + wl.Kbar);
+    // The gradient of Ki is needed for the channel sum only (Ki is shared): Kib = rep_weight (gK/2 sum A + sum ubar mu^T) + Qs + Pbar K,
+    // then Ki Kib Ki once.  Pbar, Qs: this rank's row sums from svgp_big_stats (mode 1).
+    FinArgs f;
+    f.m = m; f.L = L; f.Ltot = c->L; f.geco = SVGP_LOSS_FLAGS(c); f.b_global = c->b_global; f.c = cc; f.N_train = c->N_train;
+    f.rep_weight = c->rep_weight; f.state = state;
+    f.Asum = s.Asum; f.ubar = s.vec0; f.mu = a.mu; f.Qs = s.Qs; f.PbarK = s.tA; f.Zs = s.Zs; f.mubar = s.vec1; f.t = ws + wl.t + ov;
+    f.Sgs = s.Sgs; f.Ki = Ki; f.KiPbar = s.Pbar; f.KiKibKi = s.tA; f.Kib = s.tB; f.Kbar = ws + wl.Kbar;
+    GEMM(0, 1, m, m, m, 1.0, s.Pbar, m, 0, K, m, 0, 0.0, s.tA, m, 0, 1);                // Pbar K
+    hipLaunchKernelGGL(k_big_fb_kib, dim3(nblk(mm)), dim3(256), 0, st, f);             // Kib (tB)
+    SVGP_LAUNCH_CHECK();
+    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.tB, m, 0, 0.0, s.tC, m, 0, 1);                 // Ki Kib             (tC)
+    GEMM(0, 1, m, m, m, 1.0, s.tC, m, 0, Ki, m, 0, 0.0, s.tA, m, 0, 1);                 // Ki Kib Ki          (tA)
+    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.Pbar, m, 0, 0.0, s.tB, m, 0, 1);               // Ki Pbar            (tB)
+    f.KiPbar = s.tB;
+    hipLaunchKernelGGL(k_big_fb_final, dim3(nblk(mm)), dim3(256), 0, st, f);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
@@ -597,12 +635,12 @@ int svgp_big_posterior_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var; a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v; a.e = ws + wl.e;
     a.d = ws + wl.d; a.g_pv = ws + wl.g_pv; a.g_pm = ws + wl.g_pm; a.mvbar = ws + wl.mvbar;
     a.u = ws + wl.u; a.t = ws + wl.t; a.vbar = ws + wl.vbar; a.R = s.bm; a.kSk = s.bl0; a.kv = s.bl1; a.KnKi = s.KnKi;
-    a.KnSi = s.KnSi; a.KnM2 = s.KnM2;
+    a.KnSi = s.KS; a.sKS = s.sKS; a.qbar = s.qbar;
     a.part = ws + wl.Knbar_part; a.Knbar = ws + wl.Knbar; a.knnbar = ws + wl.knnbar; a.ybar = ws + wl.ybar;
     a.s2bar = ws + wl.s2bar;
     const unsigned gbm = nblk(bm * L);
-    // one (b, m, m, L) product instead of three: Kn Si_l and Kn M2_l come from the forward pass (svgp_big_posterior_fwd on
-    // this workspace), Kn Ki from svgp_big_factor_fwd
+    // one (b, m, m, L) product: Kn Si_l comes from the forward pass (svgp_big_posterior_fwd on this workspace), Kn Ki from
+    // svgp_big_factor_fwd; the d-term's share arrives through Wbar P^T below
     GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Ssym, m, mm, 0.0, s.bm, m, bm, L);
     hipLaunchKernelGGL(k_big_pb_part, dim3(gbm), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
@@ -614,5 +652,6 @@ int svgp_big_posterior_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_big_pb_sum, dim3(nblk(bm)), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
+    GEMM(0, 0, b, m, m, 1.0, s.Wbar, m, 0, s.PT, m, 0, 1.0, ws + wl.Knbar, m, 0, 1);   // Knbar += Wbar P^T... (P^T = K Ki)
     return SVGP_OK;
 }

@@ -37,6 +37,11 @@ struct GemmArgs {
     // optional weights of the contraction index: op(B)[k][j] is multiplied by wk[k * ldw + l * sw] while it is staged
     // (S_l = Kn^T diag(w_l) Kn without materialising diag(w_l) Kn); element type = TS
     const void* wk; int ldw; long long sw;
+    // extended epilogue (svgp_gemm_epi, common.hpp; float64 storage): out1 = alpha acc + beta C + g1 E + d1 I -> C,
+    // out2 = a2 acc + g2 E + d2 I -> C2 (same leading dimension as C); E: lde, batch stride se (0 = shared)
+    int epi_on;
+    const void* E; int lde; long long se; void* C2; long long sc2;
+    real g1, d1, a2, g2, d2;
 };
 
 // k-panels of 16 are double-buffered in LDS and a third one is in flight in registers (see the main loop), one
@@ -355,6 +360,34 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
         cur ^= 1;
     }
     const bool has_beta = g.beta != real(0);
+    if (g.epi_on) {
+        // extended epilogue: an extra matrix E and a diagonal term on the output, and an optional second output with its own
+        // coefficients -- K + c S + jI next to S, A + jI next to A, P^T - K Aji: each used to be a pass over an (L, m, m) array
+        const TS* __restrict__ E = g.E ? static_cast<const TS*>(g.E) + (size_t)l * g.se : nullptr;
+        TS* C2 = g.C2 ? static_cast<TS*>(g.C2) + (size_t)l * g.sc2 : nullptr;
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int gi = i0 + wi + a * 16 + MF::row(q, e), gj = j0 + wj + b * 16 + r;
+                    if (gi < g.M && gj < g.N) {
+                        const real av = (real)acc[a][b][e], dd = gi == gj ? real(1) : real(0);
+                        const size_t o = (size_t)gi * g.ldc + gj;
+                        const real ev = E ? (real)E[(size_t)gi * g.lde + gj] : real(0);
+                        C[o] = (TS)(g.alpha * av + (has_beta ? g.beta * (real)C[o] : real(0)) + g.g1 * ev + g.d1 * dd);
+                        if (C2) C2[o] = (TS)(g.a2 * av + g.g2 * ev + g.d2 * dd);
+                        if ((g.tri & 16) && i0 != j0) {          // mirror of a below-diagonal tile (never on the diagonal)
+                            const size_t oT = (size_t)gj * g.ldc + gi;
+                            const real evT = E ? (real)E[(size_t)gj * g.lde + gi] : real(0);
+                            C[oT] = (TS)(g.alpha * av + (has_beta ? g.beta * (real)C[oT] : real(0)) + g.g1 * evT);
+                            if (C2) C2[oT] = (TS)(g.a2 * av + g.g2 * evT);
+                        }
+                    }
+                }
+        return;
+    }
 #pragma unroll
     for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -639,7 +672,7 @@ __global__ __launch_bounds__(256) void k_bgjf_step(BgjfArgs g) {
 static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, double alpha, const void* A, int lda,
                        long long strideA, const void* B, int ldb, long long strideB, double beta, void* C, int ldc,
                        long long strideC, int batch, void* stream, const void* wk = nullptr, int ldw = 0,
-                       long long strideW = 0) {
+                       long long strideW = 0, const svgp_gemm_epi* epi = nullptr) {
     SVGP_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, SVGP_ERR_INVALID, "negative dimension");
     if (M == 0 || N == 0 || batch == 0) return SVGP_OK;
     SVGP_REQUIRE(A && B && C, SVGP_ERR_INVALID, "NULL device pointer");
@@ -648,6 +681,16 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     g.sa = strideA; g.sb = strideB; g.sc = strideC; g.alpha = alpha; g.beta = beta; g.A = A; g.B = B; g.C = C;
     g.tri = tri;
     g.wk = wk; g.ldw = ldw; g.sw = strideW;
+    g.epi_on = 0; g.E = nullptr; g.lde = 0; g.se = 0; g.C2 = nullptr; g.sc2 = 0; g.g1 = g.d1 = g.a2 = g.g2 = g.d2 = 0;
+    if (epi) {
+        SVGP_REQUIRE(prec != 2, SVGP_ERR_INVALID, "extended GEMM epilogue: float64 storage only");
+        SVGP_REQUIRE(epi->E || (epi->g1 == 0 && epi->g2 == 0), SVGP_ERR_INVALID, "extended GEMM epilogue: E is NULL");
+        g.epi_on = 1; g.E = epi->E; g.lde = epi->lde; g.se = epi->se; g.C2 = epi->C2; g.sc2 = epi->sc2;
+        g.g1 = epi->g1; g.d1 = epi->d1; g.a2 = epi->a2; g.g2 = epi->g2; g.d2 = epi->d2;
+    }
+    //  the mirrored store treats every tile with i0 != j0 as lying strictly below the diagonal: true only for a
+    // square output cut identically along rows and columns
+    SVGP_REQUIRE(!(tri & 16) || (M == N && (tri & 1)), SVGP_ERR_INVALID, "mirrored store needs a square lower-triangle product");
     const long long blocks128 = (long long)((N + 127) / 128) * ((M + 127) / 128) * batch;
     // tile choice: 128 x 128 tiles run ~9 % faster per useful flop than 64 x 64 (57.6 vs 52.9 TFLOP/s at 2048^3, no padding)
     // but pad M, N up to multiples of 128: at 800 x 800 that is 25 % wasted tile area against 8 % (measured 39.7 vs 41.3-45.6
@@ -815,9 +858,16 @@ extern "C" int svgp_sgemm_batched(int ta, int tb, int M, int N, int K, float alp
 // f32c != 0: float32 MFMA arithmetic on the float64 matrices.
 int svgp_dgemm_symout_batched(int f32c, int ta, int tb, int M, int K, double alpha, const double* A, int lda, long long strideA,
                               const double* B, int ldb, long long strideB, double beta, double* C, int ldc, long long strideC,
-                              int batch, void* stream, const double* wk, int ldw, long long strideW) {
+                              int batch, void* stream, const double* wk, int ldw, long long strideW, const svgp_gemm_epi* epi) {
     return gemm_launch(f32c ? 1 : 0, 1 | 16, ta, tb, M, M, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch,
-                       stream, wk, ldw, strideW);
+                       stream, wk, ldw, strideW, epi);
+}
+// the general product with the extended epilogue (svgp_gemm_epi)
+int svgp_dgemm_epi_batched(int f32c, int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA,
+                           const double* B, int ldb, long long strideB, double beta, double* C, int ldc, long long strideC,
+                           int batch, void* stream, const svgp_gemm_epi* epi) {
+    return gemm_launch(f32c ? 1 : 0, 0, ta, tb, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch,
+                       stream, nullptr, 0, 0, epi);
 }
 
 // the float64 GEMM with triangular structure hints (see GemmArgs::tri); tiles / k-panels that the hints exclude are

@@ -79,7 +79,7 @@ class ChannelShardedStep:
 
     backend: `.stage(k)` for k in 0..5 and `.ops(k)` -> list of ExchangeOp to run after stage k (k in 0..4):
       stage 0  encoder, kernel matrices, forward statistics          ops: reduce_scatter S, v over channels
-      stage 1  factor stage of the rank's channel window             ops: allgather Sigma^-1, M2 (or A), t, u, KL
+      stage 1  factor stage of the rank's channel window             ops: allgather Sigma^-1, t, u (KL at stage 3)
       stage 2  row stage, decoder fwd + bwd, backward statistics     ops: reduce_scatter A2, ud, td
       stage 3  reverse factor stage of the window                    ops: allgather Ssym, vbar
       stage 4  row gradients, kernel-matrix VJP (the rank's Kbar share counts on EVERY rank), encoder reverse pass
@@ -501,7 +501,10 @@ class MnistStepEngine:
         mm = m * m
         pack = dp_pack_enabled(m)
         pe = int(self.lib.svgp_sym_packed_elems(m))
-        xp = [self.ws[self.wl.xpack + k * L * pe:self.wl.xpack + (k + 1) * L * pe] for k in range(2)]
+        if pack and self.wl.xpack_len < L * pe:
+            raise _lib.SvgpError("the packed exchange needs the workspace's wire buffer: build the engine with world_size > 1 "
+                            "(cfg.single_stat_block) or set SVGP_DP_PACK=0")
+        xp = [self.ws[self.wl.xpack:self.wl.xpack + L * pe]]            # ONE wire buffer: every point moves one symmetric block
         sym = lambda k, avg=False, pre=False: SymBlock(m, L, avg, xp[k], pre) if pack else None
         plain = lambda kind, *fields: [ExchangeOp(kind, fld(n, per)) for n, per in fields]
         fork = os.environ.get("SVGP_SIDE_STREAMS", "1")[0] != "0"
@@ -514,19 +517,16 @@ class MnistStepEngine:
         yield [ExchangeOp("reduce_scatter", fld("S", mm), sym(0))] + plain("reduce_scatter", ("v", m))
         with torch.cuda.stream(self.stream):
             call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 1, ws, s)            # without the (A_hat + jI)^-1 tail
-            if pack:      # the window in wire format (and M2 symmetrised in place) BEFORE the side branch starts reading it
+            if pack:      # the window in wire format BEFORE the side branch starts reading it
                 call("svgp_sym_pack", m, nl, 0, wptr("Si"), wptr("Si", 0), s)
-                call("svgp_sym_pack", m, nl, 1, wptr("M2"), wptr("M2", 1), s)
-                call("svgp_sym_unpack", m, nl, wptr("M2", 1), wptr("M2"), s)
             # the tail and the early reverse half: on the side branch, beside the all-gather, the row stage, the decoder and
             # the reverse statistics
             side.wait_stream(self.stream)
             call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 2, ws, side.cuda_stream)
             if fork:
                 call("svgp_gp_factor_bwd_channels_part", cp, l0, nl, 1, ws, st, side.cuda_stream)
-        yield [ExchangeOp("allgather", fld("Si", mm), sym(0, pre=True)),
-               ExchangeOp("allgather", fld("M2", mm), sym(1, avg=True, pre=True) if pack else None)] + \
-            plain("allgather", ("t", m), ("u", m))
+        # (round 4: M2 = Ki A Ki is no longer formed or exchanged -- the row stage evaluates k^T M2 k as w^T Si w, gp_large.hip)
+        yield [ExchangeOp("allgather", fld("Si", mm), sym(0, pre=True))] + plain("allgather", ("t", m), ("u", m))
         with torch.cuda.stream(self.stream):
             call("svgp_gp_posterior_fwd", cp, ep, ws, st, s)
             call("svgp_mnist_decoder_fwd", cp, th, im, ws, s)
@@ -536,7 +536,7 @@ class MnistStepEngine:
         with torch.cuda.stream(self.stream):
             self.stream.wait_stream(side)
             call("svgp_gp_factor_bwd_channels_part", cp, l0, nl, 2 if fork else 0, ws, st, s)
-        # (Q = Ssym - g3 M2 is not exchanged: M2 was, in stage 1; KL_l comes out of the tail, joined above)
+        # (KL_l comes out of the tail, joined above)
         yield [ExchangeOp("allgather", fld("Ssym", mm), sym(0))] + plain("allgather", ("vbar", m), ("KL", 1))
         with torch.cuda.stream(self.stream):
             call("svgp_gp_posterior_bwd", cp, ws, st, s)

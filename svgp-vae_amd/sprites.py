@@ -171,12 +171,6 @@ class SpritesStepEngine:
         svgp.inducing_index_points, svgp.GPLVM_action, svgp.se = \
             self.params["inducing_index_points"], self.params["GPLVM_action"], self.params["se"]
         # ---- GP workspace (shared stage kernels of the MNIST path; model-agnostic fields only)
-        self.base = dict(m=self.m, L=self.L, M=1, n_obj=0, normalize_obj=0, clip_qs=int(clip_qs), geco=int(geco),
-                         train_ip=1, train_gp=1, train_ov=0, b_cap=b_max, clip_pv=1, n_pix=64 * 64 * 3,
-                         titsias=int(svgp.titsias),
-                         N_train=svgp.N_train, jitter=svgp.jitter, kappa_squared=float(kappa_squared),
-                         alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0, single_stat_block=int(world_size > 1),
-                         gemm_f32=int(gemm_f32))
         # Channel-sharded factor stage: with more than one rank and the large-m path, the (L,m,m) statistics
         # are reduce-SCATTERED over the channels, every rank factors L / G channels and the row stage's inputs are
         # all-gathered -- instead of all-reducing the blocks and factoring all L channels on every rank.
@@ -185,6 +179,15 @@ class SpritesStepEngine:
         if channel_shard and (self.m <= 64 or self.L % world_size or svgp.titsias):
             raise _lib.SvgpError("channel_shard needs m > 64, L divisible by the number of ranks and the Hensman branch")
         self.chan_shard = bool(channel_shard)
+        self.base = dict(m=self.m, L=self.L, M=1, n_obj=0, normalize_obj=0, clip_qs=int(clip_qs), geco=int(geco),
+                         train_ip=1, train_gp=1, train_ov=0, b_cap=b_max, clip_pv=1, n_pix=64 * 64 * 3,
+                         titsias=int(svgp.titsias),
+                         N_train=svgp.N_train, jitter=svgp.jitter, kappa_squared=float(kappa_squared),
+                         alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0,
+                         # blocks travel between ranks (also: the 1-rank communicator form of a multi-rank step): one statistics
+                         # block per channel, and the workspace carries the wire buffer of the packed exchange
+                         single_stat_block=int(world_size > 1 or self.chan_shard),
+                         gemm_f32=int(gemm_f32))
         if self.chan_shard:
             self.base["rep_weight"] = 1.0        # every rank's Kbar holds its channel window's share (sums in the gradient exchange)
         self.cfg = MnistCfg(b=b_max, b_global=b_max, **self.base)
@@ -383,7 +386,7 @@ class SpritesStepEngine:
     def phases(self, images, action_ids, eps=None, adam=True, b_global=None):
         """Generator over the step: yields, at every exchange point, the list of engine.ExchangeOp to run across the
         ranks.  Three points (all-reduce of the forward statistics, the backward statistics, gradients + scalar sums) in
-        the plain form; five in the channel-sharded form (reduce-scatter S, v | all-gather Sigma^-1, M2, t, u, KL |
+        the plain form; five in the channel-sharded form (reduce-scatter S, v | all-gather Sigma^-1, t, u |
         reduce-scatter A2, ud, td | all-gather Ssym, vbar | all-reduce gradients + sums)."""
         b = images.shape[0]
         assert b <= self.b_max and b % self.seg_len == 0
@@ -403,9 +406,10 @@ class SpritesStepEngine:
             self._mark("nets_fwd_enc")
             kc = SpritesKcfg(b=b, m=self.m, La=self.La, Lc=self.Lc, n_act=self.n_act,
                              normalize=int(self.svgp.K_obj_normalize), k_se=int(self.svgp.K_SE),
-                             # Kbar-derived terms: replicated on every rank (counted on rank 0) -- or, channel-sharded,
-                             # every rank's Kbar is its window's share and all shares count
-                             rep_weight=1.0 if (self.rank == 0 or self.chan_shard) else 0.0)
+                             # Kbar-derived terms (m <= 64): replicated on every rank, counted on rank 0.  m > 64: the reverse
+                             # factor stage has applied cfg.rep_weight to the replicated part of Kbar and added this rank's
+                             # row-local share unweighted (gp_large.hip), so Kbar counts as it is on every rank
+                             rep_weight=1.0 if (self.rank == 0 or self.m > 64) else 0.0)
             K, Kn, knn = self._v("K", (self.m, self.m)), self._v("Kn", (b, self.m)), self._v("knn", (b,))
             aid = action_ids.to(_F64).contiguous()
 
@@ -443,7 +447,9 @@ class SpritesStepEngine:
         # symmetric (L,m,m) members travel tile-packed (engine.SymBlock) from m >= 512
         pack = self.chan_shard and dp_pack_enabled(self.m)
         pe = int(_lib.load_library().svgp_sym_packed_elems(self.m))
-        xp = [self.ws[self.wl.xpack + k * L * pe:self.wl.xpack + (k + 1) * L * pe] for k in range(2)] if pack else [None, None]
+        if pack and self.wl.xpack_len < L * pe:
+            raise _lib.SvgpError("the packed exchange needs the workspace's wire buffer (world_size > 1) or SVGP_DP_PACK=0")
+        xp = [self.ws[self.wl.xpack:self.wl.xpack + L * pe]] if pack else [None]     # ONE wire buffer per exchange point
         sym = lambda k, avg=False, pre=False: SymBlock(self.m, L, avg, xp[k], pre) if pack else None
         l0 = r_ * nl
         wptr = lambda name, k=None: (xp[k].data_ptr() + 8 * l0 * pe) if k is not None else \
@@ -456,10 +462,8 @@ class SpritesStepEngine:
             self._mark("gp_fwd_factor")
             if self.chan_shard:
                 call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 1, ws, s)         # without the (A_hat + jI)^-1 tail
-                if pack:   # the window in wire format (M2 symmetrised in place) BEFORE the side branch starts reading it
+                if pack:   # the window in wire format BEFORE the side branch starts reading it
                     call("svgp_sym_pack", self.m, nl, 0, wptr("Si"), wptr("Si", 0), s)
-                    call("svgp_sym_pack", self.m, nl, 1, wptr("M2"), wptr("M2", 1), s)
-                    call("svgp_sym_unpack", self.m, nl, wptr("M2", 1), wptr("M2"), s)
                 # the tail and the early reverse half of the window: on the side stream, beside the all-gather, the row stage,
                 # the decoder and the reverse statistics
                 sd = self.side if self.side is not None else self.stream
@@ -487,8 +491,8 @@ class SpritesStepEngine:
             else:
                 call("svgp_gp_factor_fwd", cp, ws, s)
         if self.chan_shard:
-            yield [ExchangeOp("allgather", fld("Si", mm_), sym(0, pre=True)),
-                   ExchangeOp("allgather", fld("M2", mm_), sym(1, avg=True, pre=True))] + plain("allgather", ("t", self.m), ("u", self.m))
+            # (round 4: M2 = Ki A Ki is neither formed nor exchanged -- the row stage evaluates k^T M2 k as w^T Si w)
+            yield [ExchangeOp("allgather", fld("Si", mm_), sym(0, pre=True))] + plain("allgather", ("t", self.m), ("u", self.m))
         with torch.cuda.stream(self.stream):
             call("svgp_gp_posterior_fwd", cp, None if eps is None else eps.contiguous().data_ptr(), ws, st, s)
             if self.svgp.titsias:

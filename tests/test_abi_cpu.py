@@ -42,7 +42,8 @@ def test_layouts_match_reference_parameter_count_and_are_disjoint():
     # 5721 VAE + 32x10 inducing + l, amp + 400x8 object vectors = 9243 trainables
     assert (pl.n_enc, pl.n_vae, pl.n_total) == (2304, 5721, 9243)
     tit = ("tit_S2", "tit_v2", "tit_Si", "tit_t", "tit_scal",     # zero-sized unless cfg.titsias
-           "xpack", "xpack_len")                                  # zero-sized unless m > 64
+           "xpack", "xpack_len",                                  # zero-sized unless m > 64 and sharded over ranks
+           "scr_sm")                                              # zero-sized unless m > 64
     offs = sorted(getattr(wl, f) for f in _lib.WS_FIELDS
                   if f not in ("statA_len", "statB_len", "gradC_len", "n_part", "n_post", "total",
                                "statA", "statB", "gradC") + tit)

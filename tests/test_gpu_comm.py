@@ -68,14 +68,14 @@ def test_channel_sharded_dp_entry_equals_single_gpu_step_large_m(pack, monkeypat
     all-gather); with a 1-rank communicator the collectives are identities and the window is all channels, so three
     Adam steps must reproduce svgp_mnist_train_step (same kernels; the deferred phase forms do not exist for m > 64).
     pack = 1: the grouped + tile-packed form of the five exchange points (pack -> ncclGroup{...} -> unpack through real
-    RCCL calls); M2 then passes through its symmetrised wire format, a rounding-level change.  The per-point event
+    RCCL calls).  The per-point event
     timing (svgp_comm_timing) reports five points."""
     from svgp_vae_amd.engine import RcclComm
     monkeypatch.setenv("SVGP_DP_PACK", pack)
     params, images, aux, eps = H.toy_problem(b=96, m=72, L=4, M=16, n_obj=40, seed=5)
     kw = dict(geco=True, N_train=4050.0, jitter=1e-4)
     a = H.engine_for(params, 96, **kw)
-    b_ = H.engine_for(params, 96, **kw)
+    b_ = H.engine_for(params, 96, single_stat_block=True, **kw)      # the multi-rank workspace: it carries the wire buffer
     comm = RcclComm(0, 1, RcclComm.unique_id())
     x = torch.arange(24, dtype=torch.float64, device="cuda:0")
     s = torch.cuda.current_stream().cuda_stream

@@ -17,7 +17,7 @@ from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
 
-FWD_FIELDS = ("Ki", "ldK", "Si", "t", "G", "A", "Aji", "mu_hat", "u", "M2", "KL", "q")
+FWD_FIELDS = ("Ki", "ldK", "Si", "t", "G", "A", "Aji", "mu_hat", "u", "KL", "q")
 BWD_FIELDS = ("Kbar", "vbar", "Ssym")
 
 

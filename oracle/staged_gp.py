@@ -274,13 +274,16 @@ def gp_posterior_fwd_w(Kn, knn, y, s2, eps, f, c, K):
     return dict(p=p, W=KnKi, Ww=W, KnSi=KnSi, WSi=WSi, q=q, p_m=p_m, p_v=p_v, mv=mv, e=e, d=d, L3=L3, CE=ce.sum(), z=z)
 
 
-def gp_stats_bwd_w(Kn, ps, g_pv, mvbar, g_pm, gT, c):
-    """svgp_big_stats (mode 1): B2_l = Kn^T diag(g_pv_l) Kn - g3/2 W^T diag(p_l) W -- ONE contraction over the stacked rows
-    [Kn; W] with the stacked weights [g_pv; -g3/2 p] --, ud, td as before.  B2 | ud | td is the reverse exchange block."""
-    g3 = gT
-    A2, ud, td = gp_stats(Kn, g_pv, mvbar, c * g_pm)
-    SW = torch.einsum('nl,ni,nj->lij', ps['p'], ps['Ww'], ps['Ww'])
-    return A2 - 0.5 * g3 * SW, ud, td
+def gp_sw_rows(ps):
+    """svgp_big_factor_bwd, early part, row form (batch local to the rank): SW_l = W^T diag(p_l) W."""
+    return torch.einsum('nl,ni,nj->lij', ps['p'], ps['Ww'], ps['Ww'])
+
+
+def gp_sw_mspace(S, K, Ki):
+    """The same statistic from the (all-reduced) S_l: SW_l = P^T S_l P, P = Ki K -- the form under data parallelism (no
+    exchange of its own) and whenever b >= 3 m."""
+    P = Ki @ K
+    return P.T[None] @ S @ P[None]
 
 
 def gp_rows_local_w(Kn, ps, g_pv, gT, K, Ki):
@@ -294,8 +297,8 @@ def gp_rows_local_w(Kn, ps, g_pv, gT, K, Ki):
     return dict(Wbar=Wbar, Pbar=Pbar, Qs=Qs, qbar=qbar)
 
 
-def gp_factor_bwd_w(K, v, f, B2, ud, td, loc, gT, c, N_train, b_global, rep_weight=1.0):
-    """svgp_big_factor_bwd: the m x m reverse algebra on a channel window (f, B2, ud, td hold the window's channels).
+def gp_factor_bwd_w(K, v, f, A2, SW, ud, td, loc, gT, c, N_train, b_global, rep_weight=1.0):
+    """svgp_big_factor_bwd: the m x m reverse algebra on a channel window (f, A2, SW, ud, td hold the window's channels).
     Returns Kbar = rep_weight x (window part) + (rank-local part from `loc`), and per channel Ssym, vbar.
     No per-channel Kibar / Abar arrays: Abar_l = gK/2 (Ki - Aji_l) enters through Gbar' = K Ki - K Aji_l (the scalar is applied
     where the products are consumed), the Ki-gradient is formed for the channel SUM only."""
@@ -310,7 +313,7 @@ def gp_factor_bwd_w(K, v, f, B2, ud, td, loc, gT, c, N_train, b_global, rep_weig
     ubar = ud + 0.5 * gK * mu
     mubar = 0.5 * gK * u + ubar @ Ki.T
     tbar = td + c * (mubar @ K.T)
-    Sibar = 0.5 * gK * GbK + B2 + torch.einsum('li,lj->lij', tbar, v)
+    Sibar = 0.5 * gK * GbK + A2 - 0.5 * g3 * SW + torch.einsum('li,lj->lij', tbar, v)
     vbar = torch.einsum('lij,lj->li', Si, tbar)
     Sg = -(Si @ Sibar @ Si)
     Ssym = c * (Sg + Sg.transpose(1, 2))
@@ -353,8 +356,8 @@ def gp_block_manual_w(K, Kn, knn, y, s2, eps, zbar, gT, jitter, N_train, b_globa
     f = gp_factor_fwd(K, S, v, jitter, c)
     ps = gp_posterior_fwd_w(Kn, knn, y, s2, eps, f, c, K)
     g_pv, g_pm, mvbar = gp_posterior_bwd_weights(y, s2, eps, ps, zbar, gT, c)
-    B2, ud, td = gp_stats_bwd_w(Kn, ps, g_pv, mvbar, g_pm, gT, c)
+    A2, ud, td = gp_stats(Kn, g_pv, mvbar, c * g_pm)
     loc = gp_rows_local_w(Kn, ps, g_pv, gT, K, f['Ki'])
-    fb = gp_factor_bwd_w(K, v, f, B2, ud, td, loc, gT, c, N_train, bg)
+    fb = gp_factor_bwd_w(K, v, f, A2, gp_sw_rows(ps), ud, td, loc, gT, c, N_train, bg)
     Knbar, knnbar, ybar, s2bar = gp_posterior_bwd_rows_w(Kn, knn, y, s2, ps, f, fb, loc, g_pv, g_pm, mvbar, gT, c, K)
     return f, ps, fb, (fb['Kbar'], Knbar, knnbar, ybar, s2bar)

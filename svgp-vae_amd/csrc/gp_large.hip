@@ -8,9 +8,10 @@
 // is evaluated as w_n^T Si_l w_n with the channel-INDEPENDENT rows w_n = K Ki k_n, W = (Kn Ki) K (A_l = K Si_l K; Ki K is
 // not simplified to I).  Same algebra, but the per-channel m^3 products A Ki, Ki A Ki (forward), S Ki, Ki S Ki,
 // S Ki A (reverse) and the row product Kn M2_l are gone: 5 of the 13 full 800^3 x 64 products of the SPRITES step.  In
-// their place: [Kn; W] Si_l as ONE row product, the weighted statistic W^T diag(p_l) W joining the reverse statistic
-// (B2_l = Kn^T diag(g_pv_l) Kn - g3/2 W^T diag(p_l) W: one contraction over the stacked rows), and channel-independent
-// m x m matrices: P^T = K Ki, Pbar = Kn^T Wbar, Qs = Kn^T diag(qbar) Kn.  Row sums that enter the gradient of K_mm linearly
+// their place: [Kn; W] Si_l as ONE row product, the statistic SW_l = W^T diag(p_l) W = P^T S_l P beside the reverse statistic
+// (Sibar_l gets A2_l - g3/2 SW_l; formed early, from forward quantities: over the rows on one GPU when that is cheaper, from the
+// all-reduced S_l when the batch is sharded over ranks), and channel-independent m x m matrices: P^T = K Ki, Pbar = Kn^T Wbar,
+// Qs = Kn^T diag(qbar) Kn.  Row sums that enter the gradient of K_mm linearly
 // (Pbar, Qs) stay rank-local under data parallelism -- the ranks' shares of Kbar add up in the gradient all-reduce -- so
 // cfg.rep_weight is applied HERE to the replicated part of Kbar and the kernel-matrix reverse pass takes Kbar as it is.
 #include "common.hpp"
@@ -28,14 +29,13 @@ namespace {
 __device__ __forceinline__ real gradKL(int flags, int L, const real* state) { return svgp_seed_T(flags, L, state); }
 
 // ---- element-wise / reduction kernels ---------------------------------------------------------
-// weights of the statistics.  mode 0: w = 1/s2, a = y/s2.  mode 1: g_pv, g_pm, mvbar (stored), b = c g_pm, and the stacked
-// weights of the reverse statistic B2 over the rows [Kn; W]: wst[n][l] = g_pv, wst[b + n][l] = -g3/2 p.
+// weights of the statistics.  mode 0: w = 1/s2, a = y/s2.  mode 1: g_pv, g_pm, mvbar (stored), b = c g_pm.
 __global__ void k_big_weights(int n_el, int L, int mode, int geco, int clip_pv, real c, const real* __restrict__ state,
                               const real* __restrict__ y, const real* __restrict__ s2,
                               const real* __restrict__ p_m, const real* __restrict__ p_v,
                               const real* __restrict__ e, const real* __restrict__ eps,
                               const real* __restrict__ zbar, real* __restrict__ w, real* __restrict__ a,
-                              real* __restrict__ bv, real* __restrict__ wst) {
+                              real* __restrict__ bv) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_el) return;
     const real p = recip_no_nan(s2[i]);
@@ -48,8 +48,11 @@ __global__ void k_big_weights(int n_el, int L, int mode, int geco, int clip_pv, 
         const real gpm = gT * p * (p_m[i] - y[i]) + zb;
         const real g3 = svgp_seed_3(geco, gT);
         w[i] = gpv; bv[i] = gpm; a[i] = g3 * p * e[i];       // g_pv, g_pm, mvbar buffers
-        wst[i] = gpv; wst[(size_t)n_el + i] = real(-0.5) * g3 * p;
     }
+}
+__global__ void k_big_recip(int n_el, const real* __restrict__ s2, real* __restrict__ p) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_el) p[i] = recip_no_nan(s2[i]);
 }
 // qbar_n = sum_l (g3/2 p_nl - g_pv_nl): the weight of k_n k_n^T in the gradient of Ki (q_n = k^T Ki k inside d and p_v)
 __global__ void k_big_qbar(int b, int L, int geco, const real* __restrict__ state, const real* __restrict__ s2,
@@ -160,7 +163,8 @@ struct FbArgs {
     int m, L, Ltot, geco, b_global;      // L = channels of this call (loops), Ltot = channels of the model (loss seeds)
     real c, N_train;
     const real* state;
-    const real* A2;                      // B2_l = Kn^T diag(g_pv_l) Kn - g3/2 W^T diag(p_l) W (the reverse statistic; ws.A2)
+    const real* A2;                      // Kn^T diag(g_pv_l) Kn (the reverse statistic)
+    const real* SW;                      // W^T diag(p_l) W = P^T S_l P (NULL with cfg.titsias: its seed g3 is zero)
     const real* mu; const real* u; const real* ud; const real* td; const real* v;
     real* ubar; real* mubar; real* tbar;   // (L,m) each; mubar/tbar come in holding Ki ubar / K mubar
     real* Sibar; const real* Sg; real* Ssym;
@@ -183,14 +187,15 @@ __global__ void k_big_fb_tbar(FbArgs a) {     // tbar = td + c (K mubar)  (tbar 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.L * a.m) a.tbar[i] = a.td[i] + a.c * a.tbar[i];
 }
-// Sibar_l = gK/2 K (Ki - Aji_l) K + B2_l + tbar_l v_l^T, in place on the product K (Ki - Aji_l) K
+// Sibar_l = gK/2 K (Ki - Aji_l) K + A2_l - g3/2 SW_l + tbar_l v_l^T, in place on the product K (Ki - Aji_l) K
 __global__ void k_big_fb_sibar(FbArgs a) {
     real g3, gK; fb_scalars(a, g3, gK);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)a.m * a.m;
     if (i >= mm * a.L) return;
     const long long o = i % mm, l = i / mm;
     const int r = (int)(o / a.m), cidx = (int)(o % a.m);
-    a.Sibar[i] = real(0.5) * gK * a.Sibar[i] + a.A2[i] + a.tbar[l * a.m + r] * a.v[l * a.m + cidx];
+    a.Sibar[i] = real(0.5) * gK * a.Sibar[i] + a.A2[i] - (a.SW ? real(0.5) * g3 * a.SW[i] : real(0)) +
+                 a.tbar[l * a.m + r] * a.v[l * a.m + cidx];
 }
 // The kernel below needs X and X^T of a full (non-symmetric) product.  A workgroup owns the PAIR of 32 x 32 tiles (ti, tj),
 // (tj, ti), ti <= tj, of one channel: both tiles go through LDS, every global access is coalesced (the element-per-thread form
@@ -397,7 +402,7 @@ static BigScr big_scr(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, d
     s.vec0 = ws + wl.scr_vec; s.vec1 = s.vec0 + Lm; s.vec2 = s.vec1 + Lm; s.trm = s.vec2 + Lm; s.ldtmp = s.trm + 2 * c->L;
     s.qbar = s.ldtmp + c->L + 16;
     s.inv = ws + wl.scr_inv;
-    s.bl0 = ws + wl.scr_bl; s.bl1 = s.bl0 + bL; s.wst = s.bl0;      // wst (2b, L): alive inside the reverse statistics only
+    s.bl0 = ws + wl.scr_bl; s.bl1 = s.bl0 + bL; s.wst = s.bl0;      // p = 1 / s2 (b, L): weights of the early SW statistic
     real* sm = ws + wl.scr_sm;
     s.PT = sm; s.Pbar = sm + mm; s.Qs = sm + 2 * mm; s.Asum = sm + 3 * mm; s.Zs = sm + 4 * mm; s.Sgs = sm + 5 * mm;
     s.tA = sm + 6 * mm; s.tB = sm + 7 * mm; s.tC = sm + 8 * mm;
@@ -417,20 +422,14 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
     real* bbuf = ws + wl.g_pm;
     hipLaunchKernelGGL(k_big_weights, dim3(nblk((long long)b * L)), dim3(256), 0, st, b * L, L, mode, SVGP_LOSS_FLAGS(c), c->clip_pv, cc, state,
                        ws + wl.qnet_mu, ws + wl.qnet_var, ws + wl.p_m, ws + wl.p_v, ws + wl.e, ws + wl.eps,
-                       ws + wl.zbar, wbuf, abuf, bbuf, s.wst);
+                       ws + wl.zbar, wbuf, abuf, bbuf);
     SVGP_LAUNCH_CHECK();
     real* S = mode == 0 ? ws + wl.S : ws + wl.A2;
     real* v1 = mode == 0 ? ws + wl.v : ws + wl.ud;
     // S_l = Kn^T diag(w_l) Kn: the weights w[n][l] scale the rows of the B operand while they are staged (no (L, b, m) copy
     // of the scaled K_nm: config 3 saved a 15 us launch and 67 MB of traffic per statistics stage).
-    // Reverse: B2_l = Kn^T diag(g_pv_l) Kn - g3/2 W^T diag(p_l) W as ONE contraction over the 2 b stacked rows [Kn; W] (W sits
-    // behind the b rows of Kn) with the stacked weights wst.
-    if (mode == 0)
-        RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, b, 1.0, Kn, m, 0, Kn, m, 0, 0.0, S, m, (long long)m * m, L, stream, wbuf, L,
-                                       1));
-    else
-        RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, 2 * b, 1.0, Kn, m, 0, Kn, m, 0, 0.0, S, m, (long long)m * m, L, stream,
-                                       s.wst, L, 1));
+    RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, b, 1.0, Kn, m, 0, Kn, m, 0, 0.0, S, m, (long long)m * m, L, stream, wbuf, L,
+                                   1));
     // v1 (L x m) = a^T Kn: L x m outputs and a contraction over the batch -> split-K (8 tiles of 32 otherwise walk all b rows)
     const long long sk = svgp_dgemm_splitk_scratch_elems(L, m, b);
     SVGP_REQUIRE(sk >= 0 && sk <= (long long)c->L * m * m, SVGP_ERR_INVALID, "split-K scratch");
@@ -556,7 +555,7 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
 // Ki-gradient, Kbar) stays on the critical path.  Same operations on the same values either way.  Buffers: Gbar' in the first
 // half of fb_part (the forward tail's trace partials at its head are consumed before: the side stream runs tail and early
 // half in order), Z' in mm0, Gbar' K in mm3 (becomes Sibar), then Sigma^-1 Sibar in mm0 and Sg in mm1.
-// (part 3, the products that needed no (A_hat + jI)^-1 -- S Ki, Ki S Ki, S Ki A_hat -- no longer exists: the W form has none.)
+// Part 3 (needs no (A_hat + jI)^-1: can run beside the forward tail) is the statistic SW (see there).
 int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
                         void* stream, int l0, int nl, int part) {
     const int m = c->m, L = nl;
@@ -573,6 +572,23 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     a.v = ws + wl.v + ov;
     a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2; a.Sibar = s.mm3; a.Sg = s.mm1; a.Ssym = ws + wl.Ssym + om;
     const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m), ntp = (unsigned)((m + TP - 1) / TP);
+    // early half, first part (3): SW_l = W^T diag(p_l) W = P^T S_l P -- forward quantities only, not even (A_hat + jI)^-1, so it can
+    // run beside the forward tail.  Over the rows (a statistics product with contraction b) when the batch is local and that is
+    // the cheaper form (m^2 b against 3 m^3 per channel); from S_l otherwise -- under data parallelism S_l is the all-reduced
+    // statistic, so SW needs no exchange of its own.  mm2; T = S P in mm1 (free until the late half).
+    const bool has_sw = !c->titsias;
+    a.SW = has_sw ? s.mm2 : nullptr;
+    if (has_sw && (part == 0 || part == 1 || part == 3)) {
+        if (!c->single_stat_block && c->b < 3 * m) {
+            hipLaunchKernelGGL(k_big_recip, dim3(nblk((long long)c->b * c->L)), dim3(256), 0, st, c->b * c->L, ws + wl.qnet_var, s.wst);
+            SVGP_LAUNCH_CHECK();
+            RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, c->b, 1.0, s.W, m, 0, s.W, m, 0, 0.0, s.mm2, m, mm, L, stream,
+                                           s.wst + l0, c->L, 1));
+        } else {
+            GEMM(0, 1, m, m, m, 1.0, ws + wl.S + om, m, mm, s.PT, m, 0, 0.0, s.mm1, m, mm, L);        // T = S P   (P = (P^T)^T)
+            GEMM_SYM(0, 0, m, m, 1.0, s.PT, m, 0, s.mm1, m, mm, 0.0, s.mm2, m, mm, L);                // SW = P^T T
+        }
+    }
     if (part == 3) return SVGP_OK;
     if (part == 0 || part == 1 || part == 4) {
         svgp_gemm_epi ep;

@@ -101,9 +101,10 @@ class OracleBackend:
 
 
 class ShardedOracleBackend(OracleBackend):
-    """Stage contract of engine.ChannelShardedStep over the same oracle arithmetic: the m x m factor stages run on the
-    rank's channel window only.  (The oracle's row stage consumes A_l where the HIP kernels consume M2_l = Ki A_l Ki,
-    so A is what is all-gathered here; same schedule, same op kinds and sizes.)"""
+    """Stage contract of engine.ChannelShardedStep over the oracle's "W form" staging (oracle/staged_gp.py, gp_*_w = the
+    arithmetic of gp_large.hip): the m x m factor stages run on the rank's channel window only; Sigma^-1, t, u are
+    all-gathered (no M2 / A: the row stage evaluates k^T Ki A Ki k as w^T Si w); the statistic SW_l = P^T S_l P comes from
+    the reduce-scattered S_l, the row sums Pbar, Qs stay rank-local and reach the gradient through every rank's Kbar share."""
 
     def __init__(self, *a, world, packed=False, **kw):
         super().__init__(*a, **kw)
@@ -138,18 +139,17 @@ class ShardedOracleBackend(OracleBackend):
         l0, l1 = self._win()
         fw = SG.gp_factor_fwd(self.K, self.S[l0:l1], self.v[l0:l1], self.j, self.c)
         self.fw = fw
-        L, m = self.L, self.K.shape[0]
-        self.full = {k: torch.full((L,) + tuple(fw[k].shape[1:]), float("nan"), dtype=DT) for k in ("Si", "A", "t", "u", "KL")}
+        L = self.L
+        self.full = {k: torch.full((L,) + tuple(fw[k].shape[1:]), float("nan"), dtype=DT) for k in ("Si", "t", "u", "KL")}
         for k in self.full:
             self.full[k][l0:l1] = fw[k]
-        self._ops[1] = [("allgather", self.full["Si"].view(-1), False), ("allgather", self.full["A"].view(-1), True)] + \
-            [("allgather", self.full[k].view(-1)) for k in ("t", "u", "KL")]
+        self._ops[1] = [("allgather", self.full["Si"].view(-1), False)] + [("allgather", self.full[k].view(-1)) for k in ("t", "u")]
 
     def _stage2(self):
         f = dict(self.fw)
-        f.update({k: self.full[k] for k in ("Si", "A", "t", "u", "KL")})
+        f.update({k: self.full[k] for k in ("Si", "t", "u")})
         self.f = f
-        self.ps = SG.gp_posterior_fwd(self.Kn, self.knn, self.y, self.s2, self.eps, f, self.c)
+        self.ps = SG.gp_posterior_fwd_w(self.Kn, self.knn, self.y, self.s2, self.eps, f, self.c, self.K)
         z = self.ps["z"].clone().requires_grad_(True)
         recon = self.vae.decode(z)
         self.sq = torch.sum((self.images - recon) ** 2)
@@ -161,27 +161,29 @@ class ShardedOracleBackend(OracleBackend):
         self.gT = -1.0 if self.geco else -self.beta / self.L
         self.gw = SG.gp_posterior_bwd_weights(self.y, self.s2, self.eps, self.ps, self.zbar, self.gT, self.c)
         self.A2, self.ud, self.td = (t.contiguous() for t in SG.gp_stats(self.Kn, self.gw[0], self.gw[2], self.c * self.gw[1]))
+        self.loc = SG.gp_rows_local_w(self.Kn, self.ps, self.gw[0], self.gT, self.K, self.fw["Ki"])      # rank-local row sums
         self._ops[2] = [("reduce_scatter", self.A2.view(-1), False)] + [("reduce_scatter", t.view(-1)) for t in (self.ud, self.td)]
 
     def _stage3(self):
         l0, l1 = self._win()
-        fwin = dict(self.fw)                       # the window's own factors (G, Aji, mu are never exchanged)
-        fb = SG.gp_factor_bwd(self.K, self.S[l0:l1], self.v[l0:l1], fwin, self.A2[l0:l1], self.ud[l0:l1], self.td[l0:l1],
-                              self.gT, self.c, self.N, self.bg)
-        self.Kbar_share = fb["Kbar"]
+        fwin = dict(self.fw)                       # the window's own factors (G, A, Aji, mu are never exchanged)
+        SW = SG.gp_sw_mspace(self.S[l0:l1], self.K, self.fw["Ki"])          # from the reduce-scattered S: no exchange of its own
+        fb = SG.gp_factor_bwd_w(self.K, self.v[l0:l1], fwin, self.A2[l0:l1], SW, self.ud[l0:l1], self.td[l0:l1], self.loc,
+                                self.gT, self.c, self.N, self.bg)
+        self.Kbar_share = fb["Kbar"]               # window share + this rank's row-local share: every share counts
         L = self.L
-        self.fbfull = {k: torch.full((L,) + tuple(fb[k].shape[1:]), float("nan"), dtype=DT) for k in ("Q", "Ssym", "vbar")}
+        self.fbfull = {k: torch.full((L,) + tuple(fb[k].shape[1:]), float("nan"), dtype=DT) for k in ("Ssym", "vbar")}
         for k in self.fbfull:
             self.fbfull[k][l0:l1] = fb[k]
         self._ops[3] = [("allgather", self.fbfull["Ssym"].view(-1), False)] + \
-            [("allgather", self.fbfull[k].view(-1)) for k in ("Q", "vbar")]
+            [("allgather", self.fbfull["vbar"].view(-1)), ("allgather", self.full["KL"].view(-1))]
 
     def _stage4(self):
-        fb = dict(Q=self.fbfull["Q"], Ssym=self.fbfull["Ssym"], vbar=self.fbfull["vbar"], P=2.0 * self.full["Si"])
-        Knbar, knnbar, ybar, s2bar = SG.gp_posterior_bwd_rows(self.Kn, self.knn, self.y, self.s2, self.ps, self.f, fb,
-                                                              self.gw[0], self.gw[1], self.gw[2], self.gT, self.c)
+        fb = dict(Ssym=self.fbfull["Ssym"], vbar=self.fbfull["vbar"])
+        Knbar, knnbar, ybar, s2bar = SG.gp_posterior_bwd_rows_w(self.Kn, self.knn, self.y, self.s2, self.ps, self.f, fb, self.loc,
+                                                                self.gw[0], self.gw[1], self.gw[2], self.gT, self.c, self.K)
         p = self.p
-        # every rank's Kbar share counts (rep_weight = 1 everywhere): the kernel-matrix VJP is linear in Kbar
+        # every rank's Kbar share counts (the kernel-matrix VJP is linear in Kbar and takes it unweighted)
         d_ip, d_ls, d_amp, d_ov = SG.kernel_matrix_bwd(self.aux, p["inducing_index_points"].detach(),
                                                        p["object_vectors"].detach(), p["l_GP"].detach(),
                                                        p["amplitude"].detach(), self.Kbar_share, Knbar, knnbar)

@@ -94,7 +94,9 @@ def test_channel_sharded_dp_entry_equals_single_gpu_step_large_m(pack, monkeypat
     us = comm.timing_read()
     assert len(us) == 5 and all(0.0 < u < 1e5 for u in us), us
     comm.timing(False)
-    tol = 1e-12 if pack == "0" else 1e-8
+    # (round 4: the multi-rank workspace forms the statistic SW_l = P^T S_l P from the exchanged S_l, the single-GPU engine over its
+    # local rows W^T diag(p_l) W -- the same matrix to rounding, so the two runs agree to 1e-9 instead of bit for bit)
+    tol = 1e-8
     assert H.relerr(b_.theta, a.theta) < tol
     sa, sb = a.scalars(), b_.scalars()
     for k in ("elbo", "recon_loss", "kl_term", "c_ma", "lagrange", "adam_t"):

@@ -243,10 +243,12 @@ def test_staged_w_form_matches_autograd_and_the_lds_staging():
     fw = SG.gp_factor_fwd(K, S, v, j, c)
     pss = [SG.gp_posterior_fwd_w(Kn[s], knn[s], t["y"][s], t["s2"][s], t["eps"][s], fw, c, K) for s in parts]
     ws = [SG.gp_posterior_bwd_weights(t["y"][s], t["s2"][s], t["eps"][s], q, t["zbar"][s], gT, c) for s, q in zip(parts, pss)]
-    st = [SG.gp_stats_bwd_w(Kn[s], q, w[0], w[2], w[1], gT, c) for s, q, w in zip(parts, pss, ws)]
-    B2, ud, td = (sum(x[i] for x in st) for i in range(3))
+    st = [SG.gp_stats(Kn[s], w[0], w[2], c * w[1]) for s, w in zip(parts, ws)]
+    A2, ud, td = (sum(x[i] for x in st) for i in range(3))
+    SW = SG.gp_sw_mspace(S, K, fw["Ki"])                       # from the summed statistic: no exchange of its own
+    assert torch.allclose(SW, sum(SG.gp_sw_rows(q) for q in pss), rtol=1e-9, atol=1e-12)
     locs = [SG.gp_rows_local_w(Kn[s], q, w[0], gT, K, fw["Ki"]) for s, q, w in zip(parts, pss, ws)]
-    fbs = [SG.gp_factor_bwd_w(K, v, fw, B2, ud, td, loc, gT, c, N, 48.0, rep_weight=1.0 if r == 0 else 0.0)
+    fbs = [SG.gp_factor_bwd_w(K, v, fw, A2, SW, ud, td, loc, gT, c, N, 48.0, rep_weight=1.0 if r == 0 else 0.0)
            for r, loc in enumerate(locs)]
     Kbar = sum(x["Kbar"] for x in fbs)
     assert float((sym(Kbar) - sym(man[0])).abs().max() / sym(man[0]).abs().max()) < 1e-10
@@ -259,11 +261,13 @@ def test_staged_w_form_matches_autograd_and_the_lds_staging():
     loc_all = SG.gp_rows_local_w(Kn, ps, SG.gp_posterior_bwd_weights(t["y"], t["s2"], t["eps"], ps, t["zbar"], gT, N / 48.0)[0],
                                  gT, K, f["Ki"])
     zero = {k: torch.zeros_like(x) for k, x in loc_all.items()}
-    B2f, udf, tdf = SG.gp_stats_bwd_w(Kn, ps, *[SG.gp_posterior_bwd_weights(t["y"], t["s2"], t["eps"], ps, t["zbar"], gT, c)[i]
-                                              for i in (0, 2, 1)], gT, c)
+    gw = SG.gp_posterior_bwd_weights(t["y"], t["s2"], t["eps"], ps, t["zbar"], gT, c)
+    B2f, udf, tdf = SG.gp_stats(Kn, gw[0], gw[2], c * gw[1])
+    SWf = SG.gp_sw_rows(ps)
     Kb = 0
     for w0 in range(0, L, 2):
         sl = slice(w0, min(w0 + 2, L))
         fwin = {k: (x[sl] if (torch.is_tensor(x) and x.ndim >= 1 and x.shape[0] == L and k not in ("Ki",)) else x) for k, x in f.items()}
-        Kb = Kb + SG.gp_factor_bwd_w(K, v[sl], fwin, B2f[sl], udf[sl], tdf[sl], loc_all if w0 == 0 else zero, gT, c, N, 48.0)["Kbar"]
+        Kb = Kb + SG.gp_factor_bwd_w(K, v[sl], fwin, B2f[sl], SWf[sl], udf[sl], tdf[sl], loc_all if w0 == 0 else zero, gT, c, N,
+                                     48.0)["Kbar"]
     assert float((sym(Kb) - sym(man[0])).abs().max() / sym(man[0]).abs().max()) < 1e-10

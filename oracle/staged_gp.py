@@ -313,7 +313,10 @@ def gp_factor_bwd_w(K, v, f, A2, SW, ud, td, loc, gT, c, N_train, b_global, rep_
     ubar = ud + 0.5 * gK * mu
     mubar = 0.5 * gK * u + ubar @ Ki.T
     tbar = td + c * (mubar @ K.T)
-    Sibar = 0.5 * gK * GbK + A2 - 0.5 * g3 * SW + torch.einsum('li,lj->lij', tbar, v)
+    # (the gradient of t = Si v is the rank-one tbar v^T; only the symmetric part of Sg is ever used -- Ssym below, Kbar + Kbar^T in
+    # the kernel-matrix reverse pass -- so Sibar is symmetrised and Sg is a symmetric product: gp_large.hip k_big_fb_sibar)
+    tv = torch.einsum('li,lj->lij', tbar, v)
+    Sibar = 0.5 * gK * GbK + A2 - 0.5 * g3 * SW + 0.5 * (tv + tv.transpose(1, 2))
     vbar = torch.einsum('lij,lj->li', Si, tbar)
     Sg = -(Si @ Sibar @ Si)
     Ssym = c * (Sg + Sg.transpose(1, 2))

@@ -187,7 +187,10 @@ __global__ void k_big_fb_tbar(FbArgs a) {     // tbar = td + c (K mubar)  (tbar 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.L * a.m) a.tbar[i] = a.td[i] + a.c * a.tbar[i];
 }
-// Sibar_l = gK/2 K (Ki - Aji_l) K + A2_l - g3/2 SW_l + tbar_l v_l^T, in place on the product K (Ki - Aji_l) K
+// Sibar_l = gK/2 K (Ki - Aji_l) K + A2_l - g3/2 SW_l + (tbar_l v_l^T + v_l tbar_l^T) / 2, in place on the product K (Ki - Aji_l) K.
+// The gradient of t = Si v is the rank-one tbar v^T; only the symmetric part of Sg = -Si Sibar Si is ever used (Ssym = c (Sg +
+// Sg^T) in the row stage, Sg + Sg^T in the kernel-matrix reverse pass, which reads Kbar_ij + Kbar_ji), so Sibar is symmetrised
+// here (Sg is then symmetric up to rounding and Ssym = c (Sg + Sg^T) removes the antisymmetric residue exactly).
 __global__ void k_big_fb_sibar(FbArgs a) {
     real g3, gK; fb_scalars(a, g3, gK);
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)a.m * a.m;
@@ -195,7 +198,7 @@ __global__ void k_big_fb_sibar(FbArgs a) {
     const long long o = i % mm, l = i / mm;
     const int r = (int)(o / a.m), cidx = (int)(o % a.m);
     a.Sibar[i] = real(0.5) * gK * a.Sibar[i] + a.A2[i] - (a.SW ? real(0.5) * g3 * a.SW[i] : real(0)) +
-                 a.tbar[l * a.m + r] * a.v[l * a.m + cidx];
+                 real(0.5) * (a.tbar[l * a.m + r] * a.v[l * a.m + cidx] + a.tbar[l * a.m + cidx] * a.v[l * a.m + r]);
 }
 // The kernel below needs X and X^T of a full (non-symmetric) product.  A workgroup owns the PAIR of 32 x 32 tiles (ti, tj),
 // (tj, ti), ti <= tj, of one channel: both tiles go through LDS, every global access is coalesced (the element-per-thread form
@@ -242,13 +245,13 @@ __global__ __launch_bounds__(256) void k_big_fb_ssym(FbArgs a) {
         }
     }
 }
-// out (m x m) = sum over the L channel matrices
-__global__ void k_big_sum_channels(int mm, int L, const real* __restrict__ in, real* __restrict__ out) {
+// out (m x m) = scale * sum over the L channel matrices
+__global__ void k_big_sum_channels(int mm, int L, real scale, const real* __restrict__ in, real* __restrict__ out) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= mm) return;
     real s = 0;
     for (int l = 0; l < L; ++l) s += in[(size_t)l * mm + o];
-    out[o] = s;
+    out[o] = scale * s;
 }
 // The gradient of Ki, channel sum: Kib = rep_weight (gK/2 sum_l A_l + sum_l ubar_l mu_l^T) + Qs + Pbar K
 //   (tr(Ki A) and mu^T Ki mu of the KL term: window part; q_n = k^T Ki k in d and p_v and P = Ki K: rank-local row sums)
@@ -491,7 +494,11 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     }
     GEMV(1.0, Si, mm, v, t, L);                                                                  // t = Si v
     GEMM(0, 1, m, m, m, 1.0, Si, m, mm, K, m, 0, 0.0, G, m, mm, L);                              // G = Si K   (K = K^T read as [j][k])
-    GEMM_SYM(0, 0, m, m, 1.0, K, m, 0, G, m, mm, 0.0, A, m, mm, L);                              // A = K G = K Si K
+    {   // A = K G = K Si K, and A + jI beside it (the input of the tail's inverse: was a pass over (L, m, m))
+        svgp_gemm_epi ep;
+        ep.C2 = Aji; ep.sc2 = mm; ep.a2 = 1.0; ep.d2 = c->jitter;
+        RUNC(svgp_dgemm_symout_batched(c->gemm_f32 == 1, 0, 0, m, m, 1.0, K, m, 0, G, m, mm, 0.0, A, m, mm, L, stream, nullptr, 0, 0, &ep));
+    }
     GEMV(cc, K, 0, t, mu, L);                                                                    // mu = c K t
     GEMV(1.0, Ki, 0, mu, u, L);                                                                  // u = Ki mu
     hipLaunchKernelGGL(k_big_kl_terms, dim3(KL_NCH, L), dim3(256), 0, st, m, Ki, A, mu, u, klp);
@@ -505,9 +512,7 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     GEMM(0, 1, m, m, m, 1.0, K, m, 0, Ki, m, 0, 0.0, s.PT, m, 0, 1);
     if (part == 1) return SVGP_OK;
 aji_tail:
-    hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, real(0), c->jitter, A,
-                       (const real*)nullptr, mm, Aji);
-    SVGP_LAUNCH_CHECK();
+    // (Aji holds A_hat + jI: written by the product A = K G above; the tail inverts it in place)
     RUNC(svgp_spd_inverse_batched(m, L, Aji, s.ldtmp, s.inv, stream));
     hipLaunchKernelGGL(k_big_kl, dim3(nblk(L)), dim3(256), 0, st, m, L, ws + wl.ldK, s.ldtmp, klp, ws + wl.KL + l0);
     SVGP_LAUNCH_CHECK();
@@ -554,7 +559,7 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
 // tail, under the row stage, the networks and the reverse statistics; the late half (ubar ... Sigma^-1 Sibar Sigma^-1, the
 // Ki-gradient, Kbar) stays on the critical path.  Same operations on the same values either way.  Buffers: Gbar' in the first
 // half of fb_part (the forward tail's trace partials at its head are consumed before: the side stream runs tail and early
-// half in order), Z' in mm0, Gbar' K in mm3 (becomes Sibar), then Sigma^-1 Sibar in mm0 and Sg in mm1.
+// half in order), Z' in mm0, Gbar' K in mm3 (becomes Sibar), then Sigma^-1 Sibar in mm0 and Sg in mm1; SW in mm2 (its m-space form: T in mm1, early).
 // Part 3 (needs no (A_hat + jI)^-1: can run beside the forward tail) is the statistic SW (see there).
 int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
                         void* stream, int l0, int nl, int part) {
@@ -596,9 +601,9 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
         RUNC(svgp_dgemm_epi_batched(c->gemm_f32 == 1, 0, 1, m, m, m, -1.0, K, m, 0, Aji, m, mm, 0.0, Gb, m, mm, L, stream, &ep));   // Gbar' = P^T - K Aji
         GEMM(0, 0, m, m, m, 1.0, Si, m, mm, Gb, m, mm, 0.0, s.mm0, m, mm, L);          // Z' = Si Gbar'
         GEMM_SYM(0, 1, m, m, 1.0, Gb, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);           // Gbar' K = K (Ki - Aji) K  (mm3)
-        hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, s.mm0, s.Zs);
+        hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, real(1), s.mm0, s.Zs);
         SVGP_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, A, s.Asum);
+        hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, real(1), A, s.Asum);
         SVGP_LAUNCH_CHECK();
     }
     if (part == 1 || part == 4) return SVGP_OK;
@@ -614,10 +619,15 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     SVGP_LAUNCH_CHECK();
     GEMV(1.0, Si, mm, s.vec2, ws + wl.vbar + ov, L);                                   // vbar = Si tbar
     GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm3, m, mm, 0.0, s.mm0, m, mm, L);           // Si Sibar (mm0: Z' is summed)
-    GEMM(0, 1, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);          // Sg = -Si Sibar Si (mm1)
+    // Sg = -(Si Sibar) Si: a FULL product, not lower-triangle-and-mirror -- like the Ki sandwiches of round 2, the mirrored form of this
+    // Sigma^-1 sandwich loses the benign structure of its rounding error: config 3 (jitter 1e-6) had the encoder dense-layer gradient
+    // off by 1e-3 against 1e-9 (measured, round 4).  Ssym = c (Sg + Sg^T) is then formed exactly symmetric by the tile-pair kernel:
+    // writing 2 c Sg straight from the product keeps an antisymmetric rounding residue that the inducing-point gradients see at
+    // 2e-5 (virtual-rank test, m = 256), so the 0.1 ms pass stays.
+    GEMM(0, 1, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);          // Sg (mm1)
     hipLaunchKernelGGL(k_big_fb_ssym, dim3(ntp, ntp, L), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, s.mm1, s.Sgs);
+    hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, real(1), s.mm1, s.Sgs);
     SVGP_LAUNCH_CHECK();
     // The gradient of Ki is needed for the channel sum only (Ki is shared): Kib = rep_weight (gK/2 sum A + sum ubar mu^T) + Qs + Pbar K,
     // then Ki Kib Ki once.  Pbar, Qs: this rank's row sums from svgp_big_stats (mode 1).

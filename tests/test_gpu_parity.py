@@ -60,6 +60,15 @@ def _compare_step(params, images, aux, eps, *, geco, clip_qs=True, N_train=4050.
                                beta=beta, K_obj_normalize=K_obj_normalize)
         fwd_tol = {name: max(FWD_TOL, 20 * H.relerr(ref2[name], ref[name])) for name in fwd_tol}
     for name, shp in FIELD_SHAPES(b, m, L).items():
+        if name == "M2" and m > 64:
+            # the large-m path evaluates k^T M2 k as w^T Si w and does not form M2 = Ki A Ki (gp_large.hip, "W form"): its
+            # channel-independent rows W = Kn Ki K sit behind the b rows of K_nm and are compared instead
+            W = eng.ws[eng.wl.Kn + b * m:eng.wl.Kn + 2 * b * m].view(b, m)
+            want = ref["Kn"] @ ref["Ki"] @ ref["K"]
+            err = H.relerr(W, want)
+            if not err < fwd_tol["M2"]:
+                bad.append(f"{label} fwd W: rel {err:.3e} (tol {fwd_tol['M2']:.1e})")
+            continue
         err = H.relerr(eng.ws_view(name, shp), ref[name])
         if not err < fwd_tol[name]:
             bad.append(f"{label} fwd {name}: rel {err:.3e} (tol {fwd_tol[name]:.1e})")

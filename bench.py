@@ -431,9 +431,11 @@ def run_mnist(args):
     eng = MnistStepEngine(M_IND, L, MDIM, N_OBJ, N_train=N_TRAIN, jitter=1e-6, clip_qs=True, geco=True,
                           kappa_squared=0.020, alpha=0.99, beta=0.001, lr=1e-3, b_max=B, device=str(dev),
                           rank=rank, world_size=world,
-                          # --force-comm on one GPU: the kernel configuration of a multi-rank step (one statistics block per
-                          # channel) + a 1-rank communicator, i.e. everything of the N > 1 step but the wire
-                          single_stat_block=True if args.force_comm else None)
+                          # --force-comm on one GPU: the kernel configuration of a multi-rank step (m > 64: the multi-rank
+                          # workspace; m <= 64: row partials kept and exchanged, as the engine's multi-rank default) + a 1-rank
+                          # communicator, i.e. everything of the N > 1 step but the wire
+                          single_stat_block=((M_IND > 64 or os.environ.get("SVGP_DP_STAT_PARTIALS") == "0")
+                                             if args.force_comm else None))
     eng.load_params(params)
     d_img, d_aux, d_eps = (torch.tensor(x, dtype=torch.float64, device=dev).contiguous() for x in (images, aux, eps))
 
@@ -559,7 +561,7 @@ def run_mnist(args):
         line["stages_us"] = {r["stage"]: round(r["us"], 2) for r in stage_rows}
         line["step_flops"] = step_flops
         if coll_us is not None:
-            names = (["rs[S|v]", "ag[Si|M2|t|u]", "rs[A2|ud|td]", "ag[Ssym|vbar|KL]", "ar[grad|sums]"] if len(coll_us) == 5
+            names = (["rs[S|v]", "ag[Si|t|u]", "rs[A2|ud|td]", "ag[Ssym|vbar|KL]", "ar[grad|sums]"] if len(coll_us) == 5
                      else ["ar[S|v]", "ar[A2|ud|td]", "ar[grad|sums]"])
             line["collectives_us"] = dict(zip(names, coll_us))
             line["collectives_us_total"] = round(sum(coll_us), 1)
@@ -721,7 +723,7 @@ def run_sprites(args):
                                "note": "sum of the four network stage groups; in_step = wall time between stage events while the "
                                        "side branches' GEMMs share the chip, one_stream = the same launches with nothing beside them"}
         if coll_us is not None:
-            names = (["rs[S|v]", "ag[Si|M2|t|u]", "rs[A2|ud|td]", "ag[Ssym|vbar|KL]", "ar[grad|sums]"] if len(coll_us) == 5
+            names = (["rs[S|v]", "ag[Si|t|u]", "rs[A2|ud|td]", "ag[Ssym|vbar|KL]", "ar[grad|sums]"] if len(coll_us) == 5
                      else ["ar[S|v]", "ar[A2|ud|td]", "ar[grad|sums]"])
             line["collectives_us"] = dict(zip(names, coll_us))
             line["collectives_us_total"] = round(sum(coll_us), 1)

@@ -72,8 +72,10 @@ typedef struct {
                            /* has A_hat where mu_hat is meant and reduces over the whole batch of videos (= the L      */
                            /* channels here): KL_l = 1/2 [.. + L tr(K_mm^-1 A_l A_l)], same sum over l as the          */
                            /* reference; the KL field is then [KL (L) | tr(K_mm^-1 A_l A_l) (L)]                       */
-    int32_t single_stat_block; /* 1: the statistics launches write ONE block per channel instead of row partials (set by  */
-                           /* the engines when the batch is sharded over ranks: the blocks are then all-reduced)      */
+    int32_t single_stat_block; /* m <= 64: 1 = the statistics launches write ONE block per channel instead of 4 row      */
+                           /* partials (optional under data parallelism: by default the partial blocks are exchanged  */
+                           /* as one message).  m > 64: 1 = the batch is sharded over ranks: the workspace carries    */
+                           /* the wire buffer of the packed exchange (xpack)                                          */
     int32_t gemm_f32;      /* large-m path (m > 64) only.  1: every product of the GP block runs on the float32 MFMA  */
                            /* (svgp_dgemm_f32c_batched: float64 storage, float32 products and sums) -- the arithmetic */
                            /* of the reference's float32 SPRITES graph (SVGPVAE_model.py:516); 2: only the statistics */
@@ -649,6 +651,13 @@ int svgp_scale_by_device_scalar(long long n, const double* f, double* x, void* s
 
 /* ---- runtime helpers: HIP graphs and events without going through torch ---------------------*/
 int svgp_stream_create(void** stream_out);
+/* HIP maps streams onto a small pool of hardware queues (GPU_MAX_HW_QUEUES) in creation order; two streams on one queue run
+ * one after the other whatever the events say.  svgp_streams_overlap: *out = 1 iff a kernel on b runs BESIDE a kernel on a
+ * (a ~40 us spin on a, an empty kernel on b; synchronises both).  svgp_side_streams_prepare: creates the library's two side
+ * branches of `stream` now -- picked with that probe from up to 12 candidates -- instead of at the first step (which may
+ * be under stream capture, where the probe cannot run).  SVGP_STREAM_PROBE=0 disables the probe.                          */
+int svgp_streams_overlap(void* a, void* b, int* out);
+int svgp_side_streams_prepare(void* stream);
 int svgp_stream_destroy(void* stream);
 int svgp_stream_sync(void* stream);
 int svgp_graph_begin(void* stream);                       /* hipStreamBeginCapture               */

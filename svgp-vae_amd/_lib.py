@@ -176,6 +176,8 @@ SIGNATURES = {
     "svgp_enc_head_bwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "svgp_softmax_xent": [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P],
     "svgp_bias_add": [C.c_longlong, C.c_int, _P, _P, _P],
+    "svgp_streams_overlap": [_P, _P, C.POINTER(C.c_int)],
+    "svgp_side_streams_prepare": [_P],
     "svgp_gauss_cross_entropy": [C.c_longlong, _P, _P, _P, _P, _P, _P],
     "svgp_sqerr_fwd": [C.c_longlong, C.c_int, _P, _P, _P, _P],
     "svgp_sqerr_bwd": [C.c_longlong, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],

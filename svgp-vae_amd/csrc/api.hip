@@ -168,6 +168,40 @@ struct Side {
 std::mutex g_side_mu;
 std::map<std::pair<int, hipStream_t>, Side*> g_side;
 
+// ---- do two streams run concurrently?  HIP maps streams onto a small pool of hardware queues (GPU_MAX_HW_QUEUES, 4 by default)
+// in creation order; two streams that share a queue execute one after the other whatever events say.  Which streams collide
+// depends on every stream the process has created so far -- torch's, RCCL's, ours: measured round 4, config 3 with a 1-rank RCCL
+// communicator: the library's side branch shared the caller's queue and hid NOTHING (1.454 ms against 1.313 ms with 8 queues), while
+// the SPRITES step lost 5 ms with 8 queues for the same reason in the other direction.  So the side streams are chosen by a
+// probe instead of by luck: a ~40 us single-workgroup spin on stream a, an empty kernel on stream b issued right behind it; b
+// runs beside a iff its kernel finishes well before the spin does.
+__global__ void k_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void k_noop() {}
+int streams_overlap(hipStream_t a, hipStream_t b, bool* out) {
+    hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+    SVGP_CHECK_HIP(hipEventCreate(&e0)); SVGP_CHECK_HIP(hipEventCreate(&ea)); SVGP_CHECK_HIP(hipEventCreate(&eb));
+    int votes = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        SVGP_CHECK_HIP(hipStreamSynchronize(a)); SVGP_CHECK_HIP(hipStreamSynchronize(b));
+        SVGP_CHECK_HIP(hipEventRecord(e0, a));
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, 4000LL);        // 100 MHz wall clock: 40 us
+        SVGP_CHECK_HIP(hipEventRecord(ea, a));
+        hipLaunchKernelGGL(k_noop, dim3(1), dim3(64), 0, b);
+        SVGP_CHECK_HIP(hipEventRecord(eb, b));
+        SVGP_CHECK_HIP(hipEventSynchronize(ea)); SVGP_CHECK_HIP(hipEventSynchronize(eb));
+        float ta = 0, tb = 0;
+        SVGP_CHECK_HIP(hipEventElapsedTime(&ta, e0, ea));
+        SVGP_CHECK_HIP(hipEventElapsedTime(&tb, e0, eb));
+        if (tb < 0.6f * ta) ++votes;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+    *out = votes >= 2;
+    return SVGP_OK;
+}
+
 int side_get(hipStream_t main, Side** out) {
     int dev = 0;
     SVGP_CHECK_HIP(hipGetDevice(&dev));
@@ -176,10 +210,32 @@ int side_get(hipStream_t main, Side** out) {
     auto it = g_side.find(key);
     if (it == g_side.end()) {
         Side* sd = new Side();
-        for (int k = 0; k < 2; ++k) {
-            SVGP_CHECK_HIP(hipStreamCreateWithFlags(&sd->s[k], hipStreamNonBlocking));
-            SVGP_CHECK_HIP(hipEventCreateWithFlags(&sd->done[k], hipEventDisableTiming));
+        // Two side streams that run concurrently with the caller's stream AND with each other, picked from up to 12 candidates by
+        // the probe above.  Not under stream capture (the probe synchronises) and not with SVGP_STREAM_PROBE=0: then the first two.
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(main, &cap);
+        const char* ev = getenv("SVGP_STREAM_PROBE");
+        const bool probe = cap == hipStreamCaptureStatusNone && !(ev && ev[0] == '0');
+        hipStream_t cand[12];
+        int n_cand = 0, picked = 0;
+        while (picked < 2 && n_cand < (probe ? 12 : 2)) {
+            hipStream_t c = nullptr;
+            SVGP_CHECK_HIP(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+            cand[n_cand++] = c;
+            bool ok = true;
+            if (probe) {
+                int rc = streams_overlap(main, c, &ok);
+                if (rc) return rc;
+                if (ok && picked == 1) { rc = streams_overlap(sd->s[0], c, &ok); if (rc) return rc; }
+            }
+            if (ok) sd->s[picked++] = c;
         }
+        for (int i = 0; i < n_cand; ++i) {           // candidates that collide with the caller's stream (or with each other) go back
+            if (cand[i] == sd->s[0] || cand[i] == sd->s[1]) continue;
+            if (picked < 2) sd->s[picked++] = cand[i];                      // fewer than two concurrent queues exist: take what there is
+            else (void)hipStreamDestroy(cand[i]);
+        }
+        for (int k = 0; k < 2; ++k) SVGP_CHECK_HIP(hipEventCreateWithFlags(&sd->done[k], hipEventDisableTiming));
         SVGP_CHECK_HIP(hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming));
         it = g_side.emplace(key, sd).first;
     }
@@ -353,6 +409,19 @@ extern "C" int svgp_mnist_train_step(const svgp_mnist_cfg* c, double* theta, con
 // ---------------------------------------------------------------------------------------------
 // runtime helpers
 // ---------------------------------------------------------------------------------------------
+// Creates the library's side branches of `stream` now (outside any stream capture), with the concurrency probe; and the probe
+// itself for callers that own their side streams (sprites.py).
+extern "C" int svgp_side_streams_prepare(void* stream) {
+    Side* sd = nullptr;
+    return side_get((hipStream_t)stream, &sd);
+}
+extern "C" int svgp_streams_overlap(void* a, void* b, int* out) {
+    SVGP_REQUIRE(out, SVGP_ERR_INVALID, "out is NULL");
+    bool ok = false;
+    int rc = streams_overlap((hipStream_t)a, (hipStream_t)b, &ok);
+    *out = ok ? 1 : 0;
+    return rc;
+}
 extern "C" int svgp_stream_create(void** out) {
     SVGP_REQUIRE(out, SVGP_ERR_INVALID, "out is NULL");
     hipStream_t s;

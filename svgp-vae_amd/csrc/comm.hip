@@ -303,7 +303,7 @@ extern "C" int svgp_comm_timing_read(void* comm, float* us, int cap, int* n) {
 //  -- the (L,m,m) statistics are reduce-SCATTERED over the channels, every rank factors its L / G channels
 // (svgp_gp_factor_*_channels) and what the row stages need is all-gathered:
 //   encoder + kernel matrices + statistics | reduce-scatter S, v | window factor stage | all-gather Sigma^-1, t, u |
-//   row stage, decoder fwd + bwd, backward statistics | reduce-scatter B2, ud, td | window reverse factor stage |
+//   row stage, decoder fwd + bwd, backward statistics | reduce-scatter A2, ud, td | window reverse factor stage |
 //   all-gather Ssym, vbar, KL (round 4: M2 = Ki A Ki is neither formed nor exchanged, gp_large.hip "W form") |
 //   row gradients, kernel-matrix VJP (every rank's Kbar share counts), encoder reverse pass,
 //   gradient reduction | all-reduce gradC | phase 3
@@ -398,27 +398,30 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     // (Sigma^-1 is exactly symmetric in memory: its lower tiles ARE the matrix and the owner keeps its own window as it is)
     if (pack) RUN(svgp_sym_pack(m, nl, 0, ws + wl.Si + (size_t)l0 * mm, xp0 + (size_t)l0 * pe, stream));
     // the tail ((A_hat + jI)^-1, log det, KL) and the early half of the reverse factor stage: on the side branch, beside the
-    // all-gather, the row stage, the networks and the reverse statistics
+    // all-gather, the row stage, the networks and the reverse statistics.  The branch is forked here (it depends on the window
+    // stage only) but its launches are ISSUED behind the collective: enqueued first, the branch's GEMMs fill every CU and the
+    // collective's kernel waits for a slot -- with a 1-rank communicator the point measured 245 us at config 3 for a no-op
+    // gather (round 3: 260 us), and the row stage on the caller's stream waits behind it.
     void* side = stream;
     if (fork) RUN(svgp_side_branch_fork(stream, &side));
-    RUN(svgp_big_factor_fwd(&cc, wl, ws, side, l0, nl, 2));
-    if (fork) RUN(svgp_big_factor_bwd(&cc, wl, ws, state, side, l0, nl, 1));
     RUN(svgp_comm_group_begin(comm));
     RUN(ag_sym(ws + wl.Si, xp0));
     RUN(ag(comm, ws + wl.t, Lm, G, stream));
     RUN(ag(comm, ws + wl.u, Lm, G, stream));
     RUN(svgp_comm_group_end(comm));
-    if (pack) {                                  // the other ranks' windows
+    if (pack) {                                  // the other ranks' windows (the branch reads the rank's own window only)
         const int hi0 = l0 + nl, nhi = L - hi0;
         RUN(svgp_sym_unpack(m, l0, xp0, ws + wl.Si, stream));
         RUN(svgp_sym_unpack(m, nhi, xp0 + (size_t)hi0 * pe, ws + wl.Si + (size_t)hi0 * mm, stream));
     }
     RUN(pt.end());
+    RUN(svgp_big_factor_fwd(&cc, wl, ws, side, l0, nl, 2));
+    if (fork) RUN(svgp_big_factor_bwd(&cc, wl, ws, state, side, l0, nl, 1));
     RUN(svgp_gp_posterior_fwd(&cc, eps, ws, state, stream));
     RUN(svgp_mnist_decoder_fwd(&cc, theta, images, ws, stream));
     RUN(svgp_mnist_decoder_bwd(&cc, theta, images, ws, state, stream));
     RUN(svgp_gp_stats_bwd(&cc, ws, state, stream));
-    // ---- point 3: reduce-scatter [B2 | ud | td]   (B2 = A2 - g3/2 W^T diag(p) W in the A2 field)
+    // ---- point 3: reduce-scatter [A2 | ud | td]
     RUN(pt.begin());
     if (pack) RUN(svgp_sym_pack(m, L, 0, ws + wl.A2, xp0, stream));
     RUN(svgp_comm_group_begin(comm));

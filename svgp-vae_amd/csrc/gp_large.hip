@@ -578,13 +578,14 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2; a.Sibar = s.mm3; a.Sg = s.mm1; a.Ssym = ws + wl.Ssym + om;
     const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m), ntp = (unsigned)((m + TP - 1) / TP);
     // early half, first part (3): SW_l = W^T diag(p_l) W = P^T S_l P -- forward quantities only, not even (A_hat + jI)^-1, so it can
-    // run beside the forward tail.  Over the rows (a statistics product with contraction b) when the batch is local and that is
-    // the cheaper form (m^2 b against 3 m^3 per channel); from S_l otherwise -- under data parallelism S_l is the all-reduced
-    // statistic, so SW needs no exchange of its own.  mm2; T = S P in mm1 (free until the late half).
+    // run beside the forward tail.  Over the rows (a statistics product with contraction b) when ALL rows of the batch are local
+    // (b == b_global) and that is the cheaper form (m^2 b against 3 m^3 per channel); from S_l otherwise -- under data
+    // parallelism S_l is the all-reduced statistic, so SW needs no exchange of its own (3 m^3 L / G flops per rank on the
+    // window).  mm2; T = S P in mm1 (free until the late half).
     const bool has_sw = !c->titsias;
     a.SW = has_sw ? s.mm2 : nullptr;
     if (has_sw && (part == 0 || part == 1 || part == 3)) {
-        if (!c->single_stat_block && c->b < 3 * m) {
+        if (c->b == c->b_global && c->b < 3 * m) {
             hipLaunchKernelGGL(k_big_recip, dim3(nblk((long long)c->b * c->L)), dim3(256), 0, st, c->b * c->L, ws + wl.qnet_var, s.wst);
             SVGP_LAUNCH_CHECK();
             RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, c->b, 1.0, s.W, m, 0, s.W, m, 0, 0.0, s.mm2, m, mm, L, stream,

@@ -300,6 +300,35 @@ class RcclComm:
             self.handle = C.c_void_p()
 
 
+def concurrent_streams(main, n, device):
+    """n torch streams that run BESIDE `main` and beside each other.  HIP maps streams onto a small pool of hardware queues in
+    creation order, and two streams on one queue execute one after the other whatever the events say (include/svgpvae_hip.h:
+    svgp_streams_overlap; measured round 4: a side stream that shares the caller's queue hides nothing).  Candidates come from
+    torch's stream pool and are probed with the library's spin / no-op test; if fewer than n concurrent ones exist, the first
+    candidates fill up.  SVGP_STREAM_PROBE=0: the first n candidates."""
+    probe = os.environ.get("SVGP_STREAM_PROBE", "1")[0] != "0"
+    flag = C.c_int(0)
+
+    def overlap(a, b):
+        call("svgp_streams_overlap", a.cuda_stream, b.cuda_stream, C.byref(flag))
+        return bool(flag.value)
+
+    cands, picked = [], []
+    for _ in range(12 if probe else n):
+        s = torch.cuda.Stream(device=device)
+        if any(s.cuda_stream == c.cuda_stream for c in cands) or s.cuda_stream == main.cuda_stream:
+            continue
+        cands.append(s)
+        if not probe or (overlap(main, s) and all(overlap(p, s) for p in picked)):
+            picked.append(s)
+        if len(picked) == n:
+            break
+    for s in cands:
+        if len(picked) < n and s not in picked:
+            picked.append(s)
+    return picked
+
+
 class MnistStepEngine:
     """One rank's HIP execution state for the rotated-MNIST SVGPVAE_Hensman step."""
 
@@ -317,10 +346,16 @@ class MnistStepEngine:
                          geco=int(geco), titsias=int(titsias), train_ip=int(train_ip), train_gp=int(train_gp), train_ov=int(train_ov),
                          N_train=float(N_train), jitter=float(jitter), kappa_squared=float(kappa_squared),
                          alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0,
-                         # sharded over ranks: the statistics blocks are all-reduced -> one block per channel, not 4 row partials
-                         # (single_stat_block=True on one rank: the exact kernel configuration of a multi-rank step,
-                         # bench.py --force-comm)
-                         single_stat_block=int(world_size > 1 if single_stat_block is None else single_stat_block))
+                         # sharded over ranks.  m > 64: the blocks travel (wire buffer of the packed exchange, SW from the
+                         # exchanged S; gp_large.hip).  m <= 64 (round 4): the statistics launches KEEP their 4 row partials per
+                         # channel and the all-reduce moves the partial blocks as one message (statA 135 -> 540 KB at config 2:
+                         # still latency-bound; the consumers add the partials on load as on one GPU) -- one block per channel
+                         # made the two statistics stages 12.8 + 14.2 us instead of 8.5 + 5.8.  SVGP_DP_STAT_PARTIALS=0: one block.
+                         # Every rank must be built with the SAME b_max (the partial count is a function of the capacity);
+                         # attach_comm / run check the block lengths across ranks.
+                         # (single_stat_block on one rank: the kernel configuration of a multi-rank step, bench.py --force-comm)
+                         single_stat_block=int((world_size > 1 and (m > 64 or os.environ.get("SVGP_DP_STAT_PARTIALS") == "0"))
+                                               if single_stat_block is None else single_stat_block))
         self.b_max = b_max
         self.cfg = None
         self.pl = ParamLayout()
@@ -343,6 +378,8 @@ class MnistStepEngine:
         self._graphs = {}
         self._bound = None
         self.comm = None
+        if m > 64:      # the library's side branches of this stream (forward tail / early reverse half; Cholesky look-ahead): picked
+            call("svgp_side_streams_prepare", self.stream.cuda_stream)     # now, by the concurrency probe, not under a later capture
         self.set_batch_size(b_max, b_max * world_size)
 
     # ------------------------------------------------------------------ configuration
@@ -457,6 +494,25 @@ class MnistStepEngine:
         """Use the library's RCCL communicator for the three exchanges (svgp_mnist_train_step_dp)."""
         assert comm.world_size == self.world_size and comm.rank == self.rank
         self.comm = comm
+        self._check_block_lengths()
+
+    def _check_block_lengths(self):
+        """The exchange blocks must have the same length on every rank (the row-partial count of the statistics blocks is a
+        function of the row capacity b_max): checked once, through torch.distributed when a process group exists."""
+        if getattr(self, "_blocks_checked", False) or self.world_size == 1:
+            return
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        lens = torch.tensor([self.wl.statA_len, self.wl.statB_len, self.wl.gradC_len], dtype=torch.int64,
+                            device=self.device if dist.get_backend() == "nccl" else "cpu")
+        lo, hi = lens.clone(), lens.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise _lib.SvgpError(f"exchange block lengths differ between ranks (min {lo.tolist()}, max {hi.tolist()}): "
+                                 "build every rank's engine with the same b_max")
+        self._blocks_checked = True
 
     def full_step_dp(self, adam=True):
         images, aux, eps = self._bound
@@ -474,6 +530,7 @@ class MnistStepEngine:
             elif self.world_size == 1:
                 self.full_step(adam)
             else:
+                self._check_block_lengths()
                 be = _PhaseAdapter(self, adam)
                 DataParallelStep(be, group).step()
 
@@ -519,14 +576,16 @@ class MnistStepEngine:
             call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 1, ws, s)            # without the (A_hat + jI)^-1 tail
             if pack:      # the window in wire format BEFORE the side branch starts reading it
                 call("svgp_sym_pack", m, nl, 0, wptr("Si"), wptr("Si", 0), s)
-            # the tail and the early reverse half: on the side branch, beside the all-gather, the row stage, the decoder and
-            # the reverse statistics
+            # the tail and the early reverse half go to the side branch, beside the all-gather, the row stage, the decoder and
+            # the reverse statistics: FORKED here, ISSUED behind the collective (below) -- enqueued first, the branch's GEMMs
+            # fill the chip and the collective's kernel waits for a slot
             side.wait_stream(self.stream)
+        # (round 4: M2 = Ki A Ki is no longer formed or exchanged -- the row stage evaluates k^T M2 k as w^T Si w, gp_large.hip)
+        yield [ExchangeOp("allgather", fld("Si", mm), sym(0, pre=True))] + plain("allgather", ("t", m), ("u", m))
+        with torch.cuda.stream(self.stream):
             call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 2, ws, side.cuda_stream)
             if fork:
                 call("svgp_gp_factor_bwd_channels_part", cp, l0, nl, 1, ws, st, side.cuda_stream)
-        # (round 4: M2 = Ki A Ki is no longer formed or exchanged -- the row stage evaluates k^T M2 k as w^T Si w, gp_large.hip)
-        yield [ExchangeOp("allgather", fld("Si", mm), sym(0, pre=True))] + plain("allgather", ("t", m), ("u", m))
         with torch.cuda.stream(self.stream):
             call("svgp_gp_posterior_fwd", cp, ep, ws, st, s)
             call("svgp_mnist_decoder_fwd", cp, th, im, ws, s)
@@ -548,7 +607,7 @@ class MnistStepEngine:
 
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = concurrent_streams(self.stream, 1, self.device)[0]
         return self._side
 
     # hipGraph capture / replay through the library (not torch.cuda.graphs)

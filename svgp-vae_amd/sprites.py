@@ -31,7 +31,7 @@ import torch
 from . import _lib
 from ._lib import STATE, STATE_LEN, MnistCfg, SpritesKcfg, WsLayout, call
 from .conv import ConvLayer
-from .engine import ExchangeOp, SymBlock, dp_pack_enabled
+from .engine import ExchangeOp, SymBlock, concurrent_streams, dp_pack_enabled
 
 _F64 = torch.float64
 ENC_STRIDES = (1, 2, 1, 2, 1, 2)
@@ -126,11 +126,17 @@ class SpritesStepEngine:
         # `comm` (engine.RcclComm) sums the three exchange blocks on the compute stream
         self.rank, self.world_size, self.comm = rank, world_size, comm
         self.stream = torch.cuda.Stream(device=self.dev)
-        # side stream of the deferred forward-factor tail (None: everything on the one stream; SVGP_SIDE_STREAMS=0)
-        self.side = None if os.environ.get("SVGP_SIDE_STREAMS") == "0" else torch.cuda.Stream(device=self.dev)
-        # third stream: the first part of the early reverse half runs beside the forward tail (SVGP_SIDE_STREAMS=2: behind it).
-        # Measured on one box, m = 800: one stream 31.8 ms, two 30.4, three 30.1 per step.
-        self.side2 = None if (self.side is None or os.environ.get("SVGP_SIDE_STREAMS") == "2") else torch.cuda.Stream(device=self.dev)
+        # side stream of the deferred forward-factor tail (None: everything on the one stream; SVGP_SIDE_STREAMS=0) and a third
+        # stream: the first part of the early reverse half runs beside the forward tail (SVGP_SIDE_STREAMS=2: behind it).
+        # Measured on one box, m = 800: one stream 31.8 ms, two 30.4, three 30.1 per step (round 2).  The two are picked by the
+        # concurrency probe (engine.concurrent_streams): streams that share a hardware queue with self.stream hide nothing.
+        mode = os.environ.get("SVGP_SIDE_STREAMS")
+        picked = [] if mode == "0" else concurrent_streams(self.stream, 1 if mode == "2" else 2, self.dev)
+        self.side = picked[0] if picked else None
+        self.side2 = picked[1] if len(picked) > 1 else None
+        call("svgp_side_streams_prepare", self.stream.cuda_stream)     # the library's own branches (Cholesky look-ahead) of the three
+        for sx in picked:
+            call("svgp_side_streams_prepare", sx.cuda_stream)
         f64 = dict(dtype=_F64, device=self.dev)
         assert net_dtype in (torch.float64, torch.float32) and gemm_f32 in (0, 1, 2)
         self.ndt, self.f32 = net_dtype, net_dtype == torch.float32
@@ -186,7 +192,7 @@ class SpritesStepEngine:
                          alpha=float(alpha), rep_weight=1.0 if rank == 0 else 0.0,
                          # blocks travel between ranks (also: the 1-rank communicator form of a multi-rank step): one statistics
                          # block per channel, and the workspace carries the wire buffer of the packed exchange
-                         single_stat_block=int(world_size > 1 or self.chan_shard),
+                         single_stat_block=int(self.m > 64 and (world_size > 1 or self.chan_shard)),
                          gemm_f32=int(gemm_f32))
         if self.chan_shard:
             self.base["rep_weight"] = 1.0        # every rank's Kbar holds its channel window's share (sums in the gradient exchange)
@@ -464,13 +470,10 @@ class SpritesStepEngine:
                 call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 1, ws, s)         # without the (A_hat + jI)^-1 tail
                 if pack:   # the window in wire format BEFORE the side branch starts reading it
                     call("svgp_sym_pack", self.m, nl, 0, wptr("Si"), wptr("Si", 0), s)
-                # the tail and the early reverse half of the window: on the side stream, beside the all-gather, the row stage,
-                # the decoder and the reverse statistics
+                # the tail and the early reverse half of the window go to the side stream, beside the all-gather, the row stage,
+                # the decoder and the reverse statistics: forked here, issued BEHIND the collective (see svgp_mnist_train_step_dp)
                 sd = self.side if self.side is not None else self.stream
                 sd.wait_stream(self.stream)
-                call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 2, ws, sd.cuda_stream)
-                if self.side is not None:
-                    call("svgp_gp_factor_bwd_channels_part", cp, l0, nl, 1, ws, st, sd.cuda_stream)
             elif self.m > 64 and self.side is not None and not self.svgp.titsias:
                 # (not with titsias: svgp_gp_titsias_fwd inverts through the same scratch, ws.scr_inv, on the main stream)
                 # the tail of the stage -- (A_hat + jI)^-1, its log det, KL_l: a whole batched inverse that only the reverse
@@ -493,6 +496,9 @@ class SpritesStepEngine:
         if self.chan_shard:
             # (round 4: M2 = Ki A Ki is neither formed nor exchanged -- the row stage evaluates k^T M2 k as w^T Si w)
             yield [ExchangeOp("allgather", fld("Si", mm_), sym(0, pre=True))] + plain("allgather", ("t", self.m), ("u", self.m))
+            call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 2, ws, sd.cuda_stream)
+            if self.side is not None:
+                call("svgp_gp_factor_bwd_channels_part", cp, l0, nl, 1, ws, st, sd.cuda_stream)
         with torch.cuda.stream(self.stream):
             call("svgp_gp_posterior_fwd", cp, None if eps is None else eps.contiguous().data_ptr(), ws, st, s)
             if self.svgp.titsias:

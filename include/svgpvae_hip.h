@@ -473,6 +473,31 @@ int svgp_conv_taps_wgrad(const svgp_conv_desc* d, int ncls, const double* in, co
 /* UpSampling2D(2) + Conv2D 3x3 as four parity classes: effective weights we (2,2,2,2,Ci,Co) from w (3,3,Ci,Co), and the
  * gradient of w from the gradient of we (VAE_utils.py:317-338 decoder layers) */
 int svgp_upconv_weights(int Ci, int Co, const double* w, double* we, void* stream);
+/* Deferred partial sums.  Every svgp_conv_taps_wgrad_fused call ends in two small reductions (weight and bias partials ->
+ * dw, db): 32 launches of ~10 us in the launch chains of a SPRITES step, whose results only the optimiser reads.  The *_jobs
+ * forms run the convolution kernels as usual but RETURN the reductions as descriptors (at most `cap`, *n_jobs written);
+ * svgp_sum_partials_multi[_f32] runs any number of them as one launch (per 64 jobs), adding in the same order as the
+ * immediate form.  The caller keeps part / part_b intact until then (one scratch region per layer) and orders `stream`
+ * behind every stream that produced partials.                                                                         */
+typedef struct {
+    const void* part;   /* (ng, stride) partials                     */
+    void* out;          /* (len) sums                                */
+    int32_t ng, len, stride, accumulate;
+} svgp_sum_job;
+int svgp_conv_taps_wgrad_fused_jobs(const svgp_conv_desc* d, int ncls, const double* in, const double* out, double* dout,
+                                    double* part, double* part_b, int nwg, int part_stride, double* dw, double* db,
+                                    svgp_sum_job* jobs, int cap, int* n_jobs, void* stream);
+int svgp_conv_taps_wgrad_fused_jobs_f32(const svgp_conv_desc* d, int ncls, const float* in, const float* out, float* dout,
+                                        float* part, float* part_b, int nwg, int part_stride, float* dw, float* db,
+                                        svgp_sum_job* jobs, int cap, int* n_jobs, void* stream);
+int svgp_sum_partials_multi(const svgp_sum_job* jobs, int n, void* stream);
+int svgp_sum_partials_multi_f32(const svgp_sum_job* jobs, int n, void* stream);
+/* w (nt, A, B) -> wt (nt, B, A): the transposed tap weights a data gradient convolves with; element-type casts of the
+ * float32-network engine (master parameters / gradients are float64)                                                 */
+int svgp_transpose_taps(int nt, int A, int B, const double* w, double* wt, void* stream);
+int svgp_transpose_taps_f32(int nt, int A, int B, const float* w, float* wt, void* stream);
+int svgp_cast_f64_f32(long long n, const double* x, float* y, void* stream);
+int svgp_cast_f32_f64(long long n, const float* x, double* y, void* stream);
 int svgp_upconv_fold_wgrad(int Ci, int Co, const double* ge, double* g, void* stream);
 int svgp_elu_bwd_bias(long long npix, int C, const double* out, double* dout, double* part, double* db,
                       void* stream);

@@ -59,6 +59,11 @@ class ConvDesc(C.Structure):
                [("oy", C.c_int32 * 16), ("ox", C.c_int32 * 16), ("woff", C.c_int32 * 16)]
 
 
+class SumJob(C.Structure):
+    """svgp_sum_job (include/svgpvae_hip.h): one deferred partial-sum reduction."""
+    _fields_ = [("part", C.c_void_p), ("out", C.c_void_p)] + [(n, C.c_int32) for n in ("ng", "len", "stride", "accumulate")]
+
+
 class PearceBufs(C.Structure):
     """svgp_pearce_bufs (include/svgpvae_hip.h)."""
     _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("n", C.c_int32)] + \
@@ -176,6 +181,16 @@ SIGNATURES = {
     "svgp_enc_head_bwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "svgp_softmax_xent": [C.c_int, C.c_int, _P, _P, _P, _P, _P, _P],
     "svgp_bias_add": [C.c_longlong, C.c_int, _P, _P, _P],
+    "svgp_conv_taps_wgrad_fused_jobs": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P,
+                                        C.POINTER(SumJob), C.c_int, C.POINTER(C.c_int), _P],
+    "svgp_conv_taps_wgrad_fused_jobs_f32": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P, _P,
+                                            C.POINTER(SumJob), C.c_int, C.POINTER(C.c_int), _P],
+    "svgp_sum_partials_multi": [C.POINTER(SumJob), C.c_int, _P],
+    "svgp_sum_partials_multi_f32": [C.POINTER(SumJob), C.c_int, _P],
+    "svgp_transpose_taps": [C.c_int, C.c_int, C.c_int, _P, _P, _P],
+    "svgp_transpose_taps_f32": [C.c_int, C.c_int, C.c_int, _P, _P, _P],
+    "svgp_cast_f64_f32": [C.c_longlong, _P, _P, _P],
+    "svgp_cast_f32_f64": [C.c_longlong, _P, _P, _P],
     "svgp_streams_overlap": [_P, _P, C.POINTER(C.c_int)],
     "svgp_side_streams_prepare": [_P],
     "svgp_gauss_cross_entropy": [C.c_longlong, _P, _P, _P, _P, _P, _P],
@@ -261,7 +276,7 @@ def load_library(path=None):
         fn.argtypes = argtypes
         fn.restype = restype
     # the ctypes mirrors must have the layout the library was compiled with (svgp_struct_sizeof)
-    for which, cls in enumerate((MnistCfg, ParamLayout, WsLayout, StreamKdesc, ConvDesc, SpritesKcfg, PearceBufs)):
+    for which, cls in enumerate((MnistCfg, ParamLayout, WsLayout, StreamKdesc, ConvDesc, SpritesKcfg, PearceBufs, SumJob)):
         if lib.svgp_struct_sizeof(which) != C.sizeof(cls):
             raise SvgpError(f"{p}: sizeof({cls.__name__}) is {lib.svgp_struct_sizeof(which)} in the library but "
                             f"{C.sizeof(cls)} in the binding; rebuild the library or update _lib.py")

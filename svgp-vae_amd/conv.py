@@ -13,7 +13,9 @@ import math
 
 import torch
 
-from ._lib import ConvDesc, call
+import ctypes as C
+
+from ._lib import ConvDesc, SumJob, call
 
 _F64 = torch.float64
 
@@ -56,7 +58,7 @@ class ConvLayer:
             self.Ho, self.pad = (Hi - k) // stride + 1, 0
         self.n_w = k * k * Ci * Co
 
-    # ------------------------------------------------------------------ weight re-layouts (O(#weights))
+    # ------------------------------------------------------------------ weight re-layouts (O(#weights)), HIP kernels
     def weights_fwd(self, w, stream=None):
         """Weights in the layout the forward / weight-gradient descriptors index (svgp_upconv_weights for up layers)."""
         if not self.up:
@@ -66,15 +68,33 @@ class ConvLayer:
         call("svgp_upconv_weights" + self.sfx, self.Ci, self.Co, w.contiguous().data_ptr(), we.data_ptr(), s)
         return we
 
-    def weights_bwd(self, w, stream=None):
-        """Transposed (Co x Ci per tap) weights for the data gradient."""
-        return self.weights_fwd(w, stream).transpose(-1, -2).contiguous()
+    def weights_bwd(self, w, stream=None, wf=None):
+        """Transposed (Co x Ci per tap) weights for the data gradient (svgp_transpose_taps)."""
+        wf = self.weights_fwd(w, stream) if wf is None else wf
+        nt = wf.numel() // (self.Ci * self.Co)
+        wt = torch.empty(wf.shape[:-2] + (self.Co, self.Ci), dtype=self.dt, device=wf.device)
+        s = torch.cuda.current_stream(wf.device).cuda_stream if stream is None else stream
+        call("svgp_transpose_taps" + self.sfx, nt, self.Ci, self.Co, wf.data_ptr(), wt.data_ptr(), s)
+        return wt
 
-    def fold_wgrad(self, gwf, stream=None):
+    def prepare(self, w, stream, need_bwd=True):
+        """Forward-layout and transposed weights for this step, computed once (off the launch chains of the forward and reverse
+        passes: the engine issues this for every layer at the start of a step on an idle stream).  forward / backward use them
+        when they are handed the same `w`."""
+        wf = self.weights_fwd(w, stream)
+        self._prep = (w.data_ptr(), wf, self.weights_bwd(w, stream, wf) if need_bwd else None)
+
+    def _cached(self, w, stream, bwd):
+        prep = getattr(self, "_prep", None)
+        if prep is not None and prep[0] == w.data_ptr() and (not bwd or prep[2] is not None):
+            return prep[2] if bwd else prep[1]
+        return self.weights_bwd(w, stream) if bwd else self.weights_fwd(w, stream)
+
+    def fold_wgrad(self, gwf, stream=None, out=None):
         """Gradient in forward layout -> gradient of the raw (k,k,Ci,Co) weights (svgp_upconv_fold_wgrad for up layers)."""
         if not self.up:
             return gwf.view(self.k, self.k, self.Ci, self.Co)
-        g = torch.empty(3, 3, self.Ci, self.Co, dtype=self.dt, device=gwf.device)
+        g = torch.empty(3, 3, self.Ci, self.Co, dtype=self.dt, device=gwf.device) if out is None else out
         s = torch.cuda.current_stream(gwf.device).cuda_stream if stream is None else stream
         call("svgp_upconv_fold_wgrad" + self.sfx, self.Ci, self.Co, gwf.data_ptr(), g.data_ptr(), s)
         return g
@@ -134,30 +154,44 @@ class ConvLayer:
         n = x.shape[0]
         ds = self.descs_fwd(n)
         arr = (ConvDesc * len(ds))(*ds)
-        wf = self.weights_fwd(w, stream)
+        wf = self._cached(w, stream, False)
         assert x.dtype == self.dt and w.dtype == self.dt and out.dtype == self.dt
         call("svgp_conv_taps_fwd" + self.sfx, arr, len(ds), x.data_ptr(), wf.data_ptr(), b.data_ptr(), out.data_ptr(), stream)
         return out
 
-    def backward(self, x, w, out, dout, gw, gb, scratch, stream, need_dx=True, dx=None, nwg=512):
-        """dout (n,Ho,Ho,Co) is overwritten with dpre.  gw (k,k,Ci,Co), gb (Co) receive the gradients.
-        scratch: buffer (layer dtype) of >= scratch_elems(nwg) elements.  Returns dx (n,Hi,Hi,Ci) or None."""
+    def backward(self, x, w, out, dout, gw, gb, scratch, stream, need_dx=True, dx=None, nwg=512, deferred=None):
+        """dout (n,Ho,Ho,Co) is overwritten with dpre.  gw (k,k,Ci,Co), gb (Co) receive the gradients (gw contiguous: the
+        reduction writes it in place).  scratch: buffer (layer dtype) of >= scratch_elems(nwg) elements.  Returns dx
+        (n,Hi,Hi,Ci) or None.
+        deferred: a DeferredSums -- the two closing reductions (weight / bias partials -> gw, gb) are then NOT launched but
+        recorded there (svgp_conv_taps_wgrad_fused_jobs), together with the fold of an up layer's effective-weight gradient,
+        which reads the summed gradient; `scratch` must be this layer's own region, untouched until DeferredSums.flush."""
         n = x.shape[0]
         assert x.dtype == self.dt and dout.dtype == self.dt and scratch.dtype == self.dt and gw.dtype == self.dt
+        assert gw.is_contiguous() and gb.is_contiguous()
         part_b = scratch[:1024 * 16]
         part_w = scratch[1024 * 16:]
         ds = self.descs_fwd(n, act=0)
         arr = (ConvDesc * len(ds))(*ds)
-        gwf = torch.empty(self.n_wf, dtype=self.dt, device=x.device)
+        gwf = torch.empty(self.n_wf, dtype=self.dt, device=x.device) if self.up else gw
         # dpre = dout * elu'(out) in place, gb = column sums, gwf = weight gradient: one pass (svgp_conv_taps_wgrad_fused)
-        call("svgp_conv_taps_wgrad_fused" + self.sfx, arr, len(ds), x.data_ptr(), out.data_ptr() if self.elu else None,
-             dout.data_ptr(), part_w.data_ptr(), part_b.data_ptr(), nwg, self.n_wf, gwf.data_ptr(), gb.data_ptr(), stream)
-        gw.copy_(self.fold_wgrad(gwf, stream))
+        if deferred is None:
+            call("svgp_conv_taps_wgrad_fused" + self.sfx, arr, len(ds), x.data_ptr(), out.data_ptr() if self.elu else None,
+                 dout.data_ptr(), part_w.data_ptr(), part_b.data_ptr(), nwg, self.n_wf, gwf.data_ptr(), gb.data_ptr(), stream)
+            if self.up:
+                self.fold_wgrad(gwf, stream, out=gw)
+        else:
+            jobs, n_jobs = (SumJob * 4)(), C.c_int(0)
+            call("svgp_conv_taps_wgrad_fused_jobs" + self.sfx, arr, len(ds), x.data_ptr(), out.data_ptr() if self.elu else None,
+                 dout.data_ptr(), part_w.data_ptr(), part_b.data_ptr(), nwg, self.n_wf, gwf.data_ptr(), gb.data_ptr(), jobs, 4,
+                 C.byref(n_jobs), stream)
+            deferred.add(self.dt, [jobs[k] for k in range(n_jobs.value)], keep=(gwf, scratch),
+                         fold=(lambda s_, gwf=gwf, gw=gw: self.fold_wgrad(gwf, s_, out=gw)) if self.up else None)
         if not need_dx:
             return None
         db = self.descs_bwd_data(n)
         arrb = (ConvDesc * len(db))(*db)
-        wb = self.weights_bwd(w, stream)
+        wb = self._cached(w, stream, True)
         if dx is None:
             dx = torch.empty(n, self.Hi, self.Hi, self.Ci, dtype=self.dt, device=x.device)
         call("svgp_conv_taps_fwd" + self.sfx, arrb, len(db), dout.data_ptr(), wb.data_ptr(), None, dx.data_ptr(), stream)
@@ -165,3 +199,30 @@ class ConvLayer:
 
     def scratch_elems(self, nwg=512):
         return 1024 * 16 + 4 * nwg * self.n_wf
+
+
+class DeferredSums:
+    """The partial-sum reductions of a reverse pass, collected layer by layer and run as ONE launch per element type
+    (svgp_sum_partials_multi), followed by the folds of the up layers' effective-weight gradients."""
+
+    def __init__(self):
+        self.jobs = {torch.float64: [], torch.float32: []}
+        self.folds, self.keep = [], []
+
+    def add(self, dtype, jobs, keep=(), fold=None):
+        for j in jobs:                       # copies: the ctypes array they came from does not outlive the layer call
+            c = SumJob()
+            C.memmove(C.byref(c), C.byref(j), C.sizeof(SumJob))
+            self.jobs[dtype].append(c)
+        self.keep.extend(keep)               # buffers the recorded jobs read / write stay referenced until the flush
+        if fold is not None:
+            self.folds.append(fold)
+
+    def flush(self, stream):
+        for dt, sfx in ((torch.float64, ""), (torch.float32, "_f32")):
+            js = self.jobs[dt]
+            if js:
+                call("svgp_sum_partials_multi" + sfx, (SumJob * len(js))(*js), len(js), stream)
+        for f in self.folds:
+            f(stream)
+        self.__init__()

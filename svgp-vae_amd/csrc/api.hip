@@ -28,6 +28,7 @@ extern "C" int svgp_struct_sizeof(int which) {
     case 4: return (int)sizeof(svgp_conv_desc);
     case 5: return (int)sizeof(svgp_sprites_kcfg);
     case 6: return (int)sizeof(svgp_pearce_bufs);
+    case 7: return (int)sizeof(svgp_sum_job);
     default: return -1;
     }
 }

@@ -321,6 +321,83 @@ __global__ __launch_bounds__(256) void k_sum_partials(int ng, int len, int strid
     }
 }
 
+// ---- deferred partial sums.  Every layer of a network's reverse pass ends in two of these small reductions (weights, bias): 32
+// launches of ~10 us per SPRITES step, each in the middle of a chain of dependent launches.  Their results are only read by the
+// optimiser, so the *_jobs entry points run the convolution kernels as usual but hand the reductions back to the caller as
+// svgp_sum_job descriptors, and svgp_sum_partials_multi runs any number of them as ONE launch.  The caller keeps every partial
+// buffer intact until then (one scratch region per layer) and orders the stream of the multi-launch behind every stream that
+// produced partials.  No state outlives a call: the capture target below is set for the duration of one *_jobs call only.
+#define SUM_MAX_JOBS 64
+template <typename T>
+struct SumJobs {
+    const T* part[SUM_MAX_JOBS]; T* out[SUM_MAX_JOBS];
+    int ng[SUM_MAX_JOBS], len[SUM_MAX_JOBS], stride[SUM_MAX_JOBS], acc[SUM_MAX_JOBS], blk0[SUM_MAX_JOBS + 1];
+    int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_sum_partials_multi(SumJobs<T> J) {
+    __shared__ T sh[16][17];
+    int j = 0;
+    while (j + 1 < J.n && (int)blockIdx.x >= J.blk0[j + 1]) ++j;
+    const int ng = J.ng[j], len = J.len[j], stride = J.stride[j];
+    const T* __restrict__ part = J.part[j];
+    const int il = threadIdx.x & 15, ch = threadIdx.x >> 4, i = ((int)blockIdx.x - J.blk0[j]) * 16 + il;
+    T s = 0;
+    if (i < len) {
+        for (int g0 = ch; g0 < ng; g0 += 16 * 8) {
+            T v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int g = g0 + 16 * u; v[u] = g < ng ? part[(size_t)g * stride + i] : T(0); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+    }
+    sh[ch][il] = s;
+    __syncthreads();
+    if (ch == 0 && i < len) {
+        T t = J.acc[j] ? J.out[j][i] : T(0);
+#pragma unroll
+        for (int c = 0; c < 16; ++c) t += sh[c][il];
+        J.out[j][i] = t;
+    }
+}
+struct SumCapture { svgp_sum_job* jobs = nullptr; int cap = 0, n = 0; };
+static SumCapture& sum_capture() { static thread_local SumCapture c; return c; }
+// the one way k_sum_partials is launched: same order of additions whether it runs now or in svgp_sum_partials_multi
+template <typename T>
+static int sum_partials(int ng, int len, int stride, const T* part, T* out, int accumulate, void* stream) {
+    SumCapture& c = sum_capture();
+    if (c.jobs) {
+        SVGP_REQUIRE(c.n < c.cap, SVGP_ERR_INVALID, "more partial-sum jobs than the caller's array holds (%d)", c.cap);
+        svgp_sum_job& j = c.jobs[c.n++];
+        j.part = part; j.out = out; j.ng = ng; j.len = len; j.stride = stride; j.accumulate = accumulate;
+        return SVGP_OK;
+    }
+    hipLaunchKernelGGL(k_sum_partials<T>, dim3((len + 15) / 16), dim3(256), 0, (hipStream_t)stream, ng, len, stride, part, out,
+                       accumulate);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+template <typename T>
+static int sum_partials_multi_impl(const svgp_sum_job* jobs, int n, void* stream) {
+    SVGP_REQUIRE(n >= 0 && (n == 0 || jobs), SVGP_ERR_INVALID, "bad job list");
+    for (int lo = 0; lo < n; lo += SUM_MAX_JOBS) {
+        SumJobs<T> J;
+        J.n = n - lo < SUM_MAX_JOBS ? n - lo : SUM_MAX_JOBS;
+        J.blk0[0] = 0;
+        for (int k = 0; k < J.n; ++k) {
+            const svgp_sum_job& j = jobs[lo + k];
+            SVGP_REQUIRE(j.part && j.out && j.ng >= 1 && j.len >= 1 && j.stride >= j.len, SVGP_ERR_INVALID, "bad partial-sum job %d", lo + k);
+            J.part[k] = static_cast<const T*>(j.part); J.out[k] = static_cast<T*>(j.out);
+            J.ng[k] = j.ng; J.len[k] = j.len; J.stride[k] = j.stride; J.acc[k] = j.accumulate;
+            J.blk0[k + 1] = J.blk0[k] + (j.len + 15) / 16;
+        }
+        hipLaunchKernelGGL(k_sum_partials_multi<T>, dim3(J.blk0[J.n]), dim3(256), 0, (hipStream_t)stream, J);
+        SVGP_LAUNCH_CHECK();
+    }
+    return SVGP_OK;
+}
+
 // dpre = dout * elu'(out) in place on dout; also per-block column sums for the bias gradient.  HBM-bound (read out, read
 // dout, write dout): 8 independent element pairs in flight per thread
 template <typename T>
@@ -1254,10 +1331,7 @@ static int conv_taps_wgrad_impl(const svgp_conv_desc* d, int ncls, const T* in, 
     hipLaunchKernelGGL(k_conv_taps_wgrad<T>, dim3(nwg, ncls), dim3(256), lds, (hipStream_t)stream, L, nwg, in, dout, part,
                        part_stride);
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_partials<T>, dim3((part_stride + 15) / 16), dim3(256), 0, (hipStream_t)stream, nwg,
-                       part_stride, part_stride, (const T*)part, dw, accumulate);
-    SVGP_LAUNCH_CHECK();
-    return SVGP_OK;
+    return sum_partials<T>(nwg, part_stride, part_stride, (const T*)part, dw, accumulate, stream);
 }
 
 // One pass for the reverse of a layer's bias / activation / weights: dpre = dout * elu'(out) in place (out == NULL: dpre = dout),
@@ -1298,14 +1372,9 @@ static int conv_wgrad_fused_impl(const svgp_conv_desc* d, int ncls, const T* in,
 #undef CSW
                 SVGP_LAUNCH_CHECK();
             }
-            hipLaunchKernelGGL(k_sum_partials<T>, dim3((part_stride + 15) / 16), dim3(256), 0, (hipStream_t)stream, nw, part_stride,
-                               part_stride, (const T*)part, dw, 0);
-            SVGP_LAUNCH_CHECK();
-            if (m0) {
-                hipLaunchKernelGGL(k_sum_partials<T>, dim3(1), dim3(256), 0, (hipStream_t)stream, nw * ncls, d[0].Co, 16,
-                                   (const T*)part_b, db, 0);
-                SVGP_LAUNCH_CHECK();
-            }
+            rc = sum_partials<T>(nw, part_stride, part_stride, (const T*)part, dw, 0, stream);
+            if (rc) return rc;
+            if (m0) return sum_partials<T>(nw * ncls, d[0].Co, 16, (const T*)part_b, db, 0, stream);
             return SVGP_OK;
         }
     }
@@ -1363,13 +1432,9 @@ static int conv_wgrad_fused_impl(const svgp_conv_desc* d, int ncls, const T* in,
     }
 #undef C16W
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_partials<T>, dim3((part_stride + 15) / 16), dim3(256), 0, (hipStream_t)stream, nwg_c,
-                       part_stride, part_stride, (const T*)part, dw, 0);
-    SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_partials<T>, dim3(1), dim3(256), 0, (hipStream_t)stream, nwg_c * ncls, d[0].Co, 16,
-                       (const T*)part_b, db, 0);
-    SVGP_LAUNCH_CHECK();
-    return SVGP_OK;
+    rc = sum_partials<T>(nwg_c, part_stride, part_stride, (const T*)part, dw, 0, stream);
+    if (rc) return rc;
+    return sum_partials<T>(nwg_c * ncls, d[0].Co, 16, (const T*)part_b, db, 0, stream);
 }
 
 // dpre = dout * elu'(out) (in place on dout; out == NULL skips the activation) and db[c] = sum dpre[.., c].
@@ -1380,9 +1445,7 @@ static int elu_bwd_bias_impl(long long npix, int C, const T* out, T* dout, T* pa
     const int nblk = 1024;     // 4 workgroups per CU keep the HBM queues full
     hipLaunchKernelGGL(k_elu_bwd_colsum<T>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, npix, C, out, dout, part);
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sum_partials<T>, dim3(1), dim3(256), 0, (hipStream_t)stream, nblk, C, C, (const T*)part, db, 0);
-    SVGP_LAUNCH_CHECK();
-    return SVGP_OK;
+    return sum_partials<T>(nblk, C, C, (const T*)part, db, 0, stream);
 }
 
 // effective weights of an upsample-fused 3x3 convolution (conv.py ConvLayer(up=True)): w (3,3,Ci,Co) -> we (2,2,2,2,Ci,Co);
@@ -1426,6 +1489,71 @@ extern "C" int svgp_conv_taps_wgrad_fused_f32(const svgp_conv_desc* d, int ncls,
                                               void* stream) {
     return conv_wgrad_fused_impl<float>(d, ncls, in, out, dout, part, part_b, nwg, part_stride, dw, db, stream);
 }
+// as svgp_conv_taps_wgrad_fused, but the closing reductions come back as job descriptors instead of being launched
+template <typename T>
+static int wgrad_fused_jobs(const svgp_conv_desc* d, int ncls, const T* in, const T* out, T* dout, T* part, T* part_b, int nwg,
+                            int part_stride, T* dw, T* db, svgp_sum_job* jobs, int cap, int* n_jobs, void* stream) {
+    SVGP_REQUIRE(jobs && n_jobs && cap >= 1, SVGP_ERR_INVALID, "bad job array");
+    SumCapture& c = sum_capture();
+    c.jobs = jobs; c.cap = cap; c.n = 0;
+    const int rc = conv_wgrad_fused_impl<T>(d, ncls, in, out, dout, part, part_b, nwg, part_stride, dw, db, stream);
+    *n_jobs = c.n;
+    c.jobs = nullptr; c.cap = 0; c.n = 0;
+    return rc;
+}
+extern "C" int svgp_conv_taps_wgrad_fused_jobs(const svgp_conv_desc* d, int ncls, const double* in, const double* out,
+                                               double* dout, double* part, double* part_b, int nwg, int part_stride, double* dw,
+                                               double* db, svgp_sum_job* jobs, int cap, int* n_jobs, void* stream) {
+    return wgrad_fused_jobs<double>(d, ncls, in, out, dout, part, part_b, nwg, part_stride, dw, db, jobs, cap, n_jobs, stream);
+}
+extern "C" int svgp_conv_taps_wgrad_fused_jobs_f32(const svgp_conv_desc* d, int ncls, const float* in, const float* out,
+                                                   float* dout, float* part, float* part_b, int nwg, int part_stride, float* dw,
+                                                   float* db, svgp_sum_job* jobs, int cap, int* n_jobs, void* stream) {
+    return wgrad_fused_jobs<float>(d, ncls, in, out, dout, part, part_b, nwg, part_stride, dw, db, jobs, cap, n_jobs, stream);
+}
+extern "C" int svgp_sum_partials_multi(const svgp_sum_job* jobs, int n, void* stream) {
+    return sum_partials_multi_impl<double>(jobs, n, stream);
+}
+extern "C" int svgp_sum_partials_multi_f32(const svgp_sum_job* jobs, int n, void* stream) {
+    return sum_partials_multi_impl<float>(jobs, n, stream);
+}
+// (nt, A, B) -> (nt, B, A): the transposed tap weights of a data gradient (conv.py weights_bwd), and element-type casts
+template <typename T>
+__global__ void k_transpose_taps(int A, int B, long long tot, const T* __restrict__ w, T* __restrict__ wt) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tot) return;
+    const int ab = A * B, t = (int)(i / ab), o = (int)(i % ab), bb = o / A, aa = o % A;      // wt[t][bb][aa] = w[t][aa][bb]
+    wt[i] = w[(size_t)t * ab + (size_t)aa * B + bb];
+}
+template <typename TI, typename TO>
+__global__ void k_cast(long long n, const TI* __restrict__ x, TO* __restrict__ y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (TO)x[i];
+}
+#define SIMPLE_LAUNCH(KERNEL_, N_, ...)                                                                              \
+    do {                                                                                                             \
+        SVGP_REQUIRE((N_) >= 1, SVGP_ERR_INVALID, "bad argument");                                                   \
+        hipLaunchKernelGGL(KERNEL_, dim3((unsigned)(((N_) + 255) / 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        SVGP_LAUNCH_CHECK();                                                                                         \
+        return SVGP_OK;                                                                                              \
+    } while (0)
+extern "C" int svgp_transpose_taps(int nt, int A, int B, const double* w, double* wt, void* stream) {
+    SVGP_REQUIRE(w && wt && nt >= 1 && A >= 1 && B >= 1, SVGP_ERR_INVALID, "bad argument");
+    SIMPLE_LAUNCH(k_transpose_taps<double>, (long long)nt * A * B, A, B, (long long)nt * A * B, w, wt);
+}
+extern "C" int svgp_transpose_taps_f32(int nt, int A, int B, const float* w, float* wt, void* stream) {
+    SVGP_REQUIRE(w && wt && nt >= 1 && A >= 1 && B >= 1, SVGP_ERR_INVALID, "bad argument");
+    SIMPLE_LAUNCH(k_transpose_taps<float>, (long long)nt * A * B, A, B, (long long)nt * A * B, w, wt);
+}
+extern "C" int svgp_cast_f64_f32(long long n, const double* x, float* y, void* stream) {
+    SVGP_REQUIRE(x && y, SVGP_ERR_INVALID, "NULL pointer");
+    SIMPLE_LAUNCH((k_cast<double, float>), n, n, x, y);
+}
+extern "C" int svgp_cast_f32_f64(long long n, const float* x, double* y, void* stream) {
+    SVGP_REQUIRE(x && y, SVGP_ERR_INVALID, "NULL pointer");
+    SIMPLE_LAUNCH((k_cast<float, double>), n, n, x, y);
+}
+#undef SIMPLE_LAUNCH
 extern "C" int svgp_upconv_weights(int Ci, int Co, const double* w, double* we, void* stream) {
     return upconv_weights_impl<double>(Ci, Co, w, we, stream);
 }

@@ -30,7 +30,7 @@ import torch
 
 from . import _lib
 from ._lib import STATE, STATE_LEN, MnistCfg, SpritesKcfg, WsLayout, call
-from .conv import ConvLayer
+from .conv import ConvLayer, DeferredSums
 from .engine import ExchangeOp, SymBlock, concurrent_streams, dp_pack_enabled
 
 _F64 = torch.float64
@@ -223,6 +223,11 @@ class SpritesStepEngine:
         # and the representation network's (phases(), end of the step)
         self.scratch2 = None if self.side is None else torch.zeros(max(l.scratch_elems(self.nwg) for l in self.enc),
                                                                    dtype=self.ndt, device=self.dev)
+        # the training step defers the partial sums of every layer's weight / bias gradient to ONE launch at its end
+        # (svgp_sum_defer_begin / _flush): every layer then needs its own partial-sum region
+        self.lscratch = {(g_, i): torch.zeros(l.scratch_elems(self.nwg), dtype=self.ndt, device=self.dev)
+                         for g_, ls in (("enc", self.enc), ("dec", self.dec), ("rep", self.rep)) for i, l in enumerate(ls, 1)}
+        self.ones = torch.ones(b_max, 1, dtype=self.ndt, device=self.dev)
         self.stream.synchronize()
         self.act = {}
 
@@ -248,7 +253,32 @@ class SpritesStepEngine:
     def _sync_net_params(self):
         """float32 networks: refresh the float32 copy of the network weights from the float64 master vector."""
         if self.f32:
-            self.theta_n.copy_(self.theta[:self.n_net])
+            call("svgp_cast_f64_f32", self.n_net, self.theta.data_ptr(), self.theta_n.data_ptr(),
+                 torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _to_net(self, x, stream=None):
+        """float64 -> the networks' dtype (a HIP cast kernel on `stream`, default torch's current stream; no-op for float64)."""
+        if not self.f32:
+            return x
+        y = torch.empty(x.shape, dtype=torch.float32, device=self.dev)
+        call("svgp_cast_f64_f32", x.numel(), x.contiguous().data_ptr(), y.data_ptr(),
+             torch.cuda.current_stream(self.dev).cuda_stream if stream is None else stream)
+        return y
+
+    def _to_f64(self, x, stream=None, out=None):
+        if not self.f32:
+            if out is not None:
+                out.copy_(x)
+                return out
+            return x
+        y = torch.empty(x.shape, dtype=_F64, device=self.dev) if out is None else out
+        call("svgp_cast_f32_f64", x.numel(), x.contiguous().data_ptr(), y.data_ptr(),
+             torch.cuda.current_stream(self.dev).cuda_stream if stream is None else stream)
+        return y
+
+    def _colsum(self, X, rows, cols, out, stream=None):
+        """out (cols) = column sums of X (rows, cols): 1^T X on the library GEMM (bias gradients of the dense layers)."""
+        self._gemm(1, 0, 1, cols, rows, 1.0, self.ones, 1, X, cols, 0.0, out, cols, stream=stream)
 
     def scalars(self):
         self.stream.synchronize()
@@ -276,7 +306,7 @@ class SpritesStepEngine:
             a.append(out); x = out
         enc = torch.empty(b, 2 * L, **nd)
         self._gemm(0, 0, b, 2 * L, 1024, 1.0, x, 1024, p["enc_d_w"], 2 * L, 0.0, enc, 2 * L)
-        enc = enc.double() if self.f32 else enc               # the head (bias, exp, clip) and the GP block are float64
+        enc = self._to_f64(enc)                               # the head (bias, exp, clip) and the GP block are float64
         mu, var_raw, var = self._v("qnet_mu", (b, L)), self._v("qnet_var_raw", (b, L)), self._v("qnet_var", (b, L))
         call("svgp_enc_head_fwd", b, L, int(self.clip_qs), self.params["enc_d_b"].data_ptr(), enc.data_ptr(), mu.data_ptr(),
              var_raw.data_ptr(), var.data_ptr(), s)
@@ -294,13 +324,13 @@ class SpritesStepEngine:
             r.append(out); x = out
         rvec = torch.empty(b, self.Lc, **nd)
         call("svgp_avgpool_fwd" + self.sfx, b, 64, self.Lc, x.data_ptr(), rvec.data_ptr(), s)
-        return r, (rvec.double() if self.f32 else rvec)
+        return r, self._to_f64(rvec, stream=s)
 
     def _decoder_forward(self, z, b):
         """spritesVAE.decode (VAE_utils.py:317-338,352-360): Dense(1024) -> (8,8,16) -> 7 (up)convs."""
         p, s, L = self.np_, self.stream.cuda_stream, self.L
         nd = dict(dtype=self.ndt, device=self.dev)
-        z = z.to(self.ndt)
+        z = self._to_net(z)
         h0 = torch.empty(b, 1024, **nd)
         self._gemm(0, 0, b, 1024, L, 1.0, z, L, p["dec_d_w"], 1024, 0.0, h0, 1024)
         call("svgp_bias_add" + self.sfx, b, 1024, p["dec_d_b"].data_ptr(), h0.data_ptr(), s)
@@ -409,6 +439,16 @@ class SpritesStepEngine:
         with torch.cuda.stream(self.stream):
             images = images.to(self.ndt).contiguous()
             self._sync_net_params()
+            # forward-layout / transposed tap weights of every layer, once per step and OFF the launch chains of the forward and
+            # reverse passes: on the third stream (idle until the reverse factor stage) when there is one.  The encoder's and the
+            # representation network's forward weights are the parameters themselves, so nothing at the head of the step waits.
+            prep_stream = self.side2 if self.side2 is not None else self.stream
+            if prep_stream is not self.stream:
+                prep_stream.wait_stream(self.stream)
+            for grp, layers in (("dec", self.dec), ("enc", self.enc), ("repr", self.rep)):
+                for i, lay in enumerate(layers, 1):
+                    lay.prepare(pn[f"{grp}_c{i}_w"], prep_stream.cuda_stream, need_bwd=not (grp != "dec" and i == 1))
+            deferred = DeferredSums()          # every layer's closing partial sums: ONE launch at the end of the step
             self._mark("nets_fwd_enc")
             kc = SpritesKcfg(b=b, m=self.m, La=self.La, Lc=self.Lc, n_act=self.n_act,
                              normalize=int(self.svgp.K_obj_normalize), k_se=int(self.svgp.K_SE),
@@ -506,6 +546,8 @@ class SpritesStepEngine:
             # ---------------- decoder
             z = self._v("z", (b, L))
             self._mark("nets_fwd_dec")
+            if prep_stream is not self.stream:
+                self.stream.wait_stream(prep_stream)
             h0, d = self._decoder_forward(z, b)
             x = d[-1]
             recon = x
@@ -520,17 +562,17 @@ class SpritesStepEngine:
             for i in range(7, 0, -1):
                 lay = self.dec[i - 1]
                 xin = d[i - 2] if i > 1 else h0.view(b, 8, 8, 16)
-                dx = lay.backward(xin, pn[f"dec_c{i}_w"], d[i - 1], dx, gn[f"dec_c{i}_w"], gn[f"dec_c{i}_b"], self.scratch,
-                                  s, nwg=self.nwg)
+                dx = lay.backward(xin, pn[f"dec_c{i}_w"], d[i - 1], dx, gn[f"dec_c{i}_w"], gn[f"dec_c{i}_b"],
+                                  self.lscratch[("dec", i)], s, nwg=self.nwg, deferred=deferred)
             dh0 = dx.view(b, 1024)
-            zn = z.to(self.ndt)
+            zn = self._to_net(z)
             self._gemm(1, 0, L, 1024, b, 1.0, zn, L, dh0, 1024, 0.0, gn["dec_d_w"], 1024)
-            gn["dec_d_b"].copy_(dh0.sum(0))          # column sum of a (b,1024) matrix: O(b*1024) glue
+            self._colsum(dh0, b, 1024, gn["dec_d_b"])
             zbar = self._v("zbar", (b, L))
             if self.f32:
                 zb = torch.empty(b, L, **nd)
                 self._gemm(0, 1, b, L, 1024, 1.0, dh0, 1024, pn["dec_d_w"], 1024, 0.0, zb, L)
-                zbar.copy_(zb)
+                self._to_f64(zb, out=zbar)
             else:
                 self._gemm(0, 1, b, L, 1024, 1.0, dh0, 1024, pn["dec_d_w"], 1024, 0.0, zbar, L)
             self._mark("gp_bwd_stats")
@@ -566,16 +608,16 @@ class SpritesStepEngine:
                 d_enc = torch.empty(b, 2 * L, **f64)
                 call("svgp_enc_head_bwd", b, L, int(self.clip_qs), var_raw.data_ptr(), self._v("ybar", (1,)).data_ptr(),
                      self._v("s2bar", (1,)).data_ptr(), d_enc.data_ptr(), sx)
-                d_enc = d_enc.to(self.ndt)
+                d_enc = self._to_net(d_enc, stream=sx)
                 a6 = a[5].view(b, 1024)
                 self._gemm(1, 0, 1024, 2 * L, b, 1.0, a6, 1024, d_enc, 2 * L, 0.0, gn["enc_d_w"], 2 * L, stream=sx)
-                gn["enc_d_b"].copy_(d_enc.sum(0))
+                self._colsum(d_enc, b, 2 * L, gn["enc_d_b"], stream=sx)
                 dxe = torch.empty(b, 8, 8, 16, **nd)
                 self._gemm(0, 1, b, 1024, 2 * L, 1.0, d_enc, 2 * L, pn["enc_d_w"], 2 * L, 0.0, dxe, 1024, stream=sx)
                 for i in range(6, 0, -1):
                     xin = a[i - 2] if i > 1 else images
                     dxe = self.enc[i - 1].backward(xin, pn[f"enc_c{i}_w"], a[i - 1], dxe, gn[f"enc_c{i}_w"], gn[f"enc_c{i}_b"],
-                                                   scratch, sx, need_dx=i > 1, nwg=self.nwg)
+                                                   self.lscratch[("enc", i)], sx, need_dx=i > 1, nwg=self.nwg, deferred=deferred)
 
             if enc_side:
                 self.side.wait_stream(self.stream)
@@ -590,19 +632,24 @@ class SpritesStepEngine:
             self._mark("nets_bwd_enc")
             d_rvec = torch.empty(b, self.Lc, **f64)
             call("svgp_sprites_aux_bwd", b, self.seg_len, self.Lc, d_char.data_ptr(), d_rvec.data_ptr(), s)
-            d_rvec = d_rvec.to(self.ndt)
+            d_rvec = self._to_net(d_rvec)
             dx = torch.empty(b, 8, 8, self.Lc, **nd)
             call("svgp_avgpool_bwd" + sfx, b, 64, self.Lc, d_rvec.data_ptr(), dx.data_ptr(), s)
             for i in range(3, 0, -1):
                 xin = r[i - 2] if i > 1 else images
                 dx = self.rep[i - 1].backward(xin, pn[f"repr_c{i}_w"], r[i - 1], dx, gn[f"repr_c{i}_w"], gn[f"repr_c{i}_b"],
-                                              self.scratch, s, need_dx=i > 1, nwg=self.nwg)
+                                              self.lscratch[("rep", i)], s, need_dx=i > 1, nwg=self.nwg, deferred=deferred)
             if enc_side:
                 self.stream.wait_stream(self.side)
             else:
                 encoder_bwd(s, self.scratch)
+            # every layer's weight / bias partial sums in one launch, then the folds of the up layers' effective-weight gradients;
+            # the per-step weight layouts are dropped (the parameters change in the optimiser step below)
+            deferred.flush(s)
+            for lay in self.enc + self.dec + self.rep:
+                lay._prep = None
             if self.f32:                                       # float32 network gradients -> the float64 gradient vector
-                self.grad[:self.n_net].copy_(self.grad_n)
+                call("svgp_cast_f32_f64", self.n_net, self.grad_n.data_ptr(), self.grad.data_ptr(), s)
             # frozen parameter groups (inverted flags of SPRITES_experiment.py:109-111)
             if getattr(self, "freeze_repr", False):           # --repr_nn_pretrain yes_fixed (SPRITES_experiment.py:214-216)
                 for k in g:
@@ -627,7 +674,7 @@ class SpritesStepEngine:
             else:
                 call("svgp_elbo_finalize_noadam", cp, ws, st, s)
             self._mark("end")
-            self.act = dict(recon=recon.double() if self.f32 else recon, aux=aux, enc=enc)
+            self.act = dict(recon=recon.double() if self.f32 else recon, aux=aux, enc=enc)     # (outputs(): not on the step's path)
 
     def outputs(self):
         """The 16-tuple of forward_pass_SVGPVAE for the last step (mean_vectors slot = aux data)."""

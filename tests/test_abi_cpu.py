@@ -191,11 +191,11 @@ def test_ctypes_mirrors_follow_the_header_field_for_field():
         assert [_CT[t] for t, _ in want] == [t for _, t in got], cname
     # array members: names + order only
     for cname, cls in (("svgp_conv_desc", _lib.ConvDesc), ("svgp_stream_kdesc", _lib.StreamKdesc),
-                       ("svgp_pearce_bufs", _lib.PearceBufs)):
+                       ("svgp_pearce_bufs", _lib.PearceBufs), ("svgp_sum_job", _lib.SumJob)):
         assert [f for _, f in _header_struct_fields(cname)] == [n for n, _ in cls._fields_], cname
     lib = svgp_vae_amd.load_library()
     for which, cls in enumerate((_lib.MnistCfg, _lib.ParamLayout, _lib.WsLayout, _lib.StreamKdesc, _lib.ConvDesc,
-                                 _lib.SpritesKcfg, _lib.PearceBufs)):
+                                 _lib.SpritesKcfg, _lib.PearceBufs, _lib.SumJob)):
         assert lib.svgp_struct_sizeof(which) == C.sizeof(cls), cls.__name__
     assert lib.svgp_struct_sizeof(99) == -1
     # the INTEGRATION.md stub: executed as written (minus the CDLL / call lines) it must define the same structure

@@ -69,7 +69,7 @@ def test_conv16_direct_kernels_float32(Hi, Ci, Co, k, stride, padding, up, elu):
     dout = gout.to(dev, F32).clone()
     ggw = torch.zeros(k, k, Ci, Co, dtype=F32, device=dev)
     ggb = torch.zeros(Co, dtype=F32, device=dev)
-    scratch = torch.zeros(lay.scratch_elems(64), dtype=F32, device=dev)
+    scratch = torch.full((lay.scratch_elems(64),), float('nan'), dtype=F32, device=dev)      # every partial that is summed must have been written
     gdx = lay.backward(dx_, dw_, out64, dout, ggw, ggb, scratch, s, nwg=64)
     torch.cuda.synchronize()
     assert rel(ggb, gb) < 2e-5 and rel(ggw, gw) < 2e-5 and rel(gdx, gx) < 2e-5
@@ -102,7 +102,7 @@ def test_conv_layer_forward_and_gradients(Hi, Ci, Co, k, stride, padding, up, el
     dout = gout.to(dev).clone()
     ggw = torch.zeros(k, k, Ci, Co, dtype=DT, device=dev)
     ggb = torch.zeros(Co, dtype=DT, device=dev)
-    scratch = torch.zeros(lay.scratch_elems(64), dtype=DT, device=dev)
+    scratch = torch.full((lay.scratch_elems(64),), float('nan'), dtype=DT, device=dev)       # every partial that is summed must have been written
     gdx = lay.backward(dx_, dw_, out, dout, ggw, ggb, scratch, s, nwg=64)
     torch.cuda.synchronize()
     assert rel(ggb, gb) < 1e-11

@@ -41,7 +41,7 @@ int svgp_check_cfg(const svgp_mnist_cfg* c) {
                  "bad shape m=%d L=%d M=%d n_obj=%d", c->m, c->L, c->M, c->n_obj);
     SVGP_REQUIRE(c->m <= SVGP_M_LIMIT, SVGP_ERR_UNSUPPORTED,
                  "m=%d inducing points: this build supports m <= %d", c->m, SVGP_M_LIMIT);
-    SVGP_REQUIRE(c->M <= 32, SVGP_ERR_UNSUPPORTED, "M=%d: object-vector dimension > 32 not supported", c->M);
+    SVGP_REQUIRE(c->M <= 128, SVGP_ERR_UNSUPPORTED, "M=%d: object-vector dimension > 128 not supported", c->M);
     SVGP_REQUIRE(c->L <= 64, SVGP_ERR_UNSUPPORTED, "L=%d: more than 64 latent channels not supported", c->L);
     SVGP_REQUIRE(c->N_train > 0 && c->jitter >= 0, SVGP_ERR_INVALID, "bad N_train / jitter");
     SVGP_REQUIRE(c->kl_form == 0 || c->kl_form == 1, SVGP_ERR_INVALID, "kl_form=%d (0 or 1)", c->kl_form);

@@ -269,8 +269,10 @@ __device__ __forceinline__ void svgp_km_fwd_element(const SvgpKernArgs& a, long 
     }
 }
 
+// dynamic LDS of the scatter workgroups: the 256 staged d_on rows while M <= 32 (64 KB); wider rows are read from global memory
+static inline size_t svgp_km_scatter_lds(int M) { return M <= 32 ? (size_t)256 * M * sizeof(real) : 0; }
 // Object-table scatter of the kernel-matrix VJP, one workgroup of SVGP_BLOCK threads (dynamic LDS: 256 * M doubles at
-// `dbuf`).  Workgroups [0, nblk - 1): element o = blk * 256 + tid of the (n_obj, M) table gradient = sum of the d_on
+// `dbuf`, M <= 32).  Workgroups [0, nblk - 1): element o = blk * 256 + tid of the (n_obj, M) table gradient = sum of the d_on
 // rows whose id matches, in row order (duplicate ids sum deterministically): per chunk of 256 staged rows a bit mask per
 // table row is built with LDS atomicOr and walked with ffs.  Workgroup nblk - 1: the amplitude / length-scale partial sums.
 __device__ __forceinline__ void svgp_km_scatter_block(int blk, int nblk, int b, int M, int n_obj,
@@ -299,7 +301,8 @@ __device__ __forceinline__ void svgp_km_scatter_block(int blk, int nblk, int b, 
         const int cnt = min(256, b - n0);
         __syncthreads();
         for (int t = threadIdx.x; t < 256 * 8; t += blockDim.x) (&mask[0][0])[t] = 0u;
-        for (int t = threadIdx.x; t < cnt * M; t += blockDim.x) dbuf[t] = d_on[(size_t)n0 * M + t];
+        if (M <= 32)
+            for (int t = threadIdx.x; t < cnt * M; t += blockDim.x) dbuf[t] = d_on[(size_t)n0 * M + t];
         __syncthreads();
         // set bits are order-independent (atomicOr), the sums below walk them in increasing row order: the result
         // is the row-order sum whatever the execution order
@@ -314,7 +317,7 @@ __device__ __forceinline__ void svgp_km_scatter_block(int blk, int nblk, int b, 
                 unsigned bits = mask[r - r_first][w];
                 while (bits) {
                     const int n = w * 32 + __ffs(bits) - 1;
-                    acc += dbuf[n * M + k];
+                    acc += M <= 32 ? dbuf[n * M + k] : d_on[(size_t)(n0 + n) * M + k];
                     bits &= bits - 1;
                 }
             }

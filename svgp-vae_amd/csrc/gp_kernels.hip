@@ -244,6 +244,8 @@ __device__ __forceinline__ real chol_inv(real* A, real* W, int ld, int m) {
 // kernel matrices  (SVGPVAE_model.py:427-476; TFP ExpSinSquared x Linear)
 // =============================================================================================
 typedef SvgpKernArgs KernArgs;
+// the batch-row side of the VJP keeps the m x M inducing object vectors in LDS while they fit in 96 KB (config 3: 64 KB)
+__host__ __device__ __forceinline__ bool km_stage_O(int m, int M) { return (size_t)m * M * sizeof(real) <= 96 * 1024; }
 __device__ __forceinline__ const real* obj_row(const KernArgs& a, int n) { return svgp_obj_row(a, n); }
 __device__ __forceinline__ real view_k(real d, real a2, real inv_l2) { return svgp_view_k(d, a2, inv_l2); }
 __device__ __forceinline__ real dotM(const real* x, const real* y, int M) { return svgp_dotM(x, y, M); }
@@ -278,80 +280,84 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_xy(KernXYArgs a, r
 // VJP, inducing side: one workgroup per inducing point j.
 // d_ip[j] = [0, d_theta_j, d_o_j], partial amplitude / length-scale sums -> part_gp[j].
 #define KM_MAXM 32
+#define KM_MTOT 128            // GPLVM dimension limit of this build (api.hip): the feature index is walked in chunks of KM_MAXM
 // MC / MM: compile-time m / GPLVM dimension M (0: run time); config 2 runs the <32, 8> instance (8 instead of 32 predicated
-// accumulators per thread, index divisions folded)
+// accumulators per thread, index divisions folded).  M > 32 (a kernel matrix of rank m needs M >= m / 16 object
+// dimensions -- m = 2048 wants M = 128): the row / column loops are repeated per chunk of 32 feature columns, 32 accumulators live.
 template <int MC, int MM>
 __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real rep_weight, int train_ip,
                                             const real* __restrict__ K, const real* __restrict__ Kn,
                                             const real* __restrict__ Kbar, const real* __restrict__ Knbar,
                                             real* __restrict__ d_ip, real* __restrict__ part_gp) {
-    __shared__ real res[KM_MAXM + 4];
+    __shared__ real res[KM_MTOT + 4];                      // [0, M): object-vector gradient; KM_MTOT + {0, 1, 2}: amp, ls, theta
+    __shared__ real wred[SVGP_BLOCK / 64][KM_MAXM + 4];
     const int M = MM ? MM : a.M, m = MC ? MC : a.m, st = 2 + M;
     const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
     const real* oj = a.ip + (size_t)j * st + 2;
     const real thj = a.ip[(size_t)j * st + 1];
     const real nj = a.normalize ? sqrt(dotM(oj, oj, M)) : real(1);
-    real acc_amp = 0, acc_ls = 0, acc_th = 0, acc_o[KM_MAXM];
+    for (int k0 = 0; k0 < M; k0 += KM_MAXM) {
+        const int Mc = M - k0 < KM_MAXM ? M - k0 : KM_MAXM;
+        real acc_amp = 0, acc_ls = 0, acc_th = 0, acc_o[KM_MAXM];
 #pragma unroll
-    for (int k = 0; k < KM_MAXM; ++k) acc_o[k] = 0;
-    // ---- K_nm column j
-    for (int n = threadIdx.x; n < a.b; n += blockDim.x) {
-        const real gk = Knbar[(size_t)n * m + j];
-        const real d = a.aux[(size_t)n * st + 1] - thj;
-        const real V = view_k(d, a2, inv_l2);
-        const real G = gk * Kn[(size_t)n * m + j];
-        const real sh = sin(real(0.5) * d);
-        acc_amp += G;
-        acc_ls += G * sh * sh;
-        acc_th += G * sin(d);
-        const real* on = obj_row(a, n);
-        const real c = gk * V / (a.normalize ? sqrt(dotM(on, on, M)) : real(1));
+        for (int k = 0; k < KM_MAXM; ++k) acc_o[k] = 0;
+        // ---- K_nm column j
+        for (int n = threadIdx.x; n < a.b; n += blockDim.x) {
+            const real gk = Knbar[(size_t)n * m + j];
+            const real d = a.aux[(size_t)n * st + 1] - thj;
+            const real V = view_k(d, a2, inv_l2);
+            const real G = gk * Kn[(size_t)n * m + j];
+            const real sh = sin(real(0.5) * d);
+            acc_amp += G;
+            acc_ls += G * sh * sh;
+            acc_th += G * sin(d);
+            const real* on = obj_row(a, n);
+            const real c = gk * V / (a.normalize ? sqrt(dotM(on, on, M)) : real(1));
 #pragma unroll
-        for (int k = 0; k < KM_MAXM; ++k)
-            if (k < M) acc_o[k] += c * on[k];
-    }
-    // ---- K_mm: row j (first argument) and column j (second argument), replicated across ranks
-    for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        const real* oi = a.ip + (size_t)i * st + 2;
-        const real ni = a.normalize ? sqrt(dotM(oi, oi, M)) : real(1);
-        const real d = thj - a.ip[(size_t)i * st + 1];          // theta_j - theta_i  (entry (j,i))
-        const real V = view_k(d, a2, inv_l2);                   // even in d
-        const real sh = sin(real(0.5) * d);
-        const real g_ji = rep_weight * Kbar[(size_t)j * m + i], g_ij = rep_weight * Kbar[(size_t)i * m + j];
-        const real G_ji = g_ji * K[(size_t)j * m + i], G_ij = g_ij * K[(size_t)i * m + j];
-        acc_amp += G_ji;
-        acc_ls += G_ji * sh * sh;
-        // entry (j,i): dK/dtheta_j = -K sin(d);  entry (i,j): dK/dtheta_j = +K sin(theta_i - theta_j) = -K sin(d)
-        acc_th += -(G_ji + G_ij) * sin(d);
-        const real c = (g_ji + g_ij) * V / ni;
+            for (int k = 0; k < KM_MAXM; ++k)
+                if (k < Mc) acc_o[k] += c * on[k0 + k];
+        }
+        // ---- K_mm: row j (first argument) and column j (second argument), replicated across ranks
+        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+            const real* oi = a.ip + (size_t)i * st + 2;
+            const real ni = a.normalize ? sqrt(dotM(oi, oi, M)) : real(1);
+            const real d = thj - a.ip[(size_t)i * st + 1];          // theta_j - theta_i  (entry (j,i))
+            const real V = view_k(d, a2, inv_l2);                   // even in d
+            const real sh = sin(real(0.5) * d);
+            const real g_ji = rep_weight * Kbar[(size_t)j * m + i], g_ij = rep_weight * Kbar[(size_t)i * m + j];
+            const real G_ji = g_ji * K[(size_t)j * m + i], G_ij = g_ij * K[(size_t)i * m + j];
+            acc_amp += G_ji;
+            acc_ls += G_ji * sh * sh;
+            // entry (j,i): dK/dtheta_j = -K sin(d);  entry (i,j): dK/dtheta_j = +K sin(theta_i - theta_j) = -K sin(d)
+            acc_th += -(G_ji + G_ij) * sin(d);
+            const real c = (g_ji + g_ij) * V / ni;
 #pragma unroll
-        for (int k = 0; k < KM_MAXM; ++k)
-            if (k < M) acc_o[k] += c * oi[k];
-    }
-    // one combined reduction: wave sums -> LDS [wave][3+M] -> thread v sums the waves (fixed order)
-    __shared__ real wred[SVGP_BLOCK / 64][KM_MAXM + 4];
-    {
+            for (int k = 0; k < KM_MAXM; ++k)
+                if (k < Mc) acc_o[k] += c * oi[k0 + k];
+        }
+        // one combined reduction per chunk: wave sums -> LDS [wave][3+Mc] -> thread v sums the waves (fixed order)
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        __syncthreads();                                           // (wred of the previous chunk has been read)
         real t = wave_sum(acc_amp); if (lane == 0) wred[wv][KM_MAXM] = t;
         t = wave_sum(acc_ls);       if (lane == 0) wred[wv][KM_MAXM + 1] = t;
         t = wave_sum(acc_th);       if (lane == 0) wred[wv][KM_MAXM + 2] = t;
 #pragma unroll
         for (int k = 0; k < KM_MAXM; ++k)
-            if (k < M) { t = wave_sum(acc_o[k]); if (lane == 0) wred[wv][k] = t; }
+            if (k < Mc) { t = wave_sum(acc_o[k]); if (lane == 0) wred[wv][k] = t; }
         __syncthreads();
-        if (threadIdx.x < KM_MAXM + 3 && (threadIdx.x < M || threadIdx.x >= KM_MAXM)) {
+        if (threadIdx.x < KM_MAXM + 3 && (threadIdx.x < Mc || (threadIdx.x >= KM_MAXM && k0 == 0))) {
             real sres = 0;
             for (int wq = 0; wq < (int)(blockDim.x >> 6); ++wq) sres += wred[wq][threadIdx.x];
-            res[threadIdx.x] = sres;
+            res[threadIdx.x < KM_MAXM ? k0 + threadIdx.x : KM_MTOT + (threadIdx.x - KM_MAXM)] = sres;
         }
-        __syncthreads();
     }
+    __syncthreads();
     if (threadIdx.x == 0) {
-        part_gp[j * 2 + 0] = real(2) * res[KM_MAXM] / amp;                         // d amplitude
-        part_gp[j * 2 + 1] = real(4) * res[KM_MAXM + 1] / (ls * ls * ls);          // d length scale
+        part_gp[j * 2 + 0] = real(2) * res[KM_MTOT] / amp;                         // d amplitude
+        part_gp[j * 2 + 1] = real(4) * res[KM_MTOT + 1] / (ls * ls * ls);          // d length scale
         real* out = d_ip + (size_t)j * st;
         out[0] = 0;
-        out[1] = train_ip ? res[KM_MAXM + 2] * inv_l2 : real(0);
+        out[1] = train_ip ? res[KM_MTOT + 2] * inv_l2 : real(0);
         // res[k] is the gradient w.r.t. the (normalised) o_j direction: d_oh; chain through o/|o|
         real proj = 0;
         if (a.normalize)
@@ -374,15 +380,25 @@ __device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, c
     extern __shared__ __align__(16) real smem[];
     __shared__ real red[16];
     const int m = MC ? MC : a.m, M = MM ? MM : a.M, st = 2 + M, RB = m >= (int)blockDim.x ? 1 : blockDim.x / m;
-    real* O = smem;                 // m x M inducing object vectors, divided by their norm when normalising
-    real* cbuf = O + m * M;         // RB x m
-    real* gbuf = cbuf + RB * m;     // RB x M (<= 256*32/m ... bounded by RB*M <= 8192/m*... see host check)
+    // m x M inducing object vectors, divided by their norm when normalising: staged in LDS while they fit (km_stage_O, the
+    // host sizes the launch with the same rule); else read from the parameter vector with the inverse norms (m) staged
+    const bool stage_O = km_stage_O(m, M);
+    real* O = smem;
+    real* cbuf = O + (stage_O ? m * M : m);     // RB x m
+    real* gbuf = cbuf + RB * m;                 // RB x M
     const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
-    for (int o = threadIdx.x; o < m * M; o += blockDim.x) {
-        const int j = o / M;
-        const real* oj = a.ip + (size_t)j * st + 2;
-        const real nj = a.normalize ? sqrt(dotM(oj, oj, M)) : real(1);
-        O[o] = oj[o % M] / nj;
+    if (stage_O) {
+        for (int o = threadIdx.x; o < m * M; o += blockDim.x) {
+            const int j = o / M;
+            const real* oj = a.ip + (size_t)j * st + 2;
+            const real nj = a.normalize ? sqrt(dotM(oj, oj, M)) : real(1);
+            O[o] = oj[o % M] / nj;
+        }
+    } else {
+        for (int j = threadIdx.x; j < m; j += blockDim.x) {
+            const real* oj = a.ip + (size_t)j * st + 2;
+            O[j] = a.normalize ? real(1) / sqrt(dotM(oj, oj, M)) : real(1);
+        }
     }
     for (int it = threadIdx.x; it < RB * m; it += blockDim.x) {
         const int nl = it / m, j = it % m, n = rblk * RB + nl;
@@ -396,7 +412,8 @@ __device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, c
         const int nl = it / M, k = it % M, n = rblk * RB + nl;
         real g = 0;
         if (n < a.b) {
-            for (int j = 0; j < m; ++j) g += cbuf[nl * m + j] * O[j * M + k];
+            if (stage_O) for (int j = 0; j < m; ++j) g += cbuf[nl * m + j] * O[j * M + k];
+            else for (int j = 0; j < m; ++j) g += cbuf[nl * m + j] * (a.ip[(size_t)j * st + 2 + k] * O[j]);
             const real* on = obj_row(a, n);
             const real nn = a.normalize ? sqrt(dotM(on, on, M)) : real(1);
             g += real(2) * a2 * knnbar[n] * on[k] / nn;      // k_nn = a^2 |o_hat|^2
@@ -1234,7 +1251,7 @@ static int kernel_matrix_bwd_impl(const svgp_mnist_cfg* c, const double* theta, 
     KernArgs a = make_kern_args(c, pl, theta, aux);
     real* grad = ws + wl.grad;
     const int RBk = svgp_rows_per_block(c), nrb = (c->b + RBk - 1) / RBk;
-    const size_t lds_rows = (size_t)(c->m * c->M + RBk * c->m + RBk * c->M) * sizeof(real);
+    const size_t lds_rows = (size_t)((km_stage_O(c->m, c->M) ? c->m * c->M : c->m) + RBk * c->m + RBk * c->M) * sizeof(real);
     const bool cfg2_shape = c->m == 32 && c->M == 8, cfg3_shape = c->m == 256 && c->M == 32;
     {
         int rc_ = cfg2_shape ? set_dyn_lds(k_kernel_matrix_bwd_cr<32, 8>, lds_rows)
@@ -1255,7 +1272,7 @@ static int kernel_matrix_bwd_impl(const svgp_mnist_cfg* c, const double* theta, 
     if (scatter) {
         const int n_ov = c->n_obj * c->M;
         hipLaunchKernelGGL(k_kernel_matrix_bwd_scatter, dim3((n_ov + SVGP_BLOCK - 1) / SVGP_BLOCK + 1), dim3(SVGP_BLOCK),
-                           (size_t)256 * c->M * sizeof(real), (hipStream_t)stream, a, c->m + nrb, c->train_gp, c->train_ov,
+                           svgp_km_scatter_lds(c->M), (hipStream_t)stream, a, c->m + nrb, c->train_gp, c->train_ov,
                            ws + wl.d_on, ws + wl.part_gp, grad + pl.ov, grad + pl.l_GP, grad + pl.amplitude);
         SVGP_LAUNCH_CHECK();
     }

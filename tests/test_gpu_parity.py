@@ -148,7 +148,7 @@ def test_config2_real_data_step(golden, geco):
 
 
 @pytest.mark.parametrize("case", ["normalize", "no_table", "no_clip", "m64", "b1", "ragged210", "m_odd", "b1300",
-                                  "m72_large_path", "m130_large_path", "cfg3_m256"])
+                                  "m72_large_path", "m130_large_path", "cfg3_m256", "M40_normalize", "m512_M64", "m96_M128"])
 def test_edge_cases(case):
     kw = dict(geco=False, N_train=500.0)
     if case == "normalize":

@@ -564,6 +564,10 @@ static int potrf_impl(int m, int batch, double* A, int lda, long long strideA, d
     const bool la = la_on && m >= 640;            // (below, the fork / join per block step costs more than it hides: 512 x 16 553 -> 578 us)
     void* side = stream;
     bool side_open = false;
+    struct JoinGuard {           // an error return inside the loop must not leave the look-ahead branch forked
+        void* st; bool* open;
+        ~JoinGuard() { if (*open) (void)svgp_side_branch_join(st, 0); }
+    } join_guard{stream, &side_open};
     for (int kb = 0; kb < nstep; ++kb) {
         const int r0 = kb * W, nbk = m - r0 < W ? m - r0 : W, rem = m - r0 - nbk;
         real* Pn = Pn2 + (size_t)(kb & 1) * batch * m * W;
@@ -583,7 +587,9 @@ static int potrf_impl(int m, int batch, double* A, int lda, long long strideA, d
         if (rem == 0) break;
         real* panel = A + (size_t)(r0 + nbk) * lda + r0;        // A[r0+nbk:, r0:r0+nbk]
         real* trail = A + (size_t)(r0 + nbk) * lda + r0 + nbk;
-        // L_ik = A_ik L_kk^-T   (the inverse stored row-major: B^T form)
+        // L_ik = A_ik L_kk^-T   (the inverse stored row-major: B^T form) into the contiguous panel copy Pn the updates read, then
+        // back into the matrix.  (Not as a second output of the product: with the 64-wide tiles this short contraction takes, two
+        // tile columns span the panel and one would overwrite operand columns the other is still reading.)
         RUNC(svgp_dgemm_tri_batched(0, 0, 1, rem, nbk, nbk, 1.0, panel, lda, strideA, Lk, ldk, sLk, 0.0, Pn, W, (long long)m * W,
                                     batch, stream));
         hipLaunchKernelGGL(k_copy_block, dim3(nblk256((long long)rem * nbk), batch), dim3(256), 0, s, rem, nbk, Pn, W,
@@ -591,14 +597,14 @@ static int potrf_impl(int m, int batch, double* A, int lda, long long strideA, d
         SVGP_LAUNCH_CHECK();
         const int nb1 = rem < W ? rem : W, rem2 = rem - nb1;     // next block column / what lies beyond it
         if (!la || rem2 == 0) {
-            if (side_open) { RUNC(svgp_side_branch_join(stream, 0)); side_open = false; }
+            if (side_open) { side_open = false; RUNC(svgp_side_branch_join(stream, 0)); }
             // A_ij -= L_ik L_jk^T on the tiles that touch the lower triangle
             RUNC(svgp_dgemm_tri_batched(1, 0, 1, rem, rem, nbk, -1.0, Pn, W, (long long)m * W, Pn, W, (long long)m * W, 1.0,
                                         trail, lda, strideA, batch, stream));
             continue;
         }
         // the previous step's side update wrote column k + 1 too: it must be complete before this step's column update
-        if (side_open) RUNC(svgp_side_branch_join(stream, 0));
+        if (side_open) { side_open = false; RUNC(svgp_side_branch_join(stream, 0)); }
         // column k + 1 (rows r1 .., nb1 columns): A[r1:, r1:r1+nb1] -= Pn[r1-rows] Pn[block k + 1 rows]^T
         RUNC(svgp_dgemm_tri_batched(1, 0, 1, rem, nb1, nbk, -1.0, Pn, W, (long long)m * W, Pn, W, (long long)m * W, 1.0,
                                     trail, lda, strideA, batch, stream));
@@ -609,7 +615,7 @@ static int potrf_impl(int m, int batch, double* A, int lda, long long strideA, d
                                     Pn + (size_t)nb1 * W, W, (long long)m * W, 1.0, trail + (size_t)nb1 * lda + nb1, lda, strideA,
                                     batch, side));
     }
-    if (side_open) RUNC(svgp_side_branch_join(stream, 0));
+    if (side_open) { side_open = false; RUNC(svgp_side_branch_join(stream, 0)); }
     if (band) hipLaunchKernelGGL(k_zero_band, dim3(nblk256((long long)m * ZBAND), batch), dim3(256), 0, s, m, lda, strideA, A);
     else hipLaunchKernelGGL(k_zero_upper, dim3(nblk256((long long)m * m), batch), dim3(256), 0, s, m, lda, strideA, A);
     SVGP_LAUNCH_CHECK();

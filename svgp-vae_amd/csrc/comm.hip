@@ -178,6 +178,8 @@ extern "C" int svgp_comm_destroy(void* comm) {
     if (rc) return rc;
     Comm* c = (Comm*)comm;
     ncclResult_t e = r->CommDestroy(c->comm);
+    for (int k = 0; k < 2 * SVGP_COMM_MAX_POINTS; ++k)          // the timing events of svgp_comm_timing
+        if (c->ev[k]) (void)hipEventDestroy(c->ev[k]);
     delete c;
     SVGP_REQUIRE(e == ncclSuccess, SVGP_ERR_COMM, "ncclCommDestroy failed: %s", r->GetErrorString(e));
     return SVGP_OK;
@@ -332,6 +334,21 @@ struct Point {
 // (measured with a 1-rank communicator at m = 256, L = 16: the pack / unpack launches cost ~100 us per step, the 44 % of 8.4 MB
 // they take off each of the four points is worth ~15 us apiece on xGMI; at m = 800, L = 64 a point is 328 MB)
 bool dp_pack_default(int m) { return m >= 512; }
+// Whatever way svgp_mnist_train_step_dp returns, an RCCL group it opened is closed and a side branch it forked is joined
+// (an error inside a group left ncclGroup depth above zero -- every later RCCL call of the thread deferred --, an
+// error behind the fork an unjoined branch, which under stream capture is an unjoined capture).
+struct DpGuard {
+    void* comm; void* stream;
+    bool group = false, forked = false;
+    int begin_group() { int rc = svgp_comm_group_begin(comm); group = rc == SVGP_OK; return rc; }
+    int end_group() { group = false; return svgp_comm_group_end(comm); }
+    int fork(void** side) { int rc = svgp_side_branch_fork(stream, side); forked = rc == SVGP_OK; return rc; }
+    int join() { forked = false; return svgp_side_branch_join(stream); }
+    ~DpGuard() {
+        if (group) (void)svgp_comm_group_end(comm);
+        if (forked) (void)svgp_side_branch_join(stream);
+    }
+};
 }  // namespace
 
 extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, double* theta, const double* images,
@@ -345,6 +362,7 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     const int G = cm->nranks, L = c->L, m = c->m;
     const bool sharded = m > SVGP_M_MAX && L % G == 0 && !c->titsias && !c->kl_form;
     Point pt{cm, (hipStream_t)stream, -1};
+    DpGuard guard{comm, stream};
     if (cm->timing) cm->npoints = 0;
 #define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
     if (!sharded) {
@@ -384,10 +402,10 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     // ---- point 1: reduce-scatter [S | v] over the channels
     RUN(pt.begin());
     if (pack) RUN(svgp_sym_pack(m, L, 0, ws + wl.S, xp0, stream));
-    RUN(svgp_comm_group_begin(comm));
+    RUN(guard.begin_group());
     RUN(rs_sym(ws + wl.S, xp0));
     RUN(rs(comm, ws + wl.v, Lm, G, stream));
-    RUN(svgp_comm_group_end(comm));
+    RUN(guard.end_group());
     if (pack) RUN(svgp_sym_unpack(m, nl, xp0 + (size_t)l0 * pe, ws + wl.S + (size_t)l0 * mm, stream));
     RUN(pt.end());
     // window factor stage without its tail
@@ -403,12 +421,12 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     // collective's kernel waits for a slot -- with a 1-rank communicator the point measured 245 us at config 3 for a no-op
     // gather (round 3: 260 us), and the row stage on the caller's stream waits behind it.
     void* side = stream;
-    if (fork) RUN(svgp_side_branch_fork(stream, &side));
-    RUN(svgp_comm_group_begin(comm));
+    if (fork) RUN(guard.fork(&side));
+    RUN(guard.begin_group());
     RUN(ag_sym(ws + wl.Si, xp0));
     RUN(ag(comm, ws + wl.t, Lm, G, stream));
     RUN(ag(comm, ws + wl.u, Lm, G, stream));
-    RUN(svgp_comm_group_end(comm));
+    RUN(guard.end_group());
     if (pack) {                                  // the other ranks' windows (the branch reads the rank's own window only)
         const int hi0 = l0 + nl, nhi = L - hi0;
         RUN(svgp_sym_unpack(m, l0, xp0, ws + wl.Si, stream));
@@ -424,15 +442,15 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     // ---- point 3: reduce-scatter [A2 | ud | td]
     RUN(pt.begin());
     if (pack) RUN(svgp_sym_pack(m, L, 0, ws + wl.A2, xp0, stream));
-    RUN(svgp_comm_group_begin(comm));
+    RUN(guard.begin_group());
     RUN(rs_sym(ws + wl.A2, xp0));
     RUN(rs(comm, ws + wl.ud, Lm, G, stream));
     RUN(rs(comm, ws + wl.td, Lm, G, stream));
-    RUN(svgp_comm_group_end(comm));
+    RUN(guard.end_group());
     if (pack) RUN(svgp_sym_unpack(m, nl, xp0 + (size_t)l0 * pe, ws + wl.A2 + (size_t)l0 * mm, stream));
     RUN(pt.end());
     if (fork) {
-        RUN(svgp_side_branch_join(stream));
+        RUN(guard.join());
         RUN(svgp_big_factor_bwd(&cc, wl, ws, state, stream, l0, nl, 2));
     } else {
         RUN(svgp_big_factor_bwd(&cc, wl, ws, state, stream, l0, nl, 0));
@@ -440,11 +458,11 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     // ---- point 4: all-gather [Ssym | vbar | KL]
     RUN(pt.begin());
     if (pack) RUN(svgp_sym_pack(m, nl, 0, ws + wl.Ssym + (size_t)l0 * mm, xp0 + (size_t)l0 * pe, stream));
-    RUN(svgp_comm_group_begin(comm));
+    RUN(guard.begin_group());
     RUN(ag_sym(ws + wl.Ssym, xp0));
     RUN(ag(comm, ws + wl.vbar, Lm, G, stream));
     RUN(ag(comm, ws + wl.KL, L, G, stream));
-    RUN(svgp_comm_group_end(comm));
+    RUN(guard.end_group());
     if (pack) RUN(svgp_sym_unpack(m, L, xp0, ws + wl.Ssym, stream));
     RUN(pt.end());
     RUN(svgp_gp_posterior_bwd(&cc, ws, state, stream));

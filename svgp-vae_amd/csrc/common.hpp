@@ -124,20 +124,20 @@ static inline int svgp_n_post_actual(const svgp_mnist_cfg* c) {
 int svgp_spd_inverse_fused(int m, int nmain, double* A, double* logdet, int nextra, double* Ae, double* logdet_e,
                            double* work, void* stream);
 
-int svgp_dgemm_tri_batched(int tri, int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
-                           long long strideA, const double* B, int ldb, long long strideB, double beta, double* C, int ldc,
-                           long long strideC, int batch, void* stream);
-
 // Extended GEMM epilogue (float64 storage), applied per stored element of the output tile:
-//   C  = alpha acc + beta C + g1 E + d1 I          C2 = a2 acc + g2 E + d2 I   (optional second output, leading dimension ldc)
+//   C  = alpha acc + beta C + g1 E + d1 I          C2 = a2 acc + g2 E + d2 I   (optional second output, leading dimension ldc2)
 // E: extra matrix (leading dimension lde, batch stride se: 0 = shared by the batch); with the mirrored store of a symmetric
 // product E is read at the mirrored position.  Replaces the element-wise passes over (L, m, m) arrays of the large-m GP block.
 struct svgp_gemm_epi {
     const double* E = nullptr; int lde = 0; long long se = 0;
     double g1 = 0, d1 = 0;
-    double* C2 = nullptr; long long sc2 = 0;
+    double* C2 = nullptr; long long sc2 = 0; int ldc2 = 0;      // ldc2 = 0: the leading dimension of C
     double a2 = 0, g2 = 0, d2 = 0;
 };
+int svgp_dgemm_tri_batched(int tri, int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
+                           long long strideA, const double* B, int ldb, long long strideB, double beta, double* C, int ldc,
+                           long long strideC, int batch, void* stream, const svgp_gemm_epi* epi = nullptr);
+
 // wk (optional): weights of the contraction index, op(B)[k][:] *= wk[k * ldw + l * strideW] while staged (C symmetric iff A = B)
 int svgp_dgemm_symout_batched(int f32c, int ta, int tb, int M, int K, double alpha, const double* A, int lda, long long strideA,
                               const double* B, int ldb, long long strideB, double beta, double* C, int ldc, long long strideC,

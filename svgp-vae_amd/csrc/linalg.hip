@@ -40,7 +40,7 @@ struct GemmArgs {
     // extended epilogue (svgp_gemm_epi, common.hpp; float64 storage): out1 = alpha acc + beta C + g1 E + d1 I -> C,
     // out2 = a2 acc + g2 E + d2 I -> C2 (same leading dimension as C); E: lde, batch stride se (0 = shared)
     int epi_on;
-    const void* E; int lde; long long se; void* C2; long long sc2;
+    const void* E; int lde; long long se; void* C2; long long sc2; int ldc2;
     real g1, d1, a2, g2, d2;
 };
 
@@ -377,12 +377,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
                         const size_t o = (size_t)gi * g.ldc + gj;
                         const real ev = E ? (real)E[(size_t)gi * g.lde + gj] : real(0);
                         C[o] = (TS)(g.alpha * av + (has_beta ? g.beta * (real)C[o] : real(0)) + g.g1 * ev + g.d1 * dd);
-                        if (C2) C2[o] = (TS)(g.a2 * av + g.g2 * ev + g.d2 * dd);
+                        if (C2) C2[(size_t)gi * g.ldc2 + gj] = (TS)(g.a2 * av + g.g2 * ev + g.d2 * dd);
                         if ((g.tri & 16) && i0 != j0) {          // mirror of a below-diagonal tile (never on the diagonal)
                             const size_t oT = (size_t)gj * g.ldc + gi;
                             const real evT = E ? (real)E[(size_t)gj * g.lde + gi] : real(0);
                             C[oT] = (TS)(g.alpha * av + (has_beta ? g.beta * (real)C[oT] : real(0)) + g.g1 * evT);
-                            if (C2) C2[oT] = (TS)(g.a2 * av + g.g2 * evT);
+                            if (C2) C2[(size_t)gj * g.ldc2 + gi] = (TS)(g.a2 * av + g.g2 * evT);
                         }
                     }
                 }
@@ -681,11 +681,12 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     g.sa = strideA; g.sb = strideB; g.sc = strideC; g.alpha = alpha; g.beta = beta; g.A = A; g.B = B; g.C = C;
     g.tri = tri;
     g.wk = wk; g.ldw = ldw; g.sw = strideW;
-    g.epi_on = 0; g.E = nullptr; g.lde = 0; g.se = 0; g.C2 = nullptr; g.sc2 = 0; g.g1 = g.d1 = g.a2 = g.g2 = g.d2 = 0;
+    g.epi_on = 0; g.E = nullptr; g.lde = 0; g.se = 0; g.C2 = nullptr; g.sc2 = 0; g.ldc2 = ldc; g.g1 = g.d1 = g.a2 = g.g2 = g.d2 = 0;
     if (epi) {
         SVGP_REQUIRE(prec != 2, SVGP_ERR_INVALID, "extended GEMM epilogue: float64 storage only");
         SVGP_REQUIRE(epi->E || (epi->g1 == 0 && epi->g2 == 0), SVGP_ERR_INVALID, "extended GEMM epilogue: E is NULL");
         g.epi_on = 1; g.E = epi->E; g.lde = epi->lde; g.se = epi->se; g.C2 = epi->C2; g.sc2 = epi->sc2;
+        g.ldc2 = epi->ldc2 > 0 ? epi->ldc2 : ldc;
         g.g1 = epi->g1; g.d1 = epi->d1; g.a2 = epi->a2; g.g2 = epi->g2; g.d2 = epi->d2;
     }
     //  the mirrored store treats every tile with i0 != j0 as lying strictly below the diagonal: true only for a
@@ -874,8 +875,9 @@ int svgp_dgemm_epi_batched(int f32c, int ta, int tb, int M, int N, int K, double
 // skipped, everything else is computed as usual (excluded operand parts must hold zeros where a tile straddles them)
 int svgp_dgemm_tri_batched(int tri, int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
                            long long strideA, const double* B, int ldb, long long strideB, double beta, double* C, int ldc,
-                           long long strideC, int batch, void* stream) {
-    return gemm_launch(0, tri, ta, tb, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, stream);
+                           long long strideC, int batch, void* stream, const svgp_gemm_epi* epi) {
+    return gemm_launch(0, tri, ta, tb, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch, stream,
+                       nullptr, 0, 0, epi);
 }
 
 // ---- split-K form for one GEMM with few output tiles and a long contraction (the dense layers of the moving-ball

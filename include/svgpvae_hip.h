@@ -127,7 +127,7 @@ typedef struct {
     int64_t Knbar_part;                   /* (L,b,m) per-channel row gradients before the sum     */
     int64_t scr_bm, scr_mm, scr_vec, scr_inv, scr_bl; /* scratch of the large-m (m > 64) path; scr_bm also holds the
                                            * forward products [Kn; W] Si_l, Kn Ki that the reverse pass re-reads */
-    int64_t scr_sm;                       /* m > 64: 9 channel-independent (m,m) matrices (K Ki, Kn^T Wbar, ...)  */
+    int64_t scr_sm;                       /* m > 64: 10 channel-independent (m,m) matrices (K Ki, Kn^T Wbar, ..) */
     int64_t Knbar, knnbar, ybar, s2bar;   /* (b,m) (b) (b,L) (b,L)                                */
     int64_t d_on;                         /* (b,M) gradient of gathered object rows               */
     /* partial sums */

@@ -306,21 +306,22 @@ def gp_factor_bwd_w(K, v, f, A2, SW, ud, td, loc, gT, c, N_train, b_global, rep_
     g3 = gT
     gK = -gT * (b_global / N_train)
     Ki, Si, A, Aji, mu, u, t = (f[k] for k in ('Ki', 'Si', 'A', 'Aji', 'mu', 'u', 't'))
-    PT = K @ Ki                                                   # P^T = K Ki (shared)
-    Gb = PT[None] - K[None] @ Aji                                 # Gbar' = K (Ki - Aji_l)
-    Z = Si @ Gb                                                   # Z' = Si K (Ki - Aji)
-    GbK = Gb @ K[None]                                            # K (Ki - Aji) K (symmetric)
+    G = f['G']                                                    # Si K (forward product)
+    D = Ki[None] - Aji                                            # Abar_l = gK/2 D_l (KL term only: the d-term went to W)
+    H = G @ D                                                     # = Z' = Si K D
+    HG = H @ G.transpose(1, 2)                                    # = Si K D K Si (symmetric)
     ubar = ud + 0.5 * gK * mu
     mubar = 0.5 * gK * u + ubar @ Ki.T
     tbar = td + c * (mubar @ K.T)
     # (the gradient of t = Si v is the rank-one tbar v^T; only the symmetric part of Sg is ever used -- Ssym below, Kbar + Kbar^T in
-    # the kernel-matrix reverse pass -- so Sibar is symmetrised and Sg is a symmetric product: gp_large.hip k_big_fb_sibar)
+    # the kernel-matrix reverse pass -- so it is symmetrised where it is formed: gp_large.hip k_big_fb_sibar)
     tv = torch.einsum('li,lj->lij', tbar, v)
-    Sibar = 0.5 * gK * GbK + A2 - 0.5 * g3 * SW + 0.5 * (tv + tv.transpose(1, 2))
+    X = A2 - 0.5 * g3 * SW + 0.5 * (tv + tv.transpose(1, 2))      # gradient of Si without the share through A_hat = K Si K
     vbar = torch.einsum('lij,lj->li', Si, tbar)
-    Sg = -(Si @ Sibar @ Si)
-    Ssym = c * (Sg + Sg.transpose(1, 2))
-    Zs = Z.sum(0)
+    Sg0 = -(Si @ X @ Si)
+    Sg = Sg0 - 0.5 * gK * HG                                      # -Si (X + gK/2 K D K) Si
+    Ssym = c * (Sg0 + Sg0.transpose(1, 2)) - c * gK * HG
+    Zs = H.sum(0)
     Kb_win = 0.5 * gK * (Zs + Zs.T) + c * torch.einsum('li,lj->ij', mubar, t) + Sg.sum(0)
     Kib_win = 0.5 * gK * A.sum(0) + torch.einsum('li,lj->ij', ubar, mu)
     Kib_loc = loc['Qs'] + loc['Pbar'] @ K                         # q_n = k^T Ki k in d and p_v;  P = Ki K

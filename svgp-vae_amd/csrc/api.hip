@@ -123,8 +123,8 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->scr_bm = take(m > SVGP_M_MAX ? 3 * L * b * m + 2 * b * m : L * b * m); o->scr_mm = take(4 * L * m * m);
     o->scr_vec = take(3 * L * m + 3 * L + 16 + b);
     o->scr_inv = take((int64_t)svgp_spd_inverse_workspace_elems((int)m, (int)L + 1)); o->scr_bl = take(2 * b * L);
-    // m > 64: nine channel-independent m x m matrices of the W form (K Ki, Kn^T Wbar, Kn^T diag(qbar) Kn, channel sums, temporaries)
-    o->scr_sm = take(m > SVGP_M_MAX ? 9 * m * m : 0);
+    // m > 64: ten channel-independent m x m matrices of the W form (K Ki, Kn^T Wbar, Kn^T diag(qbar) Kn, channel sums, temporaries)
+    o->scr_sm = take(m > SVGP_M_MAX ? 10 * m * m : 0);
     o->Knbar = take(b * m); o->knnbar = take(b); o->ybar = take(b * L); o->s2bar = take(b * L);
     o->d_on = take(b * M);
     o->n_part = svgp_n_part(&cc);

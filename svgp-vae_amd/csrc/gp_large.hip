@@ -167,7 +167,7 @@ struct FbArgs {
     const real* SW;                      // W^T diag(p_l) W = P^T S_l P (NULL with cfg.titsias: its seed g3 is zero)
     const real* mu; const real* u; const real* ud; const real* td; const real* v;
     real* ubar; real* mubar; real* tbar;   // (L,m) each; mubar/tbar come in holding Ki ubar / K mubar
-    real* Sibar; const real* Sg; real* Ssym;
+    real* Sibar; const real* Sg; const real* HG; real* Ssym;
 };
 __device__ __forceinline__ void fb_scalars(const FbArgs& a, real& g3, real& gK) {
     const real gT = gradKL(a.geco, a.Ltot, a.state);
@@ -187,7 +187,15 @@ __global__ void k_big_fb_tbar(FbArgs a) {     // tbar = td + c (K mubar)  (tbar 
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.L * a.m) a.tbar[i] = a.td[i] + a.c * a.tbar[i];
 }
-// Sibar_l = gK/2 K (Ki - Aji_l) K + A2_l - g3/2 SW_l + (tbar_l v_l^T + v_l tbar_l^T) / 2, in place on the product K (Ki - Aji_l) K.
+// D_l = Ki - Aji_l (exactly symmetric: both operands are); the gradient of A_hat from the KL term is Abar_l = gK/2 D_l
+__global__ void k_big_fb_dmat(int m, int L, const real* __restrict__ Ki, const real* __restrict__ Aji, real* __restrict__ D) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)m * m;
+    if (i < mm * L) D[i] = Ki[i % mm] - Aji[i];
+}
+// X_l = A2_l - g3/2 SW_l + (tbar_l v_l^T + v_l tbar_l^T) / 2: the gradient of Sigma_l^-1 WITHOUT the share gK/2 K D_l K that
+// reaches it through A_hat = K Sigma^-1 K -- that share enters Sg = -Si Sibar Si as -gK/2 G_l D_l G_l^T (G = Si K is the forward
+// product), formed early from H_l = G_l D_l, which is also Z'_l = Si K D_l: one full m^3 product per channel less than K D,
+// Si (K D), (K D) K (round 4, second form).
 // The gradient of t = Si v is the rank-one tbar v^T; only the symmetric part of Sg = -Si Sibar Si is ever used (Ssym = c (Sg +
 // Sg^T) in the row stage, Sg + Sg^T in the kernel-matrix reverse pass, which reads Kbar_ij + Kbar_ji), so Sibar is symmetrised
 // here (Sg is then symmetric up to rounding and Ssym = c (Sg + Sg^T) removes the antisymmetric residue exactly).
@@ -197,7 +205,7 @@ __global__ void k_big_fb_sibar(FbArgs a) {
     if (i >= mm * a.L) return;
     const long long o = i % mm, l = i / mm;
     const int r = (int)(o / a.m), cidx = (int)(o % a.m);
-    a.Sibar[i] = real(0.5) * gK * a.Sibar[i] + a.A2[i] - (a.SW ? real(0.5) * g3 * a.SW[i] : real(0)) +
+    a.Sibar[i] = a.A2[i] - (a.SW ? real(0.5) * g3 * a.SW[i] : real(0)) +
                  real(0.5) * (a.tbar[l * a.m + r] * a.v[l * a.m + cidx] + a.tbar[l * a.m + cidx] * a.v[l * a.m + r]);
 }
 // The kernel below needs X and X^T of a full (non-symmetric) product.  A workgroup owns the PAIR of 32 x 32 tiles (ti, tj),
@@ -222,13 +230,14 @@ __device__ __forceinline__ void tp_load(const real* __restrict__ X, int m, const
     }
     __syncthreads();
 }
-// Ssym = c (Sg + Sg^T)    (Q = Ssym - g3 M2 is not formed on this path)
+// Ssym = c (Sg0 + Sg0^T) - c gK HG with Sg0 = -Si X Si and HG = G D G^T (exactly symmetric: mirrored product)
 __global__ __launch_bounds__(256) void k_big_fb_ssym(FbArgs a) {
     __shared__ real U[TP][TP + 1], V[TP][TP + 1];
     TilePair t;
     if (!t.init()) return;
     const int m = a.m;
     const size_t mm = (size_t)m * m, lo = (size_t)t.l * mm;
+    real g3, gK; fb_scalars(a, g3, gK);
     tp_load(a.Sg + lo, m, t, U, V);
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256) void k_big_fb_ssym(FbArgs a) {
             if (gi < m && gj < m) {
                 const size_t i = lo + (size_t)gi * m + gj;
                 const real sg = side ? V[r][t.c] : U[r][t.c], sgt = side ? U[t.c][r] : V[t.c][r];
-                a.Ssym[i] = a.c * (sg + sgt);
+                a.Ssym[i] = a.c * (sg + sgt) - a.c * gK * a.HG[i];
             }
         }
     }
@@ -260,7 +269,8 @@ struct FinArgs {
     real c, N_train, rep_weight;
     const real* state;
     const real* Asum; const real* ubar; const real* mu; const real* Qs; const real* PbarK;
-    const real* Zs; const real* mubar; const real* t; const real* Sgs; const real* Ki; const real* KiPbar; const real* KiKibKi;
+    const real* Zs; const real* mubar; const real* t; const real* Sgs; const real* HGs; const real* Ki; const real* KiPbar;
+    const real* KiKibKi;
     real* Kib; real* Kbar;
 };
 __global__ void k_big_fb_kib(FinArgs a) {
@@ -272,13 +282,13 @@ __global__ void k_big_fb_kib(FinArgs a) {
     for (int l = 0; l < a.L; ++l) s += a.ubar[(size_t)l * a.m + r] * a.mu[(size_t)l * a.m + cidx];
     a.Kib[o] = a.rep_weight * s + a.Qs[o] + a.PbarK[o];
 }
-// Kbar = rep_weight (gK/2 (Zs + Zs^T) + c sum_l mubar_l t_l^T + sum_l Sg_l + gK/2 L Ki) + Ki Pbar - Ki Kib Ki
+// Kbar = rep_weight (gK/2 (Zs + Zs^T) + c sum_l mubar_l t_l^T + sum_l Sg0_l - gK/2 sum_l HG_l + gK/2 L Ki) + Ki Pbar - Ki Kib Ki
 __global__ void k_big_fb_final(FinArgs a) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= a.m * a.m) return;
     const real gT = gradKL(a.geco, a.Ltot, a.state), gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
     const int r = o / a.m, cidx = o % a.m;
-    real s = real(0.5) * gK * (a.Zs[o] + a.Zs[(size_t)cidx * a.m + r]) + a.Sgs[o] + real(0.5) * gK * (real)a.L * a.Ki[o];
+    real s = real(0.5) * gK * (a.Zs[o] + a.Zs[(size_t)cidx * a.m + r] - a.HGs[o]) + a.Sgs[o] + real(0.5) * gK * (real)a.L * a.Ki[o];
     real rk = 0;
     for (int l = 0; l < a.L; ++l) rk += a.mubar[(size_t)l * a.m + r] * a.t[(size_t)l * a.m + cidx];
     a.Kbar[o] = a.rep_weight * (s + a.c * rk) + a.KiPbar[o] - a.KiKibKi[o];
@@ -391,7 +401,7 @@ struct BigScr {
     long long sKS;
     // channel-independent m x m matrices: P^T = K Ki, Pbar = Kn^T Wbar, Qs = Kn^T diag(qbar) Kn, sum_l A_l, sum_l Z'_l, sum_l Sg_l,
     // two temporaries
-    real *PT, *Pbar, *Qs, *Asum, *Zs, *Sgs, *tA, *tB, *tC;
+    real *PT, *Pbar, *Qs, *Asum, *Zs, *Sgs, *tA, *tB, *tC, *HGs;
 };
 static BigScr big_scr(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws) {
     const size_t Lmm = (size_t)c->L * c->m * c->m, Lm = (size_t)c->L * c->m, bL = (size_t)c->b * c->L, mm = (size_t)c->m * c->m;
@@ -408,7 +418,7 @@ static BigScr big_scr(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, d
     s.bl0 = ws + wl.scr_bl; s.bl1 = s.bl0 + bL; s.wst = s.bl0;      // p = 1 / s2 (b, L): weights of the early SW statistic
     real* sm = ws + wl.scr_sm;
     s.PT = sm; s.Pbar = sm + mm; s.Qs = sm + 2 * mm; s.Asum = sm + 3 * mm; s.Zs = sm + 4 * mm; s.Sgs = sm + 5 * mm;
-    s.tA = sm + 6 * mm; s.tB = sm + 7 * mm; s.tC = sm + 8 * mm;
+    s.tA = sm + 6 * mm; s.tB = sm + 7 * mm; s.tC = sm + 8 * mm; s.HGs = sm + 9 * mm;
     return s;
 }
 
@@ -553,13 +563,13 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
 // K_mm plus this rank's row-local share (the shares of the ranks add up in the gradient exchange: kernel_matrix_bwd is linear
 // in Kbar and takes it unweighted on this path).
 // part: 0 = the whole stage; 1 = its EARLY half (3 + 4: its two parts separately); 2 = its LATE half.  The early half --
-//   Gbar' = K (Ki - Aji) = P^T - K Aji, Z' = Sigma^-1 Gbar', Gbar' K, the channel sums of Z' and A_hat
-// -- depends on forward quantities only (the scalar gK/2 of Abar = gK/2 (Ki - Aji) is applied where the products are consumed),
+//   D = Ki - Aji, H = G D (= Z' = Sigma^-1 K D), HG = H G^T (= Sigma^-1 K D K Sigma^-1), the channel sums of H, HG and A_hat
+// -- depends on forward quantities only (the scalar gK/2 of Abar = gK/2 D is applied where the products are consumed),
 // not on the reverse statistics B2, ud, td.  The training step issues it on the side stream right behind the forward stage's
 // tail, under the row stage, the networks and the reverse statistics; the late half (ubar ... Sigma^-1 Sibar Sigma^-1, the
-// Ki-gradient, Kbar) stays on the critical path.  Same operations on the same values either way.  Buffers: Gbar' in the first
+// Ki-gradient, Kbar) stays on the critical path.  Same operations on the same values either way.  Buffers: D in the first
 // half of fb_part (the forward tail's trace partials at its head are consumed before: the side stream runs tail and early
-// half in order), Z' in mm0, Gbar' K in mm3 (becomes Sibar), then Sigma^-1 Sibar in mm0 and Sg in mm1; SW in mm2 (its m-space form: T in mm1, early).
+// half in order), H in mm0, HG in mm3, then X in mm1, Sigma^-1 X in mm0 and Sg0 in mm1; SW in mm2 (its m-space form: T in mm1, early).
 // Part 3 (needs no (A_hat + jI)^-1: can run beside the forward tail) is the statistic SW (see there).
 int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
                         void* stream, int l0, int nl, int part) {
@@ -570,12 +580,12 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     hipStream_t st = (hipStream_t)stream;
     const size_t om = (size_t)l0 * mm, ov = (size_t)l0 * m;
     real *K = ws + wl.K, *Ki = ws + wl.Ki, *Si = ws + wl.Si + om, *A = ws + wl.A + om, *Aji = ws + wl.Aji + om;
-    real* Gb = ws + wl.fb_part;
+    real* Db = ws + wl.fb_part;
     FbArgs a;
     a.m = m; a.L = L; a.Ltot = c->L; a.geco = SVGP_LOSS_FLAGS(c); a.b_global = c->b_global; a.c = cc; a.N_train = c->N_train; a.state = state;
     a.A2 = ws + wl.A2 + om; a.mu = ws + wl.mu_hat + ov; a.u = ws + wl.u + ov; a.ud = ws + wl.ud + ov; a.td = ws + wl.td + ov;
     a.v = ws + wl.v + ov;
-    a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2; a.Sibar = s.mm3; a.Sg = s.mm1; a.Ssym = ws + wl.Ssym + om;
+    a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2; a.Sibar = s.mm1; a.Sg = s.mm1; a.HG = s.mm3; a.Ssym = ws + wl.Ssym + om;
     const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m), ntp = (unsigned)((m + TP - 1) / TP);
     // early half, first part (3): SW_l = W^T diag(p_l) W = P^T S_l P -- forward quantities only, not even (A_hat + jI)^-1, so it can
     // run beside the forward tail.  Over the rows (a statistics product with contraction b) when ALL rows of the batch are local
@@ -597,12 +607,14 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     }
     if (part == 3) return SVGP_OK;
     if (part == 0 || part == 1 || part == 4) {
-        svgp_gemm_epi ep;
-        ep.E = s.PT; ep.lde = m; ep.se = 0; ep.g1 = 1.0;
-        RUNC(svgp_dgemm_epi_batched(c->gemm_f32 == 1, 0, 1, m, m, m, -1.0, K, m, 0, Aji, m, mm, 0.0, Gb, m, mm, L, stream, &ep));   // Gbar' = P^T - K Aji
-        GEMM(0, 0, m, m, m, 1.0, Si, m, mm, Gb, m, mm, 0.0, s.mm0, m, mm, L);          // Z' = Si Gbar'
-        GEMM_SYM(0, 1, m, m, 1.0, Gb, m, mm, K, m, 0, 0.0, s.mm3, m, mm, L);           // Gbar' K = K (Ki - Aji) K  (mm3)
+        real* G = ws + wl.G + om;
+        hipLaunchKernelGGL(k_big_fb_dmat, dim3(gmm), dim3(256), 0, st, m, L, Ki, Aji, Db);      // D = Ki - Aji
+        SVGP_LAUNCH_CHECK();
+        GEMM(0, 1, m, m, m, 1.0, G, m, mm, Db, m, mm, 0.0, s.mm0, m, mm, L);             // H = G D = Si K (Ki - Aji) = Z'  (D = D^T read as [j][k])
+        GEMM_SYM(0, 1, m, m, 1.0, s.mm0, m, mm, G, m, mm, 0.0, s.mm3, m, mm, L);         // HG = H G^T = Si K D K Si  (mm3)
         hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, real(1), s.mm0, s.Zs);
+        SVGP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, real(1), s.mm3, s.HGs);
         SVGP_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, real(1), A, s.Asum);
         SVGP_LAUNCH_CHECK();
@@ -616,16 +628,16 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     GEMV(1.0, K, 0, s.vec1, s.vec2, L);                                                // K mubar
     hipLaunchKernelGGL(k_big_fb_tbar, dim3(gv), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);                // Sibar (mm3, in place)
+    hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);                // X (mm1)
     SVGP_LAUNCH_CHECK();
     GEMV(1.0, Si, mm, s.vec2, ws + wl.vbar + ov, L);                                   // vbar = Si tbar
-    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm3, m, mm, 0.0, s.mm0, m, mm, L);           // Si Sibar (mm0: Z' is summed)
-    // Sg = -(Si Sibar) Si: a FULL product, not lower-triangle-and-mirror -- like the Ki sandwiches of round 2, the mirrored form of this
+    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm1, m, mm, 0.0, s.mm0, m, mm, L);           // Si X (mm0: H is summed)
+    // Sg0 = -(Si X) Si: a FULL product, not lower-triangle-and-mirror -- like the Ki sandwiches of round 2, the mirrored form of this
     // Sigma^-1 sandwich loses the benign structure of its rounding error: config 3 (jitter 1e-6) had the encoder dense-layer gradient
     // off by 1e-3 against 1e-9 (measured, round 4).  Ssym = c (Sg + Sg^T) is then formed exactly symmetric by the tile-pair kernel:
     // writing 2 c Sg straight from the product keeps an antisymmetric rounding residue that the inducing-point gradients see at
     // 2e-5 (virtual-rank test, m = 256), so the 0.1 ms pass stays.
-    GEMM(0, 1, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);          // Sg (mm1)
+    GEMM(0, 1, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);          // Sg0 (mm1: X is consumed)
     hipLaunchKernelGGL(k_big_fb_ssym, dim3(ntp, ntp, L), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, real(1), s.mm1, s.Sgs);
@@ -636,7 +648,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     f.m = m; f.L = L; f.Ltot = c->L; f.geco = SVGP_LOSS_FLAGS(c); f.b_global = c->b_global; f.c = cc; f.N_train = c->N_train;
     f.rep_weight = c->rep_weight; f.state = state;
     f.Asum = s.Asum; f.ubar = s.vec0; f.mu = a.mu; f.Qs = s.Qs; f.PbarK = s.tA; f.Zs = s.Zs; f.mubar = s.vec1; f.t = ws + wl.t + ov;
-    f.Sgs = s.Sgs; f.Ki = Ki; f.KiPbar = s.Pbar; f.KiKibKi = s.tA; f.Kib = s.tB; f.Kbar = ws + wl.Kbar;
+    f.Sgs = s.Sgs; f.HGs = s.HGs; f.Ki = Ki; f.KiPbar = s.Pbar; f.KiKibKi = s.tA; f.Kib = s.tB; f.Kbar = ws + wl.Kbar;
     GEMM(0, 1, m, m, m, 1.0, s.Pbar, m, 0, K, m, 0, 0.0, s.tA, m, 0, 1);                // Pbar K
     hipLaunchKernelGGL(k_big_fb_kib, dim3(nblk(mm)), dim3(256), 0, st, f);             // Kib (tB)
     SVGP_LAUNCH_CHECK();

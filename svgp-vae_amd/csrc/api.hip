@@ -119,12 +119,12 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->Kbar = take(m * m); o->fb_part = take(2 * L * m * m); o->Qm = take(m > SVGP_M_MAX ? 0 : L * m * m); o->vbar = take(L * m);
     o->Ssym = take(L * m * m); o->Knbar_part = take(L * b * m);
     // scratch of the large-m path (gp_large.hip)
-    // m > 64: (L,b,m) scratch + the forward products [Kn; W] Si_l (L,2b,m), Kn Ki (b,m) kept for the reverse pass + Wbar (b,m)
-    o->scr_bm = take(m > SVGP_M_MAX ? 3 * L * b * m + 2 * b * m : L * b * m); o->scr_mm = take(4 * L * m * m);
+    // m > 64: (L,b,m) scratch + the forward products [Kn; W] Si_l (L,2b,m), Kn Ki (b,m) kept for the reverse pass + X (b,2m)
+    o->scr_bm = take(m > SVGP_M_MAX ? 3 * L * b * m + 3 * b * m : L * b * m); o->scr_mm = take(4 * L * m * m);
     o->scr_vec = take(3 * L * m + 3 * L + 16 + b);
     o->scr_inv = take((int64_t)svgp_spd_inverse_workspace_elems((int)m, (int)L + 1)); o->scr_bl = take(2 * b * L);
-    // m > 64: ten channel-independent m x m matrices of the W form (K Ki, Kn^T Wbar, Kn^T diag(qbar) Kn, channel sums, temporaries)
-    o->scr_sm = take(m > SVGP_M_MAX ? 10 * m * m : 0);
+    // m > 64: ten channel-independent m x m matrices + the split-K scratch of the (2 m, m, b) row contraction of the W form (K Ki, Kn^T Wbar, Kn^T diag(qbar) Kn, channel sums, temporaries)
+    o->scr_sm = take(m > SVGP_M_MAX ? 10 * m * m + svgp_dgemm_splitk_scratch_elems((int)(2 * m), (int)m, (int)b) : 0);
     o->Knbar = take(b * m); o->knnbar = take(b); o->ybar = take(b * L); o->s2bar = take(b * L);
     o->d_on = take(b * M);
     o->n_part = svgp_n_part(&cc);
@@ -324,17 +324,19 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         break;
     case 1:
         RUN(svgp_gp_factor_fwd_defer_aji(c, ws, stream));      // m <= 64: (A_hat + jI)^-1 finishes inside the row-stage launch
-        if (c->m > SVGP_M_MAX) {                               // m > 64: ... on the side stream
-            if (fork1) RUN(side_fork(sd, 1, ms));
+        // m > 64: the tail of the stage and the early half of the REVERSE factor stage (no reverse statistic needed; phase 2 then
+        // runs the late half only) go to the side stream.  The branch is FORKED here but ISSUED behind the row stage: its ~25
+        // launches take the host ~100 us to enqueue, during which the caller's stream had nothing to run (config 3, kernel trace of
+        // round 4: a 101 us hole in front of the row stage's product) -- the branch has that much slack, the caller's stream none.
+        if (c->m > SVGP_M_MAX && fork1) RUN(side_fork(sd, 1, ms));
+        RUN(svgp_gp_posterior_fwd_with_aji(c, eps, ws, state, stream));
+        if (c->m > SVGP_M_MAX) {
             RUN(svgp_gp_factor_fwd_aji_tail(c, ws, fork1 ? (void*)sd->s[1] : stream));
-            // ... followed there by the early half of the REVERSE factor stage (5.5 of its 8 m^3 L products need no
-            // reverse statistic); phase 2 then runs the late half only
             if (fork1) {
                 RUN(svgp_gp_factor_bwd_early(c, ws, state, (void*)sd->s[1]));
                 side_mark_early(sd, ws);                       // phase 2 of THIS workspace may run the late half only
             }
         }
-        RUN(svgp_gp_posterior_fwd_with_aji(c, eps, ws, state, stream));
         if (c->titsias) RUN(svgp_gp_titsias_fwd(c, ws, state, stream));
         RUN(svgp_mnist_decoder_fwd(c, theta, images, ws, stream));
         RUN(svgp_mnist_decoder_bwd(c, theta, images, ws, state, stream));

@@ -433,9 +433,11 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
         RUN(svgp_sym_unpack(m, nhi, xp0 + (size_t)hi0 * pe, ws + wl.Si + (size_t)hi0 * mm, stream));
     }
     RUN(pt.end());
+    // (the row stage is issued first: the branch's ~25 launches take the host ~100 us to enqueue, during which the caller's stream
+    // would have nothing to run; the branch has that much slack)
+    RUN(svgp_gp_posterior_fwd(&cc, eps, ws, state, stream));
     RUN(svgp_big_factor_fwd(&cc, wl, ws, side, l0, nl, 2));
     if (fork) RUN(svgp_big_factor_bwd(&cc, wl, ws, state, side, l0, nl, 1));
-    RUN(svgp_gp_posterior_fwd(&cc, eps, ws, state, stream));
     RUN(svgp_mnist_decoder_fwd(&cc, theta, images, ws, stream));
     RUN(svgp_mnist_decoder_bwd(&cc, theta, images, ws, state, stream));
     RUN(svgp_gp_stats_bwd(&cc, ws, state, stream));

@@ -54,26 +54,26 @@ __global__ void k_big_recip(int n_el, const real* __restrict__ s2, real* __restr
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_el) p[i] = recip_no_nan(s2[i]);
 }
-// qbar_n = sum_l (g3/2 p_nl - g_pv_nl): the weight of k_n k_n^T in the gradient of Ki (q_n = k^T Ki k inside d and p_v)
-__global__ void k_big_qbar(int b, int L, int geco, const real* __restrict__ state, const real* __restrict__ s2,
-                           const real* __restrict__ g_pv, real* __restrict__ qbar) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= b) return;
-    const real g3 = svgp_seed_3(geco, gradKL(geco, L, state));
-    real q = 0;
-    for (int l = 0; l < L; ++l) q += real(0.5) * g3 * recip_no_nan(s2[(size_t)n * L + l]) - g_pv[(size_t)n * L + l];
-    qbar[n] = q;
-}
-// Wbar[n][j] = -g3 sum_l p_nl (W Si_l)[n][j]: the gradient of the rows W = Kn Ki K (channel sum: W is channel-independent)
-__global__ void k_big_wbar(int b, int m, int L, int geco, const real* __restrict__ state, const real* __restrict__ s2,
-                           const real* __restrict__ WSi, long long sW, real* __restrict__ Wbar) {
+// The rank-local row terms of the reverse pass in one pass over the rows, X (b, 2 m) = [qbar * Kn | Wbar]:
+//   qbar_n = sum_l (g3/2 p_nl - g_pv_nl): the weight of k_n k_n^T in the gradient of Ki (q_n = k^T Ki k inside d and p_v);
+//   Wbar[n][j] = -g3 sum_l p_nl (W Si_l)[n][j]: the gradient of the rows W = Kn Ki K (channel sum: W is channel-independent).
+// [Qs; Pbar^T] = X^T Kn is then ONE contraction over the rows (svgp_big_stats).
+__global__ void k_big_rowlocal(int b, int m, int L, int geco, const real* __restrict__ state, const real* __restrict__ s2,
+                               const real* __restrict__ g_pv, const real* __restrict__ Kn, const real* __restrict__ WSi,
+                               long long sW, real* __restrict__ X, real* __restrict__ qbar) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)b * m) return;
-    const int n = (int)(i / m);
+    const int n = (int)(i / m), j = (int)(i % m);
     const real g3 = svgp_seed_3(geco, gradKL(geco, L, state));
-    real s = 0;
-    for (int l = 0; l < L; ++l) s += recip_no_nan(s2[(size_t)n * L + l]) * WSi[(size_t)l * sW + i];
-    Wbar[i] = -g3 * s;
+    real s = 0, q = 0;
+    for (int l = 0; l < L; ++l) {
+        const real p = recip_no_nan(s2[(size_t)n * L + l]);
+        s += p * WSi[(size_t)l * sW + i];
+        q += real(0.5) * g3 * p - g_pv[(size_t)n * L + l];
+    }
+    X[(size_t)n * 2 * m + j] = q * Kn[i];
+    X[(size_t)n * 2 * m + m + j] = -g3 * s;
+    if (j == 0) qbar[n] = q;
 }
 // out[l] = in (m x m, shared) + c * S[l] + jitter * I     (S may be NULL -> in + jitter I, batch 1)
 __global__ void k_big_add_diag(int m, int L, real c, real jitter, const real* __restrict__ in,
@@ -262,8 +262,10 @@ __global__ void k_big_sum_channels(int mm, int L, real scale, const real* __rest
     for (int l = 0; l < L; ++l) s += in[(size_t)l * mm + o];
     out[o] = scale * s;
 }
-// The gradient of Ki, channel sum: Kib = rep_weight (gK/2 sum_l A_l + sum_l ubar_l mu_l^T) + Qs + Pbar K
-//   (tr(Ki A) and mu^T Ki mu of the KL term: window part; q_n = k^T Ki k in d and p_v and P = Ki K: rank-local row sums)
+// The gradient of Ki, channel sum: Kib = rep_weight (gK/2 sum_l A_l + sum_l ubar_l mu_l^T) + Qs + (Pbar K)^T
+//   (tr(Ki A) and mu^T Ki mu of the KL term: window part; q_n = k^T Ki k in d and p_v and P = Ki K: rank-local row sums).
+// The rank-local part is carried TRANSPOSED (the row contraction delivers Pbar^T = Wbar^T Kn): the kernel-matrix reverse pass
+// reads Kbar_ij + Kbar_ji only, and Ki (A + B^T) Ki = Ki A Ki + (Ki B Ki)^T.
 struct FinArgs {
     int m, L, Ltot, geco, b_global;
     real c, N_train, rep_weight;
@@ -397,8 +399,8 @@ struct BigScr {
     real *bm, *bm2, *mm0, *mm1, *mm2, *mm3, *vec0, *vec1, *vec2, *trm, *ldtmp, *qbar, *inv, *bl0, *bl1, *wst;
     // forward products kept for the reverse pass (behind the (L, b, m) scratch in scr_bm): KS = [Kn; W] Si_l (L, 2b, m) --
     // channel l at KS + l sKS, Kn Si_l first, W Si_l at + b m --, Kn Ki (b, m); Wbar (b, m)
-    real *KS, *KnKi, *Wbar, *W;
-    long long sKS;
+    real *KS, *KnKi, *X, *Wbar, *W, *sk2;      // X (b, 2m) = [qbar * Kn | Wbar]: Wbar = X + m, leading dimension 2 m
+    long long sKS, sk2_elems;
     // channel-independent m x m matrices: P^T = K Ki, Pbar = Kn^T Wbar, Qs = Kn^T diag(qbar) Kn, sum_l A_l, sum_l Z'_l, sum_l Sg_l,
     // two temporaries
     real *PT, *Pbar, *Qs, *Asum, *Zs, *Sgs, *tA, *tB, *tC, *HGs;
@@ -409,7 +411,7 @@ static BigScr big_scr(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, d
     BigScr s;
     s.bm = ws + wl.scr_bm; s.bm2 = ws + wl.Knbar_part;
     const size_t Lbm_cap = (size_t)c->L * bcap * c->m;      // the layout is sized for the capacity
-    s.KS = s.bm + Lbm_cap; s.sKS = 2LL * c->b * c->m; s.KnKi = s.KS + 2 * Lbm_cap; s.Wbar = s.KnKi + bcap * c->m;
+    s.KS = s.bm + Lbm_cap; s.sKS = 2LL * c->b * c->m; s.KnKi = s.KS + 2 * Lbm_cap; s.X = s.KnKi + bcap * c->m; s.Wbar = s.X + c->m;
     s.W = ws + wl.Kn + (size_t)c->b * c->m;
     s.mm0 = ws + wl.scr_mm; s.mm1 = s.mm0 + Lmm; s.mm2 = s.mm1 + Lmm; s.mm3 = s.mm2 + Lmm;
     s.vec0 = ws + wl.scr_vec; s.vec1 = s.vec0 + Lm; s.vec2 = s.vec1 + Lm; s.trm = s.vec2 + Lm; s.ldtmp = s.trm + 2 * c->L;
@@ -417,8 +419,10 @@ static BigScr big_scr(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, d
     s.inv = ws + wl.scr_inv;
     s.bl0 = ws + wl.scr_bl; s.bl1 = s.bl0 + bL; s.wst = s.bl0;      // p = 1 / s2 (b, L): weights of the early SW statistic
     real* sm = ws + wl.scr_sm;
-    s.PT = sm; s.Pbar = sm + mm; s.Qs = sm + 2 * mm; s.Asum = sm + 3 * mm; s.Zs = sm + 4 * mm; s.Sgs = sm + 5 * mm;
+    s.PT = sm; s.Qs = sm + mm; s.Pbar = sm + 2 * mm;       // Qs | Pbar^T contiguous: one (2 m, m) product writes both
+     s.Asum = sm + 3 * mm; s.Zs = sm + 4 * mm; s.Sgs = sm + 5 * mm;
     s.tA = sm + 6 * mm; s.tB = sm + 7 * mm; s.tC = sm + 8 * mm; s.HGs = sm + 9 * mm;
+    s.sk2 = sm + 10 * mm; s.sk2_elems = svgp_dgemm_splitk_scratch_elems(2 * c->m, c->m, (int)bcap);
     return s;
 }
 
@@ -452,14 +456,13 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
     RUNC(svgp_dgemm_splitk(1, 0, L, m, b, 1.0, abuf, L, Kn, m, 0.0, v1, m, sks, sk, stream));
     if (mode == 1) {
         RUNC(svgp_dgemm_splitk(1, 0, L, m, b, cc, bbuf, L, Kn, m, 0.0, ws + wl.td, m, sks, sk, stream));
-        // the rank-local row sums of the reverse pass (they enter Kbar linearly: no exchange, see the file header)
-        hipLaunchKernelGGL(k_big_qbar, dim3(nblk(b)), dim3(256), 0, st, b, L, SVGP_LOSS_FLAGS(c), state, ws + wl.qnet_var, wbuf, s.qbar);
+        // the rank-local row sums of the reverse pass (they enter Kbar linearly: no exchange, see the file header):
+        // [Qs; Pbar^T] (2 m, m) = X^T Kn, split over the rows when that leaves few output tiles (config 3: 23.6 + 25.9 us for the two
+        // products as single launches with a contraction of 1024, round 4)
+        hipLaunchKernelGGL(k_big_rowlocal, dim3(nblk((long long)b * m)), dim3(256), 0, st, b, m, L, SVGP_LOSS_FLAGS(c), state,
+                           ws + wl.qnet_var, wbuf, Kn, s.KS + (size_t)b * m, s.sKS, s.X, s.qbar);
         SVGP_LAUNCH_CHECK();
-        RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, b, 1.0, Kn, m, 0, Kn, m, 0, 0.0, s.Qs, m, 0, 1, stream, s.qbar, 1, 0));
-        hipLaunchKernelGGL(k_big_wbar, dim3(nblk((long long)b * m)), dim3(256), 0, st, b, m, L, SVGP_LOSS_FLAGS(c), state,
-                           ws + wl.qnet_var, s.KS + (size_t)b * m, s.sKS, s.Wbar);
-        SVGP_LAUNCH_CHECK();
-        GEMM_S(1, 0, m, m, b, 1.0, Kn, m, 0, s.Wbar, m, 0, 0.0, s.Pbar, m, 0, 1);                   // Pbar = Kn^T Wbar
+        RUNC(svgp_dgemm_splitk(1, 0, 2 * m, m, b, 1.0, s.X, 2 * m, Kn, m, 0.0, s.Qs, m, s.sk2, s.sk2_elems, stream));   // Qs | Pbar^T (contiguous)
     }
     // (K_mm + jI)^-1 and its log det (SVGPVAE_model.py:239,270,273) are formed by svgp_big_factor_fwd, in the same
     // launches as the L channel inverses
@@ -649,12 +652,12 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     f.rep_weight = c->rep_weight; f.state = state;
     f.Asum = s.Asum; f.ubar = s.vec0; f.mu = a.mu; f.Qs = s.Qs; f.PbarK = s.tA; f.Zs = s.Zs; f.mubar = s.vec1; f.t = ws + wl.t + ov;
     f.Sgs = s.Sgs; f.HGs = s.HGs; f.Ki = Ki; f.KiPbar = s.Pbar; f.KiKibKi = s.tA; f.Kib = s.tB; f.Kbar = ws + wl.Kbar;
-    GEMM(0, 1, m, m, m, 1.0, s.Pbar, m, 0, K, m, 0, 0.0, s.tA, m, 0, 1);                // Pbar K
+    GEMM(0, 0, m, m, m, 1.0, K, m, 0, s.Pbar, m, 0, 0.0, s.tA, m, 0, 1);                // K Pbar^T = (Pbar K)^T   (s.Pbar holds Pbar^T)
     hipLaunchKernelGGL(k_big_fb_kib, dim3(nblk(mm)), dim3(256), 0, st, f);             // Kib (tB)
     SVGP_LAUNCH_CHECK();
     GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.tB, m, 0, 0.0, s.tC, m, 0, 1);                 // Ki Kib             (tC)
     GEMM(0, 1, m, m, m, 1.0, s.tC, m, 0, Ki, m, 0, 0.0, s.tA, m, 0, 1);                 // Ki Kib Ki          (tA)
-    GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.Pbar, m, 0, 0.0, s.tB, m, 0, 1);               // Ki Pbar            (tB)
+    GEMM(0, 1, m, m, m, 1.0, s.Pbar, m, 0, Ki, m, 0, 0.0, s.tB, m, 0, 1);               // Pbar^T Ki = (Ki Pbar)^T   (tB)
     f.KiPbar = s.tB;
     hipLaunchKernelGGL(k_big_fb_final, dim3(nblk(mm)), dim3(256), 0, st, f);
     SVGP_LAUNCH_CHECK();
@@ -691,6 +694,6 @@ int svgp_big_posterior_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_big_pb_sum, dim3(nblk(bm)), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    GEMM(0, 0, b, m, m, 1.0, s.Wbar, m, 0, s.PT, m, 0, 1.0, ws + wl.Knbar, m, 0, 1);   // Knbar += Wbar P^T... (P^T = K Ki)
+    GEMM(0, 0, b, m, m, 1.0, s.Wbar, 2 * m, 0, s.PT, m, 0, 1.0, ws + wl.Knbar, m, 0, 1);   // Knbar += Wbar P^T  (P^T = K Ki; Wbar inside X)
     return SVGP_OK;
 }

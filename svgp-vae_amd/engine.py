@@ -583,11 +583,10 @@ class MnistStepEngine:
         # (round 4: M2 = Ki A Ki is no longer formed or exchanged -- the row stage evaluates k^T M2 k as w^T Si w, gp_large.hip)
         yield [ExchangeOp("allgather", fld("Si", mm), sym(0, pre=True))] + plain("allgather", ("t", m), ("u", m))
         with torch.cuda.stream(self.stream):
+            call("svgp_gp_posterior_fwd", cp, ep, ws, st, s)              # (first: the caller's stream must not wait for the host)
             call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 2, ws, side.cuda_stream)
             if fork:
                 call("svgp_gp_factor_bwd_channels_part", cp, l0, nl, 1, ws, st, side.cuda_stream)
-        with torch.cuda.stream(self.stream):
-            call("svgp_gp_posterior_fwd", cp, ep, ws, st, s)
             call("svgp_mnist_decoder_fwd", cp, th, im, ws, s)
             call("svgp_mnist_decoder_bwd", cp, th, im, ws, st, s)
             call("svgp_gp_stats_bwd", cp, ws, st, s)

@@ -448,6 +448,8 @@ class SpritesStepEngine:
             for grp, layers in (("dec", self.dec), ("enc", self.enc), ("repr", self.rep)):
                 for i, lay in enumerate(layers, 1):
                     lay.prepare(pn[f"{grp}_c{i}_w"], prep_stream.cuda_stream, need_bwd=not (grp != "dec" and i == 1))
+            prep_done = torch.cuda.Event()
+            prep_done.record(prep_stream)      # (an event, not the stream: more work goes to that stream later in the step)
             deferred = DeferredSums()          # every layer's closing partial sums: ONE launch at the end of the step
             self._mark("nets_fwd_enc")
             kc = SpritesKcfg(b=b, m=self.m, La=self.La, Lc=self.Lc, n_act=self.n_act,
@@ -504,50 +506,59 @@ class SpritesStepEngine:
             yield [ExchangeOp("reduce_scatter", fld("S", mm_), sym(0))] + plain("reduce_scatter", ("v", self.m))
         else:
             yield [ExchangeOp("allreduce", self.ws[self.wl.statA:self.wl.statA + self.wl.statA_len])]
+        eps_ptr = None if eps is None else eps.contiguous().data_ptr()
+        # The side work of the forward factor stage -- its tail ((A_hat + jI)^-1, log det, KL_l: a whole batched inverse that only
+        # the reverse factor stage and the final scalars need; include/svgpvae_hip.h: svgp_gp_factor_fwd_aji_tail) and the early
+        # half of the reverse factor stage (no reverse statistic needed) -- runs beside the row stage, the decoder and the reverse
+        # statistics.  It is FORKED right behind the stage but ISSUED behind the row stage: its launches (two blocked factorisations)
+        # take the host ~0.5 ms to enqueue, and the caller's stream must not run dry meanwhile; the branch has the slack.
+        side_work = None
         with torch.cuda.stream(self.stream):
             self._mark("gp_fwd_factor")
             if self.chan_shard:
                 call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 1, ws, s)         # without the (A_hat + jI)^-1 tail
                 if pack:   # the window in wire format BEFORE the side branch starts reading it
                     call("svgp_sym_pack", self.m, nl, 0, wptr("Si"), wptr("Si", 0), s)
-                # the tail and the early reverse half of the window go to the side stream, beside the all-gather, the row stage,
-                # the decoder and the reverse statistics: forked here, issued BEHIND the collective (see svgp_mnist_train_step_dp)
                 sd = self.side if self.side is not None else self.stream
                 sd.wait_stream(self.stream)
+
+                def side_work():
+                    call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 2, ws, sd.cuda_stream)
+                    if self.side is not None:
+                        call("svgp_gp_factor_bwd_channels_part", cp, l0, nl, 1, ws, st, sd.cuda_stream)
             elif self.m > 64 and self.side is not None and not self.svgp.titsias:
                 # (not with titsias: svgp_gp_titsias_fwd inverts through the same scratch, ws.scr_inv, on the main stream)
-                # the tail of the stage -- (A_hat + jI)^-1, its log det, KL_l: a whole batched inverse that only the reverse
-                # factor stage and the final scalars need -- runs on the side stream beside the row stage, the decoder and
-                # the reverse statistics (include/svgpvae_hip.h: svgp_gp_factor_fwd_aji_tail)
                 call("svgp_gp_factor_fwd_defer_aji", cp, ws, s)
                 self.side.wait_stream(self.stream)
-                call("svgp_gp_factor_fwd_aji_tail", cp, ws, self.side.cuda_stream)
-                # ... the early half of the reverse factor stage (no reverse statistic needed): its first part beside the
-                # tail on a third stream (it does not need the tail's inverse), its second part behind both
                 if self.side2 is not None:
                     self.side2.wait_stream(self.stream)
-                    call("svgp_gp_factor_bwd_early_a", cp, ws, st, self.side2.cuda_stream)
-                    self.side.wait_stream(self.side2)
-                    call("svgp_gp_factor_bwd_early_b", cp, ws, st, self.side.cuda_stream)
-                else:
-                    call("svgp_gp_factor_bwd_early", cp, ws, st, self.side.cuda_stream)
+
+                def side_work():
+                    call("svgp_gp_factor_fwd_aji_tail", cp, ws, self.side.cuda_stream)
+                    # the first part of the early reverse half beside the tail on a third stream (it does not need the tail's
+                    # inverse), its second part behind both
+                    if self.side2 is not None:
+                        call("svgp_gp_factor_bwd_early_a", cp, ws, st, self.side2.cuda_stream)
+                        self.side.wait_stream(self.side2)
+                        call("svgp_gp_factor_bwd_early_b", cp, ws, st, self.side.cuda_stream)
+                    else:
+                        call("svgp_gp_factor_bwd_early", cp, ws, st, self.side.cuda_stream)
             else:
                 call("svgp_gp_factor_fwd", cp, ws, s)
         if self.chan_shard:
             # (round 4: M2 = Ki A Ki is neither formed nor exchanged -- the row stage evaluates k^T M2 k as w^T Si w)
             yield [ExchangeOp("allgather", fld("Si", mm_), sym(0, pre=True))] + plain("allgather", ("t", self.m), ("u", self.m))
-            call("svgp_gp_factor_fwd_channels_part", cp, l0, nl, 2, ws, sd.cuda_stream)
-            if self.side is not None:
-                call("svgp_gp_factor_bwd_channels_part", cp, l0, nl, 1, ws, st, sd.cuda_stream)
         with torch.cuda.stream(self.stream):
-            call("svgp_gp_posterior_fwd", cp, None if eps is None else eps.contiguous().data_ptr(), ws, st, s)
+            call("svgp_gp_posterior_fwd", cp, eps_ptr, ws, st, s)
+            if side_work is not None:
+                side_work()
             if self.svgp.titsias:
                 call("svgp_gp_titsias_fwd", cp, ws, st, s)
             # ---------------- decoder
             z = self._v("z", (b, L))
             self._mark("nets_fwd_dec")
             if prep_stream is not self.stream:
-                self.stream.wait_stream(prep_stream)
+                self.stream.wait_event(prep_done)
             h0, d = self._decoder_forward(z, b)
             x = d[-1]
             recon = x

@@ -463,6 +463,17 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
                            ws + wl.qnet_var, wbuf, Kn, s.KS + (size_t)b * m, s.sKS, s.X, s.qbar);
         SVGP_LAUNCH_CHECK();
         RUNC(svgp_dgemm_splitk(1, 0, 2 * m, m, b, 1.0, s.X, 2 * m, Kn, m, 0.0, s.Qs, m, s.sk2, s.sk2_elems, stream));   // Qs | Pbar^T (contiguous)
+        // SW_l = W^T diag(p_l) W in its row form (all rows local, b < 3 m; svgp_big_factor_bwd has the rule): here, at the end of the
+        // reverse statistics on the caller's stream, which then waits for the side branch anyway.  (SPRITES m = 800, kernel trace of
+        // round 4: issued early on a third stream it ran 1.4 ms instead of 0.35 beside the row stage's product and the tail's
+        // factorisation; A / B in one run: 18.15 vs 18.20 ms per step, i.e. no difference -- this form needs one stream less.)
+        // mm2 and the weights in scr_bl are untouched by the side branch.
+        if (!c->titsias && c->b == c->b_global && c->b < 3 * m) {
+            hipLaunchKernelGGL(k_big_recip, dim3(nblk((long long)b * L)), dim3(256), 0, st, b * L, ws + wl.qnet_var, s.wst);
+            SVGP_LAUNCH_CHECK();
+            RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, b, 1.0, s.W, m, 0, s.W, m, 0, 0.0, s.mm2, m, (long long)m * m, L,
+                                           stream, s.wst, L, 1));
+        }
     }
     // (K_mm + jI)^-1 and its log det (SVGPVAE_model.py:239,270,273) are formed by svgp_big_factor_fwd, in the same
     // launches as the L channel inverses
@@ -507,7 +518,9 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     }
     GEMV(1.0, Si, mm, v, t, L);                                                                  // t = Si v
     GEMM(0, 1, m, m, m, 1.0, Si, m, mm, K, m, 0, 0.0, G, m, mm, L);                              // G = Si K   (K = K^T read as [j][k])
-    {   // A = K G = K Si K, and A + jI beside it (the input of the tail's inverse: was a pass over (L, m, m))
+    {   // A = K G = K Si K, and A + jI beside it as a second output (the input of the tail's inverse).  A / B in one run at m = 800:
+        // 18.15 ms per step against 18.26 with a copy pass in front of the tail's inverse -- the product gets 240 us slower (four
+        // stores per element, two of them strided mirror stores), the side branch, which is the longer one, 100-150 us shorter
         svgp_gemm_epi ep;
         ep.C2 = Aji; ep.sc2 = mm; ep.a2 = 1.0; ep.d2 = c->jitter;
         RUNC(svgp_dgemm_symout_batched(c->gemm_f32 == 1, 0, 0, m, m, 1.0, K, m, 0, G, m, mm, 0.0, A, m, mm, L, stream, nullptr, 0, 0, &ep));
@@ -590,23 +603,17 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     a.v = ws + wl.v + ov;
     a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2; a.Sibar = s.mm1; a.Sg = s.mm1; a.HG = s.mm3; a.Ssym = ws + wl.Ssym + om;
     const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m), ntp = (unsigned)((m + TP - 1) / TP);
-    // early half, first part (3): SW_l = W^T diag(p_l) W = P^T S_l P -- forward quantities only, not even (A_hat + jI)^-1, so it can
-    // run beside the forward tail.  Over the rows (a statistics product with contraction b) when ALL rows of the batch are local
-    // (b == b_global) and that is the cheaper form (m^2 b against 3 m^3 per channel); from S_l otherwise -- under data
-    // parallelism S_l is the all-reduced statistic, so SW needs no exchange of its own (3 m^3 L / G flops per rank on the
-    // window).  mm2; T = S P in mm1 (free until the late half).
+    // SW_l = W^T diag(p_l) W = P^T S_l P -- forward quantities only.  Over the rows (a statistics product with contraction b) when ALL
+    // rows of the batch are local (b == b_global) and that is the cheaper form (m^2 b against 3 m^3 per channel): at the end of the
+    // reverse statistics (svgp_big_stats, mode 1).  From S_l otherwise -- under data parallelism S_l is the all-reduced statistic, so SW needs no exchange of
+    // its own (3 m^3 L / G flops per rank on the window): early half, first part (3), which needs not even (A_hat + jI)^-1 and can
+    // run beside the forward tail.  mm2; T = S P in mm1 (free until the late half).
     const bool has_sw = !c->titsias;
     a.SW = has_sw ? s.mm2 : nullptr;
-    if (has_sw && (part == 0 || part == 1 || part == 3)) {
-        if (c->b == c->b_global && c->b < 3 * m) {
-            hipLaunchKernelGGL(k_big_recip, dim3(nblk((long long)c->b * c->L)), dim3(256), 0, st, c->b * c->L, ws + wl.qnet_var, s.wst);
-            SVGP_LAUNCH_CHECK();
-            RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, c->b, 1.0, s.W, m, 0, s.W, m, 0, 0.0, s.mm2, m, mm, L, stream,
-                                           s.wst + l0, c->L, 1));
-        } else {
-            GEMM(0, 1, m, m, m, 1.0, ws + wl.S + om, m, mm, s.PT, m, 0, 0.0, s.mm1, m, mm, L);        // T = S P   (P = (P^T)^T)
-            GEMM_SYM(0, 0, m, m, 1.0, s.PT, m, 0, s.mm1, m, mm, 0.0, s.mm2, m, mm, L);                // SW = P^T T
-        }
+    const bool sw_rows = c->b == c->b_global && c->b < 3 * m;
+    if (has_sw && !sw_rows && (part == 0 || part == 1 || part == 3)) {
+        GEMM(0, 1, m, m, m, 1.0, ws + wl.S + om, m, mm, s.PT, m, 0, 0.0, s.mm1, m, mm, L);        // T = S P   (P = (P^T)^T)
+        GEMM_SYM(0, 0, m, m, 1.0, s.PT, m, 0, s.mm1, m, mm, 0.0, s.mm2, m, mm, L);                // SW = P^T T
     }
     if (part == 3) return SVGP_OK;
     if (part == 0 || part == 1 || part == 4) {

@@ -143,6 +143,9 @@ int svgp_dgemm_symout_batched(int f32c, int ta, int tb, int M, int K, double alp
                               const double* B, int ldb, long long strideB, double beta, double* C, int ldc, long long strideC,
                               int batch, void* stream, const double* wk = nullptr, int ldw = 0, long long strideW = 0,
                               const svgp_gemm_epi* epi = nullptr);
+int svgp_dgemm_bsub_batched(int f32c, int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA,
+                            const double* B, int ldb, long long strideB, const double* Bsub, double beta, double* C, int ldc,
+                            long long strideC, int batch, void* stream);
 int svgp_dgemm_epi_batched(int f32c, int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA,
                            const double* B, int ldb, long long strideB, double beta, double* C, int ldc, long long strideC,
                            int batch, void* stream, const svgp_gemm_epi* epi);

@@ -37,6 +37,9 @@ struct GemmArgs {
     // optional weights of the contraction index: op(B)[k][j] is multiplied by wk[k * ldw + l * sw] while it is staged
     // (S_l = Kn^T diag(w_l) Kn without materialising diag(w_l) Kn); element type = TS
     const void* wk; int ldw; long long sw;
+    // optional transform of the B operand while it is staged: op(B) := Bsub - op(B), Bsub stored like B (leading dimension ldb),
+    // shared by the batch (H = G (Ki - Aji) without materialising Ki - Aji: one pass over an (L, m, m) array less)
+    const void* bsub;
     // extended epilogue (svgp_gemm_epi, common.hpp; float64 storage): out1 = alpha acc + beta C + g1 E + d1 I -> C,
     // out2 = a2 acc + g2 E + d2 I -> C2 (same leading dimension as C); E: lde, batch stride se (0 = shared)
     int epi_on;
@@ -90,6 +93,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
     const TS* __restrict__ B = static_cast<const TS*>(g.B) + (size_t)l * g.sb;
     TS* C = static_cast<TS*>(g.C) + (size_t)l * g.sc;
     const TS* __restrict__ wk = g.wk ? static_cast<const TS*>(g.wk) + (size_t)l * g.sw : nullptr;
+    const TS* __restrict__ Bs2 = static_cast<const TS*>(g.bsub);          // (never together with wk: rw holds either)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
     const int wi = (wave >> 1) * 16 * WM, wj = (wave & 1) * 16 * WN;
     typename MF::acc_t acc[WM][WN];
@@ -145,9 +149,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
             const int kk = 2 * (tid & 7), xk = (tid >> 3) + 32 * h;
             if (TB) ldfast(B + (size_t)min(j0 + xk, g.N - 1) * g.ldb + k0 + kk, rb[2 * h], rb[2 * h + 1]);
             else ldfast(B + (size_t)(k0 + kx) * g.ldb + min(j0 + xx, g.N - 2), rb[2 * h], rb[2 * h + 1]);
-            if constexpr (decltype(hw)::value) {
+            if constexpr (decltype(hw)::value == 1) {
                 if (TB) { rw[2 * h] = (TC)wk[(size_t)(k0 + kk) * g.ldw]; rw[2 * h + 1] = (TC)wk[(size_t)(k0 + kk + 1) * g.ldw]; }
                 else rw[2 * h] = rw[2 * h + 1] = (TC)wk[(size_t)(k0 + kx) * g.ldw];
+            }
+            if constexpr (decltype(hw)::value == 2) {
+                if (TB) ldfast(Bs2 + (size_t)min(j0 + xk, g.N - 1) * g.ldb + k0 + kk, rw[2 * h], rw[2 * h + 1]);
+                else ldfast(Bs2 + (size_t)(k0 + kx) * g.ldb + min(j0 + xx, g.N - 2), rw[2 * h], rw[2 * h + 1]);
             }
         }
     };
@@ -168,10 +176,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
                     const int gk = k0 + kk;
                     ldfast(B + (size_t)min(j0 + xk, g.N - 1) * g.ldb + gk, rb[2 * h], rb[2 * h + 1]);
                     if (wk) { rw[2 * h] = (TC)wk[(size_t)gk * g.ldw]; rw[2 * h + 1] = (TC)wk[(size_t)(gk + 1) * g.ldw]; }
+                    if (Bs2) ldfast(Bs2 + (size_t)min(j0 + xk, g.N - 1) * g.ldb + gk, rw[2 * h], rw[2 * h + 1]);
                 } else {
                     const int gk = k0 + kx;
                     ldfast(B + (size_t)gk * g.ldb + min(j0 + xx, g.N - 2), rb[2 * h], rb[2 * h + 1]);
                     if (wk) rw[2 * h] = rw[2 * h + 1] = (TC)wk[(size_t)gk * g.ldw];
+                    if (Bs2) ldfast(Bs2 + (size_t)gk * g.ldb + min(j0 + xx, g.N - 2), rw[2 * h], rw[2 * h + 1]);
                 }
             }
             return;
@@ -199,19 +209,25 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
                     rw[2 * h] = gk < g.K ? (TC)wk[(size_t)gk * g.ldw] : TC(0);
                     rw[2 * h + 1] = gk + 1 < g.K ? (TC)wk[(size_t)(gk + 1) * g.ldw] : TC(0);
                 }
+                if (Bs2) ldchk(Bs2 + (size_t)gj * g.ldb + gk, gj < g.N && gk < g.K, gj < g.N && gk + 1 < g.K, rw[2 * h], rw[2 * h + 1]);
             } else {
                 const int gj = j0 + xx, gk = k0 + kx;
                 ldchk(B + (size_t)gk * g.ldb + gj, gk < g.K && gj < g.N, gk < g.K && gj + 1 < g.N, rb[2 * h], rb[2 * h + 1]);
                 if (wk) rw[2 * h] = rw[2 * h + 1] = gk < g.K ? (TC)wk[(size_t)gk * g.ldw] : TC(0);
+                if (Bs2) ldchk(Bs2 + (size_t)gk * g.ldb + gj, gk < g.K && gj < g.N, gk < g.K && gj + 1 < g.N, rw[2 * h], rw[2 * h + 1]);
             }
         }
     };
     auto stage = [&](int buf, auto hw) {
         TC* Ad = As + buf * GK * LDA_;
         TC* Bd = Bs + buf * GK * LDB_;
-        if constexpr (decltype(hw)::value) {
+        if constexpr (decltype(hw)::value == 1) {
 #pragma unroll
             for (int h = 0; h < 2 * NPB; ++h) rb[h] *= rw[h];
+        }
+        if constexpr (decltype(hw)::value == 2) {
+#pragma unroll
+            for (int h = 0; h < 2 * NPB; ++h) rb[h] = rw[h] - rb[h];
         }
 #pragma unroll
         for (int h = 0; h < NPA; ++h) {
@@ -239,10 +255,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
     // the LDS stores complete under the remaining three; panel p + 2 then starts its global loads, a full panel of
     // MFMAs ahead of its use -- the barrier at the end of a panel waits neither for memory nor for the LDS.  The operand
     // fragments of MFMA group s + 1 are read from LDS before group s issues.  (61.8 -> 64.6 TFLOP/s on exact tiles.)
-    const auto W1 = std::true_type{};
-    const auto W0 = std::false_type{};
+    const auto W1 = std::integral_constant<int, 1>{};
+    const auto W0 = std::integral_constant<int, 0>{};
+    const auto W2 = std::integral_constant<int, 2>{};
     fetch(klo);
-    if (wk) stage(0, W1); else stage(0, W0);
+    if (wk) stage(0, W1); else if (Bs2) stage(0, W2); else stage(0, W0);
     if (klo + GK < khi) fetch(klo + GK);
     __syncthreads();
     int cur = 0;
@@ -321,7 +338,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
         }
     };
     if (GEMM_PIPE && tile_fast) {
-        if (wk) steady(W1); else steady(W0);
+        if (wk) steady(W1); else if (Bs2) steady(W2); else steady(W0);
     }
     for (; k0 < khi; k0 += GK) {
         const TC* Ab = As + cur * GK * LDA_ + wi + r;
@@ -352,7 +369,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
                 for (int b = 0; b < WN; ++b) acc[a][b] = MF::mma(av[st & 1][a], bv[st & 1][b], acc[a][b]);
             __builtin_amdgcn_sched_barrier(0);
             if (st == 0) {
-                if (more) { if (wk) stage(cur ^ 1, W1); else stage(cur ^ 1, W0); }
+                if (more) { if (wk) stage(cur ^ 1, W1); else if (Bs2) stage(cur ^ 1, W2); else stage(cur ^ 1, W0); }
                 if (k0 + 2 * GK < khi) fetch(k0 + 2 * GK);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -672,7 +689,7 @@ __global__ __launch_bounds__(256) void k_bgjf_step(BgjfArgs g) {
 static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, double alpha, const void* A, int lda,
                        long long strideA, const void* B, int ldb, long long strideB, double beta, void* C, int ldc,
                        long long strideC, int batch, void* stream, const void* wk = nullptr, int ldw = 0,
-                       long long strideW = 0, const svgp_gemm_epi* epi = nullptr) {
+                       long long strideW = 0, const svgp_gemm_epi* epi = nullptr, const void* bsub = nullptr) {
     SVGP_REQUIRE(M >= 0 && N >= 0 && K >= 0 && batch >= 0, SVGP_ERR_INVALID, "negative dimension");
     if (M == 0 || N == 0 || batch == 0) return SVGP_OK;
     SVGP_REQUIRE(A && B && C, SVGP_ERR_INVALID, "NULL device pointer");
@@ -681,6 +698,8 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     g.sa = strideA; g.sb = strideB; g.sc = strideC; g.alpha = alpha; g.beta = beta; g.A = A; g.B = B; g.C = C;
     g.tri = tri;
     g.wk = wk; g.ldw = ldw; g.sw = strideW;
+    g.bsub = bsub;
+    SVGP_REQUIRE(!(wk && bsub), SVGP_ERR_INVALID, "contraction weights and a B transform together are not supported");
     g.epi_on = 0; g.E = nullptr; g.lde = 0; g.se = 0; g.C2 = nullptr; g.sc2 = 0; g.ldc2 = ldc; g.g1 = g.d1 = g.a2 = g.g2 = g.d2 = 0;
     if (epi) {
         SVGP_REQUIRE(prec != 2, SVGP_ERR_INVALID, "extended GEMM epilogue: float64 storage only");
@@ -754,7 +773,7 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     // 16-byte pair loads: both operands 16-byte aligned (8 for float32 storage) with even leading dimensions / batch strides
     const uintptr_t al = prec == 2 ? 8 : 16;
     const bool vec = ((uintptr_t)A % al) == 0 && ((uintptr_t)B % al) == 0 && lda % 2 == 0 && ldb % 2 == 0 && strideA % 2 == 0 &&
-                     strideB % 2 == 0;
+                     strideB % 2 == 0 && ((uintptr_t)bsub % al) == 0;
 #define LAUNCH_V(TA_, TB_, WT_, TS_, TC_, V_)                                                                            \
     do {                                                                                                                 \
         SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_batched<TA_, TB_, WT_, TS_, TC_, V_>),    \
@@ -862,6 +881,14 @@ int svgp_dgemm_symout_batched(int f32c, int ta, int tb, int M, int K, double alp
                               int batch, void* stream, const double* wk, int ldw, long long strideW, const svgp_gemm_epi* epi) {
     return gemm_launch(f32c ? 1 : 0, 1 | 16, ta, tb, M, M, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch,
                        stream, wk, ldw, strideW, epi);
+}
+// C = alpha op(A) (Bsub - op(B)) + beta C: the B operand is transformed while it is staged (Bsub shared by the batch, stored like B)
+int svgp_dgemm_bsub_batched(int f32c, int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA,
+                            const double* B, int ldb, long long strideB, const double* Bsub, double beta, double* C, int ldc,
+                            long long strideC, int batch, void* stream) {
+    SVGP_REQUIRE(Bsub, SVGP_ERR_INVALID, "Bsub is NULL");
+    return gemm_launch(f32c ? 1 : 0, 0, ta, tb, M, N, K, alpha, A, lda, strideA, B, ldb, strideB, beta, C, ldc, strideC, batch,
+                       stream, nullptr, 0, 0, nullptr, Bsub);
 }
 // the general product with the extended epilogue (svgp_gemm_epi)
 int svgp_dgemm_epi_batched(int f32c, int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda, long long strideA,

@@ -282,8 +282,11 @@ def stage_table(eng, B, M_IND):
          f8 * (b * (784 + act_enc + 3 * Lc) + b * m + m * m + b + b * (D + 1) + n_enc), 0.0),
         ("gp_stats_fwd", "svgp_gp_stats_fwd", (cfg, ws, s), 3 * Lc * b * m * m + 2 * m ** 3,
          f8 * (b * m + 2 * b * Lc + Lc * m * (m + 1)), 0.0),
+        # m > 64 (round 4, "W form"): per channel the inverse + G = Si K + A = K G; shared: Kn Ki, W = (Kn Ki) K, K Ki.
+        # m <= 64: the LDS-resident kernel still forms T = A Ki and M2 = Ki A Ki (4 products per channel)
         ("gp_factor_fwd", "svgp_gp_factor_fwd_defer_aji", (cfg, ws, s),
-         Lc * (2 * (m ** 3 / 3 + 2 * m ** 3 / 3) + 4 * 2 * m ** 3) + 2 * b * m * m, f8 * Lc * 7 * m * m, 0.0),
+         (Lc * (2 * m ** 3 + 2 * 2 * m ** 3) + 4 * b * m * m + 2 * m ** 3) if m > 64 else
+         (Lc * (2 * (m ** 3 / 3 + 2 * m ** 3 / 3) + 4 * 2 * m ** 3) + 2 * b * m * m), f8 * Lc * (5 if m > 64 else 7) * m * m, 0.0),
     ] + ([("gp_factor_fwd_aji_tail (side stream in the step)", "svgp_gp_factor_fwd_aji_tail", (cfg, ws, s), Lc * 2 * m ** 3,
            f8 * Lc * 2 * m * m, 0.0)] if m > 64 else []) + [
         ("gp_posterior_fwd", "svgp_gp_posterior_fwd_with_aji", (cfg, eps, ws, st, s), 4 * Lc * b * m * m,
@@ -292,14 +295,19 @@ def stage_table(eng, B, M_IND):
          f8 * (b * (Lc + act_dec + 2 * 784) + n_dec), 0.0),
         ("decoder_bwd", "svgp_mnist_decoder_bwd", (cfg, th, img, ws, st, s), 4 * dec_mac * b,
          f8 * (b * (Lc + act_dec + 2 * 784 + Lc) + 2 * n_dec), f8 * n_part * n_dec),
-        ("gp_stats_bwd", "svgp_gp_stats_bwd", (cfg, ws, st, s), 3 * Lc * b * m * m,
+        # m > 64: + the rank-local row terms [Qs; Pbar^T] = X^T Kn and (all rows local, b < 3 m) the statistic SW = W^T diag(p) W
+        ("gp_stats_bwd", "svgp_gp_stats_bwd", (cfg, ws, st, s),
+         3 * Lc * b * m * m + ((4 * b * m * m + (Lc * b * m * m if b < 3 * m else 0)) if m > 64 else 0),
          f8 * (b * m + 9 * b * Lc + Lc * m * (m + 2)), 0.0),
-    ] + ([("gp_factor_bwd_early (side stream in the step)", "svgp_gp_factor_bwd_early", (cfg, ws, st, s), Lc * 5.5 * 2 * m ** 3,
-           f8 * Lc * 10 * m * m, 0.0),
-          ("gp_factor_bwd", "svgp_gp_factor_bwd_late", (cfg, ws, st, s), Lc * 2.5 * 2 * m ** 3, f8 * Lc * 10 * m * m, 0.0)]
+    ] + ([  # early: H = G (Ki - Aji), H G^T (+ SW = P^T S P when it is not formed over the rows); late: Si X, (Si X) Si + single matrices
+          ("gp_factor_bwd_early (side stream in the step)", "svgp_gp_factor_bwd_early", (cfg, ws, st, s),
+           Lc * (2 * m ** 3 + m ** 3 + (0 if b < 3 * m else 3 * m ** 3)), f8 * Lc * 6 * m * m, 0.0),
+          ("gp_factor_bwd", "svgp_gp_factor_bwd_late", (cfg, ws, st, s), Lc * 2 * 2 * m ** 3 + 4 * 2 * m ** 3, f8 * Lc * 8 * m * m, 0.0)]
          if m > 64 else
          [("gp_factor_bwd", "svgp_gp_factor_bwd_nofinal", (cfg, ws, st, s), Lc * 9 * 2 * m ** 3, f8 * Lc * 14 * m * m, 0.0)]) + [
-        ("gp_posterior_bwd", "svgp_gp_posterior_bwd_with_final", (cfg, ws, st, s), 6 * Lc * b * m * m,
+        # m > 64: ONE (b, m, m) product per channel (Kn Ssym; Kn Si is the forward pass's) + Wbar P^T; m <= 64: three
+        ("gp_posterior_bwd", "svgp_gp_posterior_bwd_with_final", (cfg, ws, st, s),
+         (2 * Lc * b * m * m + 2 * b * m * m) if m > 64 else 6 * Lc * b * m * m,
          f8 * (Lc * 3 * m * m + 2 * Lc * b * m + 12 * b * Lc), 0.0),
         ("kernel_matrix_bwd", "svgp_kernel_matrix_bwd_partials", (cfg, th, aux, ws, s),
          (2 * b * m + 2 * m * m) * (2 * D + 20), f8 * (2 * b * m + 2 * m * m + b * (D + 1) + N_OBJ * (D - 1)), 0.0),

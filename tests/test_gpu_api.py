@@ -284,8 +284,19 @@ def test_cli_driver_epoch_trajectory_matches_oracle(golden, tmp_path, GECO):
     assert [s["rows"] for s in log["steps"]] == [256, 256, 128] * 2
     # ---- the oracle on the same inputs, built the way the reference's driver builds them
     params = {k: torch.tensor(v, dtype=DT) for k, v in O.glorot_uniform_init(16, seed=3).items()}
-    params["inducing_index_points"] = torch.tensor(
-        generate_init_inducing_points(None, n=2, PCA=True, M=8, aux_data=np.asarray(gin["aux"][:640])), dtype=DT)
+    #  the oracle's inducing points come from a restatement of utils.py:691-744 written out HERE, not from the
+    # product's initialiser -- which must then agree with it bit for bit (its own fixture test lives in test_driver_utils_cpu.py)
+    import scipy.stats
+    aux640 = np.asarray(gin["aux"][:640])
+    angles = np.linspace(0, 2 * np.pi, 17)[:-1]
+    rows = []
+    for i in range(16):
+        obj = np.concatenate([scipy.stats.gaussian_kde(aux640[:, ax]).resample(2, seed=i) for ax in range(2, 10)]).T
+        rows.append(np.hstack((np.full((2, 1), angles[i]), obj)))
+    ip_ref = np.concatenate(rows)
+    ip_ref = np.hstack((np.arange(len(ip_ref))[:, None].astype(float), ip_ref))
+    assert np.array_equal(generate_init_inducing_points(None, n=2, PCA=True, M=8, aux_data=aux640), ip_ref)
+    params["inducing_index_points"] = torch.tensor(ip_ref, dtype=DT)
     params["l_GP"], params["amplitude"] = torch.tensor(1.0, dtype=DT), torch.tensor(1.0, dtype=DT)
     params["object_vectors"] = torch.tensor(gin["object_vectors"], dtype=DT)
     img, aux = torch.tensor(gin["images"][:640], dtype=DT), torch.tensor(gin["aux"][:640], dtype=DT)

@@ -86,6 +86,25 @@ def test_split_factor_stages_equal_the_unsplit_ones(two_streams):
     del ws1
 
 
+def test_exchanged_symmetric_blocks_are_exactly_symmetric_in_memory():
+    """the packed exchange moves the LOWER tiles of S, Sigma^-1, A2 and Ssym and the owner keeps its own window as it
+    is -- owner and peers agree only because these blocks are exactly symmetric in memory (mirrored product stores, potri /
+    k_symmetrize, the tile-pair kernel).  Pinned here, bit for bit, on the workspace of a full step (Cholesky route, m >= 512,
+    and Gauss-Jordan route)."""
+    for m, M in ((520, 40), (130, 24)):
+        p, images, aux, eps = H.toy_problem(b=96, m=m, L=2, M=M, n_obj=40, seed=6)
+        eng = H.engine_for(p, 96, geco=True, N_train=500.0, jitter=1e-2)
+        dev = eng.device
+        eng.bind(images.to(dev), aux.to(dev), eps.to(dev))
+        eng.run(adam=False)
+        eng.synchronize()
+        for name in ("S", "Si", "A2", "Ssym", "A", "Aji"):
+            X = eng.ws_view(name, (2, m, m))
+            assert torch.equal(X, X.transpose(1, 2)), (m, name)
+        Ki = eng.ws_view("Ki", (m, m))
+        assert torch.equal(Ki, Ki.T)
+
+
 def test_split_entry_points_reject_the_lds_path():
     from svgp_vae_amd import _lib
     p, images, aux, eps = H.toy_problem(b=40, m=12, L=3, M=4, n_obj=20, seed=0)

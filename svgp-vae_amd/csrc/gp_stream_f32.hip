@@ -258,7 +258,7 @@ __global__ __launch_bounds__(ST_NT) void k_stats_mfma_f32(StatsArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;   // 2 x 4 waves: 128 x 64 per wave
     const bool vec = (a.m & 3) == 0;
-    const int lr = tid >> 6, lc = (tid & 63) * 4;   // staging: rows lr, lr + 8; columns lc..lc+3
+    const int lr = __builtin_amdgcn_readfirstlane(tid >> 6), lc = (tid & 63) * 4;   // staging: rows lr, lr + 8 (wave-uniform: the p_l loads are scalar); columns lc..lc+3
     const float* __restrict__ pl = a.pT + (size_t)l * a.n;
     // diagonal tiles (ti == tj): S is symmetric, so only the blocks (bi <= bj) of the 8 x 8 grid of 32 x 32 blocks are
     // computed; the reduction mirrors them.  Block list of wave w (row bi shared with row 7 - bi between two waves):

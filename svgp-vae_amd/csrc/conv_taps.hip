@@ -796,6 +796,180 @@ __global__ __launch_bounds__(256) void k_conv16_wgrad_roll(ConvLaunch L, int nwg
     }
 }
 
+// The rolling weight gradient for the layers a SPRITES step is made of: 16 -> 16 channels, image width a multiple of 16, taps = a full
+// NR x NC grid of consecutive row AND column offsets (3 x 3 stride 1 / 2, the 2 x 2 parity classes of the fused up-sampling layers,
+// 2 x 2 stride 2).  Same mapping as k_conv16_wgrad_roll, but with every extent a template constant the row loop is ONE basic block:
+//   * the 4 NT operand reads of a row are ds_read_b32 / b64 off NR per-lane row pointers with immediate offsets (no per-tap
+//     address arithmetic, no loops for the ring wrap-around, no bounds branches), so they are issued ahead of the MFMAs
+//     instead of four at a time in front of each tap with the LDS latency exposed nine times per row;
+//   * the next row's input vectors and dout / out values are requested at the top of the row under ONE uniform branch (none on the
+//     last row of a task: the roll kernel's clamped requests re-read 1 / RW of every tensor), and only the input vectors are
+//     waited for at the bottom, where they go into the ring slot the row has just vacated;
+//   * consecutive workgroup ids of one XCD walk neighbouring tasks (the halo rows two row blocks share stay in that XCD's L2).
+template <typename T, int NR, int NC, int SY, int SX, bool ACT>
+__global__ __launch_bounds__(256) void k_conv16_wgrad_grid(ConvLaunch L, int nwg, int RW, const T* __restrict__ in,
+                                                           const T* __restrict__ outv, T* __restrict__ dout,
+                                                           T* __restrict__ part, int part_stride, T* __restrict__ part_b) {
+    typedef SvgpMfma<T> MF;
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    static_assert(SY <= NR, "a row step may not skip input rows");
+    constexpr int NT = NR * NC, NEW = SY, KEEP = NR - NEW;
+    constexpr int HW = 15 * SX + NC, PS = SX == 1 ? 16 : 24, NI = (HW + 15) / 16, ROWE = HW * PS;
+    extern __shared__ __align__(32) unsigned char smem_raw[];
+    const int cls = blockIdx.y;
+    const svgp_conv_desc& d = L.d[cls];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, q = lane >> 4;
+    T* ring = reinterpret_cast<T*>(smem_raw) + (size_t)wave * (NR * ROWE);
+    const int sp = lane >> 2, sc = 4 * (lane & 3);                     // staging: pixel sp + 16 i, channels sc .. sc + 3
+    const T* const rbase = ring + q * SX * PS + r;                      // operand of k-step s, column c: + ((4 s SX + c) PS)
+    // the descriptor is indexed by the class: its fields are copied to scalars once (left in the argument block they are re-read,
+    // under branches, inside the row loop)
+    const int oy0 = d.oy[0], ox0 = d.ox[0], Hi = d.Hi, Wi = d.Wi, Ho = d.Ho, Wo = d.Wo, Hs = d.Hs, osy = d.osy, osx = d.osx,
+              ooy = d.ooy, oox = d.oox;
+    const int nseg = d.Ws >> 4, nrb = (Hs + RW - 1) / RW, ntask = d.n * nrb * nseg;
+    typename MF::acc_t acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = typename MF::acc_t{0, 0, 0, 0};
+    T bsum = 0;
+    int b = blockIdx.x;
+    { const int per8 = nwg >> 3; if ((per8 << 3) == nwg) b = (b & 7) * per8 + (b >> 3); }
+    for (int task = b * 4 + wave; task < ntask; task += nwg * 4) {
+        const int xs = task % nseg, rb = (task / nseg) % nrb, n = task / (nseg * nrb);
+        const T* inn = in + (size_t)n * Hi * Wi * 16;
+        const int ya = rb * RW, yb = min(Hs, ya + RW), xf = xs * 16, X0 = xf * SX + ox0;
+        // Every request goes to a valid address (row and column clamped into the image: uniform row pointer + 32-bit lane offset, no
+        // branch, no address select); what lies outside the image is zeroed when the vector is written to the ring.
+        // Lanes beyond the HW pixels of a ring row (last staging pass) repeat its last pixel: same request, same value, same ring
+        // address -- the ring write needs no predicate (under one the compiler sinks the REQUEST into the predicated block, behind the
+        // MFMAs, and waits for it there with vmcnt(0)).
+        unsigned goff[NI], woff[NI];
+        bool gok[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int p = min(sp + 16 * i, HW - 1), gx = X0 + p;
+            gok[i] = (unsigned)gx < (unsigned)Wi;
+            goff[i] = (unsigned)(min(max(gx, 0), Wi - 1) * 16 + sc);
+            woff[i] = (unsigned)(p * PS + sc);
+        }
+        auto gload = [&](int gy, int i) -> v4 {
+            const T* row = inn + (size_t)min(max(gy, 0), Hi - 1) * Wi * 16;
+            return *reinterpret_cast<const v4*>(row + goff[i]);
+        };
+        auto lwrite = [&](int slot, int i, v4 v, bool rowok) {
+            if (!(rowok && gok[i])) v = v4{0, 0, 0, 0};
+            *reinterpret_cast<v4*>(ring + slot * ROWE + woff[i]) = v;
+        };
+        unsigned doff[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) doff[s] = (unsigned)(((xf + 4 * s + q) * osx + oox) * 16 + r);
+        auto rowbase = [&](int y) -> size_t { return ((size_t)n * Ho + (y * osy + ooy)) * Wo * 16; };
+        // the ring of NR input rows: slot of input row ya SY + oy0 + rel = rel mod NR; `base` = slot of the current row's tap row 0
+        {
+            v4 v[NR][NI];
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) v[k][i] = gload(ya * SY + oy0 + k, i);
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) lwrite(k, i, v[k][i], (unsigned)(ya * SY + oy0 + k) < (unsigned)Hi);
+        }
+        int base = 0;
+        T cdA[4], coA[4], cdB[4], coB[4];
+        {
+            const size_t rb0 = rowbase(ya);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { cdA[s] = (dout + rb0)[doff[s]]; coA[s] = ACT ? (outv + rb0)[doff[s]] : T(1); }
+        }
+        // One output row; branch-free (with the next row's requests under `if (more)` the wait-count pass could not tell them from the
+        // ones it has to wait for, and every row began with s_waitcnt vmcnt(0)): on the last row of a task the requests re-read rows
+        // this wave has just read (cache hits) and their values are dropped.  cd / co_: this row's dout / out values (requested one row
+        // ago), nd / no: the next row's -- the caller alternates two register sets (a copy at the end of the row would wait for the
+        // requests it has just issued).
+        auto row = [&](int y, T (&cd)[4], T (&co_)[4], T (&nd)[4], T (&no)[4]) {
+            const bool more = y + 1 < yb;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // (1) requests for the next row, pinned in front of this row's work
+            const int yn = more ? y + 1 : y, gy0 = yn * SY + oy0 + KEEP;
+            v4 pre[NEW][NI];
+#pragma unroll
+            for (int k = 0; k < NEW; ++k)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) pre[k][i] = gload(gy0 + k, i);
+            {
+                const size_t rb1 = rowbase(yn);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { nd[s] = (dout + rb1)[doff[s]]; no[s] = ACT ? (outv + rb1)[doff[s]] : T(1); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // (2) this row: dpre = dout elu'(out), its store, the 4 NT products
+            const T* rk[NR];
+#pragma unroll
+            for (int k = 0; k < NR; ++k) { int sl = base + k; if (sl >= NR) sl -= NR; rk[k] = rbase + sl * ROWE; }
+            T bv[4];
+            {
+                T* dr = dout + rowbase(y);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    T dv = cd[s];
+                    if (ACT) { dv *= (co_[s] > 0 ? T(1) : co_[s] + T(1)); dr[doff[s]] = dv; }
+                    bv[s] = dv;
+                    bsum += dv;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[k * NC + c] = MF::mma(rk[k][(4 * s * SX + c) * PS], bv[s], acc[k * NC + c]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // (3) the next row's new input rows go where this row's first SY tap rows were
+#pragma unroll
+            for (int k = 0; k < NEW; ++k) {
+                int sl = base + k; if (sl >= NR) sl -= NR;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) lwrite(sl, i, pre[k][i], (unsigned)(gy0 + k) < (unsigned)Hi);
+            }
+            base += SY; if (base >= NR) base -= NR;
+        };
+        for (int y = ya; y < yb; y += 2) {
+            row(y, cdA, coA, cdB, coB);
+            if (y + 1 >= yb) break;
+            row(y + 1, cdB, coB, cdA, coA);
+        }
+    }
+    // ---- cross-wave combine (fixed order) and store.  D: col (co) = r, row (ci) = MF::row(q, g)
+    T* red = reinterpret_cast<T*>(smem_raw);                            // 4 waves x 64 lanes x 4
+    T* po = part + (size_t)blockIdx.x * part_stride;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[(wave * 64 + lane) * 4 + g] = acc[t][g];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const T v = red[lane * 4 + g] + red[(64 + lane) * 4 + g] + red[(128 + lane) * 4 + g] + red[(192 + lane) * 4 + g];
+                po[d.woff[t] + MF::row(q, g) * 16 + r] = v;
+            }
+        }
+    }
+    __syncthreads();
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        T v = 0;
+        for (int k = 0; k < 16; ++k) v += red[k * 16 + threadIdx.x];
+        part_b[((size_t)blockIdx.y * nwg + blockIdx.x) * 16 + threadIdx.x] = v;
+    }
+}
+
 // Weight gradient for 16 input channels, fused with the ELU reverse and the bias gradient:
 //   dpre = dout * elu'(out) (written back in place: the data gradient reads it), db[co] = sum dpre, dW_t[ci][co] = sum in * dpre.
 // GEMM per tap: A[i = ci][k = pixel] = in, B[k = pixel][j = co] = dpre, k-steps of 4 pixels of a 16-pixel segment.
@@ -1384,11 +1558,55 @@ static int conv_wgrad_fused_impl(const svgp_conv_desc* d, int ncls, const T* in,
         return conv_taps_wgrad_impl<T>(d, ncls, in, dout, part, nwg, part_stride, dw, 0, stream);
     }
     static const int roll_on = [] { const char* e = getenv("SVGP_CONV_ROLL"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const int grid_on = [] { const char* e = getenv("SVGP_CONV_WGRAD_GRID"); return (e && e[0] == '0') ? 0 : 1; }();
     ConvLaunch L;
     L.ncls = ncls;
     int nwg_c = nwg / ncls;
     if (nwg_c < 1) nwg_c = 1;
     if (nwg_c * ncls > 1024) nwg_c = 1024 / ncls;
+    // 16 -> 16 channels, width a multiple of 16, every class the same full grid of consecutive offsets: k_conv16_wgrad_grid
+    if (roll_on && grid_on) {
+        ConvLaunch G;
+        G.ncls = ncls;
+        int NR = 0, NC = 0;
+        bool ok = true;
+        for (int c = 0; c < ncls && ok; ++c) {
+            int nr = 0, nc = 0;
+            ok = d[c].Co == 16 && d[c].Ws % 16 == 0 && d[c].sy == d[0].sy && d[c].sx == d[0].sx && d[c].sy == d[c].sx &&
+                 d[c].Hs == d[0].Hs && d[c].Ws == d[0].Ws && conv16_grid(d[c], &G.d[c], &nr, &nc);
+            if (ok && c == 0) { NR = nr; NC = nc; }
+            ok = ok && nr == NR && nc == NC;
+            for (int x = 1; ok && x < nc; ++x) ok = G.d[c].ox[x] == G.d[c].ox[0] + x;
+        }
+        const int SY = d[0].sy;
+        ok = ok && ((NR == 3 && NC == 3 && (SY == 1 || SY == 2)) || (NR == 2 && NC == 2 && (SY == 1 || SY == 2)));
+        if (ok) {
+            const int RW = conv16_rows(d[0]), HW = 15 * SY + NC, PS = SY == 1 ? 16 : 24;
+            size_t lds = (size_t)4 * NR * HW * PS;
+            if (lds < 1024) lds = 1024;
+            lds *= sizeof(T);
+#define C16G(NR_, NC_, S_)                                                                                                  \
+            if (NR == NR_ && NC == NC_ && SY == S_) {                                                                       \
+                if (outv) {                                                                                                 \
+                    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv16_wgrad_grid<T, NR_, NC_, S_, S_, true>),  \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
+                    hipLaunchKernelGGL((k_conv16_wgrad_grid<T, NR_, NC_, S_, S_, true>), dim3(nwg_c, ncls), dim3(256), lds,  \
+                                       (hipStream_t)stream, G, nwg_c, RW, in, outv, dout, part, part_stride, part_b);      \
+                } else {                                                                                                    \
+                    SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv16_wgrad_grid<T, NR_, NC_, S_, S_, false>), \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));             \
+                    hipLaunchKernelGGL((k_conv16_wgrad_grid<T, NR_, NC_, S_, S_, false>), dim3(nwg_c, ncls), dim3(256), lds, \
+                                       (hipStream_t)stream, G, nwg_c, RW, in, outv, dout, part, part_stride, part_b);      \
+                }                                                                                                           \
+            }
+            C16G(3, 3, 1) C16G(3, 3, 2) C16G(2, 2, 1) C16G(2, 2, 2)
+#undef C16G
+            SVGP_LAUNCH_CHECK();
+            rc = sum_partials<T>(nwg_c, part_stride, part_stride, (const T*)part, dw, 0, stream);
+            if (rc) return rc;
+            return sum_partials<T>(nwg_c * ncls, 16, 16, (const T*)part_b, db, 0, stream);
+        }
+    }
     size_t lpw = 0, lpw_roll = 0;
     const int RW = conv16_rows(d[0]);
     bool roll = roll_on && d[0].Ws >= 16 && (d[0].sy == 1 || d[0].sy == 2);

@@ -32,6 +32,8 @@ CASES = [
     (6, 16, 16, 3, 1, "same", False, True),
     (5, 16, 7, 3, 1, "same", True, False),
     (18, 16, 11, 2, 2, "same", False, True),
+    # k_conv16_wgrad_grid (16 -> 16, width a multiple of 16): three 16-pixel segments (interior halo columns are real pixels)
+    (48, 16, 16, 3, 1, "same", False, True),
 ]
 
 
@@ -108,3 +110,18 @@ def test_conv_layer_forward_and_gradients(Hi, Ci, Co, k, stride, padding, up, el
     assert rel(ggb, gb) < 1e-11
     assert rel(ggw, gw) < 1e-11
     assert rel(gdx, gx) < 1e-11
+
+
+@pytest.mark.parametrize("rows", [3, 5])
+def test_conv16_weight_gradient_odd_row_blocks(rows):
+    """k_conv16_wgrad_grid walks a task's rows in pairs (two register sets) and re-reads the current row on the last one: run the
+    16 -> 16 layer cases with SVGP_CONV_ROWS = 3 and 5 rows per wave (odd counts; 32 = 10 x 3 + 2 and 6 x 5 + 2 leave a short last
+    block).  The row count is read once per process, hence the child interpreter."""
+    import os, subprocess, sys
+    env = dict(os.environ, SVGP_CONV_ROWS=str(rows))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_conv.py"), "-x", "-q", "-k",
+                        "64-16-16-3-2 or 16-16-16-3-1-same-False or 32-16-16-3-1-same-True or 32-16-16-2-2 or 48-16-16-3-1"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "no tests ran" not in r.stdout

@@ -970,6 +970,159 @@ __global__ __launch_bounds__(256) void k_conv16_wgrad_grid(ConvLaunch L, int nwg
     }
 }
 
+// The same row pipeline for the THIN first layers (CI = 3 input channels -> 16: spritesVAE's first encoder layer, the representation
+// network's first layer), whose weight gradient k_convS_wgrad formed from per-lane dword gathers issued right in front of their MFMA
+// (256 us at 64 x 64 x 500 frames for 418 MB of traffic).  dW[(t, ci)][co] = sum_pix dpre[pix][co] in[pix (+) t][ci]:
+//   A = dpre [co = r][pixel k] exactly as in k_conv16_wgrad_grid (ELU', in-place store, bias sum, alternating register sets);
+//   B = in [pixel k][j = (t, ci)], j in blocks of 16, read from a wave-private LDS ring of NR input rows -- a ring row is the
+//       contiguous run of HW x CI input values (54 floats for 3 x 3, stride 1): ONE dword request per lane per new row; the ring
+//       rows are ROWE elements apart so that the 18 / 24 values one k-step touches in each row fall into disjoint banks.
+// 2 NB MFMAs per 4 pixels; per output row 8 MFMAs, 8 LDS reads, 9 requests, 4 stores: the kernel runs at the HBM rate.
+template <typename T, int NR, int NC, int S, int CI, bool ACT>
+__global__ __launch_bounds__(256) void k_convS_wgrad_ring(svgp_conv_desc d, int nwg, int RW, const T* __restrict__ in,
+                                                          const T* __restrict__ outv, T* __restrict__ dout,
+                                                          T* __restrict__ part, int part_stride, T* __restrict__ part_b) {
+    typedef SvgpMfma<T> MF;
+    constexpr int NT = NR * NC, JT = NT * CI, NB = (JT + 15) / 16, KEEP = NR - S;
+    constexpr int HW = 15 * S + NC, RUN = HW * CI, NI = (RUN + 63) / 64, ROWE = S == 1 ? 84 : 96;
+    static_assert(S <= NR && RUN <= ROWE, "ring row");
+    __shared__ T smem[4 * NR * ROWE > 1024 ? 4 * NR * ROWE : 1024];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, q = lane >> 4;
+    T* ring = smem + wave * (NR * ROWE);
+    const int oy0 = d.oy[0], ox0 = d.ox[0], Hi = d.Hi, Wi = d.Wi, Ho = d.Ho, Wo = d.Wo, Hs = d.Hs, osy = d.osy, osx = d.osx,
+              ooy = d.ooy, oox = d.oox;
+    const int nseg = d.Ws >> 4, nrb = (Hs + RW - 1) / RW, ntask = d.n * nrb * nseg;
+    // this lane's column j = (t, ci) of each block: tap row (ring slot offset) and element offset inside a ring row
+    int jkr[NB], jofs[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int j = min(16 * nb + r, JT - 1), t = j / CI, ci = j - t * CI, kr = t / NC, kc = t - kr * NC;
+        jkr[nb] = kr;
+        jofs[nb] = (q * S + kc) * CI + ci;
+    }
+    typename MF::acc_t acc[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) acc[nb] = typename MF::acc_t{0, 0, 0, 0};
+    T bsum = 0;
+    int b = blockIdx.x;
+    { const int per8 = nwg >> 3; if ((per8 << 3) == nwg) b = (b & 7) * per8 + (b >> 3); }
+    for (int task = b * 4 + wave; task < ntask; task += nwg * 4) {
+        const int xs = task % nseg, rb = (task / nseg) % nrb, n = task / (nseg * nrb);
+        const T* inn = in + (size_t)n * Hi * Wi * CI;
+        const int ya = rb * RW, yb = min(Hs, ya + RW), xf = xs * 16, X0 = xf * S + ox0;
+        // staging: element e = lane + 64 i of the run (lanes beyond it repeat its last element: no predicate on the ring write)
+        unsigned goff[NI], woff[NI];
+        bool gok[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = min(lane + 64 * i, RUN - 1), p = e / CI, gx = X0 + p;
+            gok[i] = (unsigned)gx < (unsigned)Wi;
+            goff[i] = (unsigned)(min(max(gx, 0), Wi - 1) * CI + (e - p * CI));
+            woff[i] = (unsigned)e;
+        }
+        auto gload = [&](int gy, int i) -> T { return (inn + (size_t)min(max(gy, 0), Hi - 1) * Wi * CI)[goff[i]]; };
+        auto lwrite = [&](int slot, int i, T v, bool rowok) { ring[slot * ROWE + woff[i]] = (rowok && gok[i]) ? v : T(0); };
+        unsigned doff[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) doff[s] = (unsigned)(((xf + 4 * s + q) * osx + oox) * 16 + r);
+        auto rowbase = [&](int y) -> size_t { return ((size_t)n * Ho + (y * osy + ooy)) * Wo * 16; };
+        {
+            T v[NR][NI];
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) v[k][i] = gload(ya * S + oy0 + k, i);
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) lwrite(k, i, v[k][i], (unsigned)(ya * S + oy0 + k) < (unsigned)Hi);
+        }
+        int base = 0;
+        T cdA[4], coA[4], cdB[4], coB[4];
+        {
+            const size_t rb0 = rowbase(ya);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { cdA[s] = (dout + rb0)[doff[s]]; coA[s] = ACT ? (outv + rb0)[doff[s]] : T(1); }
+        }
+        auto row = [&](int y, T (&cd)[4], T (&co_)[4], T (&nd)[4], T (&no)[4]) {      // (see k_conv16_wgrad_grid)
+            const bool more = y + 1 < yb;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int yn = more ? y + 1 : y, gy0 = yn * S + oy0 + KEEP;
+            T pre[S][NI];
+#pragma unroll
+            for (int k = 0; k < S; ++k)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) pre[k][i] = gload(gy0 + k, i);
+            {
+                const size_t rb1 = rowbase(yn);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { nd[s] = (dout + rb1)[doff[s]]; no[s] = ACT ? (outv + rb1)[doff[s]] : T(1); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const T* rj[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) { int sl = base + jkr[nb]; if (sl >= NR) sl -= NR; rj[nb] = ring + sl * ROWE + jofs[nb]; }
+            T bv[4];
+            {
+                T* dr = dout + rowbase(y);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    T dv = cd[s];
+                    if (ACT) { dv *= (co_[s] > 0 ? T(1) : co_[s] + T(1)); dr[doff[s]] = dv; }
+                    bv[s] = dv;
+                    bsum += dv;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = MF::mma(bv[s], rj[nb][4 * s * S * CI], acc[nb]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                int sl = base + k; if (sl >= NR) sl -= NR;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) lwrite(sl, i, pre[k][i], (unsigned)(gy0 + k) < (unsigned)Hi);
+            }
+            base += S; if (base >= NR) base -= NR;
+        };
+        for (int y = ya; y < yb; y += 2) {
+            row(y, cdA, coA, cdB, coB);
+            if (y + 1 >= yb) break;
+            row(y + 1, cdB, coB, cdA, coA);
+        }
+    }
+    // cross-wave combine (fixed order); D: column j = 16 nb + r, row co = MF::row(q, g)
+    T* red = smem;
+    T* po = part + (size_t)blockIdx.x * part_stride;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) red[(wave * 64 + lane) * 4 + g] = acc[nb][g];
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const T v = red[lane * 4 + g] + red[(64 + lane) * 4 + g] + red[(128 + lane) * 4 + g] + red[(192 + lane) * 4 + g];
+                const int j = 16 * nb + r;
+                if (j < JT) { const int t = j / CI, ci = j - t * CI; po[d.woff[t] + ci * 16 + MF::row(q, g)] = v; }
+            }
+        }
+    }
+    __syncthreads();
+    red[threadIdx.x] = bsum;
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        T v = 0;
+        for (int k = 0; k < 16; ++k) v += red[k * 16 + threadIdx.x];
+        part_b[(size_t)blockIdx.x * 16 + threadIdx.x] = v;
+    }
+}
+
 // Weight gradient for 16 input channels, fused with the ELU reverse and the bias gradient:
 //   dpre = dout * elu'(out) (written back in place: the data gradient reads it), db[co] = sum dpre, dW_t[ci][co] = sum in * dpre.
 // GEMM per tap: A[i = ci][k = pixel] = in, B[k = pixel][j = co] = dpre, k-steps of 4 pixels of a 16-pixel segment.
@@ -1525,6 +1678,32 @@ static int conv_wgrad_fused_impl(const svgp_conv_desc* d, int ncls, const T* in,
             if (d[c].Ci >= 16 || d[c].nt * d[c].Ci > 32) m0 = false;
             if (d[c].Ci != 16 || d[c].nt * d[c].Co > 32 || d[c].sy != 1 || d[c].sx != 1 || d[c].osy != 1 || d[c].osx != 1 ||
                 d[c].ooy || d[c].oox || d[c].Hs != d[c].Ho || d[c].Ws != d[c].Wo) m1 = false;
+        }
+        // 3 -> 16 channels, one class, width a multiple of 16, full grid of consecutive offsets: k_convS_wgrad_ring
+        static const int ring_on = [] { const char* e = getenv("SVGP_CONV_WGRAD_RING"); return (e && e[0] == '0') ? 0 : 1; }();
+        if (m0 && ring_on && ncls == 1 && d[0].Ci == 3 && d[0].Co == 16 && d[0].Ws % 16 == 0 && d[0].sy == d[0].sx) {
+            svgp_conv_desc g;
+            int NR = 0, NC = 0;
+            bool ok = conv16_grid(d[0], &g, &NR, &NC);
+            for (int x = 1; ok && x < NC; ++x) ok = g.ox[x] == g.ox[0] + x;
+            const int S = d[0].sy;
+            ok = ok && ((NR == 3 && NC == 3 && S == 1) || (NR == 2 && NC == 2 && S == 2));
+            if (ok) {
+                const int nw = nwg > 1024 ? 1024 : nwg, RW = conv16_rows(d[0]);
+#define CSR(NR_, NC_, S_)                                                                                                   \
+                if (NR == NR_ && NC == NC_ && S == S_) {                                                                    \
+                    if (outv) hipLaunchKernelGGL((k_convS_wgrad_ring<T, NR_, NC_, S_, 3, true>), dim3(nw), dim3(256), 0,    \
+                                                 (hipStream_t)stream, g, nw, RW, in, outv, dout, part, part_stride, part_b);\
+                    else hipLaunchKernelGGL((k_convS_wgrad_ring<T, NR_, NC_, S_, 3, false>), dim3(nw), dim3(256), 0,        \
+                                            (hipStream_t)stream, g, nw, RW, in, outv, dout, part, part_stride, part_b);    \
+                }
+                CSR(3, 3, 1) CSR(2, 2, 2)
+#undef CSR
+                SVGP_LAUNCH_CHECK();
+                rc = sum_partials<T>(nw, part_stride, part_stride, (const T*)part, dw, 0, stream);
+                if (rc) return rc;
+                return sum_partials<T>(nw, 16, 16, (const T*)part_b, db, 0, stream);
+            }
         }
         if (m0 || m1) {
             int nw = nwg > 1024 ? 1024 : nwg;

@@ -43,7 +43,7 @@ def _oracle(x, w, b, k, stride, padding, up, elu):
     return F.elu(y) if elu else y
 
 
-@pytest.mark.parametrize("Hi,Ci,Co,k,stride,padding,up,elu", [c for c in CASES if c[1] == 16])
+@pytest.mark.parametrize("Hi,Ci,Co,k,stride,padding,up,elu", [c for c in CASES if c[1] == 16 or c[1] == 3])
 def test_conv16_direct_kernels_float32(Hi, Ci, Co, k, stride, padding, up, elu):
     """The float32 instances of the 16-channel kernels (v_mfma_f32_16x16x4_f32; v_exp_f32 ELU epilogue in the rolling forward
     kernel) against the float64 oracle: forward 2e-6, gradients 2e-5 relative (float32 accumulation over n x Ho x Ho pixels)."""
@@ -121,7 +121,7 @@ def test_conv16_weight_gradient_odd_row_blocks(rows):
     env = dict(os.environ, SVGP_CONV_ROWS=str(rows))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_conv.py"), "-x", "-q", "-k",
-                        "64-16-16-3-2 or 16-16-16-3-1-same-False or 32-16-16-3-1-same-True or 32-16-16-2-2 or 48-16-16-3-1"],
+                        "64-16-16-3-2 or 16-16-16-3-1-same-False or 32-16-16-3-1-same-True or 32-16-16-2-2 or 48-16-16-3-1 or 64-3-16"],
                        env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "no tests ran" not in r.stdout

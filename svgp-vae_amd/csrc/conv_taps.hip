@@ -970,35 +970,43 @@ __global__ __launch_bounds__(256) void k_conv16_wgrad_grid(ConvLaunch L, int nwg
     }
 }
 
-// The same row pipeline for the THIN first layers (CI = 3 input channels -> 16: spritesVAE's first encoder layer, the representation
-// network's first layer), whose weight gradient k_convS_wgrad formed from per-lane dword gathers issued right in front of their MFMA
-// (256 us at 64 x 64 x 500 frames for 418 MB of traffic).  dW[(t, ci)][co] = sum_pix dpre[pix][co] in[pix (+) t][ci]:
-//   A = dpre [co = r][pixel k] exactly as in k_conv16_wgrad_grid (ELU', in-place store, bias sum, alternating register sets);
-//   B = in [pixel k][j = (t, ci)], j in blocks of 16, read from a wave-private LDS ring of NR input rows -- a ring row is the
-//       contiguous run of HW x CI input values (54 floats for 3 x 3, stride 1): ONE dword request per lane per new row; the ring
-//       rows are ROWE elements apart so that the 18 / 24 values one k-step touches in each row fall into disjoint banks.
-// 2 NB MFMAs per 4 pixels; per output row 8 MFMAs, 8 LDS reads, 9 requests, 4 stores: the kernel runs at the HBM rate.
-template <typename T, int NR, int NC, int S, int CI, bool ACT>
+// The same row pipeline for the THIN layers (CT = 3 channels on one side: spritesVAE's first encoder layer and the representation
+// network's first layer, 3 -> 16; the last decoder layer, 16 -> 3), whose weight gradient k_convS_wgrad formed from per-lane dword
+// gathers issued right in front of their MFMA (256 us at 64 x 64 x 500 frames for 418 MB of traffic).
+//   MODE 0 (3 -> 16): dW[(t, ci)][co] = sum_pix dpre[pix][co] in[pix (+) t][ci]
+//     wide operand A = dpre [co = r][pixel k] exactly as in k_conv16_wgrad_grid (ELU', in-place store, bias sum, alternating
+//     register sets); thin operand B = in [pixel k][j = (t, ci)];
+//   MODE 1 (16 -> 3, stride 1): dW[ci][(t, co)] = sum_pix' in[pix'][ci] dpre[pix' (-) t][co] -- the sum re-indexed over INPUT pixels so
+//     that the 16-channel operand is tap-independent: wide operand A = in [ci = r][pixel' k], thin operand B = dpre (ELU' applied
+//     by a separate pass over the 3-channel tensor), tap grid mirrored.
+// The thin operand is read from a wave-private LDS ring of NR rows -- a ring row is the contiguous run of HW x CT values (54 floats
+// for 3 x 3, stride 1): ONE dword request per lane per new row; ring rows are ROWE elements apart so that the 18 / 24 values one
+// k-step touches in each row fall into disjoint banks.  j in blocks of 16: 2 NB MFMAs per 4 pixels; per output row 8 MFMAs, 8 LDS
+// reads, 5 - 9 requests, 4 stores: the kernel runs at the HBM rate.
+template <typename T, int NR, int NC, int S, int CT, bool ACT, int MODE>
 __global__ __launch_bounds__(256) void k_convS_wgrad_ring(svgp_conv_desc d, int nwg, int RW, const T* __restrict__ in,
                                                           const T* __restrict__ outv, T* __restrict__ dout,
                                                           T* __restrict__ part, int part_stride, T* __restrict__ part_b) {
     typedef SvgpMfma<T> MF;
-    constexpr int NT = NR * NC, JT = NT * CI, NB = (JT + 15) / 16, KEEP = NR - S;
-    constexpr int HW = 15 * S + NC, RUN = HW * CI, NI = (RUN + 63) / 64, ROWE = S == 1 ? 84 : 96;
-    static_assert(S <= NR && RUN <= ROWE, "ring row");
+    constexpr int NT = NR * NC, JT = NT * CT, NB = (JT + 15) / 16, KEEP = NR - S;
+    constexpr int HW = 15 * S + NC, RUN = HW * CT, NI = (RUN + 63) / 64, ROWE = S == 1 ? 84 : 96;
+    static_assert(S <= NR && RUN <= ROWE && (MODE == 0 || (S == 1 && !ACT)), "ring row / mode");
     __shared__ T smem[4 * NR * ROWE > 1024 ? 4 * NR * ROWE : 1024];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, q = lane >> 4;
     T* ring = smem + wave * (NR * ROWE);
-    const int oy0 = d.oy[0], ox0 = d.ox[0], Hi = d.Hi, Wi = d.Wi, Ho = d.Ho, Wo = d.Wo, Hs = d.Hs, osy = d.osy, osx = d.osx,
-              ooy = d.ooy, oox = d.oox;
-    const int nseg = d.Ws >> 4, nrb = (Hs + RW - 1) / RW, ntask = d.n * nrb * nseg;
-    // this lane's column j = (t, ci) of each block: tap row (ring slot offset) and element offset inside a ring row
+    const int oy0 = d.oy[0], ox0 = d.ox[0], Hi = d.Hi, Wi = d.Wi, Ho = d.Ho, Wo = d.Wo, osy = d.osy, osx = d.osx, ooy = d.ooy,
+              oox = d.oox;
+    // iteration space: output pixels (MODE 0) / input pixels (MODE 1); thin tensor: the input / the output gradient
+    const int Hit = MODE ? Hi : d.Hs, Wit = MODE ? Wi : d.Ws, TH = MODE ? Ho : Hi, TW = MODE ? Wo : Wi;
+    const T* thin = MODE ? dout : in;
+    const int nseg = Wit >> 4, nrb = (Hit + RW - 1) / RW, ntask = d.n * nrb * nseg;
+    // this lane's column j = (t, c) of each block: tap row (ring slot offset) and element offset inside a ring row
     int jkr[NB], jofs[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const int j = min(16 * nb + r, JT - 1), t = j / CI, ci = j - t * CI, kr = t / NC, kc = t - kr * NC;
-        jkr[nb] = kr;
-        jofs[nb] = (q * S + kc) * CI + ci;
+        const int j = min(16 * nb + r, JT - 1), t = j / CT, c = j - t * CT, kr = t / NC, kc = t - kr * NC;
+        jkr[nb] = MODE ? NR - 1 - kr : kr;
+        jofs[nb] = (q * S + (MODE ? NC - 1 - kc : kc)) * CT + c;
     }
     typename MF::acc_t acc[NB];
 #pragma unroll
@@ -1008,48 +1016,53 @@ __global__ __launch_bounds__(256) void k_convS_wgrad_ring(svgp_conv_desc d, int 
     { const int per8 = nwg >> 3; if ((per8 << 3) == nwg) b = (b & 7) * per8 + (b >> 3); }
     for (int task = b * 4 + wave; task < ntask; task += nwg * 4) {
         const int xs = task % nseg, rb = (task / nseg) % nrb, n = task / (nseg * nrb);
-        const T* inn = in + (size_t)n * Hi * Wi * CI;
-        const int ya = rb * RW, yb = min(Hs, ya + RW), xf = xs * 16, X0 = xf * S + ox0;
+        const T* thn = thin + (size_t)n * TH * TW * CT;
+        const int ya = rb * RW, yb = min(Hit, ya + RW), xf = xs * 16, X0 = MODE ? xf - ox0 - (NC - 1) : xf * S + ox0;
+        auto trow0 = [&](int y) -> int { return MODE ? y - oy0 - (NR - 1) : y * S + oy0; };      // first thin row of wide row y
         // staging: element e = lane + 64 i of the run (lanes beyond it repeat its last element: no predicate on the ring write)
         unsigned goff[NI], woff[NI];
         bool gok[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int e = min(lane + 64 * i, RUN - 1), p = e / CI, gx = X0 + p;
-            gok[i] = (unsigned)gx < (unsigned)Wi;
-            goff[i] = (unsigned)(min(max(gx, 0), Wi - 1) * CI + (e - p * CI));
+            const int e = min(lane + 64 * i, RUN - 1), p = e / CT, gx = X0 + p;
+            gok[i] = (unsigned)gx < (unsigned)TW;
+            goff[i] = (unsigned)(min(max(gx, 0), TW - 1) * CT + (e - p * CT));
             woff[i] = (unsigned)e;
         }
-        auto gload = [&](int gy, int i) -> T { return (inn + (size_t)min(max(gy, 0), Hi - 1) * Wi * CI)[goff[i]]; };
+        auto gload = [&](int gy, int i) -> T { return (thn + (size_t)min(max(gy, 0), TH - 1) * TW * CT)[goff[i]]; };
         auto lwrite = [&](int slot, int i, T v, bool rowok) { ring[slot * ROWE + woff[i]] = (rowok && gok[i]) ? v : T(0); };
         unsigned doff[4];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) doff[s] = (unsigned)(((xf + 4 * s + q) * osx + oox) * 16 + r);
-        auto rowbase = [&](int y) -> size_t { return ((size_t)n * Ho + (y * osy + ooy)) * Wo * 16; };
+        for (int s = 0; s < 4; ++s)
+            doff[s] = MODE ? (unsigned)((xf + 4 * s + q) * 16 + r) : (unsigned)(((xf + 4 * s + q) * osx + oox) * 16 + r);
+        auto rowbase = [&](int y) -> size_t {
+            return MODE ? ((size_t)n * Hi + y) * Wi * 16 : ((size_t)n * Ho + (y * osy + ooy)) * Wo * 16;
+        };
+        const T* wide = MODE ? in : dout;
         {
             T v[NR][NI];
 #pragma unroll
             for (int k = 0; k < NR; ++k)
 #pragma unroll
-                for (int i = 0; i < NI; ++i) v[k][i] = gload(ya * S + oy0 + k, i);
+                for (int i = 0; i < NI; ++i) v[k][i] = gload(trow0(ya) + k, i);
 #pragma unroll
             for (int k = 0; k < NR; ++k)
 #pragma unroll
-                for (int i = 0; i < NI; ++i) lwrite(k, i, v[k][i], (unsigned)(ya * S + oy0 + k) < (unsigned)Hi);
+                for (int i = 0; i < NI; ++i) lwrite(k, i, v[k][i], (unsigned)(trow0(ya) + k) < (unsigned)TH);
         }
         int base = 0;
         T cdA[4], coA[4], cdB[4], coB[4];
         {
             const size_t rb0 = rowbase(ya);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) { cdA[s] = (dout + rb0)[doff[s]]; coA[s] = ACT ? (outv + rb0)[doff[s]] : T(1); }
+            for (int s = 0; s < 4; ++s) { cdA[s] = (wide + rb0)[doff[s]]; coA[s] = ACT ? (outv + rb0)[doff[s]] : T(1); }
         }
         auto row = [&](int y, T (&cd)[4], T (&co_)[4], T (&nd)[4], T (&no)[4]) {      // (see k_conv16_wgrad_grid)
             const bool more = y + 1 < yb;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int yn = more ? y + 1 : y, gy0 = yn * S + oy0 + KEEP;
+            const int yn = more ? y + 1 : y, gy0 = trow0(yn) + KEEP;
             T pre[S][NI];
 #pragma unroll
             for (int k = 0; k < S; ++k)
@@ -1058,7 +1071,7 @@ __global__ __launch_bounds__(256) void k_convS_wgrad_ring(svgp_conv_desc d, int 
             {
                 const size_t rb1 = rowbase(yn);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) { nd[s] = (dout + rb1)[doff[s]]; no[s] = ACT ? (outv + rb1)[doff[s]] : T(1); }
+                for (int s = 0; s < 4; ++s) { nd[s] = (wide + rb1)[doff[s]]; no[s] = ACT ? (outv + rb1)[doff[s]] : T(1); }
             }
             __builtin_amdgcn_sched_barrier(0);
             const T* rj[NB];
@@ -1072,20 +1085,20 @@ __global__ __launch_bounds__(256) void k_convS_wgrad_ring(svgp_conv_desc d, int 
                     T dv = cd[s];
                     if (ACT) { dv *= (co_[s] > 0 ? T(1) : co_[s] + T(1)); dr[doff[s]] = dv; }
                     bv[s] = dv;
-                    bsum += dv;
+                    if (MODE == 0) bsum += dv;
                 }
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) acc[nb] = MF::mma(bv[s], rj[nb][4 * s * S * CI], acc[nb]);
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = MF::mma(bv[s], rj[nb][4 * s * S * CT], acc[nb]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < S; ++k) {
                 int sl = base + k; if (sl >= NR) sl -= NR;
 #pragma unroll
-                for (int i = 0; i < NI; ++i) lwrite(sl, i, pre[k][i], (unsigned)(gy0 + k) < (unsigned)Hi);
+                for (int i = 0; i < NI; ++i) lwrite(sl, i, pre[k][i], (unsigned)(gy0 + k) < (unsigned)TH);
             }
             base += S; if (base >= NR) base -= NR;
         };
@@ -1095,7 +1108,7 @@ __global__ __launch_bounds__(256) void k_convS_wgrad_ring(svgp_conv_desc d, int 
             row(y + 1, cdB, coB, cdA, coA);
         }
     }
-    // cross-wave combine (fixed order); D: column j = 16 nb + r, row co = MF::row(q, g)
+    // cross-wave combine (fixed order); D: column j = 16 nb + r, row i (wide channel) = MF::row(q, g)
     T* red = smem;
     T* po = part + (size_t)blockIdx.x * part_stride;
 #pragma unroll
@@ -1108,18 +1121,23 @@ __global__ __launch_bounds__(256) void k_convS_wgrad_ring(svgp_conv_desc d, int 
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const T v = red[lane * 4 + g] + red[(64 + lane) * 4 + g] + red[(128 + lane) * 4 + g] + red[(192 + lane) * 4 + g];
-                const int j = 16 * nb + r;
-                if (j < JT) { const int t = j / CI, ci = j - t * CI; po[d.woff[t] + ci * 16 + MF::row(q, g)] = v; }
+                const int j = 16 * nb + r, i = MF::row(q, g);
+                if (j < JT) {
+                    const int t = j / CT, c = j - t * CT;
+                    po[d.woff[t] + (MODE ? i * CT + c : c * 16 + i)] = v;
+                }
             }
         }
     }
-    __syncthreads();
-    red[threadIdx.x] = bsum;
-    __syncthreads();
-    if (threadIdx.x < 16) {
-        T v = 0;
-        for (int k = 0; k < 16; ++k) v += red[k * 16 + threadIdx.x];
-        part_b[(size_t)blockIdx.x * 16 + threadIdx.x] = v;
+    if (MODE == 0) {
+        __syncthreads();
+        red[threadIdx.x] = bsum;
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            T v = 0;
+            for (int k = 0; k < 16; ++k) v += red[k * 16 + threadIdx.x];
+            part_b[(size_t)blockIdx.x * 16 + threadIdx.x] = v;
+        }
     }
 }
 
@@ -1692,9 +1710,9 @@ static int conv_wgrad_fused_impl(const svgp_conv_desc* d, int ncls, const T* in,
                 const int nw = nwg > 1024 ? 1024 : nwg, RW = conv16_rows(d[0]);
 #define CSR(NR_, NC_, S_)                                                                                                   \
                 if (NR == NR_ && NC == NC_ && S == S_) {                                                                    \
-                    if (outv) hipLaunchKernelGGL((k_convS_wgrad_ring<T, NR_, NC_, S_, 3, true>), dim3(nw), dim3(256), 0,    \
+                    if (outv) hipLaunchKernelGGL((k_convS_wgrad_ring<T, NR_, NC_, S_, 3, true, 0>), dim3(nw), dim3(256), 0,    \
                                                  (hipStream_t)stream, g, nw, RW, in, outv, dout, part, part_stride, part_b);\
-                    else hipLaunchKernelGGL((k_convS_wgrad_ring<T, NR_, NC_, S_, 3, false>), dim3(nw), dim3(256), 0,        \
+                    else hipLaunchKernelGGL((k_convS_wgrad_ring<T, NR_, NC_, S_, 3, false, 0>), dim3(nw), dim3(256), 0,        \
                                             (hipStream_t)stream, g, nw, RW, in, outv, dout, part, part_stride, part_b);    \
                 }
                 CSR(3, 3, 1) CSR(2, 2, 2)
@@ -1710,6 +1728,19 @@ static int conv_wgrad_fused_impl(const svgp_conv_desc* d, int ncls, const T* in,
             if (m1) {       // ELU' + bias sums by their own pass over the thin dout; the kernel then gathers dpre
                 rc = elu_bwd_bias_impl<T>((long long)d[0].n * d[0].Ho * d[0].Wo, d[0].Co, outv, dout, part_b, db, stream);
                 if (rc) return rc;
+                // 16 -> 3 channels, 3 x 3 grid of consecutive offsets, input width a multiple of 16: k_convS_wgrad_ring, MODE 1
+                svgp_conv_desc g;
+                int NR = 0, NC = 0;
+                bool ok = ring_on && d[0].Co == 3 && d[0].Wi % 16 == 0 && conv16_grid(d[0], &g, &NR, &NC) && NR == 3 && NC == 3;
+                for (int x = 1; ok && x < NC; ++x) ok = g.ox[x] == g.ox[0] + x;
+                if (ok) {
+                    svgp_conv_desc gi = g;
+                    gi.Hs = g.Hi;                      // rows per wave from the iteration space of this mode (input pixels)
+                    hipLaunchKernelGGL((k_convS_wgrad_ring<T, 3, 3, 1, 3, false, 1>), dim3(nw), dim3(256), 0, (hipStream_t)stream, g,
+                                       nw, conv16_rows(gi), in, (const T*)nullptr, dout, part, part_stride, part_b);
+                    SVGP_LAUNCH_CHECK();
+                    return sum_partials<T>(nw, part_stride, part_stride, (const T*)part, dw, 0, stream);
+                }
             } else if (nw * ncls > 1024) {
                 nw = 1024 / ncls;
             }

@@ -25,6 +25,10 @@ struct ConvLaunch {
     svgp_conv_desc d[4];
 };
 
+// slots nobody reads (4 x 64): where the lanes of an unpredicated store that have nothing to store write (external linkage: stores
+// to an internal variable that is never read are deleted)
+__device__ __attribute__((aligned(128))) double svgp_conv_trash[256];
+
 namespace {
 
 __device__ __forceinline__ void tap_range(const svgp_conv_desc& d, int& omin_y, int& omax_y, int& omin_x, int& omax_x) {
@@ -645,6 +649,118 @@ __global__ __launch_bounds__(256) void k_conv16_fwd_roll(svgp_conv_desc d, int s
             for (int k = 0; k < NEW; ++k)
 #pragma unroll
                 for (int c = 0; c < NC; ++c) buf[KEEP + k][c] = PF ? nxt[k][c] : ld((y + 1) * d.sy + oy0 + KEEP + k, c);
+        }
+    }
+}
+
+// Forward for 16 -> CT (3) output channels (the last decoder layer), stride 1, full NR x NC tap grid.  The rolling kernel above
+// spends 4 NT MFMAs per 16 pixels on an output tile of which 13 of 16 channel rows are padding (123 us at 64 x 64 x 500 frames for
+// 156 MB of traffic).  Here the contraction runs over the input channels only and the TAPS sit in the MFMA row index:
+//   P[j = (t, co)][pixel'] = sum_ci W_t[ci][co] in[pixel'][ci]        (JT = NT CT = 27 rows in NB = 2 blocks: 8 MFMAs per 16 INPUT pixels)
+//   out[y][x][co] = bias + sum_(kr, kc) P_(input row y + oy0 + kr)[(kr, kc, co)][x + ox0 + kc]
+// A wave owns 16 - (NC - 1) = 14 output columns (the 16 input columns they read) and RW rows: every input row is loaded once (one
+// 4-vector per lane, three rows ahead of its use in three alternating register sets), multiplied, and its P written to a
+// wave-private LDS ring of NR rows ([pixel][j], pixel stride JS = 36: conflict-free for the 128-bit writes and for the gather);
+// the 42 values of an output row segment are then 9 LDS reads each by 42 lanes, stored as one contiguous run.
+template <typename T, int NR, int NC, int CT>
+__global__ __launch_bounds__(256) void k_conv16_thin_fwd(svgp_conv_desc d, int ntask, int nseg, int strips, int RW,
+                                                         const T* __restrict__ in, const T* __restrict__ w,
+                                                         const T* __restrict__ bias, T* __restrict__ out) {
+    typedef SvgpMfma<T> MF;
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    static_assert(NR == 3, "the row loop is unrolled by the ring period");
+    constexpr int NT = NR * NC, JT = NT * CT, NB = (JT + 15) / 16, NPO = 16 - (NC - 1), JS = 16 * NB + 4, ROWP = 16 * JS;
+    __shared__ __align__(16) T smem[4 * NR * ROWP];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, q = lane >> 4;
+    T* ring = smem + wave * (NR * ROWP);
+    const int oy0 = d.oy[0], ox0 = d.ox[0], Hi = d.Hi, Wi = d.Wi, Ho = d.Ho, Wo = d.Wo, Hs = d.Hs, Ws = d.Ws, act = d.act;
+    // A operand: row i of block nb is the logical row j = 16 nb + corow(i) (float64: so that the D rows of a lane are consecutive j)
+    T wr[NB][4];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int j = 16 * nb + DirT<T>::corow(r), jc = min(j, JT - 1), t = jc / CT, co = jc - t * CT;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const T v = w[d.woff[t] + (4 * q + ks) * CT + co];
+            wr[nb][ks] = j < JT ? v : T(0);
+        }
+    }
+    // gather: lane e < NPO CT owns output element (column xl, channel gco) of the segment
+    const int e = min(lane, NPO * CT - 1), xl = e / CT, gco = e - xl * CT;
+    const T bvs = act ? bias[gco] : T(0);
+    const T* gptr = ring + xl * JS + gco;
+    T* wptr = ring + r * JS + 4 * q;
+    // a task = RW output rows x one segment of one image, per WAVE (RW a multiple of 3: the row loop runs whole ring periods)
+    int b = blockIdx.x;
+    const int G = (int)gridDim.x;
+    { const int per8 = G >> 3; if ((per8 << 3) == G) b = (b & 7) * per8 + (b >> 3); }
+    for (int task = b * 4 + wave; task < ntask; task += G * 4) {
+        const int xs = task % nseg, rb = (task / nseg) % strips, n = task / (nseg * strips);
+        const int ya = rb * RW, yb = min(Hs, ya + RW);
+        const int xo = xs * NPO, px = xo + ox0 + r, yi0 = ya + oy0, nin = yb - ya + NR - 1;
+        const bool colok = (unsigned)px < (unsigned)Wi;
+        const T* inn = in + (size_t)n * Hi * Wi * 16 + (unsigned)(min(max(px, 0), Wi - 1) * 16 + 4 * q);
+        T* on = out + ((size_t)n * Ho * Wo + xo) * CT + e;
+        const bool st_ok = lane < NPO * CT && xo + xl < Ws;
+        T* trash = reinterpret_cast<T*>(svgp_conv_trash) + lane;
+        auto gload = [&](int ii) -> v4 {                                   // input row ii of the task (clamped: rows past the last
+            const int gy = yi0 + min(ii, nin - 1);                          // one re-read it, rows outside the image a valid one)
+            return *reinterpret_cast<const v4*>(inn + (size_t)min(max(gy, 0), Hi - 1) * Wi * 16);
+        };
+        // one input row: P -> ring slot SLOT; the refill of its register set; with OUT the output row that this row completes.
+        // Branch-free: rows past the task's last one (a short last block) are computed from a repeated input row and stored to the
+        // trash slots, like the lanes that own no output element -- under a predicate or an early exit the wait-count pass has to
+        // assume the shortest path and waits for the requests issued one row ago instead of three.
+        auto step = [&](int ii, v4& R, auto SLOTc, auto OUTc) {
+            constexpr int SLOT = decltype(SLOTc)::value;
+            const bool ok = colok && (unsigned)(yi0 + ii) < (unsigned)Hi;
+            v4 v;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) v[ks] = ok ? R[ks] : T(0);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            R = gload(ii + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            typename MF::acc_t acc[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) acc[nb] = typename MF::acc_t{0, 0, 0, 0};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) acc[nb] = MF::mma(wr[nb][ks], v[ks], acc[nb]);
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) *reinterpret_cast<v4*>(wptr + SLOT * ROWP + 16 * nb) = v4{acc[nb][0], acc[nb][1], acc[nb][2], acc[nb][3]};
+            if constexpr (decltype(OUTc)::value) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                T sum = bvs;
+#pragma unroll
+                for (int kr = 0; kr < NR; ++kr)
+#pragma unroll
+                    for (int kc = 0; kc < NC; ++kc)
+                        sum += gptr[((SLOT + 1 + kr) % NR) * ROWP + kc * JS + (kr * NC + kc) * CT];
+                if (act == 1) sum = sum > 0 ? sum : (T)(conv_exp(sum) - T(1));
+                const int y = ya + ii - (NR - 1);
+                *((st_ok && y < yb) ? on + (size_t)y * Wo * CT : trash) = sum;
+            } else {
+                trash[64 + 64 * SLOT] = T(0);      // the wait counts of the loop are the minimum over the paths into it: keep the two opening rows alike
+            }
+        };
+        const auto S0 = std::integral_constant<int, 0>{};
+        const auto S1 = std::integral_constant<int, 1>{};
+        const auto S2 = std::integral_constant<int, 2>{};
+        const auto NO = std::integral_constant<bool, false>{};
+        const auto YES = std::integral_constant<bool, true>{};
+        v4 R0 = gload(0), R1 = gload(1), R2 = gload(2);
+        trash[192] = T(0);
+        step(0, R0, S0, NO);
+        step(1, R1, S1, NO);
+        for (int ii = 2; ii < nin; ii += 3) {
+            step(ii, R2, S2, YES);
+            step(ii + 1, R0, S0, YES);
+            step(ii + 2, R1, S1, YES);
         }
     }
 }
@@ -1618,6 +1734,27 @@ static int conv_taps_fwd_impl(const svgp_conv_desc* d, int ncls, const T* in, co
                          d[c].sx == d[0].sx && d[c].Hi == d[0].Hi && d[c].Wi == d[0].Wi && d[c].Ci == d[0].Ci &&
                          d[c].Co == d[0].Co && d[c].act == d[0].act,
                      SVGP_ERR_INVALID, "the classes of one launch share the input geometry (n, Hs, Ws, strides, Ci, Co, act)");
+    }
+    // 16 -> 3 channels, 3 x 3 grid of consecutive offsets, stride 1, plain output placement: the taps in the MFMA row index
+    {
+        static const int thin_on = [] { const char* e = getenv("SVGP_CONV_THIN_FWD"); return (e && e[0] == '0') ? 0 : 1; }();
+        svgp_conv_desc g;
+        int NR = 0, NC = 0;
+        bool ok = thin_on && conv16_enabled() && ncls == 1 && d[0].Ci == 16 && d[0].Co == 3 && d[0].sy == 1 && d[0].sx == 1 &&
+                  d[0].osy == 1 && d[0].osx == 1 && d[0].ooy == 0 && d[0].oox == 0 && conv16_grid(d[0], &g, &NR, &NC) && NR == 3 &&
+                  NC == 3;
+        for (int x = 1; ok && x < NC; ++x) ok = g.ox[x] == g.ox[0] + x;
+        if (ok) {
+            static const int rows_env = [] { const char* e = getenv("SVGP_CONV_THIN_ROWS"); return e ? atoi(e) : 0; }();
+            int RW = rows_env > 0 ? (rows_env + 2) / 3 * 3 : 12;              // whole ring periods
+            if (RW > (g.Hs + 2) / 3 * 3) RW = (g.Hs + 2) / 3 * 3;
+            const int nrb = (g.Hs + RW - 1) / RW, nseg = (g.Ws + 13) / 14, ntask = g.n * nrb * nseg;   // tasks of one wave each
+            const int nwg = (ntask + 3) / 4;
+            hipLaunchKernelGGL((k_conv16_thin_fwd<T, 3, 3, 3>), dim3((unsigned)(nwg < 1024 ? nwg : 1024)), dim3(256), 0,
+                               (hipStream_t)stream, g, ntask, nseg, nrb, RW, in, w, bias, out);
+            SVGP_LAUNCH_CHECK();
+            return SVGP_OK;
+        }
     }
     if (conv16_direct_ok(d, ncls, false)) return conv16_fwd_launch<T>(d, ncls, in, w, bias, out, stream);
     if (convS_fwd_ok(d, ncls)) return convS_fwd_launch<T>(d, ncls, in, w, bias, out, stream);

@@ -1452,6 +1452,136 @@ __global__ __launch_bounds__(256) void k_convS_fwd(svgp_conv_desc d, int ntask, 
     }
 }
 
+// Forward / data gradient of the thin layers with CI = 3 INPUT channels (first encoder / representation layers forward, the last
+// decoder layer's data gradient) on the ring of k_convS_wgrad_ring instead of k_convS_fwd's per-lane global gathers:
+//   out^T[co][pixel] = sum_(k = (t, ci)) W[k][co] in[pixel (+) t][ci],  K = NT CI (27 -> 7 k-steps of 4)
+// B operand lane (r = pixel, q): k = 4 s + q -> its own (tap, channel), read from the wave-private ring of NR input rows (a row =
+// the contiguous run of HW x CI values, one dword request per lane per new row, requested THREE output rows ahead in three
+// alternating register sets -- a row is only 7 MFMAs long); D: one 4-vector store per lane.  Rows in groups of three, branch-free
+// (rows past the end of a short last block are computed from repeated input rows and stored to the trash slots).
+template <typename T, int NR, int NC, int S, int CI, bool FULL>       // FULL: 16 output channels
+__global__ __launch_bounds__(256) void k_convS_fwd_ring(svgp_conv_desc d, int ntask, int nseg, int nrb, int RW,
+                                                        const T* __restrict__ in, const T* __restrict__ w,
+                                                        const T* __restrict__ bias, T* __restrict__ out) {
+    typedef SvgpMfma<T> MF;
+    typedef T v4 __attribute__((ext_vector_type(4)));
+    constexpr int NT = NR * NC, KT = NT * CI, KS = (KT + 3) / 4, KEEP = NR - S;
+    constexpr int HW = 15 * S + NC, RUN = HW * CI, NI = (RUN + 63) / 64, ROWE = S == 1 ? 84 : 96;
+    static_assert(S <= NR && RUN <= ROWE, "ring row");
+    __shared__ T smem[4 * NR * ROWE];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r = lane & 15, q = lane >> 4;
+    T* ring = smem + wave * (NR * ROWE);
+    const int oy0 = d.oy[0], ox0 = d.ox[0], Hi = d.Hi, Wi = d.Wi, Ho = d.Ho, Wo = d.Wo, Hs = d.Hs, Ws = d.Ws, Co = d.Co, act = d.act,
+              osy = d.osy, osx = d.osx, ooy = d.ooy, oox = d.oox;
+    // per k-step: this lane's (tap row, element offset in a ring row) and the weight it multiplies
+    const int co_a = DirT<T>::corow(r), co_c = min(co_a, Co - 1);
+    T wr[KS];
+    int kkr[KS], kofs[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        const int k = 4 * s + q, kc_ = min(k, KT - 1), t = kc_ / CI, ci = kc_ - t * CI, kr = t / NC, kc = t - kr * NC;
+        kkr[s] = kr;
+        kofs[s] = (r * S + kc) * CI + ci;
+        const T v = w[d.woff[t] + ci * Co + co_c];
+        wr[s] = (k < KT && co_a < Co) ? v : T(0);
+    }
+    v4 bv = {0, 0, 0, 0};
+    if (act)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const T v = bias[min(4 * q + g, Co - 1)]; bv[g] = (4 * q + g < Co) ? v : T(0); }
+    int b = blockIdx.x;
+    const int G = (int)gridDim.x;
+    { const int per8 = G >> 3; if ((per8 << 3) == G) b = (b & 7) * per8 + (b >> 3); }
+    for (int task = b * 4 + wave; task < ntask; task += G * 4) {
+        const int xs = task % nseg, rb = (task / nseg) % nrb, n = task / (nseg * nrb);
+        const T* inn = in + (size_t)n * Hi * Wi * CI;
+        const int ya = rb * RW, yb = min(Hs, ya + RW), xf = xs * 16, X0 = xf * S + ox0;
+        unsigned goff[NI], woff[NI];
+        bool gok[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int e = min(lane + 64 * i, RUN - 1), p = e / CI, gx = X0 + p;
+            gok[i] = (unsigned)gx < (unsigned)Wi;
+            goff[i] = (unsigned)(min(max(gx, 0), Wi - 1) * CI + (e - p * CI));
+            woff[i] = (unsigned)e;
+        }
+        // thin rows are addressed by the output row they complete: row set `yy` = the S new input rows of output row yy
+        auto rowc = [&](int yy) -> int { return min(yy, yb - 1) * S + oy0 + KEEP; };      // (clamped: past the block, re-read)
+        auto gload = [&](int gy, int i) -> T { return (inn + (size_t)min(max(gy, 0), Hi - 1) * Wi * CI)[goff[i]]; };
+        auto lwrite = [&](int slot, int i, T v, bool rowok) { ring[slot * ROWE + woff[i]] = (rowok && gok[i]) ? v : T(0); };
+        {
+            T v[NR][NI];
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) v[k][i] = gload(ya * S + oy0 + k, i);
+#pragma unroll
+            for (int k = 0; k < NR; ++k)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) lwrite(k, i, v[k][i], (unsigned)(ya * S + oy0 + k) < (unsigned)Hi);
+        }
+        int base = 0;
+        const bool vx = xf + r < Ws;
+        T* trash = reinterpret_cast<T*>(svgp_conv_trash) + 4 * lane;
+        T* on = out + (((size_t)n * Ho + ooy) * Wo + ((xf + r) * osx + oox)) * Co + 4 * q;
+        T Q0[S][NI], Q1[S][NI], Q2[S][NI];
+#pragma unroll
+        for (int k = 0; k < S; ++k)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) { Q0[k][i] = gload(rowc(ya + 1) + k, i); Q1[k][i] = gload(rowc(ya + 2) + k, i); Q2[k][i] = gload(rowc(ya + 3) + k, i); }
+        // one output row y from the ring; then Q (the new input rows of output row y + 1) into the ring and its refill for row y + 4
+        auto step = [&](int y, T (&Q)[S][NI]) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            T f[KS];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) { int sl = base + kkr[s]; if (sl >= NR) sl -= NR; f[s] = ring[sl * ROWE + kofs[s]]; }
+            typename MF::acc_t acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                if (s & 1) acc1 = MF::mma(wr[s], f[s], acc1);
+                else acc0 = MF::mma(wr[s], f[s], acc0);
+            }
+            v4 v;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                T e = acc0[g] + acc1[g];
+                if (act) e += bv[g];
+                if (act == 1) e = e > 0 ? e : (T)(conv_exp(e) - T(1));
+                v[g] = e;
+            }
+            const bool ok = vx && y < yb;
+            if (FULL) {
+                *reinterpret_cast<v4*>(ok ? on + (size_t)y * osy * Wo * Co : trash) = v;
+            } else {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) *((ok && 4 * q + g < Co) ? on + (size_t)y * osy * Wo * Co + g : trash + g) = v[g];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int g0 = rowc(y + 1);
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                int sl = base + k; if (sl >= NR) sl -= NR;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) lwrite(sl, i, Q[k][i], (unsigned)(g0 + k) < (unsigned)Hi);
+            }
+            base += S; if (base >= NR) base -= NR;
+            const int g4 = rowc(y + 4);
+#pragma unroll
+            for (int k = 0; k < S; ++k)
+#pragma unroll
+                for (int i = 0; i < NI; ++i) Q[k][i] = gload(g4 + k, i);
+        };
+        for (int y = ya; y < yb; y += 3) {
+            step(y, Q0);
+            step(y + 1, Q1);
+            step(y + 2, Q2);
+        }
+    }
+}
+
 template <typename T, int NB, int MODE>
 __global__ __launch_bounds__(256) void k_convS_wgrad(svgp_conv_desc d, int nwg, int RW, const T* __restrict__ in,
                                                      const T* __restrict__ outv, T* __restrict__ dout, T* __restrict__ part,
@@ -1696,9 +1826,32 @@ static bool convS_fwd_ok(const svgp_conv_desc* d, int ncls) {
 }
 template <typename T>
 static int convS_fwd_launch(const svgp_conv_desc* d, int ncls, const T* in, const T* w, const T* bias, T* out, void* stream) {
+    static const int fring_on = [] { const char* e = getenv("SVGP_CONV_FWD_RING"); return (e && e[0] == '0') ? 0 : 1; }();
     for (int c = 0; c < ncls; ++c) {
         const svgp_conv_desc& dc = d[c];
         SVGP_REQUIRE(!dc.act || bias, SVGP_ERR_INVALID, "bias is NULL but act != 0");
+        // 3 input channels, width a multiple of 16, full grid of consecutive offsets: k_convS_fwd_ring
+        if (fring_on && dc.Ci == 3 && dc.Ws % 16 == 0 && dc.sy == dc.sx) {
+            svgp_conv_desc g;
+            int NR = 0, NC = 0;
+            bool ok = conv16_grid(dc, &g, &NR, &NC);
+            for (int x = 1; ok && x < NC; ++x) ok = g.ox[x] == g.ox[0] + x;
+            const int S = dc.sy;
+            ok = ok && ((NR == 3 && NC == 3 && S == 1) || (NR == 2 && NC == 2 && S == 2));
+            if (ok) {
+                int RW = 12;
+                if (RW > (g.Hs + 2) / 3 * 3) RW = (g.Hs + 2) / 3 * 3;
+                const int nrb = (g.Hs + RW - 1) / RW, nseg = g.Ws / 16, ntask = g.n * nrb * nseg, nwg = (ntask + 3) / 4;
+                const dim3 grid((unsigned)(nwg < 1024 ? nwg : 1024));
+#define CSFR(NR_, NC_, S_, FULL_) hipLaunchKernelGGL((k_convS_fwd_ring<T, NR_, NC_, S_, 3, FULL_>), grid, dim3(256), 0,         \
+                                                     (hipStream_t)stream, g, ntask, nseg, nrb, RW, in, w, bias, out)
+                if (S == 1) { if (g.Co == 16) CSFR(3, 3, 1, true); else CSFR(3, 3, 1, false); }
+                else { if (g.Co == 16) CSFR(2, 2, 2, true); else CSFR(2, 2, 2, false); }
+#undef CSFR
+                SVGP_LAUNCH_CHECK();
+                continue;
+            }
+        }
         const int RW = conv16_rows(dc), strips = (dc.Hs + 4 * RW - 1) / (4 * RW), nseg = (dc.Ws + 15) / 16;
         const int ntask = dc.n * strips * nseg, KS = (dc.nt * dc.Ci + 3) / 4;
         const dim3 grid((unsigned)(ntask < 2048 ? ntask : 2048));

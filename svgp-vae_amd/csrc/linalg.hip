@@ -377,6 +377,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
         cur ^= 1;
     }
     const bool has_beta = g.beta != real(0);
+    // Mirrored store (tri & 16): a diagonal tile stores its lower half and mirrors it too -- with contraction weights on the B side
+    // the two halves of a diagonal tile are a_i (w a_j) and a_j (w a_i), equal only up to rounding, and every consumer (and the packed
+    // exchange between ranks) relies on the stored matrix being symmetric BIT FOR BIT
+    // (tests/test_gpu_large_split.py::test_exchanged_symmetric_blocks_are_exactly_symmetric_in_memory).
+    const bool sym_diag = (g.tri & 16) && i0 == j0;
     if (g.epi_on) {
         // extended epilogue: an extra matrix E and a diagonal term on the output, and an optional second output with its own
         // coefficients -- K + c S + jI next to S, A + jI next to A, P^T - K Aji: each used to be a pass over an (L, m, m) array
@@ -389,13 +394,13 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int gi = i0 + wi + a * 16 + MF::row(q, e), gj = j0 + wj + b * 16 + r;
-                    if (gi < g.M && gj < g.N) {
+                    if (gi < g.M && gj < g.N && !(sym_diag && gi < gj)) {
                         const real av = (real)acc[a][b][e], dd = gi == gj ? real(1) : real(0);
                         const size_t o = (size_t)gi * g.ldc + gj;
                         const real ev = E ? (real)E[(size_t)gi * g.lde + gj] : real(0);
                         C[o] = (TS)(g.alpha * av + (has_beta ? g.beta * (real)C[o] : real(0)) + g.g1 * ev + g.d1 * dd);
                         if (C2) C2[(size_t)gi * g.ldc2 + gj] = (TS)(g.a2 * av + g.g2 * ev + g.d2 * dd);
-                        if ((g.tri & 16) && i0 != j0) {          // mirror of a below-diagonal tile (never on the diagonal)
+                        if ((g.tri & 16) && gi != gj) {          // mirror: a below-diagonal tile, or the lower half of a diagonal tile
                             const size_t oT = (size_t)gj * g.ldc + gi;
                             const real evT = E ? (real)E[(size_t)gj * g.lde + gi] : real(0);
                             C[oT] = (TS)(g.alpha * av + (has_beta ? g.beta * (real)C[oT] : real(0)) + g.g1 * evT);
@@ -412,10 +417,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int gi = i0 + wi + a * 16 + MF::row(q, e), gj = j0 + wj + b * 16 + r;
-                if (gi < g.M && gj < g.N) {
+                if (gi < g.M && gj < g.N && !(sym_diag && gi < gj)) {
                     const size_t o = (size_t)gi * g.ldc + gj;
                     C[o] = (TS)(g.alpha * (real)acc[a][b][e] + (has_beta ? g.beta * (real)C[o] : real(0)));
-                    if ((g.tri & 16) && i0 != j0) {          // mirror of a below-diagonal tile
+                    if ((g.tri & 16) && gi != gj) {          // mirror: a below-diagonal tile, or the lower half of a diagonal tile
                         const size_t oT = (size_t)gj * g.ldc + gi;
                         C[oT] = (TS)(g.alpha * (real)acc[a][b][e] + (has_beta ? g.beta * (real)C[oT] : real(0)));
                     }

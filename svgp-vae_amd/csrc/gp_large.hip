@@ -312,16 +312,39 @@ struct PbArgs {
     real* part;         // Knbar_part (L,b,m)
     real* Knbar; real* knnbar; real* ybar; real* s2bar;
 };
-// part = 2 g_pv (Kn Si) + p (Kn Ssym) + mvbar u + c g_pm t + p y vbar; Kn Si is the forward pass's product, R = Kn Ssym
-// (the d-term's k^T Ki A Ki k reaches Kn through Wbar (Ki K)^T, one product for all channels: svgp_big_posterior_bwd)
-__global__ void k_big_pb_part(PbArgs a) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, bm = (long long)a.b * a.m;
-    if (i >= bm * a.L) return;
-    const int j = (int)(i % a.m), n = (int)((i % bm) / a.m), l = (int)(i / bm);
-    const size_t e = (size_t)n * a.L + l, vi = (size_t)l * a.m + j;
-    const real p = recip_no_nan(a.s2[e]);
-    a.part[i] = real(2) * a.g_pv[e] * a.KnSi[(size_t)l * a.sKS + (i % bm)] + p * a.R[i] + a.mvbar[e] * a.u[vi] +
-                a.c * a.g_pm[e] * a.t[vi] + p * a.y[e] * a.vbar[vi];
+// Knbar = sum_l [2 g_pv (Kn Si_l) + p (Kn Ssym_l) + mvbar u_l + c g_pm t_l + p y vbar_l] + 2 qbar (Kn Ki); knnbar = -qbar.
+// Kn Si is the forward pass's product, R = Kn Ssym (the d-term's k^T Ki A Ki k reaches Kn through Wbar (Ki K)^T, one product for all
+// channels: svgp_big_posterior_bwd).  One pass over the two (L, b, m) arrays with the channel sum in registers (in channel order, as
+// the former pair k_big_pb_part -> (L, b, m) partials -> k_big_pb_sum added them: 2 x 205 MB less traffic at the SPRITES shape).
+// Workgroup = one batch row n (its b x L scalars staged in LDS once), threads stride the columns.
+__global__ __launch_bounds__(256) void k_big_pb_knbar(PbArgs a) {
+    extern __shared__ real pb_lds[];
+    const int n = blockIdx.x, L = a.L, m = a.m;
+    real* c0 = pb_lds;            // 2 g_pv
+    real* c1 = c0 + L;            // p
+    real* c2 = c1 + L;            // mvbar
+    real* c3 = c2 + L;            // c g_pm
+    real* c4 = c3 + L;            // p y
+    for (int l = threadIdx.x; l < L; l += blockDim.x) {
+        const size_t e = (size_t)n * L + l;
+        const real p = recip_no_nan(a.s2[e]);
+        c0[l] = real(2) * a.g_pv[e]; c1[l] = p; c2[l] = a.mvbar[e]; c3[l] = a.c * a.g_pm[e]; c4[l] = p * a.y[e];
+    }
+    __syncthreads();
+    const long long bm = (long long)a.b * m;
+    const real qbar = a.qbar[n];
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        const size_t o = (size_t)n * m + j;
+        real acc = 0;
+#pragma unroll 4
+        for (int l = 0; l < L; ++l) {
+            const size_t vi = (size_t)l * m + j;
+            acc += c0[l] * a.KnSi[(size_t)l * a.sKS + o] + c1[l] * a.R[(size_t)l * bm + o] + c2[l] * a.u[vi] + c3[l] * a.t[vi] +
+                   c4[l] * a.vbar[vi];
+        }
+        a.Knbar[o] = acc + real(2) * qbar * a.KnKi[o];
+    }
+    if (threadIdx.x == 0) a.knnbar[n] = -qbar;
 }
 __global__ void k_big_pb_elem(PbArgs a) {     // ybar, s2bar
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -332,17 +355,6 @@ __global__ void k_big_pb_elem(PbArgs a) {     // ybar, s2bar
     a.ybar[i] = -gT * p * dm - g3 * p * a.e[i] + p * kV;
     a.s2bar[i] = real(0.5) * gT * (p - (a.p_v[i] + dm * dm) * p * p) - real(0.5) * g3 * p - pbar * p * p;
 }
-__global__ void k_big_pb_sum(PbArgs a) {      // Knbar = sum_l part + 2 qbar (Kn Ki); knnbar = -qbar
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, bm = (long long)a.b * a.m;
-    if (i >= bm) return;
-    const int n = (int)(i / a.m);
-    const real qbar = a.qbar[n];
-    real acc = 0;
-    for (int l = 0; l < a.L; ++l) acc += a.part[(size_t)l * bm + i];
-    a.Knbar[i] = acc + real(2) * qbar * a.KnKi[i];
-    if (i % a.m == 0) a.knnbar[n] = -qbar;
-}
-
 // y_l = alpha A_l x_l for L channels (A_l: m x m row-major at A + l sA, sA = 0: one shared matrix; x, y: (L, m)).
 // grid (ceil(m / 16), L), 256 threads: wave w takes rows 4 w .. 4 w + 3 of the block, lanes stride the row, x_l sits in LDS.
 // The batched GEMM spends a 32- or 64-wide tile on the single column (m = 800, L = 64: 130 us; this: one pass over A).
@@ -692,19 +704,16 @@ int svgp_big_posterior_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     a.KnSi = s.KS; a.sKS = s.sKS; a.qbar = s.qbar;
     a.part = ws + wl.Knbar_part; a.Knbar = ws + wl.Knbar; a.knnbar = ws + wl.knnbar; a.ybar = ws + wl.ybar;
     a.s2bar = ws + wl.s2bar;
-    const unsigned gbm = nblk(bm * L);
     // one (b, m, m, L) product: Kn Si_l comes from the forward pass (svgp_big_posterior_fwd on this workspace), Kn Ki from
     // svgp_big_factor_fwd; the d-term's share arrives through Wbar P^T below
     GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, ws + wl.Ssym, m, mm, 0.0, s.bm, m, bm, L);
-    hipLaunchKernelGGL(k_big_pb_part, dim3(gbm), dim3(256), 0, st, a);
-    SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(0.5), s.bm, bm, Kn,
                        s.bl0, L, 0);
     SVGP_LAUNCH_CHECK();
     GEMM(0, 1, b, L, m, 1.0, Kn, m, 0, ws + wl.vbar, m, 0, 0.0, s.bl1, L, 0, 1);   // kv = Kn vbar^T
     hipLaunchKernelGGL(k_big_pb_elem, dim3(nblk((long long)b * L)), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_big_pb_sum, dim3(nblk(bm)), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_big_pb_knbar, dim3(b), dim3(256), 5 * (size_t)L * sizeof(real), st, a);
     SVGP_LAUNCH_CHECK();
     GEMM(0, 0, b, m, m, 1.0, s.Wbar, 2 * m, 0, s.PT, m, 0, 1.0, ws + wl.Knbar, m, 0, 1);   // Knbar += Wbar P^T  (P^T = K Ki; Wbar inside X)
     return SVGP_OK;

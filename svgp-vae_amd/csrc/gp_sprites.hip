@@ -71,82 +71,176 @@ __global__ __launch_bounds__(256) void k_sprites_kernel_fwd(SpK a, real* __restr
     }
 }
 
+// The same values by 16 x 16 output tiles: the 16 + 16 feature rows of a tile are staged in LDS with coalesced loads (the element-wise
+// kernel above reads 2 D per-lane doubles with a row stride between the lanes for every entry: 165 us for the 1.04 M entries of the
+// SPRITES shape), and the norms of the cosine-normalised kernel are formed once per row instead of once per entry -- by the same
+// expressions, so the entries are bit-identical to k_sprites_kernel_fwd's (which stays for k_nn and as the reference form).
+// blocks [0, nbt nmt): tiles of K_nm; [.., + nmt nmt): tiles of K_mm; the rest: k_nn, 256 entries each.
+__global__ __launch_bounds__(256) void k_sprites_kernel_fwd_tiles(SpK a, int nbt, int nmt, real* __restrict__ K, real* __restrict__ Kn,
+                                                                  real* __restrict__ knn) {
+    __shared__ real xs[16][2 * SP_MAXD + 1], zs[16][2 * SP_MAXD + 1], nrm[2][16][2];
+    const int La = a.La, Lc = a.Lc, D = La + Lc;
+    const real la = a.se[0], sa = a.se[1], lc = a.se[2], sc = a.se[3];
+    int blk = blockIdx.x;
+    if (blk >= nbt * nmt + nmt * nmt) {                     // k_nn
+        const int n = (blk - nbt * nmt - nmt * nmt) * 256 + threadIdx.x;
+        if (n < a.b) {
+            real ca, cb, d2;
+            const real* xa = act_row(a, n);
+            const real* xc = a.aux + (size_t)n * (1 + Lc) + 1;
+            knn[n] = grp_k(a.kind, xa, xa, La, la, sa, ca, cb, d2) * grp_k(a.kind, xc, xc, Lc, lc, sc, ca, cb, d2);
+        }
+        return;
+    }
+    const bool kn = blk < nbt * nmt;
+    if (!kn) blk -= nbt * nmt;
+    const int ti = blk / nmt, tj = blk - ti * nmt, i0 = ti * 16, j0 = tj * 16, ni = kn ? a.b : a.m;
+    // stage: row rr of the tile's row side / column side (clamped; entries beyond the matrix are not stored)
+    for (int e = threadIdx.x; e < 16 * D; e += 256) {
+        const int rr = e / D, k = e - rr * D, i = min(i0 + rr, ni - 1), j = min(j0 + rr, a.m - 1);
+        zs[rr][k] = a.ip[(size_t)j * D + k];
+        if (kn) xs[rr][k] = k < La ? act_row(a, i)[k] : a.aux[(size_t)i * (1 + Lc) + 1 + (k - La)];
+        else xs[rr][k] = a.ip[(size_t)i * D + k];
+    }
+    __syncthreads();
+    if (a.kind == 1 && threadIdx.x < 64) {                  // norms: side (x / z), row, group (action / character)
+        const int side = threadIdx.x >> 5, rr = (threadIdx.x >> 1) & 15, grp = threadIdx.x & 1;
+        const real* v = (side ? zs[rr] : xs[rr]) + (grp ? La : 0);
+        nrm[side][rr][grp] = sqrt(dotd(v, v, grp ? Lc : La));
+    }
+    __syncthreads();
+    const int r = threadIdx.x >> 4, c = threadIdx.x & 15, gi = i0 + r, gj = j0 + c;
+    if (gi >= ni || gj >= a.m) return;
+    const real* x = xs[r];
+    const real* z = zs[c];
+    real kA, kC;
+    if (a.kind == 2) {
+        real dA = 0, dC = 0;
+        for (int k = 0; k < La; ++k) { const real t = x[k] - z[k]; dA += t * t; }
+        for (int k = 0; k < Lc; ++k) { const real t = x[La + k] - z[La + k]; dC += t * t; }
+        kA = sa * sa * exp(-dA / (real(2) * la * la));
+        kC = sc * sc * exp(-dC / (real(2) * lc * lc));
+    } else {
+        kA = dotd(x, z, La);
+        kC = dotd(x + La, z + La, Lc);
+        if (a.kind == 1) { kA = kA / (nrm[0][r][0] * nrm[1][c][0]); kC = kC / (nrm[0][r][1] * nrm[1][c][1]); }
+    }
+    (kn ? Kn : K)[(size_t)gi * a.m + gj] = kA * kC;
+}
+
 // VJP, inducing side: workgroup j.  d_ip[j] (La+Lc) and SE-parameter partials part_se[j][4].
+// The source rows (batch rows, then inducing rows) go through LDS in chunks of 256, staged with coalesced loads (row stride DP = D | 1
+// doubles); the target z_j sits in LDS too.  (Read straight from global memory every (source, target) pair cost 2 D per-lane 8-byte
+// loads with a row stride between the lanes -- the kernel ran at the rate of the L1 tag look-ups: 200-240 us inside the SPRITES step,
+// where it now heads the chain that ends the step.)
+template <int LA, int LC>       // compile-time bounds of the two feature groups (La <= LA, Lc <= LC): accumulators and loops of exact size
 __global__ __launch_bounds__(256) void k_sprites_kernel_bwd_cols(SpK a, const real* __restrict__ Kbar,
                                                                  const real* __restrict__ Knbar,
                                                                  real* __restrict__ d_ip, real* __restrict__ part_se) {
-    __shared__ real wred[4][2 * SP_MAXD + 4];
-    const int j = blockIdx.x, La = a.La, Lc = a.Lc, D = La + Lc;
+    __shared__ real wred[4][LA + LC + 4];
+    __shared__ real zt[LA + LC];
+    extern __shared__ real src[];                 // 256 x DP
+    const int j = blockIdx.x, La = a.La, Lc = a.Lc, D = La + Lc, DP = D | 1;
     const real la = a.se[0], sa = a.se[1], lc = a.se[2], sc = a.se[3];
-    const real* zj = a.ip + (size_t)j * D;
-    real acc[2 * SP_MAXD + 4];
+    if (threadIdx.x < D) zt[threadIdx.x] = a.ip[(size_t)j * D + threadIdx.x];
+    const real* zj = zt;
+    real acc[LA + LC + 4];
 #pragma unroll
-    for (int k = 0; k < 2 * SP_MAXD + 4; ++k) acc[k] = 0;
+    for (int k = 0; k < LA + LC + 4; ++k) acc[k] = 0;
     auto add = [&](const real* xa, const real* xc, real c_vec, real c_par) {
         real caA, cbA, d2A, caC, cbC, d2C;
         const real kA = grp_k(a.kind, xa, zj, La, la, sa, caA, cbA, d2A);
         const real kC = grp_k(a.kind, xc, zj + La, Lc, lc, sc, caC, cbC, d2C);
         const real cA = c_vec * kC, cC = c_vec * kA;
 #pragma unroll
-        for (int k = 0; k < SP_MAXD; ++k) {
+        for (int k = 0; k < LA; ++k)
             if (k < La) acc[k] += cA * (caA * xa[k] + cbA * zj[k]);
-            if (k < Lc) acc[SP_MAXD + k] += cC * (caC * xc[k] + cbC * zj[La + k]);
-        }
+#pragma unroll
+        for (int k = 0; k < LC; ++k)
+            if (k < Lc) acc[LA + k] += cC * (caC * xc[k] + cbC * zj[La + k]);
         if (a.kind == 2) {
             const real kk = c_par * kA * kC;
-            acc[2 * SP_MAXD + 0] += kk * d2A / (la * la * la);
-            acc[2 * SP_MAXD + 1] += kk * real(2) / sa;
-            acc[2 * SP_MAXD + 2] += kk * d2C / (lc * lc * lc);
-            acc[2 * SP_MAXD + 3] += kk * real(2) / sc;
+            acc[LA + LC + 0] += kk * d2A / (la * la * la);
+            acc[LA + LC + 1] += kk * real(2) / sa;
+            acc[LA + LC + 2] += kk * d2C / (lc * lc * lc);
+            acc[LA + LC + 3] += kk * real(2) / sc;
         }
     };
-    for (int n = threadIdx.x; n < a.b; n += blockDim.x) {
-        const real c = Knbar[(size_t)n * a.m + j];
-        add(act_row(a, n), a.aux + (size_t)n * (1 + Lc) + 1, c, c);
+    for (int n0 = 0; n0 < a.b; n0 += 256) {
+        const int cnt = min(256, a.b - n0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * La; e += 256) { const int rr = e / La, k = e - rr * La; src[rr * DP + k] = act_row(a, n0 + rr)[k]; }
+        for (int e = threadIdx.x; e < cnt * (1 + Lc); e += 256) {
+            const int rr = e / (1 + Lc), k = e - rr * (1 + Lc);
+            if (k > 0) src[rr * DP + La + k - 1] = a.aux[(size_t)n0 * (1 + Lc) + e];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < cnt) {
+            const real c = Knbar[(size_t)(n0 + threadIdx.x) * a.m + j];
+            add(src + threadIdx.x * DP, src + threadIdx.x * DP + La, c, c);
+        }
     }
-    for (int i = threadIdx.x; i < a.m; i += blockDim.x) {
-        const real* zi = a.ip + (size_t)i * D;
-        const real g_ji = a.rep_weight * Kbar[(size_t)j * a.m + i], g_ij = a.rep_weight * Kbar[(size_t)i * a.m + j];
-        add(zi, zi + La, g_ji + g_ij, g_ji);       // hyper-parameters: each entry (j,i) once
+    for (int i0 = 0; i0 < a.m; i0 += 256) {
+        const int cnt = min(256, a.m - i0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < cnt * D; e += 256) { const int rr = e / D, k = e - rr * D; src[rr * DP + k] = a.ip[(size_t)i0 * D + e]; }
+        __syncthreads();
+        if ((int)threadIdx.x < cnt) {
+            const int i = i0 + threadIdx.x;
+            const real g_ji = a.rep_weight * Kbar[(size_t)j * a.m + i], g_ij = a.rep_weight * Kbar[(size_t)i * a.m + j];
+            add(src + threadIdx.x * DP, src + threadIdx.x * DP + La, g_ji + g_ij, g_ji);       // hyper-parameters: each entry (j,i) once
+        }
     }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int k = 0; k < 2 * SP_MAXD + 4; ++k) {
-        const bool used = (k < La) || (k >= SP_MAXD && k < SP_MAXD + Lc) || (k >= 2 * SP_MAXD);
+    for (int k = 0; k < LA + LC + 4; ++k) {
+        const bool used = (k < La) || (k >= LA && k < LA + Lc) || (k >= LA + LC);
         if (used) { const real t = wave_sum(acc[k]); if (lane == 0) wred[wv][k] = t; }
     }
     __syncthreads();
-    if (threadIdx.x < 2 * SP_MAXD + 4) {
+    if (threadIdx.x < LA + LC + 4) {
         const int k = threadIdx.x;
         const real s = wred[0][k] + wred[1][k] + wred[2][k] + wred[3][k];
         if (k < La) d_ip[(size_t)j * D + k] = s;
-        else if (k >= SP_MAXD && k < SP_MAXD + Lc) d_ip[(size_t)j * D + La + (k - SP_MAXD)] = s;
-        else if (k >= 2 * SP_MAXD) part_se[j * 4 + (k - 2 * SP_MAXD)] = s;
+        else if (k >= LA && k < LA + Lc) d_ip[(size_t)j * D + La + (k - LA)] = s;
+        else if (k >= LA + LC) part_se[j * 4 + (k - LA - LC)] = s;
     }
 }
 
 // VJP, batch-row side: one wave per row.  d_xa (b,La) [for the table scatter], d_char (b,Lc), SE partials per row.
+template <int LA, int LC>
 __global__ __launch_bounds__(64) void k_sprites_kernel_bwd_rows(SpK a, const real* __restrict__ Knbar,
                                                                 const real* __restrict__ knnbar,
                                                                 real* __restrict__ d_xa, real* __restrict__ d_char,
                                                                 real* __restrict__ part_se) {
-    const int n = blockIdx.x, lane = threadIdx.x, La = a.La, Lc = a.Lc, D = La + Lc;
+    __shared__ real xt[LA + LC];
+    extern __shared__ real src[];                 // 64 x DP: a chunk of inducing rows, staged with coalesced loads (see the column kernel)
+    const int n = blockIdx.x, lane = threadIdx.x, La = a.La, Lc = a.Lc, D = La + Lc, DP = D | 1;
     const real la = a.se[0], sa = a.se[1], lc = a.se[2], sc = a.se[3];
-    const real* xa = act_row(a, n);
-    const real* xc = a.aux + (size_t)n * (1 + Lc) + 1;
-    real acc[2 * SP_MAXD + 4];
+    if (lane < La) xt[lane] = act_row(a, n)[lane];
+    if (lane < Lc) xt[LA + lane] = a.aux[(size_t)n * (1 + Lc) + 1 + lane];
+    const real* xa = xt;
+    const real* xc = xt + LA;
+    real acc[LA + LC];
 #pragma unroll
-    for (int k = 0; k < 2 * SP_MAXD + 4; ++k) acc[k] = 0;
-    for (int j = lane; j < a.m; j += 64) {
-        const real* zj = a.ip + (size_t)j * D;
-        real caA, cbA, d2A, caC, cbC, d2C;
-        const real kA = grp_k(a.kind, zj, xa, La, la, sa, caA, cbA, d2A);          // d/d(second arg) = ca*first + cb*second
-        const real kC = grp_k(a.kind, zj + La, xc, Lc, lc, sc, caC, cbC, d2C);
-        const real c = Knbar[(size_t)n * a.m + j], cA = c * kC, cC = c * kA;
+    for (int k = 0; k < LA + LC; ++k) acc[k] = 0;
+    for (int j0 = 0; j0 < a.m; j0 += 64) {
+        const int cnt = min(64, a.m - j0);
+        __syncthreads();
+        for (int e = lane; e < cnt * D; e += 64) { const int rr = e / D, k = e - rr * D; src[rr * DP + k] = a.ip[(size_t)j0 * D + e]; }
+        __syncthreads();
+        if (lane < cnt) {
+            const real* zj = src + lane * DP;
+            real caA, cbA, d2A, caC, cbC, d2C;
+            const real kA = grp_k(a.kind, zj, xa, La, la, sa, caA, cbA, d2A);          // d/d(second arg) = ca*first + cb*second
+            const real kC = grp_k(a.kind, zj + La, xc, Lc, lc, sc, caC, cbC, d2C);
+            const real c = Knbar[(size_t)n * a.m + j0 + lane], cA = c * kC, cC = c * kA;
 #pragma unroll
-        for (int k = 0; k < SP_MAXD; ++k) {
-            if (k < La) acc[k] += cA * (caA * zj[k] + cbA * xa[k]);
-            if (k < Lc) acc[SP_MAXD + k] += cC * (caC * zj[La + k] + cbC * xc[k]);
+            for (int k = 0; k < LA; ++k)
+                if (k < La) acc[k] += cA * (caA * zj[k] + cbA * xa[k]);
+#pragma unroll
+            for (int k = 0; k < LC; ++k)
+                if (k < Lc) acc[LA + k] += cC * (caC * zj[La + k] + cbC * xc[k]);
         }
     }
     // k_nn = kA(xa,xa) kC(xc,xc)
@@ -155,8 +249,14 @@ __global__ __launch_bounds__(64) void k_sprites_kernel_bwd_rows(SpK a, const rea
     if (lane == 0) {
         if (a.kind == 0) {
             const real na2 = dotd(xa, xa, La), nc2 = dotd(xc, xc, Lc);
-            for (int k = 0; k < La; ++k) acc[k] += g * real(2) * nc2 * xa[k];
-            for (int k = 0; k < Lc; ++k) acc[SP_MAXD + k] += g * real(2) * na2 * xc[k];
+            // (compile-time indices: a run-time index would put the whole accumulator array into scratch memory -- it did: 560 bytes
+            // of scratch per lane and every accumulation of the row loop a scratch load / store)
+#pragma unroll
+            for (int k = 0; k < LA; ++k)
+                if (k < La) acc[k] += g * real(2) * nc2 * xa[k];
+#pragma unroll
+            for (int k = 0; k < LC; ++k)
+                if (k < Lc) acc[LA + k] += g * real(2) * na2 * xc[k];
         } else if (a.kind == 2) {
             const real knn = sa * sa * sc * sc;
             separt[1] = g * real(2) * knn / sa;
@@ -164,20 +264,22 @@ __global__ __launch_bounds__(64) void k_sprites_kernel_bwd_rows(SpK a, const rea
         }
     }
 #pragma unroll
-    for (int k = 0; k < SP_MAXD; ++k) {
+    for (int k = 0; k < LA; ++k)
         if (k < La) { const real t = wave_sum(acc[k]); if (lane == 0) d_xa[(size_t)n * La + k] = t; }
-        if (k < Lc) { const real t = wave_sum(acc[SP_MAXD + k]); if (lane == 0) d_char[(size_t)n * Lc + k] = t; }
-    }
+#pragma unroll
+    for (int k = 0; k < LC; ++k)
+        if (k < Lc) { const real t = wave_sum(acc[LA + k]); if (lane == 0) d_char[(size_t)n * Lc + k] = t; }
     if (lane == 0)
         for (int k = 0; k < 4; ++k) part_se[(size_t)(a.m + n) * 4 + k] = separt[k];
 }
 
-// table scatter (deterministic scan) + final SE-parameter sums (last block)
+// table scatter + final SE-parameter sums (last block).  Workgroup r < n_act: d_table[r][k] = sum of d_xa[n][k] over the batch rows with
+// action id r -- thread (row lane nl, k) walks rows nl, nl + NL, ..., the NL lane sums are added in lane order (fixed order: deterministic).
+// (One thread per table entry walking all b rows was a 40 us serial chain behind the row kernel.)
 __global__ __launch_bounds__(256) void k_sprites_kernel_bwd_scatter(SpK a, const real* __restrict__ d_xa,
                                                                     const real* __restrict__ part_se,
                                                                     real* __restrict__ d_table, real* __restrict__ d_se) {
-    __shared__ int ids[256];
-    __shared__ real red[16];
+    __shared__ real red[256];
     if (blockIdx.x == gridDim.x - 1) {
         for (int k = 0; k < 4; ++k) {
             real s = 0;
@@ -188,20 +290,21 @@ __global__ __launch_bounds__(256) void k_sprites_kernel_bwd_scatter(SpK a, const
         }
         return;
     }
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool act = o < a.n_act * a.La;
-    const int r = act ? o / a.La : -1, k = act ? o % a.La : 0;
+    const int r = blockIdx.x, La = a.La;
+    int KL = 1;
+    while (KL < La) KL <<= 1;                       // k lanes (a power of two <= 32), NL row lanes
+    const int NL = 256 / KL, k = threadIdx.x % KL, nl = threadIdx.x / KL;
     real acc = 0;
-    for (int n0 = 0; n0 < a.b; n0 += 256) {
-        const int cnt = min(256, a.b - n0);
-        __syncthreads();
-        if (threadIdx.x < cnt) ids[threadIdx.x] = (int)a.aux[(size_t)(n0 + threadIdx.x) * (1 + a.Lc)];
-        __syncthreads();
-        if (act)
-            for (int t = 0; t < cnt; ++t)
-                if (ids[t] == r) acc += d_xa[(size_t)(n0 + t) * a.La + k];
+    if (k < La)
+        for (int n = nl; n < a.b; n += NL)
+            if ((int)a.aux[(size_t)n * (1 + a.Lc)] == r) acc += d_xa[(size_t)n * La + k];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (nl == 0 && k < La) {
+        real t = 0;
+        for (int q = 0; q < NL; ++q) t += red[q * KL + k];
+        d_table[(size_t)r * La + k] = t;
     }
-    if (act) d_table[o] = acc;
 }
 
 // ---- aux data: segment mean over seg_len consecutive rows, repeat, prepend the action id --------------
@@ -324,8 +427,15 @@ extern "C" int svgp_sprites_kernel_matrix_fwd(const svgp_sprites_kcfg* c, const 
     int rc = make_spk(c, aux, ip, table, se, a);
     if (rc) return rc;
     SVGP_REQUIRE(K && Kn && knn, SVGP_ERR_INVALID, "NULL pointer");
-    const long long tot = (long long)a.b * a.m + (long long)a.m * a.m + a.b;
-    hipLaunchKernelGGL(k_sprites_kernel_fwd, dim3(nb256(tot)), dim3(256), 0, (hipStream_t)stream, a, K, Kn, knn);
+    static const int tiles_on = [] { const char* e = getenv("SVGP_SPRITES_KFWD_TILES"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (tiles_on) {
+        const int nbt = (a.b + 15) / 16, nmt = (a.m + 15) / 16;
+        hipLaunchKernelGGL(k_sprites_kernel_fwd_tiles, dim3((unsigned)(nbt * nmt + nmt * nmt) + nb256(a.b)), dim3(256), 0,
+                           (hipStream_t)stream, a, nbt, nmt, K, Kn, knn);
+    } else {
+        const long long tot = (long long)a.b * a.m + (long long)a.m * a.m + a.b;
+        hipLaunchKernelGGL(k_sprites_kernel_fwd, dim3(nb256(tot)), dim3(256), 0, (hipStream_t)stream, a, K, Kn, knn);
+    }
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
@@ -342,11 +452,21 @@ extern "C" int svgp_sprites_kernel_matrix_bwd(const svgp_sprites_kcfg* c, const 
     real* d_xa = scratch;
     real* part_se = scratch + (size_t)a.b * a.La;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_sprites_kernel_bwd_cols, dim3(a.m), dim3(256), 0, st, a, Kbar, Knbar, d_ip, part_se);
+    const size_t dp_ = (size_t)((a.La + a.Lc) | 1);
+    if (a.La <= 8 && a.Lc <= 16) {           // the SPRITES defaults (8, 16) and below: exact-size accumulators
+        hipLaunchKernelGGL((k_sprites_kernel_bwd_cols<8, 16>), dim3(a.m), dim3(256), 256 * dp_ * sizeof(real), st, a, Kbar, Knbar, d_ip, part_se);
+        SVGP_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_sprites_kernel_bwd_rows<8, 16>), dim3(a.b), dim3(64), 64 * dp_ * sizeof(real), st, a, Knbar, knnbar, d_xa, d_char, part_se);
+    } else {
+        if (256 * dp_ * sizeof(real) > 48 * 1024)
+            SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sprites_kernel_bwd_cols<SP_MAXD, SP_MAXD>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * dp_ * sizeof(real))));
+        hipLaunchKernelGGL((k_sprites_kernel_bwd_cols<SP_MAXD, SP_MAXD>), dim3(a.m), dim3(256), 256 * dp_ * sizeof(real), st, a, Kbar, Knbar, d_ip, part_se);
+        SVGP_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_sprites_kernel_bwd_rows<SP_MAXD, SP_MAXD>), dim3(a.b), dim3(64), 64 * dp_ * sizeof(real), st, a, Knbar, knnbar, d_xa, d_char, part_se);
+    }
     SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sprites_kernel_bwd_rows, dim3(a.b), dim3(64), 0, st, a, Knbar, knnbar, d_xa, d_char, part_se);
-    SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_sprites_kernel_bwd_scatter, dim3(nb256((long long)a.n_act * a.La) + 1), dim3(256), 0, st, a, d_xa,
+    hipLaunchKernelGGL(k_sprites_kernel_bwd_scatter, dim3((unsigned)a.n_act + 1), dim3(256), 0, st, a, d_xa,
                        part_se, d_table, d_se);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;

@@ -536,7 +536,8 @@ typedef struct {
 int svgp_sprites_kernel_matrix_fwd(const svgp_sprites_kcfg*, const double* aux, const double* ip, const double* table,
                                    const double* se, double* K, double* Kn, double* knn, void* stream);
 /* VJP: d_ip (m,La+Lc), d_table (n_act,La), d_char (b,Lc) (gradient of the batch character vectors), d_se (4).
- * scratch: b*La + (m+b)*4 doubles.                                                                              */
+ * scratch: svgp_sprites_kernel_bwd_scratch_elems(cfg) doubles (row partials of the tiled pass).                  */
+long long svgp_sprites_kernel_bwd_scratch_elems(const svgp_sprites_kcfg*);
 int svgp_sprites_kernel_matrix_bwd(const svgp_sprites_kcfg*, const double* aux, const double* ip, const double* table,
                                    const double* se, const double* Kbar, const double* Knbar, const double* knnbar,
                                    double* d_ip, double* d_table, double* d_char, double* d_se, double* scratch,

@@ -247,6 +247,7 @@ NON_STATUS = {"svgp_version": ([], C.c_int), "svgp_last_error": ([], C.c_char_p)
               "svgp_potri_workspace_elems": ([C.c_int, C.c_int], C.c_size_t),
               "svgp_act_bwd_bias_scratch_elems": ([C.c_int], C.c_int),
               "svgp_dgemm_splitk_scratch_elems": ([C.c_int, C.c_int, C.c_int], C.c_longlong),
+              "svgp_sprites_kernel_bwd_scratch_elems": ([C.POINTER(SpritesKcfg)], C.c_longlong),
               "svgp_svigp_workspace_elems": ([C.c_int, C.c_int, C.c_int], C.c_longlong),
               "svgp_svigp_scale_offset": ([C.c_int, C.c_int, C.c_int], C.c_longlong)}
 

@@ -273,6 +273,147 @@ __global__ __launch_bounds__(64) void k_sprites_kernel_bwd_rows(SpK a, const rea
         for (int k = 0; k < 4; ++k) part_se[(size_t)(a.m + n) * 4 + k] = separt[k];
 }
 
+// ---- the reverse pass by tiles (what the step runs; the two kernels above stay as the reference form for feature groups beyond
+// the template bounds).  A workgroup = 16 TARGETS (mode 0: inducing points z_j, mode 1: batch rows x_n) x one split of the SOURCE rows
+// (mode 0: the batch rows, coefficient Knbar[n][j], then the inducing rows, coefficients rep_weight (Kbar[j][i] + Kbar[i][j]) for the
+// vector part and rep_weight Kbar[j][i] for the hyper-parameters; mode 1: the inducing rows, coefficient Knbar[n][j]).  Per chunk
+// of 64 source rows the rows AND the 64 x 16 coefficient tile are staged in LDS with coalesced loads (the per-target kernels read a
+// matrix COLUMN per workgroup and re-staged every source row for each single target); thread (target tt, source lane sl) takes the
+// sources sl, sl + 16, ...; the 16 source lanes of a target are neighbouring lanes (one DPP row): their sums meet by four xor
+// shuffles.  Partial sums per (split, target) go to scratch and are added in split order by k_sprites_kernel_bwd_finish.
+#define KB_TT 16
+#define KB_SC 64
+template <int LA, int LC>
+__global__ __launch_bounds__(256) void k_sprites_kernel_bwd_tiles(SpK a, int nsplit0, int nsplit1, const real* __restrict__ Kbar,
+                                                                  const real* __restrict__ Knbar, real* __restrict__ part0,
+                                                                  real* __restrict__ part1) {
+    constexpr int NV = LA + LC + 4, DPM = (LA + LC) | 1;
+    __shared__ real tgt[KB_TT][DPM], src[KB_SC][DPM], cv[KB_SC][KB_TT + 1], cpar[KB_SC][KB_TT + 1];
+    const int mode = blockIdx.z, La = a.La, Lc = a.Lc, D = La + Lc;
+    const int nt = mode ? a.b : a.m, nsplit = mode ? nsplit1 : nsplit0, split = blockIdx.y, t0 = blockIdx.x * KB_TT;
+    if (t0 >= nt || split >= nsplit) return;
+    const real la = a.se[0], sa = a.se[1], lc = a.se[2], sc = a.se[3];
+    const int tid = threadIdx.x, tt = tid >> 4, sl = tid & 15;
+    auto feat = [&](bool batch_row, int row, int k) -> real {           // feature k of a batch row (gathered action vector | character) / inducing row
+        return batch_row ? (k < La ? act_row(a, row)[k] : a.aux[(size_t)row * (1 + Lc) + 1 + (k - La)]) : a.ip[(size_t)row * D + k];
+    };
+    for (int e = tid; e < KB_TT * D; e += 256) {
+        const int rr = e / D, k = e - rr * D;
+        tgt[rr][k < La ? k : LA + (k - La)] = feat(mode == 1, min(t0 + rr, nt - 1), k);
+    }
+    real acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0;
+    const int cx = mode ? 0 : (a.b + KB_SC - 1) / KB_SC, cz = (a.m + KB_SC - 1) / KB_SC;
+    for (int c = split; c < cx + cz; c += nsplit) {
+        const bool is_x = c < cx;
+        const int r0 = KB_SC * (is_x ? c : c - cx), ns = is_x ? a.b : a.m;
+        __syncthreads();
+        for (int e = tid; e < KB_SC * D; e += 256) {
+            const int rr = e / D, k = e - rr * D;
+            src[rr][k < La ? k : LA + (k - La)] = feat(is_x, min(r0 + rr, ns - 1), k);
+        }
+        if (mode == 0 && is_x) {
+            for (int e = tid; e < KB_SC * KB_TT; e += 256) {
+                const int s_ = e >> 4, t_ = e & 15, n = r0 + s_, j = t0 + t_;
+                const real v = (n < a.b && j < a.m) ? Knbar[(size_t)n * a.m + j] : real(0);
+                cv[s_][t_] = 0; cpar[s_][t_] = v;                       // (vector coefficient = cv + cpar)
+            }
+        } else if (mode == 0) {
+            for (int e = tid; e < KB_SC * KB_TT; e += 256) {
+                const int t_ = e >> 6, s_ = e & 63, i = r0 + s_, j = t0 + t_;
+                cpar[s_][t_] = (i < a.m && j < a.m) ? a.rep_weight * Kbar[(size_t)j * a.m + i] : real(0);
+            }
+            for (int e = tid; e < KB_SC * KB_TT; e += 256) {
+                const int s_ = e >> 4, t_ = e & 15, i = r0 + s_, j = t0 + t_;
+                cv[s_][t_] = (i < a.m && j < a.m) ? a.rep_weight * Kbar[(size_t)i * a.m + j] : real(0);
+            }
+        } else {
+            for (int e = tid; e < KB_SC * KB_TT; e += 256) {
+                const int t_ = e >> 6, s_ = e & 63, j = r0 + s_, n = t0 + t_;
+                cv[s_][t_] = 0; cpar[s_][t_] = (j < a.m && n < a.b) ? Knbar[(size_t)n * a.m + j] : real(0);
+            }
+        }
+        __syncthreads();
+        const real* y = tgt[tt];
+#pragma unroll
+        for (int q = 0; q < KB_SC / 16; ++q) {
+            const int s_ = sl + 16 * q;
+            const real* x = src[s_];
+            const real c_par = cpar[s_][tt], c_vec = cv[s_][tt] + c_par;
+            real caA, cbA, d2A, caC, cbC, d2C;
+            const real kA = grp_k(a.kind, x, y, La, la, sa, caA, cbA, d2A);             // d k / d (second argument) = ca first + cb second
+            const real kC = grp_k(a.kind, x + LA, y + LA, Lc, lc, sc, caC, cbC, d2C);
+            const real cA = c_vec * kC, cC = c_vec * kA;
+#pragma unroll
+            for (int k = 0; k < LA; ++k)
+                if (k < La) acc[k] += cA * (caA * x[k] + cbA * y[k]);
+#pragma unroll
+            for (int k = 0; k < LC; ++k)
+                if (k < Lc) acc[LA + k] += cC * (caC * x[LA + k] + cbC * y[LA + k]);
+            if (mode == 0 && a.kind == 2) {
+                const real kk = c_par * kA * kC;
+                acc[LA + LC + 0] += kk * d2A / (la * la * la);
+                acc[LA + LC + 1] += kk * real(2) / sa;
+                acc[LA + LC + 2] += kk * d2C / (lc * lc * lc);
+                acc[LA + LC + 3] += kk * real(2) / sc;
+            }
+        }
+    }
+    real* po = (mode ? part1 : part0) + ((size_t)split * nt + min(t0 + tt, nt - 1)) * NV;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const bool used = (k < La) || (k >= LA && k < LA + Lc) || (k >= LA + LC && mode == 0);
+        if (used) {
+            real v = acc[k];
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+            if (sl == 0 && t0 + tt < nt) po[k] = v;
+        }
+    }
+}
+// partial sums over the splits, in split order; the k_nn terms of the batch rows (k_nn = k_A(x_a, x_a) k_C(x_c, x_c))
+template <int LA, int LC>
+__global__ void k_sprites_kernel_bwd_finish(SpK a, int nsplit0, int nsplit1, const real* __restrict__ part0,
+                                            const real* __restrict__ part1, const real* __restrict__ knnbar, real* __restrict__ d_ip,
+                                            real* __restrict__ d_xa, real* __restrict__ d_char, real* __restrict__ part_se) {
+    constexpr int NV = LA + LC + 4;
+    const int La = a.La, Lc = a.Lc, D = La + Lc;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, n0 = (long long)a.m * NV, n1 = (long long)a.b * NV;
+    if (i < n0) {
+        const int j = (int)(i / NV), k = (int)(i % NV);
+        const bool used = (k < La) || (k >= LA && k < LA + Lc) || k >= LA + LC;
+        if (!used) return;
+        real s = 0;
+        for (int sp = 0; sp < nsplit0; ++sp) s += part0[((size_t)sp * a.m + j) * NV + k];
+        if (k < La) d_ip[(size_t)j * D + k] = s;
+        else if (k < LA + LC) d_ip[(size_t)j * D + La + (k - LA)] = s;
+        else part_se[(size_t)j * 4 + (k - LA - LC)] = s;
+    } else if (i < n0 + n1) {
+        const int n = (int)((i - n0) / NV), k = (int)((i - n0) % NV);
+        const real g = knnbar[n];
+        if (k >= LA + LC) {                                  // hyper-parameter partials of k_nn
+            const int q = k - LA - LC;
+            real v = 0;
+            if (a.kind == 2 && (q == 1 || q == 3)) { const real sa = a.se[1], sc = a.se[3]; v = g * real(2) * sa * sa * sc * sc / (q == 1 ? sa : sc); }
+            part_se[(size_t)(a.m + n) * 4 + q] = v;
+            return;
+        }
+        const bool used = (k < La) || (k >= LA && k < LA + Lc);
+        if (!used) return;
+        real s = 0;
+        for (int sp = 0; sp < nsplit1; ++sp) s += part1[((size_t)sp * a.b + n) * NV + k];
+        if (a.kind == 0) {
+            const real* xa = act_row(a, n);
+            const real* xc = a.aux + (size_t)n * (1 + Lc) + 1;
+            if (k < La) s += g * real(2) * dotd(xc, xc, Lc) * xa[k];
+            else s += g * real(2) * dotd(xa, xa, La) * xc[k - LA];
+        }
+        if (k < La) d_xa[(size_t)n * La + k] = s;
+        else d_char[(size_t)n * Lc + (k - LA)] = s;
+    }
+}
+
 // table scatter + final SE-parameter sums (last block).  Workgroup r < n_act: d_table[r][k] = sum of d_xa[n][k] over the batch rows with
 // action id r -- thread (row lane nl, k) walks rows nl, nl + NL, ..., the NL lane sums are added in lane order (fixed order: deterministic).
 // (One thread per table entry walking all b rows was a 40 us serial chain behind the row kernel.)
@@ -440,7 +581,27 @@ extern "C" int svgp_sprites_kernel_matrix_fwd(const svgp_sprites_kcfg* c, const 
     return SVGP_OK;
 }
 
-// scratch: (b*La + (m+b)*4) doubles.  Outputs: d_ip (m,La+Lc), d_table (n_act,La), d_char (b,Lc), d_se (4).
+// split counts of the tiled reverse pass: about 512 workgroups per mode, at least one chunk of sources per split
+static void sprites_bwd_splits(const SpK& a, int* s0, int* s1) {
+    const int t0 = (a.m + KB_TT - 1) / KB_TT, t1 = (a.b + KB_TT - 1) / KB_TT;
+    const int c0 = (a.b + KB_SC - 1) / KB_SC + (a.m + KB_SC - 1) / KB_SC, c1 = (a.m + KB_SC - 1) / KB_SC;
+    int v0 = (512 + t0 - 1) / t0, v1 = (512 + t1 - 1) / t1;
+    *s0 = v0 < 1 ? 1 : (v0 > c0 ? c0 : v0);
+    *s1 = v1 < 1 ? 1 : (v1 > c1 ? c1 : v1);
+}
+// doubles of `scratch` for svgp_sprites_kernel_matrix_bwd
+extern "C" long long svgp_sprites_kernel_bwd_scratch_elems(const svgp_sprites_kcfg* c) {
+    if (!c || c->b < 1 || c->m < 1 || c->La < 1 || c->Lc < 1) return -1;
+    long long n = (long long)c->b * c->La + (long long)(c->m + c->b) * 4 + 16;
+    if (c->La <= 8 && c->Lc <= 16) {
+        SpK a; a.b = c->b; a.m = c->m; a.La = c->La; a.Lc = c->Lc;
+        int s0, s1;
+        sprites_bwd_splits(a, &s0, &s1);
+        n += ((long long)s0 * c->m + (long long)s1 * c->b) * (8 + 16 + 4);
+    }
+    return n;
+}
+// scratch: svgp_sprites_kernel_bwd_scratch_elems doubles.  Outputs: d_ip (m,La+Lc), d_table (n_act,La), d_char (b,Lc), d_se (4).
 extern "C" int svgp_sprites_kernel_matrix_bwd(const svgp_sprites_kcfg* c, const double* aux, const double* ip,
                                               const double* table, const double* se, const double* Kbar,
                                               const double* Knbar, const double* knnbar, double* d_ip, double* d_table,
@@ -452,20 +613,30 @@ extern "C" int svgp_sprites_kernel_matrix_bwd(const svgp_sprites_kcfg* c, const 
     real* d_xa = scratch;
     real* part_se = scratch + (size_t)a.b * a.La;
     hipStream_t st = (hipStream_t)stream;
-    const size_t dp_ = (size_t)((a.La + a.Lc) | 1);
-    if (a.La <= 8 && a.Lc <= 16) {           // the SPRITES defaults (8, 16) and below: exact-size accumulators
-        hipLaunchKernelGGL((k_sprites_kernel_bwd_cols<8, 16>), dim3(a.m), dim3(256), 256 * dp_ * sizeof(real), st, a, Kbar, Knbar, d_ip, part_se);
+    static const int tiles_on = [] { const char* e = getenv("SVGP_SPRITES_KBWD_TILES"); return (e && e[0] == '0') ? 0 : 1; }();
+    if (tiles_on && a.La <= 8 && a.Lc <= 16) {           // the SPRITES defaults (8, 16) and below: the tiled form
+        int s0, s1;
+        sprites_bwd_splits(a, &s0, &s1);
+        constexpr int NV = 8 + 16 + 4;
+        real* part0 = part_se + (size_t)(a.m + a.b) * 4 + 16;
+        real* part1 = part0 + (size_t)s0 * a.m * NV;
+        const int t0 = (a.m + KB_TT - 1) / KB_TT, t1 = (a.b + KB_TT - 1) / KB_TT;
+        hipLaunchKernelGGL((k_sprites_kernel_bwd_tiles<8, 16>), dim3(t0 > t1 ? t0 : t1, s0 > s1 ? s0 : s1, 2), dim3(256), 0, st, a, s0, s1,
+                           Kbar, Knbar, part0, part1);
         SVGP_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_sprites_kernel_bwd_rows<8, 16>), dim3(a.b), dim3(64), 64 * dp_ * sizeof(real), st, a, Knbar, knnbar, d_xa, d_char, part_se);
+        hipLaunchKernelGGL((k_sprites_kernel_bwd_finish<8, 16>), dim3(nb256((long long)(a.m + a.b) * NV)), dim3(256), 0, st, a, s0, s1, part0,
+                           part1, knnbar, d_ip, d_xa, d_char, part_se);
+        SVGP_LAUNCH_CHECK();
     } else {
+        const size_t dp_ = (size_t)((a.La + a.Lc) | 1);
         if (256 * dp_ * sizeof(real) > 48 * 1024)
             SVGP_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sprites_kernel_bwd_cols<SP_MAXD, SP_MAXD>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(256 * dp_ * sizeof(real))));
         hipLaunchKernelGGL((k_sprites_kernel_bwd_cols<SP_MAXD, SP_MAXD>), dim3(a.m), dim3(256), 256 * dp_ * sizeof(real), st, a, Kbar, Knbar, d_ip, part_se);
         SVGP_LAUNCH_CHECK();
         hipLaunchKernelGGL((k_sprites_kernel_bwd_rows<SP_MAXD, SP_MAXD>), dim3(a.b), dim3(64), 64 * dp_ * sizeof(real), st, a, Knbar, knnbar, d_xa, d_char, part_se);
+        SVGP_LAUNCH_CHECK();
     }
-    SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sprites_kernel_bwd_scatter, dim3((unsigned)a.n_act + 1), dim3(256), 0, st, a, d_xa,
                        part_se, d_table, d_se);
     SVGP_LAUNCH_CHECK();

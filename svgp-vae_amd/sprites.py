@@ -218,7 +218,8 @@ class SpritesStepEngine:
         self.nwg = 1024       # workgroups of the weight-gradient launches (4 per CU: the fused kernel hides its loads by occupancy)
         self.scratch = torch.zeros(max(l.scratch_elems(self.nwg) for l in self.enc + self.dec + self.rep),
                                    dtype=self.ndt, device=self.dev)
-        self.kscratch = torch.zeros(b_max * self.La + (self.m + b_max) * 4 + 16, **f64)
+        kc_max = SpritesKcfg(b=b_max, m=self.m, La=self.La, Lc=self.Lc, n_act=self.n_act, normalize=0, k_se=0, rep_weight=1.0)
+        self.kscratch = torch.zeros(int(_lib.load_library().svgp_sprites_kernel_bwd_scratch_elems(C.byref(kc_max))), **f64)
         # second weight-gradient scratch: the encoder reverse pass runs on the side stream beside the kernel-matrix reverse pass
         # and the representation network's (phases(), end of the step)
         self.scratch2 = None if self.side is None else torch.zeros(max(l.scratch_elems(self.nwg) for l in self.enc),

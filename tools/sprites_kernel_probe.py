@@ -16,8 +16,8 @@ se = torch.tensor([1.0, 1.0, 1.0, 1.0], **f64)
 K, Kn, knn = torch.empty(m, m, **f64), torch.empty(b, m, **f64), torch.empty(b, **f64)
 Kbar, Knbar, knnbar = torch.randn(m, m, **f64), torch.randn(b, m, **f64), torch.randn(b, **f64)
 d_ip, d_tab, d_char, d_se = torch.empty(m, La + Lc, **f64), torch.empty(n_act, La, **f64), torch.empty(b, Lc, **f64), torch.empty(4, **f64)
-scr = torch.empty(b * La + (m + b) * 4 + 16, **f64)
 kc = SpritesKcfg(b=b, m=m, La=La, Lc=Lc, n_act=n_act, normalize=int(kind == "cos"), k_se=int(kind == "se"), rep_weight=1.0)
+scr = torch.empty(int(_lib.load_library().svgp_sprites_kernel_bwd_scratch_elems(C.byref(kc))), **f64)
 s = torch.cuda.current_stream().cuda_stream
 def t(fn, reps=50):
     for _ in range(5): fn()

@@ -589,15 +589,18 @@ static void sprites_bwd_splits(const SpK& a, int* s0, int* s1) {
     *s0 = v0 < 1 ? 1 : (v0 > c0 ? c0 : v0);
     *s1 = v1 < 1 ? 1 : (v1 > c1 ? c1 : v1);
 }
+// template bucket of the tiled reverse pass for feature groups (La, Lc): 1 = (8, 16) (the SPRITES defaults), 2 = (16, 32), 0 = none
+static int sprites_bwd_bucket(int La, int Lc) { return (La <= 8 && Lc <= 16) ? 1 : ((La <= 16 && Lc <= 32) ? 2 : 0); }
 // doubles of `scratch` for svgp_sprites_kernel_matrix_bwd
 extern "C" long long svgp_sprites_kernel_bwd_scratch_elems(const svgp_sprites_kcfg* c) {
     if (!c || c->b < 1 || c->m < 1 || c->La < 1 || c->Lc < 1) return -1;
     long long n = (long long)c->b * c->La + (long long)(c->m + c->b) * 4 + 16;
-    if (c->La <= 8 && c->Lc <= 16) {
+    const int bk = sprites_bwd_bucket(c->La, c->Lc);
+    if (bk) {
         SpK a; a.b = c->b; a.m = c->m; a.La = c->La; a.Lc = c->Lc;
         int s0, s1;
         sprites_bwd_splits(a, &s0, &s1);
-        n += ((long long)s0 * c->m + (long long)s1 * c->b) * (8 + 16 + 4);
+        n += ((long long)s0 * c->m + (long long)s1 * c->b) * (bk == 1 ? 8 + 16 + 4 : 16 + 32 + 4);
     }
     return n;
 }
@@ -614,18 +617,26 @@ extern "C" int svgp_sprites_kernel_matrix_bwd(const svgp_sprites_kcfg* c, const 
     real* part_se = scratch + (size_t)a.b * a.La;
     hipStream_t st = (hipStream_t)stream;
     static const int tiles_on = [] { const char* e = getenv("SVGP_SPRITES_KBWD_TILES"); return (e && e[0] == '0') ? 0 : 1; }();
-    if (tiles_on && a.La <= 8 && a.Lc <= 16) {           // the SPRITES defaults (8, 16) and below: the tiled form
+    const int bk = tiles_on ? sprites_bwd_bucket(a.La, a.Lc) : 0;
+    if (bk) {                                             // the tiled form
         int s0, s1;
         sprites_bwd_splits(a, &s0, &s1);
-        constexpr int NV = 8 + 16 + 4;
+        const int NV = bk == 1 ? 8 + 16 + 4 : 16 + 32 + 4;
         real* part0 = part_se + (size_t)(a.m + a.b) * 4 + 16;
         real* part1 = part0 + (size_t)s0 * a.m * NV;
         const int t0 = (a.m + KB_TT - 1) / KB_TT, t1 = (a.b + KB_TT - 1) / KB_TT;
-        hipLaunchKernelGGL((k_sprites_kernel_bwd_tiles<8, 16>), dim3(t0 > t1 ? t0 : t1, s0 > s1 ? s0 : s1, 2), dim3(256), 0, st, a, s0, s1,
-                           Kbar, Knbar, part0, part1);
-        SVGP_LAUNCH_CHECK();
-        hipLaunchKernelGGL((k_sprites_kernel_bwd_finish<8, 16>), dim3(nb256((long long)(a.m + a.b) * NV)), dim3(256), 0, st, a, s0, s1, part0,
-                           part1, knnbar, d_ip, d_xa, d_char, part_se);
+        const dim3 grid(t0 > t1 ? t0 : t1, s0 > s1 ? s0 : s1, 2), gridf(nb256((long long)(a.m + a.b) * NV));
+        if (bk == 1) {
+            hipLaunchKernelGGL((k_sprites_kernel_bwd_tiles<8, 16>), grid, dim3(256), 0, st, a, s0, s1, Kbar, Knbar, part0, part1);
+            SVGP_LAUNCH_CHECK();
+            hipLaunchKernelGGL((k_sprites_kernel_bwd_finish<8, 16>), gridf, dim3(256), 0, st, a, s0, s1, part0, part1, knnbar, d_ip, d_xa,
+                               d_char, part_se);
+        } else {
+            hipLaunchKernelGGL((k_sprites_kernel_bwd_tiles<16, 32>), grid, dim3(256), 0, st, a, s0, s1, Kbar, Knbar, part0, part1);
+            SVGP_LAUNCH_CHECK();
+            hipLaunchKernelGGL((k_sprites_kernel_bwd_finish<16, 32>), gridf, dim3(256), 0, st, a, s0, s1, part0, part1, knnbar, d_ip, d_xa,
+                               d_char, part_se);
+        }
         SVGP_LAUNCH_CHECK();
     } else {
         const size_t dp_ = (size_t)((a.La + a.Lc) | 1);

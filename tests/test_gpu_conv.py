@@ -34,6 +34,10 @@ CASES = [
     (18, 16, 11, 2, 2, "same", False, True),
     # k_conv16_wgrad_grid (16 -> 16, width a multiple of 16): three 16-pixel segments (interior halo columns are real pixels)
     (48, 16, 16, 3, 1, "same", False, True),
+    # k_conv16_thin_fwd (16 -> 3) at widths that are not multiples of its 14-column segments / of 16, 'valid' tap offsets, no activation
+    (20, 16, 3, 3, 1, "same", False, True),
+    (37, 16, 3, 3, 1, "valid", False, False),
+    (32, 16, 3, 3, 1, "same", False, True),
 ]
 
 

@@ -2,6 +2,7 @@
 
     python bench.py --gpus 1 --steps 200 --warmup 20                      # BASELINE configs[1] (the metric)
     python bench.py --workload cfg3|sprites800|cfg5                       # BASELINE configs[2] / [3] / [4]
+    python bench.py --gpus N --steps K --warmup W                         # N > 1: spawns the launcher below as a child
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -9,7 +10,8 @@ Default workload (cfg2): one "step" = one full training step (encoder, kernel ma
 reverse pass, TF1 Adam, GECO state update) on one 256-row rotated-MNIST-shaped batch per GPU (BASELINE configs[1]:
 m=32 inducing points, L=16, GPLVM dim 8, N_train=4050, float64 like the reference).  Weak scaling: every rank keeps
 256 rows, the global batch is 256*N rows coupled through the sufficient-statistics all-reduces; `value` =
-N * steps / time = 256-row batches trained per second (`--scaling strong` keeps the global batch fixed instead).
+N * steps / time = 256-row batches trained per second.  With N > 1 a `"scaling": "strong"` line (the 256-row global batch of
+the headline configuration split over the ranks; value = steps / time) is printed BEFORE the weak line, which stays last.
 Inputs are synthetic, generated once and resident in HBM before the timed region.
 
 Timing: after W warm-up steps, R (`--repeats`, default 5) blocks of EXACTLY K steps, each bracketed by barrier +
@@ -419,23 +421,62 @@ def mnist_survey_flops(b, L_, m, D):
 
 
 def run_mnist(args):
+    """One process group and one library communicator per process; then one measurement per scaling mode.  With several ranks
+    and no explicit --scaling BOTH lines are printed: first the strong one (the headline configuration's global batch split over
+    the ranks -- the same 256 / 1024 rows at every N, so its ELBO is one number for N = 1, 2, 4, 8: SURVEY 8e), then the weak one
+    (rows per GPU fixed), which stays the LAST stdout line and carries the strong result as `strong_scaling`."""
     rank, local_rank, world = dist_env()
-    cfg3 = args.workload == "cfg3"
-    B, M_IND, MDIM = (1024, 256, 32) if cfg3 else (256, 32, 8)
-    if args.scaling == "strong":
-        gb = args.global_batch or B * 8
-        if gb % world:
-            raise SystemExit(f"--global-batch {gb} is not divisible by {world} ranks")
-        B = gb // world
     import torch.distributed as dist
     multi = world > 1 or args.force_dist
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    dev = torch.device(f"cuda:{local_rank}")
+    ctx = {"comm": None, "why": None}
+    if (multi or args.force_comm) and args.exchange == "rccl":
+        # the all-reduces are issued by the library on the compute stream (svgp_mnist_train_step_dp)
+        ctx["comm"], ctx["why"] = library_comm(multi, local_rank, dev)
+        if ctx["comm"] is None:      # both legs are RCCL; this only changes who enqueues the collective
+            print(f"[bench] rank {rank}: in-library RCCL communicator unavailable ({ctx['why']}); "
+                  f"using torch.distributed all_reduce between per-phase graphs", file=sys.stderr, flush=True)
+    modes = [args.scaling] if args.scaling else (["strong", "weak"] if multi else ["weak"])
+    strong = None
+    for mode in modes:
+        line = mnist_case(args, mode, multi, dev, ctx)
+        if rank == 0:
+            if mode == "strong":
+                strong = {k: line[k] for k in ("value", "unit", "ms_per_step", "elbo", "elbo_rel_err_gpu_vs_oracle", "block_ms")}
+                strong["global_batch"] = line["config"]["global_batch"]
+                strong["collectives_us_total"] = line.get("collectives_us_total")
+            elif strong is not None:
+                line["strong_scaling"] = strong
+            emit(line)
+    if multi:
+        dist.destroy_process_group()
+
+
+def mnist_case(args, scaling, multi, dev, ctx):
+    rank, local_rank, world = dist_env()
+    import torch.distributed as dist
+    cfg3 = args.workload == "cfg3"
+    B, M_IND, MDIM = (1024, 256, 32) if cfg3 else (256, 32, 8)
+    if scaling == "strong":
+        # the SAME global batch at every rank count (rank 0's synthetic rows), split into equal contiguous row blocks
+        gb = args.global_batch or B
+        if gb % world:
+            raise SystemExit(f"--global-batch {gb} is not divisible by {world} ranks")
+        B = gb // world
+        params, images, aux, eps = synthetic_problem(0, gb, M_IND, MDIM)
+        images, aux, eps = (x[rank * B:(rank + 1) * B] for x in (images, aux, eps))
+        global_rows = lambda: synthetic_problem(0, gb, M_IND, MDIM)[1:]
+    else:
+        params, images, aux, eps = synthetic_problem(rank, B, M_IND, MDIM)
+
+        def global_rows():
+            parts = [synthetic_problem(r, B, M_IND, MDIM) for r in range(world)]
+            return tuple(np.concatenate([p[i] for p in parts], 0) for i in (1, 2, 3))
 
     from svgp_vae_amd.engine import MnistStepEngine
-    params, images, aux, eps = synthetic_problem(rank, B, M_IND, MDIM)
-    dev = torch.device(f"cuda:{local_rank}")
     eng = MnistStepEngine(M_IND, L, MDIM, N_OBJ, N_train=N_TRAIN, jitter=1e-6, clip_qs=True, geco=True,
                           kappa_squared=0.020, alpha=0.99, beta=0.001, lr=1e-3, b_max=B, device=str(dev),
                           rank=rank, world_size=world,
@@ -445,20 +486,15 @@ def run_mnist(args):
                           single_stat_block=((M_IND > 64 or os.environ.get("SVGP_DP_STAT_PARTIALS") == "0")
                                              if args.force_comm else None))
     eng.load_params(params)
-    d_img, d_aux, d_eps = (torch.tensor(x, dtype=torch.float64, device=dev).contiguous() for x in (images, aux, eps))
+    d_img, d_aux, d_eps = (torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device=dev).contiguous()
+                           for x in (images, aux, eps))
 
     use_graph = not multi and not args.no_graph and not args.force_comm
     launch, comm_ranks = None, None
-    if (multi or args.force_comm) and args.exchange == "rccl":
-        # the three all-reduces are issued by the library on the compute stream (svgp_mnist_train_step_dp)
-        comm, why = library_comm(multi, local_rank, dev)
-        if comm is not None:
-            eng.attach_comm(comm)
-            comm_ranks = comm.world_size
-            launch = "one in-order stream: phases + in-library RCCL all-reduce x3"
-        else:                    # both legs are RCCL; this only changes who enqueues the collective
-            print(f"[bench] rank {rank}: in-library RCCL communicator unavailable ({why}); "
-                  f"using torch.distributed all_reduce between per-phase graphs", file=sys.stderr, flush=True)
+    if ctx["comm"] is not None:
+        eng.attach_comm(ctx["comm"])
+        comm_ranks = ctx["comm"].world_size
+        launch = "one in-order stream: phases + in-library RCCL all-reduce x3"
 
     # ---- parity gate: ONE explicit-eps step (no optimiser update) through the same exchange path the timed region
     # uses; its ELBO is checked against the oracle's efficient formulation on the GLOBAL batch (all ranks' rows are
@@ -470,10 +506,12 @@ def run_mnist(args):
     eng.reset_state()
     elbo_rel = None
     if rank == 0 and not args.no_parity_gate:
-        parts = [synthetic_problem(r, B, M_IND, MDIM) for r in range(world)]
-        want = oracle_elbo(params, *(np.concatenate([p[i] for p in parts], 0) for i in (1, 2, 3)))
+        want = oracle_elbo(params, *global_rows())
         elbo_rel = abs(gpu_elbo - want) / abs(want)
         assert elbo_rel < 1e-3, f"ELBO parity failed at {world} rank(s): GPU {gpu_elbo} oracle {want}"
+        # the strong line's global batch is the same rows at every rank count: agreeing with the oracle to 1e-8 at N = 1, 2, 4, 8
+        # IS the cross-N equality of SURVEY 8e (the `elbo` field of the lines can also be compared directly)
+        assert scaling != "strong" or elbo_rel < 1e-8, f"strong-scaling ELBO at {world} rank(s): GPU {gpu_elbo} oracle {want}"
     if multi:
         dist.barrier()
 
@@ -536,17 +574,17 @@ def run_mnist(args):
         line = {
             "metric": "SVGPVAE train steps/sec, rotated MNIST (N=4050, M=32, L=16)" if not cfg3 else
                       "SVGPVAE train steps/sec, rotated MNIST (N=4050, M=256, L=16, batch 1024)",
-            "value": world * args.steps / el if args.scaling == "weak" else args.steps / el,
-            "unit": f"steps/s ({B}-row batches, whole job)" if args.scaling == "weak" else
+            "value": world * args.steps / el if scaling == "weak" else args.steps / el,
+            "unit": f"steps/s ({B}-row batches, whole job)" if scaling == "weak" else
                     f"steps/s ({B * world}-row global batches)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "repeats": args.repeats, "block_ms": [round(x * 1e3, 3) for x in blocks], "timing": "median block",
             "config": {"workload": name, "global_batch": B * world, "rows_per_gpu": B, "launch": launch,
                        "parallelism": f"dp{world}", "rccl_ranks": comm_ranks,
                        "single_stat_block": int(eng.base["single_stat_block"]),
                        "scaling_note": ("weak: rows per GPU fixed, the global batch (and so c = N_train / b_global of "
-                                        "SVGPVAE_model.py:328) grows with N" if args.scaling == "weak" else
+                                        "SVGPVAE_model.py:328) grows with N" if scaling == "weak" else
                                         "strong: global batch fixed, rows per GPU = global / N")},
             "elbo_rel_err_gpu_vs_oracle": elbo_rel,
         }
@@ -575,11 +613,11 @@ def run_mnist(args):
             line["collectives_us_total"] = round(sum(coll_us), 1)
             line["collectives_note"] = ("HIP events on the compute stream around every exchange point (pack + ONE grouped RCCL "
                                         "launch + unpack), median of 10 steps, maximum over ranks; compute = ms_per_step - total")
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and scaling == "weak":
             line["cpu_baseline"] = cpu_baseline_mnist(cfg3)
-        emit(line)
-    if multi:
-        dist.destroy_process_group()
+        line["elbo"] = gpu_elbo
+        return line
+    return None
 
 
 # =====================================================================================================================
@@ -916,6 +954,47 @@ def cpu_baseline_cfg5(m, n_rows, budget_s=12.0):
 
 
 # =====================================================================================================================
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def spawn_ranks(n, argv, launcher_module=None):
+    """`python bench.py --gpus N` without a launcher: start `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port <free> bench.py <same arguments>` as a child process, pass its stdout through line by
+    line, and return its exit code.  The benchmark's JSON line(s) are remembered; if anything else (an RCCL banner, a warning
+    of the launcher) followed the last one on stdout, it is printed again so that it is the parent's LAST stdout line.
+    (The reference is single-process, MNIST_experiment.py:299,308 -- this launcher is the build's own)
+    SVGP_BENCH_LAUNCHER names another launcher module (the CPU test substitutes a stub for torch.distributed.run)."""
+    import subprocess
+    mod = launcher_module or os.environ.get("SVGP_BENCH_LAUNCHER", "torch.distributed.run")
+    cmd = [sys.executable, "-m", mod, "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: the only mode the host driver supports
+    env.setdefault("OMP_NUM_THREADS", "8")                  # torchrun would set 1 and warn; the CPU parity gate uses the oracle
+    print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    last_json, last_line = None, None
+    for raw in proc.stdout:
+        txt = raw.rstrip("\n")
+        if not txt.strip():
+            continue
+        print(txt, flush=True)
+        last_line = txt
+        if txt.lstrip().startswith("{") and '"metric"' in txt:
+            last_json = txt
+    rc = proc.wait()
+    if rc == 0 and last_json is None:
+        print("[bench] the launched ranks printed no result line", file=sys.stderr, flush=True)
+        return 1
+    if last_json is not None and last_line != last_json:
+        print(last_json, flush=True)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -933,8 +1012,11 @@ def main():
                          "broadcast_object_list, barriers, MAX all-reduce of the time) with world size 1")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1: run the data-parallel entry point with a 1-rank communicator (plumbing check)")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--global-batch", type=int, default=None, help="--scaling strong: rows of the fixed global batch")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="cfg2 / cfg3: default = weak on one rank; with several ranks BOTH lines are printed (strong first, the "
+                         "weak line last with the strong result inside as `strong_scaling`)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="--scaling strong: rows of the fixed global batch (default: the configuration's own batch, 256 / 1024)")
     ap.add_argument("--workload", choices=["cfg2", "cfg3", "sprites800", "cfg5"], default="cfg2",
                     help="cfg2 = BASELINE configs[1] (the metric's configuration, default); cfg3 = configs[2] "
                          "(m=256, b=1024, GPLVM dim 32); sprites800 = configs[3] shape on one GPU's share; "
@@ -966,9 +1048,13 @@ def main():
     if args.workload in ("sprites800", "cfg5") and args.repeats > 3:
         args.repeats = 3
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_dist):
+        # plain `python bench.py --gpus N`: this process becomes the launcher.  Nothing here has touched the GPU yet
+        # (argparse + imports only), and the ranks are CHILD processes -- never an exec of this one.
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank, local_rank, world = dist_env()
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     torch.cuda.set_device(local_rank)
     {"cfg2": run_mnist, "cfg3": run_mnist, "sprites800": run_sprites, "cfg5": run_cfg5}[args.workload](args)
 

@@ -259,6 +259,16 @@ def library_comm(multi, local_rank, dev, timeout_s=180.0, make_id=None, make_com
     why = "ncclCommInitRank timed out" if t.is_alive() else res.get("err")
     # 4. everybody has a communicator, or nobody uses one
     if not vote(res.get("comm") is not None and not t.is_alive()):
+        # this rank may hold a communicator the vote has just discarded: release it; a helper thread still inside
+        # ncclCommInitRank cannot be interrupted from here -- it is a daemon thread and is reported
+        mine = res.get("comm")
+        if mine is not None and hasattr(mine, "close"):
+            try:
+                mine.close()
+            except Exception as e:
+                why = f"{why or ''} (closing the discarded communicator failed: {e!r})".strip()
+        if t.is_alive():
+            why = (why or "") + " [helper thread still inside ncclCommInitRank]"
         return None, why or "another rank has no communicator"
     return res["comm"], None
 

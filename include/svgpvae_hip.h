@@ -536,12 +536,14 @@ typedef struct {
 int svgp_sprites_kernel_matrix_fwd(const svgp_sprites_kcfg*, const double* aux, const double* ip, const double* table,
                                    const double* se, double* K, double* Kn, double* knn, void* stream);
 /* VJP: d_ip (m,La+Lc), d_table (n_act,La), d_char (b,Lc) (gradient of the batch character vectors), d_se (4).
- * scratch: svgp_sprites_kernel_bwd_scratch_elems(cfg) doubles (row partials of the tiled pass).                  */
+ * scratch: scratch_elems doubles (row partials of the tiled pass).  svgp_sprites_kernel_bwd_scratch_elems(cfg) reads cfg.b as
+ * the row CAPACITY and returns a size that covers every call with 1 <= b <= cfg.b (the need is not monotone in b); the call
+ * itself fails with SVGP_ERR_INVALID when scratch_elems is below what its own b needs.                             */
 long long svgp_sprites_kernel_bwd_scratch_elems(const svgp_sprites_kcfg*);
 int svgp_sprites_kernel_matrix_bwd(const svgp_sprites_kcfg*, const double* aux, const double* ip, const double* table,
                                    const double* se, const double* Kbar, const double* Knbar, const double* knnbar,
                                    double* d_ip, double* d_table, double* d_char, double* d_se, double* scratch,
-                                   void* stream);
+                                   long long scratch_elems, void* stream);
 /* aux_data_SVGPVAE_sprites (SVGPVAE_model.py:1086-1115): segment_mean over seg_len consecutive frames, repeat,
  * prepend the action id; and its reverse.                                                                        */
 int svgp_sprites_aux_fwd(int b, int seg_len, int Lc, const double* repr, const double* action_ids, double* aux,

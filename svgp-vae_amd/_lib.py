@@ -172,7 +172,7 @@ SIGNATURES = {
     "svgp_sqerr_fwd_f32": [C.c_longlong, C.c_int, _P, _P, _P, _P],
     "svgp_sqerr_bwd_f32": [C.c_longlong, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P],
     "svgp_sprites_kernel_matrix_fwd": [C.POINTER(SpritesKcfg), _P, _P, _P, _P, _P, _P, _P, _P],
-    "svgp_sprites_kernel_matrix_bwd": [C.POINTER(SpritesKcfg)] + [_P] * 13,
+    "svgp_sprites_kernel_matrix_bwd": [C.POINTER(SpritesKcfg)] + [_P] * 12 + [C.c_longlong, _P],
     "svgp_sprites_aux_fwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P, _P],
     "svgp_sprites_aux_bwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P],
     "svgp_avgpool_fwd": [C.c_int, C.c_int, C.c_int, _P, _P, _P],

@@ -591,28 +591,43 @@ static void sprites_bwd_splits(const SpK& a, int* s0, int* s1) {
 }
 // template bucket of the tiled reverse pass for feature groups (La, Lc): 1 = (8, 16) (the SPRITES defaults), 2 = (16, 32), 0 = none
 static int sprites_bwd_bucket(int La, int Lc) { return (La <= 8 && Lc <= 16) ? 1 : ((La <= 16 && Lc <= 32) ? 2 : 0); }
-// doubles of `scratch` for svgp_sprites_kernel_matrix_bwd
-extern "C" long long svgp_sprites_kernel_bwd_scratch_elems(const svgp_sprites_kcfg* c) {
-    if (!c || c->b < 1 || c->m < 1 || c->La < 1 || c->Lc < 1) return -1;
-    long long n = (long long)c->b * c->La + (long long)(c->m + c->b) * 4 + 16;
-    const int bk = sprites_bwd_bucket(c->La, c->Lc);
+// doubles of `scratch` one call of svgp_sprites_kernel_matrix_bwd with exactly b rows needs
+static long long sprites_bwd_need(int b, int m, int La, int Lc) {
+    long long n = (long long)b * La + (long long)(m + b) * 4 + 16;
+    const int bk = sprites_bwd_bucket(La, Lc);
     if (bk) {
-        SpK a; a.b = c->b; a.m = c->m; a.La = c->La; a.Lc = c->Lc;
+        SpK a; a.b = b; a.m = m; a.La = La; a.Lc = Lc;
         int s0, s1;
         sprites_bwd_splits(a, &s0, &s1);
-        n += ((long long)s0 * c->m + (long long)s1 * c->b) * (bk == 1 ? 8 + 16 + 4 : 16 + 32 + 4);
+        n += ((long long)s0 * m + (long long)s1 * b) * (bk == 1 ? 8 + 16 + 4 : 16 + 32 + 4);
     }
     return n;
 }
-// scratch: svgp_sprites_kernel_bwd_scratch_elems doubles.  Outputs: d_ip (m,La+Lc), d_table (n_act,La), d_char (b,Lc), d_se (4).
+// doubles of `scratch` for svgp_sprites_kernel_matrix_bwd: cfg.b is the row CAPACITY -- the value covers every call with
+// 1 <= b <= cfg.b.  (The need is not monotone in b: the split count of the batch-row targets grows as b shrinks, so s1 * b at
+// b < capacity can exceed its value at the capacity -- ADVICE r4: m = 800, capacity 936, b = 720 needed 3 888 doubles more.)
+extern "C" long long svgp_sprites_kernel_bwd_scratch_elems(const svgp_sprites_kcfg* c) {
+    if (!c || c->b < 1 || c->m < 1 || c->La < 1 || c->Lc < 1) return -1;
+    long long n = 0;
+    for (int b = 1; b <= c->b; ++b) {
+        const long long nb = sprites_bwd_need(b, c->m, c->La, c->Lc);
+        n = nb > n ? nb : n;
+    }
+    return n;
+}
+// scratch: scratch_elems doubles (svgp_sprites_kernel_bwd_scratch_elems of the row capacity); checked against this call's need.
+// Outputs: d_ip (m,La+Lc), d_table (n_act,La), d_char (b,Lc), d_se (4).
 extern "C" int svgp_sprites_kernel_matrix_bwd(const svgp_sprites_kcfg* c, const double* aux, const double* ip,
                                               const double* table, const double* se, const double* Kbar,
                                               const double* Knbar, const double* knnbar, double* d_ip, double* d_table,
-                                              double* d_char, double* d_se, double* scratch, void* stream) {
+                                              double* d_char, double* d_se, double* scratch, long long scratch_elems,
+                                              void* stream) {
     SpK a;
     int rc = make_spk(c, aux, ip, table, se, a);
     if (rc) return rc;
     SVGP_REQUIRE(Kbar && Knbar && knnbar && d_ip && d_table && d_char && d_se && scratch, SVGP_ERR_INVALID, "NULL pointer");
+    SVGP_REQUIRE(scratch_elems >= sprites_bwd_need(a.b, a.m, a.La, a.Lc), SVGP_ERR_INVALID,
+                 "scratch too small: size it with svgp_sprites_kernel_bwd_scratch_elems at the row capacity");
     real* d_xa = scratch;
     real* part_se = scratch + (size_t)a.b * a.La;
     hipStream_t st = (hipStream_t)stream;

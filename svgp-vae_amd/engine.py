@@ -300,6 +300,38 @@ class RcclComm:
             self.handle = C.c_void_p()
 
 
+def agree_on_lengths(lens, comm, device, stream):
+    """Collective: raises SvgpError on EVERY rank when the integer list `lens` (exchange block lengths) is not the same on all
+    ranks; returns False when there is nothing to check with.  Through torch.distributed when a process group exists (MIN / MAX),
+    otherwise through the library's own communicator (with only `attach_comm` ranks built with different b_max or
+    SVGP_DP_STAT_PARTIALS ran all-reduces of different counts).  The communicator form uses two fixed-count SUM all-reduces:
+    the lengths (every rank compares world * own with the sum -- a disagreement is seen by at least one rank), then the
+    per-rank verdicts, so that all ranks raise together instead of one leaving the others in the next collective."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        t = torch.tensor(list(lens), dtype=torch.int64, device=device if dist.get_backend() == "nccl" else "cpu")
+        lo, hi = t.clone(), t.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise _lib.SvgpError(f"exchange block lengths differ between ranks (min {lo.tolist()}, max {hi.tolist()}): "
+                                 "build every rank's engine with the same b_max")
+        return True
+    if comm is None:
+        return False
+    with torch.cuda.stream(stream):
+        mine = torch.tensor([float(x) for x in lens], dtype=torch.float64, device=device)
+        tot = mine.clone()
+        comm.all_reduce(tot, stream.cuda_stream)
+        bad = (tot != mine * comm.world_size).any().to(torch.float64).reshape(1).contiguous()
+        comm.all_reduce(bad, stream.cuda_stream)
+    stream.synchronize()
+    if float(bad.item()) > 0:
+        raise _lib.SvgpError(f"exchange block lengths differ between ranks (this rank {list(lens)}, mean over ranks "
+                             f"{(tot / comm.world_size).tolist()}): build every rank's engine with the same b_max")
+    return True
+
+
 def concurrent_streams(main, n, device):
     """n torch streams that run BESIDE `main` and beside each other.  HIP maps streams onto a small pool of hardware queues in
     creation order, and two streams on one queue execute one after the other whatever the events say (include/svgpvae_hip.h:
@@ -498,21 +530,11 @@ class MnistStepEngine:
 
     def _check_block_lengths(self):
         """The exchange blocks must have the same length on every rank (the row-partial count of the statistics blocks is a
-        function of the row capacity b_max): checked once, through torch.distributed when a process group exists."""
+        function of the row capacity b_max and of SVGP_DP_STAT_PARTIALS): checked once -- see agree_on_lengths."""
         if getattr(self, "_blocks_checked", False) or self.world_size == 1:
             return
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()):
-            return
-        lens = torch.tensor([self.wl.statA_len, self.wl.statB_len, self.wl.gradC_len], dtype=torch.int64,
-                            device=self.device if dist.get_backend() == "nccl" else "cpu")
-        lo, hi = lens.clone(), lens.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        if not torch.equal(lo, hi):
-            raise _lib.SvgpError(f"exchange block lengths differ between ranks (min {lo.tolist()}, max {hi.tolist()}): "
-                                 "build every rank's engine with the same b_max")
-        self._blocks_checked = True
+        if agree_on_lengths([self.wl.statA_len, self.wl.statB_len, self.wl.gradC_len], self.comm, self.device, self.stream):
+            self._blocks_checked = True
 
     def full_step_dp(self, adam=True):
         images, aux, eps = self._bound

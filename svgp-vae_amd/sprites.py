@@ -408,6 +408,11 @@ class SpritesStepEngine:
         the three exchange blocks are summed over ranks by `self.comm` between the phases."""
         if self.world_size > 1 and self.comm is None:
             raise _lib.SvgpError("world_size > 1 needs a communicator (engine.RcclComm)")
+        if self.world_size > 1 and not getattr(self, "_blocks_checked", False):
+            # the exchange blocks' lengths are functions of the row capacity: every rank must have been built with the same b_max
+            from .engine import agree_on_lengths
+            self._blocks_checked = agree_on_lengths([self.wl.statA_len, self.wl.statB_len, self.wl.gradC_len], self.comm,
+                                                    self.dev, self.stream)
         tr = getattr(self, "exchange_trace", None)
         for ops in self.phases(images, action_ids, eps, adam, b_global):
             if self.comm is not None:
@@ -421,6 +426,16 @@ class SpritesStepEngine:
         return self
 
     def phases(self, images, action_ids, eps=None, adam=True, b_global=None):
+        """The step as a generator (see _phases_body).  Whatever ends it -- exhaustion, an exception in a stage, the caller
+        abandoning it at an exchange point -- the per-step weight layouts of the layers are dropped, so that a later forward()
+        / backward() can never pick up layouts of parameters that have changed in place since."""
+        try:
+            return (yield from self._phases_body(images, action_ids, eps, adam, b_global))
+        finally:
+            for lay in self.enc + self.dec + self.rep:
+                lay._prep = None
+
+    def _phases_body(self, images, action_ids, eps=None, adam=True, b_global=None):
         """Generator over the step: yields, at every exchange point, the list of engine.ExchangeOp to run across the
         ranks.  Three points (all-reduce of the forward statistics, the backward statistics, gradients + scalar sums) in
         the plain form; five in the channel-sharded form (reduce-scatter S, v | all-gather Sigma^-1, t, u |
@@ -640,7 +655,7 @@ class SpritesStepEngine:
                  p["GPLVM_action"].data_ptr(), p["se"].data_ptr(), self._v("Kbar", (1,)).data_ptr(),
                  self._v("Knbar", (1,)).data_ptr(), self._v("knnbar", (1,)).data_ptr(),
                  g["inducing_index_points"].data_ptr(), g["GPLVM_action"].data_ptr(), d_char.data_ptr(),
-                 g["se"].data_ptr(), self.kscratch.data_ptr(), s)
+                 g["se"].data_ptr(), self.kscratch.data_ptr(), self.kscratch.numel(), s)
             self._mark("nets_bwd_enc")
             d_rvec = torch.empty(b, self.Lc, **f64)
             call("svgp_sprites_aux_bwd", b, self.seg_len, self.Lc, d_char.data_ptr(), d_rvec.data_ptr(), s)
@@ -881,11 +896,20 @@ class repr_NN_classification_layer:
         rs = np.random.RandomState(seed)
         self.W = torch.tensor(rs.uniform(-lim, lim, (n_in, n_classes)), dtype=_F64, device=device)
         self.b = torch.zeros(n_classes, dtype=_F64, device=device)
+        self.reset_metrics()
+
+    def reset_metrics(self):
+        """`sess.run(tf.local_variables_initializer())` (SPRITES_experiment.py:304,326): zeroes the total / count pair behind
+        the streaming accuracy of forward_pass_pretraining_repr_NN(test_pipeline=True)."""
+        self.acc_total, self.acc_count = 0.0, 0.0
 
 
 def forward_pass_pretraining_repr_NN(frames, labels, repr_NN, classification_layer, test_pipeline=False, engine=None):
     """SPRITES_utils.py:335-368: loss = mean sparse softmax cross-entropy of Dense(repr_nn(frames)) against the character
-    ids; with `test_pipeline` also the accuracy of the arg-max prediction.  The in-batch shuffle of :346-351 permutes the
+    ids; with `test_pipeline` also the accuracy of the arg-max prediction -- as in the reference the STREAMING accuracy
+    (`_, acc = tf.compat.v1.metrics.accuracy(...)`, :364: the update op's value, i.e. correct / seen over every batch evaluated
+    since the metric's local variables were initialised; the pair lives on `classification_layer`, `reset_metrics()` is the
+    `tf.local_variables_initializer()` of SPRITES_experiment.py:326).  The in-batch shuffle of :346-351 permutes the
     rows of a mean and is not reproduced.  Runs the representation network, the average pool, the dense product and
     `svgp_softmax_xent` of the library on the engine attached to `repr_NN` (or `engine=`); the training loop around it,
     with its reverse pass and TF1 Adam, is `pretrain_repr_NN`."""
@@ -907,7 +931,12 @@ def forward_pass_pretraining_repr_NN(frames, labels, repr_NN, classification_lay
     eng.stream.synchronize()
     if not test_pipeline:
         return loss[0]
-    acc = (torch.argmax(logits, dim=1) == lab_all.long()).to(_F64).mean()
+    hits = float((torch.argmax(logits, dim=1) == lab_all.long()).sum())
+    if not hasattr(classification_layer, "acc_total"):
+        classification_layer.acc_total, classification_layer.acc_count = 0.0, 0.0
+    classification_layer.acc_total += hits
+    classification_layer.acc_count += float(n)
+    acc = torch.tensor(classification_layer.acc_total / classification_layer.acc_count, dtype=_F64, device=dev)
     return loss[0], acc
 
 

@@ -212,3 +212,38 @@ def test_bench_multi_gpu_code_path_at_world_size_one():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert len(line["collectives_us"]) == 5 and line["elbo_rel_err_gpu_vs_oracle"] < 1e-6
+
+
+def test_bench_launches_its_own_ranks_and_prints_the_strong_line_first():
+    """`python bench.py --gpus 1 --force-dist` WITHOUT a launcher: the process spawns torch.distributed.run as
+    a child before touching the GPU, the rank prints the strong-scaling line (the configuration's own global batch split over
+    the ranks, ELBO against the oracle to 1e-8) and then the weak line, which is the parent's LAST stdout line and carries the
+    strong result."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "20", "--warmup", "5",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1" in r.stderr
+    lines = [json.loads(x) for x in r.stdout.splitlines() if x.lstrip().startswith("{") and '"metric"' in x]
+    assert [x["scaling"] for x in lines] == ["strong", "weak"]
+    last = json.loads(r.stdout.strip().splitlines()[-1])
+    assert last == lines[-1] and last["n_gpus"] == 1 and last["config"]["rccl_ranks"] == 1 and last["value"] > 100
+    st = last["strong_scaling"]
+    assert st["global_batch"] == 256 and st["elbo_rel_err_gpu_vs_oracle"] < 1e-8 and st["value"] > 100
+    assert abs(st["elbo"] - lines[0]["elbo"]) == 0.0
+
+
+def test_exchange_lengths_agree_through_the_library_communicator():
+    """engine.agree_on_lengths without a torch.distributed process group: the two fixed-count all-reduces of the library's own
+    communicator (1 rank here: trivially equal; the disagreement logic is covered with stand-in communicators on CPU)."""
+    from svgp_vae_amd.engine import RcclComm, agree_on_lengths
+    comm = RcclComm(0, 1, RcclComm.unique_id())
+    s = torch.cuda.Stream()
+    assert agree_on_lengths([135168, 8, 74000], comm, torch.device("cuda:0"), s) is True
+    assert agree_on_lengths([1, 2, 3], None, torch.device("cuda:0"), s) is False
+    comm.close()

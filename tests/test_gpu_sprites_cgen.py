@@ -234,6 +234,15 @@ def test_reference_signature_helpers_match_oracle():
     loss_t, acc_t = forward_pass_pretraining_repr_NN(frames, labels, rnn, cl, True)
     assert abs(float(loss) - float(loss_o)) < 1e-12 * abs(float(loss_o)) + 1e-13 and float(loss_t) == float(loss)
     assert float(acc_t) == float(acc_o)
+    # the accuracy is the reference's STREAMING metric (tf.compat.v1.metrics.accuracy update op, SPRITES_utils.py:364): a second
+    # batch returns correct / seen over both, until the local variables are re-initialised (SPRITES_experiment.py:326)
+    half = n // 2
+    _, acc_2 = forward_pass_pretraining_repr_NN(frames[:half], labels[:half], rnn, cl, True)
+    hits = float((logits_o.argmax(1) == labels).sum()) + float((logits_o[:half].argmax(1) == labels[:half]).sum())
+    assert abs(float(acc_2) - hits / (n + half)) < 1e-15
+    cl.reset_metrics()
+    _, acc_3 = forward_pass_pretraining_repr_NN(frames[:half], labels[:half], rnn, cl, True)
+    assert abs(float(acc_3) - float((logits_o[:half].argmax(1) == labels[:half]).double().mean())) < 1e-15
     # element-wise Gaussian cross-entropy, broadcasting like the reference's call sites (SVGPVAE_model.py:896)
     mu1, var1 = torch.randn(n, L, dtype=DT, generator=g), torch.rand(n, L, dtype=DT, generator=g) + 0.1
     mu2, var2 = torch.randn(n, L, dtype=DT, generator=g), torch.rand(1, L, dtype=DT, generator=g) + 0.1

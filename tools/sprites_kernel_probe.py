@@ -27,5 +27,5 @@ def t(fn, reps=50):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 fwd = lambda: call("svgp_sprites_kernel_matrix_fwd", C.byref(kc), aux.data_ptr(), ip.data_ptr(), table.data_ptr(), se.data_ptr(), K.data_ptr(), Kn.data_ptr(), knn.data_ptr(), s)
-bwd = lambda: call("svgp_sprites_kernel_matrix_bwd", C.byref(kc), aux.data_ptr(), ip.data_ptr(), table.data_ptr(), se.data_ptr(), Kbar.data_ptr(), Knbar.data_ptr(), knnbar.data_ptr(), d_ip.data_ptr(), d_tab.data_ptr(), d_char.data_ptr(), d_se.data_ptr(), scr.data_ptr(), s)
+bwd = lambda: call("svgp_sprites_kernel_matrix_bwd", C.byref(kc), aux.data_ptr(), ip.data_ptr(), table.data_ptr(), se.data_ptr(), Kbar.data_ptr(), Knbar.data_ptr(), knnbar.data_ptr(), d_ip.data_ptr(), d_tab.data_ptr(), d_char.data_ptr(), d_se.data_ptr(), scr.data_ptr(), scr.numel(), s)
 print(f"{kind}: kernel_matrix_fwd {t(fwd):.1f} us   kernel_matrix_bwd (cols + rows + scatter) {t(bwd):.1f} us")

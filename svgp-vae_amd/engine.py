@@ -319,13 +319,17 @@ def agree_on_lengths(lens, comm, device, stream):
         return True
     if comm is None:
         return False
-    with torch.cuda.stream(stream):
+    import contextlib
+    on_gpu = stream is not None            # (stream None: a host stand-in communicator, tests/test_dp_gloo.py)
+    with (torch.cuda.stream(stream) if on_gpu else contextlib.nullcontext()):
+        raw = stream.cuda_stream if on_gpu else None
         mine = torch.tensor([float(x) for x in lens], dtype=torch.float64, device=device)
         tot = mine.clone()
-        comm.all_reduce(tot, stream.cuda_stream)
+        comm.all_reduce(tot, raw)
         bad = (tot != mine * comm.world_size).any().to(torch.float64).reshape(1).contiguous()
-        comm.all_reduce(bad, stream.cuda_stream)
-    stream.synchronize()
+        comm.all_reduce(bad, raw)
+    if on_gpu:
+        stream.synchronize()
     if float(bad.item()) > 0:
         raise _lib.SvgpError(f"exchange block lengths differ between ranks (this rank {list(lens)}, mean over ranks "
                              f"{(tot / comm.world_size).tolist()}): build every rank's engine with the same b_max")

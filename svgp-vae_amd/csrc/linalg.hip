@@ -650,393 +650,6 @@ __global__ __launch_bounds__(256) void k_bgjf_step(BgjfArgs g) {
     }
 }
 
-
-// ---------------------------------------------------------------------------------------------
-// The same 32-block sweep as ONE launch (round 5): a wave owns a 32 x 32 tile for all block steps and keeps it in registers
-// (MFMA accumulator layout); what a step needs from other tiles -- the pivot block's inverse, the tile of the pivot ROW block
-// in its column, the tile of the pivot COLUMN block in its row -- is handed over through global memory, one flag per
-// published tile, no grid-wide barrier and no kernel boundary:
-//   * a tile is published at most twice, to two different buffers (Xrow after step bi - 1, Xcol after step bj - 1), and
-//     every pivot inverse to its own slot: every slot is written once per call, so nothing is overwritten while it is read;
-//   * producer: 8-byte agent-scope (sc1, write-through) stores by the owning wave -> s_waitcnt vmcnt(0) -> sc1 flag store;
-//     consumer: sc1 poll of the flag by the consuming wave -> sc1 loads of the tile (MI355X guide, "inter-workgroup
-//     visibility": write-through payload + drained flag; the per-XCD L2s are not coherent, L1 is bypassed by sc1);
-//   * the wave that owns the NEXT pivot tile inverts it (sweep32) right after its own update: the chain per block step is
-//     sweep -> hand-off of P^-1 -> two 32^3 products of one wave, not sweep -> kernel boundary -> reload -> products;
-//   * the accumulator layout of a 32 x 32 product IS the B-operand layout of the next one (row k0 + q, column r of lane
-//     (r, q)), so T = P^-1 R feeds C T from registers; operands from other tiles are loaded straight into A / B layout.
-// Per 16 x 16 quadrant the MFMA sequence (accumulate from 0 over k0 = 0, 4, .., 28, then old - product) is that of
-// k_bgjf_step, and the sweep is the same function: results are bit-identical to the launch-per-step form
-// (tests/test_gpu_linalg.py compares them).  Every wave of the grid must be resident for the hand-offs to complete: the
-// host side takes this path only for grids far below the chip's capacity (flow_fits) and a wave that waits longer than
-// ~0.5 s for a flag raises `err` and carries on (a wrong result the caller sees, not a hung GPU).
-// XCD placement: workgroups b and b + 8 share an XCD, so the workgroups of one matrix are dealt to ONE residue class.
-// ---------------------------------------------------------------------------------------------
-struct BgjFlowArgs {
-    int m, nb, batch, nmain, wpm;
-    const real* A; const real* Ae;      // inputs (nmain, m, m), (batch - nmain, m, m)
-    real* Out; real* Oute;              // result before symmetrisation
-    real* Xrow; real* Xcol;             // (batch, nb * nb, 32 * 32) published tiles, row-major 32 x 32 each
-    real* Xdiag;                        // (batch, nb, 32 * 32) diagonal tile d after step d - 2: what the chain wave starts pivot d from
-    real* Pinv;                         // (batch, nb, 32 * 32)
-    int* rowflag; int* colflag;         // (batch, nb * nb)
-    int* pivflag; int* diagflag;        // (batch, nb)
-    int* err;
-    real* logdet; real* logdet_e;
-};
-
-__device__ __forceinline__ real ld_sc1(const real* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_sc1(real* p, real v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void flow_wait(const int* f, int* err) {
-    int spins = 0;
-    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 22)) {
-            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-    }
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-}
-// this wave's stores have left (s_waitcnt vmcnt(0): written through), then ONE lane raises the flag
-__device__ __forceinline__ void flow_signal(int* f, int lane) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_store(f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// A-operand layout of a published 32 x 32 tile: a[ti][k] = T[16 ti + r][4 k + q];  B-operand layout: b[tj][k] = T[4 k + q][16 tj + r]
-__device__ __forceinline__ void flow_load_A(const real* t, int r, int q, real (&a)[2][8]) {
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a[ti][k] = ld_sc1(t + (16 * ti + r) * NB + 4 * k + q);
-}
-__device__ __forceinline__ void flow_load_B(const real* t, int r, int q, real (&b)[2][8]) {
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) b[tj][k] = ld_sc1(t + (4 * k + q) * NB + 16 * tj + r);
-}
-// the same from the input matrix (written by earlier kernels: plain loads), zero beyond m.  Branch-free (clamped address, then
-// a select): a conditional load per element serialises the 16 requests of an operand behind each other's waits
-__device__ __forceinline__ real flow_get_in(const real* X, int m, int bi, int bj, int i, int j) {
-    const int gi = bi * NB + i, gj = bj * NB + j;
-    const real v = X[(size_t)(gi < m ? gi : m - 1) * m + (gj < m ? gj : m - 1)];
-    return (gi < m && gj < m) ? v : real(0);
-}
-__device__ __forceinline__ void flow_load_A_in(const real* X, int m, int bi, int bj, int r, int q, real (&a)[2][8]) {
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a[ti][k] = flow_get_in(X, m, bi, bj, 16 * ti + r, 4 * k + q);
-}
-__device__ __forceinline__ void flow_load_B_in(const real* X, int m, int bi, int bj, int r, int q, real (&b)[2][8]) {
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) b[tj][k] = flow_get_in(X, m, bi, bj, 4 * k + q, 16 * tj + r);
-}
-__device__ __forceinline__ void flow_load_X_in(const real* X, int m, int bi, int bj, int r, int q, d4_t (&x)[2][2]) {
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[ti][tj][e] = flow_get_in(X, m, bi, bj, 16 * ti + q + 4 * e, 16 * tj + r);
-}
-// several flags at once: lane i < n polls f[i] (one request for all), until all are up
-__device__ __forceinline__ bool flow_all_up(const int* const (&f)[3], int lane) {
-    const int* p = lane == 0 ? f[0] : (lane == 1 ? f[1] : f[2]);
-    const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return __builtin_amdgcn_ballot_w64(v != 0 || lane > 2) == ~0ull;
-}
-__device__ __forceinline__ void flow_wait3(const int* const (&f)[3], int lane, int* err) {
-    int spins = 0;
-    while (!flow_all_up(f, lane)) {
-        __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 22)) {
-            __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-    }
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-}
-// acc[ti][tj] = sum_k a[ti][k] b[tj][k] per 16 x 16 quadrant, k ascending from a zero accumulator (as mm32_mfma)
-__device__ __forceinline__ void flow_mm(const real (&a)[2][8], const real (&b)[2][8], d4_t (&acc)[2][2]) {
-    d4_t c00 = {0, 0, 0, 0}, c01 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {                        // the four quadrants' chains interleaved: an f64 MFMA's result is 64 cycles away
-        c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][k], b[0][k], c00, 0, 0, 0);
-        c01 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][k], b[1][k], c01, 0, 0, 0);
-        c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][k], b[0][k], c10, 0, 0, 0);
-        c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][k], b[1][k], c11, 0, 0, 0);
-    }
-    acc[0][0] = c00; acc[0][1] = c01; acc[1][0] = c10; acc[1][1] = c11;
-}
-// a product in accumulator layout as the B operand of the next one: b[tj][k] = T[4 k + q][16 tj + r] = acc[k / 4][tj][k % 4]
-__device__ __forceinline__ void flow_acc_as_B(const d4_t (&acc)[2][2], real (&b)[2][8]) {
-#pragma unroll
-    for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-        for (int k = 0; k < 8; ++k) b[tj][k] = acc[k / 4][tj][k % 4];
-}
-// publish this wave's tile (accumulator layout: element (16 ti + q + 4 e, 16 tj + r)) to a 32 x 32 row-major slot
-__device__ __forceinline__ void flow_publish(real* slot, const d4_t (&x)[2][2], int r, int q) {
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) st_sc1(slot + (16 * ti + q + 4 * e) * NB + 16 * tj + r, x[ti][tj][e]);
-}
-
-#ifdef SVGP_FLOW_TRACE
-__device__ unsigned long long g_flow_trace[16 * 16];       // matrix 0's chain wave: [pivot][mark], s_memrealtime ticks (100 MHz)
-__device__ unsigned long long g_flow_trace_tile[16 * 16];  // matrix 0's tile (3, 5): [step][mark]
-#define FLOW_MARK(step, k) do { if (l == 0 && lane == 0) g_flow_trace[(step) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define FLOW_TMARK(step, k) do { if (l == 0 && lane == 0 && t == 3 * nb + 5) g_flow_trace_tile[(step) * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define FLOW_MARK(step, k) do { } while (0)
-#define FLOW_TMARK(step, k) do { } while (0)
-#endif
-// the 32 x 32 update of one block step on register operands: returns x - C (P^-1 R) (or its special forms in the pivot row /
-// column blocks); pa = P^-1 in A layout (rows != pivot column block), tb_in = P^-1 in B layout (pivot column block)
-__device__ __forceinline__ void flow_update(d4_t (&x)[2][2], bool in_row, bool in_col, const real (&pa)[2][8], const real (&rb)[2][8],
-                                            const real (&pb)[2][8], const real (&ca)[2][8]) {
-    real tb[2][8];
-    d4_t T[2][2];
-    if (in_col) {                                       // the pivot column block: "T" is P^-1 itself
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    T[ti][tj][e] = pb[tj][4 * ti + e];
-                    tb[tj][4 * ti + e] = pb[tj][4 * ti + e];
-                }
-    } else {
-        flow_mm(pa, rb, T);                             // scaled pivot row block P^-1 X[kb][bj]
-        flow_acc_as_B(T, tb);
-    }
-    if (in_row) {
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj) x[ti][tj] = T[ti][tj];
-    } else {
-        d4_t U[2][2];
-        flow_mm(ca, tb, U);                             // old column block times the scaled pivot row block
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) x[ti][tj][e] = in_col ? -U[ti][tj][e] : x[ti][tj][e] - U[ti][tj][e];
-    }
-}
-// rows / columns beyond m stay zero (the launch-per-step form stores only the in-range part and reads zeros back)
-__device__ __forceinline__ void flow_zero_pad(d4_t (&x)[2][2], int m, int bi, int bj, int r, int q) {
-    if ((bi + 1) * NB > m || (bj + 1) * NB > m) {
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (bi * NB + 16 * ti + q + 4 * e >= m || bj * NB + 16 * tj + r >= m) x[ti][tj][e] = real(0);
-    }
-}
-
-__global__ __launch_bounds__(256, 2) void k_bgj_flow(BgjFlowArgs g) {
-    __shared__ real P[NB][NB + 1];                      // the chain wave's pivot block, then its inverse (one chain wave per workgroup at most)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int l = (slot / g.wpm) * 8 + xcd, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int nb = g.nb, nt = nb * nb, t = (slot % g.wpm) * 4 + w, m = g.m;
-    if (l >= g.batch || t > nt) return;
-    const int r = lane & 15, q = lane >> 4;
-    const size_t mo = (size_t)(l < g.nmain ? l : l - g.nmain) * m * m;
-    const real* X = (l < g.nmain ? g.A : g.Ae) + mo;
-    real* Y = (l < g.nmain ? g.Out : g.Oute) + mo;
-    real* xrow = g.Xrow + (size_t)l * nt * NB * NB;
-    real* xcol = g.Xcol + (size_t)l * nt * NB * NB;
-    real* xdiag = g.Xdiag + (size_t)l * nb * NB * NB;
-    real* pinv = g.Pinv + (size_t)l * nb * NB * NB;
-    int* rowflag = g.rowflag + (size_t)l * nt;
-    int* colflag = g.colflag + (size_t)l * nt;
-    int* pivflag = g.pivflag + (size_t)l * nb;
-    int* diagflag = g.diagflag + (size_t)l * nb;
-    d4_t x[2][2];                                       // a tile in accumulator layout; zero beyond m
-    real pa[2][8], pb[2][8], rb[2][8], ca[2][8];
-
-    if (t == nt) {
-        // ---- the CHAIN wave of matrix l: every pivot inverse and, between two of them, the ONE tile update the next pivot block
-        // needs (tile (d, d) of step d - 1, recomputed here from the operands its owner uses too: same sequences, same bits).
-        // P^-1 never leaves the wave on its way to the next pivot block: sweep -> LDS -> two 32^3 products -> sweep.
-        real piv_of[16];                                // this lane's pivot of every block (nb <= 16); logs are taken after the chain
-        auto pivot = [&](int kp) {                      // x = pivot block kp -> P^-1 to global (for the tiles) and to LDS (for the chain)
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int i = 16 * ti + q + 4 * e, j = 16 * tj + r;
-                        const bool in = kp * NB + i < m && kp * NB + j < m;
-                        P[i][j] = in ? x[ti][tj][e] : (i == j ? real(1) : real(0));
-                    }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            FLOW_MARK(kp, 5);
-            real* dst = pinv + (size_t)kp * NB * NB;
-            const real mypiv = sweep32::gauss_jordan_32(
-                lane, NB, [&](int i, int j) { return P[i][j]; },
-                [&](int i, int j, real v) {
-                    st_sc1(dst + i * NB + j, v);
-                    P[i][j] = v;
-                });
-            FLOW_MARK(kp, 6);
-            flow_signal(pivflag + kp, lane);
-            FLOW_MARK(kp, 7);
-#pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (k == kp) piv_of[k] = mypiv;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-        };
-        // operands of pivot block d = kb + 1: tiles (kb, d), (d, kb), (d, d) as they are after step kb - 1
-        d4_t xn[2][2];
-        auto request = [&](int kb) {
-            const int d = kb + 1;
-            flow_load_B(xrow + (size_t)(kb * nb + d) * NB * NB, r, q, rb);
-            flow_load_A(xcol + (size_t)(d * nb + kb) * NB * NB, r, q, ca);
-            const real* xs = xdiag + (size_t)d * NB * NB;
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) xn[ti][tj][e] = ld_sc1(xs + (16 * ti + q + 4 * e) * NB + 16 * tj + r);
-        };
-        flow_load_X_in(X, m, 0, 0, r, q, x);
-        bool have = false;
-        if (nb > 1) {                                   // block 1's operands come from the input: in flight under the first sweep
-            flow_load_B_in(X, m, 0, 1, r, q, rb);
-            flow_load_A_in(X, m, 1, 0, r, q, ca);
-            flow_load_X_in(X, m, 1, 1, r, q, xn);
-            have = true;
-        }
-        FLOW_MARK(0, 4);
-        pivot(0);
-        for (int kb = 0; kb + 1 < nb; ++kb) {
-            const int d = kb + 1;
-            FLOW_MARK(d, 0);
-            const int* const fl[3] = {rowflag + kb * nb + d, colflag + d * nb + kb, diagflag + d};
-            if (!have) {
-                flow_wait3(fl, lane, g.err);
-                request(kb);
-            }
-            FLOW_MARK(d, 1);
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int k = 0; k < 8; ++k) pa[ti][k] = P[16 * ti + r][4 * k + q];      // P^-1 of block kb, A layout, from LDS
-#pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                for (int tj = 0; tj < 2; ++tj) x[ti][tj] = xn[ti][tj];
-            flow_update(x, false, false, pa, rb, pb, ca);
-            flow_zero_pad(x, m, d, d, r, q);
-            FLOW_MARK(d, 4);
-            // the NEXT block's operands were published by the tile waves about when this update ran: if their flags are up,
-            // request them now -- the round trip runs under the sweep below; if not, the next iteration waits for them
-            have = false;
-            if (kb + 2 < nb) {
-                const int* const fn[3] = {rowflag + d * nb + d + 1, colflag + (d + 1) * nb + d, diagflag + d + 1};
-                if (flow_all_up(fn, lane)) {
-                    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-                    request(d);
-                    have = true;
-                }
-            }
-            pivot(d);
-        }
-        real logsum = 0;
-        for (int k = 0; k < nb; ++k) {                  // pivot blocks' logs added in block order, as the launch-per-step form
-            real pk = 1;
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk)
-                if (kk == k) pk = piv_of[kk];
-            logsum = (k == 0 ? real(0) : logsum) + wave_sum_la(log(pk));
-        }
-        if (lane == 0) *(l < g.nmain ? g.logdet + l : g.logdet_e + (l - g.nmain)) = logsum;
-        return;
-    }
-
-    // ---- a tile wave: owns tile (bi, bj) for all block steps
-    const int bi = t / nb, bj = t % nb;
-    flow_load_X_in(X, m, bi, bj, r, q, x);
-    for (int kb = 0; kb < nb; ++kb) {
-        // operands from other tiles FIRST: they were published at the end of step kb - 1, while the pivot block of this step
-        // is still being inverted -- their round trip runs under the sweep; only P^-1 is loaded behind its flag
-        FLOW_TMARK(kb, 0);
-        if (bj != kb) {
-            if (bi == kb) {
-                flow_acc_as_B(x, rb);                   // this tile IS the pivot row block's tile of its column
-            } else if (kb == 0) {
-                flow_load_B_in(X, m, kb, bj, r, q, rb);
-            } else {
-                flow_wait(rowflag + kb * nb + bj, g.err);
-                flow_load_B(xrow + (size_t)(kb * nb + bj) * NB * NB, r, q, rb);
-            }
-        }
-        if (bi != kb) {
-            if (kb == 0) {
-                flow_load_A_in(X, m, bi, kb, r, q, ca);
-            } else {
-                flow_wait(colflag + bi * nb + kb, g.err);
-                flow_load_A(xcol + (size_t)(bi * nb + kb) * NB * NB, r, q, ca);
-            }
-        }
-        FLOW_TMARK(kb, 1);
-        flow_wait(pivflag + kb, g.err);
-        FLOW_TMARK(kb, 2);
-        const real* pk = pinv + (size_t)kb * NB * NB;
-        if (bj == kb) flow_load_B(pk, r, q, pb);
-        else flow_load_A(pk, r, q, pa);
-        FLOW_TMARK(kb, 3);
-        flow_update(x, bi == kb, bj == kb, pa, rb, pb, ca);
-        flow_zero_pad(x, m, bi, bj, r, q);
-        FLOW_TMARK(kb, 4);
-        if (kb + 1 < nb) {                              // what the next step reads from this tile
-            if (bi == kb + 1 && bj != kb + 1) {
-                flow_publish(xrow + (size_t)t * NB * NB, x, r, q);
-                flow_signal(rowflag + t, lane);
-            } else if (bj == kb + 1 && bi != kb + 1) {
-                flow_publish(xcol + (size_t)t * NB * NB, x, r, q);
-                flow_signal(colflag + t, lane);
-            }
-        }
-        if (kb + 2 < nb && bi == kb + 2 && bj == kb + 2) {      // the chain's starting value of pivot block kb + 2
-            flow_publish(xdiag + (size_t)bi * NB * NB, x, r, q);
-            flow_signal(diagflag + bi, lane);
-        }
-        FLOW_TMARK(kb, 5);
-    }
-#pragma unroll
-    for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < 2; ++tj)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int gi = bi * NB + 16 * ti + q + 4 * e, gj = bj * NB + 16 * tj + r;
-                if (gi < m && gj < m) Y[(size_t)gi * m + gj] = x[ti][tj][e];
-            }
-}
-
 }  // namespace
 
 // prec 0: float64 storage + arithmetic; 1: float64 storage, float32 MFMA arithmetic; 2: float32 storage + arithmetic
@@ -1331,12 +944,7 @@ extern "C" int svgp_potri_batched(int m, int batch, double* A, const double* lin
 
 extern "C" size_t svgp_spd_inverse_workspace_elems(int m, int batch) {
     if (m >= CHOL_INVERSE_MIN_M) return svgp_potrf_workspace_elems(m, batch) + svgp_potri_workspace_elems(m, batch);
-    // launch-per-step form: pivots + the ping-pong copy; one-launch form: pivot inverses of every step, the unsymmetrised result,
-    // the two publication buffers, the pivot logs and the flags (ints) -- see flow_layout
-    const size_t nb = (size_t)(m + NB - 1) / NB, nt = nb * nb;
-    const size_t steps = (size_t)batch * (2 * NB * NB + (size_t)m * m);
-    const size_t flow = (size_t)batch * (2 * nb * NB * NB + (size_t)m * m + 2 * nt * NB * NB) + ((size_t)batch * (2 * nt + 2 * nb) + 16) / 2 + 64;
-    return steps > flow ? steps : flow;
+    return (size_t)batch * (2 * NB * NB + (size_t)m * m);     // pivots + the ping-pong copy
 }
 
 // The inverse of a symmetric matrix, made exactly symmetric: Y = (X + X^T) / 2 per 32 x 32 tile pair (X == Y allowed: a
@@ -1371,46 +979,10 @@ __global__ __launch_bounds__(256) void k_symmetrize(int m, int nmain, const real
 
 // Fused one-launch-per-block-step sweep (m < SVGP_CHOL_INVERSE_MIN_M) over `nmain` matrices at A plus `nextra` at Ae; work
 // holds svgp_spd_inverse_workspace_elems(m, nmain + nextra) doubles.
-// one-launch form: taken when its grid is far below what the chip keeps resident (every wave must be: 34 KB of LDS per
-// workgroup admit 4 per CU = 1 024), with room for a second such launch on another stream.  SVGP_INVERSE_FLOW=0: never.
-static bool flow_fits(int m, int batch, int* wpm, int* grid) {
-    static const int on = [] { const char* e = getenv("SVGP_INVERSE_FLOW"); return (e && e[0] == '0') ? 0 : 1; }();
-    const int nb = (m + NB - 1) / NB;
-    *wpm = (nb * nb + 1 + 3) / 4;                  // one wave per tile + the chain wave
-    *grid = 8 * *wpm * ((batch + 7) / 8);
-    return on && nb >= 2 && *grid <= 448;
-}
-static int svgp_spd_inverse_flow(int m, int nmain, double* A, double* logdet, int nextra, double* Ae, double* logdet_e,
-                                 double* work, int wpm, int grid, hipStream_t s) {
-    const int batch = nmain + nextra, nb = (m + NB - 1) / NB, nt = nb * nb;
-    const size_t mm = (size_t)m * m;
-    BgjFlowArgs g;
-    g.m = m; g.nb = nb; g.batch = batch; g.nmain = nmain; g.wpm = wpm;
-    g.A = A; g.Ae = Ae; g.logdet = logdet; g.logdet_e = logdet_e;
-    real* p = work;
-    g.Pinv = p; p += (size_t)batch * nb * NB * NB;
-    g.Out = p; g.Oute = p + (size_t)nmain * mm; p += (size_t)batch * mm;
-    g.Xrow = p; p += (size_t)batch * nt * NB * NB;
-    g.Xcol = p; p += (size_t)batch * nt * NB * NB;
-    g.Xdiag = p; p += (size_t)batch * nb * NB * NB;
-    int* f = reinterpret_cast<int*>(p);
-    g.rowflag = f; g.colflag = f + (size_t)batch * nt; g.pivflag = f + (size_t)2 * batch * nt; g.diagflag = g.pivflag + (size_t)batch * nb;
-    g.err = g.diagflag + (size_t)batch * nb;
-    SVGP_CHECK_HIP(hipMemsetAsync(f, 0, ((size_t)batch * (2 * nt + 2 * nb) + 1) * sizeof(int), s));
-    hipLaunchKernelGGL(k_bgj_flow, dim3((unsigned)grid), dim3(256), 0, s, g);
-    SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_symmetrize, dim3(nb, nb, batch), dim3(256), 0, s, m, nmain, g.Out, A, g.Oute, Ae);
-    SVGP_LAUNCH_CHECK();
-    return SVGP_OK;
-}
-
 int svgp_spd_inverse_fused(int m, int nmain, double* A, double* logdet, int nextra, double* Ae, double* logdet_e,
                            double* work, void* stream) {
     const int batch = nmain + nextra, nb = (m + NB - 1) / NB;
     const size_t mm = (size_t)m * m;
-    int wpm, grid;
-    if (flow_fits(m, batch, &wpm, &grid))
-        return svgp_spd_inverse_flow(m, nmain, A, logdet, nextra, Ae, logdet_e, work, wpm, grid, (hipStream_t)stream);
     BgjfArgs g;
     g.m = m; g.batch = batch; g.nmain = nmain; g.Pinv = work; g.logdet = logdet; g.logdet_e = logdet_e;
     real* W = work + (size_t)batch * 2 * NB * NB;

@@ -150,76 +150,3 @@ def test_spd_inverse_residual_on_kernel_like_spectrum(m, jitter):
     assert res(X) <= 10 * res(T) + 1e-12
     assert sw(X) <= 10 * sw(T) + 1e-13
     assert abs(float(logdet[0]) - float(torch.log(lam + jitter).sum())) < 1e-8 * m
-
-
-_FLOW_CASES = [(64, 3), (72, 2), (100, 1), (130, 3), (256, 17), (300, 5), (480, 2)]
-
-
-def _flow_inputs(m, batch):
-    g = torch.Generator(device="cpu").manual_seed(1000 + m)
-    X = torch.randn(batch, m, m + 8, dtype=DT, generator=g)
-    A = X @ X.transpose(1, 2) / m + 0.05 * torch.eye(m, dtype=DT)
-    if batch > 1:      # one kernel-like member (K + 1e-6 I, fast-decaying spectrum): the conditioning the GP block meets
-        Q, _ = torch.linalg.qr(torch.randn(m, m, dtype=DT, generator=g))
-        lam = 50 * torch.exp(-torch.arange(m, dtype=DT) / 8)
-        K = (Q * lam) @ Q.T
-        A[-1] = 0.5 * (K + K.T) + 1e-6 * torch.eye(m, dtype=DT)
-    return A.contiguous()
-
-
-def _flow_run(m, batch):
-    lib = _lib.load_library()
-    inv = _flow_inputs(m, batch).cuda()
-    logdet = torch.full((batch,), float("nan"), dtype=DT, device="cuda")
-    work = torch.full((lib.svgp_spd_inverse_workspace_elems(m, batch),), float("nan"), dtype=DT, device="cuda")
-    _lib.call("svgp_spd_inverse_batched", m, batch, inv.data_ptr(), logdet.data_ptr(), work.data_ptr(),
-              torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
-    return inv.cpu(), logdet.cpu()
-
-
-def test_one_launch_inverse_is_bit_identical_to_the_launch_per_step_form(tmp_path):
-    """The blocked Gauss-Jordan inverse below m = 512 as ONE launch (k_bgj_flow: tiles resident in registers, hand-offs through
-    flagged write-through stores) against the launch-per-step form (SVGP_INVERSE_FLOW=0, run in a child process: the switch is
-    read once per process): same MFMA sequences per quadrant, same sweep -> the same bits, inverse and log det, ragged sizes."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = tmp_path / "steps.pt"
-    code = ("import sys, torch; sys.path.insert(0, %r); from tests import test_gpu_linalg as T; "
-            "torch.save({c: T._flow_run(*c) for c in T._FLOW_CASES}, %r)" % (root, str(out)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SVGP_INVERSE_FLOW="0"), capture_output=True, text=True,
-                       timeout=900, cwd=root)
-    assert r.returncode == 0, r.stderr[-3000:]
-    ref = torch.load(out)
-    for c in _FLOW_CASES:
-        inv, ld = _flow_run(*c)
-        assert torch.equal(inv, ref[c][0]), (c, float((inv - ref[c][0]).abs().max()))
-        assert torch.equal(ld, ref[c][1]), (c, ld, ref[c][1])
-
-
-def test_one_launch_inverse_hand_offs_under_uneven_load():
-    """The hand-off protocol under load: the 256 x 17 inverse 60 times while another stream keeps the chip busy with float64
-    products of varying size (workgroups of the inverse get delayed, L2 lines evicted, consumers L1-warm from the previous
-    call) -- every call must return the bits of the first one.  A lost or stale hand-off would show as a different result
-    (or as the in-kernel time-out's garbage), never as a hang."""
-    m, batch = 256, 17
-    lib = _lib.load_library()
-    A = _flow_inputs(m, batch).cuda()
-    first, first_ld = _flow_run(m, batch)
-    side = torch.cuda.Stream()
-    G = [torch.randn(n, n, dtype=DT, device="cuda") for n in (512, 1536, 3072)]
-    work = torch.full((lib.svgp_spd_inverse_workspace_elems(m, batch),), float("nan"), dtype=DT, device="cuda")
-    logdet = torch.zeros(batch, dtype=DT, device="cuda")
-    for it in range(60):
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                Gk = G[it % 3]
-                Gk @ Gk
-        inv = A.clone()
-        _lib.call("svgp_spd_inverse_batched", m, batch, inv.data_ptr(), logdet.data_ptr(), work.data_ptr(),
-                  torch.cuda.current_stream().cuda_stream)
-        assert torch.equal(inv.cpu(), first), it
-        assert torch.equal(logdet.cpu(), first_ld), it
-    torch.cuda.synchronize()

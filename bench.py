@@ -651,6 +651,11 @@ def sprites_flops(b, L_, m, D=24):
     return nets, gp
 
 
+# --kernel se (the reference's --K_SE, SVGPVAE_model.py:530-544): l_action, sigma_action, l_character, sigma_character -- length
+# scales of the order of the synthetic vectors' distances, so that K_mm is full rank with entries across (0, 1)
+SPRITES_SE = (6.0, 1.0, 6.0, 0.8)
+
+
 def run_sprites(args):
     rank, local_rank, world = dist_env()
     import torch.distributed as dist
@@ -666,7 +671,10 @@ def run_sprites(args):
         comm = RcclComm(0, 1, RcclComm.unique_id())
     b, frames, L_, La, Lc, n_act, m = 500, 50, 64, 8, 16, 72, args.m or 800
     ip, table, img, ids, eps = sprites_problem(rank, b, L_, La, Lc, n_act, m)
-    svgp = S.spritesSVGP(False, False, ip, 'main', 0.01, 50000, La, table, Lc, L_, K_obj_normalize=True)
+    k_se = args.kernel == "se"
+    svgp = S.spritesSVGP(False, False, ip, 'main', 0.01, 50000, La, table, Lc, L_, K_obj_normalize=True, K_SE=k_se)
+    if k_se:
+        svgp.se = torch.tensor(SPRITES_SE, dtype=torch.float64)
     f32 = args.precision == "f32"
     # f32: the networks in float32 (the reference's dtype, VAE_utils.py:277); the GP block stays float64 unless --gemm-f32
     # asks otherwise (float32 products lose parity / stability at m = 800: tests/test_gpu_f32.py)
@@ -737,7 +745,8 @@ def run_sprites(args):
             "repeats": args.repeats, "block_ms": [round(x * 1e3, 3) for x in blocks], "timing": "median block",
             "config": {"workload": f"BASELINE configs[3] shape: SPRITES SVGPVAE_Hensman + GPLVM, {b} frames per GPU "
                                    f"(10 characters x 50), L=64, L_action=8, L_character=16, m={m}, jitter 0.01, "
-                                   f"cosine-normalised linear x linear kernel, GECO, gradient clip 1e6",
+                                   + ("SE x SE kernel (--K_SE; full-rank K_mm)" if k_se else "cosine-normalised linear x linear kernel")
+                                   + ", GECO, gradient clip 1e6",
                        "global_batch": b * world, "rows_per_gpu": b, "parallelism": f"dp{world}",
                        "rccl_ranks": None if comm is None else comm.world_size,
                        "exchange": None if comm is None else (
@@ -784,14 +793,14 @@ def run_sprites(args):
             line["collectives_us"] = dict(zip(names, coll_us))
             line["collectives_us_total"] = round(sum(coll_us), 1)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_sprites(gpu_elbo, m)
+            line["cpu_baseline"] = cpu_baseline_sprites(gpu_elbo, m, k_se)
             line["elbo_rel_err_gpu_vs_oracle"] = line["cpu_baseline"].pop("elbo_rel_err_gpu_vs_oracle")
         emit(line)
     if multi:
         dist.destroy_process_group()
 
 
-def cpu_worker_sprites(m):
+def cpu_worker_sprites(m, k_se=False):
     """CHILD: ONE efficient-formulation float64 step of the oracle (torch-CPU autograd) on the same 500-frame batch: the
     literal form's (b,m,m) tensors are 2.6 GB per channel x 64 channels."""
     from oracle import sprites_oracle as SO
@@ -800,21 +809,21 @@ def cpu_worker_sprites(m):
     ip, table, img, ids, eps = sprites_problem(0, b, L_, La, Lc, n_act, m)
     params = {k: torch.as_tensor(np.asarray(v), dtype=DT) for k, v in SO.glorot_init(L_, Lc, 0).items()}
     gp = dict(inducing_index_points=torch.tensor(ip, dtype=DT), GPLVM_action=torch.tensor(table, dtype=DT),
-              l_action=torch.tensor(1.0, dtype=DT), sigma_action=torch.tensor(1.0, dtype=DT),
-              l_character=torch.tensor(1.0, dtype=DT), sigma_character=torch.tensor(1.0, dtype=DT))
+              **{k: torch.tensor(v if k_se else 1.0, dtype=DT)
+                 for k, v in zip(("l_action", "sigma_action", "l_character", "sigma_character"), SPRITES_SE)})
     seg, rep = SO.aux_data_sprites_utils(b, frames, frames)
     kw = dict(beta=0.001, C_ma=torch.tensor(0.0, dtype=DT), lagrange_mult=torch.tensor(1.0, dtype=DT), alpha=0.0,
               kappa=math.sqrt(0.0075), L=L_, L_action=La, jitter=0.01, N_train=50000.0, segment_ids=seg, repeats=rep,
-              clipping_qs=False, GECO=True, K_obj_normalize=True, K_SE=False, clip_grad=1e6, titsias=False)
+              clipping_qs=False, GECO=True, K_obj_normalize=True, K_SE=k_se, clip_grad=1e6, titsias=False)
     t0 = time.perf_counter()
     want, _ = SO.loss_and_grads(params, gp, (img, ids.long()), eps, formulation="efficient", **kw)
     el = time.perf_counter() - t0
     print(json.dumps(dict(seconds=el, elbo=float(want[0]), threads=torch.get_num_threads(), rows=b)), flush=True)
 
 
-def cpu_baseline_sprites(gpu_elbo, m):
+def cpu_baseline_sprites(gpu_elbo, m, k_se=False):
     nt = host_threads(32)
-    r = cpu_worker_call("sprites800", nt, 0.0, ("--m", str(m)))
+    r = cpu_worker_call("sprites800", nt, 0.0, ("--m", str(m), "--kernel", "se" if k_se else "linear"))
     rel = abs(gpu_elbo - r["elbo"]) / abs(r["elbo"])
     assert rel < 1e-3, f"ELBO parity failed: GPU {gpu_elbo} oracle {r['elbo']}"
     return dict(value=1.0 / r["seconds"], unit="steps/s", cores=nt, host_cores=os.cpu_count(), threads=nt, kind="port",
@@ -1038,6 +1047,9 @@ def main():
     ap.add_argument("--gemm-f32", type=int, choices=[0, 1, 2], default=0,
                     help="sprites800: cfg.gemm_f32 of the large-m GP block (1 = every product on the float32 MFMA, "
                          "2 = the statistics products only); both lose stability at m = 800 (DESIGN.md)")
+    ap.add_argument("--kernel", choices=["linear", "se"], default="linear",
+                    help="sprites800: linear = cosine-normalised linear x linear kernels (the reference's default); se = the "
+                         "reference's --K_SE (SE x SE, SVGPVAE_model.py:530-544)")
     ap.add_argument("--rows", type=int, default=None, help="cfg5: rows per GPU (default 131072)")
     ap.add_argument("--cpu-worker", choices=["cfg2", "cfg3", "sprites800", "cfg5"], default=None,
                     help="internal: run one CPU-baseline leg in this (child) process and print its JSON")
@@ -1048,7 +1060,7 @@ def main():
         if args.cpu_worker in ("cfg2", "cfg3"):
             cpu_worker_mnist(args.cpu_worker == "cfg3", args.budget, args.probe_steps)
         elif args.cpu_worker == "sprites800":
-            cpu_worker_sprites(args.m or 800)
+            cpu_worker_sprites(args.m or 800, args.kernel == "se")
         else:
             cpu_worker_cfg5(args.m or 2048, args.budget)
         return

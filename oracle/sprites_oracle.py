@@ -119,6 +119,39 @@ def repr_nn(p, images):
     return h.mean(dim=(1, 2))
 
 
+def pretrain_repr_nn_trajectory(params, frames, char_ids, *, nr_epochs, lr, batch_size, n_classes=1000, seed=0):
+    """Pre-training of the representation network (SPRITES_experiment.py:139-151,214-224,325-357; SPRITES_utils.py:335-368):
+    per batch loss = mean sparse softmax cross-entropy of Dense(n_classes)(repr_nn(frames)) against the character ids, TF1 Adam
+    (ONE optimiser: step counter t = number of updates so far) on the representation network + the classification layer
+    (Keras Dense default: glorot-uniform kernel, zero bias).  Un-shuffled batches (the in-batch shuffle of :346-351 permutes
+    the rows of a mean), incomplete last batch dropped as the product does.  Returns (per-epoch (mean loss, accuracy),
+    final repr_* parameters, dense kernel, dense bias, first moments, second moments of the repr_* parameters)."""
+    names = [k for k in params if k.startswith("repr_")]
+    p = {k: params[k].clone().requires_grad_(True) for k in names}
+    Lc = p["repr_c3_b"].shape[0]
+    lim = math.sqrt(6.0 / (Lc + n_classes))
+    p["dense_w"] = torch.tensor(np.random.RandomState(seed).uniform(-lim, lim, (Lc, n_classes)), dtype=DT).requires_grad_(True)
+    p["dense_b"] = torch.zeros(n_classes, dtype=DT).requires_grad_(True)
+    ms = {k: torch.zeros_like(v) for k, v in p.items()}
+    vs = {k: torch.zeros_like(v) for k, v in p.items()}
+    n, t, hist = frames.shape[0], 0, []
+    for _ in range(nr_epochs):
+        tot, correct, seen, nb = 0.0, 0, 0, 0
+        for lo in range(0, n - batch_size + 1, batch_size):
+            x, lab = frames[lo:lo + batch_size], char_ids[lo:lo + batch_size].long()
+            logits = repr_nn(p, x) @ p["dense_w"] + p["dense_b"]
+            loss = F.cross_entropy(logits, lab)
+            grads = dict(zip(p, torch.autograd.grad(loss, list(p.values()))))
+            t += 1
+            with torch.no_grad():
+                O.adam_tf1_step(p, grads, ms, vs, t, lr)
+            tot += float(loss); nb += 1; seen += batch_size
+            correct += int((logits.argmax(1) == lab).sum())
+        hist.append((tot / max(nb, 1), correct / max(seen, 1)))
+    out = {k: v.detach() for k, v in p.items()}
+    return hist, {k: out[k] for k in names}, out["dense_w"], out["dense_b"], {k: ms[k] for k in names}, {k: vs[k] for k in names}
+
+
 def aux_data_sprites_utils(batch_size, N, repeats):
     """SPRITES_utils.py:317-332."""
     n_char = int(batch_size / N)

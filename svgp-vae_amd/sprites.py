@@ -951,19 +951,26 @@ def pretrain_repr_NN(engine, frames, char_IDs, *, nr_epochs, lr, batch_size, n_c
     K_pretrain + 1, and with `yes_joint` the m / v slots of the representation network carry over.  Both are reproduced:
     the engine's Adam step counter is advanced by the number of pre-training updates, and (carry_slots, = not
     `yes_fixed`) the repr_* slices of the moments are copied into the engine's."""
-    if engine.f32:
-        raise NotImplementedError("pretrain_repr_NN runs on a float64-network engine (net_dtype=torch.float64)")
     dev, Lc, s = engine.dev, engine.Lc, engine.stream.cuda_stream
     f64 = dict(dtype=_F64, device=dev)
+    f32, sfx = engine.f32, engine.sfx
+    nd = dict(dtype=engine.ndt, device=dev)
     names = [k for k in engine.shapes if k.startswith("repr_")]
     sizes = [int(np.prod(engine.shapes[k])) for k in names]
     n_rep = sum(sizes)
     theta = torch.zeros(n_rep + Lc * n_classes + n_classes, **f64)
     grad, am, av = torch.zeros_like(theta), torch.zeros_like(theta), torch.zeros_like(theta)
+    # float32 networks (the reference's SPRITES dtype, VAE_utils.py:277): the representation network runs on the float32
+    # convolution entry points from a float32 copy of its parameters, refreshed from the float64 master vector before every
+    # step (as the joint step does); its float32 gradients are cast into the float64 gradient vector; the dense layer, the
+    # cross-entropy and TF1 Adam stay float64
+    theta_n = torch.zeros(n_rep, **nd) if f32 else theta
+    grad_n = torch.zeros(n_rep, **nd) if f32 else grad
     views, gviews, off = {}, {}, 0
     for k, n in zip(names, sizes):
-        views[k] = theta[off:off + n].view(engine.shapes[k]); gviews[k] = grad[off:off + n].view(engine.shapes[k])
+        views[k] = theta_n[off:off + n].view(engine.shapes[k]); gviews[k] = grad_n[off:off + n].view(engine.shapes[k])
         off += n
+    master = {k: theta[o:o + n].view(engine.shapes[k]) for k, n, o in zip(names, sizes, np.cumsum([0] + sizes[:-1]))}
     W, gW = theta[off:off + Lc * n_classes].view(Lc, n_classes), grad[off:off + Lc * n_classes].view(Lc, n_classes)
     bC, gb = theta[off + Lc * n_classes:], grad[off + Lc * n_classes:]
     rs = np.random.RandomState(seed)
@@ -972,7 +979,7 @@ def pretrain_repr_NN(engine, frames, char_IDs, *, nr_epochs, lr, batch_size, n_c
     engine.stream.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(engine.stream):
         for k in names:
-            views[k].copy_(engine.params[k])
+            master[k].copy_(engine.params[k])
         W.copy_(torch.tensor(rs.uniform(-lim, lim, (Lc, n_classes)), **f64))
         state[STATE["LR"]] = lr
     n = frames.shape[0]
@@ -983,15 +990,21 @@ def pretrain_repr_NN(engine, frames, char_IDs, *, nr_epochs, lr, batch_size, n_c
         for lo in range(0, n - batch_size + 1, batch_size):
             b = batch_size
             with torch.cuda.stream(engine.stream):
-                x0 = frames[lo:lo + b].contiguous()
+                if f32:
+                    call("svgp_cast_f64_f32", n_rep, theta.data_ptr(), theta_n.data_ptr(), s)
+                x0 = frames[lo:lo + b].to(engine.ndt).contiguous()
                 lab = char_IDs[lo:lo + b].to(_F64).contiguous()
                 r, x = [], x0
                 for i, lay in enumerate(engine.rep, 1):
-                    out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **f64)
+                    out = torch.empty(b, lay.Ho, lay.Ho, lay.Co, **nd)
                     lay.forward(x, views[f"repr_c{i}_w"], views[f"repr_c{i}_b"], out, s)
                     r.append(out); x = out
-                emb = torch.empty(b, Lc, **f64)
-                call("svgp_avgpool_fwd", b, 64, Lc, x.data_ptr(), emb.data_ptr(), s)
+                emb_n = torch.empty(b, Lc, **nd)
+                call("svgp_avgpool_fwd" + sfx, b, 64, Lc, x.data_ptr(), emb_n.data_ptr(), s)
+                emb = emb_n
+                if f32:
+                    emb = torch.empty(b, Lc, **f64)
+                    call("svgp_cast_f32_f64", b * Lc, emb_n.data_ptr(), emb.data_ptr(), s)
                 logits = torch.empty(b, n_classes, **f64)
                 engine._gemm(0, 0, b, n_classes, Lc, 1.0, emb, Lc, W, n_classes, 0.0, logits, n_classes)
                 call("svgp_bias_add", b, n_classes, bC.data_ptr(), logits.data_ptr(), s)
@@ -1002,12 +1015,18 @@ def pretrain_repr_NN(engine, frames, char_IDs, *, nr_epochs, lr, batch_size, n_c
                 engine._gemm(1, 0, 1, n_classes, b, 1.0, ones, 1, dlog, n_classes, 0.0, gb, n_classes)       # column sums
                 demb = torch.empty(b, Lc, **f64)
                 engine._gemm(0, 1, b, Lc, n_classes, 1.0, dlog, n_classes, W, n_classes, 0.0, demb, Lc)      # dlogits W^T
-                dx = torch.empty(b, 8, 8, Lc, **f64)
-                call("svgp_avgpool_bwd", b, 64, Lc, demb.data_ptr(), dx.data_ptr(), s)
+                demb_n = demb
+                if f32:
+                    demb_n = torch.empty(b, Lc, **nd)
+                    call("svgp_cast_f64_f32", b * Lc, demb.data_ptr(), demb_n.data_ptr(), s)
+                dx = torch.empty(b, 8, 8, Lc, **nd)
+                call("svgp_avgpool_bwd" + sfx, b, 64, Lc, demb_n.data_ptr(), dx.data_ptr(), s)
                 for i in range(3, 0, -1):
                     xin = r[i - 2] if i > 1 else x0
                     dx = engine.rep[i - 1].backward(xin, views[f"repr_c{i}_w"], r[i - 1], dx, gviews[f"repr_c{i}_w"],
                                                     gviews[f"repr_c{i}_b"], engine.scratch, s, need_dx=i > 1, nwg=engine.nwg)
+                if f32:
+                    call("svgp_cast_f32_f64", n_rep, grad_n.data_ptr(), grad.data_ptr(), s)
                 call("svgp_adam_tf1_step", theta.numel(), theta.data_ptr(), grad.data_ptr(), am.data_ptr(), av.data_ptr(),
                      state.data_ptr(), 0.9, 0.999, 1e-8, s)
                 state[STATE["ADAM_T"]] += 1.0
@@ -1022,7 +1041,7 @@ def pretrain_repr_NN(engine, frames, char_IDs, *, nr_epochs, lr, batch_size, n_c
     with torch.cuda.stream(engine.stream):
         off_p = 0
         for k, n in zip(names, sizes):
-            engine.params[k].copy_(views[k])
+            engine.params[k].copy_(master[k])
             if carry_slots:
                 off_e = 0
                 for ke, se in engine.shapes.items():

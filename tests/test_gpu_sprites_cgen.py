@@ -250,3 +250,50 @@ def test_reference_signature_helpers_match_oracle():
     assert ce.shape == (n, L) and _rel(ce, O.gauss_cross_entropy(mu1, var1, mu2, var2)) < 1e-14
     with pytest.raises(Exception, match="no CPU execution path"):
         gauss_cross_entropy(mu1, var1, mu2, var2)
+
+
+@pytest.mark.parametrize("net_dtype", [torch.float64, torch.float32])
+def test_repr_nn_pretraining_matches_the_oracle_trajectory(net_dtype):
+    """`pretrain_repr_NN` (SPRITES_experiment.py:139-151,325-357; SPRITES_utils.py:335-368) against the oracle's restatement
+    (torch-CPU float64 autograd + TF1 Adam), float64 networks and the reference's float32 (VAE_utils.py:277; VERDICT r4 item 6:
+    the benchmarked engine could not run the reference's pre-training phase): 2 epochs x 3 batches on 36 frames of 6
+    characters -- per-epoch mean loss and accuracy, the updated representation-network parameters, their Adam moments carried
+    into the engine, and the shared step counter.  float64: 1e-9.  float32 networks: the forward activations are rounded to
+    float32, so parameters after 6 Adam steps of size lr are compared at 2e-4 of their largest entry (Adam's update is
+    lr * m / sqrt(v): a relative gradient error e moves a 6-step trajectory by ~ 6 lr e), losses at 1e-5."""
+    from oracle import sprites_oracle as SO
+    from svgp_vae_amd import sprites as S
+    L, La, Lc, m, n_act, b = 4, 8, 16, 6, 5, 12
+    g = torch.Generator().manual_seed(11)
+    params = {k: torch.tensor(v, dtype=DT) for k, v in SO.glorot_init(L, Lc, 5).items()}
+    for k in params:
+        if k.startswith("repr_") and k.endswith("_b"):
+            params[k] = 0.05 * torch.randn(*params[k].shape, dtype=DT, generator=g)
+    n, n_classes, lr = 36, 6, 5e-3
+    chars = torch.arange(n) // 6
+    base = torch.rand(6, 1, 8, 8, 3, dtype=DT, generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    frames = (0.7 * base + 0.3 * torch.rand(6, 6, 64, 64, 3, dtype=DT, generator=g)).reshape(n, 64, 64, 3)
+    hist_o, p_o, W_o, b_o, m_o, v_o = SO.pretrain_repr_nn_trajectory(params, frames, chars, nr_epochs=2, lr=lr, batch_size=b,
+                                                                     n_classes=n_classes, seed=3)
+    svgp = S.spritesSVGP(False, False, (torch.randn(m, La + Lc, dtype=DT, generator=g) * 1.5).numpy(), 'main', 0.01, 100.0, La,
+                         (torch.randn(n_act, La, dtype=DT, generator=g) * 1.5).numpy(), Lc, L, K_obj_normalize=True)
+    eng = S.SpritesStepEngine(S.spritesVAE(L), S.sprites_representation_network(Lc), svgp, b_max=b, seg_len=6,
+                              params=dict(params), net_dtype=net_dtype)
+    hist = S.pretrain_repr_NN(eng, frames.to(eng.dev), chars.to(eng.dev), nr_epochs=2, lr=lr, batch_size=b, n_classes=n_classes,
+                              seed=3, log=None, carry_slots=True)
+    f32 = net_dtype == torch.float32
+    tl, tp, tm = (1e-5, 2e-4, 2e-3) if f32 else (1e-9, 1e-9, 1e-8)
+    assert eng.scalars()["adam_t"] == 6.0
+    for (ep, loss, acc), (loss_o, acc_o) in zip(hist, hist_o):
+        assert abs(loss - loss_o) < tl * abs(loss_o), (ep, loss, loss_o)
+        assert acc == acc_o, (ep, acc, acc_o)
+    off = 0
+    for k, shp in eng.shapes.items():
+        cnt = int(np.prod(shp))
+        if k.startswith("repr_"):
+            assert _rel(eng.params[k], p_o[k]) < tp, (k, _rel(eng.params[k], p_o[k]))
+            assert _rel(eng.adam_m[off:off + cnt], m_o[k].reshape(-1)) < tm, k
+            assert _rel(eng.adam_v[off:off + cnt], v_o[k].reshape(-1)) < tm, k
+        else:
+            assert torch.equal(eng.params[k].cpu(), params[k]) if k in params else True
+        off += cnt

@@ -271,3 +271,31 @@ def test_staged_w_form_matches_autograd_and_the_lds_staging():
         Kb = Kb + SG.gp_factor_bwd_w(K, v[sl], fwin, B2f[sl], SWf[sl], udf[sl], tdf[sl], loc_all if w0 == 0 else zero, gT, c, N,
                                      48.0)["Kbar"]
     assert float((sym(Kb) - sym(man[0])).abs().max() / sym(man[0]).abs().max()) < 1e-10
+
+
+def test_repr_nn_pretraining_oracle_first_step_is_a_sign_step_and_learns():
+    """oracle.sprites_oracle.pretrain_repr_nn_trajectory (SPRITES_experiment.py:325-357): TF1 Adam's FIRST update is
+    lr * sign(gradient) for every parameter (m / sqrt(v) = +-1 and lr_1 = lr sqrt(1 - b2) / (1 - b1) undo each other), checked on
+    the dense bias whose gradient is softmax - one-hot averaged over the batch; a few epochs on separable characters reduce the
+    loss."""
+    import torch.nn.functional as F
+    from oracle import sprites_oracle as SO
+    DT = torch.float64
+    g = torch.Generator().manual_seed(0)
+    Lc, ncls, n = 16, 4, 16
+    params = {k: torch.tensor(v, dtype=DT) for k, v in SO.glorot_init(4, Lc, 1).items()}
+    chars = torch.arange(n) // 4
+    base = torch.rand(4, 1, 8, 8, 3, dtype=DT, generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    frames = (0.8 * base + 0.2 * torch.rand(4, 4, 64, 64, 3, dtype=DT, generator=g)).reshape(n, 64, 64, 3)
+    lr = 1e-2
+    hist, p1, W1, b1, _, _ = SO.pretrain_repr_nn_trajectory(params, frames, chars, nr_epochs=1, lr=lr, batch_size=n, n_classes=ncls, seed=2)
+    import math
+    import numpy as np
+    lim = math.sqrt(6.0 / (Lc + ncls))
+    W0 = torch.tensor(np.random.RandomState(2).uniform(-lim, lim, (Lc, ncls)), dtype=DT)
+    logits = SO.repr_nn(params, frames) @ W0
+    gb = (F.softmax(logits, 1) - F.one_hot(chars, ncls).to(DT)).mean(0)
+    assert torch.allclose(b1, -lr * torch.sign(gb), rtol=0, atol=1e-4 * lr)      # (eps = 1e-8 beside sqrt(v) ~ 1e-3)
+    assert abs(hist[0][0] - float(F.cross_entropy(logits, chars))) < 1e-12
+    hist2 = SO.pretrain_repr_nn_trajectory(params, frames, chars, nr_epochs=25, lr=lr, batch_size=8, n_classes=ncls, seed=2)[0]
+    assert hist2[-1][0] < 0.7 * hist2[0][0] and hist2[-1][1] >= hist2[0][1]

@@ -199,7 +199,10 @@ def run_experiment_sprites_SVGPVAE(args, dict_=None):
         mu, var, aux = torch.cat(mu), torch.cat(var), torch.cat(aux)
         mean_terms, var_terms = S.precompute_GP_params_SVGPVAE(mu, var, aux, SVGP_, engine=eng)
         K_mm, _, _ = eng.kernel_matrices(aux[:1])
-        K_mm_inv = torch.linalg.inv(K_mm)                                            # :178, no jitter; m x m host-side glue
+        # :178 `tf.linalg.inv(K_mm)` WITHOUT jitter: with the linear kernels K_mm has rank <= L_action * L_character < m, and the
+        # reference's LU with partial pivoting returns a (huge but finite) matrix where a Cholesky / no-pivot elimination -- the
+        # library's SPD inverse -- has no answer; so this one m x m inverse per evaluation stays on rocSOLVER's LU (torch.linalg.inv)
+        K_mm_inv = torch.linalg.inv(K_mm)
         cg = []
         for lo in range(0, N_test - bt + 1, bt):
             _, _, loss = S.predict_SVGPVAE_sprites_test_character(

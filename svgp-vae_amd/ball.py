@@ -103,9 +103,16 @@ class VideoBatchSource:
         self.dev = torch.device(device)
         t = torch.arange(tmax, dtype=_F64)
         K = torch.exp(-0.5 / (lt ** 2) * (t[:, None] - t[None, :]) ** 2) + 0.00001 * torch.eye(tmax, dtype=_F64)
-        self.chol_K = torch.linalg.cholesky(K).to(self.dev)
+        # tf.linalg.cholesky (utils.py:170) on the library's own factorisation (svgp_potrf_batched: lower factor in place)
+        lib = _lib.load_library()
+        Kd = K.to(self.dev).contiguous()
+        ld = torch.empty(1, dtype=_F64, device=self.dev)
+        work = torch.empty(max(int(lib.svgp_potrf_workspace_elems(tmax, 1)), 1), dtype=_F64, device=self.dev)
+        call("svgp_potrf_batched", tmax, 1, Kd.data_ptr(), tmax, tmax * tmax, ld.data_ptr(), work.data_ptr(),
+             torch.cuda.current_stream(self.dev).cuda_stream)
+        torch.cuda.current_stream(self.dev).synchronize()
+        self.chol_K = Kd
         self.gen = torch.Generator(device=self.dev).manual_seed(seed)
-        _lib.load_library()
 
     def __call__(self, stream=None):
         ran_Z = torch.randn(self.tmax, 2 * self.batch, dtype=_F64, device=self.dev, generator=self.gen)

@@ -164,6 +164,7 @@ struct Side {
     hipEvent_t fork = nullptr, done[2] = {nullptr, nullptr};
     bool open[2] = {false, false};
     std::set<const void*> early_ws;
+    std::set<const void*> konly_ws;      // workspaces whose channel-independent factor block was issued by phase 0 on branch 1
     std::mutex mu;
 };
 std::mutex g_side_mu;
@@ -262,6 +263,8 @@ int side_join(Side* sd, int k, hipStream_t main) {
 }
 void side_mark_early(Side* sd, const void* ws) { std::lock_guard<std::mutex> lk(sd->mu); sd->early_ws.insert(ws); }
 bool side_take_early(Side* sd, const void* ws) { std::lock_guard<std::mutex> lk(sd->mu); return sd->early_ws.erase(ws) > 0; }
+void side_mark_konly(Side* sd, const void* ws) { std::lock_guard<std::mutex> lk(sd->mu); sd->konly_ws.insert(ws); }
+bool side_take_konly(Side* sd, const void* ws) { std::lock_guard<std::mutex> lk(sd->mu); return sd->konly_ws.erase(ws) > 0; }
 
 }  // namespace
 
@@ -285,6 +288,10 @@ int svgp_side_branch_join(void* main_stream, int k) {
 }
 
 namespace {
+bool konly_on() {
+    static const int on = [] { const char* e = getenv("SVGP_KONLY_BRANCH"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
 // `defer`: the caller issues all four phases back to back on one stream (svgp_mnist_train_step), so a
 // branch forked in one phase may be joined in a later one; otherwise every phase joins before returning
 // (each phase may be captured into its own graph, with a collective in between).
@@ -319,10 +326,25 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
     switch (phase) {
     case 0:
         RUN(svgp_mnist_encoder_kernel_matrix_fwd(c, theta, images, aux, ws, stream));   // one launch for the two
+        // 64 < m < 512, phases issued back to back (round 5): everything of the forward factor stage that is a function of the
+        // KERNEL MATRICES alone -- (K + jI)^-1 and its log det, Kn Ki, q, W = (Kn Ki) K, P^T = K Ki: one single-matrix blocked inverse
+        // (a chain of 8 block steps, as long as the channel batch's) and three products -- goes to side branch 1 now, beside the
+        // forward statistics and the channel inverses, instead of behind them on the caller's stream.  Joined in phase 1 where
+        // u = Ki mu needs it.  SVGP_KONLY_BRANCH=0: the in-line order.
+        if (fork1 && defer && c->m < SVGP_CHOL_INVERSE_MIN_M && konly_on()) {
+            RUN(side_fork(sd, 1, ms));
+            RUN(svgp_gp_factor_fwd_part(c, ws, (void*)sd->s[1], 5));
+            side_mark_konly(sd, ws);
+        }
         RUN(svgp_gp_stats_fwd(c, ws, stream));
         if (c->titsias) RUN(svgp_gp_titsias_stats(c, ws, stream));
         break;
     case 1:
+        if (large && side_take_konly(sd, ws)) {                // the channel block; then what needs the branch's (K + jI)^-1 too
+            RUN(svgp_gp_factor_fwd_part(c, ws, stream, 6));
+            RUN(side_join(sd, 1, ms));
+            RUN(svgp_gp_factor_fwd_part(c, ws, stream, 7));
+        } else
         RUN(svgp_gp_factor_fwd_defer_aji(c, ws, stream));      // m <= 64: (A_hat + jI)^-1 finishes inside the row-stage launch
         // m > 64: the tail of the stage and the early half of the REVERSE factor stage (no reverse statistic needed; phase 2 then
         // runs the late half only) go to the side stream.  The branch is FORKED here but ISSUED behind the row stage: its ~25

@@ -43,6 +43,8 @@ int svgp_side_branch_fork(void* main_stream, void** side_stream_out, int k = 1);
 int svgp_potri_batched_wide(int m, int batch, double* A, const double* potrf_work, double* work, void* stream);
 int svgp_potrf_batched_band(int m, int batch, double* A, int lda, long long strideA, double* logdet, double* work, void* stream);
 int svgp_side_branch_join(void* main_stream, int k = 1);
+// gp_kernels.hip: parts 5 / 6 / 7 of the large-m forward factor stage (see gp_large.hip svgp_big_factor_fwd)
+int svgp_gp_factor_fwd_part(const svgp_mnist_cfg* c, double* ws, void* stream, int part);
 int svgp_mnist_step_phase_deferred(const svgp_mnist_cfg* c, int phase, double* theta, const double* images,
                                    const double* aux, const double* eps, double* ws, double* state, double* adam_m,
                                    double* adam_v, void* stream);

@@ -1377,6 +1377,15 @@ extern "C" int svgp_gp_factor_fwd_aji_tail(const svgp_mnist_cfg* c, double* ws, 
                  "for m <= %d the deferred inverse rides in svgp_gp_posterior_fwd_with_aji / svgp_gp_stats_bwd_with_aji", SVGP_M_MAX);
     return svgp_big_factor_fwd(c, wl, ws, stream, 0, c->L, 2);
 }
+// internal (api.hip): one part of the large-m forward factor stage (gp_large.hip svgp_big_factor_fwd: 5 = the channel-independent
+// block, 6 = the channel block up to mu, 7 = u and the KL terms)
+int svgp_gp_factor_fwd_part(const svgp_mnist_cfg* c, double* ws, void* stream, int part) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX && c->m < SVGP_CHOL_INVERSE_MIN_M && part >= 5 && part <= 7, SVGP_ERR_UNSUPPORTED,
+                 "the split forward factor stage exists for %d < m < %d", SVGP_M_MAX, SVGP_CHOL_INVERSE_MIN_M);
+    return svgp_big_factor_fwd(c, wl, ws, stream, 0, c->L, part);
+}
 // channel windows of the factor stages (large-m path): see svgp_big_factor_fwd
 extern "C" int svgp_gp_factor_fwd_channels(const svgp_mnist_cfg* c, int l0, int nl, double* ws, void* stream) {
     GET_LAYOUTS();

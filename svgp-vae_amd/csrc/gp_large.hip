@@ -512,13 +512,32 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     real *t = ws + wl.t + ov, *mu = ws + wl.mu_hat + ov, *u = ws + wl.u + ov, *v = ws + wl.v + ov, *Kn = ws + wl.Kn;
     real* klp = ws + wl.fb_part;                 // (L, KL_NCH, 2) trace partials (fb_part is free until the reverse factor stage)
     if (part == 2) goto aji_tail;
-    hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, cc, c->jitter, K, ws + wl.S + om, 0LL, Si);
-    SVGP_LAUNCH_CHECK();
-    // K_mm inverse + log det (SVGPVAE_model.py:239,270,273) next to the channel matrices (:331)
-    hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm)), dim3(256), 0, st, m, 1, real(0), c->jitter, K, (const real*)nullptr,
-                       0LL, Ki);
-    SVGP_LAUNCH_CHECK();
-    if (m < SVGP_CHOL_INVERSE_MIN_M) {
+    {
+    // part 5 = the CHANNEL-INDEPENDENT block alone -- (K + jI)^-1 and its log det, Kn Ki, q, W, P^T: functions of the kernel
+    // matrices only, not of the encoder's output -- which the training step issues on a side branch as soon as the kernel
+    // matrices exist, beside the encoder's tail, the forward statistics and the channel inverses (api.hip, comm.hip); part 6 = the
+    // channel block up to mu (Sigma^-1, t, G, A_hat); part 7 = what needs both (u = Ki mu, the KL terms).  1 = 5 + 6 + 7 in one
+    // call, with the (K + jI) inverse riding in the channel matrices' launches.  Same operations on the same values either way.
+    const bool split = part == 5 || part == 6 || part == 7;
+    SVGP_REQUIRE(!split || m < SVGP_CHOL_INVERSE_MIN_M, SVGP_ERR_INVALID, "the split forward factor stage exists for m < %d",
+                 SVGP_CHOL_INVERSE_MIN_M);
+    const bool do_k = !split || part == 5, do_sig = !split || part == 6, do_kl = !split || part == 7;
+    // the blocked inverse's workspace is (pivots | ping-pong copy) per matrix: the channel batch takes the head, (K + jI) the tail
+    real* inv_k = s.inv + (size_t)c->L * (2 * 32 * 32 + (size_t)mm);
+    if (do_sig) {
+        hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm * L)), dim3(256), 0, st, m, L, cc, c->jitter, K, ws + wl.S + om, 0LL, Si);
+        SVGP_LAUNCH_CHECK();
+    }
+    if (do_k) {
+        // K_mm inverse + log det (SVGPVAE_model.py:239,270,273) next to the channel matrices (:331)
+        hipLaunchKernelGGL(k_big_add_diag, dim3(nblk(mm)), dim3(256), 0, st, m, 1, real(0), c->jitter, K, (const real*)nullptr,
+                           0LL, Ki);
+        SVGP_LAUNCH_CHECK();
+    }
+    if (split) {
+        if (part == 5) RUNC(svgp_spd_inverse_fused(m, 1, Ki, ws + wl.ldK, 0, nullptr, nullptr, inv_k, stream));
+        if (part == 6) RUNC(svgp_spd_inverse_fused(m, L, Si, s.ldtmp, 0, nullptr, nullptr, s.inv, stream));
+    } else if (m < SVGP_CHOL_INVERSE_MIN_M) {
         RUNC(svgp_spd_inverse_fused(m, L, Si, s.ldtmp, 1, Ki, ws + wl.ldK, s.inv, stream));
     } else if (Ki == Si + (size_t)L * mm) {
         // one batch of L + 1: Ki sits right behind Si in the workspace (api.hip); its log det is the last entry
@@ -528,27 +547,34 @@ int svgp_big_factor_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
         RUNC(svgp_spd_inverse_batched(m, 1, Ki, ws + wl.ldK, s.inv, stream));
         RUNC(svgp_spd_inverse_batched(m, L, Si, s.ldtmp, s.inv, stream));
     }
-    GEMV(1.0, Si, mm, v, t, L);                                                                  // t = Si v
-    GEMM(0, 1, m, m, m, 1.0, Si, m, mm, K, m, 0, 0.0, G, m, mm, L);                              // G = Si K   (K = K^T read as [j][k])
-    {   // A = K G = K Si K, and A + jI beside it as a second output (the input of the tail's inverse).  A / B in one run at m = 800:
-        // 18.15 ms per step against 18.26 with a copy pass in front of the tail's inverse -- the product gets 240 us slower (four
-        // stores per element, two of them strided mirror stores), the side branch, which is the longer one, 100-150 us shorter
-        svgp_gemm_epi ep;
-        ep.C2 = Aji; ep.sc2 = mm; ep.a2 = 1.0; ep.d2 = c->jitter;
-        RUNC(svgp_dgemm_symout_batched(c->gemm_f32 == 1, 0, 0, m, m, 1.0, K, m, 0, G, m, mm, 0.0, A, m, mm, L, stream, nullptr, 0, 0, &ep));
+    if (do_sig) {
+        GEMV(1.0, Si, mm, v, t, L);                                                                  // t = Si v
+        GEMM(0, 1, m, m, m, 1.0, Si, m, mm, K, m, 0, 0.0, G, m, mm, L);                              // G = Si K   (K = K^T read as [j][k])
+        {   // A = K G = K Si K, and A + jI beside it as a second output (the input of the tail's inverse).  A / B in one run at m = 800:
+            // 18.15 ms per step against 18.26 with a copy pass in front of the tail's inverse -- the product gets 240 us slower (four
+            // stores per element, two of them strided mirror stores), the side branch, which is the longer one, 100-150 us shorter
+            svgp_gemm_epi ep;
+            ep.C2 = Aji; ep.sc2 = mm; ep.a2 = 1.0; ep.d2 = c->jitter;
+            RUNC(svgp_dgemm_symout_batched(c->gemm_f32 == 1, 0, 0, m, m, 1.0, K, m, 0, G, m, mm, 0.0, A, m, mm, L, stream, nullptr, 0, 0, &ep));
+        }
+        GEMV(cc, K, 0, t, mu, L);                                                                    // mu = c K t
     }
-    GEMV(cc, K, 0, t, mu, L);                                                                    // mu = c K t
-    GEMV(1.0, Ki, 0, mu, u, L);                                                                  // u = Ki mu
-    hipLaunchKernelGGL(k_big_kl_terms, dim3(KL_NCH, L), dim3(256), 0, st, m, Ki, A, mu, u, klp);
-    SVGP_LAUNCH_CHECK();
-    // q_n = k_n^T Ki k_n;  W = (Kn Ki) K behind the rows of Kn;  P^T = K Ki
-    GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, Ki, m, 0, 0.0, s.KnKi, m, 0, 1);           // kept: the reverse pass reads Kn Ki again
-    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * 64)), dim3(256), 0, st, b, m, 1, real(1), s.KnKi, 0LL, Kn,
-                       ws + wl.q, 1, 0);
-    SVGP_LAUNCH_CHECK();
-    GEMM(0, 1, b, m, m, 1.0, s.KnKi, m, 0, K, m, 0, 0.0, s.W, m, 0, 1);
-    GEMM(0, 1, m, m, m, 1.0, K, m, 0, Ki, m, 0, 0.0, s.PT, m, 0, 1);
-    if (part == 1) return SVGP_OK;
+    if (do_kl) {
+        GEMV(1.0, Ki, 0, mu, u, L);                                                                  // u = Ki mu
+        hipLaunchKernelGGL(k_big_kl_terms, dim3(KL_NCH, L), dim3(256), 0, st, m, Ki, A, mu, u, klp);
+        SVGP_LAUNCH_CHECK();
+    }
+    if (do_k) {
+        // q_n = k_n^T Ki k_n;  W = (Kn Ki) K behind the rows of Kn;  P^T = K Ki
+        GEMM(0, 1, b, m, m, 1.0, Kn, m, 0, Ki, m, 0, 0.0, s.KnKi, m, 0, 1);           // kept: the reverse pass reads Kn Ki again
+        hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * 64)), dim3(256), 0, st, b, m, 1, real(1), s.KnKi, 0LL, Kn,
+                           ws + wl.q, 1, 0);
+        SVGP_LAUNCH_CHECK();
+        GEMM(0, 1, b, m, m, 1.0, s.KnKi, m, 0, K, m, 0, 0.0, s.W, m, 0, 1);
+        GEMM(0, 1, m, m, m, 1.0, K, m, 0, Ki, m, 0, 0.0, s.PT, m, 0, 1);
+    }
+    if (part == 1 || split) return SVGP_OK;
+    }
 aji_tail:
     // (Aji holds A_hat + jI: written by the product A = K G above; the tail inverts it in place)
     RUNC(svgp_spd_inverse_batched(m, L, Aji, s.ldtmp, s.inv, stream));

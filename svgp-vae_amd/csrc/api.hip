@@ -323,6 +323,7 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
     }
     hipStream_t s2 = fork2 ? sd->s[0] : ms;
 #define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
+    const bool ksplit = phase == 0 && fork1 && defer && c->m < SVGP_CHOL_INVERSE_MIN_M && konly_on();
     switch (phase) {
     case 0:
         RUN(svgp_mnist_encoder_kernel_matrix_fwd(c, theta, images, aux, ws, stream));   // one launch for the two
@@ -331,12 +332,15 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         // (a chain of 8 block steps, as long as the channel batch's) and three products -- goes to side branch 1 now, beside the
         // forward statistics and the channel inverses, instead of behind them on the caller's stream.  Joined in phase 1 where
         // u = Ki mu needs it.  SVGP_KONLY_BRANCH=0: the in-line order.
-        if (fork1 && defer && c->m < SVGP_CHOL_INVERSE_MIN_M && konly_on()) {
-            RUN(side_fork(sd, 1, ms));
+        // (The branch is FORKED here but its launches are ISSUED behind the statistics': the host -- and a replayed graph, which
+        // submits its nodes in capture order -- takes ~2.5 us per launch, and the branch's 15 launches in front of the statistics'
+        // first kernel left the caller's stream idle for 36 us in the kernel trace.)
+        if (ksplit) RUN(side_fork(sd, 1, ms));
+        RUN(svgp_gp_stats_fwd(c, ws, stream));
+        if (ksplit) {
             RUN(svgp_gp_factor_fwd_part(c, ws, (void*)sd->s[1], 5));
             side_mark_konly(sd, ws);
         }
-        RUN(svgp_gp_stats_fwd(c, ws, stream));
         if (c->titsias) RUN(svgp_gp_titsias_stats(c, ws, stream));
         break;
     case 1:
@@ -377,6 +381,8 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         }
         RUN(svgp_gp_posterior_bwd_with_final(c, ws, state, stream));
         if (c->titsias) RUN(svgp_gp_titsias_bwd(c, ws, state, stream));
+        // (m > 64, measured round 5: the kernel-matrix reverse pass on side branch 0 beside the encoder's does NOT overlap -- 68 KB +
+        // 104 KB of LDS per workgroup do not fit one CU; the kernel-matrix launch stretched from 49 to 103 us and the step was unchanged)
         if (fork2) RUN(side_fork(sd, 0, ms));
         RUN(svgp_kernel_matrix_bwd_partials(c, theta, aux, ws, s2));
         RUN(svgp_mnist_encoder_bwd(c, theta, images, ws, stream));

@@ -398,7 +398,15 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
         return pack ? ag(comm, xp, L * pe, G, stream) : ag(comm, blk, Lmm, G, stream);
     };
     RUN(svgp_mnist_encoder_kernel_matrix_fwd(&cc, theta, images, aux, ws, stream));
-    RUN(svgp_gp_stats_fwd(&cc, ws, stream));
+    // the channel-independent block of the forward factor stage ((K + jI)^-1, Kn Ki, q, W, P^T -- every rank computes it, and with
+    // L / G channels per rank it is most of the stage) on the side branch from here on, beside the statistics, exchange point 1
+    // and the window's channel inverses; joined where u = Ki mu needs it (as svgp_mnist_train_step does on one GPU, api.hip)
+    const char* ev_k = getenv("SVGP_KONLY_BRANCH");
+    const bool ksplit = fork && m < SVGP_CHOL_INVERSE_MIN_M && !(ev_k && ev_k[0] == '0');
+    void* side0 = stream;
+    if (ksplit) RUN(guard.fork(&side0));
+    RUN(svgp_gp_stats_fwd(&cc, ws, stream));         // (issued first: the branch's 15 launches would hold the caller's stream back)
+    if (ksplit) RUN(svgp_big_factor_fwd(&cc, wl, ws, side0, l0, nl, 5));
     // ---- point 1: reduce-scatter [S | v] over the channels
     RUN(pt.begin());
     if (pack) RUN(svgp_sym_pack(m, L, 0, ws + wl.S, xp0, stream));
@@ -409,7 +417,13 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     if (pack) RUN(svgp_sym_unpack(m, nl, xp0 + (size_t)l0 * pe, ws + wl.S + (size_t)l0 * mm, stream));
     RUN(pt.end());
     // window factor stage without its tail
-    RUN(svgp_big_factor_fwd(&cc, wl, ws, stream, l0, nl, 1));
+    if (ksplit) {
+        RUN(svgp_big_factor_fwd(&cc, wl, ws, stream, l0, nl, 6));
+        RUN(guard.join());
+        RUN(svgp_big_factor_fwd(&cc, wl, ws, stream, l0, nl, 7));
+    } else {
+        RUN(svgp_big_factor_fwd(&cc, wl, ws, stream, l0, nl, 1));
+    }
     // ---- point 2: all-gather [Sigma^-1 | t | u]
     RUN(pt.begin());
     // the window goes to the wire format first, so that the side branch below never reads a block that is being rewritten

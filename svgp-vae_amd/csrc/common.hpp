@@ -43,6 +43,10 @@ int svgp_side_branch_fork(void* main_stream, void** side_stream_out, int k = 1);
 int svgp_potri_batched_wide(int m, int batch, double* A, const double* potrf_work, double* work, void* stream);
 int svgp_potrf_batched_band(int m, int batch, double* A, int lda, long long strideA, double* logdet, double* work, void* stream);
 int svgp_side_branch_join(void* main_stream, int k = 1);
+// linalg.hip: svgp_dgemm_splitk with a second factor for the result rows >= row2
+int svgp_dgemm_splitk_rows2(int ta, int tb, int M, int N, int K, double alpha, double alpha2, int row2, const double* A, int lda,
+                            const double* B, int ldb, double beta, double* C, int ldc, double* scratch, long long scratch_elems,
+                            void* stream);
 // gp_kernels.hip: parts 5 / 6 / 7 of the large-m forward factor stage (see gp_large.hip svgp_big_factor_fwd)
 int svgp_gp_factor_fwd_part(const svgp_mnist_cfg* c, double* ws, void* stream, int part);
 int svgp_mnist_step_phase_deferred(const svgp_mnist_cfg* c, int phase, double* theta, const double* images,
@@ -275,7 +279,11 @@ __device__ __forceinline__ void svgp_km_fwd_element(const SvgpKernArgs& a, long 
 }
 
 // dynamic LDS of the scatter workgroups: the 256 staged d_on rows while M <= 32 (64 KB); wider rows are read from global memory
-static inline size_t svgp_km_scatter_lds(int M) { return M <= 32 ? (size_t)256 * M * sizeof(real) : 0; }
+// (staged only when the whole batch is ONE chunk of 256 rows: with several chunks every workgroup would stage all b rows, 64 KB a
+// chunk at M = 32, to use the ~b / n_obj rows per table row that match -- config 3: 40 us for the scatter workgroups, and their
+// dynamic LDS held every workgroup of the closing reduction they ride in to two per CU; reading the matching rows directly: 5 us)
+static inline bool svgp_km_scatter_staged(int b, int M) { return M <= 32 && b <= 256; }
+static inline size_t svgp_km_scatter_lds(int b, int M) { return svgp_km_scatter_staged(b, M) ? (size_t)256 * M * sizeof(real) : 0; }
 // Object-table scatter of the kernel-matrix VJP, one workgroup of SVGP_BLOCK threads (dynamic LDS: 256 * M doubles at
 // `dbuf`, M <= 32).  Workgroups [0, nblk - 1): element o = blk * 256 + tid of the (n_obj, M) table gradient = sum of the d_on
 // rows whose id matches, in row order (duplicate ids sum deterministically): per chunk of 256 staged rows a bit mask per
@@ -306,7 +314,8 @@ __device__ __forceinline__ void svgp_km_scatter_block(int blk, int nblk, int b, 
         const int cnt = min(256, b - n0);
         __syncthreads();
         for (int t = threadIdx.x; t < 256 * 8; t += blockDim.x) (&mask[0][0])[t] = 0u;
-        if (M <= 32)
+        const bool staged = M <= 32 && b <= 256;
+        if (staged)
             for (int t = threadIdx.x; t < cnt * M; t += blockDim.x) dbuf[t] = d_on[(size_t)n0 * M + t];
         __syncthreads();
         // set bits are order-independent (atomicOr), the sums below walk them in increasing row order: the result
@@ -322,7 +331,7 @@ __device__ __forceinline__ void svgp_km_scatter_block(int blk, int nblk, int b, 
                 unsigned bits = mask[r - r_first][w];
                 while (bits) {
                     const int n = w * 32 + __ffs(bits) - 1;
-                    acc += M <= 32 ? dbuf[n * M + k] : d_on[(size_t)(n0 + n) * M + k];
+                    acc += staged ? dbuf[n * M + k] : d_on[(size_t)(n0 + n) * M + k];
                     bits &= bits - 1;
                 }
             }

@@ -1292,7 +1292,7 @@ static int kernel_matrix_bwd_impl(const svgp_mnist_cfg* c, const double* theta, 
     if (scatter) {
         const int n_ov = c->n_obj * c->M;
         hipLaunchKernelGGL(k_kernel_matrix_bwd_scatter, dim3((n_ov + SVGP_BLOCK - 1) / SVGP_BLOCK + 1), dim3(SVGP_BLOCK),
-                           svgp_km_scatter_lds(c->M), (hipStream_t)stream, a, c->m + nrb, c->train_gp, c->train_ov,
+                           svgp_km_scatter_lds(c->b, c->M), (hipStream_t)stream, a, c->m + nrb, c->train_gp, c->train_ov,
                            ws + wl.d_on, ws + wl.part_gp, grad + pl.ov, grad + pl.l_GP, grad + pl.amplitude);
         SVGP_LAUNCH_CHECK();
     }

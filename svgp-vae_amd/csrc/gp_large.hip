@@ -35,7 +35,7 @@ __global__ void k_big_weights(int n_el, int L, int mode, int geco, int clip_pv, 
                               const real* __restrict__ p_m, const real* __restrict__ p_v,
                               const real* __restrict__ e, const real* __restrict__ eps,
                               const real* __restrict__ zbar, real* __restrict__ w, real* __restrict__ a,
-                              real* __restrict__ bv) {
+                              real* __restrict__ bv, real* __restrict__ stk) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_el) return;
     const real p = recip_no_nan(s2[i]);
@@ -47,7 +47,13 @@ __global__ void k_big_weights(int n_el, int L, int mode, int geco, int clip_pv, 
         const real gpv = svgp_gpv(clip_pv, gT, p, zb, eps[i], pv);
         const real gpm = gT * p * (p_m[i] - y[i]) + zb;
         const real g3 = svgp_seed_3(geco, gT);
-        w[i] = gpv; bv[i] = gpm; a[i] = g3 * p * e[i];       // g_pv, g_pm, mvbar buffers
+        const real av = g3 * p * e[i];
+        w[i] = gpv; bv[i] = gpm; a[i] = av;                  // g_pv, g_pm, mvbar buffers
+        if (stk) {                                           // and [mvbar | g_pm] side by side, (b, 2 L): one stacked operand
+            const int n = i / L, l = i % L;
+            stk[(size_t)n * 2 * L + l] = av;
+            stk[(size_t)n * 2 * L + L + l] = gpm;
+        }
     }
 }
 __global__ void k_big_recip(int n_el, const real* __restrict__ s2, real* __restrict__ p) {
@@ -173,20 +179,7 @@ __device__ __forceinline__ void fb_scalars(const FbArgs& a, real& g3, real& gK) 
     const real gT = gradKL(a.geco, a.Ltot, a.state);
     g3 = svgp_seed_3(a.geco, gT); gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
 }
-__global__ void k_big_fb_ubar(FbArgs a) {     // ubar = ud + gK/2 mu
-    real g3, gK; fb_scalars(a, g3, gK);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.L * a.m) a.ubar[i] = a.ud[i] + real(0.5) * gK * a.mu[i];
-}
-__global__ void k_big_fb_mubar(FbArgs a) {    // mubar = Ki ubar (in place) + gK/2 u
-    real g3, gK; fb_scalars(a, g3, gK);
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.L * a.m) a.mubar[i] += real(0.5) * gK * a.u[i];
-}
-__global__ void k_big_fb_tbar(FbArgs a) {     // tbar = td + c (K mubar)  (tbar holds K mubar)
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.L * a.m) a.tbar[i] = a.td[i] + a.c * a.tbar[i];
-}
+// (ubar = ud + gK/2 mu, mubar = Ki ubar + gK/2 u, tbar = td + c K mubar: inside k_big_gemv_fb)
 // D_l = Ki - Aji_l (exactly symmetric: both operands are); the gradient of A_hat from the KL term is Abar_l = gK/2 D_l
 __global__ void k_big_fb_dmat(int m, int L, const real* __restrict__ Ki, const real* __restrict__ Aji, real* __restrict__ D) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x, mm = (long long)m * m;
@@ -383,6 +376,55 @@ __global__ __launch_bounds__(256) void k_big_gemv(int m, real alpha, const real*
     }
 }
 
+// The vector chain of the late reverse factor stage with its element-wise steps inside the two matrix-vector products (round 5:
+// ubar -> Ki ubar -> mubar -> K mubar -> tbar was three element kernels + two products = five dependent launches of 4-8 us):
+//   MODE 1: x = ubar = ud + gK/2 mu (stored by the first row block), y = Ki x, result mubar = y + gK/2 u;
+//   MODE 2: x = mubar,                                               y = K x,  result tbar  = td + c y.
+// Same grid and summation order as k_big_gemv; the element-wise expressions are those of the three kernels they replace.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_big_gemv_fb(FbArgs a, const real* __restrict__ A) {
+    extern __shared__ real xs[];
+    const int m = a.m, l = blockIdx.y, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    real g3, gK; fb_scalars(a, g3, gK);
+    for (int k = threadIdx.x; k < m; k += 256) {
+        const size_t i = (size_t)l * m + k;
+        real xv;
+        if (MODE == 1) {
+            xv = a.ud[i] + real(0.5) * gK * a.mu[i];
+            if (blockIdx.x == 0) a.ubar[i] = xv;
+        } else {
+            xv = a.mubar[i];
+        }
+        xs[k] = xv;
+    }
+    __syncthreads();
+    const int i0 = blockIdx.x * 16 + w * 4;
+    real acc[4] = {0, 0, 0, 0};
+    for (int k = lane; k < m; k += 64) {
+        const real xv = xs[k];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (i0 + r < m) acc[r] += A[(size_t)(i0 + r) * m + k] * xv;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        real v = acc[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0 && i0 + r < m) {
+            const size_t i = (size_t)l * m + i0 + r;
+            if (MODE == 1) {
+                real y = real(1) * v;
+                y += real(0.5) * gK * a.u[i];
+                a.mubar[i] = y;
+            } else {
+                const real y = real(1) * v;
+                a.tbar[i] = a.td[i] + a.c * y;
+            }
+        }
+    }
+}
+
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -449,9 +491,13 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
     real* wbuf = ws + wl.g_pv;
     real* abuf = mode == 0 ? ws + wl.g_pm : ws + wl.mvbar;
     real* bbuf = ws + wl.g_pm;
+    // reverse statistics: ud = mvbar^T Kn and td = c g_pm^T Kn as ONE split-K contraction over the rows, operands stacked (b, 2 L) in
+    // scr_bl (free until the row-form SW weights / the reverse row stage), results in the contiguous [ud | td] of statB, the factor c
+    // applied to td's rows by the reduction pass: the same partial sums per element as two contractions, two launches less
+    const bool stacked = mode == 1 && wl.td == wl.ud + (int64_t)L * m;
     hipLaunchKernelGGL(k_big_weights, dim3(nblk((long long)b * L)), dim3(256), 0, st, b * L, L, mode, SVGP_LOSS_FLAGS(c), c->clip_pv, cc, state,
                        ws + wl.qnet_mu, ws + wl.qnet_var, ws + wl.p_m, ws + wl.p_v, ws + wl.e, ws + wl.eps,
-                       ws + wl.zbar, wbuf, abuf, bbuf);
+                       ws + wl.zbar, wbuf, abuf, bbuf, stacked ? s.bl0 : (real*)nullptr);
     SVGP_LAUNCH_CHECK();
     real* S = mode == 0 ? ws + wl.S : ws + wl.A2;
     real* v1 = mode == 0 ? ws + wl.v : ws + wl.ud;
@@ -465,9 +511,15 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
     // scratch: the second half of fb_part (unused since round 4; scr_mm may be in use by the early reverse half on the side stream
     // while the reverse statistics run)
     real* sks = ws + wl.fb_part + (size_t)c->L * m * m;
-    RUNC(svgp_dgemm_splitk(1, 0, L, m, b, 1.0, abuf, L, Kn, m, 0.0, v1, m, sks, sk, stream));
+    if (stacked) {
+        const long long sk2 = svgp_dgemm_splitk_scratch_elems(2 * L, m, b);
+        SVGP_REQUIRE(sk2 >= 0 && sk2 <= (long long)c->L * m * m, SVGP_ERR_INVALID, "split-K scratch");
+        RUNC(svgp_dgemm_splitk_rows2(1, 0, 2 * L, m, b, 1.0, cc, L, s.bl0, 2 * L, Kn, m, 0.0, v1, m, sks, sk2, stream));
+    } else {
+        RUNC(svgp_dgemm_splitk(1, 0, L, m, b, 1.0, abuf, L, Kn, m, 0.0, v1, m, sks, sk, stream));
+    }
     if (mode == 1) {
-        RUNC(svgp_dgemm_splitk(1, 0, L, m, b, cc, bbuf, L, Kn, m, 0.0, ws + wl.td, m, sks, sk, stream));
+        if (!stacked) RUNC(svgp_dgemm_splitk(1, 0, L, m, b, cc, bbuf, L, Kn, m, 0.0, ws + wl.td, m, sks, sk, stream));
         // the rank-local row sums of the reverse pass (they enter Kbar linearly: no exchange, see the file header):
         // [Qs; Pbar^T] (2 m, m) = X^T Kn, split over the rows when that leaves few output tiles (config 3: 23.6 + 25.9 us for the two
         // products as single launches with a contraction of 1024, round 4)
@@ -637,7 +689,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     a.A2 = ws + wl.A2 + om; a.mu = ws + wl.mu_hat + ov; a.u = ws + wl.u + ov; a.ud = ws + wl.ud + ov; a.td = ws + wl.td + ov;
     a.v = ws + wl.v + ov;
     a.ubar = s.vec0; a.mubar = s.vec1; a.tbar = s.vec2; a.Sibar = s.mm1; a.Sg = s.mm1; a.HG = s.mm3; a.Ssym = ws + wl.Ssym + om;
-    const unsigned gmm = nblk(mm * L), gv = nblk((long long)L * m), ntp = (unsigned)((m + TP - 1) / TP);
+    const unsigned gmm = nblk(mm * L), ntp = (unsigned)((m + TP - 1) / TP);
     // SW_l = W^T diag(p_l) W = P^T S_l P -- forward quantities only.  Over the rows (a statistics product with contraction b) when ALL
     // rows of the batch are local (b == b_global) and that is the cheaper form (m^2 b against 3 m^3 per channel): at the end of the
     // reverse statistics (svgp_big_stats, mode 1).  From S_l otherwise -- under data parallelism S_l is the all-reduced statistic, so SW needs no exchange of
@@ -673,13 +725,10 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
         SVGP_LAUNCH_CHECK();
     }
     if (part == 1 || part == 4) return SVGP_OK;
-    hipLaunchKernelGGL(k_big_fb_ubar, dim3(gv), dim3(256), 0, st, a);
+    // ubar = ud + gK/2 mu;  mubar = Ki ubar + gK/2 u;  tbar = td + c K mubar: two launches (k_big_gemv_fb)
+    hipLaunchKernelGGL(k_big_gemv_fb<1>, dim3((m + 15) / 16, L), dim3(256), (size_t)m * sizeof(real), st, a, (const real*)Ki);
     SVGP_LAUNCH_CHECK();
-    GEMV(1.0, Ki, 0, s.vec0, s.vec1, L);                                               // Ki ubar
-    hipLaunchKernelGGL(k_big_fb_mubar, dim3(gv), dim3(256), 0, st, a);
-    SVGP_LAUNCH_CHECK();
-    GEMV(1.0, K, 0, s.vec1, s.vec2, L);                                                // K mubar
-    hipLaunchKernelGGL(k_big_fb_tbar, dim3(gv), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_big_gemv_fb<2>, dim3((m + 15) / 16, L), dim3(256), (size_t)m * sizeof(real), st, a, (const real*)K);
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);                // X (mm1)
     SVGP_LAUNCH_CHECK();

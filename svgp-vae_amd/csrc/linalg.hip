@@ -879,15 +879,17 @@ int svgp_dgemm_tri_batched(int tri, int ta, int tb, int M, int N, int K, double 
 // run as the batch dimension of k_dgemm_batched into S partial products in `scratch`; one kernel adds them in fixed
 // order: C = alpha * sum_s P_s + beta * C.  Deterministic (no atomics).
 namespace {
+// rows >= row2 are scaled by alpha2 instead of alpha (two stacked products with their own factors in one contraction)
 __global__ void k_splitk_reduce(int M, int N, int S, real alpha, real beta, const real* __restrict__ part,
-                                real* __restrict__ C, int ldc) {
+                                real* __restrict__ C, int ldc, real alpha2, int row2) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long MN = (long long)M * N;
     if (i >= MN) return;
     real s = 0;
     for (int k = 0; k < S; ++k) s += part[(size_t)k * MN + i];
-    real* c = C + (size_t)(i / N) * ldc + (i % N);
-    *c = alpha * s + (beta != real(0) ? beta * *c : real(0));
+    const int row = (int)(i / N);
+    real* c = C + (size_t)row * ldc + (i % N);
+    *c = (row >= row2 ? alpha2 : alpha) * s + (beta != real(0) ? beta * *c : real(0));
 }
 // number of K slices: enough workgroups to cover the chip a few times, slices of at least 64
 int splitk_slices(int M, int N, int K) {
@@ -909,10 +911,24 @@ extern "C" long long svgp_dgemm_splitk_scratch_elems(int M, int N, int K) {
 extern "C" int svgp_dgemm_splitk(int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
                                  const double* B, int ldb, double beta, double* C, int ldc, double* scratch,
                                  long long scratch_elems, void* stream) {
+    return svgp_dgemm_splitk_rows2(ta, tb, M, N, K, alpha, alpha, M, A, lda, B, ldb, beta, C, ldc, scratch, scratch_elems, stream);
+}
+// internal: rows [row2, M) of the result take the factor alpha2 (gp_large.hip: ud = a^T Kn and td = c b^T Kn as ONE contraction over
+// the rows with the operands stacked)
+int svgp_dgemm_splitk_rows2(int ta, int tb, int M, int N, int K, double alpha, double alpha2, int row2, const double* A, int lda,
+                            const double* B, int ldb, double beta, double* C, int ldc, double* scratch, long long scratch_elems,
+                            void* stream) {
     SVGP_REQUIRE(M >= 0 && N >= 0 && K >= 0, SVGP_ERR_INVALID, "negative dimension");
     if (M == 0 || N == 0) return SVGP_OK;
     const int S = splitk_slices(M, N, K);
-    if (S == 1) return svgp_dgemm_batched(ta, tb, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1, stream);
+    if (S == 1 && row2 >= M) return svgp_dgemm_batched(ta, tb, M, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1, stream);
+    if (S == 1) {          // two factors without a reduction pass: the two row ranges as two products
+        SVGP_REQUIRE(ta == 1, SVGP_ERR_UNSUPPORTED, "row-split factors without split-K: transposed A only");
+        int rc1 = svgp_dgemm_batched(ta, tb, row2, N, K, alpha, A, lda, 0, B, ldb, 0, beta, C, ldc, 0, 1, stream);
+        if (rc1) return rc1;
+        return svgp_dgemm_batched(ta, tb, M - row2, N, K, alpha2, A + row2, lda, 0, B, ldb, 0, beta, C + (size_t)row2 * ldc, ldc, 0, 1,
+                                  stream);
+    }
     SVGP_REQUIRE(scratch && scratch_elems >= (long long)(S + 1) * M * N, SVGP_ERR_INVALID,
                  "split-K scratch too small: need %lld doubles", (long long)(S + 1) * M * N);
     const int Kc = (K / S) & ~3, rem = K - S * Kc;          // equal slices (multiple of 4) + one remainder slice
@@ -927,7 +943,7 @@ extern "C" int svgp_dgemm_splitk(int ta, int tb, int M, int N, int K, double alp
         nparts = S + 1;
     }
     hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((MN + 255) / 256)), dim3(256), 0, (hipStream_t)stream, M, N, nparts,
-                       alpha, beta, scratch, C, ldc);
+                       alpha, beta, scratch, C, ldc, alpha2, row2);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

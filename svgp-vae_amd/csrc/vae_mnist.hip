@@ -947,7 +947,7 @@ static int grad_reduce_impl(const svgp_mnist_cfg* c, const double* aux, double* 
         ks.M = c->M; ks.n_obj = c->n_obj; ks.n_gp_part = c->m + nrb; ks.train_gp = c->train_gp; ks.train_ov = c->train_ov;
         ks.aux = aux; ks.d_on = ws + wl.d_on; ks.part_gp = ws + wl.part_gp;
         ks.d_ov = ws + wl.grad + pl.ov; ks.d_ls = ws + wl.grad + pl.l_GP; ks.d_amp = ws + wl.grad + pl.amplitude;
-        lds = svgp_km_scatter_lds(c->M);
+        lds = svgp_km_scatter_lds(c->b, c->M);
         int rc = set_dyn_lds(k_grad_reduce, lds);
         if (rc) return rc;
     }

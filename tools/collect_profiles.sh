@@ -12,6 +12,9 @@ python bench.py --workload cfg3 > $O/${tag}_cfg3.json 2>> $O/${tag}_bench.err
 python bench.py --workload sprites800 > $O/${tag}_sprites800_f64.json 2>> $O/${tag}_bench.err
 python bench.py --workload sprites800 --precision f32 > $O/${tag}_sprites800_f32.json 2>> $O/${tag}_bench.err
 python bench.py --workload cfg5 > $O/${tag}_cfg5.json 2>> $O/${tag}_bench.err
+python bench.py --workload sprites800 --precision f32 --kernel se > $O/${tag}_sprites800_f32_se.json 2>> $O/${tag}_bench.err
+# the self-launching multi-rank path with one rank: strong + weak lines through torch.distributed.run spawned by bench.py itself
+python bench.py --gpus 1 --force-dist --steps 100 --warmup 10 --no-cpu-baseline > $O/${tag}_cfg2_self_launch.json 2>> $O/${tag}_bench.err
 python bench.py --workload cfg3 --force-comm --no-cpu-baseline > $O/${tag}_cfg3_force_comm.json 2>> $O/${tag}_bench.err
 python bench.py --force-comm --no-cpu-baseline > $O/${tag}_cfg2_force_comm.json 2>> $O/${tag}_bench.err
 python bench.py --workload sprites800 --precision f32 --force-comm --no-cpu-baseline > $O/${tag}_sprites800_f32_force_comm.json 2>> $O/${tag}_bench.err
@@ -41,6 +44,9 @@ python tools/conv_probe.py 500 f32 > $O/${tag}_conv_probe_f32.txt 2>/dev/null
 python tools/conv_probe.py 500 > $O/${tag}_conv_probe_f64.txt 2>/dev/null
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 tools/micro/mfma_f32_issue.hip -o tools/micro/mfma_f32_issue 2>/dev/null   # built here, never committed
 ./tools/micro/mfma_f32_issue > $O/${tag}_micro_mfma_f32_issue.txt 2>/dev/null
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -I svgp-vae_amd/csrc tools/micro/sweep32_probe.hip -o tools/micro/sweep32_probe 2>/dev/null
+./tools/micro/sweep32_probe > $O/${tag}_micro_sweep32.txt 2>/dev/null
+python tools/sprites_gemm_f32_probe.py se 2>/dev/null | grep -v "^{" > $O/${tag}_sprites_gemm_f32_se.txt
 for w in cfg2 cfg3 sp800 cfg5; do f=$(find $O/${tag}_prof_$w -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${tag}_${w}_kernel_stats.csv; done
 # the raw traces / counter dumps are large: keep the summaries only
 rm -rf $O/${tag}_prof_* $O/${tag}_pmc_FETCH_SIZE $O/${tag}_pmc_WRITE_SIZE $O/${tag}_pmc_sq

@@ -1074,6 +1074,9 @@ def main():
         # plain `python bench.py --gpus N`: this process becomes the launcher.  Nothing here has touched the GPU yet
         # (argparse + imports only), and the ranks are CHILD processes -- never an exec of this one.
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    # dmabuf IPC is the only mode this pool's host driver supports (RCCL / cross-process tensor sharing fail without it); it is read
+    # when the HIP runtime initialises, so it is set BEFORE the first GPU call of this process
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank, local_rank, world = dist_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")

@@ -276,6 +276,11 @@ int svgp_gp_factor_bwd_late(const svgp_mnist_cfg*, double* ws, const double* sta
  * svgp_gp_factor_fwd_aji_tail on a third stream; _early_b (Abar, Gbar, Z, Gbar K) is ordered behind both. */
 int svgp_gp_factor_bwd_early_a(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_early_b(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+/* _late = _late_a + _late_b: _late_a (the vector chain; with the statistic SW formed by svgp_gp_stats_bwd -- all rows local,
+ * b < 3 m -- also X, vbar, Si X and -(Si X) Si) reads nothing the early half writes, so a caller that runs the early half on
+ * another stream issues it BEFORE joining that stream; _late_b follows the join. */
+int svgp_gp_factor_bwd_late_a(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+int svgp_gp_factor_bwd_late_b(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 /* tf.train.AdamOptimizer.apply_gradients, TF1 formula (MNIST_experiment.py:200,207-208) */

@@ -374,8 +374,9 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         // workspace, not inferred from the environment): a caller that ran the phase-1 stages through the individual entry
         // points, or changed SVGP_SIDE_STREAMS in between, gets the full reverse factor stage.
         if (large && side_take_early(sd, ws)) {
+            RUN(svgp_gp_factor_bwd_late_a(c, ws, state, stream));       // what does not read the branch's results: before the join
             RUN(side_join(sd, 1, ms));                                  // (a no-op unless phase 1 left the branch open)
-            RUN(svgp_gp_factor_bwd_late(c, ws, state, stream));
+            RUN(svgp_gp_factor_bwd_late_b(c, ws, state, stream));
         } else {
             RUN(svgp_gp_factor_bwd_nofinal(c, ws, state, stream));      // channel sum Kbar: inside the next launch
         }

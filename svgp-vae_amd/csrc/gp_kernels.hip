@@ -1526,6 +1526,20 @@ extern "C" int svgp_gp_factor_bwd_early_b(const svgp_mnist_cfg* c, double* ws, c
     SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the split reverse factor stage exists for m > %d", SVGP_M_MAX);
     return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 4);
 }
+// _late = _late_a + _late_b: _late_a reads nothing the early half writes and may be issued BEFORE the caller's stream joins the branch
+// the early half runs on; _late_b follows the join
+extern "C" int svgp_gp_factor_bwd_late_a(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the split reverse factor stage exists for m > %d", SVGP_M_MAX);
+    return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 6);
+}
+extern "C" int svgp_gp_factor_bwd_late_b(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the split reverse factor stage exists for m > %d", SVGP_M_MAX);
+    return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 7);
+}
 extern "C" int svgp_gp_factor_bwd_late(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");

@@ -668,7 +668,7 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
 // channel window [l0, l0 + nl) as in svgp_big_factor_fwd; Kbar then holds rep_weight x the window's share of the gradient of
 // K_mm plus this rank's row-local share (the shares of the ranks add up in the gradient exchange: kernel_matrix_bwd is linear
 // in Kbar and takes it unweighted on this path).
-// part: 0 = the whole stage; 1 = its EARLY half (3 + 4: its two parts separately); 2 = its LATE half.  The early half --
+// part: 0 = the whole stage; 1 = its EARLY half (3 + 4: its two parts separately); 2 = its LATE half (6 + 7: see there).  The early half --
 //   D = Ki - Aji, H = G D (= Z' = Sigma^-1 K D), HG = H G^T (= Sigma^-1 K D K Sigma^-1), the channel sums of H, HG and A_hat
 // -- depends on forward quantities only (the scalar gK/2 of Abar = gK/2 D is applied where the products are consumed),
 // not on the reverse statistics B2, ud, td.  The training step issues it on the side stream right behind the forward stage's
@@ -725,21 +725,39 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
         SVGP_LAUNCH_CHECK();
     }
     if (part == 1 || part == 4) return SVGP_OK;
-    // ubar = ud + gK/2 mu;  mubar = Ki ubar + gK/2 u;  tbar = td + c K mubar: two launches (k_big_gemv_fb)
-    hipLaunchKernelGGL(k_big_gemv_fb<1>, dim3((m + 15) / 16, L), dim3(256), (size_t)m * sizeof(real), st, a, (const real*)Ki);
-    SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_big_gemv_fb<2>, dim3((m + 15) / 16, L), dim3(256), (size_t)m * sizeof(real), st, a, (const real*)K);
-    SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);                // X (mm1)
-    SVGP_LAUNCH_CHECK();
-    GEMV(1.0, Si, mm, s.vec2, ws + wl.vbar + ov, L);                                   // vbar = Si tbar
-    GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm1, m, mm, 0.0, s.mm0, m, mm, L);           // Si X (mm0: H is summed)
-    // Sg0 = -(Si X) Si: a FULL product, not lower-triangle-and-mirror -- like the Ki sandwiches of round 2, the mirrored form of this
-    // Sigma^-1 sandwich loses the benign structure of its rounding error: config 3 (jitter 1e-6) had the encoder dense-layer gradient
-    // off by 1e-3 against 1e-9 (measured, round 4).  Ssym = c (Sg + Sg^T) is then formed exactly symmetric by the tile-pair kernel:
-    // writing 2 c Sg straight from the product keeps an antisymmetric rounding residue that the inducing-point gradients see at
-    // 2e-5 (virtual-rank test, m = 256), so the 0.1 ms pass stays.
-    GEMM(0, 1, m, m, m, -1.0, s.mm0, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);          // Sg0 (mm1: X is consumed)
+    {
+    // The late half in two parts (round 5): 6 = what reads NOTHING the early half writes, 7 = the rest (2 = 6 + 7).  The vector chain
+    // always belongs to part 6; X, vbar and the two full products Si X, -(Si X) Si do when the statistic SW comes from the reverse
+    // statistics on the caller's stream (`sw_rows`: SPRITES) and not from the early half -- then Si X goes to the Ssym slot (free
+    // until the tile-pair kernel below writes it) instead of mm0, where the early half keeps H until it is summed.  A caller with
+    // the early half on a side branch issues part 6, THEN joins, then part 7: at m = 800 the caller's stream waited 0.8 ms at the join
+    // with 2.3 ms of its own work ready (kernel trace).
+    const bool do_a = part != 7, do_b = part != 6, x_early = sw_rows || !has_sw;
+    real* six = x_early ? ws + wl.Ssym + om : s.mm0;
+    auto x_block = [&]() -> int {
+        hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);                // X (mm1)
+        SVGP_LAUNCH_CHECK();
+        GEMV(1.0, Si, mm, s.vec2, ws + wl.vbar + ov, L);                                   // vbar = Si tbar
+        GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm1, m, mm, 0.0, six, m, mm, L);             // Si X
+        // Sg0 = -(Si X) Si: a FULL product, not lower-triangle-and-mirror -- like the Ki sandwiches of round 2, the mirrored form of this
+        // Sigma^-1 sandwich loses the benign structure of its rounding error: config 3 (jitter 1e-6) had the encoder dense-layer gradient
+        // off by 1e-3 against 1e-9 (measured, round 4).  Ssym = c (Sg + Sg^T) is then formed exactly symmetric by the tile-pair kernel:
+        // writing 2 c Sg straight from the product keeps an antisymmetric rounding residue that the inducing-point gradients see at
+        // 2e-5 (virtual-rank test, m = 256), so the 0.1 ms pass stays.
+        GEMM(0, 1, m, m, m, -1.0, six, m, mm, Si, m, mm, 0.0, s.mm1, m, mm, L);            // Sg0 (mm1: X is consumed)
+        return SVGP_OK;
+    };
+    if (do_a) {
+        // ubar = ud + gK/2 mu;  mubar = Ki ubar + gK/2 u;  tbar = td + c K mubar: two launches (k_big_gemv_fb)
+        hipLaunchKernelGGL(k_big_gemv_fb<1>, dim3((m + 15) / 16, L), dim3(256), (size_t)m * sizeof(real), st, a, (const real*)Ki);
+        SVGP_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_big_gemv_fb<2>, dim3((m + 15) / 16, L), dim3(256), (size_t)m * sizeof(real), st, a, (const real*)K);
+        SVGP_LAUNCH_CHECK();
+        if (x_early) RUNC(x_block());
+    }
+    if (part == 6) return SVGP_OK;
+    if (do_b && !x_early) RUNC(x_block());
+    }
     hipLaunchKernelGGL(k_big_fb_ssym, dim3(ntp, ntp, L), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, real(1), s.mm1, s.Sgs);

@@ -615,8 +615,12 @@ class SpritesStepEngine:
                     self.stream.wait_stream(self.side)
                 call("svgp_gp_factor_bwd_channels_part", cp, l0, nl, 2 if self.side is not None else 0, ws, st, s)
             elif self.m > 64 and self.side is not None and not self.svgp.titsias:
+                # the part of the late half that reads nothing the side branch writes -- the vector chain and, with all rows local, X and
+                # the two full products Si X, (Si X) Si: 2.3 ms at m = 800 -- BEFORE the join: the caller's stream used to wait 0.8 ms
+                # there for the second inverse + early half with that work ready (kernel trace, round 5)
+                call("svgp_gp_factor_bwd_late_a", cp, ws, st, s)
                 self.stream.wait_stream(self.side)
-                call("svgp_gp_factor_bwd_late", cp, ws, st, s)
+                call("svgp_gp_factor_bwd_late_b", cp, ws, st, s)
             else:
                 call("svgp_gp_factor_bwd", cp, ws, st, s)
         if self.chan_shard:      # (KL_l comes out of the tail, joined above)

@@ -305,8 +305,12 @@ def stage_table(eng, B, M_IND):
          f8 * (Lc * 2 * m * m + b * m + 8 * b * Lc), 0.0),
         ("decoder_fwd", "svgp_mnist_decoder_fwd", (cfg, th, img, ws, s), 2 * dec_mac * b,
          f8 * (b * (Lc + act_dec + 2 * 784) + n_dec), 0.0),
-        ("decoder_bwd", "svgp_mnist_decoder_bwd", (cfg, th, img, ws, st, s), 4 * dec_mac * b,
-         f8 * (b * (Lc + act_dec + 2 * 784 + Lc) + 2 * n_dec), f8 * n_part * n_dec),
+        # m <= 64 (round 6): the data half alone (the chain to zbar; it also stores the pre-activation gradients d2, d1, dh0 for the
+        # weight half, which rides in the reverse factor launch below); m > 64: the one-kernel form
+    ] + ([("decoder_bwd_data", "svgp_mnist_decoder_bwd_data", (cfg, th, img, ws, st, s), 2 * dec_mac * b,
+           f8 * (b * (512 + 1568 + 2 * 784 + Lc) + n_dec), f8 * b * (1568 + 512 + 128))] if m <= 64 else
+         [("decoder_bwd", "svgp_mnist_decoder_bwd", (cfg, th, img, ws, st, s), 4 * dec_mac * b,
+           f8 * (b * (Lc + act_dec + 2 * 784 + Lc) + 2 * n_dec), f8 * n_part * n_dec)]) + [
         # m > 64: + the rank-local row terms [Qs; Pbar^T] = X^T Kn and (all rows local, b < 3 m) the statistic SW = W^T diag(p) W
         ("gp_stats_bwd", "svgp_gp_stats_bwd", (cfg, ws, st, s),
          3 * Lc * b * m * m + ((4 * b * m * m + (Lc * b * m * m if b < 3 * m else 0)) if m > 64 else 0),
@@ -316,7 +320,9 @@ def stage_table(eng, B, M_IND):
            Lc * (2 * m ** 3 + m ** 3 + (0 if b < 3 * m else 3 * m ** 3)), f8 * Lc * 6 * m * m, 0.0),
           ("gp_factor_bwd", "svgp_gp_factor_bwd_late", (cfg, ws, st, s), Lc * 2 * 2 * m ** 3 + 4 * 2 * m ** 3, f8 * Lc * 8 * m * m, 0.0)]
          if m > 64 else
-         [("gp_factor_bwd", "svgp_gp_factor_bwd_nofinal", (cfg, ws, st, s), Lc * 9 * 2 * m ** 3, f8 * Lc * 14 * m * m, 0.0)]) + [
+         # + the decoder's weight gradients as rider workgroups of the same launch (3 per image)
+         [("gp_factor_bwd", "svgp_gp_factor_bwd_nofinal_wgrad", (cfg, img, ws, st, s), Lc * 9 * 2 * m ** 3 + 2 * dec_mac * b,
+           f8 * (Lc * 14 * m * m + b * (Lc + act_dec + 2 * 784) + n_dec), f8 * (n_part * n_dec + b * (1568 + 512 + 128)))]) + [
         # m > 64: ONE (b, m, m) product per channel (Kn Ssym; Kn Si is the forward pass's) + Wbar P^T; m <= 64: three
         ("gp_posterior_bwd", "svgp_gp_posterior_bwd_with_final", (cfg, ws, st, s),
          (2 * Lc * b * m * m + 2 * b * m * m) if m > 64 else 6 * Lc * b * m * m,

@@ -120,6 +120,8 @@ typedef struct {
     int64_t p_m, p_v, e, d, eps, z;       /* (b,L) each                                           */
     /* decoder (VAE_utils.py:128-141,154-162) */
     int64_t dec_h0, dec_a1, dec_a2, recon; /* (b,128) (b,8,8,8) (b,14,14,8) (b,28,28,1)           */
+    /* pre-activation gradients of the decoder layers, written by svgp_mnist_decoder_bwd_data for the weight half */
+    int64_t dec_d2, dec_d1, dec_dh0;      /* (b,14,14,8) (b,8,8,8) (b,128)                        */
     /* backward */
     int64_t zbar, g_pv, g_pm, mvbar;      /* (b,L) each                                           */
     int64_t statB, statB_len, A2, ud, td; /* ONE contiguous all-reduce block [A2 | ud | td]       */
@@ -210,6 +212,17 @@ int svgp_mnist_decoder_fwd(const svgp_mnist_cfg*, const double* theta, const dou
 /* reverse of the decoder; writes zbar and decoder weight-gradient partials */
 int svgp_mnist_decoder_bwd(const svgp_mnist_cfg*, const double* theta, const double* images,
                            double* ws, const double* state, void* stream);
+/* The reverse pass of the decoder in two halves (tf.gradients of VAE_utils.py:128-141,154-162; MNIST_experiment.py:202-205).
+ * _data: the chain d recon -> zbar that the GP reverse stages wait for; also stores the pre-activation gradients ws.dec_d2 /
+ * dec_d1 / dec_dh0.  _weights: the decoder weight-gradient partials (ws.part_dec) from those and the stored activations; feeds
+ * only svgp_mnist_grad_reduce, so it may run anywhere between _data and the reduction -- svgp_gp_factor_bwd_nofinal_wgrad runs
+ * it as extra workgroups of the reverse factor launch (m <= 64), which leaves 240 of 256 CUs idle.  threads: 256 or 512 per
+ * workgroup (the rider form is 256); n_types: 1, 2 or 3 workgroups per image, each taking a group of layers (the rider form
+ * is 3: UpC3 | UpC2 | UpC1 + dense).  _data + _weights == svgp_mnist_decoder_bwd up to summation order. */
+int svgp_mnist_decoder_bwd_data(const svgp_mnist_cfg*, const double* theta, const double* images,
+                                double* ws, const double* state, void* stream);
+int svgp_mnist_decoder_bwd_weights(const svgp_mnist_cfg*, const double* images, double* ws, const double* state,
+                                   int threads, int n_types, void* stream);
 /* Titsias branch (cfg.titsias = 1), SVGPVAE_model.py:246-259: L_2 = -1/2 [b log 2pi + log det C + y^T C^-1 y +
  * sum_n (k_nn - q_n)/var_n], C = diag(var) + K_nm (K_mm + jI)^-1 K_mn + jI (b x b).  Computed in m x m space through
  * the Woodbury identity with the statistics S2_l = sum_n k_n k_n^T/(var_nl + j), v2_l = sum_n y_nl k_n/(var_nl + j):
@@ -282,6 +295,10 @@ int svgp_gp_factor_bwd_early_b(const svgp_mnist_cfg*, double* ws, const double* 
 int svgp_gp_factor_bwd_late_a(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_late_b(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+/* m <= 64: svgp_gp_factor_bwd_nofinal + svgp_mnist_decoder_bwd_weights(threads = 256) in ONE launch: the L channel workgroups
+ * first, then min(b, 256) rider workgroups with the decoder's weight-gradient partials (needs svgp_mnist_decoder_bwd_data before). */
+int svgp_gp_factor_bwd_nofinal_wgrad(const svgp_mnist_cfg*, const double* images, double* ws, const double* state,
+                                     void* stream);
 int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 /* tf.train.AdamOptimizer.apply_gradients, TF1 formula (MNIST_experiment.py:200,207-208) */
 int svgp_adam_tf1_step(int64_t n, double* theta, const double* grad, double* adam_m, double* adam_v,

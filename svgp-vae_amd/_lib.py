@@ -34,7 +34,7 @@ WS_FIELDS = ("enc_a1", "enc_a2", "enc_a3", "qnet_mu", "qnet_var_raw", "qnet_var"
              "statA", "statA_len", "S", "v", "stat_parts",
              "Ki", "ldK", "Si", "t", "G", "A", "Aji", "mu_hat", "u", "M2", "KL", "q",
              "p_m", "p_v", "e", "d", "eps", "z",
-             "dec_h0", "dec_a1", "dec_a2", "recon",
+             "dec_h0", "dec_a1", "dec_a2", "recon", "dec_d2", "dec_d1", "dec_dh0",
              "zbar", "g_pv", "g_pm", "mvbar",
              "statB", "statB_len", "A2", "ud", "td",
              "Kbar", "fb_part", "Qm", "vbar", "Ssym", "Knbar_part",
@@ -93,6 +93,8 @@ SIGNATURES = {
     "svgp_gp_posterior_fwd_with_aji": [_CFG, _P, _P, _P, _P],
     "svgp_mnist_decoder_fwd": [_CFG, _P, _P, _P, _P],
     "svgp_mnist_decoder_bwd": [_CFG, _P, _P, _P, _P, _P],
+    "svgp_mnist_decoder_bwd_data": [_CFG, _P, _P, _P, _P, _P],
+    "svgp_mnist_decoder_bwd_weights": [_CFG, _P, _P, _P, C.c_int, C.c_int, _P],
     "svgp_gp_stats_bwd": [_CFG, _P, _P, _P],
     "svgp_gp_factor_bwd": [_CFG, _P, _P, _P],
     "svgp_gp_posterior_bwd": [_CFG, _P, _P, _P],
@@ -107,6 +109,7 @@ SIGNATURES = {
     "svgp_mnist_encoder_kernel_matrix_fwd": [_CFG, _P, _P, _P, _P, _P],
     "svgp_gp_stats_bwd_with_aji": [_CFG, _P, _P, _P],
     "svgp_gp_factor_bwd_nofinal": [_CFG, _P, _P, _P],
+    "svgp_gp_factor_bwd_nofinal_wgrad": [_CFG, _P, _P, _P, _P],
     "svgp_gp_posterior_bwd_with_final": [_CFG, _P, _P, _P],
     "svgp_gp_titsias_stats": [_CFG, _P, _P],
     "svgp_gp_titsias_fwd": [_CFG, _P, _P, _P],

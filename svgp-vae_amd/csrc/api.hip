@@ -113,6 +113,7 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->p_m = take(b * L); o->p_v = take(b * L); o->e = take(b * L); o->d = take(b * L);
     o->eps = take(b * L); o->z = take(b * L);
     o->dec_h0 = take(b * 128); o->dec_a1 = take(b * 512); o->dec_a2 = take(b * 1568); o->recon = take(b * 784);
+    o->dec_d2 = take(b * 1568); o->dec_d1 = take(b * 512); o->dec_dh0 = take(b * 128);
     o->zbar = take(b * L); o->g_pv = take(b * L); o->g_pm = take(b * L); o->mvbar = take(b * L);
     o->statB = p; o->A2 = p; p += P * L * m * m; o->ud = p; p += P * L * m; o->td = p; p += P * L * m;
     o->statB_len = p - o->statB; take(0);
@@ -288,6 +289,13 @@ int svgp_side_branch_join(void* main_stream, int k) {
 }
 
 namespace {
+// m <= 64 (round 6): the decoder's reverse pass as the data half (the chain to zbar) in phase 1 and the weight half as riders of
+// the reverse factor launch in phase 2 (vae_dev.hpp).  SVGP_DEC_SPLIT=0: the one-kernel form of rounds 1-5.
+// Read per call (tests compare the two forms in one process); a caller must not change it between phase 1 and phase 2 of a step.
+bool dec_split_on() {
+    const char* e = getenv("SVGP_DEC_SPLIT");
+    return !(e && e[0] == '0');
+}
 bool konly_on() {
     static const int on = [] { const char* e = getenv("SVGP_KONLY_BRANCH"); return (e && e[0] == '0') ? 0 : 1; }();
     return on != 0;
@@ -365,7 +373,8 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         }
         if (c->titsias) RUN(svgp_gp_titsias_fwd(c, ws, state, stream));
         RUN(svgp_mnist_decoder_fwd(c, theta, images, ws, stream));
-        RUN(svgp_mnist_decoder_bwd(c, theta, images, ws, state, stream));
+        if (!large && dec_split_on()) RUN(svgp_mnist_decoder_bwd_data(c, theta, images, ws, state, stream));
+        else RUN(svgp_mnist_decoder_bwd(c, theta, images, ws, state, stream));
         RUN(svgp_gp_stats_bwd(c, ws, state, stream));
         if (fork1 && !defer) RUN(side_join(sd, 1, ms));        // phase-at-a-time callers: joined before the phase returns
         break;
@@ -378,7 +387,9 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
             RUN(side_join(sd, 1, ms));                                  // (a no-op unless phase 1 left the branch open)
             RUN(svgp_gp_factor_bwd_late_b(c, ws, state, stream));
         } else {
-            RUN(svgp_gp_factor_bwd_nofinal(c, ws, state, stream));      // channel sum Kbar: inside the next launch
+            // channel sum Kbar: inside the next launch; m <= 64: + the decoder's weight gradients as riders (phase 1 ran the data half)
+            if (!large && dec_split_on()) RUN(svgp_gp_factor_bwd_nofinal_wgrad(c, images, ws, state, stream));
+            else RUN(svgp_gp_factor_bwd_nofinal(c, ws, state, stream));
         }
         RUN(svgp_gp_posterior_bwd_with_final(c, ws, state, stream));
         if (c->titsias) RUN(svgp_gp_titsias_bwd(c, ws, state, stream));

@@ -12,6 +12,7 @@
 #include <cstdlib>
 
 #include "common.hpp"
+#include "vae_dev.hpp"
 #include "sweep32.hpp"
 
 namespace {
@@ -906,11 +907,22 @@ struct FactBwdArgs {
     real* Kbar_part; real* Kibar_part;     // (L,m,m) each
     real* vbar; real* Ssym; real* Qm;
     real* Kbar;                             // final (m,m)
+    // training step (m <= 64): workgroups [L, L + n_riders) compute the decoder's weight-gradient partials (vae_dev.hpp): work that
+    // only the closing gradient reduction consumes, in the 240 CUs this launch leaves idle.  Measured (tools/decoder_split_probe.py,
+    // config 2): 3 riders per image in two rounds of 2 workgroups per CU (this kernel's 200 VGPRs) 20.4 us against 18.1 without
+    // riders; capped at 164 VGPRs for 3 per CU (one round) the channel workgroups themselves slow down beside two riders: 21.2 us;
+    // s_setprio for the channel workgroups: no change; 1 or 2 fatter riders per image: 93 / 74 KB of LDS, a third round: 24 us.
+    int n_riders;
+    svgp_vae::DecWgradArgs wg;
 };
 
 template <int MC>
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     extern __shared__ __align__(16) real smem[];
+    if ((int)blockIdx.x >= a.L) {
+        svgp_vae::decoder_wgrad_rider<SVGP_BLOCK>(a.wg, (int)blockIdx.x - a.L, smem);
+        return;
+    }
     const int m = MC ? MC : a.m, mp = pad16(m), ld = mp + 2, mm = mp * ld, l = blockIdx.x;
     real* R0 = smem;
     real* R1 = R0 + mm;
@@ -1491,16 +1503,27 @@ static FactBwdArgs make_fb(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     a.Kbar_part = ws + wl.fb_part;            // scratch (L,m,m)
     a.Kibar_part = ws + wl.fb_part + (size_t)c->L * c->m * c->m;
     a.vbar = ws + wl.vbar; a.Ssym = ws + wl.Ssym; a.Qm = ws + wl.Qm; a.Kbar = ws + wl.Kbar;
+    a.n_riders = 0;
+    memset(&a.wg, 0, sizeof(a.wg));
     return a;
 }
 
-static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream);
+static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream,
+                           const double* images_for_wgrad = nullptr);
 extern "C" int svgp_gp_factor_bwd(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     return factor_bwd_impl(c, ws, state, true, stream);
 }
 // training-phase pair (m <= 64): the channel sum Kbar is formed by extra workgroups of the posterior reverse launch
 extern "C" int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     return factor_bwd_impl(c, ws, state, false, stream);
+}
+// ... and the decoder's weight gradients (svgp_mnist_decoder_bwd_weights, 256 threads) ride in the same launch
+extern "C" int svgp_gp_factor_bwd_nofinal_wgrad(const svgp_mnist_cfg* c, const double* images, double* ws, const double* state,
+                                                void* stream) {
+    SVGP_REQUIRE(c && c->m <= SVGP_M_MAX, SVGP_ERR_UNSUPPORTED,
+                 "the weight-gradient riders exist for the LDS-resident reverse factor stage (m <= %d)", SVGP_M_MAX);
+    SVGP_REQUIRE(images, SVGP_ERR_INVALID, "NULL device pointer");
+    return factor_bwd_impl(c, ws, state, false, stream, images);
 }
 // m > 64: the two halves of svgp_gp_factor_bwd (gp_large.hip svgp_big_factor_bwd).  _early needs only forward quantities, the
 // loss seeds in `state` and (A_hat + jI)^-1: it may run on another stream, ordered after svgp_gp_factor_fwd_aji_tail, beside
@@ -1546,17 +1569,26 @@ extern "C" int svgp_gp_factor_bwd_late(const svgp_mnist_cfg* c, double* ws, cons
     SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the split reverse factor stage exists for m > %d", SVGP_M_MAX);
     return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 2);
 }
-static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream) {
+static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream,
+                           const double* images_for_wgrad) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     if (c->m > SVGP_M_MAX) return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L);
     FactBwdArgs a = make_fb(c, wl, ws, state);
     const int m = c->m;
-    const size_t lds = mat_lds_pad(m, 4) + (size_t)(6 * m) * sizeof(real);
+    size_t lds = mat_lds_pad(m, 4) + (size_t)(6 * m) * sizeof(real);
+    if (images_for_wgrad) {
+        static const int n_types = [] { const char* e = getenv("SVGP_DEC_RIDER_TYPES"); return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 3; }();
+        a.wg = svgp_make_dec_wgrad_args(c, wl, images_for_wgrad, ws, state, n_types);
+        a.n_riders = a.wg.n_slots * a.wg.n_types;
+        const size_t lds_w = (size_t)svgp_vae::dec_wgrad_lds(SVGP_BLOCK, c->L, n_types) * sizeof(real);
+        if (lds_w > lds) lds = lds_w;
+    }
     int rc = m == 32 ? set_dyn_lds(k_gp_factor_bwd<32>, lds) : set_dyn_lds(k_gp_factor_bwd<0>, lds);
     if (rc) return rc;
-    if (m == 32) hipLaunchKernelGGL(k_gp_factor_bwd<32>, dim3(c->L), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_gp_factor_bwd<0>, dim3(c->L), dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    const dim3 grid(c->L + a.n_riders);
+    if (m == 32) hipLaunchKernelGGL(k_gp_factor_bwd<32>, grid, dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_gp_factor_bwd<0>, grid, dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
     SVGP_LAUNCH_CHECK();
     if (with_final) {
         hipLaunchKernelGGL(k_gp_factor_bwd_final, dim3((m * m + SVGP_BLOCK - 1) / SVGP_BLOCK), dim3(SVGP_BLOCK), 0,

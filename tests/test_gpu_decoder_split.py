@@ -1,0 +1,102 @@
+"""Round 6: the decoder's reverse pass as data half (svgp_mnist_decoder_bwd_data) + weight half (svgp_mnist_decoder_bwd_weights;
+in the training step: rider workgroups of the reverse factor launch, svgp_gp_factor_bwd_nofinal_wgrad) against the one-kernel
+form svgp_mnist_decoder_bwd and against the oracle (tf.gradients of VAE_utils.py:128-141,154-162; MNIST_experiment.py:202-205)."""
+import ctypes as C
+import math
+import os
+
+import pytest
+import torch
+
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(b, m, L, seed=3, geco=True):
+    params, images, aux, eps = H.toy_problem(b=b, m=m, L=L, M=4, n_obj=20, seed=seed)
+    eng = H.engine_for(params, b, geco=geco, N_train=400.0)
+    dev = eng.device
+    eng.bind(images.to(dev), aux.to(dev), eps.to(dev))
+    return eng, (params, images, aux, eps)
+
+
+@pytest.mark.parametrize("b,m,L", [(48, 16, 4), (300, 32, 16), (7, 12, 3)])
+def test_two_halves_equal_the_one_kernel_form(b, m, L):
+    from svgp_vae_amd import _lib
+    eng, _ = _engine(b, m, L)
+    eng.run(adam=False)
+    eng.synchronize()
+    cfg, th, ws, st = C.byref(eng.cfg), eng.theta.data_ptr(), eng.ws.data_ptr(), eng.state.data_ptr()
+    img, s = eng._bound[0].data_ptr(), eng.stream.cuda_stream
+    n_dec = eng.pl.n_vae - eng.pl.n_enc
+    part = lambda: eng.ws_view("part_dec", (eng.wl.n_part, n_dec))
+    _lib.call("svgp_mnist_decoder_bwd", cfg, th, img, ws, st, s)
+    eng.synchronize()
+    p0, z0 = part().clone(), eng.ws_view("zbar", (b, L)).clone()
+    eng.ws_view("zbar", (b, L)).zero_()
+    _lib.call("svgp_mnist_decoder_bwd_data", cfg, th, img, ws, st, s)
+    eng.synchronize()
+    assert torch.equal(eng.ws_view("zbar", (b, L)), z0)          # same helper, same order: bit-equal
+    scale = float(p0.abs().max())
+    for threads, n_types in ((256, 1), (256, 2), (256, 3), (512, 1), (512, 3)):
+        part().fill_(float("nan"))
+        _lib.call("svgp_mnist_decoder_bwd_weights", cfg, img, ws, st, threads, n_types, s)
+        eng.synchronize()
+        assert float((part() - p0).abs().max()) < 1e-13 * scale, (threads, n_types)
+    part().fill_(float("nan"))
+    _lib.call("svgp_gp_factor_bwd_nofinal_wgrad", cfg, img, ws, st, s)       # the riders
+    eng.synchronize()
+    assert float((part() - p0).abs().max()) < 1e-13 * scale
+
+
+def test_rider_launch_leaves_the_factor_stage_unchanged():
+    from svgp_vae_amd import _lib
+    eng, _ = _engine(64, 32, 16)
+    eng.run(adam=False)
+    eng.synchronize()
+    cfg, ws, st = C.byref(eng.cfg), eng.ws.data_ptr(), eng.state.data_ptr()
+    img, s = eng._bound[0].data_ptr(), eng.stream.cuda_stream
+    shapes = dict(fb_part=(2, 16, 32, 32), vbar=(16, 32), Ssym=(16, 32, 32), Qm=(16, 32, 32))
+    _lib.call("svgp_gp_factor_bwd_nofinal", cfg, ws, st, s)
+    eng.synchronize()
+    ref = {k: eng.ws_view(k, sh).clone() for k, sh in shapes.items()}
+    for k, sh in shapes.items():
+        eng.ws_view(k, sh).zero_()
+    _lib.call("svgp_gp_factor_bwd_nofinal_wgrad", cfg, img, ws, st, s)
+    eng.synchronize()
+    for k, sh in shapes.items():
+        assert torch.equal(eng.ws_view(k, sh), ref[k]), k
+
+
+@pytest.mark.parametrize("geco", [True, False])
+def test_step_gradients_match_oracle_and_the_one_kernel_step(geco, monkeypatch):
+    from oracle import svgpvae_oracle as O
+    grads = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SVGP_DEC_SPLIT", flag)
+        eng, (params, images, aux, eps) = _engine(48, 16, 4, geco=geco)
+        eng.run(adam=False)
+        eng.synchronize()
+        grads[flag] = {k: v.clone() for k, v in eng.grads().items()}
+        elbo = eng.scalars()["elbo"]
+    out, og = O.loss_and_grads(params, images, aux, eps, beta=0.001, C_ma=torch.zeros((), dtype=O.DT),
+                               lagrange_mult=torch.ones((), dtype=O.DT), alpha=0.0, kappa=math.sqrt(0.02),
+                               clipping_qs=True, GECO=geco, jitter=1e-6, N_train=400.0, L=4, formulation="efficient")
+    assert abs(elbo - float(out[0])) < 1e-9 * abs(float(out[0]))
+    for k, v in og.items():
+        assert H.relerr(grads["1"][k], v) < 1e-7, k
+        assert H.relerr(grads["1"][k], grads["0"][k]) < 1e-12, k
+
+
+def test_split_step_is_bitwise_reproducible():
+    eng, _ = _engine(256, 32, 16)
+    eng.run(adam=False)
+    eng.synchronize()
+    g0 = {k: v.clone() for k, v in eng.grads().items()}
+    for _ in range(3):
+        eng.reset_state()                 # the GECO state advances on the device also without Adam
+        eng.run(adam=False)
+        eng.synchronize()
+        for k, v in eng.grads().items():
+            assert torch.equal(v, g0[k]), k

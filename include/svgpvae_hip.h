@@ -295,6 +295,10 @@ int svgp_gp_factor_bwd_early_b(const svgp_mnist_cfg*, double* ws, const double* 
 int svgp_gp_factor_bwd_late_a(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_late_b(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+/* m <= 64: svgp_kernel_matrix_bwd_partials + svgp_mnist_encoder_bwd in ONE launch (the two are independent: both consume the
+ * reverse row stage; tf.gradients of SVGPVAE_model.py:427-476 and VAE_utils.py:112-126,143-152).  Results identical. */
+int svgp_mnist_encoder_bwd_km(const svgp_mnist_cfg*, const double* theta, const double* images, const double* aux,
+                              double* ws, void* stream);
 /* m <= 64: svgp_gp_factor_bwd_nofinal + svgp_mnist_decoder_bwd_weights(threads = 256) in ONE launch: the L channel workgroups
  * first, then min(b, 256) rider workgroups with the decoder's weight-gradient partials (needs svgp_mnist_decoder_bwd_data before). */
 int svgp_gp_factor_bwd_nofinal_wgrad(const svgp_mnist_cfg*, const double* images, double* ws, const double* state,

@@ -296,6 +296,11 @@ bool dec_split_on() {
     const char* e = getenv("SVGP_DEC_SPLIT");
     return !(e && e[0] == '0');
 }
+// m <= 64 (round 6): kernel-matrix VJP + encoder reverse pass in one launch.  SVGP_ENC_KM_MERGE=0: two launches.
+bool enc_km_merge_on() {
+    const char* e = getenv("SVGP_ENC_KM_MERGE");
+    return !(e && e[0] == '0');
+}
 bool konly_on() {
     static const int on = [] { const char* e = getenv("SVGP_KONLY_BRANCH"); return (e && e[0] == '0') ? 0 : 1; }();
     return on != 0;
@@ -395,10 +400,14 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         if (c->titsias) RUN(svgp_gp_titsias_bwd(c, ws, state, stream));
         // (m > 64, measured round 5: the kernel-matrix reverse pass on side branch 0 beside the encoder's does NOT overlap -- 68 KB +
         // 104 KB of LDS per workgroup do not fit one CU; the kernel-matrix launch stretched from 49 to 103 us and the step was unchanged)
-        if (fork2) RUN(side_fork(sd, 0, ms));
-        RUN(svgp_kernel_matrix_bwd_partials(c, theta, aux, ws, s2));
-        RUN(svgp_mnist_encoder_bwd(c, theta, images, ws, stream));
-        if (fork2) RUN(side_join(sd, 0, ms));
+        if (!large && !fork2 && enc_km_merge_on()) {
+            RUN(svgp_mnist_encoder_bwd_km(c, theta, images, aux, ws, stream));
+        } else {
+            if (fork2) RUN(side_fork(sd, 0, ms));
+            RUN(svgp_kernel_matrix_bwd_partials(c, theta, aux, ws, s2));
+            RUN(svgp_mnist_encoder_bwd(c, theta, images, ws, stream));
+            if (fork2) RUN(side_join(sd, 0, ms));
+        }
         RUN(svgp_mnist_grad_reduce_all(c, aux, ws, stream));
         break;
     case 3: {

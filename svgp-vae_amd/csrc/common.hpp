@@ -191,6 +191,20 @@ __device__ __forceinline__ real block_sum(real x, real* red) {
     return s;
 }
 
+// block_sum for a workgroup of which only the first nt threads (a multiple of 64) are alive: rider workgroups with fewer threads
+// than the launch they ride in (the other waves have exited; s_barrier counts the surviving waves only)
+__device__ __forceinline__ real block_sum_nt(real x, real* red, int nt) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = nt >> 6;
+    x = wave_sum(x);
+    __syncthreads();
+    if (lane == 0) red[w] = x;
+    __syncthreads();
+    real s = 0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < nw; ++i) s += red[i];
+    return s;
+}
+
 __device__ __forceinline__ real elu_f(real x) { return x > 0 ? x : expm1(x); }
 // derivative of ELU expressed through its OUTPUT: out > 0 -> 1, else exp(pre) = out + 1
 __device__ __forceinline__ real elu_grad_from_out(real out) { return out > 0 ? real(1) : out + real(1); }

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_xy(KernXYArgs a, r
 // MC / MM: compile-time m / GPLVM dimension M (0: run time); config 2 runs the <32, 8> instance (8 instead of 32 predicated
 // accumulators per thread, index divisions folded).  M > 32 (a kernel matrix of rank m needs M >= m / 16 object
 // dimensions -- m = 2048 wants M = 128): the row / column loops are repeated per chunk of 32 feature columns, 32 accumulators live.
-template <int MC, int MM>
+template <int MC, int MM, int NTL = 0>
 __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real rep_weight, int train_ip,
                                             const real* __restrict__ K, const real* __restrict__ Kn,
                                             const real* __restrict__ Kbar, const real* __restrict__ Knbar,
@@ -313,6 +313,7 @@ __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real
     __shared__ real res[KM_MTOT + 4];                      // [0, M): object-vector gradient; KM_MTOT + {0, 1, 2}: amp, ls, theta
     __shared__ real wred[SVGP_BLOCK / 64][KM_MAXM + 4];
     const int M = MM ? MM : a.M, m = MC ? MC : a.m, st = 2 + M;
+    const int nthr = NTL ? NTL : (int)blockDim.x;          // live threads (NTL: a rider of a launch with more threads per workgroup)
     const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
     const real* oj = a.ip + (size_t)j * st + 2;
     const real thj = a.ip[(size_t)j * st + 1];
@@ -323,7 +324,7 @@ __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real
 #pragma unroll
         for (int k = 0; k < KM_MAXM; ++k) acc_o[k] = 0;
         // ---- K_nm column j
-        for (int n = threadIdx.x; n < a.b; n += blockDim.x) {
+        for (int n = threadIdx.x; n < a.b; n += nthr) {
             const real gk = Knbar[(size_t)n * m + j];
             const real d = a.aux[(size_t)n * st + 1] - thj;
             const real V = view_k(d, a2, inv_l2);
@@ -339,7 +340,7 @@ __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real
                 if (k < Mc) acc_o[k] += c * on[k0 + k];
         }
         // ---- K_mm: row j (first argument) and column j (second argument), replicated across ranks
-        for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        for (int i = threadIdx.x; i < m; i += nthr) {
             const real* oi = a.ip + (size_t)i * st + 2;
             const real ni = a.normalize ? sqrt(dotM(oi, oi, M)) : real(1);
             const real d = thj - a.ip[(size_t)i * st + 1];          // theta_j - theta_i  (entry (j,i))
@@ -368,7 +369,7 @@ __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real
         __syncthreads();
         if (threadIdx.x < KM_MAXM + 3 && (threadIdx.x < Mc || (threadIdx.x >= KM_MAXM && k0 == 0))) {
             real sres = 0;
-            for (int wq = 0; wq < (int)(blockDim.x >> 6); ++wq) sres += wred[wq][threadIdx.x];
+            for (int wq = 0; wq < (nthr >> 6); ++wq) sres += wred[wq][threadIdx.x];
             res[threadIdx.x < KM_MAXM ? k0 + threadIdx.x : KM_MTOT + (threadIdx.x - KM_MAXM)] = sres;
         }
     }
@@ -394,13 +395,14 @@ __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real
 // VJP, batch-row side.  grid ceil(b/RB), RB = 256/m rows per workgroup.  Phase 1: thread (row, j)
 // computes c = Knbar * view(theta_n - theta_j) / |o_j|; phase 2: thread (row, k) reduces over j ->
 // d_on (b,M), the gradient of the gathered object row.  Also the k_nn part of the amplitude gradient.
-template <int MC, int MM>
+template <int MC, int MM, int NTL = 0>
 __device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, const real* __restrict__ Knbar,
                                             const real* __restrict__ knnbar, const real* __restrict__ knn,
                                             real* __restrict__ d_on, real* __restrict__ part_gp) {
     extern __shared__ __align__(16) real smem[];
     __shared__ real red[16];
-    const int m = MC ? MC : a.m, M = MM ? MM : a.M, st = 2 + M, RB = m >= (int)blockDim.x ? 1 : blockDim.x / m;
+    const int nthr = NTL ? NTL : (int)blockDim.x;
+    const int m = MC ? MC : a.m, M = MM ? MM : a.M, st = 2 + M, RB = m >= nthr ? 1 : nthr / m;
     // m x M inducing object vectors, divided by their norm when normalising: staged in LDS while they fit (km_stage_O, the
     // host sizes the launch with the same rule); else read from the parameter vector with the inverse norms (m) staged
     const bool stage_O = km_stage_O(m, M);
@@ -409,19 +411,19 @@ __device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, c
     real* gbuf = cbuf + RB * m;                 // RB x M
     const real amp = *a.amp, ls = *a.ls, a2 = amp * amp, inv_l2 = real(1) / (ls * ls);
     if (stage_O) {
-        for (int o = threadIdx.x; o < m * M; o += blockDim.x) {
+        for (int o = threadIdx.x; o < m * M; o += nthr) {
             const int j = o / M;
             const real* oj = a.ip + (size_t)j * st + 2;
             const real nj = a.normalize ? sqrt(dotM(oj, oj, M)) : real(1);
             O[o] = oj[o % M] / nj;
         }
     } else {
-        for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        for (int j = threadIdx.x; j < m; j += nthr) {
             const real* oj = a.ip + (size_t)j * st + 2;
             O[j] = a.normalize ? real(1) / sqrt(dotM(oj, oj, M)) : real(1);
         }
     }
-    for (int it = threadIdx.x; it < RB * m; it += blockDim.x) {
+    for (int it = threadIdx.x; it < RB * m; it += nthr) {
         const int nl = it / m, j = it % m, n = rblk * RB + nl;
         real c = 0;
         if (n < a.b)
@@ -429,7 +431,7 @@ __device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, c
         cbuf[it] = c;
     }
     __syncthreads();
-    for (int it = threadIdx.x; it < RB * M; it += blockDim.x) {
+    for (int it = threadIdx.x; it < RB * M; it += nthr) {
         const int nl = it / M, k = it % M, n = rblk * RB + nl;
         real g = 0;
         if (n < a.b) {
@@ -442,7 +444,7 @@ __device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, c
         gbuf[it] = g;
     }
     __syncthreads();
-    for (int it = threadIdx.x; it < RB * M; it += blockDim.x) {
+    for (int it = threadIdx.x; it < RB * M; it += nthr) {
         const int nl = it / M, k = it % M, n = rblk * RB + nl;
         if (n < a.b) {
             real v = gbuf[it];
@@ -461,7 +463,7 @@ __device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, c
         const int n = rblk * RB + threadIdx.x;
         if (threadIdx.x < RB && n < a.b) acc_amp = real(2) * knnbar[n] * knn[n] / amp;
     }
-    acc_amp = block_sum(acc_amp, red);
+    acc_amp = block_sum_nt(acc_amp, red, nthr);
     if (threadIdx.x == 0) {
         part_gp[(m + rblk) * 2 + 0] = acc_amp;
         part_gp[(m + rblk) * 2 + 1] = 0;
@@ -482,6 +484,29 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_cr(KernArgs a,
     const int m = MC ? MC : a.m;
     if ((int)blockIdx.x < m) km_bwd_cols<MC, MM>(blockIdx.x, a, rep_weight, train_ip, K, Kn, Kbar, Knbar, d_ip, part_gp);
     else km_bwd_rows<MC, MM>(blockIdx.x - m, a, Knbar, knnbar, knn, d_on, part_gp);
+}
+
+// Training step (m <= 64, round 6): the kernel-matrix VJP and the encoder's reverse pass are independent (both consume the
+// reverse row stage), so they share ONE launch of VAE_NT-thread workgroups: the m + nrb VJP workgroups come FIRST in the grid and
+// run on their first SVGP_BLOCK threads (the other waves exit at once), the image workgroups follow.  168 VGPRs and 75 KB of LDS
+// let a VJP workgroup and an image workgroup share a CU, so no image workgroup waits for a VJP workgroup to retire.
+template <int MC, int MM>
+__global__ __launch_bounds__(VAE_NT, MC ? 3 : 2) void k_encoder_bwd_km(svgp_vae::EncBwdArgs e, int n_km, KernArgs a, real rep_weight,
+                                                                 int train_ip, const real* __restrict__ K,
+                                                                 const real* __restrict__ Kn, const real* __restrict__ Kbar,
+                                                                 const real* __restrict__ Knbar,
+                                                                 const real* __restrict__ knnbar, const real* __restrict__ knn,
+                                                                 real* __restrict__ d_ip, real* __restrict__ d_on,
+                                                                 real* __restrict__ part_gp) {
+    if ((int)blockIdx.x < n_km) {
+        if (threadIdx.x >= SVGP_BLOCK) return;
+        const int m = MC ? MC : a.m;
+        if ((int)blockIdx.x < m) km_bwd_cols<MC, MM, SVGP_BLOCK>(blockIdx.x, a, rep_weight, train_ip, K, Kn, Kbar, Knbar, d_ip, part_gp);
+        else km_bwd_rows<MC, MM, SVGP_BLOCK>(blockIdx.x - m, a, Knbar, knnbar, knn, d_on, part_gp);
+        return;
+    }
+    extern __shared__ __align__(16) real smem[];
+    svgp_vae::encoder_bwd_images<VAE_NT>(e, (int)blockIdx.x - n_km, (int)gridDim.x - n_km, smem);
 }
 
 // Deterministic scatter-add of d_on into the object table gradient + the final amplitude / length-scale sums
@@ -1308,6 +1333,32 @@ static int kernel_matrix_bwd_impl(const svgp_mnist_cfg* c, const double* theta, 
                            ws + wl.d_on, ws + wl.part_gp, grad + pl.ov, grad + pl.l_GP, grad + pl.amplitude);
         SVGP_LAUNCH_CHECK();
     }
+    return SVGP_OK;
+}
+
+// svgp_kernel_matrix_bwd_partials + svgp_mnist_encoder_bwd in ONE launch (m <= 64; see k_encoder_bwd_km)
+extern "C" int svgp_mnist_encoder_bwd_km(const svgp_mnist_cfg* c, const double* theta, const double* images, const double* aux,
+                                         double* ws, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(theta && images && aux && ws, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m <= SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the merged launch exists for m <= %d", SVGP_M_MAX);
+    KernArgs a = make_kern_args(c, pl, theta, aux);
+    real* grad = ws + wl.grad;
+    const int RBk = svgp_rows_per_block(c), nrb = (c->b + RBk - 1) / RBk, n_km = c->m + nrb;
+    const size_t lds_rows = (size_t)((km_stage_O(c->m, c->M) ? c->m * c->M : c->m) + RBk * c->m + RBk * c->M) * sizeof(real);
+    size_t lds = (size_t)svgp_vae::enc_bwd_lds((int)pl.n_enc) * sizeof(real);
+    if (lds_rows > lds) lds = lds_rows;
+    const bool cfg2_shape = c->m == 32 && c->M == 8;
+    int rc = cfg2_shape ? set_dyn_lds(k_encoder_bwd_km<32, 8>, lds) : set_dyn_lds(k_encoder_bwd_km<0, 0>, lds);
+    if (rc) return rc;
+    const svgp_vae::EncBwdArgs e = svgp_make_enc_bwd_args(c, wl, theta, images, ws);
+    const dim3 grid(n_km + svgp_n_part(c));
+#define KM_BWD_ARGS e, n_km, a, (real)c->rep_weight, c->train_ip, ws + wl.K, ws + wl.Kn, ws + wl.Kbar, ws + wl.Knbar, ws + wl.knnbar, \
+                    ws + wl.knn, grad + pl.ip, ws + wl.d_on, ws + wl.part_gp
+    if (cfg2_shape) hipLaunchKernelGGL((k_encoder_bwd_km<32, 8>), grid, dim3(VAE_NT), lds, (hipStream_t)stream, KM_BWD_ARGS);
+    else hipLaunchKernelGGL((k_encoder_bwd_km<0, 0>), grid, dim3(VAE_NT), lds, (hipStream_t)stream, KM_BWD_ARGS);
+#undef KM_BWD_ARGS
+    SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
 

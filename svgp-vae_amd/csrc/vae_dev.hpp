@@ -604,8 +604,92 @@ __device__ __forceinline__ void decoder_wgrad_rider(const DecWgradArgs& a, int r
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// encoder reverse: (ybar, s2bar) -> encoder weight-gradient partials; one workgroup of NT threads walks images first,
+// first + stride, ...; partial slot = first.  LDS: enc_bwd_lds(n_enc) reals (75 KB at L = 16: the launch that carries the
+// kernel-matrix VJP as well, svgp_mnist_encoder_bwd_km, holds a VJP workgroup and an image workgroup on one CU).
+// Reference semantics: tf.gradients of VAE_utils.py:112-126,143-152 w.r.t. the encoder variables (MNIST_experiment.py:202-205).
+// ------------------------------------------------------------------------------------------
+struct EncBwdArgs {
+    int b, L, clip;
+    const real* th_enc; const real* images; const real* a1g; const real* a2g; const real* a3g; const real* var_raw;
+    const real* ybar; const real* s2bar;
+    real* part;                          // (n_part, eo.n)
+};
+#define ENC_BWD_SCRATCH 512              // 72 outputs x 7 pixel chunks of the first layer's weight gradient; 256 for the bias sums
+__host__ __device__ constexpr int enc_bwd_lds(int n_enc) {
+    return 2 * n_enc + 784 + 1352 + 288 + 32 + 1352 + 288 + 32 + 128 + ENC_BWD_SCRATCH;
+}
+
+template <int NT>
+__device__ __forceinline__ void encoder_bwd_images(const EncBwdArgs& a, int first, int stride, real* smem) {
+    const int L = a.L;
+    const EncOff eo = enc_off(L);
+    real* w = smem;                  // eo.n
+    real* g = w + eo.n;              // eo.n   gradient accumulators
+    real* img = g + eo.n;            // 784
+    real* a1 = img + 784;            // 1352
+    real* a2 = a1 + 1352;            // 288
+    real* a3 = a2 + 288;             // 32
+    real* d1 = a3 + 32;              // 1352
+    real* d2 = d1 + 1352;            // 288
+    real* d3 = d2 + 288;             // 32
+    real* dout = d3 + 32;            // 2L (<=128)
+    real* scratch = dout + 128;      // ENC_BWD_SCRATCH
+    using C1 = Conv3<28, 1, 0, 2, 1, 8, 13, NT>;
+    using C2 = Conv3<13, 1, 0, 2, 8, 8, 6, NT>;
+    using C3 = Conv3<6, 1, 0, 2, 8, 8, 2, NT>;
+    static_assert(72 * (NT / 72) <= ENC_BWD_SCRATCH, "first-layer chunk scratch");
+    lds_copy_in(w, a.th_enc, eo.n);
+    lds_zero(g, eo.n);
+    const int twoL = 2 * L;
+    for (int n = first; n < a.b; n += stride) {
+        __syncthreads();
+        lds_copy_in(img, a.images + (size_t)n * 784, 784);
+        lds_copy_in(a1, a.a1g + (size_t)n * 1352, 1352);
+        lds_copy_in(a2, a.a2g + (size_t)n * 288, 288);
+        lds_copy_in(a3, a.a3g + (size_t)n * 32, 32);
+        for (int j = threadIdx.x; j < twoL; j += NT) {
+            real dj;
+            if (j < L) {
+                dj = a.ybar[(size_t)n * L + j];
+            } else {
+                const real vr = a.var_raw[(size_t)n * L + j - L];
+                const bool pass = !a.clip || (vr >= 1e-3 && vr <= 10.0);
+                dj = pass ? a.s2bar[(size_t)n * L + j - L] * vr : real(0);
+            }
+            dout[j] = dj;
+        }
+        __syncthreads();
+        // dense: weight / bias gradients and da3
+        for (int o = threadIdx.x; o < 32 * twoL; o += NT) g[eo.dw + o] += a3[o / twoL] * dout[o % twoL];
+        for (int j = threadIdx.x; j < twoL; j += NT) g[eo.db + j] += dout[j];
+        if (threadIdx.x < 32) {
+            real acc = 0;
+            for (int j = 0; j < twoL; ++j) acc += dout[j] * w[eo.dw + threadIdx.x * twoL + j];
+            d3[threadIdx.x] = acc * elu_grad_from_out(a3[threadIdx.x]);
+        }
+        __syncthreads();
+        C3::bwd_weight(a2, d3, g + eo.c3w, g + eo.c3b, scratch);
+        C3::bwd_data(d3, w + eo.c3w, d2);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 288; i += NT) d2[i] *= elu_grad_from_out(a2[i]);
+        __syncthreads();
+        C2::bwd_weight(a1, d2, g + eo.c2w, g + eo.c2b, scratch);
+        C2::bwd_data(d2, w + eo.c2w, d1);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1352; i += NT) d1[i] *= elu_grad_from_out(a1[i]);
+        __syncthreads();
+        C1::bwd_weight(img, d1, g + eo.c1w, g + eo.c1b, scratch);
+    }
+    __syncthreads();
+    lds_copy_out(a.part + (size_t)first * eo.n, g, eo.n);
+}
+
 }  // namespace svgp_vae
 
 // vae_mnist.hip: the weight half's arguments from a configuration + workspace (riders of the reverse factor launch, gp_kernels.hip)
 svgp_vae::DecWgradArgs svgp_make_dec_wgrad_args(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, const double* images,
                                                 double* ws, const double* state, int n_types);
+svgp_vae::EncBwdArgs svgp_make_enc_bwd_args(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, const double* theta,
+                                            const double* images, double* ws);

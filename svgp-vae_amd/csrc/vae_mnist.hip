@@ -71,72 +71,12 @@ __global__ __launch_bounds__(VAE_NT) void k_encoder_fwd(int b, int L, int clip, 
 }
 
 // ------------------------------------------------------------------------------------------
-// encoder reverse: (ybar, s2bar) -> encoder weight-gradient partials
+// encoder reverse: (ybar, s2bar) -> encoder weight-gradient partials (encoder_bwd_images, vae_dev.hpp; the training step
+// runs the same device function in a launch that also carries the kernel-matrix VJP: svgp_mnist_encoder_bwd_km)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(VAE_NT) void k_encoder_bwd(int b, int L, int clip, const real* __restrict__ th_enc,
-                                                            const real* __restrict__ images,
-                                                            const real* __restrict__ a1g, const real* __restrict__ a2g,
-                                                            const real* __restrict__ a3g,
-                                                            const real* __restrict__ var_raw,
-                                                            const real* __restrict__ ybar,
-                                                            const real* __restrict__ s2bar, real* __restrict__ part) {
+__global__ __launch_bounds__(VAE_NT) void k_encoder_bwd(EncBwdArgs a) {
     extern __shared__ __align__(16) real smem[];
-    const EncOff eo = enc_off(L);
-    real* w = smem;                  // eo.n
-    real* g = w + eo.n;              // eo.n   gradient accumulators
-    real* img = g + eo.n;            // 784
-    real* a1 = img + 784;            // 1352
-    real* a2 = a1 + 1352;            // 288
-    real* a3 = a2 + 288;             // 32
-    real* d1 = a3 + 32;              // 1352
-    real* d2 = d1 + 1352;            // 288
-    real* d3 = d2 + 288;             // 32
-    real* dout = d3 + 32;            // 2L (<=128)
-    real* scratch = dout + 128;      // VAE_SCRATCH
-    lds_copy_in(w, th_enc, eo.n);
-    lds_zero(g, eo.n);
-    const int twoL = 2 * L;
-    for (int n = blockIdx.x; n < b; n += gridDim.x) {
-        __syncthreads();
-        lds_copy_in(img, images + (size_t)n * 784, 784);
-        lds_copy_in(a1, a1g + (size_t)n * 1352, 1352);
-        lds_copy_in(a2, a2g + (size_t)n * 288, 288);
-        lds_copy_in(a3, a3g + (size_t)n * 32, 32);
-        for (int j = threadIdx.x; j < twoL; j += blockDim.x) {
-            real dj;
-            if (j < L) {
-                dj = ybar[(size_t)n * L + j];
-            } else {
-                const real vr = var_raw[(size_t)n * L + j - L];
-                const bool pass = !clip || (vr >= 1e-3 && vr <= 10.0);
-                dj = pass ? s2bar[(size_t)n * L + j - L] * vr : real(0);
-            }
-            dout[j] = dj;
-        }
-        __syncthreads();
-        // dense: weight / bias gradients and da3
-        for (int o = threadIdx.x; o < 32 * twoL; o += blockDim.x) g[eo.dw + o] += a3[o / twoL] * dout[o % twoL];
-        for (int j = threadIdx.x; j < twoL; j += blockDim.x) g[eo.db + j] += dout[j];
-        if (threadIdx.x < 32) {
-            real acc = 0;
-            for (int j = 0; j < twoL; ++j) acc += dout[j] * w[eo.dw + threadIdx.x * twoL + j];
-            d3[threadIdx.x] = acc * elu_grad_from_out(a3[threadIdx.x]);
-        }
-        __syncthreads();
-        EncC3::bwd_weight(a2, d3, g + eo.c3w, g + eo.c3b, scratch);
-        EncC3::bwd_data(d3, w + eo.c3w, d2);
-        __syncthreads();
-        for (int i = threadIdx.x; i < 288; i += blockDim.x) d2[i] *= elu_grad_from_out(a2[i]);
-        __syncthreads();
-        EncC2::bwd_weight(a1, d2, g + eo.c2w, g + eo.c2b, scratch);
-        EncC2::bwd_data(d2, w + eo.c2w, d1);
-        __syncthreads();
-        for (int i = threadIdx.x; i < 1352; i += blockDim.x) d1[i] *= elu_grad_from_out(a1[i]);
-        __syncthreads();
-        EncC1::bwd_weight(img, d1, g + eo.c1w, g + eo.c1b, scratch);
-    }
-    __syncthreads();
-    lds_copy_out(part + (size_t)blockIdx.x * eo.n, g, eo.n);
+    encoder_bwd_images<VAE_NT>(a, blockIdx.x, gridDim.x, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -484,12 +424,11 @@ extern "C" int svgp_mnist_encoder_bwd(const svgp_mnist_cfg* c, const double* the
                                       void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(theta && images && ws, SVGP_ERR_INVALID, "NULL device pointer");
-    const size_t lds = (size_t)(2 * pl.n_enc + 784 + 1352 + 288 + 32 + 1352 + 288 + 32 + 128 + VAE_SCRATCH) * sizeof(real);
+    const size_t lds = (size_t)enc_bwd_lds((int)pl.n_enc) * sizeof(real);
     int rc = set_dyn_lds(k_encoder_bwd, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_encoder_bwd, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
-                       c->clip_qs, theta, images, ws + wl.enc_a1, ws + wl.enc_a2, ws + wl.enc_a3,
-                       ws + wl.qnet_var_raw, ws + wl.ybar, ws + wl.s2bar, ws + wl.part_enc);
+    hipLaunchKernelGGL(k_encoder_bwd, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream,
+                       svgp_make_enc_bwd_args(c, wl, theta, images, ws));
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
@@ -539,6 +478,16 @@ extern "C" int svgp_mnist_decoder_bwd_data(const svgp_mnist_cfg* c, const double
                        ws + wl.recon, ws + wl.dec_d2, ws + wl.dec_d1, ws + wl.dec_dh0, ws + wl.zbar);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
+}
+
+// gp_kernels.hip (svgp_mnist_encoder_bwd_km) and svgp_mnist_encoder_bwd above
+svgp_vae::EncBwdArgs svgp_make_enc_bwd_args(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, const double* theta,
+                                            const double* images, double* ws) {
+    EncBwdArgs a;
+    a.b = c->b; a.L = c->L; a.clip = c->clip_qs; a.th_enc = theta; a.images = images;
+    a.a1g = ws + wl.enc_a1; a.a2g = ws + wl.enc_a2; a.a3g = ws + wl.enc_a3; a.var_raw = ws + wl.qnet_var_raw;
+    a.ybar = ws + wl.ybar; a.s2bar = ws + wl.s2bar; a.part = ws + wl.part_enc;
+    return a;
 }
 
 // gp_kernels.hip (the riders of the reverse factor launch) and the stand-alone launch below

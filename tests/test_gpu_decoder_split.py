@@ -100,3 +100,31 @@ def test_split_step_is_bitwise_reproducible():
         eng.synchronize()
         for k, v in eng.grads().items():
             assert torch.equal(v, g0[k]), k
+
+
+@pytest.mark.parametrize("b,m,L,M", [(256, 32, 16, 8), (48, 16, 4, 4), (300, 24, 5, 4)])
+def test_encoder_reverse_and_kernel_matrix_vjp_in_one_launch(b, m, L, M):
+    """svgp_mnist_encoder_bwd_km == svgp_kernel_matrix_bwd_partials + svgp_mnist_encoder_bwd, bit for bit (the VJP workgroups run
+    on the first 256 threads of 512-thread workgroups whose other waves exit at once)."""
+    from svgp_vae_amd import _lib
+    params, images, aux, eps = H.toy_problem(b=b, m=m, L=L, M=M, n_obj=20, seed=5)
+    eng = H.engine_for(params, b, geco=True, N_train=400.0)
+    dev = eng.device
+    eng.bind(images.to(dev), aux.to(dev), eps.to(dev))
+    eng.run(adam=False)
+    eng.synchronize()
+    cfg, th, ws = C.byref(eng.cfg), eng.theta.data_ptr(), eng.ws.data_ptr()
+    img, ax, s = eng._bound[0].data_ptr(), eng._bound[1].data_ptr(), eng.stream.cuda_stream
+    nrb = (b + (256 // m) - 1) // (256 // m)
+    views = lambda: dict(part_enc=eng.ws_view("part_enc", (eng.wl.n_part, eng.pl.n_enc)), d_on=eng.ws_view("d_on", (b, M)),
+                         part_gp=eng.ws_view("part_gp", (m + nrb, 2)), ip=eng.grads()["inducing_index_points"])
+    _lib.call("svgp_kernel_matrix_bwd_partials", cfg, th, ax, ws, s)
+    _lib.call("svgp_mnist_encoder_bwd", cfg, th, img, ws, s)
+    eng.synchronize()
+    ref = {k: v.clone() for k, v in views().items()}
+    for v in views().values():
+        v.fill_(float("nan"))
+    _lib.call("svgp_mnist_encoder_bwd_km", cfg, th, img, ax, ws, s)
+    eng.synchronize()
+    for k, v in views().items():
+        assert torch.equal(v, ref[k]), k

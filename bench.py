@@ -186,91 +186,10 @@ def synthetic_problem(rank, B, M_IND, MDIM, seed=0):
 
 
 def library_comm(multi, local_rank, dev, timeout_s=180.0, make_id=None, make_comm=None):
-    """The library's own RCCL communicator (engine.RcclComm), or (None, reason).  With several ranks the decision is COLLECTIVE
-    and every collective of the decision is issued by the MAIN thread of every rank in the same order, whatever fails where:
-      1. rank 0 creates the unique id (or None on failure) and broadcasts it -- all ranks take part, always;
-      2. MIN over ranks of "I hold an id and my library loaded" -- a rank that cannot even load the library is seen here,
-         before anybody enters ncclCommInitRank (which would otherwise wait for it);
-      3. ONLY ncclCommInitRank (no torch.distributed call) runs in a helper thread with a time limit;
-      4. MIN over ranks of "my communicator exists".
-    A rank that fails or times out anywhere therefore never leaves the others in a collective it does not join
-    (the id broadcast used to sit inside the helper thread, so a rank failing before it paired its all_reduce
-    with the other ranks' broadcast).  `make_id` / `make_comm(rank, world, id)` are injectable for the CPU (gloo) test of the
-    decision path; test hooks: SVGP_BENCH_FAIL_LIBCOMM=1 (every rank), SVGP_BENCH_FAIL_LIBCOMM_RANK=<r>[:id|:init] (one rank)."""
-    if make_id is None or make_comm is None:
-        from svgp_vae_amd.engine import RcclComm
-        make_id = make_id or RcclComm.unique_id
-        make_comm = make_comm or RcclComm
-    if not multi:
-        try:
-            return make_comm(0, 1, make_id()), None
-        except Exception as e:
-            return None, repr(e)
-    import threading
-    import torch.distributed as dist
-    rank, world = dist.get_rank(), dist.get_world_size()
-    hook_all = os.environ.get("SVGP_BENCH_FAIL_LIBCOMM") == "1"
-    hook_rank, _, hook_where = os.environ.get("SVGP_BENCH_FAIL_LIBCOMM_RANK", "").partition(":")
-    hook_me = hook_rank != "" and int(hook_rank) == rank
-    on_gpu = torch.device(dev).type == "cuda"
-
-    def vote(flag):
-        ok = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=dev)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        return float(ok.item()) >= 0.5
-
-    # 1. the id: created by rank 0 on its main thread, broadcast by every rank's main thread
-    why, box = None, [None]
-    if rank == 0:
-        try:
-            if hook_all or (hook_me and hook_where in ("", "id")):
-                raise RuntimeError("library communicator disabled by SVGP_BENCH_FAIL_LIBCOMM")
-            box[0] = make_id()
-        except Exception as e:
-            why = repr(e)
-    dist.broadcast_object_list(box, src=0)
-    # 2. every rank holds an id and can reach its library
-    mine = box[0] is not None
-    if mine and rank != 0:
-        try:
-            if hook_all or (hook_me and hook_where in ("", "id")):
-                raise RuntimeError("library communicator disabled by SVGP_BENCH_FAIL_LIBCOMM")
-            make_id()                                  # loads the library and resolves RCCL on this rank (id discarded)
-        except Exception as e:
-            mine, why = False, repr(e)
-    if not vote(mine):
-        return None, why or "another rank has no unique id / library"
-    # 3. ncclCommInitRank alone, time-limited
-    res = {}
-
-    def work():
-        try:
-            if on_gpu:
-                torch.cuda.set_device(local_rank)      # the current device is per thread; ncclCommInitRank binds to it
-            if hook_me and hook_where == "init":
-                raise RuntimeError("library communicator disabled by SVGP_BENCH_FAIL_LIBCOMM_RANK")
-            res["comm"] = make_comm(rank, world, box[0])
-        except Exception as e:
-            res["err"] = repr(e)
-
-    t = threading.Thread(target=work, daemon=True)
-    t.start()
-    t.join(timeout_s)
-    why = "ncclCommInitRank timed out" if t.is_alive() else res.get("err")
-    # 4. everybody has a communicator, or nobody uses one
-    if not vote(res.get("comm") is not None and not t.is_alive()):
-        # this rank may hold a communicator the vote has just discarded: release it (ADVICE r4); a helper thread still inside
-        # ncclCommInitRank cannot be interrupted from here -- it is a daemon thread and is reported
-        mine = res.get("comm")
-        if mine is not None and hasattr(mine, "close"):
-            try:
-                mine.close()
-            except Exception as e:
-                why = f"{why or ''} (closing the discarded communicator failed: {e!r})".strip()
-        if t.is_alive():
-            why = (why or "") + " [helper thread still inside ncclCommInitRank]"
-        return None, why or "another rank has no communicator"
-    return res["comm"], None
+    """The library's own RCCL communicator, decided collectively: svgp_vae_amd.dp.library_comm (shared with the *_experiment.py
+    drivers).  Test hooks: SVGP_BENCH_FAIL_LIBCOMM=1 (every rank), SVGP_BENCH_FAIL_LIBCOMM_RANK=<r>[:id|:init] (one rank)."""
+    from svgp_vae_amd.dp import library_comm as impl
+    return impl(multi, local_rank, dev, timeout_s=timeout_s, make_id=make_id, make_comm=make_comm)
 
 
 def stage_table(eng, B, M_IND):
@@ -458,10 +377,22 @@ def run_mnist(args):
     modes = [args.scaling] if args.scaling else (["strong", "weak"] if multi else ["weak"])
     strong = None
     for mode in modes:
-        line = mnist_case(args, mode, multi, dev, ctx)
+        # Without an explicit --scaling the strong case is BEST EFFORT: it must never cost the run its headline (weak)
+        # line.  A global batch the rank count does not divide is skipped with a note -- decided from the arguments alone, so
+        # every rank skips together -- and an ELBO further than 1e-8 from the oracle is reported in the line, not asserted.
+        best_effort = mode == "strong" and not args.scaling
+        if best_effort:
+            gb = args.global_batch or ((1024 if args.workload == "cfg3" else 256))
+            if gb % world:
+                if rank == 0:
+                    print(f"[bench] strong-scaling case skipped: global batch {gb} is not divisible by {world} ranks",
+                          file=sys.stderr, flush=True)
+                continue
+        line = mnist_case(args, mode, multi, dev, ctx, strict=not best_effort)
         if rank == 0:
             if mode == "strong":
-                strong = {k: line[k] for k in ("value", "unit", "ms_per_step", "elbo", "elbo_rel_err_gpu_vs_oracle", "block_ms")}
+                strong = {k: line.get(k) for k in ("value", "unit", "ms_per_step", "elbo", "elbo_rel_err_gpu_vs_oracle", "block_ms",
+                                                   "elbo_within_1e-8_of_oracle")}
                 strong["global_batch"] = line["config"]["global_batch"]
                 strong["collectives_us_total"] = line.get("collectives_us_total")
             elif strong is not None:
@@ -471,7 +402,7 @@ def run_mnist(args):
         dist.destroy_process_group()
 
 
-def mnist_case(args, scaling, multi, dev, ctx):
+def mnist_case(args, scaling, multi, dev, ctx, strict=True):
     rank, local_rank, world = dist_env()
     import torch.distributed as dist
     cfg3 = args.workload == "cfg3"
@@ -527,7 +458,10 @@ def mnist_case(args, scaling, multi, dev, ctx):
         assert elbo_rel < 1e-3, f"ELBO parity failed at {world} rank(s): GPU {gpu_elbo} oracle {want}"
         # the strong line's global batch is the same rows at every rank count: agreeing with the oracle to 1e-8 at N = 1, 2, 4, 8
         # IS the cross-N equality of SURVEY 8e (the `elbo` field of the lines can also be compared directly)
-        assert scaling != "strong" or elbo_rel < 1e-8, f"strong-scaling ELBO at {world} rank(s): GPU {gpu_elbo} oracle {want}"
+        if scaling == "strong" and elbo_rel >= 1e-8:
+            msg = f"strong-scaling ELBO at {world} rank(s): GPU {gpu_elbo} oracle {want} (rel {elbo_rel:.2e} >= 1e-8)"
+            assert not strict, msg            # a hard failure only with an explicit --scaling strong
+            print("[bench] " + msg, file=sys.stderr, flush=True)
     if multi:
         dist.barrier()
 
@@ -604,6 +538,8 @@ def mnist_case(args, scaling, multi, dev, ctx):
                                         "strong: global batch fixed, rows per GPU = global / N")},
             "elbo_rel_err_gpu_vs_oracle": elbo_rel,
         }
+        if scaling == "strong" and elbo_rel is not None:
+            line["elbo_within_1e-8_of_oracle"] = bool(elbo_rel < 1e-8)
         top = stage_rows[0]
         traffic, src = committed_traffic("k_" + top["stage"]) if not cfg3 else (None, None)
         roof = roofline_of(top["flops"], top["bytes"], top["us"], F64_PEAK_TFLOPS, kernel=top["stage"],
@@ -667,16 +603,48 @@ def run_sprites(args):
     import torch.distributed as dist
     from svgp_vae_amd import sprites as S
     from svgp_vae_amd.engine import RcclComm
-    multi = world > 1
-    comm = None
+    multi = world > 1 or args.force_dist          # --force-dist: process group + communicator + exchange points with ONE rank
+    comm, comm_why = None, None
     if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        comm = RcclComm.from_process_group()
+        # the library's communicator when EVERY rank can create one (collective MIN vote), torch.distributed otherwise
+        from svgp_vae_amd.dp import TorchDistComm
+        comm, comm_why = library_comm(True, local_rank, torch.device(f"cuda:{local_rank}"))
+        if comm is None:
+            print(f"[bench] rank {rank}: in-library RCCL communicator unavailable ({comm_why}); exchanging through "
+                  f"torch.distributed", file=sys.stderr, flush=True)
+            comm = TorchDistComm()
     elif args.force_comm:
         comm = RcclComm(0, 1, RcclComm.unique_id())
-    b, frames, L_, La, Lc, n_act, m = 500, 50, 64, 8, 16, 72, args.m or 800
-    ip, table, img, ids, eps = sprites_problem(rank, b, L_, La, Lc, n_act, m)
+    # several ranks and no explicit --scaling: the strong line first (the configuration's own 500 frames cut in whole 50-frame
+    # character groups -- one ELBO at every rank count, checked against the oracle), then the weak line, which stays last
+    modes = [args.scaling] if args.scaling else (["strong", "weak"] if multi and world <= 10 else ["weak"])
+    for scaling in modes:
+        sprites_case(args, scaling, multi, comm, comm_why)
+    if multi:
+        dist.destroy_process_group()
+
+
+def sprites_case(args, scaling, multi, comm, comm_why):
+    rank, local_rank, world = dist_env()
+    import torch.distributed as dist
+    from svgp_vae_amd import sprites as S
+    frames, L_, La, Lc, n_act, m = 50, 64, 8, 16, 72, args.m or 800
+    if scaling == "strong":
+        # the SAME 500 frames (rank 0's synthetic batch) at every rank count, cut in whole 50-frame character groups
+        from svgp_vae_amd.dp import shard_batch
+        gb = args.global_batch or 500
+        lo, hi = shard_batch(0, gb, world, rank, frames)
+        if hi <= lo:
+            raise SystemExit(f"--scaling strong: {gb} frames leave rank {rank} of {world} without a character group")
+        ip, table, img, ids, eps = sprites_problem(0, gb, L_, La, Lc, n_act, m)
+        img, ids, eps = img[lo:hi], ids[lo:hi], eps[lo:hi]
+        b, b_global, b_cap = hi - lo, gb, -(-(gb // frames) // world) * frames
+    else:
+        b = b_global = b_cap = 500
+        b_global = b * world
+        ip, table, img, ids, eps = sprites_problem(rank, b, L_, La, Lc, n_act, m)
     k_se = args.kernel == "se"
     svgp = S.spritesSVGP(False, False, ip, 'main', 0.01, 50000, La, table, Lc, L_, K_obj_normalize=True, K_SE=k_se)
     if k_se:
@@ -684,7 +652,7 @@ def run_sprites(args):
     f32 = args.precision == "f32"
     # f32: the networks in float32 (the reference's dtype, VAE_utils.py:277); the GP block stays float64 unless --gemm-f32
     # asks otherwise (float32 products lose parity / stability at m = 800: tests/test_gpu_f32.py)
-    eng = S.SpritesStepEngine(S.spritesVAE(L_), S.sprites_representation_network(Lc), svgp, b_max=b, seg_len=frames,
+    eng = S.SpritesStepEngine(S.spritesVAE(L_), S.sprites_representation_network(Lc), svgp, b_max=b_cap, seg_len=frames,
                               geco=True, kappa_squared=0.0075, clip_grad=1e6, device=f"cuda:{local_rank}", rank=rank,
                               world_size=world, comm=comm, net_dtype=torch.float32 if f32 else torch.float64,
                               gemm_f32=args.gemm_f32,
@@ -694,10 +662,10 @@ def run_sprites(args):
     dev = eng.dev
     d_img, d_ids, d_eps = img.to(dev, eng.ndt), ids.to(dev), eps.to(dev)
     # parity gate (N = 1): explicit-eps step, ELBO against the oracle's efficient formulation -- inside cpu_baseline
-    eng.step(d_img, d_ids, d_eps, adam=False)
+    eng.step(d_img, d_ids, d_eps, adam=False, b_global=b_global)
     gpu_elbo = eng.scalars()["elbo"]
     eng.set_scalars(c_ma=0.0, lagrange=1.0, alpha=0.0)
-    step = lambda: eng.step(d_img, d_ids, None, adam=True)
+    step = lambda: eng.step(d_img, d_ids, None, adam=True, b_global=b_global)
     blocks = timed_blocks(step, eng.stream.synchronize, args.steps, args.warmup, args.repeats, multi, dev)
     el = float(np.median(blocks))
     # ---- stage times: HIP events recorded on the engine's stream at the stage boundaries of one more step
@@ -744,17 +712,21 @@ def run_sprites(args):
         nets, gp = sprites_flops(b, L_, m)
         ms = el / args.steps * 1e3
         line = {
-            "metric": f"SVGPVAE train steps/sec, SPRITES 64x64 (m={m}, L=64, 500 frames per GPU)",
-            "value": world * args.steps / el, "unit": "steps/s (500-frame batches, whole job)", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+            "metric": f"SVGPVAE train steps/sec, SPRITES 64x64 (m={m}, L=64, 500 frames per GPU)" if scaling == "weak" else
+                      f"SVGPVAE train steps/sec, SPRITES 64x64 (m={m}, L=64, {b_global} frames per step over all GPUs)",
+            "value": world * args.steps / el if scaling == "weak" else args.steps / el,
+            "unit": "steps/s (500-frame batches, whole job)" if scaling == "weak" else f"steps/s ({b_global}-frame global batches)",
+            "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": eng.dtype_name, "data": "synthetic",
             "repeats": args.repeats, "block_ms": [round(x * 1e3, 3) for x in blocks], "timing": "median block",
             "config": {"workload": f"BASELINE configs[3] shape: SPRITES SVGPVAE_Hensman + GPLVM, {b} frames per GPU "
                                    f"(10 characters x 50), L=64, L_action=8, L_character=16, m={m}, jitter 0.01, "
                                    + ("SE x SE kernel (--K_SE; full-rank K_mm)" if k_se else "cosine-normalised linear x linear kernel")
                                    + ", GECO, gradient clip 1e6",
-                       "global_batch": b * world, "rows_per_gpu": b, "parallelism": f"dp{world}",
-                       "rccl_ranks": None if comm is None else comm.world_size,
+                       "global_batch": b_global, "rows_per_gpu": b, "parallelism": f"dp{world}",
+                       "rccl_ranks": None if (comm is None or comm_why is not None) else comm.world_size,
+                       "comm_fallback": comm_why,
                        "exchange": None if comm is None else (
                            "channel-sharded, one grouped RCCL launch per point, symmetric blocks tile-packed: reduce-scatter "
                            "S,v | all-gather Sigma^-1,M2,t,u | reduce-scatter A2,ud,td | all-gather Ssym,vbar,KL | all-reduce "
@@ -798,12 +770,13 @@ def run_sprites(args):
                      else ["ar[S|v]", "ar[A2|ud|td]", "ar[grad|sums]"])
             line["collectives_us"] = dict(zip(names, coll_us))
             line["collectives_us_total"] = round(sum(coll_us), 1)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_sprites(gpu_elbo, m, k_se)
-            line["elbo_rel_err_gpu_vs_oracle"] = line["cpu_baseline"].pop("elbo_rel_err_gpu_vs_oracle")
+        # the oracle step is on rank 0's 500 frames: the batch of the one-rank run and of the strong case at any rank count
+        if (world == 1 or (scaling == "strong" and b_global == 500)) and not args.no_cpu_baseline:
+            cb = cpu_baseline_sprites(gpu_elbo, m, k_se)
+            line["elbo_rel_err_gpu_vs_oracle"] = cb.pop("elbo_rel_err_gpu_vs_oracle")
+            if world == 1 and scaling == "weak":
+                line["cpu_baseline"] = cb
         emit(line)
-    if multi:
-        dist.destroy_process_group()
 
 
 def cpu_worker_sprites(m, k_se=False):
@@ -845,13 +818,17 @@ def run_cfg5(args):
     rank, local_rank, world = dist_env()
     import torch.distributed as dist
     from svgp_vae_amd import stream_stats as SS
-    multi = world > 1
-    comm = None
+    multi = world > 1 or args.force_dist          # --force-dist: process group + communicator + the S, v all-reduce with ONE rank
+    comm, comm_why = None, None
     if multi:
-        from svgp_vae_amd.engine import RcclComm
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-        comm = RcclComm.from_process_group()
+        from svgp_vae_amd.dp import TorchDistComm
+        comm, comm_why = library_comm(True, local_rank, torch.device(f"cuda:{local_rank}"))
+        if comm is None:
+            print(f"[bench] rank {rank}: in-library RCCL communicator unavailable ({comm_why}); all-reducing through "
+                  f"torch.distributed", file=sys.stderr, flush=True)
+            comm = TorchDistComm()
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     n, m, L_, M = args.rows or 131072, args.m or 2048, 16, 8
@@ -908,9 +885,10 @@ def run_cfg5(args):
             "block_ms": [round(x * 1e3, 3) for x in blocks], "timing": "median block",
             "config": {"workload": f"BASELINE configs[4], one GPU's shard: {n} rows x m={m} inducing, L={L_}, "
                                    f"periodic x linear kernel (D={D}), float32: features, materialised K_nm (5a), "
-                                   f"S_l / v_l statistics (5b)" + (", RCCL all-reduce of S, v" if multi else ""),
+                                   f"S_l / v_l statistics (5b)" + (", RCCL all-reduce of S, v" if comm is not None else ""),
                        "rows_per_gpu": n, "parallelism": f"dp{world}",
-                       "rccl_ranks": None if comm is None else comm.world_size},
+                       "rccl_ranks": None if (comm is None or comm_why is not None) else comm.world_size,
+                       "comm_fallback": comm_why},
             "probe_rel_err_S": err,
         }
         t_s, src_s = committed_traffic("k_stats_mfma_f32", per_pass_of="k_stats_reduce_f32")
@@ -995,6 +973,8 @@ def spawn_ranks(n, argv, launcher_module=None):
     SVGP_BENCH_LAUNCHER names another launcher module (the CPU test substitutes a stub for torch.distributed.run)."""
     import subprocess
     mod = launcher_module or os.environ.get("SVGP_BENCH_LAUNCHER", "torch.distributed.run")
+    # torch.distributed.run scans the script's flags as well and rejects `--m` (a prefix of its --max-restarts / --master-addr / ...)
+    argv = ["--inducing" if a == "--m" else ("--inducing=" + a[4:] if a.startswith("--m=") else a) for a in argv]
     cmd = [sys.executable, "-m", mod, "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__), *argv]
     env = dict(os.environ)
@@ -1015,6 +995,9 @@ def spawn_ranks(n, argv, launcher_module=None):
     if rc == 0 and last_json is None:
         print("[bench] the launched ranks printed no result line", file=sys.stderr, flush=True)
         return 1
+    if rc != 0:      #  a failed run must not leave a remembered result line of an EARLIER case as its last stdout line
+        print(f"[bench] the launched ranks exited with code {rc}; no result line is re-emitted", file=sys.stderr, flush=True)
+        return rc
     if last_json is not None and last_line != last_json:
         print(last_json, flush=True)
     return rc
@@ -1046,7 +1029,9 @@ def main():
                     help="cfg2 = BASELINE configs[1] (the metric's configuration, default); cfg3 = configs[2] "
                          "(m=256, b=1024, GPLVM dim 32); sprites800 = configs[3] shape on one GPU's share; "
                          "cfg5 = configs[4] shard (N=131072, m=2048, float32 statistics pass)")
-    ap.add_argument("--m", type=int, default=None, help="sprites800 / cfg5: inducing points (default 800 / 2048)")
+    ap.add_argument("--m", "--inducing", dest="m", type=int, default=None,
+                    help="sprites800 / cfg5: inducing points (default 800 / 2048); --inducing is the spelling the self-launcher "
+                         "passes on (torch.distributed.run's own parser rejects --m as an ambiguous abbreviation)")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64",
                     help="sprites800: f64 = everything float64; f32 = the three networks in float32 (the reference's "
                          "dtype), GP block float64")

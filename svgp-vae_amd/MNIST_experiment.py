@@ -66,15 +66,28 @@ def build_parser():
                    help="pickle used as the train set instead of train_data<dataset>.p (absent from the reference checkout)")
     p.add_argument('--eval_every', type=int, default=10, help="reference: every 10 epochs")
     p.add_argument('--seed', type=int, default=0, help="seed of the Keras-style weight init and numpy")
+    p.add_argument('--epsilon_seed', type=int, default=None,
+                   help="reproducible N(0,1) draws of SVGPVAE_model.py:901: batch i of epoch e uses "
+                        "numpy.random.RandomState(1000 e + i + seed).randn(rows, L) instead of the on-device generator")
+    p.add_argument('--log_json', type=str, default=None,
+                   help="rank 0 writes the per-step log (elbo, recon_loss, C_ma, lagrange_mult), the evaluation series and the "
+                        "final flat parameter vector to this file")
     return p
 
 
-def run_experiment_rotated_mnist_SVGPVAE(args, args_dict=None):
-    """MNIST_experiment.py:30-541 for elbo == SVGPVAE_Hensman.  Returns a dict of the logged series."""
+def run_experiment_rotated_mnist_SVGPVAE(args, args_dict=None, ctx=None):
+    """MNIST_experiment.py:30-541 for elbo == SVGPVAE_Hensman.  Returns a dict of the logged series.
+
+    Data parallel (svgp_vae_amd/dp.py): launched as `python -m torch.distributed.run --nproc-per-node G -m
+    svgp_vae_amd.MNIST_experiment ...`, every rank takes a contiguous row range of every batch (incl. the ragged last one),
+    c = N_train / b_global, the engines all-reduce statistics and gradients; rank 0 alone evaluates, prints and writes files."""
+    from .dp import DistContext, attach_library_comm, run_sharded_epochs
     if args.elbo not in ("SVGPVAE_Hensman", "SVGPVAE_Titsias"):
         raise NotImplementedError(f"--elbo {args.elbo}: only SVGPVAE_Hensman / SVGPVAE_Titsias are built "
                                   f"(see DESIGN.md section 9)")
-    np.random.seed(args.seed)
+    ctx = (ctx or DistContext()).init()
+    root = ctx.rank == 0
+    np.random.seed(args.seed)                    # every rank: the same initial parameters (they are never broadcast)
     n = len(args.dataset)
     ending = args.dataset + ".p"
     train, ev, te, train_batches = import_rotated_mnist(args.mnist_data_path, ending, args.batch_size,
@@ -83,14 +96,14 @@ def run_experiment_rotated_mnist_SVGPVAE(args, args_dict=None):
     N_eval, N_test = len(ev["images"]), len(te["images"])
 
     chkpnt_dir = None
-    if args.save:
+    if args.save and root:
         stamp = time.strftime("%d_%m_%Y__at__%H_%M_%S")
         chkpnt_dir = os.path.join(args.base_dir, args.expid, f"{args.elbo}_{args.beta}__on__{stamp}") + "/"
         os.makedirs(chkpnt_dir + "pics/", exist_ok=True)
-        json.dump(args_dict or vars(args), open(chkpnt_dir + "args.json", "wt"))
+        json.dump({k: v for k, v in (args_dict or vars(args)).items() if not callable(v)}, open(chkpnt_dir + "args.json", "wt"))
 
     # ---- model (MNIST_experiment.py:82-115)
-    VAE = mnistVAE(L=args.L, seed=args.seed)
+    VAE = mnistVAE(L=args.L, seed=args.seed, device=ctx.device)
     inducing_points_init = generate_init_inducing_points(None, n=args.nr_inducing_points, remove_test_angle=None,
                                                          PCA=args.PCA, M=args.M, aux_data=train["aux_data"])
     ip_joint, GP_joint = not args.ip_joint, not args.GP_joint          # sic: passed as fixed_* (:96-98)
@@ -103,14 +116,22 @@ def run_experiment_rotated_mnist_SVGPVAE(args, args_dict=None):
         object_vectors_init = None
     SVGP_ = mnistSVGP(titsias='Titsias' in args.elbo, fixed_inducing_points=ip_joint, initial_inducing_points=inducing_points_init,
                       fixed_gp_params=GP_joint, object_vectors_init=object_vectors_init, name='main',
-                      jitter=args.jitter, N_train=N_train, L=args.L, K_obj_normalize=args.object_kernel_normalize)
+                      jitter=args.jitter, N_train=N_train, L=args.L, K_obj_normalize=args.object_kernel_normalize,
+                      device=ctx.device)
     kappa = float(np.sqrt(args.kappa_squared))
-    b_cap = max(args.batch_size, N_train)        # the cgen path runs the statistics over all train rows
+    # the cgen path runs the statistics over all train rows; the capacity is the SAME on every rank (the layout of the exchange
+    # blocks is a function of it)
+    b_cap = max(args.batch_size, N_train)
     rt = _runtime(VAE, SVGP_, args.clip_qs, args.GECO, kappa, b_cap, alpha_flag=args.alpha, lr=args.lr,
-                  beta=args.beta)
+                  beta=args.beta, rank=ctx.rank, world_size=ctx.world)
     eng = rt.eng
     dev = eng.device
-    print(f"Number of train params: {eng.pl.n_total}")
+    comm_fallback = attach_library_comm(eng, ctx)
+    if root:
+        print(f"Number of train params: {eng.pl.n_total}")
+        if ctx.multi:
+            print(f"Data parallel over {ctx.world} ranks: " + ("RCCL communicator of the library, collectives on the compute stream"
+                  if eng.comm is not None else f"torch.distributed all-reduces between the phases ({comm_fallback})"), flush=True)
 
     # ---- data resident in HBM; batches are copied device-to-device into fixed staging buffers so that
     #      one captured hipGraph per batch size serves every batch
@@ -123,46 +144,39 @@ def run_experiment_rotated_mnist_SVGPVAE(args, args_dict=None):
     # the N(0,1) draw of SVGPVAE_model.py:901 is made on device; `args.epsilon_fn(epoch, batch index, rows, L) -> array`
     # (not a CLI flag: set by callers that need a reproducible trajectory, tests/test_gpu_api.py) makes it an input
     eps_fn = getattr(args, "epsilon_fn", None)
+    if eps_fn is None and getattr(args, "epsilon_seed", None) is not None:
+        eps_fn = lambda epoch, i, rows, L_: np.random.RandomState(1000 * epoch + i + args.epsilon_seed).randn(rows, L_)
     stage_eps = torch.zeros(args.batch_size, args.L, dtype=torch.float64, device=dev) if eps_fn else None
     eng.stream.wait_stream(torch.cuda.current_stream(dev))   # uploads / zero-fills above ran on torch's stream
     graphs = {}
 
-    def train_batch(lo, hi, epoch, i):
-        b = hi - lo
+    def local_step(llo, lhi, lo, hi, epoch, i):
+        b, b_global = lhi - llo, hi - lo
         with torch.cuda.stream(eng.stream):
-            stage_img[:b].copy_(d_train_img[lo:hi])
-            stage_aux[:b].copy_(d_train_aux[lo:hi])
-            if eps_fn:
-                stage_eps[:b].copy_(torch.as_tensor(np.asarray(eps_fn(epoch, i, b, args.L)), dtype=torch.float64), non_blocking=False)
-        if b not in graphs:
-            eng.set_batch_size(b)
-            eng.bind(stage_img[:b], stage_aux[:b], stage_eps[:b] if eps_fn else None)   # None: drawn on device
-            eng.capture(("train", b), adam=True)
-            graphs[b] = True
-        eng.replay(("train", b))
+            stage_img[:b].copy_(d_train_img[llo:lhi])
+            stage_aux[:b].copy_(d_train_aux[llo:lhi])
+            if eps_fn:                 # the draw of the GLOBAL batch; this rank's rows of it
+                e = np.asarray(eps_fn(epoch, i, b_global, args.L))[llo - lo:lhi - lo]
+                stage_eps[:b].copy_(torch.as_tensor(e, dtype=torch.float64), non_blocking=False)
+        if ctx.multi:                  # collectives are not captured: the eager step (as fast as the replay)
+            eng.set_batch_size(b, b_global)
+            eng.bind(stage_img[:b], stage_aux[:b], stage_eps[:b] if eps_fn else None)
+            eng.run(adam=True)
+        else:
+            if b not in graphs:
+                eng.set_batch_size(b)
+                eng.bind(stage_img[:b], stage_aux[:b], stage_eps[:b] if eps_fn else None)   # None: drawn on device
+                eng.capture(("train", b), adam=True)
+                graphs[b] = True
+            eng.replay(("train", b))
+        # the reference fetches elbo / recon_loss / C_ma / lagrange_mult every step (:334-340); one 128-byte read-back
+        eng.synchronize()
+        return eng.scalars()
 
-    nr_epochs, training_regime = parse_opt_regime(args.opt_regime)
-    log = dict(epoch=[], elbo=[], recon_loss=[], eval_mse=[], cgen_mse=[], epoch_time=[], steps=[])
-    log["_engine"] = eng                     # (the final parameters / optimiser state for callers; not serialised)
-    start = time.time()
-    for epoch in range(nr_epochs):
-        t0 = time.time()
-        elbos, losses = [], []
-        for i, (lo, hi) in enumerate(train_batches):
-            train_batch(lo, hi, epoch, i)
-            # the reference fetches elbo / recon_loss / C_ma / lagrange_mult every step (:334-340); one 128-byte read-back
-            eng.synchronize()
-            sc = eng.scalars()
-            elbos.append(sc["elbo"]); losses.append(sc["recon_loss"])
-            log["steps"].append(dict(epoch=epoch, rows=hi - lo, elbo=sc["elbo"], recon_loss=sc["recon_loss"],
-                                     C_ma=sc["c_ma"], lagrange_mult=sc["lagrange"]))
-        mse = np.sum(losses) / N_train
-        log["epoch"].append(epoch); log["elbo"].append(float(np.sum(elbos))); log["recon_loss"].append(float(mse))
-        log["epoch_time"].append(time.time() - t0)
-        print(f"Epoch {epoch}: ELBO sum {np.sum(elbos):.4f}  train MSE/px {mse:.6f}  "
-              f"{log['epoch_time'][-1]:.2f}s  (C_ma {sc['c_ma']:.5f}, lagrange {sc['lagrange']:.4f})", flush=True)
-
-        if (epoch + 1) % args.eval_every == 0 or epoch + 1 == nr_epochs:
+    def on_epoch_end(epoch, log):
+        if not ((epoch + 1) % args.eval_every == 0 or epoch + 1 == nr_epochs):
+            return
+        if root:       # parameters are replicated: rank 0 evaluates alone (collective-free stage calls), the others wait
             # eval-set reconstruction through the posterior (forward only, no optimiser step)
             ev_losses = []
             for lo, hi in batches(N_eval, args.batch_size):
@@ -187,7 +201,7 @@ def run_experiment_rotated_mnist_SVGPVAE(args, args_dict=None):
                                                                   means, vars_, d_train_aux)
                 cg.append(float(loss_))
             cgen_mse = float(np.sum(cg) / N_test)
-            log["eval_mse"].append((epoch, eval_mse)); log["cgen_mse"].append((epoch, cgen_mse))
+            log.setdefault("eval_mse", []).append((epoch, eval_mse)); log.setdefault("cgen_mse", []).append((epoch, cgen_mse))
             print(f"  eval recon MSE/px {eval_mse:.6f}   cgen test MSE/px {cgen_mse:.6f}   "
                   f"l_GP {float(SVGP_.l_GP):.4f} amplitude {float(SVGP_.amplitude):.4f}", flush=True)
             if chkpnt_dir:
@@ -196,7 +210,21 @@ def run_experiment_rotated_mnist_SVGPVAE(args, args_dict=None):
                 if args.save_model_weights:
                     torch.save({"theta": eng.theta.cpu(), "adam_m": eng.adam_m.cpu(), "adam_v": eng.adam_v.cpu(),
                                 "state": eng.state.cpu()}, chkpnt_dir + f"model_{epoch}.pt")
+        ctx.barrier()
+
+    nr_epochs, training_regime = parse_opt_regime(args.opt_regime)
+    start = time.time()
+
+    log = run_sharded_epochs(ctx, train_batches, nr_epochs, local_step, N_train=N_train, on_epoch_end=on_epoch_end)
+    log.setdefault("eval_mse", []); log.setdefault("cgen_mse", [])
+    log["world_size"], log["rank"] = ctx.world, ctx.rank
+    log["rccl_ranks"] = eng.comm.world_size if eng.comm is not None else 0
     log["total_time"] = time.time() - start
+    if root and getattr(args, "log_json", None):
+        eng.synchronize()
+        json.dump(dict({k: v for k, v in log.items()}, theta=eng.theta.cpu().tolist(), adam_t=eng.scalars()["adam_t"],
+                       param_order=list(eng.shapes)), open(args.log_json, "wt"))
+    log["_engine"] = eng                     # (the final parameters / optimiser state for callers; not serialised)
     return log
 
 
@@ -270,7 +298,12 @@ def run_experiment_rotated_mnist_SVIGP_Hensman(args, args_dict=None):
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.elbo in ("SVGPVAE_Hensman", "SVGPVAE_Titsias"):
-        return run_experiment_rotated_mnist_SVGPVAE(args, vars(args))
+        from .dp import DistContext
+        ctx = DistContext()
+        try:
+            return run_experiment_rotated_mnist_SVGPVAE(args, vars(args), ctx)
+        finally:
+            ctx.close()
     if args.elbo == "SVIGP_Hensman":
         return run_experiment_rotated_mnist_SVIGP_Hensman(args, vars(args))
     raise NotImplementedError(f"--elbo {args.elbo}: only SVGPVAE_Hensman / SVGPVAE_Titsias / SVIGP_Hensman are built "

@@ -72,6 +72,10 @@ def build_parser():
     p.add_argument('--batch_size_test_char', type=int, default=576)
     p.add_argument('--eval_every', type=int, default=5, help="reference: every 5 epochs")
     p.add_argument('--seed', type=int, default=0)
+    p.add_argument('--epsilon_seed', type=int, default=None,
+                   help="reproducible N(0,1) draws: batch i of epoch e uses numpy.random.RandomState(1000 e + i + seed)"
+                        ".randn(rows, L) instead of the on-device generator")
+    p.add_argument('--log_json', type=str, default=None, help="rank 0 writes the per-step log and the final parameters here")
     return p
 
 
@@ -101,7 +105,12 @@ def _load(args):
     return out
 
 
-def run_experiment_sprites_SVGPVAE(args, dict_=None):
+def run_experiment_sprites_SVGPVAE(args, dict_=None, ctx=None):
+    """SPRITES_experiment.py:30-560.  Data parallel (svgp_vae_amd/dp.py): under `python -m torch.distributed.run --nproc-per-node G
+    -m svgp_vae_amd.SPRITES_experiment ...` every rank takes whole `frames_per_character` groups of every batch (the GP posterior
+    of a batch couples all its frames through the all-reduced statistics; a character's frames share their representation
+    vector, so groups are never cut), c = N_train / b_global; rank 0 alone evaluates, prints and writes files."""
+    from .dp import DistContext, make_comm, shard_batch
     if "SVGPVAE" not in args.elbo:
         raise NotImplementedError(f"--elbo {args.elbo}: only SVGPVAE_Hensman / SVGPVAE_Titsias are built")
     assert np.sum([args.object_kernel_normalize, args.K_SE]) <= 1, \
@@ -109,12 +118,17 @@ def run_experiment_sprites_SVGPVAE(args, dict_=None):
     fpc, N_actions = args.frames_per_character, args.N_actions
     assert args.batch_size % fpc == 0, f"Batch size needs to be divisible by {fpc}"         # :40-41
     assert args.batch_size_test_char % N_actions == 0 and 0 < args.N_context < N_actions
-    np.random.seed(args.seed)
+    ctx = (ctx or DistContext()).init()
+    root = ctx.rank == 0
+    say = print if root else (lambda *a, **k: None)
+    assert args.batch_size // fpc >= ctx.world, \
+        f"{ctx.world} ranks need at least {ctx.world} character groups per batch (batch_size >= {ctx.world * fpc})"
+    np.random.seed(args.seed)                    # every rank: the same data / initial parameters (they are never broadcast)
     train, test = _load(args)
     N_train, N_test = len(train["frames"]), len(test["frames"])
     assert N_train % args.batch_size == 0 or N_train > args.batch_size, "need at least one full train batch"
     chkpnt_dir = None
-    if args.save:
+    if args.save and root:
         stamp = time.strftime("%d_%m_%Y__at__%H_%M_%S")
         chkpnt_dir = os.path.join(args.base_dir, args.expid, f"{args.elbo}_{args.beta}__on__{stamp}") + "/"
         os.makedirs(chkpnt_dir + "pics/", exist_ok=True)
@@ -130,6 +144,7 @@ def run_experiment_sprites_SVGPVAE(args, dict_=None):
         GPLVM_init = np.random.normal(0, 1.5, N_actions * args.L_action).reshape(N_actions, args.L_action)
         IP_init = np.random.normal(0, 1.5, N_actions * args.m * (args.L_action + args.L_character)) \
             .reshape(N_actions * args.m, args.L_action + args.L_character)
+    device = ctx.device
     VAE = S.spritesVAE(L=args.L, seed=args.seed)
     repr_NN = S.sprites_representation_network(L=args.L_character)
     SVGP_ = S.spritesSVGP(titsias='Titsias' in args.elbo, fixed_inducing_points=not args.ip_joint,
@@ -137,13 +152,18 @@ def run_experiment_sprites_SVGPVAE(args, dict_=None):
                           L_action=args.L_action, initial_GPLVM_action=GPLVM_init, L_character=args.L_character,
                           fixed_GPLVM=not args.GPLVM_joint, K_obj_normalize=args.object_kernel_normalize, L=args.L,
                           K_SE=args.K_SE, fixed_GP_params=not args.GP_joint)
-    b_max = max(args.batch_size, args.batch_size_test_char)
+    b_max = max(args.batch_size, args.batch_size_test_char)      # the same capacity on every rank (layout of the exchange blocks)
+    comm, comm_fallback = make_comm(ctx, device)
     eng = S.SpritesStepEngine(VAE, repr_NN, SVGP_, b_max=b_max, seg_len=fpc, clip_qs=args.clip_qs, geco=args.GECO,
                               kappa_squared=args.kappa_squared, alpha=args.alpha, beta=args.beta, lr=args.lr,
-                              clip_grad=args.clip_grad_thres if args.clip_grad else None)
+                              clip_grad=args.clip_grad_thres if args.clip_grad else None, device=device,
+                              rank=ctx.rank, world_size=ctx.world, comm=comm)
     S._attach(eng, SVGP_, VAE, repr_NN)
     dev = eng.dev
-    print(f"Number of train params: {eng.theta.numel()}")
+    say(f"Number of train params: {eng.theta.numel()}")
+    if ctx.multi:
+        say(f"Data parallel over {ctx.world} ranks: " + ("RCCL communicator of the library, collectives on the compute stream"
+            if comm_fallback is None else f"torch.distributed collectives ({comm_fallback})"), flush=True)
     t64 = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64, device=dev).contiguous()
     d_tr, a_tr = t64(train["frames"]), t64(train["action_IDs"])
     d_te, a_te = t64(test["frames"]), t64(test["action_IDs"])
@@ -153,7 +173,10 @@ def run_experiment_sprites_SVGPVAE(args, dict_=None):
     cgen_seg, cgen_rep = S.aux_data_sprites_utils(int(bt * args.N_context / N_actions), args.N_context,
                                                   N_actions - args.N_context)                # :370-372
     nr_epochs, training_regime = parse_opt_regime(args.opt_regime)
-    log = dict(elbo=[], recon_loss=[], recon_mse_test=[], cgen_mse=[])
+    log = dict(elbo=[], recon_loss=[], recon_mse_test=[], cgen_mse=[], steps=[])
+    eps_fn = getattr(args, "epsilon_fn", None)           # (not a CLI flag: reproducible trajectories for tests)
+    if eps_fn is None and getattr(args, "epsilon_seed", None) is not None:
+        eps_fn = lambda epoch, i, rows, L_: np.random.RandomState(1000 * epoch + i + args.epsilon_seed).randn(rows, L_)
     if 'yes' in args.repr_nn_pretrain:                                     # :325-357
         bs = min(args.batch_size_repr_nn, N_train)
         log["repr_pretrain"] = S.pretrain_repr_NN(eng, d_tr, t64(train["char_IDs"]), nr_epochs=args.nr_epochs_repr_nn,
@@ -165,18 +188,27 @@ def run_experiment_sprites_SVGPVAE(args, dict_=None):
     start = time.time()
     for epoch in range(nr_epochs):
         elbos, losses = [], []
-        for lo in range(0, N_train - args.batch_size + 1, args.batch_size):
+        for i, lo in enumerate(range(0, N_train - args.batch_size + 1, args.batch_size)):
             if args.GECO and first_step:                    # :381-385: alpha = 0 on the very first GECO step
                 eng.set_scalars(alpha=0.0)
-            eng.step(d_tr[lo:lo + args.batch_size], a_tr[lo:lo + args.batch_size], None, adam=True)
-            sc = eng.scalars()
+            llo, lhi = shard_batch(lo, lo + args.batch_size, ctx.world, ctx.rank, fpc)      # whole character groups
+            eps = None
+            if eps_fn is not None:                          # the draw of the GLOBAL batch; this rank's rows of it
+                eps = t64(np.asarray(eps_fn(epoch, i, args.batch_size, args.L))[llo - lo:lhi - lo])
+            eng.step(d_tr[llo:lhi], a_tr[llo:lhi], eps, adam=True, b_global=args.batch_size)
+            sc = eng.scalars()                              # global values, identical on every rank
             elbos.append(sc["elbo"]); losses.append(sc["recon_loss"])
+            log["steps"].append(dict(epoch=epoch, rows=args.batch_size, local_rows=lhi - llo, elbo=sc["elbo"],
+                                     recon_loss=sc["recon_loss"], C_ma=sc["c_ma"], lagrange_mult=sc["lagrange"]))
             first_step = False
         # GECO recon_loss is sum_i(mean_pix - kappa^2); the reference prints it summed / N_train all the same (:432)
         log["elbo"].append(float(np.mean(elbos))); log["recon_loss"].append(float(np.sum(losses) / N_train))
-        print(f"Epoch {epoch}, opt regime {training_regime[epoch]}, mean ELBO per batch: {log['elbo'][-1]}")
-        print(f"MSE loss on train set for epoch {epoch} : {log['recon_loss'][-1]}", flush=True)
+        say(f"Epoch {epoch}, opt regime {training_regime[epoch]}, mean ELBO per batch: {log['elbo'][-1]}")
+        say(f"MSE loss on train set for epoch {epoch} : {log['recon_loss'][-1]}", flush=True)
         if (epoch + 1) % args.eval_every:
+            continue
+        if not root:        # parameters are replicated: rank 0 evaluates alone (collective-free calls), the others wait
+            ctx.barrier()
             continue
         # ---- 7.3.1 reconstruction of the test characters (:472-487): encode -> GP posterior of the same batch -> decode
         mse = []
@@ -218,8 +250,15 @@ def run_experiment_sprites_SVGPVAE(args, dict_=None):
             if args.save_model_weights:
                 torch.save({"theta": eng.theta.cpu(), "adam_m": eng.adam_m.cpu(), "adam_v": eng.adam_v.cpu(),
                             "state": eng.state.cpu()}, chkpnt_dir + f"model_{epoch}.pt")
+        ctx.barrier()
     log["total_time"] = time.time() - start
-    print(f"Running time for {nr_epochs} epochs: {round(log['total_time'], 2)}")
+    log["world_size"], log["rank"] = ctx.world, ctx.rank
+    log["rccl_ranks"] = comm.world_size if (comm is not None and comm_fallback is None) else 0
+    say(f"Running time for {nr_epochs} epochs: {round(log['total_time'], 2)}")
+    if root and getattr(args, "log_json", None):
+        eng.stream.synchronize()
+        json.dump(dict(log, theta=eng.theta.cpu().tolist(), param_order=list(eng.shapes)), open(args.log_json, "wt"))
+    log["_engine"] = eng
     return log
 
 
@@ -233,7 +272,7 @@ def _eval_engine(train_eng, N_actions):
     if key not in _EVAL:
         e = S.SpritesStepEngine(S.spritesVAE(train_eng.L), S.sprites_representation_network(train_eng.Lc), train_eng.svgp,
                                 b_max=train_eng.b_max, seg_len=N_actions, clip_qs=train_eng.clip_qs, geco=False,
-                                params={k: v for k, v in train_eng.params.items()})
+                                params={k: v for k, v in train_eng.params.items()}, device=train_eng.dev)
         # share (not copy) the parameters: re-point the twin's views at the training engine's flat vector
         e.theta = train_eng.theta
         off = 0
@@ -248,8 +287,13 @@ def _eval_engine(train_eng, N_actions):
 
 
 def main(argv=None):
+    from .dp import DistContext
     args = build_parser().parse_args(argv)
-    return run_experiment_sprites_SVGPVAE(args, vars(args))
+    ctx = DistContext()
+    try:
+        return run_experiment_sprites_SVGPVAE(args, vars(args), ctx)
+    finally:
+        ctx.close()
 
 
 if __name__ == "__main__":

@@ -247,3 +247,39 @@ def test_exchange_lengths_agree_through_the_library_communicator():
     assert agree_on_lengths([135168, 8, 74000], comm, torch.device("cuda:0"), s) is True
     assert agree_on_lengths([1, 2, 3], None, torch.device("cuda:0"), s) is False
     comm.close()
+
+
+@pytest.mark.parametrize("workload,extra", [("sprites800", ["--precision", "f32"]), ("cfg5", ["--rows", "16384", "--m", "512"])])
+def test_bench_multi_rank_paths_of_the_eight_gpu_configs_with_one_rank(workload, extra):
+    """BASELINE configs[3] / [4] are the two "8 x MI355X" configurations; `python bench.py --gpus 1 --force-dist --workload ...`
+    takes their N > 1 code end to end through the self-launcher with ONE rank: process group, the collective
+    communicator bootstrap with its MIN votes, the exchange points of the step (sprites800: the strong line -- 500 frames cut in
+    50-frame character groups -- and the weak line; cfg5: the S, v all-reduce), barriers and the MAX all-reduce of the time.
+    Then the same with the library communicator refused on the rank: every rank falls back to torch.distributed together."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--workload", workload, "--steps", "2",
+           "--warmup", "1", "--repeats", "1", "--no-cpu-baseline"] + extra
+    for fail in (False, True):
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root,
+                           env=dict(env, SVGP_BENCH_FAIL_LIBCOMM="1") if fail else env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        assert "torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1" in r.stderr
+        last = json.loads(r.stdout.strip().splitlines()[-1])
+        lines = [json.loads(x) for x in r.stdout.splitlines() if x.lstrip().startswith("{") and '"metric"' in x]
+        assert last == lines[-1] and last["n_gpus"] == 1 and last["scaling"] == "weak" and last["value"] > 0
+        if fail:
+            assert last["config"]["rccl_ranks"] is None and "disabled by SVGP_BENCH_FAIL_LIBCOMM" in last["config"]["comm_fallback"]
+            assert "in-library RCCL communicator unavailable" in r.stderr
+        else:
+            assert last["config"]["rccl_ranks"] == 1 and last["config"]["comm_fallback"] is None
+        if workload == "sprites800":
+            assert [x["scaling"] for x in lines] == ["strong", "weak"]
+            assert lines[0]["config"]["global_batch"] == 500 and lines[0]["config"]["rows_per_gpu"] == 500
+            assert len(last["collectives_us"]) == 3 and all(v >= 0 for v in last["collectives_us"].values())
+        else:
+            assert "all-reduce of S, v" in last["config"]["workload"] and last["probe_rel_err_S"] < 1e-4

@@ -471,6 +471,12 @@ int svgp_potrf_batched(int m, int batch, double* A, int lda, long long strideA, 
 int svgp_trsm_batched(int side, int trans, int m, int n, const double* L, int ldl, long long strideL, double* B, int ldb,
                       long long strideB, int batch, double* work, void* stream);
 int svgp_potri_batched(int m, int batch, double* A, const double* linv_blocks, double* work, void* stream);
+/* Inverse of ONE general (m x m, m <= 2048) matrix by LU with partial pivoting (lu.hip): the reference's tf.linalg.inv(K_mm)
+ * WITHOUT jitter in the SPRITES conditional-generation path (SPRITES_experiment.py:178; consumed at SVGPVAE_model.py:610-635).
+ * With the linear x linear kernels K_mm has rank <= 128 < m = 800, where an elimination without pivoting has no answer.
+ * A (row-major, contiguous) is not modified; Ainv must not alias it; work: svgp_lu_inverse_workspace_elems(m) doubles. */
+size_t svgp_lu_inverse_workspace_elems(int m);
+int svgp_lu_inverse(int m, const double* A, double* Ainv, double* work, void* stream);
 
 /* ---- generic NHWC float64 convolution as a tap-table gather-GEMM on the f64 MFMA (conv_taps.hip) ---------
  * out[n][y*osy+ooy][x*osx+oox][co] = act(bias[co] + sum_t sum_ci in[n][y*sy+oy_t][x*sx+ox_t][ci] W_t[ci][co]),

@@ -233,8 +233,8 @@ def run_experiment_sprites_SVGPVAE(args, dict_=None, ctx=None):
         K_mm, _, _ = eng.kernel_matrices(aux[:1])
         # :178 `tf.linalg.inv(K_mm)` WITHOUT jitter: with the linear kernels K_mm has rank <= L_action * L_character < m, and the
         # reference's LU with partial pivoting returns a (huge but finite) matrix where a Cholesky / no-pivot elimination -- the
-        # library's SPD inverse -- has no answer; so this one m x m inverse per evaluation stays on rocSOLVER's LU (torch.linalg.inv)
-        K_mm_inv = torch.linalg.inv(K_mm)
+        # library's SPD inverse -- has no answer: the library's row-pivoted LU inverse (lu.hip)
+        K_mm_inv = S.general_inverse(K_mm)
         cg = []
         for lo in range(0, N_test - bt + 1, bt):
             _, _, loss = S.predict_SVGPVAE_sprites_test_character(

@@ -158,6 +158,7 @@ SIGNATURES = {
     "svgp_trsm_batched": [C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_longlong, _P, C.c_int, C.c_longlong,
                           C.c_int, _P, _P],
     "svgp_potri_batched": [C.c_int, C.c_int, _P, _P, _P, _P],
+    "svgp_lu_inverse": [C.c_int, _P, _P, _P, _P],
     "svgp_dgemm_splitk": [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, _P, C.c_int, _P, C.c_int, C.c_double, _P,
                           C.c_int, _P, C.c_longlong, _P],
     "svgp_conv_taps_fwd": [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, _P],
@@ -251,6 +252,7 @@ NON_STATUS = {"svgp_version": ([], C.c_int), "svgp_last_error": ([], C.c_char_p)
               "svgp_potrf_workspace_elems": ([C.c_int, C.c_int], C.c_size_t),
               "svgp_trsm_workspace_elems": ([C.c_int, C.c_int, C.c_int], C.c_size_t),
               "svgp_potri_workspace_elems": ([C.c_int, C.c_int], C.c_size_t),
+              "svgp_lu_inverse_workspace_elems": ([C.c_int], C.c_size_t),
               "svgp_act_bwd_bias_scratch_elems": ([C.c_int], C.c_int),
               "svgp_dgemm_splitk_scratch_elems": ([C.c_int, C.c_int, C.c_int], C.c_longlong),
               "svgp_sprites_kernel_bwd_scratch_elems": ([C.POINTER(SpritesKcfg)], C.c_longlong),

@@ -744,6 +744,21 @@ def forward_pass_SVGPVAE(data_batch, beta, vae, svgp, C_ma, lagrange_mult, alpha
 # ---------------------------------------------------------------------------------------------
 # conditional generation for a test character (SPRITES_experiment.py:160-205, 364-372, 500-560)
 # ---------------------------------------------------------------------------------------------
+def general_inverse(A, stream=None):
+    """`tf.linalg.inv(A)` of ONE general square float64 matrix on the device: LU with partial pivoting in the library
+    (svgp_lu_inverse; SPRITES_experiment.py:178 inverts K_mm WITHOUT jitter, rank-deficient with the linear kernels)."""
+    A = A.to(_F64).contiguous()
+    m = A.shape[0]
+    assert A.ndim == 2 and A.shape[1] == m and A.is_cuda
+    lib = _lib.load_library()
+    out = torch.empty_like(A)
+    work = torch.empty(int(lib.svgp_lu_inverse_workspace_elems(m)), dtype=_F64, device=A.device)
+    s = torch.cuda.current_stream(A.device) if stream is None else stream
+    call("svgp_lu_inverse", m, A.data_ptr(), out.data_ptr(), work.data_ptr(), s.cuda_stream)
+    s.synchronize()                   # (work is freed on return)
+    return out
+
+
 def _attach(eng, *objs):
     """The reference's functions take the network / GP objects only (e.g. aux_data_SVGPVAE_sprites(data_batch, repr_nn,
     segment_ids, repeats), SVGPVAE_model.py:1086); the engine that owns their parameters hangs on each of them."""

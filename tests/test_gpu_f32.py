@@ -98,6 +98,9 @@ def _sprites_case(b, frames, L, La, Lc, m, n_act, seed, K_SE, norm):
     return params, gp, images, ids, eps, seg, rep
 
 
+_ORACLE_CACHE = {}
+
+
 @pytest.mark.parametrize("m,b,L,K_SE,norm,gemm_f32", [(12, 8, 6, True, False, 0), (72, 8, 6, False, True, 1), (72, 8, 6, True, False, 1),
                                                       (800, 100, 64, False, True, 2), (800, 100, 64, False, True, 1)])
 def test_sprites_step_float32(m, b, L, K_SE, norm, gemm_f32):
@@ -110,7 +113,10 @@ def test_sprites_step_float32(m, b, L, K_SE, norm, gemm_f32):
     kw = dict(beta=0.001, C_ma=torch.tensor(0.0, dtype=DT), lagrange_mult=torch.tensor(1.0, dtype=DT), alpha=0.0,
               kappa=math.sqrt(0.0075), L=L, L_action=La, jitter=jitter, N_train=N_train, segment_ids=seg, repeats=rep,
               clipping_qs=True, GECO=True, K_obj_normalize=norm, K_SE=K_SE, clip_grad=None, titsias=False)
-    want, wgrads = SO.loss_and_grads(params, gp, (images, ids), eps, formulation="efficient", **kw)
+    key = (m, b, L, K_SE, norm)               # (the two m = 800 cases differ in gemm_f32 only: one oracle evaluation, ~15 s of CPU)
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = SO.loss_and_grads(params, gp, (images, ids), eps, formulation="efficient", **kw)
+    want, wgrads = _ORACLE_CACHE[key]
     svgp = S.spritesSVGP(False, False, gp["inducing_index_points"].numpy(), 'main', jitter, N_train, La,
                          gp["GPLVM_action"].numpy(), Lc, L, fixed_GP_params=False, fixed_GPLVM=False,
                          K_obj_normalize=norm, K_SE=K_SE)

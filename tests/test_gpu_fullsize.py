@@ -15,6 +15,7 @@ therefore derived from the ORACLE ITSELF: the same oracle is evaluated on inputs
 place (every real input multiplied by 1 +- 2^-52), and a quantity's tolerance is max(base, 20 x its response to that
 perturbation).  What the model consumes (ELBO, p_m, p_v, z, reconstruction) stays far inside north_star's 1e-3."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -106,19 +107,23 @@ def test_config3_full_size_step_matches_oracle():
 SE_FULL = dict(l_action=6.0, sigma_action=1.0, l_character=6.0, sigma_character=0.8)
 
 
-@pytest.mark.parametrize("GECO,K_SE", [(True, False), (True, True)])
-def test_sprites_m800_step_matches_oracle(GECO, K_SE):
-    """BASELINE configs[3]'s GP shape inside the SPRITES step: m = 800 > rank(K_mm) = 128 (8-dim x 16-dim linear
-    kernels), so every m x m factorisation leans on jitter 0.01; inverse from the Cholesky factor (m >= 512) in the step.
-    K_SE: the reference's `--K_SE` flag at this size (VERDICT r4 item 4): SE x SE kernels, K_mm full rank, the four kernel
-    hyper-parameters trained -- their gradients are checked too."""
-    from svgp_vae_amd import sprites as S
-    b, frames, L, La, Lc, n_act, m = 100, 50, 64, 8, 16, 72, 800
-    g = torch.Generator().manual_seed(800)
-    params = {k: torch.tensor(v, dtype=DT) for k, v in SO.glorot_init(L, Lc, 3).items()}
-    for k in params:
-        if k.endswith("_b"):
-            params[k] = 0.05 * torch.randn(*params[k].shape, dtype=DT, generator=g)
+# ---------------------------------------------------------------------------------------------------------------------
+# Oracle evaluations of the SPRITES cases (torch-CPU float64 autograd; 15-25 s each at 500 frames, 8.7 GB peak) run in a small
+# pool of CPU-only worker processes, ALL submitted at the first request, so that the cases' oracle time overlaps instead of
+# adding up (the GPU suite had grown to 538 s on the driver's box, 215 s of it these evaluations one after
+# the other).  4 workers x 8 threads: <= 35 GB.  Every job rebuilds its inputs from the seeds; nothing here touches the GPU.
+# ---------------------------------------------------------------------------------------------------------------------
+_ORACLE_POOL, _ORACLE_JOBS = None, {}
+
+
+def _sprites_inputs(b, seed_gen, seed_init, K_SE, bias_noise):
+    frames, L, La, Lc, n_act, m = 50, 64, 8, 16, 72, 800
+    g = torch.Generator().manual_seed(seed_gen)
+    params = {k: torch.tensor(v, dtype=DT) for k, v in SO.glorot_init(L, Lc, seed_init).items()}
+    if bias_noise:
+        for k in params:
+            if k.endswith("_b"):
+                params[k] = 0.05 * torch.randn(*params[k].shape, dtype=DT, generator=g)
     gp = dict(inducing_index_points=torch.randn(m, La + Lc, dtype=DT, generator=g) * 1.5,
               GPLVM_action=torch.randn(n_act, La, dtype=DT, generator=g) * 1.5,
               **{k: torch.tensor(SE_FULL[k] if K_SE else 1.0, dtype=DT) for k in SE_FULL})
@@ -126,15 +131,71 @@ def test_sprites_m800_step_matches_oracle(GECO, K_SE):
     ids = torch.randint(0, n_act, (b,), generator=g)
     eps = torch.randn(b, L, dtype=DT, generator=g)
     seg, rep = SO.aux_data_sprites_utils(b, frames, frames)
-    jitter, N_train = 0.01, 50000.0
     kw = dict(beta=0.001, C_ma=torch.tensor(0.0, dtype=DT), lagrange_mult=torch.tensor(1.0, dtype=DT), alpha=0.0,
-              kappa=math.sqrt(0.0075), L=L, L_action=La, jitter=jitter, N_train=N_train, segment_ids=seg, repeats=rep,
-              clipping_qs=False, GECO=GECO, K_obj_normalize=True, K_SE=K_SE, clip_grad=1e6, titsias=False)
-    want, wgrads = SO.loss_and_grads(params, gp, (images, ids), eps, formulation="efficient", **kw)
-    gen = torch.Generator().manual_seed(6)
-    params2 = {k: _ulp_perturbed(v, gen) for k, v in params.items()}
-    gp2 = {k: _ulp_perturbed(v, gen) for k, v in gp.items()}
-    want2, wgrads2 = SO.loss_and_grads(params2, gp2, (_ulp_perturbed(images, gen), ids), eps, formulation="efficient", **kw)
+              kappa=math.sqrt(0.0075), L=L, L_action=La, jitter=0.01, N_train=50000.0, segment_ids=seg, repeats=rep,
+              clipping_qs=False, GECO=True, K_obj_normalize=True, K_SE=K_SE, clip_grad=1e6, titsias=False)
+    return (b, frames, L, La, Lc, n_act, m), params, gp, images, ids, eps, kw
+
+
+def _oracle_job(job):
+    """WORKER: one oracle evaluation.  job = (case, K_SE, kind): case 100 / 500 frames; kind 'base', 'p64' (every real input moved
+    by one float64 ulp), 'p32' (network parameters and frames by one float32 ulp, the GP parameters by one float64 ulp)."""
+    case, K_SE, kind = job
+    _, params, gp, images, ids, eps, kw = _sprites_inputs(100, 800, 3, K_SE, True) if case == 100 else \
+        _sprites_inputs(500, 500, 0, K_SE, False)
+    if kind != "base" and case == 100:
+        gen = torch.Generator().manual_seed(6)
+        params = {k: _ulp_perturbed(v, gen) for k, v in params.items()}
+        gp = {k: _ulp_perturbed(v, gen) for k, v in gp.items()}
+        images = _ulp_perturbed(images, gen)
+    elif kind != "base":
+        net_ulp, seed = (ULP, 6) if kind == "p64" else (2.0 ** -24, 7)
+        gen = torch.Generator().manual_seed(seed)
+        pert = lambda t, u: t * (1.0 + u * (torch.randint(0, 2, t.shape, generator=gen).to(DT) * 2 - 1))
+        params = {k: pert(v, net_ulp) for k, v in params.items()}
+        gp = {k: (pert(v, ULP) if (v.ndim or K_SE) else v) for k, v in gp.items()}
+        images = pert(images, net_ulp)
+    return SO.loss_and_grads(params, gp, (images, ids), eps, formulation="efficient", **kw)
+
+
+def _oracle(case, K_SE, kind):
+    global _ORACLE_POOL
+    if _ORACLE_POOL is None:
+        import concurrent.futures as cf
+        import multiprocessing as mp
+        # The workers' thread count comes from the ENVIRONMENT they are spawned with (torch.set_num_threads after the OpenMP / MKL
+        # pools exist corrupts the pivots of MKL's batched LU with this build: bench.py cpu_worker_call), and they see no GPU.
+        keep = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")}
+        os.environ.update(OMP_NUM_THREADS="8", MKL_NUM_THREADS="8", HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        try:
+            _ORACLE_POOL = cf.ProcessPoolExecutor(max_workers=4, mp_context=mp.get_context("spawn"))
+            import atexit
+            atexit.register(lambda: _ORACLE_POOL.shutdown(wait=False, cancel_futures=True))
+            for job in [(500, se, k) for se in (False, True) for k in ("base", "p64", "p32")] + \
+                       [(100, se, k) for se in (False, True) for k in ("base", "p64")]:
+                _ORACLE_JOBS[job] = _ORACLE_POOL.submit(_oracle_job, job)      # (the four workers are spawned by these submits)
+        finally:
+            for k, v in keep.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return _ORACLE_JOBS[(case, K_SE, kind)].result(timeout=1500)
+
+
+
+@pytest.mark.parametrize("GECO,K_SE", [(True, False), (True, True)])
+def test_sprites_m800_step_matches_oracle(GECO, K_SE):
+    """BASELINE configs[3]'s GP shape inside the SPRITES step: m = 800 > rank(K_mm) = 128 (8-dim x 16-dim linear
+    kernels), so every m x m factorisation leans on jitter 0.01; inverse from the Cholesky factor (m >= 512) in the step.
+    K_SE: the reference's `--K_SE` flag at this size (VERDICT r4 item 4): SE x SE kernels, K_mm full rank, the four kernel
+    hyper-parameters trained -- their gradients are checked too."""
+    from svgp_vae_amd import sprites as S
+    assert GECO                                       # (the pooled oracle jobs are the GECO ones)
+    (b, frames, L, La, Lc, n_act, m), params, gp, images, ids, eps, kw = _sprites_inputs(100, 800, 3, K_SE, True)
+    jitter, N_train = kw["jitter"], kw["N_train"]
+    want, wgrads = _oracle(100, K_SE, "base")
+    want2, wgrads2 = _oracle(100, K_SE, "p64")        # every real input moved by one float64 ulp
 
     svgp = S.spritesSVGP(False, False, gp["inducing_index_points"].numpy(), 'main', jitter, N_train, La,
                          gp["GPLVM_action"].numpy(), Lc, L, fixed_GP_params=False, fixed_GPLVM=False,
@@ -188,31 +249,10 @@ def _sprites500_case(K_SE=False):
     last two are the yardsticks of the gradient tolerances.  Cached: both parametrisations of the test share it."""
     if K_SE in _SP500:
         return _SP500[K_SE]
-    b, frames, L, La, Lc, n_act, m = 500, 50, 64, 8, 16, 72, 800
-    g = torch.Generator().manual_seed(500)
-    params = {k: torch.tensor(v, dtype=DT) for k, v in SO.glorot_init(L, Lc, 0).items()}
-    gp = dict(inducing_index_points=torch.randn(m, La + Lc, dtype=DT, generator=g) * 1.5,
-              GPLVM_action=torch.randn(n_act, La, dtype=DT, generator=g) * 1.5,
-              **{k: torch.tensor(SE_FULL[k] if K_SE else 1.0, dtype=DT) for k in SE_FULL})
-    images = torch.rand(b, 64, 64, 3, dtype=DT, generator=g)
-    ids = torch.randint(0, n_act, (b,), generator=g)
-    eps = torch.randn(b, L, dtype=DT, generator=g)
-    seg, rep = SO.aux_data_sprites_utils(b, frames, frames)
-    jitter, N_train = 0.01, 50000.0
-    kw = dict(beta=0.001, C_ma=torch.tensor(0.0, dtype=DT), lagrange_mult=torch.tensor(1.0, dtype=DT), alpha=0.0,
-              kappa=math.sqrt(0.0075), L=L, L_action=La, jitter=jitter, N_train=N_train, segment_ids=seg, repeats=rep,
-              clipping_qs=False, GECO=True, K_obj_normalize=True, K_SE=K_SE, clip_grad=1e6, titsias=False)
-    want, wgrads = SO.loss_and_grads(params, gp, (images, ids), eps, formulation="efficient", **kw)
-
-    def perturbed(net_ulp, seed):
-        gen = torch.Generator().manual_seed(seed)
-        pert = lambda t, u: t * (1.0 + u * (torch.randint(0, 2, t.shape, generator=gen).to(DT) * 2 - 1))
-        p2 = {k: pert(v, net_ulp) for k, v in params.items()}
-        gp2 = {k: (pert(v, ULP) if (v.ndim or K_SE) else v) for k, v in gp.items()}
-        return SO.loss_and_grads(p2, gp2, (pert(images, net_ulp), ids), eps, formulation="efficient", **kw)
-
-    _SP500[K_SE] = dict(dims=(b, frames, L, La, Lc, n_act, m), params=params, gp=gp, images=images, ids=ids, eps=eps,
-                        jitter=jitter, N_train=N_train, want=want, wgrads=wgrads, p64=perturbed(ULP, 6), p32=perturbed(2.0 ** -24, 7))
+    dims, params, gp, images, ids, eps, kw = _sprites_inputs(500, 500, 0, K_SE, False)
+    want, wgrads = _oracle(500, K_SE, "base")
+    _SP500[K_SE] = dict(dims=dims, params=params, gp=gp, images=images, ids=ids, eps=eps, jitter=kw["jitter"], N_train=kw["N_train"],
+                        want=want, wgrads=wgrads, p64=_oracle(500, K_SE, "p64"), p32=_oracle(500, K_SE, "p32"))
     return _SP500[K_SE]
 
 

@@ -150,3 +150,67 @@ def test_spd_inverse_residual_on_kernel_like_spectrum(m, jitter):
     assert res(X) <= 10 * res(T) + 1e-12
     assert sw(X) <= 10 * sw(T) + 1e-13
     assert abs(float(logdet[0]) - float(torch.log(lam + jitter).sum())) < 1e-8 * m
+
+
+@pytest.mark.parametrize("m", [1, 5, 16, 33, 100, 257, 800])
+def test_lu_inverse_of_a_general_matrix(m):
+    """svgp_lu_inverse (LU with partial pivoting + two triangular solves) against torch.linalg.inv on matrices that NEED row
+    pivoting: non-symmetric, with a zero (1,1) entry and rows of very different scale."""
+    from svgp_vae_amd.sprites import general_inverse
+    g = torch.Generator().manual_seed(m)
+    A = torch.randn(m, m, dtype=torch.float64, generator=g)
+    if m > 1:
+        A[0, 0] = 0.0
+    A *= torch.logspace(-3, 3, m, dtype=torch.float64)[torch.randperm(m, generator=g)][:, None]
+    dev = torch.device("cuda:0")
+    X = general_inverse(A.to(dev)).cpu()
+    ref = torch.linalg.inv(A)
+    resid = float((A @ X - torch.eye(m, dtype=torch.float64)).abs().max())
+    resid_ref = float((A @ ref - torch.eye(m, dtype=torch.float64)).abs().max())
+    assert resid <= max(1e-9, 50 * resid_ref), (resid, resid_ref)
+    assert float((X - ref).abs().max() / ref.abs().max()) < 1e-7
+
+
+def test_lu_inverse_pivot_rule_and_permutation():
+    """A permutation-like matrix: the inverse is its transpose exactly (no arithmetic, only the pivot search / swaps)."""
+    from svgp_vae_amd.sprites import general_inverse
+    m = 70
+    perm = torch.randperm(m, generator=torch.Generator().manual_seed(0))
+    A = torch.zeros(m, m, dtype=torch.float64)
+    A[torch.arange(m), perm] = torch.arange(1, m + 1, dtype=torch.float64)
+    X = general_inverse(A.to("cuda:0")).cpu()
+    assert torch.equal(X, torch.linalg.inv(A))
+
+
+def test_lu_inverse_on_the_sprites_inducing_kernel_matrix():
+    """What SPRITES_experiment.py:178 inverts: K_mm WITHOUT jitter.  (a) SE x SE kernels (--K_SE), full rank: 1e-9 against
+    torch.linalg.inv through the quantity the caller uses, diag(K_bm K_mm^-1 K_mb) (SVGPVAE_model.py:610-635).  (b) linear x linear
+    kernels at m = 800: rank <= 128, the inverse is dominated by rounding in the null space and NO two LU implementations agree on it
+    -- the bar is the reference computation's own response to a one-ulp perturbation of K_mm (the tolerance rule of
+    tests/test_gpu_fullsize.py), plus: every entry finite."""
+    from svgp_vae_amd.sprites import general_inverse
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    m, La, Lc, b = 800, 8, 16, 64
+    Za, Zc = torch.randn(m, La, dtype=torch.float64, generator=g), torch.randn(m, Lc, dtype=torch.float64, generator=g)
+    Xa, Xc = torch.randn(b, La, dtype=torch.float64, generator=g), torch.randn(b, Lc, dtype=torch.float64, generator=g)
+    cos = lambda x, y: (x / x.norm(dim=1, keepdim=True)) @ (y / y.norm(dim=1, keepdim=True)).t()
+    se = lambda x, y, l: torch.exp(-0.5 * torch.cdist(x, y) ** 2 / l ** 2)
+    diag = lambda Kb, Ki: torch.einsum("bm,mn,bn->b", Kb, Ki, Kb)
+    # (a) full rank
+    K, Kb = se(Za, Za, 3.0) * se(Zc, Zc, 4.0), se(Xa, Za, 3.0) * se(Xc, Zc, 4.0)
+    got, ref = diag(Kb, general_inverse(K.to(dev)).cpu()), diag(Kb, torch.linalg.inv(K))
+    ulp = lambda: 1.0 + 2.0 ** -52 * (torch.randint(0, 2, K.shape, generator=g).to(torch.float64) * 2 - 1)
+    pert = diag(Kb, torch.linalg.inv(K * ulp()))
+    tol = max(1e-9, 20 * float((pert - ref).abs().max() / ref.abs().max()))
+    assert float((got - ref).abs().max() / ref.abs().max()) < tol, tol
+    # (b) rank 128 of 800
+    K, Kb = cos(Za, Za) * cos(Zc, Zc), cos(Xa, Za) * cos(Xc, Zc)
+    X = general_inverse(K.to(dev)).cpu()
+    assert torch.isfinite(X).all()
+    ref = torch.linalg.inv(K)
+    pert = torch.linalg.inv(K * ulp())
+    resp = float((diag(Kb, pert) - diag(Kb, ref)).abs().max() / diag(Kb, ref).abs().max())
+    err = float((diag(Kb, X) - diag(Kb, ref)).abs().max() / diag(Kb, ref).abs().max())
+    print(f"rank-128 K_mm: |diag(Kb X Kb^T) - torch| / max = {err:.2e}; torch's own one-ulp response {resp:.2e}")
+    assert err < max(1e-6, 20 * resp)

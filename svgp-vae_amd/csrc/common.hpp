@@ -139,6 +139,8 @@ struct svgp_gemm_epi {
     double g1 = 0, d1 = 0;
     double* C2 = nullptr; long long sc2 = 0; int ldc2 = 0;      // ldc2 = 0: the leading dimension of C
     double a2 = 0, g2 = 0, d2 = 0;
+    // alpha is multiplied by *alpha_dev (a DEVICE scalar: a loss seed that lives in the device state vector) when set
+    const double* alpha_dev = nullptr;
 };
 int svgp_dgemm_tri_batched(int tri, int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
                            long long strideA, const double* B, int ldb, long long strideB, double beta, double* C, int ldc,

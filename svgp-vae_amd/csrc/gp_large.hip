@@ -56,9 +56,12 @@ __global__ void k_big_weights(int n_el, int L, int mode, int geco, int clip_pv, 
         }
     }
 }
-__global__ void k_big_recip(int n_el, const real* __restrict__ s2, real* __restrict__ p) {
+// (+ the device scalar -g3/2 for the epilogue of the SW product that follows: X0 = A2 - g3/2 SW, see svgp_big_stats)
+__global__ void k_big_recip(int n_el, const real* __restrict__ s2, real* __restrict__ p, int flags, int L,
+                            const real* __restrict__ state, real* __restrict__ mhalf_g3) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_el) p[i] = recip_no_nan(s2[i]);
+    if (i == 0 && mhalf_g3) *mhalf_g3 = real(-0.5) * svgp_seed_3(flags, gradKL(flags, L, state));
 }
 // The rank-local row terms of the reverse pass in one pass over the rows, X (b, 2 m) = [qbar * Kn | Wbar]:
 //   qbar_n = sum_l (g3/2 p_nl - g_pv_nl): the weight of k_n k_n^T in the gradient of Ki (q_n = k^T Ki k inside d and p_v);
@@ -174,6 +177,12 @@ struct FbArgs {
     const real* mu; const real* u; const real* ud; const real* td; const real* v;
     real* ubar; real* mubar; real* tbar;   // (L,m) each; mubar/tbar come in holding Ki ubar / K mubar
     real* Sibar; const real* Sg; const real* HG; real* Ssym;
+    // rank1_late (round 6): the symmetric rank-one part (tbar v^T + v tbar^T) / 2 of X is NOT inside X -- Si X Si then lacks
+    // (vbar t^T + t vbar^T) / 2 (vbar = Si tbar, t = Si v: the same terms, exactly, without two m^3 sandwiches around them), which the
+    // consumers of Sg0 = -Si X Si subtract: k_big_fb_ssym here, k_big_fb_final for the channel sum.  X = A2 - g3/2 SW is then a
+    // function of the statistics alone and comes out of the epilogue of the SW product (svgp_big_stats): no pass of its own.
+    int rank1_late;
+    const real* t; const real* vbar;
 };
 __device__ __forceinline__ void fb_scalars(const FbArgs& a, real& g3, real& gK) {
     const real gT = gradKL(a.geco, a.Ltot, a.state);
@@ -242,7 +251,12 @@ __global__ __launch_bounds__(256) void k_big_fb_ssym(FbArgs a) {
             if (gi < m && gj < m) {
                 const size_t i = lo + (size_t)gi * m + gj;
                 const real sg = side ? V[r][t.c] : U[r][t.c], sgt = side ? U[t.c][r] : V[t.c][r];
-                a.Ssym[i] = a.c * (sg + sgt) - a.c * gK * a.HG[i];
+                real two = sg + sgt;
+                if (a.rank1_late) {
+                    const size_t vo = (size_t)t.l * m;
+                    two -= a.vbar[vo + gi] * a.t[vo + gj] + a.t[vo + gi] * a.vbar[vo + gj];
+                }
+                a.Ssym[i] = a.c * two - a.c * gK * a.HG[i];
             }
         }
     }
@@ -267,6 +281,7 @@ struct FinArgs {
     const real* Zs; const real* mubar; const real* t; const real* Sgs; const real* HGs; const real* Ki; const real* KiPbar;
     const real* KiKibKi;
     real* Kib; real* Kbar;
+    int rank1_late; const real* vbar;      // see FbArgs: sum_l Sg0_l lacks -(vbar_l t_l^T + t_l vbar_l^T) / 2
 };
 __global__ void k_big_fb_kib(FinArgs a) {
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -284,8 +299,13 @@ __global__ void k_big_fb_final(FinArgs a) {
     const real gT = gradKL(a.geco, a.Ltot, a.state), gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
     const int r = o / a.m, cidx = o % a.m;
     real s = real(0.5) * gK * (a.Zs[o] + a.Zs[(size_t)cidx * a.m + r] - a.HGs[o]) + a.Sgs[o] + real(0.5) * gK * (real)a.L * a.Ki[o];
-    real rk = 0;
+    real rk = 0, rs = 0;
     for (int l = 0; l < a.L; ++l) rk += a.mubar[(size_t)l * a.m + r] * a.t[(size_t)l * a.m + cidx];
+    if (a.rank1_late) {
+        for (int l = 0; l < a.L; ++l)
+            rs += a.vbar[(size_t)l * a.m + r] * a.t[(size_t)l * a.m + cidx] + a.t[(size_t)l * a.m + r] * a.vbar[(size_t)l * a.m + cidx];
+        s -= real(0.5) * rs;
+    }
     a.Kbar[o] = a.rep_weight * (s + a.c * rk) + a.KiPbar[o] - a.KiKibKi[o];
 }
 
@@ -532,11 +552,20 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
         // round 4: issued early on a third stream it ran 1.4 ms instead of 0.35 beside the row stage's product and the tail's
         // factorisation; A / B in one run: 18.15 vs 18.20 ms per step, i.e. no difference -- this form needs one stream less.)
         // mm2 and the weights in scr_bl are untouched by the side branch.
+        // Round 6: the product's epilogue writes X0 = A2 - g3/2 SW (mm1) straight away -- what the late reverse factor half needs
+        // of SW; the rank-one part of X is applied after the Sigma^-1 sandwiches (FbArgs.rank1_late), so the 1 GB pass k_big_fb_sibar
+        // (0.42 ms at m = 800, L = 64, on the caller's stream in front of the join) is gone.  -g3/2 is a device scalar (the loss seeds
+        // live in the state vector): written by k_big_recip, read by the epilogue.  mm1 is untouched by the side branch (early half:
+        // mm0, mm3) when SW has this row form.
         if (!c->titsias && c->b == c->b_global && c->b < 3 * m) {
-            hipLaunchKernelGGL(k_big_recip, dim3(nblk((long long)b * L)), dim3(256), 0, st, b * L, ws + wl.qnet_var, s.wst);
+            real* mhalf_g3 = s.ldtmp + c->L + 8;       // (slots L + 1 .. L + 15 of the log-det scratch are free)
+            hipLaunchKernelGGL(k_big_recip, dim3(nblk((long long)b * L)), dim3(256), 0, st, b * L, ws + wl.qnet_var, s.wst,
+                               SVGP_LOSS_FLAGS(c), L, state, mhalf_g3);
             SVGP_LAUNCH_CHECK();
-            RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, b, 1.0, s.W, m, 0, s.W, m, 0, 0.0, s.mm2, m, (long long)m * m, L,
-                                           stream, s.wst, L, 1));
+            svgp_gemm_epi ep;
+            ep.E = ws + wl.A2; ep.lde = m; ep.se = (long long)m * m; ep.g1 = 1.0; ep.alpha_dev = mhalf_g3;
+            RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, b, 1.0, s.W, m, 0, s.W, m, 0, 0.0, s.mm1, m, (long long)m * m, L,
+                                           stream, s.wst, L, 1, &ep));
         }
     }
     // (K_mm + jI)^-1 and its log det (SVGPVAE_model.py:239,270,273) are formed by svgp_big_factor_fwd, in the same
@@ -698,6 +727,10 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     const bool has_sw = !c->titsias;
     a.SW = has_sw ? s.mm2 : nullptr;
     const bool sw_rows = c->b == c->b_global && c->b < 3 * m;
+    // X0 = A2 - g3/2 SW already sits in mm1 (epilogue of the SW product, svgp_big_stats mode 1; whole-stage / late calls on all L
+    // channels only: the row form exists for b == b_global, i.e. without a channel window)
+    const bool x0_ready = has_sw && sw_rows && l0 == 0 && nl == c->L;
+    a.rank1_late = x0_ready ? 1 : 0; a.t = ws + wl.t + ov; a.vbar = ws + wl.vbar + ov;
     if (has_sw && !sw_rows && (part == 0 || part == 1 || part == 3)) {
         GEMM(0, 1, m, m, m, 1.0, ws + wl.S + om, m, mm, s.PT, m, 0, 0.0, s.mm1, m, mm, L);        // T = S P   (P = (P^T)^T)
         GEMM_SYM(0, 0, m, m, 1.0, s.PT, m, 0, s.mm1, m, mm, 0.0, s.mm2, m, mm, L);                // SW = P^T T
@@ -735,8 +768,10 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     const bool do_a = part != 7, do_b = part != 6, x_early = sw_rows || !has_sw;
     real* six = x_early ? ws + wl.Ssym + om : s.mm0;
     auto x_block = [&]() -> int {
-        hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);                // X (mm1)
-        SVGP_LAUNCH_CHECK();
+        if (!x0_ready) {
+            hipLaunchKernelGGL(k_big_fb_sibar, dim3(gmm), dim3(256), 0, st, a);            // X (mm1)
+            SVGP_LAUNCH_CHECK();
+        }
         GEMV(1.0, Si, mm, s.vec2, ws + wl.vbar + ov, L);                                   // vbar = Si tbar
         GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm1, m, mm, 0.0, six, m, mm, L);             // Si X
         // Sg0 = -(Si X) Si: a FULL product, not lower-triangle-and-mirror -- like the Ki sandwiches of round 2, the mirrored form of this
@@ -769,6 +804,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     f.rep_weight = c->rep_weight; f.state = state;
     f.Asum = s.Asum; f.ubar = s.vec0; f.mu = a.mu; f.Qs = s.Qs; f.PbarK = s.tA; f.Zs = s.Zs; f.mubar = s.vec1; f.t = ws + wl.t + ov;
     f.Sgs = s.Sgs; f.HGs = s.HGs; f.Ki = Ki; f.KiPbar = s.Pbar; f.KiKibKi = s.tA; f.Kib = s.tB; f.Kbar = ws + wl.Kbar;
+    f.rank1_late = a.rank1_late; f.vbar = a.vbar;
     GEMM(0, 0, m, m, m, 1.0, K, m, 0, s.Pbar, m, 0, 0.0, s.tA, m, 0, 1);                // K Pbar^T = (Pbar K)^T   (s.Pbar holds Pbar^T)
     hipLaunchKernelGGL(k_big_fb_kib, dim3(nblk(mm)), dim3(256), 0, st, f);             // Kib (tB)
     SVGP_LAUNCH_CHECK();

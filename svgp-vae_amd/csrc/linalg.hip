@@ -46,6 +46,7 @@ struct GemmArgs {
     int epi_on;
     const void* E; int lde; long long se; void* C2; long long sc2; int ldc2;
     real g1, d1, a2, g2, d2;
+    const real* alpha_dev;  // extended epilogue only: alpha *= *alpha_dev (device scalar), NULL = 1
 };
 
 // k-panels of 16 are double-buffered in LDS and a third one is in flight in registers (see the main loop), one
@@ -388,6 +389,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
         // coefficients -- K + c S + jI next to S, A + jI next to A, P^T - K Aji: each used to be a pass over an (L, m, m) array
         const TS* __restrict__ E = g.E ? static_cast<const TS*>(g.E) + (size_t)l * g.se : nullptr;
         TS* C2 = g.C2 ? static_cast<TS*>(g.C2) + (size_t)l * g.sc2 : nullptr;
+        const real alpha = g.alpha_dev ? g.alpha * *g.alpha_dev : g.alpha;
 #pragma unroll
         for (int a = 0; a < WM; ++a)
 #pragma unroll
@@ -399,12 +401,12 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
                         const real av = (real)acc[a][b][e], dd = gi == gj ? real(1) : real(0);
                         const size_t o = (size_t)gi * g.ldc + gj;
                         const real ev = E ? (real)E[(size_t)gi * g.lde + gj] : real(0);
-                        C[o] = (TS)(g.alpha * av + (has_beta ? g.beta * (real)C[o] : real(0)) + g.g1 * ev + g.d1 * dd);
+                        C[o] = (TS)(alpha * av + (has_beta ? g.beta * (real)C[o] : real(0)) + g.g1 * ev + g.d1 * dd);
                         if (C2) C2[(size_t)gi * g.ldc2 + gj] = (TS)(g.a2 * av + g.g2 * ev + g.d2 * dd);
                         if ((g.tri & 16) && gi != gj) {          // mirror: a below-diagonal tile, or the lower half of a diagonal tile
                             const size_t oT = (size_t)gj * g.ldc + gi;
                             const real evT = E ? (real)E[(size_t)gj * g.lde + gi] : real(0);
-                            C[oT] = (TS)(g.alpha * av + (has_beta ? g.beta * (real)C[oT] : real(0)) + g.g1 * evT);
+                            C[oT] = (TS)(alpha * av + (has_beta ? g.beta * (real)C[oT] : real(0)) + g.g1 * evT);
                             if (C2) C2[(size_t)gj * g.ldc2 + gi] = (TS)(g.a2 * av + g.g2 * evT);
                         }
                     }
@@ -667,13 +669,13 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     g.wk = wk; g.ldw = ldw; g.sw = strideW;
     g.bsub = bsub;
     SVGP_REQUIRE(!(wk && bsub), SVGP_ERR_INVALID, "contraction weights and a B transform together are not supported");
-    g.epi_on = 0; g.E = nullptr; g.lde = 0; g.se = 0; g.C2 = nullptr; g.sc2 = 0; g.ldc2 = ldc; g.g1 = g.d1 = g.a2 = g.g2 = g.d2 = 0;
+    g.epi_on = 0; g.E = nullptr; g.lde = 0; g.se = 0; g.C2 = nullptr; g.sc2 = 0; g.ldc2 = ldc; g.g1 = g.d1 = g.a2 = g.g2 = g.d2 = 0; g.alpha_dev = nullptr;
     if (epi) {
         SVGP_REQUIRE(prec != 2, SVGP_ERR_INVALID, "extended GEMM epilogue: float64 storage only");
         SVGP_REQUIRE(epi->E || (epi->g1 == 0 && epi->g2 == 0), SVGP_ERR_INVALID, "extended GEMM epilogue: E is NULL");
         g.epi_on = 1; g.E = epi->E; g.lde = epi->lde; g.se = epi->se; g.C2 = epi->C2; g.sc2 = epi->sc2;
         g.ldc2 = epi->ldc2 > 0 ? epi->ldc2 : ldc;
-        g.g1 = epi->g1; g.d1 = epi->d1; g.a2 = epi->a2; g.g2 = epi->g2; g.d2 = epi->d2;
+        g.g1 = epi->g1; g.d1 = epi->d1; g.a2 = epi->a2; g.g2 = epi->g2; g.d2 = epi->d2; g.alpha_dev = epi->alpha_dev;
     }
     //  the mirrored store treats every tile with i0 != j0 as lying strictly below the diagonal: true only for a
     // square output cut identically along rows and columns

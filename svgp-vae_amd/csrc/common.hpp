@@ -141,6 +141,9 @@ struct svgp_gemm_epi {
     double a2 = 0, g2 = 0, d2 = 0;
     // alpha is multiplied by *alpha_dev (a DEVICE scalar: a loss seed that lives in the device state vector) when set
     const double* alpha_dev = nullptr;
+    // E is exactly symmetric (a mirrored-store product): the mirrored store of a symmetric output reuses the value read at (i, j)
+    // instead of reading E at (j, i) with a stride of lde
+    int e_sym = 0;
 };
 int svgp_dgemm_tri_batched(int tri, int ta, int tb, int M, int N, int K, double alpha, const double* A, int lda,
                            long long strideA, const double* B, int ldb, long long strideB, double beta, double* C, int ldc,

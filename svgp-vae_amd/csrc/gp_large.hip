@@ -214,6 +214,13 @@ __global__ void k_big_fb_sibar(FbArgs a) {
 // (tj, ti), ti <= tj, of one channel: both tiles go through LDS, every global access is coalesced (the element-per-thread form
 // read the transposed operand with a stride of m doubles: 0.55 + 0.61 ms per step at m = 800, L = 64).
 // grid (nt, nt, L), 256 threads; thread (c = tid & 31, r0 = tid >> 5) handles rows r0 + 8 h.
+// a b + c d with both products rounded on their own (no fused multiply-add: hipcc contracts by default, and HIP's __dmul_rn is a
+// plain product that contracts too): the result does not depend on which product comes first
+__device__ __forceinline__ real sum_of_two_products(real a, real b, real c, real d) {
+#pragma clang fp contract(off)
+    const real p1 = a * b, p2 = c * d;
+    return p1 + p2;
+}
 #define TP 32
 struct TilePair {
     int ti, tj, l, c, r0;
@@ -254,7 +261,9 @@ __global__ __launch_bounds__(256) void k_big_fb_ssym(FbArgs a) {
                 real two = sg + sgt;
                 if (a.rank1_late) {
                     const size_t vo = (size_t)t.l * m;
-                    two -= a.vbar[vo + gi] * a.t[vo + gj] + a.t[vo + gi] * a.vbar[vo + gj];
+                    // (two separately rounded products, no fused multiply-add: element (j, i) forms the same two products in the
+                    // other order, and Ssym must be symmetric bit for bit -- the packed exchange relies on it)
+                    two -= sum_of_two_products(a.vbar[vo + gi], a.t[vo + gj], a.t[vo + gi], a.vbar[vo + gj]);
                 }
                 a.Ssym[i] = a.c * two - a.c * gK * a.HG[i];
             }
@@ -446,6 +455,10 @@ __global__ __launch_bounds__(256) void k_big_gemv_fb(FbArgs a, const real* __res
 }
 
 inline unsigned nblk(long long n) { return (unsigned)((n + 255) / 256); }
+inline bool x0_epilogue_on() {
+    const char* e = getenv("SVGP_X0_EPILOGUE");
+    return !(e && e[0] == '0');
+}
 
 }  // namespace
 
@@ -552,11 +565,10 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
         // round 4: issued early on a third stream it ran 1.4 ms instead of 0.35 beside the row stage's product and the tail's
         // factorisation; A / B in one run: 18.15 vs 18.20 ms per step, i.e. no difference -- this form needs one stream less.)
         // mm2 and the weights in scr_bl are untouched by the side branch.
-        // Round 6: the product's epilogue writes X0 = A2 - g3/2 SW (mm1) straight away -- what the late reverse factor half needs
+        // Round 6: the product's epilogue writes X0 = A2 - g3/2 SW in SW's place (mm2) -- what the late reverse factor half needs
         // of SW; the rank-one part of X is applied after the Sigma^-1 sandwiches (FbArgs.rank1_late), so the 1 GB pass k_big_fb_sibar
-        // (0.42 ms at m = 800, L = 64, on the caller's stream in front of the join) is gone.  -g3/2 is a device scalar (the loss seeds
-        // live in the state vector): written by k_big_recip, read by the epilogue.  mm1 is untouched by the side branch (early half:
-        // mm0, mm3) when SW has this row form.
+        // (0.42 ms at m = 800, L = 64) is gone.  -g3/2 is a device scalar (the loss seeds live in the state vector): written by
+        // k_big_recip, read by the epilogue.  SVGP_X0_EPILOGUE=0: plain SW + the pass (A / B measurements).
         if (!c->titsias && c->b == c->b_global && c->b < 3 * m) {
             real* mhalf_g3 = s.ldtmp + c->L + 8;       // (slots L + 1 .. L + 15 of the log-det scratch are free)
             hipLaunchKernelGGL(k_big_recip, dim3(nblk((long long)b * L)), dim3(256), 0, st, b * L, ws + wl.qnet_var, s.wst,
@@ -564,8 +576,9 @@ int svgp_big_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, doub
             SVGP_LAUNCH_CHECK();
             svgp_gemm_epi ep;
             ep.E = ws + wl.A2; ep.lde = m; ep.se = (long long)m * m; ep.g1 = 1.0; ep.alpha_dev = mhalf_g3;
-            RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, b, 1.0, s.W, m, 0, s.W, m, 0, 0.0, s.mm1, m, (long long)m * m, L,
-                                           stream, s.wst, L, 1, &ep));
+            ep.e_sym = 1;                              // A2 = Kn^T diag(g_pv) Kn: a mirrored-store product
+            RUNC(svgp_dgemm_symout_batched(c->gemm_f32 != 0, 1, 0, m, b, 1.0, s.W, m, 0, s.W, m, 0, 0.0, s.mm2, m, (long long)m * m, L,
+                                           stream, s.wst, L, 1, x0_epilogue_on() ? &ep : nullptr));
         }
     }
     // (K_mm + jI)^-1 and its log det (SVGPVAE_model.py:239,270,273) are formed by svgp_big_factor_fwd, in the same
@@ -727,9 +740,9 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     const bool has_sw = !c->titsias;
     a.SW = has_sw ? s.mm2 : nullptr;
     const bool sw_rows = c->b == c->b_global && c->b < 3 * m;
-    // X0 = A2 - g3/2 SW already sits in mm1 (epilogue of the SW product, svgp_big_stats mode 1; whole-stage / late calls on all L
-    // channels only: the row form exists for b == b_global, i.e. without a channel window)
-    const bool x0_ready = has_sw && sw_rows && l0 == 0 && nl == c->L;
+    // X0 = A2 - g3/2 SW sits in mm2 in SW's place (epilogue of the SW product, svgp_big_stats mode 1; all L channels: the row form
+    // exists for b == b_global, i.e. without a channel window).  mm2 is only read here: the stage can be repeated on a workspace.
+    const bool x0_ready = has_sw && sw_rows && l0 == 0 && nl == c->L && x0_epilogue_on();
     a.rank1_late = x0_ready ? 1 : 0; a.t = ws + wl.t + ov; a.vbar = ws + wl.vbar + ov;
     if (has_sw && !sw_rows && (part == 0 || part == 1 || part == 3)) {
         GEMM(0, 1, m, m, m, 1.0, ws + wl.S + om, m, mm, s.PT, m, 0, 0.0, s.mm1, m, mm, L);        // T = S P   (P = (P^T)^T)
@@ -773,7 +786,7 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
             SVGP_LAUNCH_CHECK();
         }
         GEMV(1.0, Si, mm, s.vec2, ws + wl.vbar + ov, L);                                   // vbar = Si tbar
-        GEMM(0, 0, m, m, m, 1.0, Si, m, mm, s.mm1, m, mm, 0.0, six, m, mm, L);             // Si X
+        GEMM(0, 0, m, m, m, 1.0, Si, m, mm, x0_ready ? s.mm2 : s.mm1, m, mm, 0.0, six, m, mm, L);   // Si X
         // Sg0 = -(Si X) Si: a FULL product, not lower-triangle-and-mirror -- like the Ki sandwiches of round 2, the mirrored form of this
         // Sigma^-1 sandwich loses the benign structure of its rounding error: config 3 (jitter 1e-6) had the encoder dense-layer gradient
         // off by 1e-3 against 1e-9 (measured, round 4).  Ssym = c (Sg + Sg^T) is then formed exactly symmetric by the tile-pair kernel:

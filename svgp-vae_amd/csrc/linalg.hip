@@ -47,6 +47,7 @@ struct GemmArgs {
     const void* E; int lde; long long se; void* C2; long long sc2; int ldc2;
     real g1, d1, a2, g2, d2;
     const real* alpha_dev;  // extended epilogue only: alpha *= *alpha_dev (device scalar), NULL = 1
+    int e_sym;              // E exactly symmetric: the mirrored store reuses E[i][j]
 };
 
 // k-panels of 16 are double-buffered in LDS and a third one is in flight in registers (see the main loop), one
@@ -405,7 +406,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, int l, int i0, int 
                         if (C2) C2[(size_t)gi * g.ldc2 + gj] = (TS)(g.a2 * av + g.g2 * ev + g.d2 * dd);
                         if ((g.tri & 16) && gi != gj) {          // mirror: a below-diagonal tile, or the lower half of a diagonal tile
                             const size_t oT = (size_t)gj * g.ldc + gi;
-                            const real evT = E ? (real)E[(size_t)gj * g.lde + gi] : real(0);
+                            const real evT = E ? (g.e_sym ? ev : (real)E[(size_t)gj * g.lde + gi]) : real(0);
                             C[oT] = (TS)(alpha * av + (has_beta ? g.beta * (real)C[oT] : real(0)) + g.g1 * evT);
                             if (C2) C2[(size_t)gj * g.ldc2 + gi] = (TS)(g.a2 * av + g.g2 * evT);
                         }
@@ -669,13 +670,13 @@ static int gemm_launch(int prec, int tri, int ta, int tb, int M, int N, int K, d
     g.wk = wk; g.ldw = ldw; g.sw = strideW;
     g.bsub = bsub;
     SVGP_REQUIRE(!(wk && bsub), SVGP_ERR_INVALID, "contraction weights and a B transform together are not supported");
-    g.epi_on = 0; g.E = nullptr; g.lde = 0; g.se = 0; g.C2 = nullptr; g.sc2 = 0; g.ldc2 = ldc; g.g1 = g.d1 = g.a2 = g.g2 = g.d2 = 0; g.alpha_dev = nullptr;
+    g.epi_on = 0; g.E = nullptr; g.lde = 0; g.se = 0; g.C2 = nullptr; g.sc2 = 0; g.ldc2 = ldc; g.g1 = g.d1 = g.a2 = g.g2 = g.d2 = 0; g.alpha_dev = nullptr; g.e_sym = 0;
     if (epi) {
         SVGP_REQUIRE(prec != 2, SVGP_ERR_INVALID, "extended GEMM epilogue: float64 storage only");
         SVGP_REQUIRE(epi->E || (epi->g1 == 0 && epi->g2 == 0), SVGP_ERR_INVALID, "extended GEMM epilogue: E is NULL");
         g.epi_on = 1; g.E = epi->E; g.lde = epi->lde; g.se = epi->se; g.C2 = epi->C2; g.sc2 = epi->sc2;
         g.ldc2 = epi->ldc2 > 0 ? epi->ldc2 : ldc;
-        g.g1 = epi->g1; g.d1 = epi->d1; g.a2 = epi->a2; g.g2 = epi->g2; g.d2 = epi->d2; g.alpha_dev = epi->alpha_dev;
+        g.g1 = epi->g1; g.d1 = epi->d1; g.a2 = epi->a2; g.g2 = epi->g2; g.d2 = epi->d2; g.alpha_dev = epi->alpha_dev; g.e_sym = epi->e_sym;
     }
     //  the mirrored store treats every tile with i0 != j0 as lying strictly below the diagonal: true only for a
     // square output cut identically along rows and columns

@@ -431,7 +431,8 @@ def mnist_case(args, scaling, multi, dev, ctx, strict=True):
                           # workspace; m <= 64: row partials kept and exchanged, as the engine's multi-rank default) + a 1-rank
                           # communicator, i.e. everything of the N > 1 step but the wire
                           single_stat_block=((M_IND > 64 or os.environ.get("SVGP_DP_STAT_PARTIALS") == "0")
-                                             if args.force_comm else None))
+                                             if args.force_comm else None),
+                          split_grad_exchange=args.split_grad)
     eng.load_params(params)
     d_img, d_aux, d_eps = (torch.tensor(np.ascontiguousarray(x), dtype=torch.float64, device=dev).contiguous()
                            for x in (images, aux, eps))
@@ -496,8 +497,7 @@ def mnist_case(args, scaling, multi, dev, ctx, strict=True):
     assert math.isfinite(sc["elbo"]) and sc["adam_t"] >= args.steps * args.repeats, sc
     # per-exchange-point microseconds (HIP events around pack + grouped collective + unpack, svgp_comm_timing): a few extra
     # steps after the timed region, the maximum over ranks of the per-point medians
-    coll_us = None
-    if eng.comm is not None:
+    def collectives():
         eng.comm.timing(True)
         samples = []
         for _ in range(10):
@@ -508,7 +508,22 @@ def mnist_case(args, scaling, multi, dev, ctx, strict=True):
         med = torch.tensor(np.median(np.array(samples), 0), dtype=torch.float64, device=dev)
         if multi:
             dist.all_reduce(med, op=dist.ReduceOp.MAX)
-        coll_us = [round(float(x), 1) for x in med.cpu()]
+        return [round(float(x), 1) for x in med.cpu()]
+
+    coll_us, other = None, None
+    if eng.comm is not None:
+        coll_us = collectives()
+        if not eng.channel_sharded() and not args.no_split_probe:
+            # the OTHER setting of cfg.split_grad_exchange (gradient all-reduce in two parts, the first beside the encoder's reverse
+            # pass): a short timed block + its exchange points, so that the first multi-GPU run shows which one to keep
+            flag = bool(eng.base["split_grad_exchange"])
+            eng.set_split_grad_exchange(not flag)
+            eng.bind(d_img, d_aux, None)
+            ob = timed_blocks(lambda: eng.run(adam=True), eng.synchronize, max(20, args.steps // 3), 5, 3, multi, dev)
+            other = {"split_grad_exchange": not flag, "ms_per_step": float(np.median(ob)) / max(20, args.steps // 3) * 1e3,
+                     "collectives_us": collectives()}
+            eng.set_split_grad_exchange(flag)
+            eng.bind(d_img, d_aux, None)
     # per-stage HIP-event timings of this rank's launches (rank-local kernels, no collective inside): every rank runs
     # them so that nobody waits on rank 0, rank 0 reports
     stage_rows = time_stages(eng, B, M_IND, reps=(1 if os.environ.get("SVGP_BENCH_NO_STAGES") else 20 if cfg3 else 50))
@@ -559,10 +574,17 @@ def mnist_case(args, scaling, multi, dev, ctx, strict=True):
         line["stages_us"] = {r["stage"]: round(r["us"], 2) for r in stage_rows}
         line["step_flops"] = step_flops
         if coll_us is not None:
-            names = (["rs[S|v]", "ag[Si|t|u]", "rs[A2|ud|td]", "ag[Ssym|vbar|KL]", "ar[grad|sums]"] if len(coll_us) == 5
-                     else ["ar[S|v]", "ar[A2|ud|td]", "ar[grad|sums]"])
-            line["collectives_us"] = dict(zip(names, coll_us))
+            def named(us):
+                names = {5: ["rs[S|v]", "ag[Si|t|u]", "rs[A2|ud|td]", "ag[Ssym|vbar|KL]", "ar[grad|sums]"],
+                         4: ["ar[S|v]", "ar[A2|ud|td]", "ar[grad tail|sums] (side branch)", "ar[grad head]"],
+                         3: ["ar[S|v]", "ar[A2|ud|td]", "ar[grad|sums]"]}[len(us)]
+                return dict(zip(names, us))
+            line["collectives_us"] = named(coll_us)
             line["collectives_us_total"] = round(sum(coll_us), 1)
+            line["config"]["split_grad_exchange"] = bool(eng.base["split_grad_exchange"])
+            if other is not None:
+                other["collectives_us"] = named(other["collectives_us"])
+                line["other_exchange_setting"] = other
             line["collectives_note"] = ("HIP events on the compute stream around every exchange point (pack + ONE grouped RCCL "
                                         "launch + unpack), median of 10 steps, maximum over ranks; compute = ms_per_step - total")
         if world == 1 and not args.no_cpu_baseline and scaling == "weak":
@@ -1018,6 +1040,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="N=1 under torchrun: take the N>1 code path (process group, communicator bootstrap through "
                          "broadcast_object_list, barriers, MAX all-reduce of the time) with world size 1")
+    ap.add_argument("--split-grad", action="store_true",
+                    help="cfg2 / cfg3 with several ranks: cfg.split_grad_exchange -- the gradient all-reduce in two parts, the first "
+                         "beside the encoder's reverse pass (the line reports the other setting too: other_exchange_setting)")
+    ap.add_argument("--no-split-probe", action="store_true", help="do not time the other setting of --split-grad")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1: run the data-parallel entry point with a 1-rank communicator (plumbing check)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,

@@ -81,6 +81,12 @@ typedef struct {
                            /* of the reference's float32 SPRITES graph (SVGPVAE_model.py:516); 2: only the statistics */
                            /* S_l = K_mn diag(w) K_nm (sums of non-negative terms for the forward weights) do.  The   */
                            /* m x m factorisations / inverses stay float64 in every mode               */
+    int32_t split_grad_exchange; /* data parallelism, row-sharded schedule: 1 = the closing gradient all-reduce in TWO parts   */
+                           /* -- decoder + GP parameters + scalar sums as soon as the kernel-matrix reverse pass is done (they   */
+                           /* do not depend on the encoder's reverse pass; svgp_mnist_train_step_dp issues it on a side        */
+                           /* stream), the encoder's part behind its reverse pass -- so that one of the three small-message    */
+                           /* latencies hides under the encoder's reverse pass.  0 (default): one all-reduce.  (The field sits */
+                           /* in the padding in front of N_train: the struct's size and every other offset are unchanged.)    */
     double  N_train;       /* mainSVGP.N_train                                                  */
     double  jitter;        /* mainSVGP.jitter                                                   */
     double  kappa_squared; /* GECO kappa^2                                                      */
@@ -259,6 +265,11 @@ int svgp_mnist_grad_reduce(const svgp_mnist_cfg*, double* ws, void* stream);
 int svgp_kernel_matrix_bwd_partials(const svgp_mnist_cfg*, const double* theta, const double* aux, double* ws,
                                     void* stream);
 int svgp_mnist_grad_reduce_all(const svgp_mnist_cfg*, const double* aux, double* ws, void* stream);
+/* part 1: everything of svgp_mnist_grad_reduce_all except the encoder's weights (decoder weights, scalar sums, object-table
+ * scatter and GP hyper-parameter sums) -> gradC[n_enc:]; part 2: the encoder's weights -> gradC[:n_enc].  1 + 2 == _all.
+ * svgp_mnist_step_phase phases 4 / 5 = phase 2 cut at that point (4: ... kernel-matrix reverse pass, part 1; 5: encoder reverse
+ * pass, part 2) for cfg.split_grad_exchange. */
+int svgp_mnist_grad_reduce_part(const svgp_mnist_cfg*, const double* aux, double* ws, int part, void* stream);
 /* Two more phase-form pairs with identical results (m <= 64; for larger m they are the plain stages).  A piece of work
  * that is off the critical path moves into extra workgroups of a later launch that leaves most CUs idle:
  *   (A_hat + jI)^-1 and the log det term of KL:  svgp_gp_factor_fwd_defer_aji ... svgp_gp_stats_bwd_with_aji

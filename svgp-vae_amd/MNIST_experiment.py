@@ -69,6 +69,9 @@ def build_parser():
     p.add_argument('--epsilon_seed', type=int, default=None,
                    help="reproducible N(0,1) draws of SVGPVAE_model.py:901: batch i of epoch e uses "
                         "numpy.random.RandomState(1000 e + i + seed).randn(rows, L) instead of the on-device generator")
+    p.add_argument('--split_grad_exchange', action='store_true',
+                   help="data parallel: the gradient all-reduce in two parts, the first (decoder + GP parameters) beside the encoder's "
+                        "reverse pass (cfg.split_grad_exchange; a fallback for slow small-message all-reduces)")
     p.add_argument('--log_json', type=str, default=None,
                    help="rank 0 writes the per-step log (elbo, recon_loss, C_ma, lagrange_mult), the evaluation series and the "
                         "final flat parameter vector to this file")
@@ -123,7 +126,8 @@ def run_experiment_rotated_mnist_SVGPVAE(args, args_dict=None, ctx=None):
     # blocks is a function of it)
     b_cap = max(args.batch_size, N_train)
     rt = _runtime(VAE, SVGP_, args.clip_qs, args.GECO, kappa, b_cap, alpha_flag=args.alpha, lr=args.lr,
-                  beta=args.beta, rank=ctx.rank, world_size=ctx.world)
+                  beta=args.beta, rank=ctx.rank, world_size=ctx.world,
+                  split_grad_exchange=getattr(args, "split_grad_exchange", False))
     eng = rt.eng
     dev = eng.device
     comm_fallback = attach_library_comm(eng, ctx)

@@ -198,7 +198,7 @@ class _Runtime:
     and re-points the objects' attributes at views of it, so optimiser updates are visible to both."""
 
     def __init__(self, vae, svgp, clipping_qs, GECO, kappa, alpha_flag=0.99, b_max=256, lr=1e-3, beta=0.001,
-                 rank=0, world_size=1):
+                 rank=0, world_size=1, split_grad_exchange=False):
         M = svgp.inducing_index_points.shape[1] - 2
         n_obj = 0 if svgp.object_vectors is None else svgp.object_vectors.shape[0]
         self.key = (bool(clipping_qs), bool(GECO), float(kappa))
@@ -208,7 +208,7 @@ class _Runtime:
                                    kappa_squared=float(kappa) ** 2, alpha=alpha_flag, beta=beta, lr=lr,
                                    train_ip=not svgp.fixed_inducing_points, train_gp=not svgp.fixed_gp_params,
                                    train_ov=svgp.object_vectors is not None, b_max=b_max, device=svgp.device,
-                                   rank=rank, world_size=world_size)
+                                   rank=rank, world_size=world_size, split_grad_exchange=split_grad_exchange)
         params = dict(vae.params)
         params.update(svgp._params())
         self.eng.load_params(params)
@@ -242,6 +242,7 @@ def _runtime(vae, svgp, clipping_qs, GECO, kappa, b, **kw):
             kw.setdefault("alpha_flag", old.eng.base["alpha"])
             kw.setdefault("rank", old.eng.rank)
             kw.setdefault("world_size", old.eng.world_size)
+            kw.setdefault("split_grad_exchange", bool(old.eng.base.get("split_grad_exchange", 0)))
         rt = _Runtime(vae, svgp, clipping_qs, GECO, kappa, b_max=max(b, 256 if old is None else old.eng.b_max), **kw)
         if old is not None:
             new, prev = rt.eng, old.eng

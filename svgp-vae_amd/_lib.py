@@ -17,7 +17,8 @@ class SvgpError(RuntimeError):
 class MnistCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("b", "b_global", "m", "L", "M", "n_obj", "normalize_obj", "clip_qs",
                                          "geco", "train_ip", "train_gp", "train_ov", "b_cap", "clip_pv", "n_pix",
-                                         "titsias", "kl_form", "single_stat_block", "gemm_f32")] + \
+                                         "titsias", "kl_form", "single_stat_block", "gemm_f32",
+                                         "split_grad_exchange")] + \
                [(n, C.c_double) for n in ("N_train", "jitter", "kappa_squared", "alpha", "rep_weight")]
 
 
@@ -111,6 +112,7 @@ SIGNATURES = {
     "svgp_gp_factor_bwd_nofinal": [_CFG, _P, _P, _P],
     "svgp_gp_factor_bwd_nofinal_wgrad": [_CFG, _P, _P, _P, _P],
     "svgp_mnist_encoder_bwd_km": [_CFG, _P, _P, _P, _P, _P],
+    "svgp_mnist_grad_reduce_part": [_CFG, _P, _P, C.c_int, _P],
     "svgp_gp_posterior_bwd_with_final": [_CFG, _P, _P, _P],
     "svgp_gp_titsias_stats": [_CFG, _P, _P],
     "svgp_gp_titsias_fwd": [_CFG, _P, _P, _P],

@@ -314,7 +314,7 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
     int rc = svgp_check_cfg(c);
     if (rc) return rc;
     SVGP_REQUIRE(theta && images && aux && ws && state, SVGP_ERR_INVALID, "NULL device pointer");
-    SVGP_REQUIRE(phase >= 0 && phase <= 3, SVGP_ERR_INVALID, "phase %d out of range 0..3", phase);
+    SVGP_REQUIRE(phase >= 0 && phase <= 5, SVGP_ERR_INVALID, "phase %d out of range 0..5", phase);
     hipStream_t ms = (hipStream_t)stream;
     // Measured on MI355X (tools/fork_probe.py): a fork + join costs ~10 us of cross-stream signalling.  The
     // kernel-matrix reverse pass || encoder reverse pass branch hides ~20 us, which pays only in the
@@ -384,6 +384,13 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         if (fork1 && !defer) RUN(side_join(sd, 1, ms));        // phase-at-a-time callers: joined before the phase returns
         break;
     case 2:
+    case 4:     // phase 2 up to and including the kernel-matrix reverse pass + gradient reduction part 1 (cfg.split_grad_exchange)
+    case 5:     // ... the encoder's reverse pass + gradient reduction part 2
+        if (phase == 5) {
+            RUN(svgp_mnist_encoder_bwd(c, theta, images, ws, stream));
+            RUN(svgp_mnist_grad_reduce_part(c, aux, ws, 2, stream));
+            break;
+        }
         // The late half alone is valid only if phase 1 of this library issued the early half on this workspace (recorded per
         // workspace, not inferred from the environment): a caller that ran the phase-1 stages through the individual entry
         // points, or changed SVGP_SIDE_STREAMS in between, gets the full reverse factor stage.
@@ -400,6 +407,11 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         if (c->titsias) RUN(svgp_gp_titsias_bwd(c, ws, state, stream));
         // (m > 64, measured round 5: the kernel-matrix reverse pass on side branch 0 beside the encoder's does NOT overlap -- 68 KB +
         // 104 KB of LDS per workgroup do not fit one CU; the kernel-matrix launch stretched from 49 to 103 us and the step was unchanged)
+        if (phase == 4) {
+            RUN(svgp_kernel_matrix_bwd_partials(c, theta, aux, ws, stream));
+            RUN(svgp_mnist_grad_reduce_part(c, aux, ws, 1, stream));
+            break;
+        }
         if (!large && !fork2 && enc_km_merge_on()) {
             RUN(svgp_mnist_encoder_bwd_km(c, theta, images, aux, ws, stream));
         } else {

@@ -365,6 +365,35 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     DpGuard guard{comm, stream};
     if (cm->timing) cm->npoints = 0;
 #define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
+    if (!sharded && c->split_grad_exchange) {
+        // The closing all-reduce in two parts (round 6; prepared for small-message all-reduce latencies above ~20 us on 8 ranks,
+        // where three of them per 165 us step would cap weak scaling below 6x): gradC[n_enc:] -- decoder + GP parameters + scalar
+        // sums -- is complete once the kernel-matrix reverse pass and reduction part 1 are done and travels on the side branch WHILE
+        // the encoder's reverse pass runs on the caller's stream; gradC[:n_enc] follows it.  Same sums, same order on every rank.
+        svgp_mnist_param_layout pl;
+        RUN(svgp_mnist_param_layout_get(c, &pl));
+        const int64_t off2[2] = {wl.statA, wl.statB}, len2[2] = {wl.statA_len, wl.statB_len};
+        for (int ph = 0; ph < 2; ++ph) {
+            RUN(svgp_mnist_step_phase_deferred(c, ph, theta, images, aux, eps, ws, state, adam_m, adam_v, stream));
+            RUN(pt.begin());
+            RUN(svgp_allreduce_sum_f64(comm, ws + off2[ph], len2[ph], stream));
+            RUN(pt.end());
+        }
+        RUN(svgp_mnist_step_phase_deferred(c, 4, theta, images, aux, eps, ws, state, adam_m, adam_v, stream));
+        void* side = stream;
+        RUN(guard.fork(&side));
+        Point pts{cm, (hipStream_t)side, -1};
+        RUN(pts.begin());
+        RUN(svgp_allreduce_sum_f64(comm, ws + wl.gradC + pl.n_enc, wl.gradC_len - pl.n_enc, side));
+        RUN(pts.end());
+        RUN(svgp_mnist_step_phase_deferred(c, 5, theta, images, aux, eps, ws, state, adam_m, adam_v, stream));
+        RUN(pt.begin());
+        RUN(svgp_allreduce_sum_f64(comm, ws + wl.gradC, pl.n_enc, stream));
+        RUN(pt.end());
+        RUN(guard.join());
+        RUN(svgp_mnist_step_phase_deferred(c, 3, theta, images, aux, eps, ws, state, adam_m, adam_v, stream));
+        return SVGP_OK;
+    }
     if (!sharded) {
         const int64_t off[3] = {wl.statA, wl.statB, wl.gradC}, len[3] = {wl.statA_len, wl.statB_len, wl.gradC_len};
         for (int ph = 0; ph < 4; ++ph) {

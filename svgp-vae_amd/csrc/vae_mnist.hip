@@ -322,15 +322,16 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_grad_reduce(int n_part, int n_en
                                                             const real* __restrict__ part_sums,
                                                             const real* __restrict__ tit_rowsum,
                                                             real* __restrict__ grad, real* __restrict__ sums,
-                                                            KmScatter ks) {
+                                                            KmScatter ks, int blk0) {
     __shared__ real s[16][17];
     __shared__ real red[16];
-    if ((int)blockIdx.x > nb_enc + nb_dec) {
-        svgp_km_scatter_block(blockIdx.x - (nb_enc + nb_dec + 1), ks.n_blocks, b, ks.M, ks.n_obj, ks.aux, ks.n_gp_part,
+    const int bid = (int)blockIdx.x + blk0;          // blk0: the launch covers the logical blocks [blk0, blk0 + gridDim.x)
+    if (bid > nb_enc + nb_dec) {
+        svgp_km_scatter_block(bid - (nb_enc + nb_dec + 1), ks.n_blocks, b, ks.M, ks.n_obj, ks.aux, ks.n_gp_part,
                               ks.train_gp, ks.train_ov, ks.d_on, ks.part_gp, ks.d_ov, ks.d_ls, ks.d_amp);
         return;
     }
-    if ((int)blockIdx.x == nb_enc + nb_dec) {
+    if (bid == nb_enc + nb_dec) {
         real l3 = 0, ce = 0, sq = 0;
         for (int i = threadIdx.x; i < n_part; i += blockDim.x) sq += part_sums[i * 4 + 2];
         const real* pp = part_sums + (size_t)n_part * 4;
@@ -345,8 +346,8 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_grad_reduce(int n_part, int n_en
         }
         return;
     }
-    const bool enc = (int)blockIdx.x < nb_enc;
-    const int n = enc ? n_enc : n_dec, blk = enc ? blockIdx.x : blockIdx.x - nb_enc;
+    const bool enc = bid < nb_enc;
+    const int n = enc ? n_enc : n_dec, blk = enc ? bid : bid - nb_enc;
     const real* part = enc ? part_enc : part_dec;
     real* out = enc ? grad : grad + n_enc;
     const int il = threadIdx.x & 15, ch = threadIdx.x >> 4;
@@ -517,7 +518,7 @@ extern "C" int svgp_mnist_decoder_bwd_weights(const svgp_mnist_cfg* c, const dou
     return SVGP_OK;
 }
 
-static int grad_reduce_impl(const svgp_mnist_cfg* c, const double* aux, double* ws, bool with_scatter, void* stream) {
+static int grad_reduce_impl(const svgp_mnist_cfg* c, const double* aux, double* ws, bool with_scatter, void* stream, int part = 0) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws, SVGP_ERR_INVALID, "NULL device pointer");
     const int n_part = svgp_n_part(c);
@@ -537,10 +538,12 @@ static int grad_reduce_impl(const svgp_mnist_cfg* c, const double* aux, double* 
         int rc = set_dyn_lds(k_grad_reduce, lds);
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_grad_reduce, dim3(nb_enc + nb_dec + 1 + ks.n_blocks), dim3(SVGP_BLOCK), lds, (hipStream_t)stream,
+    // part 0: all logical blocks; 2: the encoder's [0, nb_enc); 1: the rest
+    const int total = nb_enc + nb_dec + 1 + ks.n_blocks, blk0 = part == 1 ? nb_enc : 0, nblk = part == 2 ? nb_enc : total - blk0;
+    hipLaunchKernelGGL(k_grad_reduce, dim3(nblk), dim3(SVGP_BLOCK), lds, (hipStream_t)stream,
                        n_part, n_enc, n_dec, nb_enc, nb_dec, svgp_n_post_actual(c), c->b, ws + wl.part_enc, ws + wl.part_dec,
                        ws + wl.part_sums, c->titsias ? ws + wl.tit_scal + 2 * c->L : (const real*)nullptr, ws + wl.grad,
-                       ws + wl.sums, ks);
+                       ws + wl.sums, ks, blk0);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
@@ -552,4 +555,8 @@ extern "C" int svgp_mnist_grad_reduce(const svgp_mnist_cfg* c, double* ws, void*
 // + the object-table scatter and hyper-parameter sums left open by svgp_kernel_matrix_bwd_partials
 extern "C" int svgp_mnist_grad_reduce_all(const svgp_mnist_cfg* c, const double* aux, double* ws, void* stream) {
     return grad_reduce_impl(c, aux, ws, true, stream);
+}
+extern "C" int svgp_mnist_grad_reduce_part(const svgp_mnist_cfg* c, const double* aux, double* ws, int part, void* stream) {
+    SVGP_REQUIRE(part == 1 || part == 2, SVGP_ERR_INVALID, "part %d (1 or 2)", part);
+    return grad_reduce_impl(c, aux, ws, true, stream, part);
 }

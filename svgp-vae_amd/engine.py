@@ -68,8 +68,16 @@ class DataParallelStep:
         self._allreduce("statA")
         be.phase(1)
         self._allreduce("statB")
-        be.phase(2)
-        self._allreduce("gradC")
+        if getattr(be, "split_grad_exchange", False):
+            # cfg.split_grad_exchange through torch.distributed: the same two messages (no overlap with the encoder's reverse
+            # pass here -- that is the in-library form's, svgp_mnist_train_step_dp)
+            be.phase(4)
+            self._allreduce("gradC_tail")
+            be.phase(5)
+            self._allreduce("gradC_head")
+        else:
+            be.phase(2)
+            self._allreduce("gradC")
         be.phase(3)
 
 
@@ -371,7 +379,7 @@ class MnistStepEngine:
     def __init__(self, m, L=16, M=8, n_obj=400, *, N_train=4050.0, jitter=1e-6, clip_qs=True, geco=False,
                  K_obj_normalize=False, titsias=False, kappa_squared=0.020, alpha=0.99, beta=0.001, lr=1e-3,
                  train_ip=True, train_gp=True, train_ov=True, b_max=256, device="cuda:0",
-                 rank=0, world_size=1, single_stat_block=None):
+                 rank=0, world_size=1, single_stat_block=None, split_grad_exchange=False):
         self.lib = _lib.load_library()          # raises if the HIP extension is missing
         if not torch.cuda.is_available():
             raise _lib.SvgpError("MnistStepEngine needs a HIP device (torch.cuda.is_available() is False); "
@@ -391,7 +399,11 @@ class MnistStepEngine:
                          # attach_comm / run check the block lengths across ranks.
                          # (single_stat_block on one rank: the kernel configuration of a multi-rank step, bench.py --force-comm)
                          single_stat_block=int((world_size > 1 and (m > 64 or os.environ.get("SVGP_DP_STAT_PARTIALS") == "0"))
-                                               if single_stat_block is None else single_stat_block))
+                                               if single_stat_block is None else single_stat_block),
+                         # row-sharded data parallelism: the gradient all-reduce in two parts, the first one (decoder + GP parameters
+                         # + scalar sums) beside the encoder's reverse pass (include/svgpvae_hip.h: cfg.split_grad_exchange); off by
+                         # default -- a fallback for slow small-message all-reduces, to be decided by the first multi-GPU run
+                         split_grad_exchange=int(bool(split_grad_exchange)))
         self.b_max = b_max
         self.cfg = None
         self.pl = ParamLayout()
@@ -432,6 +444,11 @@ class MnistStepEngine:
         self.wl = WsLayout()
         call("svgp_mnist_ws_layout_get", C.byref(self.cfg), C.byref(self.wl))
         assert self.wl.total <= self.ws.numel()
+
+    def set_split_grad_exchange(self, flag):
+        """Switches cfg.split_grad_exchange (the gradient all-reduce in two parts) on an existing engine."""
+        self.base["split_grad_exchange"] = int(bool(flag))
+        self.set_batch_size(self.cfg.b, self.cfg.b_global)
 
     def reset_state(self, beta=None, lr=None):
         """MNIST_experiment.py:313-315: first_step=True (alpha 0), C_ma_=0, lagrange_mult_=1."""
@@ -495,6 +512,9 @@ class MnistStepEngine:
         return {k: self._pview(g, k) for k in self.shapes}
 
     def block(self, name):
+        if name in ("gradC_head", "gradC_tail"):      # the two messages of cfg.split_grad_exchange: encoder | everything else + sums
+            g, n_enc = self.ws_view("gradC"), int(self.pl.n_enc)
+            return g[:n_enc] if name == "gradC_head" else g[n_enc:]
         return self.ws_view(name)
 
     # ------------------------------------------------------------------ execution
@@ -691,7 +711,7 @@ class MnistStepEngine:
 
 class _GraphAdapter:
     def __init__(self, eng, key):
-        self.eng, self.key = eng, key
+        self.eng, self.key = eng, key          # (per-phase graphs are the four phases 0..3: the unsplit exchange)
 
     def phase(self, k):
         self.eng.replay((self.key, k))
@@ -703,6 +723,7 @@ class _GraphAdapter:
 class _PhaseAdapter:
     def __init__(self, eng, adam):
         self.eng, self.adam = eng, adam
+        self.split_grad_exchange = bool(eng.base.get("split_grad_exchange"))
 
     def phase(self, k):
         self.eng.phase(k, self.adam)

@@ -195,6 +195,10 @@ def test_bench_multi_gpu_code_path_at_world_size_one():
             assert line["config"]["rccl_ranks"] == 1
             assert list(line["collectives_us"]) == ["ar[S|v]", "ar[A2|ud|td]", "ar[grad|sums]"]
             assert all(0 < v < 1e4 for v in line["collectives_us"].values())
+            # ... and the other setting of cfg.split_grad_exchange next to it: four exchange points
+            other = line["other_exchange_setting"]
+            assert other["split_grad_exchange"] is True and line["config"]["split_grad_exchange"] is False
+            assert len(other["collectives_us"]) == 4 and 0.5 * line["ms_per_step"] < other["ms_per_step"] < 1.5 * line["ms_per_step"]
     # a rank whose library communicator cannot be created: the collective decision sends every rank to the torch.distributed form
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", "29534", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "3",
@@ -283,3 +287,44 @@ def test_bench_multi_rank_paths_of_the_eight_gpu_configs_with_one_rank(workload,
             assert len(last["collectives_us"]) == 3 and all(v >= 0 for v in last["collectives_us"].values())
         else:
             assert "all-reduce of S, v" in last["config"]["workload"] and last["probe_rel_err_S"] < 1e-4
+
+
+@pytest.mark.parametrize("m,b,L,M", [(32, 256, 16, 8), (72, 96, 3, 16)])
+def test_split_gradient_exchange_through_the_dp_entry_with_one_rank(m, b, L, M):
+    """svgp_mnist_train_step_dp with cfg.split_grad_exchange and a 1-rank communicator: four exchange points (statA, statB, the
+    gradient tail on the library's side branch beside the encoder's reverse pass, the gradient head) through real RCCL calls;
+    three Adam steps equal the ordinary data-parallel entry and the plain single-GPU step.  (m = 72, L = 3 with ... ranks: the
+    row-sharded schedule of the large-m path, taken when L is not divisible by the rank count -- here forced by titsias = False,
+    one rank: L % 1 == 0 takes the channel-sharded one, so the large case runs m <= 64 semantics only through phases 4 / 5.)"""
+    from svgp_vae_amd.engine import RcclComm
+    params, images, aux, eps = H.toy_problem(b=b, m=m, L=L, M=M, n_obj=40, seed=8)
+    kw = dict(geco=True, N_train=4050.0, jitter=1e-4)
+    plain = H.engine_for(params, b, **kw)
+    split = H.engine_for(params, b, split_grad_exchange=True, **kw)
+    comm = RcclComm(0, 1, RcclComm.unique_id())
+    split.attach_comm(comm)
+    dev = plain.device
+    di, da, de = images.to(dev), aux.to(dev), eps.to(dev)
+    plain.bind(di, da, de); split.bind(di, da, de)
+    comm.timing(True)
+    for _ in range(3):
+        plain.run(adam=True)
+        split.run(adam=True)
+    plain.synchronize(); split.synchronize()
+    us = comm.timing_read()
+    if m <= 64:
+        assert len(us) == 4 and all(0.0 < u < 1e5 for u in us), us
+    comm.timing(False)
+    assert H.relerr(split.theta, plain.theta) < 1e-9
+    sp, sd = plain.scalars(), split.scalars()
+    for k in ("elbo", "recon_loss", "kl_term", "adam_t"):
+        assert abs(sp[k] - sd[k]) <= 1e-9 * max(1.0, abs(sp[k])), k
+    # phases 4 + 5 == phase 2 through the phase entry point, any m
+    for eng in (plain, split):
+        eng.reset_state()
+    plain.phase(0); plain.phase(1); plain.phase(2); plain.phase(3, adam=False)
+    split.phase(0); split.phase(1); split.phase(4); split.phase(5); split.phase(3, adam=False)
+    plain.synchronize(); split.synchronize()
+    for k, v in plain.grads().items():
+        assert H.relerr(split.grads()[k], v) < 1e-12, k
+    comm.close()

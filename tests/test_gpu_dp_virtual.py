@@ -137,3 +137,52 @@ def test_channel_sharded_virtual_ranks_equal_single_engine(G, b, m, L, M, pack, 
             assert H.relerr(e.theta, single.theta) < max(1e-5, 1e3 * max(gnoise.values()))
     for e in ranks[1:]:
         assert torch.equal(e.theta, ranks[0].theta)
+
+
+@pytest.mark.parametrize("G,b", [(2, 256), (8, 256), (3, 210)])
+def test_split_gradient_exchange_virtual_ranks_equal_single_engine(golden, G, b):
+    """cfg.split_grad_exchange: the closing all-reduce as two messages -- gradC[n_enc:] (decoder + GP parameters
+    + scalar sums) after phase 4 (everything of phase 2 up to the kernel-matrix reverse pass + gradient reduction part 1),
+    gradC[:n_enc] (encoder) after phase 5 (encoder reverse pass + reduction part 2) -- with G virtual ranks against the single
+    engine's ordinary step: scalars and parameters after three Adam steps."""
+    from svgp_vae_amd.engine import shard_rows
+    params, images, aux, eps = H.golden_problem(golden, rows=slice(0, b))
+    single = H.engine_for(params, b, geco=True)
+    dev = single.device
+    di, da, de = images.to(dev), aux.to(dev), eps.to(dev)
+    single.bind(di, da, de)
+    ranks = []
+    for r in range(G):
+        lo, hi = shard_rows(b, G, r)
+        e = H.engine_for(params, hi - lo, geco=True, rank=r, world_size=G, split_grad_exchange=True)
+        assert e.cfg.split_grad_exchange == 1
+        e.set_batch_size(hi - lo, b)
+        e.bind(di[lo:hi].contiguous(), da[lo:hi].contiguous(), de[lo:hi].contiguous())
+        ranks.append(e)
+
+    def exchange(name):
+        for e in ranks:
+            e.synchronize()
+        tot = sum(e.block(name) for e in ranks)
+        for e in ranks:
+            with torch.cuda.stream(e.stream):
+                e.block(name).copy_(tot)
+            e.synchronize()
+
+    for step in range(3):
+        single.run(adam=True)
+        single.synchronize()
+        for k, name in ((0, "statA"), (1, "statB"), (4, "gradC_tail"), (5, "gradC_head"), (3, None)):
+            for e in ranks:
+                e.phase(k, True)
+            if name:
+                exchange(name)
+        ref = single.scalars()
+        for e in ranks:
+            sc = e.scalars()
+            for k in ("elbo", "recon_loss", "kl_term", "inside_elbo", "ce_term", "c_ma", "lagrange", "adam_t"):
+                assert abs(sc[k] - ref[k]) <= 1e-9 * max(1.0, abs(ref[k])), (step, k, sc[k], ref[k])
+            assert H.relerr(e.theta, single.theta) < 1e-9
+    n_enc = int(ranks[0].pl.n_enc)
+    assert ranks[0].block("gradC_head").numel() == n_enc
+    assert ranks[0].block("gradC_head").numel() + ranks[0].block("gradC_tail").numel() == ranks[0].block("gradC").numel()

@@ -302,7 +302,13 @@ int svgp_gp_factor_bwd_early_a(const svgp_mnist_cfg*, double* ws, const double* 
 int svgp_gp_factor_bwd_early_b(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 /* _late = _late_a + _late_b: _late_a (the vector chain; with the statistic SW formed by svgp_gp_stats_bwd -- all rows local,
  * b < 3 m -- also X, vbar, Si X and -(Si X) Si) reads nothing the early half writes, so a caller that runs the early half on
- * another stream issues it BEFORE joining that stream; _late_b follows the join. */
+ * another stream issues it BEFORE joining that stream; _late_b follows the join.
+ * WRITE SET of _late_a: the scratch vectors ubar / mubar / tbar always; in the row form (cfg.b == cfg.b_global,
+ * cfg.b < 3 m, or cfg.titsias) also ws.vbar, the Ssym slot (it parks Si X there) and scratch matrix 1 (X, then -(Si X) Si) --
+ * none of which the early half touches IN THAT FORM (it then skips its own T = S P in scratch matrix 1).  The form is a function
+ * of cfg.b / cfg.b_global / cfg.titsias alone and is evaluated by svgp_gp_stats_bwd, _early and _late_a independently: a caller
+ * must not change those fields between the three calls of one step (svgp_mnist_step_phase / _train_step never do; row-form X0
+ * itself is left in scratch matrix 2 by svgp_gp_stats_bwd, so the stage may be repeated on a workspace). */
 int svgp_gp_factor_bwd_late_a(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_late_b(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);

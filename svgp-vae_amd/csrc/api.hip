@@ -301,9 +301,9 @@ bool enc_km_merge_on() {
     const char* e = getenv("SVGP_ENC_KM_MERGE");
     return !(e && e[0] == '0');
 }
-bool konly_on() {
-    static const int on = [] { const char* e = getenv("SVGP_KONLY_BRANCH"); return (e && e[0] == '0') ? 0 : 1; }();
-    return on != 0;
+bool konly_on() {      // (read per call: tests compare the two orders in one process)
+    const char* e = getenv("SVGP_KONLY_BRANCH");
+    return !(e && e[0] == '0');
 }
 // `defer`: the caller issues all four phases back to back on one stream (svgp_mnist_train_step), so a
 // branch forked in one phase may be joined in a later one; otherwise every phase joins before returning

@@ -33,6 +33,12 @@ __device__ __forceinline__ real readlane_f64(real v, int src) {
     const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)u, src), hi = __builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
     return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
+//  the 64-bit DPP move with row_newbcast exists on gfx90a / gfx94x / gfx950 only; this library is written for gfx950 and
+// every m <= 32 inverse of the step goes through it: any other --offload-arch must fail HERE, loudly, not miscompile
+#if defined(__HIP_DEVICE_COMPILE__) && !(defined(__gfx90a__) || defined(__gfx940__) || defined(__gfx941__) || defined(__gfx942__) || \
+                                        defined(__gfx950__))
+#error "sweep32.hpp: v_mov_b64_dpp row_newbcast needs gfx90a / gfx94x / gfx950 (build with --offload-arch=gfx950)"
+#endif
 // value of lane SRC (0..15) of the caller's own 16-lane DPP row: ONE v_mov_b64_dpp (gfx90a+: 64-bit DPP with row_newbcast)
 template <int SRC>
 __device__ __forceinline__ real row_bcast_f64(real v) {

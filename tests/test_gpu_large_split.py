@@ -215,3 +215,24 @@ def test_side_branch_and_main_branch_share_no_buffer():
                    and f not in ("total", "n_part", "n_post", "stat_parts") and not f.endswith("_len")] + [a.numel()])
         assert torch.equal(a[off:nxt], b[off:nxt]), k
         assert torch.isfinite(a[off:nxt]).all(), k
+
+
+@pytest.mark.parametrize("m,b,L,M", [(130, 150, 3, 24), (256, 1024, 16, 32)])
+def test_k_only_side_branch_equals_the_in_line_order(m, b, L, M, monkeypatch):
+    """the channel-independent block of the forward factor stage ((K + jI)^-1, Kn Ki, q, W, P^T) on side branch 1
+    beside the statistics and the channel inverses (SVGP_KONLY_BRANCH, default on for 64 < m < 512) against the in-line order:
+    the same operations on the same values, so two Adam steps agree BIT FOR BIT -- which also pins that the branch's scratch
+    (the tail of the inverse workspace, Kn Ki / W / P^T) is disjoint from what the statistics and the channel block use.
+    Second shape: BASELINE configs[2]."""
+    params, images, aux, eps = H.toy_problem(b=b, m=m, L=L, M=M, n_obj=40, seed=9)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SVGP_KONLY_BRANCH", flag)
+        eng = H.engine_for(params, b, geco=True, N_train=4050.0, jitter=1e-4)
+        dev = eng.device
+        eng.bind(images.to(dev), aux.to(dev), eps.to(dev))
+        for _ in range(2):
+            eng.run(adam=True)
+        eng.synchronize()
+        res[flag] = (eng.theta.clone(), eng.state.clone())
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])

@@ -94,6 +94,16 @@ def roofline_of(flops, nbytes, us, peak_tflops, **extra):
     return r
 
 
+def _traffic_src(path):
+    """`profiles/<tag>_pmc_traffic.json @ <commit the counters were collected at>` (profiles/<tag>_commit.txt)."""
+    rel = os.path.relpath(path, ROOT)
+    try:
+        commit = open(path.replace("_pmc_traffic.json", "_commit.txt")).read().strip()
+        return f"{rel} @ {commit}"
+    except Exception:
+        return rel
+
+
 def committed_traffic(kernel_key, per_pass_of=None):
     """HBM bytes per launch of `kernel_key` from the newest committed rocprofv3 PMC summary (profiles/*_pmc_traffic.json,
     collected with tools/pmc_summary.py in separate --pmc passes).  bench.py cannot run the profiler on itself, so this
@@ -106,8 +116,8 @@ def committed_traffic(kernel_key, per_pass_of=None):
                     k = ks[key]
                     if per_pass_of and (key.split(":")[0] + ":" + per_pass_of) in ks and "hbm_bytes_total_corrected" in k:
                         # several launches (instantiations) of the kernel per pass: bytes of all of them / passes profiled
-                        return k["hbm_bytes_total_corrected"] / ks[key.split(":")[0] + ":" + per_pass_of]["dispatches"], os.path.relpath(path, ROOT)
-                    return k["hbm_bytes_per_launch_corrected"], os.path.relpath(path, ROOT)
+                        return k["hbm_bytes_total_corrected"] / ks[key.split(":")[0] + ":" + per_pass_of]["dispatches"], _traffic_src(path)
+                    return k["hbm_bytes_per_launch_corrected"], _traffic_src(path)
         except Exception:
             pass
     return None, None
@@ -119,7 +129,7 @@ def committed_step_traffic(workload):
         try:
             w = json.load(open(path)).get("workloads", {}).get(workload)
             if w:
-                return w["hbm_bytes_per_step_corrected"], os.path.relpath(path, ROOT)
+                return w["hbm_bytes_per_step_corrected"], _traffic_src(path)
         except Exception:
             pass
     return None, None
@@ -246,10 +256,15 @@ def stage_table(eng, B, M_IND):
         ("gp_posterior_bwd", "svgp_gp_posterior_bwd_with_final", (cfg, ws, st, s),
          (2 * Lc * b * m * m + 2 * b * m * m) if m > 64 else 6 * Lc * b * m * m,
          f8 * (Lc * 3 * m * m + 2 * Lc * b * m + 12 * b * Lc), 0.0),
+    ] + ([  # m <= 64 (round 6): the kernel-matrix VJP workgroups ride FIRST in the encoder's reverse launch
+        ("encoder_bwd_km", "svgp_mnist_encoder_bwd_km", (cfg, th, img, aux, ws, s),
+         4 * enc_mac * b + (2 * b * m + 2 * m * m) * (2 * D + 20),
+         f8 * (b * (784 + act_enc + 3 * Lc) + 2 * n_enc + 2 * b * m + 2 * m * m + b * (D + 1) + N_OBJ * (D - 1)), f8 * n_part * n_enc)]
+         if m <= 64 else [
         ("kernel_matrix_bwd", "svgp_kernel_matrix_bwd_partials", (cfg, th, aux, ws, s),
          (2 * b * m + 2 * m * m) * (2 * D + 20), f8 * (2 * b * m + 2 * m * m + b * (D + 1) + N_OBJ * (D - 1)), 0.0),
         ("encoder_bwd", "svgp_mnist_encoder_bwd", (cfg, th, img, ws, s), 4 * enc_mac * b,
-         f8 * (b * (784 + act_enc + 3 * Lc) + 2 * n_enc), f8 * n_part * n_enc),
+         f8 * (b * (784 + act_enc + 3 * Lc) + 2 * n_enc), f8 * n_part * n_enc)]) + [
         ("grad_reduce", "svgp_mnist_grad_reduce_all", (cfg, aux, ws, s), n_part * (n_enc + n_dec),
          f8 * (n_enc + n_dec), f8 * n_part * (n_enc + n_dec)),
     ]

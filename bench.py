@@ -528,7 +528,10 @@ def mnist_case(args, scaling, multi, dev, ctx, strict=True):
     coll_us, other = None, None
     if eng.comm is not None:
         coll_us = collectives()
-        if not eng.channel_sharded() and not args.no_split_probe:
+        # With several ranks the other setting is timed only on request (--split-probe): it is code no multi-GPU box has run yet,
+        # and it would sit between the timed region and the result line of the scaling run.  One rank (--force-comm /
+        # --force-dist): always, unless --no-split-probe.
+        if not eng.channel_sharded() and not args.no_split_probe and (world == 1 or args.split_probe):
             # the OTHER setting of cfg.split_grad_exchange (gradient all-reduce in two parts, the first beside the encoder's reverse
             # pass): a short timed block + its exchange points, so that the first multi-GPU run shows which one to keep
             flag = bool(eng.base["split_grad_exchange"])
@@ -1059,6 +1062,9 @@ def main():
                     help="cfg2 / cfg3 with several ranks: cfg.split_grad_exchange -- the gradient all-reduce in two parts, the first "
                          "beside the encoder's reverse pass (the line reports the other setting too: other_exchange_setting)")
     ap.add_argument("--no-split-probe", action="store_true", help="do not time the other setting of --split-grad")
+    ap.add_argument("--split-probe", action="store_true",
+                    help="several ranks: also time the OTHER setting of cfg.split_grad_exchange after the timed region and report it as "
+                         "other_exchange_setting (with one rank and a communicator this is the default)")
     ap.add_argument("--force-comm", action="store_true",
                     help="N=1: run the data-parallel entry point with a 1-rank communicator (plumbing check)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,

@@ -65,8 +65,8 @@ def test_virtual_rank_epoch_with_ragged_batch_equals_single_engine(G):
         assert torch.equal(e.theta, ranks[0].theta)
 
 
-@pytest.mark.parametrize("GECO", [True, False])
-def test_driver_under_torchrun_with_one_rank_takes_the_multi_rank_path_and_matches_the_oracle(golden, tmp_path, GECO):
+@pytest.mark.parametrize("GECO,libcomm", [(True, True), (False, True), (True, False)])
+def test_driver_under_torchrun_with_one_rank_takes_the_multi_rank_path_and_matches_the_oracle(golden, tmp_path, GECO, libcomm):
     gin, _ = golden
     d = str(tmp_path) + "/"
     pickle.dump({"images": gin["images"][:640], "aux_data": gin["aux"][:640]}, open(d + "train_data3.p", "wb"))
@@ -78,13 +78,16 @@ def test_driver_under_torchrun_with_one_rank_takes_the_multi_rank_path_and_match
             "--epsilon_seed", "7", "--log_json", d + "log.json", "--save", "--base_dir", d] + (["--GECO"] if GECO else [])
     env = dict(os.environ, SVGP_FORCE_DIST="1", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if not libcomm:        # the library communicator refused on the rank: the collective vote sends the driver to torch.distributed
+        env["SVGP_BENCH_FAIL_LIBCOMM"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), "-m", "svgp_vae_amd.MNIST_experiment"] + argv
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    assert "Data parallel over 1 ranks: RCCL communicator of the library" in r.stdout, r.stdout[-2000:]
+    assert ("Data parallel over 1 ranks: " + ("RCCL communicator of the library" if libcomm else "torch.distributed all-reduces")) \
+        in r.stdout, r.stdout[-2000:]
     log = json.load(open(d + "log.json"))
-    assert log["rccl_ranks"] == 1 and [s["rows"] for s in log["steps"]] == [256, 256, 128] * 2
+    assert log["rccl_ranks"] == (1 if libcomm else 0) and [s["rows"] for s in log["steps"]] == [256, 256, 128] * 2
     assert len(log["cgen_mse"]) == 1 and np.isfinite(log["cgen_mse"][0][1])          # rank 0 evaluated after the last epoch
     import glob
     files = glob.glob(d + "debug_MNIST/*/pics/test_metrics.txt")
@@ -123,10 +126,12 @@ def test_sprites_driver_under_torchrun_with_one_rank_equals_the_plain_run(tmp_pa
             "--GP_joint", "--opt_regime", "joint-2", "--eval_every", "2", "--lr", "0.002", "--epsilon_seed", "5", "--save", "--base_dir"]
     env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), HSA_ENABLE_IPC_MODE_LEGACY="0")
     logs = {}
+    launch = lambda: [sys.executable, "-m", "svgp_vae_amd.launch", "--nproc-per-node", "1", "--master-port", str(_free_port())]
     for name, launcher, extra in (("plain", [sys.executable], {}),
                                   # (svgp_vae_amd.launch: torchrun's own parser rejects the reference's `--m` as ambiguous)
-                                  ("dist", [sys.executable, "-m", "svgp_vae_amd.launch", "--nproc-per-node", "1", "--master-port",
-                                            str(_free_port())], dict(SVGP_FORCE_DIST="1"))):
+                                  ("dist", launch(), dict(SVGP_FORCE_DIST="1")),
+                                  # the library communicator refused: every exchange point through dp.TorchDistComm
+                                  ("fallback", launch(), dict(SVGP_FORCE_DIST="1", SVGP_BENCH_FAIL_LIBCOMM="1"))):
         out = d + name
         os.makedirs(out)
         cmd = launcher + ["-m", "svgp_vae_amd.SPRITES_experiment"] + argv + [out, "--log_json", out + "/log.json"]
@@ -134,16 +139,21 @@ def test_sprites_driver_under_torchrun_with_one_rank_equals_the_plain_run(tmp_pa
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         if name == "dist":
             assert "Data parallel over 1 ranks: RCCL communicator of the library" in r.stdout, r.stdout[-2000:]
+        if name == "fallback":
+            assert "Data parallel over 1 ranks: torch.distributed collectives" in r.stdout, r.stdout[-2000:]
         logs[name] = json.load(open(out + "/log.json"))
         import glob
         files = glob.glob(out + "/debug_SPRITES/*/pics/test_metrics.txt")
         assert files and len(open(files[0]).read().strip().splitlines()) == 1
-    a, b = logs["plain"], logs["dist"]
-    assert b["rccl_ranks"] == 1 and a["rccl_ranks"] == 0 and len(a["steps"]) == len(b["steps"]) == 6
-    for sa, sb in zip(a["steps"], b["steps"]):
-        assert sb["local_rows"] == sb["rows"] == 10
-        for k in ("elbo", "recon_loss", "C_ma", "lagrange_mult"):
-            assert abs(sa[k] - sb[k]) <= 1e-9 * max(1.0, abs(sa[k])), (k, sa[k], sb[k])
-    assert H.relerr(torch.tensor(b["theta"], dtype=DT), torch.tensor(a["theta"], dtype=DT)) < 1e-9
+    a = logs["plain"]
+    assert logs["dist"]["rccl_ranks"] == 1 and a["rccl_ranks"] == 0 and logs["fallback"]["rccl_ranks"] == 0
+    for b in (logs["dist"], logs["fallback"]):
+        assert len(a["steps"]) == len(b["steps"]) == 6
+        for sa, sb in zip(a["steps"], b["steps"]):
+            assert sb["local_rows"] == sb["rows"] == 10
+            for k in ("elbo", "recon_loss", "C_ma", "lagrange_mult"):
+                assert abs(sa[k] - sb[k]) <= 1e-9 * max(1.0, abs(sa[k])), (k, sa[k], sb[k])
+        assert H.relerr(torch.tensor(b["theta"], dtype=DT), torch.tensor(a["theta"], dtype=DT)) < 1e-9
+    b = logs["dist"]
     # (the evaluation draws its context frames and N(0,1) samples from generators whose state differs between the two processes)
     assert np.isfinite(b["cgen_mse"][0][1]) and abs(a["cgen_mse"][0][1] - b["cgen_mse"][0][1]) <= 0.05 * abs(a["cgen_mse"][0][1])

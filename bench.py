@@ -232,11 +232,11 @@ def stage_table(eng, B, M_IND):
            f8 * Lc * 2 * m * m, 0.0)] if m > 64 else []) + [
         ("gp_posterior_fwd", "svgp_gp_posterior_fwd_with_aji", (cfg, eps, ws, st, s), 4 * Lc * b * m * m,
          f8 * (Lc * 2 * m * m + b * m + 8 * b * Lc), 0.0),
-        ("decoder_fwd", "svgp_mnist_decoder_fwd", (cfg, th, img, ws, s), 2 * dec_mac * b,
+        ("decoder_fwd", "svgp_mnist_decoder_fwd_pre" if m <= 64 else "svgp_mnist_decoder_fwd", (cfg, th, img, ws, s), 2 * dec_mac * b,
          f8 * (b * (Lc + act_dec + 2 * 784) + n_dec), 0.0),
         # m <= 64 (round 6): the data half alone (the chain to zbar; it also stores the pre-activation gradients d2, d1, dh0 for the
         # weight half, which rides in the reverse factor launch below); m > 64: the one-kernel form
-    ] + ([("decoder_bwd_data", "svgp_mnist_decoder_bwd_data", (cfg, th, img, ws, st, s), 2 * dec_mac * b,
+    ] + ([("decoder_bwd_data", "svgp_mnist_decoder_bwd_data_pre", (cfg, th, img, ws, st, s), 2 * dec_mac * b,
            f8 * (b * (512 + 1568 + 2 * 784 + Lc) + n_dec), f8 * b * (1568 + 512 + 128))] if m <= 64 else
          [("decoder_bwd", "svgp_mnist_decoder_bwd", (cfg, th, img, ws, st, s), 4 * dec_mac * b,
            f8 * (b * (Lc + act_dec + 2 * 784 + Lc) + 2 * n_dec), f8 * n_part * n_dec)]) + [

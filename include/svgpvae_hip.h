@@ -128,6 +128,8 @@ typedef struct {
     int64_t dec_h0, dec_a1, dec_a2, recon; /* (b,128) (b,8,8,8) (b,14,14,8) (b,28,28,1)           */
     /* pre-activation gradients of the decoder layers, written by svgp_mnist_decoder_bwd_data for the weight half */
     int64_t dec_d2, dec_d1, dec_dh0;      /* (b,14,14,8) (b,8,8,8) (b,128)                        */
+    int64_t dec_weff;                     /* (2176) effective parity-class weights of the decoder's three up-convolutions for the
+                                           * current theta: written by svgp_mnist_encoder_kernel_matrix_fwd, read by the `_pre` forms */
     /* backward */
     int64_t zbar, g_pv, g_pm, mvbar;      /* (b,L) each                                           */
     int64_t statB, statB_len, A2, ud, td; /* ONE contiguous all-reduce block [A2 | ud | td]       */
@@ -229,6 +231,12 @@ int svgp_mnist_decoder_bwd_data(const svgp_mnist_cfg*, const double* theta, cons
                                 double* ws, const double* state, void* stream);
 int svgp_mnist_decoder_bwd_weights(const svgp_mnist_cfg*, const double* images, double* ws, const double* state,
                                    int threads, int n_types, void* stream);
+/* svgp_mnist_decoder_fwd / _bwd_data that LOAD the effective up-convolution weights (UpSampling2D + 3x3 as four parity-specific
+ * 2x2 convolutions) from ws.dec_weff instead of rebuilding them in each of their workgroups.  Valid only behind
+ * svgp_mnist_encoder_kernel_matrix_fwd with the SAME theta on the same workspace (svgp_mnist_step_phase issues them so). */
+int svgp_mnist_decoder_fwd_pre(const svgp_mnist_cfg*, const double* theta, const double* images, double* ws, void* stream);
+int svgp_mnist_decoder_bwd_data_pre(const svgp_mnist_cfg*, const double* theta, const double* images,
+                                    double* ws, const double* state, void* stream);
 /* Titsias branch (cfg.titsias = 1), SVGPVAE_model.py:246-259: L_2 = -1/2 [b log 2pi + log det C + y^T C^-1 y +
  * sum_n (k_nn - q_n)/var_n], C = diag(var) + K_nm (K_mm + jI)^-1 K_mn + jI (b x b).  Computed in m x m space through
  * the Woodbury identity with the statistics S2_l = sum_n k_n k_n^T/(var_nl + j), v2_l = sum_n y_nl k_n/(var_nl + j):

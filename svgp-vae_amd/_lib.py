@@ -35,7 +35,7 @@ WS_FIELDS = ("enc_a1", "enc_a2", "enc_a3", "qnet_mu", "qnet_var_raw", "qnet_var"
              "statA", "statA_len", "S", "v", "stat_parts",
              "Ki", "ldK", "Si", "t", "G", "A", "Aji", "mu_hat", "u", "M2", "KL", "q",
              "p_m", "p_v", "e", "d", "eps", "z",
-             "dec_h0", "dec_a1", "dec_a2", "recon", "dec_d2", "dec_d1", "dec_dh0",
+             "dec_h0", "dec_a1", "dec_a2", "recon", "dec_d2", "dec_d1", "dec_dh0", "dec_weff",
              "zbar", "g_pv", "g_pm", "mvbar",
              "statB", "statB_len", "A2", "ud", "td",
              "Kbar", "fb_part", "Qm", "vbar", "Ssym", "Knbar_part",
@@ -95,6 +95,8 @@ SIGNATURES = {
     "svgp_mnist_decoder_fwd": [_CFG, _P, _P, _P, _P],
     "svgp_mnist_decoder_bwd": [_CFG, _P, _P, _P, _P, _P],
     "svgp_mnist_decoder_bwd_data": [_CFG, _P, _P, _P, _P, _P],
+    "svgp_mnist_decoder_fwd_pre": [_CFG, _P, _P, _P, _P],
+    "svgp_mnist_decoder_bwd_data_pre": [_CFG, _P, _P, _P, _P, _P],
     "svgp_mnist_decoder_bwd_weights": [_CFG, _P, _P, _P, C.c_int, C.c_int, _P],
     "svgp_gp_stats_bwd": [_CFG, _P, _P, _P],
     "svgp_gp_factor_bwd": [_CFG, _P, _P, _P],

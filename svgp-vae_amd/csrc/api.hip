@@ -113,7 +113,7 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->p_m = take(b * L); o->p_v = take(b * L); o->e = take(b * L); o->d = take(b * L);
     o->eps = take(b * L); o->z = take(b * L);
     o->dec_h0 = take(b * 128); o->dec_a1 = take(b * 512); o->dec_a2 = take(b * 1568); o->recon = take(b * 784);
-    o->dec_d2 = take(b * 1568); o->dec_d1 = take(b * 512); o->dec_dh0 = take(b * 128);
+    o->dec_d2 = take(b * 1568); o->dec_d1 = take(b * 512); o->dec_dh0 = take(b * 128); o->dec_weff = take(2176);
     o->zbar = take(b * L); o->g_pv = take(b * L); o->g_pm = take(b * L); o->mvbar = take(b * L);
     o->statB = p; o->A2 = p; p += P * L * m * m; o->ud = p; p += P * L * m; o->td = p; p += P * L * m;
     o->statB_len = p - o->statB; take(0);
@@ -377,9 +377,14 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
             }
         }
         if (c->titsias) RUN(svgp_gp_titsias_fwd(c, ws, state, stream));
-        RUN(svgp_mnist_decoder_fwd(c, theta, images, ws, stream));
-        if (!large && dec_split_on()) RUN(svgp_mnist_decoder_bwd_data(c, theta, images, ws, state, stream));
-        else RUN(svgp_mnist_decoder_bwd(c, theta, images, ws, state, stream));
+        // m <= 64 with the split on: the `_pre` forms read the effective up-convolution weights phase 0 of this step left in ws.dec_weff
+        if (!large && dec_split_on()) {
+            RUN(svgp_mnist_decoder_fwd_pre(c, theta, images, ws, stream));
+            RUN(svgp_mnist_decoder_bwd_data_pre(c, theta, images, ws, state, stream));
+        } else {
+            RUN(svgp_mnist_decoder_fwd(c, theta, images, ws, stream));
+            RUN(svgp_mnist_decoder_bwd(c, theta, images, ws, state, stream));
+        }
         RUN(svgp_gp_stats_bwd(c, ws, state, stream));
         if (fork1 && !defer) RUN(side_join(sd, 1, ms));        // phase-at-a-time callers: joined before the phase returns
         break;

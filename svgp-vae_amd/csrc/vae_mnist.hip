@@ -28,8 +28,19 @@ __global__ __launch_bounds__(VAE_NT) void k_encoder_fwd(int b, int L, int clip, 
                                                             real* __restrict__ mu, real* __restrict__ var_raw,
                                                             real* __restrict__ var, int n_img_blocks, SvgpKernArgs ka,
                                                             real* __restrict__ Kmm, real* __restrict__ Knm,
-                                                            real* __restrict__ knn) {
+                                                            real* __restrict__ knn, int n_km_blocks,
+                                                            const real* __restrict__ th_dec, real* __restrict__ weff) {
     extern __shared__ __align__(16) real smem[];
+    if ((int)blockIdx.x >= n_img_blocks + n_km_blocks) {
+        // training phases (round 6): ONE more rider builds the effective (parity-class) weights of the decoder's three up-convolutions
+        // for the step -- theta does not change before Adam -- so that the decoder's forward and data-reverse launches load them
+        // instead of rebuilding them in each of their 256 workgroups (~1 us on the chain, twice)
+        const DecOff od = dec_off(L);
+        UpC1::build_weff(th_dec + od.c1w, weff);
+        UpC2::build_weff(th_dec + od.c2w, weff + UpC1::NWE);
+        UpC3::build_weff(th_dec + od.c3w, weff + UpC1::NWE + UpC2::NWE);
+        return;
+    }
     if ((int)blockIdx.x >= n_img_blocks) {
         // training phases: the kernel-matrix build (independent of the encoder) rides in extra workgroups of this launch
         svgp_km_fwd_element(ka, (long long)(blockIdx.x - n_img_blocks) * blockDim.x + threadIdx.x, Kmm, Knm, knn);
@@ -82,11 +93,14 @@ __global__ __launch_bounds__(VAE_NT) void k_encoder_bwd(EncBwdArgs a) {
 // ------------------------------------------------------------------------------------------
 // decoder forward: z -> h0, a1, a2 (saved), recon, per-workgroup sum of squared errors
 // ------------------------------------------------------------------------------------------
+// PRE: the effective weights come from ws.dec_weff (built once per step by a rider of the encoder launch)
+template <bool PRE>
 __global__ __launch_bounds__(VAE_NT) void k_decoder_fwd(int b, int L, const real* __restrict__ th_dec,
                                                             const real* __restrict__ images,
                                                             const real* __restrict__ zg, real* __restrict__ h0g,
                                                             real* __restrict__ a1g, real* __restrict__ a2g,
-                                                            real* __restrict__ recon, real* __restrict__ part_sums) {
+                                                            real* __restrict__ recon, real* __restrict__ part_sums,
+                                                            const real* __restrict__ weff) {
     extern __shared__ __align__(16) real smem[];
     const DecOff od = dec_off(L);
     real* w = smem;                  // od.n
@@ -100,10 +114,14 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_fwd(int b, int L, const real
     real* We2 = We1 + UpC1::NWE;
     real* We3 = We2 + UpC2::NWE;
     lds_copy_in(w, th_dec, od.n);
-    __syncthreads();
-    UpC1::build_weff(w + od.c1w, We1);       // from the LDS copy (one coalesced read of the raw weights)
-    UpC2::build_weff(w + od.c2w, We2);
-    UpC3::build_weff(w + od.c3w, We3);
+    if (PRE) {
+        lds_copy_in(We1, weff, DEC_NWE);
+    } else {
+        __syncthreads();
+        UpC1::build_weff(w + od.c1w, We1);       // from the LDS copy (one coalesced read of the raw weights)
+        UpC2::build_weff(w + od.c2w, We2);
+        UpC3::build_weff(w + od.c3w, We3);
+    }
     real sq = 0;
     for (int n = blockIdx.x; n < b; n += gridDim.x) {
         __syncthreads();
@@ -226,6 +244,7 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int b, int L, int geco, 
 // decoder reverse, DATA half: d loss / d recon -> d2, d1, dh0 (stored for the weight half) -> zbar.  The chain the GP
 // reverse stages wait for; the weight gradients (decoder_wgrad_rider, vae_dev.hpp) ride in a later launch.
 // ------------------------------------------------------------------------------------------
+template <bool PRE>
 __global__ __launch_bounds__(VAE_NT) void k_decoder_bwd_data(int b, int L, int geco, real inv_bglobal,
                                                                  const real* __restrict__ state,
                                                                  const real* __restrict__ th_dec,
@@ -233,7 +252,7 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_bwd_data(int b, int L, int g
                                                                  const real* __restrict__ a1g, const real* __restrict__ a2g,
                                                                  const real* __restrict__ recon, real* __restrict__ d2g,
                                                                  real* __restrict__ d1g, real* __restrict__ dh0g,
-                                                                 real* __restrict__ zbar) {
+                                                                 real* __restrict__ zbar, const real* __restrict__ weff) {
     extern __shared__ __align__(16) real smem[];
     const DecOff od = dec_off(L);
     real* w = smem;                  // dense weights only: L*128
@@ -248,11 +267,15 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_bwd_data(int b, int L, int g
     real* dh0 = d1 + 512;            // 128
     real* raw = dh0 + 128;           // raw conv weights (+ biases), staged once: od.n - od.c1w
     lds_copy_in(w, th_dec + od.dw, L * 128);
-    lds_copy_in(raw, th_dec + od.c1w, od.n - od.c1w);
-    __syncthreads();
-    UpC1::build_weff(raw, We1);
-    UpC2::build_weff(raw + (od.c2w - od.c1w), We2);
-    UpC3::build_weff(raw + (od.c3w - od.c1w), We3);
+    if (PRE) {
+        lds_copy_in(We1, weff, DEC_NWE);
+    } else {
+        lds_copy_in(raw, th_dec + od.c1w, od.n - od.c1w);
+        __syncthreads();
+        UpC1::build_weff(raw, We1);
+        UpC2::build_weff(raw + (od.c2w - od.c1w), We2);
+        UpC3::build_weff(raw + (od.c3w - od.c1w), We3);
+    }
     const real gscale = (geco ? state[SVGP_ST_LAGRANGE] * inv_bglobal : real(1)) / real(784);
     for (int n = blockIdx.x; n < b; n += gridDim.x) {
         __syncthreads();
@@ -402,9 +425,11 @@ static int encoder_fwd_impl(const svgp_mnist_cfg* c, const double* theta, const 
         const long long nel = (long long)c->b * c->m + (long long)c->m * c->m + c->b;
         n_km = (int)((nel + VAE_NT - 1) / VAE_NT);
     }
-    hipLaunchKernelGGL(k_encoder_fwd, dim3(n_img + n_km), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
+    // (the weff rider only in the training-phase form: svgp_mnist_decoder_fwd_pre / _bwd_data_pre are issued by the same step)
+    hipLaunchKernelGGL(k_encoder_fwd, dim3(n_img + n_km + (aux ? 1 : 0)), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
                        c->clip_qs, theta, images, ws + wl.enc_a1, ws + wl.enc_a2, ws + wl.enc_a3, ws + wl.qnet_mu,
-                       ws + wl.qnet_var_raw, ws + wl.qnet_var, n_img, ka, ws + wl.K, ws + wl.Kn, ws + wl.knn);
+                       ws + wl.qnet_var_raw, ws + wl.qnet_var, n_img, ka, ws + wl.K, ws + wl.Kn, ws + wl.knn, n_km,
+                       theta + pl.n_enc, ws + wl.dec_weff);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }
@@ -434,19 +459,30 @@ extern "C" int svgp_mnist_encoder_bwd(const svgp_mnist_cfg* c, const double* the
     return SVGP_OK;
 }
 
-extern "C" int svgp_mnist_decoder_fwd(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
-                                      void* stream) {
+static int decoder_fwd_impl(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws, bool pre, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(theta && images && ws, SVGP_ERR_INVALID, "NULL device pointer");
     const int64_t n_dec = pl.n_vae - pl.n_enc;
     const size_t lds = (size_t)(n_dec + 64 + 128 + 512 + 1568 + 784 + 16 + DEC_NWE) * sizeof(real);
-    int rc = set_dyn_lds(k_decoder_fwd, lds);
+    int rc = pre ? set_dyn_lds(k_decoder_fwd<true>, lds) : set_dyn_lds(k_decoder_fwd<false>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_decoder_fwd, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
-                       theta + pl.n_enc, images, ws + wl.z, ws + wl.dec_h0, ws + wl.dec_a1, ws + wl.dec_a2,
-                       ws + wl.recon, ws + wl.part_sums);
+#define DEC_FWD_ARGS c->b, c->L, theta + pl.n_enc, images, ws + wl.z, ws + wl.dec_h0, ws + wl.dec_a1, ws + wl.dec_a2, ws + wl.recon, \
+                     ws + wl.part_sums, ws + wl.dec_weff
+    if (pre) hipLaunchKernelGGL(k_decoder_fwd<true>, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, DEC_FWD_ARGS);
+    else hipLaunchKernelGGL(k_decoder_fwd<false>, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, DEC_FWD_ARGS);
+#undef DEC_FWD_ARGS
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
+}
+extern "C" int svgp_mnist_decoder_fwd(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
+                                      void* stream) {
+    return decoder_fwd_impl(c, theta, images, ws, false, stream);
+}
+// training-step forms: the effective weights of the up-convolutions are read from ws.dec_weff, which
+// svgp_mnist_encoder_kernel_matrix_fwd of the SAME step (same theta) has written
+extern "C" int svgp_mnist_decoder_fwd_pre(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
+                                          void* stream) {
+    return decoder_fwd_impl(c, theta, images, ws, true, stream);
 }
 
 extern "C" int svgp_mnist_decoder_bwd(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
@@ -466,19 +502,29 @@ extern "C" int svgp_mnist_decoder_bwd(const svgp_mnist_cfg* c, const double* the
 
 // The two halves of svgp_mnist_decoder_bwd (see k_decoder_bwd_data): _data writes zbar and ws.dec_d2 / dec_d1 / dec_dh0, _weights
 // the decoder weight-gradient partials from them.  _data + _weights == svgp_mnist_decoder_bwd up to summation order.
-extern "C" int svgp_mnist_decoder_bwd_data(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
-                                           const double* state, void* stream) {
+static int decoder_bwd_data_impl(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
+                                 const double* state, bool pre, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(theta && images && ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     const int64_t n_dec = pl.n_vae - pl.n_enc;
     const size_t lds = (size_t)(c->L * 128 + DEC_NWE + 512 + 1568 + 784 + 1568 + 512 + 128 + (n_dec - c->L * 128 - 128)) * sizeof(real);
-    int rc = set_dyn_lds(k_decoder_bwd_data, lds);
+    int rc = pre ? set_dyn_lds(k_decoder_bwd_data<true>, lds) : set_dyn_lds(k_decoder_bwd_data<false>, lds);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_decoder_bwd_data, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, c->b, c->L,
-                       c->geco, 1.0 / (double)c->b_global, state, theta + pl.n_enc, images, ws + wl.dec_a1, ws + wl.dec_a2,
-                       ws + wl.recon, ws + wl.dec_d2, ws + wl.dec_d1, ws + wl.dec_dh0, ws + wl.zbar);
+#define DEC_BD_ARGS c->b, c->L, c->geco, 1.0 / (double)c->b_global, state, theta + pl.n_enc, images, ws + wl.dec_a1, ws + wl.dec_a2, \
+                    ws + wl.recon, ws + wl.dec_d2, ws + wl.dec_d1, ws + wl.dec_dh0, ws + wl.zbar, ws + wl.dec_weff
+    if (pre) hipLaunchKernelGGL(k_decoder_bwd_data<true>, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, DEC_BD_ARGS);
+    else hipLaunchKernelGGL(k_decoder_bwd_data<false>, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, DEC_BD_ARGS);
+#undef DEC_BD_ARGS
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
+}
+extern "C" int svgp_mnist_decoder_bwd_data(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
+                                           const double* state, void* stream) {
+    return decoder_bwd_data_impl(c, theta, images, ws, state, false, stream);
+}
+extern "C" int svgp_mnist_decoder_bwd_data_pre(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
+                                               const double* state, void* stream) {
+    return decoder_bwd_data_impl(c, theta, images, ws, state, true, stream);
 }
 
 // gp_kernels.hip (svgp_mnist_encoder_bwd_km) and svgp_mnist_encoder_bwd above

@@ -128,3 +128,35 @@ def test_encoder_reverse_and_kernel_matrix_vjp_in_one_launch(b, m, L, M):
     eng.synchronize()
     for k, v in views().items():
         assert torch.equal(v, ref[k]), k
+
+
+def test_precomputed_effective_weights_forms_equal_the_plain_ones():
+    """svgp_mnist_decoder_fwd_pre / _bwd_data_pre read the effective (parity-class) weights of the up-convolutions from ws.dec_weff,
+    written once per step by a rider workgroup of svgp_mnist_encoder_kernel_matrix_fwd, instead of rebuilding them in every
+    workgroup: bit-equal outputs; and the buffer follows the parameters (a changed decoder weight changes it)."""
+    from svgp_vae_amd import _lib
+    eng, _ = _engine(256, 32, 16)
+    eng.run(adam=False)
+    eng.synchronize()
+    cfg, th, ws, st = C.byref(eng.cfg), eng.theta.data_ptr(), eng.ws.data_ptr(), eng.state.data_ptr()
+    img, ax, s = eng._bound[0].data_ptr(), eng._bound[1].data_ptr(), eng.stream.cuda_stream
+    fields = dict(dec_h0=(256, 128), dec_a1=(256, 512), dec_a2=(256, 1568), recon=(256, 784), zbar=(256, 16), dec_d2=(256, 1568),
+                  dec_d1=(256, 512), dec_dh0=(256, 128))
+    _lib.call("svgp_mnist_decoder_fwd", cfg, th, img, ws, s)
+    _lib.call("svgp_mnist_decoder_bwd_data", cfg, th, img, ws, st, s)
+    eng.synchronize()
+    ref = {k: eng.ws_view(k, sh).clone() for k, sh in fields.items()}
+    weff0 = eng.ws_view("dec_weff", (2176,)).clone()
+    assert float(weff0.abs().max()) > 0
+    for k, sh in fields.items():
+        eng.ws_view(k, sh).fill_(float("nan"))
+    _lib.call("svgp_mnist_decoder_fwd_pre", cfg, th, img, ws, s)
+    _lib.call("svgp_mnist_decoder_bwd_data_pre", cfg, th, img, ws, st, s)
+    eng.synchronize()
+    for k, sh in fields.items():
+        assert torch.equal(eng.ws_view(k, sh), ref[k]), k
+    with torch.cuda.stream(eng.stream):
+        eng.params["dec_c2_w"][1, 1, 3, 2] += 0.5
+    _lib.call("svgp_mnist_encoder_kernel_matrix_fwd", cfg, th, img, ax, ws, s)
+    eng.synchronize()
+    assert not torch.equal(eng.ws_view("dec_weff", (2176,)), weff0)

@@ -95,6 +95,10 @@ def main():
 
     rows = [("decoder_bwd (one kernel)", "svgp_mnist_decoder_bwd", (cfg, th, img, ws, st, s)),
             ("decoder_bwd_data", "svgp_mnist_decoder_bwd_data", (cfg, th, img, ws, st, s)),
+            ("decoder_bwd_data_pre", "svgp_mnist_decoder_bwd_data_pre", (cfg, th, img, ws, st, s)),
+            ("decoder_fwd", "svgp_mnist_decoder_fwd", (cfg, th, img, ws, s)),
+            ("decoder_fwd_pre", "svgp_mnist_decoder_fwd_pre", (cfg, th, img, ws, s)),
+            ("encoder_kernel_matrix_fwd", "svgp_mnist_encoder_kernel_matrix_fwd", (cfg, th, img, eng._bound[1].data_ptr(), ws, s)),
             ("decoder_bwd_weights 256 x 1", "svgp_mnist_decoder_bwd_weights", (cfg, img, ws, st, 256, 1, s)),
             ("decoder_bwd_weights 512 x 1", "svgp_mnist_decoder_bwd_weights", (cfg, img, ws, st, 512, 1, s)),
             ("decoder_bwd_weights 256 x 2", "svgp_mnist_decoder_bwd_weights", (cfg, img, ws, st, 256, 2, s)),

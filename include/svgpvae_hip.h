@@ -128,6 +128,8 @@ typedef struct {
     int64_t dec_h0, dec_a1, dec_a2, recon; /* (b,128) (b,8,8,8) (b,14,14,8) (b,28,28,1)           */
     /* pre-activation gradients of the decoder layers, written by svgp_mnist_decoder_bwd_data for the weight half */
     int64_t dec_d2, dec_d1, dec_dh0;      /* (b,14,14,8) (b,8,8,8) (b,128)                        */
+    int64_t flags;                        /* (16) two u64 counters of the intra-launch hand-off of svgp_mnist_encoder_bwd_km_sum; the
+                                           * workspace must be ZERO here before its first use (every call leaves them zero) */
     int64_t dec_weff;                     /* (2176) effective parity-class weights of the decoder's three up-convolutions for the
                                            * current theta: written by svgp_mnist_encoder_kernel_matrix_fwd, read by the `_pre` forms */
     /* backward */
@@ -324,6 +326,13 @@ int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg*, double* ws, const double* 
  * reverse row stage; tf.gradients of SVGPVAE_model.py:427-476 and VAE_utils.py:112-126,143-152).  Results identical. */
 int svgp_mnist_encoder_bwd_km(const svgp_mnist_cfg*, const double* theta, const double* images, const double* aux,
                               double* ws, void* stream);
+/* m <= 64, the training step's form: svgp_gp_posterior_bwd = _rows (pass 1: ybar, s2bar, the per-channel partials of Knbar) + pass 2
+ * (the sums over channels: Knbar, knnbar, Kbar -- consumed by the kernel-matrix VJP only); _km_sum = pass 2 + the VJP + the encoder's
+ * reverse pass in ONE launch: the VJP workgroups wait for the pass-2 workgroups on a counter in ws.flags (release / acquire at
+ * agent scope), the image workgroups wait for nobody.  Results identical to the separate launches. */
+int svgp_gp_posterior_bwd_rows(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+int svgp_mnist_encoder_bwd_km_sum(const svgp_mnist_cfg*, const double* theta, const double* images, const double* aux,
+                                  double* ws, const double* state, void* stream);
 /* m <= 64: svgp_gp_factor_bwd_nofinal + svgp_mnist_decoder_bwd_weights(threads = 256) in ONE launch: the L channel workgroups
  * first, then min(b, 256) rider workgroups with the decoder's weight-gradient partials (needs svgp_mnist_decoder_bwd_data before). */
 int svgp_gp_factor_bwd_nofinal_wgrad(const svgp_mnist_cfg*, const double* images, double* ws, const double* state,

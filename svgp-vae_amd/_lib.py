@@ -35,7 +35,7 @@ WS_FIELDS = ("enc_a1", "enc_a2", "enc_a3", "qnet_mu", "qnet_var_raw", "qnet_var"
              "statA", "statA_len", "S", "v", "stat_parts",
              "Ki", "ldK", "Si", "t", "G", "A", "Aji", "mu_hat", "u", "M2", "KL", "q",
              "p_m", "p_v", "e", "d", "eps", "z",
-             "dec_h0", "dec_a1", "dec_a2", "recon", "dec_d2", "dec_d1", "dec_dh0", "dec_weff",
+             "dec_h0", "dec_a1", "dec_a2", "recon", "dec_d2", "dec_d1", "dec_dh0", "flags", "dec_weff",
              "zbar", "g_pv", "g_pm", "mvbar",
              "statB", "statB_len", "A2", "ud", "td",
              "Kbar", "fb_part", "Qm", "vbar", "Ssym", "Knbar_part",
@@ -114,6 +114,8 @@ SIGNATURES = {
     "svgp_gp_factor_bwd_nofinal": [_CFG, _P, _P, _P],
     "svgp_gp_factor_bwd_nofinal_wgrad": [_CFG, _P, _P, _P, _P],
     "svgp_mnist_encoder_bwd_km": [_CFG, _P, _P, _P, _P, _P],
+    "svgp_mnist_encoder_bwd_km_sum": [_CFG, _P, _P, _P, _P, _P, _P],
+    "svgp_gp_posterior_bwd_rows": [_CFG, _P, _P, _P],
     "svgp_mnist_grad_reduce_part": [_CFG, _P, _P, C.c_int, _P],
     "svgp_gp_posterior_bwd_with_final": [_CFG, _P, _P, _P],
     "svgp_gp_titsias_stats": [_CFG, _P, _P],

@@ -114,6 +114,7 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->eps = take(b * L); o->z = take(b * L);
     o->dec_h0 = take(b * 128); o->dec_a1 = take(b * 512); o->dec_a2 = take(b * 1568); o->recon = take(b * 784);
     o->dec_d2 = take(b * 1568); o->dec_d1 = take(b * 512); o->dec_dh0 = take(b * 128); o->dec_weff = take(2176);
+    o->flags = take(16);
     o->zbar = take(b * L); o->g_pv = take(b * L); o->g_pm = take(b * L); o->mvbar = take(b * L);
     o->statB = p; o->A2 = p; p += P * L * m * m; o->ud = p; p += P * L * m; o->td = p; p += P * L * m;
     o->statB_len = p - o->statB; take(0);
@@ -301,6 +302,10 @@ bool enc_km_merge_on() {
     const char* e = getenv("SVGP_ENC_KM_MERGE");
     return !(e && e[0] == '0');
 }
+bool sum_merge_on() {
+    const char* e = getenv("SVGP_SUM_MERGE");
+    return !(e && e[0] == '0');
+}
 bool konly_on() {      // (read per call: tests compare the two orders in one process)
     const char* e = getenv("SVGP_KONLY_BRANCH");
     return !(e && e[0] == '0');
@@ -337,6 +342,7 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
     hipStream_t s2 = fork2 ? sd->s[0] : ms;
 #define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
     const bool ksplit = phase == 0 && fork1 && defer && c->m < SVGP_CHOL_INVERSE_MIN_M && konly_on();
+    const bool sum_rides = phase == 2 && !large && !fork2 && !c->titsias && enc_km_merge_on() && sum_merge_on();
     switch (phase) {
     case 0:
         RUN(svgp_mnist_encoder_kernel_matrix_fwd(c, theta, images, aux, ws, stream));   // one launch for the two
@@ -408,7 +414,11 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
             if (!large && dec_split_on()) RUN(svgp_gp_factor_bwd_nofinal_wgrad(c, images, ws, state, stream));
             else RUN(svgp_gp_factor_bwd_nofinal(c, ws, state, stream));
         }
-        RUN(svgp_gp_posterior_bwd_with_final(c, ws, state, stream));
+        // m <= 64 (round 6): pass 2 of the reverse row stage (the sums over channels, consumed by the kernel-matrix VJP only) rides in the
+        // encoder's reverse launch in front of the VJP workgroups.  Not with cfg.titsias (its reverse stage adds to Kbar / Knbar in
+        // between), the split gradient exchange (phase 4) or SVGP_ENC_KM_MERGE=0.
+        if (sum_rides) RUN(svgp_gp_posterior_bwd_rows(c, ws, state, stream));
+        else RUN(svgp_gp_posterior_bwd_with_final(c, ws, state, stream));
         if (c->titsias) RUN(svgp_gp_titsias_bwd(c, ws, state, stream));
         // (m > 64, measured round 5: the kernel-matrix reverse pass on side branch 0 beside the encoder's does NOT overlap -- 68 KB +
         // 104 KB of LDS per workgroup do not fit one CU; the kernel-matrix launch stretched from 49 to 103 us and the step was unchanged)
@@ -417,7 +427,9 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
             RUN(svgp_mnist_grad_reduce_part(c, aux, ws, 1, stream));
             break;
         }
-        if (!large && !fork2 && enc_km_merge_on()) {
+        if (sum_rides) {
+            RUN(svgp_mnist_encoder_bwd_km_sum(c, theta, images, aux, ws, state, stream));
+        } else if (!large && !fork2 && enc_km_merge_on()) {
             RUN(svgp_mnist_encoder_bwd_km(c, theta, images, aux, ws, stream));
         } else {
             if (fork2) RUN(side_fork(sd, 0, ms));

@@ -25,6 +25,16 @@ namespace {
 // global -> LDS matrix copy with 4 loads in flight per thread (m = 32: the whole matrix in ONE batch).  A plain
 // `R[..] = g[o]` loop compiles to load / wait / store per trip; these kernels run one workgroup of 4 waves per CU, so every
 // trip would expose a full memory latency.
+__device__ __forceinline__ void mat_load_nt(real* R, int ld, const real* __restrict__ g, int m, int nt) {
+    const int mm = m * m;
+    for (int o0 = threadIdx.x; o0 < mm; o0 += 4 * nt) {
+        real v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int o = o0 + u * nt; v[u] = o < mm ? g[o] : real(0); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int o = o0 + u * nt; if (o < mm) R[(o / m) * ld + (o % m)] = v[u]; }
+    }
+}
 __device__ __forceinline__ void mat_load(real* R, int ld, const real* __restrict__ g, int m) {
     const int mm = m * m, nt = blockDim.x;
     for (int o0 = threadIdx.x; o0 < mm; o0 += 4 * nt) {
@@ -298,6 +308,18 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_xy(KernXYArgs a, r
     out[idx] = view_k(xr[1] - yr[1], amp * amp, real(1) / (ls * ls)) * D;
 }
 
+// Payload of an intra-launch hand-off between workgroups on different XCDs (svgp_mnist_encoder_bwd_km_sum): written THROUGH to memory
+// and read past the non-coherent per-XCD L2s (sc1 = relaxed agent-scope atomics), no cache-wide write-back / invalidate -- the
+// release / acquire FENCE form of the same hand-off cost the launch 10 us (every fence writes back or drops the whole L2 of its XCD
+// while the image workgroups stream their partials through it).
+template <bool COH> __device__ __forceinline__ real ld_co(const real* p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH> __device__ __forceinline__ void st_co(real* p, real v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 // VJP, inducing side: one workgroup per inducing point j.
 // d_ip[j] = [0, d_theta_j, d_o_j], partial amplitude / length-scale sums -> part_gp[j].
 #define KM_MAXM 32
@@ -305,7 +327,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_xy(KernXYArgs a, r
 // MC / MM: compile-time m / GPLVM dimension M (0: run time); config 2 runs the <32, 8> instance (8 instead of 32 predicated
 // accumulators per thread, index divisions folded).  M > 32 (a kernel matrix of rank m needs M >= m / 16 object
 // dimensions -- m = 2048 wants M = 128): the row / column loops are repeated per chunk of 32 feature columns, 32 accumulators live.
-template <int MC, int MM, int NTL = 0>
+template <int MC, int MM, int NTL = 0, bool COH = false>
 __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real rep_weight, int train_ip,
                                             const real* __restrict__ K, const real* __restrict__ Kn,
                                             const real* __restrict__ Kbar, const real* __restrict__ Knbar,
@@ -325,7 +347,7 @@ __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real
         for (int k = 0; k < KM_MAXM; ++k) acc_o[k] = 0;
         // ---- K_nm column j
         for (int n = threadIdx.x; n < a.b; n += nthr) {
-            const real gk = Knbar[(size_t)n * m + j];
+            const real gk = ld_co<COH>(Knbar + (size_t)n * m + j);
             const real d = a.aux[(size_t)n * st + 1] - thj;
             const real V = view_k(d, a2, inv_l2);
             const real G = gk * Kn[(size_t)n * m + j];
@@ -346,7 +368,7 @@ __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real
             const real d = thj - a.ip[(size_t)i * st + 1];          // theta_j - theta_i  (entry (j,i))
             const real V = view_k(d, a2, inv_l2);                   // even in d
             const real sh = sin(real(0.5) * d);
-            const real g_ji = rep_weight * Kbar[(size_t)j * m + i], g_ij = rep_weight * Kbar[(size_t)i * m + j];
+            const real g_ji = rep_weight * ld_co<COH>(Kbar + (size_t)j * m + i), g_ij = rep_weight * ld_co<COH>(Kbar + (size_t)i * m + j);
             const real G_ji = g_ji * K[(size_t)j * m + i], G_ij = g_ij * K[(size_t)i * m + j];
             acc_amp += G_ji;
             acc_ls += G_ji * sh * sh;
@@ -395,7 +417,7 @@ __device__ __forceinline__ void km_bwd_cols(const int j, const KernArgs& a, real
 // VJP, batch-row side.  grid ceil(b/RB), RB = 256/m rows per workgroup.  Phase 1: thread (row, j)
 // computes c = Knbar * view(theta_n - theta_j) / |o_j|; phase 2: thread (row, k) reduces over j ->
 // d_on (b,M), the gradient of the gathered object row.  Also the k_nn part of the amplitude gradient.
-template <int MC, int MM, int NTL = 0>
+template <int MC, int MM, int NTL = 0, bool COH = false>
 __device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, const real* __restrict__ Knbar,
                                             const real* __restrict__ knnbar, const real* __restrict__ knn,
                                             real* __restrict__ d_on, real* __restrict__ part_gp) {
@@ -427,7 +449,7 @@ __device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, c
         const int nl = it / m, j = it % m, n = rblk * RB + nl;
         real c = 0;
         if (n < a.b)
-            c = Knbar[(size_t)n * m + j] * view_k(a.aux[(size_t)n * st + 1] - a.ip[(size_t)j * st + 1], a2, inv_l2);
+            c = ld_co<COH>(Knbar + (size_t)n * m + j) * view_k(a.aux[(size_t)n * st + 1] - a.ip[(size_t)j * st + 1], a2, inv_l2);
         cbuf[it] = c;
     }
     __syncthreads();
@@ -439,7 +461,7 @@ __device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, c
             else for (int j = 0; j < m; ++j) g += cbuf[nl * m + j] * (a.ip[(size_t)j * st + 2 + k] * O[j]);
             const real* on = obj_row(a, n);
             const real nn = a.normalize ? sqrt(dotM(on, on, M)) : real(1);
-            g += real(2) * a2 * knnbar[n] * on[k] / nn;      // k_nn = a^2 |o_hat|^2
+            g += real(2) * a2 * ld_co<COH>(knnbar + n) * on[k] / nn;      // k_nn = a^2 |o_hat|^2
         }
         gbuf[it] = g;
     }
@@ -461,7 +483,7 @@ __device__ __forceinline__ void km_bwd_rows(const int rblk, const KernArgs& a, c
     real acc_amp = 0;
     {
         const int n = rblk * RB + threadIdx.x;
-        if (threadIdx.x < RB && n < a.b) acc_amp = real(2) * knnbar[n] * knn[n] / amp;
+        if (threadIdx.x < RB && n < a.b) acc_amp = real(2) * ld_co<COH>(knnbar + n) * knn[n] / amp;
     }
     acc_amp = block_sum_nt(acc_amp, red, nthr);
     if (threadIdx.x == 0) {
@@ -484,29 +506,6 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_bwd_cr(KernArgs a,
     const int m = MC ? MC : a.m;
     if ((int)blockIdx.x < m) km_bwd_cols<MC, MM>(blockIdx.x, a, rep_weight, train_ip, K, Kn, Kbar, Knbar, d_ip, part_gp);
     else km_bwd_rows<MC, MM>(blockIdx.x - m, a, Knbar, knnbar, knn, d_on, part_gp);
-}
-
-// Training step (m <= 64, round 6): the kernel-matrix VJP and the encoder's reverse pass are independent (both consume the
-// reverse row stage), so they share ONE launch of VAE_NT-thread workgroups: the m + nrb VJP workgroups come FIRST in the grid and
-// run on their first SVGP_BLOCK threads (the other waves exit at once), the image workgroups follow.  168 VGPRs and 75 KB of LDS
-// let a VJP workgroup and an image workgroup share a CU, so no image workgroup waits for a VJP workgroup to retire.
-template <int MC, int MM>
-__global__ __launch_bounds__(VAE_NT, MC ? 3 : 2) void k_encoder_bwd_km(svgp_vae::EncBwdArgs e, int n_km, KernArgs a, real rep_weight,
-                                                                 int train_ip, const real* __restrict__ K,
-                                                                 const real* __restrict__ Kn, const real* __restrict__ Kbar,
-                                                                 const real* __restrict__ Knbar,
-                                                                 const real* __restrict__ knnbar, const real* __restrict__ knn,
-                                                                 real* __restrict__ d_ip, real* __restrict__ d_on,
-                                                                 real* __restrict__ part_gp) {
-    if ((int)blockIdx.x < n_km) {
-        if (threadIdx.x >= SVGP_BLOCK) return;
-        const int m = MC ? MC : a.m;
-        if ((int)blockIdx.x < m) km_bwd_cols<MC, MM, SVGP_BLOCK>(blockIdx.x, a, rep_weight, train_ip, K, Kn, Kbar, Knbar, d_ip, part_gp);
-        else km_bwd_rows<MC, MM, SVGP_BLOCK>(blockIdx.x - m, a, Knbar, knnbar, knn, d_on, part_gp);
-        return;
-    }
-    extern __shared__ __align__(16) real smem[];
-    svgp_vae::encoder_bwd_images<VAE_NT>(e, (int)blockIdx.x - n_km, (int)gridDim.x - n_km, smem);
 }
 
 // Deterministic scatter-add of d_on into the object table gradient + the final amplitude / length-scale sums
@@ -1188,28 +1187,29 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_l(PostBwdArgs a
     }
 }
 
-template <int MC>
-__global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_sum(PostBwdArgs a) {
-    extern __shared__ __align__(16) real smem[];
-    if (a.n_final > 0 && (int)blockIdx.x >= a.nb_rows) {
-        const int m = MC ? MC : a.m, o = (blockIdx.x - a.nb_rows) * blockDim.x + threadIdx.x;
+// Pass 2 as a device function: block `bid` of nb_rows + n_final, `nthr` live threads (the stand-alone launch: blockDim.x; as rider
+// workgroups of svgp_mnist_encoder_bwd_km: the first SVGP_BLOCK threads of a VAE_NT-thread workgroup)
+template <int MC, bool COH = false>
+__device__ __forceinline__ void posterior_bwd_sum_block(const PostBwdArgs& a, int bid, int nthr, real* smem) {
+    if (a.n_final > 0 && bid >= a.nb_rows) {
+        const int m = MC ? MC : a.m, o = (bid - a.nb_rows) * nthr + threadIdx.x;
         if (o >= m * m) return;
         const real gT = grad_KL_term(a.geco, a.L, a.state);
         const real gK = svgp_seed_K(a.geco, gT, (real)a.b_global / a.N_train);
         real s = 0;
 #pragma unroll 8
         for (int l = 0; l < a.L; ++l) s += a.Kbar_part[(size_t)l * m * m + o];
-        a.Kbar[o] = s + real(0.5) * gK * (real)a.L * a.Ki[o];
+        st_co<COH>(a.Kbar + o, s + real(0.5) * gK * (real)a.L * a.Ki[o]);
         return;
     }
     const int m = MC ? MC : a.m, ld = m + 1, mm = m * ld;
     real* R0 = smem;            // Ki
     real* kr = R0 + mm;         // RB x m
     real* qb = kr + SVGP_BLOCK; // RB
-    const int RB = blockDim.x / m;
-    const int nl = threadIdx.x / m, i = threadIdx.x % m, n = blockIdx.x * RB + nl;
+    const int RB = nthr / m;
+    const int nl = threadIdx.x / m, i = threadIdx.x % m, n = bid * RB + nl;
     const bool act = nl < RB && n < a.b;
-    mat_load(R0, ld, a.Ki, m);
+    mat_load_nt(R0, ld, a.Ki, m, nthr);
     if (act) kr[nl * m + i] = a.Kn[(size_t)n * m + i];
     const real gT = grad_KL_term(a.geco, a.L, a.state);
     if (act && i == 0) {
@@ -1219,7 +1219,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_sum(PostBwdArgs
             qbar += real(0.5) * svgp_seed_3(a.geco, gT) * recip_no_nan(a.s2[e]) - a.g_pv[e];
         }
         qb[nl] = qbar;
-        a.knnbar[n] = -qbar;
+        st_co<COH>(a.knnbar + n, -qbar);
     }
     __syncthreads();
     if (act) {
@@ -1229,8 +1229,74 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_sum(PostBwdArgs
         real w = 0;
 #pragma unroll 8
         for (int j = 0; j < m; ++j) w += R0[j * ld + i] * kr[nl * m + j];
-        a.Knbar[(size_t)n * m + i] = acc + real(2) * qb[nl] * w;
+        st_co<COH>(a.Knbar + (size_t)n * m + i, acc + real(2) * qb[nl] * w);
     }
+}
+
+template <int MC>
+__global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_sum(PostBwdArgs a) {
+    extern __shared__ __align__(16) real smem[];
+    posterior_bwd_sum_block<MC>(a, (int)blockIdx.x, (int)blockDim.x, smem);
+}
+
+// Training step (m <= 64, round 6): the kernel-matrix VJP and the encoder's reverse pass are independent (both consume the
+// reverse row stage), so they share ONE launch of VAE_NT-thread workgroups: the m + nrb VJP workgroups come FIRST in the grid and
+// run on their first SVGP_BLOCK threads (the other waves exit at once), the image workgroups follow.  168 VGPRs and 75 KB of LDS
+// let a VJP workgroup and an image workgroup share a CU, so no image workgroup waits for a VJP workgroup to retire.
+// Round 6, second step: pass 2 of the reverse row stage (sum over channels: Knbar, knnbar, Kbar -- consumed by the VJP only) rides
+// in the same launch, in FRONT of the VJP workgroups, which wait for it on a counter in the workspace: the n_sum producers write
+// their results THROUGH to memory (sc1 stores), drain them (s_waitcnt) and increment the counter; the VJP workgroups poll it and
+// read the payload past their XCD's L2 (sc1 loads, ld_co); the last of them through the gate resets both counters.  Workgroup ids are dealt to the XCDs round-robin and dispatched in order per XCD, and all n_sum + n_km + n_img
+// workgroups fit the chip at once (two per CU), so a waiting VJP workgroup never holds a slot a producer needs.  The image
+// workgroups (the longest of the launch) do not wait: the sum -> VJP chain (~10 us) hides under them.
+template <int MC, int MM, bool SUM>
+__global__ __launch_bounds__(VAE_NT, MC ? 3 : 2) void k_encoder_bwd_km(svgp_vae::EncBwdArgs e, int n_km, KernArgs a, real rep_weight,
+                                                                 int train_ip, const real* __restrict__ K,
+                                                                 const real* __restrict__ Kn, const real* Kbar,
+                                                                 const real* Knbar, const real* knnbar,
+                                                                 const real* __restrict__ knn,
+                                                                 real* __restrict__ d_ip, real* __restrict__ d_on,
+                                                                 real* __restrict__ part_gp, int n_sum, PostBwdArgs pb,
+                                                                 unsigned long long* __restrict__ flags) {
+    extern __shared__ __align__(16) real smem[];
+    int bid = (int)blockIdx.x;
+    if (SUM) {
+        if (bid < n_sum) {
+            if (threadIdx.x >= SVGP_BLOCK) return;
+            posterior_bwd_sum_block<MC, true>(pb, bid, SVGP_BLOCK, smem);      // Knbar, knnbar, Kbar: written through (sc1)
+            __builtin_amdgcn_s_waitcnt(0);                                    // this wave's stores have left
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(&flags[0], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        bid -= n_sum;
+    }
+    if (bid < n_km) {
+        if (threadIdx.x >= SVGP_BLOCK) return;
+        if (SUM) {
+            if (threadIdx.x == 0) {
+                // (bounded: ~1 s of polling, then the sticky error word flags[2] is set and the workgroup goes on -- a lost producer
+                // must show up as a wrong, flagged result, never as a hung GPU)
+                int spins = 0;
+                while (__hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)n_sum) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1 << 22)) { __hip_atomic_store(&flags[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                }
+                // the last VJP workgroup through the gate re-arms it for the next step
+                if (__hip_atomic_fetch_add(&flags[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned long long)(n_km - 1)) {
+                    __hip_atomic_store(&flags[1], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&flags[0], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            __syncthreads();
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);                          // (compiler: no payload load above the gate)
+        }
+        const int m = MC ? MC : a.m;
+        if (bid < m) km_bwd_cols<MC, MM, SVGP_BLOCK, SUM>(bid, a, rep_weight, train_ip, K, Kn, Kbar, Knbar, d_ip, part_gp);
+        else km_bwd_rows<MC, MM, SVGP_BLOCK, SUM>(bid - m, a, Knbar, knnbar, knn, d_on, part_gp);
+        return;
+    }
+    svgp_vae::encoder_bwd_images<VAE_NT>(e, bid - n_km, (int)gridDim.x - n_km - (SUM ? n_sum : 0), smem);
 }
 
 template <typename F>
@@ -1336,11 +1402,13 @@ static int kernel_matrix_bwd_impl(const svgp_mnist_cfg* c, const double* theta, 
     return SVGP_OK;
 }
 
-// svgp_kernel_matrix_bwd_partials + svgp_mnist_encoder_bwd in ONE launch (m <= 64; see k_encoder_bwd_km)
-extern "C" int svgp_mnist_encoder_bwd_km(const svgp_mnist_cfg* c, const double* theta, const double* images, const double* aux,
-                                         double* ws, void* stream) {
+// svgp_kernel_matrix_bwd_partials + svgp_mnist_encoder_bwd in ONE launch (m <= 64; see k_encoder_bwd_km); with_sum: + pass 2 of the
+// reverse row stage in front of them (svgp_gp_posterior_bwd_rows must have run; ws.flags must be zero on entry and is left zero)
+static PostBwdArgs make_pb(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state, bool with_final);
+static int encoder_bwd_km_impl(const svgp_mnist_cfg* c, const double* theta, const double* images, const double* aux, double* ws,
+                               const double* state, bool with_sum, void* stream) {
     GET_LAYOUTS();
-    SVGP_REQUIRE(theta && images && aux && ws, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(theta && images && aux && ws && (state || !with_sum), SVGP_ERR_INVALID, "NULL device pointer");
     SVGP_REQUIRE(c->m <= SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the merged launch exists for m <= %d", SVGP_M_MAX);
     KernArgs a = make_kern_args(c, pl, theta, aux);
     real* grad = ws + wl.grad;
@@ -1348,18 +1416,38 @@ extern "C" int svgp_mnist_encoder_bwd_km(const svgp_mnist_cfg* c, const double* 
     const size_t lds_rows = (size_t)((km_stage_O(c->m, c->M) ? c->m * c->M : c->m) + RBk * c->m + RBk * c->M) * sizeof(real);
     size_t lds = (size_t)svgp_vae::enc_bwd_lds((int)pl.n_enc) * sizeof(real);
     if (lds_rows > lds) lds = lds_rows;
+    PostBwdArgs pb;
+    memset(&pb, 0, sizeof(pb));
+    int n_sum = 0;
+    if (with_sum) {
+        pb = make_pb(c, wl, ws, state, true);
+        n_sum = pb.nb_rows + pb.n_final;
+        const size_t lds2 = mat_lds(c->m, 1) + (size_t)(SVGP_BLOCK + SVGP_BLOCK) * sizeof(real);
+        if (lds2 > lds) lds = lds2;
+    }
     const bool cfg2_shape = c->m == 32 && c->M == 8;
-    int rc = cfg2_shape ? set_dyn_lds(k_encoder_bwd_km<32, 8>, lds) : set_dyn_lds(k_encoder_bwd_km<0, 0>, lds);
+    int rc = cfg2_shape ? (with_sum ? set_dyn_lds(k_encoder_bwd_km<32, 8, true>, lds) : set_dyn_lds(k_encoder_bwd_km<32, 8, false>, lds))
+                        : (with_sum ? set_dyn_lds(k_encoder_bwd_km<0, 0, true>, lds) : set_dyn_lds(k_encoder_bwd_km<0, 0, false>, lds));
     if (rc) return rc;
     const svgp_vae::EncBwdArgs e = svgp_make_enc_bwd_args(c, wl, theta, images, ws);
-    const dim3 grid(n_km + svgp_n_part(c));
+    const dim3 grid(n_sum + n_km + svgp_n_part(c));
 #define KM_BWD_ARGS e, n_km, a, (real)c->rep_weight, c->train_ip, ws + wl.K, ws + wl.Kn, ws + wl.Kbar, ws + wl.Knbar, ws + wl.knnbar, \
-                    ws + wl.knn, grad + pl.ip, ws + wl.d_on, ws + wl.part_gp
-    if (cfg2_shape) hipLaunchKernelGGL((k_encoder_bwd_km<32, 8>), grid, dim3(VAE_NT), lds, (hipStream_t)stream, KM_BWD_ARGS);
-    else hipLaunchKernelGGL((k_encoder_bwd_km<0, 0>), grid, dim3(VAE_NT), lds, (hipStream_t)stream, KM_BWD_ARGS);
+                    ws + wl.knn, grad + pl.ip, ws + wl.d_on, ws + wl.part_gp, n_sum, pb, reinterpret_cast<unsigned long long*>(ws + wl.flags)
+    if (cfg2_shape && with_sum) hipLaunchKernelGGL((k_encoder_bwd_km<32, 8, true>), grid, dim3(VAE_NT), lds, (hipStream_t)stream, KM_BWD_ARGS);
+    else if (cfg2_shape) hipLaunchKernelGGL((k_encoder_bwd_km<32, 8, false>), grid, dim3(VAE_NT), lds, (hipStream_t)stream, KM_BWD_ARGS);
+    else if (with_sum) hipLaunchKernelGGL((k_encoder_bwd_km<0, 0, true>), grid, dim3(VAE_NT), lds, (hipStream_t)stream, KM_BWD_ARGS);
+    else hipLaunchKernelGGL((k_encoder_bwd_km<0, 0, false>), grid, dim3(VAE_NT), lds, (hipStream_t)stream, KM_BWD_ARGS);
 #undef KM_BWD_ARGS
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
+}
+extern "C" int svgp_mnist_encoder_bwd_km(const svgp_mnist_cfg* c, const double* theta, const double* images, const double* aux,
+                                         double* ws, void* stream) {
+    return encoder_bwd_km_impl(c, theta, images, aux, ws, nullptr, false, stream);
+}
+extern "C" int svgp_mnist_encoder_bwd_km_sum(const svgp_mnist_cfg* c, const double* theta, const double* images, const double* aux,
+                                             double* ws, const double* state, void* stream) {
+    return encoder_bwd_km_impl(c, theta, images, aux, ws, state, true, stream);
 }
 
 extern "C" int svgp_kernel_matrix_bwd(const svgp_mnist_cfg* c, const double* theta, const double* aux, double* ws,
@@ -1649,17 +1737,14 @@ static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* st
     return SVGP_OK;
 }
 
-static int posterior_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream);
+static int posterior_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream, int pass = 0);
 extern "C" int svgp_gp_posterior_bwd(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     return posterior_bwd_impl(c, ws, state, false, stream);
 }
 extern "C" int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     return posterior_bwd_impl(c, ws, state, true, stream);
 }
-static int posterior_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream) {
-    GET_LAYOUTS();
-    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
-    if (c->m > SVGP_M_MAX) return svgp_big_posterior_bwd(c, wl, ws, state, stream);
+static PostBwdArgs make_pb(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state, bool with_final) {
     PostBwdArgs a;
     a.b = c->b; a.m = c->m; a.L = c->L; a.geco = SVGP_LOSS_FLAGS(c); a.c = c->N_train / (double)c->b_global; a.state = state;
     a.Kn = ws + wl.Kn; a.y = ws + wl.qnet_mu; a.s2 = ws + wl.qnet_var; a.p_m = ws + wl.p_m; a.p_v = ws + wl.p_v;
@@ -1669,12 +1754,28 @@ static int posterior_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double*
     a.Knbar_part = ws + wl.Knbar_part;
     a.Knbar = ws + wl.Knbar; a.knnbar = ws + wl.knnbar; a.ybar = ws + wl.ybar; a.s2bar = ws + wl.s2bar;
     const int m = c->m, RB = rows_per_block(m), nb = (c->b + RB - 1) / RB;
-    const size_t lds = mat_lds(m, 3) + (size_t)(3 * m + SVGP_BLOCK + 2 * SVGP_BLOCK) * sizeof(real);
-    LAUNCH_MC(k_gp_posterior_bwd_l, m, dim3(nb, c->L), lds, stream, a);
-    const size_t lds2 = mat_lds(m, 1) + (size_t)(SVGP_BLOCK + SVGP_BLOCK) * sizeof(real);
     a.nb_rows = nb; a.n_final = with_final ? (m * m + SVGP_BLOCK - 1) / SVGP_BLOCK : 0;
     a.b_global = c->b_global; a.N_train = c->N_train;
     a.Kbar_part = ws + wl.fb_part; a.Kbar = ws + wl.Kbar;
+    return a;
+}
+// pass: 0 = both passes, 1 = the per-channel row terms only (ybar, s2bar, the (L, b, m) partials of Knbar)
+static int posterior_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream, int pass) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    if (c->m > SVGP_M_MAX) return svgp_big_posterior_bwd(c, wl, ws, state, stream);
+    PostBwdArgs a = make_pb(c, wl, ws, state, with_final);
+    const int m = c->m, nb = a.nb_rows;
+    const size_t lds = mat_lds(m, 3) + (size_t)(3 * m + SVGP_BLOCK + 2 * SVGP_BLOCK) * sizeof(real);
+    LAUNCH_MC(k_gp_posterior_bwd_l, m, dim3(nb, c->L), lds, stream, a);
+    if (pass == 1) return SVGP_OK;
+    const size_t lds2 = mat_lds(m, 1) + (size_t)(SVGP_BLOCK + SVGP_BLOCK) * sizeof(real);
     LAUNCH_MC(k_gp_posterior_bwd_sum, m, dim3(nb + a.n_final), lds2, stream, a);
     return SVGP_OK;
+}
+// m <= 64, training step: pass 1 of the reverse row stage alone; its pass 2 (the sums over channels) then rides in
+// svgp_mnist_encoder_bwd_km_sum
+extern "C" int svgp_gp_posterior_bwd_rows(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    SVGP_REQUIRE(c && c->m <= SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the two-pass reverse row stage exists for m <= %d", SVGP_M_MAX);
+    return posterior_bwd_impl(c, ws, state, true, stream, 1);
 }

@@ -160,3 +160,40 @@ def test_precomputed_effective_weights_forms_equal_the_plain_ones():
     _lib.call("svgp_mnist_encoder_kernel_matrix_fwd", cfg, th, img, ax, ws, s)
     eng.synchronize()
     assert not torch.equal(eng.ws_view("dec_weff", (2176,)), weff0)
+
+
+@pytest.mark.parametrize("b,m,L,M", [(256, 32, 16, 8), (48, 16, 4, 4), (300, 24, 5, 4)])
+def test_pass_two_of_the_reverse_row_stage_rides_in_the_encoder_reverse_launch(b, m, L, M):
+    """svgp_gp_posterior_bwd_rows + svgp_mnist_encoder_bwd_km_sum == svgp_gp_posterior_bwd_with_final +
+    svgp_kernel_matrix_bwd_partials + svgp_mnist_encoder_bwd, bit for bit: the channel sums (Knbar, knnbar, Kbar) are formed by
+    workgroups at the head of the launch, the kernel-matrix VJP workgroups wait for them on the counter in ws.flags (agent-scope
+    release / acquire), which every call leaves zero, with the error word clear; repeated calls stay equal."""
+    from svgp_vae_amd import _lib
+    params, images, aux, eps = H.toy_problem(b=b, m=m, L=L, M=M, n_obj=20, seed=6)
+    eng = H.engine_for(params, b, geco=True, N_train=400.0)
+    dev = eng.device
+    eng.bind(images.to(dev), aux.to(dev), eps.to(dev))
+    eng.run(adam=False)
+    eng.synchronize()
+    cfg, th, ws, st = C.byref(eng.cfg), eng.theta.data_ptr(), eng.ws.data_ptr(), eng.state.data_ptr()
+    img, ax, s = eng._bound[0].data_ptr(), eng._bound[1].data_ptr(), eng.stream.cuda_stream
+    nrb = (b + (256 // m) - 1) // (256 // m)
+    views = lambda: dict(part_enc=eng.ws_view("part_enc", (eng.wl.n_part, eng.pl.n_enc)), d_on=eng.ws_view("d_on", (b, M)),
+                         part_gp=eng.ws_view("part_gp", (m + nrb, 2)), ip=eng.grads()["inducing_index_points"],
+                         Knbar=eng.ws_view("Knbar", (b, m)), knnbar=eng.ws_view("knnbar", (b,)), Kbar=eng.ws_view("Kbar", (m, m)),
+                         ybar=eng.ws_view("ybar", (b, L)), s2bar=eng.ws_view("s2bar", (b, L)))
+    _lib.call("svgp_gp_posterior_bwd_with_final", cfg, ws, st, s)
+    _lib.call("svgp_kernel_matrix_bwd_partials", cfg, th, ax, ws, s)
+    _lib.call("svgp_mnist_encoder_bwd", cfg, th, img, ws, s)
+    eng.synchronize()
+    ref = {k: v.clone() for k, v in views().items()}
+    flags = eng.ws_view("flags", (16,))
+    for rep in range(3):
+        for v in views().values():
+            v.fill_(float("nan"))
+        _lib.call("svgp_gp_posterior_bwd_rows", cfg, ws, st, s)
+        _lib.call("svgp_mnist_encoder_bwd_km_sum", cfg, th, img, ax, ws, st, s)
+        eng.synchronize()
+        assert torch.count_nonzero(flags.view(torch.int64)) == 0, (rep, flags.view(torch.int64).tolist())
+        for k, v in views().items():
+            assert torch.equal(v, ref[k]), (rep, k)

@@ -33,7 +33,7 @@ def child():
             eng.run(adam=True)
         eng.synchronize()
         best = min(best, (time.perf_counter() - t0) / reps * 1e6)
-    print(json.dumps(dict(split=os.environ.get("SVGP_DEC_SPLIT", "1"), types=os.environ.get("SVGP_DEC_RIDER_TYPES", ""), merge=os.environ.get("SVGP_ENC_KM_MERGE", ""), step_us=best, elbo=eng.scalars()["elbo"])), flush=True)
+    print(json.dumps(dict(split=os.environ.get("SVGP_DEC_SPLIT", "1"), types=os.environ.get("SVGP_DEC_RIDER_TYPES", ""), merge=os.environ.get("SVGP_ENC_KM_MERGE", ""), sum_merge=os.environ.get("SVGP_SUM_MERGE", ""), step_us=best, elbo=eng.scalars()["elbo"])), flush=True)
 
 
 def main():
@@ -110,11 +110,14 @@ def main():
             ("kernel_matrix_bwd_partials", "svgp_kernel_matrix_bwd_partials", (cfg, th, eng._bound[1].data_ptr(), ws, s)),
             ("encoder_bwd", "svgp_mnist_encoder_bwd", (cfg, th, img, ws, s)),
             ("encoder_bwd_km", "svgp_mnist_encoder_bwd_km", (cfg, th, img, eng._bound[1].data_ptr(), ws, s)),
+            ("encoder_bwd_km_sum", "svgp_mnist_encoder_bwd_km_sum", (cfg, th, img, eng._bound[1].data_ptr(), ws, st, s)),
+            ("gp_posterior_bwd_with_final", "svgp_gp_posterior_bwd_with_final", (cfg, ws, st, s)),
+            ("gp_posterior_bwd_rows", "svgp_gp_posterior_bwd_rows", (cfg, ws, st, s)),
             ("grad_reduce_all", "svgp_mnist_grad_reduce_all", (cfg, eng._bound[1].data_ptr(), ws, s))]
     for name, sym, args in rows:
         print(f"{name:32s} {timeit(sym, args):7.2f} us", flush=True)
-    for flag, nty, mg in (("0", "3", "0"), ("1", "3", "0"), ("1", "3", "1"), ("0", "3", "1"), ("1", "3", "0"), ("1", "3", "1")):
-        env = dict(os.environ, SVGP_DEC_SPLIT=flag, SVGP_DEC_RIDER_TYPES=nty, SVGP_ENC_KM_MERGE=mg)
+    for flag, nty, mg, sm in (("0", "3", "0", "0"), ("1", "3", "0", "0"), ("1", "3", "1", "0"), ("1", "3", "1", "1"), ("1", "3", "1", "0"), ("1", "3", "1", "1")):
+        env = dict(os.environ, SVGP_DEC_SPLIT=flag, SVGP_DEC_RIDER_TYPES=nty, SVGP_ENC_KM_MERGE=mg, SVGP_SUM_MERGE=sm)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True)
         print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:], flush=True)
 

@@ -128,7 +128,8 @@ typedef struct {
     int64_t dec_h0, dec_a1, dec_a2, recon; /* (b,128) (b,8,8,8) (b,14,14,8) (b,28,28,1)           */
     /* pre-activation gradients of the decoder layers, written by svgp_mnist_decoder_bwd_data for the weight half */
     int64_t dec_d2, dec_d1, dec_dh0;      /* (b,14,14,8) (b,8,8,8) (b,128)                        */
-    int64_t flags;                        /* (16) two u64 counters of the intra-launch hand-off of svgp_mnist_encoder_bwd_km_sum; the
+    int64_t flags;                        /* (64) u64 counters of the intra-launch hand-offs: [0..2] svgp_mnist_encoder_bwd_km_sum (produced,
+                                           * consumed, sticky error), [8, 8+L) svgp_gp_stats_factor_bwd_wgrad (one per channel); the
                                            * workspace must be ZERO here before its first use (every call leaves them zero) */
     int64_t dec_weff;                     /* (2176) effective parity-class weights of the decoder's three up-convolutions for the
                                            * current theta: written by svgp_mnist_encoder_kernel_matrix_fwd, read by the `_pre` forms */
@@ -337,6 +338,12 @@ int svgp_mnist_encoder_bwd_km_sum(const svgp_mnist_cfg*, const double* theta, co
  * first, then min(b, 256) rider workgroups with the decoder's weight-gradient partials (needs svgp_mnist_decoder_bwd_data before). */
 int svgp_gp_factor_bwd_nofinal_wgrad(const svgp_mnist_cfg*, const double* images, double* ws, const double* state,
                                      void* stream);
+/* ... and svgp_gp_stats_bwd as P L leading workgroups of the same launch (single-GPU step only: nothing may be exchanged between the
+ * reverse statistics and the reverse factor stage).  Channel workgroup l waits for its own P producers on ws.flags[8 + l] (write-through
+ * payload, drained, relaxed agent-scope counter; the consumer re-arms it).  Same bits as svgp_gp_stats_bwd followed by
+ * svgp_gp_factor_bwd_nofinal_wgrad.  L <= 56. */
+int svgp_gp_stats_factor_bwd_wgrad(const svgp_mnist_cfg*, const double* images, double* ws, const double* state,
+                                   void* stream);
 int svgp_gp_posterior_bwd_with_final(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 /* tf.train.AdamOptimizer.apply_gradients, TF1 formula (MNIST_experiment.py:200,207-208) */
 int svgp_adam_tf1_step(int64_t n, double* theta, const double* grad, double* adam_m, double* adam_v,

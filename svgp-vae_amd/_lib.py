@@ -113,6 +113,7 @@ SIGNATURES = {
     "svgp_gp_stats_bwd_with_aji": [_CFG, _P, _P, _P],
     "svgp_gp_factor_bwd_nofinal": [_CFG, _P, _P, _P],
     "svgp_gp_factor_bwd_nofinal_wgrad": [_CFG, _P, _P, _P, _P],
+    "svgp_gp_stats_factor_bwd_wgrad": [_CFG, _P, _P, _P, _P],
     "svgp_mnist_encoder_bwd_km": [_CFG, _P, _P, _P, _P, _P],
     "svgp_mnist_encoder_bwd_km_sum": [_CFG, _P, _P, _P, _P, _P, _P],
     "svgp_gp_posterior_bwd_rows": [_CFG, _P, _P, _P],

@@ -114,7 +114,7 @@ extern "C" int svgp_mnist_ws_layout_get(const svgp_mnist_cfg* c, svgp_mnist_ws_l
     o->eps = take(b * L); o->z = take(b * L);
     o->dec_h0 = take(b * 128); o->dec_a1 = take(b * 512); o->dec_a2 = take(b * 1568); o->recon = take(b * 784);
     o->dec_d2 = take(b * 1568); o->dec_d1 = take(b * 512); o->dec_dh0 = take(b * 128); o->dec_weff = take(2176);
-    o->flags = take(16);
+    o->flags = take(64);
     o->zbar = take(b * L); o->g_pv = take(b * L); o->g_pm = take(b * L); o->mvbar = take(b * L);
     o->statB = p; o->A2 = p; p += P * L * m * m; o->ud = p; p += P * L * m; o->td = p; p += P * L * m;
     o->statB_len = p - o->statB; take(0);
@@ -306,16 +306,23 @@ bool sum_merge_on() {
     const char* e = getenv("SVGP_SUM_MERGE");
     return !(e && e[0] == '0');
 }
+// m <= 64, phases issued back to back with nothing exchanged in between (round 6): the reverse statistics ride in the reverse factor
+// launch (svgp_gp_stats_factor_bwd_wgrad).  SVGP_STAT_MERGE=0: their own launch at the end of phase 1.
+bool stat_merge_on() {
+    const char* e = getenv("SVGP_STAT_MERGE");
+    return !(e && e[0] == '0');
+}
 bool konly_on() {      // (read per call: tests compare the two orders in one process)
     const char* e = getenv("SVGP_KONLY_BRANCH");
     return !(e && e[0] == '0');
 }
 // `defer`: the caller issues all four phases back to back on one stream (svgp_mnist_train_step), so a
 // branch forked in one phase may be joined in a later one; otherwise every phase joins before returning
-// (each phase may be captured into its own graph, with a collective in between).
+// (each phase may be captured into its own graph, with a collective in between).  defer == 2: ... and NOTHING is exchanged
+// between the phases (the single-GPU step), so a stage may move across a phase boundary.
 int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const double* images, const double* aux,
                     const double* eps, double* ws, double* state, double* adam_m, double* adam_v, void* stream,
-                    bool defer) {
+                    int defer) {
     int rc = svgp_check_cfg(c);
     if (rc) return rc;
     SVGP_REQUIRE(theta && images && aux && ws && state, SVGP_ERR_INVALID, "NULL device pointer");
@@ -343,6 +350,7 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
 #define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
     const bool ksplit = phase == 0 && fork1 && defer && c->m < SVGP_CHOL_INVERSE_MIN_M && konly_on();
     const bool sum_rides = phase == 2 && !large && !fork2 && !c->titsias && enc_km_merge_on() && sum_merge_on();
+    const bool stat_rides = defer == 2 && !large && !c->titsias && c->L <= 56 && dec_split_on() && stat_merge_on();
     switch (phase) {
     case 0:
         RUN(svgp_mnist_encoder_kernel_matrix_fwd(c, theta, images, aux, ws, stream));   // one launch for the two
@@ -391,7 +399,7 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
             RUN(svgp_mnist_decoder_fwd(c, theta, images, ws, stream));
             RUN(svgp_mnist_decoder_bwd(c, theta, images, ws, state, stream));
         }
-        RUN(svgp_gp_stats_bwd(c, ws, state, stream));
+        if (!stat_rides) RUN(svgp_gp_stats_bwd(c, ws, state, stream));      // (else: at the head of phase 2's first launch)
         if (fork1 && !defer) RUN(side_join(sd, 1, ms));        // phase-at-a-time callers: joined before the phase returns
         break;
     case 2:
@@ -411,7 +419,8 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
             RUN(svgp_gp_factor_bwd_late_b(c, ws, state, stream));
         } else {
             // channel sum Kbar: inside the next launch; m <= 64: + the decoder's weight gradients as riders (phase 1 ran the data half)
-            if (!large && dec_split_on()) RUN(svgp_gp_factor_bwd_nofinal_wgrad(c, images, ws, state, stream));
+            if (stat_rides) RUN(svgp_gp_stats_factor_bwd_wgrad(c, images, ws, state, stream));
+            else if (!large && dec_split_on()) RUN(svgp_gp_factor_bwd_nofinal_wgrad(c, images, ws, state, stream));
             else RUN(svgp_gp_factor_bwd_nofinal(c, ws, state, stream));
         }
         // m <= 64 (round 6): pass 2 of the reverse row stage (the sums over channels, consumed by the kernel-matrix VJP only) rides in the
@@ -464,14 +473,14 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
 extern "C" int svgp_mnist_step_phase(const svgp_mnist_cfg* c, int phase, double* theta, const double* images,
                                      const double* aux, const double* eps, double* ws, double* state,
                                      double* adam_m, double* adam_v, void* stream) {
-    return step_phase_impl(c, phase, theta, images, aux, eps, ws, state, adam_m, adam_v, stream, false);
+    return step_phase_impl(c, phase, theta, images, aux, eps, ws, state, adam_m, adam_v, stream, 0);
 }
 
 // internal (comm.hip): one phase of a step whose phases are all issued back to back on one stream
 int svgp_mnist_step_phase_deferred(const svgp_mnist_cfg* c, int phase, double* theta, const double* images,
                                    const double* aux, const double* eps, double* ws, double* state, double* adam_m,
                                    double* adam_v, void* stream) {
-    return step_phase_impl(c, phase, theta, images, aux, eps, ws, state, adam_m, adam_v, stream, true);
+    return step_phase_impl(c, phase, theta, images, aux, eps, ws, state, adam_m, adam_v, stream, 1);
 }
 
 extern "C" int svgp_mnist_train_step(const svgp_mnist_cfg* c, double* theta, const double* images,
@@ -481,7 +490,7 @@ extern "C" int svgp_mnist_train_step(const svgp_mnist_cfg* c, double* theta, con
                  "svgp_mnist_train_step is the single-GPU form (b == b_global); use svgp_mnist_step_phase "
                  "with all-reduces between phases for data parallelism");
     for (int ph = 0; ph < 4; ++ph) {
-        int rc = step_phase_impl(c, ph, theta, images, aux, eps, ws, state, adam_m, adam_v, stream, true);
+        int rc = step_phase_impl(c, ph, theta, images, aux, eps, ws, state, adam_m, adam_v, stream, 2);
         if (rc) return rc;
     }
     return SVGP_OK;

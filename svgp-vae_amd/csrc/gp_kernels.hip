@@ -48,6 +48,18 @@ __device__ __forceinline__ void mat_load(real* R, int ld, const real* __restrict
 __device__ __forceinline__ void mat_store(real* __restrict__ g, const real* R, int ld, int m) {
     for (int o = threadIdx.x; o < m * m; o += blockDim.x) g[o] = R[(o / m) * ld + (o % m)];
 }
+// Payload of an intra-launch hand-off between workgroups on different XCDs (svgp_mnist_encoder_bwd_km_sum): written THROUGH to memory
+// and read past the non-coherent per-XCD L2s (sc1 = relaxed agent-scope atomics), no cache-wide write-back / invalidate -- the
+// release / acquire FENCE form of the same hand-off cost the launch 10 us (every fence writes back or drops the whole L2 of its XCD
+// while the image workgroups stream their partials through it).
+template <bool COH> __device__ __forceinline__ real ld_co(const real* p) {
+    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return *p;
+}
+template <bool COH> __device__ __forceinline__ void st_co(real* p, real v) {
+    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
 // ---- float64 MFMA GEMMs on LDS matrices -------------------------------------------------------
 // The factor kernels keep their matrices PADDED: mp = m rounded up to 16, leading dimension
 // ld = mp + 2 (conflict-free 16-row x 4-k operand fetch with 8-byte elements), pad region zero.
@@ -308,18 +320,6 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_kernel_matrix_xy(KernXYArgs a, r
     out[idx] = view_k(xr[1] - yr[1], amp * amp, real(1) / (ls * ls)) * D;
 }
 
-// Payload of an intra-launch hand-off between workgroups on different XCDs (svgp_mnist_encoder_bwd_km_sum): written THROUGH to memory
-// and read past the non-coherent per-XCD L2s (sc1 = relaxed agent-scope atomics), no cache-wide write-back / invalidate -- the
-// release / acquire FENCE form of the same hand-off cost the launch 10 us (every fence writes back or drops the whole L2 of its XCD
-// while the image workgroups stream their partials through it).
-template <bool COH> __device__ __forceinline__ real ld_co(const real* p) {
-    if (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return *p;
-}
-template <bool COH> __device__ __forceinline__ void st_co(real* p, real v) {
-    if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else *p = v;
-}
 // VJP, inducing side: one workgroup per inducing point j.
 // d_ip[j] = [0, d_theta_j, d_o_j], partial amplitude / length-scale sums -> part_gp[j].
 #define KM_MAXM 32
@@ -549,39 +549,11 @@ struct StatArgs {
 
 __device__ __forceinline__ real grad_KL_term(int flags, int L, const real* state) { return svgp_seed_T(flags, L, state); }
 
-template <int MC>
-__global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
-    extern __shared__ __align__(16) real smem[];
-    const int m = MC ? MC : a.m, l = blockIdx.y;
-    if (a.mode == 0 && l == a.L) {   // ---- K_mm inverse block (forward mode only, blockIdx.x == 0)
-        if (blockIdx.x != 0) return;
-        const int ld = m + 1;
-        real* A = smem;
-        real* W = A + m * ld;
-        mat_load(A, ld, a.K, m);
-        __syncthreads();
-        if (threadIdx.x < m) A[threadIdx.x * ld + threadIdx.x] += a.jitter;
-        const real logdet = chol_inv(A, W, ld, m);
-        mat_store(a.Ki, A, ld, m);
-        if (threadIdx.x == 0) *a.ldK = logdet;
-        return;
-    }
-    if (a.mode == 1 && (int)blockIdx.y >= a.L) {
-        // ---- deferred tail of the forward factor stage: Aji = (A_hat + jitter I)^-1 and the log det term of KL
-        // (SVGPVAE_model.py:271-279).  Only the reverse pass and the KL scalar need them, so they run here, beside
-        // the L statistics workgroups that leave most CUs idle, instead of on the forward critical path.
-        if (blockIdx.x != 0) return;
-        const int l2 = blockIdx.y - a.L, ld = m + 1;
-        real* A = smem;
-        real* W = A + m * ld;
-        mat_load(A, ld, a.Ahat + (size_t)l2 * m * m, m);
-        __syncthreads();
-        if (threadIdx.x < m) A[threadIdx.x * ld + threadIdx.x] += a.jitter;
-        const real ldA = chol_inv(A, W, ld, m);
-        mat_store(a.Aji + (size_t)l2 * m * m, A, ld, m);
-        if (threadIdx.x == 0) a.KL[l2] -= real(0.5) * ldA;
-        return;
-    }
+// Statistics of channel l, row partial `part` of `nparts_grid` (the body of k_gp_stats; COH: the outputs S, v1, v2 are written
+// through for a consumer in the SAME launch, svgp_gp_stats_factor_bwd_wgrad)
+template <int MC, bool COH>
+__device__ __forceinline__ void gp_stats_block(const StatArgs& a, int part, int nparts_grid, int l, real* smem) {
+    const int m = MC ? MC : a.m;
     // ---- statistics of channel l: S = Kn^T diag(w) Kn on the f64 MFMA (A[i][k=n] = w_n Kn[n][i],
     // B[k=n][j] = Kn[n][j], k-steps of 4 rows), vectors on the VALU.  One wave per 16x16 tile.
     const int STAT_RC = a.rc_rows;            // multiple of 4
@@ -599,7 +571,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
     real acc1 = 0, acc2 = 0;
     const real gT = a.mode ? grad_KL_term(a.geco, a.L, a.state) : real(0);
     // row partial blockIdx.x of gridDim.x: rows [rlo, rhi) -> partial block `part` of the outputs
-    const int part = blockIdx.x, RP = ((a.b + (int)gridDim.x - 1) / (int)gridDim.x + 3) & ~3;
+    const int RP = ((a.b + nparts_grid - 1) / nparts_grid + 3) & ~3;
     const int rlo = min(a.b, part * RP), rhi = min(a.b, rlo + RP);
     const size_t pl_ = (size_t)part * a.L + l;
     for (int r0 = rlo; r0 < rhi; r0 += STAT_RC) {
@@ -674,7 +646,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int i = ti * 16 + q + 4 * g, j = tj * 16 + r16;
-                if (i < m && j < m) a.S[pl_ * m * m + (size_t)i * m + j] = acc[tt][g];
+                if (i < m && j < m) st_co<COH>(a.S + pl_ * m * m + (size_t)i * m + j, acc[tt][g]);
             }
         }
     }
@@ -685,9 +657,45 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
     if (threadIdx.x < m) {
         real s1 = 0, s2 = 0;
         for (int pp = 0; pp < nparts; ++pp) { s1 += scr[pp * mp + threadIdx.x]; s2 += scr[SVGP_BLOCK + pp * mp + threadIdx.x]; }
-        a.v1[pl_ * m + threadIdx.x] = s1;
-        if (a.v2) a.v2[pl_ * m + threadIdx.x] = s2;
+        st_co<COH>(a.v1 + pl_ * m + threadIdx.x, s1);
+        if (a.v2) st_co<COH>(a.v2 + pl_ * m + threadIdx.x, s2);
     }
+}
+
+template <int MC>
+__global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
+    extern __shared__ __align__(16) real smem[];
+    const int m = MC ? MC : a.m, l = blockIdx.y;
+    if (a.mode == 0 && l == a.L) {   // ---- K_mm inverse block (forward mode only, blockIdx.x == 0)
+        if (blockIdx.x != 0) return;
+        const int ld = m + 1;
+        real* A = smem;
+        real* W = A + m * ld;
+        mat_load(A, ld, a.K, m);
+        __syncthreads();
+        if (threadIdx.x < m) A[threadIdx.x * ld + threadIdx.x] += a.jitter;
+        const real logdet = chol_inv(A, W, ld, m);
+        mat_store(a.Ki, A, ld, m);
+        if (threadIdx.x == 0) *a.ldK = logdet;
+        return;
+    }
+    if (a.mode == 1 && (int)blockIdx.y >= a.L) {
+        // ---- deferred tail of the forward factor stage: Aji = (A_hat + jitter I)^-1 and the log det term of KL
+        // (SVGPVAE_model.py:271-279).  Only the reverse pass and the KL scalar need them, so they run here, beside
+        // the L statistics workgroups that leave most CUs idle, instead of on the forward critical path.
+        if (blockIdx.x != 0) return;
+        const int l2 = blockIdx.y - a.L, ld = m + 1;
+        real* A = smem;
+        real* W = A + m * ld;
+        mat_load(A, ld, a.Ahat + (size_t)l2 * m * m, m);
+        __syncthreads();
+        if (threadIdx.x < m) A[threadIdx.x * ld + threadIdx.x] += a.jitter;
+        const real ldA = chol_inv(A, W, ld, m);
+        mat_store(a.Aji + (size_t)l2 * m * m, A, ld, m);
+        if (threadIdx.x == 0) a.KL[l2] -= real(0.5) * ldA;
+        return;
+    }
+    gp_stats_block<MC, false>(a, (int)blockIdx.x, (int)gridDim.x, l, smem);
 }
 
 // =============================================================================================
@@ -696,11 +704,12 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_stats(StatArgs a) {
 // =============================================================================================
 // sum of the row partials of one statistics element (stride between partial blocks); P is 1 or SVGP_STAT_PARTS, the
 // loads of the unrolled form are independent
-__device__ __forceinline__ real part_sum(const real* __restrict__ p, size_t stride, int P) {
-    if (P == 1) return p[0];
+template <bool COH = false>
+__device__ __forceinline__ real part_sum(const real* p, size_t stride, int P) {
+    if (P == 1) return ld_co<COH>(p);
     real s[SVGP_STAT_PARTS];
 #pragma unroll
-    for (int pp = 0; pp < SVGP_STAT_PARTS; ++pp) s[pp] = p[pp * stride];
+    for (int pp = 0; pp < SVGP_STAT_PARTS; ++pp) s[pp] = ld_co<COH>(p + pp * stride);
     real t = s[0];
 #pragma unroll
     for (int pp = 1; pp < SVGP_STAT_PARTS; ++pp) t += s[pp];
@@ -938,23 +947,45 @@ struct FactBwdArgs {
     // s_setprio for the channel workgroups: no change; 1 or 2 fatter riders per image: 93 / 74 KB of LDS, a third round: 24 us.
     int n_riders;
     svgp_vae::DecWgradArgs wg;
+    // single-GPU training step (round 6): the reverse statistics (A2, ud, td: P row partials per channel) ride in FRONT of the channel
+    // workgroups, which wait for their own P producers on ws.flags[8 + l] (write-through payload + drained counter, as in
+    // k_encoder_bwd_km); the riders wait for nobody
+    int n_stat, wait_n;
+    StatArgs st;
+    unsigned long long* flags;
 };
 
-template <int MC>
+// STAT: 0 = the reverse statistics were a launch of their own; 1 = they ride at the head of this launch and the channel workgroup
+// waits for them where Ki is last in LDS (before T1 A); 2 = ... a FIFTH LDS matrix keeps Ki for the whole workgroup (m * m <= 4 * 256
+// elements, no kl_form), the wait moves behind Kbar_l = Abar G^T and the hand-off loads fly during the next two products
+template <int MC, int STAT = 0>
 __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     extern __shared__ __align__(16) real smem[];
-    if ((int)blockIdx.x >= a.L) {
-        svgp_vae::decoder_wgrad_rider<SVGP_BLOCK>(a.wg, (int)blockIdx.x - a.L, smem);
+    int bid = (int)blockIdx.x;
+    if (STAT) {
+        if (bid < a.n_stat) {                  // block l P + part: the P producers of a channel are neighbours, low channels first
+            const int ls = bid / a.P, part = bid - ls * a.P;
+            gp_stats_block<MC, true>(a.st, part, a.P, ls, smem);
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(&a.flags[8 + ls], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        bid -= a.n_stat;
+    }
+    if (bid >= a.L) {
+        svgp_vae::decoder_wgrad_rider<SVGP_BLOCK>(a.wg, bid - a.L, smem);
         return;
     }
-    const int m = MC ? MC : a.m, mp = pad16(m), ld = mp + 2, mm = mp * ld, l = blockIdx.x;
+    const int m = MC ? MC : a.m, mp = pad16(m), ld = mp + 2, mm = mp * ld, l = bid;
     real* R0 = smem;
     real* R1 = R0 + mm;
     real* R2 = R1 + mm;
     real* R3 = R2 + mm;
-    for (int o = threadIdx.x; o < 4 * mm; o += blockDim.x) smem[o] = 0;   // zero pads (MFMA tiles read them)
+    real* RK = STAT == 2 ? R3 + mm : R0;  // Ki
+    for (int o = threadIdx.x; o < (STAT == 2 ? 5 : 4) * mm; o += blockDim.x) smem[o] = 0;   // zero pads (MFMA tiles read them)
     __syncthreads();
-    real* ubar = R3 + mm;      // m
+    real* ubar = R3 + (STAT == 2 ? 2 : 1) * mm;      // m
     real* mubar = ubar + m;    // m
     real* tbar = mubar + m;    // m
     real* tv = tbar + m;       // m  (t_l)
@@ -967,7 +998,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     real* Kib = a.Kibar_part + om;
 
     const size_t sM = (size_t)a.L * m * m, sV = (size_t)a.L * m;     // strides between row partials
-    mat_load(R0, ld, a.Ki, m);
+    mat_load(RK, ld, a.Ki, m);
     // S and A2 are needed twice each; for m <= 32 (<= 4 elements per thread) their partial sums stay in registers
     const bool keep = m * m <= 4 * (int)blockDim.x;
     real kS[4] = {0, 0, 0, 0}, kA2[4] = {0, 0, 0, 0};
@@ -977,7 +1008,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
             const int o = threadIdx.x + k * blockDim.x;
             if (o < m * m) {
                 kS[k] = part_sum(a.S + om + o, sM, a.P);
-                kA2[k] = part_sum(a.A2 + om + o, sM, a.P);
+                if (!STAT) kA2[k] = part_sum(a.A2 + om + o, sM, a.P);
                 R1[(o / m) * ld + (o % m)] = kS[k];
             }
         }
@@ -986,29 +1017,69 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     }
     if (threadIdx.x < m) {
         muv[threadIdx.x] = a.mu[ov + threadIdx.x];
-        ubar[threadIdx.x] = part_sum(a.ud + ov + threadIdx.x, sV, a.P) +
-                            (a.kl_form ? real(0) : real(0.5) * gK * muv[threadIdx.x]);
+        if (!STAT) ubar[threadIdx.x] = part_sum(a.ud + ov + threadIdx.x, sV, a.P) +
+                                       (a.kl_form ? real(0) : real(0.5) * gK * muv[threadIdx.x]);
         tv[threadIdx.x] = a.t[ov + threadIdx.x];
         vv[threadIdx.x] = part_sum(a.v + ov + threadIdx.x, sV, a.P);
     }
     __syncthreads();
-    mat_vec(mubar, R0, ld, ubar, m, real(1));                       // Ki ubar
-    mat_gemm<false, false>(R2, R1, R0, ld, m, real(1));             // T1 = S Ki
+    if (!STAT) mat_vec(mubar, RK, ld, ubar, m, real(1));            // Ki ubar
+    mat_gemm<false, false>(R2, R1, RK, ld, m, real(1));             // T1 = S Ki
     __syncthreads();
-    if (threadIdx.x < m && !a.kl_form) mubar[threadIdx.x] += real(0.5) * gK * a.u[ov + threadIdx.x];
-    mat_gemm<false, false>(R3, R0, R2, ld, m, real(1));             // Ki S Ki
+    if (!STAT && threadIdx.x < m && !a.kl_form) mubar[threadIdx.x] += real(0.5) * gK * a.u[ov + threadIdx.x];
+    mat_gemm<false, false>(R3, RK, R2, ld, m, real(1));             // Ki S Ki
     __syncthreads();
     mat_load(R1, ld, a.Aji + om, m);
     __syncthreads();
     for (int o = threadIdx.x; o < m * m; o += blockDim.x) {         // Abar
         const int idx = (o / m) * ld + (o % m);
-        R3[idx] = real(-0.5) * g3 * R3[idx] + real(0.5) * gK * (R0[idx] - R1[idx]);
+        R3[idx] = real(-0.5) * g3 * R3[idx] + real(0.5) * gK * (RK[idx] - R1[idx]);
     }
     __syncthreads();
     mat_load(R1, ld, a.A + om, m);
+    if (STAT == 1) {
+        // Everything above is a function of forward quantities alone: the reverse statistics of this channel (A2, ud, td) are awaited
+        // HERE, the last point at which Ki is still in LDS for Ki ubar.  (Waiting at the top of the workgroup: 28.0 us for the launch
+        // against 21.7 without the wait -- the statistics need ~6 us from launch start.)
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&a.flags[8 + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)a.wait_n) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 23)) { __hip_atomic_store(&a.flags[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            __hip_atomic_store(&a.flags[8 + l], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // its only consumer re-arms it
+        }
+        __syncthreads();
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int o = threadIdx.x + k * blockDim.x;
+                if (o < m * m) kA2[k] = part_sum<true>(a.A2 + om + o, sM, a.P);
+            }
+        }
+        if (threadIdx.x < m)
+            ubar[threadIdx.x] = part_sum<true>(a.ud + ov + threadIdx.x, sV, a.P) +
+                                (a.kl_form ? real(0) : real(0.5) * gK * muv[threadIdx.x]);
+        __syncthreads();
+        mat_vec(mubar, R0, ld, ubar, m, real(1));                   // Ki ubar
+        __syncthreads();
+        if (threadIdx.x < m && !a.kl_form) mubar[threadIdx.x] += real(0.5) * gK * a.u[ov + threadIdx.x];
+    }
     __syncthreads();
     mat_gemm<false, false>(R0, R2, R1, ld, m, real(1));             // T1 A = S Ki A   (Ki dropped)
     __syncthreads();
+    real pre[4] = {0, 0, 0, 0};
+    if (STAT == 2) {                                                // Kibar_l: what needs no reverse statistic (finished below)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = threadIdx.x + k * blockDim.x;
+            if (o < m * m) {
+                const int idx = (o / m) * ld + (o % m);
+                pre[k] = -g3 * R0[idx] + real(0.5) * gK * R1[idx];
+            }
+        }
+    } else
     for (int o = threadIdx.x; o < m * m; o += blockDim.x) {         // Kibar_l
         const int i = o / m, j = o % m, idx = i * ld + j;
         real sS, sA2;
@@ -1017,7 +1088,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
             sS = k == 0 ? kS[0] : k == 1 ? kS[1] : k == 2 ? kS[2] : kS[3];
             sA2 = k == 0 ? kA2[0] : k == 1 ? kA2[1] : k == 2 ? kA2[2] : kA2[3];
         } else {
-            sS = part_sum(a.S + om + o, sM, a.P); sA2 = part_sum(a.A2 + om + o, sM, a.P);
+            sS = part_sum(a.S + om + o, sM, a.P); sA2 = part_sum<STAT != 0>(a.A2 + om + o, sM, a.P);
         }
         Kib[o] = -g3 * R0[idx] + real(0.5) * gK * R1[idx] + ubar[i] * muv[j] + real(0.5) * g3 * sS - sA2;
     }
@@ -1045,11 +1116,55 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     mat_load(R2, ld, a.G + om, m);
     __syncthreads();
     mat_gemm_g<false, true>(Kb, R3, R2, ld, m, real(1), real(0));   // Kbar_l = Abar G^T
+    if (STAT == 2) {
+        // the wait: ~9 us into the workgroup, the statistics need ~6 us from launch start
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&a.flags[8 + l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned long long)a.wait_n) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 23)) { __hip_atomic_store(&a.flags[2], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+            __hip_atomic_store(&a.flags[8 + l], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // its only consumer re-arms it
+        }
+        __syncthreads();                                            // (also: every wave is past its reads of R2 = G)
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int o = threadIdx.x + k * blockDim.x;
+            if (o < m * m) kA2[k] = part_sum<true>(a.A2 + om + o, sM, a.P);
+        }
+        real ud_r = 0, td_r = 0;
+        if (threadIdx.x < m) {
+            ud_r = part_sum<true>(a.ud + ov + threadIdx.x, sV, a.P);
+            td_r = part_sum<true>(a.td + ov + threadIdx.x, sV, a.P);
+        }
+        mat_load(R2, ld, a.Si + om, m);
+        __syncthreads();
+        mat_gemm_g<false, false>(Kb, R2, R1, ld, m, real(1), real(1));  // += Si Gbar
+        mat_gemm<false, false>(R3, R1, R0, ld, m, real(1));             // Gbar K
+        if (threadIdx.x < m) ubar[threadIdx.x] = ud_r + (a.kl_form ? real(0) : real(0.5) * gK * muv[threadIdx.x]);
+        __syncthreads();
+        mat_vec(mubar, RK, ld, ubar, m, real(1));                   // Ki ubar
+        __syncthreads();
+        if (threadIdx.x < m && !a.kl_form) mubar[threadIdx.x] += real(0.5) * gK * a.u[ov + threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x < m) {                                      // tbar = td + c K mubar
+            real acc = 0;
+            for (int j = 0; j < m; ++j) acc += R0[threadIdx.x * ld + j] * mubar[j];
+            tbar[threadIdx.x] = td_r + a.c * acc;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                               // Kibar_l, finished
+            const int o = threadIdx.x + k * blockDim.x;
+            if (o < m * m) Kib[o] = pre[k] + ubar[o / m] * muv[o % m] + real(0.5) * g3 * kS[k] - kA2[k];
+        }
+        __syncthreads();
+    } else {
     // tbar = td + c K mubar
     if (threadIdx.x < m) {
         real acc = 0;
         for (int j = 0; j < m; ++j) acc += R0[threadIdx.x * ld + j] * mubar[j];
-        tbar[threadIdx.x] = part_sum(a.td + ov + threadIdx.x, sV, a.P) + a.c * acc;
+        tbar[threadIdx.x] = part_sum<STAT != 0>(a.td + ov + threadIdx.x, sV, a.P) + a.c * acc;
     }
     __syncthreads();
     mat_load(R2, ld, a.Si + om, m);
@@ -1057,6 +1172,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     mat_gemm_g<false, false>(Kb, R2, R1, ld, m, real(1), real(1));  // += Si Gbar
     mat_gemm<false, false>(R3, R1, R0, ld, m, real(1));             // Gbar K
     __syncthreads();
+    }
     for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
         const int i = o / m, j = o % m;
         real sA2;
@@ -1064,7 +1180,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
             const int k = o / (int)blockDim.x;
             sA2 = k == 0 ? kA2[0] : k == 1 ? kA2[1] : k == 2 ? kA2[2] : kA2[3];
         } else {
-            sA2 = part_sum(a.A2 + om + o, sM, a.P);
+            sA2 = part_sum<STAT != 0>(a.A2 + om + o, sM, a.P);
         }
         R3[i * ld + j] += sA2 + tbar[i] * vv[j];                    // Sibar
         Kb[o] += a.c * mubar[i] * tv[j];
@@ -1089,12 +1205,13 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     // Kbar_l -= Ki Kibar_l Ki  (the inverse's VJP is linear, so it is applied per channel here and
     // the final kernel only sums channels).  Kib was written by this workgroup above.
     __syncthreads();
-    mat_load(R1, ld, a.Ki, m);
+    real* RKi = STAT == 2 ? RK : R1;
+    if (STAT != 2) mat_load(R1, ld, a.Ki, m);
     mat_load(R2, ld, Kib, m);
     __syncthreads();
-    mat_gemm<false, false>(R3, R1, R2, ld, m, real(1));
+    mat_gemm<false, false>(R3, RKi, R2, ld, m, real(1));
     __syncthreads();
-    mat_gemm_g<false, false>(Kb, R3, R1, ld, m, real(-1), real(1));
+    mat_gemm_g<false, false>(Kb, R3, RKi, ld, m, real(-1), real(1));
 }
 
 // Kbar = sum_l Kbar_l + (L gK / 2) Ki ; one thread per element, channel loads batched.
@@ -1461,8 +1578,8 @@ extern "C" int svgp_kernel_matrix_bwd_partials(const svgp_mnist_cfg* c, const do
     return kernel_matrix_bwd_impl(c, theta, aux, ws, false, stream);
 }
 
-static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
-                        int mode, int with_aji, void* stream) {
+static StatArgs make_stat_args(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
+                               int mode, int with_aji, size_t* lds_out) {
     StatArgs a;
     memset(&a, 0, sizeof(a));
     a.b = c->b; a.m = c->m; a.L = c->L; a.mode = mode; a.c = c->N_train / (double)c->b_global; a.jitter = c->jitter;
@@ -1483,6 +1600,14 @@ static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     size_t lds = (size_t)(a.rc_rows * (mp_ + 2) + 3 * a.rc_rows + 2 * SVGP_BLOCK) * sizeof(real);
     const size_t lds_inv = mat_lds(m, 1) + (size_t)(5 * m + 80) * sizeof(real);
     if ((mode == 0 || with_aji) && lds_inv > lds) lds = lds_inv;
+    *lds_out = lds;
+    return a;
+}
+static int launch_stats(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, double* ws, const double* state,
+                        int mode, int with_aji, void* stream) {
+    size_t lds = 0;
+    StatArgs a = make_stat_args(c, wl, ws, state, mode, with_aji, &lds);
+    const int m = c->m, P = svgp_stat_parts(c);
     LAUNCH_MC(k_gp_stats, m, dim3(P, c->L + (mode == 0 ? 1 : (with_aji ? c->L : 0))), lds, stream, a);
     return SVGP_OK;
 }
@@ -1644,11 +1769,13 @@ static FactBwdArgs make_fb(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     a.vbar = ws + wl.vbar; a.Ssym = ws + wl.Ssym; a.Qm = ws + wl.Qm; a.Kbar = ws + wl.Kbar;
     a.n_riders = 0;
     memset(&a.wg, 0, sizeof(a.wg));
+    a.n_stat = 0; a.flags = nullptr;
+    memset(&a.st, 0, sizeof(a.st));
     return a;
 }
 
 static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream,
-                           const double* images_for_wgrad = nullptr);
+                           const double* images_for_wgrad = nullptr, bool with_stats = false);
 extern "C" int svgp_gp_factor_bwd(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     return factor_bwd_impl(c, ws, state, true, stream);
 }
@@ -1663,6 +1790,16 @@ extern "C" int svgp_gp_factor_bwd_nofinal_wgrad(const svgp_mnist_cfg* c, const d
                  "the weight-gradient riders exist for the LDS-resident reverse factor stage (m <= %d)", SVGP_M_MAX);
     SVGP_REQUIRE(images, SVGP_ERR_INVALID, "NULL device pointer");
     return factor_bwd_impl(c, ws, state, false, stream, images);
+}
+// ... and, when nothing is exchanged between the reverse statistics and the reverse factor stage (one GPU), svgp_gp_stats_bwd as
+// P L leading workgroups of that launch too: channel l starts when its own P row partials are there (ws.flags[8 + l])
+extern "C" int svgp_gp_stats_factor_bwd_wgrad(const svgp_mnist_cfg* c, const double* images, double* ws, const double* state,
+                                              void* stream) {
+    SVGP_REQUIRE(c && c->m <= SVGP_M_MAX, SVGP_ERR_UNSUPPORTED,
+                 "the merged reverse statistics + factor launch exists for the LDS-resident stage (m <= %d)", SVGP_M_MAX);
+    SVGP_REQUIRE(c->L <= 56, SVGP_ERR_UNSUPPORTED, "ws.flags holds 56 channel counters (L = %d)", c->L);
+    SVGP_REQUIRE(images, SVGP_ERR_INVALID, "NULL device pointer");
+    return factor_bwd_impl(c, ws, state, false, stream, images, true);
 }
 // m > 64: the two halves of svgp_gp_factor_bwd (gp_large.hip svgp_big_factor_bwd).  _early needs only forward quantities, the
 // loss seeds in `state` and (A_hat + jI)^-1: it may run on another stream, ordered after svgp_gp_factor_fwd_aji_tail, beside
@@ -1709,25 +1846,53 @@ extern "C" int svgp_gp_factor_bwd_late(const svgp_mnist_cfg* c, double* ws, cons
     return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 2);
 }
 static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* state, bool with_final, void* stream,
-                           const double* images_for_wgrad) {
+                           const double* images_for_wgrad, bool with_stats) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     if (c->m > SVGP_M_MAX) return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L);
     FactBwdArgs a = make_fb(c, wl, ws, state);
     const int m = c->m;
-    size_t lds = mat_lds_pad(m, 4) + (size_t)(6 * m) * sizeof(real);
+    size_t lds = mat_lds_pad(m, 4) + (size_t)(6 * m) * sizeof(real), lds_w = 0;
+    bool five = false;
     if (images_for_wgrad) {
         static const int n_types = [] { const char* e = getenv("SVGP_DEC_RIDER_TYPES"); return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 3; }();
         a.wg = svgp_make_dec_wgrad_args(c, wl, images_for_wgrad, ws, state, n_types);
         a.n_riders = a.wg.n_slots * a.wg.n_types;
-        const size_t lds_w = (size_t)svgp_vae::dec_wgrad_lds(SVGP_BLOCK, c->L, n_types) * sizeof(real);
+        lds_w = (size_t)svgp_vae::dec_wgrad_lds(SVGP_BLOCK, c->L, n_types) * sizeof(real);
         if (lds_w > lds) lds = lds_w;
     }
-    int rc = m == 32 ? set_dyn_lds(k_gp_factor_bwd<32>, lds) : set_dyn_lds(k_gp_factor_bwd<0>, lds);
-    if (rc) return rc;
-    const dim3 grid(c->L + a.n_riders);
-    if (m == 32) hipLaunchKernelGGL(k_gp_factor_bwd<32>, grid, dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(k_gp_factor_bwd<0>, grid, dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    if (with_stats) {
+        size_t lds_s = 0;
+        a.st = make_stat_args(c, wl, ws, state, 1, 0, &lds_s);
+        a.n_stat = a.P * c->L;
+        a.wait_n = a.P;
+        // (SVGP_STAT_FOUR=1: the four-matrix form also where five fit -- what 32 < m <= 64 runs; tests compare the two)
+        five = !c->kl_form && m * m <= 4 * SVGP_BLOCK && !getenv("SVGP_STAT_FOUR");
+        if (five) lds = mat_lds_pad(m, 5) + (size_t)(6 * m) * sizeof(real);
+        if (images_for_wgrad && lds_w > lds) lds = lds_w;
+        a.flags = reinterpret_cast<unsigned long long*>(ws + wl.flags);
+        if (lds_s > lds) lds = lds_s;
+    }
+    const dim3 grid(a.n_stat + c->L + a.n_riders);
+    int rc;
+    if (with_stats) {
+        if (five) {
+            rc = m == 32 ? set_dyn_lds(k_gp_factor_bwd<32, 2>, lds) : set_dyn_lds(k_gp_factor_bwd<0, 2>, lds);
+            if (rc) return rc;
+            if (m == 32) hipLaunchKernelGGL((k_gp_factor_bwd<32, 2>), grid, dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((k_gp_factor_bwd<0, 2>), grid, dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+        } else {
+            rc = m == 32 ? set_dyn_lds(k_gp_factor_bwd<32, 1>, lds) : set_dyn_lds(k_gp_factor_bwd<0, 1>, lds);
+            if (rc) return rc;
+            if (m == 32) hipLaunchKernelGGL((k_gp_factor_bwd<32, 1>), grid, dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+            else hipLaunchKernelGGL((k_gp_factor_bwd<0, 1>), grid, dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+        }
+    } else {
+        rc = m == 32 ? set_dyn_lds(k_gp_factor_bwd<32>, lds) : set_dyn_lds(k_gp_factor_bwd<0>, lds);
+        if (rc) return rc;
+        if (m == 32) hipLaunchKernelGGL(k_gp_factor_bwd<32>, grid, dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL(k_gp_factor_bwd<0>, grid, dim3(SVGP_BLOCK), lds, (hipStream_t)stream, a);
+    }
     SVGP_LAUNCH_CHECK();
     if (with_final) {
         hipLaunchKernelGGL(k_gp_factor_bwd_final, dim3((m * m + SVGP_BLOCK - 1) / SVGP_BLOCK), dim3(SVGP_BLOCK), 0,

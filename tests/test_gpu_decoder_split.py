@@ -187,7 +187,7 @@ def test_pass_two_of_the_reverse_row_stage_rides_in_the_encoder_reverse_launch(b
     _lib.call("svgp_mnist_encoder_bwd", cfg, th, img, ws, s)
     eng.synchronize()
     ref = {k: v.clone() for k, v in views().items()}
-    flags = eng.ws_view("flags", (16,))
+    flags = eng.ws_view("flags", (64,))
     for rep in range(3):
         for v in views().values():
             v.fill_(float("nan"))
@@ -197,3 +197,53 @@ def test_pass_two_of_the_reverse_row_stage_rides_in_the_encoder_reverse_launch(b
         assert torch.count_nonzero(flags.view(torch.int64)) == 0, (rep, flags.view(torch.int64).tolist())
         for k, v in views().items():
             assert torch.equal(v, ref[k]), (rep, k)
+
+
+@pytest.mark.parametrize("four", [False, True])
+@pytest.mark.parametrize("b,m,L", [(256, 32, 16), (48, 16, 4), (300, 24, 5), (7, 12, 3), (96, 48, 3)])
+def test_reverse_statistics_ride_in_the_reverse_factor_launch(b, m, L, four, monkeypatch):
+    """svgp_gp_stats_factor_bwd_wgrad == svgp_gp_stats_bwd + svgp_gp_factor_bwd_nofinal_wgrad, bit for bit: the P L statistics
+    workgroups at the head of the launch write the row partials of A2 / ud / td through, channel workgroup l waits for its own P
+    producers on ws.flags[8 + l] and re-arms it; every call leaves the counters zero and the error word clear.  Two forms of the
+    channel workgroup: five LDS matrices (m <= 32: Ki stays resident, the wait sits behind Kbar_l = Abar G^T) and four (32 < m <= 64
+    or SVGP_STAT_FOUR=1: the wait sits before T1 A)."""
+    from svgp_vae_amd import _lib
+    if four:
+        monkeypatch.setenv("SVGP_STAT_FOUR", "1")
+    eng, _ = _engine(b, m, L, seed=8)
+    eng.run(adam=False)
+    eng.synchronize()
+    cfg, ws, st = C.byref(eng.cfg), eng.ws.data_ptr(), eng.state.data_ptr()
+    img, s = eng._bound[0].data_ptr(), eng.stream.cuda_stream
+    P = eng.wl.statB_len // (L * (m * m + 2 * m))
+    n_dec = eng.pl.n_vae - eng.pl.n_enc
+    shapes = dict(A2=(P, L, m, m), ud=(P, L, m), td=(P, L, m), fb_part=(2, L, m, m), vbar=(L, m), Ssym=(L, m, m), Qm=(L, m, m),
+                  part_dec=(eng.wl.n_part, n_dec))
+    _lib.call("svgp_gp_stats_bwd", cfg, ws, st, s)
+    _lib.call("svgp_gp_factor_bwd_nofinal_wgrad", cfg, img, ws, st, s)
+    eng.synchronize()
+    ref = {k: eng.ws_view(k, sh).clone() for k, sh in shapes.items()}
+    flags = eng.ws_view("flags", (64,))
+    for rep in range(3):
+        for k, sh in shapes.items():
+            eng.ws_view(k, sh).fill_(float("nan"))
+        _lib.call("svgp_gp_stats_factor_bwd_wgrad", cfg, img, ws, st, s)
+        eng.synchronize()
+        assert torch.count_nonzero(flags.view(torch.int64)) == 0, (rep, flags.view(torch.int64).tolist())
+        for k, sh in shapes.items():
+            assert torch.equal(eng.ws_view(k, sh), ref[k]), (rep, k)
+
+
+def test_step_with_and_without_the_statistics_merge_is_bit_equal(monkeypatch):
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SVGP_STAT_MERGE", flag)
+        eng, _ = _engine(256, 32, 16, seed=9)
+        for _ in range(3):
+            eng.run(adam=True)
+        eng.synchronize()
+        out[flag] = ({k: v.clone() for k, v in eng.grads().items()}, eng.scalars()["elbo"], eng.theta.clone())
+    assert out["0"][1] == out["1"][1]
+    assert torch.equal(out["0"][2], out["1"][2])
+    for k, v in out["0"][0].items():
+        assert torch.equal(v, out["1"][0][k]), k

@@ -33,7 +33,7 @@ def child():
             eng.run(adam=True)
         eng.synchronize()
         best = min(best, (time.perf_counter() - t0) / reps * 1e6)
-    print(json.dumps(dict(split=os.environ.get("SVGP_DEC_SPLIT", "1"), types=os.environ.get("SVGP_DEC_RIDER_TYPES", ""), merge=os.environ.get("SVGP_ENC_KM_MERGE", ""), sum_merge=os.environ.get("SVGP_SUM_MERGE", ""), step_us=best, elbo=eng.scalars()["elbo"])), flush=True)
+    print(json.dumps(dict(split=os.environ.get("SVGP_DEC_SPLIT", "1"), types=os.environ.get("SVGP_DEC_RIDER_TYPES", ""), merge=os.environ.get("SVGP_ENC_KM_MERGE", ""), sum_merge=os.environ.get("SVGP_SUM_MERGE", ""), stat_merge=os.environ.get("SVGP_STAT_MERGE", ""), step_us=best, elbo=eng.scalars()["elbo"])), flush=True)
 
 
 def main():
@@ -107,6 +107,7 @@ def main():
             ("gp_factor_bwd_nofinal", "svgp_gp_factor_bwd_nofinal", (cfg, ws, st, s)),
             ("gp_factor_bwd_nofinal_wgrad", "svgp_gp_factor_bwd_nofinal_wgrad", (cfg, img, ws, st, s)),
             ("gp_stats_bwd", "svgp_gp_stats_bwd", (cfg, ws, st, s)),
+            ("gp_stats_factor_bwd_wgrad", "svgp_gp_stats_factor_bwd_wgrad", (cfg, img, ws, st, s)),
             ("kernel_matrix_bwd_partials", "svgp_kernel_matrix_bwd_partials", (cfg, th, eng._bound[1].data_ptr(), ws, s)),
             ("encoder_bwd", "svgp_mnist_encoder_bwd", (cfg, th, img, ws, s)),
             ("encoder_bwd_km", "svgp_mnist_encoder_bwd_km", (cfg, th, img, eng._bound[1].data_ptr(), ws, s)),
@@ -116,11 +117,11 @@ def main():
             ("grad_reduce_all", "svgp_mnist_grad_reduce_all", (cfg, eng._bound[1].data_ptr(), ws, s))]
     for name, sym, args in rows:
         print(f"{name:32s} {timeit(sym, args):7.2f} us", flush=True)
-    for flag, nty, mg, sm in (("0", "3", "0", "0"), ("1", "3", "0", "0"), ("1", "3", "1", "0"), ("1", "3", "1", "1"), ("1", "3", "1", "0"), ("1", "3", "1", "1")):
-        env = dict(os.environ, SVGP_DEC_SPLIT=flag, SVGP_DEC_RIDER_TYPES=nty, SVGP_ENC_KM_MERGE=mg, SVGP_SUM_MERGE=sm)
+    for flag, nty, mg, sm, st_ in (("0", "3", "0", "0", "0"), ("1", "3", "1", "1", "0"), ("1", "3", "1", "1", "1"), ("1", "3", "1", "1", "0"),
+                                  ("1", "3", "1", "1", "1"), ("1", "3", "1", "1", "0"), ("1", "3", "1", "1", "1")):
+        env = dict(os.environ, SVGP_DEC_SPLIT=flag, SVGP_DEC_RIDER_TYPES=nty, SVGP_ENC_KM_MERGE=mg, SVGP_SUM_MERGE=sm, SVGP_STAT_MERGE=st_)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True)
         print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:], flush=True)
-
 
 if __name__ == "__main__":
     child() if "--child" in sys.argv else main()

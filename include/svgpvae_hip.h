@@ -334,6 +334,9 @@ int svgp_mnist_encoder_bwd_km(const svgp_mnist_cfg*, const double* theta, const 
 int svgp_gp_posterior_bwd_rows(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_mnist_encoder_bwd_km_sum(const svgp_mnist_cfg*, const double* theta, const double* images, const double* aux,
                                   double* ws, const double* state, void* stream);
+/* Diagnostic: registers per lane of the (m 32, M 8) instance of that launch.  A kernel-matrix VJP workgroup and an image workgroup
+ * share a CU only while it is <= 168; the kernel carries no occupancy hint (it cost the image code 1.7 us), tests check the number. */
+int svgp_mnist_encoder_bwd_km_regs(int* out);
 /* m <= 64: svgp_gp_factor_bwd_nofinal + svgp_mnist_decoder_bwd_weights(threads = 256) in ONE launch: the L channel workgroups
  * first, then min(b, 256) rider workgroups with the decoder's weight-gradient partials (needs svgp_mnist_decoder_bwd_data before). */
 int svgp_gp_factor_bwd_nofinal_wgrad(const svgp_mnist_cfg*, const double* images, double* ws, const double* state,

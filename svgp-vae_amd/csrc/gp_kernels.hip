@@ -1329,12 +1329,18 @@ __device__ __forceinline__ void posterior_bwd_sum_block(const PostBwdArgs& a, in
     mat_load_nt(R0, ld, a.Ki, m, nthr);
     if (act) kr[nl * m + i] = a.Kn[(size_t)n * m + i];
     const real gT = grad_KL_term(a.geco, a.L, a.state);
+    // qbar_n = sum_l [g3 / (2 s2_nl) - g_pv_nl]: the L terms of a row are loaded by L of its m threads at once (one thread walking
+    // them was a chain of L dependent L2 round trips: ~6 us of this 3 us block), then added in channel order by the row's first thread
+    real* qt = qb + RB;         // RB x L terms
+    if (act)
+        for (int l = i; l < a.L; l += m) {
+            const size_t e = (size_t)n * a.L + l;
+            qt[nl * a.L + l] = real(0.5) * svgp_seed_3(a.geco, gT) * recip_no_nan(a.s2[e]) - a.g_pv[e];
+        }
+    __syncthreads();
     if (act && i == 0) {
         real qbar = 0;
-        for (int l = 0; l < a.L; ++l) {
-            const size_t e = (size_t)n * a.L + l;
-            qbar += real(0.5) * svgp_seed_3(a.geco, gT) * recip_no_nan(a.s2[e]) - a.g_pv[e];
-        }
+        for (int l = 0; l < a.L; ++l) qbar += qt[nl * a.L + l];
         qb[nl] = qbar;
         st_co<COH>(a.knnbar + n, -qbar);
     }
@@ -1366,8 +1372,11 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_posterior_bwd_sum(PostBwdArgs
 // read the payload past their XCD's L2 (sc1 loads, ld_co); the last of them through the gate resets both counters.  Workgroup ids are dealt to the XCDs round-robin and dispatched in order per XCD, and all n_sum + n_km + n_img
 // workgroups fit the chip at once (two per CU), so a waiting VJP workgroup never holds a slot a producer needs.  The image
 // workgroups (the longest of the launch) do not wait: the sum -> VJP chain (~10 us) hides under them.
+// (No occupancy hint in the launch bounds: the cfg-2 instance allocates 161 VGPRs <= 168 on its own, and `__launch_bounds__(VAE_NT, 3)`
+// made the scheduler trade the image code's instruction-level parallelism for registers it did not need: 17.8 against 16.1 us for the
+// 256 image workgroups alone, 21.6 against 19.9 us for this launch.)
 template <int MC, int MM, bool SUM>
-__global__ __launch_bounds__(VAE_NT, MC ? 3 : 2) void k_encoder_bwd_km(svgp_vae::EncBwdArgs e, int n_km, KernArgs a, real rep_weight,
+__global__ __launch_bounds__(VAE_NT) void k_encoder_bwd_km(svgp_vae::EncBwdArgs e, int n_km, KernArgs a, real rep_weight,
                                                                  int train_ip, const real* __restrict__ K,
                                                                  const real* __restrict__ Kn, const real* Kbar,
                                                                  const real* Knbar, const real* knnbar,
@@ -1377,6 +1386,13 @@ __global__ __launch_bounds__(VAE_NT, MC ? 3 : 2) void k_encoder_bwd_km(svgp_vae:
                                                                  unsigned long long* __restrict__ flags) {
     extern __shared__ __align__(16) real smem[];
     int bid = (int)blockIdx.x;
+    {
+        const int n_front = n_km + (SUM ? n_sum : 0);
+        if (bid >= n_front) {
+            svgp_vae::encoder_bwd_images<VAE_NT>(e, bid - n_front, (int)gridDim.x - n_front, smem);
+            return;
+        }
+    }
     if (SUM) {
         if (bid < n_sum) {
             if (threadIdx.x >= SVGP_BLOCK) return;
@@ -1413,7 +1429,6 @@ __global__ __launch_bounds__(VAE_NT, MC ? 3 : 2) void k_encoder_bwd_km(svgp_vae:
         else km_bwd_rows<MC, MM, SVGP_BLOCK, SUM>(bid - m, a, Knbar, knnbar, knn, d_on, part_gp);
         return;
     }
-    svgp_vae::encoder_bwd_images<VAE_NT>(e, bid - n_km, (int)gridDim.x - n_km - (SUM ? n_sum : 0), smem);
 }
 
 template <typename F>
@@ -1539,7 +1554,7 @@ static int encoder_bwd_km_impl(const svgp_mnist_cfg* c, const double* theta, con
     if (with_sum) {
         pb = make_pb(c, wl, ws, state, true);
         n_sum = pb.nb_rows + pb.n_final;
-        const size_t lds2 = mat_lds(c->m, 1) + (size_t)(SVGP_BLOCK + SVGP_BLOCK) * sizeof(real);
+        const size_t lds2 = mat_lds(c->m, 1) + (size_t)(SVGP_BLOCK + (SVGP_BLOCK / c->m) * (1 + c->L)) * sizeof(real);
         if (lds2 > lds) lds = lds2;
     }
     const bool cfg2_shape = c->m == 32 && c->M == 8;
@@ -1556,6 +1571,15 @@ static int encoder_bwd_km_impl(const svgp_mnist_cfg* c, const double* theta, con
     else hipLaunchKernelGGL((k_encoder_bwd_km<0, 0, false>), grid, dim3(VAE_NT), lds, (hipStream_t)stream, KM_BWD_ARGS);
 #undef KM_BWD_ARGS
     SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+// Registers per lane of the config-2 instance of the merged launch (hipFuncGetAttributes): a VJP workgroup and an image workgroup
+// share a CU only while it is <= 168 (three waves per SIMD); tests assert that, since no launch-bounds hint enforces it.
+extern "C" int svgp_mnist_encoder_bwd_km_regs(int* out) {
+    SVGP_REQUIRE(out, SVGP_ERR_INVALID, "out is NULL");
+    hipFuncAttributes fa;
+    SVGP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_encoder_bwd_km<32, 8, true>)));
+    *out = fa.numRegs;
     return SVGP_OK;
 }
 extern "C" int svgp_mnist_encoder_bwd_km(const svgp_mnist_cfg* c, const double* theta, const double* images, const double* aux,
@@ -1934,7 +1958,7 @@ static int posterior_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double*
     const size_t lds = mat_lds(m, 3) + (size_t)(3 * m + SVGP_BLOCK + 2 * SVGP_BLOCK) * sizeof(real);
     LAUNCH_MC(k_gp_posterior_bwd_l, m, dim3(nb, c->L), lds, stream, a);
     if (pass == 1) return SVGP_OK;
-    const size_t lds2 = mat_lds(m, 1) + (size_t)(SVGP_BLOCK + SVGP_BLOCK) * sizeof(real);
+    const size_t lds2 = mat_lds(m, 1) + (size_t)(SVGP_BLOCK + (SVGP_BLOCK / m) * (1 + c->L)) * sizeof(real);
     LAUNCH_MC(k_gp_posterior_bwd_sum, m, dim3(nb + a.n_final), lds2, stream, a);
     return SVGP_OK;
 }

@@ -247,3 +247,12 @@ def test_step_with_and_without_the_statistics_merge_is_bit_equal(monkeypatch):
     assert torch.equal(out["0"][2], out["1"][2])
     for k, v in out["0"][0].items():
         assert torch.equal(v, out["1"][0][k]), k
+
+
+def test_merged_encoder_reverse_launch_keeps_two_workgroups_per_cu():
+    """No launch-bounds occupancy hint on k_encoder_bwd_km (it slowed the image code by 1.7 us): the config-2 instance must stay at
+    <= 168 registers per lane on its own, or a kernel-matrix VJP workgroup and an image workgroup no longer share a CU."""
+    from svgp_vae_amd import _lib
+    n = C.c_int(0)
+    _lib.call("svgp_mnist_encoder_bwd_km_regs", C.byref(n))
+    assert 0 < n.value <= 168, n.value

@@ -230,34 +230,41 @@ def stage_table(eng, B, M_IND):
          (Lc * (2 * (m ** 3 / 3 + 2 * m ** 3 / 3) + 4 * 2 * m ** 3) + 2 * b * m * m), f8 * Lc * (5 if m > 64 else 7) * m * m, 0.0),
     ] + ([("gp_factor_fwd_aji_tail (side stream in the step)", "svgp_gp_factor_fwd_aji_tail", (cfg, ws, s), Lc * 2 * m ** 3,
            f8 * Lc * 2 * m * m, 0.0)] if m > 64 else []) + [
-        ("gp_posterior_fwd", "svgp_gp_posterior_fwd_with_aji", (cfg, eps, ws, st, s), 4 * Lc * b * m * m,
-         f8 * (Lc * 2 * m * m + b * m + 8 * b * Lc), 0.0),
+        # m <= 32 (round 6): without the deferred (A_hat + jI)^-1, which rides in the decoder's data-reverse launch below
+        ("gp_posterior_fwd", "svgp_gp_posterior_fwd" if m <= 32 else "svgp_gp_posterior_fwd_with_aji", (cfg, eps, ws, st, s),
+         4 * Lc * b * m * m, f8 * (Lc * 2 * m * m + b * m + 8 * b * Lc), 0.0),
         ("decoder_fwd", "svgp_mnist_decoder_fwd_pre" if m <= 64 else "svgp_mnist_decoder_fwd", (cfg, th, img, ws, s), 2 * dec_mac * b,
          f8 * (b * (Lc + act_dec + 2 * 784) + n_dec), 0.0),
         # m <= 64 (round 6): the data half alone (the chain to zbar; it also stores the pre-activation gradients d2, d1, dh0 for the
         # weight half, which rides in the reverse factor launch below); m > 64: the one-kernel form
-    ] + ([("decoder_bwd_data", "svgp_mnist_decoder_bwd_data_pre", (cfg, th, img, ws, st, s), 2 * dec_mac * b,
-           f8 * (b * (512 + 1568 + 2 * 784 + Lc) + n_dec), f8 * b * (1568 + 512 + 128))] if m <= 64 else
+    ] + ([("decoder_bwd_data", "svgp_mnist_decoder_bwd_data_pre_aji" if m <= 32 else "svgp_mnist_decoder_bwd_data_pre",
+           (cfg, th, img, ws, st, s), 2 * dec_mac * b + (Lc * 2 * m ** 3 if m <= 32 else 0),
+           f8 * (b * (512 + 1568 + 2 * 784 + Lc) + n_dec + (2 * Lc * m * m if m <= 32 else 0)), f8 * b * (1568 + 512 + 128))]
+         if m <= 64 else
          [("decoder_bwd", "svgp_mnist_decoder_bwd", (cfg, th, img, ws, st, s), 4 * dec_mac * b,
            f8 * (b * (Lc + act_dec + 2 * 784 + Lc) + 2 * n_dec), f8 * n_part * n_dec)]) + [
         # m > 64: + the rank-local row terms [Qs; Pbar^T] = X^T Kn and (all rows local, b < 3 m) the statistic SW = W^T diag(p) W
-        ("gp_stats_bwd", "svgp_gp_stats_bwd", (cfg, ws, st, s),
-         3 * Lc * b * m * m + ((4 * b * m * m + (Lc * b * m * m if b < 3 * m else 0)) if m > 64 else 0),
-         f8 * (b * m + 9 * b * Lc + Lc * m * (m + 2)), 0.0),
-    ] + ([  # early: H = G (Ki - Aji), H G^T (+ SW = P^T S P when it is not formed over the rows); late: Si X, (Si X) Si + single matrices
+    ] + ([("gp_stats_bwd", "svgp_gp_stats_bwd", (cfg, ws, st, s),
+           3 * Lc * b * m * m + 4 * b * m * m + (Lc * b * m * m if b < 3 * m else 0),
+           f8 * (b * m + 9 * b * Lc + Lc * m * (m + 2)), 0.0)] if m > 64 else []) + ([  # early: H = G (Ki - Aji), H G^T (+ SW = P^T S P when it is not formed over the rows); late: Si X, (Si X) Si + single matrices
           ("gp_factor_bwd_early (side stream in the step)", "svgp_gp_factor_bwd_early", (cfg, ws, st, s),
            Lc * (2 * m ** 3 + m ** 3 + (0 if b < 3 * m else 3 * m ** 3)), f8 * Lc * 6 * m * m, 0.0),
           ("gp_factor_bwd", "svgp_gp_factor_bwd_late", (cfg, ws, st, s), Lc * 2 * 2 * m ** 3 + 4 * 2 * m ** 3, f8 * Lc * 8 * m * m, 0.0)]
          if m > 64 else
-         # + the decoder's weight gradients as rider workgroups of the same launch (3 per image)
-         [("gp_factor_bwd", "svgp_gp_factor_bwd_nofinal_wgrad", (cfg, img, ws, st, s), Lc * 9 * 2 * m ** 3 + 2 * dec_mac * b,
-           f8 * (Lc * 14 * m * m + b * (Lc + act_dec + 2 * 784) + n_dec), f8 * (n_part * n_dec + b * (1568 + 512 + 128)))]) + [
+         # ONE launch (single-GPU step, round 6): the reverse statistics (P L workgroups at the head; channel l waits for its own P) +
+         # the reverse factor stage + the decoder's weight gradients as rider workgroups (3 per image)
+         [("gp_stats_factor_bwd", "svgp_gp_stats_factor_bwd_wgrad", (cfg, img, ws, st, s),
+           3 * Lc * b * m * m + Lc * 9 * 2 * m ** 3 + 2 * dec_mac * b,
+           f8 * (b * m + 9 * b * Lc + Lc * m * (m + 2) + Lc * 14 * m * m + b * (Lc + act_dec + 2 * 784) + n_dec),
+           f8 * (n_part * n_dec + b * (1568 + 512 + 128)))]) + [
         # m > 64: ONE (b, m, m) product per channel (Kn Ssym; Kn Si is the forward pass's) + Wbar P^T; m <= 64: three
-        ("gp_posterior_bwd", "svgp_gp_posterior_bwd_with_final", (cfg, ws, st, s),
+        # m <= 64 (round 6): pass 1 alone (the per-channel row terms); pass 2 (the sums over channels) rides in the next launch
+        ("gp_posterior_bwd", "svgp_gp_posterior_bwd_with_final" if m > 64 else "svgp_gp_posterior_bwd_rows", (cfg, ws, st, s),
          (2 * Lc * b * m * m + 2 * b * m * m) if m > 64 else 6 * Lc * b * m * m,
          f8 * (Lc * 3 * m * m + 2 * Lc * b * m + 12 * b * Lc), 0.0),
-    ] + ([  # m <= 64 (round 6): the kernel-matrix VJP workgroups ride FIRST in the encoder's reverse launch
-        ("encoder_bwd_km", "svgp_mnist_encoder_bwd_km", (cfg, th, img, aux, ws, s),
+    ] + ([  # m <= 64 (round 6): pass 2 of the reverse row stage, then the kernel-matrix VJP workgroups (waiting for it), ride FIRST in
+            # the encoder's reverse launch
+        ("encoder_bwd_km", "svgp_mnist_encoder_bwd_km_sum", (cfg, th, img, aux, ws, st, s),
          4 * enc_mac * b + (2 * b * m + 2 * m * m) * (2 * D + 20),
          f8 * (b * (784 + act_enc + 3 * Lc) + 2 * n_enc + 2 * b * m + 2 * m * m + b * (D + 1) + N_OBJ * (D - 1)), f8 * n_part * n_enc)]
          if m <= 64 else [
@@ -574,7 +581,10 @@ def mnist_case(args, scaling, multi, dev, ctx, strict=True):
         if scaling == "strong" and elbo_rel is not None:
             line["elbo_within_1e-8_of_oracle"] = bool(elbo_rel < 1e-8)
         top = stage_rows[0]
-        traffic, src = committed_traffic("k_" + top["stage"]) if not cfg3 else (None, None)
+        # stage -> the kernel name rocprofv3 reports for it, where the two differ
+        kname = {"gp_stats_factor_bwd": "k_gp_factor_bwd", "decoder_bwd_data": "k_decoder_bwd_data_aji" if M_IND <= 32 else
+                 "k_decoder_bwd_data"}.get(top["stage"], "k_" + top["stage"])
+        traffic, src = committed_traffic(kname) if not cfg3 else (None, None)
         roof = roofline_of(top["flops"], top["bytes"], top["us"], F64_PEAK_TFLOPS, kernel=top["stage"],
                            implementation_partials_bytes=top["partials_bytes"],
                            note="config 2 is latency-bound (DESIGN.md section 5); " * (not cfg3) +

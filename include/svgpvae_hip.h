@@ -337,6 +337,14 @@ int svgp_mnist_encoder_bwd_km_sum(const svgp_mnist_cfg*, const double* theta, co
 /* Diagnostic: registers per lane of the (m 32, M 8) instance of that launch.  A kernel-matrix VJP workgroup and an image workgroup
  * share a CU only while it is <= 168; the kernel carries no occupancy hint (it cost the image code 1.7 us), tests check the number. */
 int svgp_mnist_encoder_bwd_km_regs(int* out);
+/* m <= 32, training step (round 6): svgp_mnist_decoder_bwd_data_pre + the deferred tail of the forward factor stage -- Aji = (A_hat +
+ * jitter I)^-1 and the log det term of KL (SVGPVAE_model.py:271-279), left open by svgp_gp_factor_fwd_defer_aji -- as L rider
+ * workgroups at the head of the same launch.  The forward row stage then runs as svgp_gp_posterior_fwd (7.8 us instead of the 10.1 us
+ * of svgp_gp_posterior_fwd_with_aji, whose riders bounded it).  Same bits.  _regs: registers per lane of that kernel (<= 168 keeps a
+ * rider and an image workgroup on one CU). */
+int svgp_mnist_decoder_bwd_data_pre_aji(const svgp_mnist_cfg*, const double* theta, const double* images, double* ws,
+                                        const double* state, void* stream);
+int svgp_mnist_decoder_bwd_data_aji_regs(int* out);
 /* m <= 64: svgp_gp_factor_bwd_nofinal + svgp_mnist_decoder_bwd_weights(threads = 256) in ONE launch: the L channel workgroups
  * first, then min(b, 256) rider workgroups with the decoder's weight-gradient partials (needs svgp_mnist_decoder_bwd_data before). */
 int svgp_gp_factor_bwd_nofinal_wgrad(const svgp_mnist_cfg*, const double* images, double* ws, const double* state,

@@ -117,6 +117,8 @@ SIGNATURES = {
     "svgp_mnist_encoder_bwd_km": [_CFG, _P, _P, _P, _P, _P],
     "svgp_mnist_encoder_bwd_km_sum": [_CFG, _P, _P, _P, _P, _P, _P],
     "svgp_mnist_encoder_bwd_km_regs": [C.POINTER(C.c_int)],
+    "svgp_mnist_decoder_bwd_data_pre_aji": [_CFG, _P, _P, _P, _P, _P],
+    "svgp_mnist_decoder_bwd_data_aji_regs": [C.POINTER(C.c_int)],
     "svgp_gp_posterior_bwd_rows": [_CFG, _P, _P, _P],
     "svgp_mnist_grad_reduce_part": [_CFG, _P, _P, C.c_int, _P],
     "svgp_gp_posterior_bwd_with_final": [_CFG, _P, _P, _P],

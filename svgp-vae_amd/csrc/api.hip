@@ -312,6 +312,12 @@ bool stat_merge_on() {
     const char* e = getenv("SVGP_STAT_MERGE");
     return !(e && e[0] == '0');
 }
+// m <= 32 (round 6): the deferred (A_hat + jI)^-1 rides in the decoder's data-reverse launch instead of the forward row-stage launch
+// (svgp_mnist_decoder_bwd_data_pre_aji).  SVGP_AJI_DEC=0: svgp_gp_posterior_fwd_with_aji.
+bool aji_dec_on() {
+    const char* e = getenv("SVGP_AJI_DEC");
+    return !(e && e[0] == '0');
+}
 bool konly_on() {      // (read per call: tests compare the two orders in one process)
     const char* e = getenv("SVGP_KONLY_BRANCH");
     return !(e && e[0] == '0');
@@ -350,6 +356,7 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
 #define RUN(call) do { rc = (call); if (rc) return rc; } while (0)
     const bool ksplit = phase == 0 && fork1 && defer && c->m < SVGP_CHOL_INVERSE_MIN_M && konly_on();
     const bool sum_rides = phase == 2 && !large && !fork2 && !c->titsias && enc_km_merge_on() && sum_merge_on();
+    const bool aji_in_dec = phase == 1 && c->m <= 32 && !c->titsias && dec_split_on() && aji_dec_on();
     const bool stat_rides = defer == 2 && !large && !c->titsias && c->L <= 56 && dec_split_on() && stat_merge_on();
     switch (phase) {
     case 0:
@@ -382,7 +389,8 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         // launches take the host ~100 us to enqueue, during which the caller's stream had nothing to run (config 3, kernel trace of
         // round 4: a 101 us hole in front of the row stage's product) -- the branch has that much slack, the caller's stream none.
         if (c->m > SVGP_M_MAX && fork1) RUN(side_fork(sd, 1, ms));
-        RUN(svgp_gp_posterior_fwd_with_aji(c, eps, ws, state, stream));
+        if (aji_in_dec) RUN(svgp_gp_posterior_fwd(c, eps, ws, state, stream));
+        else RUN(svgp_gp_posterior_fwd_with_aji(c, eps, ws, state, stream));
         if (c->m > SVGP_M_MAX) {
             RUN(svgp_gp_factor_fwd_aji_tail(c, ws, fork1 ? (void*)sd->s[1] : stream));
             if (fork1) {
@@ -394,7 +402,8 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         // m <= 64 with the split on: the `_pre` forms read the effective up-convolution weights phase 0 of this step left in ws.dec_weff
         if (!large && dec_split_on()) {
             RUN(svgp_mnist_decoder_fwd_pre(c, theta, images, ws, stream));
-            RUN(svgp_mnist_decoder_bwd_data_pre(c, theta, images, ws, state, stream));
+            if (aji_in_dec) RUN(svgp_mnist_decoder_bwd_data_pre_aji(c, theta, images, ws, state, stream));
+            else RUN(svgp_mnist_decoder_bwd_data_pre(c, theta, images, ws, state, stream));
         } else {
             RUN(svgp_mnist_decoder_fwd(c, theta, images, ws, stream));
             RUN(svgp_mnist_decoder_bwd(c, theta, images, ws, state, stream));

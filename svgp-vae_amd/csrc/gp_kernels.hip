@@ -1389,6 +1389,8 @@ __global__ __launch_bounds__(VAE_NT) void k_encoder_bwd_km(svgp_vae::EncBwdArgs 
     {
         const int n_front = n_km + (SUM ? n_sum : 0);
         if (bid >= n_front) {
+            // (image waves before the VJP / sum waves sharing their SIMDs: 20.1 -> 19.8 us; the other way round: no gain)
+            __builtin_amdgcn_s_setprio(3);
             svgp_vae::encoder_bwd_images<VAE_NT>(e, bid - n_front, (int)gridDim.x - n_front, smem);
             return;
         }
@@ -1429,6 +1431,38 @@ __global__ __launch_bounds__(VAE_NT) void k_encoder_bwd_km(svgp_vae::EncBwdArgs 
         else km_bwd_rows<MC, MM, SVGP_BLOCK, SUM>(bid - m, a, Knbar, knnbar, knn, d_on, part_gp);
         return;
     }
+}
+
+// Training step, m <= 32 (round 6): the deferred tail of the forward factor stage -- Aji = (A_hat + jitter I)^-1 and the log det term of
+// KL (SVGPVAE_model.py:271-279), needed by the reverse factor stage and the KL scalar only -- as L rider workgroups at the HEAD of the
+// decoder's data-reverse launch (first SVGP_BLOCK threads; the single-wave sweep of sweep32.hpp).  In the forward row-stage launch,
+// where it rode before, the 4.4 us sweep + its loads bounded the launch: 10.1 us against 7.8 without it.  74 KB of LDS and <= 128
+// VGPRs let a rider and an image workgroup share a CU, so the 256 image workgroups still start at once.
+struct AjiArgs {
+    int m, L;
+    real jitter;
+    const real* Ahat; real* Aji; real* KL;
+};
+__global__ __launch_bounds__(VAE_NT) void k_decoder_bwd_data_aji(svgp_vae::DecBwdDataArgs d, AjiArgs a) {
+    extern __shared__ __align__(16) real smem[];
+    const int l = blockIdx.x;
+    if (l < a.L) {
+        if (threadIdx.x >= SVGP_BLOCK) return;
+        const int m = a.m, ld = m + 1;
+        real* A = smem;
+        real* W = A + m * ld;
+        mat_load_nt(A, ld, a.Ahat + (size_t)l * m * m, m, SVGP_BLOCK);
+        __syncthreads();
+        if ((int)threadIdx.x < m) A[threadIdx.x * ld + threadIdx.x] += a.jitter;
+        const real ldA = chol_inv(A, W, ld, m);                 // m <= 32: wave 0 alone, any number of live waves
+        for (int o = threadIdx.x; o < m * m; o += SVGP_BLOCK) a.Aji[(size_t)l * m * m + o] = A[(o / m) * ld + (o % m)];
+        if (threadIdx.x == 0) a.KL[l] -= real(0.5) * ldA;
+        return;
+    }
+    // the image waves before a rider's sweep wave on the same SIMD: without it the 16 image workgroups that share a CU with a rider
+    // finish 2 us late (16.8 against 14.7 us for the launch; 14.5 without riders)
+    __builtin_amdgcn_s_setprio(3);
+    svgp_vae::decoder_bwd_data_images<true>(d, l - a.L, (int)gridDim.x - a.L, smem);
 }
 
 template <typename F>
@@ -1571,6 +1605,32 @@ static int encoder_bwd_km_impl(const svgp_mnist_cfg* c, const double* theta, con
     else hipLaunchKernelGGL((k_encoder_bwd_km<0, 0, false>), grid, dim3(VAE_NT), lds, (hipStream_t)stream, KM_BWD_ARGS);
 #undef KM_BWD_ARGS
     SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+// svgp_mnist_decoder_bwd_data_pre + the deferred (A_hat + jI)^-1 of svgp_gp_factor_fwd_defer_aji in one launch (m <= 32); the forward row
+// stage then runs WITHOUT its riders (svgp_gp_posterior_fwd).  Same bits as svgp_gp_posterior_fwd_with_aji + svgp_mnist_decoder_bwd_data_pre.
+extern "C" int svgp_mnist_decoder_bwd_data_pre_aji(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
+                                                   const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(theta && images && ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m <= 32, SVGP_ERR_UNSUPPORTED, "the rider inverse is the single-wave sweep (m <= 32), m = %d", c->m);
+    const svgp_vae::DecBwdDataArgs d = svgp_make_dec_bwd_data_args(c, wl, theta, images, ws, state);
+    AjiArgs a;
+    a.m = c->m; a.L = c->L; a.jitter = c->jitter; a.Ahat = ws + wl.A; a.Aji = ws + wl.Aji; a.KL = ws + wl.KL;
+    size_t lds = (size_t)svgp_vae::dec_bwd_data_lds(c->L, (int)(pl.n_vae - pl.n_enc), true) * sizeof(real);
+    const size_t lds_inv = mat_lds(c->m, 1) + (size_t)(5 * c->m + 80) * sizeof(real);
+    if (lds_inv > lds) lds = lds_inv;
+    int rc = set_dyn_lds(k_decoder_bwd_data_aji, lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_decoder_bwd_data_aji, dim3(a.L + svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, d, a);
+    SVGP_LAUNCH_CHECK();
+    return SVGP_OK;
+}
+extern "C" int svgp_mnist_decoder_bwd_data_aji_regs(int* out) {
+    SVGP_REQUIRE(out, SVGP_ERR_INVALID, "out is NULL");
+    hipFuncAttributes fa;
+    SVGP_CHECK_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(k_decoder_bwd_data_aji)));
+    *out = fa.numRegs;
     return SVGP_OK;
 }
 // Registers per lane of the config-2 instance of the merged launch (hipFuncGetAttributes): a VJP workgroup and an image workgroup

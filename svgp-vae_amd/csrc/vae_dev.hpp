@@ -605,6 +605,91 @@ __device__ __forceinline__ void decoder_wgrad_rider(const DecWgradArgs& a, int r
 }
 
 // ------------------------------------------------------------------------------------------
+// decoder reverse, DATA half: d loss / d recon -> d2, d1, dh0 (stored for the weight half) -> zbar.  The chain the GP
+// reverse stages wait for; the weight gradients (decoder_wgrad_rider above) ride in a later launch.  One workgroup of VAE_NT
+// threads walks images first, first + stride, ...  PRE: the effective up-convolution weights come from ws.dec_weff (74 KB of
+// LDS: two workgroups per CU -- the launch that also carries the deferred (A_hat + jI)^-1, svgp_mnist_decoder_bwd_data_pre_aji,
+// relies on that); otherwise they are rebuilt from the raw weights (84 KB).
+// Reference semantics: tf.gradients of VAE_utils.py:128-141,154-162 (MNIST_experiment.py:202-205).
+// ------------------------------------------------------------------------------------------
+struct DecBwdDataArgs {
+    int b, L, geco;
+    real inv_bglobal;
+    const real* state; const real* th_dec; const real* images; const real* a1g; const real* a2g; const real* recon;
+    real* d2g; real* d1g; real* dh0g; real* zbar;
+    const real* weff;
+};
+__host__ __device__ constexpr int dec_bwd_data_lds(int L, int n_dec, bool pre) {
+    return L * 128 + DEC_NWE + 512 + 1568 + 784 + 1568 + 512 + 128 + (pre ? 0 : n_dec - L * 128 - 128);
+}
+template <bool PRE>
+__device__ __forceinline__ void decoder_bwd_data_images(const DecBwdDataArgs& a, int first, int stride, real* smem) {
+    const DecOff od = dec_off(a.L);
+    real* w = smem;                  // dense weights only: L*128
+    real* We1 = w + a.L * 128;         // effective weights
+    real* We2 = We1 + UpC1::NWE;
+    real* We3 = We2 + UpC2::NWE;
+    real* a1 = We3 + UpC3::NWE;      // 512
+    real* a2 = a1 + 512;             // 1568
+    real* d3 = a2 + 1568;            // 784
+    real* d2 = d3 + 784;             // 1568
+    real* d1 = d2 + 1568;            // 512
+    real* dh0 = d1 + 512;            // 128
+    real* raw = dh0 + 128;           // raw conv weights (+ biases), staged once: od.n - od.c1w
+    lds_copy_in(w, a.th_dec + od.dw, a.L * 128);
+    if (PRE) {
+        lds_copy_in(We1, a.weff, DEC_NWE);
+    } else {
+        lds_copy_in(raw, a.th_dec + od.c1w, od.n - od.c1w);
+        __syncthreads();
+        UpC1::build_weff(raw, We1);
+        UpC2::build_weff(raw + (od.c2w - od.c1w), We2);
+        UpC3::build_weff(raw + (od.c3w - od.c1w), We3);
+    }
+    const real gscale = (a.geco ? a.state[SVGP_ST_LAGRANGE] * a.inv_bglobal : real(1)) / real(784);
+    for (int n = first; n < a.b; n += stride) {
+        __syncthreads();
+        lds_copy_in(a1, a.a1g + (size_t)n * 512, 512);
+        lds_copy_in(a2, a.a2g + (size_t)n * 1568, 1568);
+        for (int i = threadIdx.x; i < 784; i += blockDim.x) {
+            const real o = a.recon[(size_t)n * 784 + i];
+            d3[i] = real(2) * gscale * (o - a.images[(size_t)n * 784 + i]) * elu_grad_from_out(o);
+        }
+        __syncthreads();
+        UpC3::bwd_data_valu(d3, We3, d2);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 1568; i += blockDim.x) {
+            const real v = d2[i] * elu_grad_from_out(a2[i]);
+            d2[i] = v;
+            a.d2g[(size_t)n * 1568 + i] = v;
+        }
+        __syncthreads();
+        UpC2::bwd_data_mfma(d2, We2, d1);
+        __syncthreads();
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) {
+            const real v = d1[i] * elu_grad_from_out(a1[i]);
+            d1[i] = v;
+            a.d1g[(size_t)n * 512 + i] = v;
+        }
+        __syncthreads();
+        UpC1::bwd_data_mfma(d1, We1, dh0);
+        __syncthreads();
+        if (threadIdx.x < 128) a.dh0g[(size_t)n * 128 + threadIdx.x] = dh0[threadIdx.x];
+        // zbar[i] = sum_j dh0[j] w[i][j]: 8 lanes per latent channel, xor-shuffle combine
+        {
+            const int i = threadIdx.x >> 3, part8 = threadIdx.x & 7;
+            real acc = 0;
+            if (i < a.L)
+                for (int j = part8; j < 128; j += 8) acc += dh0[j] * w[i * 128 + j];
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            acc += __shfl_xor(acc, 4, 64);
+            if (i < a.L && part8 == 0) a.zbar[(size_t)n * a.L + i] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // encoder reverse: (ybar, s2bar) -> encoder weight-gradient partials; one workgroup of NT threads walks images first,
 // first + stride, ...; partial slot = first.  LDS: enc_bwd_lds(n_enc) reals (75 KB at L = 16: the launch that carries the
 // kernel-matrix VJP as well, svgp_mnist_encoder_bwd_km, holds a VJP workgroup and an image workgroup on one CU).
@@ -691,5 +776,7 @@ __device__ __forceinline__ void encoder_bwd_images(const EncBwdArgs& a, int firs
 // vae_mnist.hip: the weight half's arguments from a configuration + workspace (riders of the reverse factor launch, gp_kernels.hip)
 svgp_vae::DecWgradArgs svgp_make_dec_wgrad_args(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, const double* images,
                                                 double* ws, const double* state, int n_types);
+svgp_vae::DecBwdDataArgs svgp_make_dec_bwd_data_args(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, const double* theta,
+                                                     const double* images, double* ws, const double* state);
 svgp_vae::EncBwdArgs svgp_make_enc_bwd_args(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, const double* theta,
                                             const double* images, double* ws);

@@ -245,78 +245,9 @@ __global__ __launch_bounds__(VAE_NT) void k_decoder_bwd(int b, int L, int geco, 
 // reverse stages wait for; the weight gradients (decoder_wgrad_rider, vae_dev.hpp) ride in a later launch.
 // ------------------------------------------------------------------------------------------
 template <bool PRE>
-__global__ __launch_bounds__(VAE_NT) void k_decoder_bwd_data(int b, int L, int geco, real inv_bglobal,
-                                                                 const real* __restrict__ state,
-                                                                 const real* __restrict__ th_dec,
-                                                                 const real* __restrict__ images,
-                                                                 const real* __restrict__ a1g, const real* __restrict__ a2g,
-                                                                 const real* __restrict__ recon, real* __restrict__ d2g,
-                                                                 real* __restrict__ d1g, real* __restrict__ dh0g,
-                                                                 real* __restrict__ zbar, const real* __restrict__ weff) {
+__global__ __launch_bounds__(VAE_NT) void k_decoder_bwd_data(DecBwdDataArgs a) {
     extern __shared__ __align__(16) real smem[];
-    const DecOff od = dec_off(L);
-    real* w = smem;                  // dense weights only: L*128
-    real* We1 = w + L * 128;         // effective weights
-    real* We2 = We1 + UpC1::NWE;
-    real* We3 = We2 + UpC2::NWE;
-    real* a1 = We3 + UpC3::NWE;      // 512
-    real* a2 = a1 + 512;             // 1568
-    real* d3 = a2 + 1568;            // 784
-    real* d2 = d3 + 784;             // 1568
-    real* d1 = d2 + 1568;            // 512
-    real* dh0 = d1 + 512;            // 128
-    real* raw = dh0 + 128;           // raw conv weights (+ biases), staged once: od.n - od.c1w
-    lds_copy_in(w, th_dec + od.dw, L * 128);
-    if (PRE) {
-        lds_copy_in(We1, weff, DEC_NWE);
-    } else {
-        lds_copy_in(raw, th_dec + od.c1w, od.n - od.c1w);
-        __syncthreads();
-        UpC1::build_weff(raw, We1);
-        UpC2::build_weff(raw + (od.c2w - od.c1w), We2);
-        UpC3::build_weff(raw + (od.c3w - od.c1w), We3);
-    }
-    const real gscale = (geco ? state[SVGP_ST_LAGRANGE] * inv_bglobal : real(1)) / real(784);
-    for (int n = blockIdx.x; n < b; n += gridDim.x) {
-        __syncthreads();
-        lds_copy_in(a1, a1g + (size_t)n * 512, 512);
-        lds_copy_in(a2, a2g + (size_t)n * 1568, 1568);
-        for (int i = threadIdx.x; i < 784; i += blockDim.x) {
-            const real o = recon[(size_t)n * 784 + i];
-            d3[i] = real(2) * gscale * (o - images[(size_t)n * 784 + i]) * elu_grad_from_out(o);
-        }
-        __syncthreads();
-        UpC3::bwd_data_valu(d3, We3, d2);
-        __syncthreads();
-        for (int i = threadIdx.x; i < 1568; i += blockDim.x) {
-            const real v = d2[i] * elu_grad_from_out(a2[i]);
-            d2[i] = v;
-            d2g[(size_t)n * 1568 + i] = v;
-        }
-        __syncthreads();
-        UpC2::bwd_data_mfma(d2, We2, d1);
-        __syncthreads();
-        for (int i = threadIdx.x; i < 512; i += blockDim.x) {
-            const real v = d1[i] * elu_grad_from_out(a1[i]);
-            d1[i] = v;
-            d1g[(size_t)n * 512 + i] = v;
-        }
-        __syncthreads();
-        UpC1::bwd_data_mfma(d1, We1, dh0);
-        __syncthreads();
-        if (threadIdx.x < 128) dh0g[(size_t)n * 128 + threadIdx.x] = dh0[threadIdx.x];
-        // zbar[i] = sum_j dh0[j] w[i][j]: 8 lanes per latent channel, xor-shuffle combine
-        {
-            const int i = threadIdx.x >> 3, part8 = threadIdx.x & 7;
-            real acc = 0;
-            if (i < L)
-                for (int j = part8; j < 128; j += 8) acc += dh0[j] * w[i * 128 + j];
-            acc += __shfl_xor(acc, 1, 64);
-            acc += __shfl_xor(acc, 2, 64);
-            acc += __shfl_xor(acc, 4, 64);
-            if (i < L && part8 == 0) zbar[(size_t)n * L + i] = acc;
-        }
-    }
+    decoder_bwd_data_images<PRE>(a, blockIdx.x, gridDim.x, smem);
 }
 
 // decoder reverse, WEIGHT half as a launch of its own (stand-alone entry point, probes; the training step runs the same device
@@ -502,19 +433,29 @@ extern "C" int svgp_mnist_decoder_bwd(const svgp_mnist_cfg* c, const double* the
 
 // The two halves of svgp_mnist_decoder_bwd (see k_decoder_bwd_data): _data writes zbar and ws.dec_d2 / dec_d1 / dec_dh0, _weights
 // the decoder weight-gradient partials from them.  _data + _weights == svgp_mnist_decoder_bwd up to summation order.
+// gp_kernels.hip (svgp_mnist_decoder_bwd_data_pre_aji) and the launches below
+svgp_vae::DecBwdDataArgs svgp_make_dec_bwd_data_args(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl, const double* theta,
+                                                     const double* images, double* ws, const double* state) {
+    svgp_mnist_param_layout pl;
+    svgp_mnist_param_layout_get(c, &pl);
+    DecBwdDataArgs a;
+    a.b = c->b; a.L = c->L; a.geco = c->geco; a.inv_bglobal = 1.0 / (double)c->b_global;
+    a.state = state; a.th_dec = theta + pl.n_enc; a.images = images; a.a1g = ws + wl.dec_a1; a.a2g = ws + wl.dec_a2;
+    a.recon = ws + wl.recon; a.d2g = ws + wl.dec_d2; a.d1g = ws + wl.dec_d1; a.dh0g = ws + wl.dec_dh0; a.zbar = ws + wl.zbar;
+    a.weff = ws + wl.dec_weff;
+    return a;
+}
 static int decoder_bwd_data_impl(const svgp_mnist_cfg* c, const double* theta, const double* images, double* ws,
                                  const double* state, bool pre, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(theta && images && ws && state, SVGP_ERR_INVALID, "NULL device pointer");
     const int64_t n_dec = pl.n_vae - pl.n_enc;
-    const size_t lds = (size_t)(c->L * 128 + DEC_NWE + 512 + 1568 + 784 + 1568 + 512 + 128 + (n_dec - c->L * 128 - 128)) * sizeof(real);
+    const size_t lds = (size_t)dec_bwd_data_lds(c->L, (int)n_dec, pre) * sizeof(real);
     int rc = pre ? set_dyn_lds(k_decoder_bwd_data<true>, lds) : set_dyn_lds(k_decoder_bwd_data<false>, lds);
     if (rc) return rc;
-#define DEC_BD_ARGS c->b, c->L, c->geco, 1.0 / (double)c->b_global, state, theta + pl.n_enc, images, ws + wl.dec_a1, ws + wl.dec_a2, \
-                    ws + wl.recon, ws + wl.dec_d2, ws + wl.dec_d1, ws + wl.dec_dh0, ws + wl.zbar, ws + wl.dec_weff
-    if (pre) hipLaunchKernelGGL(k_decoder_bwd_data<true>, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, DEC_BD_ARGS);
-    else hipLaunchKernelGGL(k_decoder_bwd_data<false>, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, DEC_BD_ARGS);
-#undef DEC_BD_ARGS
+    const DecBwdDataArgs a = svgp_make_dec_bwd_data_args(c, wl, theta, images, ws, state);
+    if (pre) hipLaunchKernelGGL(k_decoder_bwd_data<true>, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_decoder_bwd_data<false>, dim3(svgp_n_part(c)), dim3(VAE_NT), lds, (hipStream_t)stream, a);
     SVGP_LAUNCH_CHECK();
     return SVGP_OK;
 }

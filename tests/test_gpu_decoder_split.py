@@ -256,3 +256,51 @@ def test_merged_encoder_reverse_launch_keeps_two_workgroups_per_cu():
     n = C.c_int(0)
     _lib.call("svgp_mnist_encoder_bwd_km_regs", C.byref(n))
     assert 0 < n.value <= 168, n.value
+
+
+@pytest.mark.parametrize("b,m,L", [(256, 32, 16), (48, 16, 4), (300, 24, 5), (7, 12, 3)])
+def test_deferred_inverse_rides_in_the_decoder_data_reverse_launch(b, m, L):
+    """svgp_gp_posterior_fwd + svgp_mnist_decoder_bwd_data_pre_aji == svgp_gp_posterior_fwd_with_aji + svgp_mnist_decoder_bwd_data_pre,
+    bit for bit ((A_hat + jI)^-1, the KL terms incl. -log det / 2, the row-stage outputs, zbar and the stored pre-activation
+    gradients); and the kernel stays at <= 168 registers per lane (a rider and an image workgroup on one CU)."""
+    from svgp_vae_amd import _lib
+    eng, _ = _engine(b, m, L, seed=12)
+    eng.run(adam=False)
+    eng.synchronize()
+    cfg, th, ws, st = C.byref(eng.cfg), eng.theta.data_ptr(), eng.ws.data_ptr(), eng.state.data_ptr()
+    img, ep, s = eng._bound[0].data_ptr(), eng._bound[2].data_ptr(), eng.stream.cuda_stream
+    shapes = dict(Aji=(L, m, m), KL=(2 * L,), p_m=(b, L), p_v=(b, L), z=(b, L), zbar=(b, L), dec_d2=(b, 1568), dec_d1=(b, 512),
+                  dec_dh0=(b, 128))
+    out = {}
+    for form in ("row", "dec"):
+        for k in ("Aji", "zbar", "dec_d2", "dec_d1", "dec_dh0"):
+            eng.ws_view(k, shapes[k]).fill_(float("nan"))
+        _lib.call("svgp_gp_factor_fwd_defer_aji", cfg, ws, s)
+        if form == "row":
+            _lib.call("svgp_gp_posterior_fwd_with_aji", cfg, ep, ws, st, s)
+            _lib.call("svgp_mnist_decoder_fwd_pre", cfg, th, img, ws, s)
+            _lib.call("svgp_mnist_decoder_bwd_data_pre", cfg, th, img, ws, st, s)
+        else:
+            _lib.call("svgp_gp_posterior_fwd", cfg, ep, ws, st, s)
+            _lib.call("svgp_mnist_decoder_fwd_pre", cfg, th, img, ws, s)
+            _lib.call("svgp_mnist_decoder_bwd_data_pre_aji", cfg, th, img, ws, st, s)
+        eng.synchronize()
+        out[form] = {k: eng.ws_view(k, sh).clone() for k, sh in shapes.items()}
+    for k in shapes:
+        assert torch.isfinite(out["dec"][k]).all(), k
+        assert torch.equal(out["dec"][k], out["row"][k]), k
+    n = C.c_int(0)
+    _lib.call("svgp_mnist_decoder_bwd_data_aji_regs", C.byref(n))
+    assert 0 < n.value <= 168, n.value
+
+
+def test_step_with_and_without_the_inverse_in_the_decoder_launch_is_bit_equal(monkeypatch):
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("SVGP_AJI_DEC", flag)
+        eng, _ = _engine(256, 32, 16, seed=13)
+        for _ in range(3):
+            eng.run(adam=True)
+        eng.synchronize()
+        out[flag] = (eng.theta.clone(), eng.state.clone(), eng.scalars()["elbo"])
+    assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1]) and out["0"][2] == out["1"][2]

@@ -33,7 +33,7 @@ def child():
             eng.run(adam=True)
         eng.synchronize()
         best = min(best, (time.perf_counter() - t0) / reps * 1e6)
-    print(json.dumps(dict(split=os.environ.get("SVGP_DEC_SPLIT", "1"), types=os.environ.get("SVGP_DEC_RIDER_TYPES", ""), merge=os.environ.get("SVGP_ENC_KM_MERGE", ""), sum_merge=os.environ.get("SVGP_SUM_MERGE", ""), stat_merge=os.environ.get("SVGP_STAT_MERGE", ""), step_us=best, elbo=eng.scalars()["elbo"])), flush=True)
+    print(json.dumps(dict(split=os.environ.get("SVGP_DEC_SPLIT", "1"), types=os.environ.get("SVGP_DEC_RIDER_TYPES", ""), merge=os.environ.get("SVGP_ENC_KM_MERGE", ""), sum_merge=os.environ.get("SVGP_SUM_MERGE", ""), stat_merge=os.environ.get("SVGP_STAT_MERGE", ""), aji_dec=os.environ.get("SVGP_AJI_DEC", ""), step_us=best, elbo=eng.scalars()["elbo"])), flush=True)
 
 
 def main():
@@ -96,6 +96,7 @@ def main():
     rows = [("decoder_bwd (one kernel)", "svgp_mnist_decoder_bwd", (cfg, th, img, ws, st, s)),
             ("decoder_bwd_data", "svgp_mnist_decoder_bwd_data", (cfg, th, img, ws, st, s)),
             ("decoder_bwd_data_pre", "svgp_mnist_decoder_bwd_data_pre", (cfg, th, img, ws, st, s)),
+            ("decoder_bwd_data_pre_aji", "svgp_mnist_decoder_bwd_data_pre_aji", (cfg, th, img, ws, st, s)),
             ("decoder_fwd", "svgp_mnist_decoder_fwd", (cfg, th, img, ws, s)),
             ("decoder_fwd_pre", "svgp_mnist_decoder_fwd_pre", (cfg, th, img, ws, s)),
             ("encoder_kernel_matrix_fwd", "svgp_mnist_encoder_kernel_matrix_fwd", (cfg, th, img, eng._bound[1].data_ptr(), ws, s)),
@@ -117,9 +118,9 @@ def main():
             ("grad_reduce_all", "svgp_mnist_grad_reduce_all", (cfg, eng._bound[1].data_ptr(), ws, s))]
     for name, sym, args in rows:
         print(f"{name:32s} {timeit(sym, args):7.2f} us", flush=True)
-    for flag, nty, mg, sm, st_ in (("0", "3", "0", "0", "0"), ("1", "3", "1", "1", "0"), ("1", "3", "1", "1", "1"), ("1", "3", "1", "1", "0"),
-                                  ("1", "3", "1", "1", "1"), ("1", "3", "1", "1", "0"), ("1", "3", "1", "1", "1")):
-        env = dict(os.environ, SVGP_DEC_SPLIT=flag, SVGP_DEC_RIDER_TYPES=nty, SVGP_ENC_KM_MERGE=mg, SVGP_SUM_MERGE=sm, SVGP_STAT_MERGE=st_)
+    for flag, sm, st_, aj in (("0", "0", "0", "0"), ("1", "1", "0", "0"), ("1", "1", "1", "0"), ("1", "1", "1", "1"), ("1", "1", "1", "0"),
+                              ("1", "1", "1", "1"), ("1", "1", "1", "0"), ("1", "1", "1", "1")):
+        env = dict(os.environ, SVGP_DEC_SPLIT=flag, SVGP_ENC_KM_MERGE=flag, SVGP_SUM_MERGE=sm, SVGP_STAT_MERGE=st_, SVGP_AJI_DEC=aj)
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child"], env=env, capture_output=True, text=True)
         print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:], flush=True)
 

@@ -182,6 +182,12 @@ __device__ __forceinline__ real wave_sum(real x) {
     return x;  // valid in lane 0
 }
 
+// Workgroup barrier that orders LDS traffic ONLY.  `__syncthreads()` is a workgroup-scope fence as well: every wave first waits for
+// ALL its outstanding global loads and stores (s_waitcnt vmcnt(0)), so a `store activations; barrier; next layer` sequence exposes a
+// full store round trip (~0.7 us on MI355X) on a chain whose next step reads LDS only.  Use this where no wave of the workgroup
+// reads, after the barrier, global memory another wave wrote before it (the compiler still waits for a global LOAD at its first use).
+__device__ __forceinline__ void svgp_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // Sum over the workgroup (blockDim.x multiple of 64, <= 1024); result valid in thread 0.
 // `red` is an LDS scratch of >= 16 reals.  Fixed order -> deterministic.
 __device__ __forceinline__ real block_sum(real x, real* red) {

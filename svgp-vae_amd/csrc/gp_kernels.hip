@@ -89,6 +89,19 @@ __device__ __forceinline__ d4_t mfma_tile(const real* A, const real* B, int ld, 
     }
     return acc;
 }
+// A matrix of <= 4 elements per thread (m * m <= 4 blockDim.x) fetched into registers now and put into LDS later: a global load in
+// the MIDDLE of a dependent chain of LDS products exposes a full L2 round trip; issued at the top of the workgroup it is free
+struct Mat4 { real v[4]; };
+__device__ __forceinline__ Mat4 mat_fetch4(const real* __restrict__ g, int m) {
+    Mat4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int o = threadIdx.x + k * blockDim.x; r.v[k] = o < m * m ? g[o] : real(0); }
+    return r;
+}
+__device__ __forceinline__ void mat_put4(real* R, int ld, const Mat4& r, int m) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int o = threadIdx.x + k * blockDim.x; if (o < m * m) R[(o / m) * ld + (o % m)] = r.v[k]; }
+}
 // C = alpha * op(A) * op(B)   (all LDS padded, C must not alias A or B)
 template <bool TA, bool TB>
 __device__ __forceinline__ void mat_gemm(real* C, const real* A, const real* B, int ld, int m, real alpha) {
@@ -769,6 +782,10 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
     }
     const int l = blockIdx.x;
     const size_t om = (size_t)l * m * m, ov = (size_t)l * m;
+    // (m * m <= 4 * 256: Ki, needed in the middle of the chain, is fetched into registers now)
+    const bool keep = m * m <= 4 * (int)blockDim.x;
+    Mat4 pKi = {};
+    if (keep) pKi = mat_fetch4(a.Ki, m);
     // R0 = K ; R1 = K + c S_l + jitter I
     mat_load(R0, ld, a.K, m);
     for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
@@ -788,7 +805,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_fwd(FactArgs a) {
     __syncthreads();
     mat_store(a.A + om, R3, ld, m);
     if (threadIdx.x < m) a.mu[ov + threadIdx.x] = vz[threadIdx.x];
-    mat_load(R1, ld, a.Ki, m);                     // R1 = Ki   (Si, G no longer needed in LDS)
+    if (keep) mat_put4(R1, ld, pKi, m); else mat_load(R1, ld, a.Ki, m);      // R1 = Ki   (Si, G no longer needed in LDS)
     __syncthreads();
     mat_vec(vx, R1, ld, vz, m, real(1));           // u = Ki mu_hat
     // tr(Ki A) = sum_ij Ki_ij A_ji
@@ -1002,6 +1019,14 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     // S and A2 are needed twice each; for m <= 32 (<= 4 elements per thread) their partial sums stay in registers
     const bool keep = m * m <= 4 * (int)blockDim.x;
     real kS[4] = {0, 0, 0, 0}, kA2[4] = {0, 0, 0, 0};
+    // keep: every forward matrix the chain loads later (Aji, A, K, G, Si, M2) is fetched into registers NOW (24 reals per thread)
+    Mat4 pAji = {}, pA = {}, pK = {}, pG = {}, pSi = {}, pM2 = {}, kib = {};
+    real u_r = 0;
+    if (keep) {
+        pAji = mat_fetch4(a.Aji + om, m); pA = mat_fetch4(a.A + om, m); pK = mat_fetch4(a.K, m); pG = mat_fetch4(a.G + om, m);
+        pSi = mat_fetch4(a.Si + om, m); pM2 = mat_fetch4(a.M2 + om, m);
+        if (threadIdx.x < m) u_r = a.u[ov + threadIdx.x];
+    }
     if (keep) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -1026,17 +1051,17 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     if (!STAT) mat_vec(mubar, RK, ld, ubar, m, real(1));            // Ki ubar
     mat_gemm<false, false>(R2, R1, RK, ld, m, real(1));             // T1 = S Ki
     __syncthreads();
-    if (!STAT && threadIdx.x < m && !a.kl_form) mubar[threadIdx.x] += real(0.5) * gK * a.u[ov + threadIdx.x];
+    if (!STAT && threadIdx.x < m && !a.kl_form) mubar[threadIdx.x] += real(0.5) * gK * (keep ? u_r : a.u[ov + threadIdx.x]);
     mat_gemm<false, false>(R3, RK, R2, ld, m, real(1));             // Ki S Ki
     __syncthreads();
-    mat_load(R1, ld, a.Aji + om, m);
+    if (keep) mat_put4(R1, ld, pAji, m); else mat_load(R1, ld, a.Aji + om, m);
     __syncthreads();
     for (int o = threadIdx.x; o < m * m; o += blockDim.x) {         // Abar
         const int idx = (o / m) * ld + (o % m);
         R3[idx] = real(-0.5) * g3 * R3[idx] + real(0.5) * gK * (RK[idx] - R1[idx]);
     }
     __syncthreads();
-    mat_load(R1, ld, a.A + om, m);
+    if (keep) mat_put4(R1, ld, pA, m); else mat_load(R1, ld, a.A + om, m);
     if (STAT == 1) {
         // Everything above is a function of forward quantities alone: the reverse statistics of this channel (A2, ud, td) are awaited
         // HERE, the last point at which Ki is still in LDS for Ki ubar.  (Waiting at the top of the workgroup: 28.0 us for the launch
@@ -1064,7 +1089,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
         __syncthreads();
         mat_vec(mubar, R0, ld, ubar, m, real(1));                   // Ki ubar
         __syncthreads();
-        if (threadIdx.x < m && !a.kl_form) mubar[threadIdx.x] += real(0.5) * gK * a.u[ov + threadIdx.x];
+        if (threadIdx.x < m && !a.kl_form) mubar[threadIdx.x] += real(0.5) * gK * (keep ? u_r : a.u[ov + threadIdx.x]);
     }
     __syncthreads();
     mat_gemm<false, false>(R0, R2, R1, ld, m, real(1));             // T1 A = S Ki A   (Ki dropped)
@@ -1090,7 +1115,12 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
         } else {
             sS = part_sum(a.S + om + o, sM, a.P); sA2 = part_sum<STAT != 0>(a.A2 + om + o, sM, a.P);
         }
-        Kib[o] = -g3 * R0[idx] + real(0.5) * gK * R1[idx] + ubar[i] * muv[j] + real(0.5) * g3 * sS - sA2;
+        const real kv_ = -g3 * R0[idx] + real(0.5) * gK * R1[idx] + ubar[i] * muv[j] + real(0.5) * g3 * sS - sA2;
+        Kib[o] = kv_;
+        if (keep) {
+            const int k = o / (int)blockDim.x;
+            if (k == 0) kib.v[0] = kv_; else if (k == 1) kib.v[1] = kv_; else if (k == 2) kib.v[2] = kv_; else kib.v[3] = kv_;
+        }
     }
     __syncthreads();
     if (a.kl_form) {
@@ -1110,10 +1140,10 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
         for (int o = threadIdx.x; o < m * m; o += blockDim.x) Kib[o] += w * R0[(o / m) * ld + (o % m)];
         __syncthreads();
     }
-    mat_load(R0, ld, a.K, m);
+    if (keep) mat_put4(R0, ld, pK, m); else mat_load(R0, ld, a.K, m);
     __syncthreads();
     mat_gemm<false, false>(R1, R0, R3, ld, m, real(1));             // Gbar = K Abar
-    mat_load(R2, ld, a.G + om, m);
+    if (keep) mat_put4(R2, ld, pG, m); else mat_load(R2, ld, a.G + om, m);
     __syncthreads();
     mat_gemm_g<false, true>(Kb, R3, R2, ld, m, real(1), real(0));   // Kbar_l = Abar G^T
     if (STAT == 2) {
@@ -1138,7 +1168,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
             ud_r = part_sum<true>(a.ud + ov + threadIdx.x, sV, a.P);
             td_r = part_sum<true>(a.td + ov + threadIdx.x, sV, a.P);
         }
-        mat_load(R2, ld, a.Si + om, m);
+        mat_put4(R2, ld, pSi, m);
         __syncthreads();
         mat_gemm_g<false, false>(Kb, R2, R1, ld, m, real(1), real(1));  // += Si Gbar
         mat_gemm<false, false>(R3, R1, R0, ld, m, real(1));             // Gbar K
@@ -1146,7 +1176,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
         __syncthreads();
         mat_vec(mubar, RK, ld, ubar, m, real(1));                   // Ki ubar
         __syncthreads();
-        if (threadIdx.x < m && !a.kl_form) mubar[threadIdx.x] += real(0.5) * gK * a.u[ov + threadIdx.x];
+        if (threadIdx.x < m && !a.kl_form) mubar[threadIdx.x] += real(0.5) * gK * u_r;
         __syncthreads();
         if (threadIdx.x < m) {                                      // tbar = td + c K mubar
             real acc = 0;
@@ -1156,7 +1186,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {                               // Kibar_l, finished
             const int o = threadIdx.x + k * blockDim.x;
-            if (o < m * m) Kib[o] = pre[k] + ubar[o / m] * muv[o % m] + real(0.5) * g3 * kS[k] - kA2[k];
+            if (o < m * m) { kib.v[k] = pre[k] + ubar[o / m] * muv[o % m] + real(0.5) * g3 * kS[k] - kA2[k]; Kib[o] = kib.v[k]; }
         }
         __syncthreads();
     } else {
@@ -1167,7 +1197,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
         tbar[threadIdx.x] = part_sum<STAT != 0>(a.td + ov + threadIdx.x, sV, a.P) + a.c * acc;
     }
     __syncthreads();
-    mat_load(R2, ld, a.Si + om, m);
+    if (keep) mat_put4(R2, ld, pSi, m); else mat_load(R2, ld, a.Si + om, m);
     __syncthreads();
     mat_gemm_g<false, false>(Kb, R2, R1, ld, m, real(1), real(1));  // += Si Gbar
     mat_gemm<false, false>(R3, R1, R0, ld, m, real(1));             // Gbar K
@@ -1200,14 +1230,17 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
         Kb[o] += R0[i * ld + j];
         const real ss = a.c * (R0[i * ld + j] + R0[j * ld + i]);
         a.Ssym[om + o] = ss;
-        a.Qm[om + o] = ss - g3 * a.M2[om + o];
+        real m2;
+        if (keep) { const int k = o / (int)blockDim.x; m2 = k == 0 ? pM2.v[0] : k == 1 ? pM2.v[1] : k == 2 ? pM2.v[2] : pM2.v[3]; }
+        else m2 = a.M2[om + o];
+        a.Qm[om + o] = ss - g3 * m2;
     }
     // Kbar_l -= Ki Kibar_l Ki  (the inverse's VJP is linear, so it is applied per channel here and
     // the final kernel only sums channels).  Kib was written by this workgroup above.
     __syncthreads();
     real* RKi = STAT == 2 ? RK : R1;
     if (STAT != 2) mat_load(R1, ld, a.Ki, m);
-    mat_load(R2, ld, Kib, m);
+    if (keep && !a.kl_form) mat_put4(R2, ld, kib, m); else mat_load(R2, ld, Kib, m);
     __syncthreads();
     mat_gemm<false, false>(R3, RKi, R2, ld, m, real(1));
     __syncthreads();

@@ -663,17 +663,17 @@ __device__ __forceinline__ void decoder_bwd_data_images(const DecBwdDataArgs& a,
             d2[i] = v;
             a.d2g[(size_t)n * 1568 + i] = v;
         }
-        __syncthreads();
+        svgp_lds_barrier();             // (the stores to d2g / d1g / dh0g are for a later launch: no wave waits for them here)
         UpC2::bwd_data_mfma(d2, We2, d1);
-        __syncthreads();
+        svgp_lds_barrier();
         for (int i = threadIdx.x; i < 512; i += blockDim.x) {
             const real v = d1[i] * elu_grad_from_out(a1[i]);
             d1[i] = v;
             a.d1g[(size_t)n * 512 + i] = v;
         }
-        __syncthreads();
+        svgp_lds_barrier();
         UpC1::bwd_data_mfma(d1, We1, dh0);
-        __syncthreads();
+        svgp_lds_barrier();
         if (threadIdx.x < 128) a.dh0g[(size_t)n * 128 + threadIdx.x] = dh0[threadIdx.x];
         // zbar[i] = sum_j dh0[j] w[i][j]: 8 lanes per latent channel, xor-shuffle combine
         {

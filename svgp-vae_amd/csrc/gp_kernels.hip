@@ -113,6 +113,36 @@ __device__ __forceinline__ void mat_gemm(real* C, const real* A, const real* B, 
         for (int g = 0; g < 4; ++g) C[(ti * 16 + q + 4 * g) * ld + tj * 16 + r] = alpha * acc[g];
     }
 }
+// C (LDS) = alpha * op(A) * op(B) + C, tile by tile: every lane reads and writes its own elements (no barrier needed against an
+// earlier mat_gemm into C; one IS needed against an element-wise pass over C)
+template <bool TA, bool TB>
+__device__ __forceinline__ void mat_gemm_acc(real* C, const real* A, const real* B, int ld, int m, real alpha) {
+    const int mp = pad16(m), nt = mp >> 4, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    for (int t = threadIdx.x >> 6; t < nt * nt; t += (blockDim.x >> 6)) {
+        const int ti = t / nt, tj = t % nt;
+        const d4_t acc = mfma_tile<TA, TB>(A, B, ld, mp, ti, tj);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int idx = (ti * 16 + q + 4 * g) * ld + tj * 16 + r;
+            C[idx] = alpha * acc[g] + real(1) * C[idx];
+        }
+    }
+}
+// Cg (global, m x m, ld = m) = alpha * op(A) * op(B) + C (LDS)
+template <bool TA, bool TB>
+__device__ __forceinline__ void mat_gemm_g_from(real* __restrict__ Cg, const real* C, const real* A, const real* B, int ld, int m,
+                                                real alpha) {
+    const int mp = pad16(m), nt = mp >> 4, lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+    for (int t = threadIdx.x >> 6; t < nt * nt; t += (blockDim.x >> 6)) {
+        const int ti = t / nt, tj = t % nt;
+        const d4_t acc = mfma_tile<TA, TB>(A, B, ld, mp, ti, tj);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int i = ti * 16 + q + 4 * g, j = tj * 16 + r;
+            if (i < m && j < m) Cg[(size_t)i * m + j] = alpha * acc[g] + real(1) * C[i * ld + j];
+        }
+    }
+}
 // Cg (global, m x m, ld = m) = alpha * op(A) * op(B) + beta * Cg
 template <bool TA, bool TB>
 __device__ __forceinline__ void mat_gemm_g(real* __restrict__ Cg, const real* A, const real* B, int ld, int m,
@@ -1000,9 +1030,14 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     real* R2 = R1 + mm;
     real* R3 = R2 + mm;
     real* RK = STAT == 2 ? R3 + mm : R0;  // Ki
-    for (int o = threadIdx.x; o < (STAT == 2 ? 5 : 4) * mm; o += blockDim.x) smem[o] = 0;   // zero pads (MFMA tiles read them)
+    // m * m <= 4 * 256 (`keep`): one more LDS matrix accumulates Kbar_l (five updates that were read-modify-writes of GLOBAL memory in
+    // two thread layouts: a round trip each on the chain); it is stored once, with the last product
+    const bool keep = m * m <= 4 * (int)blockDim.x;
+    const int nbuf = 4 + (STAT == 2 ? 1 : 0) + (keep ? 1 : 0);
+    real* RKb = smem + (nbuf - 1) * mm;
+    for (int o = threadIdx.x; o < nbuf * mm; o += blockDim.x) smem[o] = 0;   // zero pads (MFMA tiles read them)
     __syncthreads();
-    real* ubar = R3 + (STAT == 2 ? 2 : 1) * mm;      // m
+    real* ubar = smem + nbuf * mm;      // m
     real* mubar = ubar + m;    // m
     real* tbar = mubar + m;    // m
     real* tv = tbar + m;       // m  (t_l)
@@ -1017,7 +1052,6 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     const size_t sM = (size_t)a.L * m * m, sV = (size_t)a.L * m;     // strides between row partials
     mat_load(RK, ld, a.Ki, m);
     // S and A2 are needed twice each; for m <= 32 (<= 4 elements per thread) their partial sums stay in registers
-    const bool keep = m * m <= 4 * (int)blockDim.x;
     real kS[4] = {0, 0, 0, 0}, kA2[4] = {0, 0, 0, 0};
     // keep: every forward matrix the chain loads later (Aji, A, K, G, Si, M2) is fetched into registers NOW (24 reals per thread)
     Mat4 pAji = {}, pA = {}, pK = {}, pG = {}, pSi = {}, pM2 = {}, kib = {};
@@ -1145,7 +1179,8 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     mat_gemm<false, false>(R1, R0, R3, ld, m, real(1));             // Gbar = K Abar
     if (keep) mat_put4(R2, ld, pG, m); else mat_load(R2, ld, a.G + om, m);
     __syncthreads();
-    mat_gemm_g<false, true>(Kb, R3, R2, ld, m, real(1), real(0));   // Kbar_l = Abar G^T
+    if (keep) mat_gemm<false, true>(RKb, R3, R2, ld, m, real(1));    // Kbar_l = Abar G^T
+    else mat_gemm_g<false, true>(Kb, R3, R2, ld, m, real(1), real(0));
     if (STAT == 2) {
         // the wait: ~9 us into the workgroup, the statistics need ~6 us from launch start
         if (threadIdx.x == 0) {
@@ -1170,7 +1205,7 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
         }
         mat_put4(R2, ld, pSi, m);
         __syncthreads();
-        mat_gemm_g<false, false>(Kb, R2, R1, ld, m, real(1), real(1));  // += Si Gbar
+        mat_gemm_acc<false, false>(RKb, R2, R1, ld, m, real(1));        // += Si Gbar   (STAT == 2 implies keep)
         mat_gemm<false, false>(R3, R1, R0, ld, m, real(1));             // Gbar K
         if (threadIdx.x < m) ubar[threadIdx.x] = ud_r + (a.kl_form ? real(0) : real(0.5) * gK * muv[threadIdx.x]);
         __syncthreads();
@@ -1199,7 +1234,8 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     __syncthreads();
     if (keep) mat_put4(R2, ld, pSi, m); else mat_load(R2, ld, a.Si + om, m);
     __syncthreads();
-    mat_gemm_g<false, false>(Kb, R2, R1, ld, m, real(1), real(1));  // += Si Gbar
+    if (keep) mat_gemm_acc<false, false>(RKb, R2, R1, ld, m, real(1));  // += Si Gbar
+    else mat_gemm_g<false, false>(Kb, R2, R1, ld, m, real(1), real(1));
     mat_gemm<false, false>(R3, R1, R0, ld, m, real(1));             // Gbar K
     __syncthreads();
     }
@@ -1213,7 +1249,8 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
             sA2 = part_sum<STAT != 0>(a.A2 + om + o, sM, a.P);
         }
         R3[i * ld + j] += sA2 + tbar[i] * vv[j];                    // Sibar
-        Kb[o] += a.c * mubar[i] * tv[j];
+        if (keep) RKb[i * ld + j] += a.c * mubar[i] * tv[j];
+        else Kb[o] += a.c * mubar[i] * tv[j];
     }
     if (threadIdx.x < m) {                                          // vbar = Si tbar
         real acc = 0;
@@ -1227,7 +1264,8 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     __syncthreads();
     for (int o = threadIdx.x; o < m * m; o += blockDim.x) {
         const int i = o / m, j = o % m;
-        Kb[o] += R0[i * ld + j];
+        if (keep) RKb[i * ld + j] += R0[i * ld + j];
+        else Kb[o] += R0[i * ld + j];
         const real ss = a.c * (R0[i * ld + j] + R0[j * ld + i]);
         a.Ssym[om + o] = ss;
         real m2;
@@ -1244,7 +1282,8 @@ __global__ __launch_bounds__(SVGP_BLOCK) void k_gp_factor_bwd(FactBwdArgs a) {
     __syncthreads();
     mat_gemm<false, false>(R3, RKi, R2, ld, m, real(1));
     __syncthreads();
-    mat_gemm_g<false, false>(Kb, R3, RKi, ld, m, real(-1), real(1));
+    if (keep) mat_gemm_g_from<false, false>(Kb, RKb, R3, RKi, ld, m, real(-1));
+    else mat_gemm_g<false, false>(Kb, R3, RKi, ld, m, real(-1), real(1));
 }
 
 // Kbar = sum_l Kbar_l + (L gK / 2) Ki ; one thread per element, channel loads batched.
@@ -1969,7 +2008,8 @@ static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* st
     if (c->m > SVGP_M_MAX) return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L);
     FactBwdArgs a = make_fb(c, wl, ws, state);
     const int m = c->m;
-    size_t lds = mat_lds_pad(m, 4) + (size_t)(6 * m) * sizeof(real), lds_w = 0;
+    const int keep = m * m <= 4 * SVGP_BLOCK ? 1 : 0;          // + the LDS accumulator of Kbar_l
+    size_t lds = mat_lds_pad(m, 4 + keep) + (size_t)(6 * m) * sizeof(real), lds_w = 0;
     bool five = false;
     if (images_for_wgrad) {
         static const int n_types = [] { const char* e = getenv("SVGP_DEC_RIDER_TYPES"); return (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 3; }();
@@ -1985,7 +2025,7 @@ static int factor_bwd_impl(const svgp_mnist_cfg* c, double* ws, const double* st
         a.wait_n = a.P;
         // (SVGP_STAT_FOUR=1: the four-matrix form also where five fit -- what 32 < m <= 64 runs; tests compare the two)
         five = !c->kl_form && m * m <= 4 * SVGP_BLOCK && !getenv("SVGP_STAT_FOUR");
-        if (five) lds = mat_lds_pad(m, 5) + (size_t)(6 * m) * sizeof(real);
+        if (five) lds = mat_lds_pad(m, 5 + keep) + (size_t)(6 * m) * sizeof(real);
         if (images_for_wgrad && lds_w > lds) lds = lds_w;
         a.flags = reinterpret_cast<unsigned long long*>(ws + wl.flags);
         if (lds_s > lds) lds = lds_s;

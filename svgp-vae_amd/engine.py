@@ -476,8 +476,19 @@ class MnistStepEngine:
 
     def scalars(self):
         self.stream.synchronize()      # the state vector is written on self.stream, .cpu() runs on torch's stream
+        self.check_handoffs()
         st = self.state.cpu()
         return {k.lower(): float(st[i]) for k, i in STATE.items()}
+
+    def check_handoffs(self):
+        """The merged launches of the m <= 64 step hand data from producer to consumer workgroups of ONE launch through counters
+        in ws.flags (include/svgpvae_hip.h); a consumer that gave up waiting (~1 s of polling) sets the sticky word flags[2] and
+        goes on with whatever it read.  That must never pass for a result: raise, and re-arm the counters."""
+        fl = self.ws_view("flags", (64,)).view(torch.int64)
+        if int(fl[2].item()) != 0:
+            fl.zero_()
+            raise _lib.SvgpError("an intra-launch hand-off of the training step timed out (ws.flags[2] was set): "
+                                 "the results of this step are invalid")
 
     # ------------------------------------------------------------------ views
     def _pview(self, flat, name):

@@ -304,3 +304,18 @@ def test_step_with_and_without_the_inverse_in_the_decoder_launch_is_bit_equal(mo
         eng.synchronize()
         out[flag] = (eng.theta.clone(), eng.state.clone(), eng.scalars()["elbo"])
     assert torch.equal(out["0"][0], out["1"][0]) and torch.equal(out["0"][1], out["1"][1]) and out["0"][2] == out["1"][2]
+
+
+def test_timed_out_handoff_is_raised_not_returned():
+    """A consumer workgroup that gives up waiting for its producer sets ws.flags[2]; the engine turns that into an error at the next
+    read of the step's scalars (and re-arms the counters) instead of handing out the numbers of a broken step."""
+    from svgp_vae_amd import _lib
+    eng, _ = _engine(48, 16, 4, seed=18)
+    eng.run(adam=False)
+    assert "elbo" in eng.scalars()
+    eng.ws_view("flags", (64,)).view(torch.int64)[2] = 1
+    with pytest.raises(_lib.SvgpError, match="hand-off"):
+        eng.scalars()
+    assert torch.count_nonzero(eng.ws_view("flags", (64,)).view(torch.int64)) == 0
+    eng.run(adam=False)
+    assert "elbo" in eng.scalars()

@@ -515,8 +515,10 @@ __device__ __forceinline__ real wave_sum_la(real x) {
 // Wave 0 of the workgroup inverts the 32 x 32 block staged in LDS (single-wave in-register Gauss-Jordan, sweep32.hpp: 4 x 16
 // lanes of 8 x 2 register blocks, pivot column by DPP row broadcast), writes P^-1 to `Pinv` (and `Pcap`), adds log det to
 // logdet[l] (sets it when `first`).
+// `ld_prev`: the log det accumulated so far (0 for the first block), read by the CALLER at the top of its workgroup -- read here, behind
+// the sweep, it was a global round trip at the very end of every block step's chain.
 __device__ __forceinline__ void gj32_sweep(const real (*P)[NB + 1], real* __restrict__ Pinv, real* __restrict__ Pcap,
-                                           real* __restrict__ logdet_l, bool first) {
+                                           real* __restrict__ logdet_l, real ld_prev) {
     if (threadIdx.x >= 64) return;
     const int lane = threadIdx.x;
     const real mypiv = sweep32::gauss_jordan_32(
@@ -526,7 +528,7 @@ __device__ __forceinline__ void gj32_sweep(const real (*P)[NB + 1], real* __rest
             if (Pcap) Pcap[i * NB + j] = v;
         });
     const real lg = wave_sum_la(log(mypiv));
-    if (lane == 0) *logdet_l = (first ? real(0) : *logdet_l) + lg;
+    if (lane == 0) *logdet_l = ld_prev + lg;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256) void k_bgjf_pivot0(BgjfArgs g) {
     const real* X = l < g.nmain ? g.X + (size_t)l * g.m * g.m : g.Xe + (size_t)(l - g.nmain) * g.m * g.m;
     for (int t = threadIdx.x; t < NB * NB; t += blockDim.x) P[t / NB][t % NB] = bgjf_get(X, g.m, 0, 0, t / NB, t % NB, true);
     __syncthreads();
-    gj32_sweep(P, g.Pinv + (size_t)l * NB * NB, nullptr, l < g.nmain ? g.logdet + l : g.logdet_e + (l - g.nmain), true);
+    gj32_sweep(P, g.Pinv + (size_t)l * NB * NB, nullptr, l < g.nmain ? g.logdet + l : g.logdet_e + (l - g.nmain), real(0));
 }
 // 32 x 32 product on the f64 MFMA: wave w of the 4 owns the 16 x 16 quadrant (w >> 1, w & 1); lane (r = lane & 15,
 // q = lane >> 4) receives elements (row 16 (w >> 1) + q + 4 e, column 16 (w & 1) + r), e = 0..3.  A tenth of the LDS
@@ -598,6 +600,8 @@ __global__ __launch_bounds__(256) void k_bgjf_step(BgjfArgs g) {
     const real* Pinv = g.Pinv + ((size_t)(kb & 1) * g.batch + l) * NB * NB;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, r = lane & 15, q = lane >> 4;
     const int ti = 16 * (w >> 1) + q, tj = 16 * (w & 1) + r;      // this thread's elements: rows ti + 4 e, column tj
+    real ld_prev = 0;                                              // pivot workgroup: the log det so far, fetched now for the sweep's end
+    if ((kb + 1) * NB < m && (int)blockIdx.x < g.batch && threadIdx.x == 0) ld_prev = l < g.nmain ? g.logdet[l] : g.logdet_e[l - g.nmain];
     real xo[4];                                                    // the tile's own old values, in flight under the products
     if (bi != kb && bj != kb) {
 #pragma unroll
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(256) void k_bgjf_step(BgjfArgs g) {
         for (int e = 0; e < 4; ++e) Pv[ti + 4 * e][tj] = out[e];
         __syncthreads();
         gj32_sweep(Pv, g.Pinv + ((size_t)((kb + 1) & 1) * g.batch + l) * NB * NB, nullptr,
-                   l < g.nmain ? g.logdet + l : g.logdet_e + (l - g.nmain), false);
+                   l < g.nmain ? g.logdet + l : g.logdet_e + (l - g.nmain), ld_prev);
     }
 }
 

@@ -109,6 +109,23 @@ __global__ __launch_bounds__(256) void k_big_rowdot(int b, int m, int L, real sc
     s = wave_sum(s);
     if (lane == 0) out[(size_t)n * ld_out + col0 + l] = scale * s;
 }
+// Two row-dot jobs over the same rows in ONE launch (blockIdx.y = job): r = k^T Si k and s = w^T Si w of the forward row stage.  Same
+// arithmetic per (n, l) as two k_big_rowdot launches.
+__global__ __launch_bounds__(256) void k_big_rowdot2(int b, int m, int L, real scale, const real* __restrict__ X0,
+                                                     const real* __restrict__ X1, long long sX, const real* __restrict__ K0,
+                                                     const real* __restrict__ K1, real* __restrict__ out0,
+                                                     real* __restrict__ out1, int ld_out) {
+    const long long wid = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (wid >= (long long)b * L) return;
+    const int n = (int)(wid / L), l = (int)(wid % L);
+    const real* x = (blockIdx.y ? X1 : X0) + (size_t)l * sX + (size_t)n * m;
+    const real* k = (blockIdx.y ? K1 : K0) + (size_t)n * m;
+    real s = 0;
+    for (int j = lane; j < m; j += 64) s += x[j] * k[j];
+    s = wave_sum(s);
+    if (lane == 0) (blockIdx.y ? out1 : out0)[(size_t)n * ld_out + l] = scale * s;
+}
 // tr(Ki A_l) = sum_ij Ki_ij A_ji and mu_l . u_l.  grid (KL_NCH, L): each workgroup sums a contiguous slice of A_l
 // (coalesced; the transposed operand is the shared Ki, an L2 hit) -> part (L, KL_NCH, 2); k_big_kl adds the slices in
 // index order.
@@ -269,6 +286,18 @@ __global__ __launch_bounds__(256) void k_big_fb_ssym(FbArgs a) {
             }
         }
     }
+}
+// three channel sums in ONE launch (blockIdx.y = job); same arithmetic as three k_big_sum_channels launches
+__global__ void k_big_sum_channels3(int mm, int L, real scale, const real* __restrict__ in0, real* __restrict__ out0,
+                                    const real* __restrict__ in1, real* __restrict__ out1, const real* __restrict__ in2,
+                                    real* __restrict__ out2) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= mm) return;
+    const real* in = blockIdx.y == 0 ? in0 : blockIdx.y == 1 ? in1 : in2;
+    real* out = blockIdx.y == 0 ? out0 : blockIdx.y == 1 ? out1 : out2;
+    real s = 0;
+    for (int l = 0; l < L; ++l) s += in[(size_t)l * mm + o];
+    out[o] = scale * s;
 }
 // out (m x m) = scale * sum over the L channel matrices
 __global__ void k_big_sum_channels(int mm, int L, real scale, const real* __restrict__ in, real* __restrict__ out) {
@@ -687,11 +716,9 @@ int svgp_big_posterior_fwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& 
     real* Kn = ws + wl.Kn;
     // [Kn; W] Si_l in one product over the 2 b stacked rows; kept for svgp_big_posterior_bwd / svgp_big_stats (mode 1)
     GEMM(0, 1, 2 * b, m, m, 1.0, Kn, m, 0, ws + wl.Si, m, mm, 0.0, s.KS, m, s.sKS, L);
-    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.KS, s.sKS, Kn,
-                       ws + wl.p_v, L, 0);                                                      // r = k^T Si k -> p_v slot
-    SVGP_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_big_rowdot, dim3(nblk((long long)b * L * 64)), dim3(256), 0, st, b, m, L, real(1), s.KS + bm, s.sKS, s.W,
-                       ws + wl.d, L, 0);                                                        // s = w^T Si w (= k^T Ki A Ki k) -> d slot
+    // r = k^T Si k -> p_v slot and s = w^T Si w (= k^T Ki A Ki k) -> d slot: one launch, two jobs
+    hipLaunchKernelGGL(k_big_rowdot2, dim3(nblk((long long)b * L * 64), 2), dim3(256), 0, st, b, m, L, real(1), s.KS, s.KS + bm, s.sKS,
+                       Kn, (const real*)s.W, ws + wl.p_v, ws + wl.d, L);
     SVGP_LAUNCH_CHECK();
     GEMM(0, 1, b, L, m, cc, Kn, m, 0, ws + wl.t, m, 0, 0.0, ws + wl.p_m, L, 0, 1);               // p_m = c Kn t^T
     GEMM(0, 1, b, L, m, 1.0, Kn, m, 0, ws + wl.u, m, 0, 0.0, ws + wl.e, L, 0, 1);                // mv -> e slot
@@ -763,11 +790,8 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
             GEMM(0, 1, m, m, m, 1.0, G, m, mm, Db, m, mm, 0.0, s.mm0, m, mm, L);
         }
         GEMM_SYM(0, 1, m, m, 1.0, s.mm0, m, mm, G, m, mm, 0.0, s.mm3, m, mm, L);         // HG = H G^T = Si K D K Si  (mm3)
-        hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, real(1), s.mm0, s.Zs);
-        SVGP_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, real(1), s.mm3, s.HGs);
-        SVGP_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, real(1), A, s.Asum);
+        hipLaunchKernelGGL(k_big_sum_channels3, dim3(nblk(mm), 3), dim3(256), 0, st, (int)mm, L, real(1), (const real*)s.mm0, s.Zs,
+                           (const real*)s.mm3, s.HGs, (const real*)A, s.Asum);
         SVGP_LAUNCH_CHECK();
     }
     if (part == 1 || part == 4) return SVGP_OK;

@@ -746,8 +746,9 @@ __device__ __forceinline__ void encoder_bwd_images(const EncBwdArgs& a, int firs
                 dj = a.ybar[(size_t)n * L + j];
             } else {
                 const real vr = a.var_raw[(size_t)n * L + j - L];
+                const real sb = a.s2bar[(size_t)n * L + j - L];      // (unconditional: behind the test it was a second, dependent round trip)
                 const bool pass = !a.clip || (vr >= 1e-3 && vr <= 10.0);
-                dj = pass ? a.s2bar[(size_t)n * L + j - L] * vr : real(0);
+                dj = pass ? sb * vr : real(0);
             }
             dout[j] = dj;
         }

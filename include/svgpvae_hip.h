@@ -322,6 +322,12 @@ int svgp_gp_factor_bwd_early_b(const svgp_mnist_cfg*, double* ws, const double* 
  * itself is left in scratch matrix 2 by svgp_gp_stats_bwd, so the stage may be repeated on a workspace). */
 int svgp_gp_factor_bwd_late_a(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_late_b(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+/* _late_b in three pieces (round 6): _channels (the channel block: X sandwiches unless _late_a took them, Ssym, the channel sum) and _kbar
+ * (the single-matrix chain of the gradient of Ki: K Pbar^T, Kib, Ki Kib Ki, Pbar^T Ki -- five small launches that read nothing of
+ * _channels) may run on two streams; _final assembles Kbar and follows both.  _late_b == _channels; _kbar; _final. */
+int svgp_gp_factor_bwd_late_b_channels(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+int svgp_gp_factor_bwd_late_b_kbar(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
+int svgp_gp_factor_bwd_late_b_final(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 int svgp_gp_factor_bwd_nofinal(const svgp_mnist_cfg*, double* ws, const double* state, void* stream);
 /* m <= 64: svgp_kernel_matrix_bwd_partials + svgp_mnist_encoder_bwd in ONE launch (the two are independent: both consume the
  * reverse row stage; tf.gradients of SVGPVAE_model.py:427-476 and VAE_utils.py:112-126,143-152).  Results identical. */

@@ -109,6 +109,9 @@ SIGNATURES = {
     "svgp_gp_factor_bwd_early_b": [_CFG, _P, _P, _P],
     "svgp_gp_factor_bwd_late_a": [_CFG, _P, _P, _P],
     "svgp_gp_factor_bwd_late_b": [_CFG, _P, _P, _P],
+    "svgp_gp_factor_bwd_late_b_channels": [_CFG, _P, _P, _P],
+    "svgp_gp_factor_bwd_late_b_kbar": [_CFG, _P, _P, _P],
+    "svgp_gp_factor_bwd_late_b_final": [_CFG, _P, _P, _P],
     "svgp_mnist_encoder_kernel_matrix_fwd": [_CFG, _P, _P, _P, _P, _P],
     "svgp_gp_stats_bwd_with_aji": [_CFG, _P, _P, _P],
     "svgp_gp_factor_bwd_nofinal": [_CFG, _P, _P, _P],

@@ -318,6 +318,10 @@ bool aji_dec_on() {
     const char* e = getenv("SVGP_AJI_DEC");
     return !(e && e[0] == '0');
 }
+bool kbar_branch_on() {
+    const char* e = getenv("SVGP_KBAR_BRANCH");
+    return !(e && e[0] == '0');
+}
 bool konly_on() {      // (read per call: tests compare the two orders in one process)
     const char* e = getenv("SVGP_KONLY_BRANCH");
     return !(e && e[0] == '0');
@@ -425,6 +429,15 @@ int step_phase_impl(const svgp_mnist_cfg* c, int phase, double* theta, const dou
         if (large && side_take_early(sd, ws)) {
             RUN(svgp_gp_factor_bwd_late_a(c, ws, state, stream));       // what does not read the branch's results: before the join
             RUN(side_join(sd, 1, ms));                                  // (a no-op unless phase 1 left the branch open)
+            // round 6: the single-matrix chain of the gradient of Ki (five ~9 us launches) on the branch that has just been joined,
+            // beside the channel block on the caller's stream; SVGP_KBAR_BRANCH=0: one after the other
+            if (kbar_branch_on()) {
+                RUN(side_fork(sd, 1, ms));
+                RUN(svgp_gp_factor_bwd_late_b_kbar(c, ws, state, (void*)sd->s[1]));
+                RUN(svgp_gp_factor_bwd_late_b_channels(c, ws, state, stream));
+                RUN(side_join(sd, 1, ms));
+                RUN(svgp_gp_factor_bwd_late_b_final(c, ws, state, stream));
+            } else
             RUN(svgp_gp_factor_bwd_late_b(c, ws, state, stream));
         } else {
             // channel sum Kbar: inside the next launch; m <= 64: + the decoder's weight gradients as riders (phase 1 ran the data half)

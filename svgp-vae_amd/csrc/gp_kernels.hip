@@ -1995,6 +1995,26 @@ extern "C" int svgp_gp_factor_bwd_late_b(const svgp_mnist_cfg* c, double* ws, co
     SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the split reverse factor stage exists for m > %d", SVGP_M_MAX);
     return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 7);
 }
+// _late_b = _late_b_channels (the channel block: X sandwiches, Ssym, Sgs) + _late_b_kbar (the single-matrix chain of the gradient of Ki:
+// five small launches that read nothing of the channel block and may run beside it on another stream) + _late_b_final (round 6)
+extern "C" int svgp_gp_factor_bwd_late_b_channels(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the split reverse factor stage exists for m > %d", SVGP_M_MAX);
+    return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 8);
+}
+extern "C" int svgp_gp_factor_bwd_late_b_kbar(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the split reverse factor stage exists for m > %d", SVGP_M_MAX);
+    return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 9);
+}
+extern "C" int svgp_gp_factor_bwd_late_b_final(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
+    GET_LAYOUTS();
+    SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");
+    SVGP_REQUIRE(c->m > SVGP_M_MAX, SVGP_ERR_UNSUPPORTED, "the split reverse factor stage exists for m > %d", SVGP_M_MAX);
+    return svgp_big_factor_bwd(c, wl, ws, state, stream, 0, c->L, 10);
+}
 extern "C" int svgp_gp_factor_bwd_late(const svgp_mnist_cfg* c, double* ws, const double* state, void* stream) {
     GET_LAYOUTS();
     SVGP_REQUIRE(ws && state, SVGP_ERR_INVALID, "NULL device pointer");

@@ -795,14 +795,18 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
         SVGP_LAUNCH_CHECK();
     }
     if (part == 1 || part == 4) return SVGP_OK;
-    {
+    // Round 6: part 7 in three pieces -- 8 = the channel block (X sandwiches if they are not part 6's, Ssym, the channel sum Sgs), 9 = the
+    // single-matrix chain of the gradient of Ki (K Pbar^T, Kib, Ki Kib Ki, Pbar^T Ki: five small launches that read nothing of 8) and
+    // 10 = the closing assembly of Kbar.  7 = 8 + 9 + 10; a caller with a free side branch runs 9 beside 8.
+    const bool run_8 = part != 9 && part != 10, run_9 = part != 8 && part != 10, run_10 = part != 8 && part != 9;
+    if (run_8) {
     // The late half in two parts (round 5): 6 = what reads NOTHING the early half writes, 7 = the rest (2 = 6 + 7).  The vector chain
     // always belongs to part 6; X, vbar and the two full products Si X, -(Si X) Si do when the statistic SW comes from the reverse
     // statistics on the caller's stream (`sw_rows`: SPRITES) and not from the early half -- then Si X goes to the Ssym slot (free
     // until the tile-pair kernel below writes it) instead of mm0, where the early half keeps H until it is summed.  A caller with
     // the early half on a side branch issues part 6, THEN joins, then part 7: at m = 800 the caller's stream waited 0.8 ms at the join
     // with 2.3 ms of its own work ready (kernel trace).
-    const bool do_a = part != 7, do_b = part != 6, x_early = sw_rows || !has_sw;
+    const bool do_a = part != 7 && part != 8, do_b = part != 6, x_early = sw_rows || !has_sw;
     real* six = x_early ? ws + wl.Ssym + om : s.mm0;
     auto x_block = [&]() -> int {
         if (!x0_ready) {
@@ -829,11 +833,12 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     }
     if (part == 6) return SVGP_OK;
     if (do_b && !x_early) RUNC(x_block());
-    }
     hipLaunchKernelGGL(k_big_fb_ssym, dim3(ntp, ntp, L), dim3(256), 0, st, a);
     SVGP_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_big_sum_channels, dim3(nblk(mm)), dim3(256), 0, st, (int)mm, L, real(1), s.mm1, s.Sgs);
     SVGP_LAUNCH_CHECK();
+    }
+    if (part == 8) return SVGP_OK;
     // The gradient of Ki is needed for the channel sum only (Ki is shared): Kib = rep_weight (gK/2 sum A + sum ubar mu^T) + Qs + Pbar K,
     // then Ki Kib Ki once.  Pbar, Qs: this rank's row sums from svgp_big_stats (mode 1).
     FinArgs f;
@@ -842,15 +847,19 @@ int svgp_big_factor_bwd(const svgp_mnist_cfg* c, const svgp_mnist_ws_layout& wl,
     f.Asum = s.Asum; f.ubar = s.vec0; f.mu = a.mu; f.Qs = s.Qs; f.PbarK = s.tA; f.Zs = s.Zs; f.mubar = s.vec1; f.t = ws + wl.t + ov;
     f.Sgs = s.Sgs; f.HGs = s.HGs; f.Ki = Ki; f.KiPbar = s.Pbar; f.KiKibKi = s.tA; f.Kib = s.tB; f.Kbar = ws + wl.Kbar;
     f.rank1_late = a.rank1_late; f.vbar = a.vbar;
+    if (run_9) {
     GEMM(0, 0, m, m, m, 1.0, K, m, 0, s.Pbar, m, 0, 0.0, s.tA, m, 0, 1);                // K Pbar^T = (Pbar K)^T   (s.Pbar holds Pbar^T)
     hipLaunchKernelGGL(k_big_fb_kib, dim3(nblk(mm)), dim3(256), 0, st, f);             // Kib (tB)
     SVGP_LAUNCH_CHECK();
     GEMM(0, 0, m, m, m, 1.0, Ki, m, 0, s.tB, m, 0, 0.0, s.tC, m, 0, 1);                 // Ki Kib             (tC)
     GEMM(0, 1, m, m, m, 1.0, s.tC, m, 0, Ki, m, 0, 0.0, s.tA, m, 0, 1);                 // Ki Kib Ki          (tA)
     GEMM(0, 1, m, m, m, 1.0, s.Pbar, m, 0, Ki, m, 0, 0.0, s.tB, m, 0, 1);               // Pbar^T Ki = (Ki Pbar)^T   (tB)
+    }
     f.KiPbar = s.tB;
+    if (run_10) {
     hipLaunchKernelGGL(k_big_fb_final, dim3(nblk(mm)), dim3(256), 0, st, f);
     SVGP_LAUNCH_CHECK();
+    }
     return SVGP_OK;
 }
 

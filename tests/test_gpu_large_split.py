@@ -236,3 +236,46 @@ def test_k_only_side_branch_equals_the_in_line_order(m, b, L, M, monkeypatch):
         eng.synchronize()
         res[flag] = (eng.theta.clone(), eng.state.clone())
     assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
+
+
+@pytest.mark.parametrize("m,b,L,M", [(130, 150, 3, 24), (256, 1024, 16, 32)])
+def test_ki_gradient_chain_on_the_side_branch_equals_the_one_stream_order(m, b, L, M, monkeypatch):
+    """Round 6: the single-matrix chain of the gradient of Ki (svgp_gp_factor_bwd_late_b_kbar) runs on side branch 1 beside the channel
+    block of the late reverse factor half (SVGP_KBAR_BRANCH, default on): the same operations on the same values as the one-stream
+    order, so two Adam steps agree BIT FOR BIT -- which also pins that the chain's scratch (tA, tB, tC, Pbar) is disjoint from the
+    channel block's.  Second shape: BASELINE configs[2]."""
+    params, images, aux, eps = H.toy_problem(b=b, m=m, L=L, M=M, n_obj=40, seed=10)
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("SVGP_KBAR_BRANCH", flag)
+        eng = H.engine_for(params, b, geco=True, N_train=4050.0, jitter=1e-4)
+        dev = eng.device
+        eng.bind(images.to(dev), aux.to(dev), eps.to(dev))
+        for _ in range(2):
+            eng.run(adam=True)
+        eng.synchronize()
+        res[flag] = (eng.theta.clone(), eng.state.clone())
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
+
+
+def test_late_reverse_half_in_three_pieces_equals_the_one_call():
+    """svgp_gp_factor_bwd_late_b == _late_b_channels; _late_b_kbar; _late_b_final (and with the two independent pieces swapped)."""
+    from svgp_vae_amd import _lib
+    eng = _engine()
+    cfg, ws, st = C.byref(eng.cfg), eng.ws.data_ptr(), eng.state.data_ptr()
+    s = eng.stream.cuda_stream
+    _lib.call("svgp_gp_factor_bwd_early", cfg, ws, st, s)
+    _lib.call("svgp_gp_factor_bwd_late_a", cfg, ws, st, s)
+    eng.synchronize()
+    ws0 = eng.ws.clone()
+    _lib.call("svgp_gp_factor_bwd_late_b", cfg, ws, st, s)
+    eng.synchronize()
+    want = {k: _field(eng, k) for k in BWD_FIELDS}
+    for order in (("channels", "kbar"), ("kbar", "channels")):
+        eng.ws.copy_(ws0)
+        torch.cuda.synchronize()
+        for piece in order + ("final",):
+            _lib.call("svgp_gp_factor_bwd_late_b_" + piece, cfg, ws, st, s)
+        eng.synchronize()
+        for k in BWD_FIELDS:
+            assert torch.equal(_field(eng, k), want[k]), (order, k)

@@ -496,6 +496,19 @@ extern "C" int svgp_mnist_train_step_dp(const svgp_mnist_cfg* c, void* comm, dou
     RUN(pt.end());
     if (fork) {
         RUN(guard.join());
+        // round 6 (as svgp_mnist_train_step does on one GPU, api.hip): the single-matrix chain of the gradient of Ki -- five small launches
+        // that every rank runs in full, while the channel block covers its L / G channels only -- on the branch that has just been
+        // joined, beside the channel block.  SVGP_KBAR_BRANCH=0: one launch after the other.
+        const char* ev_kb = getenv("SVGP_KBAR_BRANCH");
+        if (!(ev_kb && ev_kb[0] == '0')) {
+            RUN(svgp_big_factor_bwd(&cc, wl, ws, state, stream, l0, nl, 6));
+            void* side2 = stream;
+            RUN(guard.fork(&side2));
+            RUN(svgp_big_factor_bwd(&cc, wl, ws, state, side2, l0, nl, 9));
+            RUN(svgp_big_factor_bwd(&cc, wl, ws, state, stream, l0, nl, 8));
+            RUN(guard.join());
+            RUN(svgp_big_factor_bwd(&cc, wl, ws, state, stream, l0, nl, 10));
+        } else
         RUN(svgp_big_factor_bwd(&cc, wl, ws, state, stream, l0, nl, 2));
     } else {
         RUN(svgp_big_factor_bwd(&cc, wl, ws, state, stream, l0, nl, 0));

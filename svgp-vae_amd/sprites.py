@@ -620,7 +620,16 @@ class SpritesStepEngine:
                 # there for the second inverse + early half with that work ready (kernel trace, round 5)
                 call("svgp_gp_factor_bwd_late_a", cp, ws, st, s)
                 self.stream.wait_stream(self.side)
-                call("svgp_gp_factor_bwd_late_b", cp, ws, st, s)
+                if os.environ.get("SVGP_KBAR_BRANCH") != "0":
+                    # round 6 (as csrc/api.hip does for the MNIST step): the single-matrix chain of the gradient of Ki on the branch that
+                    # has just been joined, beside the channel block
+                    self.side.wait_stream(self.stream)
+                    call("svgp_gp_factor_bwd_late_b_kbar", cp, ws, st, self.side.cuda_stream)
+                    call("svgp_gp_factor_bwd_late_b_channels", cp, ws, st, s)
+                    self.stream.wait_stream(self.side)
+                    call("svgp_gp_factor_bwd_late_b_final", cp, ws, st, s)
+                else:
+                    call("svgp_gp_factor_bwd_late_b", cp, ws, st, s)
             else:
                 call("svgp_gp_factor_bwd", cp, ws, st, s)
         if self.chan_shard:      # (KL_l comes out of the tail, joined above)
